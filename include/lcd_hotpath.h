@@ -1,0 +1,142 @@
+/*
+ * lcd_hotpath.h -- C ABI of liblcd_hotpath.so: the MI355X (gfx950) implementation of longcallD's
+ * per-noisy-region alignment/phasing hot path.  Plain pointers and sizes only; no torch, no C++ types.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the longcallD tree).
+ * INTEGRATION.md shows the few lines a longcallD maintainer adds to src/align.c / src/assign_hap.c /
+ * src/collect_var.c to route the reference's own symbols here.
+ *
+ * Conventions kept from the reference:
+ *   - byte codes A0 C1 G2 T3 N4, gap 5 (src/seq.c:14-31, src/align.c:316,321);
+ *   - buffers handed back are libc malloc()'d and owned by the caller, with the reference's interior
+ *     pointer layout (aln_str_t: one block, target row first; only target_aln is free()d,
+ *     src/collect_var.c:2718-2724);
+ *   - return values: n_cons for the region call, distance/-1 for edlib, 0 for the WFA wrapper with
+ *     failure signalled by *cigar_length == 0 (src/align.c:703);
+ *   - unrecoverable states (no GPU, kernel error, arena exhaustion after retries) return a negative
+ *     code and set lcd_last_error(); there is NO CPU fallback.
+ *   - all entry points are thread-safe: each call (or each lcd_batch_t) owns its HIP stream and buffers.
+ */
+#ifndef LCD_HOTPATH_H
+#define LCD_HOTPATH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* the fields of call_var_opt_t (src/call_var_main.h:128-180) that the path reads */
+typedef struct lcd_opt_t {
+    int match, mismatch, gap_open1, gap_ext1, gap_open2, gap_ext2; /* src/align.h:21-26 */
+    int gap_aln;                                                   /* LONGCALLD_GAP_LEFT_ALN = 1 */
+    double min_af;
+    int min_dp;
+    double partial_aln_ratio;
+    int min_noisy_reg_size_to_sample_reads, max_noisy_reg_len, noisy_reg_flank_len;
+    int min_hap_full_reads, min_hap_reads;
+    int collect_ref_read_aln_str; /* (refine_bam && out_aln_fp) || out_somatic, src/align.c:1785-1786 */
+    int is_ont;
+} lcd_opt_t;
+
+/* == aln_str_t, src/collect_var.h:106-112 */
+typedef struct lcd_aln_str_t {
+    uint8_t *target_aln;
+    uint8_t *query_aln;
+    int aln_len;
+    int target_beg, target_end, query_beg, query_end;
+} lcd_aln_str_t;
+
+/* digar1_t / digar_t views (src/bam_utils.h:27-43) for the read-slicing step (src/align.c:1377-1461) */
+typedef struct lcd_digar1_t {
+    int64_t pos;
+    int type, len, qi;
+} lcd_digar1_t;
+typedef struct lcd_read_view_t {
+    const lcd_digar1_t *digars;
+    int n_digar;
+    int qlen;            /* digar2qlen() */
+    const uint8_t *bseq; /* BAM 4-bit packed bases (bam_get_seq) */
+    const uint8_t *qual;
+    int hap;             /* chunk->haps[read] */
+    int64_t phase_set;   /* chunk->phase_sets[read] */
+} lcd_read_view_t;
+
+void lcd_opt_default(lcd_opt_t *opt);          /* src/call_var_main.c:140-224 */
+int lcd_init(int device);                      /* 0 ok; <0: no usable gfx950 device */
+const char *lcd_last_error(void);
+const char *lcd_version(void);
+
+/* ---- drop-in mirrors of src/align.h:50-65 ---- */
+
+/* replaces wfa_end2end_aln (definition src/align.c:374-376; parameter meaning follows the DEFINITION:
+ * gap_aln, b, q, e, q2, e2, heuristic, affine_gap).  Only heuristic == 0 (none) and affine_gap == 1 (2-piece)
+ * -- the germline-live configuration -- are implemented; others return -2. */
+int lcd_wfa_end2end_aln(uint8_t *pattern, int plen, uint8_t *text, int tlen, int gap_aln, int b, int q, int e, int q2,
+                        int e2, int heuristic, int affine_gap, uint32_t **cigar_buf, int *cigar_length,
+                        uint8_t **pattern_alg, uint8_t **text_alg, int *alg_length);
+/* replaces edlib_end2end_aln (src/align.c:234), edlib_xgaps (:222), edlib_edit_distance (:210) */
+int lcd_edlib_end2end_aln(uint8_t *target, int tlen, uint8_t *query, int qlen, int *n_eq, int *n_xid);
+int lcd_edlib_xgaps(uint8_t *target, int tlen, uint8_t *query, int qlen);
+int lcd_edlib_edit_distance(uint8_t *target, int tlen, uint8_t *query, int qlen);
+
+/* replaces collect_noisy_reg_aln_strs (src/align.c:1760) with bam_chunk_t flattened to per-read views.
+ * noisy_reads[] is permuted in place exactly as the reference does (src/align.c:1774). */
+int lcd_collect_noisy_reg_aln_strs(const lcd_opt_t *opt, const lcd_read_view_t *chunk_reads, int64_t noisy_reg_beg,
+                                   int64_t noisy_reg_end, int noisy_reg_i, int n_noisy_reg_reads, int *noisy_reads,
+                                   const uint8_t *ref_seq, int ref_seq_len, int *clu_n_seqs, int **clu_read_ids,
+                                   lcd_aln_str_t **aln_strs);
+
+/* ---- batched form (additive; legal because regions of one pass are independent, SURVEY CS-2) ---- */
+typedef struct lcd_batch_s lcd_batch_t;
+
+typedef struct lcd_batch_stats_t {
+    int n_regions, n_regions_resolved; /* regions reaching K1/K2 ; regions with n_cons > 0 */
+    int n_chains, n_anchor_jobs, n_wfa_jobs, n_edlib_jobs;
+    uint64_t poa_aligned_bases, poa_cells, wfa_offsets, edlib_blocks;
+    uint64_t poa_alg_bytes; /* SURVEY 8d B_poa summed over aligned reads */
+    double ms_total, ms_anchor, ms_poa, ms_wfa, ms_strings; /* HIP-event times on the batch stream */
+    double ms_upload, ms_download, ms_host;
+    int poa_retries;
+} lcd_batch_stats_t;
+
+lcd_batch_t *lcd_batch_create(const lcd_opt_t *opt);
+void lcd_batch_destroy(lcd_batch_t *b);
+void lcd_batch_clear(lcd_batch_t *b);
+/* add one region AFTER read slicing (the outputs of collect_noisy_read_info, src/align.c:1377): returns region index */
+int lcd_batch_add_region(lcd_batch_t *b, int64_t reg_len, int n_reads, const int *read_ids, const int *lens,
+                         const uint8_t *const *seqs, const uint8_t *const *quals, const int *fully_covers, const int *haps,
+                         const int64_t *phase_sets, const uint8_t *ref_seq, int ref_seq_len);
+/* add one region from chunk views (does the digar walk of src/align.c:1392-1458 on the host) */
+int lcd_batch_add_region_from_chunk(lcd_batch_t *b, const lcd_read_view_t *chunk_reads, int64_t noisy_reg_beg,
+                                    int64_t noisy_reg_end, int n_noisy_reg_reads, const int *noisy_reads,
+                                    const uint8_t *ref_seq, int ref_seq_len);
+int lcd_batch_upload(lcd_batch_t *b);  /* host -> HBM (not part of the timed hot path) */
+int lcd_batch_run(lcd_batch_t *b);     /* anchors -> POA chains -> ref/cons WFA -> strings; inputs and outputs stay in HBM */
+int lcd_batch_download(lcd_batch_t *b);/* HBM -> host */
+/* region results; clu_read_ids[c] and aln_strs[c][j].target_aln are malloc()'d (aln_strs[c] must hold 1+2*n_reads zeroed entries) */
+int lcd_batch_region_result(lcd_batch_t *b, int region, int *clu_n_seqs, int **clu_read_ids, lcd_aln_str_t **aln_strs);
+int lcd_batch_region_sorted_ids(lcd_batch_t *b, int region, int *read_ids_out); /* the in-place permutation of noisy_reads */
+int lcd_batch_get_stats(lcd_batch_t *b, lcd_batch_stats_t *st);
+/* a 64-bit FNV-1a digest over every region's results (n_cons, clusters, all alignment rows) -- cheap whole-batch parity check */
+uint64_t lcd_batch_digest(lcd_batch_t *b);
+
+/* ---- kernel-level batches (also what the per-call mirrors above run on) ---- */
+int lcd_edlib_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *q_off, const int *qlen,
+                    const uint64_t *t_off, const int *tlen, int *dist, int *xgaps, int *n_eq, int *n_xid);
+/* want bit0: cigars into cigars[i*cigar_stride ..], bit1: rows into rows[i*2*row_stride ..] (pattern row, then text row at +row_stride) */
+int lcd_wfa_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *p_off, const int *plen, const uint64_t *t_off,
+                  const int *tlen, const int *gap_aln, int b, int q, int e, int q2, int e2, int want, int *score,
+                  uint32_t *cigars, int cigar_stride, int *n_cigar, uint8_t *rows, int row_stride, int *aln_len);
+/* POA chains with the anchor results supplied by the caller: mode 0 = K1 (src/align.c:762), 1 = K2 (:872).
+ * anchors: 4 ints per read (ref_beg, ref_end, read_beg, read_end; 1-based).  Outputs are copied into caller arrays:
+ * cons (2*cons_stride per chain), msa ((max_reads+2)*msa_stride per chain, row r at r*msa_stride), clu_ids (2*max_reads per chain). */
+int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int *chain_read0, const int *chain_n_reads,
+                  int n_reads_total, const uint64_t *seq_off, const int *len, const int *skip, const int *anchors,
+                  const uint8_t *pool, uint64_t pool_len, int *status, int *n_cons, int *cons_len, int *msa_len, int *clu_n,
+                  uint8_t *cons, int cons_stride, uint8_t *msa, int msa_stride, int max_reads, int *clu_ids);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

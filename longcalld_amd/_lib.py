@@ -1,0 +1,103 @@
+"""ctypes loader for liblcd_hotpath.so (built in-tree by __graft_entry__.build / csrc/Makefile)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblcd_hotpath.so")
+
+
+class LcdError(RuntimeError):
+    pass
+
+
+class LcdOpt(C.Structure):
+    """lcd_opt_t == the call_var_opt_t fields the path reads (src/call_var_main.h:128-180)."""
+    _fields_ = [(n, C.c_int) for n in ("match", "mismatch", "gap_open1", "gap_ext1", "gap_open2", "gap_ext2", "gap_aln")] + [
+        ("min_af", C.c_double), ("min_dp", C.c_int), ("partial_aln_ratio", C.c_double)] + [
+        (n, C.c_int) for n in ("min_noisy_reg_size_to_sample_reads", "max_noisy_reg_len", "noisy_reg_flank_len",
+                               "min_hap_full_reads", "min_hap_reads", "collect_ref_read_aln_str", "is_ont")]
+
+
+class LcdAlnStr(C.Structure):
+    """lcd_aln_str_t == aln_str_t (src/collect_var.h:106-112)."""
+    _fields_ = [("target_aln", C.POINTER(C.c_uint8)), ("query_aln", C.POINTER(C.c_uint8)), ("aln_len", C.c_int),
+                ("target_beg", C.c_int), ("target_end", C.c_int), ("query_beg", C.c_int), ("query_end", C.c_int)]
+
+
+class LcdDigar1(C.Structure):
+    _fields_ = [("pos", C.c_int64), ("type", C.c_int), ("len", C.c_int), ("qi", C.c_int)]
+
+
+class LcdReadView(C.Structure):
+    _fields_ = [("digars", C.POINTER(LcdDigar1)), ("n_digar", C.c_int), ("qlen", C.c_int), ("bseq", C.POINTER(C.c_uint8)),
+                ("qual", C.POINTER(C.c_uint8)), ("hap", C.c_int), ("phase_set", C.c_int64)]
+
+
+class LcdBatchStats(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("n_regions", "n_regions_resolved", "n_chains", "n_anchor_jobs", "n_wfa_jobs", "n_edlib_jobs")] + [
+        (n, C.c_uint64) for n in ("poa_aligned_bases", "poa_cells", "wfa_offsets", "edlib_blocks", "poa_alg_bytes")] + [
+        (n, C.c_double) for n in ("ms_total", "ms_anchor", "ms_poa", "ms_wfa", "ms_strings", "ms_upload", "ms_download", "ms_host")] + [
+        ("poa_retries", C.c_int)]
+
+
+_lib = None
+
+# every symbol include/lcd_hotpath.h declares (tests check the .so exports all of them)
+EXPORTS = [
+    "lcd_opt_default", "lcd_init", "lcd_last_error", "lcd_version", "lcd_wfa_end2end_aln", "lcd_edlib_end2end_aln",
+    "lcd_edlib_xgaps", "lcd_edlib_edit_distance", "lcd_collect_noisy_reg_aln_strs", "lcd_batch_create", "lcd_batch_destroy",
+    "lcd_batch_clear", "lcd_batch_add_region", "lcd_batch_add_region_from_chunk", "lcd_batch_upload", "lcd_batch_run",
+    "lcd_batch_download", "lcd_batch_region_result", "lcd_batch_region_sorted_ids", "lcd_batch_get_stats", "lcd_batch_digest",
+    "lcd_edlib_batch", "lcd_wfa_batch", "lcd_poa_batch",
+]
+
+
+def load_library():
+    """Load liblcd_hotpath.so; raises LcdError (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LcdError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    u8p, i32p, u64p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    lib.lcd_last_error.restype = C.c_char_p
+    lib.lcd_version.restype = C.c_char_p
+    lib.lcd_opt_default.argtypes = [C.POINTER(LcdOpt)]
+    lib.lcd_init.argtypes = [C.c_int]
+    lib.lcd_batch_create.restype = C.c_void_p
+    lib.lcd_batch_create.argtypes = [C.POINTER(LcdOpt)]
+    lib.lcd_batch_destroy.argtypes = [C.c_void_p]
+    lib.lcd_batch_destroy.restype = None
+    lib.lcd_batch_clear.argtypes = [C.c_void_p]
+    lib.lcd_batch_clear.restype = None
+    lib.lcd_batch_add_region.argtypes = [C.c_void_p, C.c_int64, C.c_int, i32p, i32p, C.POINTER(u8p), C.POINTER(u8p), i32p, i32p,
+                                         C.POINTER(C.c_int64), u8p, C.c_int]
+    lib.lcd_batch_add_region_from_chunk.argtypes = [C.c_void_p, C.POINTER(LcdReadView), C.c_int64, C.c_int64, C.c_int, i32p, u8p, C.c_int]
+    for f in ("lcd_batch_upload", "lcd_batch_run", "lcd_batch_download"):
+        getattr(lib, f).argtypes = [C.c_void_p]
+    lib.lcd_batch_region_result.argtypes = [C.c_void_p, C.c_int, i32p, C.POINTER(i32p), C.POINTER(C.POINTER(LcdAlnStr))]
+    lib.lcd_batch_region_sorted_ids.argtypes = [C.c_void_p, C.c_int, i32p]
+    lib.lcd_batch_get_stats.argtypes = [C.c_void_p, C.POINTER(LcdBatchStats)]
+    lib.lcd_batch_digest.argtypes = [C.c_void_p]
+    lib.lcd_batch_digest.restype = C.c_uint64
+    lib.lcd_edlib_batch.argtypes = [C.c_int, u8p, C.c_uint64, u64p, i32p, u64p, i32p, i32p, i32p, i32p, i32p]
+    lib.lcd_wfa_batch.argtypes = [C.c_int, u8p, C.c_uint64, u64p, i32p, u64p, i32p, i32p] + [C.c_int] * 6 + [i32p, u32p, C.c_int, i32p, u8p, C.c_int, i32p]
+    lib.lcd_poa_batch.argtypes = [C.POINTER(LcdOpt), C.c_int, i32p, i32p, i32p, C.c_int, u64p, i32p, i32p, i32p, u8p, C.c_uint64, i32p,
+                                  i32p, i32p, i32p, i32p, u8p, C.c_int, u8p, C.c_int, C.c_int, i32p]
+    lib.lcd_wfa_end2end_aln.argtypes = [u8p, C.c_int, u8p, C.c_int] + [C.c_int] * 8 + [C.POINTER(u32p), i32p, C.POINTER(u8p), C.POINTER(u8p), i32p]
+    lib.lcd_edlib_end2end_aln.argtypes = [u8p, C.c_int, u8p, C.c_int, i32p, i32p]
+    lib.lcd_edlib_xgaps.argtypes = [u8p, C.c_int, u8p, C.c_int]
+    lib.lcd_edlib_edit_distance.argtypes = [u8p, C.c_int, u8p, C.c_int]
+    lib.lcd_collect_noisy_reg_aln_strs.argtypes = [C.POINTER(LcdOpt), C.POINTER(LcdReadView), C.c_int64, C.c_int64, C.c_int, C.c_int, i32p,
+                                                   u8p, C.c_int, i32p, C.POINTER(i32p), C.POINTER(C.POINTER(LcdAlnStr))]
+    _lib = lib
+    return lib
+
+
+def check(rc, lib=None):
+    if rc < 0:
+        lib = lib or load_library()
+        raise LcdError(f"liblcd_hotpath error {rc}: {lib.lcd_last_error().decode()}")
+    return rc

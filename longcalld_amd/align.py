@@ -1,0 +1,244 @@
+"""Host-side mirror of the reference's src/align.h surface over the C ABI (liblcd_hotpath.so).
+
+Function names and argument meaning follow the reference (src/align.c); arrays are numpy uint8 byte codes
+A0 C1 G2 T3 N4, gap 5.  Everything here calls the HIP library -- nothing is computed in Python.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import LcdAlnStr, LcdBatchStats, LcdOpt, check, load_library
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+u8p, i32p, u64p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+
+GAP_LEFT_ALN, GAP_RIGHT_ALN = 1, 2  # src/align.h:28-29
+WFA_NO_HEURISTIC, WFA_AFFINE_2P = 0, 1  # src/align.h:35-40
+NOISY_RIGHT_GAP, NOISY_LEFT_GAP, NOISY_RIGHT_COVER, NOISY_LEFT_COVER, NOISY_BOTH_COVER = 1, 2, 4, 8, 12  # src/align.h:6-11
+
+
+def default_opt():
+    lib = load_library()
+    o = LcdOpt()
+    lib.lcd_opt_default(C.byref(o))
+    return o
+
+
+def _p8(a):
+    return a.ctypes.data_as(u8p)
+
+
+def _pool(arrays):
+    """pack byte arrays into one pool, 16-byte aligned; returns pool, offsets"""
+    offs, tot = [], 0
+    for a in arrays:
+        offs.append(tot)
+        tot += (len(a) + 15) // 16 * 16
+    pool = np.full(tot + 16, 4, np.uint8)
+    for a, o in zip(arrays, offs):
+        pool[o:o + len(a)] = a
+    return pool, np.array(offs, np.uint64)
+
+
+def edlib_batch(pairs):
+    """pairs: list of (target, query) uint8 arrays -> dict of int arrays dist/xgaps/n_eq/n_xid  (src/align.c:210-254)."""
+    lib = load_library()
+    n = len(pairs)
+    arrs = [np.ascontiguousarray(x, np.uint8) for p in pairs for x in (p[1], p[0])]  # query, target
+    pool, offs = _pool(arrs)
+    qo, to = np.ascontiguousarray(offs[0::2]), np.ascontiguousarray(offs[1::2])
+    ql = np.array([len(p[1]) for p in pairs], np.int32)
+    tl = np.array([len(p[0]) for p in pairs], np.int32)
+    out = {k: np.zeros(n, np.int32) for k in ("dist", "xgaps", "n_eq", "n_xid")}
+    check(lib.lcd_edlib_batch(n, _p8(pool), pool.size, qo.ctypes.data_as(u64p), ql.ctypes.data_as(i32p), to.ctypes.data_as(u64p),
+                              tl.ctypes.data_as(i32p), *[out[k].ctypes.data_as(i32p) for k in ("dist", "xgaps", "n_eq", "n_xid")]), lib)
+    return out
+
+
+def edlib_xgaps(target, query):
+    """edlib_xgaps, src/align.c:222"""
+    return int(edlib_batch([(target, query)])["xgaps"][0])
+
+
+def edlib_end2end_aln(target, query):
+    """edlib_end2end_aln, src/align.c:234 -> (distance, n_eq, n_xid)"""
+    r = edlib_batch([(target, query)])
+    return int(r["dist"][0]), int(r["n_eq"][0]), int(r["n_xid"][0])
+
+
+def wfa_batch(pairs, gap_aln=GAP_LEFT_ALN, b=6, q=6, e=2, q2=24, e2=1):
+    """pairs: list of (pattern, text) -> list of dict(score, cigar[uint32], pattern_alg, text_alg)  (src/align.c:374-460)."""
+    lib = load_library()
+    n = len(pairs)
+    arrs = [np.ascontiguousarray(x, np.uint8) for p in pairs for x in (p[0], p[1])]
+    pool, offs = _pool(arrs)
+    po, to = np.ascontiguousarray(offs[0::2]), np.ascontiguousarray(offs[1::2])
+    pl = np.array([len(p[0]) for p in pairs], np.int32)
+    tl = np.array([len(p[1]) for p in pairs], np.int32)
+    ga = np.full(n, gap_aln, np.int32) if np.isscalar(gap_aln) else np.asarray(gap_aln, np.int32)
+    stride = int((pl + tl).max()) + 1 if n else 1
+    score, ncig, alen = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    cig = np.zeros((n, stride), np.uint32)
+    rows = np.zeros((n, 2, stride), np.uint8)
+    check(lib.lcd_wfa_batch(n, _p8(pool), pool.size, po.ctypes.data_as(u64p), pl.ctypes.data_as(i32p), to.ctypes.data_as(u64p),
+                            tl.ctypes.data_as(i32p), ga.ctypes.data_as(i32p), b, q, e, q2, e2, 3, score.ctypes.data_as(i32p),
+                            cig.ctypes.data_as(u32p), stride, ncig.ctypes.data_as(i32p), _p8(rows), stride, alen.ctypes.data_as(i32p)), lib)
+    return [dict(score=int(score[i]), cigar=cig[i, :ncig[i]].copy(), pattern_alg=rows[i, 0, :alen[i]].copy(), text_alg=rows[i, 1, :alen[i]].copy())
+            for i in range(n)]
+
+
+def wfa_end2end_aln(pattern, text, gap_aln=GAP_LEFT_ALN, b=6, q=6, e=2, q2=24, e2=1):
+    """wfa_end2end_aln through the per-call C mirror (exercises the malloc/ownership contract, src/align.c:374)."""
+    lib = load_library()
+    pattern = np.ascontiguousarray(pattern, np.uint8)
+    text = np.ascontiguousarray(text, np.uint8)
+    cb, cl, pa, ta, al = u32p(), C.c_int(), u8p(), u8p(), C.c_int()
+    check(lib.lcd_wfa_end2end_aln(_p8(pattern), len(pattern), _p8(text), len(text), gap_aln, b, q, e, q2, e2, WFA_NO_HEURISTIC, WFA_AFFINE_2P,
+                                  C.byref(cb), C.byref(cl), C.byref(pa), C.byref(ta), C.byref(al)), lib)
+    cigar = np.ctypeslib.as_array(cb, shape=(max(cl.value, 1),))[:cl.value].copy()
+    p_alg = np.ctypeslib.as_array(pa, shape=(max(al.value, 1),))[:al.value].copy()
+    t_alg = np.ctypeslib.as_array(ta, shape=(max(al.value, 1),))[:al.value].copy()
+    _libc.free(cb)
+    _libc.free(pa)  # one block: only the first pointer is freed (src/align.c:490)
+    return cigar, p_alg, t_alg
+
+
+def poa_batch(chains, opt=None):
+    """chains: list of dict(mode, reads=[uint8 arrays], skip=[...], anchors=[(ref_beg, ref_end, read_beg, read_end)]) -> list of dict."""
+    lib = load_library()
+    opt = opt or default_opt()
+    reads = [np.ascontiguousarray(r, np.uint8) for ch in chains for r in ch["reads"]]
+    pool, offs = _pool(reads)
+    lens = np.array([len(r) for r in reads], np.int32)
+    nC = len(chains)
+    mode = np.array([ch["mode"] for ch in chains], np.int32)
+    nr = np.array([len(ch["reads"]) for ch in chains], np.int32)
+    r0 = np.concatenate([[0], np.cumsum(nr)[:-1]]).astype(np.int32)
+    skip = np.array([s for ch in chains for s in ch.get("skip", [0] * len(ch["reads"]))], np.int32)
+    anch = []
+    for ch in chains:
+        a = ch.get("anchors")
+        for k, r in enumerate(ch["reads"]):
+            anch.extend(a[k] if a is not None else (1, len(ch["reads"][0]), 1, len(r)))
+    anch = np.array(anch, np.int32)
+    max_reads = int(nr.max())
+    stride = int(max(sum(len(r) for r in ch["reads"]) for ch in chains)) + 2
+    status, n_cons, msa_len = np.zeros(nC, np.int32), np.zeros(nC, np.int32), np.zeros(nC, np.int32)
+    cons_len, clu_n = np.zeros((nC, 2), np.int32), np.zeros((nC, 2), np.int32)
+    cons = np.zeros((nC, 2, stride), np.uint8)
+    msa = np.zeros((nC, max_reads + 2, stride), np.uint8)
+    clu_ids = np.zeros((nC, 2, max_reads), np.int32)
+    check(lib.lcd_poa_batch(C.byref(opt), nC, mode.ctypes.data_as(i32p), r0.ctypes.data_as(i32p), nr.ctypes.data_as(i32p), len(reads),
+                            offs.ctypes.data_as(u64p), lens.ctypes.data_as(i32p), skip.ctypes.data_as(i32p), anch.ctypes.data_as(i32p),
+                            _p8(pool), pool.size, status.ctypes.data_as(i32p), n_cons.ctypes.data_as(i32p), cons_len.ctypes.data_as(i32p),
+                            msa_len.ctypes.data_as(i32p), clu_n.ctypes.data_as(i32p), _p8(cons), stride, _p8(msa), stride, max_reads,
+                            clu_ids.ctypes.data_as(i32p)), lib)
+    out = []
+    for c in range(nC):
+        nc = int(n_cons[c])
+        out.append(dict(status=int(status[c]), n_cons=nc, msa_len=int(msa_len[c]),
+                        cons=[cons[c, k, :cons_len[c, k]].copy() for k in range(nc)],
+                        msa=[msa[c, r, :msa_len[c]].copy() for r in range(int(nr[c]) + nc)],
+                        clu=[clu_ids[c, k, :clu_n[c, k]].copy() for k in range(nc)]))
+    return out
+
+
+class RegionBatch:
+    """Batched collect_noisy_reg_aln_strs (src/align.c:1760) over many independent regions of one pass (SURVEY CS-2)."""
+
+    def __init__(self, opt=None):
+        self.lib = load_library()
+        self.opt = opt or default_opt()
+        self.h = self.lib.lcd_batch_create(C.byref(self.opt))
+        if not self.h:
+            raise RuntimeError("lcd_batch_create failed: " + self.lib.lcd_last_error().decode())
+        self.n_reads = []
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.lib.lcd_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self):
+        self.lib.lcd_batch_clear(self.h)
+        self.n_reads = []
+
+    def add_region(self, reg):
+        """reg: dict(reg_len, read_ids, seqs, quals(optional), covers, haps, phase_sets, ref) -- the outputs of collect_noisy_read_info"""
+        n = len(reg["seqs"])
+        seqs = [np.ascontiguousarray(s, np.uint8) for s in reg["seqs"]]
+        quals = reg.get("quals")
+        quals = [np.ascontiguousarray(s, np.uint8) for s in quals] if quals is not None else [np.zeros(max(len(s), 1), np.uint8) for s in seqs]
+        sp = (u8p * n)(*[_p8(s) for s in seqs])
+        qp = (u8p * n)(*[_p8(s) for s in quals])
+        ids = np.asarray(reg["read_ids"], np.int32)
+        lens = np.array([len(s) for s in seqs], np.int32)
+        cov = np.asarray(reg["covers"], np.int32)
+        haps = np.asarray(reg["haps"], np.int32)
+        pss = np.asarray(reg["phase_sets"], np.int64)
+        ref = np.ascontiguousarray(reg["ref"], np.uint8)
+        idx = check(self.lib.lcd_batch_add_region(self.h, int(reg["reg_len"]), n, ids.ctypes.data_as(i32p), lens.ctypes.data_as(i32p), sp, qp,
+                                                  cov.ctypes.data_as(i32p), haps.ctypes.data_as(i32p), pss.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                  _p8(ref), len(ref)), self.lib)
+        self.n_reads.append(n)
+        return idx
+
+    def upload(self):
+        check(self.lib.lcd_batch_upload(self.h), self.lib)
+
+    def run(self):
+        check(self.lib.lcd_batch_run(self.h), self.lib)
+
+    def download(self):
+        check(self.lib.lcd_batch_download(self.h), self.lib)
+
+    def stats(self):
+        st = LcdBatchStats()
+        self.lib.lcd_batch_get_stats(self.h, C.byref(st))
+        return {f[0]: getattr(st, f[0]) for f in LcdBatchStats._fields_}
+
+    def digest(self):
+        return int(self.lib.lcd_batch_digest(self.h))
+
+    def sorted_ids(self, region):
+        out = np.zeros(max(self.n_reads[region], 1), np.int32)
+        n = self.lib.lcd_batch_region_sorted_ids(self.h, region, out.ctypes.data_as(i32p))
+        return out[:n].copy()
+
+    def result(self, region):
+        """-> dict(n_cons, clu_n_seqs, clu_read_ids, aln_strs[c][j] = None | dict(target, query, beg/end...)), freeing the C buffers"""
+        n = self.n_reads[region]
+        m = 1 + 2 * n
+        clu_n = (C.c_int * 2)(0, 0)
+        clu_ids = (i32p * 2)()
+        a0, a1 = (LcdAlnStr * m)(), (LcdAlnStr * m)()
+        arr = (C.POINTER(LcdAlnStr) * 2)(C.cast(a0, C.POINTER(LcdAlnStr)), C.cast(a1, C.POINTER(LcdAlnStr)))
+        nc = check(self.lib.lcd_batch_region_result(self.h, region, clu_n, clu_ids, arr), self.lib)
+        res = dict(n_cons=nc, clu_n_seqs=[int(clu_n[0]), int(clu_n[1])], clu_read_ids=[], aln_strs=[[], []])
+        for c in range(2):
+            if clu_ids[c]:
+                res["clu_read_ids"].append(np.ctypeslib.as_array(clu_ids[c], shape=(max(clu_n[c], 1),))[:clu_n[c]].copy())
+                _libc.free(clu_ids[c])
+            else:
+                res["clu_read_ids"].append(None)
+            for j in range(m):
+                s = (a0, a1)[c][j]
+                if not s.target_aln:
+                    res["aln_strs"][c].append(None)
+                    continue
+                L = s.aln_len
+                t = np.ctypeslib.as_array(s.target_aln, shape=(max(L, 1),))[:L].copy()
+                q = np.ctypeslib.as_array(s.query_aln, shape=(max(L, 1),))[:L].copy()
+                res["aln_strs"][c].append(dict(target=t, query=q, aln_len=L, target_beg=s.target_beg, target_end=s.target_end,
+                                               query_beg=s.query_beg, query_end=s.query_end))
+                _libc.free(s.target_aln)
+        return res

@@ -1,0 +1,237 @@
+// edlib_kernel.hip -- K4: Myers bit-vector NW edit distance + edlib's exact optimal path on gfx950.
+//
+// Replaces edlibAlign(query, target, {k=-1, NW, TASK_PATH}) as called from src/align.c:210-254
+// (edlib_xgaps / edlib_end2end_aln / edlib_edit_distance).  One 64-lane wavefront owns one pair.
+// Lanes are the 64-row blocks of the query (Myers/Hyyro word = uint64, edlib/src/edlib.cpp:412-447);
+// a column sweep is skewed so lane b works on target column (step - b) and receives its horizontal
+// delta from lane b-1 by a wave shift -- the vertical state Pv/Mv never leaves registers.
+// The path is edlib's: stored-column traceback with precedence Up -> Left -> Diagonal when
+// 20*ceil(q/64)*t + 8*t < 1 MiB (edlib.cpp:1188-1190, :942-1141), else Hirschberg splits at t/2 taking the
+// first query row whose left+right scores meet the optimum (edlib.cpp:1231-1396).  The Ukkonen band and
+// k-doubling of edlib are omitted on purpose: every cell on an optimal path is exact inside the band, so
+// the unbanded matrix yields the same path (proved in oracle/edlib_nw.c, which is pinned to real edlib).
+// Only the counters longcallD consumes are produced: distance, #mismatch + #gap-runs (xgaps), n_eq, n_xid.
+#include <hip/hip_runtime.h>
+#include "lcd_types.h"
+#include "lcd_kernels.h"
+
+namespace {
+
+typedef unsigned long long Word;
+
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+__device__ __forceinline__ int calc_block(Word Pv, Word Mv, Word Eq, int hin, Word &PvOut, Word &MvOut) {
+    const Word hinIsNeg = (Word)(hin < 0);
+    const Word Xv = Eq | Mv;
+    Eq |= hinIsNeg;
+    const Word Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+    Word Ph = Mv | ~(Xh | Pv);
+    Word Mh = Pv & Xh;
+    int hout = (int)(Ph >> 63) - (int)(Mh >> 63);
+    Ph <<= 1; Mh <<= 1;
+    Mh |= hinIsNeg;
+    Ph |= (Word)(hin > 0);
+    PvOut = Mh | ~(Xv | Ph);
+    MvOut = Ph & Xv;
+    return hout;
+}
+
+struct Sub { // sub-problem in the coordinates of the job's query/target
+    const uint8_t *q, *t;
+    int qlen, tlen;
+};
+
+// One NW pass over `ncols` target columns.  rev: walk both strings from their ends.
+// store != 0: keep P/M/score of every (column, block) for the traceback (caller guarantees it fits).
+// col_out != nullptr: scores of the last column for every query row.
+// Returns (lane-uniform) the score at (qlen-1, ncols-1).
+__device__ int myers_pass(const Sub &sp, int ncols, bool rev, int lane, Word *P, Word *M, int *S, int *col_out, signed char *hcarry,
+                          unsigned long long *blocks_acc) {
+    const int qlen = sp.qlen, nb = (qlen + 63) >> 6;
+    int result = 0;
+    for (int tile0 = 0; tile0 < nb; tile0 += 64) {
+        const int b = tile0 + lane;
+        const bool act = b < nb;
+        Word peq[5] = {0, 0, 0, 0, 0};
+        if (act) {
+            const int base = b << 6, lim = imin(64, qlen - base);
+            for (int r = 0; r < lim; ++r) {
+                const int qi = base + r;
+                const uint8_t c = rev ? sp.q[qlen - 1 - qi] : sp.q[qi];
+                const Word bit = 1ull << r;
+                if (c == 0) peq[0] |= bit; else if (c == 1) peq[1] |= bit; else if (c == 2) peq[2] |= bit;
+                else if (c == 3) peq[3] |= bit; else peq[4] |= bit;
+            }
+        }
+        Word Pv = ~0ull, Mv = 0;
+        int score = (b + 1) << 6, hout = 0;
+        const bool more = tile0 + 64 < nb;
+        const int nsteps = ncols + 63;
+        for (int step = 0; step < nsteps; ++step) {
+            const int hleft = __shfl_up(hout, 1);
+            const int c = step - lane;
+            if (act && c >= 0 && c < ncols) {
+                const int hin = lane == 0 ? (tile0 == 0 ? 1 : (int)hcarry[c]) : hleft;
+                const uint8_t tc = rev ? sp.t[sp.tlen - 1 - c] : sp.t[c];
+                const Word Eq = tc == 0 ? peq[0] : tc == 1 ? peq[1] : tc == 2 ? peq[2] : tc == 3 ? peq[3] : peq[4];
+                hout = calc_block(Pv, Mv, Eq, hin, Pv, Mv);
+                score += hout;
+                if (P) { const size_t o = (size_t)c * nb + b; P[o] = Pv; M[o] = Mv; S[o] = score; }
+                if (more && lane == 63) hcarry[ncols + c] = (signed char)hout;
+            }
+        }
+        __syncthreads();
+        if (more) { // lane 63's horizontal deltas (written to the upper half during the sweep) feed the next tile
+            for (int c = lane; c < ncols; c += 64) hcarry[c] = hcarry[ncols + c];
+            __syncthreads();
+        }
+        *blocks_acc += (unsigned long long)ncols * (unsigned long long)(imin(64, nb - tile0));
+        // last-column scores of this tile's rows
+        if (act) {
+            const int base = b << 6, lim = imin(64, qlen - base);
+            if (col_out)
+                for (int pos = 0; pos < lim; ++pos) {
+                    int v = score;
+                    if (pos < 63) v += -__popcll(Pv >> (pos + 1)) + __popcll(Mv >> (pos + 1));
+                    col_out[base + pos] = v;
+                }
+        }
+        const int lastb = nb - 1;
+        if (lastb >= tile0 && lastb < tile0 + 64) {
+            const int pos = (qlen - 1) & 63;
+            int v = score;
+            if (pos < 63) v += -__popcll(Pv >> (pos + 1)) + __popcll(Mv >> (pos + 1));
+            result = __shfl(v, lastb - tile0);
+        }
+        __syncthreads();
+    }
+    return result;
+}
+
+struct Tally {
+    int n_mis, n_eq, n_ins, n_del, runs;
+    int last_op; // forward-order last op of everything tallied so far (-1 none)
+};
+
+} // namespace
+
+__global__ void __launch_bounds__(64) lcd_edlib_kernel(const EdJob *jobs, const uint8_t *pool, uint8_t *arena, EdOut *outs, int n_jobs) {
+    const int jid = blockIdx.x;
+    if (jid >= n_jobs) return;
+    const int lane = threadIdx.x;
+    const EdJob jb = jobs[jid];
+    EdOut out; out.status = LCD_OK; out.dist = -1; out.xgaps = 0; out.n_eq = 0; out.n_xid = 0; out.blocks = 0;
+    const uint8_t *q = pool + jb.q_off, *t = pool + jb.t_off;
+    const int qlen = jb.qlen, tlen = jb.tlen;
+    if (qlen == 0 || tlen == 0) { // edlib.cpp:166-173: distance only, no alignment
+        out.dist = qlen > tlen ? qlen : tlen;
+        if (lane == 0) outs[jid] = out;
+        return;
+    }
+    // arena: P[52429] M[52429] (u64) S[52429] (i32) | colL[qlen] colR[qlen] | hcarry[2*tlen]
+    const size_t TB_CAP = 52432;
+    uint8_t *ws = arena + jb.ws_off;
+    Word *P = (Word *)ws, *M = P + TB_CAP;
+    int *S = (int *)(M + TB_CAP);
+    int *colL = S + TB_CAP, *colR = colL + qlen;
+    signed char *hcarry = (signed char *)(colR + qlen);
+    unsigned long long blocks = 0;
+    Sub top = {q, t, qlen, tlen};
+    const int dist = myers_pass(top, tlen, false, lane, nullptr, nullptr, nullptr, nullptr, hcarry, &blocks);
+    out.dist = dist;
+    __shared__ int stk[64][5]; // qoff, qlen, toff, tlen, best
+    int sp = 0;
+    if (lane == 0) { stk[0][0] = 0; stk[0][1] = qlen; stk[0][2] = 0; stk[0][3] = tlen; stk[0][4] = dist; }
+    sp = 1;
+    __syncthreads();
+    Tally T = {0, 0, 0, 0, 0, -1};
+    while (sp > 0 && out.status == LCD_OK) {
+        --sp;
+        const int qo = stk[sp][0], ql = stk[sp][1], to = stk[sp][2], tl = stk[sp][3], best = stk[sp][4];
+        __syncthreads();
+        if (ql == 0 || tl == 0) { // edlib.cpp:1169-1176
+            const int n = ql + tl;
+            if (n > 0) {
+                const int op = ql == 0 ? 2 : 1;
+                if (op == 2) T.n_del += n; else T.n_ins += n;
+                if (T.last_op != op) T.runs++;
+                T.last_op = op;
+            }
+            continue;
+        }
+        Sub s = {q + qo, t + to, ql, tl};
+        const long long nb = (ql + 63) >> 6;
+        const long long data_size = 20ll * nb * tl + 8ll * tl;
+        if (data_size < 1024 * 1024) {
+            myers_pass(s, tl, false, lane, P, M, S, nullptr, hcarry, &blocks);
+            __syncthreads();
+            // traceback on lane 0; tallies broadcast afterwards
+            int r_mis = 0, r_eq = 0, r_ins = 0, r_del = 0, r_runs = 0, leaf_first = -1, leaf_last = -1;
+            if (lane == 0) {
+                const int NB = (int)nb;
+#define VAL(r, c) ((r) < 0 ? (c) + 1 : (c) < 0 ? (r) + 1 : \
+                   S[(size_t)(c) * NB + ((r) >> 6)] + ((((r) & 63) < 63) ? (-__popcll(P[(size_t)(c) * NB + ((r) >> 6)] >> (((r) & 63) + 1)) + __popcll(M[(size_t)(c) * NB + ((r) >> 6)] >> (((r) & 63) + 1))) : 0))
+                int r = ql - 1, c = tl - 1, cur = VAL(r, c), prev = -1;
+                while (r >= 0 && c >= 0) {
+                    int op;
+                    const int up = VAL(r - 1, c);
+                    if (up + 1 == cur) { op = 1; --r; cur = up; }
+                    else {
+                        const int left = VAL(r, c - 1);
+                        if (left + 1 == cur) { op = 2; --c; cur = left; }
+                        else { const int d = VAL(r - 1, c - 1); op = d == cur ? 0 : 3; --r; --c; cur = d; }
+                    }
+                    if (op == 0) r_eq++; else if (op == 3) r_mis++; else { if (op == 1) r_ins++; else r_del++; if (op != prev) r_runs++; }
+                    if (leaf_last < 0) leaf_last = op;
+                    leaf_first = op; prev = op;
+                }
+#undef VAL
+                if (c >= 0) { const int n = c + 1; r_del += n; if (prev != 2) r_runs++; if (leaf_last < 0) leaf_last = 2; leaf_first = 2; }
+                if (r >= 0) { const int n = r + 1; r_ins += n; if (prev != 1) r_runs++; if (leaf_last < 0) leaf_last = 1; leaf_first = 1; }
+            }
+            r_mis = __shfl(r_mis, 0); r_eq = __shfl(r_eq, 0); r_ins = __shfl(r_ins, 0); r_del = __shfl(r_del, 0);
+            r_runs = __shfl(r_runs, 0); leaf_first = __shfl(leaf_first, 0); leaf_last = __shfl(leaf_last, 0);
+            T.n_mis += r_mis; T.n_eq += r_eq; T.n_ins += r_ins; T.n_del += r_del; T.runs += r_runs;
+            if (leaf_first >= 0) {
+                if ((leaf_first == 1 || leaf_first == 2) && T.last_op == leaf_first) T.runs--; // run continues across leaves
+                T.last_op = leaf_last;
+            }
+            __syncthreads();
+        } else {
+            const int left_w = tl / 2, right_w = tl - left_w;
+            myers_pass(s, left_w, false, lane, nullptr, nullptr, nullptr, colL, hcarry, &blocks);
+            myers_pass(s, right_w, true, lane, nullptr, nullptr, nullptr, colR, hcarry, &blocks);
+            __syncthreads();
+            // first row i in [0, ql-2] with colL[i] + right[i+1] == best, right[idx] = colR[ql-1-idx]
+            int cand = 1 << 30;
+            for (int i = lane; i <= ql - 2; i += 64)
+                if (colL[i] + colR[ql - 1 - (i + 1)] == best) { cand = i; break; }
+            for (int d = 32; d >= 1; d >>= 1) cand = imin(cand, __shfl_xor(cand, d));
+            int q_idx, ls, rs;
+            if (cand < (1 << 30)) { q_idx = cand; ls = colL[cand]; rs = colR[ql - 1 - (cand + 1)]; }
+            else if (left_w + colR[ql - 1] == best) { q_idx = -1; ls = left_w; rs = colR[ql - 1]; }
+            else if (colL[ql - 1] + right_w == best) { q_idx = ql - 1; ls = colL[ql - 1]; rs = right_w; }
+            else { out.status = LCD_ERR_BACKTRACK; break; }
+            const int ul_h = q_idx + 1, lr_h = ql - ul_h;
+            if (sp + 2 > 64) { out.status = LCD_ERR_BACKTRACK; break; }
+            __syncthreads();
+            if (lane == 0) { // push lower-right first so the upper-left is processed first (forward order)
+                stk[sp][0] = qo + ul_h; stk[sp][1] = lr_h; stk[sp][2] = to + left_w; stk[sp][3] = right_w; stk[sp][4] = rs;
+                stk[sp + 1][0] = qo; stk[sp + 1][1] = ul_h; stk[sp + 1][2] = to; stk[sp + 1][3] = left_w; stk[sp + 1][4] = ls;
+            }
+            sp += 2;
+            __syncthreads();
+        }
+    }
+    out.xgaps = T.n_mis + T.runs;
+    out.n_eq = T.n_eq;
+    out.n_xid = T.n_mis + T.n_ins + T.n_del;
+    out.blocks = blocks;
+    if (lane == 0) outs[jid] = out;
+}
+
+void lcd_launch_edlib(const EdJob *jobs, const uint8_t *pool, uint8_t *arena, EdOut *outs, int n_jobs, hipStream_t stream) {
+    if (n_jobs <= 0) return;
+    hipLaunchKernelGGL(lcd_edlib_kernel, dim3(n_jobs), dim3(64), 0, stream, jobs, pool, arena, outs, n_jobs);
+}

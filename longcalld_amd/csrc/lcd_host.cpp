@@ -1,0 +1,1054 @@
+// lcd_host.cpp -- host orchestration + C ABI of liblcd_hotpath.so (compiled with hipcc, HIP runtime only).
+//
+// Host glue kept in C++ because the reference's glue is compiled C (src/align.c): read ordering
+// (sort_noisy_region_reads :955), phase-set choice (:1225), homopolymer test (:1000), anchor windows
+// (:667-707) and the final malloc()'d aln_str_t materialisation.  Everything with a DP in it runs on the
+// GPU: K4 edlib_kernel.hip, K3 wfa_kernel.hip, K1/K2 poa_kernel.hip, MSA->strings strings_kernel.hip.
+// There is no CPU fallback: if HIP reports no device every entry point fails with an error string.
+//
+// All *_off fields handed to kernels are absolute device addresses (kernels get nullptr bases), so every
+// stage can live in its own grow-only hipMalloc buffer.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/lcd_hotpath.h"
+#include "lcd_kernels.h"
+#include "lcd_types.h"
+
+namespace {
+
+thread_local std::string g_err;
+int set_err(int code, const std::string &m) { g_err = m; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { return set_err(-10, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+
+std::mutex g_init_mu;
+int g_device = -1;
+
+int ensure_init() {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    if (g_device >= 0) { hipSetDevice(g_device); return 0; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return set_err(-1, "liblcd_hotpath: no HIP device visible (this library has no CPU path)");
+    int dev = 0;
+    const char *lr = getenv("LOCAL_RANK");
+    if (lr) dev = atoi(lr) % n;
+    if (hipSetDevice(dev) != hipSuccess) return set_err(-1, "hipSetDevice failed");
+    g_device = dev;
+    return 0;
+}
+
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) hipFree(p);
+        size_t want = n + n / 4 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; cap = 0; return set_err(-11, "hipMalloc failed for " + std::to_string(want) + " bytes"); }
+        cap = want; return 0;
+    }
+    uint64_t addr() const { return (uint64_t)(uintptr_t)p; }
+    ~DevBuf() { if (p) hipFree(p); }
+};
+struct PinBuf {
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) hipHostFree(p);
+        size_t want = n + n / 4 + 256;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; cap = 0; return set_err(-11, "hipHostMalloc failed"); }
+        cap = want; return 0;
+    }
+    ~PinBuf() { if (p) hipHostFree(p); }
+};
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---------------- host glue (restating src/align.c; see cited lines) ----------------
+int full_cover_cmp(int c1, int c2) { // src/align.c:945-952
+    if (c1 == c2) return 0;
+    if (LCD_IS_BOTH_COVER(c1)) return 1;
+    else if (LCD_IS_BOTH_COVER(c2)) return -1;
+    if (LCD_IS_LEFT_COVER(c1) && LCD_IS_LEFT_COVER(c2)) return 0;
+    if (LCD_IS_RIGHT_COVER(c1) && LCD_IS_RIGHT_COVER(c2)) return 0;
+    return c1 - c2;
+}
+double calc_read_error_rate(int len, const uint8_t *qual) { // src/seq.c:429-436
+    if (len <= 0 || qual == nullptr) return 0.0;
+    double e = 0.0;
+    for (int i = 0; i < len; ++i) e += pow(10.0, -((double)qual[i]) / 10.0);
+    return e / len;
+}
+bool is_homopolymer(const uint8_t *seq, int seq_len, int flank) { // src/align.c:1000-1026
+    if (seq_len < 2 * flank || seq_len > 2 * flank + 50) return false;
+    int hp_len = 0;
+    for (int i = flank - 1; i < seq_len - flank + 1; ++i) {
+        if (seq[i] == seq[i - 1]) hp_len++;
+        else { if (hp_len >= 5) return true; hp_len = 0; }
+    }
+    return hp_len >= 5;
+}
+
+struct RegRead { // one read of a region, in sorted order after add
+    int id, len, cover, hap; int64_t ps; uint64_t off; double err;
+};
+struct ChainRec {
+    int region, clu;              // clu: hap-1 for K1, 0 for K2 (clusters come out of the kernel)
+    int mode;
+    std::vector<int> members;     // indices into the region's sorted read list
+    int read0;                    // first PoaRead
+};
+struct AnchorRec {
+    int pread;                    // index into preads
+    int ext;                      // 1 L->R, 2 R->L ; 0: sampling-mode full-read K4 filter only
+    int tlen_full, qlen_full;     // _tlen, _qlen
+    int ed_job, wfa_job;
+    int min_len;
+};
+struct RegionRec {
+    int64_t reg_len; int n_reads;
+    std::vector<RegRead> reads;   // sorted (src/align.c:1774)
+    uint64_t ref_off; int ref_len;
+    int branch;                   // 0 skipped, 1 with-PS (K1 x2), 2 no-PS (K2)
+    int sampling;
+    int chain[2];                 // chain indices (-1 none)
+    // results
+    int n_cons = 0;
+};
+
+struct OutStr { // one aln_str in the final output pool
+    uint64_t off; int stride; int aln_len, tb, te, qb, qe, shift; bool present;
+};
+
+} // namespace
+
+struct lcd_batch_s {
+    lcd_opt_t opt;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[10];
+    std::vector<uint8_t> h_pool;
+    std::vector<RegionRec> regs;
+    std::vector<ChainRec> chains;
+    std::vector<PoaRead> preads;         // seq_off relative to h_pool until run()
+    std::vector<AnchorRec> anchors;
+    std::vector<EdJob> ed_jobs;          // offsets relative to h_pool until run()
+    std::vector<WfaJob> wfa_jobs;
+    // device
+    DevBuf d_in, d_chains, d_preads, d_poa_arena, d_poa_out, d_poa_outs, d_ed_jobs, d_ed_arena, d_ed_outs, d_wfa_jobs, d_wfa_arena,
+        d_wfa_out, d_wfa_outs, d_str_jobs, d_str_outs, d_final;
+    bool uploaded = false, ran = false, downloaded = false;
+    // results (host)
+    std::vector<PoaChainOut> couts;
+    std::vector<PoaChain> pchains;
+    std::vector<WfaJob> rc_jobs; std::vector<WfaOut> rc_outs; // ref<->cons
+    std::vector<int> rc_region, rc_clu;
+    std::vector<StrJob> str_jobs; std::vector<StrOut> str_outs;
+    std::vector<int> str_region, str_clu, str_k;
+    std::vector<uint8_t> h_final; std::vector<uint8_t> h_poa_out;
+    uint64_t final_bytes = 0;
+    lcd_batch_stats_t st;
+};
+
+namespace {
+
+LcdScoring scoring_of(const lcd_opt_t &o) { LcdScoring s; s.match = o.match; s.mismatch = o.mismatch; s.o1 = o.gap_open1; s.e1 = o.gap_ext1; s.o2 = o.gap_open2; s.e2 = o.gap_ext2; return s; }
+
+uint64_t wfa_arena_bytes(int plen, int tlen, int s_cap) {
+    // header + ops + sum_{s<=s_cap} 5*(2s+3) offsets, diagonals never exceed plen+tlen+3
+    uint64_t hdr = lcd_align_up((uint64_t)3 * (s_cap + 1) * 4 + (uint64_t)(plen + tlen + 2), 16);
+    uint64_t wmax = (uint64_t)plen + tlen + 3, tot = 0;
+    // closed form: widths min(2s+3, wmax)
+    uint64_t s_sw = wmax > 3 ? (wmax - 3) / 2 : 0; // scores with 2s+3 <= wmax
+    if ((uint64_t)s_cap <= s_sw) tot = (uint64_t)(s_cap + 1) * (s_cap + 3);
+    else tot = (s_sw + 1) * (s_sw + 3) + ((uint64_t)s_cap - s_sw) * wmax;
+    return hdr + tot * 5 * 4 + 256;
+}
+int wfa_default_scap(int plen, int tlen) {
+    int d = plen > tlen ? plen - tlen : tlen - plen;
+    int m = plen < tlen ? plen : tlen;
+    // enough for the length difference as one long gap plus ~6% divergence; retried x4 on overflow
+    long long s = 24 + d + 64 + (long long)(m * 0.06) * 6;
+    return (int)std::min<long long>(s, 2000000);
+}
+uint64_t ed_arena_bytes(int qlen, int tlen) { return (uint64_t)52432 * 20 + (uint64_t)qlen * 8 + (uint64_t)tlen * 2 + 512; }
+
+// ---- generic stage runners (absolute device addresses in job structs) ----
+int run_edlib_stage(hipStream_t st, std::vector<EdJob> &jobs, DevBuf &d_jobs, DevBuf &d_arena, DevBuf &d_outs, std::vector<EdOut> &outs) {
+    const int n = (int)jobs.size();
+    outs.resize(n);
+    if (n == 0) return 0;
+    uint64_t tot = 0;
+    for (auto &j : jobs) { j.ws_bytes = lcd_align_up(ed_arena_bytes(j.qlen, j.tlen), 256); j.ws_off = tot; tot += j.ws_bytes; }
+    if (d_arena.ensure(tot)) return -11;
+    for (auto &j : jobs) j.ws_off += d_arena.addr();
+    if (d_jobs.ensure(n * sizeof(EdJob)) || d_outs.ensure(n * sizeof(EdOut))) return -11;
+    HIPCHK(hipMemcpyAsync(d_jobs.p, jobs.data(), n * sizeof(EdJob), hipMemcpyHostToDevice, st));
+    lcd_launch_edlib((const EdJob *)d_jobs.p, nullptr, nullptr, (EdOut *)d_outs.p, n, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(outs.data(), d_outs.p, n * sizeof(EdOut), hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
+// lays out arenas + outputs and launches; caller syncs and checks statuses. out_bytes per job = cigar area + rows area
+uint64_t wfa_out_bytes(const WfaJob &j) {
+    uint64_t maxl = (uint64_t)j.plen + j.tlen + 1, o = 0;
+    if (j.want & 1) o += lcd_align_up(maxl * 4, 16);
+    if (j.want & 2) o += lcd_align_up(maxl * 2, 16);
+    return o;
+}
+int launch_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, const std::vector<int> &which, DevBuf &d_jobs, DevBuf &d_arena,
+                     DevBuf &d_out, uint64_t out_base_reserved, DevBuf &d_outs, LcdScoring sc) {
+    // jobs[which[i]] get fresh arenas; out_off must already be set by the caller (absolute)
+    const int n = (int)which.size();
+    if (n == 0) return 0;
+    uint64_t tot = 0;
+    std::vector<WfaJob> sub(n);
+    for (int i = 0; i < n; ++i) {
+        WfaJob &j = jobs[which[i]];
+        j.ws_bytes = lcd_align_up(wfa_arena_bytes(j.plen, j.tlen, j.s_cap), 256); j.ws_off = tot; tot += j.ws_bytes;
+    }
+    if (d_arena.ensure(tot)) return -11;
+    for (int i = 0; i < n; ++i) { jobs[which[i]].ws_off += d_arena.addr(); sub[i] = jobs[which[i]]; }
+    if (d_jobs.ensure(n * sizeof(WfaJob)) || d_outs.ensure(n * sizeof(WfaOut))) return -11;
+    HIPCHK(hipMemcpyAsync(d_jobs.p, sub.data(), n * sizeof(WfaJob), hipMemcpyHostToDevice, st));
+    lcd_launch_wfa((const WfaJob *)d_jobs.p, nullptr, nullptr, nullptr, (WfaOut *)d_outs.p, sc, n, st);
+    HIPCHK(hipGetLastError());
+    (void)d_out; (void)out_base_reserved;
+    return 0;
+}
+// full WFA stage with the overflow retry ladder (s_cap x4)
+int run_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, DevBuf &d_jobs, DevBuf &d_arena, DevBuf &d_out, DevBuf &d_outs,
+                  std::vector<WfaOut> &outs, LcdScoring sc, int *retries) {
+    const int n = (int)jobs.size();
+    outs.assign(n, WfaOut());
+    if (n == 0) return 0;
+    uint64_t otot = 0;
+    std::vector<uint64_t> ooff(n);
+    for (int i = 0; i < n; ++i) { ooff[i] = otot; otot += lcd_align_up(wfa_out_bytes(jobs[i]), 256); }
+    if (d_out.ensure(otot)) return -11;
+    for (int i = 0; i < n; ++i) jobs[i].out_off = d_out.addr() + ooff[i];
+    std::vector<int> which(n);
+    for (int i = 0; i < n; ++i) which[i] = i;
+    for (int round = 0; round < 8 && !which.empty(); ++round) {
+        int rc = launch_wfa_stage(st, jobs, which, d_jobs, d_arena, d_out, 0, d_outs, sc);
+        if (rc) return rc;
+        std::vector<WfaOut> tmp(which.size());
+        HIPCHK(hipMemcpyAsync(tmp.data(), d_outs.p, which.size() * sizeof(WfaOut), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        std::vector<int> again;
+        for (size_t i = 0; i < which.size(); ++i) {
+            unsigned long long prev = outs[which[i]].offsets;
+            outs[which[i]] = tmp[i]; outs[which[i]].offsets += prev;
+            if (tmp[i].status == LCD_ERR_WF) { jobs[which[i]].s_cap = (int)std::min<long long>((long long)jobs[which[i]].s_cap * 4 + 64, 4000000); again.push_back(which[i]); }
+            else if (tmp[i].status != LCD_OK) return set_err(-20, "WFA kernel status " + std::to_string(tmp[i].status));
+        }
+        if (!again.empty() && retries) (*retries)++;
+        which.swap(again);
+    }
+    if (!which.empty()) return set_err(-21, "WFA arena exhausted after retries");
+    return 0;
+}
+
+} // namespace
+
+// =====================================================================================================
+extern "C" {
+
+void lcd_opt_default(lcd_opt_t *o) {
+    o->match = 2; o->mismatch = 6; o->gap_open1 = 6; o->gap_ext1 = 2; o->gap_open2 = 24; o->gap_ext2 = 1;
+    o->gap_aln = 1; o->min_af = 0.20; o->min_dp = 5; o->partial_aln_ratio = 1.1;
+    o->min_noisy_reg_size_to_sample_reads = 10000; o->max_noisy_reg_len = 50000; o->noisy_reg_flank_len = 10;
+    o->min_hap_full_reads = 1; o->min_hap_reads = 2; o->collect_ref_read_aln_str = 0; o->is_ont = 0;
+}
+int lcd_init(int device) {
+    {
+        std::lock_guard<std::mutex> lk(g_init_mu);
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return set_err(-1, "liblcd_hotpath: no HIP device visible (this library has no CPU path)");
+        if (device < 0 || device >= n) return set_err(-1, "bad device index");
+        if (hipSetDevice(device) != hipSuccess) return set_err(-1, "hipSetDevice failed");
+        g_device = device;
+    }
+    return 0;
+}
+const char *lcd_last_error(void) { return g_err.c_str(); }
+const char *lcd_version(void) { return "longcalld_amd hot path 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------------------------------------------
+lcd_batch_t *lcd_batch_create(const lcd_opt_t *opt) {
+    if (ensure_init()) return nullptr;
+    lcd_batch_t *b = new lcd_batch_s();
+    b->opt = *opt;
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { set_err(-10, "hipStreamCreate failed"); delete b; return nullptr; }
+    for (auto &e : b->ev) hipEventCreate(&e);
+    memset(&b->st, 0, sizeof(b->st));
+    return b;
+}
+void lcd_batch_destroy(lcd_batch_t *b) {
+    if (!b) return;
+    hipSetDevice(g_device);
+    for (auto &e : b->ev) hipEventDestroy(e);
+    if (b->stream) hipStreamDestroy(b->stream);
+    delete b;
+}
+void lcd_batch_clear(lcd_batch_t *b) {
+    b->h_pool.clear(); b->regs.clear(); b->chains.clear(); b->preads.clear(); b->anchors.clear(); b->ed_jobs.clear(); b->wfa_jobs.clear();
+    b->uploaded = b->ran = b->downloaded = false;
+    memset(&b->st, 0, sizeof(b->st));
+}
+
+static uint64_t pool_push(std::vector<uint8_t> &pool, const uint8_t *p, int n) {
+    uint64_t off = pool.size();
+    pool.insert(pool.end(), p, p + n);
+    size_t pad = (16 - (pool.size() & 15)) & 15;
+    pool.insert(pool.end(), pad, (uint8_t)4);
+    return off;
+}
+
+int lcd_batch_add_region(lcd_batch_t *b, int64_t reg_len, int n_reads, const int *read_ids, const int *lens, const uint8_t *const *seqs,
+                         const uint8_t *const *quals, const int *fully_covers, const int *haps, const int64_t *phase_sets,
+                         const uint8_t *ref_seq, int ref_seq_len) {
+    const lcd_opt_t &opt = b->opt;
+    if (opt.collect_ref_read_aln_str) return set_err(-2, "collect_ref_read_aln_str (--refine-aln -b / -s) is not implemented on the device path yet");
+    b->uploaded = b->ran = b->downloaded = false;
+    RegionRec R;
+    R.reg_len = reg_len; R.n_reads = n_reads; R.branch = 0; R.chain[0] = R.chain[1] = -1;
+    R.sampling = reg_len >= opt.min_noisy_reg_size_to_sample_reads;
+    R.ref_off = pool_push(b->h_pool, ref_seq, ref_seq_len); R.ref_len = ref_seq_len;
+    R.reads.resize(n_reads > 0 ? n_reads : 0);
+    for (int i = 0; i < n_reads; ++i) {
+        RegRead &r = R.reads[i];
+        r.id = read_ids[i]; r.len = lens[i]; r.cover = fully_covers[i]; r.hap = haps[i]; r.ps = phase_sets[i];
+        r.off = lens[i] > 0 ? pool_push(b->h_pool, seqs[i], lens[i]) : b->h_pool.size();
+        r.err = R.sampling ? calc_read_error_rate(lens[i], quals ? quals[i] : nullptr) : 0.0;
+    }
+    if (n_reads <= 0) { b->regs.push_back(R); return (int)b->regs.size() - 1; }
+    // sort_noisy_region_reads, src/align.c:963-985 (exchange sort, exact swap sequence)
+    const bool use_err = R.sampling;
+    for (int i = 0; i < n_reads - 1; ++i)
+        for (int j = i + 1; j < n_reads; ++j) {
+            int cc = full_cover_cmp(R.reads[i].cover, R.reads[j].cover);
+            if (cc < 0 || (cc == 0 && use_err && R.reads[i].err > R.reads[j].err) ||
+                (cc == 0 && ((use_err && R.reads[i].err == R.reads[j].err) || !use_err) && R.reads[i].len < R.reads[j].len))
+                std::swap(R.reads[i], R.reads[j]);
+        }
+    // collect_phase_set_with_both_haps, src/align.c:1225-1279
+    int64_t ps_sel = -1;
+    {
+        std::vector<int64_t> uniq; std::vector<std::array<int, 2>> full, all, minlen;
+        for (int i = 0; i < n_reads; ++i) {
+            const RegRead &r = R.reads[i];
+            if (r.hap == 0) continue;
+            size_t k = 0;
+            for (; k < uniq.size(); ++k) if (uniq[k] == r.ps) break;
+            if (k == uniq.size()) { uniq.push_back(r.ps); full.push_back({0, 0}); all.push_back({0, 0}); minlen.push_back({INT32_MAX, INT32_MAX}); }
+            const int h = r.hap - 1;
+            if (LCD_IS_BOTH_COVER(r.cover)) { full[k][h]++; all[k][h]++; if (minlen[k][h] > r.len) minlen[k][h] = r.len; }
+            else if (LCD_IS_LEFT_COVER(r.cover) || LCD_IS_RIGHT_COVER(r.cover)) { if (r.len >= minlen[k][h]) all[k][h]++; }
+        }
+        int max_i = -1, m1 = -1, m2 = -1;
+        for (size_t i = 0; i < uniq.size(); ++i) {
+            int c1 = std::min(full[i][0], full[i][1]), c2 = std::max(full[i][0], full[i][1]);
+            if (c1 > m1) { m1 = c1; m2 = c2; ps_sel = uniq[i]; max_i = (int)i; }
+            else if (c1 == m1 && c2 > m2) { m2 = c2; ps_sel = uniq[i]; max_i = (int)i; }
+        }
+        if (m1 < opt.min_hap_full_reads) ps_sel = -1;
+        if (ps_sel != -1 && max_i != -1)
+            if (all[max_i][0] < opt.min_hap_reads || all[max_i][1] < opt.min_hap_reads) ps_sel = -1;
+    }
+    int n_full = 0;
+    for (auto &r : R.reads) if (LCD_IS_BOTH_COVER(r.cover)) n_full++;
+    const int region_idx = (int)b->regs.size();
+    auto add_chain = [&](int mode, int clu, const std::vector<int> &members) {
+        ChainRec C; C.region = region_idx; C.clu = clu; C.mode = mode; C.members = members; C.read0 = (int)b->preads.size();
+        const RegRead &r0 = R.reads[members[0]];
+        for (size_t k = 0; k < members.size(); ++k) {
+            const RegRead &r = R.reads[members[k]];
+            PoaRead pr; pr.seq_off = r.off; pr.len = r.len; pr.skip = 0; pr.ref_beg = 1; pr.ref_end = r0.len; pr.read_beg = 1; pr.read_end = r.len;
+            const int pidx = (int)b->preads.size();
+            b->preads.push_back(pr);
+            if (mode != 0 || k == 0) continue;
+            // collect_partial_aln_beg_end, src/align.c:709-745 (target = read 0, always both-cover)
+            const int qfc = r.cover;
+            if (LCD_IS_BOTH_COVER(qfc) || (LCD_IS_LEFT_COVER(qfc) && LCD_IS_RIGHT_GAP(qfc)) || (LCD_IS_RIGHT_COVER(qfc) && LCD_IS_LEFT_GAP(qfc))) {
+                if (R.sampling) {
+                    AnchorRec A; A.pread = pidx; A.ext = 0; A.tlen_full = r0.len; A.qlen_full = r.len; A.wfa_job = -1; A.min_len = std::min(r0.len, r.len);
+                    EdJob ej; ej.t_off = r0.off; ej.tlen = r0.len; ej.q_off = r.off; ej.qlen = r.len; ej.ws_off = 0; ej.ws_bytes = 0;
+                    A.ed_job = (int)b->ed_jobs.size(); b->ed_jobs.push_back(ej); b->anchors.push_back(A);
+                }
+            } else if (LCD_IS_LEFT_COVER(qfc) || LCD_IS_RIGHT_COVER(qfc)) {
+                // cal_wfa_partial_aln_beg_end, src/align.c:667-707
+                const int ext = LCD_IS_LEFT_COVER(qfc) ? 1 : 2;
+                const int _tlen = r0.len, _qlen = r.len; const double ratio = opt.partial_aln_ratio;
+                int tlen = _tlen, qlen = _qlen; uint64_t toff = r0.off, qoff = r.off;
+                if (ext == 1) {
+                    if (_tlen > _qlen * ratio) tlen = (int)(_qlen * ratio);
+                    else if (_qlen > _tlen * ratio) qlen = (int)(_tlen * ratio);
+                } else {
+                    if (_tlen > _qlen * ratio) { toff = r0.off + _tlen - (int)(_qlen * ratio); tlen = (int)(_qlen * ratio); }
+                    else if (_qlen > _tlen * ratio) { qoff = r.off + _qlen - (int)(_tlen * ratio); qlen = (int)(_tlen * ratio); }
+                }
+                int gap_aln = opt.gap_aln;
+                if (ext == 1) gap_aln = (gap_aln == 2) ? 1 : 2;
+                const int min_len = std::min(tlen, qlen);
+                AnchorRec A; A.pread = pidx; A.ext = ext; A.tlen_full = _tlen; A.qlen_full = _qlen; A.min_len = min_len;
+                EdJob ej; ej.qlen = min_len; ej.tlen = min_len; ej.ws_off = 0; ej.ws_bytes = 0;
+                if (ext == 1) { ej.t_off = toff; ej.q_off = qoff; } else { ej.t_off = toff + tlen - min_len; ej.q_off = qoff + qlen - min_len; }
+                A.ed_job = (int)b->ed_jobs.size(); b->ed_jobs.push_back(ej);
+                WfaJob wj; wj.p_off = toff; wj.plen = tlen; wj.t_off = qoff; wj.tlen = qlen; wj.gap_aln = gap_aln; wj.want = 1;
+                wj.s_cap = wfa_default_scap(tlen, qlen); wj.ws_off = 0; wj.ws_bytes = 0; wj.out_off = 0;
+                A.wfa_job = (int)b->wfa_jobs.size(); b->wfa_jobs.push_back(wj);
+                b->anchors.push_back(A);
+            }
+        }
+        b->chains.push_back(C);
+        return (int)b->chains.size() - 1;
+    };
+    if (ps_sel > 0) { // src/align.c:1789 with wfa_collect_noisy_aln_str_with_ps_hap :1286-1375
+        const bool use_non_full = !is_homopolymer(ref_seq, ref_seq_len, opt.noisy_reg_flank_len);
+        int stale_len0 = 0, n_ch = 0; bool broke = false;
+        std::vector<int> mem[2];
+        for (int hap = 1; hap <= 2; ++hap) {
+            std::vector<int> &m = mem[hap - 1];
+            for (int i = 0; i < n_reads; ++i) {
+                const RegRead &r = R.reads[i];
+                if (r.len <= 0 || r.ps != ps_sel || r.hap != hap) continue;
+                if (!use_non_full && !LCD_IS_BOTH_COVER(r.cover)) continue;
+                m.push_back(i);
+            }
+            if (!m.empty()) stale_len0 = R.reads[m[0]].len;
+            if (stale_len0 >= opt.max_noisy_reg_len) { broke = true; break; }
+            if (m.empty()) continue;
+            n_ch++;
+        }
+        if (!broke && n_ch == 2) {
+            R.branch = 1;
+            R.chain[0] = add_chain(0, 0, mem[0]);
+            R.chain[1] = add_chain(0, 1, mem[1]);
+        }
+    } else if (n_full >= opt.min_dp) { // src/align.c:1794 with wfa_collect_noisy_aln_str_no_ps_hap :1148-1211
+        std::vector<int> m;
+        for (int i = 0; i < n_reads; ++i) { const RegRead &r = R.reads[i]; if (r.len > 0 && LCD_IS_BOTH_COVER(r.cover)) m.push_back(i); }
+        if (!m.empty() && R.reads[m[0]].len < opt.max_noisy_reg_len) { R.branch = 2; R.chain[0] = add_chain(1, 0, m); }
+    }
+    b->regs.push_back(R);
+    return region_idx;
+}
+
+int lcd_batch_add_region_from_chunk(lcd_batch_t *b, const lcd_read_view_t *cr, int64_t reg_beg, int64_t reg_end, int n, const int *noisy_reads,
+                                    const uint8_t *ref_seq, int ref_seq_len) {
+    // collect_noisy_read_info, src/align.c:1377-1461
+    static const uint8_t nt16_int[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4}; // htslib seq_nt16_int
+    std::vector<int> ids(n), lens(n), covers(n), haps(n); std::vector<int64_t> pss(n);
+    std::vector<std::vector<uint8_t>> seqs(n), quals(n);
+    std::vector<const uint8_t *> sp(n), qp(n);
+    for (int i = 0; i < n; ++i) {
+        const lcd_read_view_t &rv = cr[noisy_reads[i]];
+        const lcd_digar1_t *d = rv.digars; const int nd = rv.n_digar;
+        int64_t rdb = -1, rde = -1;
+        int rb = 0, re = rv.qlen - 1;
+        if (d[0].type == 5) rb = d[0].len;
+        if (d[nd - 1].type == 5) re = d[nd - 1].qi - 1;
+        int beg_is_del = 0, end_is_del = 0, cover = 0;
+        for (int k = 0; k < nd; ++k) {
+            int64_t db = d[k].pos, de; const int op = d[k].type, len = d[k].len, qi = d[k].qi;
+            if (op == 4 || op == 5) continue;
+            if (op == 8 || op == 7 || op == 2) de = db + len - 1; else de = db;
+            if (db > reg_end) break;
+            if (de < reg_beg) continue;
+            if (db <= reg_beg && de >= reg_beg) {
+                if (op == 2) { rdb = reg_beg; rb = qi; if (len > b->opt.noisy_reg_flank_len) beg_is_del = 1; }
+                else { rdb = reg_beg; rb = qi + (int)(reg_beg - db); }
+            }
+            if (db <= reg_end && de >= reg_end) {
+                if (op == 2) { rde = reg_end; re = qi - 1; if (len > b->opt.noisy_reg_flank_len) end_is_del = 1; }
+                else { rde = reg_end; re = qi + (int)(reg_end - db); }
+            }
+        }
+        if (rdb == reg_beg && rde == reg_end) {
+            if (!beg_is_del && !end_is_del) cover = LCD_LEFT_COVER | LCD_RIGHT_COVER;
+            else if (!beg_is_del && end_is_del) cover = LCD_LEFT_COVER | LCD_RIGHT_GAP;
+            else if (beg_is_del && !end_is_del) cover = LCD_LEFT_GAP | LCD_RIGHT_COVER;
+            else cover = LCD_LEFT_GAP | LCD_RIGHT_GAP;
+        } else if (rdb == reg_beg) cover = beg_is_del ? LCD_LEFT_GAP : LCD_LEFT_COVER;
+        else if (rde == reg_end) cover = end_is_del ? LCD_RIGHT_GAP : LCD_RIGHT_COVER;
+        const int L = re - rb + 1;
+        ids[i] = noisy_reads[i]; lens[i] = L; covers[i] = cover; haps[i] = rv.hap; pss[i] = rv.phase_set;
+        if (L > 0) {
+            seqs[i].resize(L); quals[i].resize(L);
+            for (int j = rb; j <= re; ++j) {
+                seqs[i][j - rb] = nt16_int[(rv.bseq[j >> 1] >> ((~j & 1) << 2)) & 0xf]; // bam_seqi
+                quals[i][j - rb] = rv.qual ? rv.qual[j] : 0;
+            }
+        }
+        sp[i] = seqs[i].data(); qp[i] = quals[i].data();
+    }
+    return lcd_batch_add_region(b, reg_end - reg_beg + 1, n, ids.data(), lens.data(), sp.data(), qp.data(), covers.data(), haps.data(),
+                                pss.data(), ref_seq, ref_seq_len);
+}
+
+int lcd_batch_upload(lcd_batch_t *b) {
+    if (ensure_init()) return -1;
+    const double t0 = now_ms();
+    if (b->d_in.ensure(b->h_pool.size() + 64)) return -11;
+    HIPCHK(hipMemcpyAsync(b->d_in.p, b->h_pool.data(), b->h_pool.size(), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->uploaded = true; b->ran = false; b->downloaded = false;
+    b->st.ms_upload = now_ms() - t0;
+    return 0;
+}
+
+static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vector<PoaRead> &preads, int scale, PoaChain &pc) {
+    const int n = (int)C.members.size();
+    long long sum = 0; int maxl = 0;
+    for (int k = 0; k < n; ++k) { const PoaRead &r = preads[C.read0 + k]; sum += r.len; maxl = std::max(maxl, r.len); }
+    pc.n_reads = n; pc.read0 = C.read0; pc.mode = C.mode;
+    pc.node_cap = (int)std::min<long long>(sum + 2, 2000000000ll);
+    pc.edge_cap = (int)std::min<long long>(sum + n + 2, 2000000000ll);
+    pc.rid_words = (n + 63) / 64; pc.max_len = maxl;
+    int mw = (int)(n * opt.min_af); if (mw < 2) mw = 2;
+    pc.min_w = (uint32_t)mw;
+    // rows actually visited ~ graph size ~ a small multiple of the backbone; band ~ 2w+1 plus drift.  Overflow is detected
+    // in-kernel (LCD_ERR_CELLS) and the chain is re-run with `scale` x more, up to the worst case.
+    const long long rows_worst = pc.node_cap;
+    const long long rows_est = std::min<long long>(rows_worst, 2ll * maxl + 64);
+    long long band;
+    if (C.mode == 0) band = std::min<long long>(maxl + 1, 2ll * (10 + maxl / 100) + 1 + 64);
+    else band = maxl + 1;
+    long long cells = rows_est * band;
+    const long long worst = rows_worst * (long long)(maxl + 1);
+    for (int s = 1; s < scale && cells < worst; s *= 2) cells *= 8;
+    cells = std::min(cells, worst);
+    pc.cell_cap = (uint64_t)std::max<long long>(cells, maxl + 64);
+}
+
+int lcd_batch_run(lcd_batch_t *b) {
+    if (!b->uploaded) return set_err(-3, "lcd_batch_run before lcd_batch_upload");
+    if (ensure_init()) return -1;
+    hipStream_t st = b->stream;
+    const LcdScoring sc = scoring_of(b->opt);
+    const uint64_t in_base = b->d_in.addr();
+    const double t_begin = now_ms();
+    lcd_batch_stats_t &S = b->st;
+    const double keep_up = S.ms_upload;
+    memset(&S, 0, sizeof(S)); S.ms_upload = keep_up;
+    S.n_chains = (int)b->chains.size(); S.n_anchor_jobs = (int)b->anchors.size();
+    HIPCHK(hipEventRecord(b->ev[0], st));
+    // ---------------- S1: anchors (K4 prefilter + K3b) ----------------
+    std::vector<PoaRead> preads = b->preads;
+    for (auto &r : preads) r.seq_off += in_base;
+    if (!b->anchors.empty()) {
+        std::vector<EdJob> ej = b->ed_jobs; std::vector<WfaJob> wj = b->wfa_jobs;
+        for (auto &j : ej) { j.q_off += in_base; j.t_off += in_base; }
+        for (auto &j : wj) { j.p_off += in_base; j.t_off += in_base; }
+        std::vector<EdOut> eo; std::vector<WfaOut> wo;
+        int rc = run_edlib_stage(st, ej, b->d_ed_jobs, b->d_ed_arena, b->d_ed_outs, eo);
+        if (rc) return rc;
+        rc = run_wfa_stage(st, wj, b->d_wfa_jobs, b->d_wfa_arena, b->d_wfa_out, b->d_wfa_outs, wo, sc, nullptr);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(st));
+        // cigars of the anchor jobs
+        std::vector<std::vector<uint32_t>> cig(wj.size());
+        for (size_t i = 0; i < wj.size(); ++i) {
+            cig[i].resize(wo[i].n_cigar);
+            if (wo[i].n_cigar) HIPCHK(hipMemcpyAsync(cig[i].data(), (void *)(uintptr_t)wj[i].out_off, wo[i].n_cigar * 4, hipMemcpyDeviceToHost, st));
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        for (auto &e : eo) { if (e.status != LCD_OK) return set_err(-20, "edlib kernel status " + std::to_string(e.status)); S.edlib_blocks += e.blocks; }
+        for (auto &w : wo) S.wfa_offsets += w.offsets;
+        S.n_edlib_jobs = (int)ej.size(); S.n_wfa_jobs += (int)wj.size();
+        for (const AnchorRec &A : b->anchors) {
+            PoaRead &pr = preads[A.pread];
+            const int x = eo[A.ed_job].xgaps;
+            if (x > A.min_len * 0.10) { pr.skip = 1; continue; }
+            if (A.ext == 0) continue;
+            const std::vector<uint32_t> &c = cig[A.wfa_job];
+            if (c.empty()) { pr.skip = 1; continue; }
+            // collect_aln_beg_end, src/align.c:630-663
+            int rb = 1, qb = 1, re = A.tlen_full, qe = A.qlen_full;
+            if (A.ext == 1) {
+                int tr = 0, tq = 0;
+                for (uint32_t cg : c) { int op = cg & 0xf, len = cg >> 4;
+                    if (op == 7 || op == 0) { tr += len; tq += len; re = tr; qe = tq; } else if (op == 8) { tr += len; tq += len; } else if (op == 2) tr += len; else if (op == 1) tq += len; }
+            } else {
+                int tr = A.tlen_full + 1, tq = A.qlen_full + 1;
+                for (int i = (int)c.size() - 1; i >= 0; --i) { int op = c[i] & 0xf, len = c[i] >> 4;
+                    if (op == 7 || op == 0) { tr -= len; tq -= len; rb = tr; qb = tq; } else if (op == 8) { tr -= len; tq -= len; } else if (op == 2) tr -= len; else if (op == 1) tq -= len; }
+            }
+            pr.ref_beg = rb; pr.ref_end = re; pr.read_beg = qb; pr.read_end = qe;
+        }
+    }
+    HIPCHK(hipEventRecord(b->ev[1], st));
+    // ---------------- S2: POA chains ----------------
+    const int nC = (int)b->chains.size();
+    b->couts.assign(nC, PoaChainOut());
+    b->pchains.assign(nC, PoaChain());
+    std::vector<uint64_t> out_rel(nC);
+    uint64_t out_tot = 0;
+    for (int c = 0; c < nC; ++c) {
+        chain_caps(b->opt, b->chains[c], preads, 1, b->pchains[c]);
+        out_rel[c] = out_tot; out_tot += lcd_align_up(poa_out_bytes(b->pchains[c].node_cap, b->pchains[c].n_reads), 256);
+    }
+    if (nC) {
+        if (b->d_poa_out.ensure(out_tot) || b->d_preads.ensure(preads.size() * sizeof(PoaRead)) || b->d_chains.ensure(nC * sizeof(PoaChain)) ||
+            b->d_poa_outs.ensure(nC * sizeof(PoaChainOut))) return -11;
+        HIPCHK(hipMemcpyAsync(b->d_preads.p, preads.data(), preads.size() * sizeof(PoaRead), hipMemcpyHostToDevice, st));
+        for (int c = 0; c < nC; ++c) b->pchains[c].out_off = b->d_poa_out.addr() + out_rel[c];
+        std::vector<int> which(nC);
+        for (int c = 0; c < nC; ++c) which[c] = c;
+        // biggest first so the long chains start early (LPT)
+        std::sort(which.begin(), which.end(), [&](int a, int c2) { return b->pchains[a].cell_cap > b->pchains[c2].cell_cap; });
+        int scale = 1;
+        for (int round = 0; round < 12 && !which.empty(); ++round) {
+            uint64_t tot = 0;
+            std::vector<PoaChain> sub(which.size());
+            for (size_t i = 0; i < which.size(); ++i) {
+                PoaChain &pc = b->pchains[which[i]];
+                if (round) chain_caps(b->opt, b->chains[which[i]], preads, scale, pc), pc.out_off = b->d_poa_out.addr() + out_rel[which[i]];
+                PoaLayout L = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads);
+                pc.ws_off = tot; tot += L.total;
+            }
+            if (b->d_poa_arena.ensure(tot)) return -11;
+            for (size_t i = 0; i < which.size(); ++i) { b->pchains[which[i]].ws_off += b->d_poa_arena.addr(); sub[i] = b->pchains[which[i]]; }
+            HIPCHK(hipMemcpyAsync(b->d_chains.p, sub.data(), sub.size() * sizeof(PoaChain), hipMemcpyHostToDevice, st));
+            lcd_launch_poa((const PoaChain *)b->d_chains.p, (const PoaRead *)b->d_preads.p, nullptr, nullptr, nullptr, (PoaChainOut *)b->d_poa_outs.p, sc,
+                           (int)sub.size(), st);
+            HIPCHK(hipGetLastError());
+            std::vector<PoaChainOut> tmp(sub.size());
+            HIPCHK(hipMemcpyAsync(tmp.data(), b->d_poa_outs.p, sub.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            std::vector<int> again;
+            for (size_t i = 0; i < which.size(); ++i) {
+                b->couts[which[i]] = tmp[i];
+                if (tmp[i].status == LCD_ERR_CELLS) again.push_back(which[i]);
+                else if (tmp[i].status != LCD_OK) return set_err(-20, "POA kernel status " + std::to_string(tmp[i].status) + " on chain " + std::to_string(which[i]));
+            }
+            if (!again.empty()) { S.poa_retries++; scale *= 2; }
+            which.swap(again);
+        }
+        if (!which.empty()) return set_err(-21, "POA DP arena exhausted after retries");
+    }
+    HIPCHK(hipEventRecord(b->ev[2], st));
+    // ---------------- S3: ref<->cons WFA, S4: MSA rows -> strings ----------------
+    b->rc_jobs.clear(); b->rc_region.clear(); b->rc_clu.clear();
+    b->str_jobs.clear(); b->str_region.clear(); b->str_clu.clear(); b->str_k.clear();
+    uint64_t str_tot = 0;
+    for (size_t ri = 0; ri < b->regs.size(); ++ri) {
+        RegionRec &R = b->regs[ri];
+        R.n_cons = 0;
+        if (R.branch == 0) continue;
+        S.n_regions++;
+        if (R.branch == 1) {
+            const PoaChainOut &o0 = b->couts[R.chain[0]], &o1 = b->couts[R.chain[1]];
+            if (o0.n_cons + o1.n_cons != 2) continue; // src/align.c:1339
+            R.n_cons = 2;
+        } else R.n_cons = b->couts[R.chain[0]].n_cons;
+        if (R.n_cons > 0) S.n_regions_resolved++;
+        for (int c = 0; c < R.n_cons; ++c) {
+            const int ch = R.branch == 1 ? R.chain[c] : R.chain[0];
+            const int cc = R.branch == 1 ? 0 : c; // consensus index inside the chain
+            const PoaChain &pc = b->pchains[ch]; const PoaChainOut &co = b->couts[ch];
+            WfaJob wj; wj.p_off = in_base + R.ref_off; wj.plen = R.ref_len; wj.t_off = pc.out_off + (uint64_t)cc * pc.node_cap; wj.tlen = co.cons_len[cc];
+            wj.gap_aln = b->opt.gap_aln; wj.want = 2; wj.s_cap = wfa_default_scap(wj.plen, wj.tlen); wj.ws_off = wj.ws_bytes = wj.out_off = 0;
+            b->rc_jobs.push_back(wj); b->rc_region.push_back((int)ri); b->rc_clu.push_back(c);
+            const uint64_t msa0 = pc.out_off + 2ull * pc.node_cap;
+            const uint64_t cons_row = msa0 + (uint64_t)(pc.n_reads + cc) * pc.node_cap;
+            const int *dummy = nullptr; (void)dummy;
+            const int nk = R.branch == 1 ? pc.n_reads : co.clu_n[cc];
+            for (int k = 0; k < nk; ++k) {
+                StrJob sj; sj.cons_off = cons_row; sj.msa_len = co.msa_len; sj.out_off = str_tot; str_tot += lcd_align_up((uint64_t)2 * co.msa_len + 16, 16);
+                if (R.branch == 1) { sj.read_off = msa0 + (uint64_t)k * pc.node_cap; sj.full_cover = R.reads[b->chains[ch].members[k]].cover; }
+                else { sj.read_off = 0; sj.full_cover = R.reads[c].cover; /* fully_covers[cluster] quirk, src/align.c:1194 */ }
+                b->str_jobs.push_back(sj); b->str_region.push_back((int)ri); b->str_clu.push_back(c); b->str_k.push_back(k);
+            }
+        }
+    }
+    // K2 member rows need the cluster id lists (device -> host, small)
+    {
+        std::vector<std::vector<int>> clu_cache(nC);
+        for (size_t j = 0; j < b->str_jobs.size(); ++j) {
+            const RegionRec &R = b->regs[b->str_region[j]];
+            if (R.branch != 2) continue;
+            const int ch = R.chain[0]; const PoaChain &pc = b->pchains[ch];
+            if (clu_cache[ch].empty()) {
+                clu_cache[ch].resize(2 * (size_t)pc.n_reads);
+                const uint64_t clu_addr = pc.out_off + lcd_align_up((uint64_t)(pc.n_reads + 4) * pc.node_cap, 16);
+                HIPCHK(hipMemcpyAsync(clu_cache[ch].data(), (void *)(uintptr_t)clu_addr, 2 * (size_t)pc.n_reads * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+            }
+            const int member = clu_cache[ch][(size_t)b->str_clu[j] * pc.n_reads + b->str_k[j]];
+            b->str_jobs[j].read_off = pc.out_off + 2ull * pc.node_cap + (uint64_t)member * pc.node_cap;
+        }
+        b->h_poa_out.clear();
+        // stash cluster lists for result assembly
+        b->h_poa_out.resize(0);
+        for (int ch = 0; ch < nC; ++ch) if (!clu_cache[ch].empty()) {
+            // store as bytes: [ch:int][n:int][ids...]
+            int hdr[2] = {ch, (int)clu_cache[ch].size()};
+            const uint8_t *p = (const uint8_t *)hdr; b->h_poa_out.insert(b->h_poa_out.end(), p, p + 8);
+            p = (const uint8_t *)clu_cache[ch].data(); b->h_poa_out.insert(b->h_poa_out.end(), p, p + clu_cache[ch].size() * 4);
+        }
+    }
+    HIPCHK(hipEventRecord(b->ev[3], st));
+    int wret = 0;
+    int rc = run_wfa_stage(st, b->rc_jobs, b->d_wfa_jobs, b->d_wfa_arena, b->d_wfa_out, b->d_wfa_outs, b->rc_outs, sc, &wret);
+    if (rc) return rc;
+    S.n_wfa_jobs += (int)b->rc_jobs.size();
+    for (auto &w : b->rc_outs) S.wfa_offsets += w.offsets;
+    HIPCHK(hipEventRecord(b->ev[4], st));
+    b->str_outs.assign(b->str_jobs.size(), StrOut());
+    if (!b->str_jobs.empty()) {
+        if (b->d_final.ensure(str_tot) || b->d_str_jobs.ensure(b->str_jobs.size() * sizeof(StrJob)) || b->d_str_outs.ensure(b->str_jobs.size() * sizeof(StrOut))) return -11;
+        for (auto &j : b->str_jobs) j.out_off += b->d_final.addr();
+        HIPCHK(hipMemcpyAsync(b->d_str_jobs.p, b->str_jobs.data(), b->str_jobs.size() * sizeof(StrJob), hipMemcpyHostToDevice, st));
+        lcd_launch_strings((const StrJob *)b->d_str_jobs.p, nullptr, (StrOut *)b->d_str_outs.p, (int)b->str_jobs.size(), st);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(b->str_outs.data(), b->d_str_outs.p, b->str_jobs.size() * sizeof(StrOut), hipMemcpyDeviceToHost, st));
+    }
+    b->final_bytes = str_tot;
+    HIPCHK(hipEventRecord(b->ev[5], st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0;
+    hipEventElapsedTime(&ms, b->ev[0], b->ev[1]); S.ms_anchor = ms;
+    hipEventElapsedTime(&ms, b->ev[1], b->ev[2]); S.ms_poa = ms;
+    hipEventElapsedTime(&ms, b->ev[3], b->ev[4]); S.ms_wfa = ms;
+    hipEventElapsedTime(&ms, b->ev[4], b->ev[5]); S.ms_strings = ms;
+    hipEventElapsedTime(&ms, b->ev[0], b->ev[5]); S.ms_total = ms;
+    for (int c = 0; c < nC; ++c) {
+        const PoaChainOut &o = b->couts[c];
+        S.poa_aligned_bases += o.aligned_bases; S.poa_cells += o.cells;
+        // B_poa = q + 5*N_sub + C + (q + N_sub) per aligned read; N_sub ~ final graph size (upper bound per read)
+        S.poa_alg_bytes += 2 * o.aligned_bases + o.cells + 6ull * (uint64_t)o.n_node * (uint64_t)o.n_aligned_reads;
+    }
+    S.ms_host = (now_ms() - t_begin) - S.ms_total;
+    b->ran = true; b->downloaded = false;
+    return 0;
+}
+
+int lcd_batch_download(lcd_batch_t *b) {
+    if (!b->ran) return set_err(-3, "lcd_batch_download before lcd_batch_run");
+    const double t0 = now_ms();
+    hipStream_t st = b->stream;
+    b->h_final.resize(b->final_bytes);
+    if (b->final_bytes) HIPCHK(hipMemcpyAsync(b->h_final.data(), b->d_final.p, b->final_bytes, hipMemcpyDeviceToHost, st));
+    // ref<->cons rows: append after the strings
+    uint64_t extra = 0;
+    std::vector<uint64_t> rc_off(b->rc_jobs.size());
+    for (size_t i = 0; i < b->rc_jobs.size(); ++i) { rc_off[i] = b->final_bytes + extra; extra += lcd_align_up(2ull * (b->rc_jobs[i].plen + b->rc_jobs[i].tlen + 1), 16); }
+    b->h_final.resize(b->final_bytes + extra);
+    for (size_t i = 0; i < b->rc_jobs.size(); ++i)
+        HIPCHK(hipMemcpyAsync(b->h_final.data() + rc_off[i], (void *)(uintptr_t)b->rc_jobs[i].out_off, 2ull * (b->rc_jobs[i].plen + b->rc_jobs[i].tlen + 1), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    // remember where the ref<->cons rows are
+    for (size_t i = 0; i < b->rc_jobs.size(); ++i) b->rc_jobs[i].ws_off = rc_off[i];
+    b->downloaded = true;
+    b->st.ms_download = now_ms() - t0;
+    return 0;
+}
+
+static const std::vector<int> *clu_list(lcd_batch_t *b, int ch, std::vector<int> &tmp) {
+    const uint8_t *p = b->h_poa_out.data(), *e = p + b->h_poa_out.size();
+    while (p < e) {
+        int hdr[2]; memcpy(hdr, p, 8); p += 8;
+        if (hdr[0] == ch) { tmp.resize(hdr[1]); memcpy(tmp.data(), p, (size_t)hdr[1] * 4); return &tmp; }
+        p += (size_t)hdr[1] * 4;
+    }
+    return nullptr;
+}
+
+int lcd_batch_region_result(lcd_batch_t *b, int region, int *clu_n_seqs, int **clu_read_ids, lcd_aln_str_t **aln_strs) {
+    if (!b->downloaded) return set_err(-3, "lcd_batch_region_result before lcd_batch_download");
+    if (region < 0 || region >= (int)b->regs.size()) return set_err(-4, "bad region index");
+    const RegionRec &R = b->regs[region];
+    if (R.branch == 0) return 0;
+    // src/align.c:832-834 / :907-920: clu_read_ids are filled whenever K1/K2 ran, even if the region ends with n_cons = 0
+    std::vector<int> tmp;
+    if (R.branch == 1) {
+        for (int c = 0; c < 2; ++c) {
+            const ChainRec &C = b->chains[R.chain[c]];
+            clu_n_seqs[c] = (int)C.members.size();
+            clu_read_ids[c] = (int *)malloc(C.members.size() * sizeof(int));
+            for (size_t k = 0; k < C.members.size(); ++k) clu_read_ids[c][k] = R.reads[C.members[k]].id;
+        }
+    } else {
+        const ChainRec &C = b->chains[R.chain[0]]; const PoaChainOut &co = b->couts[R.chain[0]];
+        const std::vector<int> *cl = clu_list(b, R.chain[0], tmp);
+        if (co.n_cons == 2) {
+            for (int c = 0; c < 2; ++c) {
+                clu_n_seqs[c] = co.clu_n[c];
+                clu_read_ids[c] = (int *)malloc((co.clu_n[c] > 0 ? co.clu_n[c] : 1) * sizeof(int));
+                for (int k = 0; k < co.clu_n[c]; ++k) clu_read_ids[c][k] = R.reads[C.members[(*cl)[(size_t)c * C.members.size() + k]]].id;
+            }
+        } else {
+            clu_n_seqs[0] = (int)C.members.size();
+            clu_read_ids[0] = (int *)malloc(C.members.size() * sizeof(int));
+            for (size_t k = 0; k < C.members.size(); ++k) clu_read_ids[0][k] = R.reads[C.members[k]].id;
+        }
+    }
+    if (R.n_cons == 0) return 0;
+    for (size_t i = 0; i < b->rc_jobs.size(); ++i) {
+        if (b->rc_region[i] != region) continue;
+        const int c = b->rc_clu[i]; const WfaJob &wj = b->rc_jobs[i]; const WfaOut &wo = b->rc_outs[i];
+        const int maxl = wj.plen + wj.tlen + 1; // wfa_collect_pretty_alignment layout, src/align.c:288-291
+        uint8_t *mem = (uint8_t *)calloc(2 * (size_t)maxl, 1);
+        memcpy(mem, b->h_final.data() + wj.ws_off, (size_t)wo.aln_len);
+        memcpy(mem + maxl, b->h_final.data() + wj.ws_off + maxl, (size_t)wo.aln_len);
+        lcd_aln_str_t &s = aln_strs[c][0];
+        s.target_aln = mem; s.query_aln = mem + maxl; s.aln_len = wo.aln_len;
+        s.target_beg = 0; s.target_end = wo.aln_len - 1; s.query_beg = 0; s.query_end = wo.aln_len - 1;
+    }
+    const uint64_t fbase = b->d_final.addr();
+    for (size_t j = 0; j < b->str_jobs.size(); ++j) {
+        if (b->str_region[j] != region) continue;
+        const int c = b->str_clu[j], k = b->str_k[j]; const StrJob &sj = b->str_jobs[j]; const StrOut &so = b->str_outs[j];
+        const uint8_t *src = b->h_final.data() + (sj.out_off - fbase);
+        lcd_aln_str_t &s = aln_strs[c][2 * k + 1];
+        if (so.shift != 0) { // src/align.c:541-549: re-allocated compact block
+            uint8_t *mem = (uint8_t *)malloc((size_t)so.aln_len * 2 + 1);
+            memcpy(mem, src + so.shift, so.aln_len); memcpy(mem + so.aln_len, src + sj.msa_len + so.shift, so.aln_len);
+            s.target_aln = mem; s.query_aln = mem + so.aln_len;
+        } else {
+            uint8_t *mem = (uint8_t *)malloc((size_t)sj.msa_len * 2 + 1);
+            memcpy(mem, src, so.aln_len > 0 ? so.aln_len : 0); memcpy(mem + sj.msa_len, src + sj.msa_len, so.aln_len > 0 ? so.aln_len : 0);
+            s.target_aln = mem; s.query_aln = mem + sj.msa_len;
+        }
+        s.aln_len = so.aln_len; s.target_beg = so.target_beg; s.target_end = so.target_end; s.query_beg = so.query_beg; s.query_end = so.query_end;
+    }
+    return R.n_cons;
+}
+
+int lcd_batch_region_sorted_ids(lcd_batch_t *b, int region, int *out) {
+    if (region < 0 || region >= (int)b->regs.size()) return set_err(-4, "bad region index");
+    const RegionRec &R = b->regs[region];
+    for (size_t i = 0; i < R.reads.size(); ++i) out[i] = R.reads[i].id;
+    return (int)R.reads.size();
+}
+
+int lcd_batch_get_stats(lcd_batch_t *b, lcd_batch_stats_t *st) { *st = b->st; return 0; }
+
+uint64_t lcd_batch_digest(lcd_batch_t *b) {
+    if (!b->downloaded) return 0;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) { const uint8_t *q = (const uint8_t *)p; for (size_t i = 0; i < n; ++i) { h ^= q[i]; h *= 1099511628211ull; } };
+    for (size_t ri = 0; ri < b->regs.size(); ++ri) {
+        const RegionRec &R = b->regs[ri];
+        std::vector<int> cn(2, 0); std::vector<int *> ids(2, nullptr);
+        std::vector<lcd_aln_str_t> a0(1 + 2 * (size_t)std::max(R.n_reads, 0)), a1(a0.size());
+        memset(a0.data(), 0, a0.size() * sizeof(lcd_aln_str_t)); memset(a1.data(), 0, a1.size() * sizeof(lcd_aln_str_t));
+        lcd_aln_str_t *as[2] = {a0.data(), a1.data()};
+        int nc = lcd_batch_region_result(b, (int)ri, cn.data(), ids.data(), as);
+        mix(&nc, 4);
+        for (int c = 0; c < 2; ++c) {
+            if (nc > 0 && c < nc) { mix(&cn[c], 4); mix(ids[c], (size_t)cn[c] * 4); }
+            free(ids[c]);
+            for (size_t j = 0; j < a0.size(); ++j) {
+                lcd_aln_str_t &s = as[c][j];
+                if (!s.target_aln) continue;
+                if (nc > 0) { mix(&s.aln_len, 4); mix(&s.target_beg, 16); mix(s.target_aln, s.aln_len > 0 ? s.aln_len : 0); mix(s.query_aln, s.aln_len > 0 ? s.aln_len : 0); }
+                free(s.target_aln);
+            }
+        }
+    }
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kernel-level batches
+int lcd_edlib_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *q_off, const int *qlen, const uint64_t *t_off,
+                    const int *tlen, int *dist, int *xgaps, int *n_eq, int *n_xid) {
+    if (ensure_init()) return -1;
+    hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    DevBuf d_pool, d_jobs, d_arena, d_outs;
+    if (d_pool.ensure(pool_len + 64)) return -11;
+    HIPCHK(hipMemcpyAsync(d_pool.p, pool, pool_len, hipMemcpyHostToDevice, st));
+    std::vector<EdJob> jobs(n);
+    for (int i = 0; i < n; ++i) { jobs[i].q_off = d_pool.addr() + q_off[i]; jobs[i].t_off = d_pool.addr() + t_off[i]; jobs[i].qlen = qlen[i]; jobs[i].tlen = tlen[i]; }
+    std::vector<EdOut> outs;
+    int rc = run_edlib_stage(st, jobs, d_jobs, d_arena, d_outs, outs);
+    if (rc) { hipStreamDestroy(st); return rc; }
+    HIPCHK(hipStreamSynchronize(st));
+    hipStreamDestroy(st);
+    for (int i = 0; i < n; ++i) {
+        if (outs[i].status != LCD_OK) return set_err(-20, "edlib kernel status " + std::to_string(outs[i].status));
+        if (dist) dist[i] = outs[i].dist;
+        if (xgaps) xgaps[i] = outs[i].xgaps;
+        if (n_eq) n_eq[i] = outs[i].n_eq;
+        if (n_xid) n_xid[i] = outs[i].n_xid;
+    }
+    return 0;
+}
+
+int lcd_wfa_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *p_off, const int *plen, const uint64_t *t_off, const int *tlen,
+                  const int *gap_aln, int b, int q, int e, int q2, int e2, int want, int *score, uint32_t *cigars, int cigar_stride, int *n_cigar,
+                  uint8_t *rows, int row_stride, int *aln_len) {
+    if (ensure_init()) return -1;
+    hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    DevBuf d_pool, d_jobs, d_arena, d_out, d_outs;
+    if (d_pool.ensure(pool_len + 64)) return -11;
+    HIPCHK(hipMemcpyAsync(d_pool.p, pool, pool_len, hipMemcpyHostToDevice, st));
+    std::vector<WfaJob> jobs(n);
+    for (int i = 0; i < n; ++i) {
+        WfaJob &j = jobs[i];
+        j.p_off = d_pool.addr() + p_off[i]; j.t_off = d_pool.addr() + t_off[i]; j.plen = plen[i]; j.tlen = tlen[i]; j.gap_aln = gap_aln[i]; j.want = want;
+        j.s_cap = wfa_default_scap(plen[i], tlen[i]); j.ws_off = j.ws_bytes = j.out_off = 0;
+    }
+    LcdScoring sc; sc.match = 0; sc.mismatch = b; sc.o1 = q; sc.e1 = e; sc.o2 = q2; sc.e2 = e2;
+    std::vector<WfaOut> outs;
+    int rc = run_wfa_stage(st, jobs, d_jobs, d_arena, d_out, d_outs, outs, sc, nullptr);
+    if (rc) { hipStreamDestroy(st); return rc; }
+    for (int i = 0; i < n; ++i) {
+        const uint64_t maxl = (uint64_t)plen[i] + tlen[i] + 1;
+        uint64_t o = 0;
+        if (score) score[i] = outs[i].score;
+        if (want & 1) {
+            if (n_cigar) n_cigar[i] = outs[i].n_cigar;
+            if (outs[i].n_cigar > cigar_stride) { hipStreamDestroy(st); return set_err(-5, "cigar_stride too small"); }
+            if (outs[i].n_cigar) HIPCHK(hipMemcpyAsync(cigars + (size_t)i * cigar_stride, (void *)(uintptr_t)jobs[i].out_off, (size_t)outs[i].n_cigar * 4, hipMemcpyDeviceToHost, st));
+            o = lcd_align_up(maxl * 4, 16);
+        }
+        if (want & 2) {
+            if (aln_len) aln_len[i] = outs[i].aln_len;
+            if (outs[i].aln_len > row_stride) { hipStreamDestroy(st); return set_err(-5, "row_stride too small"); }
+            if (outs[i].aln_len) {
+                HIPCHK(hipMemcpyAsync(rows + (size_t)i * 2 * row_stride, (void *)(uintptr_t)(jobs[i].out_off + o), outs[i].aln_len, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipMemcpyAsync(rows + (size_t)i * 2 * row_stride + row_stride, (void *)(uintptr_t)(jobs[i].out_off + o + maxl), outs[i].aln_len, hipMemcpyDeviceToHost, st));
+            }
+        }
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    hipStreamDestroy(st);
+    return 0;
+}
+
+int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int *chain_read0, const int *chain_n_reads, int n_reads_total,
+                  const uint64_t *seq_off, const int *len, const int *skip, const int *anchors, const uint8_t *pool, uint64_t pool_len, int *status,
+                  int *n_cons, int *cons_len, int *msa_len, int *clu_n, uint8_t *cons, int cons_stride, uint8_t *msa, int msa_stride, int max_reads,
+                  int *clu_ids) {
+    if (ensure_init()) return -1;
+    hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    DevBuf d_pool, d_chains, d_reads, d_arena, d_out, d_outs;
+    if (d_pool.ensure(pool_len + 64)) return -11;
+    HIPCHK(hipMemcpyAsync(d_pool.p, pool, pool_len, hipMemcpyHostToDevice, st));
+    std::vector<PoaRead> preads(n_reads_total);
+    for (int i = 0; i < n_reads_total; ++i) {
+        PoaRead &r = preads[i]; r.seq_off = d_pool.addr() + seq_off[i]; r.len = len[i]; r.skip = skip ? skip[i] : 0;
+        r.ref_beg = anchors[4 * i]; r.ref_end = anchors[4 * i + 1]; r.read_beg = anchors[4 * i + 2]; r.read_end = anchors[4 * i + 3];
+    }
+    std::vector<ChainRec> crec(n_chains); std::vector<PoaChain> pch(n_chains); std::vector<uint64_t> out_rel(n_chains);
+    uint64_t out_tot = 0;
+    for (int c = 0; c < n_chains; ++c) {
+        crec[c].mode = mode[c]; crec[c].read0 = chain_read0[c]; crec[c].members.resize(chain_n_reads[c]);
+        chain_caps(*opt, crec[c], preads, 1, pch[c]);
+        out_rel[c] = out_tot; out_tot += lcd_align_up(poa_out_bytes(pch[c].node_cap, pch[c].n_reads), 256);
+    }
+    if (d_out.ensure(out_tot) || d_reads.ensure(preads.size() * sizeof(PoaRead) + 16) || d_chains.ensure(n_chains * sizeof(PoaChain)) || d_outs.ensure(n_chains * sizeof(PoaChainOut))) return -11;
+    HIPCHK(hipMemcpyAsync(d_reads.p, preads.data(), preads.size() * sizeof(PoaRead), hipMemcpyHostToDevice, st));
+    std::vector<PoaChainOut> couts(n_chains);
+    std::vector<int> which(n_chains);
+    for (int c = 0; c < n_chains; ++c) which[c] = c;
+    int scale = 1;
+    const LcdScoring sc = scoring_of(*opt);
+    for (int round = 0; round < 12 && !which.empty(); ++round) {
+        uint64_t tot = 0; std::vector<PoaChain> sub(which.size());
+        for (size_t i = 0; i < which.size(); ++i) {
+            PoaChain &pc = pch[which[i]];
+            if (round) chain_caps(*opt, crec[which[i]], preads, scale, pc);
+            pc.out_off = d_out.addr() + out_rel[which[i]];
+            PoaLayout L = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads);
+            pc.ws_off = tot; tot += L.total;
+        }
+        if (d_arena.ensure(tot)) return -11;
+        for (size_t i = 0; i < which.size(); ++i) { pch[which[i]].ws_off += d_arena.addr(); sub[i] = pch[which[i]]; }
+        HIPCHK(hipMemcpyAsync(d_chains.p, sub.data(), sub.size() * sizeof(PoaChain), hipMemcpyHostToDevice, st));
+        lcd_launch_poa((const PoaChain *)d_chains.p, (const PoaRead *)d_reads.p, nullptr, nullptr, nullptr, (PoaChainOut *)d_outs.p, sc, (int)sub.size(), st);
+        HIPCHK(hipGetLastError());
+        std::vector<PoaChainOut> tmp(sub.size());
+        HIPCHK(hipMemcpyAsync(tmp.data(), d_outs.p, sub.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        std::vector<int> again;
+        for (size_t i = 0; i < which.size(); ++i) { couts[which[i]] = tmp[i]; if (tmp[i].status == LCD_ERR_CELLS) again.push_back(which[i]); }
+        if (!again.empty()) scale *= 2;
+        which.swap(again);
+    }
+    for (int c = 0; c < n_chains; ++c) {
+        const PoaChainOut &o = couts[c]; const PoaChain &pc = pch[c];
+        status[c] = o.status; n_cons[c] = o.n_cons; cons_len[2 * c] = o.cons_len[0]; cons_len[2 * c + 1] = o.cons_len[1]; msa_len[c] = o.msa_len;
+        clu_n[2 * c] = o.clu_n[0]; clu_n[2 * c + 1] = o.clu_n[1];
+        if (o.status != LCD_OK) continue;
+        if (o.msa_len > msa_stride || o.cons_len[0] > cons_stride || o.cons_len[1] > cons_stride || pc.n_reads > max_reads) { hipStreamDestroy(st); return set_err(-5, "output strides too small"); }
+        for (int k = 0; k < o.n_cons; ++k)
+            if (o.cons_len[k]) HIPCHK(hipMemcpyAsync(cons + ((size_t)2 * c + k) * cons_stride, (void *)(uintptr_t)(pc.out_off + (uint64_t)k * pc.node_cap), o.cons_len[k], hipMemcpyDeviceToHost, st));
+        for (int r = 0; r < pc.n_reads + o.n_cons; ++r)
+            if (o.msa_len) HIPCHK(hipMemcpyAsync(msa + ((size_t)c * (max_reads + 2) + r) * msa_stride, (void *)(uintptr_t)(pc.out_off + 2ull * pc.node_cap + (uint64_t)r * pc.node_cap), o.msa_len, hipMemcpyDeviceToHost, st));
+        const uint64_t clu_addr = pc.out_off + lcd_align_up((uint64_t)(pc.n_reads + 4) * pc.node_cap, 16);
+        for (int k = 0; k < o.n_cons; ++k)
+            if (o.clu_n[k]) HIPCHK(hipMemcpyAsync(clu_ids + ((size_t)2 * c + k) * max_reads, (void *)(uintptr_t)(clu_addr + (uint64_t)k * pc.n_reads * 4), (size_t)o.clu_n[k] * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    hipStreamDestroy(st);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-call mirrors of src/align.h
+int lcd_wfa_end2end_aln(uint8_t *pattern, int plen, uint8_t *text, int tlen, int gap_aln, int b, int q, int e, int q2, int e2, int heuristic,
+                        int affine_gap, uint32_t **cigar_buf, int *cigar_length, uint8_t **pattern_alg, uint8_t **text_alg, int *alg_length) {
+    if (heuristic != 0 || affine_gap != 1) return set_err(-2, "only heuristic=NONE, affine_gap=2P (the germline-live WFA configuration) is implemented");
+    std::vector<uint8_t> pool((size_t)plen + tlen + 32, 4);
+    if (plen) memcpy(pool.data(), pattern, plen);
+    const uint64_t toff = lcd_align_up(plen, 16);
+    pool.resize(toff + tlen + 16, 4);
+    if (tlen) memcpy(pool.data() + toff, text, tlen);
+    const uint64_t po = 0; const int want = ((cigar_buf && cigar_length) ? 1 : 0) | ((pattern_alg && text_alg) ? 2 : 0);
+    const int maxl = plen + tlen + 1;
+    std::vector<uint32_t> cig(maxl); std::vector<uint8_t> rows(2 * (size_t)maxl);
+    int score = 0, nc = 0, al = 0;
+    int rc = lcd_wfa_batch(1, pool.data(), pool.size(), &po, &plen, &toff, &tlen, &gap_aln, b, q, e, q2, e2, want, &score, cig.data(), maxl, &nc, rows.data(), maxl, &al);
+    if (rc) return rc;
+    if (want & 1) { *cigar_buf = (uint32_t *)malloc((nc > 0 ? nc : 1) * sizeof(uint32_t)); memcpy(*cigar_buf, cig.data(), (size_t)nc * 4); *cigar_length = nc; }
+    if (want & 2) {
+        uint8_t *mem = (uint8_t *)calloc(2 * (size_t)maxl, 1); // src/align.c:288-291
+        memcpy(mem, rows.data(), al); memcpy(mem + maxl, rows.data() + maxl, al);
+        *pattern_alg = mem; *text_alg = mem + maxl; *alg_length = al;
+    }
+    return 0;
+}
+
+static int ed1(uint8_t *target, int tlen, uint8_t *query, int qlen, int *dist, int *xg, int *neq, int *nxid) {
+    std::vector<uint8_t> pool((size_t)lcd_align_up(qlen, 16) + tlen + 32, 4);
+    if (qlen) memcpy(pool.data(), query, qlen);
+    const uint64_t qo = 0, to = lcd_align_up(qlen, 16);
+    if (tlen) memcpy(pool.data() + to, target, tlen);
+    return lcd_edlib_batch(1, pool.data(), pool.size(), &qo, &qlen, &to, &tlen, dist, xg, neq, nxid);
+}
+int lcd_edlib_end2end_aln(uint8_t *target, int tlen, uint8_t *query, int qlen, int *n_eq, int *n_xid) {
+    int d, x, a, c; if (ed1(target, tlen, query, qlen, &d, &x, &a, &c)) return -1;
+    if (n_eq && n_xid) { *n_eq = a; *n_xid = c; }
+    return d;
+}
+int lcd_edlib_xgaps(uint8_t *target, int tlen, uint8_t *query, int qlen) { int d, x, a, c; if (ed1(target, tlen, query, qlen, &d, &x, &a, &c)) return -1; return x; }
+int lcd_edlib_edit_distance(uint8_t *target, int tlen, uint8_t *query, int qlen) { int d, x, a, c; if (ed1(target, tlen, query, qlen, &d, &x, &a, &c)) return -1; return d; }
+
+int lcd_collect_noisy_reg_aln_strs(const lcd_opt_t *opt, const lcd_read_view_t *chunk_reads, int64_t noisy_reg_beg, int64_t noisy_reg_end, int noisy_reg_i,
+                                   int n, int *noisy_reads, const uint8_t *ref_seq, int ref_seq_len, int *clu_n_seqs, int **clu_read_ids, lcd_aln_str_t **aln_strs) {
+    (void)noisy_reg_i;
+    if (n <= 0) return 0;
+    lcd_batch_t *b = lcd_batch_create(opt);
+    if (!b) return -1;
+    int rc = lcd_batch_add_region_from_chunk(b, chunk_reads, noisy_reg_beg, noisy_reg_end, n, noisy_reads, ref_seq, ref_seq_len);
+    if (rc < 0) { lcd_batch_destroy(b); return rc; }
+    if ((rc = lcd_batch_upload(b)) || (rc = lcd_batch_run(b)) || (rc = lcd_batch_download(b))) { lcd_batch_destroy(b); return rc; }
+    lcd_batch_region_sorted_ids(b, 0, noisy_reads);
+    int nc = lcd_batch_region_result(b, 0, clu_n_seqs, clu_read_ids, aln_strs);
+    lcd_batch_destroy(b);
+    return nc;
+}
+
+} // extern "C"

@@ -1,0 +1,149 @@
+// lcd_types.h -- POD descriptors shared by the host orchestration (lcd_host.cpp) and the gfx950 kernels.
+// Names follow the reference's domain (regions, reads, chains = one abPOA graph build, cons, msa).
+#pragma once
+#include <stdint.h>
+
+#ifdef __HIPCC__
+#define LCD_HD __host__ __device__
+#else
+#define LCD_HD
+#endif
+
+#define LCD_NEG (-(1 << 29))
+#define LCD_GAP 5
+
+// cover flags, src/align.h:6-18
+#define LCD_RIGHT_GAP 0x1
+#define LCD_LEFT_GAP 0x2
+#define LCD_RIGHT_COVER 0x4
+#define LCD_LEFT_COVER 0x8
+#define LCD_IS_BOTH_COVER(c) (((c)&LCD_LEFT_COVER) && ((c)&LCD_RIGHT_COVER))
+#define LCD_IS_LEFT_COVER(c) (((c)&LCD_LEFT_COVER) && ((c)&LCD_RIGHT_COVER) == 0)
+#define LCD_IS_LEFT_GAP(c) ((c)&LCD_LEFT_GAP)
+#define LCD_IS_RIGHT_COVER(c) (((c)&LCD_LEFT_COVER) == 0 && ((c)&LCD_RIGHT_COVER))
+#define LCD_IS_RIGHT_GAP(c) ((c)&LCD_RIGHT_GAP)
+#define LCD_IS_NOT_COVER(c) (((c)&LCD_LEFT_COVER) == 0 && ((c)&LCD_RIGHT_COVER) == 0)
+
+// scoring, src/align.h:21-26 via call_var_opt_t
+struct LcdScoring {
+    int match, mismatch, o1, e1, o2, e2;
+};
+
+// status codes written by kernels (0 = ok). Anything else makes the host fail loudly or retry with a bigger arena.
+enum { LCD_OK = 0, LCD_ERR_CELLS = 1, LCD_ERR_NODES = 2, LCD_ERR_EDGES = 3, LCD_ERR_BACKTRACK = 4, LCD_ERR_WF = 5, LCD_ERR_TOPO = 6 };
+
+// ---------------- POA chain (one graph build = one abpoa_t life, src/align.c:762 / :872) ----------------
+struct PoaRead {
+    uint64_t seq_off;  // into the device pool (1 B/base codes 0-4)
+    int len;
+    int skip;          // 1: rejected by the anchor step (src/align.c:796 `continue`)
+    int ref_beg, ref_end;   // 1-based anchors on the backbone read (collect_partial_aln_beg_end); beg_id=ref_beg+1
+    int read_beg, read_end; // 1-based anchors on this read
+};
+
+struct PoaChain {
+    int n_reads;
+    int read0;        // first PoaRead of this chain
+    int mode;         // 0: K1 sub-graph incremental, wb=10 wf=0.01, 1 consensus; 1: K2 unbanded, <=2 consensus
+    int node_cap, edge_cap, rid_words, max_len;
+    uint32_t min_w;   // (int)(n*min_af) clipped below at 2 (cluster threshold)
+    uint64_t cell_cap;
+    uint64_t ws_off;  // byte offset of this chain's arena
+    uint64_t out_off; // byte offset in the chain-output pool: cons[2][node_cap] + msa[(n_reads+2)][node_cap] + clu[2][n_reads] ints
+};
+
+struct PoaChainOut {
+    int status;
+    int n_cons;
+    int cons_len[2];
+    int msa_len;
+    int clu_n[2];
+    int n_node, n_edge;
+    int n_aligned_reads;
+    unsigned long long cells;          // DP cells computed (K1/K2 algorithmic unit)
+    unsigned long long aligned_bases;  // POA-aligned bases (BASELINE metric)
+};
+
+// arena layout (byte offsets relative to ws_off); identical on host and device
+struct PoaLayout {
+    uint64_t H, E1, E2;                                  // int32[cell_cap]
+    uint64_t rbeg, rend, roff;                           // int32/int32/uint32 [node_cap], by topological index
+    uint64_t mpl, mpr;                                   // int32[node_cap], by node id
+    uint64_t idx2node, node2idx, remain, deg, queue;     // int32[node_cap]
+    uint64_t n_out_head, n_out_tail, n_in_head, n_in_tail, n_nin, n_aligned;  // int32[node_cap]
+    uint64_t e_from, e_to, e_w, e_next_out, e_next_in;   // int32[edge_cap]
+    uint64_t rid;                                        // uint64[edge_cap*rid_words]
+    uint64_t cig_node, cig_qpos;                         // int32[max_len+1]
+    uint64_t n_base, imap;                               // uint8[node_cap]
+    uint64_t het, clu, nclu, prof;                       // int32[node_cap], int32[n_reads] x2, uint8[2*node_cap]
+    uint64_t total;
+};
+
+static inline LCD_HD uint64_t lcd_align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+static inline LCD_HD PoaLayout poa_layout(int node_cap, int edge_cap, int rid_words, int max_len, uint64_t cell_cap, int n_reads) {
+    PoaLayout L;
+    uint64_t o = 0;
+#define LCD_TAKE(field, bytes) do { L.field = o; o = lcd_align_up(o + (uint64_t)(bytes), 16); } while (0)
+    LCD_TAKE(H, cell_cap * 4); LCD_TAKE(E1, cell_cap * 4); LCD_TAKE(E2, cell_cap * 4);
+    LCD_TAKE(rbeg, (uint64_t)node_cap * 4); LCD_TAKE(rend, (uint64_t)node_cap * 4); LCD_TAKE(roff, (uint64_t)node_cap * 4);
+    LCD_TAKE(mpl, (uint64_t)node_cap * 4); LCD_TAKE(mpr, (uint64_t)node_cap * 4);
+    LCD_TAKE(idx2node, (uint64_t)node_cap * 4); LCD_TAKE(node2idx, (uint64_t)node_cap * 4); LCD_TAKE(remain, (uint64_t)node_cap * 4);
+    LCD_TAKE(deg, (uint64_t)node_cap * 4); LCD_TAKE(queue, (uint64_t)node_cap * 4);
+    LCD_TAKE(n_out_head, (uint64_t)node_cap * 4); LCD_TAKE(n_out_tail, (uint64_t)node_cap * 4);
+    LCD_TAKE(n_in_head, (uint64_t)node_cap * 4); LCD_TAKE(n_in_tail, (uint64_t)node_cap * 4);
+    LCD_TAKE(n_nin, (uint64_t)node_cap * 4); LCD_TAKE(n_aligned, (uint64_t)node_cap * 4);
+    LCD_TAKE(e_from, (uint64_t)edge_cap * 4); LCD_TAKE(e_to, (uint64_t)edge_cap * 4); LCD_TAKE(e_w, (uint64_t)edge_cap * 4);
+    LCD_TAKE(e_next_out, (uint64_t)edge_cap * 4); LCD_TAKE(e_next_in, (uint64_t)edge_cap * 4);
+    LCD_TAKE(rid, (uint64_t)edge_cap * rid_words * 8);
+    LCD_TAKE(cig_node, (uint64_t)(max_len + 1) * 4); LCD_TAKE(cig_qpos, (uint64_t)(max_len + 1) * 4);
+    LCD_TAKE(n_base, (uint64_t)node_cap); LCD_TAKE(imap, (uint64_t)node_cap);
+    LCD_TAKE(het, (uint64_t)node_cap * 4); LCD_TAKE(clu, (uint64_t)n_reads * 4); LCD_TAKE(nclu, (uint64_t)n_reads * 4);
+    LCD_TAKE(prof, (uint64_t)node_cap * 2);
+#undef LCD_TAKE
+    L.total = lcd_align_up(o, 256);
+    return L;
+}
+
+// chain-output pool layout: cons[2][node_cap] u8, msa[(n_reads+2)][node_cap] u8, clu_ids[2][n_reads] i32
+static inline LCD_HD uint64_t poa_out_bytes(int node_cap, int n_reads) {
+    return lcd_align_up((uint64_t)(n_reads + 4) * node_cap, 16) + lcd_align_up((uint64_t)2 * n_reads * 4, 16);
+}
+
+// ---------------- WFA job (K3, src/align.c:374-460, heuristic none, affine-2p) ----------------
+struct WfaJob {
+    uint64_t p_off, t_off; // pattern / text byte offsets in the device pool (inputs, or a chain's consensus)
+    int plen, tlen;
+    int gap_aln;           // 1 = left (reverse both, reverse outputs), 2 = right
+    int want;              // bit0: cigar, bit1: aligned strings
+    int s_cap;             // max score the arena can hold
+    uint64_t ws_off;       // wavefront arena (byte offset)
+    uint64_t ws_bytes;
+    uint64_t out_off;      // output: cigar uint32[plen+tlen+1] | or rows uint8[2*(plen+tlen+1)]
+};
+struct WfaOut {
+    int status, score, n_cigar, aln_len;
+    unsigned long long offsets; // wavefront offsets computed (K3 algorithmic unit)
+};
+
+// ---------------- edlib NW job (K4, src/align.c:222-232) ----------------
+struct EdJob {
+    uint64_t q_off, t_off;
+    int qlen, tlen;
+    uint64_t ws_off, ws_bytes;
+};
+struct EdOut {
+    int status, dist, xgaps, n_eq, n_xid;
+    unsigned long long blocks; // Myers block-columns computed
+};
+
+// ---------------- MSA row -> cons/read pairwise string (src/align.c:1029-1054 + wfa_trim_aln_str :496-562) ----------------
+struct StrJob {
+    uint64_t cons_off, read_off; // MSA rows in the device pool
+    int msa_len, full_cover;
+    uint64_t out_off;            // target row at out_off, query row at out_off + msa_len (src/align.c:1032-1033)
+};
+struct StrOut {
+    int aln_len, target_beg, target_end, query_beg, query_end;
+    int shift;                   // right-cover trim: rows start at +shift (the reference re-allocates, :541-549)
+};

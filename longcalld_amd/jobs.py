@@ -1,0 +1,108 @@
+"""Synthetic region-job generator in the shape of BASELINE.json's configs.
+
+A *region job* is what collect_noisy_reg_aln_strs sees after collect_noisy_read_info (src/align.c:1377):
+the reference bytes of the noisy region (with 10-bp flanks) and, per read, its slice of bases, cover flag,
+haplotype tag and phase set.  Generated directly (bypassing BAM) from a seeded diploid truth so the CPU
+oracle and the GPU consume identical bytes.
+"""
+import numpy as np
+
+BOTH, LEFT, RIGHT = 12, 8, 4
+
+HIFI = dict(name="hifi", err=0.001, hp_frac=0.7, depth=30, median_len=500.0, sigma=0.75, min_len=67, max_len=3995,
+            partial_frac=0.03, untagged_frac=0.12, no_ps_frac=0.15, sv_frac=0.05)
+ONT = dict(name="ont", err=0.05, hp_frac=0.5, depth=30, median_len=500.0, sigma=0.75, min_len=67, max_len=3995,
+           partial_frac=0.04, untagged_frac=0.2, no_ps_frac=0.2, sv_frac=0.05)
+
+
+def _mutate(rng, seq, err, hp_frac):
+    n = len(seq)
+    k = rng.binomial(n, err) if n else 0
+    if k == 0:
+        return seq.copy()
+    pos = np.sort(rng.choice(n, size=min(k, n), replace=False))
+    out, last = [], 0
+    for p in pos:
+        out.append(seq[last:p])
+        x = rng.random()
+        if x < hp_frac:  # homopolymer-style indel: drop or duplicate the base
+            if rng.random() < 0.5:
+                pass
+            else:
+                out.append(seq[p:p + 1]); out.append(seq[p:p + 1])
+        else:
+            y = rng.random()
+            if y < 1 / 3:
+                out.append(np.array([(seq[p] + 1 + rng.integers(0, 3)) % 4], np.uint8))
+            elif y < 2 / 3:
+                out.append(seq[p:p + 1]); out.append(rng.integers(0, 4, 1).astype(np.uint8))
+        last = p + 1
+    out.append(seq[last:])
+    return np.concatenate(out).astype(np.uint8)
+
+
+def _make_hap(rng, ref, flank, want_var, sv_frac):
+    """one haplotype of the region: ref with 0-3 variants inside the flanks"""
+    if not want_var:
+        return ref.copy()
+    L = len(ref)
+    pieces, last = [], 0
+    nvar = 1 + rng.integers(0, 3)
+    pos = np.sort(rng.integers(flank + 2, max(flank + 3, L - flank - 2), nvar))
+    for p in pos:
+        if p <= last:
+            continue
+        pieces.append(ref[last:p])
+        x = rng.random()
+        if x < 0.35:
+            pieces.append(np.array([(ref[p] + 1 + rng.integers(0, 3)) % 4], np.uint8)); last = p + 1   # SNP
+        elif x < 0.65:
+            ins = int(rng.integers(6, 30)) if rng.random() > sv_frac else int(rng.integers(30, 120))
+            pieces.append(rng.integers(0, 4, ins).astype(np.uint8)); last = p                                # insertion
+        else:
+            dl = int(rng.integers(6, 30)) if rng.random() > sv_frac else int(rng.integers(30, 120))
+            last = min(p + dl, L - flank - 1)                                                               # deletion
+    pieces.append(ref[last:])
+    return np.concatenate(pieces).astype(np.uint8)
+
+
+def make_region(rng, shape=HIFI, length=None, n_reads=None, flank=10):
+    L = int(length) if length else int(np.clip(np.exp(rng.normal(np.log(shape["median_len"]), shape["sigma"])), shape["min_len"], shape["max_len"]))
+    ref = rng.integers(0, 4, L).astype(np.uint8)
+    if rng.random() < 0.3 and L > 60:  # tandem-repeat / homopolymer block
+        unit = rng.integers(0, 4, int(rng.integers(1, 5))).astype(np.uint8)
+        rl = int(rng.integers(8, min(40, L - 2 * flank - 4)))
+        s = int(rng.integers(flank + 1, L - flank - rl))
+        ref[s:s + rl] = np.resize(unit, rl)
+    hap_seq = [_make_hap(rng, ref, flank, True, shape["sv_frac"]), _make_hap(rng, ref, flank, rng.random() < 0.5, shape["sv_frac"])]
+    n = int(n_reads) if n_reads else int(np.clip(rng.poisson(shape["depth"]), 5, 60))
+    no_ps = rng.random() < shape["no_ps_frac"]
+    ps = int(rng.integers(1000, 10_000_000))
+    seqs, covers, haps, pss, quals = [], [], [], [], []
+    for i in range(n):
+        h = int(rng.integers(0, 2))
+        s = _mutate(rng, hap_seq[h], shape["err"], shape["hp_frac"])
+        cover = BOTH
+        if rng.random() < shape["partial_frac"] and len(s) > 40:
+            cut = int(rng.integers(20, len(s) - 10))
+            if rng.random() < 0.5:
+                s, cover = s[:cut], LEFT
+            else:
+                s, cover = s[cut:], RIGHT
+        tagged = (not no_ps) and rng.random() > shape["untagged_frac"]
+        seqs.append(s); covers.append(cover)
+        haps.append(h + 1 if tagged else 0)
+        pss.append(ps if tagged else -1)
+        quals.append(np.full(len(s), 30, np.uint8))
+    return dict(reg_len=L, read_ids=np.arange(n, dtype=np.int32) + 100, seqs=seqs, quals=quals, covers=np.array(covers, np.int32),
+                haps=np.array(haps, np.int32), phase_sets=np.array(pss, np.int64), ref=ref)
+
+
+def make_regions(seed, n_regions, shape=HIFI):
+    rng = np.random.default_rng(seed)
+    return [make_region(rng, shape) for _ in range(n_regions)]
+
+
+def regions_for_ref_mb(ref_mb):
+    """~1 250 regions per 10 Mb of 30x HiFi"""
+    return int(round(125 * ref_mb))

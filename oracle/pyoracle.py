@@ -1,0 +1,247 @@
+"""ctypes binding of the CPU oracle (oracle/liblcd_oracle.so) and the reference's edlib (oracle/_ref).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing under longcalld_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+u8p, i32p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int), C.POINTER(C.c_uint32)
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+class Opt(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("match", "mismatch", "gap_open1", "gap_ext1", "gap_open2", "gap_ext2", "gap_aln")] + [
+        ("min_af", C.c_double), ("min_dp", C.c_int), ("partial_aln_ratio", C.c_double)] + [
+        (n, C.c_int) for n in ("min_noisy_reg_size_to_sample_reads", "max_noisy_reg_len", "noisy_reg_flank_len",
+                               "min_hap_full_reads", "min_hap_reads", "collect_ref_read_aln_str", "is_ont")]
+
+
+class PoaRes(C.Structure):
+    _fields_ = [("n_cons", C.c_int), ("cons_len", C.c_int * 2), ("cons_seq", u8p * 2), ("clu_n_seq", C.c_int * 2), ("clu_read_ids", i32p * 2),
+                ("n_seq", C.c_int), ("msa_len", C.c_int), ("msa", C.POINTER(u8p))]
+
+
+class AlnStr(C.Structure):
+    _fields_ = [("target_aln", u8p), ("query_aln", u8p), ("aln_len", C.c_int), ("target_beg", C.c_int), ("target_end", C.c_int),
+                ("query_beg", C.c_int), ("query_end", C.c_int)]
+
+
+class RegionReads(C.Structure):
+    _fields_ = [("n_reads", C.c_int), ("read_ids", i32p), ("lens", i32p), ("seqs", C.POINTER(u8p)), ("quals", C.POINTER(u8p)),
+                ("fully_covers", i32p), ("haps", i32p), ("phase_sets", C.POINTER(C.c_int64))]
+
+
+_lib = None
+_ref = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liblcd_oracle.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        L = _lib
+        L.lcdo_edlib_nw.argtypes = [u8p, C.c_int, u8p, C.c_int, C.POINTER(u8p), i32p]
+        L.lcdo_edlib_xgaps.argtypes = [u8p, C.c_int, u8p, C.c_int]
+        L.lcdo_edlib_end2end_aln.argtypes = [u8p, C.c_int, u8p, C.c_int, i32p, i32p]
+        L.lcdo_wfa_end2end_aln.argtypes = [u8p, C.c_int, u8p, C.c_int] + [C.c_int] * 6 + [C.POINTER(u32p), i32p, C.POINTER(u8p), C.POINTER(u8p), i32p, i32p]
+        L.lcdo_gotoh2p_score.argtypes = [u8p, C.c_int, u8p, C.c_int] + [C.c_int] * 5
+        L.lcdo_cigar_score2p.argtypes = [u32p, C.c_int, u8p, C.c_int, u8p, C.c_int] + [C.c_int] * 5
+        L.lcdo_poa_partial_aln_msa_cons.argtypes = [C.POINTER(Opt), C.c_int, C.c_int, C.POINTER(u8p), i32p, i32p, C.POINTER(PoaRes)]
+        L.lcdo_poa_aln_msa_cons.argtypes = [C.POINTER(Opt), C.c_int, C.POINTER(u8p), i32p, C.c_int, C.POINTER(PoaRes)]
+        L.lcdo_collect_partial_aln_beg_end.argtypes = [C.POINTER(Opt), C.c_int, u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int, i32p, i32p, i32p, i32p]
+        L.lcdo_collect_noisy_reg_aln_strs.argtypes = [C.POINTER(Opt), C.c_int64, C.POINTER(RegionReads), u8p, C.c_int, i32p, C.POINTER(i32p),
+                                                      C.POINTER(C.POINTER(AlnStr))]
+    return _lib
+
+
+def ref_edlib():
+    """the reference's own vendored edlib, compiled by oracle/Makefile into oracle/_ref (None if not built)"""
+    global _ref
+    if _ref is None:
+        p = os.path.join(_HERE, "_ref", "libedlib_ref.so")
+        if not os.path.exists(p):
+            return None
+        _ref = C.CDLL(p)
+        _ref.ref_edlib_nw_path.argtypes = [u8p, C.c_int, u8p, C.c_int, u8p, C.c_int, i32p]
+        _ref.ref_edlib_distance.argtypes = [u8p, C.c_int, u8p, C.c_int]
+    return _ref
+
+
+def default_opt():
+    o = Opt()
+    lib().lcdo_opt_default(C.byref(o))
+    return o
+
+
+def _p(a):
+    return a.ctypes.data_as(u8p)
+
+
+def _c8(a):
+    return np.ascontiguousarray(a, np.uint8)
+
+
+def edlib_nw(query, target):
+    """-> (distance, ops uint8 array) with edlib's exact path"""
+    q, t = _c8(query), _c8(target)
+    ap, n = u8p(), C.c_int()
+    d = lib().lcdo_edlib_nw(_p(q), len(q), _p(t), len(t), C.byref(ap), C.byref(n))
+    ops = np.ctypeslib.as_array(ap, shape=(max(n.value, 1),))[:n.value].copy() if n.value else np.zeros(0, np.uint8)
+    if ap:
+        _libc.free(ap)
+    return d, ops
+
+
+def ref_edlib_nw(query, target):
+    r = ref_edlib()
+    q, t = _c8(query), _c8(target)
+    buf = np.zeros(len(q) + len(t) + 8, np.uint8)
+    n = C.c_int()
+    d = r.ref_edlib_nw_path(_p(q), len(q), _p(t), len(t), _p(buf), len(buf), C.byref(n))
+    return d, buf[:n.value].copy()
+
+
+def ops_to_xgaps(ops):
+    """edlibAlignmentToXGAPS, src/align.c:189-208"""
+    x = 0
+    for i, o in enumerate(ops):
+        if o == 3:
+            x += 1
+        elif o in (1, 2) and (i == 0 or ops[i - 1] != o):
+            x += 1
+    return x
+
+
+def edlib_xgaps(target, query):
+    t, q = _c8(target), _c8(query)
+    return lib().lcdo_edlib_xgaps(_p(t), len(t), _p(q), len(q))
+
+
+def edlib_end2end_aln(target, query):
+    t, q = _c8(target), _c8(query)
+    a, b = C.c_int(), C.c_int()
+    d = lib().lcdo_edlib_end2end_aln(_p(t), len(t), _p(q), len(q), C.byref(a), C.byref(b))
+    return d, a.value, b.value
+
+
+def wfa_end2end_aln(pattern, text, gap_aln=1, b=6, q=6, e=2, q2=24, e2=1):
+    """-> dict(score, cigar, pattern_alg, text_alg)"""
+    p, t = _c8(pattern), _c8(text)
+    cb, cl, pa, ta, al, sc = u32p(), C.c_int(), u8p(), u8p(), C.c_int(), C.c_int()
+    lib().lcdo_wfa_end2end_aln(_p(p), len(p), _p(t), len(t), gap_aln, b, q, e, q2, e2, C.byref(cb), C.byref(cl), C.byref(pa), C.byref(ta), C.byref(al), C.byref(sc))
+    out = dict(score=sc.value, cigar=np.ctypeslib.as_array(cb, shape=(max(cl.value, 1),))[:cl.value].copy(),
+               pattern_alg=np.ctypeslib.as_array(pa, shape=(max(al.value, 1),))[:al.value].copy(),
+               text_alg=np.ctypeslib.as_array(ta, shape=(max(al.value, 1),))[:al.value].copy())
+    _libc.free(cb)
+    _libc.free(pa)
+    return out
+
+
+def gotoh2p_score(pattern, text, b=6, q=6, e=2, q2=24, e2=1):
+    p, t = _c8(pattern), _c8(text)
+    return lib().lcdo_gotoh2p_score(_p(p), len(p), _p(t), len(t), b, q, e, q2, e2)
+
+
+def cigar_score2p(cigar, pattern, text, b=6, q=6, e=2, q2=24, e2=1):
+    p, t = _c8(pattern), _c8(text)
+    c = np.ascontiguousarray(cigar, np.uint32)
+    return lib().lcdo_cigar_score2p(c.ctypes.data_as(u32p), len(c), _p(p), len(p), _p(t), len(t), b, q, e, q2, e2)
+
+
+def _poa_unpack(res, n, nc):
+    out = dict(n_cons=nc, msa_len=res.msa_len,
+               cons=[np.ctypeslib.as_array(res.cons_seq[c], shape=(max(res.cons_len[c], 1),))[:res.cons_len[c]].copy() for c in range(nc)],
+               msa=[np.ctypeslib.as_array(res.msa[i], shape=(max(res.msa_len, 1),))[:res.msa_len].copy() for i in range(n + nc)],
+               clu=[np.array(res.clu_read_ids[c][:res.clu_n_seq[c]], np.int32) for c in range(nc)])
+    lib().lcdo_poa_result_free(C.byref(res))
+    return out
+
+
+def poa_partial_aln_msa_cons(reads, covers, opt=None, sampling=0):
+    """K1, src/align.c:762"""
+    opt = opt or default_opt()
+    reads = [_c8(r) for r in reads]
+    n = len(reads)
+    arr = (u8p * n)(*[_p(r) for r in reads])
+    lens = (C.c_int * n)(*[len(r) for r in reads])
+    fc = (C.c_int * n)(*[int(c) for c in covers])
+    res = PoaRes()
+    nc = lib().lcdo_poa_partial_aln_msa_cons(C.byref(opt), sampling, n, arr, lens, fc, C.byref(res))
+    return _poa_unpack(res, n, nc)
+
+
+def poa_aln_msa_cons(reads, max_n_cons=2, opt=None):
+    """K2, src/align.c:872"""
+    opt = opt or default_opt()
+    reads = [_c8(r) for r in reads]
+    n = len(reads)
+    arr = (u8p * n)(*[_p(r) for r in reads])
+    lens = (C.c_int * n)(*[len(r) for r in reads])
+    res = PoaRes()
+    nc = lib().lcdo_poa_aln_msa_cons(C.byref(opt), n, arr, lens, max_n_cons, C.byref(res))
+    return _poa_unpack(res, n, nc)
+
+
+def collect_partial_aln_beg_end(target, tcover, query, qcover, opt=None, sampling=0):
+    opt = opt or default_opt()
+    t, q = _c8(target), _c8(query)
+    a = [C.c_int() for _ in range(4)]
+    r = lib().lcdo_collect_partial_aln_beg_end(C.byref(opt), sampling, _p(t), len(t), tcover, _p(q), len(q), qcover, *[C.byref(x) for x in a])
+    return r, tuple(x.value for x in a)
+
+
+def collect_noisy_reg_aln_strs(reg, opt=None):
+    """region driver (src/align.c:1760 after read slicing) -> same dict layout as longcalld_amd.align.RegionBatch.result, plus sorted_ids"""
+    opt = opt or default_opt()
+    n = len(reg["seqs"])
+    seqs = [_c8(s) for s in reg["seqs"]]
+    quals = reg.get("quals")
+    quals = [_c8(s) for s in quals] if quals is not None else [np.zeros(max(len(s), 1), np.uint8) for s in seqs]
+    sp = (u8p * n)(*[_p(s) for s in seqs])
+    qp = (u8p * n)(*[_p(s) for s in quals])
+    ids = np.array(reg["read_ids"], np.int32).copy()
+    lens = np.array([len(s) for s in seqs], np.int32)
+    cov = np.array(reg["covers"], np.int32).copy()
+    haps = np.array(reg["haps"], np.int32).copy()
+    pss = np.array(reg["phase_sets"], np.int64).copy()
+    rr = RegionReads(n, ids.ctypes.data_as(i32p), lens.ctypes.data_as(i32p), sp, qp, cov.ctypes.data_as(i32p), haps.ctypes.data_as(i32p),
+                     pss.ctypes.data_as(C.POINTER(C.c_int64)))
+    ref = _c8(reg["ref"])
+    m = 1 + 2 * n
+    clu_n = (C.c_int * 2)(0, 0)
+    clu_ids = (i32p * 2)()
+    a0, a1 = (AlnStr * m)(), (AlnStr * m)()
+    arr = (C.POINTER(AlnStr) * 2)(C.cast(a0, C.POINTER(AlnStr)), C.cast(a1, C.POINTER(AlnStr)))
+    nc = lib().lcdo_collect_noisy_reg_aln_strs(C.byref(opt), int(reg["reg_len"]), C.byref(rr), _p(ref), len(ref), clu_n, clu_ids, arr)
+    res = dict(n_cons=nc, clu_n_seqs=[int(clu_n[0]), int(clu_n[1])], clu_read_ids=[], aln_strs=[[], []], sorted_ids=ids.copy())
+    for c in range(2):
+        if clu_ids[c]:
+            res["clu_read_ids"].append(np.ctypeslib.as_array(clu_ids[c], shape=(max(clu_n[c], 1),))[:clu_n[c]].copy())
+            _libc.free(clu_ids[c])
+        else:
+            res["clu_read_ids"].append(None)
+        for j in range(m):
+            s = (a0, a1)[c][j]
+            if not s.target_aln:
+                res["aln_strs"][c].append(None)
+                continue
+            L = s.aln_len
+            t = np.ctypeslib.as_array(s.target_aln, shape=(max(L, 1),))[:L].copy()
+            q = np.ctypeslib.as_array(s.query_aln, shape=(max(L, 1),))[:L].copy()
+            res["aln_strs"][c].append(dict(target=t, query=q, aln_len=L, target_beg=s.target_beg, target_end=s.target_end,
+                                           query_beg=s.query_beg, query_end=s.query_end))
+            _libc.free(s.target_aln)
+    return res

@@ -1,0 +1,67 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pyoracle
+    pyoracle.build()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def lcd():
+    """the HIP library through its Python mirror; fails loudly if liblcd_hotpath.so is missing"""
+    from longcalld_amd import align
+    align.load_library()
+    return align
+
+
+def mutate(rng, s, rate, sv=0.0):
+    out, i = [], 0
+    while i < len(s):
+        x = rng.random()
+        if x < rate / 3:
+            out.append(rng.integers(0, 4))
+        elif x < 2 * rate / 3:
+            out.append(s[i]); out.append(rng.integers(0, 4))
+        elif x < rate:
+            pass
+        elif x < rate + sv:
+            L = int(rng.integers(5, 80))
+            if rng.random() < 0.5:
+                out.extend(rng.integers(0, 4, L)); out.append(s[i])
+            else:
+                i += L
+        else:
+            out.append(s[i])
+        i += 1
+    return np.array(out, dtype=np.uint8)
+
+
+def same_result(a, b):
+    """compare two region results (oracle vs HIP): n_cons, cluster membership, every alignment string and coordinate"""
+    assert a["n_cons"] == b["n_cons"]
+    if a["n_cons"] == 0:
+        return
+    for c in range(a["n_cons"]):
+        assert a["clu_n_seqs"][c] == b["clu_n_seqs"][c]
+        assert (a["clu_read_ids"][c] == b["clu_read_ids"][c]).all()
+        for j, (x, y) in enumerate(zip(a["aln_strs"][c], b["aln_strs"][c])):
+            assert (x is None) == (y is None), (c, j)
+            if x is None:
+                continue
+            for k in ("aln_len", "target_beg", "target_end", "query_beg", "query_end"):
+                assert x[k] == y[k], (c, j, k, x[k], y[k])
+            assert (x["target"] == y["target"]).all() and (x["query"] == y["query"]).all(), (c, j)

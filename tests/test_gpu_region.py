@@ -1,0 +1,152 @@
+"""Region-level parity: lcd_batch_* (anchors -> POA chains -> ref/cons WFA -> strings) vs the oracle's restatement of
+collect_noisy_reg_aln_strs (src/align.c:1760) on seeded synthetic region jobs, HiFi and ONT shapes."""
+import numpy as np
+import pytest
+
+from conftest import same_result
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_batch(lcd, regs):
+    b = lcd.RegionBatch()
+    for r in regs:
+        b.add_region(r)
+    b.upload(); b.run(); b.download()
+    out = [b.result(i) for i in range(len(regs))]
+    ids = [b.sorted_ids(i) for i in range(len(regs))]
+    st = b.stats(); dg = b.digest()
+    b.close()
+    return out, ids, st, dg
+
+
+@pytest.mark.parametrize("shape,seed,n", [("hifi", 1, 48), ("ont", 2, 16)])
+def test_regions_match_oracle(lcd, oracle, shape, seed, n):
+    from longcalld_amd import jobs
+    regs = jobs.make_regions(seed, n, jobs.HIFI if shape == "hifi" else jobs.ONT)
+    got, ids, st, _ = _run_batch(lcd, regs)
+    n_res = 0
+    for r, g, sid in zip(regs, got, ids):
+        exp = oracle.collect_noisy_reg_aln_strs(r)
+        assert (sid == exp["sorted_ids"]).all()  # the in-place permutation of noisy_reads (src/align.c:1774)
+        same_result(exp, g)
+        n_res += g["n_cons"] > 0
+    assert st["n_regions_resolved"] == n_res and st["poa_aligned_bases"] > 0
+
+
+def test_edge_regions(lcd, oracle):
+    """empty / ragged inputs the reference guards: too few reads, no full-cover read, partial-only haplotype, zero-length slices"""
+    from longcalld_amd import jobs
+    rng = np.random.default_rng(5)
+    base = jobs.make_region(rng, jobs.HIFI, length=200, n_reads=12)
+    few = jobs.make_region(rng, jobs.HIFI, length=150, n_reads=5)
+    few["haps"][:] = 0; few["phase_sets"][:] = -1
+    few["covers"][:2] = 8  # only 3 full-cover reads < min_dp: region skipped (src/align.c:1794)
+    nofull = jobs.make_region(rng, jobs.HIFI, length=150, n_reads=8)
+    nofull["covers"][:] = 8
+    zero = jobs.make_region(rng, jobs.HIFI, length=180, n_reads=10)
+    zero["seqs"][3] = np.zeros(0, np.uint8)
+    part = jobs.make_region(rng, jobs.HIFI, length=400, n_reads=14)
+    for i in range(0, 14, 3):
+        s = part["seqs"][i]
+        if len(s) > 120:
+            part["seqs"][i] = s[:len(s) // 2]; part["covers"][i] = 8
+    for i in range(1, 14, 5):
+        s = part["seqs"][i]
+        if len(s) > 120:
+            part["seqs"][i] = s[len(s) // 3:]; part["covers"][i] = 4
+    regs = [base, few, nofull, zero, part]
+    got, ids, _, _ = _run_batch(lcd, regs)
+    for r, g in zip(regs, got):
+        same_result(oracle.collect_noisy_reg_aln_strs(r), g)
+    assert got[1]["n_cons"] == 0 and got[2]["n_cons"] == 0
+
+
+def test_run_is_idempotent_and_order_independent(lcd):
+    """size-independent properties: re-running a batch gives the same digest; a region's result does not depend on its batch mates"""
+    from longcalld_amd import jobs
+    regs = jobs.make_regions(9, 24)
+    b = lcd.RegionBatch()
+    for r in regs:
+        b.add_region(r)
+    b.upload(); b.run(); b.download(); d1 = b.digest()
+    b.run(); b.download(); d2 = b.digest()
+    one = b.result(5)
+    b.close()
+    assert d1 == d2 and d1 != 0
+    got, _, _, _ = _run_batch(lcd, [regs[5]])
+    same_result(one, got[0])
+
+
+def test_per_call_mirror(lcd, oracle):
+    """lcd_collect_noisy_reg_aln_strs through chunk views: digar walk (src/align.c:1392-1458) + 4-bit base unpacking + in-place permutation"""
+    import ctypes as C
+    from longcalld_amd import _lib, jobs
+    lib = _lib.load_library()
+    rng = np.random.default_rng(21)
+    reg = jobs.make_region(rng, jobs.HIFI, length=300, n_reads=14)
+    # embed every slice in a longer read: 50 flanking bases each side, one '=' digar covering it, region = [1051, 1050+len(ref)]
+    n = len(reg["seqs"])
+    views = (_lib.LcdReadView * n)()
+    keep = []
+    reg_beg, reg_end = 1051, 1050 + len(reg["ref"])
+    exp_cover = []
+    for i, s in enumerate(reg["seqs"]):
+        cover = int(reg["covers"][i])
+        left = rng.integers(0, 4, 50).astype(np.uint8) if cover & 8 else np.zeros(0, np.uint8)
+        right = rng.integers(0, 4, 50).astype(np.uint8) if cover & 4 else np.zeros(0, np.uint8)
+        full = np.concatenate([left, s, right])
+        # BAM 4-bit packing: A1 C2 G4 T8
+        code = np.array([1, 2, 4, 8, 15], np.uint8)[full]
+        if len(code) % 2:
+            code = np.append(code, 0)
+        packed = ((code[0::2] << 4) | code[1::2]).astype(np.uint8)
+        qual = np.full(len(full), 30, np.uint8)
+        # reference span of the read: cover both ends -> starts 50 before the region; the read's ref length is faked with one '=' op
+        # of the right length so that boundaries fall where the slice is
+        if cover == 12:
+            pos, rlen = reg_beg - 50, 50 + (reg_end - reg_beg + 1) + 50
+        elif cover == 8:
+            pos, rlen = reg_beg - 50, 50 + len(s)
+        else:
+            pos, rlen = reg_end - len(s) + 1, len(s) + 50
+        # a single EQUAL digar cannot express length differences; build: '=' up to the region start, then an 'I'/'D' free walk is not
+        # needed because lcd only uses (pos, len, qi) of the digars that contain the boundaries.
+        d = (_lib.LcdDigar1 * 3)()
+        if cover == 12:
+            d[0] = _lib.LcdDigar1(pos, 7, 50 + 1, 0)                                        # '=' containing reg_beg -> read_beg = 50
+            d[1] = _lib.LcdDigar1(reg_beg + 1, 1, max(len(s) - 2, 0), 51)                    # 'I' (body of the slice), ref length 0
+            d[2] = _lib.LcdDigar1(reg_end, 7, 51, 50 + len(s) - 1)                          # '=' containing reg_end -> read_end
+            nd = 3
+        elif cover == 8:
+            d[0] = _lib.LcdDigar1(pos, 7, 50 + 1, 0)
+            d[1] = _lib.LcdDigar1(reg_beg + 1, 1, len(s) - 1, 51)
+            nd = 2
+        else:
+            d[0] = _lib.LcdDigar1(reg_end - 1, 1, len(s) - 1, 0)
+            d[1] = _lib.LcdDigar1(reg_end, 7, 51, len(s) - 1)
+            nd = 2
+        keep += [packed, qual, d]
+        views[i] = _lib.LcdReadView(C.cast(d, C.POINTER(_lib.LcdDigar1)), nd, len(full), packed.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                    qual.ctypes.data_as(C.POINTER(C.c_uint8)), int(reg["haps"][i]), int(reg["phase_sets"][i]))
+        exp_cover.append(cover)
+    opt = lcd.default_opt()
+    noisy = np.arange(n, dtype=np.int32)
+    m = 1 + 2 * n
+    clu_n = (C.c_int * 2)(0, 0)
+    clu_ids = (C.POINTER(C.c_int) * 2)()
+    a0, a1 = (_lib.LcdAlnStr * m)(), (_lib.LcdAlnStr * m)()
+    arr = (C.POINTER(_lib.LcdAlnStr) * 2)(C.cast(a0, C.POINTER(_lib.LcdAlnStr)), C.cast(a1, C.POINTER(_lib.LcdAlnStr)))
+    ref = np.ascontiguousarray(reg["ref"])
+    nc = lib.lcd_collect_noisy_reg_aln_strs(C.byref(opt), views, reg_beg, reg_end, 0, n, noisy.ctypes.data_as(C.POINTER(C.c_int)),
+                                            ref.ctypes.data_as(C.POINTER(C.c_uint8)), len(ref), clu_n, clu_ids, arr)
+    assert nc >= 0, lib.lcd_last_error()
+    reg2 = dict(reg); reg2["read_ids"] = np.arange(n, dtype=np.int32)
+    exp = oracle.collect_noisy_reg_aln_strs(reg2)
+    assert nc == exp["n_cons"]
+    assert (noisy == exp["sorted_ids"]).all()
+    for c in range(nc):
+        assert clu_n[c] == exp["clu_n_seqs"][c]
+        s = (a0, a1)[c][0]
+        t = np.ctypeslib.as_array(s.target_aln, shape=(s.aln_len,))
+        assert (t == exp["aln_strs"][c][0]["target"]).all()
