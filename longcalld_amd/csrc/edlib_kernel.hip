@@ -43,11 +43,13 @@ struct Sub { // sub-problem in the coordinates of the job's query/target
 };
 
 // One NW pass over `ncols` target columns.  rev: walk both strings from their ends.
-// store != 0: keep P/M/score of every (column, block) for the traceback (caller guarantees it fits).
-// col_out != nullptr: scores of the last column for every query row.
+// STORE: keep P/M/score of every (column, block) for the traceback (caller guarantees it fits).
+// COLS: write the scores of the last column for every query row to col_out.
+// (compile-time flags, not nullable pointers: hipcc folded the `if (P)` form of this test away.)
 // Returns (lane-uniform) the score at (qlen-1, ncols-1).
-__device__ int myers_pass(const Sub &sp, int ncols, bool rev, int lane, Word *P, Word *M, int *S, int *col_out, signed char *hcarry,
-                          unsigned long long *blocks_acc) {
+template <bool STORE, bool COLS>
+__device__ __forceinline__ int myers_pass(const Sub &sp, int ncols, bool rev, int lane, Word *P, Word *M, int *S, int *col_out, signed char *hcarry,
+                                          unsigned long long *blocks_acc) {
     const int qlen = sp.qlen, nb = (qlen + 63) >> 6;
     int result = 0;
     for (int tile0 = 0; tile0 < nb; tile0 += 64) {
@@ -77,7 +79,7 @@ __device__ int myers_pass(const Sub &sp, int ncols, bool rev, int lane, Word *P,
                 const Word Eq = tc == 0 ? peq[0] : tc == 1 ? peq[1] : tc == 2 ? peq[2] : tc == 3 ? peq[3] : peq[4];
                 hout = calc_block(Pv, Mv, Eq, hin, Pv, Mv);
                 score += hout;
-                if (P) { const size_t o = (size_t)c * nb + b; P[o] = Pv; M[o] = Mv; S[o] = score; }
+                if (STORE) { const size_t o = (size_t)c * nb + b; P[o] = Pv; M[o] = Mv; S[o] = score; }
                 if (more && lane == 63) hcarry[ncols + c] = (signed char)hout;
             }
         }
@@ -90,7 +92,7 @@ __device__ int myers_pass(const Sub &sp, int ncols, bool rev, int lane, Word *P,
         // last-column scores of this tile's rows
         if (act) {
             const int base = b << 6, lim = imin(64, qlen - base);
-            if (col_out)
+            if (COLS)
                 for (int pos = 0; pos < lim; ++pos) {
                     int v = score;
                     if (pos < 63) v += -__popcll(Pv >> (pos + 1)) + __popcll(Mv >> (pos + 1));
@@ -138,7 +140,7 @@ __global__ void __launch_bounds__(64) lcd_edlib_kernel(const EdJob *jobs, const 
     signed char *hcarry = (signed char *)(colR + qlen);
     unsigned long long blocks = 0;
     Sub top = {q, t, qlen, tlen};
-    const int dist = myers_pass(top, tlen, false, lane, nullptr, nullptr, nullptr, nullptr, hcarry, &blocks);
+    const int dist = myers_pass<false, false>(top, tlen, false, lane, nullptr, nullptr, nullptr, nullptr, hcarry, &blocks);
     out.dist = dist;
     __shared__ int stk[64][5]; // qoff, qlen, toff, tlen, best
     int sp = 0;
@@ -164,7 +166,7 @@ __global__ void __launch_bounds__(64) lcd_edlib_kernel(const EdJob *jobs, const 
         const long long nb = (ql + 63) >> 6;
         const long long data_size = 20ll * nb * tl + 8ll * tl;
         if (data_size < 1024 * 1024) {
-            myers_pass(s, tl, false, lane, P, M, S, nullptr, hcarry, &blocks);
+            myers_pass<true, false>(s, tl, false, lane, P, M, S, nullptr, hcarry, &blocks);
             __syncthreads();
             // traceback on lane 0; tallies broadcast afterwards
             int r_mis = 0, r_eq = 0, r_ins = 0, r_del = 0, r_runs = 0, leaf_first = -1, leaf_last = -1;
@@ -200,8 +202,8 @@ __global__ void __launch_bounds__(64) lcd_edlib_kernel(const EdJob *jobs, const 
             __syncthreads();
         } else {
             const int left_w = tl / 2, right_w = tl - left_w;
-            myers_pass(s, left_w, false, lane, nullptr, nullptr, nullptr, colL, hcarry, &blocks);
-            myers_pass(s, right_w, true, lane, nullptr, nullptr, nullptr, colR, hcarry, &blocks);
+            myers_pass<false, true>(s, left_w, false, lane, nullptr, nullptr, nullptr, colL, hcarry, &blocks);
+            myers_pass<false, true>(s, right_w, true, lane, nullptr, nullptr, nullptr, colR, hcarry, &blocks);
             __syncthreads();
             // first row i in [0, ql-2] with colL[i] + right[i+1] == best, right[idx] = colR[ql-1-idx]
             int cand = 1 << 30;
