@@ -1,0 +1,137 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on its configs[1]: regions/sec (+ POA-aligned bases/sec) of the per-region hot path
+on synthetic 30x HiFi-shape region jobs (15 kb reads, 0.1 % error, 10 Mb reference => 1 250 regions per GPU).
+
+One "step" = one pass of the hot path (anchors -> POA chains -> ref/cons WFA -> MSA strings) over the rank's batch with
+inputs already resident in HBM.  N > 1: regions are sharded across ranks as independent work items (no data-path
+collective); torch.distributed (RCCL) is used for the barrier and the max-over-ranks time only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--ref-mb", type=float, default=10.0, help="synthetic reference size per GPU (10 Mb = configs[1])")
+    ap.add_argument("--shape", default="hifi", choices=["hifi", "ont"])
+    ap.add_argument("--cpu-sample", type=int, default=300, help="regions timed on the CPU oracle for cpu_baseline (rank 0, N=1 only)")
+    ap.add_argument("--seed", type=int, default=20250928)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank)
+
+    from longcalld_amd import align, jobs, _lib
+    lib = _lib.load_library()
+    _lib.check(lib.lcd_init(local_rank), lib)
+
+    shape = jobs.HIFI if args.shape == "hifi" else jobs.ONT
+    n_regions = jobs.regions_for_ref_mb(args.ref_mb)
+    regs = jobs.make_regions(args.seed + 1000 * rank, n_regions, shape)   # weak scaling: same work per GPU, different seed
+    batch = align.RegionBatch()
+    for r in regs:
+        batch.add_region(r)
+    t_up0 = time.perf_counter()
+    batch.upload()
+    t_up = time.perf_counter() - t_up0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.run()
+    barrier()
+    t0 = time.perf_counter()
+    poa_kernel_ms, poa_launches, st = 0.0, 0, None
+    for _ in range(args.steps):
+        batch.run()
+        st = batch.stats()
+        poa_kernel_ms += st["ms_poa_kernel"]
+        poa_launches += st["n_poa_launches"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([float(st["n_regions"]), float(st["poa_aligned_bases"])], dtype=torch.float64, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        tot_regions, tot_bases = float(cnt[0].item()), float(cnt[1].item())
+    else:
+        tot_regions, tot_bases = float(st["n_regions"]), float(st["poa_aligned_bases"])
+
+    # PCIe-inclusive figure for DESIGN.md (never `value`)
+    t_dl0 = time.perf_counter()
+    batch.download()
+    digest = batch.digest()
+    t_dl = time.perf_counter() - t_dl0
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = tot_regions * args.steps / elapsed
+        # roofline of the dominant kernel (POA chains): algorithmic bytes (SURVEY 8d B_poa) per launch / mean launch time
+        alg_bytes = float(st["poa_alg_bytes"])
+        mean_launch_s = poa_kernel_ms / max(poa_launches, 1) * 1e-3
+        achieved = alg_bytes / mean_launch_s / 1e9 if mean_launch_s > 0 else 0.0
+        roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                    "traffic": None, "kernel": "lcd_poa_chain_kernel", "ms_per_launch": round(mean_launch_s * 1e3, 4),
+                    "alg_bytes_per_launch": alg_bytes, "cells_per_launch": int(st["poa_cells"]),
+                    "gcups": round(st["poa_cells"] / mean_launch_s / 1e9, 3) if mean_launch_s > 0 else 0.0}
+        cpu = None
+        if world == 1 and args.cpu_sample > 0:
+            from oracle import pyoracle
+            sample = regs[: min(args.cpu_sample, len(regs))]
+            c0 = time.perf_counter()
+            for r in sample:
+                pyoracle.collect_noisy_reg_aln_strs(r)
+            c = time.perf_counter() - c0
+            cpu = {"value": round(len(sample) / c, 2), "unit": "regions/s", "cores": 1, "kind": "port",
+                   "sample": f"first {len(sample)} of the {len(regs)} regions of the same workload, oracle/ C restatement (-O3 scalar, not upstream SIMD abPOA/WFA2: "
+                             f"those submodules are absent), {c:.1f} s on one host core of {os.cpu_count()}"}
+        out = {
+            "metric": "regions_per_sec", "value": round(value, 2), "unit": "regions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": f"configs[1]: synthetic 30x {shape['name']} region jobs over {args.ref_mb:g} Mb reference per GPU "
+                                   f"({n_regions} regions/GPU, ~{tot_bases / max(world, 1) / 1e6:.1f} Mbase POA-aligned/GPU)",
+                       "regions_per_gpu": n_regions, "sharding": "regions sharded across ranks, no data-path collective"},
+            "poa_aligned_bases_per_sec": round(tot_bases * args.steps / elapsed, 1),
+            "regions_resolved": int(st["n_regions_resolved"]),
+            "stage_ms": {k: round(st[k], 3) for k in ("ms_anchor", "ms_poa", "ms_wfa", "ms_strings", "ms_total", "ms_host", "ms_poa_kernel")},
+            "pcie_inclusive": {"upload_s": round(t_up, 4), "download_and_digest_s": round(t_dl, 4),
+                               "regions_per_sec": round(tot_regions / max(world, 1) / (t_up + ms_step / 1e3 + t_dl), 2)},
+            "digest": f"{digest:016x}",
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    batch.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -97,6 +97,8 @@ typedef struct lcd_batch_stats_t {
     uint64_t poa_alg_bytes; /* SURVEY 8d B_poa summed over aligned reads */
     double ms_total, ms_anchor, ms_poa, ms_wfa, ms_strings; /* HIP-event times on the batch stream */
     double ms_upload, ms_download, ms_host;
+    double ms_poa_kernel;   /* HIP events tight around the POA chain kernel launch(es) only */
+    int n_poa_launches;
     int poa_retries;
 } lcd_batch_stats_t;
 

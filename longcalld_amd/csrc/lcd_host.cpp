@@ -618,12 +618,15 @@ int lcd_batch_run(lcd_batch_t *b) {
             if (b->d_poa_arena.ensure(tot)) return -11;
             for (size_t i = 0; i < which.size(); ++i) { b->pchains[which[i]].ws_off += b->d_poa_arena.addr(); sub[i] = b->pchains[which[i]]; }
             HIPCHK(hipMemcpyAsync(b->d_chains.p, sub.data(), sub.size() * sizeof(PoaChain), hipMemcpyHostToDevice, st));
+            HIPCHK(hipEventRecord(b->ev[6], st));
             lcd_launch_poa((const PoaChain *)b->d_chains.p, (const PoaRead *)b->d_preads.p, nullptr, nullptr, nullptr, (PoaChainOut *)b->d_poa_outs.p, sc,
                            (int)sub.size(), st);
             HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(b->ev[7], st));
             std::vector<PoaChainOut> tmp(sub.size());
             HIPCHK(hipMemcpyAsync(tmp.data(), b->d_poa_outs.p, sub.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
+            { float kms = 0; hipEventElapsedTime(&kms, b->ev[6], b->ev[7]); S.ms_poa_kernel += kms; S.n_poa_launches++; }
             std::vector<int> again;
             for (size_t i = 0; i < which.size(); ++i) {
                 b->couts[which[i]] = tmp[i];
