@@ -132,7 +132,9 @@ struct OutStr { // one aln_str in the final output pool
 struct lcd_batch_s {
     lcd_opt_t opt;
     hipStream_t stream = nullptr;
+    hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev[10];
+    hipEvent_t sev[3];
     std::vector<uint8_t> h_pool;
     std::vector<RegionRec> regs;
     std::vector<ChainRec> chains;
@@ -288,6 +290,8 @@ lcd_batch_t *lcd_batch_create(const lcd_opt_t *opt) {
     b->opt = *opt;
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { set_err(-10, "hipStreamCreate failed"); delete b; return nullptr; }
     for (auto &e : b->ev) hipEventCreate(&e);
+    for (auto &e : b->sev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    for (auto &s : b->side) hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
     memset(&b->st, 0, sizeof(b->st));
     return b;
 }
@@ -295,6 +299,8 @@ void lcd_batch_destroy(lcd_batch_t *b) {
     if (!b) return;
     hipSetDevice(g_device);
     for (auto &e : b->ev) hipEventDestroy(e);
+    for (auto &e : b->sev) hipEventDestroy(e);
+    for (auto &s : b->side) if (s) hipStreamDestroy(s);
     if (b->stream) hipStreamDestroy(b->stream);
     delete b;
 }
@@ -529,6 +535,33 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     pc.cell_cap = (uint64_t)std::max<long long>(cells, maxl + 64);
 }
 
+// workgroup size class of a chain: follows the DP row width (poa_kernel.hip)
+static int chain_threads(const PoaChain &pc) {
+    const long long width = pc.mode == 1 ? (long long)pc.max_len + 1 : 2ll * (10 + pc.max_len / 100) + 1 + 32;
+    return width <= 128 ? 64 : width <= 1024 ? 256 : 1024;
+}
+// uploads `sub` (already ordered so that equal classes are contiguous) and launches one kernel per class
+// (different classes go to side streams so a long wide chain does not hold back the narrow ones)
+static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, DevBuf &d_chains, const PoaRead *d_reads, DevBuf &d_outs, LcdScoring sc,
+                              hipStream_t *side = nullptr, hipEvent_t *sev = nullptr) {
+    HIPCHK(hipMemcpyAsync(d_chains.p, sub.data(), sub.size() * sizeof(PoaChain), hipMemcpyHostToDevice, st));
+    if (side) HIPCHK(hipEventRecord(sev[0], st));
+    size_t i = 0; int nside = 0;
+    while (i < sub.size()) {
+        const int cls = chain_threads(sub[i]);
+        size_t j = i;
+        while (j < sub.size() && chain_threads(sub[j]) == cls) ++j;
+        hipStream_t s = st;
+        if (side && nside < 2 && j < sub.size()) { s = side[nside]; HIPCHK(hipStreamWaitEvent(s, sev[0], 0)); }
+        lcd_launch_poa((const PoaChain *)d_chains.p + i, d_reads, nullptr, nullptr, nullptr, (PoaChainOut *)d_outs.p + i, sc, (int)(j - i), cls, s);
+        HIPCHK(hipGetLastError());
+        if (s != st) { HIPCHK(hipEventRecord(sev[1 + nside], s)); ++nside; }
+        i = j;
+    }
+    for (int k = 0; k < nside; ++k) HIPCHK(hipStreamWaitEvent(st, sev[1 + k], 0));
+    return 0;
+}
+
 int lcd_batch_run(lcd_batch_t *b) {
     if (!b->uploaded) return set_err(-3, "lcd_batch_run before lcd_batch_upload");
     if (ensure_init()) return -1;
@@ -604,7 +637,10 @@ int lcd_batch_run(lcd_batch_t *b) {
         std::vector<int> which(nC);
         for (int c = 0; c < nC; ++c) which[c] = c;
         // biggest first so the long chains start early (LPT)
-        std::sort(which.begin(), which.end(), [&](int a, int c2) { return b->pchains[a].cell_cap > b->pchains[c2].cell_cap; });
+        std::sort(which.begin(), which.end(), [&](int a, int c2) {
+            const int ta = chain_threads(b->pchains[a]), tc = chain_threads(b->pchains[c2]);
+            if (ta != tc) return ta > tc; // widest class first, then biggest first (LPT)
+            return b->pchains[a].cell_cap > b->pchains[c2].cell_cap; });
         int scale = 1;
         for (int round = 0; round < 12 && !which.empty(); ++round) {
             uint64_t tot = 0;
@@ -617,11 +653,8 @@ int lcd_batch_run(lcd_batch_t *b) {
             }
             if (b->d_poa_arena.ensure(tot)) return -11;
             for (size_t i = 0; i < which.size(); ++i) { b->pchains[which[i]].ws_off += b->d_poa_arena.addr(); sub[i] = b->pchains[which[i]]; }
-            HIPCHK(hipMemcpyAsync(b->d_chains.p, sub.data(), sub.size() * sizeof(PoaChain), hipMemcpyHostToDevice, st));
             HIPCHK(hipEventRecord(b->ev[6], st));
-            lcd_launch_poa((const PoaChain *)b->d_chains.p, (const PoaRead *)b->d_preads.p, nullptr, nullptr, nullptr, (PoaChainOut *)b->d_poa_outs.p, sc,
-                           (int)sub.size(), st);
-            HIPCHK(hipGetLastError());
+            { int rc2 = launch_poa_grouped(st, sub, b->d_chains, (const PoaRead *)b->d_preads.p, b->d_poa_outs, sc, b->side, b->sev); if (rc2) return rc2; }
             HIPCHK(hipEventRecord(b->ev[7], st));
             std::vector<PoaChainOut> tmp(sub.size());
             HIPCHK(hipMemcpyAsync(tmp.data(), b->d_poa_outs.p, sub.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, st));
@@ -729,6 +762,19 @@ int lcd_batch_run(lcd_batch_t *b) {
         S.poa_aligned_bases += o.aligned_bases; S.poa_cells += o.cells;
         // B_poa = q + 5*N_sub + C + (q + N_sub) per aligned read; N_sub ~ final graph size (upper bound per read)
         S.poa_alg_bytes += 2 * o.aligned_bases + o.cells + 6ull * (uint64_t)o.n_node * (uint64_t)o.n_aligned_reads;
+    }
+    if (getenv("LCD_PROFILE_CHAINS")) {
+        // per-phase shader-clock ticks, summed per workgroup class and for the slowest chain
+        for (int cls : {64, 256, 1024}) {
+            unsigned long long tt = 0, td = 0, tb = 0, tg = 0, to = 0, ts = 0, mx = 0; int cnt = 0, mxc = -1;
+            for (int c = 0; c < nC; ++c) { if (chain_threads(b->pchains[c]) != cls) continue; const PoaChainOut &o = b->couts[c]; ++cnt;
+                tt += o.t_total; td += o.t_dp; tb += o.t_bt; tg += o.t_graph; to += o.t_out; ts += o.t_sub; if (o.t_total > mx) { mx = o.t_total; mxc = c; } }
+            if (!cnt) continue;
+            fprintf(stderr, "[lcd] class %4d: %5d chains  sum ticks total %.3e dp %.3e bt %.3e graph %.3e sub %.3e out %.3e\n", cls, cnt, (double)tt, (double)td, (double)tb, (double)tg, (double)ts, (double)to);
+            const PoaChainOut &o = b->couts[mxc];
+            fprintf(stderr, "[lcd]   slowest chain %d: mode %d reads %d maxlen %d nodes %d  total %.3e dp %.3e bt %.3e graph %.3e sub %.3e out %.3e cells %llu\n", mxc, b->pchains[mxc].mode,
+                    b->pchains[mxc].n_reads, b->pchains[mxc].max_len, o.n_node, (double)o.t_total, (double)o.t_dp, (double)o.t_bt, (double)o.t_graph, (double)o.t_sub, (double)o.t_out, o.cells);
+        }
     }
     S.ms_host = (now_ms() - t_begin) - S.ms_total;
     b->ran = true; b->downloaded = false;
@@ -969,9 +1015,7 @@ int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int
         }
         if (d_arena.ensure(tot)) return -11;
         for (size_t i = 0; i < which.size(); ++i) { pch[which[i]].ws_off += d_arena.addr(); sub[i] = pch[which[i]]; }
-        HIPCHK(hipMemcpyAsync(d_chains.p, sub.data(), sub.size() * sizeof(PoaChain), hipMemcpyHostToDevice, st));
-        lcd_launch_poa((const PoaChain *)d_chains.p, (const PoaRead *)d_reads.p, nullptr, nullptr, nullptr, (PoaChainOut *)d_outs.p, sc, (int)sub.size(), st);
-        HIPCHK(hipGetLastError());
+        { int rc2 = launch_poa_grouped(st, sub, d_chains, (const PoaRead *)d_reads.p, d_outs, sc); if (rc2) return rc2; }
         std::vector<PoaChainOut> tmp(sub.size());
         HIPCHK(hipMemcpyAsync(tmp.data(), d_outs.p, sub.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));

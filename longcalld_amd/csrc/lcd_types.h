@@ -62,13 +62,14 @@ struct PoaChainOut {
     int n_aligned_reads;
     unsigned long long cells;          // DP cells computed (K1/K2 algorithmic unit)
     unsigned long long aligned_bases;  // POA-aligned bases (BASELINE metric)
+    unsigned long long t_total, t_dp, t_bt, t_graph, t_out, t_sub; // shader-clock ticks per phase (profiling aid)
 };
 
 // arena layout (byte offsets relative to ws_off); identical on host and device
 struct PoaLayout {
     uint64_t H, E1, E2;                                  // int32[cell_cap]
     uint64_t rbeg, rend, roff;                           // int32/int32/uint32 [node_cap], by topological index
-    uint64_t mpl, mpr;                                   // int32[node_cap], by node id
+    uint64_t mpl, mpr;                                   // int32[node_cap]: leftmost/rightmost row-max column, by topological index
     uint64_t idx2node, node2idx, remain, deg, queue;     // int32[node_cap]
     uint64_t n_out_head, n_out_tail, n_in_head, n_in_tail, n_nin, n_aligned;  // int32[node_cap]
     uint64_t e_from, e_to, e_w, e_next_out, e_next_in;   // int32[edge_cap]
@@ -76,6 +77,7 @@ struct PoaLayout {
     uint64_t cig_node, cig_qpos;                         // int32[max_len+1]
     uint64_t n_base, imap;                               // uint8[node_cap]
     uint64_t het, clu, nclu, prof;                       // int32[node_cap], int32[n_reads] x2, uint8[2*node_cap]
+    uint64_t pl_start, pl_pidx, pl_bonus;                // row plan: int32[node_cap+2], int32[edge_cap] x2
     uint64_t total;
 };
 
@@ -100,6 +102,7 @@ static inline LCD_HD PoaLayout poa_layout(int node_cap, int edge_cap, int rid_wo
     LCD_TAKE(n_base, (uint64_t)node_cap); LCD_TAKE(imap, (uint64_t)node_cap);
     LCD_TAKE(het, (uint64_t)node_cap * 4); LCD_TAKE(clu, (uint64_t)n_reads * 4); LCD_TAKE(nclu, (uint64_t)n_reads * 4);
     LCD_TAKE(prof, (uint64_t)node_cap * 2);
+    LCD_TAKE(pl_start, (uint64_t)(node_cap + 2) * 4); LCD_TAKE(pl_pidx, (uint64_t)edge_cap * 4); LCD_TAKE(pl_bonus, (uint64_t)edge_cap * 4);
 #undef LCD_TAKE
     L.total = lcd_align_up(o, 256);
     return L;

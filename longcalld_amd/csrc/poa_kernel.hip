@@ -1,13 +1,20 @@
 // poa_kernel.hip -- K1/K2: partial-order alignment chains on gfx950 (CDNA4, wave64).
 //
 // Replaces what src/align.c:762-857 (abpoa_partial_aln_msa_cons) and :872-943 (abpoa_aln_msa_cons) ask
-// of abPOA.  One 64-lane wavefront owns one chain (= one abpoa_t life: region x haplotype for K1, region
-// for K2) and keeps the whole graph build device-resident: align read -> backtrack -> add alignment ->
-// re-sort -> next read, then MSA / clustering / consensus.  No host round trip inside a chain.
+// of abPOA.  One workgroup owns one chain (= one abpoa_t life: region x haplotype for K1, region for K2)
+// and keeps the whole graph build device-resident: align read -> backtrack -> add alignment -> re-sort ->
+// next read, then MSA / clustering / consensus.  No host round trip inside a chain.
 //
-// Integer DP only (no MFMA): a DP row is one coalesced 64-column sweep; the horizontal-gap recurrence is a
-// wave-level exclusive prefix max (F[j] = max_k<j Hpre[k] - o - (j-k)e  ==  prefixmax(Hpre[k]+k e) - o - j e);
-// only H, E1, E2 are stored (12 B/cell), the insertion run is re-derived from H in the backtrack.
+// Workgroup size follows the DP row width: 64 threads for banded HiFi rows (<=128 columns), 256 / 1024 for
+// the unbanded K2 rows, so a 4 000-column row is 4 rounds of 16 wavefronts instead of 63 serial chunks.
+// Integer DP only (no MFMA):
+//   * per read a "row plan" (CSR of the usable predecessors + edge bonus of every row) is built in parallel,
+//     so a row costs one dependent load level instead of a linked-list walk;
+//   * a row's predecessor metadata is staged once in LDS and shared by all wavefronts;
+//   * the horizontal-gap recurrence is a wave-level exclusive prefix max with an LDS carry across wavefronts
+//     (F[j] = max_k<j Hpre[k] - o - (j-k)e  ==  prefixmax(Hpre[k]+k e) - o - j e);
+//   * the adaptive band is pulled from the predecessors' row-max columns (no scatter);
+//   * only H, E1, E2 are stored (12 B/cell); the insertion run is re-derived from H in the backtrack.
 // Semantics are defined by oracle/poa.c (see its header); this file must match it bit for bit.
 #include <hip/hip_runtime.h>
 #include "lcd_types.h"
@@ -15,19 +22,33 @@
 
 namespace {
 
+constexpr int MAXP = 64;   // predecessors staged in LDS per row (more are read from the plan in HBM)
+constexpr int MAXW = 16;   // wavefronts per workgroup
+
+struct Smem {
+    int tot1[2][MAXW], tot2[2][MAXW];
+    int bh[MAXW], bl[MAXW], br[MAXW];
+    int pb[MAXP], pe[MAXP], bonus[MAXP], pml[MAXP], pmr[MAXP];
+    unsigned po[MAXP];
+    int scan[MAXW];
+    int bc[8];
+};
+
 struct Ctx {
     int *H, *E1, *E2;
     int *rbeg, *rend; uint32_t *roff;
-    int *mpl, *mpr, *idx2node, *node2idx, *remain, *deg, *queue;
+    int *ml, *mr, *idx2node, *node2idx, *remain, *deg, *queue;
     int *out_head, *out_tail, *in_head, *in_tail, *nin, *aligned;
     int *e_from, *e_to, *e_w, *e_next_out, *e_next_in;
     unsigned long long *rid;
     int *cig_node, *cig_qpos;
     uint8_t *base, *imap;
     int *het, *clu, *nclu; uint8_t *prof;
+    int *pl_start, *pl_pidx, *pl_bonus;
     int n_node, n_edge, node_cap, edge_cap, rid_words;
     unsigned long long cell_cap;
     int status;
+    unsigned long long t_dp, t_bt;
 };
 
 __device__ __forceinline__ int ilog2_32(int v) { return 31 - __clz(v); }
@@ -42,18 +63,23 @@ __device__ __forceinline__ int wave_min(int v) {
     for (int d = 32; d >= 1; d >>= 1) v = imin(v, __shfl_xor(v, d));
     return v;
 }
-// exclusive prefix max over lanes (lane 0 gets `identity`)
-__device__ __forceinline__ int wave_excl_prefix_max(int v, int lane, int identity) {
-    int x = v;
+// inclusive prefix max over lanes
+__device__ __forceinline__ int wave_incl_prefix_max(int v, int lane) {
     for (int d = 1; d < 64; d <<= 1) {
-        int y = __shfl_up(x, d);
-        if (lane >= d) x = imax(x, y);
+        int y = __shfl_up(v, d);
+        if (lane >= d) v = imax(v, y);
     }
-    int e = __shfl_up(x, 1);
-    return lane == 0 ? identity : e;
+    return v;
+}
+__device__ __forceinline__ int wave_incl_prefix_add(int v, int lane) {
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(v, d);
+        if (lane >= d) v += y;
+    }
+    return v;
 }
 
-// ---------------- graph mutation (lane 0 only) ----------------
+// ---------------- graph mutation (thread 0 only) ----------------
 __device__ int add_node(Ctx &g, uint8_t b) {
     if (g.n_node >= g.node_cap) { g.status = LCD_ERR_NODES; return g.node_cap - 1; }
     int id = g.n_node++;
@@ -145,8 +171,8 @@ __device__ void add_alignment(Ctx &g, int beg_node, int end_node, const uint8_t 
     if (g.status == LCD_OK) topo_sort(g);
 }
 
-// sub-graph boundaries (oracle/poa.c subgraph_nodes), wave-parallel min/max sweeps
-__device__ void subgraph_nodes(Ctx &g, int lane, int inc_beg, int inc_end, int *exc_beg, int *exc_end) {
+// sub-graph boundaries (oracle/poa.c subgraph_nodes): min/max sweeps on wavefront 0, result broadcast through LDS
+__device__ void subgraph_nodes_wave0(Ctx &g, int lane, int inc_beg, int inc_end, int *exc_beg, int *exc_end) {
     const int bi = g.node2idx[inc_beg], ei = g.node2idx[inc_end];
     int b = bi, e = ei, up, down;
     for (;;) {
@@ -176,23 +202,26 @@ __device__ void subgraph_nodes(Ctx &g, int lane, int inc_beg, int inc_end, int *
 }
 
 // banded convex-gap global alignment of seq[0..qlen) to the sub-graph (beg_node,end_node); returns #cigar
-// entries written to cig_node/cig_qpos in start->end order (lane-uniform result).
-__device__ int align_to_subgraph(Ctx &g, int lane, const LcdScoring &sc, int wb, int wf_milli, int beg_node, int end_node,
+// entries written to cig_node/cig_qpos in start->end order (block-uniform result).
+template <int NT>
+__device__ int align_to_subgraph(Ctx &g, Smem &sm, const LcdScoring &sc, int wb, int wf_milli, int beg_node, int end_node,
                                  const uint8_t *seq, int qlen, unsigned long long *cells_acc) {
+    constexpr int NW = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (qlen <= 0) return 0;
     const int bi = g.node2idx[beg_node], ei = g.node2idx[end_node];
     const int o1 = sc.o1, e1 = sc.e1, o2 = sc.o2, e2 = sc.e2, oe1 = o1 + e1, oe2 = o2 + e2;
-    // w = wb<0 ? qlen : wb + (int)(wf*qlen);  wf is 0.01 or 0 on this path: (int)(0.01*q) == q/100 for q < 2^31/100
+    // w = wb<0 ? qlen : wb + (int)(wf*qlen);  wf is 0.01 or 0 on this path: (int)(0.01*q) == q/100
     const int w = wb < 0 ? qlen : wb + (int)(((long long)wf_milli * qlen) / 1000);
     const int remain_end = g.remain[end_node];
     const int n = g.n_node;
-    // reachability map over [bi, ei]
+    // ---- reachability map over [bi, ei] ----
     if (bi == 0 && ei == n - 1) {
-        for (int i = lane; i < n; i += 64) g.imap[i] = 1;
+        for (int i = tid; i < n; i += NT) g.imap[i] = 1;
     } else {
-        for (int i = bi + lane; i <= ei; i += 64) g.imap[i] = 0;
+        for (int i = bi + tid; i <= ei; i += NT) g.imap[i] = 0;
         __syncthreads();
-        if (lane == 0) {
+        if (tid == 0) {
             g.imap[bi] = 1; g.imap[ei] = 1;
             for (int i = bi; i < ei; ++i) {
                 if (!g.imap[i]) continue;
@@ -203,66 +232,119 @@ __device__ int align_to_subgraph(Ctx &g, int lane, const LcdScoring &sc, int wb,
             }
         }
     }
-    for (int i = lane; i < n; i += 64) { g.mpl[i] = 1 << 30; g.mpr[i] = 0; }
     __syncthreads();
+    // ---- row plan: CSR of usable predecessors (in edge order) + edge bonus, rows bi..ei ----
+    {
+        int carry = 0;
+        for (int base = bi; base <= ei; base += NT) {
+            const int idx = base + tid;
+            int cnt = 0, v = -1;
+            if (idx <= ei && g.imap[idx]) {
+                v = g.idx2node[idx];
+                for (int e = g.in_head[v]; e >= 0; e = g.e_next_in[e]) {
+                    int pi = g.node2idx[g.e_from[e]];
+                    cnt += (pi >= bi && pi < ei && g.imap[pi]);
+                }
+            }
+            const int incl = wave_incl_prefix_add(cnt, lane);
+            if (lane == 63) sm.scan[wave] = incl;
+            __syncthreads();
+            int woff = 0, tot = 0;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) { const int t = sm.scan[k]; if (k < wave) woff += t; tot += t; }
+            const int start = carry + woff + incl - cnt;
+            if (idx <= ei) {
+                g.pl_start[idx] = start;
+                if (v >= 0) {
+                    int k = start;
+                    for (int e = g.in_head[v]; e >= 0; e = g.e_next_in[e]) {
+                        int pi = g.node2idx[g.e_from[e]];
+                        if (pi >= bi && pi < ei && g.imap[pi]) { g.pl_pidx[k] = pi; g.pl_bonus[k] = ilog2_32(g.e_w[e]); ++k; }
+                    }
+                }
+            }
+            carry += tot;
+            __syncthreads();
+        }
+        if (tid == 0) g.pl_start[ei + 1] = carry;
+    }
     unsigned long long used = 0;
+    const long long t_dp0 = clock64();
     // ---- source row ----
+    int last_idx, last_beg, last_end, last_ml, last_mr; unsigned last_off;
     {
         int r = g.remain[beg_node] - remain_end;
         int end = qlen - r; if (end < 0) end = 0; end += w; if (end > qlen) end = qlen;
         if ((unsigned long long)end + 1 > g.cell_cap) { g.status = LCD_ERR_CELLS; return 0; }
-        if (lane == 0) { g.rbeg[bi] = 0; g.rend[bi] = end; g.roff[bi] = 0; }
-        for (int j = lane; j <= end; j += 64) {
+        if (tid == 0) { g.rbeg[bi] = 0; g.rend[bi] = end; g.roff[bi] = 0; g.ml[bi] = 0; g.mr[bi] = 0; }
+        for (int j = tid; j <= end; j += NT) {
             int f1 = j ? -(o1 + e1 * j) : LCD_NEG, f2 = j ? -(o2 + e2 * j) : LCD_NEG;
             int h = j ? imax(f1, f2) : 0;
             g.H[j] = h; g.E1[j] = h - oe1; g.E2[j] = h - oe2;
         }
         used = end + 1;
-        if (lane == 0)
-            for (int e = g.out_head[beg_node]; e >= 0; e = g.e_next_out[e]) {
-                int o = g.e_to[e];
-                g.mpl[o] = imin(g.mpl[o], 1); g.mpr[o] = imax(g.mpr[o], 1);
-            }
+        last_idx = bi; last_beg = 0; last_end = end; last_ml = 0; last_mr = 0; last_off = 0;
         __syncthreads();
     }
     // ---- rows ----
     for (int idx = bi + 1; idx < ei; ++idx) {
-        if (!g.imap[idx]) { if (lane == 0) { g.rbeg[idx] = 1; g.rend[idx] = 0; g.roff[idx] = (uint32_t)used; } __syncthreads(); continue; }
+        if (!g.imap[idx]) {
+            if (tid == 0) { g.rbeg[idx] = 1; g.rend[idx] = 0; g.roff[idx] = (uint32_t)used; g.ml[idx] = 0; g.mr[idx] = 0; }
+            __syncthreads();
+            continue;
+        }
         const int v = g.idx2node[idx];
-        const int rem = g.remain[v] - remain_end;
-        int beg = imin(g.mpl[v], qlen - rem) - w; if (beg < 0) beg = 0;
-        int end = imax(g.mpr[v], qlen - rem) + w; if (end > qlen) end = qlen;
-        int minpb = 1 << 30, maxpe = -1;
-        for (int e = g.in_head[v]; e >= 0; e = g.e_next_in[e]) {
-            int pi = g.node2idx[g.e_from[e]];
-            if (pi < bi || pi >= ei || !g.imap[pi]) continue;
-            int pb = g.rbeg[pi], pe = g.rend[pi];
+        const int p0 = g.pl_start[idx], np = g.pl_start[idx + 1] - p0;
+        // stage predecessor metadata in LDS (the row just computed comes from registers, not from HBM)
+        if (tid < np && tid < MAXP) {
+            const int pi = g.pl_pidx[p0 + tid];
+            sm.bonus[tid] = g.pl_bonus[p0 + tid];
+            if (pi == last_idx) { sm.pb[tid] = last_beg; sm.pe[tid] = last_end; sm.po[tid] = last_off; sm.pml[tid] = last_ml; sm.pmr[tid] = last_mr; }
+            else { sm.pb[tid] = g.rbeg[pi]; sm.pe[tid] = g.rend[pi]; sm.po[tid] = g.roff[pi]; sm.pml[tid] = g.ml[pi]; sm.pmr[tid] = g.mr[pi]; }
+        }
+        __syncthreads();
+        // band: pulled from the predecessors' row-max columns (same values the oracle pushes to successors)
+        int mplv = 1 << 30, mprv = 0, minpb = 1 << 30, maxpe = -1;
+        for (int t = 0; t < np; ++t) {
+            int pb, pe, pml, pmr;
+            if (t < MAXP) { pb = sm.pb[t]; pe = sm.pe[t]; pml = sm.pml[t]; pmr = sm.pmr[t]; }
+            else { const int pi = g.pl_pidx[p0 + t]; pb = g.rbeg[pi]; pe = g.rend[pi]; pml = g.ml[pi]; pmr = g.mr[pi]; }
             if (pb > pe) continue;
             minpb = imin(minpb, pb); maxpe = imax(maxpe, pe);
+            mplv = imin(mplv, pml + 1); mprv = imax(mprv, pmr + 1);
         }
+        const int rem = g.remain[v] - remain_end;
+        int beg = imin(mplv, qlen - rem) - w; if (beg < 0) beg = 0;
+        int end = imax(mprv, qlen - rem) + w; if (end > qlen) end = qlen;
         if (beg < minpb) beg = minpb;
         if (end > maxpe + 1) end = maxpe + 1;
-        if (beg > end) { if (lane == 0) { g.rbeg[idx] = 1; g.rend[idx] = 0; g.roff[idx] = (uint32_t)used; } __syncthreads(); continue; }
+        if (beg > end) {
+            if (tid == 0) { g.rbeg[idx] = 1; g.rend[idx] = 0; g.roff[idx] = (uint32_t)used; g.ml[idx] = 0; g.mr[idx] = 0; }
+            __syncthreads();
+            continue;
+        }
         const unsigned long long off = used;
-        used += (unsigned long long)(end - beg + 1);
+        const int width = end - beg + 1;
+        used += (unsigned long long)width;
         if (used > g.cell_cap) { g.status = LCD_ERR_CELLS; return 0; }
-        if (lane == 0) { g.rbeg[idx] = beg; g.rend[idx] = end; g.roff[idx] = (uint32_t)off; }
+        if (tid == 0) { g.rbeg[idx] = beg; g.rend[idx] = end; g.roff[idx] = (uint32_t)off; }
         const uint8_t vb = g.base[v];
-        int carry1 = LCD_NEG, carry2 = LCD_NEG; // running max of Hpre[k]+k*e over previous chunks (k*e can be large: use offsets from beg)
+        const int nchunks = (width + 63) >> 6;
+        int carry1 = LCD_NEG * 2, carry2 = LCD_NEG * 2;
         int best_h = LCD_NEG - 64, best_l = 1 << 30, best_r = -1;
-        for (int c0 = beg; c0 <= end; c0 += 64) {
-            const int j = c0 + lane;
+        int round = 0;
+        for (int c0 = 0; c0 < nchunks; c0 += NW, ++round) {
+            const int rel = ((c0 + wave) << 6) + lane;
+            const int j = beg + rel;
             const bool act = j <= end;
             int mx = LCD_NEG, e1i = LCD_NEG, e2i = LCD_NEG;
-            int s = 0;
-            if (act && j >= 1) { uint8_t qb = seq[j - 1]; s = (vb >= 4 || qb >= 4) ? 0 : (vb == qb ? sc.match : -sc.mismatch); }
-            for (int e = g.in_head[v]; e >= 0; e = g.e_next_in[e]) {
-                int pi = g.node2idx[g.e_from[e]];
-                if (pi < bi || pi >= ei || !g.imap[pi]) continue;
-                const int pb = g.rbeg[pi], pe = g.rend[pi];
-                const uint32_t po = g.roff[pi];
-                const int bonus = ilog2_32(g.e_w[e]);
-                if (act) {
+            if (act) {
+                int s = 0;
+                if (j >= 1) { const uint8_t qb = seq[j - 1]; s = (vb >= 4 || qb >= 4) ? 0 : (vb == qb ? sc.match : -sc.mismatch); }
+                for (int t = 0; t < np; ++t) {
+                    int pb, pe, bonus; unsigned po;
+                    if (t < MAXP) { pb = sm.pb[t]; pe = sm.pe[t]; po = sm.po[t]; bonus = sm.bonus[t]; }
+                    else { const int pi = g.pl_pidx[p0 + t]; pb = g.rbeg[pi]; pe = g.rend[pi]; po = g.roff[pi]; bonus = g.pl_bonus[p0 + t]; }
                     if (j >= 1 && j - 1 >= pb && j - 1 <= pe) mx = imax(mx, g.H[po + (j - 1 - pb)] + s + bonus);
                     if (j >= pb && j <= pe) {
                         e1i = imax(e1i, g.E1[po + (j - pb)] + bonus);
@@ -270,46 +352,79 @@ __device__ int align_to_subgraph(Ctx &g, int lane, const LcdScoring &sc, int wb,
                     }
                 }
             }
-            int hpre = imax(mx, imax(e1i, e2i));
-            // F via exclusive prefix max of A[k] = Hpre[k] + (k-beg)*e
-            const int rel = j - beg;
-            int a1 = act ? hpre + rel * e1 : LCD_NEG * 2, a2 = act ? hpre + rel * e2 : LCD_NEG * 2;
-            int p1 = wave_excl_prefix_max(a1, lane, LCD_NEG * 2), p2 = wave_excl_prefix_max(a2, lane, LCD_NEG * 2);
-            p1 = imax(p1, carry1); p2 = imax(p2, carry2);
-            int f1 = (j > beg) ? imax(LCD_NEG, p1 - o1 - rel * e1) : LCD_NEG;
-            int f2 = (j > beg) ? imax(LCD_NEG, p2 - o2 - rel * e2) : LCD_NEG;
-            carry1 = imax(carry1, wave_max(a1)); carry2 = imax(carry2, wave_max(a2));
-            int h = imax(hpre, imax(f1, f2)); if (h < LCD_NEG) h = LCD_NEG;
-            int eo1 = imax(h - oe1, e1i - e1), eo2 = imax(h - oe2, e2i - e2);
-            if (eo1 < LCD_NEG) eo1 = LCD_NEG;
-            if (eo2 < LCD_NEG) eo2 = LCD_NEG;
+            const int hpre = imax(mx, imax(e1i, e2i));
+            // F via prefix max of A[k] = Hpre[k] + (k-beg)*e : inside the wavefront by shuffles, across wavefronts through LDS
+            const int a1 = act ? hpre + rel * e1 : LCD_NEG * 2, a2 = act ? hpre + rel * e2 : LCD_NEG * 2;
+            const int i1 = wave_incl_prefix_max(a1, lane), i2 = wave_incl_prefix_max(a2, lane);
+            int p1 = __shfl_up(i1, 1), p2 = __shfl_up(i2, 1);
+            if (lane == 0) { p1 = LCD_NEG * 2; p2 = LCD_NEG * 2; }
+            const int buf = round & 1;
+            if (NW > 1) {
+                if (lane == 63) { sm.tot1[buf][wave] = i1; sm.tot2[buf][wave] = i2; }
+                __syncthreads();
+                int all1 = carry1, all2 = carry2;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) {
+                    const int t1 = sm.tot1[buf][k], t2 = sm.tot2[buf][k];
+                    if (k < wave) { p1 = imax(p1, t1); p2 = imax(p2, t2); }
+                    all1 = imax(all1, t1); all2 = imax(all2, t2);
+                }
+                p1 = imax(p1, carry1); p2 = imax(p2, carry2);
+                carry1 = all1; carry2 = all2;
+            } else {
+                p1 = imax(p1, carry1); p2 = imax(p2, carry2);
+                carry1 = imax(carry1, __shfl(i1, 63)); carry2 = imax(carry2, __shfl(i2, 63));
+            }
             if (act) {
+                const int f1 = (j > beg) ? imax(LCD_NEG, p1 - o1 - rel * e1) : LCD_NEG;
+                const int f2 = (j > beg) ? imax(LCD_NEG, p2 - o2 - rel * e2) : LCD_NEG;
+                int h = imax(hpre, imax(f1, f2)); if (h < LCD_NEG) h = LCD_NEG;
+                int eo1 = imax(h - oe1, e1i - e1), eo2 = imax(h - oe2, e2i - e2);
+                if (eo1 < LCD_NEG) eo1 = LCD_NEG;
+                if (eo2 < LCD_NEG) eo2 = LCD_NEG;
                 g.H[off + rel] = h; g.E1[off + rel] = eo1; g.E2[off + rel] = eo2;
                 if (h > best_h) { best_h = h; best_l = j; best_r = j; } else if (h == best_h) best_r = j;
             }
         }
         // row maximum, leftmost / rightmost column
-        int rowmax = wave_max(best_h);
-        int ml = wave_min(best_h == rowmax ? best_l : (1 << 30));
-        int mr = wave_max(best_h == rowmax ? best_r : -1);
-        if (lane == 0)
-            for (int e = g.out_head[v]; e >= 0; e = g.e_next_out[e]) {
-                int o = g.e_to[e];
-                g.mpl[o] = imin(g.mpl[o], ml + 1); g.mpr[o] = imax(g.mpr[o], mr + 1);
+        int ml, mr;
+        {
+            const int wmax = wave_max(best_h);
+            const int wl = wave_min(best_h == wmax ? best_l : (1 << 30));
+            const int wr = wave_max(best_h == wmax ? best_r : -1);
+            if (NW > 1) {
+                if (lane == 0) { sm.bh[wave] = wmax; sm.bl[wave] = wl; sm.br[wave] = wr; }
+                __syncthreads();
+                int rowmax = sm.bh[0];
+#pragma unroll
+                for (int k = 1; k < NW; ++k) rowmax = imax(rowmax, sm.bh[k]);
+                ml = 1 << 30; mr = -1;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) if (sm.bh[k] == rowmax) { ml = imin(ml, sm.bl[k]); mr = imax(mr, sm.br[k]); }
+            } else {
+                ml = wl; mr = wr;
+                __syncthreads(); // row data + staging reuse
             }
-        __syncthreads();
+        }
+        if (tid == 0) { g.ml[idx] = ml; g.mr[idx] = mr; }
+        last_idx = idx; last_beg = beg; last_end = end; last_ml = ml; last_mr = mr; last_off = (unsigned)off;
     }
+    __syncthreads();
     *cells_acc += used;
-    // ---- end node: best predecessor at column qlen, then backtrack (lane 0) ----
-    int n_cig = 0;
-    if (lane == 0) {
+    const long long t_bt0 = clock64();
+    g.t_dp += (unsigned long long)(t_bt0 - t_dp0);
+    // ---- end node: best predecessor at column qlen, then backtrack (thread 0) ----
+    if (tid == 0) {
+        int n_cig = 0;
         int best = LCD_NEG, br = -1;
-        for (int e = g.in_head[end_node]; e >= 0; e = g.e_next_in[e]) {
-            int pi = g.node2idx[g.e_from[e]];
-            if (pi < bi || pi >= ei || !g.imap[pi]) continue;
-            if (qlen < g.rbeg[pi] || qlen > g.rend[pi]) continue;
-            int c = g.H[g.roff[pi] + (qlen - g.rbeg[pi])] + ilog2_32(g.e_w[e]);
-            if (c > best) { best = c; br = pi; }
+        {
+            const int p0 = g.pl_start[ei], np = g.pl_start[ei + 1] - p0;
+            for (int t = 0; t < np; ++t) {
+                const int pi = g.pl_pidx[p0 + t];
+                if (qlen < g.rbeg[pi] || qlen > g.rend[pi]) continue;
+                int c = g.H[g.roff[pi] + (qlen - g.rbeg[pi])] + g.pl_bonus[p0 + t];
+                if (c > best) { best = c; br = pi; }
+            }
         }
         if (br >= 0 && best > LCD_NEG / 2) {
             int pos = qlen;
@@ -318,24 +433,25 @@ __device__ int align_to_subgraph(Ctx &g, int lane, const LcdScoring &sc, int wb,
 #define INB(pi, jj) ((jj) >= g.rbeg[pi] && (jj) <= g.rend[pi])
             while (i != bi && j > 0 && g.status == LCD_OK) {
                 const int v = g.idx2node[i];
+                const int p0 = g.pl_start[i], np = g.pl_start[i + 1] - p0;
                 if (st == 0) {
                     const int hv = CELLH(i, j);
                     bool hit = false;
-                    uint8_t vb = g.base[v], qb = seq[j - 1];
+                    const uint8_t vb = g.base[v], qb = seq[j - 1];
                     const int s = (vb >= 4 || qb >= 4) ? 0 : (vb == qb ? sc.match : -sc.mismatch);
-                    for (int e = g.in_head[v]; e >= 0 && !hit; e = g.e_next_in[e]) {
-                        int pi = g.node2idx[g.e_from[e]];
-                        if (pi < bi || pi >= ei || !g.imap[pi] || !INB(pi, j - 1)) continue;
-                        if (CELLH(pi, j - 1) + s + ilog2_32(g.e_w[e]) == hv) {
+                    for (int t = 0; t < np && !hit; ++t) {
+                        const int pi = g.pl_pidx[p0 + t];
+                        if (!INB(pi, j - 1)) continue;
+                        if (CELLH(pi, j - 1) + s + g.pl_bonus[p0 + t] == hv) {
                             --pos; g.cig_node[pos] = v; g.cig_qpos[pos] = j - 1; i = pi; --j; hit = true;
                         }
                     }
                     for (int c = 1; c <= 2 && !hit; ++c) {
                         const int *E = c == 1 ? g.E1 : g.E2;
-                        for (int e = g.in_head[v]; e >= 0 && !hit; e = g.e_next_in[e]) {
-                            int pi = g.node2idx[g.e_from[e]];
-                            if (pi < bi || pi >= ei || !g.imap[pi] || !INB(pi, j)) continue;
-                            if (E[g.roff[pi] + (j - g.rbeg[pi])] + ilog2_32(g.e_w[e]) == hv) { i = pi; st = c; hit = true; }
+                        for (int t = 0; t < np && !hit; ++t) {
+                            const int pi = g.pl_pidx[p0 + t];
+                            if (!INB(pi, j)) continue;
+                            if (E[g.roff[pi] + (j - g.rbeg[pi])] + g.pl_bonus[p0 + t] == hv) { i = pi; st = c; hit = true; }
                         }
                     }
                     if (!hit) {
@@ -355,10 +471,10 @@ __device__ int align_to_subgraph(Ctx &g, int lane, const LcdScoring &sc, int wb,
                     const int ev = E[g.roff[i] + (j - g.rbeg[i])];
                     if (CELLH(i, j) - oe == ev) { st = 0; continue; }
                     bool hit = false;
-                    for (int e = g.in_head[v]; e >= 0 && !hit; e = g.e_next_in[e]) {
-                        int pi = g.node2idx[g.e_from[e]];
-                        if (pi < bi || pi >= ei || !g.imap[pi] || !INB(pi, j)) continue;
-                        if (E[g.roff[pi] + (j - g.rbeg[pi])] + ilog2_32(g.e_w[e]) - ee == ev) { i = pi; hit = true; }
+                    for (int t = 0; t < np && !hit; ++t) {
+                        const int pi = g.pl_pidx[p0 + t];
+                        if (!INB(pi, j)) continue;
+                        if (E[g.roff[pi] + (j - g.rbeg[pi])] + g.pl_bonus[p0 + t] - ee == ev) { i = pi; hit = true; }
                     }
                     if (!hit) g.status = LCD_ERR_BACKTRACK;
                 }
@@ -369,28 +485,33 @@ __device__ int align_to_subgraph(Ctx &g, int lane, const LcdScoring &sc, int wb,
             n_cig = qlen - pos;
             if (pos > 0) for (int t = 0; t < n_cig; ++t) { g.cig_node[t] = g.cig_node[t + pos]; g.cig_qpos[t] = g.cig_qpos[t + pos]; }
         }
+        sm.bc[0] = n_cig; sm.bc[1] = g.status;
     }
-    n_cig = __shfl(n_cig, 0);
     __syncthreads();
+    const int n_cig = sm.bc[0];
+    g.status = sm.bc[1];
+    __syncthreads();
+    g.t_bt += (unsigned long long)(clock64() - t_bt0);
     return n_cig;
 }
 
 } // namespace
 
-// one wavefront per chain
-__global__ void __launch_bounds__(64) lcd_poa_chain_kernel(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool,
+template <int NT>
+__global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool,
                                                            uint8_t *arena, uint8_t *outpool, PoaChainOut *outs, LcdScoring sc,
                                                            int n_chains) {
     const int cid = blockIdx.x;
     if (cid >= n_chains) return;
-    const int lane = threadIdx.x;
+    __shared__ Smem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const PoaChain ch = chains[cid];
     const PoaLayout L = poa_layout(ch.node_cap, ch.edge_cap, ch.rid_words, ch.max_len, ch.cell_cap, ch.n_reads);
     uint8_t *ws = arena + ch.ws_off;
     Ctx g;
     g.H = (int *)(ws + L.H); g.E1 = (int *)(ws + L.E1); g.E2 = (int *)(ws + L.E2);
     g.rbeg = (int *)(ws + L.rbeg); g.rend = (int *)(ws + L.rend); g.roff = (uint32_t *)(ws + L.roff);
-    g.mpl = (int *)(ws + L.mpl); g.mpr = (int *)(ws + L.mpr);
+    g.ml = (int *)(ws + L.mpl); g.mr = (int *)(ws + L.mpr);
     g.idx2node = (int *)(ws + L.idx2node); g.node2idx = (int *)(ws + L.node2idx); g.remain = (int *)(ws + L.remain);
     g.deg = (int *)(ws + L.deg); g.queue = (int *)(ws + L.queue);
     g.out_head = (int *)(ws + L.n_out_head); g.out_tail = (int *)(ws + L.n_out_tail);
@@ -402,9 +523,12 @@ __global__ void __launch_bounds__(64) lcd_poa_chain_kernel(const PoaChain *chain
     g.cig_node = (int *)(ws + L.cig_node); g.cig_qpos = (int *)(ws + L.cig_qpos);
     g.base = ws + L.n_base; g.imap = ws + L.imap;
     g.het = (int *)(ws + L.het); g.clu = (int *)(ws + L.clu); g.nclu = (int *)(ws + L.nclu); g.prof = ws + L.prof;
+    g.pl_start = (int *)(ws + L.pl_start); g.pl_pidx = (int *)(ws + L.pl_pidx); g.pl_bonus = (int *)(ws + L.pl_bonus);
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
-    g.n_node = 2; g.n_edge = 0; g.status = LCD_OK;
-    if (lane == 0)
+    g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0;
+    const long long t_begin = clock64();
+    unsigned long long t_graph = 0, t_sub = 0;
+    if (tid == 0)
         for (int i = 0; i < 2; ++i) {
             g.base[i] = 4; g.out_head[i] = g.out_tail[i] = g.in_head[i] = g.in_tail[i] = -1; g.nin[i] = 0; g.aligned[i] = i;
         }
@@ -413,32 +537,42 @@ __global__ void __launch_bounds__(64) lcd_poa_chain_kernel(const PoaChain *chain
     int n_aligned_reads = 0;
     const int n_seq = ch.n_reads;
     const PoaRead *rd = reads + ch.read0;
-    const int backbone_len = rd[0].len;
-    (void)backbone_len;
     for (int i = 0; i < n_seq && g.status == LCD_OK; ++i) {
         const PoaRead r = rd[i];
         if (r.skip) continue;
         int exc_beg = 0, exc_end = 1, beg_cut = 0, end_cut = 0;
         if (ch.mode == 0 && i != 0) {
+            const long long ts0 = clock64();
             beg_cut = r.read_beg - 1; end_cut = r.len - r.read_end;
-            subgraph_nodes(g, lane, r.ref_beg + 1, r.ref_end + 1, &exc_beg, &exc_end);
+            if (wave == 0) {
+                int eb, ee;
+                subgraph_nodes_wave0(g, lane, r.ref_beg + 1, r.ref_end + 1, &eb, &ee);
+                if (lane == 0) { sm.bc[2] = eb; sm.bc[3] = ee; }
+            }
+            __syncthreads();
+            exc_beg = sm.bc[2]; exc_end = sm.bc[3];
+            __syncthreads();
+            t_sub += (unsigned long long)(clock64() - ts0);
         }
         const uint8_t *seq = pool + r.seq_off + beg_cut;
         const int len = r.len - beg_cut - end_cut;
         int n_cig = 0;
         if (g.n_node > 2) {
-            n_cig = align_to_subgraph(g, lane, sc, ch.mode == 0 ? 10 : -1, ch.mode == 0 ? 10 : 0, exc_beg, exc_end, seq, len, &cells);
+            n_cig = align_to_subgraph<NT>(g, sm, sc, ch.mode == 0 ? 10 : -1, ch.mode == 0 ? 10 : 0, exc_beg, exc_end, seq, len, &cells);
             if (len > 0) { aligned_bases += len; n_aligned_reads++; }
         }
-        // graph update + re-sort: serial pointer work, lane 0; results published through memory
-        int nn = 0, ne = 0, st = 0;
-        if (lane == 0) {
+        // graph update + re-sort: serial pointer work on thread 0; results published through LDS
+        const long long tg0 = clock64();
+        if (tid == 0) {
             if (len > 0 && g.status == LCD_OK) add_alignment(g, exc_beg, exc_end, seq, len, n_cig, i);
-            nn = g.n_node; ne = g.n_edge; st = g.status;
+            sm.bc[4] = g.n_node; sm.bc[5] = g.n_edge; sm.bc[6] = g.status;
         }
-        g.n_node = __shfl(nn, 0); g.n_edge = __shfl(ne, 0); g.status = __shfl(st, 0);
         __syncthreads();
+        g.n_node = sm.bc[4]; g.n_edge = sm.bc[5]; g.status = sm.bc[6];
+        __syncthreads();
+        t_graph += (unsigned long long)(clock64() - tg0);
     }
+    const long long t_out0 = clock64();
     // ---------------- output: MSA rank, rows, clusters, consensus (oracle/poa.c poa_output) ----------------
     PoaChainOut out;
     out.status = g.status; out.n_cons = 0; out.cons_len[0] = out.cons_len[1] = 0; out.msa_len = 0; out.clu_n[0] = out.clu_n[1] = 0;
@@ -451,22 +585,23 @@ __global__ void __launch_bounds__(64) lcd_poa_chain_kernel(const PoaChain *chain
     if (g.status == LCD_OK && g.n_node > 2) {
         const int n = g.n_node;
         int *rank = g.deg;
-        int ncol = 0;
-        if (lane == 0) {
+        if (tid == 0) {
+            int nc = 0;
             for (int i = 0; i < n; ++i) rank[i] = -1;
             for (int idx = 1; idx < n - 1; ++idx) {
                 int v = g.idx2node[idx];
                 if (rank[v] >= 0) continue;
-                rank[v] = ncol;
-                for (int a = g.aligned[v]; a != v; a = g.aligned[a]) rank[a] = ncol;
-                ++ncol;
+                rank[v] = nc;
+                for (int a = g.aligned[v]; a != v; a = g.aligned[a]) rank[a] = nc;
+                ++nc;
             }
+            sm.bc[0] = nc;
         }
-        ncol = __shfl(ncol, 0);
         __syncthreads();
-        for (size_t t = lane; t < (size_t)(n_seq + 2) * ncol; t += 64) msa[(t / ncol) * (size_t)nc_cap + (t % ncol)] = LCD_GAP;
+        const int ncol = sm.bc[0];
+        for (size_t t = tid; t < (size_t)(n_seq + 2) * ncol; t += NT) msa[(t / ncol) * (size_t)nc_cap + (t % ncol)] = LCD_GAP;
         __syncthreads();
-        for (int v = 2 + lane; v < n; v += 64) {
+        for (int v = 2 + tid; v < n; v += NT) {
             const int col = rank[v]; const uint8_t b = g.base[v];
             for (int e = g.out_head[v]; e >= 0; e = g.e_next_out[e])
                 for (int wd = 0; wd < g.rid_words; ++wd) {
@@ -474,57 +609,61 @@ __global__ void __launch_bounds__(64) lcd_poa_chain_kernel(const PoaChain *chain
                     while (bits) { int r = __ffsll((long long)bits) - 1; bits &= bits - 1; msa[(size_t)(wd * 64 + r) * nc_cap + col] = b; }
                 }
         }
+        for (int r = tid; r < n_seq; r += NT) g.clu[r] = 0;
         __syncthreads();
-        // clustering
+        // clustering + consensus run on wavefront 0 (ballot compactions); the other wavefronts only meet the barriers
         int n_clu = 1;
-        for (int r = lane; r < n_seq; r += 64) g.clu[r] = 0;
-        __syncthreads();
         if (ch.mode == 1 && n_seq >= 2) {
             const int min_w = (int)ch.min_w;
-            // het columns (ordered compaction, 64 columns per step)
-            int n_het = 0;
-            for (int c0 = 0; c0 < ncol; c0 += 64) {
-                int c = c0 + lane, ishet = 0;
-                if (c < ncol) {
-                    int cnt[6] = {0, 0, 0, 0, 0, 0};
-                    for (int r = 0; r < n_seq; ++r) cnt[msa[(size_t)r * nc_cap + c]]++;
-                    int k = 0;
-                    for (int a = 0; a < 6; ++a) k += cnt[a] >= min_w;
-                    ishet = k >= 2;
+            if (wave == 0) {
+                int n_het = 0;
+                for (int c0 = 0; c0 < ncol; c0 += 64) {
+                    int c = c0 + lane, ishet = 0;
+                    if (c < ncol) {
+                        int cnt[6] = {0, 0, 0, 0, 0, 0};
+                        for (int r = 0; r < n_seq; ++r) cnt[msa[(size_t)r * nc_cap + c]]++;
+                        int k = 0;
+                        for (int a = 0; a < 6; ++a) k += cnt[a] >= min_w;
+                        ishet = k >= 2;
+                    }
+                    unsigned long long m = __ballot(ishet);
+                    if (ishet) g.het[n_het + __popcll(m & ((1ull << lane) - 1))] = c;
+                    n_het += __popcll(m);
                 }
-                unsigned long long m = __ballot(ishet);
-                if (ishet) g.het[n_het + __popcll(m & ((1ull << lane) - 1))] = c;
-                n_het += __popcll(m);
+                if (lane == 0) sm.bc[1] = n_het;
             }
             __syncthreads();
+            const int n_het = sm.bc[1];
             if (n_het > 0) {
-                // pivot: most balanced het column (largest runner-up count, leftmost)
-                int bv2 = -1, bh = 1 << 30, ba0 = 0, ba1 = 0;
-                for (int h = lane; h < n_het; h += 64) {
-                    int cnt[6] = {0, 0, 0, 0, 0, 0};
-                    for (int r = 0; r < n_seq; ++r) cnt[msa[(size_t)r * nc_cap + g.het[h]]]++;
-                    int m0 = 0; for (int a = 1; a < 6; ++a) if (cnt[a] > cnt[m0]) m0 = a;
-                    int m1 = -1; for (int a = 0; a < 6; ++a) if (a != m0 && (m1 < 0 || cnt[a] > cnt[m1])) m1 = a;
-                    if (cnt[m1] > bv2) { bv2 = cnt[m1]; bh = h; ba0 = m0; ba1 = m1; }
+                if (wave == 0) {
+                    int bv2 = -1, bh = 1 << 30, ba0 = 0, ba1 = 0;
+                    for (int h = lane; h < n_het; h += 64) {
+                        int cnt[6] = {0, 0, 0, 0, 0, 0};
+                        for (int r = 0; r < n_seq; ++r) cnt[msa[(size_t)r * nc_cap + g.het[h]]]++;
+                        int m0 = 0; for (int a = 1; a < 6; ++a) if (cnt[a] > cnt[m0]) m0 = a;
+                        int m1 = -1; for (int a = 0; a < 6; ++a) if (a != m0 && (m1 < 0 || cnt[a] > cnt[m1])) m1 = a;
+                        if (cnt[m1] > bv2) { bv2 = cnt[m1]; bh = h; ba0 = m0; ba1 = m1; }
+                    }
+                    int gv2 = wave_max(bv2);
+                    int gh = wave_min(bv2 == gv2 ? bh : (1 << 30));
+                    int src = __ffsll((long long)__ballot(bv2 == gv2 && bh == gh)) - 1;
+                    const int a0 = __shfl(ba0, src), a1 = __shfl(ba1, src);
+                    const int pcol = g.het[gh];
+                    for (int r = lane; r < n_seq; r += 64) { int al = msa[(size_t)r * nc_cap + pcol]; g.clu[r] = al == a0 ? 0 : al == a1 ? 1 : -1; }
                 }
-                int gv2 = wave_max(bv2);
-                int gh = wave_min(bv2 == gv2 ? bh : (1 << 30));
-                int src = __ffsll((long long)__ballot(bv2 == gv2 && bh == gh)) - 1;
-                const int a0 = __shfl(ba0, src), a1 = __shfl(ba1, src);
-                const int pcol = g.het[gh];
-                for (int r = lane; r < n_seq; r += 64) { int al = msa[(size_t)r * nc_cap + pcol]; g.clu[r] = al == a0 ? 0 : al == a1 ? 1 : -1; }
                 __syncthreads();
                 for (int it = 0; it < 10; ++it) {
-                    for (int t = lane; t < 2 * n_het; t += 64) {
+                    for (int t = tid; t < 2 * n_het; t += NT) {
                         int c = t / n_het, h = t % n_het;
                         int cnt[6] = {0, 0, 0, 0, 0, 0};
                         for (int r = 0; r < n_seq; ++r) if (g.clu[r] == c) cnt[msa[(size_t)r * nc_cap + g.het[h]]]++;
                         int m0 = 0; for (int a = 1; a < 6; ++a) if (cnt[a] > cnt[m0]) m0 = a;
                         g.prof[t] = (uint8_t)m0;
                     }
+                    if (tid == 0) sm.bc[2] = 0;
                     __syncthreads();
                     int changed = 0;
-                    for (int r = lane; r < n_seq; r += 64) {
+                    for (int r = tid; r < n_seq; r += NT) {
                         int d0 = 0, d1 = 0;
                         for (int h = 0; h < n_het; ++h) {
                             uint8_t al = msa[(size_t)r * nc_cap + g.het[h]];
@@ -535,59 +674,82 @@ __global__ void __launch_bounds__(64) lcd_poa_chain_kernel(const PoaChain *chain
                         if (nc != cur) changed = 1;
                         g.nclu[r] = nc;
                     }
+                    if (changed) sm.bc[2] = 1;
                     __syncthreads();
-                    for (int r = lane; r < n_seq; r += 64) g.clu[r] = g.nclu[r];
+                    for (int r = tid; r < n_seq; r += NT) g.clu[r] = g.nclu[r];
+                    const int any_changed = sm.bc[2];
                     __syncthreads();
-                    if (!__any(changed)) break;
+                    if (!any_changed) break;
                 }
-                int c1 = 0;
-                for (int r = lane; r < n_seq; r += 64) c1 += g.clu[r];
-                for (int d = 32; d >= 1; d >>= 1) c1 += __shfl_xor(c1, d);
-                const int c0n = n_seq - c1;
+                if (wave == 0) {
+                    int c1 = 0;
+                    for (int r = lane; r < n_seq; r += 64) c1 += g.clu[r];
+                    for (int d = 32; d >= 1; d >>= 1) c1 += __shfl_xor(c1, d);
+                    if (lane == 0) sm.bc[3] = c1;
+                }
+                __syncthreads();
+                const int c1 = sm.bc[3], c0n = n_seq - c1;
                 if (c0n >= min_w && c1 >= min_w) {
                     n_clu = 2;
-                    if (c1 > c0n) for (int r = lane; r < n_seq; r += 64) g.clu[r] ^= 1;
+                    if (c1 > c0n) for (int r = tid; r < n_seq; r += NT) g.clu[r] ^= 1;
                 } else
-                    for (int r = lane; r < n_seq; r += 64) g.clu[r] = 0;
+                    for (int r = tid; r < n_seq; r += NT) g.clu[r] = 0;
                 __syncthreads();
             }
         }
         out.n_cons = n_clu; out.msa_len = ncol;
         for (int c = 0; c < n_clu; ++c) {
-            // member list, ascending read index (ordered compaction)
-            int csize = 0;
-            for (int r0 = 0; r0 < n_seq; r0 += 64) {
-                int r = r0 + lane, in = r < n_seq && g.clu[r] == c;
-                unsigned long long m = __ballot(in);
-                if (in) clu_ids[c * n_seq + csize + __popcll(m & ((1ull << lane) - 1))] = r;
-                csize += __popcll(m);
+            if (wave == 0) {
+                int csize = 0;
+                for (int r0 = 0; r0 < n_seq; r0 += 64) {
+                    int r = r0 + lane, in = r < n_seq && g.clu[r] == c;
+                    unsigned long long m = __ballot(in);
+                    if (in) clu_ids[c * n_seq + csize + __popcll(m & ((1ull << lane) - 1))] = r;
+                    csize += __popcll(m);
+                }
+                if (lane == 0) sm.bc[4] = csize;
             }
             __syncthreads();
+            const int csize = sm.bc[4];
             out.clu_n[c] = csize;
             uint8_t *crow = msa + (size_t)(n_seq + c) * nc_cap;
             uint8_t *cons = c == 0 ? cons0 : cons1;
-            int cl = 0;
-            for (int c0 = 0; c0 < ncol; c0 += 64) {
-                int col = c0 + lane, emit = 0, mb = 0;
-                if (col < ncol) {
-                    int cnt[6] = {0, 0, 0, 0, 0, 0};
-                    for (int k = 0; k < csize; ++k) cnt[msa[(size_t)clu_ids[c * n_seq + k] * nc_cap + col]]++;
-                    for (int a = 1; a < 5; ++a) if (cnt[a] > cnt[mb]) mb = a;
-                    emit = cnt[mb] > 0 && cnt[mb] >= cnt[5];
+            if (wave == 0) {
+                int cl = 0;
+                for (int c0 = 0; c0 < ncol; c0 += 64) {
+                    int col = c0 + lane, emit = 0, mb = 0;
+                    if (col < ncol) {
+                        int cnt[6] = {0, 0, 0, 0, 0, 0};
+                        for (int k = 0; k < csize; ++k) cnt[msa[(size_t)clu_ids[c * n_seq + k] * nc_cap + col]]++;
+                        for (int a = 1; a < 5; ++a) if (cnt[a] > cnt[mb]) mb = a;
+                        emit = cnt[mb] > 0 && cnt[mb] >= cnt[5];
+                    }
+                    unsigned long long m = __ballot(emit);
+                    if (emit) { cons[cl + __popcll(m & ((1ull << lane) - 1))] = (uint8_t)mb; crow[col] = (uint8_t)mb; }
+                    cl += __popcll(m);
                 }
-                unsigned long long m = __ballot(emit);
-                if (emit) { cons[cl + __popcll(m & ((1ull << lane) - 1))] = (uint8_t)mb; crow[col] = (uint8_t)mb; }
-                cl += __popcll(m);
+                if (lane == 0) sm.bc[5] = cl;
             }
-            out.cons_len[c] = cl;
+            __syncthreads();
+            out.cons_len[c] = sm.bc[5];
             __syncthreads();
         }
     }
-    if (lane == 0) outs[cid] = out;
+    if (tid == 0) {
+        const long long t_end = clock64();
+        out.t_total = (unsigned long long)(t_end - t_begin); out.t_dp = g.t_dp; out.t_bt = g.t_bt; out.t_graph = t_graph; out.t_sub = t_sub;
+        out.t_out = (unsigned long long)(t_end - t_out0);
+        outs[cid] = out;
+    }
 }
 
-extern "C++" void lcd_launch_poa(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool, uint8_t *arena, uint8_t *outpool,
-                                 PoaChainOut *outs, LcdScoring sc, int n_chains, hipStream_t stream) {
+void lcd_launch_poa(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool, uint8_t *arena, uint8_t *outpool,
+                    PoaChainOut *outs, LcdScoring sc, int n_chains, int threads, hipStream_t stream) {
     if (n_chains <= 0) return;
-    hipLaunchKernelGGL(lcd_poa_chain_kernel, dim3(n_chains), dim3(64), 0, stream, chains, reads, pool, arena, outpool, outs, sc, n_chains);
+    if (threads <= 64)
+        hipLaunchKernelGGL(lcd_poa_chain_kernel<64>, dim3(n_chains), dim3(64), 0, stream, chains, reads, pool, arena, outpool, outs, sc, n_chains);
+    else if (threads <= 256)
+        hipLaunchKernelGGL(lcd_poa_chain_kernel<256>, dim3(n_chains), dim3(256), 0, stream, chains, reads, pool, arena, outpool, outs, sc, n_chains);
+    else
+        hipLaunchKernelGGL(lcd_poa_chain_kernel<1024>, dim3(n_chains), dim3(1024), 0, stream, chains, reads, pool, arena, outpool, outs, sc, n_chains);
 }

@@ -9,8 +9,8 @@ def main(db_path, out_path, title):
     cur = db.cursor()
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
     with open(out_path, "w") as f:
-        f.write(f"# {title}\n# source: rocprofv3 --kernel-trace --stats (durations in ns)\n")
-        f.write(f"{'kernel':70s} {'calls':>8s} {'total_ns':>16s} {'avg_ns':>14s} {'pct':>7s}\n")
+        f.write(f"# {title}\n# source: rocprofv3 --kernel-trace --stats (durations in us)\n")
+        f.write(f"{'kernel':70s} {'calls':>8s} {'total_us':>16s} {'avg_us':>14s} {'pct':>7s}\n")
         for name, calls, tot, avg, pct in rows:
             f.write(f"{name.split('(')[0][:70]:70s} {calls:8d} {tot:16.0f} {avg:14.1f} {pct:7.2f}\n")
         try:
