@@ -30,6 +30,8 @@ struct Smem {
     int bh[MAXW], bl[MAXW], br[MAXW];
     int pb[MAXP], pe[MAXP], bonus[MAXP], pml[MAXP], pmr[MAXP];
     unsigned po[MAXP];
+    int ppi[MAXP], pslot[MAXP];
+    int rm[4][5];          // ring slot meta: beg, end, HBM offset, row-max leftmost / rightmost column
     int scan[MAXW];
     int bc[8];
 };
@@ -44,7 +46,7 @@ struct Ctx {
     int *cig_node, *cig_qpos;
     uint8_t *base, *imap;
     int *het, *clu, *nclu; uint8_t *prof;
-    int *pl_start, *pl_pidx, *pl_bonus;
+    int *pl_start, *pl_pidx, *pl_bonus, *pl_rem; uint8_t *pl_base;
     int n_node, n_edge, node_cap, edge_cap, rid_words;
     unsigned long long cell_cap;
     int status;
@@ -201,12 +203,54 @@ __device__ void subgraph_nodes_wave0(Ctx &g, int lane, int inc_beg, int inc_end,
     *exc_beg = g.idx2node[up]; *exc_end = g.idx2node[down];
 }
 
+// ---- DPP wave scans (gfx9 row_shr / row_bcast forms; all 64 lanes must be active) ----
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_take(int identity, int v) { return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROWMASK, 0xf, false); }
+#define LCD_DPP_SCAN(OP, ID)                                        \
+    v = OP(v, dpp_take<0x111, 0xf>(ID, v)); v = OP(v, dpp_take<0x112, 0xf>(ID, v)); \
+    v = OP(v, dpp_take<0x114, 0xf>(ID, v)); v = OP(v, dpp_take<0x118, 0xf>(ID, v)); \
+    v = OP(v, dpp_take<0x142, 0xa>(ID, v)); v = OP(v, dpp_take<0x143, 0xc>(ID, v));
+__device__ __forceinline__ int iadd(int a, int b) { return a + b; }
+__device__ __forceinline__ int scan_max(int v) { LCD_DPP_SCAN(imax, LCD_NEG * 2) return v; }
+__device__ __forceinline__ int scan_min(int v) { LCD_DPP_SCAN(imin, (1 << 30)) return v; }
+__device__ __forceinline__ int scan_add(int v) { LCD_DPP_SCAN(iadd, 0) return v; }
+__device__ __forceinline__ int shr1(int identity, int v) { return dpp_take<0x138, 0xf>(identity, v); } // wave_shr:1
+__device__ __forceinline__ int lane63(int v) { return __builtin_amdgcn_readlane(v, 63); }
+
+// LDS-only workgroup barrier: orders LDS traffic without draining the HBM store queue (vmcnt), which a
+// __syncthreads() would do.  Single-wavefront workgroups need no s_barrier at all (LDS ops of one wave are in order).
+template <int NT>
+__device__ __forceinline__ void lds_barrier() {
+    if (NT > 64) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("" ::: "memory");
+}
+
+#define LCD_RL(v, t) __builtin_amdgcn_readlane((v), (t))
+
+template <int NT> struct Cfg;
+template <> struct Cfg<64> { static constexpr int WMAX = 256, K = 4, SEQ_CAP = 4096; };   // class 64: reads <= 3.7 kb by construction
+template <> struct Cfg<256> { static constexpr int WMAX = 1024, K = 2, SEQ_CAP = 51200; };
+template <> struct Cfg<1024> { static constexpr int WMAX = 4096, K = 2, SEQ_CAP = 51200; };
+// six per-symbol counters packed 3 x 21 bits into two 64-bit words (register-resident, no dynamic array indexing)
+struct Cnt6 {
+    unsigned long long a, b;
+    __device__ __forceinline__ Cnt6() : a(0), b(0) {}
+    __device__ __forceinline__ void add(int sym) { if (sym < 3) a += 1ull << (21 * sym); else b += 1ull << (21 * (sym - 3)); }
+    __device__ __forceinline__ int get(int sym) const { return (int)(((sym < 3 ? a >> (21 * sym) : b >> (21 * (sym - 3)))) & 0x1fffff); }
+};
+constexpr int RMAX = 4; // 64-column chunks per wavefront per sweep: NW*RMAX*64 == WMAX
+
 // banded convex-gap global alignment of seq[0..qlen) to the sub-graph (beg_node,end_node); returns #cigar
 // entries written to cig_node/cig_qpos in start->end order (block-uniform result).
+//
+// Row data flow: every row is written to HBM (the backtrack and far predecessors read it there) AND, when it
+// fits, into a K-slot LDS ring; a predecessor that is still in the ring is read from LDS, so the common
+// row-to-row dependency never waits for an HBM store->load round trip.  HBM rows are only read once a full
+// barrier has drained the stores issued before it (tracked with last_full).
 template <int NT>
-__device__ int align_to_subgraph(Ctx &g, Smem &sm, const LcdScoring &sc, int wb, int wf_milli, int beg_node, int end_node,
-                                 const uint8_t *seq, int qlen, unsigned long long *cells_acc) {
-    constexpr int NW = NT / 64;
+__device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, const LcdScoring &sc, int wb, int wf_milli, int beg_node, int end_node,
+                                 const uint8_t *seq_hbm, int qlen, unsigned long long *cells_acc) {
+    constexpr int NW = NT / 64, WMAX = Cfg<NT>::WMAX, K = Cfg<NT>::K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (qlen <= 0) return 0;
     const int bi = g.node2idx[beg_node], ei = g.node2idx[end_node];
@@ -215,6 +259,12 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, const LcdScoring &sc, int wb,
     const int w = wb < 0 ? qlen : wb + (int)(((long long)wf_milli * qlen) / 1000);
     const int remain_end = g.remain[end_node];
     const int n = g.n_node;
+    // the read's bases are re-read by every row: keep them in LDS when they fit
+    // (two explicit pointers, never one that may be either: a maybe-LDS pointer compiles to FLAT loads, whose s_waitcnt
+    //  couples vmcnt and lgkmcnt and would stall every chunk behind the row stores still draining to HBM)
+    const uint8_t *seq = seq_hbm;
+    if (qlen > Cfg<NT>::SEQ_CAP) { g.status = LCD_ERR_NODES; return 0; } // read slice longer than the LDS query cache (host sizes the class)
+    for (int i = tid; i < qlen; i += NT) sseq[i] = seq_hbm[i];
     // ---- reachability map over [bi, ei] ----
     if (bi == 0 && ei == n - 1) {
         for (int i = tid; i < n; i += NT) g.imap[i] = 1;
@@ -233,7 +283,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, const LcdScoring &sc, int wb,
         }
     }
     __syncthreads();
-    // ---- row plan: CSR of usable predecessors (in edge order) + edge bonus, rows bi..ei ----
+    // ---- row plan: per row (by topological index) remain / base / CSR of usable predecessors + edge bonus ----
     {
         int carry = 0;
         for (int base = bi; base <= ei; base += NT) {
@@ -246,7 +296,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, const LcdScoring &sc, int wb,
                     cnt += (pi >= bi && pi < ei && g.imap[pi]);
                 }
             }
-            const int incl = wave_incl_prefix_add(cnt, lane);
+            const int incl = scan_add(cnt);
             if (lane == 63) sm.scan[wave] = incl;
             __syncthreads();
             int woff = 0, tot = 0;
@@ -255,6 +305,8 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, const LcdScoring &sc, int wb,
             const int start = carry + woff + incl - cnt;
             if (idx <= ei) {
                 g.pl_start[idx] = start;
+                g.pl_rem[idx] = v >= 0 ? g.remain[v] - remain_end : (1 << 30); // 1<<30: row not reachable from beg
+                g.pl_base[idx] = v >= 0 ? g.base[v] : 4;
                 if (v >= 0) {
                     int k = start;
                     for (int e = g.in_head[v]; e >= 0; e = g.e_next_in[e]) {
@@ -266,61 +318,123 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, const LcdScoring &sc, int wb,
             carry += tot;
             __syncthreads();
         }
-        if (tid == 0) g.pl_start[ei + 1] = carry;
+        if (tid == 0) { g.pl_start[ei + 1] = carry; g.pl_start[ei + 2] = carry; g.pl_start[ei + 3] = carry; }
     }
+    __syncthreads();
     unsigned long long used = 0;
     const long long t_dp0 = clock64();
+    // ring bookkeeping (block-uniform registers): which row each slot holds; meta of ring rows lives in sm.rm
+    int si0 = -1, si1 = -1, si2 = -1, si3 = -1; // row held by ring slot 0..3 (scalars, not an array: keeps them out of scratch)
+#define LCD_SLOT_OF(pi) ((pi) == si0 ? 0 : (K > 1 && (pi) == si1) ? 1 : (K > 2 && (pi) == si2) ? 2 : (K > 3 && (pi) == si3) ? 3 : -1)
+    int next_slot = 0;
+    int last_full = bi; // every row with index < last_full is complete in HBM
     // ---- source row ----
-    int last_idx, last_beg, last_end, last_ml, last_mr; unsigned last_off;
+    int last_idx, last_beg, last_end, last_ml, last_mr, last_slot; unsigned last_off;
     {
         int r = g.remain[beg_node] - remain_end;
         int end = qlen - r; if (end < 0) end = 0; end += w; if (end > qlen) end = qlen;
         if ((unsigned long long)end + 1 > g.cell_cap) { g.status = LCD_ERR_CELLS; return 0; }
+        const bool fits = end + 1 <= WMAX;
         if (tid == 0) { g.rbeg[bi] = 0; g.rend[bi] = end; g.roff[bi] = 0; g.ml[bi] = 0; g.mr[bi] = 0; }
         for (int j = tid; j <= end; j += NT) {
             int f1 = j ? -(o1 + e1 * j) : LCD_NEG, f2 = j ? -(o2 + e2 * j) : LCD_NEG;
             int h = j ? imax(f1, f2) : 0;
             g.H[j] = h; g.E1[j] = h - oe1; g.E2[j] = h - oe2;
+            if (fits) { ring[j] = h; ring[WMAX + j] = h - oe1; ring[2 * WMAX + j] = h - oe2; }
         }
         used = end + 1;
-        last_idx = bi; last_beg = 0; last_end = end; last_ml = 0; last_mr = 0; last_off = 0;
+        last_idx = bi; last_beg = 0; last_end = end; last_ml = 0; last_mr = 0; last_off = 0; last_slot = fits ? 0 : -1;
+        if (fits) {
+            si0 = bi; next_slot = 1 % K;
+            if (tid == 0) { sm.rm[0][0] = 0; sm.rm[0][1] = end; sm.rm[0][2] = 0; sm.rm[0][3] = 0; sm.rm[0][4] = 0; }
+        }
         __syncthreads();
+        last_full = bi + 1;
     }
+    // Plan window: every 64 rows each lane loads the plan of one upcoming row (start, #preds, remain, base and the first two
+    // predecessor entries); rows then take it by v_readlane.  The row loop therefore issues no HBM load in the common case,
+    // so it never waits (vmcnt is in-order) behind the row stores that are still draining.
+    int wbase = -(1 << 20);
+    int w_p0 = 0, w_np = 0, w_rem = 1 << 30, w_vb = 4, w_pi0 = 0, w_b0 = 0, w_pi1 = 0, w_b1 = 0;
     // ---- rows ----
     for (int idx = bi + 1; idx < ei; ++idx) {
-        if (!g.imap[idx]) {
+        if (idx - wbase >= 64) {
+            wbase = idx;
+            const int ri = idx + lane;
+            w_np = 0; w_rem = 1 << 30;
+            if (ri < ei) {
+                const int s0 = g.pl_start[ri], s1 = g.pl_start[ri + 1];
+                w_p0 = s0; w_np = s1 - s0; w_rem = g.pl_rem[ri]; w_vb = g.pl_base[ri];
+                if (w_np > 0) { w_pi0 = g.pl_pidx[s0]; w_b0 = g.pl_bonus[s0]; }
+                if (w_np > 1) { w_pi1 = g.pl_pidx[s0 + 1]; w_b1 = g.pl_bonus[s0 + 1]; }
+            }
+        }
+        const int wk = idx - wbase;
+        const int p0 = LCD_RL(w_p0, wk), np = LCD_RL(w_np, wk);
+        const int rem = LCD_RL(w_rem, wk); const uint8_t vb = (uint8_t)LCD_RL(w_vb, wk);
+        int my_pi = 0, my_bonus = 0;
+        if (np <= 2) {
+            const int a0 = LCD_RL(w_pi0, wk), a1 = LCD_RL(w_pi1, wk), c0 = LCD_RL(w_b0, wk), c1 = LCD_RL(w_b1, wk);
+            my_pi = lane == 0 ? a0 : a1; my_bonus = lane == 0 ? c0 : c1;
+        } else if (tid < np && tid < MAXP) { my_pi = g.pl_pidx[p0 + tid]; my_bonus = g.pl_bonus[p0 + tid]; }
+        if (rem == (1 << 30)) { // not reachable
             if (tid == 0) { g.rbeg[idx] = 1; g.rend[idx] = 0; g.roff[idx] = (uint32_t)used; g.ml[idx] = 0; g.mr[idx] = 0; }
-            __syncthreads();
             continue;
         }
-        const int v = g.idx2node[idx];
-        const int p0 = g.pl_start[idx], np = g.pl_start[idx + 1] - p0;
-        // stage predecessor metadata in LDS (the row just computed comes from registers, not from HBM)
-        if (tid < np && tid < MAXP) {
-            const int pi = g.pl_pidx[p0 + tid];
-            sm.bonus[tid] = g.pl_bonus[p0 + tid];
-            if (pi == last_idx) { sm.pb[tid] = last_beg; sm.pe[tid] = last_end; sm.po[tid] = last_off; sm.pml[tid] = last_ml; sm.pmr[tid] = last_mr; }
-            else { sm.pb[tid] = g.rbeg[pi]; sm.pe[tid] = g.rend[pi]; sm.po[tid] = g.roff[pi]; sm.pml[tid] = g.ml[pi]; sm.pmr[tid] = g.mr[pi]; }
+        // predecessor metadata.  One wavefront (NT == 64): lane t keeps predecessor t in registers and the row loops
+        // broadcast it with v_readlane (no LDS round trip).  More wavefronts: staged in LDS for everybody.
+        const bool regstage = (NW == 1) && np <= 64;
+        int r_pb = 1, r_pe = 0, r_pml = 0, r_pmr = 0, r_slot = -1, r_bonus = my_bonus; unsigned r_po = 0;
+        if (regstage) {
+            const bool mine = lane < np;
+            if (mine) r_slot = LCD_SLOT_OF(my_pi);
+            // a predecessor row (or its metadata) must be read from HBM: drain the stores issued since the last full barrier
+            if (__any(mine && r_slot < 0 && my_pi >= last_full)) { __syncthreads(); last_full = idx; }
+            if (mine) {
+                if (my_pi == last_idx) { r_pb = last_beg; r_pe = last_end; r_po = last_off; r_pml = last_ml; r_pmr = last_mr; }
+                else if (r_slot >= 0) { r_pb = sm.rm[r_slot][0]; r_pe = sm.rm[r_slot][1]; r_po = (unsigned)sm.rm[r_slot][2]; r_pml = sm.rm[r_slot][3]; r_pmr = sm.rm[r_slot][4]; }
+                else { r_pb = g.rbeg[my_pi]; r_pe = g.rend[my_pi]; r_po = g.roff[my_pi]; r_pml = g.ml[my_pi]; r_pmr = g.mr[my_pi]; }
+            }
+        } else {
+            // pass 1: where does each predecessor row live (ring slot or HBM only)
+            if (tid < np && tid < MAXP) {
+                const int slot = LCD_SLOT_OF(my_pi);
+                sm.bonus[tid] = my_bonus; sm.ppi[tid] = my_pi; sm.pslot[tid] = slot;
+            }
+            lds_barrier<NT>();
+            {
+                int far_pi = np > MAXP ? (1 << 30) : -1;
+                const int ns = imin(np, MAXP);
+                for (int t = 0; t < ns; ++t) if (sm.pslot[t] < 0) far_pi = imax(far_pi, sm.ppi[t]);
+                if (far_pi >= last_full) { __syncthreads(); last_full = idx; }
+            }
+            // pass 2: metadata from registers (row just computed), ring meta (LDS) or HBM
+            if (tid < np && tid < MAXP) {
+                const int pi = my_pi, slot = sm.pslot[tid];
+                if (pi == last_idx) { sm.pb[tid] = last_beg; sm.pe[tid] = last_end; sm.po[tid] = last_off; sm.pml[tid] = last_ml; sm.pmr[tid] = last_mr; }
+                else if (slot >= 0) { sm.pb[tid] = sm.rm[slot][0]; sm.pe[tid] = sm.rm[slot][1]; sm.po[tid] = (unsigned)sm.rm[slot][2]; sm.pml[tid] = sm.rm[slot][3]; sm.pmr[tid] = sm.rm[slot][4]; }
+                else { sm.pb[tid] = g.rbeg[pi]; sm.pe[tid] = g.rend[pi]; sm.po[tid] = g.roff[pi]; sm.pml[tid] = g.ml[pi]; sm.pmr[tid] = g.mr[pi]; }
+            }
+            lds_barrier<NT>();
         }
-        __syncthreads();
         // band: pulled from the predecessors' row-max columns (same values the oracle pushes to successors)
         int mplv = 1 << 30, mprv = 0, minpb = 1 << 30, maxpe = -1;
         for (int t = 0; t < np; ++t) {
             int pb, pe, pml, pmr;
-            if (t < MAXP) { pb = sm.pb[t]; pe = sm.pe[t]; pml = sm.pml[t]; pmr = sm.pmr[t]; }
+            if (regstage) { pb = LCD_RL(r_pb, t); pe = LCD_RL(r_pe, t); pml = LCD_RL(r_pml, t); pmr = LCD_RL(r_pmr, t); }
+            else if (t < MAXP) { pb = sm.pb[t]; pe = sm.pe[t]; pml = sm.pml[t]; pmr = sm.pmr[t]; }
             else { const int pi = g.pl_pidx[p0 + t]; pb = g.rbeg[pi]; pe = g.rend[pi]; pml = g.ml[pi]; pmr = g.mr[pi]; }
             if (pb > pe) continue;
             minpb = imin(minpb, pb); maxpe = imax(maxpe, pe);
             mplv = imin(mplv, pml + 1); mprv = imax(mprv, pmr + 1);
         }
-        const int rem = g.remain[v] - remain_end;
         int beg = imin(mplv, qlen - rem) - w; if (beg < 0) beg = 0;
         int end = imax(mprv, qlen - rem) + w; if (end > qlen) end = qlen;
         if (beg < minpb) beg = minpb;
         if (end > maxpe + 1) end = maxpe + 1;
         if (beg > end) {
             if (tid == 0) { g.rbeg[idx] = 1; g.rend[idx] = 0; g.roff[idx] = (uint32_t)used; g.ml[idx] = 0; g.mr[idx] = 0; }
-            __syncthreads();
+            lds_barrier<NT>();
             continue;
         }
         const unsigned long long off = used;
@@ -328,86 +442,117 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, const LcdScoring &sc, int wb,
         used += (unsigned long long)width;
         if (used > g.cell_cap) { g.status = LCD_ERR_CELLS; return 0; }
         if (tid == 0) { g.rbeg[idx] = beg; g.rend[idx] = end; g.roff[idx] = (uint32_t)off; }
-        const uint8_t vb = g.base[v];
         const int nchunks = (width + 63) >> 6;
-        int carry1 = LCD_NEG * 2, carry2 = LCD_NEG * 2;
+        const bool fits = width <= WMAX;
+        const int slot = fits ? next_slot : -1;
+        int *rH = ring + (size_t)(slot < 0 ? 0 : slot) * 3 * WMAX, *rE1 = rH + WMAX, *rE2 = rH + 2 * WMAX;
+        int carry1 = LCD_NEG * 2, carry2 = LCD_NEG * 2; // running max over the sweeps already done (rows wider than WMAX)
         int best_h = LCD_NEG - 64, best_l = 1 << 30, best_r = -1;
-        int round = 0;
-        for (int c0 = 0; c0 < nchunks; c0 += NW, ++round) {
-            const int rel = ((c0 + wave) << 6) + lane;
-            const int j = beg + rel;
-            const bool act = j <= end;
-            int mx = LCD_NEG, e1i = LCD_NEG, e2i = LCD_NEG;
-            if (act) {
+        int sweep = 0;
+        for (int cb = 0; cb < nchunks; cb += NW * RMAX, ++sweep) {
+            const int left = nchunks - cb;
+            const int R = imin(RMAX, (left + NW - 1) / NW); // chunks per wavefront in this sweep (contiguous per wavefront)
+            // per-chunk values live in named scalars (h0.., not arrays: hipcc put the array form into scratch memory)
+            int hp0 = LCD_NEG, hp1 = LCD_NEG, hp2 = LCD_NEG, hp3 = LCD_NEG, ea0 = LCD_NEG, ea1 = LCD_NEG, ea2 = LCD_NEG, ea3 = LCD_NEG;
+            int eb0 = LCD_NEG, eb1 = LCD_NEG, eb2 = LCD_NEG, eb3 = LCD_NEG;
+            int pa0 = LCD_NEG * 2, pa1 = LCD_NEG * 2, pa2 = LCD_NEG * 2, pa3 = LCD_NEG * 2, pb0 = LCD_NEG * 2, pb1 = LCD_NEG * 2, pb2 = LCD_NEG * 2, pb3 = LCD_NEG * 2;
+            int wc1 = LCD_NEG * 2, wc2 = LCD_NEG * 2; // in-wavefront carry
+            auto phaseA = [&](const int r, int &hp, int &ev1, int &ev2, int &pr1, int &pr2) {
+                const int rel = ((cb + wave * R + r) << 6) + lane;
+                const int j = beg + rel;
+                const bool act = j <= end;
+                int mx = LCD_NEG, e1i = LCD_NEG, e2i = LCD_NEG;
                 int s = 0;
-                if (j >= 1) { const uint8_t qb = seq[j - 1]; s = (vb >= 4 || qb >= 4) ? 0 : (vb == qb ? sc.match : -sc.mismatch); }
-                for (int t = 0; t < np; ++t) {
-                    int pb, pe, bonus; unsigned po;
-                    if (t < MAXP) { pb = sm.pb[t]; pe = sm.pe[t]; po = sm.po[t]; bonus = sm.bonus[t]; }
-                    else { const int pi = g.pl_pidx[p0 + t]; pb = g.rbeg[pi]; pe = g.rend[pi]; po = g.roff[pi]; bonus = g.pl_bonus[p0 + t]; }
-                    if (j >= 1 && j - 1 >= pb && j - 1 <= pe) mx = imax(mx, g.H[po + (j - 1 - pb)] + s + bonus);
-                    if (j >= pb && j <= pe) {
-                        e1i = imax(e1i, g.E1[po + (j - pb)] + bonus);
-                        e2i = imax(e2i, g.E2[po + (j - pb)] + bonus);
+                if (act && j >= 1) { const uint8_t qb = sseq[j - 1]; s = (vb >= 4 || qb >= 4) ? 0 : (vb == qb ? sc.match : -sc.mismatch); }
+                for (int t = 0; t < np; ++t) { // uniform loop: every lane takes part in the readlane broadcasts
+                    int pb, pe, bonus, ps; unsigned po;
+                    if (regstage) { pb = LCD_RL(r_pb, t); pe = LCD_RL(r_pe, t); po = (unsigned)LCD_RL((int)r_po, t); bonus = LCD_RL(r_bonus, t); ps = LCD_RL(r_slot, t); }
+                    else if (t < MAXP) { pb = sm.pb[t]; pe = sm.pe[t]; po = sm.po[t]; bonus = sm.bonus[t]; ps = sm.pslot[t]; }
+                    else { const int pi = g.pl_pidx[p0 + t]; pb = g.rbeg[pi]; pe = g.rend[pi]; po = g.roff[pi]; bonus = g.pl_bonus[p0 + t]; ps = -1; }
+                    if (!act) continue;
+                    if (ps >= 0) {
+                        const int *qH = ring + (size_t)ps * 3 * WMAX;
+                        if (j >= 1 && j - 1 >= pb && j - 1 <= pe) mx = imax(mx, qH[j - 1 - pb] + s + bonus);
+                        if (j >= pb && j <= pe) { e1i = imax(e1i, qH[WMAX + (j - pb)] + bonus); e2i = imax(e2i, qH[2 * WMAX + (j - pb)] + bonus); }
+                    } else {
+                        if (j >= 1 && j - 1 >= pb && j - 1 <= pe) mx = imax(mx, g.H[po + (j - 1 - pb)] + s + bonus);
+                        if (j >= pb && j <= pe) { e1i = imax(e1i, g.E1[po + (j - pb)] + bonus); e2i = imax(e2i, g.E2[po + (j - pb)] + bonus); }
                     }
                 }
-            }
-            const int hpre = imax(mx, imax(e1i, e2i));
-            // F via prefix max of A[k] = Hpre[k] + (k-beg)*e : inside the wavefront by shuffles, across wavefronts through LDS
-            const int a1 = act ? hpre + rel * e1 : LCD_NEG * 2, a2 = act ? hpre + rel * e2 : LCD_NEG * 2;
-            const int i1 = wave_incl_prefix_max(a1, lane), i2 = wave_incl_prefix_max(a2, lane);
-            int p1 = __shfl_up(i1, 1), p2 = __shfl_up(i2, 1);
-            if (lane == 0) { p1 = LCD_NEG * 2; p2 = LCD_NEG * 2; }
-            const int buf = round & 1;
+                const int hpre = imax(mx, imax(e1i, e2i));
+                hp = hpre; ev1 = e1i; ev2 = e2i;
+                // F via prefix max of A[k] = Hpre[k] + (k-beg)*e
+                const int a1 = act ? hpre + rel * e1 : LCD_NEG * 2, a2 = act ? hpre + rel * e2 : LCD_NEG * 2;
+                const int i1 = scan_max(a1), i2 = scan_max(a2);
+                pr1 = imax(shr1(LCD_NEG * 2, i1), wc1); pr2 = imax(shr1(LCD_NEG * 2, i2), wc2);
+                wc1 = imax(wc1, lane63(i1)); wc2 = imax(wc2, lane63(i2));
+            };
+            if (0 < R) phaseA(0, hp0, ea0, eb0, pa0, pb0);
+            if (1 < R) phaseA(1, hp1, ea1, eb1, pa1, pb1);
+            if (2 < R) phaseA(2, hp2, ea2, eb2, pa2, pb2);
+            if (3 < R) phaseA(3, hp3, ea3, eb3, pa3, pb3);
+            int cin1 = carry1, cin2 = carry2;
             if (NW > 1) {
-                if (lane == 63) { sm.tot1[buf][wave] = i1; sm.tot2[buf][wave] = i2; }
-                __syncthreads();
-                int all1 = carry1, all2 = carry2;
+                const int buf = sweep & 1;
+                if (lane == 0) { sm.tot1[buf][wave] = wc1; sm.tot2[buf][wave] = wc2; }
+                lds_barrier<NT>();
 #pragma unroll
                 for (int k = 0; k < NW; ++k) {
                     const int t1 = sm.tot1[buf][k], t2 = sm.tot2[buf][k];
-                    if (k < wave) { p1 = imax(p1, t1); p2 = imax(p2, t2); }
-                    all1 = imax(all1, t1); all2 = imax(all2, t2);
+                    if (k < wave) { cin1 = imax(cin1, t1); cin2 = imax(cin2, t2); }
+                    carry1 = imax(carry1, t1); carry2 = imax(carry2, t2);
                 }
-                p1 = imax(p1, carry1); p2 = imax(p2, carry2);
-                carry1 = all1; carry2 = all2;
-            } else {
-                p1 = imax(p1, carry1); p2 = imax(p2, carry2);
-                carry1 = imax(carry1, __shfl(i1, 63)); carry2 = imax(carry2, __shfl(i2, 63));
-            }
-            if (act) {
-                const int f1 = (j > beg) ? imax(LCD_NEG, p1 - o1 - rel * e1) : LCD_NEG;
-                const int f2 = (j > beg) ? imax(LCD_NEG, p2 - o2 - rel * e2) : LCD_NEG;
-                int h = imax(hpre, imax(f1, f2)); if (h < LCD_NEG) h = LCD_NEG;
-                int eo1 = imax(h - oe1, e1i - e1), eo2 = imax(h - oe2, e2i - e2);
-                if (eo1 < LCD_NEG) eo1 = LCD_NEG;
-                if (eo2 < LCD_NEG) eo2 = LCD_NEG;
-                g.H[off + rel] = h; g.E1[off + rel] = eo1; g.E2[off + rel] = eo2;
-                if (h > best_h) { best_h = h; best_l = j; best_r = j; } else if (h == best_h) best_r = j;
-            }
+            } else { carry1 = imax(carry1, wc1); carry2 = imax(carry2, wc2); }
+            auto phaseB = [&](const int r, const int hp, const int ev1, const int ev2, const int pr1, const int pr2) {
+                const int rel = ((cb + wave * R + r) << 6) + lane;
+                const int j = beg + rel;
+                if (j <= end) {
+                    const int p1 = imax(pr1, cin1), p2 = imax(pr2, cin2);
+                    const int f1 = (j > beg) ? imax(LCD_NEG, p1 - o1 - rel * e1) : LCD_NEG;
+                    const int f2 = (j > beg) ? imax(LCD_NEG, p2 - o2 - rel * e2) : LCD_NEG;
+                    int h = imax(hp, imax(f1, f2)); if (h < LCD_NEG) h = LCD_NEG;
+                    int eo1 = imax(h - oe1, ev1 - e1), eo2 = imax(h - oe2, ev2 - e2);
+                    if (eo1 < LCD_NEG) eo1 = LCD_NEG;
+                    if (eo2 < LCD_NEG) eo2 = LCD_NEG;
+                    g.H[off + rel] = h; g.E1[off + rel] = eo1; g.E2[off + rel] = eo2;
+                    if (fits) { rH[rel] = h; rE1[rel] = eo1; rE2[rel] = eo2; }
+                    if (h > best_h) { best_h = h; best_l = j; best_r = j; } else if (h == best_h) best_r = j;
+                }
+            };
+            if (0 < R) phaseB(0, hp0, ea0, eb0, pa0, pb0);
+            if (1 < R) phaseB(1, hp1, ea1, eb1, pa1, pb1);
+            if (2 < R) phaseB(2, hp2, ea2, eb2, pa2, pb2);
+            if (3 < R) phaseB(3, hp3, ea3, eb3, pa3, pb3);
         }
         // row maximum, leftmost / rightmost column
         int ml, mr;
         {
-            const int wmax = wave_max(best_h);
-            const int wl = wave_min(best_h == wmax ? best_l : (1 << 30));
-            const int wr = wave_max(best_h == wmax ? best_r : -1);
+            const int wmax = lane63(scan_max(best_h));
+            const int wl = lane63(scan_min(best_h == wmax ? best_l : (1 << 30)));
+            const int wr = lane63(scan_max(best_h == wmax ? best_r : -1));
             if (NW > 1) {
                 if (lane == 0) { sm.bh[wave] = wmax; sm.bl[wave] = wl; sm.br[wave] = wr; }
-                __syncthreads();
+                lds_barrier<NT>();
                 int rowmax = sm.bh[0];
 #pragma unroll
                 for (int k = 1; k < NW; ++k) rowmax = imax(rowmax, sm.bh[k]);
                 ml = 1 << 30; mr = -1;
 #pragma unroll
                 for (int k = 0; k < NW; ++k) if (sm.bh[k] == rowmax) { ml = imin(ml, sm.bl[k]); mr = imax(mr, sm.br[k]); }
-            } else {
-                ml = wl; mr = wr;
-                __syncthreads(); // row data + staging reuse
-            }
+            } else { ml = wl; mr = wr; }
         }
-        if (tid == 0) { g.ml[idx] = ml; g.mr[idx] = mr; }
-        last_idx = idx; last_beg = beg; last_end = end; last_ml = ml; last_mr = mr; last_off = (unsigned)off;
+        if (tid == 0) {
+            g.ml[idx] = ml; g.mr[idx] = mr;
+            if (fits) { sm.rm[slot][0] = beg; sm.rm[slot][1] = end; sm.rm[slot][2] = (int)(unsigned)off; sm.rm[slot][3] = ml; sm.rm[slot][4] = mr; }
+        }
+        if (fits) {
+            if (slot == 0) si0 = idx; else if (slot == 1) si1 = idx; else if (slot == 2) si2 = idx; else si3 = idx;
+            next_slot = (slot + 1) % K;
+        } else {
+            // the row lives in HBM only: forget any ring row it might alias and make it readable before it is used
+            __syncthreads(); last_full = idx + 1;
+        }
+        last_idx = idx; last_beg = beg; last_end = end; last_ml = ml; last_mr = mr; last_off = (unsigned)off; last_slot = slot;
     }
     __syncthreads();
     *cells_acc += used;
@@ -504,6 +649,8 @@ __global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chain
     const int cid = blockIdx.x;
     if (cid >= n_chains) return;
     __shared__ Smem sm;
+    __shared__ int ring[Cfg<NT>::K * 3 * Cfg<NT>::WMAX];
+    __shared__ uint8_t sseq[Cfg<NT>::SEQ_CAP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const PoaChain ch = chains[cid];
     const PoaLayout L = poa_layout(ch.node_cap, ch.edge_cap, ch.rid_words, ch.max_len, ch.cell_cap, ch.n_reads);
@@ -524,6 +671,7 @@ __global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chain
     g.base = ws + L.n_base; g.imap = ws + L.imap;
     g.het = (int *)(ws + L.het); g.clu = (int *)(ws + L.clu); g.nclu = (int *)(ws + L.nclu); g.prof = ws + L.prof;
     g.pl_start = (int *)(ws + L.pl_start); g.pl_pidx = (int *)(ws + L.pl_pidx); g.pl_bonus = (int *)(ws + L.pl_bonus);
+    g.pl_rem = (int *)(ws + L.pl_rem); g.pl_base = ws + L.pl_base;
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
     g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0;
     const long long t_begin = clock64();
@@ -558,7 +706,7 @@ __global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chain
         const int len = r.len - beg_cut - end_cut;
         int n_cig = 0;
         if (g.n_node > 2) {
-            n_cig = align_to_subgraph<NT>(g, sm, sc, ch.mode == 0 ? 10 : -1, ch.mode == 0 ? 10 : 0, exc_beg, exc_end, seq, len, &cells);
+            n_cig = align_to_subgraph<NT>(g, sm, ring, sseq, sc, ch.mode == 0 ? 10 : -1, ch.mode == 0 ? 10 : 0, exc_beg, exc_end, seq, len, &cells);
             if (len > 0) { aligned_bases += len; n_aligned_reads++; }
         }
         // graph update + re-sort: serial pointer work on thread 0; results published through LDS
@@ -620,10 +768,10 @@ __global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chain
                 for (int c0 = 0; c0 < ncol; c0 += 64) {
                     int c = c0 + lane, ishet = 0;
                     if (c < ncol) {
-                        int cnt[6] = {0, 0, 0, 0, 0, 0};
-                        for (int r = 0; r < n_seq; ++r) cnt[msa[(size_t)r * nc_cap + c]]++;
+                        Cnt6 cnt;
+                        for (int r = 0; r < n_seq; ++r) cnt.add(msa[(size_t)r * nc_cap + c]);
                         int k = 0;
-                        for (int a = 0; a < 6; ++a) k += cnt[a] >= min_w;
+                        for (int a = 0; a < 6; ++a) k += cnt.get(a) >= min_w;
                         ishet = k >= 2;
                     }
                     unsigned long long m = __ballot(ishet);
@@ -638,11 +786,11 @@ __global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chain
                 if (wave == 0) {
                     int bv2 = -1, bh = 1 << 30, ba0 = 0, ba1 = 0;
                     for (int h = lane; h < n_het; h += 64) {
-                        int cnt[6] = {0, 0, 0, 0, 0, 0};
-                        for (int r = 0; r < n_seq; ++r) cnt[msa[(size_t)r * nc_cap + g.het[h]]]++;
-                        int m0 = 0; for (int a = 1; a < 6; ++a) if (cnt[a] > cnt[m0]) m0 = a;
-                        int m1 = -1; for (int a = 0; a < 6; ++a) if (a != m0 && (m1 < 0 || cnt[a] > cnt[m1])) m1 = a;
-                        if (cnt[m1] > bv2) { bv2 = cnt[m1]; bh = h; ba0 = m0; ba1 = m1; }
+                        Cnt6 cnt;
+                        for (int r = 0; r < n_seq; ++r) cnt.add(msa[(size_t)r * nc_cap + g.het[h]]);
+                        int m0 = 0; for (int a = 1; a < 6; ++a) if (cnt.get(a) > cnt.get(m0)) m0 = a;
+                        int m1 = -1; for (int a = 0; a < 6; ++a) if (a != m0 && (m1 < 0 || cnt.get(a) > cnt.get(m1))) m1 = a;
+                        if (cnt.get(m1) > bv2) { bv2 = cnt.get(m1); bh = h; ba0 = m0; ba1 = m1; }
                     }
                     int gv2 = wave_max(bv2);
                     int gh = wave_min(bv2 == gv2 ? bh : (1 << 30));
@@ -655,9 +803,9 @@ __global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chain
                 for (int it = 0; it < 10; ++it) {
                     for (int t = tid; t < 2 * n_het; t += NT) {
                         int c = t / n_het, h = t % n_het;
-                        int cnt[6] = {0, 0, 0, 0, 0, 0};
-                        for (int r = 0; r < n_seq; ++r) if (g.clu[r] == c) cnt[msa[(size_t)r * nc_cap + g.het[h]]]++;
-                        int m0 = 0; for (int a = 1; a < 6; ++a) if (cnt[a] > cnt[m0]) m0 = a;
+                        Cnt6 cnt;
+                        for (int r = 0; r < n_seq; ++r) if (g.clu[r] == c) cnt.add(msa[(size_t)r * nc_cap + g.het[h]]);
+                        int m0 = 0; for (int a = 1; a < 6; ++a) if (cnt.get(a) > cnt.get(m0)) m0 = a;
                         g.prof[t] = (uint8_t)m0;
                     }
                     if (tid == 0) sm.bc[2] = 0;
@@ -719,10 +867,10 @@ __global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chain
                 for (int c0 = 0; c0 < ncol; c0 += 64) {
                     int col = c0 + lane, emit = 0, mb = 0;
                     if (col < ncol) {
-                        int cnt[6] = {0, 0, 0, 0, 0, 0};
-                        for (int k = 0; k < csize; ++k) cnt[msa[(size_t)clu_ids[c * n_seq + k] * nc_cap + col]]++;
-                        for (int a = 1; a < 5; ++a) if (cnt[a] > cnt[mb]) mb = a;
-                        emit = cnt[mb] > 0 && cnt[mb] >= cnt[5];
+                        Cnt6 cnt;
+                        for (int k = 0; k < csize; ++k) cnt.add(msa[(size_t)clu_ids[c * n_seq + k] * nc_cap + col]);
+                        for (int a = 1; a < 5; ++a) if (cnt.get(a) > cnt.get(mb)) mb = a;
+                        emit = cnt.get(mb) > 0 && cnt.get(mb) >= cnt.get(5);
                     }
                     unsigned long long m = __ballot(emit);
                     if (emit) { cons[cl + __popcll(m & ((1ull << lane) - 1))] = (uint8_t)mb; crow[col] = (uint8_t)mb; }
