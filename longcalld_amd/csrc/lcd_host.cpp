@@ -538,8 +538,12 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
 // workgroup size class of a chain: follows the DP row width (poa_kernel.hip)
 static int chain_threads(const PoaChain &pc) {
     const long long width = pc.mode == 1 ? (long long)pc.max_len + 1 : 2ll * (10 + pc.max_len / 100) + 1 + 32;
-    // class 64 caches <= 4096 query bases in LDS, the wider classes 51200 (poa_kernel.hip Cfg<>)
-    return (width <= 128 && pc.max_len <= 4096) ? 64 : width <= 1024 ? 256 : 1024;
+    // class 64 caches <= 4096 query bases in LDS, the wider classes 51200; the LDS pool also has to hold the 16-bit graph copy of
+    // the re-sort (about 22 B per node): 24 KB / 80 KB / 146 KB (poa_kernel.hip Cfg<>)
+    const long long est_nodes = (long long)(pc.max_len * 1.15) + 64;
+    if (width <= 128 && pc.max_len <= 4096 && est_nodes * 22 <= 24576) return 64;
+    if (width <= 1024 && est_nodes * 22 <= 81920) return 256;
+    return 1024;
 }
 // uploads `sub` (already ordered so that equal classes are contiguous) and launches one kernel per class
 // (different classes go to side streams so a long wide chain does not hold back the narrow ones)

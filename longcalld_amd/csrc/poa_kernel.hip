@@ -36,6 +36,12 @@ struct Smem {
     int bc[8];
 };
 
+template <int NT> struct Cfg;
+// One LDS pool per workgroup: [row ring | query cache] during the DP, re-used as 16-bit graph arrays by the re-sort.
+template <> struct Cfg<64> { static constexpr int WMAX = 256, K = 4, SEQ_CAP = 4096, POOL_WORDS = 6144; };   // 24 KB; reads <= 4 kb by class
+template <> struct Cfg<256> { static constexpr int WMAX = 1024, K = 2, SEQ_CAP = 51200, POOL_WORDS = 20480; }; // 80 KB
+template <> struct Cfg<1024> { static constexpr int WMAX = 4096, K = 2, SEQ_CAP = 51200, POOL_WORDS = 37376; }; // 146 KB
+
 struct Ctx {
     int *H, *E1, *E2;
     int *rbeg, *rend; uint32_t *roff;
@@ -140,15 +146,14 @@ __device__ void topo_sort(Ctx &g) {
     }
 }
 
-__device__ void add_alignment(Ctx &g, int beg_node, int end_node, const uint8_t *seq, int len, int n_cig, int read_id) {
+__device__ bool add_alignment(Ctx &g, int beg_node, int end_node, const uint8_t *seq, int len, int n_cig, int read_id) {
     if (g.n_node == 2) {
         int last = 0;
         for (int i = 0; i < len; ++i) { int id = add_node(g, seq[i]); add_edge(g, last, id, 0, read_id); last = id; }
         add_edge(g, last, 1, 0, read_id);
-        topo_sort(g);
-        return;
+        return true;
     }
-    if (n_cig == 0) return;
+    if (n_cig == 0) return false;
     int last = beg_node, last_new = 0;
     for (int i = 0; i < n_cig; ++i) {
         uint8_t b = seq[g.cig_qpos[i]];
@@ -170,7 +175,65 @@ __device__ void add_alignment(Ctx &g, int beg_node, int end_node, const uint8_t 
         }
     }
     add_edge(g, last, end_node, 1 - last_new, read_id);
-    if (g.status == LCD_OK) topo_sort(g);
+    return true;
+}
+
+// Kahn BFS order + remain for the whole workgroup: the pointer-chasing part still runs on one lane (the FIFO order is
+// inherently serial) but on 16-bit copies of the graph staged in LDS, so each dependent step costs an LDS access (~60 clk)
+// instead of an HBM/L2 access (~500 clk); staging in and out is a coalesced parallel copy.  Falls back to HBM when the
+// graph does not fit the pool.
+template <int NT>
+__device__ void topo_sort_block(Ctx &g, Smem &sm, int *lds_pool) {
+    const int tid = threadIdx.x;
+    const int n = g.n_node, E = g.n_edge;
+    const bool fits = n < 65535 && E < 65535 && (size_t)14 * n + (size_t)6 * E + 64 <= (size_t)Cfg<NT>::POOL_WORDS * 4;
+    if (!fits) {
+        if (tid == 0) { topo_sort(g); sm.bc[6] = g.status; }
+        __syncthreads();
+        g.status = sm.bc[6];
+        __syncthreads();
+        return;
+    }
+    unsigned short *deg = (unsigned short *)lds_pool, *queue = deg + n, *oh = queue + n, *al = oh + n, *i2n = al + n, *n2i = i2n + n, *rem = n2i + n;
+    unsigned short *en = rem + n, *et = en + E, *ew = et + E;
+    for (int i = tid; i < n; i += NT) { deg[i] = (unsigned short)g.nin[i]; oh[i] = (unsigned short)(g.out_head[i] + 1); al[i] = (unsigned short)g.aligned[i]; }
+    for (int e = tid; e < E; e += NT) { en[e] = (unsigned short)(g.e_next_out[e] + 1); et[e] = (unsigned short)g.e_to[e]; const int w = g.e_w[e]; ew[e] = (unsigned short)(w > 65535 ? 65535 : w); }
+    __syncthreads();
+    if (tid == 0) {
+        int qh = 0, qt = 0, index = 0;
+        queue[qt++] = 0;
+        while (qh < qt) {
+            const int cur = queue[qh++];
+            i2n[index] = (unsigned short)cur; n2i[cur] = (unsigned short)index; ++index;
+            if (cur == 1) break;
+            for (int e = oh[cur]; e != 0; e = en[e - 1]) {
+                const int out = et[e - 1];
+                const int d = deg[out] - 1; deg[out] = (unsigned short)d;
+                if (d == 0) {
+                    bool ok = true;
+                    for (int a = al[out]; a != out; a = al[a]) if (deg[a] != 0) { ok = false; break; }
+                    if (!ok) continue;
+                    queue[qt++] = (unsigned short)out;
+                    for (int a = al[out]; a != out; a = al[a]) queue[qt++] = (unsigned short)a;
+                }
+            }
+        }
+        if (index != n) g.status = LCD_ERR_TOPO;
+        else {
+            rem[1] = 0; // remain + 1
+            for (int i = n - 2; i >= 0; --i) {
+                const int v = i2n[i]; int mw = -1, mid = 1;
+                for (int e = oh[v]; e != 0; e = en[e - 1]) if ((int)ew[e - 1] > mw) { mw = ew[e - 1]; mid = et[e - 1]; }
+                rem[v] = (unsigned short)(rem[mid] + 1);
+            }
+        }
+        sm.bc[6] = g.status;
+    }
+    __syncthreads();
+    g.status = sm.bc[6];
+    if (g.status == LCD_OK)
+        for (int i = tid; i < n; i += NT) { g.idx2node[i] = i2n[i]; g.node2idx[i] = n2i[i]; g.remain[i] = (int)rem[i] - 1; }
+    __syncthreads();
 }
 
 // sub-graph boundaries (oracle/poa.c subgraph_nodes): min/max sweeps on wavefront 0, result broadcast through LDS
@@ -227,10 +290,6 @@ __device__ __forceinline__ void lds_barrier() {
 
 #define LCD_RL(v, t) __builtin_amdgcn_readlane((v), (t))
 
-template <int NT> struct Cfg;
-template <> struct Cfg<64> { static constexpr int WMAX = 256, K = 4, SEQ_CAP = 4096; };   // class 64: reads <= 3.7 kb by construction
-template <> struct Cfg<256> { static constexpr int WMAX = 1024, K = 2, SEQ_CAP = 51200; };
-template <> struct Cfg<1024> { static constexpr int WMAX = 4096, K = 2, SEQ_CAP = 51200; };
 // six per-symbol counters packed 3 x 21 bits into two 64-bit words (register-resident, no dynamic array indexing)
 struct Cnt6 {
     unsigned long long a, b;
@@ -248,7 +307,7 @@ constexpr int RMAX = 4; // 64-column chunks per wavefront per sweep: NW*RMAX*64 
 // row-to-row dependency never waits for an HBM store->load round trip.  HBM rows are only read once a full
 // barrier has drained the stores issued before it (tracked with last_full).
 template <int NT>
-__device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, const LcdScoring &sc, int wb, int wf_milli, int beg_node, int end_node,
+__device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, const LcdScoring &sc, const int wb, int wf_milli, int beg_node, int end_node,
                                  const uint8_t *seq_hbm, int qlen, unsigned long long *cells_acc) {
     constexpr int NW = NT / 64, WMAX = Cfg<NT>::WMAX, K = Cfg<NT>::K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -525,8 +584,8 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
             if (3 < R) phaseB(3, hp3, ea3, eb3, pa3, pb3);
         }
         // row maximum, leftmost / rightmost column
-        int ml, mr;
-        {
+        int ml = 0, mr = 0;
+        if (wb >= 0) { // (unbanded rows: w = qlen makes every band [0, qlen], the row-max columns are never consumed)
             const int wmax = lane63(scan_max(best_h));
             const int wl = lane63(scan_min(best_h == wmax ? best_l : (1 << 30)));
             const int wr = lane63(scan_max(best_h == wmax ? best_r : -1));
@@ -649,8 +708,10 @@ __global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chain
     const int cid = blockIdx.x;
     if (cid >= n_chains) return;
     __shared__ Smem sm;
-    __shared__ int ring[Cfg<NT>::K * 3 * Cfg<NT>::WMAX];
-    __shared__ uint8_t sseq[Cfg<NT>::SEQ_CAP];
+    __shared__ int lds_pool[Cfg<NT>::POOL_WORDS];
+    int *ring = lds_pool;
+    uint8_t *sseq = (uint8_t *)(lds_pool + Cfg<NT>::K * 3 * Cfg<NT>::WMAX);
+    static_assert(Cfg<NT>::K * 3 * Cfg<NT>::WMAX * 4 + Cfg<NT>::SEQ_CAP <= Cfg<NT>::POOL_WORDS * 4, "LDS pool too small");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const PoaChain ch = chains[cid];
     const PoaLayout L = poa_layout(ch.node_cap, ch.edge_cap, ch.rid_words, ch.max_len, ch.cell_cap, ch.n_reads);
@@ -712,12 +773,15 @@ __global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chain
         // graph update + re-sort: serial pointer work on thread 0; results published through LDS
         const long long tg0 = clock64();
         if (tid == 0) {
-            if (len > 0 && g.status == LCD_OK) add_alignment(g, exc_beg, exc_end, seq, len, n_cig, i);
-            sm.bc[4] = g.n_node; sm.bc[5] = g.n_edge; sm.bc[6] = g.status;
+            bool changed = false;
+            if (len > 0 && g.status == LCD_OK) changed = add_alignment(g, exc_beg, exc_end, seq, len, n_cig, i);
+            sm.bc[4] = g.n_node; sm.bc[5] = g.n_edge; sm.bc[6] = g.status; sm.bc[7] = changed;
         }
         __syncthreads();
         g.n_node = sm.bc[4]; g.n_edge = sm.bc[5]; g.status = sm.bc[6];
+        const bool changed = sm.bc[7] != 0;
         __syncthreads();
+        if (changed && g.status == LCD_OK) topo_sort_block<NT>(g, sm, lds_pool);
         t_graph += (unsigned long long)(clock64() - tg0);
     }
     const long long t_out0 = clock64();
