@@ -410,6 +410,118 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         __syncthreads();
         last_full = bi + 1;
     }
+    // ================= unbanded fast path (K2, wb < 0) =================
+    // w = qlen makes every row [0, qlen] (oracle: beg = max(0, .. - qlen) = 0, end = min(qlen, .. + qlen) = qlen, and the
+    // source row already spans it), every node is reachable, so row metadata is implicit: rbeg = 0, rend = qlen,
+    // roff = (idx - bi) * (qlen + 1).  No staging, no band, no row-max: per row one LDS barrier for the F carry.
+    if (wb < 0 && bi == 0 && ei == n - 1 && qlen + 1 <= WMAX) {
+        const int W1 = qlen + 1;
+        const int nchunks = (W1 + 63) >> 6;
+        const int R = (nchunks + NW - 1) / NW;
+        if ((unsigned long long)(ei - bi) * W1 > g.cell_cap) { g.status = LCD_ERR_CELLS; return 0; }
+        for (int i = bi + 1 + tid; i < ei; i += NT) { g.rbeg[i] = 0; g.rend[i] = qlen; g.roff[i] = (uint32_t)((i - bi) * (unsigned)W1); }
+        used = (unsigned long long)(ei - bi) * W1;
+        int wbase = -(1 << 20);
+        int w_p0 = 0, w_np = 0, w_vb = 4, w_pi0 = 0, w_b0 = 0, w_pi1 = 0, w_b1 = 0;
+        for (int idx = bi + 1; idx < ei; ++idx) {
+            if (idx - wbase >= 64) {
+                wbase = idx;
+                const int ri = idx + lane;
+                w_np = 0;
+                if (ri < ei) {
+                    const int s0 = g.pl_start[ri], s1 = g.pl_start[ri + 1];
+                    w_p0 = s0; w_np = s1 - s0; w_vb = g.pl_base[ri];
+                    if (w_np > 0) { w_pi0 = g.pl_pidx[s0]; w_b0 = g.pl_bonus[s0]; }
+                    if (w_np > 1) { w_pi1 = g.pl_pidx[s0 + 1]; w_b1 = g.pl_bonus[s0 + 1]; }
+                }
+            }
+            const int wk = idx - wbase;
+            const int p0 = LCD_RL(w_p0, wk), np = LCD_RL(w_np, wk);
+            const uint8_t vb = (uint8_t)LCD_RL(w_vb, wk);
+            const int pi0 = LCD_RL(w_pi0, wk), bz0 = LCD_RL(w_b0, wk), pi1 = LCD_RL(w_pi1, wk), bz1 = LCD_RL(w_b1, wk);
+            const int sl0 = np > 0 ? LCD_SLOT_OF(pi0) : 0, sl1 = np > 1 ? LCD_SLOT_OF(pi1) : 0;
+            // predecessors that are not in the ring are read from HBM: their stores must have drained
+            {
+                int far = -1;
+                if (np > 0 && sl0 < 0) far = pi0;
+                if (np > 1 && sl1 < 0) far = imax(far, pi1);
+                if (np > 2) far = 1 << 30;
+                if (far >= last_full) { __syncthreads(); last_full = idx; }
+            }
+            const unsigned off = (unsigned)(idx - bi) * (unsigned)W1;
+            const int slot = next_slot;
+            int *rH = ring + (size_t)slot * 3 * WMAX, *rE1 = rH + WMAX, *rE2 = rH + 2 * WMAX;
+            int hp0 = LCD_NEG, hp1 = LCD_NEG, hp2 = LCD_NEG, hp3 = LCD_NEG, ea0 = LCD_NEG, ea1 = LCD_NEG, ea2 = LCD_NEG, ea3 = LCD_NEG;
+            int eb0 = LCD_NEG, eb1 = LCD_NEG, eb2 = LCD_NEG, eb3 = LCD_NEG;
+            int pa0 = LCD_NEG * 2, pa1 = LCD_NEG * 2, pa2 = LCD_NEG * 2, pa3 = LCD_NEG * 2, pb0 = LCD_NEG * 2, pb1 = LCD_NEG * 2, pb2 = LCD_NEG * 2, pb3 = LCD_NEG * 2;
+            int wc1 = LCD_NEG * 2, wc2 = LCD_NEG * 2;
+            auto predU = [&](const int j, const int s, const int pi, const int bonus, const int sl, int &mx, int &e1i, int &e2i) {
+                if (sl >= 0) {
+                    const int *qH = ring + (size_t)sl * 3 * WMAX;
+                    if (j >= 1) mx = imax(mx, qH[j - 1] + s + bonus);
+                    e1i = imax(e1i, qH[WMAX + j] + bonus); e2i = imax(e2i, qH[2 * WMAX + j] + bonus);
+                } else {
+                    const size_t po = (size_t)(pi - bi) * W1;
+                    if (j >= 1) mx = imax(mx, g.H[po + j - 1] + s + bonus);
+                    e1i = imax(e1i, g.E1[po + j] + bonus); e2i = imax(e2i, g.E2[po + j] + bonus);
+                }
+            };
+            auto phaseA = [&](const int r, int &hp, int &ev1, int &ev2, int &pr1, int &pr2) {
+                const int rel = ((wave * R + r) << 6) + lane;
+                const int j = rel;
+                const bool act = j <= qlen;
+                int mx = LCD_NEG, e1i = LCD_NEG, e2i = LCD_NEG;
+                if (act) {
+                    int s = 0;
+                    if (j >= 1) { const uint8_t qb = sseq[j - 1]; s = (vb >= 4 || qb >= 4) ? 0 : (vb == qb ? sc.match : -sc.mismatch); }
+                    if (np > 0) predU(j, s, pi0, bz0, sl0, mx, e1i, e2i);
+                    if (np > 1) predU(j, s, pi1, bz1, sl1, mx, e1i, e2i);
+                    for (int t = 2; t < np; ++t) predU(j, s, g.pl_pidx[p0 + t], g.pl_bonus[p0 + t], -1, mx, e1i, e2i);
+                }
+                const int hpre = imax(mx, imax(e1i, e2i));
+                hp = hpre; ev1 = e1i; ev2 = e2i;
+                const int a1 = act ? hpre + rel * e1 : LCD_NEG * 2, a2 = act ? hpre + rel * e2 : LCD_NEG * 2;
+                const int i1 = scan_max(a1), i2 = scan_max(a2);
+                pr1 = imax(shr1(LCD_NEG * 2, i1), wc1); pr2 = imax(shr1(LCD_NEG * 2, i2), wc2);
+                wc1 = imax(wc1, lane63(i1)); wc2 = imax(wc2, lane63(i2));
+            };
+            if (0 < R) phaseA(0, hp0, ea0, eb0, pa0, pb0);
+            if (1 < R) phaseA(1, hp1, ea1, eb1, pa1, pb1);
+            if (2 < R) phaseA(2, hp2, ea2, eb2, pa2, pb2);
+            if (3 < R) phaseA(3, hp3, ea3, eb3, pa3, pb3);
+            int cin1 = LCD_NEG * 2, cin2 = LCD_NEG * 2;
+            if (NW > 1) {
+                const int buf = idx & 1;
+                if (lane == 0) { sm.tot1[buf][wave] = wc1; sm.tot2[buf][wave] = wc2; }
+                lds_barrier<NT>();
+#pragma unroll
+                for (int k = 0; k < NW; ++k) if (k < wave) { cin1 = imax(cin1, sm.tot1[buf][k]); cin2 = imax(cin2, sm.tot2[buf][k]); }
+            }
+            auto phaseB = [&](const int r, const int hp, const int ev1, const int ev2, const int pr1, const int pr2) {
+                const int rel = ((wave * R + r) << 6) + lane;
+                if (rel <= qlen) {
+                    const int p1 = imax(pr1, cin1), p2 = imax(pr2, cin2);
+                    const int f1 = (rel > 0) ? imax(LCD_NEG, p1 - o1 - rel * e1) : LCD_NEG;
+                    const int f2 = (rel > 0) ? imax(LCD_NEG, p2 - o2 - rel * e2) : LCD_NEG;
+                    int h = imax(hp, imax(f1, f2)); if (h < LCD_NEG) h = LCD_NEG;
+                    int eo1 = imax(h - oe1, ev1 - e1), eo2 = imax(h - oe2, ev2 - e2);
+                    if (eo1 < LCD_NEG) eo1 = LCD_NEG;
+                    if (eo2 < LCD_NEG) eo2 = LCD_NEG;
+                    g.H[off + rel] = h; g.E1[off + rel] = eo1; g.E2[off + rel] = eo2;
+                    rH[rel] = h; rE1[rel] = eo1; rE2[rel] = eo2;
+                }
+            };
+            if (0 < R) phaseB(0, hp0, ea0, eb0, pa0, pb0);
+            if (1 < R) phaseB(1, hp1, ea1, eb1, pa1, pb1);
+            if (2 < R) phaseB(2, hp2, ea2, eb2, pa2, pb2);
+            if (3 < R) phaseB(3, hp3, ea3, eb3, pa3, pb3);
+            if (slot == 0) si0 = idx; else if (slot == 1) si1 = idx; else if (slot == 2) si2 = idx; else si3 = idx;
+            next_slot = (slot + 1) % K;
+            // the ring slot just written is read by the next row; with one wavefront LDS is in order, otherwise the next
+            // row's totals barrier comes too late for phase A, so publish the row here
+            lds_barrier<NT>();
+        }
+    } else {
     // Plan window: every 64 rows each lane loads the plan of one upcoming row (start, #preds, remain, base and the first two
     // predecessor entries); rows then take it by v_readlane.  The row loop therefore issues no HBM load in the common case,
     // so it never waits (vmcnt is in-order) behind the row stores that are still draining.
@@ -613,6 +725,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         }
         last_idx = idx; last_beg = beg; last_end = end; last_ml = ml; last_mr = mr; last_off = (unsigned)off; last_slot = slot;
     }
+    } // banded / generic rows
     __syncthreads();
     *cells_acc += used;
     const long long t_bt0 = clock64();
