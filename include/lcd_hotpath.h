@@ -87,6 +87,34 @@ int lcd_collect_noisy_reg_aln_strs(const lcd_opt_t *opt, const lcd_read_view_t *
                                    const uint8_t *ref_seq, int ref_seq_len, int *clu_n_seqs, int **clu_read_ids,
                                    lcd_aln_str_t **aln_strs);
 
+/* ---- K5: replaces assign_hap_based_on_germline_het_vars_kmeans (src/assign_hap.h:12, src/assign_hap.c:473-547) ----
+ * bam_chunk_t / cand_var_t / read_var_profile_t flattened (src/collect_var.h:71-104, src/bam_utils.h:45-92). */
+typedef struct lcd_hap_problem_t {
+    int n_reads, n_vars, is_ont;
+    const int64_t *var_pos;            /* cand_var_t.pos */
+    const int *var_type;               /* BAM_CDIFF 8 / BAM_CINS 1 / BAM_CDEL 2 */
+    const int *var_cate;               /* chunk->var_i_to_cate */
+    const int *is_homopolymer_indel;
+    const int *total_cov;
+    const int *alle_off;               /* n_vars+1 CSR offsets into alle_covs and the three profile planes */
+    const int *alle_covs;
+    const int *start_var_idx, *end_var_idx; /* read_var_profile_t (-1 / -2: no variant) */
+    const int *allele_off;             /* n_reads+1 CSR offsets into alleles */
+    const int *alleles;
+    const int *ordered_read_ids;
+    const uint8_t *is_skipped;
+    int n_cr;
+    const int *cr_read;                /* labels of chunk->read_var_cr in its sorted interval order (cr->r[i].label) */
+    int *haps;                         /* out: chunk->haps */
+    int64_t *phase_sets;               /* out: chunk->phase_sets */
+    int *n_clean_agree_snps, *n_clean_conflict_snps;
+    int64_t *var_phase_set;            /* out: cand_var_t.phase_set */
+    int *hap_to_cons_alle;             /* in/out n_vars*3 */
+    int *hap_to_alle_profile;          /* in/out 3 planes of alle_off[n_vars] */
+} lcd_hap_problem_t;
+int lcd_assign_hap_germline(lcd_hap_problem_t *p, int target_var_cate);
+int lcd_assign_hap_batch(int n, lcd_hap_problem_t *probs, const int *target_var_cates);
+
 /* ---- batched form (additive; legal because regions of one pass are independent, SURVEY CS-2) ---- */
 typedef struct lcd_batch_s lcd_batch_t;
 

@@ -40,6 +40,16 @@ class LcdBatchStats(C.Structure):
         ("n_poa_launches", C.c_int), ("poa_retries", C.c_int)]
 
 
+class LcdHapProblem(C.Structure):
+    """lcd_hap_problem_t: bam_chunk_t / cand_var_t / read_var_profile_t flattened for K5 (src/assign_hap.c:473)"""
+    _i32p, _i64p, _u8p = C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_uint8)
+    _fields_ = [("n_reads", C.c_int), ("n_vars", C.c_int), ("is_ont", C.c_int), ("var_pos", _i64p), ("var_type", _i32p), ("var_cate", _i32p),
+                ("is_homopolymer_indel", _i32p), ("total_cov", _i32p), ("alle_off", _i32p), ("alle_covs", _i32p), ("start_var_idx", _i32p),
+                ("end_var_idx", _i32p), ("allele_off", _i32p), ("alleles", _i32p), ("ordered_read_ids", _i32p), ("is_skipped", _u8p),
+                ("n_cr", C.c_int), ("cr_read", _i32p), ("haps", _i32p), ("phase_sets", _i64p), ("n_clean_agree_snps", _i32p),
+                ("n_clean_conflict_snps", _i32p), ("var_phase_set", _i64p), ("hap_to_cons_alle", _i32p), ("hap_to_alle_profile", _i32p)]
+
+
 _lib = None
 
 # every symbol include/lcd_hotpath.h declares (tests check the .so exports all of them)
@@ -48,7 +58,7 @@ EXPORTS = [
     "lcd_edlib_xgaps", "lcd_edlib_edit_distance", "lcd_collect_noisy_reg_aln_strs", "lcd_batch_create", "lcd_batch_destroy",
     "lcd_batch_clear", "lcd_batch_add_region", "lcd_batch_add_region_from_chunk", "lcd_batch_upload", "lcd_batch_run",
     "lcd_batch_download", "lcd_batch_region_result", "lcd_batch_region_sorted_ids", "lcd_batch_get_stats", "lcd_batch_digest",
-    "lcd_edlib_batch", "lcd_wfa_batch", "lcd_poa_batch",
+    "lcd_edlib_batch", "lcd_wfa_batch", "lcd_poa_batch", "lcd_assign_hap_germline", "lcd_assign_hap_batch",
 ]
 
 
@@ -86,6 +96,8 @@ def load_library():
     lib.lcd_wfa_batch.argtypes = [C.c_int, u8p, C.c_uint64, u64p, i32p, u64p, i32p, i32p] + [C.c_int] * 6 + [i32p, u32p, C.c_int, i32p, u8p, C.c_int, i32p]
     lib.lcd_poa_batch.argtypes = [C.POINTER(LcdOpt), C.c_int, i32p, i32p, i32p, C.c_int, u64p, i32p, i32p, i32p, u8p, C.c_uint64, i32p,
                                   i32p, i32p, i32p, i32p, u8p, C.c_int, u8p, C.c_int, C.c_int, i32p]
+    lib.lcd_assign_hap_germline.argtypes = [C.POINTER(LcdHapProblem), C.c_int]
+    lib.lcd_assign_hap_batch.argtypes = [C.c_int, C.POINTER(LcdHapProblem), i32p]
     lib.lcd_wfa_end2end_aln.argtypes = [u8p, C.c_int, u8p, C.c_int] + [C.c_int] * 8 + [C.POINTER(u32p), i32p, C.POINTER(u8p), C.POINTER(u8p), i32p]
     lib.lcd_edlib_end2end_aln.argtypes = [u8p, C.c_int, u8p, C.c_int, i32p, i32p]
     lib.lcd_edlib_xgaps.argtypes = [u8p, C.c_int, u8p, C.c_int]

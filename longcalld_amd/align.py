@@ -242,3 +242,42 @@ class RegionBatch:
                                                query_beg=s.query_beg, query_end=s.query_end))
                 _libc.free(s.target_aln)
         return res
+
+
+def _hap_state(prob):
+    R, V, TA = prob["n_reads"], prob["n_vars"], int(prob["alle_off"][-1])
+    return dict(haps=np.zeros(R, np.int32), phase_sets=np.full(R, -1, np.int64), n_clean_agree_snps=np.zeros(R, np.int32),
+                n_clean_conflict_snps=np.zeros(R, np.int32), var_phase_set=np.full(V, -1, np.int64),
+                hap_to_cons_alle=np.full(V * 3, -1, np.int32), hap_to_alle_profile=np.zeros(3 * TA, np.int32))
+
+
+def _fill_hap_struct(S, prob, state, keep):
+    i32p, i64p = C.POINTER(C.c_int), C.POINTER(C.c_int64)
+    s = S()
+    s.n_reads, s.n_vars, s.is_ont, s.n_cr = prob["n_reads"], prob["n_vars"], prob["is_ont"], len(prob["cr_read"])
+    for name, ty in (("var_pos", i64p), ("var_type", i32p), ("var_cate", i32p), ("is_homopolymer_indel", i32p), ("total_cov", i32p),
+                     ("alle_off", i32p), ("alle_covs", i32p), ("start_var_idx", i32p), ("end_var_idx", i32p), ("allele_off", i32p),
+                     ("alleles", i32p), ("ordered_read_ids", i32p), ("cr_read", i32p)):
+        a = np.ascontiguousarray(prob[name], np.int64 if ty is i64p else np.int32)
+        if a.size == 0:
+            a = np.zeros(1, a.dtype)
+        keep.append(a)
+        setattr(s, name, a.ctypes.data_as(ty))
+    sk = np.ascontiguousarray(prob["is_skipped"], np.uint8)
+    keep.append(sk)
+    s.is_skipped = sk.ctypes.data_as(u8p)
+    for name, ty in (("haps", i32p), ("phase_sets", i64p), ("n_clean_agree_snps", i32p), ("n_clean_conflict_snps", i32p), ("var_phase_set", i64p),
+                     ("hap_to_cons_alle", i32p), ("hap_to_alle_profile", i32p)):
+        setattr(s, name, state[name].ctypes.data_as(ty))
+    return s
+
+
+def assign_hap_germline(prob, target_var_cate, state=None):
+    """assign_hap_based_on_germline_het_vars_kmeans (src/assign_hap.c:473) on a flattened chunk; returns the mutated state dict"""
+    from ._lib import LcdHapProblem
+    lib = load_library()
+    state = state or _hap_state(prob)
+    keep = []
+    s = _fill_hap_struct(LcdHapProblem, prob, state, keep)
+    check(lib.lcd_assign_hap_germline(C.byref(s), int(target_var_cate)), lib)
+    return state

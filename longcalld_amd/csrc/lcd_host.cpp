@@ -1049,6 +1049,69 @@ int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K5
+int lcd_assign_hap_batch(int n, lcd_hap_problem_t *probs, const int *targets) {
+    if (ensure_init()) return -1;
+    if (n <= 0) return 0;
+    hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    std::vector<uint8_t> hb; // host staging; offsets become device addresses
+    auto put = [&](const void *p, size_t bytes) { size_t o = lcd_align_up(hb.size(), 16); hb.resize(o + bytes); if (p && bytes) memcpy(hb.data() + o, p, bytes); return (uint64_t)o; };
+    struct Off { uint64_t var_pos, var_type, var_cate, is_hp, total_cov, alle_off, alle_covs, start_var, end_var, allele_off, alleles, ordered, cr_read, is_skipped,
+                 haps, phase_sets, agree, conflict, var_ps, cons, prof, valid, vii, het, is_het, n_agree, n_conflict, cur_cons, flags; };
+    std::vector<Off> offs(n);
+    for (int i = 0; i < n; ++i) {
+        const lcd_hap_problem_t &p = probs[i]; Off &o = offs[i];
+        const int R = p.n_reads, V = p.n_vars, TA = V ? p.alle_off[V] : 0, NA = R ? p.allele_off[R] : 0;
+        o.var_pos = put(p.var_pos, (size_t)V * 8); o.var_type = put(p.var_type, (size_t)V * 4); o.var_cate = put(p.var_cate, (size_t)V * 4);
+        o.is_hp = put(p.is_homopolymer_indel, (size_t)V * 4); o.total_cov = put(p.total_cov, (size_t)V * 4);
+        o.alle_off = put(p.alle_off, (size_t)(V + 1) * 4); o.alle_covs = put(p.alle_covs, (size_t)TA * 4);
+        o.start_var = put(p.start_var_idx, (size_t)R * 4); o.end_var = put(p.end_var_idx, (size_t)R * 4);
+        o.allele_off = put(p.allele_off, (size_t)(R + 1) * 4); o.alleles = put(p.alleles, (size_t)NA * 4);
+        o.ordered = put(p.ordered_read_ids, (size_t)R * 4); o.cr_read = put(p.cr_read, (size_t)p.n_cr * 4); o.is_skipped = put(p.is_skipped, (size_t)R);
+        o.haps = put(p.haps, (size_t)R * 4); o.phase_sets = put(p.phase_sets, (size_t)R * 8);
+        o.agree = put(p.n_clean_agree_snps, (size_t)R * 4); o.conflict = put(p.n_clean_conflict_snps, (size_t)R * 4);
+        o.var_ps = put(p.var_phase_set, (size_t)V * 8); o.cons = put(p.hap_to_cons_alle, (size_t)V * 3 * 4); o.prof = put(p.hap_to_alle_profile, (size_t)TA * 3 * 4);
+        o.valid = put(nullptr, (size_t)V * 4); o.vii = put(nullptr, (size_t)V * 4); o.het = put(nullptr, (size_t)V * 4); o.is_het = put(nullptr, (size_t)V * 4);
+        o.n_agree = put(nullptr, (size_t)V * 4); o.n_conflict = put(nullptr, (size_t)V * 4); o.cur_cons = put(nullptr, (size_t)V * 2 * 4); o.flags = put(nullptr, 64);
+    }
+    DevBuf d_buf, d_probs;
+    if (d_buf.ensure(hb.size() + 64) || d_probs.ensure(n * sizeof(HapProb))) return -11;
+    HIPCHK(hipMemcpyAsync(d_buf.p, hb.data(), hb.size(), hipMemcpyHostToDevice, st));
+    std::vector<HapProb> hp(n);
+    const uint64_t B = d_buf.addr();
+    for (int i = 0; i < n; ++i) {
+        const lcd_hap_problem_t &p = probs[i]; const Off &o = offs[i]; HapProb &q = hp[i];
+        q.n_reads = p.n_reads; q.n_vars = p.n_vars; q.is_ont = p.is_ont; q.n_cr = p.n_cr; q.total_alle = p.n_vars ? p.alle_off[p.n_vars] : 0; q.target = targets[i];
+#define DP(T, f) (T)(uintptr_t)(B + o.f)
+        q.var_pos = DP(const long long *, var_pos); q.var_type = DP(const int *, var_type); q.var_cate = DP(const int *, var_cate); q.is_hp = DP(const int *, is_hp);
+        q.total_cov = DP(const int *, total_cov); q.alle_off = DP(const int *, alle_off); q.alle_covs = DP(const int *, alle_covs);
+        q.start_var = DP(const int *, start_var); q.end_var = DP(const int *, end_var); q.allele_off = DP(const int *, allele_off); q.alleles = DP(const int *, alleles);
+        q.ordered = DP(const int *, ordered); q.cr_read = DP(const int *, cr_read); q.is_skipped = DP(const uint8_t *, is_skipped);
+        q.haps = DP(int *, haps); q.phase_sets = DP(long long *, phase_sets); q.n_agree_snps = DP(int *, agree); q.n_conflict_snps = DP(int *, conflict);
+        q.var_ps = DP(long long *, var_ps); q.cons = DP(int *, cons); q.prof = DP(int *, prof);
+        q.valid = DP(int *, valid); q.vii = DP(int *, vii); q.het = DP(int *, het); q.is_het = DP(int *, is_het); q.n_agree = DP(int *, n_agree); q.n_conflict = DP(int *, n_conflict);
+        q.cur_cons = DP(int *, cur_cons); q.flags = DP(int *, flags);
+#undef DP
+    }
+    HIPCHK(hipMemcpyAsync(d_probs.p, hp.data(), n * sizeof(HapProb), hipMemcpyHostToDevice, st));
+    lcd_launch_hap((const HapProb *)d_probs.p, n, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(hb.data(), d_buf.p, hb.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    hipStreamDestroy(st);
+    for (int i = 0; i < n; ++i) {
+        lcd_hap_problem_t &p = probs[i]; const Off &o = offs[i];
+        const int R = p.n_reads, V = p.n_vars, TA = V ? p.alle_off[V] : 0;
+        memcpy(p.haps, hb.data() + o.haps, (size_t)R * 4); memcpy(p.phase_sets, hb.data() + o.phase_sets, (size_t)R * 8);
+        memcpy(p.n_clean_agree_snps, hb.data() + o.agree, (size_t)R * 4); memcpy(p.n_clean_conflict_snps, hb.data() + o.conflict, (size_t)R * 4);
+        memcpy(p.var_phase_set, hb.data() + o.var_ps, (size_t)V * 8); memcpy(p.hap_to_cons_alle, hb.data() + o.cons, (size_t)V * 3 * 4);
+        memcpy(p.hap_to_alle_profile, hb.data() + o.prof, (size_t)TA * 3 * 4);
+    }
+    return 0;
+}
+int lcd_assign_hap_germline(lcd_hap_problem_t *p, int target_var_cate) { return lcd_assign_hap_batch(1, p, &target_var_cate); }
+
+// ---------------------------------------------------------------------------------------------------
 // per-call mirrors of src/align.h
 int lcd_wfa_end2end_aln(uint8_t *pattern, int plen, uint8_t *text, int tlen, int gap_aln, int b, int q, int e, int q2, int e2, int heuristic,
                         int affine_gap, uint32_t **cigar_buf, int *cigar_length, uint8_t **pattern_alg, uint8_t **text_alg, int *alg_length) {

@@ -151,3 +151,17 @@ struct StrOut {
     int aln_len, target_beg, target_end, query_beg, query_end;
     int shift;                   // right-cover trim: rows start at +shift (the reference re-allocates, :541-549)
 };
+
+// ---------------- K5: haplotype assignment (src/assign_hap.c:473-547) ----------------
+// bam_chunk_t / cand_var_t / read_var_profile_t flattened; every pointer is an absolute device address.
+struct HapProb {
+    int n_reads, n_vars, is_ont, n_cr, total_alle, target;
+    const long long *var_pos;
+    const int *var_type, *var_cate, *is_hp, *total_cov, *alle_off, *alle_covs;
+    const int *start_var, *end_var, *allele_off, *alleles, *ordered, *cr_read;
+    const uint8_t *is_skipped;
+    int *haps; long long *phase_sets; int *n_agree_snps, *n_conflict_snps;
+    long long *var_ps; int *cons; int *prof;
+    // scratch
+    int *valid, *vii, *het, *is_het, *n_agree, *n_conflict, *cur_cons, *flags;
+};

@@ -106,3 +106,55 @@ def make_regions(seed, n_regions, shape=HIFI):
 def regions_for_ref_mb(ref_mb):
     """~1 250 regions per 10 Mb of 30x HiFi"""
     return int(round(125 * ref_mb))
+
+
+# ---------------- K5: synthetic haplotype-assignment problems (src/assign_hap.c:473) ----------------
+CLEAN_HET_SNP, CLEAN_HET_INDEL, CLEAN_HOM_VAR, NOISY_HET, NOISY_HOM, NON_VAR = 0x004, 0x008, 0x080, 0x100, 0x200, 0x800
+GERMLINE_CLEAN = CLEAN_HET_SNP | CLEAN_HET_INDEL | CLEAN_HOM_VAR
+GERMLINE_ALL = GERMLINE_CLEAN | NOISY_HET | NOISY_HOM
+
+
+def make_hap_problem(rng, n_vars=300, n_reads=400, span=(8, 30), err=0.02, is_ont=0, gap_every=0):
+    """one chunk's read x variant profile in the flattened form of lcd_hap_problem_t; returns dict of numpy arrays + truth"""
+    pos = np.sort(rng.choice(np.arange(1000, 1000 + n_vars * 400), n_vars, replace=False)).astype(np.int64)
+    cate = rng.choice([CLEAN_HET_SNP, CLEAN_HET_INDEL, CLEAN_HOM_VAR, NOISY_HET, NOISY_HOM, NON_VAR], n_vars, p=[0.55, 0.1, 0.1, 0.12, 0.05, 0.08]).astype(np.int32)
+    vtype = np.where(np.isin(cate, [CLEAN_HET_SNP]), 8, rng.choice([8, 1, 2], n_vars)).astype(np.int32)
+    vtype[cate == CLEAN_HET_INDEL] = rng.choice([1, 2], int((cate == CLEAN_HET_INDEL).sum()))
+    is_hp = ((vtype != 8) & (rng.random(n_vars) < 0.15)).astype(np.int32)
+    hom = np.isin(cate, [CLEAN_HOM_VAR, NOISY_HOM])
+    h1 = rng.integers(0, 2, n_vars)
+    truth = np.stack([np.where(hom, 1, h1), np.where(hom, 1, 1 - h1)])  # allele of hap 1 / hap 2
+    n_alle = np.where(rng.random(n_vars) < 0.05, 3, 2).astype(np.int32)
+    alle_off = np.concatenate([[0], np.cumsum(n_alle)]).astype(np.int32)
+    starts = np.sort(rng.integers(0, max(1, n_vars - span[0]), n_reads))
+    read_hap = rng.integers(1, 3, n_reads)
+    start_var, end_var, alleles, allele_off = [], [], [], [0]
+    for r in range(n_reads):
+        s = int(starts[r]); e = min(n_vars - 1, s + int(rng.integers(span[0], span[1])))
+        if gap_every and (s // gap_every) != (e // gap_every):
+            e = (s // gap_every + 1) * gap_every - 1          # reads never bridge a block boundary -> several phase sets
+        if rng.random() < 0.03:
+            start_var.append(-1); end_var.append(-2); allele_off.append(allele_off[-1]); continue
+        a = truth[read_hap[r] - 1, s:e + 1].copy()
+        flip = rng.random(e - s + 1) < err
+        a = np.where(flip, 1 - a, a)
+        lowq = rng.random(e - s + 1)
+        a = np.where(lowq < 0.02, -1, np.where(lowq < 0.03, -2, a))
+        start_var.append(s); end_var.append(e); alleles.extend(a.tolist()); allele_off.append(allele_off[-1] + len(a))
+    start_var = np.array(start_var, np.int32); end_var = np.array(end_var, np.int32)
+    alleles = np.array(alleles, np.int32); allele_off = np.array(allele_off, np.int32)
+    is_skipped = (rng.random(n_reads) < 0.03).astype(np.uint8)
+    alle_covs = np.zeros(alle_off[-1], np.int32)
+    for r in range(n_reads):
+        if start_var[r] < 0 or is_skipped[r]:
+            continue
+        for k, v in enumerate(range(start_var[r], end_var[r] + 1)):
+            al = alleles[allele_off[r] + k]
+            if al >= 0:
+                alle_covs[alle_off[v] + al] += 1
+    total_cov = np.array([alle_covs[alle_off[v]:alle_off[v + 1]].sum() for v in range(n_vars)], np.int32)
+    ordered = np.arange(n_reads, dtype=np.int32)
+    cr_read = np.array([r for r in ordered if start_var[r] >= 0 and not is_skipped[r]], np.int32)  # cr_add order == sorted by start
+    return dict(n_reads=n_reads, n_vars=n_vars, is_ont=is_ont, var_pos=pos, var_type=vtype, var_cate=cate, is_homopolymer_indel=is_hp,
+                total_cov=total_cov, alle_off=alle_off, alle_covs=alle_covs, start_var_idx=start_var, end_var_idx=end_var, allele_off=allele_off,
+                alleles=alleles, ordered_read_ids=ordered, is_skipped=is_skipped, cr_read=cr_read, read_hap_truth=read_hap)

@@ -166,36 +166,39 @@ void lcdo_read_region_slice(const lcdo_digar1_t *digars, int n_digar, int qlen, 
                             int noisy_reg_flank_len, int *reg_read_beg, int *reg_read_end, int *cover);
 
 /* ---------------- K5: hap assignment (src/assign_hap.c:473-547) ---------------- */
+/* bam_chunk_t / cand_var_t / read_var_profile_t flattened (src/collect_var.h:71-104, src/bam_utils.h:45-92).
+ * Identical field list to lcd_hap_problem_t in include/lcd_hotpath.h (kept separate on purpose: the oracle never includes
+ * product headers). */
 typedef struct {
-    int n_reads, n_vars;
-    /* per var */
-    int64_t *var_pos;
-    int *var_type;          /* BAM_CDIFF / CINS / CDEL */
-    int *var_cate;          /* var_i_to_cate */
-    int *is_homopolymer_indel;
-    int *total_cov;
-    int *n_uniq_alles;
-    int *alle_cov_off;      /* n_vars+1 offsets into alle_covs / profiles */
-    int *alle_covs;
+    int n_reads, n_vars, is_ont;
+    /* per var (index = position in chunk->cand_vars, sorted by position) */
+    const int64_t *var_pos;          /* cand_var_t.pos */
+    const int *var_type;             /* BAM_CDIFF 8 / BAM_CINS 1 / BAM_CDEL 2 */
+    const int *var_cate;             /* chunk->var_i_to_cate */
+    const int *is_homopolymer_indel;
+    const int *total_cov;
+    const int *alle_off;             /* n_vars+1: CSR offsets into alle_covs and the profile planes */
+    const int *alle_covs;
     /* per read */
-    int *start_var_idx, *end_var_idx; /* -1 if none */
-    int *allele_off;                  /* n_reads+1 offsets into alleles */
-    int *alleles;                     /* {-2,-1,0,1,..} */
-    int *ordered_read_ids;
-    uint8_t *is_skipped;
-    /* cgranges order of (start_var_idx, end_var_idx+1, read) intervals: read ids sorted as cr_index sorts them */
+    const int *start_var_idx, *end_var_idx; /* read_var_profile_t; -1 = no var */
+    const int *allele_off;           /* n_reads+1: CSR offsets into alleles */
+    const int *alleles;              /* 0 ref, 1 alt, -1, -2 */
+    const int *ordered_read_ids;     /* chunk->ordered_read_ids, n_reads */
+    const uint8_t *is_skipped;
+    /* chunk->read_var_cr after cr_index(): labels (read ids) in the sorted interval order cr_overlap reports them */
     int n_cr;
-    int *cr_read;
-    int is_ont;
-    /* outputs (caller allocated) */
-    int *haps;              /* n_reads */
-    int64_t *phase_sets;    /* n_reads */
-    int *n_clean_agree_snps, *n_clean_conflict_snps;
-    int64_t *var_phase_set; /* n_vars */
-    int *hap_to_cons_alle;  /* n_vars*3 */
-    int *hap_to_alle_profile; /* 3 * sum(n_uniq_alles), [h][alle_cov_off[v]+a] with stride total */
+    const int *cr_read;
+    /* in/out state */
+    int *haps;                       /* n_reads */
+    int64_t *phase_sets;             /* n_reads */
+    int *n_clean_agree_snps, *n_clean_conflict_snps; /* n_reads */
+    int64_t *var_phase_set;          /* n_vars */
+    int *hap_to_cons_alle;           /* n_vars*3 */
+    int *hap_to_alle_profile;        /* 3 planes of alle_off[n_vars] ints: [h*total + alle_off[v] + a] */
 } lcdo_hap_problem_t;
 int lcdo_assign_hap_germline(lcdo_hap_problem_t *p, int target_var_cate);
+/* order of intervals (st[i], en[i], label i) after cr_index(): cr_is_sorted / radix_sort_cr_intv (src/cgranges.c:13-86,162,350) */
+void lcdo_cr_sorted_order(int n, const int *st, const int *en, int *order_out);
 
 #ifdef __cplusplus
 }

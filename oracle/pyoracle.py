@@ -245,3 +245,51 @@ def collect_noisy_reg_aln_strs(reg, opt=None):
                                            query_beg=s.query_beg, query_end=s.query_end))
             _libc.free(s.target_aln)
     return res
+
+
+class HapProblem(C.Structure):
+    _i64p = C.POINTER(C.c_int64)
+    _fields_ = [("n_reads", C.c_int), ("n_vars", C.c_int), ("is_ont", C.c_int), ("var_pos", _i64p), ("var_type", i32p), ("var_cate", i32p),
+                ("is_homopolymer_indel", i32p), ("total_cov", i32p), ("alle_off", i32p), ("alle_covs", i32p), ("start_var_idx", i32p),
+                ("end_var_idx", i32p), ("allele_off", i32p), ("alleles", i32p), ("ordered_read_ids", i32p), ("is_skipped", u8p),
+                ("n_cr", C.c_int), ("cr_read", i32p), ("haps", i32p), ("phase_sets", _i64p), ("n_clean_agree_snps", i32p),
+                ("n_clean_conflict_snps", i32p), ("var_phase_set", _i64p), ("hap_to_cons_alle", i32p), ("hap_to_alle_profile", i32p)]
+
+
+def assign_hap_germline(prob, target_var_cate, state=None):
+    """K5 oracle (oracle/assign_hap.c) on the same flattened problem dict the HIP mirror takes"""
+    R, V, TA = prob["n_reads"], prob["n_vars"], int(prob["alle_off"][-1])
+    state = state or dict(haps=np.zeros(R, np.int32), phase_sets=np.full(R, -1, np.int64), n_clean_agree_snps=np.zeros(R, np.int32),
+                          n_clean_conflict_snps=np.zeros(R, np.int32), var_phase_set=np.full(V, -1, np.int64),
+                          hap_to_cons_alle=np.full(V * 3, -1, np.int32), hap_to_alle_profile=np.zeros(3 * TA, np.int32))
+    keep = []
+    s = HapProblem()
+    s.n_reads, s.n_vars, s.is_ont, s.n_cr = R, V, prob["is_ont"], len(prob["cr_read"])
+    i64p = C.POINTER(C.c_int64)
+    for name, ty in (("var_pos", i64p), ("var_type", i32p), ("var_cate", i32p), ("is_homopolymer_indel", i32p), ("total_cov", i32p),
+                     ("alle_off", i32p), ("alle_covs", i32p), ("start_var_idx", i32p), ("end_var_idx", i32p), ("allele_off", i32p),
+                     ("alleles", i32p), ("ordered_read_ids", i32p), ("cr_read", i32p)):
+        a = np.ascontiguousarray(prob[name], np.int64 if ty is i64p else np.int32)
+        if a.size == 0:
+            a = np.zeros(1, a.dtype)
+        keep.append(a)
+        setattr(s, name, a.ctypes.data_as(ty))
+    sk = np.ascontiguousarray(prob["is_skipped"], np.uint8)
+    s.is_skipped = sk.ctypes.data_as(u8p)
+    for name, ty in (("haps", i32p), ("phase_sets", i64p), ("n_clean_agree_snps", i32p), ("n_clean_conflict_snps", i32p), ("var_phase_set", i64p),
+                     ("hap_to_cons_alle", i32p), ("hap_to_alle_profile", i32p)):
+        setattr(s, name, state[name].ctypes.data_as(ty))
+    L = lib()
+    L.lcdo_assign_hap_germline.argtypes = [C.POINTER(HapProblem), C.c_int]
+    L.lcdo_assign_hap_germline(C.byref(s), int(target_var_cate))
+    return state
+
+
+def cr_sorted_order(st, en):
+    """order in which cgranges holds intervals after cr_index() (src/cgranges.c:350-353 + radix sort :13-86)"""
+    st = np.ascontiguousarray(st, np.int32); en = np.ascontiguousarray(en, np.int32)
+    out = np.zeros(len(st), np.int32)
+    L = lib()
+    L.lcdo_cr_sorted_order.argtypes = [C.c_int, i32p, i32p, i32p]
+    L.lcdo_cr_sorted_order(len(st), st.ctypes.data_as(i32p), en.ctypes.data_as(i32p), out.ctypes.data_as(i32p))
+    return out
