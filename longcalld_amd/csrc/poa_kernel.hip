@@ -53,6 +53,7 @@ struct Ctx {
     uint8_t *base, *imap;
     int *het, *clu, *nclu; uint8_t *prof;
     int *pl_start, *pl_pidx, *pl_bonus, *pl_rem; uint8_t *pl_base;
+    int *aa_node, *aa_flag, *aa_eid;
     int n_node, n_edge, node_cap, edge_cap, rid_words;
     unsigned long long cell_cap;
     int status;
@@ -86,6 +87,21 @@ __device__ __forceinline__ int wave_incl_prefix_add(int v, int lane) {
     }
     return v;
 }
+
+// ---- DPP wave scans (gfx9 row_shr / row_bcast forms; all 64 lanes must be active) ----
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_take(int identity, int v) { return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROWMASK, 0xf, false); }
+#define LCD_DPP_SCAN(OP, ID)                                        \
+    v = OP(v, dpp_take<0x111, 0xf>(ID, v)); v = OP(v, dpp_take<0x112, 0xf>(ID, v)); \
+    v = OP(v, dpp_take<0x114, 0xf>(ID, v)); v = OP(v, dpp_take<0x118, 0xf>(ID, v)); \
+    v = OP(v, dpp_take<0x142, 0xa>(ID, v)); v = OP(v, dpp_take<0x143, 0xc>(ID, v));
+__device__ __forceinline__ int iadd(int a, int b) { return a + b; }
+__device__ __forceinline__ int scan_max(int v) { LCD_DPP_SCAN(imax, LCD_NEG * 2) return v; }
+__device__ __forceinline__ int scan_min(int v) { LCD_DPP_SCAN(imin, (1 << 30)) return v; }
+__device__ __forceinline__ int scan_add(int v) { LCD_DPP_SCAN(iadd, 0) return v; }
+__device__ __forceinline__ int shr1(int identity, int v) { return dpp_take<0x138, 0xf>(identity, v); } // wave_shr:1
+__device__ __forceinline__ int lane63(int v) { return __builtin_amdgcn_readlane(v, 63); }
+
 
 // ---------------- graph mutation (thread 0 only) ----------------
 __device__ int add_node(Ctx &g, uint8_t b) {
@@ -178,6 +194,119 @@ __device__ bool add_alignment(Ctx &g, int beg_node, int end_node, const uint8_t 
     return true;
 }
 
+// ---- parallel graph update (oracle/poa.c add_alignment; abpoa_add_subgraph_alignment) ----
+// Almost every cigar entry re-uses an existing node along an existing edge, and a read's path visits every node at most
+// once, so the entries are independent: resolve each entry's node in parallel, number the new nodes / new edges by prefix
+// sums in cigar order (== the ids the serial algorithm hands out), then create and link them in parallel -- every node
+// gains at most one out-edge, one in-edge and one aligned sibling per read, so the list appends never collide.
+template <int NT>
+__device__ int block_excl_scan(int v, Smem &sm, int *total) { // exclusive prefix sum over the NT threads; one call = two barriers
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = NT / 64;
+    const int incl = scan_add(v);
+    if (lane == 63) sm.scan[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { const int t = sm.scan[k]; if (k < wave) woff += t; tot += t; }
+    __syncthreads();
+    *total = tot;
+    return woff + incl - v;
+}
+
+template <int NT>
+__device__ bool add_alignment_block(Ctx &g, Smem &sm, int beg_node, int end_node, const uint8_t *seq, int len, int n_cig, int read_id) {
+    const int tid = threadIdx.x;
+    const int rw = read_id >> 6; const unsigned long long rbit = 1ull << (read_id & 63);
+    if (g.n_node == 2) { // first read: a chain source -> bases -> sink (abpoa_add_graph_sequence)
+        if (len + 2 > g.node_cap || len + 1 > g.edge_cap) { g.status = LCD_ERR_NODES; return false; }
+        for (int i = tid; i < len; i += NT) {
+            const int id = 2 + i;
+            g.base[id] = seq[i]; g.in_head[id] = g.in_tail[id] = i; g.out_head[id] = g.out_tail[id] = i + 1; g.nin[id] = 1; g.aligned[id] = id;
+        }
+        for (int e = tid; e <= len; e += NT) {
+            g.e_from[e] = e == 0 ? 0 : 1 + e; g.e_to[e] = e == len ? 1 : 2 + e; g.e_w[e] = 1; g.e_next_out[e] = -1; g.e_next_in[e] = -1;
+            for (int k = 0; k < g.rid_words; ++k) g.rid[(size_t)e * g.rid_words + k] = k == rw ? rbit : 0ull;
+        }
+        if (tid == 0) { g.out_head[0] = g.out_tail[0] = 0; g.in_head[1] = g.in_tail[1] = len; g.nin[1] = 1; }
+        g.n_node = len + 2; g.n_edge = len + 1;
+        __syncthreads();
+        return true;
+    }
+    if (n_cig == 0) return false;
+    // phase 1: the node each entry lands on: existing (>= 0), new and aligned to an anchor, or plain new
+    int carry = 0;
+    for (int base = 0; base < n_cig; base += NT) {
+        const int i = base + tid;
+        int isnew = 0, flag = -2, T = 0;
+        if (i < n_cig) {
+            const uint8_t b = seq[g.cig_qpos[i]];
+            const int node = g.cig_node[i];
+            if (node >= 0) {
+                if (g.base[node] == b) T = node;
+                else {
+                    int a = -1;
+                    for (int x = g.aligned[node]; x != node; x = g.aligned[x]) if (g.base[x] == b) { a = x; break; }
+                    if (a >= 0) T = a; else { isnew = 1; flag = node; }
+                }
+            } else { isnew = 1; flag = -1; }
+        }
+        int tot;
+        const int rank = block_excl_scan<NT>(isnew, sm, &tot);
+        if (i < n_cig) { g.aa_node[i] = isnew ? g.n_node + carry + rank : T; g.aa_flag[i] = flag; }
+        carry += tot;
+    }
+    const int n_new = carry;
+    if (g.n_node + n_new > g.node_cap) { g.status = LCD_ERR_NODES; return false; }
+    __syncthreads();
+    // phase 2: new nodes
+    for (int i = tid; i < n_cig; i += NT) {
+        const int flag = g.aa_flag[i];
+        if (flag == -2) continue;
+        const int id = g.aa_node[i];
+        g.base[id] = seq[g.cig_qpos[i]]; g.out_head[id] = g.out_tail[id] = g.in_head[id] = g.in_tail[id] = -1; g.nin[id] = 0;
+        if (flag >= 0) { g.aligned[id] = g.aligned[flag]; g.aligned[flag] = id; } else g.aligned[id] = id;
+    }
+    // phase 3: edges j = 0..n_cig (from path[j-1] to path[j]); existing ones gain weight + read id, the others are numbered
+    carry = 0;
+    for (int base = 0; base <= n_cig; base += NT) {
+        const int j = base + tid;
+        int need = 0;
+        if (j <= n_cig) {
+            const int from = j == 0 ? beg_node : g.aa_node[j - 1], to = j == n_cig ? end_node : g.aa_node[j];
+            const bool from_new = j > 0 && g.aa_flag[j - 1] != -2, to_new = j < n_cig && g.aa_flag[j] != -2;
+            need = 1;
+            if (!from_new && !to_new)
+                for (int e = g.out_head[from]; e >= 0; e = g.e_next_out[e])
+                    if (g.e_to[e] == to) { g.e_w[e] += 1; g.rid[(size_t)e * g.rid_words + rw] |= rbit; need = 0; break; }
+        }
+        int tot;
+        const int rank = block_excl_scan<NT>(need, sm, &tot);
+        if (j <= n_cig) g.aa_eid[j] = need ? g.n_edge + carry + rank : -1;
+        carry += tot;
+    }
+    const int n_newe = carry;
+    if (g.n_edge + n_newe > g.edge_cap) { g.status = LCD_ERR_EDGES; return false; }
+    __syncthreads(); // new-node fields (phase 2) and edge numbers are visible
+    // phase 4: create + link the new edges
+    for (int j = tid; j <= n_cig; j += NT) {
+        const int e = g.aa_eid[j];
+        if (e < 0) continue;
+        const int from = j == 0 ? beg_node : g.aa_node[j - 1], to = j == n_cig ? end_node : g.aa_node[j];
+        g.e_from[e] = from; g.e_to[e] = to; g.e_w[e] = 1; g.e_next_out[e] = -1; g.e_next_in[e] = -1;
+        for (int k = 0; k < g.rid_words; ++k) g.rid[(size_t)e * g.rid_words + k] = k == rw ? rbit : 0ull;
+        const int ot = g.out_tail[from];
+        if (ot < 0) g.out_head[from] = e; else g.e_next_out[ot] = e;
+        g.out_tail[from] = e;
+        const int it = g.in_tail[to];
+        if (it < 0) g.in_head[to] = e; else g.e_next_in[it] = e;
+        g.in_tail[to] = e; g.nin[to] += 1;
+    }
+    g.n_node += n_new; g.n_edge += n_newe;
+    __syncthreads();
+    return true;
+}
+
 // Kahn BFS order + remain for the whole workgroup: the pointer-chasing part still runs on one lane (the FIFO order is
 // inherently serial) but on 16-bit copies of the graph staged in LDS, so each dependent step costs an LDS access (~60 clk)
 // instead of an HBM/L2 access (~500 clk); staging in and out is a coalesced parallel copy.  Falls back to HBM when the
@@ -265,20 +394,6 @@ __device__ void subgraph_nodes_wave0(Ctx &g, int lane, int inc_beg, int inc_end,
     }
     *exc_beg = g.idx2node[up]; *exc_end = g.idx2node[down];
 }
-
-// ---- DPP wave scans (gfx9 row_shr / row_bcast forms; all 64 lanes must be active) ----
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ int dpp_take(int identity, int v) { return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROWMASK, 0xf, false); }
-#define LCD_DPP_SCAN(OP, ID)                                        \
-    v = OP(v, dpp_take<0x111, 0xf>(ID, v)); v = OP(v, dpp_take<0x112, 0xf>(ID, v)); \
-    v = OP(v, dpp_take<0x114, 0xf>(ID, v)); v = OP(v, dpp_take<0x118, 0xf>(ID, v)); \
-    v = OP(v, dpp_take<0x142, 0xa>(ID, v)); v = OP(v, dpp_take<0x143, 0xc>(ID, v));
-__device__ __forceinline__ int iadd(int a, int b) { return a + b; }
-__device__ __forceinline__ int scan_max(int v) { LCD_DPP_SCAN(imax, LCD_NEG * 2) return v; }
-__device__ __forceinline__ int scan_min(int v) { LCD_DPP_SCAN(imin, (1 << 30)) return v; }
-__device__ __forceinline__ int scan_add(int v) { LCD_DPP_SCAN(iadd, 0) return v; }
-__device__ __forceinline__ int shr1(int identity, int v) { return dpp_take<0x138, 0xf>(identity, v); } // wave_shr:1
-__device__ __forceinline__ int lane63(int v) { return __builtin_amdgcn_readlane(v, 63); }
 
 // LDS-only workgroup barrier: orders LDS traffic without draining the HBM store queue (vmcnt), which a
 // __syncthreads() would do.  Single-wavefront workgroups need no s_barrier at all (LDS ops of one wave are in order).
@@ -846,6 +961,7 @@ __global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chain
     g.het = (int *)(ws + L.het); g.clu = (int *)(ws + L.clu); g.nclu = (int *)(ws + L.nclu); g.prof = ws + L.prof;
     g.pl_start = (int *)(ws + L.pl_start); g.pl_pidx = (int *)(ws + L.pl_pidx); g.pl_bonus = (int *)(ws + L.pl_bonus);
     g.pl_rem = (int *)(ws + L.pl_rem); g.pl_base = ws + L.pl_base;
+    g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
     g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0;
     const long long t_begin = clock64();
@@ -885,15 +1001,8 @@ __global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chain
         }
         // graph update + re-sort: serial pointer work on thread 0; results published through LDS
         const long long tg0 = clock64();
-        if (tid == 0) {
-            bool changed = false;
-            if (len > 0 && g.status == LCD_OK) changed = add_alignment(g, exc_beg, exc_end, seq, len, n_cig, i);
-            sm.bc[4] = g.n_node; sm.bc[5] = g.n_edge; sm.bc[6] = g.status; sm.bc[7] = changed;
-        }
-        __syncthreads();
-        g.n_node = sm.bc[4]; g.n_edge = sm.bc[5]; g.status = sm.bc[6];
-        const bool changed = sm.bc[7] != 0;
-        __syncthreads();
+        bool changed = false;
+        if (len > 0 && g.status == LCD_OK) changed = add_alignment_block<NT>(g, sm, exc_beg, exc_end, seq, len, n_cig, i);
         if (changed && g.status == LCD_OK) topo_sort_block<NT>(g, sm, lds_pool);
         t_graph += (unsigned long long)(clock64() - tg0);
     }
