@@ -99,6 +99,31 @@ __device__ __forceinline__ int iadd(int a, int b) { return a + b; }
 __device__ __forceinline__ int scan_max(int v) { LCD_DPP_SCAN(imax, LCD_NEG * 2) return v; }
 __device__ __forceinline__ int scan_min(int v) { LCD_DPP_SCAN(imin, (1 << 30)) return v; }
 __device__ __forceinline__ int scan_add(int v) { LCD_DPP_SCAN(iadd, 0) return v; }
+// two inclusive prefix-max scans interleaved: v_max_i32_dpp leaves lanes without a source untouched (no bound_ctrl), which
+// is exactly max(v, nothing); the other scan's instruction + s_nop 0 fill the 2 wait states a DPP read needs after a write
+__device__ __forceinline__ void scan_max2(int &a, int &b) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(a), "+v"(b));
+}
 __device__ __forceinline__ int shr1(int identity, int v) { return dpp_take<0x138, 0xf>(identity, v); } // wave_shr:1
 __device__ __forceinline__ int lane63(int v) { return __builtin_amdgcn_readlane(v, 63); }
 
@@ -528,14 +553,33 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
     // ================= unbanded fast path (K2, wb < 0) =================
     // w = qlen makes every row [0, qlen] (oracle: beg = max(0, .. - qlen) = 0, end = min(qlen, .. + qlen) = qlen, and the
     // source row already spans it), every node is reachable, so row metadata is implicit: rbeg = 0, rend = qlen,
-    // roff = (idx - bi) * (qlen + 1).  No staging, no band, no row-max: per row one LDS barrier for the F carry.
-    if (wb < 0 && bi == 0 && ei == n - 1 && qlen + 1 <= WMAX) {
+    // roff = (idx - bi) * (qlen + 1).  No staging, no band, no row-max.
+    // The row code is written for few instructions per 64-cell chunk (the chain is issue-bound, not bandwidth-bound):
+    //   * per-chunk column constants live in registers for the whole read;
+    //   * ring slot = [guard | H(0..qlen)] [E1] [E2]: the guard word (-2^30) stands in for H[j-1] at j = 0, so the
+    //     match term needs no bounds test;
+    //   * both prefix-max scans run interleaved as v_max_i32_dpp (row_shr / row_bcast) in one asm block.
+    if (wb < 0 && bi == 0 && ei == n - 1 && qlen + 2 <= WMAX) {
         const int W1 = qlen + 1;
         const int nchunks = (W1 + 63) >> 6;
         const int R = (nchunks + NW - 1) / NW;
         if ((unsigned long long)(ei - bi) * W1 > g.cell_cap) { g.status = LCD_ERR_CELLS; return 0; }
         for (int i = bi + 1 + tid; i < ei; i += NT) { g.rbeg[i] = 0; g.rend[i] = qlen; g.roff[i] = (uint32_t)((i - bi) * (unsigned)W1); }
         used = (unsigned long long)(ei - bi) * W1;
+        constexpr int SLOTW = 3 * WMAX; // words per ring slot
+        // source row into slot 0 with the guarded layout; guards of every slot
+        for (int j = tid; j <= qlen; j += NT) {
+            const int f1 = j ? -(o1 + e1 * j) : LCD_NEG, f2 = j ? -(o2 + e2 * j) : LCD_NEG;
+            const int h = j ? imax(f1, f2) : 0;
+            ring[1 + j] = h; ring[WMAX + j] = h - oe1; ring[2 * WMAX + j] = h - oe2;
+        }
+        if (tid < K) ring[tid * SLOTW] = LCD_NEG * 2;
+        si0 = bi; si1 = -1; si2 = -1; si3 = -1; next_slot = 1 % K;
+        __syncthreads();
+        last_full = bi + 1;
+        // per-chunk constants of this thread (chunks of a wavefront are contiguous): column, activity, a-offsets, f-offsets
+        int col0 = ((wave * R + 0) << 6) + lane, col1 = col0 + 64, col2 = col0 + 128, col3 = col0 + 192;
+        const bool ac0 = 0 < R && col0 <= qlen, ac1 = 1 < R && col1 <= qlen, ac2 = 2 < R && col2 <= qlen, ac3 = 3 < R && col3 <= qlen;
         int wbase = -(1 << 20);
         int w_p0 = 0, w_np = 0, w_vb = 4, w_pi0 = 0, w_b0 = 0, w_pi1 = 0, w_b1 = 0;
         for (int idx = bi + 1; idx < ei; ++idx) {
@@ -552,11 +596,11 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
             }
             const int wk = idx - wbase;
             const int p0 = LCD_RL(w_p0, wk), np = LCD_RL(w_np, wk);
-            const uint8_t vb = (uint8_t)LCD_RL(w_vb, wk);
+            const int vb = LCD_RL(w_vb, wk);
             const int pi0 = LCD_RL(w_pi0, wk), bz0 = LCD_RL(w_b0, wk), pi1 = LCD_RL(w_pi1, wk), bz1 = LCD_RL(w_b1, wk);
             const int sl0 = np > 0 ? LCD_SLOT_OF(pi0) : 0, sl1 = np > 1 ? LCD_SLOT_OF(pi1) : 0;
-            // predecessors that are not in the ring are read from HBM: their stores must have drained
-            {
+            const bool fastrow = np >= 1 && np <= 2 && sl0 >= 0 && sl1 >= 0;
+            if (!fastrow) { // predecessors that are not in the ring are read from HBM: their stores must have drained
                 int far = -1;
                 if (np > 0 && sl0 < 0) far = pi0;
                 if (np > 1 && sl1 < 0) far = imax(far, pi1);
@@ -565,45 +609,60 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
             }
             const unsigned off = (unsigned)(idx - bi) * (unsigned)W1;
             const int slot = next_slot;
-            int *rH = ring + (size_t)slot * 3 * WMAX, *rE1 = rH + WMAX, *rE2 = rH + 2 * WMAX;
+            int *rS = ring + slot * SLOTW;
             int hp0 = LCD_NEG, hp1 = LCD_NEG, hp2 = LCD_NEG, hp3 = LCD_NEG, ea0 = LCD_NEG, ea1 = LCD_NEG, ea2 = LCD_NEG, ea3 = LCD_NEG;
             int eb0 = LCD_NEG, eb1 = LCD_NEG, eb2 = LCD_NEG, eb3 = LCD_NEG;
             int pa0 = LCD_NEG * 2, pa1 = LCD_NEG * 2, pa2 = LCD_NEG * 2, pa3 = LCD_NEG * 2, pb0 = LCD_NEG * 2, pb1 = LCD_NEG * 2, pb2 = LCD_NEG * 2, pb3 = LCD_NEG * 2;
             int wc1 = LCD_NEG * 2, wc2 = LCD_NEG * 2;
-            auto predU = [&](const int j, const int s, const int pi, const int bonus, const int sl, int &mx, int &e1i, int &e2i) {
-                if (sl >= 0) {
-                    const int *qH = ring + (size_t)sl * 3 * WMAX;
-                    if (j >= 1) mx = imax(mx, qH[j - 1] + s + bonus);
-                    e1i = imax(e1i, qH[WMAX + j] + bonus); e2i = imax(e2i, qH[2 * WMAX + j] + bonus);
-                } else {
-                    const size_t po = (size_t)(pi - bi) * W1;
-                    if (j >= 1) mx = imax(mx, g.H[po + j - 1] + s + bonus);
-                    e1i = imax(e1i, g.E1[po + j] + bonus); e2i = imax(e2i, g.E2[po + j] + bonus);
+            // ---- phase A: Hpre of every chunk + in-wavefront prefix maxima ----
+            auto hpre_fast = [&](const int c, const bool act, int &hp, int &ev1, int &ev2) {
+                // c - 1 >= -1 : sseq[-1] is never used (the guard makes the match term irrelevant at c == 0)
+                const uint8_t qb = sseq[c > 0 ? c - 1 : 0];
+                const int s = (vb >= 4 || qb >= 4) ? 0 : (vb == qb ? sc.match : -sc.mismatch);
+                const int *q0 = ring + sl0 * SLOTW;
+                int mx = q0[c] + s + bz0, e1i = q0[WMAX + c] + bz0, e2i = q0[2 * WMAX + c] + bz0; // q0[c] == guarded H[c-1]
+                if (np > 1) {
+                    const int *q1 = ring + sl1 * SLOTW;
+                    mx = imax(mx, q1[c] + s + bz1); e1i = imax(e1i, q1[WMAX + c] + bz1); e2i = imax(e2i, q1[2 * WMAX + c] + bz1);
                 }
+                (void)act;
+                hp = imax(mx, imax(e1i, e2i)); ev1 = e1i; ev2 = e2i;
             };
-            auto phaseA = [&](const int r, int &hp, int &ev1, int &ev2, int &pr1, int &pr2) {
-                const int rel = ((wave * R + r) << 6) + lane;
-                const int j = rel;
-                const bool act = j <= qlen;
+            auto hpre_slow = [&](const int c, const bool act, int &hp, int &ev1, int &ev2) {
                 int mx = LCD_NEG, e1i = LCD_NEG, e2i = LCD_NEG;
                 if (act) {
                     int s = 0;
-                    if (j >= 1) { const uint8_t qb = sseq[j - 1]; s = (vb >= 4 || qb >= 4) ? 0 : (vb == qb ? sc.match : -sc.mismatch); }
-                    if (np > 0) predU(j, s, pi0, bz0, sl0, mx, e1i, e2i);
-                    if (np > 1) predU(j, s, pi1, bz1, sl1, mx, e1i, e2i);
-                    for (int t = 2; t < np; ++t) predU(j, s, g.pl_pidx[p0 + t], g.pl_bonus[p0 + t], -1, mx, e1i, e2i);
+                    if (c >= 1) { const uint8_t qb = sseq[c - 1]; s = (vb >= 4 || qb >= 4) ? 0 : (vb == qb ? sc.match : -sc.mismatch); }
+                    for (int t = 0; t < np; ++t) {
+                        const int pi = t == 0 ? pi0 : t == 1 ? pi1 : g.pl_pidx[p0 + t];
+                        const int bonus = t == 0 ? bz0 : t == 1 ? bz1 : g.pl_bonus[p0 + t];
+                        const int sl = t == 0 ? sl0 : t == 1 ? sl1 : -1;
+                        if (sl >= 0) {
+                            const int *q = ring + sl * SLOTW;
+                            if (c >= 1) mx = imax(mx, q[c] + s + bonus);
+                            e1i = imax(e1i, q[WMAX + c] + bonus); e2i = imax(e2i, q[2 * WMAX + c] + bonus);
+                        } else {
+                            const size_t po = (size_t)(pi - bi) * W1;
+                            if (c >= 1) mx = imax(mx, g.H[po + c - 1] + s + bonus);
+                            e1i = imax(e1i, g.E1[po + c] + bonus); e2i = imax(e2i, g.E2[po + c] + bonus);
+                        }
+                    }
                 }
-                const int hpre = imax(mx, imax(e1i, e2i));
-                hp = hpre; ev1 = e1i; ev2 = e2i;
-                const int a1 = act ? hpre + rel * e1 : LCD_NEG * 2, a2 = act ? hpre + rel * e2 : LCD_NEG * 2;
-                const int i1 = scan_max(a1), i2 = scan_max(a2);
-                pr1 = imax(shr1(LCD_NEG * 2, i1), wc1); pr2 = imax(shr1(LCD_NEG * 2, i2), wc2);
-                wc1 = imax(wc1, lane63(i1)); wc2 = imax(wc2, lane63(i2));
+                hp = imax(mx, imax(e1i, e2i)); ev1 = e1i; ev2 = e2i;
             };
-            if (0 < R) phaseA(0, hp0, ea0, eb0, pa0, pb0);
-            if (1 < R) phaseA(1, hp1, ea1, eb1, pa1, pb1);
-            if (2 < R) phaseA(2, hp2, ea2, eb2, pa2, pb2);
-            if (3 < R) phaseA(3, hp3, ea3, eb3, pa3, pb3);
+#define LCD_PHASE_A(r, c, act, hp, ev1, ev2, pr1, pr2)                                              \
+            if (r < R) {                                                                                \
+                if (fastrow) hpre_fast(c, act, hp, ev1, ev2); else hpre_slow(c, act, hp, ev1, ev2);      \
+                int a1 = act ? hp + c * e1 : LCD_NEG * 2, a2 = act ? hp + c * e2 : LCD_NEG * 2;          \
+                scan_max2(a1, a2);                                                                       \
+                pr1 = imax(shr1(LCD_NEG * 2, a1), wc1); pr2 = imax(shr1(LCD_NEG * 2, a2), wc2);          \
+                wc1 = imax(wc1, lane63(a1)); wc2 = imax(wc2, lane63(a2));                                \
+            }
+            LCD_PHASE_A(0, col0, ac0, hp0, ea0, eb0, pa0, pb0)
+            LCD_PHASE_A(1, col1, ac1, hp1, ea1, eb1, pa1, pb1)
+            LCD_PHASE_A(2, col2, ac2, hp2, ea2, eb2, pa2, pb2)
+            LCD_PHASE_A(3, col3, ac3, hp3, ea3, eb3, pa3, pb3)
+#undef LCD_PHASE_A
             int cin1 = LCD_NEG * 2, cin2 = LCD_NEG * 2;
             if (NW > 1) {
                 const int buf = idx & 1;
@@ -612,28 +671,27 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
 #pragma unroll
                 for (int k = 0; k < NW; ++k) if (k < wave) { cin1 = imax(cin1, sm.tot1[buf][k]); cin2 = imax(cin2, sm.tot2[buf][k]); }
             }
-            auto phaseB = [&](const int r, const int hp, const int ev1, const int ev2, const int pr1, const int pr2) {
-                const int rel = ((wave * R + r) << 6) + lane;
-                if (rel <= qlen) {
-                    const int p1 = imax(pr1, cin1), p2 = imax(pr2, cin2);
-                    const int f1 = (rel > 0) ? imax(LCD_NEG, p1 - o1 - rel * e1) : LCD_NEG;
-                    const int f2 = (rel > 0) ? imax(LCD_NEG, p2 - o2 - rel * e2) : LCD_NEG;
-                    int h = imax(hp, imax(f1, f2)); if (h < LCD_NEG) h = LCD_NEG;
-                    int eo1 = imax(h - oe1, ev1 - e1), eo2 = imax(h - oe2, ev2 - e2);
-                    if (eo1 < LCD_NEG) eo1 = LCD_NEG;
-                    if (eo2 < LCD_NEG) eo2 = LCD_NEG;
-                    g.H[off + rel] = h; g.E1[off + rel] = eo1; g.E2[off + rel] = eo2;
-                    rH[rel] = h; rE1[rel] = eo1; rE2[rel] = eo2;
-                }
-            };
-            if (0 < R) phaseB(0, hp0, ea0, eb0, pa0, pb0);
-            if (1 < R) phaseB(1, hp1, ea1, eb1, pa1, pb1);
-            if (2 < R) phaseB(2, hp2, ea2, eb2, pa2, pb2);
-            if (3 < R) phaseB(3, hp3, ea3, eb3, pa3, pb3);
+            // ---- phase B: F, H, E; row to the ring slot and to HBM ----
+#define LCD_PHASE_B(c, act, hp, ev1, ev2, pr1, pr2)                                                  \
+            if (act) {                                                                                  \
+                const int f1 = imax(LCD_NEG, imax(pr1, cin1) - o1 - c * e1);                             \
+                const int f2 = imax(LCD_NEG, imax(pr2, cin2) - o2 - c * e2);                             \
+                int h = imax(hp, imax(f1, f2)); if (h < LCD_NEG) h = LCD_NEG;                             \
+                int eo1 = imax(h - oe1, ev1 - e1), eo2 = imax(h - oe2, ev2 - e2);                         \
+                if (eo1 < LCD_NEG) eo1 = LCD_NEG;                                                         \
+                if (eo2 < LCD_NEG) eo2 = LCD_NEG;                                                         \
+                g.H[off + c] = h; g.E1[off + c] = eo1; g.E2[off + c] = eo2;                               \
+                rS[1 + c] = h; rS[WMAX + c] = eo1; rS[2 * WMAX + c] = eo2;                                \
+            }
+            // (at c == 0 the prefix values are -2^30, so f clamps to LCD_NEG exactly as the oracle's "j > beg" test does)
+            LCD_PHASE_B(col0, ac0, hp0, ea0, eb0, pa0, pb0)
+            LCD_PHASE_B(col1, ac1, hp1, ea1, eb1, pa1, pb1)
+            LCD_PHASE_B(col2, ac2, hp2, ea2, eb2, pa2, pb2)
+            LCD_PHASE_B(col3, ac3, hp3, ea3, eb3, pa3, pb3)
+#undef LCD_PHASE_B
             if (slot == 0) si0 = idx; else if (slot == 1) si1 = idx; else if (slot == 2) si2 = idx; else si3 = idx;
             next_slot = (slot + 1) % K;
-            // the ring slot just written is read by the next row; with one wavefront LDS is in order, otherwise the next
-            // row's totals barrier comes too late for phase A, so publish the row here
+            // publish the ring slot to the other wavefronts before the next row's phase A
             lds_barrier<NT>();
         }
     } else {
