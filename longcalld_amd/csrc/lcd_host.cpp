@@ -160,7 +160,7 @@ struct lcd_batch_s {
 
 namespace {
 
-LcdScoring scoring_of(const lcd_opt_t &o) { LcdScoring s; s.match = o.match; s.mismatch = o.mismatch; s.o1 = o.gap_open1; s.e1 = o.gap_ext1; s.o2 = o.gap_open2; s.e2 = o.gap_ext2; return s; }
+LcdScoring scoring_of(const lcd_opt_t &o) { LcdScoring s; s.match = o.match; s.mismatch = o.mismatch; s.o1 = o.gap_open1; s.e1 = o.gap_ext1; s.o2 = o.gap_open2; s.e2 = o.gap_ext2; s.dbg = getenv("LCD_DBG") ? atoi(getenv("LCD_DBG")) : 0; return s; }
 
 uint64_t wfa_arena_bytes(int plen, int tlen, int s_cap) {
     // header + ops + sum_{s<=s_cap} 5*(2s+3) offsets, diagonals never exceed plen+tlen+3
@@ -953,7 +953,7 @@ int lcd_wfa_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t 
         j.p_off = d_pool.addr() + p_off[i]; j.t_off = d_pool.addr() + t_off[i]; j.plen = plen[i]; j.tlen = tlen[i]; j.gap_aln = gap_aln[i]; j.want = want;
         j.s_cap = wfa_default_scap(plen[i], tlen[i]); j.ws_off = j.ws_bytes = j.out_off = 0;
     }
-    LcdScoring sc; sc.match = 0; sc.mismatch = b; sc.o1 = q; sc.e1 = e; sc.o2 = q2; sc.e2 = e2;
+    LcdScoring sc; sc.dbg = 0; sc.match = 0; sc.mismatch = b; sc.o1 = q; sc.e1 = e; sc.o2 = q2; sc.e2 = e2;
     std::vector<WfaOut> outs;
     int rc = run_wfa_stage(st, jobs, d_jobs, d_arena, d_out, d_outs, outs, sc, nullptr);
     if (rc) { hipStreamDestroy(st); return rc; }

@@ -553,33 +553,36 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
     // ================= unbanded fast path (K2, wb < 0) =================
     // w = qlen makes every row [0, qlen] (oracle: beg = max(0, .. - qlen) = 0, end = min(qlen, .. + qlen) = qlen, and the
     // source row already spans it), every node is reachable, so row metadata is implicit: rbeg = 0, rend = qlen,
-    // roff = (idx - bi) * (qlen + 1).  No staging, no band, no row-max.
-    // The row code is written for few instructions per 64-cell chunk (the chain is issue-bound, not bandwidth-bound):
-    //   * per-chunk column constants live in registers for the whole read;
-    //   * ring slot = [guard | H(0..qlen)] [E1] [E2]: the guard word (-2^30) stands in for H[j-1] at j = 0, so the
-    //     match term needs no bounds test;
-    //   * both prefix-max scans run interleaved as v_max_i32_dpp (row_shr / row_bcast) in one asm block.
-    if (wb < 0 && bi == 0 && ei == n - 1 && qlen + 2 <= WMAX) {
-        const int W1 = qlen + 1;
-        const int nchunks = (W1 + 63) >> 6;
-        const int R = (nchunks + NW - 1) / NW;
-        if ((unsigned long long)(ei - bi) * W1 > g.cell_cap) { g.status = LCD_ERR_CELLS; return 0; }
-        for (int i = bi + 1 + tid; i < ei; i += NT) { g.rbeg[i] = 0; g.rend[i] = qlen; g.roff[i] = (uint32_t)((i - bi) * (unsigned)W1); }
-        used = (unsigned long long)(ei - bi) * W1;
+    // roff = (idx - bi) * W1p (row stride padded to 4 cells).  No staging, no band, no row-max.
+    // FOUR cells per lane: a wavefront covers 256 columns, so a row is one sweep of the workgroup.  Predecessor rows
+    // come from the LDS ring as ds_read_b128, the row goes to HBM as global_store_dwordx4, the horizontal-gap prefix is
+    // 3 in-lane max + ONE interleaved DPP scan pair per 256 cells.  (The chain is issue-bound: this is ~4x fewer
+    // instructions per cell than one cell per lane.)
+    // Ring slot layout (words): H plane = [.. guard @3 | H(0..qlen) @4..], E1 plane @WMAX, E2 plane @2*WMAX; the guard
+    // (-2^30) stands in for H[j-1] at j = 0 so the match term needs no bounds test.  Query bases are kept shifted by one
+    // byte (q[j-1] at byte j) so a lane's four bases are one aligned ds_read_b32.
+    if (wb < 0 && bi == 0 && ei == n - 1 && qlen + 5 <= WMAX && 2 * (qlen + 8) <= Cfg<NT>::SEQ_CAP) {
+        const int W1 = qlen + 1, W1p = (W1 + 3) & ~3;
+        if ((unsigned long long)(ei - bi) * W1p > g.cell_cap) { g.status = LCD_ERR_CELLS; return 0; }
+        for (int i = bi + 1 + tid; i < ei; i += NT) { g.rbeg[i] = 0; g.rend[i] = qlen; g.roff[i] = (uint32_t)((i - bi) * (unsigned)W1p); }
+        used = (unsigned long long)(ei - bi) * W1p;
         constexpr int SLOTW = 3 * WMAX; // words per ring slot
-        // source row into slot 0 with the guarded layout; guards of every slot
+        uint8_t *sq1 = sseq + ((qlen + 8 + 15) & ~15); // shifted copy: sq1[j] = q[j-1]
+        for (int j = tid; j <= qlen + 3; j += NT) sq1[j] = (j >= 1 && j <= qlen) ? seq_hbm[j - 1] : 4;
+        // source row into slot 0; guards of every slot
         for (int j = tid; j <= qlen; j += NT) {
             const int f1 = j ? -(o1 + e1 * j) : LCD_NEG, f2 = j ? -(o2 + e2 * j) : LCD_NEG;
             const int h = j ? imax(f1, f2) : 0;
-            ring[1 + j] = h; ring[WMAX + j] = h - oe1; ring[2 * WMAX + j] = h - oe2;
+            ring[4 + j] = h; ring[WMAX + j] = h - oe1; ring[2 * WMAX + j] = h - oe2;
         }
-        if (tid < K) ring[tid * SLOTW] = LCD_NEG * 2;
+        if (tid < K) ring[tid * SLOTW + 3] = LCD_NEG * 2;
         si0 = bi; si1 = -1; si2 = -1; si3 = -1; next_slot = 1 % K;
         __syncthreads();
         last_full = bi + 1;
-        // per-chunk constants of this thread (chunks of a wavefront are contiguous): column, activity, a-offsets, f-offsets
-        int col0 = ((wave * R + 0) << 6) + lane, col1 = col0 + 64, col2 = col0 + 128, col3 = col0 + 192;
-        const bool ac0 = 0 < R && col0 <= qlen, ac1 = 1 < R && col1 <= qlen, ac2 = 2 < R && col2 <= qlen, ac3 = 3 < R && col3 <= qlen;
+        // this lane's four columns
+        const int c = (wave << 8) + (lane << 2);
+        const bool k0 = c <= qlen, k1 = c + 1 <= qlen, k2 = c + 2 <= qlen, k3 = c + 3 <= qlen;
+        const int c1a = c * e1, c2a = c * e2; // a-offsets of cell 0 (cell k adds k*e)
         int wbase = -(1 << 20);
         int w_p0 = 0, w_np = 0, w_vb = 4, w_pi0 = 0, w_b0 = 0, w_pi1 = 0, w_b1 = 0;
         for (int idx = bi + 1; idx < ei; ++idx) {
@@ -607,88 +610,104 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
                 if (np > 2) far = 1 << 30;
                 if (far >= last_full) { __syncthreads(); last_full = idx; }
             }
-            const unsigned off = (unsigned)(idx - bi) * (unsigned)W1;
+            const size_t off = (size_t)(idx - bi) * W1p;
             const int slot = next_slot;
             int *rS = ring + slot * SLOTW;
-            int hp0 = LCD_NEG, hp1 = LCD_NEG, hp2 = LCD_NEG, hp3 = LCD_NEG, ea0 = LCD_NEG, ea1 = LCD_NEG, ea2 = LCD_NEG, ea3 = LCD_NEG;
-            int eb0 = LCD_NEG, eb1 = LCD_NEG, eb2 = LCD_NEG, eb3 = LCD_NEG;
-            int pa0 = LCD_NEG * 2, pa1 = LCD_NEG * 2, pa2 = LCD_NEG * 2, pa3 = LCD_NEG * 2, pb0 = LCD_NEG * 2, pb1 = LCD_NEG * 2, pb2 = LCD_NEG * 2, pb3 = LCD_NEG * 2;
-            int wc1 = LCD_NEG * 2, wc2 = LCD_NEG * 2;
-            // ---- phase A: Hpre of every chunk + in-wavefront prefix maxima ----
-            auto hpre_fast = [&](const int c, const bool act, int &hp, int &ev1, int &ev2) {
-                // c - 1 >= -1 : sseq[-1] is never used (the guard makes the match term irrelevant at c == 0)
-                const uint8_t qb = sseq[c > 0 ? c - 1 : 0];
-                const int s = (vb >= 4 || qb >= 4) ? 0 : (vb == qb ? sc.match : -sc.mismatch);
-                const int *q0 = ring + sl0 * SLOTW;
-                int mx = q0[c] + s + bz0, e1i = q0[WMAX + c] + bz0, e2i = q0[2 * WMAX + c] + bz0; // q0[c] == guarded H[c-1]
-                if (np > 1) {
-                    const int *q1 = ring + sl1 * SLOTW;
-                    mx = imax(mx, q1[c] + s + bz1); e1i = imax(e1i, q1[WMAX + c] + bz1); e2i = imax(e2i, q1[2 * WMAX + c] + bz1);
+            // ---- phase A: Hpre of the four cells ----
+            int h0, h1, h2, h3, u0, u1, u2, u3, v0, v1, v2, v3; // Hpre, E1in, E2in
+            if (fastrow) {
+                const unsigned qw = *(const unsigned *)(sq1 + c); // q[c-1], q[c], q[c+1], q[c+2]
+                int s0, s1, s2, s3;
+                {
+                    const int q0 = qw & 255, q1 = (qw >> 8) & 255, q2 = (qw >> 16) & 255, q3 = qw >> 24;
+                    s0 = (vb >= 4 || q0 >= 4) ? 0 : (vb == q0 ? sc.match : -sc.mismatch);
+                    s1 = (vb >= 4 || q1 >= 4) ? 0 : (vb == q1 ? sc.match : -sc.mismatch);
+                    s2 = (vb >= 4 || q2 >= 4) ? 0 : (vb == q2 ? sc.match : -sc.mismatch);
+                    s3 = (vb >= 4 || q3 >= 4) ? 0 : (vb == q3 ? sc.match : -sc.mismatch);
                 }
-                (void)act;
-                hp = imax(mx, imax(e1i, e2i)); ev1 = e1i; ev2 = e2i;
-            };
-            auto hpre_slow = [&](const int c, const bool act, int &hp, int &ev1, int &ev2) {
-                int mx = LCD_NEG, e1i = LCD_NEG, e2i = LCD_NEG;
-                if (act) {
-                    int s = 0;
-                    if (c >= 1) { const uint8_t qb = sseq[c - 1]; s = (vb >= 4 || qb >= 4) ? 0 : (vb == qb ? sc.match : -sc.mismatch); }
-                    for (int t = 0; t < np; ++t) {
-                        const int pi = t == 0 ? pi0 : t == 1 ? pi1 : g.pl_pidx[p0 + t];
-                        const int bonus = t == 0 ? bz0 : t == 1 ? bz1 : g.pl_bonus[p0 + t];
-                        const int sl = t == 0 ? sl0 : t == 1 ? sl1 : -1;
-                        if (sl >= 0) {
-                            const int *q = ring + sl * SLOTW;
-                            if (c >= 1) mx = imax(mx, q[c] + s + bonus);
-                            e1i = imax(e1i, q[WMAX + c] + bonus); e2i = imax(e2i, q[2 * WMAX + c] + bonus);
-                        } else {
-                            const size_t po = (size_t)(pi - bi) * W1;
-                            if (c >= 1) mx = imax(mx, g.H[po + c - 1] + s + bonus);
-                            e1i = imax(e1i, g.E1[po + c] + bonus); e2i = imax(e2i, g.E2[po + c] + bonus);
+                const int *q = ring + sl0 * SLOTW;
+                const int hm = q[3 + c];                                        // H[c-1] (guard at c == 0)
+                const int4 hv = *(const int4 *)(q + 4 + c);                     // H[c..c+3]
+                const int4 av = *(const int4 *)(q + WMAX + c), bv = *(const int4 *)(q + 2 * WMAX + c);
+                const int m0 = hm + s0 + bz0, m1 = hv.x + s1 + bz0, m2 = hv.y + s2 + bz0, m3 = hv.z + s3 + bz0;
+                u0 = av.x + bz0; u1 = av.y + bz0; u2 = av.z + bz0; u3 = av.w + bz0;
+                v0 = bv.x + bz0; v1 = bv.y + bz0; v2 = bv.z + bz0; v3 = bv.w + bz0;
+                int n0 = m0, n1 = m1, n2 = m2, n3 = m3;
+                if (np > 1) {
+                    const int *r = ring + sl1 * SLOTW;
+                    const int gm = r[3 + c];
+                    const int4 gv = *(const int4 *)(r + 4 + c);
+                    const int4 cv = *(const int4 *)(r + WMAX + c), dv = *(const int4 *)(r + 2 * WMAX + c);
+                    n0 = imax(n0, gm + s0 + bz1); n1 = imax(n1, gv.x + s1 + bz1); n2 = imax(n2, gv.y + s2 + bz1); n3 = imax(n3, gv.z + s3 + bz1);
+                    u0 = imax(u0, cv.x + bz1); u1 = imax(u1, cv.y + bz1); u2 = imax(u2, cv.z + bz1); u3 = imax(u3, cv.w + bz1);
+                    v0 = imax(v0, dv.x + bz1); v1 = imax(v1, dv.y + bz1); v2 = imax(v2, dv.z + bz1); v3 = imax(v3, dv.w + bz1);
+                }
+                h0 = imax(n0, imax(u0, v0)); h1 = imax(n1, imax(u1, v1)); h2 = imax(n2, imax(u2, v2)); h3 = imax(n3, imax(u3, v3));
+            } else {
+                auto slow = [&](const int cc, const bool act, int &hp, int &ev1, int &ev2) {
+                    int mx = LCD_NEG, e1i = LCD_NEG, e2i = LCD_NEG;
+                    if (act) {
+                        int s = 0;
+                        if (cc >= 1) { const uint8_t qb = sq1[cc]; s = (vb >= 4 || qb >= 4) ? 0 : (vb == qb ? sc.match : -sc.mismatch); }
+                        for (int t = 0; t < np; ++t) {
+                            const int pi = t == 0 ? pi0 : t == 1 ? pi1 : g.pl_pidx[p0 + t];
+                            const int bonus = t == 0 ? bz0 : t == 1 ? bz1 : g.pl_bonus[p0 + t];
+                            const int sl = t == 0 ? sl0 : t == 1 ? sl1 : -1;
+                            if (sl >= 0) {
+                                const int *q = ring + sl * SLOTW;
+                                if (cc >= 1) mx = imax(mx, q[3 + cc] + s + bonus);
+                                e1i = imax(e1i, q[WMAX + cc] + bonus); e2i = imax(e2i, q[2 * WMAX + cc] + bonus);
+                            } else {
+                                const size_t po = (size_t)(pi - bi) * W1p;
+                                if (cc >= 1) mx = imax(mx, g.H[po + cc - 1] + s + bonus);
+                                e1i = imax(e1i, g.E1[po + cc] + bonus); e2i = imax(e2i, g.E2[po + cc] + bonus);
+                            }
                         }
                     }
-                }
-                hp = imax(mx, imax(e1i, e2i)); ev1 = e1i; ev2 = e2i;
-            };
-#define LCD_PHASE_A(r, c, act, hp, ev1, ev2, pr1, pr2)                                              \
-            if (r < R) {                                                                                \
-                if (fastrow) hpre_fast(c, act, hp, ev1, ev2); else hpre_slow(c, act, hp, ev1, ev2);      \
-                int a1 = act ? hp + c * e1 : LCD_NEG * 2, a2 = act ? hp + c * e2 : LCD_NEG * 2;          \
-                scan_max2(a1, a2);                                                                       \
-                pr1 = imax(shr1(LCD_NEG * 2, a1), wc1); pr2 = imax(shr1(LCD_NEG * 2, a2), wc2);          \
-                wc1 = imax(wc1, lane63(a1)); wc2 = imax(wc2, lane63(a2));                                \
+                    hp = imax(mx, imax(e1i, e2i)); ev1 = e1i; ev2 = e2i;
+                };
+                slow(c, k0, h0, u0, v0); slow(c + 1, k1, h1, u1, v1); slow(c + 2, k2, h2, u2, v2); slow(c + 3, k3, h3, u3, v3);
             }
-            LCD_PHASE_A(0, col0, ac0, hp0, ea0, eb0, pa0, pb0)
-            LCD_PHASE_A(1, col1, ac1, hp1, ea1, eb1, pa1, pb1)
-            LCD_PHASE_A(2, col2, ac2, hp2, ea2, eb2, pa2, pb2)
-            LCD_PHASE_A(3, col3, ac3, hp3, ea3, eb3, pa3, pb3)
-#undef LCD_PHASE_A
-            int cin1 = LCD_NEG * 2, cin2 = LCD_NEG * 2;
+            // ---- F: A[k] = Hpre[k] + k*e; in-lane inclusive prefix, then one scan pair over the lane totals ----
+            const int a10 = k0 ? h0 + c1a : LCD_NEG * 2, a11 = imax(a10, k1 ? h1 + c1a + e1 : LCD_NEG * 2), a12 = imax(a11, k2 ? h2 + c1a + 2 * e1 : LCD_NEG * 2);
+            const int a20 = k0 ? h0 + c2a : LCD_NEG * 2, a21 = imax(a20, k1 ? h1 + c2a + e2 : LCD_NEG * 2), a22 = imax(a21, k2 ? h2 + c2a + 2 * e2 : LCD_NEG * 2);
+            int t1 = imax(a12, k3 ? h3 + c1a + 3 * e1 : LCD_NEG * 2), t2 = imax(a22, k3 ? h3 + c2a + 3 * e2 : LCD_NEG * 2);
+            scan_max2(t1, t2);
+            int x1 = shr1(LCD_NEG * 2, t1), x2 = shr1(LCD_NEG * 2, t2); // exclusive prefix over the lanes of this wavefront
             if (NW > 1) {
                 const int buf = idx & 1;
-                if (lane == 0) { sm.tot1[buf][wave] = wc1; sm.tot2[buf][wave] = wc2; }
+                if (lane == 63) { sm.tot1[buf][wave] = t1; sm.tot2[buf][wave] = t2; }
                 lds_barrier<NT>();
 #pragma unroll
-                for (int k = 0; k < NW; ++k) if (k < wave) { cin1 = imax(cin1, sm.tot1[buf][k]); cin2 = imax(cin2, sm.tot2[buf][k]); }
+                for (int k = 0; k < NW; ++k) if (k < wave) { x1 = imax(x1, sm.tot1[buf][k]); x2 = imax(x2, sm.tot2[buf][k]); }
             }
-            // ---- phase B: F, H, E; row to the ring slot and to HBM ----
-#define LCD_PHASE_B(c, act, hp, ev1, ev2, pr1, pr2)                                                  \
-            if (act) {                                                                                  \
-                const int f1 = imax(LCD_NEG, imax(pr1, cin1) - o1 - c * e1);                             \
-                const int f2 = imax(LCD_NEG, imax(pr2, cin2) - o2 - c * e2);                             \
-                int h = imax(hp, imax(f1, f2)); if (h < LCD_NEG) h = LCD_NEG;                             \
-                int eo1 = imax(h - oe1, ev1 - e1), eo2 = imax(h - oe2, ev2 - e2);                         \
-                if (eo1 < LCD_NEG) eo1 = LCD_NEG;                                                         \
-                if (eo2 < LCD_NEG) eo2 = LCD_NEG;                                                         \
-                g.H[off + c] = h; g.E1[off + c] = eo1; g.E2[off + c] = eo2;                               \
-                rS[1 + c] = h; rS[WMAX + c] = eo1; rS[2 * WMAX + c] = eo2;                                \
+            // ---- phase B: F, H, E of the four cells; row to the ring slot and to HBM ----
+            // (at column 0 the prefix is -2^30, so f clamps to LCD_NEG exactly as the oracle's "j > beg" test does)
+            if (k0) {
+                int4 H4, A4, B4;
+#define LCD_CELL(k, hp, ev1, ev2, p1, p2, HO, AO, BO)                                                   \
+                {                                                                                        \
+                    const int f1 = imax(LCD_NEG, (p1) - o1 - c1a - (k) * e1), f2 = imax(LCD_NEG, (p2) - o2 - c2a - (k) * e2); \
+                    int h = imax(hp, imax(f1, f2)); if (h < LCD_NEG) h = LCD_NEG;                          \
+                    int eo1 = imax(h - oe1, (ev1) - e1), eo2 = imax(h - oe2, (ev2) - e2);                  \
+                    if (eo1 < LCD_NEG) eo1 = LCD_NEG;                                                      \
+                    if (eo2 < LCD_NEG) eo2 = LCD_NEG;                                                      \
+                    HO = h; AO = eo1; BO = eo2;                                                            \
+                }
+                LCD_CELL(0, h0, u0, v0, x1, x2, H4.x, A4.x, B4.x)
+                LCD_CELL(1, h1, u1, v1, imax(x1, a10), imax(x2, a20), H4.y, A4.y, B4.y)
+                LCD_CELL(2, h2, u2, v2, imax(x1, a11), imax(x2, a21), H4.z, A4.z, B4.z)
+                LCD_CELL(3, h3, u3, v3, imax(x1, a12), imax(x2, a22), H4.w, A4.w, B4.w)
+#undef LCD_CELL
+                if (k3) {
+                    if (!(sc.dbg & 1)) { *(int4 *)(g.H + off + c) = H4; *(int4 *)(g.E1 + off + c) = A4; *(int4 *)(g.E2 + off + c) = B4; }
+                    if (!(sc.dbg & 2)) *(int4 *)(rS + 4 + c) = H4; *(int4 *)(rS + WMAX + c) = A4; *(int4 *)(rS + 2 * WMAX + c) = B4;
+                } else {
+                    g.H[off + c] = H4.x; g.E1[off + c] = A4.x; g.E2[off + c] = B4.x; rS[4 + c] = H4.x; rS[WMAX + c] = A4.x; rS[2 * WMAX + c] = B4.x;
+                    if (k1) { g.H[off + c + 1] = H4.y; g.E1[off + c + 1] = A4.y; g.E2[off + c + 1] = B4.y; rS[5 + c] = H4.y; rS[WMAX + c + 1] = A4.y; rS[2 * WMAX + c + 1] = B4.y; }
+                    if (k2) { g.H[off + c + 2] = H4.z; g.E1[off + c + 2] = A4.z; g.E2[off + c + 2] = B4.z; rS[6 + c] = H4.z; rS[WMAX + c + 2] = A4.z; rS[2 * WMAX + c + 2] = B4.z; }
+                }
             }
-            // (at c == 0 the prefix values are -2^30, so f clamps to LCD_NEG exactly as the oracle's "j > beg" test does)
-            LCD_PHASE_B(col0, ac0, hp0, ea0, eb0, pa0, pb0)
-            LCD_PHASE_B(col1, ac1, hp1, ea1, eb1, pa1, pb1)
-            LCD_PHASE_B(col2, ac2, hp2, ea2, eb2, pa2, pb2)
-            LCD_PHASE_B(col3, ac3, hp3, ea3, eb3, pa3, pb3)
-#undef LCD_PHASE_B
             if (slot == 0) si0 = idx; else if (slot == 1) si1 = idx; else if (slot == 2) si2 = idx; else si3 = idx;
             next_slot = (slot + 1) % K;
             // publish the ring slot to the other wavefronts before the next row's phase A
@@ -916,7 +935,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
                 if (c > best) { best = c; br = pi; }
             }
         }
-        if (br >= 0 && best > LCD_NEG / 2) {
+        if (br >= 0 && best > LCD_NEG / 2 && !(sc.dbg & 5)) {
             int pos = qlen;
             int i = br, j = qlen, st = 0;
 #define CELLH(pi, jj) g.H[g.roff[pi] + ((jj) - g.rbeg[pi])]
