@@ -14,6 +14,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# every submission lane owns two HIP streams; give the runtime enough hardware queues that lanes do not serialise behind
+# each other's long-tailed chain kernels (the ROCm default maps all streams onto 4 queues)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 
@@ -27,7 +30,7 @@ def main():
     ap.add_argument("--shape", default="hifi", choices=["hifi", "ont"])
     ap.add_argument("--cpu-sample", type=int, default=300, help="regions timed on the CPU oracle for cpu_baseline (rank 0, N=1 only)")
     ap.add_argument("--seed", type=int, default=20250928)
-    ap.add_argument("--lanes", type=int, default=8,
+    ap.add_argument("--lanes", type=int, default=4,
                     help="concurrent submission lanes per GPU (host threads, one lcd_batch_t + HIP stream each) -- the reference's own "
                          "execution model: kt_for runs n_threads chunk workers concurrently (src/call_var_main.c:773); the K steps are "
                          "dealt round-robin to the lanes and ALL of them complete inside the timed region")

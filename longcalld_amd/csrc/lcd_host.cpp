@@ -129,12 +129,13 @@ struct OutStr { // one aln_str in the final output pool
 
 } // namespace
 
+#define LCD_NSIDE 12
 struct lcd_batch_s {
     lcd_opt_t opt;
     hipStream_t stream = nullptr;
-    hipStream_t side[2] = {nullptr, nullptr};
+    hipStream_t side[LCD_NSIDE] = {};
     hipEvent_t ev[10];
-    hipEvent_t sev[3];
+    hipEvent_t sev[LCD_NSIDE + 1];
     std::vector<uint8_t> h_pool;
     std::vector<RegionRec> regs;
     std::vector<ChainRec> chains;
@@ -511,6 +512,7 @@ int lcd_batch_upload(lcd_batch_t *b) {
     return 0;
 }
 
+static void chain_class(PoaChain &pc);
 static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vector<PoaRead> &preads, int scale, PoaChain &pc) {
     const int n = (int)C.members.size();
     long long sum = 0; int maxl = 0;
@@ -533,18 +535,33 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     for (int s = 1; s < scale && cells < worst; s *= 2) cells *= 8;
     cells = std::min(cells, worst);
     pc.cell_cap = (uint64_t)std::max<long long>(cells, maxl + 64);
+    chain_class(pc);
 }
 
-// workgroup size class of a chain: follows the DP row width (poa_kernel.hip)
-static int chain_threads(const PoaChain &pc) {
+// Workgroup size class + LDS budget of a chain (poa_kernel.hip): threads follow the DP row width; the dynamic LDS pool holds
+// K ring slots of `wmax` columns + the query cache during the DP and the 16-bit graph copy of the re-sort (about 22 B per node)
+// afterwards.  Chains are launched in groups of equal (threads, LDS bucket) so that short chains do not pay a long chain's LDS.
+static void chain_class(PoaChain &pc) {
     const long long width = pc.mode == 1 ? (long long)pc.max_len + 1 : 2ll * (10 + pc.max_len / 100) + 1 + 32;
-    // class 64 caches <= 4096 query bases in LDS, the wider classes 51200; the LDS pool also has to hold the 16-bit graph copy of
-    // the re-sort (about 22 B per node): 24 KB / 80 KB / 146 KB (poa_kernel.hip Cfg<>)
+    int threads, K, wmax;
+    if (width <= 128 && pc.max_len <= 4000) { threads = 64; K = 4; wmax = 256; }
+    else if (width <= 1024) { threads = 256; K = 2; wmax = pc.mode == 1 ? (int)lcd_align_up(pc.max_len + 8, 64) : 1024; }
+    else { threads = 1024; K = 2; wmax = pc.mode == 1 ? (int)std::min<long long>(4096, (long long)lcd_align_up(pc.max_len + 8, 64)) : 4096; }
+    const long long seq_bytes = lcd_align_up(pc.mode == 1 ? 2ll * (pc.max_len + 24) + 32 : (long long)pc.max_len + 16, 64);
+    const long long dp_bytes = (long long)K * 3 * wmax * 4 + seq_bytes;
     const long long est_nodes = (long long)(pc.max_len * 1.15) + 64;
-    if (width <= 128 && pc.max_len <= 4096 && est_nodes * 22 <= 24576) return 64;
-    if (width <= 1024 && est_nodes * 22 <= 81920) return 256;
-    return 1024;
+    const long long need = std::max(dp_bytes, est_nodes * 22 + 64);
+    static const int buckets[] = {16 << 10, 32 << 10, 64 << 10, 148 << 10}; // few buckets: every (threads, bucket) group is one launch
+    int lds = buckets[3];
+    for (int b : buckets) if (need <= b) { lds = b; break; }
+    if (dp_bytes > lds) { // the ring cannot hold a full row: shrink the slot (rows wider than wmax go through HBM)
+        const long long room = (lds - seq_bytes) / (K * 3 * 4);
+        wmax = (int)std::max<long long>(64, room / 64 * 64);
+    }
+    pc.threads = threads; pc.wmax = wmax; pc.lds_words = lds / 4;
 }
+static int chain_threads(const PoaChain &pc) { return pc.threads; }
+static long long chain_group_key(const PoaChain &pc) { return (long long)pc.threads * (1 << 20) + pc.lds_words; }
 // uploads `sub` (already ordered so that equal classes are contiguous) and launches one kernel per class
 // (different classes go to side streams so a long wide chain does not hold back the narrow ones)
 static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, DevBuf &d_chains, const PoaRead *d_reads, DevBuf &d_outs, LcdScoring sc,
@@ -554,11 +571,15 @@ static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, 
     size_t i = 0; int nside = 0;
     while (i < sub.size()) {
         const int cls = chain_threads(sub[i]);
+        const long long key = chain_group_key(sub[i]);
         size_t j = i;
-        while (j < sub.size() && chain_threads(sub[j]) == cls) ++j;
+        while (j < sub.size() && chain_group_key(sub[j]) == key) ++j;
+        // every (threads, LDS) group on its own stream so that a long-tailed group does not hold back the others.  Streams that
+        // share a hardware queue still serialise: callers that run several batches at once should raise GPU_MAX_HW_QUEUES
+        // (ROCm maps all streams onto 4 queues by default; bench.py sets 24).
         hipStream_t s = st;
-        if (side && nside < 2 && j < sub.size()) { s = side[nside]; HIPCHK(hipStreamWaitEvent(s, sev[0], 0)); }
-        lcd_launch_poa((const PoaChain *)d_chains.p + i, d_reads, nullptr, nullptr, nullptr, (PoaChainOut *)d_outs.p + i, sc, (int)(j - i), cls, s);
+        if (side && nside < LCD_NSIDE && j < sub.size()) { s = side[nside]; HIPCHK(hipStreamWaitEvent(s, sev[0], 0)); }
+        lcd_launch_poa((const PoaChain *)d_chains.p + i, d_reads, nullptr, nullptr, nullptr, (PoaChainOut *)d_outs.p + i, sc, (int)(j - i), cls, sub[i].lds_words * 4, s);
         HIPCHK(hipGetLastError());
         if (s != st) { HIPCHK(hipEventRecord(sev[1 + nside], s)); ++nside; }
         i = j;
@@ -643,8 +664,8 @@ int lcd_batch_run(lcd_batch_t *b) {
         for (int c = 0; c < nC; ++c) which[c] = c;
         // biggest first so the long chains start early (LPT)
         std::sort(which.begin(), which.end(), [&](int a, int c2) {
-            const int ta = chain_threads(b->pchains[a]), tc = chain_threads(b->pchains[c2]);
-            if (ta != tc) return ta > tc; // widest class first, then biggest first (LPT)
+            const long long ta = chain_group_key(b->pchains[a]), tc = chain_group_key(b->pchains[c2]);
+            if (ta != tc) return ta > tc; // widest / largest-LDS group first, then biggest first (LPT)
             return b->pchains[a].cell_cap > b->pchains[c2].cell_cap; });
         int scale = 1;
         for (int round = 0; round < 12 && !which.empty(); ++round) {

@@ -47,6 +47,9 @@ struct PoaChain {
     int read0;        // first PoaRead of this chain
     int mode;         // 0: K1 sub-graph incremental, wb=10 wf=0.01, 1 consensus; 1: K2 unbanded, <=2 consensus
     int node_cap, edge_cap, rid_words, max_len;
+    int threads;      // workgroup size class: 64 / 256 / 1024 (by DP row width)
+    int wmax;         // columns per LDS ring slot
+    int lds_words;    // dynamic LDS of the launch this chain is in (ring + query cache, re-used by the re-sort)
     uint32_t min_w;   // (int)(n*min_af) clipped below at 2 (cluster threshold)
     uint64_t cell_cap;
     uint64_t ws_off;  // byte offset of this chain's arena

@@ -38,9 +38,10 @@ struct Smem {
 
 template <int NT> struct Cfg;
 // One LDS pool per workgroup: [row ring | query cache] during the DP, re-used as 16-bit graph arrays by the re-sort.
-template <> struct Cfg<64> { static constexpr int WMAX = 256, K = 4, SEQ_CAP = 4096, POOL_WORDS = 6144; };   // 24 KB; reads <= 4 kb by class
-template <> struct Cfg<256> { static constexpr int WMAX = 1024, K = 2, SEQ_CAP = 51200, POOL_WORDS = 20480; }; // 80 KB
-template <> struct Cfg<1024> { static constexpr int WMAX = 4096, K = 2, SEQ_CAP = 51200, POOL_WORDS = 37376; }; // 146 KB
+// (sizes are per launch: PoaChain.wmax columns per ring slot, PoaChain.lds_words in total; only the slot count is per class)
+template <> struct Cfg<64> { static constexpr int K = 4; };
+template <> struct Cfg<256> { static constexpr int K = 2; };
+template <> struct Cfg<1024> { static constexpr int K = 2; };
 
 struct Ctx {
     int *H, *E1, *E2;
@@ -54,6 +55,7 @@ struct Ctx {
     int *het, *clu, *nclu; uint8_t *prof;
     int *pl_start, *pl_pidx, *pl_bonus, *pl_rem; uint8_t *pl_base;
     int *aa_node, *aa_flag, *aa_eid;
+    int wmax, seq_cap, pool_words;
     int n_node, n_edge, node_cap, edge_cap, rid_words;
     unsigned long long cell_cap;
     int status;
@@ -340,7 +342,7 @@ template <int NT>
 __device__ void topo_sort_block(Ctx &g, Smem &sm, int *lds_pool) {
     const int tid = threadIdx.x;
     const int n = g.n_node, E = g.n_edge;
-    const bool fits = n < 65535 && E < 65535 && (size_t)14 * n + (size_t)6 * E + 64 <= (size_t)Cfg<NT>::POOL_WORDS * 4;
+    const bool fits = n < 65535 && E < 65535 && (size_t)14 * n + (size_t)6 * E + 64 <= (size_t)g.pool_words * 4;
     if (!fits) {
         if (tid == 0) { topo_sort(g); sm.bc[6] = g.status; }
         __syncthreads();
@@ -449,7 +451,8 @@ constexpr int RMAX = 4; // 64-column chunks per wavefront per sweep: NW*RMAX*64 
 template <int NT>
 __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, const LcdScoring &sc, const int wb, int wf_milli, int beg_node, int end_node,
                                  const uint8_t *seq_hbm, int qlen, unsigned long long *cells_acc) {
-    constexpr int NW = NT / 64, WMAX = Cfg<NT>::WMAX, K = Cfg<NT>::K;
+    constexpr int NW = NT / 64, K = Cfg<NT>::K;
+    const int WMAX = g.wmax; // ring slot capacity in columns: chosen per launch from the chains' lengths (dynamic LDS)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (qlen <= 0) return 0;
     const int bi = g.node2idx[beg_node], ei = g.node2idx[end_node];
@@ -462,7 +465,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
     // (two explicit pointers, never one that may be either: a maybe-LDS pointer compiles to FLAT loads, whose s_waitcnt
     //  couples vmcnt and lgkmcnt and would stall every chunk behind the row stores still draining to HBM)
     const uint8_t *seq = seq_hbm;
-    if (qlen > Cfg<NT>::SEQ_CAP) { g.status = LCD_ERR_NODES; return 0; } // read slice longer than the LDS query cache (host sizes the class)
+    if (qlen > g.seq_cap) { g.status = LCD_ERR_NODES; return 0; } // read slice longer than the LDS query cache (host sizes the class)
     for (int i = tid; i < qlen; i += NT) sseq[i] = seq_hbm[i];
     // ---- reachability map over [bi, ei] ----
     if (bi == 0 && ei == n - 1) {
@@ -561,12 +564,12 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
     // Ring slot layout (words): H plane = [.. guard @3 | H(0..qlen) @4..], E1 plane @WMAX, E2 plane @2*WMAX; the guard
     // (-2^30) stands in for H[j-1] at j = 0 so the match term needs no bounds test.  Query bases are kept shifted by one
     // byte (q[j-1] at byte j) so a lane's four bases are one aligned ds_read_b32.
-    if (wb < 0 && bi == 0 && ei == n - 1 && qlen + 5 <= WMAX && 2 * (qlen + 8) <= Cfg<NT>::SEQ_CAP) {
+    if (wb < 0 && bi == 0 && ei == n - 1 && qlen + 5 <= WMAX && qlen + 5 <= NT * 4 && 2 * (qlen + 24) <= g.seq_cap) {
         const int W1 = qlen + 1, W1p = (W1 + 3) & ~3;
         if ((unsigned long long)(ei - bi) * W1p > g.cell_cap) { g.status = LCD_ERR_CELLS; return 0; }
         for (int i = bi + 1 + tid; i < ei; i += NT) { g.rbeg[i] = 0; g.rend[i] = qlen; g.roff[i] = (uint32_t)((i - bi) * (unsigned)W1p); }
         used = (unsigned long long)(ei - bi) * W1p;
-        constexpr int SLOTW = 3 * WMAX; // words per ring slot
+        const int SLOTW = 3 * WMAX; // words per ring slot
         uint8_t *sq1 = sseq + ((qlen + 8 + 15) & ~15); // shifted copy: sq1[j] = q[j-1]
         for (int j = tid; j <= qlen + 3; j += NT) sq1[j] = (j >= 1 && j <= qlen) ? seq_hbm[j - 1] : 4;
         // source row into slot 0; guards of every slot
@@ -1013,12 +1016,11 @@ __global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chain
     const int cid = blockIdx.x;
     if (cid >= n_chains) return;
     __shared__ Smem sm;
-    __shared__ int lds_pool[Cfg<NT>::POOL_WORDS];
+    extern __shared__ int lds_pool[]; // [row ring | query cache], re-used by the re-sort; sized per launch (PoaChain.lds_words)
     int *ring = lds_pool;
-    uint8_t *sseq = (uint8_t *)(lds_pool + Cfg<NT>::K * 3 * Cfg<NT>::WMAX);
-    static_assert(Cfg<NT>::K * 3 * Cfg<NT>::WMAX * 4 + Cfg<NT>::SEQ_CAP <= Cfg<NT>::POOL_WORDS * 4, "LDS pool too small");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const PoaChain ch = chains[cid];
+    uint8_t *sseq = (uint8_t *)(lds_pool + Cfg<NT>::K * 3 * ch.wmax);
     const PoaLayout L = poa_layout(ch.node_cap, ch.edge_cap, ch.rid_words, ch.max_len, ch.cell_cap, ch.n_reads);
     uint8_t *ws = arena + ch.ws_off;
     Ctx g;
@@ -1040,6 +1042,7 @@ __global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chain
     g.pl_rem = (int *)(ws + L.pl_rem); g.pl_base = ws + L.pl_base;
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
+    g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - Cfg<NT>::K * 3 * ch.wmax) * 4;
     g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0;
     const long long t_begin = clock64();
     unsigned long long t_graph = 0, t_sub = 0;
@@ -1255,12 +1258,19 @@ __global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chain
 }
 
 void lcd_launch_poa(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool, uint8_t *arena, uint8_t *outpool,
-                    PoaChainOut *outs, LcdScoring sc, int n_chains, int threads, hipStream_t stream) {
+                    PoaChainOut *outs, LcdScoring sc, int n_chains, int threads, int lds_bytes, hipStream_t stream) {
     if (n_chains <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) { // allow > 64 KB of dynamic LDS (gfx950 has 160 KB per CU)
+        hipFuncSetAttribute((const void *)lcd_poa_chain_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipFuncSetAttribute((const void *)lcd_poa_chain_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipFuncSetAttribute((const void *)lcd_poa_chain_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
     if (threads <= 64)
-        hipLaunchKernelGGL(lcd_poa_chain_kernel<64>, dim3(n_chains), dim3(64), 0, stream, chains, reads, pool, arena, outpool, outs, sc, n_chains);
+        hipLaunchKernelGGL(lcd_poa_chain_kernel<64>, dim3(n_chains), dim3(64), lds_bytes, stream, chains, reads, pool, arena, outpool, outs, sc, n_chains);
     else if (threads <= 256)
-        hipLaunchKernelGGL(lcd_poa_chain_kernel<256>, dim3(n_chains), dim3(256), 0, stream, chains, reads, pool, arena, outpool, outs, sc, n_chains);
+        hipLaunchKernelGGL(lcd_poa_chain_kernel<256>, dim3(n_chains), dim3(256), lds_bytes, stream, chains, reads, pool, arena, outpool, outs, sc, n_chains);
     else
-        hipLaunchKernelGGL(lcd_poa_chain_kernel<1024>, dim3(n_chains), dim3(1024), 0, stream, chains, reads, pool, arena, outpool, outs, sc, n_chains);
+        hipLaunchKernelGGL(lcd_poa_chain_kernel<1024>, dim3(n_chains), dim3(1024), lds_bytes, stream, chains, reads, pool, arena, outpool, outs, sc, n_chains);
 }
