@@ -23,3 +23,16 @@ def main(db_path, out_path, title):
 
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "rocprofv3 kernel stats")
+
+
+def pmc_summary(db_path, counter):
+    """sum of a PMC counter (rocprofv3 --pmc X) per kernel over all its dispatches"""
+    db = sqlite3.connect(db_path)
+    cur = db.cursor()
+    out = {}
+    for name, val in cur.execute("select name, counter_value from pmc_events where counter_name = ?", (counter,)):
+        k = name.split("(")[0]
+        out.setdefault(k, [0, 0.0])
+        out[k][0] += 1
+        out[k][1] += val
+    return out
