@@ -542,22 +542,19 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
 // K ring slots of `wmax` columns + the query cache during the DP and the 16-bit graph copy of the re-sort (about 22 B per node)
 // afterwards.  Chains are launched in groups of equal (threads, LDS bucket) so that short chains do not pay a long chain's LDS.
 static void chain_class(PoaChain &pc) {
-    const long long width = pc.mode == 1 ? (long long)pc.max_len + 1 : 2ll * (10 + pc.max_len / 100) + 1 + 32;
-    int threads, K, wmax;
-    if (width <= 128 && pc.max_len <= 4000) { threads = 64; K = 4; wmax = 256; }
-    else if (width <= 1024) { threads = 256; K = 2; wmax = pc.mode == 1 ? (int)lcd_align_up(pc.max_len + 8, 64) : 1024; }
-    else { threads = 1024; K = 2; wmax = pc.mode == 1 ? (int)std::min<long long>(4096, (long long)lcd_align_up(pc.max_len + 8, 64)) : 4096; }
-    const long long seq_bytes = lcd_align_up(pc.mode == 1 ? 2ll * (pc.max_len + 24) + 32 : (long long)pc.max_len + 16, 64);
-    const long long dp_bytes = (long long)K * 3 * wmax * 4 + seq_bytes;
+    // DP row width: K2 rows span the whole read (+2 guard columns of the window); K1 rows are the adaptive band plus drift
+    const long long width = pc.mode == 1 ? (long long)pc.max_len + 2 : 2ll * (10 + pc.max_len / 100) + 1 + 48;
+    int threads, K, wmax; // wmax: window / ring-slot width in columns, a power of two <= 4 * threads (poa_kernel.hip align_windowed)
+    if (width <= 256) { threads = 64; K = 4; wmax = 256; }
+    else if (width <= 1024) { threads = 256; K = 2; wmax = width <= 512 ? 512 : 1024; }
+    else { threads = 1024; K = 2; wmax = width <= 2048 ? 2048 : 4096; } // wider rows take the generic (HBM) rows of the kernel
     const long long est_nodes = (long long)(pc.max_len * 1.15) + 64;
+    const long long seq_bytes = lcd_align_up((long long)pc.max_len + 28, 16) + lcd_align_up(est_nodes + 16, 16); // query cache + first-predecessor distances
+    const long long dp_bytes = (long long)K * 3 * wmax * 4 + seq_bytes;
     const long long need = std::max(dp_bytes, est_nodes * 22 + 64);
     static const int buckets[] = {16 << 10, 32 << 10, 64 << 10, 148 << 10}; // few buckets: every (threads, bucket) group is one launch
     int lds = buckets[3];
     for (int b : buckets) if (need <= b) { lds = b; break; }
-    if (dp_bytes > lds) { // the ring cannot hold a full row: shrink the slot (rows wider than wmax go through HBM)
-        const long long room = (lds - seq_bytes) / (K * 3 * 4);
-        wmax = (int)std::max<long long>(64, room / 64 * 64);
-    }
     pc.threads = threads; pc.wmax = wmax; pc.lds_words = lds / 4;
 }
 static int chain_threads(const PoaChain &pc) { return pc.threads; }

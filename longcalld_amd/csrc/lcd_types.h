@@ -72,7 +72,7 @@ struct PoaChainOut {
 // arena layout (byte offsets relative to ws_off); identical on host and device
 struct PoaLayout {
     uint64_t H, E1, E2;                                  // int32[cell_cap]
-    uint64_t rbeg, rend, roff;                           // int32/int32/uint32 [node_cap], by topological index
+    uint64_t rbeg, rend, roff, ooff, spoff;              // int32/int32/uint32 x3 [node_cap], by topological index
     uint64_t mpl, mpr;                                   // int32[node_cap]: leftmost/rightmost row-max column, by topological index
     uint64_t idx2node, node2idx, remain, deg, queue;     // int32[node_cap]
     uint64_t n_out_head, n_out_tail, n_in_head, n_in_tail, n_nin, n_aligned;  // int32[node_cap]
@@ -94,6 +94,7 @@ static inline LCD_HD PoaLayout poa_layout(int node_cap, int edge_cap, int rid_wo
 #define LCD_TAKE(field, bytes) do { L.field = o; o = lcd_align_up(o + (uint64_t)(bytes), 16); } while (0)
     LCD_TAKE(H, cell_cap * 4); LCD_TAKE(E1, cell_cap * 4); LCD_TAKE(E2, cell_cap * 4);
     LCD_TAKE(rbeg, (uint64_t)node_cap * 4); LCD_TAKE(rend, (uint64_t)node_cap * 4); LCD_TAKE(roff, (uint64_t)node_cap * 4);
+    LCD_TAKE(ooff, (uint64_t)node_cap * 4); LCD_TAKE(spoff, (uint64_t)node_cap * 4);
     LCD_TAKE(mpl, (uint64_t)node_cap * 4); LCD_TAKE(mpr, (uint64_t)node_cap * 4);
     LCD_TAKE(idx2node, (uint64_t)node_cap * 4); LCD_TAKE(node2idx, (uint64_t)node_cap * 4); LCD_TAKE(remain, (uint64_t)node_cap * 4);
     LCD_TAKE(deg, (uint64_t)node_cap * 4); LCD_TAKE(queue, (uint64_t)node_cap * 4);

@@ -44,13 +44,14 @@ template <> struct Cfg<256> { static constexpr int K = 2; };
 template <> struct Cfg<1024> { static constexpr int K = 2; };
 
 struct Ctx {
-    int *H, *E1, *E2;
-    int *rbeg, *rend; uint32_t *roff;
+    int *H, *E1, *E2;                 // generic rows: values in HBM
+    uint8_t *code8; int *ord, *spill;  // windowed rows: direction codes / predecessor ordinals / spilled value rows (same arena bytes)
+    int *rbeg, *rend; uint32_t *roff, *ooff, *spoff;
     int *ml, *mr, *idx2node, *node2idx, *remain, *deg, *queue;
     int *out_head, *out_tail, *in_head, *in_tail, *nin, *aligned;
     int *e_from, *e_to, *e_w, *e_next_out, *e_next_in;
     unsigned long long *rid;
-    int *cig_node, *cig_qpos;
+    int *cig_node, *cig_qpos, *cig_node0, *cig_qpos0;
     uint8_t *base, *imap;
     int *het, *clu, *nclu; uint8_t *prof;
     int *pl_start, *pl_pidx, *pl_bonus, *pl_rem; uint8_t *pl_base;
@@ -441,33 +442,51 @@ struct Cnt6 {
 };
 constexpr int RMAX = 4; // 64-column chunks per wavefront per sweep: NW*RMAX*64 == WMAX
 
-// banded convex-gap global alignment of seq[0..qlen) to the sub-graph (beg_node,end_node); returns #cigar
-// entries written to cig_node/cig_qpos in start->end order (block-uniform result).
-//
-// Row data flow: every row is written to HBM (the backtrack and far predecessors read it there) AND, when it
-// fits, into a K-slot LDS ring; a predecessor that is still in the ring is read from LDS, so the common
-// row-to-row dependency never waits for an HBM store->load round trip.  HBM rows are only read once a full
-// barrier has drained the stores issued before it (tracked with last_full).
+// ---------------------------------------------------------------------------------------------------------------------
+// Direction codes.  The windowed DP below keeps H/E1/E2 VALUES only in the LDS ring (and, for the few rows that a far
+// successor or the end node will read, in a small HBM spill area); what it streams to HBM is ONE byte per cell (+ 4 bytes
+// per cell on rows with >= 2 usable predecessors) that lets the backtrack replay oracle/poa.c's decisions exactly:
+//   bits 0-2  source of H, in the oracle's priority order: 0 match/mismatch, 1 E1, 2 E2, 3 insertion run (gap piece 1),
+//             4 insertion run (piece 2), 5 both pieces tie
+//   bit 3/4   Y1/Y2: this column is NOT where a piece-1/2 insertion run ending further right would open, i.e.
+//             prefixmax_{k<j}(Hpre[k]+k e) > Hpre[j]+j e.  The oracle's "closest k with H[k]-gap(j-k)==H[j]" is the
+//             largest k<j with Y==0 (oracle/poa.c:353-361; a k whose H came from F can never satisfy the equality)
+//   bit 5/6   O1/O2: E-out of this cell opens here (H-oe >= Ein-e), the oracle's first test in the E state (:366)
+//   bit 7     the match predecessor is not the first one of the row's plan (rows with >= 2 predecessors only)
+// The predecessor ordinals (first maximum in plan order == first equality the oracle's backtrack finds) of rows with >= 2
+// predecessors go to the `ord` plane: bits 0-7 match, 8-15 E1, 16-23 E2.
+// ---------------------------------------------------------------------------------------------------------------------
+
+// Explicit address spaces for the two homes of a predecessor row.  With generic pointers hipcc merges "ring slot or HBM"
+// into ONE flat_load behind a pointer select, and a flat load makes every row wait on vmcnt(0) -- i.e. on the row stores
+// still draining to HBM (~2 us) -- although the common case only touches LDS.
+typedef int lcd_v4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) int lcd_lds_i32;
+typedef __attribute__((address_space(3))) lcd_v4i lcd_lds_v4i;
+typedef __attribute__((address_space(1))) int lcd_glb_i32;
+typedef __attribute__((address_space(1))) lcd_v4i lcd_glb_v4i;
+__device__ __forceinline__ int lds_ld(const int *p) { return *(const lcd_lds_i32 *)p; }
+__device__ __forceinline__ int4 lds_ld4(const int *p) { const lcd_v4i v = *(const lcd_lds_v4i *)p; return make_int4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void lds_st4(int *p, const int4 v) { lcd_v4i t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(lcd_lds_v4i *)p = t; }
+__device__ __forceinline__ int glb_ld(const int *p) { return *(const lcd_glb_i32 *)p; }
+__device__ __forceinline__ int4 glb_ld4(const int *p) { const lcd_v4i v = *(const lcd_glb_v4i *)p; return make_int4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void glb_st4(int *p, const int4 v) { lcd_v4i t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(lcd_glb_v4i *)p = t; }
+// A value loaded from HBM inside a conditional must be waited for INSIDE that conditional: otherwise the compiler places the
+// s_waitcnt vmcnt(0) at the join, where it also waits (in-order vmcnt) for the row stores of every iteration that did not
+// take the branch -- a full HBM store round trip (~2 us) per DP row.
+#define LCD_PIN(x) asm volatile("" : "+v"(x))
+constexpr int CB_Y1 = 8, CB_Y2 = 16, CB_O1 = 32, CB_O2 = 64, CB_PM = 128;
+constexpr int LCD_GUARD = LCD_NEG * 2; // out-of-band filler: (guard + anything a cell can add) stays below LCD_NEG, so it never wins a max
+
+// reachability map over [bi, ei] + the row plan (per row, by topological index: remain / base / CSR of the usable
+// predecessors + edge bonus).  Also marks (imap bit 1) every row whose VALUES must outlive the LDS ring: a predecessor more
+// than K rows back, or a predecessor of the end node; and fills pd[] (LDS, optional) with the distance to each row's first
+// predecessor for the speculative backtrack.
 template <int NT>
-__device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, const LcdScoring &sc, const int wb, int wf_milli, int beg_node, int end_node,
-                                 const uint8_t *seq_hbm, int qlen, unsigned long long *cells_acc) {
-    constexpr int NW = NT / 64, K = Cfg<NT>::K;
-    const int WMAX = g.wmax; // ring slot capacity in columns: chosen per launch from the chains' lengths (dynamic LDS)
+__device__ void build_plan(Ctx &g, Smem &sm, const int bi, const int ei, const int remain_end, uint8_t *pd, const int K) {
+    constexpr int NW = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (qlen <= 0) return 0;
-    const int bi = g.node2idx[beg_node], ei = g.node2idx[end_node];
-    const int o1 = sc.o1, e1 = sc.e1, o2 = sc.o2, e2 = sc.e2, oe1 = o1 + e1, oe2 = o2 + e2;
-    // w = wb<0 ? qlen : wb + (int)(wf*qlen);  wf is 0.01 or 0 on this path: (int)(0.01*q) == q/100
-    const int w = wb < 0 ? qlen : wb + (int)(((long long)wf_milli * qlen) / 1000);
-    const int remain_end = g.remain[end_node];
     const int n = g.n_node;
-    // the read's bases are re-read by every row: keep them in LDS when they fit
-    // (two explicit pointers, never one that may be either: a maybe-LDS pointer compiles to FLAT loads, whose s_waitcnt
-    //  couples vmcnt and lgkmcnt and would stall every chunk behind the row stores still draining to HBM)
-    const uint8_t *seq = seq_hbm;
-    if (qlen > g.seq_cap) { g.status = LCD_ERR_NODES; return 0; } // read slice longer than the LDS query cache (host sizes the class)
-    for (int i = tid; i < qlen; i += NT) sseq[i] = seq_hbm[i];
-    // ---- reachability map over [bi, ei] ----
     if (bi == 0 && ei == n - 1) {
         for (int i = tid; i < n; i += NT) g.imap[i] = 1;
     } else {
@@ -485,43 +504,432 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         }
     }
     __syncthreads();
-    // ---- row plan: per row (by topological index) remain / base / CSR of usable predecessors + edge bonus ----
-    {
-        int carry = 0;
-        for (int base = bi; base <= ei; base += NT) {
-            const int idx = base + tid;
-            int cnt = 0, v = -1;
-            if (idx <= ei && g.imap[idx]) {
-                v = g.idx2node[idx];
+    int carry = 0;
+    for (int base = bi; base <= ei; base += NT) {
+        const int idx = base + tid;
+        int cnt = 0, v = -1;
+        if (idx <= ei && g.imap[idx]) {
+            v = g.idx2node[idx];
+            for (int e = g.in_head[v]; e >= 0; e = g.e_next_in[e]) {
+                int pi = g.node2idx[g.e_from[e]];
+                cnt += (pi >= bi && pi < ei && g.imap[pi]);
+            }
+        }
+        const int incl = scan_add(cnt);
+        if (lane == 63) sm.scan[wave] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { const int t = sm.scan[k]; if (k < wave) woff += t; tot += t; }
+        const int start = carry + woff + incl - cnt;
+        if (idx <= ei) {
+            g.pl_start[idx] = start;
+            g.pl_rem[idx] = v >= 0 ? g.remain[v] - remain_end : (1 << 30); // 1<<30: row not reachable from beg
+            g.pl_base[idx] = v >= 0 ? g.base[v] : 4;
+            int first = 255;
+            if (v >= 0) {
+                int k = start;
                 for (int e = g.in_head[v]; e >= 0; e = g.e_next_in[e]) {
                     int pi = g.node2idx[g.e_from[e]];
-                    cnt += (pi >= bi && pi < ei && g.imap[pi]);
-                }
-            }
-            const int incl = scan_add(cnt);
-            if (lane == 63) sm.scan[wave] = incl;
-            __syncthreads();
-            int woff = 0, tot = 0;
-#pragma unroll
-            for (int k = 0; k < NW; ++k) { const int t = sm.scan[k]; if (k < wave) woff += t; tot += t; }
-            const int start = carry + woff + incl - cnt;
-            if (idx <= ei) {
-                g.pl_start[idx] = start;
-                g.pl_rem[idx] = v >= 0 ? g.remain[v] - remain_end : (1 << 30); // 1<<30: row not reachable from beg
-                g.pl_base[idx] = v >= 0 ? g.base[v] : 4;
-                if (v >= 0) {
-                    int k = start;
-                    for (int e = g.in_head[v]; e >= 0; e = g.e_next_in[e]) {
-                        int pi = g.node2idx[g.e_from[e]];
-                        if (pi >= bi && pi < ei && g.imap[pi]) { g.pl_pidx[k] = pi; g.pl_bonus[k] = ilog2_32(g.e_w[e]); ++k; }
+                    if (pi >= bi && pi < ei && g.imap[pi]) {
+                        g.pl_pidx[k] = pi; g.pl_bonus[k] = ilog2_32(g.e_w[e]);
+                        if (k == start && idx - pi < 255) first = idx - pi;
+                        if (idx == ei || idx - pi > K) g.imap[pi] = 3; // same value from every writer
+                        ++k;
                     }
                 }
             }
-            carry += tot;
-            __syncthreads();
+            if (pd) pd[idx - bi] = (uint8_t)first;
         }
-        if (tid == 0) { g.pl_start[ei + 1] = carry; g.pl_start[ei + 2] = carry; g.pl_start[ei + 3] = carry; }
+        carry += tot;
+        __syncthreads();
     }
+    if (tid == 0) { g.pl_start[ei + 1] = carry; g.pl_start[ei + 2] = carry; g.pl_start[ei + 3] = carry; }
+    __syncthreads();
+}
+
+// ================= windowed DP (banded K1 rows and unbanded K2 rows that fit one sweep of the workgroup) =================
+// Every lane owns FOUR consecutive columns of a WIN-column window [beg4, beg4+WIN) that starts at the row's band (beg4 = beg
+// rounded down to 4), so a row is ONE sweep: predecessor rows come from the LDS ring as ds_read_b128, the horizontal-gap
+// prefix is 3 in-lane max + ONE interleaved DPP scan pair per 256 cells, the row maximum is one DPP scan + a ballot.
+// A ring slot is addressed by (column mod WIN) and is rewritten in full by every row (LCD_GUARD outside the band), so rows
+// whose windows are shifted against each other need no per-cell bounds test; the few alias cases (a predecessor band that
+// reaches a full window away) are detected per row and make the caller fall back to the generic rows.
+// Returns the number of cigar entries (written at g.cig_node0/g.cig_qpos0 + *cig_pos), or -1 = not representable here.
+template <int NT, bool BANDED>
+__device__ int align_windowed(Ctx &g, Smem &sm, int *ring, uint8_t *sq1, const uint8_t *pd, const LcdScoring &sc, const int w,
+                              const int bi, const int ei, const int rem_beg, const uint8_t *seq_hbm, const int qlen,
+                              unsigned long long *cells_acc, int *cig_pos) {
+    constexpr int NW = NT / 64, K = Cfg<NT>::K;
+    const int WIN = g.wmax, WM = WIN - 1, SLOTW = 3 * WIN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int o1 = sc.o1, e1 = sc.e1, o2 = sc.o2, e2 = sc.e2, oe1 = o1 + e1, oe2 = o2 + e2;
+    const bool act = 4 * tid < WIN;
+    const int QB = (qlen + 12 + 15) & ~15;
+    for (int j = tid; j < QB; j += NT) sq1[j] = (j >= 1 && j <= qlen) ? seq_hbm[j - 1] : 4; // shifted: sq1[j] = q[j-1]
+    const int qclamp = QB - 4;
+    const unsigned long long code_cap = g.cell_cap, ord_cap = g.cell_cap; // bytes / ints
+    const long long spill_rows = g.cell_cap * 7 > 64 ? (long long)((g.cell_cap * 7 - 64) / ((unsigned long long)SLOTW * 4)) : 0;
+    // ---- source row (slot 0, window at column 0) ----
+    int end0 = qlen - rem_beg; if (end0 < 0) end0 = 0; end0 += w; if (end0 > qlen) end0 = qlen;
+    if (end0 + 2 > WIN) return -1;
+    int nsp = 0;
+    {
+        const bool spf = (g.imap[bi] & 2) != 0;
+        if (spf && spill_rows < 1) { g.status = LCD_ERR_CELLS; return 0; }
+        if (act) {
+            int hh[4], aa[4], bb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = 4 * tid + k;
+                if (j <= end0) {
+                    const int f1 = j ? -(o1 + e1 * j) : LCD_NEG, f2 = j ? -(o2 + e2 * j) : LCD_NEG;
+                    const int h = j ? imax(f1, f2) : 0;
+                    hh[k] = h; aa[k] = h - oe1; bb[k] = h - oe2;
+                } else { hh[k] = LCD_GUARD; aa[k] = LCD_GUARD; bb[k] = LCD_GUARD; }
+            }
+            const int4 H4 = make_int4(hh[0], hh[1], hh[2], hh[3]), A4 = make_int4(aa[0], aa[1], aa[2], aa[3]), B4 = make_int4(bb[0], bb[1], bb[2], bb[3]);
+            lds_st4(ring + 4 * tid, H4); lds_st4(ring + WIN + 4 * tid, A4); lds_st4(ring + 2 * WIN + 4 * tid, B4);
+            if (spf) { int *G = g.spill; glb_st4(G + 4 * tid, H4); glb_st4(G + WIN + 4 * tid, A4); glb_st4(G + 2 * WIN + 4 * tid, B4); }
+        }
+        if (tid == 0) { g.rbeg[bi] = 0; g.rend[bi] = end0; g.roff[bi] = 0; g.ml[bi] = 0; g.mr[bi] = 0; g.spoff[bi] = 0; }
+        if (spf) nsp = 1;
+    }
+    // ring slot meta: lane s of every wavefront holds (beg, end, row-max leftmost / rightmost column) of slot s
+    int m_beg = 1, m_end = 0, m_ml = 0, m_mr = 0;
+    if (lane == 0) { m_beg = 0; m_end = end0; }
+    unsigned long long cused = 0, oused = 0, ncell = (unsigned long long)end0 + 1;
+    __syncthreads();
+    const long long t_dp0 = clock64();
+    int wbase = -(1 << 20);
+    int w_p0 = 0, w_np = 0, w_rem = 1 << 30, w_vb = 4, w_pi0 = 0, w_b0 = 0, w_pi1 = 0, w_b1 = 0, w_sp = 0;
+    for (int idx = bi + 1; idx < ei; ++idx) {
+        if (idx - wbase >= 64) { // plan window: each lane loads the plan of one upcoming row; rows then take it by v_readlane
+            wbase = idx;
+            const int ri = idx + lane;
+            w_np = 0; w_rem = 1 << 30;
+            if (ri < ei) {
+                const int s0 = g.pl_start[ri], s1 = g.pl_start[ri + 1];
+                w_p0 = s0; w_np = s1 - s0; w_rem = g.pl_rem[ri]; w_vb = g.pl_base[ri]; w_sp = g.imap[ri] & 2;
+                if (w_np > 0) { w_pi0 = g.pl_pidx[s0]; w_b0 = g.pl_bonus[s0]; }
+                if (w_np > 1) { w_pi1 = g.pl_pidx[s0 + 1]; w_b1 = g.pl_bonus[s0 + 1]; }
+            }
+            LCD_PIN(w_p0); LCD_PIN(w_np); LCD_PIN(w_rem); LCD_PIN(w_vb); LCD_PIN(w_sp); LCD_PIN(w_pi0); LCD_PIN(w_b0); LCD_PIN(w_pi1); LCD_PIN(w_b1);
+        }
+        const int wk = idx - wbase;
+        const int p0 = LCD_RL(w_p0, wk), np = LCD_RL(w_np, wk), rem = LCD_RL(w_rem, wk), vb = LCD_RL(w_vb, wk);
+        const int pi0 = LCD_RL(w_pi0, wk), bz0 = LCD_RL(w_b0, wk), pi1 = LCD_RL(w_pi1, wk), bz1 = LCD_RL(w_b1, wk);
+        const bool spf = LCD_RL(w_sp, wk) != 0;
+        const int s = (idx - bi) & (K - 1);
+        if (rem == (1 << 30)) { // not reachable
+            if (lane == s) { m_beg = 1; m_end = 0; }
+            if (tid == 0) { g.rbeg[idx] = 1; g.rend[idx] = 0; }
+            continue;
+        }
+        bool synced = false;
+        int beg = 0, end = qlen;
+        if (BANDED) { // band: pulled from the predecessors' row-max columns (same values the oracle pushes to successors)
+            int mplv = 1 << 30, mprv = 0, minpb = 1 << 30, maxpe = -1;
+            for (int t = 0; t < np; ++t) {
+                int pi = t == 0 ? pi0 : pi1;
+                if (t > 1) { pi = g.pl_pidx[p0 + t]; LCD_PIN(pi); }
+                int pb, pe, pml, pmr;
+                if (idx - pi <= K) { const int sp = (pi - bi) & (K - 1); pb = LCD_RL(m_beg, sp); pe = LCD_RL(m_end, sp); pml = LCD_RL(m_ml, sp); pmr = LCD_RL(m_mr, sp); }
+                else {
+                    if (!synced) { __syncthreads(); synced = true; } // far row: its metadata / spilled values were stored to HBM earlier
+                    pb = g.rbeg[pi]; pe = g.rend[pi]; pml = g.ml[pi]; pmr = g.mr[pi];
+                    LCD_PIN(pb); LCD_PIN(pe); LCD_PIN(pml); LCD_PIN(pmr);
+                }
+                if (pb > pe) continue;
+                minpb = imin(minpb, pb); maxpe = imax(maxpe, pe);
+                mplv = imin(mplv, pml + 1); mprv = imax(mprv, pmr + 1);
+            }
+            beg = imin(mplv, qlen - rem) - w; if (beg < 0) beg = 0;
+            end = imax(mprv, qlen - rem) + w; if (end > qlen) end = qlen;
+            if (beg < minpb) beg = minpb;
+            if (end > maxpe + 1) end = maxpe + 1;
+            if (beg > end) { // empty row
+                if (lane == s) { m_beg = 1; m_end = 0; }
+                if (tid == 0) { g.rbeg[idx] = 1; g.rend[idx] = 0; }
+                continue;
+            }
+            if (end - (beg & ~3) + 2 > WIN) return -1;
+        }
+        const int beg4 = beg & ~3;
+        const int jb = beg4 + 4 * tid;
+        const int x = jb & WM, xm = (jb - 1) & WM;
+        const bool i0 = act && jb >= beg && jb <= end, i1 = act && jb + 1 >= beg && jb + 1 <= end;
+        const bool i2 = act && jb + 2 >= beg && jb + 2 <= end, i3 = act && jb + 3 >= beg && jb + 3 <= end;
+        int s0, s1, s2, s3;
+        {
+            const unsigned qw = (unsigned)lds_ld((const int *)(sq1 + imin(jb, qclamp))); // q[jb-1], q[jb], q[jb+1], q[jb+2]
+            const int q0 = qw & 255, q1 = (qw >> 8) & 255, q2 = (qw >> 16) & 255, q3 = qw >> 24;
+            s0 = (vb >= 4 || q0 >= 4) ? 0 : (vb == q0 ? sc.match : -sc.mismatch);
+            s1 = (vb >= 4 || q1 >= 4) ? 0 : (vb == q1 ? sc.match : -sc.mismatch);
+            s2 = (vb >= 4 || q2 >= 4) ? 0 : (vb == q2 ? sc.match : -sc.mismatch);
+            s3 = (vb >= 4 || q3 >= 4) ? 0 : (vb == q3 ? sc.match : -sc.mismatch);
+        }
+        // ---- phase A: best match / E1 / E2 input of the four cells over the predecessors (first maximum keeps its ordinal) ----
+        int n0 = LCD_NEG, n1 = LCD_NEG, n2 = LCD_NEG, n3 = LCD_NEG, u0 = LCD_NEG, u1 = LCD_NEG, u2 = LCD_NEG, u3 = LCD_NEG;
+        int v0 = LCD_NEG, v1 = LCD_NEG, v2 = LCD_NEG, v3 = LCD_NEG;
+        int om = 0, oa = 0, ob = 0; // ordinals, one byte per cell
+        bool overflow = false;
+        for (int t = 0; t < np; ++t) {
+            int pi = t == 0 ? pi0 : pi1, bz = t == 0 ? bz0 : bz1;
+            if (t > 1) { pi = g.pl_pidx[p0 + t]; bz = g.pl_bonus[p0 + t]; LCD_PIN(pi); LCD_PIN(bz); }
+            const bool near = idx - pi <= K;
+            const int sp = (pi - bi) & (K - 1);
+            if (BANDED) {
+                int pb, pe;
+                if (near) { pb = LCD_RL(m_beg, sp); pe = LCD_RL(m_end, sp); } else { pb = g.rbeg[pi]; pe = g.rend[pi]; LCD_PIN(pb); LCD_PIN(pe); }
+                if (pb > pe) continue;
+                if (pe - beg + 2 >= WIN || end - pb + 1 >= WIN) { overflow = true; break; }
+            }
+            int hm = LCD_GUARD; int4 hv = make_int4(LCD_GUARD, LCD_GUARD, LCD_GUARD, LCD_GUARD), av = hv, bv = hv;
+            if (near) {
+                const int *S = ring + sp * SLOTW;
+                if (act) { hm = lds_ld(S + xm); hv = lds_ld4(S + x); av = lds_ld4(S + WIN + x); bv = lds_ld4(S + 2 * WIN + x); }
+            } else {
+                if (!synced) { __syncthreads(); synced = true; }
+                const int *G = g.spill + (size_t)g.spoff[pi] * SLOTW;
+                if (act) { hm = glb_ld(G + xm); hv = glb_ld4(G + x); av = glb_ld4(G + WIN + x); bv = glb_ld4(G + 2 * WIN + x); }
+                LCD_PIN(hm); LCD_PIN(hv.x); LCD_PIN(hv.y); LCD_PIN(hv.z); LCD_PIN(hv.w); LCD_PIN(av.x); LCD_PIN(av.y); LCD_PIN(av.z); LCD_PIN(av.w);
+                LCD_PIN(bv.x); LCD_PIN(bv.y); LCD_PIN(bv.z); LCD_PIN(bv.w);
+            }
+            const int c0 = hm + s0 + bz, c1 = hv.x + s1 + bz, c2 = hv.y + s2 + bz, c3 = hv.z + s3 + bz;
+            const int a0 = av.x + bz, a1 = av.y + bz, a2 = av.z + bz, a3 = av.w + bz;
+            const int b0 = bv.x + bz, b1 = bv.y + bz, b2 = bv.z + bz, b3 = bv.w + bz;
+            if (t == 0) {
+                n0 = imax(n0, c0); n1 = imax(n1, c1); n2 = imax(n2, c2); n3 = imax(n3, c3);
+                u0 = imax(u0, a0); u1 = imax(u1, a1); u2 = imax(u2, a2); u3 = imax(u3, a3);
+                v0 = imax(v0, b0); v1 = imax(v1, b1); v2 = imax(v2, b2); v3 = imax(v3, b3);
+            } else {
+                const int tt = t > 255 ? 255 : t;
+#define LCD_UPD(cur, cand, ordv, sh) if ((cand) > (cur)) { cur = (cand); ordv = (ordv & ~(255 << (sh))) | (tt << (sh)); }
+                LCD_UPD(n0, c0, om, 0) LCD_UPD(n1, c1, om, 8) LCD_UPD(n2, c2, om, 16) LCD_UPD(n3, c3, om, 24)
+                LCD_UPD(u0, a0, oa, 0) LCD_UPD(u1, a1, oa, 8) LCD_UPD(u2, a2, oa, 16) LCD_UPD(u3, a3, oa, 24)
+                LCD_UPD(v0, b0, ob, 0) LCD_UPD(v1, b1, ob, 8) LCD_UPD(v2, b2, ob, 16) LCD_UPD(v3, b3, ob, 24)
+#undef LCD_UPD
+            }
+        }
+        if (overflow) return -1;
+        if (np > 256) { g.status = LCD_ERR_NODES; return 0; } // ordinals are 8 bits
+        const int h0 = imax(n0, imax(u0, v0)), h1 = imax(n1, imax(u1, v1)), h2 = imax(n2, imax(u2, v2)), h3 = imax(n3, imax(u3, v3)); // Hpre
+        // ---- F: A[k] = Hpre[k] + k*e; in-lane inclusive prefix, then one scan pair over the lane totals ----
+        const int je1 = jb * e1, je2 = jb * e2;
+        const int a10 = i0 ? h0 + je1 : LCD_GUARD, a11 = i1 ? h1 + je1 + e1 : LCD_GUARD, a12 = i2 ? h2 + je1 + 2 * e1 : LCD_GUARD, a13 = i3 ? h3 + je1 + 3 * e1 : LCD_GUARD;
+        const int a20 = i0 ? h0 + je2 : LCD_GUARD, a21 = i1 ? h1 + je2 + e2 : LCD_GUARD, a22 = i2 ? h2 + je2 + 2 * e2 : LCD_GUARD, a23 = i3 ? h3 + je2 + 3 * e2 : LCD_GUARD;
+        const int p10 = a10, p11 = imax(p10, a11), p12 = imax(p11, a12);
+        const int p20 = a20, p21 = imax(p20, a21), p22 = imax(p21, a22);
+        int t1 = imax(p12, a13), t2 = imax(p22, a23);
+        scan_max2(t1, t2);
+        int x1 = shr1(LCD_GUARD, t1), x2 = shr1(LCD_GUARD, t2); // exclusive prefix over the lanes of this wavefront
+        if (NW > 1) {
+            const int buf = idx & 1;
+            if (lane == 63) { sm.tot1[buf][wave] = t1; sm.tot2[buf][wave] = t2; }
+            lds_barrier<NT>();
+#pragma unroll
+            for (int k = 0; k < NW; ++k) if (k < wave) { x1 = imax(x1, sm.tot1[buf][k]); x2 = imax(x2, sm.tot2[buf][k]); }
+        }
+        // ---- phase B: F, H, E-out, direction code of the four cells ----
+        int hh0, hh1, hh2, hh3, ea0, ea1, ea2, ea3, eb0, eb1, eb2, eb3;
+        unsigned code = 0;
+#define LCD_CELL(k, inb, hp, mxv, ev1, ev2, pf1, pf2, ak1, ak2, HO, AO, BO)                                                \
+        {                                                                                                                   \
+            const int f1 = imax(LCD_NEG, (pf1) - o1 - je1 - (k) * e1), f2 = imax(LCD_NEG, (pf2) - o2 - je2 - (k) * e2);     \
+            const int h = imax(hp, imax(f1, f2));                                                                           \
+            int eo1 = imax(h - oe1, (ev1) - e1), eo2 = imax(h - oe2, (ev2) - e2);                                           \
+            if (BANDED) { eo1 = imax(eo1, LCD_NEG); eo2 = imax(eo2, LCD_NEG); }                                             \
+            const int hs = (mxv) == h ? 0 : (ev1) == h ? 1 : (ev2) == h ? 2 : f1 == h ? (f2 == h ? 5 : 3) : 4;              \
+            const unsigned cd = (unsigned)hs | ((pf1) > (ak1) ? CB_Y1 : 0) | ((pf2) > (ak2) ? CB_Y2 : 0) |                  \
+                                (h - oe1 >= (ev1) - e1 ? CB_O1 : 0) | (h - oe2 >= (ev2) - e2 ? CB_O2 : 0) |                 \
+                                (((om >> (8 * (k))) & 255) ? CB_PM : 0);                                                    \
+            code |= cd << (8 * (k));                                                                                        \
+            HO = (inb) ? h : LCD_GUARD; AO = (inb) ? eo1 : LCD_GUARD; BO = (inb) ? eo2 : LCD_GUARD;                         \
+        }
+        LCD_CELL(0, i0, h0, n0, u0, v0, x1, x2, a10, a20, hh0, ea0, eb0)
+        LCD_CELL(1, i1, h1, n1, u1, v1, imax(x1, p10), imax(x2, p20), a11, a21, hh1, ea1, eb1)
+        LCD_CELL(2, i2, h2, n2, u2, v2, imax(x1, p11), imax(x2, p21), a12, a22, hh2, ea2, eb2)
+        LCD_CELL(3, i3, h3, n3, u3, v3, imax(x1, p12), imax(x2, p22), a13, a23, hh3, ea3, eb3)
+#undef LCD_CELL
+        // ---- row maximum, leftmost / rightmost column (banded rows only: w = qlen never consumes them) ----
+        int ml = 0, mr = 0;
+        if (BANDED) {
+            int hb = LCD_GUARD, bl = 0, brr = 0;
+            if (i0) { hb = hh0; bl = jb; brr = jb; }
+            if (i1) { if (hh1 > hb) { hb = hh1; bl = jb + 1; brr = jb + 1; } else if (hh1 == hb) brr = jb + 1; }
+            if (i2) { if (hh2 > hb) { hb = hh2; bl = jb + 2; brr = jb + 2; } else if (hh2 == hb) brr = jb + 2; }
+            if (i3) { if (hh3 > hb) { hb = hh3; bl = jb + 3; brr = jb + 3; } else if (hh3 == hb) brr = jb + 3; }
+            const int wm = lane63(scan_max(hb));
+            const unsigned long long mk = __ballot(hb == wm && hb > LCD_GUARD);
+            int wl = 1 << 30, wr = -1;
+            if (mk) {
+                const int fl = __builtin_amdgcn_readfirstlane(__ffsll((long long)mk) - 1), ll = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)mk));
+                wl = LCD_RL(bl, fl); wr = LCD_RL(brr, ll);
+            }
+            if (NW > 1) {
+                if (lane == 0) { sm.bh[wave] = wm; sm.bl[wave] = wl; sm.br[wave] = wr; }
+                lds_barrier<NT>();
+                int rowmax = sm.bh[0];
+#pragma unroll
+                for (int k = 1; k < NW; ++k) rowmax = imax(rowmax, sm.bh[k]);
+                ml = 1 << 30; mr = -1;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) if (sm.bh[k] == rowmax) { ml = imin(ml, sm.bl[k]); mr = imax(mr, sm.br[k]); }
+            } else { ml = wl; mr = wr; }
+        }
+        // ---- stores: ring slot (values), HBM (codes; values only for rows a far successor / the end node will read) ----
+        const int cw4 = (((end - beg4) >> 2) + 1) << 2; // cells of this row in HBM, padded to the lanes' 4-cell groups
+        if (cused + cw4 > code_cap || (np > 1 && oused + cw4 > ord_cap) || (spf && nsp >= spill_rows)) { g.status = LCD_ERR_CELLS; return 0; }
+        if (act) {
+            int *S = ring + s * SLOTW;
+            const int4 H4 = make_int4(hh0, hh1, hh2, hh3), A4 = make_int4(ea0, ea1, ea2, ea3), B4 = make_int4(eb0, eb1, eb2, eb3);
+            lds_st4(S + x, H4); lds_st4(S + WIN + x, A4); lds_st4(S + 2 * WIN + x, B4);
+            if (spf) { int *G = g.spill + (size_t)nsp * SLOTW; glb_st4(G + x, H4); glb_st4(G + WIN + x, A4); glb_st4(G + 2 * WIN + x, B4); }
+            if (4 * tid < cw4) {
+                *(unsigned *)(g.code8 + cused + 4 * tid) = code;
+                if (np > 1) *(int4 *)(g.ord + oused + 4 * tid) = make_int4((om & 255) | ((oa & 255) << 8) | ((ob & 255) << 16),
+                                                                           ((om >> 8) & 255) | (((oa >> 8) & 255) << 8) | (((ob >> 8) & 255) << 16),
+                                                                           ((om >> 16) & 255) | (((oa >> 16) & 255) << 8) | (((ob >> 16) & 255) << 16),
+                                                                           ((om >> 24) & 255) | (((oa >> 24) & 255) << 8) | (((ob >> 24) & 255) << 16));
+            }
+        }
+        if (tid == 0) {
+            g.rbeg[idx] = beg; g.rend[idx] = end; g.roff[idx] = (uint32_t)cused; g.ooff[idx] = (uint32_t)oused;
+            if (spf) { g.ml[idx] = ml; g.mr[idx] = mr; g.spoff[idx] = (uint32_t)nsp; }
+        }
+        if (lane == s) { m_beg = beg; m_end = end; m_ml = ml; m_mr = mr; }
+        cused += cw4; if (np > 1) oused += cw4; if (spf) ++nsp;
+        ncell += (unsigned long long)(end - beg + 1);
+        lds_barrier<NT>(); // publish the ring slot to the other wavefronts before the next row's phase A
+    }
+    __syncthreads();
+    *cells_acc += ncell;
+    const long long t_bt0 = clock64();
+    g.t_dp += (unsigned long long)(t_bt0 - t_dp0);
+    // ---- end node: best predecessor at column qlen (its values are in the spill area), then the code-driven backtrack ----
+    if (wave == 0) {
+        int best = LCD_NEG, br = -1;
+        {
+            const int p0 = g.pl_start[ei], np = g.pl_start[ei + 1] - p0;
+            for (int t = 0; t < np; ++t) {
+                const int pi = g.pl_pidx[p0 + t];
+                if (qlen < g.rbeg[pi] || qlen > g.rend[pi]) continue;
+                const int c = g.spill[(size_t)g.spoff[pi] * SLOTW + (qlen & WM)] + g.pl_bonus[p0 + t];
+                if (c > best) { best = c; br = pi; }
+            }
+        }
+        int pos = qlen;
+        int status = g.status;
+        if (br >= 0 && best > LCD_NEG / 2 && status == LCD_OK) {
+            int i = br, j = qlen, st = 0;
+            while (i != bi && j > 0 && status == LCD_OK) {
+                if (st == 0 && pd) {
+                    // speculate a run of matches along first predecessors: lane t looks at the cell t steps up the diagonal
+                    int my_i = -1, my_nx = -1;
+                    {
+                        int cur = i; bool alive = true;
+                        for (int t = 0; t < 64; ++t) {
+                            const bool ok = alive && cur != bi && j - t > 0;
+                            const int d = ok ? (int)pd[cur - bi] : 255;
+                            if (lane == t) { my_i = ok ? cur : -1; my_nx = d != 255 ? cur - d : -1; }
+                            alive = ok && d != 255;
+                            if (!alive) break;
+                            cur -= d;
+                        }
+                    }
+                    bool good = false;
+                    const int jj = j - lane;
+                    if (my_i >= 0 && my_nx >= 0) {
+                        const int rb = g.rbeg[my_i], re = g.rend[my_i];
+                        if (jj >= rb && jj <= re) good = (g.code8[(size_t)g.roff[my_i] + (jj - (rb & ~3))] & (7 | CB_PM)) == 0;
+                    }
+                    const unsigned long long bad = __ballot(!good);
+                    const int m = bad ? __ffsll((long long)bad) - 1 : 64;
+                    if (m > 0) {
+                        if (lane < m) { g.cig_node0[pos - 1 - lane] = g.idx2node[my_i]; g.cig_qpos0[pos - 1 - lane] = jj - 1; }
+                        i = LCD_RL(my_nx, __builtin_amdgcn_readfirstlane(m - 1));
+                        pos -= m; j -= m;
+                        continue;
+                    }
+                }
+                // one step, replaying the oracle's decision from the code
+                const int rb = g.rbeg[i], rb4 = rb & ~3;
+                const size_t ro = g.roff[i];
+                const int c = g.code8[ro + (j - rb4)];
+                const int p0 = g.pl_start[i], np = g.pl_start[i + 1] - p0;
+                const int ow = np > 1 ? g.ord[(size_t)g.ooff[i] + (j - rb4)] : 0;
+                if (st == 0) {
+                    const int hs = c & 7;
+                    if (hs == 0) {
+                        if (lane == 0) { g.cig_node0[pos - 1] = g.idx2node[i]; g.cig_qpos0[pos - 1] = j - 1; }
+                        --pos; i = g.pl_pidx[p0 + (ow & 255)]; --j;
+                    } else if (hs <= 2) {
+                        i = g.pl_pidx[p0 + ((ow >> (8 * hs)) & 255)]; st = hs;
+                    } else if (hs <= 5) { // insertion run: back to the closest opening column of a matching gap piece
+                        int k = -1;
+                        if (hs != 4) { int p = j - 1; while (p > rb && (g.code8[ro + (p - rb4)] & CB_Y1)) --p; k = p; }
+                        if (hs != 3) { int p = j - 1; while (p > rb && (g.code8[ro + (p - rb4)] & CB_Y2)) --p; k = imax(k, p); }
+                        const int nins = j - k;
+                        for (int u = lane; u < nins; u += 64) { g.cig_node0[pos - nins + u] = -1; g.cig_qpos0[pos - nins + u] = k + u; }
+                        pos -= nins; j = k;
+                    } else status = LCD_ERR_BACKTRACK;
+                } else {
+                    if (c & (st == 1 ? CB_O1 : CB_O2)) st = 0;
+                    else i = g.pl_pidx[p0 + ((ow >> (8 * st)) & 255)];
+                }
+            }
+            for (int u = lane; u < j; u += 64) { g.cig_node0[pos - j + u] = -1; g.cig_qpos0[pos - j + u] = u; }
+            pos -= j;
+        }
+        if (lane == 0) { sm.bc[0] = qlen - pos; sm.bc[1] = status; sm.bc[4] = pos; }
+    }
+    __syncthreads();
+    const int n_cig = sm.bc[0];
+    g.status = sm.bc[1];
+    *cig_pos = sm.bc[4];
+    __syncthreads();
+    g.t_bt += (unsigned long long)(clock64() - t_bt0);
+    return n_cig;
+}
+
+// banded convex-gap global alignment of seq[0..qlen) to the sub-graph (beg_node,end_node); returns #cigar
+// entries written to g.cig_node/g.cig_qpos in start->end order (block-uniform result).
+//
+// Rows that fit one sweep of the workgroup take the windowed path above (values stay in LDS, direction codes go to HBM).
+// The generic rows below are the fallback for rows wider than the window (reads longer than 4*NT columns, band drift of
+// noisy reads): every row is written to HBM as H/E1/E2 (the value backtrack and far predecessors read it there) AND, when
+// it fits, into the K-slot LDS ring.  HBM rows are only read once a full barrier has drained the stores issued before it
+// (tracked with last_full).
+template <int NT>
+__device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, const LcdScoring &sc, const int wb, int wf_milli, int beg_node, int end_node,
+                                 const uint8_t *seq_hbm, int qlen, unsigned long long *cells_acc) {
+    constexpr int NW = NT / 64, K = Cfg<NT>::K;
+    const int WMAX = g.wmax; // ring slot capacity in columns: chosen per launch from the chains' lengths (dynamic LDS)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    g.cig_node = g.cig_node0; g.cig_qpos = g.cig_qpos0;
+    if (qlen <= 0) return 0;
+    const int bi = g.node2idx[beg_node], ei = g.node2idx[end_node];
+    const int o1 = sc.o1, e1 = sc.e1, o2 = sc.o2, e2 = sc.e2, oe1 = o1 + e1, oe2 = o2 + e2;
+    // w = wb<0 ? qlen : wb + (int)(wf*qlen);  wf is 0.01 or 0 on this path: (int)(0.01*q) == q/100
+    const int w = wb < 0 ? qlen : wb + (int)(((long long)wf_milli * qlen) / 1000);
+    const int remain_end = g.remain[end_node];
+    const int n = g.n_node;
+    const uint8_t *seq = seq_hbm;
+    // LDS after the ring: [query cache | first-predecessor distances]
+    const int QB = (qlen + 12 + 15) & ~15;
+    if (QB > g.seq_cap) { g.status = LCD_ERR_NODES; return 0; } // read slice longer than the LDS query cache (host sizes the class)
+    uint8_t *pd = (QB + (ei - bi) + 16 <= g.seq_cap) ? sseq + QB : nullptr;
+    build_plan<NT>(g, sm, bi, ei, remain_end, pd, K);
+    if (!(sc.dbg & 8) && WMAX <= NT * 4 && (WMAX & (WMAX - 1)) == 0) {
+        int cpos = 0;
+        const int rem_beg = g.remain[beg_node] - remain_end;
+        const int nc = wb < 0 ? align_windowed<NT, false>(g, sm, ring, sseq, pd, sc, w, bi, ei, rem_beg, seq_hbm, qlen, cells_acc, &cpos)
+                              : align_windowed<NT, true>(g, sm, ring, sseq, pd, sc, w, bi, ei, rem_beg, seq_hbm, qlen, cells_acc, &cpos);
+        if (nc >= 0) { g.cig_node = g.cig_node0 + cpos; g.cig_qpos = g.cig_qpos0 + cpos; return nc; }
+        __syncthreads();
+    }
+    for (int i = tid; i < qlen; i += NT) sseq[i] = seq_hbm[i];
     __syncthreads();
     unsigned long long used = 0;
     const long long t_dp0 = clock64();
@@ -553,170 +961,6 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         __syncthreads();
         last_full = bi + 1;
     }
-    // ================= unbanded fast path (K2, wb < 0) =================
-    // w = qlen makes every row [0, qlen] (oracle: beg = max(0, .. - qlen) = 0, end = min(qlen, .. + qlen) = qlen, and the
-    // source row already spans it), every node is reachable, so row metadata is implicit: rbeg = 0, rend = qlen,
-    // roff = (idx - bi) * W1p (row stride padded to 4 cells).  No staging, no band, no row-max.
-    // FOUR cells per lane: a wavefront covers 256 columns, so a row is one sweep of the workgroup.  Predecessor rows
-    // come from the LDS ring as ds_read_b128, the row goes to HBM as global_store_dwordx4, the horizontal-gap prefix is
-    // 3 in-lane max + ONE interleaved DPP scan pair per 256 cells.  (The chain is issue-bound: this is ~4x fewer
-    // instructions per cell than one cell per lane.)
-    // Ring slot layout (words): H plane = [.. guard @3 | H(0..qlen) @4..], E1 plane @WMAX, E2 plane @2*WMAX; the guard
-    // (-2^30) stands in for H[j-1] at j = 0 so the match term needs no bounds test.  Query bases are kept shifted by one
-    // byte (q[j-1] at byte j) so a lane's four bases are one aligned ds_read_b32.
-    if (wb < 0 && bi == 0 && ei == n - 1 && qlen + 5 <= WMAX && qlen + 5 <= NT * 4 && 2 * (qlen + 24) <= g.seq_cap) {
-        const int W1 = qlen + 1, W1p = (W1 + 3) & ~3;
-        if ((unsigned long long)(ei - bi) * W1p > g.cell_cap) { g.status = LCD_ERR_CELLS; return 0; }
-        for (int i = bi + 1 + tid; i < ei; i += NT) { g.rbeg[i] = 0; g.rend[i] = qlen; g.roff[i] = (uint32_t)((i - bi) * (unsigned)W1p); }
-        used = (unsigned long long)(ei - bi) * W1p;
-        const int SLOTW = 3 * WMAX; // words per ring slot
-        uint8_t *sq1 = sseq + ((qlen + 8 + 15) & ~15); // shifted copy: sq1[j] = q[j-1]
-        for (int j = tid; j <= qlen + 3; j += NT) sq1[j] = (j >= 1 && j <= qlen) ? seq_hbm[j - 1] : 4;
-        // source row into slot 0; guards of every slot
-        for (int j = tid; j <= qlen; j += NT) {
-            const int f1 = j ? -(o1 + e1 * j) : LCD_NEG, f2 = j ? -(o2 + e2 * j) : LCD_NEG;
-            const int h = j ? imax(f1, f2) : 0;
-            ring[4 + j] = h; ring[WMAX + j] = h - oe1; ring[2 * WMAX + j] = h - oe2;
-        }
-        if (tid < K) ring[tid * SLOTW + 3] = LCD_NEG * 2;
-        si0 = bi; si1 = -1; si2 = -1; si3 = -1; next_slot = 1 % K;
-        __syncthreads();
-        last_full = bi + 1;
-        // this lane's four columns
-        const int c = (wave << 8) + (lane << 2);
-        const bool k0 = c <= qlen, k1 = c + 1 <= qlen, k2 = c + 2 <= qlen, k3 = c + 3 <= qlen;
-        const int c1a = c * e1, c2a = c * e2; // a-offsets of cell 0 (cell k adds k*e)
-        int wbase = -(1 << 20);
-        int w_p0 = 0, w_np = 0, w_vb = 4, w_pi0 = 0, w_b0 = 0, w_pi1 = 0, w_b1 = 0;
-        for (int idx = bi + 1; idx < ei; ++idx) {
-            if (idx - wbase >= 64) {
-                wbase = idx;
-                const int ri = idx + lane;
-                w_np = 0;
-                if (ri < ei) {
-                    const int s0 = g.pl_start[ri], s1 = g.pl_start[ri + 1];
-                    w_p0 = s0; w_np = s1 - s0; w_vb = g.pl_base[ri];
-                    if (w_np > 0) { w_pi0 = g.pl_pidx[s0]; w_b0 = g.pl_bonus[s0]; }
-                    if (w_np > 1) { w_pi1 = g.pl_pidx[s0 + 1]; w_b1 = g.pl_bonus[s0 + 1]; }
-                }
-            }
-            const int wk = idx - wbase;
-            const int p0 = LCD_RL(w_p0, wk), np = LCD_RL(w_np, wk);
-            const int vb = LCD_RL(w_vb, wk);
-            const int pi0 = LCD_RL(w_pi0, wk), bz0 = LCD_RL(w_b0, wk), pi1 = LCD_RL(w_pi1, wk), bz1 = LCD_RL(w_b1, wk);
-            const int sl0 = np > 0 ? LCD_SLOT_OF(pi0) : 0, sl1 = np > 1 ? LCD_SLOT_OF(pi1) : 0;
-            const bool fastrow = np >= 1 && np <= 2 && sl0 >= 0 && sl1 >= 0;
-            if (!fastrow) { // predecessors that are not in the ring are read from HBM: their stores must have drained
-                int far = -1;
-                if (np > 0 && sl0 < 0) far = pi0;
-                if (np > 1 && sl1 < 0) far = imax(far, pi1);
-                if (np > 2) far = 1 << 30;
-                if (far >= last_full) { __syncthreads(); last_full = idx; }
-            }
-            const size_t off = (size_t)(idx - bi) * W1p;
-            const int slot = next_slot;
-            int *rS = ring + slot * SLOTW;
-            // ---- phase A: Hpre of the four cells ----
-            int h0, h1, h2, h3, u0, u1, u2, u3, v0, v1, v2, v3; // Hpre, E1in, E2in
-            if (fastrow) {
-                const unsigned qw = *(const unsigned *)(sq1 + c); // q[c-1], q[c], q[c+1], q[c+2]
-                int s0, s1, s2, s3;
-                {
-                    const int q0 = qw & 255, q1 = (qw >> 8) & 255, q2 = (qw >> 16) & 255, q3 = qw >> 24;
-                    s0 = (vb >= 4 || q0 >= 4) ? 0 : (vb == q0 ? sc.match : -sc.mismatch);
-                    s1 = (vb >= 4 || q1 >= 4) ? 0 : (vb == q1 ? sc.match : -sc.mismatch);
-                    s2 = (vb >= 4 || q2 >= 4) ? 0 : (vb == q2 ? sc.match : -sc.mismatch);
-                    s3 = (vb >= 4 || q3 >= 4) ? 0 : (vb == q3 ? sc.match : -sc.mismatch);
-                }
-                const int *q = ring + sl0 * SLOTW;
-                const int hm = q[3 + c];                                        // H[c-1] (guard at c == 0)
-                const int4 hv = *(const int4 *)(q + 4 + c);                     // H[c..c+3]
-                const int4 av = *(const int4 *)(q + WMAX + c), bv = *(const int4 *)(q + 2 * WMAX + c);
-                const int m0 = hm + s0 + bz0, m1 = hv.x + s1 + bz0, m2 = hv.y + s2 + bz0, m3 = hv.z + s3 + bz0;
-                u0 = av.x + bz0; u1 = av.y + bz0; u2 = av.z + bz0; u3 = av.w + bz0;
-                v0 = bv.x + bz0; v1 = bv.y + bz0; v2 = bv.z + bz0; v3 = bv.w + bz0;
-                int n0 = m0, n1 = m1, n2 = m2, n3 = m3;
-                if (np > 1) {
-                    const int *r = ring + sl1 * SLOTW;
-                    const int gm = r[3 + c];
-                    const int4 gv = *(const int4 *)(r + 4 + c);
-                    const int4 cv = *(const int4 *)(r + WMAX + c), dv = *(const int4 *)(r + 2 * WMAX + c);
-                    n0 = imax(n0, gm + s0 + bz1); n1 = imax(n1, gv.x + s1 + bz1); n2 = imax(n2, gv.y + s2 + bz1); n3 = imax(n3, gv.z + s3 + bz1);
-                    u0 = imax(u0, cv.x + bz1); u1 = imax(u1, cv.y + bz1); u2 = imax(u2, cv.z + bz1); u3 = imax(u3, cv.w + bz1);
-                    v0 = imax(v0, dv.x + bz1); v1 = imax(v1, dv.y + bz1); v2 = imax(v2, dv.z + bz1); v3 = imax(v3, dv.w + bz1);
-                }
-                h0 = imax(n0, imax(u0, v0)); h1 = imax(n1, imax(u1, v1)); h2 = imax(n2, imax(u2, v2)); h3 = imax(n3, imax(u3, v3));
-            } else {
-                auto slow = [&](const int cc, const bool act, int &hp, int &ev1, int &ev2) {
-                    int mx = LCD_NEG, e1i = LCD_NEG, e2i = LCD_NEG;
-                    if (act) {
-                        int s = 0;
-                        if (cc >= 1) { const uint8_t qb = sq1[cc]; s = (vb >= 4 || qb >= 4) ? 0 : (vb == qb ? sc.match : -sc.mismatch); }
-                        for (int t = 0; t < np; ++t) {
-                            const int pi = t == 0 ? pi0 : t == 1 ? pi1 : g.pl_pidx[p0 + t];
-                            const int bonus = t == 0 ? bz0 : t == 1 ? bz1 : g.pl_bonus[p0 + t];
-                            const int sl = t == 0 ? sl0 : t == 1 ? sl1 : -1;
-                            if (sl >= 0) {
-                                const int *q = ring + sl * SLOTW;
-                                if (cc >= 1) mx = imax(mx, q[3 + cc] + s + bonus);
-                                e1i = imax(e1i, q[WMAX + cc] + bonus); e2i = imax(e2i, q[2 * WMAX + cc] + bonus);
-                            } else {
-                                const size_t po = (size_t)(pi - bi) * W1p;
-                                if (cc >= 1) mx = imax(mx, g.H[po + cc - 1] + s + bonus);
-                                e1i = imax(e1i, g.E1[po + cc] + bonus); e2i = imax(e2i, g.E2[po + cc] + bonus);
-                            }
-                        }
-                    }
-                    hp = imax(mx, imax(e1i, e2i)); ev1 = e1i; ev2 = e2i;
-                };
-                slow(c, k0, h0, u0, v0); slow(c + 1, k1, h1, u1, v1); slow(c + 2, k2, h2, u2, v2); slow(c + 3, k3, h3, u3, v3);
-            }
-            // ---- F: A[k] = Hpre[k] + k*e; in-lane inclusive prefix, then one scan pair over the lane totals ----
-            const int a10 = k0 ? h0 + c1a : LCD_NEG * 2, a11 = imax(a10, k1 ? h1 + c1a + e1 : LCD_NEG * 2), a12 = imax(a11, k2 ? h2 + c1a + 2 * e1 : LCD_NEG * 2);
-            const int a20 = k0 ? h0 + c2a : LCD_NEG * 2, a21 = imax(a20, k1 ? h1 + c2a + e2 : LCD_NEG * 2), a22 = imax(a21, k2 ? h2 + c2a + 2 * e2 : LCD_NEG * 2);
-            int t1 = imax(a12, k3 ? h3 + c1a + 3 * e1 : LCD_NEG * 2), t2 = imax(a22, k3 ? h3 + c2a + 3 * e2 : LCD_NEG * 2);
-            scan_max2(t1, t2);
-            int x1 = shr1(LCD_NEG * 2, t1), x2 = shr1(LCD_NEG * 2, t2); // exclusive prefix over the lanes of this wavefront
-            if (NW > 1) {
-                const int buf = idx & 1;
-                if (lane == 63) { sm.tot1[buf][wave] = t1; sm.tot2[buf][wave] = t2; }
-                lds_barrier<NT>();
-#pragma unroll
-                for (int k = 0; k < NW; ++k) if (k < wave) { x1 = imax(x1, sm.tot1[buf][k]); x2 = imax(x2, sm.tot2[buf][k]); }
-            }
-            // ---- phase B: F, H, E of the four cells; row to the ring slot and to HBM ----
-            // (at column 0 the prefix is -2^30, so f clamps to LCD_NEG exactly as the oracle's "j > beg" test does)
-            if (k0) {
-                int4 H4, A4, B4;
-#define LCD_CELL(k, hp, ev1, ev2, p1, p2, HO, AO, BO)                                                   \
-                {                                                                                        \
-                    const int f1 = imax(LCD_NEG, (p1) - o1 - c1a - (k) * e1), f2 = imax(LCD_NEG, (p2) - o2 - c2a - (k) * e2); \
-                    int h = imax(hp, imax(f1, f2)); if (h < LCD_NEG) h = LCD_NEG;                          \
-                    int eo1 = imax(h - oe1, (ev1) - e1), eo2 = imax(h - oe2, (ev2) - e2);                  \
-                    if (eo1 < LCD_NEG) eo1 = LCD_NEG;                                                      \
-                    if (eo2 < LCD_NEG) eo2 = LCD_NEG;                                                      \
-                    HO = h; AO = eo1; BO = eo2;                                                            \
-                }
-                LCD_CELL(0, h0, u0, v0, x1, x2, H4.x, A4.x, B4.x)
-                LCD_CELL(1, h1, u1, v1, imax(x1, a10), imax(x2, a20), H4.y, A4.y, B4.y)
-                LCD_CELL(2, h2, u2, v2, imax(x1, a11), imax(x2, a21), H4.z, A4.z, B4.z)
-                LCD_CELL(3, h3, u3, v3, imax(x1, a12), imax(x2, a22), H4.w, A4.w, B4.w)
-#undef LCD_CELL
-                if (k3) {
-                    if (!(sc.dbg & 1)) { *(int4 *)(g.H + off + c) = H4; *(int4 *)(g.E1 + off + c) = A4; *(int4 *)(g.E2 + off + c) = B4; }
-                    if (!(sc.dbg & 2)) *(int4 *)(rS + 4 + c) = H4; *(int4 *)(rS + WMAX + c) = A4; *(int4 *)(rS + 2 * WMAX + c) = B4;
-                } else {
-                    g.H[off + c] = H4.x; g.E1[off + c] = A4.x; g.E2[off + c] = B4.x; rS[4 + c] = H4.x; rS[WMAX + c] = A4.x; rS[2 * WMAX + c] = B4.x;
-                    if (k1) { g.H[off + c + 1] = H4.y; g.E1[off + c + 1] = A4.y; g.E2[off + c + 1] = B4.y; rS[5 + c] = H4.y; rS[WMAX + c + 1] = A4.y; rS[2 * WMAX + c + 1] = B4.y; }
-                    if (k2) { g.H[off + c + 2] = H4.z; g.E1[off + c + 2] = A4.z; g.E2[off + c + 2] = B4.z; rS[6 + c] = H4.z; rS[WMAX + c + 2] = A4.z; rS[2 * WMAX + c + 2] = B4.z; }
-                }
-            }
-            if (slot == 0) si0 = idx; else if (slot == 1) si1 = idx; else if (slot == 2) si2 = idx; else si3 = idx;
-            next_slot = (slot + 1) % K;
-            // publish the ring slot to the other wavefronts before the next row's phase A
-            lds_barrier<NT>();
-        }
-    } else {
     // Plan window: every 64 rows each lane loads the plan of one upcoming row (start, #preds, remain, base and the first two
     // predecessor entries); rows then take it by v_readlane.  The row loop therefore issues no HBM load in the common case,
     // so it never waits (vmcnt is in-order) behind the row stores that are still draining.
@@ -920,7 +1164,6 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         }
         last_idx = idx; last_beg = beg; last_end = end; last_ml = ml; last_mr = mr; last_off = (unsigned)off; last_slot = slot;
     }
-    } // banded / generic rows
     __syncthreads();
     *cells_acc += used;
     const long long t_bt0 = clock64();
@@ -1025,6 +1268,9 @@ __global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chain
     uint8_t *ws = arena + ch.ws_off;
     Ctx g;
     g.H = (int *)(ws + L.H); g.E1 = (int *)(ws + L.E1); g.E2 = (int *)(ws + L.E2);
+    // the windowed path re-partitions the same 12*cell_cap bytes: [codes: cell_cap B | ordinals: 4*cell_cap B | spilled rows: the rest]
+    g.code8 = ws + L.H; g.ord = (int *)(ws + L.H + lcd_align_up(ch.cell_cap, 16)); g.spill = (int *)(ws + L.H + lcd_align_up(ch.cell_cap, 16) + lcd_align_up(ch.cell_cap * 4, 16));
+    g.ooff = (uint32_t *)(ws + L.ooff); g.spoff = (uint32_t *)(ws + L.spoff);
     g.rbeg = (int *)(ws + L.rbeg); g.rend = (int *)(ws + L.rend); g.roff = (uint32_t *)(ws + L.roff);
     g.ml = (int *)(ws + L.mpl); g.mr = (int *)(ws + L.mpr);
     g.idx2node = (int *)(ws + L.idx2node); g.node2idx = (int *)(ws + L.node2idx); g.remain = (int *)(ws + L.remain);
@@ -1035,7 +1281,7 @@ __global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chain
     g.e_from = (int *)(ws + L.e_from); g.e_to = (int *)(ws + L.e_to); g.e_w = (int *)(ws + L.e_w);
     g.e_next_out = (int *)(ws + L.e_next_out); g.e_next_in = (int *)(ws + L.e_next_in);
     g.rid = (unsigned long long *)(ws + L.rid);
-    g.cig_node = (int *)(ws + L.cig_node); g.cig_qpos = (int *)(ws + L.cig_qpos);
+    g.cig_node0 = g.cig_node = (int *)(ws + L.cig_node); g.cig_qpos0 = g.cig_qpos = (int *)(ws + L.cig_qpos);
     g.base = ws + L.n_base; g.imap = ws + L.imap;
     g.het = (int *)(ws + L.het); g.clu = (int *)(ws + L.clu); g.nclu = (int *)(ws + L.nclu); g.prof = ws + L.prof;
     g.pl_start = (int *)(ws + L.pl_start); g.pl_pidx = (int *)(ws + L.pl_pidx); g.pl_bonus = (int *)(ws + L.pl_bonus);
