@@ -34,7 +34,12 @@ struct Smem {
     int rm[4][5];          // ring slot meta: beg, end, HBM offset, row-max leftmost / rightmost column
     int scan[MAXW];
     int bc[8];
+    // mailboxes of the systolic unbanded rows (align_unbanded): progress counter, F-scan carry, boundary H, per wavefront
+    int prog[MAXW];
+    int carry1[16][MAXW], carry2[16][MAXW], bndH[16][MAXW];
 };
+
+__shared__ Smem g_smem; // file scope: non-inlined device functions reach it as LDS (a Smem& parameter would be a generic pointer -> flat ops)
 
 template <int NT> struct Cfg;
 // One LDS pool per workgroup: [row ring | query cache] during the DP, re-used as 16-bit graph arrays by the re-sort.
@@ -465,11 +470,19 @@ typedef __attribute__((address_space(3))) int lcd_lds_i32;
 typedef __attribute__((address_space(3))) lcd_v4i lcd_lds_v4i;
 typedef __attribute__((address_space(1))) int lcd_glb_i32;
 typedef __attribute__((address_space(1))) lcd_v4i lcd_glb_v4i;
-__device__ __forceinline__ int lds_ld(const int *p) { return *(const lcd_lds_i32 *)p; }
-__device__ __forceinline__ int4 lds_ld4(const int *p) { const lcd_v4i v = *(const lcd_lds_v4i *)p; return make_int4(v.x, v.y, v.z, v.w); }
-__device__ __forceinline__ void lds_st4(int *p, const int4 v) { lcd_v4i t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(lcd_lds_v4i *)p = t; }
+// LDS is addressed by 32-bit byte offset (an integer, not a pointer: a generic->LDS pointer cast inside a non-inlined function
+// needs a null check that hipcc 7.2 mis-selects for gfx950)
+typedef __attribute__((address_space(3))) uint8_t lcd_lds_u8;
+__device__ __forceinline__ int lds_ld(const unsigned o) { return *(const lcd_lds_i32 *)(uintptr_t)o; }
+__device__ __forceinline__ int4 lds_ld4(const unsigned o) { const lcd_v4i v = *(const lcd_lds_v4i *)(uintptr_t)o; return make_int4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void lds_st4(const unsigned o, const int4 v) { lcd_v4i t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(lcd_lds_v4i *)(uintptr_t)o = t; }
+__device__ __forceinline__ int lds_ld_u8(const unsigned o) { return *(const lcd_lds_u8 *)(uintptr_t)o; }
+__device__ __forceinline__ void lds_st_u8(const unsigned o, const int v) { *(lcd_lds_u8 *)(uintptr_t)o = (uint8_t)v; }
+__device__ __forceinline__ unsigned lds_off(const void *p) { return (unsigned)(uintptr_t)(const lcd_lds_u8 *)p; }
 __device__ __forceinline__ int glb_ld(const int *p) { return *(const lcd_glb_i32 *)p; }
 __device__ __forceinline__ int4 glb_ld4(const int *p) { const lcd_v4i v = *(const lcd_glb_v4i *)p; return make_int4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void glb_st(void *p, const int v) { *(lcd_glb_i32 *)p = v; }
+__device__ __forceinline__ int glb_ld_u8(const uint8_t *p) { return *(const __attribute__((address_space(1))) uint8_t *)p; }
 __device__ __forceinline__ void glb_st4(int *p, const int4 v) { lcd_v4i t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(lcd_glb_v4i *)p = t; }
 // A value loaded from HBM inside a conditional must be waited for INSIDE that conditional: otherwise the compiler places the
 // s_waitcnt vmcnt(0) at the join, where it also waits (in-order vmcnt) for the row stores of every iteration that did not
@@ -556,17 +569,124 @@ __device__ void build_plan(Ctx &g, Smem &sm, const int bi, const int ei, const i
 // whose windows are shifted against each other need no per-cell bounds test; the few alias cases (a predecessor band that
 // reaches a full window away) are detected per row and make the caller fall back to the generic rows.
 // Returns the number of cigar entries (written at g.cig_node0/g.cig_qpos0 + *cig_pos), or -1 = not representable here.
+
+// Arguments of a non-inlined device function arrive in VGPRs (and a by-value struct through the stack), so the compiler
+// treats them as per-lane values: 64-bit pointers cost VGPR pairs and every "scalar" computation runs on the vector ALU.
+// These put workgroup-uniform values back into SGPRs.
+__device__ __forceinline__ int usgpr(const int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned usgpr(const unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ unsigned long long usgpr(const unsigned long long v) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+}
+template <typename T> __device__ __forceinline__ T *usgpr(T *p) { return (T *)usgpr((unsigned long long)p); }
+__device__ void ctx_to_sgpr(Ctx &g) {
+    g.code8 = usgpr(g.code8); g.ord = usgpr(g.ord); g.spill = usgpr(g.spill);
+    g.rbeg = usgpr(g.rbeg); g.rend = usgpr(g.rend); g.roff = usgpr(g.roff); g.ooff = usgpr(g.ooff); g.spoff = usgpr(g.spoff);
+    g.ml = usgpr(g.ml); g.mr = usgpr(g.mr); g.idx2node = usgpr(g.idx2node);
+    g.cig_node0 = usgpr(g.cig_node0); g.cig_qpos0 = usgpr(g.cig_qpos0); g.imap = usgpr(g.imap);
+    g.pl_start = usgpr(g.pl_start); g.pl_pidx = usgpr(g.pl_pidx); g.pl_bonus = usgpr(g.pl_bonus); g.pl_rem = usgpr(g.pl_rem); g.pl_base = usgpr(g.pl_base);
+    g.wmax = usgpr(g.wmax); g.cell_cap = usgpr(g.cell_cap); g.status = usgpr(g.status);
+}
+// End node (best predecessor at column qlen; its values are in the spill area) + the code-driven backtrack, on wavefront 0.
+// Results through sm.bc[0] = #cigar entries, [1] = status, [4] = first cigar slot.
+__device__ __forceinline__ void code_backtrack(const Ctx &g, Smem &sm, const unsigned pd, const int bi, const int ei, const int qlen, const int SLOTW, const int WM,
+                                               const int lane) {
+        int best = LCD_NEG, br = -1;
+        {
+            const int p0 = g.pl_start[ei], np = g.pl_start[ei + 1] - p0;
+            for (int t = 0; t < np; ++t) {
+                const int pi = g.pl_pidx[p0 + t];
+                if (qlen < g.rbeg[pi] || qlen > g.rend[pi]) continue;
+                const int c = g.spill[(size_t)g.spoff[pi] * SLOTW + (qlen & WM)] + g.pl_bonus[p0 + t];
+                if (c > best) { best = c; br = pi; }
+            }
+        }
+        int pos = qlen;
+        int status = g.status;
+        if (br >= 0 && best > LCD_NEG / 2 && status == LCD_OK) {
+            int i = br, j = qlen, st = 0;
+            while (i != bi && j > 0 && status == LCD_OK) {
+                if (st == 0 && pd != 0xffffffffu) {
+                    // speculate a run of matches along first predecessors: lane t looks at the cell t steps up the diagonal
+                    int my_i = -1, my_nx = -1;
+                    {
+                        int cur = i; bool alive = true;
+                        for (int t = 0; t < 64; ++t) {
+                            const bool ok = alive && cur != bi && j - t > 0;
+                            const int d = ok ? lds_ld_u8(pd + (cur - bi)) : 255;
+                            if (lane == t) { my_i = ok ? cur : -1; my_nx = d != 255 ? cur - d : -1; }
+                            alive = ok && d != 255;
+                            if (!alive) break;
+                            cur -= d;
+                        }
+                    }
+                    bool good = false;
+                    const int jj = j - lane;
+                    if (my_i >= 0 && my_nx >= 0) {
+                        const int rb = g.rbeg[my_i], re = g.rend[my_i];
+                        if (jj >= rb && jj <= re) good = (g.code8[(size_t)g.roff[my_i] + (jj - (rb & ~3))] & (7 | CB_PM)) == 0;
+                    }
+                    const unsigned long long bad = __ballot(!good);
+                    const int m = bad ? __ffsll((long long)bad) - 1 : 64;
+                    if (m > 0) {
+                        if (lane < m) { g.cig_node0[pos - 1 - lane] = g.idx2node[my_i]; g.cig_qpos0[pos - 1 - lane] = jj - 1; }
+                        i = LCD_RL(my_nx, __builtin_amdgcn_readfirstlane(m - 1));
+                        pos -= m; j -= m;
+                        continue;
+                    }
+                }
+                // one step, replaying the oracle's decision from the code
+                const int rb = g.rbeg[i], rb4 = rb & ~3;
+                const size_t ro = g.roff[i];
+                const int c = g.code8[ro + (j - rb4)];
+                const int p0 = g.pl_start[i], np = g.pl_start[i + 1] - p0;
+                const int ow = np > 1 ? g.ord[(size_t)g.ooff[i] + (j - rb4)] : 0;
+                if (st == 0) {
+                    const int hs = c & 7;
+                    if (hs == 0) {
+                        if (lane == 0) { g.cig_node0[pos - 1] = g.idx2node[i]; g.cig_qpos0[pos - 1] = j - 1; }
+                        --pos; i = g.pl_pidx[p0 + (ow & 255)]; --j;
+                    } else if (hs <= 2) {
+                        i = g.pl_pidx[p0 + ((ow >> (8 * hs)) & 255)]; st = hs;
+                    } else if (hs <= 5) { // insertion run: back to the closest opening column of a matching gap piece
+                        int k = -1;
+                        if (hs != 4) { int p = j - 1; while (p > rb && (g.code8[ro + (p - rb4)] & CB_Y1)) --p; k = p; }
+                        if (hs != 3) { int p = j - 1; while (p > rb && (g.code8[ro + (p - rb4)] & CB_Y2)) --p; k = imax(k, p); }
+                        const int nins = j - k;
+                        for (int u = lane; u < nins; u += 64) { g.cig_node0[pos - nins + u] = -1; g.cig_qpos0[pos - nins + u] = k + u; }
+                        pos -= nins; j = k;
+                    } else status = LCD_ERR_BACKTRACK;
+                } else {
+                    if (c & (st == 1 ? CB_O1 : CB_O2)) st = 0;
+                    else i = g.pl_pidx[p0 + ((ow >> (8 * st)) & 255)];
+                }
+            }
+            for (int u = lane; u < j; u += 64) { g.cig_node0[pos - j + u] = -1; g.cig_qpos0[pos - j + u] = u; }
+            pos -= j;
+        }
+        if (lane == 0) { sm.bc[0] = qlen - pos; sm.bc[1] = status; sm.bc[4] = pos; }
+    }
+
+struct WinOut { int status; unsigned long long t_dp, t_bt, cells; int cig_pos; };
+// (not inlined, context by value: the row loop then only carries the dozen pointers it uses instead of the chain's whole
+//  context -- inlined, hipcc spilled the scalar registers of ~45 pointers into VGPR lanes and re-read them every row)
 template <int NT, bool BANDED>
-__device__ int align_windowed(Ctx &g, Smem &sm, int *ring, uint8_t *sq1, const uint8_t *pd, const LcdScoring &sc, const int w,
-                              const int bi, const int ei, const int rem_beg, const uint8_t *seq_hbm, const int qlen,
-                              unsigned long long *cells_acc, int *cig_pos) {
+__device__ __attribute__((noinline)) int align_windowed(Ctx g, const unsigned ring_, const unsigned sq1_, const unsigned pd_ /* 0xffffffff: none */, const LcdScoring sc_, const int w_,
+                              const int bi_, const int ei_, const int rem_beg_, const uint8_t *seq_hbm_, const int qlen_,
+                              WinOut *wo_) {
     constexpr int NW = NT / 64, K = Cfg<NT>::K;
+    Smem &sm = g_smem;
+    ctx_to_sgpr(g);
+    const unsigned ring = usgpr(ring_), sq1 = usgpr(sq1_), pd = usgpr(pd_);
+    const int w = usgpr(w_), bi = usgpr(bi_), ei = usgpr(ei_), rem_beg = usgpr(rem_beg_), qlen = usgpr(qlen_);
+    const uint8_t *seq_hbm = usgpr(seq_hbm_); WinOut *wo = usgpr(wo_);
+    LcdScoring sc; sc.match = usgpr(sc_.match); sc.mismatch = usgpr(sc_.mismatch); sc.o1 = usgpr(sc_.o1); sc.e1 = usgpr(sc_.e1); sc.o2 = usgpr(sc_.o2); sc.e2 = usgpr(sc_.e2); sc.dbg = usgpr(sc_.dbg);
     const int WIN = g.wmax, WM = WIN - 1, SLOTW = 3 * WIN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = usgpr(tid >> 6); // (wave in an SGPR: branches on it are scalar)
     const int o1 = sc.o1, e1 = sc.e1, o2 = sc.o2, e2 = sc.e2, oe1 = o1 + e1, oe2 = o2 + e2;
     const bool act = 4 * tid < WIN;
     const int QB = (qlen + 12 + 15) & ~15;
-    for (int j = tid; j < QB; j += NT) sq1[j] = (j >= 1 && j <= qlen) ? seq_hbm[j - 1] : 4; // shifted: sq1[j] = q[j-1]
+    for (int j = tid; j < QB; j += NT) lds_st_u8(sq1 + j, (j >= 1 && j <= qlen) ? seq_hbm[j - 1] : 4); // shifted: sq1[j] = q[j-1]
     const int qclamp = QB - 4;
     const unsigned long long code_cap = g.cell_cap, ord_cap = g.cell_cap; // bytes / ints
     const long long spill_rows = g.cell_cap * 7 > 64 ? (long long)((g.cell_cap * 7 - 64) / ((unsigned long long)SLOTW * 4)) : 0;
@@ -576,7 +696,7 @@ __device__ int align_windowed(Ctx &g, Smem &sm, int *ring, uint8_t *sq1, const u
     int nsp = 0;
     {
         const bool spf = (g.imap[bi] & 2) != 0;
-        if (spf && spill_rows < 1) { g.status = LCD_ERR_CELLS; return 0; }
+        if (spf && spill_rows < 1) { wo->status = LCD_ERR_CELLS; return 0; }
         if (act) {
             int hh[4], aa[4], bb[4];
 #pragma unroll
@@ -589,7 +709,7 @@ __device__ int align_windowed(Ctx &g, Smem &sm, int *ring, uint8_t *sq1, const u
                 } else { hh[k] = LCD_GUARD; aa[k] = LCD_GUARD; bb[k] = LCD_GUARD; }
             }
             const int4 H4 = make_int4(hh[0], hh[1], hh[2], hh[3]), A4 = make_int4(aa[0], aa[1], aa[2], aa[3]), B4 = make_int4(bb[0], bb[1], bb[2], bb[3]);
-            lds_st4(ring + 4 * tid, H4); lds_st4(ring + WIN + 4 * tid, A4); lds_st4(ring + 2 * WIN + 4 * tid, B4);
+            lds_st4(ring + 16 * tid, H4); lds_st4(ring + 4 * (WIN + 4 * tid), A4); lds_st4(ring + 4 * (2 * WIN + 4 * tid), B4);
             if (spf) { int *G = g.spill; glb_st4(G + 4 * tid, H4); glb_st4(G + WIN + 4 * tid, A4); glb_st4(G + 2 * WIN + 4 * tid, B4); }
         }
         if (tid == 0) { g.rbeg[bi] = 0; g.rend[bi] = end0; g.roff[bi] = 0; g.ml[bi] = 0; g.mr[bi] = 0; g.spoff[bi] = 0; }
@@ -609,10 +729,10 @@ __device__ int align_windowed(Ctx &g, Smem &sm, int *ring, uint8_t *sq1, const u
             const int ri = idx + lane;
             w_np = 0; w_rem = 1 << 30;
             if (ri < ei) {
-                const int s0 = g.pl_start[ri], s1 = g.pl_start[ri + 1];
-                w_p0 = s0; w_np = s1 - s0; w_rem = g.pl_rem[ri]; w_vb = g.pl_base[ri]; w_sp = g.imap[ri] & 2;
-                if (w_np > 0) { w_pi0 = g.pl_pidx[s0]; w_b0 = g.pl_bonus[s0]; }
-                if (w_np > 1) { w_pi1 = g.pl_pidx[s0 + 1]; w_b1 = g.pl_bonus[s0 + 1]; }
+                const int s0 = glb_ld(g.pl_start + ri), s1 = glb_ld(g.pl_start + ri + 1);
+                w_p0 = s0; w_np = s1 - s0; w_rem = glb_ld(g.pl_rem + ri); w_vb = glb_ld_u8(g.pl_base + ri); w_sp = glb_ld_u8(g.imap + ri) & 2;
+                if (w_np > 0) { w_pi0 = glb_ld(g.pl_pidx + s0); w_b0 = glb_ld(g.pl_bonus + s0); }
+                if (w_np > 1) { w_pi1 = glb_ld(g.pl_pidx + s0 + 1); w_b1 = glb_ld(g.pl_bonus + s0 + 1); }
             }
             LCD_PIN(w_p0); LCD_PIN(w_np); LCD_PIN(w_rem); LCD_PIN(w_vb); LCD_PIN(w_sp); LCD_PIN(w_pi0); LCD_PIN(w_b0); LCD_PIN(w_pi1); LCD_PIN(w_b1);
         }
@@ -623,7 +743,7 @@ __device__ int align_windowed(Ctx &g, Smem &sm, int *ring, uint8_t *sq1, const u
         const int s = (idx - bi) & (K - 1);
         if (rem == (1 << 30)) { // not reachable
             if (lane == s) { m_beg = 1; m_end = 0; }
-            if (tid == 0) { g.rbeg[idx] = 1; g.rend[idx] = 0; }
+            if (tid == 0) { glb_st(g.rbeg + idx, 1); glb_st(g.rend + idx, 0); }
             continue;
         }
         bool synced = false;
@@ -650,7 +770,7 @@ __device__ int align_windowed(Ctx &g, Smem &sm, int *ring, uint8_t *sq1, const u
             if (end > maxpe + 1) end = maxpe + 1;
             if (beg > end) { // empty row
                 if (lane == s) { m_beg = 1; m_end = 0; }
-                if (tid == 0) { g.rbeg[idx] = 1; g.rend[idx] = 0; }
+                if (tid == 0) { glb_st(g.rbeg + idx, 1); glb_st(g.rend + idx, 0); }
                 continue;
             }
             if (end - (beg & ~3) + 2 > WIN) return -1;
@@ -662,7 +782,7 @@ __device__ int align_windowed(Ctx &g, Smem &sm, int *ring, uint8_t *sq1, const u
         const bool i2 = act && jb + 2 >= beg && jb + 2 <= end, i3 = act && jb + 3 >= beg && jb + 3 <= end;
         int s0, s1, s2, s3;
         {
-            const unsigned qw = (unsigned)lds_ld((const int *)(sq1 + imin(jb, qclamp))); // q[jb-1], q[jb], q[jb+1], q[jb+2]
+            const unsigned qw = (unsigned)lds_ld(sq1 + imin(jb, qclamp)); // q[jb-1], q[jb], q[jb+1], q[jb+2]
             const int q0 = qw & 255, q1 = (qw >> 8) & 255, q2 = (qw >> 16) & 255, q3 = qw >> 24;
             s0 = (vb >= 4 || q0 >= 4) ? 0 : (vb == q0 ? sc.match : -sc.mismatch);
             s1 = (vb >= 4 || q1 >= 4) ? 0 : (vb == q1 ? sc.match : -sc.mismatch);
@@ -687,8 +807,8 @@ __device__ int align_windowed(Ctx &g, Smem &sm, int *ring, uint8_t *sq1, const u
             }
             int hm = LCD_GUARD; int4 hv = make_int4(LCD_GUARD, LCD_GUARD, LCD_GUARD, LCD_GUARD), av = hv, bv = hv;
             if (near) {
-                const int *S = ring + sp * SLOTW;
-                if (act) { hm = lds_ld(S + xm); hv = lds_ld4(S + x); av = lds_ld4(S + WIN + x); bv = lds_ld4(S + 2 * WIN + x); }
+                const unsigned S = ring + 4 * sp * SLOTW;
+                if (act) { hm = lds_ld(S + 4 * xm); hv = lds_ld4(S + 4 * x); av = lds_ld4(S + 4 * (WIN + x)); bv = lds_ld4(S + 4 * (2 * WIN + x)); }
             } else {
                 if (!synced) { __syncthreads(); synced = true; }
                 const int *G = g.spill + (size_t)g.spoff[pi] * SLOTW;
@@ -713,7 +833,7 @@ __device__ int align_windowed(Ctx &g, Smem &sm, int *ring, uint8_t *sq1, const u
             }
         }
         if (overflow) return -1;
-        if (np > 256) { g.status = LCD_ERR_NODES; return 0; } // ordinals are 8 bits
+        if (np > 256) { wo->status = LCD_ERR_NODES; return 0; } // ordinals are 8 bits
         const int h0 = imax(n0, imax(u0, v0)), h1 = imax(n1, imax(u1, v1)), h2 = imax(n2, imax(u2, v2)), h3 = imax(n3, imax(u3, v3)); // Hpre
         // ---- F: A[k] = Hpre[k] + k*e; in-lane inclusive prefix, then one scan pair over the lane totals ----
         const int je1 = jb * e1, je2 = jb * e2;
@@ -780,23 +900,23 @@ __device__ int align_windowed(Ctx &g, Smem &sm, int *ring, uint8_t *sq1, const u
         }
         // ---- stores: ring slot (values), HBM (codes; values only for rows a far successor / the end node will read) ----
         const int cw4 = (((end - beg4) >> 2) + 1) << 2; // cells of this row in HBM, padded to the lanes' 4-cell groups
-        if (cused + cw4 > code_cap || (np > 1 && oused + cw4 > ord_cap) || (spf && nsp >= spill_rows)) { g.status = LCD_ERR_CELLS; return 0; }
+        if (cused + cw4 > code_cap || (np > 1 && oused + cw4 > ord_cap) || (spf && nsp >= spill_rows)) { wo->status = LCD_ERR_CELLS; return 0; }
         if (act) {
-            int *S = ring + s * SLOTW;
+            const unsigned S = ring + 4 * s * SLOTW;
             const int4 H4 = make_int4(hh0, hh1, hh2, hh3), A4 = make_int4(ea0, ea1, ea2, ea3), B4 = make_int4(eb0, eb1, eb2, eb3);
-            lds_st4(S + x, H4); lds_st4(S + WIN + x, A4); lds_st4(S + 2 * WIN + x, B4);
+            lds_st4(S + 4 * x, H4); lds_st4(S + 4 * (WIN + x), A4); lds_st4(S + 4 * (2 * WIN + x), B4);
             if (spf) { int *G = g.spill + (size_t)nsp * SLOTW; glb_st4(G + x, H4); glb_st4(G + WIN + x, A4); glb_st4(G + 2 * WIN + x, B4); }
             if (4 * tid < cw4) {
-                *(unsigned *)(g.code8 + cused + 4 * tid) = code;
-                if (np > 1) *(int4 *)(g.ord + oused + 4 * tid) = make_int4((om & 255) | ((oa & 255) << 8) | ((ob & 255) << 16),
+                glb_st(g.code8 + cused + 4 * tid, (int)code);
+                if (np > 1) glb_st4(g.ord + oused + 4 * tid, make_int4((om & 255) | ((oa & 255) << 8) | ((ob & 255) << 16),
                                                                            ((om >> 8) & 255) | (((oa >> 8) & 255) << 8) | (((ob >> 8) & 255) << 16),
                                                                            ((om >> 16) & 255) | (((oa >> 16) & 255) << 8) | (((ob >> 16) & 255) << 16),
-                                                                           ((om >> 24) & 255) | (((oa >> 24) & 255) << 8) | (((ob >> 24) & 255) << 16));
+                                                                           ((om >> 24) & 255) | (((oa >> 24) & 255) << 8) | (((ob >> 24) & 255) << 16)));
             }
         }
         if (tid == 0) {
-            g.rbeg[idx] = beg; g.rend[idx] = end; g.roff[idx] = (uint32_t)cused; g.ooff[idx] = (uint32_t)oused;
-            if (spf) { g.ml[idx] = ml; g.mr[idx] = mr; g.spoff[idx] = (uint32_t)nsp; }
+            glb_st(g.rbeg + idx, beg); glb_st(g.rend + idx, end); glb_st(g.roff + idx, (int)cused); glb_st(g.ooff + idx, (int)oused);
+            if (spf) { glb_st(g.ml + idx, ml); glb_st(g.mr + idx, mr); glb_st(g.spoff + idx, nsp); }
         }
         if (lane == s) { m_beg = beg; m_end = end; m_ml = ml; m_mr = mr; }
         cused += cw4; if (np > 1) oused += cw4; if (spf) ++nsp;
@@ -804,92 +924,260 @@ __device__ int align_windowed(Ctx &g, Smem &sm, int *ring, uint8_t *sq1, const u
         lds_barrier<NT>(); // publish the ring slot to the other wavefronts before the next row's phase A
     }
     __syncthreads();
-    *cells_acc += ncell;
+    wo->cells = ncell;
     const long long t_bt0 = clock64();
-    g.t_dp += (unsigned long long)(t_bt0 - t_dp0);
-    // ---- end node: best predecessor at column qlen (its values are in the spill area), then the code-driven backtrack ----
-    if (wave == 0) {
-        int best = LCD_NEG, br = -1;
-        {
-            const int p0 = g.pl_start[ei], np = g.pl_start[ei + 1] - p0;
-            for (int t = 0; t < np; ++t) {
-                const int pi = g.pl_pidx[p0 + t];
-                if (qlen < g.rbeg[pi] || qlen > g.rend[pi]) continue;
-                const int c = g.spill[(size_t)g.spoff[pi] * SLOTW + (qlen & WM)] + g.pl_bonus[p0 + t];
-                if (c > best) { best = c; br = pi; }
-            }
-        }
-        int pos = qlen;
-        int status = g.status;
-        if (br >= 0 && best > LCD_NEG / 2 && status == LCD_OK) {
-            int i = br, j = qlen, st = 0;
-            while (i != bi && j > 0 && status == LCD_OK) {
-                if (st == 0 && pd) {
-                    // speculate a run of matches along first predecessors: lane t looks at the cell t steps up the diagonal
-                    int my_i = -1, my_nx = -1;
-                    {
-                        int cur = i; bool alive = true;
-                        for (int t = 0; t < 64; ++t) {
-                            const bool ok = alive && cur != bi && j - t > 0;
-                            const int d = ok ? (int)pd[cur - bi] : 255;
-                            if (lane == t) { my_i = ok ? cur : -1; my_nx = d != 255 ? cur - d : -1; }
-                            alive = ok && d != 255;
-                            if (!alive) break;
-                            cur -= d;
-                        }
-                    }
-                    bool good = false;
-                    const int jj = j - lane;
-                    if (my_i >= 0 && my_nx >= 0) {
-                        const int rb = g.rbeg[my_i], re = g.rend[my_i];
-                        if (jj >= rb && jj <= re) good = (g.code8[(size_t)g.roff[my_i] + (jj - (rb & ~3))] & (7 | CB_PM)) == 0;
-                    }
-                    const unsigned long long bad = __ballot(!good);
-                    const int m = bad ? __ffsll((long long)bad) - 1 : 64;
-                    if (m > 0) {
-                        if (lane < m) { g.cig_node0[pos - 1 - lane] = g.idx2node[my_i]; g.cig_qpos0[pos - 1 - lane] = jj - 1; }
-                        i = LCD_RL(my_nx, __builtin_amdgcn_readfirstlane(m - 1));
-                        pos -= m; j -= m;
-                        continue;
-                    }
-                }
-                // one step, replaying the oracle's decision from the code
-                const int rb = g.rbeg[i], rb4 = rb & ~3;
-                const size_t ro = g.roff[i];
-                const int c = g.code8[ro + (j - rb4)];
-                const int p0 = g.pl_start[i], np = g.pl_start[i + 1] - p0;
-                const int ow = np > 1 ? g.ord[(size_t)g.ooff[i] + (j - rb4)] : 0;
-                if (st == 0) {
-                    const int hs = c & 7;
-                    if (hs == 0) {
-                        if (lane == 0) { g.cig_node0[pos - 1] = g.idx2node[i]; g.cig_qpos0[pos - 1] = j - 1; }
-                        --pos; i = g.pl_pidx[p0 + (ow & 255)]; --j;
-                    } else if (hs <= 2) {
-                        i = g.pl_pidx[p0 + ((ow >> (8 * hs)) & 255)]; st = hs;
-                    } else if (hs <= 5) { // insertion run: back to the closest opening column of a matching gap piece
-                        int k = -1;
-                        if (hs != 4) { int p = j - 1; while (p > rb && (g.code8[ro + (p - rb4)] & CB_Y1)) --p; k = p; }
-                        if (hs != 3) { int p = j - 1; while (p > rb && (g.code8[ro + (p - rb4)] & CB_Y2)) --p; k = imax(k, p); }
-                        const int nins = j - k;
-                        for (int u = lane; u < nins; u += 64) { g.cig_node0[pos - nins + u] = -1; g.cig_qpos0[pos - nins + u] = k + u; }
-                        pos -= nins; j = k;
-                    } else status = LCD_ERR_BACKTRACK;
-                } else {
-                    if (c & (st == 1 ? CB_O1 : CB_O2)) st = 0;
-                    else i = g.pl_pidx[p0 + ((ow >> (8 * st)) & 255)];
-                }
-            }
-            for (int u = lane; u < j; u += 64) { g.cig_node0[pos - j + u] = -1; g.cig_qpos0[pos - j + u] = u; }
-            pos -= j;
-        }
-        if (lane == 0) { sm.bc[0] = qlen - pos; sm.bc[1] = status; sm.bc[4] = pos; }
-    }
+    wo->t_dp = (unsigned long long)(t_bt0 - t_dp0);
+    if (wave == 0) code_backtrack(g, sm, pd, bi, ei, qlen, SLOTW, WM, lane);
     __syncthreads();
     const int n_cig = sm.bc[0];
-    g.status = sm.bc[1];
-    *cig_pos = sm.bc[4];
+    wo->status = sm.bc[1];
+    wo->cig_pos = sm.bc[4];
     __syncthreads();
-    g.t_bt += (unsigned long long)(clock64() - t_bt0);
+    wo->t_bt = (unsigned long long)(clock64() - t_bt0);
+    return n_cig;
+}
+
+// ================= unbanded K2 rows: systolic across the wavefronts of the workgroup =================
+// wb < 0 makes every row [0, qlen] (oracle: w = qlen), so nothing about a row depends on the other rows' maxima and the only
+// data that crosses a wavefront boundary is (a) H of the last column of the left neighbour's 256-column segment, for the
+// match term of lane 0, and (b) the running prefix of the horizontal-gap scan.  Both go through small LDS mailboxes
+// (bndH / carry, SYS_D rows deep) and a per-wavefront progress counter: wavefront w starts row r once w-1 has published row
+// r, so the workgroup runs as a pipeline (w works on row r while w-1 is on r+1 ...) with NO workgroup barrier in the row
+// loop -- with s_barrier twice per row the 16 wavefronts of a 4 096-column row spent 2/3 of their cycles parked.
+// Per-lane constants (query bases, column * e) are loaded once per read; out-of-range columns (> qlen) are computed and
+// stored like the others and never read, so there is no band mask.  E planes hold E + e ("E-out before the extension
+// charge"): max(H - o, Ein), one subtraction less per cell; the reader folds the -e into the edge bonus.
+constexpr int SYS_D = 16;
+__device__ __forceinline__ void poll_ge(const int *p, const int v) { // p is in LDS (g_smem): volatile ds_read, no flat access
+    const volatile lcd_lds_i32 *q = (const volatile lcd_lds_i32 *)(uintptr_t)lds_off(p);
+    while (*q < v) __builtin_amdgcn_s_sleep(1);
+}
+
+template <int NT>
+__device__ __attribute__((noinline)) int align_unbanded(Ctx g, const unsigned ring_, const unsigned pd_ /* 0xffffffff: none */, const LcdScoring sc_,
+                                                        const int bi_, const int ei_, const uint8_t *seq_hbm_, const int qlen_, WinOut *wo_) {
+    constexpr int NW = NT / 64, K = Cfg<NT>::K;
+    constexpr bool SYS = NW > 1;
+    Smem &sm = g_smem;
+    ctx_to_sgpr(g);
+    const unsigned ring = usgpr(ring_), pd = usgpr(pd_);
+    const int bi = usgpr(bi_), ei = usgpr(ei_), qlen = usgpr(qlen_);
+    const uint8_t *seq_hbm = usgpr(seq_hbm_); WinOut *wo = usgpr(wo_);
+    LcdScoring sc; sc.match = usgpr(sc_.match); sc.mismatch = usgpr(sc_.mismatch); sc.o1 = usgpr(sc_.o1); sc.e1 = usgpr(sc_.e1); sc.o2 = usgpr(sc_.o2); sc.e2 = usgpr(sc_.e2); sc.dbg = usgpr(sc_.dbg);
+    const int WIN = g.wmax, WM = WIN - 1, SLOTW = 3 * WIN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = usgpr(tid >> 6); // (wave in an SGPR: branches on it are scalar)
+    const int o1 = sc.o1, e1 = sc.e1, o2 = sc.o2, e2 = sc.e2;
+    if (qlen + 2 > WIN) return -1;
+    const int jb = 4 * tid;
+    const int AW = imin(NW, (qlen >> 8) + 1); // wavefronts that own a column <= qlen
+    const int cw4 = ((qlen >> 2) + 1) << 2;  // cells of a row in HBM, padded to the lanes' 4-cell groups
+    const unsigned long long code_cap = g.cell_cap, ord_cap = g.cell_cap;
+    const long long spill_rows = g.cell_cap * 7 > 64 ? (long long)((g.cell_cap * 7 - 64) / ((unsigned long long)SLOTW * 4)) : 0;
+    // per-lane constants of this read
+    // (one packed register: q[jb-1], q[jb], q[jb+1], q[jb+2] in bytes 0..3; columns outside the read get 15, which matches no base)
+    unsigned qpk = 0; int has_n = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = jb + k;
+        int b = 15;
+        if (j >= 1 && j <= qlen) { b = seq_hbm[j - 1]; has_n |= b >= 4; }
+        qpk |= (unsigned)b << (8 * k);
+    }
+    if (__syncthreads_or(has_n)) return -1; // reads with N bases (score 0 against everything) take the windowed rows
+    const int je1 = jb * e1, je2 = jb * e2;            // A[k] = Hpre[k] + (jb + k) * e
+    const int noj1 = -(o1 + je1), noj2 = -(o2 + je2);  // F[k] = prefix + noj - k * e
+    const unsigned lofs = 16u * (unsigned)tid;         // this lane's 4 cells inside a plane (bytes)
+    const unsigned PL = 4u * (unsigned)WIN;            // plane stride (bytes)
+    int nsp = 0;
+    // ---- source row (slot 0) ----
+    {
+        const bool spf = (g.imap[bi] & 2) != 0;
+        if (spf && spill_rows < 1) { wo->status = LCD_ERR_CELLS; return 0; }
+        int hh[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = jb + k;
+            const int f1 = j ? -(o1 + e1 * j) : LCD_NEG, f2 = j ? -(o2 + e2 * j) : LCD_NEG;
+            hh[k] = j <= qlen ? (j ? imax(f1, f2) : 0) : LCD_GUARD;
+        }
+        const int4 H4 = make_int4(hh[0], hh[1], hh[2], hh[3]);
+        const int4 A4 = make_int4(hh[0] - o1, hh[1] - o1, hh[2] - o1, hh[3] - o1), B4 = make_int4(hh[0] - o2, hh[1] - o2, hh[2] - o2, hh[3] - o2);
+        if (jb < WIN) {
+            lds_st4(ring + lofs, H4); lds_st4(ring + PL + lofs, A4); lds_st4(ring + 2 * PL + lofs, B4);
+            if (spf) { int *G = g.spill; glb_st4(G + jb, H4); glb_st4(G + WIN + jb, A4); glb_st4(G + 2 * WIN + jb, B4); }
+        }
+        if (SYS && lane == 63) { sm.bndH[bi & (SYS_D - 1)][wave] = H4.w; sm.prog[wave] = bi; }
+        if (tid == 0) { g.rbeg[bi] = 0; g.rend[bi] = qlen; g.roff[bi] = 0; g.ml[bi] = 0; g.mr[bi] = 0; g.spoff[bi] = 0; sm.bc[7] = LCD_OK; }
+        if (spf) nsp = 1;
+    }
+    unsigned long long cused = 0, oused = 0, ncell = (unsigned long long)qlen + 1;
+    __syncthreads();
+    const long long t_dp0 = clock64();
+    int err = LCD_OK;
+    if (wave < AW) {
+        int wbase = -(1 << 20);
+        int w_pk = 0, w_pi0 = 0, w_pi1 = 0; // w_pk: #preds (16 bits) | base << 16 | spill << 19 | unreachable << 20 | bonus0 << 21 | bonus1 << 26
+        const int ke1 = e1, ke2 = e2;
+        for (int idx = bi + 1; idx < ei; ++idx) {
+            if (idx - wbase >= 64) { // plan window: each lane loads the plan of one upcoming row; rows then take it by v_readlane
+                wbase = idx;
+                const int ri = idx + lane;
+                w_pk = 1 << 20;
+                if (ri < ei) {
+                    const int s0 = glb_ld(g.pl_start + ri), s1 = glb_ld(g.pl_start + ri + 1);
+                    const int cnt = s1 - s0;
+                    int b0 = 0, b1 = 0;
+                    if (cnt > 0) { w_pi0 = glb_ld(g.pl_pidx + s0); b0 = glb_ld(g.pl_bonus + s0); }
+                    if (cnt > 1) { w_pi1 = glb_ld(g.pl_pidx + s0 + 1); b1 = glb_ld(g.pl_bonus + s0 + 1); }
+                    w_pk = imin(cnt, 65535) | (glb_ld_u8(g.pl_base + ri) << 16) | ((glb_ld_u8(g.imap + ri) & 2) << 18) | (glb_ld(g.pl_rem + ri) == (1 << 30) ? 1 << 20 : 0) | (b0 << 21) | (b1 << 26);
+                }
+                LCD_PIN(w_pk); LCD_PIN(w_pi0); LCD_PIN(w_pi1);
+            }
+            const int wk = idx - wbase;
+            const int pk = LCD_RL(w_pk, wk), pi0 = LCD_RL(w_pi0, wk), pi1 = LCD_RL(w_pi1, wk);
+            const int np = pk & 65535, vb = (pk >> 16) & 7, bz0 = (pk >> 21) & 31, bz1 = (pk >> 26) & 31;
+            const bool spf = (pk >> 19) & 1;
+            if ((pk >> 20) & 1) { // not reachable from the begin node (sub-graph alignments only)
+                if (tid == 0) { glb_st(g.rbeg + idx, 1); glb_st(g.rend + idx, 0); }
+                continue;
+            }
+            // every wavefront takes the same decisions from the same plan, so an error leaves the loop in all of them at the same row
+            if (cused + cw4 > code_cap || (np > 1 && oused + cw4 > ord_cap) || (spf && nsp >= spill_rows)) { err = LCD_ERR_CELLS; break; }
+            if (np > 256) { err = LCD_ERR_NODES; break; } // ordinals are 8 bits (and the packed plan word holds 16)
+            const int s = (idx - bi) & (K - 1);
+            if (SYS) {
+                if (wave + 1 < AW) poll_ge(&sm.prog[wave + 1], idx - (SYS_D - K - 1)); // mailbox slot (idx mod SYS_D) is free again
+                if (wave > 0) poll_ge(&sm.prog[wave - 1], idx);                          // left neighbour has published this row
+                asm volatile("" ::: "memory");
+            }
+            const int d0 = idx - pi0, d1 = idx - pi1;
+            int s0, s1, s2, s3;
+            if (vb < 4) {
+                const int mt = sc.match, mm = -sc.mismatch;
+                s0 = (int)(qpk & 255) == vb ? mt : mm; s1 = (int)((qpk >> 8) & 255) == vb ? mt : mm;
+                s2 = (int)((qpk >> 16) & 255) == vb ? mt : mm; s3 = (int)(qpk >> 24) == vb ? mt : mm;
+            } else { s0 = s1 = s2 = s3 = 0; } // N in the graph scores 0 against everything
+            // ---- phase A: best match / E1 / E2 input of the four cells ----
+            int n0, n1, n2, n3, u0, u1, u2, u3, v0, v1, v2, v3;
+            int om = 0, oa = 0, ob = 0; // ordinals of the first maximum, one byte per cell
+            auto near_row = [&](const int pi, int &hm, int4 &hv, int4 &av, int4 &bv) {
+                const unsigned S = ring + 4u * (unsigned)(((pi - bi) & (K - 1)) * SLOTW);
+                hm = lds_ld(S + lofs - 4); hv = lds_ld4(S + lofs); av = lds_ld4(S + PL + lofs); bv = lds_ld4(S + 2 * PL + lofs);
+                if (lane == 0) hm = wave == 0 ? LCD_GUARD : (SYS ? sm.bndH[pi & (SYS_D - 1)][wave - 1] : hm);
+            };
+            auto far_row = [&](const int pi, int &hm, int4 &hv, int4 &av, int4 &bv) {
+                const int *G = g.spill + (size_t)g.spoff[pi] * SLOTW;
+                hm = tid ? glb_ld(G + jb - 1) : LCD_GUARD; hv = glb_ld4(G + jb); av = glb_ld4(G + WIN + jb); bv = glb_ld4(G + 2 * WIN + jb);
+                LCD_PIN(hm); LCD_PIN(hv.x); LCD_PIN(hv.y); LCD_PIN(hv.z); LCD_PIN(hv.w); LCD_PIN(av.x); LCD_PIN(av.y); LCD_PIN(av.z); LCD_PIN(av.w);
+                LCD_PIN(bv.x); LCD_PIN(bv.y); LCD_PIN(bv.z); LCD_PIN(bv.w);
+            };
+            if (np == 1 && d0 <= K) {
+                int hm; int4 hv, av, bv;
+                near_row(pi0, hm, hv, av, bv);
+                const int be1 = bz0 - e1, be2 = bz0 - e2;
+                n0 = hm + s0 + bz0; n1 = hv.x + s1 + bz0; n2 = hv.y + s2 + bz0; n3 = hv.z + s3 + bz0;
+                u0 = av.x + be1; u1 = av.y + be1; u2 = av.z + be1; u3 = av.w + be1;
+                v0 = bv.x + be2; v1 = bv.y + be2; v2 = bv.z + be2; v3 = bv.w + be2;
+            } else {
+                if ((np > 0 && d0 > K) || (np > 1 && d1 > K) || np > 2) { // a far row may be read from HBM: its stores (own ones included) must have landed
+                    if (SYS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else __syncthreads(); // (systolic: the neighbours waited before publishing a spilled row)
+                }
+                n0 = n1 = n2 = n3 = u0 = u1 = u2 = u3 = v0 = v1 = v2 = v3 = LCD_NEG;
+                int p0 = 0;
+                if (np > 2) { p0 = g.pl_start[idx]; LCD_PIN(p0); }
+                for (int t = 0; t < np; ++t) {
+                    int pi = t == 0 ? pi0 : pi1, bz = t == 0 ? bz0 : bz1;
+                    if (t > 1) { pi = g.pl_pidx[p0 + t]; bz = g.pl_bonus[p0 + t]; LCD_PIN(pi); LCD_PIN(bz); }
+                    int hm; int4 hv, av, bv;
+                    if (idx - pi <= K) near_row(pi, hm, hv, av, bv); else far_row(pi, hm, hv, av, bv);
+                    const int be1 = bz - e1, be2 = bz - e2;
+                    const int c0 = hm + s0 + bz, c1 = hv.x + s1 + bz, c2 = hv.y + s2 + bz, c3 = hv.z + s3 + bz;
+                    const int a0 = av.x + be1, a1 = av.y + be1, a2 = av.z + be1, a3 = av.w + be1;
+                    const int b0 = bv.x + be2, b1 = bv.y + be2, b2 = bv.z + be2, b3 = bv.w + be2;
+                    const int tt = t > 255 ? 255 : t;
+#define LCD_UPD(cur, cand, ordv, sh) if ((cand) > (cur)) { cur = (cand); ordv = (ordv & ~(255 << (sh))) | (tt << (sh)); }
+                    LCD_UPD(n0, c0, om, 0) LCD_UPD(n1, c1, om, 8) LCD_UPD(n2, c2, om, 16) LCD_UPD(n3, c3, om, 24)
+                    LCD_UPD(u0, a0, oa, 0) LCD_UPD(u1, a1, oa, 8) LCD_UPD(u2, a2, oa, 16) LCD_UPD(u3, a3, oa, 24)
+                    LCD_UPD(v0, b0, ob, 0) LCD_UPD(v1, b1, ob, 8) LCD_UPD(v2, b2, ob, 16) LCD_UPD(v3, b3, ob, 24)
+#undef LCD_UPD
+                }
+            }
+            const int h0 = imax(n0, imax(u0, v0)), h1 = imax(n1, imax(u1, v1)), h2 = imax(n2, imax(u2, v2)), h3 = imax(n3, imax(u3, v3)); // Hpre
+            // which of match / E1 / E2 gives Hpre (the oracle's priority): used when H == Hpre
+            const int sp0 = n0 == h0 ? 0 : u0 == h0 ? 1 : 2, sp1 = n1 == h1 ? 0 : u1 == h1 ? 1 : 2, sp2 = n2 == h2 ? 0 : u2 == h2 ? 1 : 2, sp3 = n3 == h3 ? 0 : u3 == h3 ? 1 : 2;
+            // ---- F: A[k] = Hpre[k] + k*e; in-lane inclusive prefix, one scan pair over the lane totals, carry from the left wavefront ----
+            const int a10 = h0 + je1, a11 = h1 + je1 + ke1, a12 = h2 + je1 + 2 * ke1, a13 = h3 + je1 + 3 * ke1;
+            const int a20 = h0 + je2, a21 = h1 + je2 + ke2, a22 = h2 + je2 + 2 * ke2, a23 = h3 + je2 + 3 * ke2;
+            const int p10 = a10, p11 = imax(p10, a11), p12 = imax(p11, a12);
+            const int p20 = a20, p21 = imax(p20, a21), p22 = imax(p21, a22);
+            int t1 = imax(p12, a13), t2 = imax(p22, a23);
+            scan_max2(t1, t2);
+            int x1 = shr1(LCD_GUARD, t1), x2 = shr1(LCD_GUARD, t2); // exclusive prefix over the lanes of this wavefront
+            int cin1 = LCD_GUARD, cin2 = LCD_GUARD;
+            if (SYS && wave > 0) { cin1 = sm.carry1[idx & (SYS_D - 1)][wave - 1]; cin2 = sm.carry2[idx & (SYS_D - 1)][wave - 1]; x1 = imax(x1, cin1); x2 = imax(x2, cin2); }
+            // ---- phase B: F, H, E-out, direction code of the four cells ----
+            int hh0, hh1, hh2, hh3, ea0, ea1, ea2, ea3, eb0, eb1, eb2, eb3;
+            unsigned code = 0;
+#define LCD_CELL(k, hp, spk, ev1, ev2, pf1, pf2, ak1, ak2, HO, AO, BO)                                                        \
+            {                                                                                                               \
+                const int f1 = (pf1) + noj1 - (k) * ke1, f2 = (pf2) + noj2 - (k) * ke2;                                     \
+                const int h = imax(hp, imax(f1, f2));                                                                       \
+                const int ho1 = h - o1, ho2 = h - o2;                                                                       \
+                const int fk = f1 == h ? (f2 == h ? 5 : 3) : 4;                                                             \
+                const unsigned cd = (unsigned)((hp) == h ? (spk) : fk) | ((pf1) > (ak1) ? CB_Y1 : 0) | ((pf2) > (ak2) ? CB_Y2 : 0) | \
+                                    (ho1 >= (ev1) ? CB_O1 : 0) | (ho2 >= (ev2) ? CB_O2 : 0) | (((om >> (8 * (k))) & 255) ? CB_PM : 0); \
+                code |= cd << (8 * (k));                                                                                    \
+                HO = h; AO = imax(ho1, ev1); BO = imax(ho2, ev2);                                                           \
+            }
+            LCD_CELL(0, h0, sp0, u0, v0, x1, x2, a10, a20, hh0, ea0, eb0)
+            LCD_CELL(1, h1, sp1, u1, v1, imax(x1, p10), imax(x2, p20), a11, a21, hh1, ea1, eb1)
+            LCD_CELL(2, h2, sp2, u2, v2, imax(x1, p11), imax(x2, p21), a12, a22, hh2, ea2, eb2)
+            LCD_CELL(3, h3, sp3, u3, v3, imax(x1, p12), imax(x2, p22), a13, a23, hh3, ea3, eb3)
+#undef LCD_CELL
+            // ---- stores: ring slot (values), HBM (codes; values only for rows a far successor / the end node will read) ----
+            const int4 H4 = make_int4(hh0, hh1, hh2, hh3), A4 = make_int4(ea0, ea1, ea2, ea3), B4 = make_int4(eb0, eb1, eb2, eb3);
+            if (jb < WIN) {
+                const unsigned S = ring + 4u * (unsigned)(s * SLOTW);
+                lds_st4(S + lofs, H4); lds_st4(S + PL + lofs, A4); lds_st4(S + 2 * PL + lofs, B4);
+                if (spf) { int *G = g.spill + (size_t)nsp * SLOTW; glb_st4(G + jb, H4); glb_st4(G + WIN + jb, A4); glb_st4(G + 2 * WIN + jb, B4); }
+                if (jb < cw4) {
+                    glb_st(g.code8 + cused + jb, (int)code);
+                    if (np > 1) glb_st4(g.ord + oused + jb, make_int4((om & 255) | ((oa & 255) << 8) | ((ob & 255) << 16),
+                                                                         ((om >> 8) & 255) | (((oa >> 8) & 255) << 8) | (((ob >> 8) & 255) << 16),
+                                                                         ((om >> 16) & 255) | (((oa >> 16) & 255) << 8) | (((ob >> 16) & 255) << 16),
+                                                                         ((om >> 24) & 255) | (((oa >> 24) & 255) << 8) | (((ob >> 24) & 255) << 16)));
+                }
+            }
+            if (tid == 0) {
+                glb_st(g.rbeg + idx, 0); glb_st(g.rend + idx, qlen); glb_st(g.roff + idx, (int)cused); glb_st(g.ooff + idx, (int)oused);
+                if (spf) { glb_st(g.ml + idx, 0); glb_st(g.mr + idx, 0); glb_st(g.spoff + idx, nsp); }
+            }
+            if (SYS) {
+                if (lane == 63) {
+                    sm.bndH[idx & (SYS_D - 1)][wave] = hh3;
+                    sm.carry1[idx & (SYS_D - 1)][wave] = imax(cin1, t1); sm.carry2[idx & (SYS_D - 1)][wave] = imax(cin2, t2);
+                }
+                // the row is complete in LDS (and, for a spilled row, in HBM) before the neighbours may look at it
+                if (spf) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 63) *(volatile lcd_lds_i32 *)(uintptr_t)lds_off(&sm.prog[wave]) = idx; // (LDS-typed: a generic volatile store is a flat store + vmcnt(0))
+            }
+            cused += cw4; if (np > 1) oused += cw4; if (spf) ++nsp;
+            ncell += (unsigned long long)qlen + 1;
+        }
+    }
+    if (tid == 0 && err != LCD_OK) sm.bc[7] = err;
+    __syncthreads();
+    if (sm.bc[7] != LCD_OK) { wo->status = sm.bc[7]; __syncthreads(); return 0; }
+    wo->cells = ncell;
+    const long long t_bt0 = clock64();
+    wo->t_dp = (unsigned long long)(t_bt0 - t_dp0);
+    if (wave == 0) code_backtrack(g, sm, pd, bi, ei, qlen, SLOTW, WM, lane);
+    __syncthreads();
+    const int n_cig = sm.bc[0];
+    wo->status = sm.bc[1];
+    wo->cig_pos = sm.bc[4];
+    __syncthreads();
+    wo->t_bt = (unsigned long long)(clock64() - t_bt0);
     return n_cig;
 }
 
@@ -922,11 +1210,17 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
     uint8_t *pd = (QB + (ei - bi) + 16 <= g.seq_cap) ? sseq + QB : nullptr;
     build_plan<NT>(g, sm, bi, ei, remain_end, pd, K);
     if (!(sc.dbg & 8) && WMAX <= NT * 4 && (WMAX & (WMAX - 1)) == 0) {
-        int cpos = 0;
+        WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0;
         const int rem_beg = g.remain[beg_node] - remain_end;
-        const int nc = wb < 0 ? align_windowed<NT, false>(g, sm, ring, sseq, pd, sc, w, bi, ei, rem_beg, seq_hbm, qlen, cells_acc, &cpos)
-                              : align_windowed<NT, true>(g, sm, ring, sseq, pd, sc, w, bi, ei, rem_beg, seq_hbm, qlen, cells_acc, &cpos);
-        if (nc >= 0) { g.cig_node = g.cig_node0 + cpos; g.cig_qpos = g.cig_qpos0 + cpos; return nc; }
+        const unsigned pdo = pd ? lds_off(pd) : 0xffffffffu;
+        int nc = wb < 0 ? align_unbanded<NT>(g, lds_off(ring), pdo, sc, bi, ei, seq_hbm, qlen, &wo)
+                        : align_windowed<NT, true>(g, lds_off(ring), lds_off(sseq), pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+        if (nc < 0 && wb < 0) { __syncthreads(); nc = align_windowed<NT, false>(g, lds_off(ring), lds_off(sseq), pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+        if (nc >= 0) {
+            g.status = wo.status; g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells;
+            g.cig_node = g.cig_node0 + wo.cig_pos; g.cig_qpos = g.cig_qpos0 + wo.cig_pos;
+            return nc;
+        }
         __syncthreads();
     }
     for (int i = tid; i < qlen; i += NT) sseq[i] = seq_hbm[i];
@@ -1258,7 +1552,7 @@ __global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chain
                                                            int n_chains) {
     const int cid = blockIdx.x;
     if (cid >= n_chains) return;
-    __shared__ Smem sm;
+    Smem &sm = g_smem;
     extern __shared__ int lds_pool[]; // [row ring | query cache], re-used by the re-sort; sized per launch (PoaChain.lds_words)
     int *ring = lds_pool;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
