@@ -1547,7 +1547,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
 } // namespace
 
 template <int NT>
-__global__ void __launch_bounds__(NT) lcd_poa_chain_kernel(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool,
+__global__ void __launch_bounds__(NT, (NT == 256 ? 2 : 4)) lcd_poa_chain_kernel(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool,
                                                            uint8_t *arena, uint8_t *outpool, PoaChainOut *outs, LcdScoring sc,
                                                            int n_chains) {
     const int cid = blockIdx.x;

@@ -148,3 +148,66 @@ def test_poa_invariants_large(lcd):
     crow = g["msa"][len(reads)]
     assert (crow[crow != 5] == g["cons"][0]).all()
     assert abs(len(g["cons"][0]) - 6000) < 60
+
+
+def _sv_haps(rng, L):
+    """two haplotypes that differ by SNPs, a 40-base deletion and a 30-base insertion: the graph gets long bubbles, i.e. rows whose
+    predecessor is far back in topological order (the kernel's spilled rows)"""
+    h1 = rng.integers(0, 4, L).astype(np.uint8)
+    h2 = h1.copy()
+    for p in range(15, L - 15, max(25, L // 8)):
+        h2[p] = (h2[p] + 1) % 4
+    a, b = L // 3, 2 * L // 3
+    h2 = np.concatenate([h2[:a], h2[a + 40:b], rng.integers(0, 4, 30).astype(np.uint8), h2[b:]])
+    return h1, h2
+
+
+def _check_k2(got, exp):
+    assert got["status"] == 0 and got["n_cons"] == exp["n_cons"] and got["msa_len"] == exp["msa_len"]
+    for c in range(got["n_cons"]):
+        assert len(got["cons"][c]) == len(exp["cons"][c]) and (got["cons"][c] == exp["cons"][c]).all()
+        assert (got["clu"][c] == exp["clu"][c]).all()
+    for a, b in zip(got["msa"], exp["msa"]):
+        assert (a == b).all()
+
+
+@pytest.mark.parametrize("L", [230, 900, 2600])
+def test_poa_k2_bubbles_all_workgroup_classes(lcd, oracle, L):
+    """K2 on het-SV regions in the 64-, 256- and 1024-thread classes (the last two run the systolic rows): == oracle"""
+    rng = np.random.default_rng(400 + L)
+    h1, h2 = _sv_haps(rng, L)
+    reads = [mutate(rng, h1 if i % 2 == 0 else h2, 0.002) for i in range(10)]
+    got = lcd.poa_batch([dict(mode=1, reads=reads)])[0]
+    _check_k2(got, oracle.poa_aln_msa_cons(reads, 2))
+
+
+def test_poa_reads_with_n(lcd, oracle):
+    """N bases (code 4, score 0 against everything, src/align.c:316) in reads: K2 leaves the systolic rows for the windowed ones"""
+    rng = np.random.default_rng(500)
+    h1, h2 = _sv_haps(rng, 400)
+    reads = [mutate(rng, h1 if i % 2 == 0 else h2, 0.01) for i in range(9)]
+    for r in reads[::3]:
+        r[rng.integers(5, len(r) - 5, 3)] = 4
+    got = lcd.poa_batch([dict(mode=1, reads=reads), dict(mode=0, reads=reads)])
+    _check_k2(got[0], oracle.poa_aln_msa_cons(reads, 2))
+    exp = oracle.poa_partial_aln_msa_cons(reads, [12] * len(reads))
+    assert got[1]["status"] == 0 and got[1]["msa_len"] == exp["msa_len"] and (got[1]["cons"][0] == exp["cons"][0]).all()
+
+
+def test_poa_generic_rows_agree_with_windowed(lcd, monkeypatch):
+    """the fallback for rows wider than the window (values in HBM, value backtrack; LCD_DBG=8 forces it) gives the same chains"""
+    rng = np.random.default_rng(600)
+    jobs = []
+    for L, rate, mode in [(150, 0.01, 0), (600, 0.05, 0), (300, 0.02, 1), (1200, 0.002, 1)]:
+        h1, h2 = _sv_haps(rng, L)
+        jobs.append(dict(mode=mode, reads=[mutate(rng, h1 if i % 2 == 0 else h2, rate) for i in range(8)]))
+    a = lcd.poa_batch(jobs)
+    monkeypatch.setenv("LCD_DBG", "8")
+    b = lcd.poa_batch(jobs)
+    monkeypatch.delenv("LCD_DBG")
+    for x, y in zip(a, b):
+        assert x["status"] == 0 and y["status"] == 0 and x["n_cons"] == y["n_cons"] and x["msa_len"] == y["msa_len"]
+        for r, q in zip(x["msa"], y["msa"]):
+            assert (r == q).all()
+        for c in range(x["n_cons"]):
+            assert (x["cons"][c] == y["cons"][c]).all() and (x["clu"][c] == y["clu"][c]).all()
