@@ -125,8 +125,17 @@ def main():
         alg_bytes = float(st["poa_alg_bytes"])
         mean_launch_s = poa_kernel_ms / max(poa_launches, 1) * 1e-3
         achieved = alg_bytes / mean_launch_s / 1e9 if mean_launch_s > 0 else 0.0
+        # HBM bytes of the same launch from the PMC counters: they need rocprofv3 (separate --pmc passes, tools/profile_round.sh), so the
+        # figure is the committed measurement of this exact workload (profiles/<tag>_traffic.json), or null for any other workload
+        traffic, traffic_src = None, None
+        if args.ref_mb == 10 and shape["name"] == "hifi" and world == 1:
+            import glob
+            cand = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")))
+            if cand:
+                tj = json.load(open(cand[-1]))
+                traffic, traffic_src = float(tj["hbm_bytes_per_step"]), tj["source"]
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                    "traffic": None, "kernel": "lcd_poa_chain_kernel", "ms_per_launch": round(mean_launch_s * 1e3, 4),
+                    "traffic": traffic, "traffic_source": traffic_src, "kernel": "lcd_poa_chain_kernel", "ms_per_launch": round(mean_launch_s * 1e3, 4),
                     "alg_bytes_per_launch": alg_bytes, "cells_per_launch": int(st["poa_cells"]),
                     "gcups": round(st["poa_cells"] / mean_launch_s / 1e9, 3) if mean_launch_s > 0 else 0.0}
         cpu = None

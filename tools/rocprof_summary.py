@@ -1,12 +1,17 @@
 #!/usr/bin/env python
-"""Turn a rocprofv3 results .db (rocpd sqlite) into the per-kernel summary text committed under profiles/."""
+"""Turn the rocprofv3 results of tools/profile_round.sh (rocpd sqlite .db files) into the summaries committed under profiles/.
+
+usage: python tools/rocprof_summary.py <tag> "<title>"
+  reads  gpurun_out/prof_<tag>/kt_results.db, gpurun_out/pmc_fetch_<tag>/f_results.db, gpurun_out/pmc_write_<tag>/w_results.db
+  writes profiles/<tag>_bench_kernel_stats.txt, profiles/<tag>_pmc_hbm_traffic.txt, profiles/<tag>_traffic.json
+"""
+import json
 import sqlite3
 import sys
 
 
-def main(db_path, out_path, title):
-    db = sqlite3.connect(db_path)
-    cur = db.cursor()
+def kernel_stats(db_path, out_path, title):
+    cur = sqlite3.connect(db_path).cursor()
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
     with open(out_path, "w") as f:
         f.write(f"# {title}\n# source: rocprofv3 --kernel-trace --stats (durations in us)\n")
@@ -18,17 +23,12 @@ def main(db_path, out_path, title):
                 f.write(f"# {r[0].split('(')[0]}: grid={r[1]} wg={r[2]} lds={r[3]} vgpr={r[4]} sgpr={r[5]} scratch={r[6]}\n")
         except Exception as e:  # noqa
             f.write(f"# (no dispatch detail: {e})\n")
-    print(open(out_path).read())
-
-
-if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "rocprofv3 kernel stats")
+    return rows
 
 
 def pmc_summary(db_path, counter):
     """sum of a PMC counter (rocprofv3 --pmc X) per kernel over all its dispatches"""
-    db = sqlite3.connect(db_path)
-    cur = db.cursor()
+    cur = sqlite3.connect(db_path).cursor()
     out = {}
     for name, val in cur.execute("select name, counter_value from pmc_events where counter_name = ?", (counter,)):
         k = name.split("(")[0]
@@ -36,3 +36,31 @@ def pmc_summary(db_path, counter):
         out[k][0] += 1
         out[k][1] += val
     return out
+
+
+def main(tag, title):
+    kernel_stats(f"gpurun_out/prof_{tag}/kt_results.db", f"profiles/{tag}_bench_kernel_stats.txt", title)
+    f = pmc_summary(f"gpurun_out/pmc_fetch_{tag}/f_results.db", "FETCH_SIZE")
+    w = pmc_summary(f"gpurun_out/pmc_write_{tag}/w_results.db", "WRITE_SIZE")
+    poa = 0.0
+    with open(f"profiles/{tag}_pmc_hbm_traffic.txt", "w") as o:
+        o.write(f"# {title}\n# HBM traffic from PMC counters over ONE bench step (python bench.py --steps 1 --warmup 0 --lanes 1), separate passes:\n")
+        o.write("#   rocprofv3 --pmc FETCH_SIZE ...   and   rocprofv3 --pmc WRITE_SIZE ...   (KB per dispatch, summed per kernel)\n")
+        o.write("# gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half of a wide coalesced read -> x2; WRITE_SIZE as reported\n")
+        o.write(f"{'kernel':30s} {'dispatches':>10s} {'FETCH_KB':>14s} {'WRITE_KB':>14s} {'bytes=(2*F+W)*1024':>22s}\n")
+        for k in sorted(set(f) | set(w)):
+            fk = f.get(k, [0, 0.0]); wk = w.get(k, [0, 0.0])
+            b = (2 * fk[1] + wk[1]) * 1024
+            if "lcd_poa_chain_kernel" in k:
+                poa += b
+            o.write(f"{k[:30]:30s} {fk[0]:10d} {fk[1]:14.1f} {wk[1]:14.1f} {b:22.0f}\n")
+        o.write(f"# lcd_poa_chain_kernel (all workgroup classes of one step): {poa:.0f} bytes\n")
+    json.dump({"tag": tag, "kernel": "lcd_poa_chain_kernel", "hbm_bytes_per_step": poa,
+               "source": f"profiles/{tag}_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)"},
+              open(f"profiles/{tag}_traffic.json", "w"), indent=1)
+    print(open(f"profiles/{tag}_bench_kernel_stats.txt").read())
+    print(open(f"profiles/{tag}_pmc_hbm_traffic.txt").read())
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "rocprofv3 summary")
