@@ -154,7 +154,7 @@ struct lcd_batch_s {
     std::vector<int> rc_region, rc_clu;
     std::vector<StrJob> str_jobs; std::vector<StrOut> str_outs;
     std::vector<int> str_region, str_clu, str_k;
-    std::vector<uint8_t> h_final; std::vector<uint8_t> h_poa_out;
+    std::vector<uint8_t> h_final; std::vector<uint8_t> h_poa_out; std::vector<uint8_t> h_cig;
     uint64_t final_bytes = 0;
     lcd_batch_stats_t st;
 };
@@ -612,11 +612,18 @@ int lcd_batch_run(lcd_batch_t *b) {
         HIPCHK(hipStreamSynchronize(st));
         // cigars of the anchor jobs
         std::vector<std::vector<uint32_t>> cig(wj.size());
-        for (size_t i = 0; i < wj.size(); ++i) {
-            cig[i].resize(wo[i].n_cigar);
-            if (wo[i].n_cigar) HIPCHK(hipMemcpyAsync(cig[i].data(), (void *)(uintptr_t)wj[i].out_off, wo[i].n_cigar * 4, hipMemcpyDeviceToHost, st));
+        { // ONE device->host copy of the output span of all anchor jobs (a copy per job costs more in launch overhead than in bytes)
+            uint64_t lo = ~0ull, hi = 0;
+            for (size_t i = 0; i < wj.size(); ++i)
+                if (wo[i].n_cigar) { lo = std::min<uint64_t>(lo, wj[i].out_off); hi = std::max<uint64_t>(hi, wj[i].out_off + (uint64_t)wo[i].n_cigar * 4); }
+            if (hi > lo) {
+                b->h_cig.resize(hi - lo);
+                HIPCHK(hipMemcpyAsync(b->h_cig.data(), (void *)(uintptr_t)lo, hi - lo, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                for (size_t i = 0; i < wj.size(); ++i)
+                    if (wo[i].n_cigar) { const uint32_t *src = (const uint32_t *)(b->h_cig.data() + (wj[i].out_off - lo)); cig[i].assign(src, src + wo[i].n_cigar); }
+            }
         }
-        HIPCHK(hipStreamSynchronize(st));
         for (auto &e : eo) { if (e.status != LCD_OK) return set_err(-20, "edlib kernel status " + std::to_string(e.status)); S.edlib_blocks += e.blocks; }
         for (auto &w : wo) S.wfa_offsets += w.offsets;
         S.n_edlib_jobs = (int)ej.size(); S.n_wfa_jobs += (int)wj.size();
@@ -722,39 +729,19 @@ int lcd_batch_run(lcd_batch_t *b) {
             const int *dummy = nullptr; (void)dummy;
             const int nk = R.branch == 1 ? pc.n_reads : co.clu_n[cc];
             for (int k = 0; k < nk; ++k) {
-                StrJob sj; sj.cons_off = cons_row; sj.msa_len = co.msa_len; sj.out_off = str_tot; str_tot += lcd_align_up((uint64_t)2 * co.msa_len + 16, 16);
+                StrJob sj; sj.member_addr = 0; sj.row0 = 0; sj.row_stride = 0; sj.cons_off = cons_row; sj.msa_len = co.msa_len; sj.out_off = str_tot; str_tot += lcd_align_up((uint64_t)2 * co.msa_len + 16, 16);
                 if (R.branch == 1) { sj.read_off = msa0 + (uint64_t)k * pc.node_cap; sj.full_cover = R.reads[b->chains[ch].members[k]].cover; }
-                else { sj.read_off = 0; sj.full_cover = R.reads[c].cover; /* fully_covers[cluster] quirk, src/align.c:1194 */ }
+                else { // K2: row of the k-th member of cluster cc, resolved on the device from the chain's cluster list
+                    const uint64_t clu_addr = pc.out_off + lcd_align_up((uint64_t)(pc.n_reads + 4) * pc.node_cap, 16);
+                    sj.read_off = 0; sj.member_addr = clu_addr + ((uint64_t)cc * pc.n_reads + k) * 4; sj.row0 = msa0; sj.row_stride = pc.node_cap;
+                    sj.full_cover = R.reads[c].cover; /* fully_covers[cluster] quirk, src/align.c:1194 */
+                }
                 b->str_jobs.push_back(sj); b->str_region.push_back((int)ri); b->str_clu.push_back(c); b->str_k.push_back(k);
             }
         }
     }
-    // K2 member rows need the cluster id lists (device -> host, small)
-    {
-        std::vector<std::vector<int>> clu_cache(nC);
-        for (size_t j = 0; j < b->str_jobs.size(); ++j) {
-            const RegionRec &R = b->regs[b->str_region[j]];
-            if (R.branch != 2) continue;
-            const int ch = R.chain[0]; const PoaChain &pc = b->pchains[ch];
-            if (clu_cache[ch].empty()) {
-                clu_cache[ch].resize(2 * (size_t)pc.n_reads);
-                const uint64_t clu_addr = pc.out_off + lcd_align_up((uint64_t)(pc.n_reads + 4) * pc.node_cap, 16);
-                HIPCHK(hipMemcpyAsync(clu_cache[ch].data(), (void *)(uintptr_t)clu_addr, 2 * (size_t)pc.n_reads * 4, hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
-            }
-            const int member = clu_cache[ch][(size_t)b->str_clu[j] * pc.n_reads + b->str_k[j]];
-            b->str_jobs[j].read_off = pc.out_off + 2ull * pc.node_cap + (uint64_t)member * pc.node_cap;
-        }
-        b->h_poa_out.clear();
-        // stash cluster lists for result assembly
-        b->h_poa_out.resize(0);
-        for (int ch = 0; ch < nC; ++ch) if (!clu_cache[ch].empty()) {
-            // store as bytes: [ch:int][n:int][ids...]
-            int hdr[2] = {ch, (int)clu_cache[ch].size()};
-            const uint8_t *p = (const uint8_t *)hdr; b->h_poa_out.insert(b->h_poa_out.end(), p, p + 8);
-            p = (const uint8_t *)clu_cache[ch].data(); b->h_poa_out.insert(b->h_poa_out.end(), p, p + clu_cache[ch].size() * 4);
-        }
-    }
+    // (K2 member rows: the strings kernel looks the member read up in the chain's cluster list itself, see StrJob.member_addr;
+    //  the host copy of the lists is fetched by lcd_batch_download)
     HIPCHK(hipEventRecord(b->ev[3], st));
     int wret = 0;
     int rc = run_wfa_stage(st, b->rc_jobs, b->d_wfa_jobs, b->d_wfa_arena, b->d_wfa_out, b->d_wfa_outs, b->rc_outs, sc, &wret);
@@ -818,6 +805,26 @@ int lcd_batch_download(lcd_batch_t *b) {
     for (size_t i = 0; i < b->rc_jobs.size(); ++i)
         HIPCHK(hipMemcpyAsync(b->h_final.data() + rc_off[i], (void *)(uintptr_t)b->rc_jobs[i].out_off, 2ull * (b->rc_jobs[i].plen + b->rc_jobs[i].tlen + 1), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    // cluster id lists of the K2 chains, for lcd_batch_region_result: stored as [ch:int][n:int][ids...]
+    {
+        const int nC = (int)b->pchains.size();
+        std::vector<std::vector<int>> clu_cache(nC);
+        for (const RegionRec &R : b->regs) {
+            if (R.branch != 2) continue;
+            const int ch = R.chain[0]; const PoaChain &pc = b->pchains[ch];
+            if (!clu_cache[ch].empty()) continue;
+            clu_cache[ch].resize(2 * (size_t)pc.n_reads);
+            const uint64_t clu_addr = pc.out_off + lcd_align_up((uint64_t)(pc.n_reads + 4) * pc.node_cap, 16);
+            HIPCHK(hipMemcpyAsync(clu_cache[ch].data(), (void *)(uintptr_t)clu_addr, 2 * (size_t)pc.n_reads * 4, hipMemcpyDeviceToHost, st));
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        b->h_poa_out.clear();
+        for (int ch = 0; ch < nC; ++ch) if (!clu_cache[ch].empty()) {
+            int hdr[2] = {ch, (int)clu_cache[ch].size()};
+            const uint8_t *p = (const uint8_t *)hdr; b->h_poa_out.insert(b->h_poa_out.end(), p, p + 8);
+            p = (const uint8_t *)clu_cache[ch].data(); b->h_poa_out.insert(b->h_poa_out.end(), p, p + clu_cache[ch].size() * 4);
+        }
+    }
     // remember where the ref<->cons rows are
     for (size_t i = 0; i < b->rc_jobs.size(); ++i) b->rc_jobs[i].ws_off = rc_off[i];
     b->downloaded = true;

@@ -153,6 +153,9 @@ struct StrJob {
     uint64_t cons_off, read_off; // MSA rows in the device pool
     int msa_len, full_cover;
     uint64_t out_off;            // target row at out_off, query row at out_off + msa_len (src/align.c:1032-1033)
+    uint64_t member_addr;        // != 0: the read row is row0 + (*(int *)member_addr) * row_stride (K2: k-th member of a cluster)
+    uint64_t row0;
+    int row_stride;
 };
 struct StrOut {
     int aln_len, target_beg, target_end, query_beg, query_end;

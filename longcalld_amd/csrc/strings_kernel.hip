@@ -15,7 +15,8 @@ __global__ void __launch_bounds__(64) lcd_strings_kernel(const StrJob *jobs, uin
     if (jid >= n_jobs) return;
     const int lane = threadIdx.x;
     const StrJob jb = jobs[jid];
-    const uint8_t *cons = pool + jb.cons_off, *read = pool + jb.read_off;
+    const uint8_t *cons = pool + jb.cons_off;
+    const uint8_t *read = pool + (jb.member_addr ? jb.row0 + (uint64_t)(*(const int *)(pool + jb.member_addr)) * (uint64_t)jb.row_stride : jb.read_off);
     uint8_t *t = pool + jb.out_off, *q = t + jb.msa_len;
     int aln = 0;
     for (int c0 = 0; c0 < jb.msa_len; c0 += 64) {
