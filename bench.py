@@ -14,9 +14,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# every submission lane owns two HIP streams; give the runtime enough hardware queues that lanes do not serialise behind
-# each other's long-tailed chain kernels (the ROCm default maps all streams onto 4 queues)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# The library spreads one submission's launch groups over 4 streams (LCD_STREAMS).  Keep the number of hardware queues equal to that:
+# with more queues holding runnable kernels the queue scheduler time-slices them (measured: the same chains run 2.6x slower next to
+# 8 other active queues); concurrency comes from coalescing batches into one submission (--coalesce), not from more queues.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 
@@ -24,16 +25,19 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured co
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ref-mb", type=float, default=10.0, help="synthetic reference size per GPU (10 Mb = configs[1])")
     ap.add_argument("--shape", default="hifi", choices=["hifi", "ont"])
     ap.add_argument("--cpu-sample", type=int, default=300, help="regions timed on the CPU oracle for cpu_baseline (rank 0, N=1 only)")
     ap.add_argument("--seed", type=int, default=20250928)
-    ap.add_argument("--lanes", type=int, default=4,
+    ap.add_argument("--lanes", type=int, default=1,
                     help="concurrent submission lanes per GPU (host threads, one lcd_batch_t + HIP stream each) -- the reference's own "
                          "execution model: kt_for runs n_threads chunk workers concurrently (src/call_var_main.c:773); the K steps are "
                          "dealt round-robin to the lanes and ALL of them complete inside the timed region")
+    ap.add_argument("--coalesce", type=int, default=16,
+                    help="steps (batches) submitted together through lcd_batch_run_many: one set of launches per stage over the chains of "
+                         "all of them, so that the GPU's workgroup dispatcher -- not HIP streams -- packs several chunks' chains onto the CUs")
     args = ap.parse_args()
 
     import torch
@@ -57,17 +61,24 @@ def main():
     n_regions = jobs.regions_for_ref_mb(args.ref_mb)
     regs = jobs.make_regions(args.seed + 1000 * rank, n_regions, shape)   # weak scaling: same work per GPU, different seed
     import threading
-    n_lanes = max(1, min(args.lanes, args.steps))
-    batches = []
+    # a step = one batch (the configs[1] workload).  `coalesce` steps are submitted together through lcd_batch_run_many (one set of
+    # launches per stage over all their chains), `lanes` host threads keep that many such submissions in flight.
+    n_co = max(1, min(args.coalesce, args.steps))
+    n_lanes = max(1, min(args.lanes, (args.steps + n_co - 1) // n_co))
+    groups = []
     t_up = 0.0
     for _ in range(n_lanes):
-        bt = align.RegionBatch()
-        for r in regs:
-            bt.add_region(r)
-        t_up0 = time.perf_counter()
-        bt.upload()
-        t_up = time.perf_counter() - t_up0
-        batches.append(bt)
+        grp = []
+        for _ in range(n_co):
+            bt = align.RegionBatch()
+            for r in regs:
+                bt.add_region(r)
+            t_up0 = time.perf_counter()
+            bt.upload()
+            t_up = time.perf_counter() - t_up0
+            grp.append(bt)
+        groups.append(grp)
+    batches = [bt for grp in groups for bt in grp]
     batch = batches[0]
 
     def barrier():
@@ -75,27 +86,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    acc = {"ms": 0.0, "launches": 0, "st": None}
+    acc = {"ms": 0.0, "launches": 0, "st": None, "alg": 0.0, "cells": 0.0}
     lock = threading.Lock()
 
-    def lane_work(bt, n_steps, record):
-        for _ in range(n_steps):
-            bt.run()
+    def lane_work(grp, sizes, record):
+        for k in sizes:
+            align.RegionBatch.run_many(grp[:k])
             if record:
-                s_ = bt.stats()
+                sts = [bt.stats() for bt in grp[:k]]
                 with lock:
-                    acc["ms"] += s_["ms_poa_kernel"]; acc["launches"] += s_["n_poa_launches"]; acc["st"] = s_
+                    acc["ms"] += sts[0]["ms_poa_kernel"]; acc["launches"] += sts[0]["n_poa_launches"]; acc["st"] = sts[0]
+                    acc["alg"] += sum(float(x["poa_alg_bytes"]) for x in sts); acc["cells"] += sum(float(x["poa_cells"]) for x in sts)
 
     def run_steps(n_steps, record):
-        # deal the steps round-robin to the lanes; every lane runs its share back to back, lanes overlap on the GPU
-        share = [n_steps // n_lanes + (1 if i < n_steps % n_lanes else 0) for i in range(n_lanes)]
-        ths = [threading.Thread(target=lane_work, args=(batches[i], share[i], record)) for i in range(n_lanes) if share[i]]
+        # cut the steps into submissions of `coalesce` and deal those round-robin to the lanes; lanes overlap on the GPU
+        subs = [n_co] * (n_steps // n_co) + ([n_steps % n_co] if n_steps % n_co else [])
+        share = [subs[i::n_lanes] for i in range(n_lanes)]
+        ths = [threading.Thread(target=lane_work, args=(groups[i], share[i], record)) for i in range(n_lanes) if share[i]]
         for t in ths:
             t.start()
         for t in ths:
             t.join()
 
-    run_steps(max(args.warmup, n_lanes if args.warmup else 0), False)   # every lane warms its buffers at least once
+    run_steps(max(args.warmup, n_lanes * n_co if args.warmup else 0), False)   # every lane warms its buffers at least once
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps, True)
@@ -122,7 +135,7 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         value = tot_regions * args.steps / elapsed
         # roofline of the dominant kernel (POA chains): algorithmic bytes (SURVEY 8d B_poa) per launch / mean launch time
-        alg_bytes = float(st["poa_alg_bytes"])
+        alg_bytes = acc["alg"] / max(poa_launches, 1)     # per launch set: the chains of `coalesce` batches
         mean_launch_s = poa_kernel_ms / max(poa_launches, 1) * 1e-3
         achieved = alg_bytes / mean_launch_s / 1e9 if mean_launch_s > 0 else 0.0
         # HBM bytes of the same launch from the PMC counters: they need rocprofv3 (separate --pmc passes, tools/profile_round.sh), so the
@@ -133,11 +146,11 @@ def main():
             cand = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")))
             if cand:
                 tj = json.load(open(cand[-1]))
-                traffic, traffic_src = float(tj["hbm_bytes_per_step"]), tj["source"]
+                traffic, traffic_src = float(tj["hbm_bytes_per_step"]) * n_co, tj["source"] + f" x {n_co} coalesced steps"
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                     "traffic": traffic, "traffic_source": traffic_src, "kernel": "lcd_poa_chain_kernel", "ms_per_launch": round(mean_launch_s * 1e3, 4),
-                    "alg_bytes_per_launch": alg_bytes, "cells_per_launch": int(st["poa_cells"]),
-                    "gcups": round(st["poa_cells"] / mean_launch_s / 1e9, 3) if mean_launch_s > 0 else 0.0}
+                    "alg_bytes_per_launch": alg_bytes, "cells_per_launch": int(acc["cells"] / max(poa_launches, 1)),
+                    "gcups": round(acc["cells"] / max(poa_launches, 1) / mean_launch_s / 1e9, 3) if mean_launch_s > 0 else 0.0}
         cpu = None
         if world == 1 and args.cpu_sample > 0:
             from oracle import pyoracle
@@ -156,7 +169,7 @@ def main():
             "config": {"workload": f"configs[1]: synthetic 30x {shape['name']} region jobs over {args.ref_mb:g} Mb reference per GPU "
                                    f"({n_regions} regions/GPU, ~{tot_bases / max(world, 1) / 1e6:.1f} Mbase POA-aligned/GPU)",
                        "regions_per_gpu": n_regions, "sharding": "regions sharded across ranks, no data-path collective",
-                       "lanes_per_gpu": n_lanes},
+                       "lanes_per_gpu": n_lanes, "coalesced_steps_per_submission": n_co},
             "poa_aligned_bases_per_sec": round(tot_bases * args.steps / elapsed, 1),
             "regions_resolved": int(st["n_regions_resolved"]),
             "stage_ms": {k: round(st[k], 3) for k in ("ms_anchor", "ms_poa", "ms_wfa", "ms_strings", "ms_total", "ms_host", "ms_poa_kernel")},

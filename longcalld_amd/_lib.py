@@ -56,7 +56,7 @@ _lib = None
 EXPORTS = [
     "lcd_opt_default", "lcd_init", "lcd_last_error", "lcd_version", "lcd_wfa_end2end_aln", "lcd_edlib_end2end_aln",
     "lcd_edlib_xgaps", "lcd_edlib_edit_distance", "lcd_collect_noisy_reg_aln_strs", "lcd_batch_create", "lcd_batch_destroy",
-    "lcd_batch_clear", "lcd_batch_add_region", "lcd_batch_add_region_from_chunk", "lcd_batch_upload", "lcd_batch_run",
+    "lcd_batch_clear", "lcd_batch_add_region", "lcd_batch_add_region_from_chunk", "lcd_batch_upload", "lcd_batch_run", "lcd_batch_run_many",
     "lcd_batch_download", "lcd_batch_region_result", "lcd_batch_region_sorted_ids", "lcd_batch_get_stats", "lcd_batch_digest",
     "lcd_edlib_batch", "lcd_wfa_batch", "lcd_poa_batch", "lcd_assign_hap_germline", "lcd_assign_hap_batch",
 ]
@@ -87,6 +87,7 @@ def load_library():
     lib.lcd_batch_add_region_from_chunk.argtypes = [C.c_void_p, C.POINTER(LcdReadView), C.c_int64, C.c_int64, C.c_int, i32p, u8p, C.c_int]
     for f in ("lcd_batch_upload", "lcd_batch_run", "lcd_batch_download"):
         getattr(lib, f).argtypes = [C.c_void_p]
+    lib.lcd_batch_run_many.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     lib.lcd_batch_region_result.argtypes = [C.c_void_p, C.c_int, i32p, C.POINTER(i32p), C.POINTER(C.POINTER(LcdAlnStr))]
     lib.lcd_batch_region_sorted_ids.argtypes = [C.c_void_p, C.c_int, i32p]
     lib.lcd_batch_get_stats.argtypes = [C.c_void_p, C.POINTER(LcdBatchStats)]

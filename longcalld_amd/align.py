@@ -198,6 +198,14 @@ class RegionBatch:
     def run(self):
         check(self.lib.lcd_batch_run(self.h), self.lib)
 
+    @staticmethod
+    def run_many(batches):
+        """lcd_batch_run_many: the hot path of several uploaded batches as ONE set of launches per stage (batches[0] leads)"""
+        if not batches:
+            return
+        arr = (C.c_void_p * len(batches))(*[b.h for b in batches])
+        check(batches[0].lib.lcd_batch_run_many(arr, len(batches)), batches[0].lib)
+
     def download(self):
         check(self.lib.lcd_batch_download(self.h), self.lib)
 

@@ -32,6 +32,7 @@ int set_err(int code, const std::string &m) { g_err = m; return code; }
 std::mutex g_init_mu;
 int g_device = -1;
 
+int g_n_cus = 256; // compute units of the device (MI355X: 256)
 int ensure_init() {
     std::lock_guard<std::mutex> lk(g_init_mu);
     if (g_device >= 0) { hipSetDevice(g_device); return 0; }
@@ -42,6 +43,8 @@ int ensure_init() {
     if (lr) dev = atoi(lr) % n;
     if (hipSetDevice(dev) != hipSuccess) return set_err(-1, "hipSetDevice failed");
     g_device = dev;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) g_n_cus = prop.multiProcessorCount;
     return 0;
 }
 
@@ -145,7 +148,7 @@ struct lcd_batch_s {
     std::vector<WfaJob> wfa_jobs;
     // device
     DevBuf d_in, d_chains, d_preads, d_poa_arena, d_poa_out, d_poa_outs, d_ed_jobs, d_ed_arena, d_ed_outs, d_wfa_jobs, d_wfa_arena,
-        d_wfa_out, d_wfa_outs, d_str_jobs, d_str_outs, d_final;
+        d_wfa_out, d_wfa_outs, d_str_jobs, d_str_outs, d_final, d_gate;
     bool uploaded = false, ran = false, downloaded = false;
     // results (host)
     std::vector<PoaChainOut> couts;
@@ -520,13 +523,17 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     pc.n_reads = n; pc.read0 = C.read0; pc.mode = C.mode;
     pc.node_cap = (int)std::min<long long>(sum + 2, 2000000000ll);
     pc.edge_cap = (int)std::min<long long>(sum + n + 2, 2000000000ll);
+    if (getenv("LCD_NODE_EST")) { // experiment: graph arrays sized from an estimate instead of the worst case
+        const long long est = (long long)(atof(getenv("LCD_NODE_EST")) * maxl) + 64;
+        pc.node_cap = (int)std::min<long long>(pc.node_cap, est); pc.edge_cap = (int)std::min<long long>(pc.edge_cap, est + est / 2);
+    }
     pc.rid_words = (n + 63) / 64; pc.max_len = maxl;
     int mw = (int)(n * opt.min_af); if (mw < 2) mw = 2;
     pc.min_w = (uint32_t)mw;
     // rows actually visited ~ graph size ~ a small multiple of the backbone; band ~ 2w+1 plus drift.  Overflow is detected
     // in-kernel (LCD_ERR_CELLS) and the chain is re-run with `scale` x more, up to the worst case.
     const long long rows_worst = pc.node_cap;
-    const long long rows_est = std::min<long long>(rows_worst, 2ll * maxl + 64);
+    const long long rows_est = std::min<long long>(rows_worst, (long long)(1.3 * maxl) + 64);
     long long band;
     if (C.mode == 0) band = std::min<long long>(maxl + 1, 2ll * (10 + maxl / 100) + 1 + 64);
     else band = maxl + 1;
@@ -545,9 +552,13 @@ static void chain_class(PoaChain &pc) {
     // DP row width: K2 rows span the whole read (+2 guard columns of the window); K1 rows are the adaptive band plus drift
     const long long width = pc.mode == 1 ? (long long)pc.max_len + 2 : 2ll * (10 + pc.max_len / 100) + 1 + 48;
     int threads, K, wmax; // wmax: window / ring-slot width in columns, a power of two <= 4 * threads (poa_kernel.hip align_windowed)
+    // one lane per four columns of the window: 64 / 128 / 256 / 512 / 1024 threads, so that no wavefront of a workgroup idles
+    // (a 2 048-column chain in a 1 024-thread workgroup would hold a whole CU's registers with half of its wavefronts parked)
     if (width <= 256) { threads = 64; K = 4; wmax = 256; }
-    else if (width <= 1024) { threads = 256; K = 2; wmax = width <= 512 ? 512 : 1024; }
-    else { threads = 1024; K = 2; wmax = width <= 2048 ? 2048 : 4096; } // wider rows take the generic (HBM) rows of the kernel
+    else if (width <= 512) { threads = 128; K = 2; wmax = 512; }
+    else if (width <= 1024) { threads = 256; K = 2; wmax = 1024; }
+    else if (width <= 2048) { threads = 512; K = 2; wmax = 2048; }
+    else { threads = 1024; K = 2; wmax = 4096; } // wider rows take the generic (HBM) rows of the kernel
     const long long est_nodes = (long long)(pc.max_len * 1.15) + 64;
     const long long seq_bytes = lcd_align_up((long long)pc.max_len + 28, 16) + lcd_align_up(est_nodes + 16, 16); // query cache + first-predecessor distances
     const long long dp_bytes = (long long)K * 3 * wmax * 4 + seq_bytes;
@@ -562,234 +573,339 @@ static long long chain_group_key(const PoaChain &pc) { return (long long)pc.thre
 // uploads `sub` (already ordered so that equal classes are contiguous) and launches one kernel per class
 // (different classes go to side streams so a long wide chain does not hold back the narrow ones)
 static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, DevBuf &d_chains, const PoaRead *d_reads, DevBuf &d_outs, LcdScoring sc,
-                              hipStream_t *side = nullptr, hipEvent_t *sev = nullptr) {
+                              hipStream_t *side = nullptr, hipEvent_t *sev = nullptr, DevBuf *d_gate = nullptr) {
     HIPCHK(hipMemcpyAsync(d_chains.p, sub.data(), sub.size() * sizeof(PoaChain), hipMemcpyHostToDevice, st));
+    // wide classes (>= 512 threads: half a CU's vector registers or all of them) start before the narrow ones are let in (lcd_gate_kernel):
+    // `target` = how many of their workgroups fit the chip at once, leaving a share of the CUs to the narrow classes
+    int n_wide = 0, target = 0; bool any_narrow = false;
+    {
+        double cus = 0; const double cap = 0.80 * g_n_cus;
+        for (const PoaChain &pc : sub) {
+            if (pc.threads >= 512) { ++n_wide; const double share = pc.threads >= 1024 ? 1.0 : 0.5; if (cus + share <= cap) { cus += share; ++target; } }
+            else any_narrow = true;
+        }
+    }
+    int *gate = nullptr;
+    if (side && d_gate && n_wide && any_narrow && target > 0) {
+        if (d_gate->ensure(64)) return -11;
+        gate = (int *)d_gate->p;
+        HIPCHK(hipMemsetAsync(gate, 0, 4, st));
+    }
     if (side) HIPCHK(hipEventRecord(sev[0], st));
-    size_t i = 0; int nside = 0;
-    while (i < sub.size()) {
-        const int cls = chain_threads(sub[i]);
+    // groups of equal (threads, LDS bucket) -> a small pool of streams (LCD_STREAMS, default 4 with the caller's): every stream is a
+    // hardware queue, and with many queues holding runnable kernels the queue scheduler time-slices them -- measured on MI355X: the
+    // same 48 wide chains take 1.09 s next to 8 other active queues and 0.42 s with 4 queues in total.  Groups are dealt to the
+    // streams longest-first by their DP work (LPT); a stream runs its groups back to back.
+    struct Grp { size_t i, j; double cost; };
+    std::vector<Grp> grps;
+    for (size_t i = 0; i < sub.size();) {
         const long long key = chain_group_key(sub[i]);
-        size_t j = i;
-        while (j < sub.size() && chain_group_key(sub[j]) == key) ++j;
-        // every (threads, LDS) group on its own stream so that a long-tailed group does not hold back the others.  Streams that
-        // share a hardware queue still serialise: callers that run several batches at once should raise GPU_MAX_HW_QUEUES
-        // (ROCm maps all streams onto 4 queues by default; bench.py sets 24).
-        hipStream_t s = st;
-        if (side && nside < LCD_NSIDE && j < sub.size()) { s = side[nside]; HIPCHK(hipStreamWaitEvent(s, sev[0], 0)); }
-        lcd_launch_poa((const PoaChain *)d_chains.p + i, d_reads, nullptr, nullptr, nullptr, (PoaChainOut *)d_outs.p + i, sc, (int)(j - i), cls, sub[i].lds_words * 4, s);
-        HIPCHK(hipGetLastError());
-        if (s != st) { HIPCHK(hipEventRecord(sev[1 + nside], s)); ++nside; }
+        size_t j = i; double cost = 0;
+        while (j < sub.size() && chain_group_key(sub[j]) == key) { cost += (double)sub[j].cell_cap * sub[j].n_reads; ++j; }
+        grps.push_back({i, j, cost});
         i = j;
     }
-    for (int k = 0; k < nside; ++k) HIPCHK(hipStreamWaitEvent(st, sev[1 + k], 0));
+    static const int n_streams = std::max(1, std::min(LCD_NSIDE + 1, getenv("LCD_STREAMS") ? atoi(getenv("LCD_STREAMS")) : 4));
+    const int ns = side ? n_streams : 1;
+    std::vector<size_t> order(grps.size());
+    for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t c) { return grps[a].cost > grps[c].cost; });
+    std::vector<double> load(ns, 0.0);
+    std::vector<bool> used(ns, false);
+    for (size_t k : order) {
+        int best = 0;
+        for (int t = 1; t < ns; ++t) if (load[t] < load[best]) best = t;
+        load[best] += grps[k].cost;
+        // stream 0 is the caller's; the others are side streams that first wait for the chain table to be uploaded
+        hipStream_t s = best == 0 ? st : side[best - 1];
+        if (best != 0 && !used[best]) HIPCHK(hipStreamWaitEvent(s, sev[0], 0));
+        used[best] = true;
+        const int cls = chain_threads(sub[grps[k].i]);
+        if (gate && cls < 512) lcd_launch_gate(gate, target, s);
+        lcd_launch_poa((const PoaChain *)d_chains.p + grps[k].i, d_reads, nullptr, nullptr, nullptr, (PoaChainOut *)d_outs.p + grps[k].i, sc, (int)(grps[k].j - grps[k].i), cls,
+                       sub[grps[k].i].lds_words * 4, s, cls >= 512 ? gate : nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    for (int t = 1; t < ns; ++t) if (used[t]) { HIPCHK(hipEventRecord(sev[t], side[t - 1])); HIPCHK(hipStreamWaitEvent(st, sev[t], 0)); }
     return 0;
 }
 
-int lcd_batch_run(lcd_batch_t *b) {
-    if (!b->uploaded) return set_err(-3, "lcd_batch_run before lcd_batch_upload");
+// Runs the hot path of n batches JOINTLY: every stage is one set of launches over the jobs / chains of all batches, so the GPU's
+// own workgroup dispatcher packs the chains of several batches onto the CUs (a chain is a sequential object that can use at most
+// one CU; one batch of configs[1] size cannot fill 256 CUs, and separate streams per batch serialise on shared hardware queues).
+// The leader (batches[0]) lends its stream and its job / arena buffers; inputs, chain outputs and final strings stay per batch.
+// Results of batch k must be downloaded before the same leader runs again (the ref<->cons rows live in the leader's WFA buffer).
+int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
+    if (nb <= 0) return 0;
+    for (int k = 0; k < nb; ++k) {
+        if (!bs[k]->uploaded) return set_err(-3, "lcd_batch_run before lcd_batch_upload");
+        if (memcmp(&bs[k]->opt, &bs[0]->opt, sizeof(lcd_opt_t)) != 0) return set_err(-4, "lcd_batch_run_many: batches with different options");
+    }
     if (ensure_init()) return -1;
-    hipStream_t st = b->stream;
-    const LcdScoring sc = scoring_of(b->opt);
-    const uint64_t in_base = b->d_in.addr();
+    lcd_batch_t *L = bs[0];
+    hipStream_t st = L->stream;
+    const LcdScoring sc = scoring_of(L->opt);
     const double t_begin = now_ms();
-    lcd_batch_stats_t &S = b->st;
-    const double keep_up = S.ms_upload;
-    memset(&S, 0, sizeof(S)); S.ms_upload = keep_up;
-    S.n_chains = (int)b->chains.size(); S.n_anchor_jobs = (int)b->anchors.size();
-    HIPCHK(hipEventRecord(b->ev[0], st));
+    for (int k = 0; k < nb; ++k) {
+        lcd_batch_stats_t &S = bs[k]->st;
+        const double keep_up = S.ms_upload;
+        memset(&S, 0, sizeof(S)); S.ms_upload = keep_up;
+        S.n_chains = (int)bs[k]->chains.size(); S.n_anchor_jobs = (int)bs[k]->anchors.size();
+    }
+    HIPCHK(hipEventRecord(L->ev[0], st));
     // ---------------- S1: anchors (K4 prefilter + K3b) ----------------
-    std::vector<PoaRead> preads = b->preads;
-    for (auto &r : preads) r.seq_off += in_base;
-    if (!b->anchors.empty()) {
-        std::vector<EdJob> ej = b->ed_jobs; std::vector<WfaJob> wj = b->wfa_jobs;
-        for (auto &j : ej) { j.q_off += in_base; j.t_off += in_base; }
-        for (auto &j : wj) { j.p_off += in_base; j.t_off += in_base; }
-        std::vector<EdOut> eo; std::vector<WfaOut> wo;
-        int rc = run_edlib_stage(st, ej, b->d_ed_jobs, b->d_ed_arena, b->d_ed_outs, eo);
-        if (rc) return rc;
-        rc = run_wfa_stage(st, wj, b->d_wfa_jobs, b->d_wfa_arena, b->d_wfa_out, b->d_wfa_outs, wo, sc, nullptr);
-        if (rc) return rc;
-        HIPCHK(hipStreamSynchronize(st));
-        // cigars of the anchor jobs
-        std::vector<std::vector<uint32_t>> cig(wj.size());
-        { // ONE device->host copy of the output span of all anchor jobs (a copy per job costs more in launch overhead than in bytes)
+    std::vector<std::vector<PoaRead>> preads(nb);
+    {
+        std::vector<EdJob> ej; std::vector<WfaJob> wj;
+        std::vector<size_t> ej_base(nb + 1, 0), wj_base(nb + 1, 0);
+        for (int k = 0; k < nb; ++k) {
+            lcd_batch_t *b = bs[k];
+            const uint64_t in_base = b->d_in.addr();
+            preads[k] = b->preads;
+            for (auto &r : preads[k]) r.seq_off += in_base;
+            ej_base[k] = ej.size(); wj_base[k] = wj.size();
+            if (b->anchors.empty()) continue;
+            for (EdJob j : b->ed_jobs) { j.q_off += in_base; j.t_off += in_base; ej.push_back(j); }
+            for (WfaJob j : b->wfa_jobs) { j.p_off += in_base; j.t_off += in_base; wj.push_back(j); }
+        }
+        ej_base[nb] = ej.size(); wj_base[nb] = wj.size();
+        if (!ej.empty() || !wj.empty()) {
+            std::vector<EdOut> eo; std::vector<WfaOut> wo;
+            int rc = run_edlib_stage(st, ej, L->d_ed_jobs, L->d_ed_arena, L->d_ed_outs, eo);
+            if (rc) return rc;
+            rc = run_wfa_stage(st, wj, L->d_wfa_jobs, L->d_wfa_arena, L->d_wfa_out, L->d_wfa_outs, wo, sc, nullptr);
+            if (rc) return rc;
+            HIPCHK(hipStreamSynchronize(st));
+            // cigars of the anchor jobs: ONE device->host copy of the output span of all of them (a copy per job costs more in
+            // launch overhead than in bytes)
             uint64_t lo = ~0ull, hi = 0;
             for (size_t i = 0; i < wj.size(); ++i)
                 if (wo[i].n_cigar) { lo = std::min<uint64_t>(lo, wj[i].out_off); hi = std::max<uint64_t>(hi, wj[i].out_off + (uint64_t)wo[i].n_cigar * 4); }
             if (hi > lo) {
-                b->h_cig.resize(hi - lo);
-                HIPCHK(hipMemcpyAsync(b->h_cig.data(), (void *)(uintptr_t)lo, hi - lo, hipMemcpyDeviceToHost, st));
+                L->h_cig.resize(hi - lo);
+                HIPCHK(hipMemcpyAsync(L->h_cig.data(), (void *)(uintptr_t)lo, hi - lo, hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
-                for (size_t i = 0; i < wj.size(); ++i)
-                    if (wo[i].n_cigar) { const uint32_t *src = (const uint32_t *)(b->h_cig.data() + (wj[i].out_off - lo)); cig[i].assign(src, src + wo[i].n_cigar); }
             }
-        }
-        for (auto &e : eo) { if (e.status != LCD_OK) return set_err(-20, "edlib kernel status " + std::to_string(e.status)); S.edlib_blocks += e.blocks; }
-        for (auto &w : wo) S.wfa_offsets += w.offsets;
-        S.n_edlib_jobs = (int)ej.size(); S.n_wfa_jobs += (int)wj.size();
-        for (const AnchorRec &A : b->anchors) {
-            PoaRead &pr = preads[A.pread];
-            const int x = eo[A.ed_job].xgaps;
-            if (x > A.min_len * 0.10) { pr.skip = 1; continue; }
-            if (A.ext == 0) continue;
-            const std::vector<uint32_t> &c = cig[A.wfa_job];
-            if (c.empty()) { pr.skip = 1; continue; }
-            // collect_aln_beg_end, src/align.c:630-663
-            int rb = 1, qb = 1, re = A.tlen_full, qe = A.qlen_full;
-            if (A.ext == 1) {
-                int tr = 0, tq = 0;
-                for (uint32_t cg : c) { int op = cg & 0xf, len = cg >> 4;
-                    if (op == 7 || op == 0) { tr += len; tq += len; re = tr; qe = tq; } else if (op == 8) { tr += len; tq += len; } else if (op == 2) tr += len; else if (op == 1) tq += len; }
-            } else {
-                int tr = A.tlen_full + 1, tq = A.qlen_full + 1;
-                for (int i = (int)c.size() - 1; i >= 0; --i) { int op = c[i] & 0xf, len = c[i] >> 4;
-                    if (op == 7 || op == 0) { tr -= len; tq -= len; rb = tr; qb = tq; } else if (op == 8) { tr -= len; tq -= len; } else if (op == 2) tr -= len; else if (op == 1) tq -= len; }
+            for (auto &e : eo) if (e.status != LCD_OK) return set_err(-20, "edlib kernel status " + std::to_string(e.status));
+            for (int k = 0; k < nb; ++k) {
+                lcd_batch_t *b = bs[k]; lcd_batch_stats_t &S = b->st;
+                for (size_t i = ej_base[k]; i < ej_base[k + 1]; ++i) S.edlib_blocks += eo[i].blocks;
+                for (size_t i = wj_base[k]; i < wj_base[k + 1]; ++i) S.wfa_offsets += wo[i].offsets;
+                S.n_edlib_jobs = (int)(ej_base[k + 1] - ej_base[k]); S.n_wfa_jobs += (int)(wj_base[k + 1] - wj_base[k]);
+                for (const AnchorRec &A : b->anchors) {
+                    PoaRead &pr = preads[k][A.pread];
+                    const int x = eo[ej_base[k] + A.ed_job].xgaps;
+                    if (x > A.min_len * 0.10) { pr.skip = 1; continue; }
+                    if (A.ext == 0) continue;
+                    const size_t wi = wj_base[k] + A.wfa_job;
+                    const int ncg = wo[wi].n_cigar;
+                    if (ncg == 0) { pr.skip = 1; continue; }
+                    const uint32_t *c = (const uint32_t *)(L->h_cig.data() + (wj[wi].out_off - lo));
+                    // collect_aln_beg_end, src/align.c:630-663
+                    int rb = 1, qb = 1, re = A.tlen_full, qe = A.qlen_full;
+                    if (A.ext == 1) {
+                        int tr = 0, tq = 0;
+                        for (int i = 0; i < ncg; ++i) { int op = c[i] & 0xf, len = c[i] >> 4;
+                            if (op == 7 || op == 0) { tr += len; tq += len; re = tr; qe = tq; } else if (op == 8) { tr += len; tq += len; } else if (op == 2) tr += len; else if (op == 1) tq += len; }
+                    } else {
+                        int tr = A.tlen_full + 1, tq = A.qlen_full + 1;
+                        for (int i = ncg - 1; i >= 0; --i) { int op = c[i] & 0xf, len = c[i] >> 4;
+                            if (op == 7 || op == 0) { tr -= len; tq -= len; rb = tr; qb = tq; } else if (op == 8) { tr -= len; tq -= len; } else if (op == 2) tr -= len; else if (op == 1) tq -= len; }
+                    }
+                    pr.ref_beg = rb; pr.ref_end = re; pr.read_beg = qb; pr.read_end = qe;
+                }
             }
-            pr.ref_beg = rb; pr.ref_end = re; pr.read_beg = qb; pr.read_end = qe;
         }
     }
-    HIPCHK(hipEventRecord(b->ev[1], st));
+    HIPCHK(hipEventRecord(L->ev[1], st));
     // ---------------- S2: POA chains ----------------
-    const int nC = (int)b->chains.size();
-    b->couts.assign(nC, PoaChainOut());
-    b->pchains.assign(nC, PoaChain());
-    std::vector<uint64_t> out_rel(nC);
-    uint64_t out_tot = 0;
-    for (int c = 0; c < nC; ++c) {
-        chain_caps(b->opt, b->chains[c], preads, 1, b->pchains[c]);
-        out_rel[c] = out_tot; out_tot += lcd_align_up(poa_out_bytes(b->pchains[c].node_cap, b->pchains[c].n_reads), 256);
+    std::vector<size_t> chain_base(nb + 1, 0), pread_base(nb + 1, 0);
+    for (int k = 0; k < nb; ++k) { chain_base[k + 1] = chain_base[k] + bs[k]->chains.size(); pread_base[k + 1] = pread_base[k] + preads[k].size(); }
+    const size_t nC_all = chain_base[nb];
+    std::vector<int> chain_batch(nC_all);
+    for (int k = 0; k < nb; ++k) for (size_t g = chain_base[k]; g < chain_base[k + 1]; ++g) chain_batch[g] = k;
+    std::vector<std::vector<uint64_t>> out_rel(nb);
+    for (int k = 0; k < nb; ++k) {
+        lcd_batch_t *b = bs[k];
+        const int nC = (int)b->chains.size();
+        b->couts.assign(nC, PoaChainOut());
+        b->pchains.assign(nC, PoaChain());
+        out_rel[k].resize(nC);
+        uint64_t out_tot = 0;
+        for (int c = 0; c < nC; ++c) {
+            chain_caps(b->opt, b->chains[c], preads[k], 1, b->pchains[c]);
+            out_rel[k][c] = out_tot; out_tot += lcd_align_up(poa_out_bytes(b->pchains[c].node_cap, b->pchains[c].n_reads), 256);
+        }
+        if (nC && b->d_poa_out.ensure(out_tot)) return -11;
+        for (int c = 0; c < nC; ++c) b->pchains[c].out_off = b->d_poa_out.addr() + out_rel[k][c];
     }
-    if (nC) {
-        if (b->d_poa_out.ensure(out_tot) || b->d_preads.ensure(preads.size() * sizeof(PoaRead)) || b->d_chains.ensure(nC * sizeof(PoaChain)) ||
-            b->d_poa_outs.ensure(nC * sizeof(PoaChainOut))) return -11;
-        HIPCHK(hipMemcpyAsync(b->d_preads.p, preads.data(), preads.size() * sizeof(PoaRead), hipMemcpyHostToDevice, st));
-        for (int c = 0; c < nC; ++c) b->pchains[c].out_off = b->d_poa_out.addr() + out_rel[c];
-        std::vector<int> which(nC);
-        for (int c = 0; c < nC; ++c) which[c] = c;
-        // biggest first so the long chains start early (LPT)
-        std::sort(which.begin(), which.end(), [&](int a, int c2) {
-            const long long ta = chain_group_key(b->pchains[a]), tc = chain_group_key(b->pchains[c2]);
-            if (ta != tc) return ta > tc; // widest / largest-LDS group first, then biggest first (LPT)
-            return b->pchains[a].cell_cap > b->pchains[c2].cell_cap; });
+    auto PC = [&](size_t g) -> PoaChain & { const int k = chain_batch[g]; return bs[k]->pchains[g - chain_base[k]]; };
+    if (nC_all) {
+        if (L->d_preads.ensure(pread_base[nb] * sizeof(PoaRead)) || L->d_chains.ensure(nC_all * sizeof(PoaChain)) || L->d_poa_outs.ensure(nC_all * sizeof(PoaChainOut))) return -11;
+        for (int k = 0; k < nb; ++k)
+            if (!preads[k].empty())
+                HIPCHK(hipMemcpyAsync((PoaRead *)L->d_preads.p + pread_base[k], preads[k].data(), preads[k].size() * sizeof(PoaRead), hipMemcpyHostToDevice, st));
+        std::vector<size_t> which(nC_all);
+        for (size_t g = 0; g < nC_all; ++g) which[g] = g;
+        // widest / largest-LDS group first, then biggest first so the long chains start early (LPT)
+        std::sort(which.begin(), which.end(), [&](size_t a, size_t c2) {
+            const long long ta = chain_group_key(PC(a)), tc = chain_group_key(PC(c2));
+            if (ta != tc) return ta > tc;
+            if (PC(a).cell_cap != PC(c2).cell_cap) return PC(a).cell_cap > PC(c2).cell_cap;
+            return a < c2; });
         int scale = 1;
         for (int round = 0; round < 12 && !which.empty(); ++round) {
             uint64_t tot = 0;
             std::vector<PoaChain> sub(which.size());
             for (size_t i = 0; i < which.size(); ++i) {
-                PoaChain &pc = b->pchains[which[i]];
-                if (round) chain_caps(b->opt, b->chains[which[i]], preads, scale, pc), pc.out_off = b->d_poa_out.addr() + out_rel[which[i]];
-                PoaLayout L = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads);
-                pc.ws_off = tot; tot += L.total;
+                const int k = chain_batch[which[i]]; const size_t c = which[i] - chain_base[k];
+                PoaChain &pc = bs[k]->pchains[c];
+                if (round) chain_caps(bs[k]->opt, bs[k]->chains[c], preads[k], scale, pc), pc.out_off = bs[k]->d_poa_out.addr() + out_rel[k][c];
+                PoaLayout Lay = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads);
+                pc.ws_off = tot; tot += Lay.total;
             }
-            if (b->d_poa_arena.ensure(tot)) return -11;
-            for (size_t i = 0; i < which.size(); ++i) { b->pchains[which[i]].ws_off += b->d_poa_arena.addr(); sub[i] = b->pchains[which[i]]; }
-            HIPCHK(hipEventRecord(b->ev[6], st));
-            { int rc2 = launch_poa_grouped(st, sub, b->d_chains, (const PoaRead *)b->d_preads.p, b->d_poa_outs, sc, b->side, b->sev); if (rc2) return rc2; }
-            HIPCHK(hipEventRecord(b->ev[7], st));
-            std::vector<PoaChainOut> tmp(sub.size());
-            HIPCHK(hipMemcpyAsync(tmp.data(), b->d_poa_outs.p, sub.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            { float kms = 0; hipEventElapsedTime(&kms, b->ev[6], b->ev[7]); S.ms_poa_kernel += kms; S.n_poa_launches++; }
-            std::vector<int> again;
+            if (L->d_poa_arena.ensure(tot)) return -11;
             for (size_t i = 0; i < which.size(); ++i) {
-                b->couts[which[i]] = tmp[i];
-                if (tmp[i].status == LCD_ERR_CELLS) again.push_back(which[i]);
-                else if (tmp[i].status != LCD_OK) return set_err(-20, "POA kernel status " + std::to_string(tmp[i].status) + " on chain " + std::to_string(which[i]));
+                const int k = chain_batch[which[i]];
+                PoaChain &pc = PC(which[i]);
+                pc.ws_off += L->d_poa_arena.addr();
+                sub[i] = pc; sub[i].read0 += (int)pread_base[k]; // the device read table is the concatenation of the batches' tables
             }
-            if (!again.empty()) { S.poa_retries++; scale *= 2; }
+            HIPCHK(hipEventRecord(L->ev[6], st));
+            { int rc2 = launch_poa_grouped(st, sub, L->d_chains, (const PoaRead *)L->d_preads.p, L->d_poa_outs, sc, L->side, L->sev, &L->d_gate); if (rc2) return rc2; }
+            HIPCHK(hipEventRecord(L->ev[7], st));
+            std::vector<PoaChainOut> tmp(sub.size());
+            HIPCHK(hipMemcpyAsync(tmp.data(), L->d_poa_outs.p, sub.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            { float kms = 0; hipEventElapsedTime(&kms, L->ev[6], L->ev[7]); for (int k = 0; k < nb; ++k) { bs[k]->st.ms_poa_kernel += kms; bs[k]->st.n_poa_launches++; } }
+            std::vector<size_t> again;
+            for (size_t i = 0; i < which.size(); ++i) {
+                const int k = chain_batch[which[i]];
+                bs[k]->couts[which[i] - chain_base[k]] = tmp[i];
+                if (tmp[i].status == LCD_ERR_CELLS) again.push_back(which[i]);
+                else if (tmp[i].status != LCD_OK) return set_err(-20, "POA kernel status " + std::to_string(tmp[i].status) + " on chain " + std::to_string(which[i] - chain_base[k]));
+            }
+            if (!again.empty()) { for (int k = 0; k < nb; ++k) bs[k]->st.poa_retries++; scale *= 2; }
             which.swap(again);
         }
         if (!which.empty()) return set_err(-21, "POA DP arena exhausted after retries");
     }
-    HIPCHK(hipEventRecord(b->ev[2], st));
+    HIPCHK(hipEventRecord(L->ev[2], st));
     // ---------------- S3: ref<->cons WFA, S4: MSA rows -> strings ----------------
-    b->rc_jobs.clear(); b->rc_region.clear(); b->rc_clu.clear();
-    b->str_jobs.clear(); b->str_region.clear(); b->str_clu.clear(); b->str_k.clear();
-    uint64_t str_tot = 0;
-    for (size_t ri = 0; ri < b->regs.size(); ++ri) {
-        RegionRec &R = b->regs[ri];
-        R.n_cons = 0;
-        if (R.branch == 0) continue;
-        S.n_regions++;
-        if (R.branch == 1) {
-            const PoaChainOut &o0 = b->couts[R.chain[0]], &o1 = b->couts[R.chain[1]];
-            if (o0.n_cons + o1.n_cons != 2) continue; // src/align.c:1339
-            R.n_cons = 2;
-        } else R.n_cons = b->couts[R.chain[0]].n_cons;
-        if (R.n_cons > 0) S.n_regions_resolved++;
-        for (int c = 0; c < R.n_cons; ++c) {
-            const int ch = R.branch == 1 ? R.chain[c] : R.chain[0];
-            const int cc = R.branch == 1 ? 0 : c; // consensus index inside the chain
-            const PoaChain &pc = b->pchains[ch]; const PoaChainOut &co = b->couts[ch];
-            WfaJob wj; wj.p_off = in_base + R.ref_off; wj.plen = R.ref_len; wj.t_off = pc.out_off + (uint64_t)cc * pc.node_cap; wj.tlen = co.cons_len[cc];
-            wj.gap_aln = b->opt.gap_aln; wj.want = 2; wj.s_cap = wfa_default_scap(wj.plen, wj.tlen); wj.ws_off = wj.ws_bytes = wj.out_off = 0;
-            b->rc_jobs.push_back(wj); b->rc_region.push_back((int)ri); b->rc_clu.push_back(c);
-            const uint64_t msa0 = pc.out_off + 2ull * pc.node_cap;
-            const uint64_t cons_row = msa0 + (uint64_t)(pc.n_reads + cc) * pc.node_cap;
-            const int *dummy = nullptr; (void)dummy;
-            const int nk = R.branch == 1 ? pc.n_reads : co.clu_n[cc];
-            for (int k = 0; k < nk; ++k) {
-                StrJob sj; sj.member_addr = 0; sj.row0 = 0; sj.row_stride = 0; sj.cons_off = cons_row; sj.msa_len = co.msa_len; sj.out_off = str_tot; str_tot += lcd_align_up((uint64_t)2 * co.msa_len + 16, 16);
-                if (R.branch == 1) { sj.read_off = msa0 + (uint64_t)k * pc.node_cap; sj.full_cover = R.reads[b->chains[ch].members[k]].cover; }
-                else { // K2: row of the k-th member of cluster cc, resolved on the device from the chain's cluster list
-                    const uint64_t clu_addr = pc.out_off + lcd_align_up((uint64_t)(pc.n_reads + 4) * pc.node_cap, 16);
-                    sj.read_off = 0; sj.member_addr = clu_addr + ((uint64_t)cc * pc.n_reads + k) * 4; sj.row0 = msa0; sj.row_stride = pc.node_cap;
-                    sj.full_cover = R.reads[c].cover; /* fully_covers[cluster] quirk, src/align.c:1194 */
+    std::vector<WfaJob> rc_all; std::vector<StrJob> str_all;
+    std::vector<size_t> rc_base(nb + 1, 0), str_base(nb + 1, 0);
+    for (int k = 0; k < nb; ++k) {
+        lcd_batch_t *b = bs[k]; lcd_batch_stats_t &S = b->st;
+        const uint64_t in_base = b->d_in.addr();
+        b->rc_jobs.clear(); b->rc_region.clear(); b->rc_clu.clear();
+        b->str_jobs.clear(); b->str_region.clear(); b->str_clu.clear(); b->str_k.clear();
+        uint64_t str_tot = 0;
+        for (size_t ri = 0; ri < b->regs.size(); ++ri) {
+            RegionRec &R = b->regs[ri];
+            R.n_cons = 0;
+            if (R.branch == 0) continue;
+            S.n_regions++;
+            if (R.branch == 1) {
+                const PoaChainOut &o0 = b->couts[R.chain[0]], &o1 = b->couts[R.chain[1]];
+                if (o0.n_cons + o1.n_cons != 2) continue; // src/align.c:1339
+                R.n_cons = 2;
+            } else R.n_cons = b->couts[R.chain[0]].n_cons;
+            if (R.n_cons > 0) S.n_regions_resolved++;
+            for (int c = 0; c < R.n_cons; ++c) {
+                const int ch = R.branch == 1 ? R.chain[c] : R.chain[0];
+                const int cc = R.branch == 1 ? 0 : c; // consensus index inside the chain
+                const PoaChain &pc = b->pchains[ch]; const PoaChainOut &co = b->couts[ch];
+                WfaJob wj; wj.p_off = in_base + R.ref_off; wj.plen = R.ref_len; wj.t_off = pc.out_off + (uint64_t)cc * pc.node_cap; wj.tlen = co.cons_len[cc];
+                wj.gap_aln = b->opt.gap_aln; wj.want = 2; wj.s_cap = wfa_default_scap(wj.plen, wj.tlen); wj.ws_off = wj.ws_bytes = wj.out_off = 0;
+                b->rc_jobs.push_back(wj); b->rc_region.push_back((int)ri); b->rc_clu.push_back(c);
+                const uint64_t msa0 = pc.out_off + 2ull * pc.node_cap;
+                const uint64_t cons_row = msa0 + (uint64_t)(pc.n_reads + cc) * pc.node_cap;
+                const int nk = R.branch == 1 ? pc.n_reads : co.clu_n[cc];
+                for (int kk = 0; kk < nk; ++kk) {
+                    StrJob sj; sj.member_addr = 0; sj.row0 = 0; sj.row_stride = 0; sj.cons_off = cons_row; sj.msa_len = co.msa_len; sj.out_off = str_tot; str_tot += lcd_align_up((uint64_t)2 * co.msa_len + 16, 16);
+                    if (R.branch == 1) { sj.read_off = msa0 + (uint64_t)kk * pc.node_cap; sj.full_cover = R.reads[b->chains[ch].members[kk]].cover; }
+                    else { // K2: row of the kk-th member of cluster cc, resolved on the device from the chain's cluster list (the host copy
+                           // of the lists is fetched by lcd_batch_download)
+                        const uint64_t clu_addr = pc.out_off + lcd_align_up((uint64_t)(pc.n_reads + 4) * pc.node_cap, 16);
+                        sj.read_off = 0; sj.member_addr = clu_addr + ((uint64_t)cc * pc.n_reads + kk) * 4; sj.row0 = msa0; sj.row_stride = pc.node_cap;
+                        sj.full_cover = R.reads[c].cover; /* fully_covers[cluster] quirk, src/align.c:1194 */
+                    }
+                    b->str_jobs.push_back(sj); b->str_region.push_back((int)ri); b->str_clu.push_back(c); b->str_k.push_back(kk);
                 }
-                b->str_jobs.push_back(sj); b->str_region.push_back((int)ri); b->str_clu.push_back(c); b->str_k.push_back(k);
             }
         }
-    }
-    // (K2 member rows: the strings kernel looks the member read up in the chain's cluster list itself, see StrJob.member_addr;
-    //  the host copy of the lists is fetched by lcd_batch_download)
-    HIPCHK(hipEventRecord(b->ev[3], st));
-    int wret = 0;
-    int rc = run_wfa_stage(st, b->rc_jobs, b->d_wfa_jobs, b->d_wfa_arena, b->d_wfa_out, b->d_wfa_outs, b->rc_outs, sc, &wret);
-    if (rc) return rc;
-    S.n_wfa_jobs += (int)b->rc_jobs.size();
-    for (auto &w : b->rc_outs) S.wfa_offsets += w.offsets;
-    HIPCHK(hipEventRecord(b->ev[4], st));
-    b->str_outs.assign(b->str_jobs.size(), StrOut());
-    if (!b->str_jobs.empty()) {
-        if (b->d_final.ensure(str_tot) || b->d_str_jobs.ensure(b->str_jobs.size() * sizeof(StrJob)) || b->d_str_outs.ensure(b->str_jobs.size() * sizeof(StrOut))) return -11;
+        if (!b->str_jobs.empty() && b->d_final.ensure(str_tot)) return -11;
         for (auto &j : b->str_jobs) j.out_off += b->d_final.addr();
-        HIPCHK(hipMemcpyAsync(b->d_str_jobs.p, b->str_jobs.data(), b->str_jobs.size() * sizeof(StrJob), hipMemcpyHostToDevice, st));
-        lcd_launch_strings((const StrJob *)b->d_str_jobs.p, nullptr, (StrOut *)b->d_str_outs.p, (int)b->str_jobs.size(), st);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(b->str_outs.data(), b->d_str_outs.p, b->str_jobs.size() * sizeof(StrOut), hipMemcpyDeviceToHost, st));
+        b->final_bytes = str_tot;
+        rc_base[k] = rc_all.size(); str_base[k] = str_all.size();
+        rc_all.insert(rc_all.end(), b->rc_jobs.begin(), b->rc_jobs.end());
+        str_all.insert(str_all.end(), b->str_jobs.begin(), b->str_jobs.end());
     }
-    b->final_bytes = str_tot;
-    HIPCHK(hipEventRecord(b->ev[5], st));
+    rc_base[nb] = rc_all.size(); str_base[nb] = str_all.size();
+    HIPCHK(hipEventRecord(L->ev[3], st));
+    {
+        int wret = 0;
+        std::vector<WfaOut> rc_outs;
+        int rc = run_wfa_stage(st, rc_all, L->d_wfa_jobs, L->d_wfa_arena, L->d_wfa_out, L->d_wfa_outs, rc_outs, sc, &wret);
+        if (rc) return rc;
+        for (int k = 0; k < nb; ++k) {
+            lcd_batch_t *b = bs[k];
+            b->rc_jobs.assign(rc_all.begin() + rc_base[k], rc_all.begin() + rc_base[k + 1]);
+            b->rc_outs.assign(rc_outs.begin() + rc_base[k], rc_outs.begin() + rc_base[k + 1]);
+            b->st.n_wfa_jobs += (int)b->rc_jobs.size();
+            for (auto &w : b->rc_outs) b->st.wfa_offsets += w.offsets;
+        }
+    }
+    HIPCHK(hipEventRecord(L->ev[4], st));
+    std::vector<StrOut> str_outs(str_all.size());
+    if (!str_all.empty()) {
+        if (L->d_str_jobs.ensure(str_all.size() * sizeof(StrJob)) || L->d_str_outs.ensure(str_all.size() * sizeof(StrOut))) return -11;
+        HIPCHK(hipMemcpyAsync(L->d_str_jobs.p, str_all.data(), str_all.size() * sizeof(StrJob), hipMemcpyHostToDevice, st));
+        lcd_launch_strings((const StrJob *)L->d_str_jobs.p, nullptr, (StrOut *)L->d_str_outs.p, (int)str_all.size(), st);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(str_outs.data(), L->d_str_outs.p, str_all.size() * sizeof(StrOut), hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipEventRecord(L->ev[5], st));
     HIPCHK(hipStreamSynchronize(st));
-    float ms = 0;
-    hipEventElapsedTime(&ms, b->ev[0], b->ev[1]); S.ms_anchor = ms;
-    hipEventElapsedTime(&ms, b->ev[1], b->ev[2]); S.ms_poa = ms;
-    hipEventElapsedTime(&ms, b->ev[3], b->ev[4]); S.ms_wfa = ms;
-    hipEventElapsedTime(&ms, b->ev[4], b->ev[5]); S.ms_strings = ms;
-    hipEventElapsedTime(&ms, b->ev[0], b->ev[5]); S.ms_total = ms;
-    for (int c = 0; c < nC; ++c) {
-        const PoaChainOut &o = b->couts[c];
-        S.poa_aligned_bases += o.aligned_bases; S.poa_cells += o.cells;
-        // B_poa = q + 5*N_sub + C + (q + N_sub) per aligned read; N_sub ~ final graph size (upper bound per read)
-        S.poa_alg_bytes += 2 * o.aligned_bases + o.cells + 6ull * (uint64_t)o.n_node * (uint64_t)o.n_aligned_reads;
+    float ms_anchor = 0, ms_poa = 0, ms_wfa = 0, ms_str = 0, ms_tot = 0;
+    hipEventElapsedTime(&ms_anchor, L->ev[0], L->ev[1]); hipEventElapsedTime(&ms_poa, L->ev[1], L->ev[2]);
+    hipEventElapsedTime(&ms_wfa, L->ev[3], L->ev[4]); hipEventElapsedTime(&ms_str, L->ev[4], L->ev[5]); hipEventElapsedTime(&ms_tot, L->ev[0], L->ev[5]);
+    const double host_ms = (now_ms() - t_begin) - ms_tot;
+    for (int k = 0; k < nb; ++k) {
+        lcd_batch_t *b = bs[k]; lcd_batch_stats_t &S = b->st;
+        b->str_outs.assign(str_outs.begin() + str_base[k], str_outs.begin() + str_base[k + 1]);
+        // stage times are those of the joint run (the same for every batch of the call)
+        S.ms_anchor = ms_anchor; S.ms_poa = ms_poa; S.ms_wfa = ms_wfa; S.ms_strings = ms_str; S.ms_total = ms_tot; S.ms_host = host_ms;
+        for (const PoaChainOut &o : b->couts) {
+            S.poa_aligned_bases += o.aligned_bases; S.poa_cells += o.cells;
+            // B_poa = q + 5*N_sub + C + (q + N_sub) per aligned read; N_sub ~ final graph size (upper bound per read)
+            S.poa_alg_bytes += 2 * o.aligned_bases + o.cells + 6ull * (uint64_t)o.n_node * (uint64_t)o.n_aligned_reads;
+        }
+        b->ran = true; b->downloaded = false;
+    }
+    if (getenv("LCD_PLACEMENT")) { // experiment: which CU did every wide chain run on, and when
+        for (size_t g = 0; g < nC_all; ++g) { if (chain_threads(PC(g)) < 512) continue; const PoaChainOut &o = bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]];
+            fprintf(stderr, "[place] thr %d xcc %u se %u sh %u cu %u simd %u  t %.1f..%.1f ms ticks %.3e\n", chain_threads(PC(g)), o.xcc_id & 15, (o.hw_id >> 13) & 7, (o.hw_id >> 12) & 1, (o.hw_id >> 8) & 15, (o.hw_id >> 4) & 3,
+                    o.rt_begin / 1e5, o.rt_end / 1e5, (double)o.t_total); }
     }
     if (getenv("LCD_PROFILE_CHAINS")) {
         // per-phase shader-clock ticks, summed per workgroup class and for the slowest chain
-        for (int cls : {64, 256, 1024}) {
-            unsigned long long tt = 0, td = 0, tb = 0, tg = 0, to = 0, ts = 0, mx = 0; int cnt = 0, mxc = -1;
-            for (int c = 0; c < nC; ++c) { if (chain_threads(b->pchains[c]) != cls) continue; const PoaChainOut &o = b->couts[c]; ++cnt;
-                tt += o.t_total; td += o.t_dp; tb += o.t_bt; tg += o.t_graph; to += o.t_out; ts += o.t_sub; if (o.t_total > mx) { mx = o.t_total; mxc = c; } }
+        for (int cls : {64, 128, 256, 512, 1024}) {
+            unsigned long long tt = 0, td = 0, tb = 0, tg = 0, to = 0, ts = 0, mx = 0; int cnt = 0; size_t mxc = 0;
+            for (size_t g = 0; g < nC_all; ++g) { if (chain_threads(PC(g)) != cls) continue; const PoaChainOut &o = bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]]; ++cnt;
+                tt += o.t_total; td += o.t_dp; tb += o.t_bt; tg += o.t_graph; to += o.t_out; ts += o.t_sub; if (o.t_total >= mx) { mx = o.t_total; mxc = g; } }
             if (!cnt) continue;
             fprintf(stderr, "[lcd] class %4d: %5d chains  sum ticks total %.3e dp %.3e bt %.3e graph %.3e sub %.3e out %.3e\n", cls, cnt, (double)tt, (double)td, (double)tb, (double)tg, (double)ts, (double)to);
-            const PoaChainOut &o = b->couts[mxc];
-            fprintf(stderr, "[lcd]   slowest chain %d: mode %d reads %d maxlen %d nodes %d  total %.3e dp %.3e bt %.3e graph %.3e sub %.3e out %.3e cells %llu\n", mxc, b->pchains[mxc].mode,
-                    b->pchains[mxc].n_reads, b->pchains[mxc].max_len, o.n_node, (double)o.t_total, (double)o.t_dp, (double)o.t_bt, (double)o.t_graph, (double)o.t_sub, (double)o.t_out, o.cells);
+            const PoaChainOut &o = bs[chain_batch[mxc]]->couts[mxc - chain_base[chain_batch[mxc]]];
+            fprintf(stderr, "[lcd]   slowest chain %zu: mode %d reads %d maxlen %d nodes %d  total %.3e dp %.3e bt %.3e graph %.3e sub %.3e out %.3e cells %llu\n", mxc, PC(mxc).mode,
+                    PC(mxc).n_reads, PC(mxc).max_len, o.n_node, (double)o.t_total, (double)o.t_dp, (double)o.t_bt, (double)o.t_graph, (double)o.t_sub, (double)o.t_out, o.cells);
+            fprintf(stderr, "[lcd]     of its dp: plan-window refreshes %.3e  mailbox polls %.3e (one wavefront)\n", (double)o.t_plan, (double)o.t_poll);
         }
     }
-    S.ms_host = (now_ms() - t_begin) - S.ms_total;
-    b->ran = true; b->downloaded = false;
     return 0;
 }
+
+int lcd_batch_run(lcd_batch_t *b) { return lcd_batch_run_many(&b, 1); }
 
 int lcd_batch_download(lcd_batch_t *b) {
     if (!b->ran) return set_err(-3, "lcd_batch_download before lcd_batch_run");

@@ -67,11 +67,13 @@ struct PoaChainOut {
     unsigned long long cells;          // DP cells computed (K1/K2 algorithmic unit)
     unsigned long long aligned_bases;  // POA-aligned bases (BASELINE metric)
     unsigned long long t_total, t_dp, t_bt, t_graph, t_out, t_sub; // shader-clock ticks per phase (profiling aid)
+    unsigned long long rt_begin, rt_end; unsigned hw_id, xcc_id;    // placement probe: s_memrealtime (100 MHz) at start / end, HW_ID, XCC_ID
+    unsigned long long t_plan, t_poll;                             // inside t_dp: plan-window refreshes / mailbox polls of one wavefront (unbanded rows)
 };
 
 // arena layout (byte offsets relative to ws_off); identical on host and device
 struct PoaLayout {
-    uint64_t H, E1, E2;                                  // int32[cell_cap]
+    uint64_t H, E1, E2;                                  // DP region of 4*cell_cap bytes (codes | ordinals | spilled rows, or H/E1/E2 planes)
     uint64_t rbeg, rend, roff, ooff, spoff;              // int32/int32/uint32 x3 [node_cap], by topological index
     uint64_t mpl, mpr;                                   // int32[node_cap]: leftmost/rightmost row-max column, by topological index
     uint64_t idx2node, node2idx, remain, deg, queue;     // int32[node_cap]
@@ -92,7 +94,7 @@ static inline LCD_HD PoaLayout poa_layout(int node_cap, int edge_cap, int rid_wo
     PoaLayout L;
     uint64_t o = 0;
 #define LCD_TAKE(field, bytes) do { L.field = o; o = lcd_align_up(o + (uint64_t)(bytes), 16); } while (0)
-    LCD_TAKE(H, cell_cap * 4); LCD_TAKE(E1, cell_cap * 4); LCD_TAKE(E2, cell_cap * 4);
+    LCD_TAKE(H, cell_cap * 4 + 64); L.E1 = L.E2 = L.H; // DP region, partitioned by the kernel (poa_kernel.hip prologue)
     LCD_TAKE(rbeg, (uint64_t)node_cap * 4); LCD_TAKE(rend, (uint64_t)node_cap * 4); LCD_TAKE(roff, (uint64_t)node_cap * 4);
     LCD_TAKE(ooff, (uint64_t)node_cap * 4); LCD_TAKE(spoff, (uint64_t)node_cap * 4);
     LCD_TAKE(mpl, (uint64_t)node_cap * 4); LCD_TAKE(mpr, (uint64_t)node_cap * 4);

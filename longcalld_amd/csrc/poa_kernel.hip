@@ -37,6 +37,7 @@ struct Smem {
     // mailboxes of the systolic unbanded rows (align_unbanded): progress counter, F-scan carry, boundary H, per wavefront
     int prog[MAXW];
     int carry1[16][MAXW], carry2[16][MAXW], bndH[16][MAXW];
+    unsigned long long prof[4];
 };
 
 __shared__ Smem g_smem; // file scope: non-inlined device functions reach it as LDS (a Smem& parameter would be a generic pointer -> flat ops)
@@ -45,7 +46,9 @@ template <int NT> struct Cfg;
 // One LDS pool per workgroup: [row ring | query cache] during the DP, re-used as 16-bit graph arrays by the re-sort.
 // (sizes are per launch: PoaChain.wmax columns per ring slot, PoaChain.lds_words in total; only the slot count is per class)
 template <> struct Cfg<64> { static constexpr int K = 4; };
+template <> struct Cfg<128> { static constexpr int K = 2; };
 template <> struct Cfg<256> { static constexpr int K = 2; };
+template <> struct Cfg<512> { static constexpr int K = 2; };
 template <> struct Cfg<1024> { static constexpr int K = 2; };
 
 struct Ctx {
@@ -65,7 +68,7 @@ struct Ctx {
     int n_node, n_edge, node_cap, edge_cap, rid_words;
     unsigned long long cell_cap;
     int status;
-    unsigned long long t_dp, t_bt;
+    unsigned long long t_dp, t_bt, t_plan, t_poll;
 };
 
 __device__ __forceinline__ int ilog2_32(int v) { return 31 - __clz(v); }
@@ -667,7 +670,7 @@ __device__ __forceinline__ void code_backtrack(const Ctx &g, Smem &sm, const uns
         if (lane == 0) { sm.bc[0] = qlen - pos; sm.bc[1] = status; sm.bc[4] = pos; }
     }
 
-struct WinOut { int status; unsigned long long t_dp, t_bt, cells; int cig_pos; };
+struct WinOut { int status; unsigned long long t_dp, t_bt, cells; int cig_pos; unsigned long long t_plan, t_poll; };
 // (not inlined, context by value: the row loop then only carries the dozen pointers it uses instead of the chain's whole
 //  context -- inlined, hipcc spilled the scalar registers of ~45 pointers into VGPR lanes and re-read them every row)
 template <int NT, bool BANDED>
@@ -688,8 +691,8 @@ __device__ __attribute__((noinline)) int align_windowed(Ctx g, const unsigned ri
     const int QB = (qlen + 12 + 15) & ~15;
     for (int j = tid; j < QB; j += NT) lds_st_u8(sq1 + j, (j >= 1 && j <= qlen) ? seq_hbm[j - 1] : 4); // shifted: sq1[j] = q[j-1]
     const int qclamp = QB - 4;
-    const unsigned long long code_cap = g.cell_cap, ord_cap = g.cell_cap; // bytes / ints
-    const long long spill_rows = g.cell_cap * 7 > 64 ? (long long)((g.cell_cap * 7 - 64) / ((unsigned long long)SLOTW * 4)) : 0;
+    const unsigned long long code_cap = g.cell_cap, ord_cap = g.cell_cap / 4; // bytes / ints (arena partition: see the kernel prologue)
+    const long long spill_rows = g.cell_cap * 2 > 64 ? (long long)((g.cell_cap * 2 - 64) / ((unsigned long long)SLOTW * 4)) : 0;
     // ---- source row (slot 0, window at column 0) ----
     int end0 = qlen - rem_beg; if (end0 < 0) end0 = 0; end0 += w; if (end0 > qlen) end0 = qlen;
     if (end0 + 2 > WIN) return -1;
@@ -971,8 +974,8 @@ __device__ __attribute__((noinline)) int align_unbanded(Ctx g, const unsigned ri
     const int jb = 4 * tid;
     const int AW = imin(NW, (qlen >> 8) + 1); // wavefronts that own a column <= qlen
     const int cw4 = ((qlen >> 2) + 1) << 2;  // cells of a row in HBM, padded to the lanes' 4-cell groups
-    const unsigned long long code_cap = g.cell_cap, ord_cap = g.cell_cap;
-    const long long spill_rows = g.cell_cap * 7 > 64 ? (long long)((g.cell_cap * 7 - 64) / ((unsigned long long)SLOTW * 4)) : 0;
+    const unsigned long long code_cap = g.cell_cap, ord_cap = g.cell_cap / 4;
+    const long long spill_rows = g.cell_cap * 2 > 64 ? (long long)((g.cell_cap * 2 - 64) / ((unsigned long long)SLOTW * 4)) : 0;
     // per-lane constants of this read
     // (one packed register: q[jb-1], q[jb], q[jb+1], q[jb+2] in bytes 0..3; columns outside the read get 15, which matches no base)
     unsigned qpk = 0; int has_n = 0;
@@ -1014,12 +1017,14 @@ __device__ __attribute__((noinline)) int align_unbanded(Ctx g, const unsigned ri
     __syncthreads();
     const long long t_dp0 = clock64();
     int err = LCD_OK;
+    unsigned long long t_plan = 0, t_poll = 0;
     if (wave < AW) {
         int wbase = -(1 << 20);
         int w_pk = 0, w_pi0 = 0, w_pi1 = 0; // w_pk: #preds (16 bits) | base << 16 | spill << 19 | unreachable << 20 | bonus0 << 21 | bonus1 << 26
         const int ke1 = e1, ke2 = e2;
         for (int idx = bi + 1; idx < ei; ++idx) {
             if (idx - wbase >= 64) { // plan window: each lane loads the plan of one upcoming row; rows then take it by v_readlane
+                const long long tp0 = clock64();
                 wbase = idx;
                 const int ri = idx + lane;
                 w_pk = 1 << 20;
@@ -1032,6 +1037,7 @@ __device__ __attribute__((noinline)) int align_unbanded(Ctx g, const unsigned ri
                     w_pk = imin(cnt, 65535) | (glb_ld_u8(g.pl_base + ri) << 16) | ((glb_ld_u8(g.imap + ri) & 2) << 18) | (glb_ld(g.pl_rem + ri) == (1 << 30) ? 1 << 20 : 0) | (b0 << 21) | (b1 << 26);
                 }
                 LCD_PIN(w_pk); LCD_PIN(w_pi0); LCD_PIN(w_pi1);
+                t_plan += (unsigned long long)(clock64() - tp0);
             }
             const int wk = idx - wbase;
             const int pk = LCD_RL(w_pk, wk), pi0 = LCD_RL(w_pi0, wk), pi1 = LCD_RL(w_pi1, wk);
@@ -1045,11 +1051,13 @@ __device__ __attribute__((noinline)) int align_unbanded(Ctx g, const unsigned ri
             if (cused + cw4 > code_cap || (np > 1 && oused + cw4 > ord_cap) || (spf && nsp >= spill_rows)) { err = LCD_ERR_CELLS; break; }
             if (np > 256) { err = LCD_ERR_NODES; break; } // ordinals are 8 bits (and the packed plan word holds 16)
             const int s = (idx - bi) & (K - 1);
+            const long long tq0 = clock64();
             if (SYS) {
                 if (wave + 1 < AW) poll_ge(&sm.prog[wave + 1], idx - (SYS_D - K - 1)); // mailbox slot (idx mod SYS_D) is free again
                 if (wave > 0) poll_ge(&sm.prog[wave - 1], idx);                          // left neighbour has published this row
                 asm volatile("" ::: "memory");
             }
+            t_poll += (unsigned long long)(clock64() - tq0);
             const int d0 = idx - pi0, d1 = idx - pi1;
             int s0, s1, s2, s3;
             if (vb < 4) {
@@ -1140,7 +1148,7 @@ __device__ __attribute__((noinline)) int align_unbanded(Ctx g, const unsigned ri
                 const unsigned S = ring + 4u * (unsigned)(s * SLOTW);
                 lds_st4(S + lofs, H4); lds_st4(S + PL + lofs, A4); lds_st4(S + 2 * PL + lofs, B4);
                 if (spf) { int *G = g.spill + (size_t)nsp * SLOTW; glb_st4(G + jb, H4); glb_st4(G + WIN + jb, A4); glb_st4(G + 2 * WIN + jb, B4); }
-                if (jb < cw4) {
+                if (jb < cw4 && !(sc.dbg & 16)) {
                     glb_st(g.code8 + cused + jb, (int)code);
                     if (np > 1) glb_st4(g.ord + oused + jb, make_int4((om & 255) | ((oa & 255) << 8) | ((ob & 255) << 16),
                                                                          ((om >> 8) & 255) | (((oa >> 8) & 255) << 8) | (((ob >> 8) & 255) << 16),
@@ -1148,7 +1156,7 @@ __device__ __attribute__((noinline)) int align_unbanded(Ctx g, const unsigned ri
                                                                          ((om >> 24) & 255) | (((oa >> 24) & 255) << 8) | (((ob >> 24) & 255) << 16)));
                 }
             }
-            if (tid == 0) {
+            if (tid == 0 && !(sc.dbg & 16)) {
                 glb_st(g.rbeg + idx, 0); glb_st(g.rend + idx, qlen); glb_st(g.roff + idx, (int)cused); glb_st(g.ooff + idx, (int)oused);
                 if (spf) { glb_st(g.ml + idx, 0); glb_st(g.mr + idx, 0); glb_st(g.spoff + idx, nsp); }
             }
@@ -1169,13 +1177,15 @@ __device__ __attribute__((noinline)) int align_unbanded(Ctx g, const unsigned ri
     __syncthreads();
     if (sm.bc[7] != LCD_OK) { wo->status = sm.bc[7]; __syncthreads(); return 0; }
     wo->cells = ncell;
+    if (tid == (AW - 1) * 64) { sm.prof[0] = t_plan; sm.prof[1] = t_poll; } // (profiling aid: the LAST active wavefront's view)
     const long long t_bt0 = clock64();
     wo->t_dp = (unsigned long long)(t_bt0 - t_dp0);
-    if (wave == 0) code_backtrack(g, sm, pd, bi, ei, qlen, SLOTW, WM, lane);
+    if (wave == 0) { if (sc.dbg & 16) { if (lane == 0) { sm.bc[0] = 0; sm.bc[1] = LCD_OK; sm.bc[4] = qlen; } } else code_backtrack(g, sm, pd, bi, ei, qlen, SLOTW, WM, lane); }
     __syncthreads();
     const int n_cig = sm.bc[0];
     wo->status = sm.bc[1];
     wo->cig_pos = sm.bc[4];
+    wo->t_plan = sm.prof[0]; wo->t_poll = sm.prof[1];
     __syncthreads();
     wo->t_bt = (unsigned long long)(clock64() - t_bt0);
     return n_cig;
@@ -1210,14 +1220,14 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
     uint8_t *pd = (QB + (ei - bi) + 16 <= g.seq_cap) ? sseq + QB : nullptr;
     build_plan<NT>(g, sm, bi, ei, remain_end, pd, K);
     if (!(sc.dbg & 8) && WMAX <= NT * 4 && (WMAX & (WMAX - 1)) == 0) {
-        WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0;
+        WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0; wo.t_plan = wo.t_poll = 0;
         const int rem_beg = g.remain[beg_node] - remain_end;
         const unsigned pdo = pd ? lds_off(pd) : 0xffffffffu;
         int nc = wb < 0 ? align_unbanded<NT>(g, lds_off(ring), pdo, sc, bi, ei, seq_hbm, qlen, &wo)
                         : align_windowed<NT, true>(g, lds_off(ring), lds_off(sseq), pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
         if (nc < 0 && wb < 0) { __syncthreads(); nc = align_windowed<NT, false>(g, lds_off(ring), lds_off(sseq), pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
         if (nc >= 0) {
-            g.status = wo.status; g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells;
+            g.status = wo.status; g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells; g.t_plan += wo.t_plan; g.t_poll += wo.t_poll;
             g.cig_node = g.cig_node0 + wo.cig_pos; g.cig_qpos = g.cig_qpos0 + wo.cig_pos;
             return nc;
         }
@@ -1237,7 +1247,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
     {
         int r = g.remain[beg_node] - remain_end;
         int end = qlen - r; if (end < 0) end = 0; end += w; if (end > qlen) end = qlen;
-        if ((unsigned long long)end + 1 > g.cell_cap) { g.status = LCD_ERR_CELLS; return 0; }
+        if ((unsigned long long)end + 1 > g.cell_cap / 3) { g.status = LCD_ERR_CELLS; return 0; }
         const bool fits = end + 1 <= WMAX;
         if (tid == 0) { g.rbeg[bi] = 0; g.rend[bi] = end; g.roff[bi] = 0; g.ml[bi] = 0; g.mr[bi] = 0; }
         for (int j = tid; j <= end; j += NT) {
@@ -1344,7 +1354,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         const unsigned long long off = used;
         const int width = end - beg + 1;
         used += (unsigned long long)width;
-        if (used > g.cell_cap) { g.status = LCD_ERR_CELLS; return 0; }
+        if (used > g.cell_cap / 3) { g.status = LCD_ERR_CELLS; return 0; }
         if (tid == 0) { g.rbeg[idx] = beg; g.rend[idx] = end; g.roff[idx] = (uint32_t)off; }
         const int nchunks = (width + 63) >> 6;
         const bool fits = width <= WMAX;
@@ -1549,9 +1559,10 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
 template <int NT>
 __global__ void __launch_bounds__(NT, (NT == 256 ? 2 : 4)) lcd_poa_chain_kernel(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool,
                                                            uint8_t *arena, uint8_t *outpool, PoaChainOut *outs, LcdScoring sc,
-                                                           int n_chains) {
+                                                           int n_chains, int *gate) {
     const int cid = blockIdx.x;
     if (cid >= n_chains) return;
+    if (gate && threadIdx.x == 0) atomicAdd(gate, 1); // "this workgroup is resident" (see lcd_gate_kernel)
     Smem &sm = g_smem;
     extern __shared__ int lds_pool[]; // [row ring | query cache], re-used by the re-sort; sized per launch (PoaChain.lds_words)
     int *ring = lds_pool;
@@ -1561,9 +1572,11 @@ __global__ void __launch_bounds__(NT, (NT == 256 ? 2 : 4)) lcd_poa_chain_kernel(
     const PoaLayout L = poa_layout(ch.node_cap, ch.edge_cap, ch.rid_words, ch.max_len, ch.cell_cap, ch.n_reads);
     uint8_t *ws = arena + ch.ws_off;
     Ctx g;
-    g.H = (int *)(ws + L.H); g.E1 = (int *)(ws + L.E1); g.E2 = (int *)(ws + L.E2);
-    // the windowed path re-partitions the same 12*cell_cap bytes: [codes: cell_cap B | ordinals: 4*cell_cap B | spilled rows: the rest]
-    g.code8 = ws + L.H; g.ord = (int *)(ws + L.H + lcd_align_up(ch.cell_cap, 16)); g.spill = (int *)(ws + L.H + lcd_align_up(ch.cell_cap, 16) + lcd_align_up(ch.cell_cap * 4, 16));
+    // DP region: 4 * cell_cap bytes.  Windowed / systolic rows: [direction codes: cell_cap B | predecessor ordinals: cell_cap B (one row
+    // in four may have >= 2 predecessors) | spilled value rows: 2 * cell_cap B].  Generic rows: int32 H, E1, E2 planes of cell_cap / 3
+    // cells.  Whatever does not fit ends the chain with LCD_ERR_CELLS and the host re-runs it with a larger arena.
+    g.H = (int *)(ws + L.H); g.E1 = g.H + ch.cell_cap / 3; g.E2 = g.E1 + ch.cell_cap / 3;
+    g.code8 = ws + L.H; g.ord = (int *)(ws + L.H + lcd_align_up(ch.cell_cap, 16)); g.spill = (int *)(ws + L.H + 2 * lcd_align_up(ch.cell_cap, 16));
     g.ooff = (uint32_t *)(ws + L.ooff); g.spoff = (uint32_t *)(ws + L.spoff);
     g.rbeg = (int *)(ws + L.rbeg); g.rend = (int *)(ws + L.rend); g.roff = (uint32_t *)(ws + L.roff);
     g.ml = (int *)(ws + L.mpl); g.mr = (int *)(ws + L.mpr);
@@ -1583,8 +1596,9 @@ __global__ void __launch_bounds__(NT, (NT == 256 ? 2 : 4)) lcd_poa_chain_kernel(
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
     g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - Cfg<NT>::K * 3 * ch.wmax) * 4;
-    g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0;
+    g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0;
     const long long t_begin = clock64();
+    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
     unsigned long long t_graph = 0, t_sub = 0;
     if (tid == 0)
         for (int i = 0; i < 2; ++i) {
@@ -1791,26 +1805,40 @@ __global__ void __launch_bounds__(NT, (NT == 256 ? 2 : 4)) lcd_poa_chain_kernel(
     }
     if (tid == 0) {
         const long long t_end = clock64();
-        out.t_total = (unsigned long long)(t_end - t_begin); out.t_dp = g.t_dp; out.t_bt = g.t_bt; out.t_graph = t_graph; out.t_sub = t_sub;
+        out.t_total = (unsigned long long)(t_end - t_begin); out.t_dp = g.t_dp; out.t_bt = g.t_bt; out.t_graph = t_graph; out.t_sub = t_sub; out.t_plan = g.t_plan; out.t_poll = g.t_poll;
+        out.hw_id = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); out.xcc_id = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+        out.rt_begin = rt_begin; out.rt_end = __builtin_amdgcn_s_memrealtime();
         out.t_out = (unsigned long long)(t_end - t_out0);
         outs[cid] = out;
     }
 }
 
+// Holds a stream until `target` workgroups of the wide classes have started.  A 1 024-thread chain needs ALL the vector registers of a
+// CU; if the thousands of 64-thread chains of the same step are dispatched at the same time they take a few wavefront slots on every
+// CU and the wide chains -- the longest ones, the step's critical path -- wait for a CU to drain completely (measured: 1.09 s instead
+// of 0.39 s for the wide launch).  The narrow classes' streams therefore start with this one-lane kernel.
+__global__ void lcd_gate_kernel(const int *ctr, int target) {
+    while (__atomic_load_n(ctr, __ATOMIC_RELAXED) < target) __builtin_amdgcn_s_sleep(32);
+}
+void lcd_launch_gate(const int *ctr, int target, hipStream_t stream) { hipLaunchKernelGGL(lcd_gate_kernel, dim3(1), dim3(1), 0, stream, ctr, target); }
+
 void lcd_launch_poa(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool, uint8_t *arena, uint8_t *outpool,
-                    PoaChainOut *outs, LcdScoring sc, int n_chains, int threads, int lds_bytes, hipStream_t stream) {
+                    PoaChainOut *outs, LcdScoring sc, int n_chains, int threads, int lds_bytes, hipStream_t stream, int *gate) {
     if (n_chains <= 0) return;
     static bool attr_set = false;
     if (!attr_set) { // allow > 64 KB of dynamic LDS (gfx950 has 160 KB per CU)
         hipFuncSetAttribute((const void *)lcd_poa_chain_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipFuncSetAttribute((const void *)lcd_poa_chain_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         hipFuncSetAttribute((const void *)lcd_poa_chain_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipFuncSetAttribute((const void *)lcd_poa_chain_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         hipFuncSetAttribute((const void *)lcd_poa_chain_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    if (threads <= 64)
-        hipLaunchKernelGGL(lcd_poa_chain_kernel<64>, dim3(n_chains), dim3(64), lds_bytes, stream, chains, reads, pool, arena, outpool, outs, sc, n_chains);
-    else if (threads <= 256)
-        hipLaunchKernelGGL(lcd_poa_chain_kernel<256>, dim3(n_chains), dim3(256), lds_bytes, stream, chains, reads, pool, arena, outpool, outs, sc, n_chains);
-    else
-        hipLaunchKernelGGL(lcd_poa_chain_kernel<1024>, dim3(n_chains), dim3(1024), lds_bytes, stream, chains, reads, pool, arena, outpool, outs, sc, n_chains);
+#define LCD_LAUNCH(NT) hipLaunchKernelGGL(lcd_poa_chain_kernel<NT>, dim3(n_chains), dim3(NT), lds_bytes, stream, chains, reads, pool, arena, outpool, outs, sc, n_chains, gate)
+    if (threads <= 64) LCD_LAUNCH(64);
+    else if (threads <= 128) LCD_LAUNCH(128);
+    else if (threads <= 256) LCD_LAUNCH(256);
+    else if (threads <= 512) LCD_LAUNCH(512);
+    else LCD_LAUNCH(1024);
+#undef LCD_LAUNCH
 }
