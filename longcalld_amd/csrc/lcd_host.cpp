@@ -19,6 +19,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <map>
 #include "../../include/lcd_hotpath.h"
 #include "lcd_kernels.h"
 #include "lcd_types.h"
@@ -554,7 +555,7 @@ static void chain_class(PoaChain &pc) {
     int threads, K, wmax; // wmax: window / ring-slot width in columns, a power of two <= 4 * threads (poa_kernel.hip align_windowed)
     // one lane per four columns of the window: 64 / 128 / 256 / 512 / 1024 threads, so that no wavefront of a workgroup idles
     // (a 2 048-column chain in a 1 024-thread workgroup would hold a whole CU's registers with half of its wavefronts parked)
-    if (width <= 256) { threads = 64; K = 4; wmax = 256; }
+    if (width <= 256) { threads = 64; K = 2; wmax = 256; }
     else if (width <= 512) { threads = 128; K = 2; wmax = 512; }
     else if (width <= 1024) { threads = 256; K = 2; wmax = 1024; }
     else if (width <= 2048) { threads = 512; K = 2; wmax = 2048; }
@@ -562,9 +563,12 @@ static void chain_class(PoaChain &pc) {
     const long long est_nodes = (long long)(pc.max_len * 1.15) + 64;
     const long long seq_bytes = lcd_align_up((long long)pc.max_len + 28, 16) + lcd_align_up(est_nodes + 16, 16); // query cache + first-predecessor distances
     const long long dp_bytes = (long long)K * 3 * wmax * 4 + seq_bytes;
-    const long long need = std::max(dp_bytes, est_nodes * 22 + 64);
-    static const int buckets[] = {16 << 10, 32 << 10, 64 << 10, 148 << 10}; // few buckets: every (threads, bucket) group is one launch
-    int lds = buckets[3];
+    // the re-sort's LDS copy of the graph: 8 B per node + 4 B per edge (topo_sort_block); edges ~ nodes + a few per bubble
+    const long long need = std::max(dp_bytes, est_nodes * 8 + (est_nodes + est_nodes / 8) * 4 + 64);
+    // LDS per workgroup decides how many single-wavefront chains share a CU (160 KB, 16 wavefronts at 128 VGPRs), and those chains are
+    // most of the work: fine-grained buckets; every (threads, bucket) group is one launch, a few streams run the groups (launch_poa_grouped)
+    static const int buckets[] = {8 << 10, 12 << 10, 16 << 10, 24 << 10, 32 << 10, 48 << 10, 64 << 10, 96 << 10, 148 << 10};
+    int lds = buckets[8];
     for (int b : buckets) if (need <= b) { lds = b; break; }
     pc.threads = threads; pc.wmax = wmax; pc.lds_words = lds / 4;
 }
@@ -889,6 +893,19 @@ int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
                     o.rt_begin / 1e5, o.rt_end / 1e5, (double)o.t_total); }
     }
     if (getenv("LCD_PROFILE_CHAINS")) {
+        { // CU-seconds per launch group: sum of chain ticks / workgroups that fit a CU (LDS- or register-limited)
+            std::map<long long, std::pair<double, int>> gsum;
+            for (size_t g = 0; g < nC_all; ++g) { const PoaChainOut &o = bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]]; auto &e = gsum[chain_group_key(PC(g))]; e.first += (double)o.t_total; e.second++; }
+            double tot = 0;
+            for (auto &kv : gsum) {
+                const int thr = (int)(kv.first >> 20), lds = (int)(kv.first & ((1 << 20) - 1)) * 4;
+                const int by_lds = std::max(1, (160 * 1024) / (lds + (thr == 64 ? 1 : 6) * 1024)), by_reg = std::max(1, 1024 / thr); // 128 VGPRs: 16 wavefronts per CU
+                const int per_cu = std::min(by_lds, by_reg);
+                const double cus = kv.second.first / 2.4e9 / per_cu; tot += cus;
+                fprintf(stderr, "[lcd] group thr %4d lds %3dK: %6d chains, %7.2f wg-s, %2d per CU -> %7.2f CU-s\n", thr, lds >> 10, kv.second.second, kv.second.first / 2.4e9, per_cu, cus);
+            }
+            fprintf(stderr, "[lcd] total %.2f CU-s = %.1f ms of %d CUs\n", tot, tot / g_n_cus * 1e3, g_n_cus);
+        }
         // per-phase shader-clock ticks, summed per workgroup class and for the slowest chain
         for (int cls : {64, 128, 256, 512, 1024}) {
             unsigned long long tt = 0, td = 0, tb = 0, tg = 0, to = 0, ts = 0, mx = 0; int cnt = 0; size_t mxc = 0;

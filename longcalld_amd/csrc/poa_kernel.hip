@@ -25,27 +25,30 @@ namespace {
 constexpr int MAXP = 64;   // predecessors staged in LDS per row (more are read from the plan in HBM)
 constexpr int MAXW = 16;   // wavefronts per workgroup
 
-struct Smem {
+struct Smem { // small per-workgroup state of every class (static LDS counts against the workgroups-per-CU budget of the narrow classes)
     int tot1[2][MAXW], tot2[2][MAXW];
     int bh[MAXW], bl[MAXW], br[MAXW];
-    int pb[MAXP], pe[MAXP], bonus[MAXP], pml[MAXP], pmr[MAXP];
-    unsigned po[MAXP];
-    int ppi[MAXP], pslot[MAXP];
     int rm[4][5];          // ring slot meta: beg, end, HBM offset, row-max leftmost / rightmost column
     int scan[MAXW];
     int bc[8];
+    unsigned long long prof[4];
+};
+struct SmemWide { // multi-wavefront classes only (never referenced by the 64-thread kernel, so it costs that class no LDS)
+    int pb[MAXP], pe[MAXP], bonus[MAXP], pml[MAXP], pmr[MAXP];
+    unsigned po[MAXP];
+    int ppi[MAXP], pslot[MAXP];
     // mailboxes of the systolic unbanded rows (align_unbanded): progress counter, F-scan carry, boundary H, per wavefront
     int prog[MAXW];
     int carry1[16][MAXW], carry2[16][MAXW], bndH[16][MAXW];
-    unsigned long long prof[4];
 };
 
+__shared__ SmemWide g_wide;
 __shared__ Smem g_smem; // file scope: non-inlined device functions reach it as LDS (a Smem& parameter would be a generic pointer -> flat ops)
 
 template <int NT> struct Cfg;
 // One LDS pool per workgroup: [row ring | query cache] during the DP, re-used as 16-bit graph arrays by the re-sort.
 // (sizes are per launch: PoaChain.wmax columns per ring slot, PoaChain.lds_words in total; only the slot count is per class)
-template <> struct Cfg<64> { static constexpr int K = 4; };
+template <> struct Cfg<64> { static constexpr int K = 2; };
 template <> struct Cfg<128> { static constexpr int K = 2; };
 template <> struct Cfg<256> { static constexpr int K = 2; };
 template <> struct Cfg<512> { static constexpr int K = 2; };
@@ -347,11 +350,15 @@ __device__ bool add_alignment_block(Ctx &g, Smem &sm, int beg_node, int end_node
 // inherently serial) but on 16-bit copies of the graph staged in LDS, so each dependent step costs an LDS access (~60 clk)
 // instead of an HBM/L2 access (~500 clk); staging in and out is a coalesced parallel copy.  Falls back to HBM when the
 // graph does not fit the pool.
+// LDS budget: 8 B per node + 4 B per edge (the pool size decides how many single-wavefront chains fit a CU, and those chains are
+// most of the work): deg | queue (= the topological order itself) | out_head | aligned ring ; edge next | edge to.  node2idx goes
+// straight to HBM (stores do not stall the walk); after the walk `aligned` is overwritten by each node's heaviest successor
+// (computed in parallel from the edge weights in HBM) and `deg` by remain + 1.
 template <int NT>
 __device__ void topo_sort_block(Ctx &g, Smem &sm, int *lds_pool) {
     const int tid = threadIdx.x;
     const int n = g.n_node, E = g.n_edge;
-    const bool fits = n < 65535 && E < 65535 && (size_t)14 * n + (size_t)6 * E + 64 <= (size_t)g.pool_words * 4;
+    const bool fits = n < 65535 && E < 65535 && (size_t)8 * n + (size_t)4 * E + 64 <= (size_t)g.pool_words * 4;
     if (!fits) {
         if (tid == 0) { topo_sort(g); sm.bc[6] = g.status; }
         __syncthreads();
@@ -359,17 +366,17 @@ __device__ void topo_sort_block(Ctx &g, Smem &sm, int *lds_pool) {
         __syncthreads();
         return;
     }
-    unsigned short *deg = (unsigned short *)lds_pool, *queue = deg + n, *oh = queue + n, *al = oh + n, *i2n = al + n, *n2i = i2n + n, *rem = n2i + n;
-    unsigned short *en = rem + n, *et = en + E, *ew = et + E;
+    unsigned short *deg = (unsigned short *)lds_pool, *queue = deg + n, *oh = queue + n, *al = oh + n;
+    unsigned short *en = al + n, *et = en + E;
     for (int i = tid; i < n; i += NT) { deg[i] = (unsigned short)g.nin[i]; oh[i] = (unsigned short)(g.out_head[i] + 1); al[i] = (unsigned short)g.aligned[i]; }
-    for (int e = tid; e < E; e += NT) { en[e] = (unsigned short)(g.e_next_out[e] + 1); et[e] = (unsigned short)g.e_to[e]; const int w = g.e_w[e]; ew[e] = (unsigned short)(w > 65535 ? 65535 : w); }
+    for (int e = tid; e < E; e += NT) { en[e] = (unsigned short)(g.e_next_out[e] + 1); et[e] = (unsigned short)g.e_to[e]; }
     __syncthreads();
     if (tid == 0) {
         int qh = 0, qt = 0, index = 0;
         queue[qt++] = 0;
         while (qh < qt) {
             const int cur = queue[qh++];
-            i2n[index] = (unsigned short)cur; n2i[cur] = (unsigned short)index; ++index;
+            g.node2idx[cur] = index; ++index; // (idx2node is the queue itself, copied out below)
             if (cur == 1) break;
             for (int e = oh[cur]; e != 0; e = en[e - 1]) {
                 const int out = et[e - 1];
@@ -384,20 +391,26 @@ __device__ void topo_sort_block(Ctx &g, Smem &sm, int *lds_pool) {
             }
         }
         if (index != n) g.status = LCD_ERR_TOPO;
-        else {
-            rem[1] = 0; // remain + 1
-            for (int i = n - 2; i >= 0; --i) {
-                const int v = i2n[i]; int mw = -1, mid = 1;
-                for (int e = oh[v]; e != 0; e = en[e - 1]) if ((int)ew[e - 1] > mw) { mw = ew[e - 1]; mid = et[e - 1]; }
-                rem[v] = (unsigned short)(rem[mid] + 1);
-            }
-        }
         sm.bc[6] = g.status;
     }
     __syncthreads();
     g.status = sm.bc[6];
-    if (g.status == LCD_OK)
-        for (int i = tid; i < n; i += NT) { g.idx2node[i] = i2n[i]; g.node2idx[i] = n2i[i]; g.remain[i] = (int)rem[i] - 1; }
+    if (g.status == LCD_OK) {
+        // heaviest successor of every node (first maximum in out-edge order; 1 = the sink when there is no out-edge), in parallel
+        unsigned short *hs = al, *rem = deg;
+        for (int v = tid; v < n; v += NT) {
+            int mw = -1, mid = 1;
+            for (int e = oh[v]; e != 0; e = en[e - 1]) { const int w = g.e_w[e - 1]; if (w > mw) { mw = w; mid = et[e - 1]; } }
+            hs[v] = (unsigned short)mid;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            rem[1] = 0; // remain + 1
+            for (int i = n - 2; i >= 0; --i) { const int v = queue[i]; rem[v] = (unsigned short)(rem[hs[v]] + 1); }
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) { g.idx2node[i] = queue[i]; g.remain[i] = (int)rem[i] - 1; }
+    }
     __syncthreads();
 }
 
@@ -1009,7 +1022,7 @@ __device__ __attribute__((noinline)) int align_unbanded(Ctx g, const unsigned ri
             lds_st4(ring + lofs, H4); lds_st4(ring + PL + lofs, A4); lds_st4(ring + 2 * PL + lofs, B4);
             if (spf) { int *G = g.spill; glb_st4(G + jb, H4); glb_st4(G + WIN + jb, A4); glb_st4(G + 2 * WIN + jb, B4); }
         }
-        if (SYS && lane == 63) { sm.bndH[bi & (SYS_D - 1)][wave] = H4.w; sm.prog[wave] = bi; }
+        if (SYS && lane == 63) { g_wide.bndH[bi & (SYS_D - 1)][wave] = H4.w; g_wide.prog[wave] = bi; }
         if (tid == 0) { g.rbeg[bi] = 0; g.rend[bi] = qlen; g.roff[bi] = 0; g.ml[bi] = 0; g.mr[bi] = 0; g.spoff[bi] = 0; sm.bc[7] = LCD_OK; }
         if (spf) nsp = 1;
     }
@@ -1053,8 +1066,8 @@ __device__ __attribute__((noinline)) int align_unbanded(Ctx g, const unsigned ri
             const int s = (idx - bi) & (K - 1);
             const long long tq0 = clock64();
             if (SYS) {
-                if (wave + 1 < AW) poll_ge(&sm.prog[wave + 1], idx - (SYS_D - K - 1)); // mailbox slot (idx mod SYS_D) is free again
-                if (wave > 0) poll_ge(&sm.prog[wave - 1], idx);                          // left neighbour has published this row
+                if (wave + 1 < AW) poll_ge(&g_wide.prog[wave + 1], idx - (SYS_D - K - 1)); // mailbox slot (idx mod SYS_D) is free again
+                if (wave > 0) poll_ge(&g_wide.prog[wave - 1], idx);                          // left neighbour has published this row
                 asm volatile("" ::: "memory");
             }
             t_poll += (unsigned long long)(clock64() - tq0);
@@ -1071,7 +1084,7 @@ __device__ __attribute__((noinline)) int align_unbanded(Ctx g, const unsigned ri
             auto near_row = [&](const int pi, int &hm, int4 &hv, int4 &av, int4 &bv) {
                 const unsigned S = ring + 4u * (unsigned)(((pi - bi) & (K - 1)) * SLOTW);
                 hm = lds_ld(S + lofs - 4); hv = lds_ld4(S + lofs); av = lds_ld4(S + PL + lofs); bv = lds_ld4(S + 2 * PL + lofs);
-                if (lane == 0) hm = wave == 0 ? LCD_GUARD : (SYS ? sm.bndH[pi & (SYS_D - 1)][wave - 1] : hm);
+                if (lane == 0) hm = wave == 0 ? LCD_GUARD : (SYS ? g_wide.bndH[pi & (SYS_D - 1)][wave - 1] : hm);
             };
             auto far_row = [&](const int pi, int &hm, int4 &hv, int4 &av, int4 &bv) {
                 const int *G = g.spill + (size_t)g.spoff[pi] * SLOTW;
@@ -1122,7 +1135,7 @@ __device__ __attribute__((noinline)) int align_unbanded(Ctx g, const unsigned ri
             scan_max2(t1, t2);
             int x1 = shr1(LCD_GUARD, t1), x2 = shr1(LCD_GUARD, t2); // exclusive prefix over the lanes of this wavefront
             int cin1 = LCD_GUARD, cin2 = LCD_GUARD;
-            if (SYS && wave > 0) { cin1 = sm.carry1[idx & (SYS_D - 1)][wave - 1]; cin2 = sm.carry2[idx & (SYS_D - 1)][wave - 1]; x1 = imax(x1, cin1); x2 = imax(x2, cin2); }
+            if (SYS && wave > 0) { cin1 = g_wide.carry1[idx & (SYS_D - 1)][wave - 1]; cin2 = g_wide.carry2[idx & (SYS_D - 1)][wave - 1]; x1 = imax(x1, cin1); x2 = imax(x2, cin2); }
             // ---- phase B: F, H, E-out, direction code of the four cells ----
             int hh0, hh1, hh2, hh3, ea0, ea1, ea2, ea3, eb0, eb1, eb2, eb3;
             unsigned code = 0;
@@ -1162,12 +1175,12 @@ __device__ __attribute__((noinline)) int align_unbanded(Ctx g, const unsigned ri
             }
             if (SYS) {
                 if (lane == 63) {
-                    sm.bndH[idx & (SYS_D - 1)][wave] = hh3;
-                    sm.carry1[idx & (SYS_D - 1)][wave] = imax(cin1, t1); sm.carry2[idx & (SYS_D - 1)][wave] = imax(cin2, t2);
+                    g_wide.bndH[idx & (SYS_D - 1)][wave] = hh3;
+                    g_wide.carry1[idx & (SYS_D - 1)][wave] = imax(cin1, t1); g_wide.carry2[idx & (SYS_D - 1)][wave] = imax(cin2, t2);
                 }
                 // the row is complete in LDS (and, for a spilled row, in HBM) before the neighbours may look at it
                 if (spf) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 63) *(volatile lcd_lds_i32 *)(uintptr_t)lds_off(&sm.prog[wave]) = idx; // (LDS-typed: a generic volatile store is a flat store + vmcnt(0))
+                if (lane == 63) *(volatile lcd_lds_i32 *)(uintptr_t)lds_off(&g_wide.prog[wave]) = idx; // (LDS-typed: a generic volatile store is a flat store + vmcnt(0))
             }
             cused += cw4; if (np > 1) oused += cw4; if (spf) ++nsp;
             ncell += (unsigned long long)qlen + 1;
@@ -1203,6 +1216,7 @@ template <int NT>
 __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, const LcdScoring &sc, const int wb, int wf_milli, int beg_node, int end_node,
                                  const uint8_t *seq_hbm, int qlen, unsigned long long *cells_acc) {
     constexpr int NW = NT / 64, K = Cfg<NT>::K;
+    constexpr int MP = NW == 1 ? 0 : MAXP; // predecessors staged in LDS per row (single-wavefront rows keep them in registers or read the plan)
     const int WMAX = g.wmax; // ring slot capacity in columns: chosen per launch from the chains' lengths (dynamic LDS)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     g.cig_node = g.cig_node0; g.cig_qpos = g.cig_qpos0;
@@ -1309,25 +1323,27 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
                 else if (r_slot >= 0) { r_pb = sm.rm[r_slot][0]; r_pe = sm.rm[r_slot][1]; r_po = (unsigned)sm.rm[r_slot][2]; r_pml = sm.rm[r_slot][3]; r_pmr = sm.rm[r_slot][4]; }
                 else { r_pb = g.rbeg[my_pi]; r_pe = g.rend[my_pi]; r_po = g.roff[my_pi]; r_pml = g.ml[my_pi]; r_pmr = g.mr[my_pi]; }
             }
+        } else if constexpr (NW == 1) {
+            __syncthreads(); last_full = idx; // > 64 predecessors on a single-wavefront row: everything through the plan and HBM
         } else {
             // pass 1: where does each predecessor row live (ring slot or HBM only)
-            if (tid < np && tid < MAXP) {
+            if (tid < np && tid < MP) {
                 const int slot = LCD_SLOT_OF(my_pi);
-                sm.bonus[tid] = my_bonus; sm.ppi[tid] = my_pi; sm.pslot[tid] = slot;
+                g_wide.bonus[tid] = my_bonus; g_wide.ppi[tid] = my_pi; g_wide.pslot[tid] = slot;
             }
             lds_barrier<NT>();
             {
-                int far_pi = np > MAXP ? (1 << 30) : -1;
-                const int ns = imin(np, MAXP);
-                for (int t = 0; t < ns; ++t) if (sm.pslot[t] < 0) far_pi = imax(far_pi, sm.ppi[t]);
+                int far_pi = np > MP ? (1 << 30) : -1;
+                const int ns = imin(np, MP);
+                for (int t = 0; t < ns; ++t) if (g_wide.pslot[t] < 0) far_pi = imax(far_pi, g_wide.ppi[t]);
                 if (far_pi >= last_full) { __syncthreads(); last_full = idx; }
             }
             // pass 2: metadata from registers (row just computed), ring meta (LDS) or HBM
-            if (tid < np && tid < MAXP) {
-                const int pi = my_pi, slot = sm.pslot[tid];
-                if (pi == last_idx) { sm.pb[tid] = last_beg; sm.pe[tid] = last_end; sm.po[tid] = last_off; sm.pml[tid] = last_ml; sm.pmr[tid] = last_mr; }
-                else if (slot >= 0) { sm.pb[tid] = sm.rm[slot][0]; sm.pe[tid] = sm.rm[slot][1]; sm.po[tid] = (unsigned)sm.rm[slot][2]; sm.pml[tid] = sm.rm[slot][3]; sm.pmr[tid] = sm.rm[slot][4]; }
-                else { sm.pb[tid] = g.rbeg[pi]; sm.pe[tid] = g.rend[pi]; sm.po[tid] = g.roff[pi]; sm.pml[tid] = g.ml[pi]; sm.pmr[tid] = g.mr[pi]; }
+            if (tid < np && tid < MP) {
+                const int pi = my_pi, slot = g_wide.pslot[tid];
+                if (pi == last_idx) { g_wide.pb[tid] = last_beg; g_wide.pe[tid] = last_end; g_wide.po[tid] = last_off; g_wide.pml[tid] = last_ml; g_wide.pmr[tid] = last_mr; }
+                else if (slot >= 0) { g_wide.pb[tid] = sm.rm[slot][0]; g_wide.pe[tid] = sm.rm[slot][1]; g_wide.po[tid] = (unsigned)sm.rm[slot][2]; g_wide.pml[tid] = sm.rm[slot][3]; g_wide.pmr[tid] = sm.rm[slot][4]; }
+                else { g_wide.pb[tid] = g.rbeg[pi]; g_wide.pe[tid] = g.rend[pi]; g_wide.po[tid] = g.roff[pi]; g_wide.pml[tid] = g.ml[pi]; g_wide.pmr[tid] = g.mr[pi]; }
             }
             lds_barrier<NT>();
         }
@@ -1336,7 +1352,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         for (int t = 0; t < np; ++t) {
             int pb, pe, pml, pmr;
             if (regstage) { pb = LCD_RL(r_pb, t); pe = LCD_RL(r_pe, t); pml = LCD_RL(r_pml, t); pmr = LCD_RL(r_pmr, t); }
-            else if (t < MAXP) { pb = sm.pb[t]; pe = sm.pe[t]; pml = sm.pml[t]; pmr = sm.pmr[t]; }
+            else if (t < MP) { pb = g_wide.pb[t]; pe = g_wide.pe[t]; pml = g_wide.pml[t]; pmr = g_wide.pmr[t]; }
             else { const int pi = g.pl_pidx[p0 + t]; pb = g.rbeg[pi]; pe = g.rend[pi]; pml = g.ml[pi]; pmr = g.mr[pi]; }
             if (pb > pe) continue;
             minpb = imin(minpb, pb); maxpe = imax(maxpe, pe);
@@ -1381,7 +1397,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
                 for (int t = 0; t < np; ++t) { // uniform loop: every lane takes part in the readlane broadcasts
                     int pb, pe, bonus, ps; unsigned po;
                     if (regstage) { pb = LCD_RL(r_pb, t); pe = LCD_RL(r_pe, t); po = (unsigned)LCD_RL((int)r_po, t); bonus = LCD_RL(r_bonus, t); ps = LCD_RL(r_slot, t); }
-                    else if (t < MAXP) { pb = sm.pb[t]; pe = sm.pe[t]; po = sm.po[t]; bonus = sm.bonus[t]; ps = sm.pslot[t]; }
+                    else if (t < MP) { pb = g_wide.pb[t]; pe = g_wide.pe[t]; po = g_wide.po[t]; bonus = g_wide.bonus[t]; ps = g_wide.pslot[t]; }
                     else { const int pi = g.pl_pidx[p0 + t]; pb = g.rbeg[pi]; pe = g.rend[pi]; po = g.roff[pi]; bonus = g.pl_bonus[p0 + t]; ps = -1; }
                     if (!act) continue;
                     if (ps >= 0) {
@@ -1557,7 +1573,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
 } // namespace
 
 template <int NT>
-__global__ void __launch_bounds__(NT, (NT == 256 ? 2 : 4)) lcd_poa_chain_kernel(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool,
+__global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool,
                                                            uint8_t *arena, uint8_t *outpool, PoaChainOut *outs, LcdScoring sc,
                                                            int n_chains, int *gate) {
     const int cid = blockIdx.x;
