@@ -78,6 +78,38 @@ def test_run_is_idempotent_and_order_independent(lcd):
     same_result(one, got[0])
 
 
+def test_run_many_equals_separate_runs(lcd):
+    """lcd_batch_run_many (one launch set per stage over the chains of several batches) == each batch run on its own"""
+    from longcalld_amd import jobs
+    sets = [jobs.make_regions(31, 14), jobs.make_regions(32, 9, jobs.ONT), jobs.make_regions(33, 11)]
+    alone = []
+    for regs in sets:
+        b = lcd.RegionBatch()
+        for r in regs:
+            b.add_region(r)
+        b.upload(); b.run(); b.download()
+        alone.append((b.digest(), [b.result(i) for i in range(len(regs))]))
+        b.close()
+    bs = []
+    for regs in sets:
+        b = lcd.RegionBatch()
+        for r in regs:
+            b.add_region(r)
+        b.upload()
+        bs.append(b)
+    lcd.RegionBatch.run_many(bs)
+    for b in bs:          # (the ref<->cons rows live in the leader's buffers: download everything before the leader runs again or is closed)
+        b.download()
+    for b, (dig, res) in zip(bs, alone):
+        assert b.digest() == dig
+        for i, r in enumerate(res):
+            same_result(r, b.result(i))
+        st = b.stats()
+        assert st["n_regions"] > 0 and st["ms_poa_kernel"] > 0
+    for b in bs:
+        b.close()
+
+
 def test_per_call_mirror(lcd, oracle):
     """lcd_collect_noisy_reg_aln_strs through chunk views: digar walk (src/align.c:1392-1458) + 4-bit base unpacking + in-place permutation"""
     import ctypes as C

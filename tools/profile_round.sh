@@ -1,13 +1,13 @@
 #!/bin/bash
-# rocprofv3 runs behind profiles/: kernel trace + stats of the bench command, then the two HBM PMC passes (FETCH_SIZE and
-# WRITE_SIZE cannot share a pass on gfx950).  Usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>
+# rocprofv3 runs behind profiles/: kernel trace + stats of the default bench command, then the two HBM PMC passes (FETCH_SIZE and
+# WRITE_SIZE cannot share a pass on gfx950) on ONE step.  Usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>
 tag=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-CMD="python bench.py --steps 4 --warmup 1 --lanes 1 --cpu-sample 0"
+CMD="python bench.py --steps 32 --warmup 16 --cpu-sample 0"
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o kt -- $CMD > gpurun_out/prof_$tag.log 2>&1
-CMD1="python bench.py --steps 1 --warmup 0 --lanes 1 --cpu-sample 0"
+CMD1="python bench.py --steps 1 --warmup 0 --lanes 1 --coalesce 1 --cpu-sample 0"
 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch_$tag -o f -- $CMD1 > gpurun_out/pmc_fetch_$tag.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write_$tag -o w -- $CMD1 > gpurun_out/pmc_write_$tag.log 2>&1
 grep -h '"metric"' gpurun_out/prof_$tag.log | tail -1 | cut -c1-200
