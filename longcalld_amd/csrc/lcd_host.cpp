@@ -579,21 +579,20 @@ static long long chain_group_key(const PoaChain &pc) { return (long long)pc.thre
 static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, DevBuf &d_chains, const PoaRead *d_reads, DevBuf &d_outs, LcdScoring sc,
                               hipStream_t *side = nullptr, hipEvent_t *sev = nullptr, DevBuf *d_gate = nullptr) {
     HIPCHK(hipMemcpyAsync(d_chains.p, sub.data(), sub.size() * sizeof(PoaChain), hipMemcpyHostToDevice, st));
-    // wide classes (>= 512 threads: half a CU's vector registers or all of them) start before the narrow ones are let in (lcd_gate_kernel):
-    // `target` = how many of their workgroups fit the chip at once, leaving a share of the CUs to the narrow classes
-    int n_wide = 0, target = 0; bool any_narrow = false;
-    {
-        double cus = 0; const double cap = 0.80 * g_n_cus;
-        for (const PoaChain &pc : sub) {
-            if (pc.threads >= 512) { ++n_wide; const double share = pc.threads >= 1024 ? 1.0 : 0.5; if (cus + share <= cap) { cus += share; ++target; } }
-            else any_narrow = true;
-        }
-    }
+    // The wide classes start first, widest first: a 1 024-thread chain needs ALL the vector registers of a CU and a 512-thread chain half of
+    // them, so once narrower workgroups are spread over the chip they wait for a CU to drain completely -- and they are the longest
+    // chains.  gate[0] / gate[1] count the 1 024- / 512-thread workgroups that have started; the 512-thread launch is held
+    // (lcd_gate_kernel) until target0 of the former are resident, the narrow launches until target1 of the latter are as well.
+    static const int n_streams = std::max(1, std::min(LCD_NSIDE + 1, getenv("LCD_STREAMS") ? atoi(getenv("LCD_STREAMS")) : 4));
+    int n1024 = 0, n512 = 0; bool any_narrow = false;
+    for (const PoaChain &pc : sub) { if (pc.threads >= 1024) ++n1024; else if (pc.threads >= 512) ++n512; else any_narrow = true; }
+    const int cap = (int)(0.80 * g_n_cus); // leave a share of the CUs to the narrow classes from the start
+    const int target0 = std::min(n1024, cap), target1 = std::min(n512, std::max(0, 2 * (cap - target0)));
     int *gate = nullptr;
-    if (side && d_gate && n_wide && any_narrow && target > 0) {
+    if (side && d_gate && n_streams > 1 && (n1024 + n512) > 0 && (any_narrow || (n1024 && n512))) {
         if (d_gate->ensure(64)) return -11;
         gate = (int *)d_gate->p;
-        HIPCHK(hipMemsetAsync(gate, 0, 4, st));
+        HIPCHK(hipMemsetAsync(gate, 0, 8, st));
     }
     if (side) HIPCHK(hipEventRecord(sev[0], st));
     // groups of equal (threads, LDS bucket) -> a small pool of streams (LCD_STREAMS, default 4 with the caller's): every stream is a
@@ -605,15 +604,24 @@ static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, 
     for (size_t i = 0; i < sub.size();) {
         const long long key = chain_group_key(sub[i]);
         size_t j = i; double cost = 0;
-        while (j < sub.size() && chain_group_key(sub[j]) == key) { cost += (double)sub[j].cell_cap * sub[j].n_reads; ++j; }
+        // a group's demand in CU-time: a chain runs ~ reads x rows (a row costs about the same few thousand cycles in every class), and
+        // `per_cu` chains of this (threads, LDS) shape share a CU (160 KB LDS, 16 wavefronts at 128 VGPRs)
+        while (j < sub.size() && chain_group_key(sub[j]) == key) { cost += (double)sub[j].n_reads * (sub[j].max_len + 64); ++j; }
+        {
+            const int lds = sub[i].lds_words * 4, thr = sub[i].threads;
+            const int per_cu = std::max(1, std::min((160 * 1024) / (lds + (thr == 64 ? 1 : 6) * 1024), 1024 / thr));
+            cost /= per_cu;
+        }
         grps.push_back({i, j, cost});
         i = j;
     }
-    static const int n_streams = std::max(1, std::min(LCD_NSIDE + 1, getenv("LCD_STREAMS") ? atoi(getenv("LCD_STREAMS")) : 4));
     const int ns = side ? n_streams : 1;
     std::vector<size_t> order(grps.size());
     for (size_t k = 0; k < order.size(); ++k) order[k] = k;
-    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t c) { return grps[a].cost > grps[c].cost; });
+    // launch order: 1 024-thread groups, then 512-thread groups, then the rest (a gate only ever waits for kernels enqueued before it, so it
+    // cannot deadlock whatever the stream -> hardware-queue mapping is); longest first inside a class
+    auto rank = [&](size_t k) { const int t = chain_threads(sub[grps[k].i]); return t >= 1024 ? 0 : t >= 512 ? 1 : 2; };
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t c) { return rank(a) != rank(c) ? rank(a) < rank(c) : grps[a].cost > grps[c].cost; });
     std::vector<double> load(ns, 0.0);
     std::vector<bool> used(ns, false);
     for (size_t k : order) {
@@ -625,9 +633,9 @@ static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, 
         if (best != 0 && !used[best]) HIPCHK(hipStreamWaitEvent(s, sev[0], 0));
         used[best] = true;
         const int cls = chain_threads(sub[grps[k].i]);
-        if (gate && cls < 512) lcd_launch_gate(gate, target, s);
+        if (gate && cls < 1024 && (target0 > 0 || (cls < 512 && target1 > 0))) lcd_launch_gate(gate, target0, cls < 512 ? target1 : 0, s);
         lcd_launch_poa((const PoaChain *)d_chains.p + grps[k].i, d_reads, nullptr, nullptr, nullptr, (PoaChainOut *)d_outs.p + grps[k].i, sc, (int)(grps[k].j - grps[k].i), cls,
-                       sub[grps[k].i].lds_words * 4, s, cls >= 512 ? gate : nullptr);
+                       sub[grps[k].i].lds_words * 4, s, !gate ? nullptr : cls >= 1024 ? gate : cls >= 512 ? gate + 1 : nullptr);
         HIPCHK(hipGetLastError());
     }
     for (int t = 1; t < ns; ++t) if (used[t]) { HIPCHK(hipEventRecord(sev[t], side[t - 1])); HIPCHK(hipStreamWaitEvent(st, sev[t], 0)); }

@@ -1833,10 +1833,10 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
 // CU; if the thousands of 64-thread chains of the same step are dispatched at the same time they take a few wavefront slots on every
 // CU and the wide chains -- the longest ones, the step's critical path -- wait for a CU to drain completely (measured: 1.09 s instead
 // of 0.39 s for the wide launch).  The narrow classes' streams therefore start with this one-lane kernel.
-__global__ void lcd_gate_kernel(const int *ctr, int target) {
-    while (__atomic_load_n(ctr, __ATOMIC_RELAXED) < target) __builtin_amdgcn_s_sleep(32);
+__global__ void lcd_gate_kernel(const int *ctr, int target0, int target1) {
+    while (__atomic_load_n(ctr, __ATOMIC_RELAXED) < target0 || __atomic_load_n(ctr + 1, __ATOMIC_RELAXED) < target1) __builtin_amdgcn_s_sleep(32);
 }
-void lcd_launch_gate(const int *ctr, int target, hipStream_t stream) { hipLaunchKernelGGL(lcd_gate_kernel, dim3(1), dim3(1), 0, stream, ctr, target); }
+void lcd_launch_gate(const int *ctr, int target0, int target1, hipStream_t stream) { hipLaunchKernelGGL(lcd_gate_kernel, dim3(1), dim3(1), 0, stream, ctr, target0, target1); }
 
 void lcd_launch_poa(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool, uint8_t *arena, uint8_t *outpool,
                     PoaChainOut *outs, LcdScoring sc, int n_chains, int threads, int lds_bytes, hipStream_t stream, int *gate) {
