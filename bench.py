@@ -89,7 +89,15 @@ def main():
     acc = {"ms": 0.0, "launches": 0, "st": None, "alg": 0.0, "cells": 0.0}
     lock = threading.Lock()
 
+    lane_errors = []
+
     def lane_work(grp, sizes, record):
+        try:
+            _lane_work(grp, sizes, record)
+        except Exception as e:  # noqa: surfaced after the join (a thread's traceback alone would leave a half-measured line)
+            lane_errors.append(e)
+
+    def _lane_work(grp, sizes, record):
         for k in sizes:
             align.RegionBatch.run_many(grp[:k])
             if record:
@@ -107,6 +115,8 @@ def main():
             t.start()
         for t in ths:
             t.join()
+        if lane_errors:
+            raise lane_errors[0]
 
     run_steps(max(args.warmup, n_lanes * n_co if args.warmup else 0), False)   # every lane warms its buffers at least once
     barrier()

@@ -964,9 +964,13 @@ __device__ __attribute__((noinline)) int align_windowed(Ctx g, const unsigned ri
 // stored like the others and never read, so there is no band mask.  E planes hold E + e ("E-out before the extension
 // charge"): max(H - o, Ein), one subtraction less per cell; the reader folds the -e into the edge bonus.
 constexpr int SYS_D = 16;
-__device__ __forceinline__ void poll_ge(const int *p, const int v) { // p is in LDS (g_smem): volatile ds_read, no flat access
+// returns false if the neighbour did not get there within ~2^26 polls (seconds): cannot happen unless the kernel is broken, but a bounded
+// spin turns such a bug into an error status instead of a hung GPU
+__device__ __forceinline__ bool poll_ge(const int *p, const int v) { // p is in LDS: volatile ds_read, no flat access
     const volatile lcd_lds_i32 *q = (const volatile lcd_lds_i32 *)(uintptr_t)lds_off(p);
-    while (*q < v) __builtin_amdgcn_s_sleep(1);
+    int spins = 0;
+    while (*q < v) { __builtin_amdgcn_s_sleep(1); if (++spins > (1 << 26)) return false; }
+    return true;
 }
 
 template <int NT>
@@ -1066,8 +1070,10 @@ __device__ __attribute__((noinline)) int align_unbanded(Ctx g, const unsigned ri
             const int s = (idx - bi) & (K - 1);
             const long long tq0 = clock64();
             if (SYS) {
-                if (wave + 1 < AW) poll_ge(&g_wide.prog[wave + 1], idx - (SYS_D - K - 1)); // mailbox slot (idx mod SYS_D) is free again
-                if (wave > 0) poll_ge(&g_wide.prog[wave - 1], idx);                          // left neighbour has published this row
+                bool ok = true;
+                if (wave + 1 < AW) ok = poll_ge(&g_wide.prog[wave + 1], idx - (SYS_D - K - 1)); // mailbox slot (idx mod SYS_D) is free again
+                if (ok && wave > 0) ok = poll_ge(&g_wide.prog[wave - 1], idx);                   // left neighbour has published this row
+                if (!ok) { err = LCD_ERR_SYNC; if (lane == 0) g_smem.bc[7] = LCD_ERR_SYNC; break; }
                 asm volatile("" ::: "memory");
             }
             t_poll += (unsigned long long)(clock64() - tq0);
@@ -1834,7 +1840,12 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
 // CU and the wide chains -- the longest ones, the step's critical path -- wait for a CU to drain completely (measured: 1.09 s instead
 // of 0.39 s for the wide launch).  The narrow classes' streams therefore start with this one-lane kernel.
 __global__ void lcd_gate_kernel(const int *ctr, int target0, int target1) {
-    while (__atomic_load_n(ctr, __ATOMIC_RELAXED) < target0 || __atomic_load_n(ctr + 1, __ATOMIC_RELAXED) < target1) __builtin_amdgcn_s_sleep(32);
+    // bounded (about 2 s): the gate is a scheduling hint, never a correctness condition -- if the wide launches failed or are held
+    // back by something else the narrow classes simply start
+    for (int spins = 0; spins < (1 << 21); ++spins) {
+        if (__atomic_load_n(ctr, __ATOMIC_RELAXED) >= target0 && __atomic_load_n(ctr + 1, __ATOMIC_RELAXED) >= target1) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
 }
 void lcd_launch_gate(const int *ctr, int target0, int target1, hipStream_t stream) { hipLaunchKernelGGL(lcd_gate_kernel, dim3(1), dim3(1), 0, stream, ctr, target0, target1); }
 
