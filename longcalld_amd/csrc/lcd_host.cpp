@@ -590,9 +590,9 @@ static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, 
     const int target0 = std::min(n1024, cap), target1 = std::min(n512, std::max(0, 2 * (cap - target0)));
     int *gate = nullptr;
     if (side && d_gate && n_streams > 1 && (n1024 + n512) > 0 && (any_narrow || (n1024 && n512))) {
-        if (d_gate->ensure(64)) return -11;
+        if (d_gate->ensure(256)) return -11;
         gate = (int *)d_gate->p;
-        HIPCHK(hipMemsetAsync(gate, 0, 8, st));
+        HIPCHK(hipMemsetAsync(gate, 0, 128, st));
     }
     if (side) HIPCHK(hipEventRecord(sev[0], st));
     // groups of equal (threads, LDS bucket) -> a small pool of streams (LCD_STREAMS, default 4 with the caller's): every stream is a
@@ -639,6 +639,7 @@ static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, 
         HIPCHK(hipGetLastError());
     }
     for (int t = 1; t < ns; ++t) if (used[t]) { HIPCHK(hipEventRecord(sev[t], side[t - 1])); HIPCHK(hipStreamWaitEvent(st, sev[t], 0)); }
+    if (gate && getenv("LCD_GATE_DEBUG")) { int h[8]; hipStreamSynchronize(st); hipMemcpy(h, gate, 32, hipMemcpyDeviceToHost); fprintf(stderr, "[gate] started: %d x 1024-thread, %d x 512-thread workgroups; longest gate wait %d polls (targets %d, %d)\n", h[0], h[1], h[4], target0, target1); }
     return 0;
 }
 

@@ -5,7 +5,7 @@
 
 void lcd_launch_poa(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool, uint8_t *arena, uint8_t *outpool,
                     PoaChainOut *outs, LcdScoring sc, int n_chains, int threads, int lds_bytes, hipStream_t stream, int *gate = nullptr);
-void lcd_launch_gate(const int *ctr, int target0, int target1, hipStream_t stream);
+void lcd_launch_gate(int *ctr, int target0, int target1, hipStream_t stream);
 void lcd_launch_wfa(const WfaJob *jobs, const uint8_t *pool, uint8_t *arena, uint8_t *outpool, WfaOut *outs, LcdScoring sc,
                     int n_jobs, hipStream_t stream);
 void lcd_launch_edlib(const EdJob *jobs, const uint8_t *pool, uint8_t *arena, EdOut *outs, int n_jobs, hipStream_t stream);

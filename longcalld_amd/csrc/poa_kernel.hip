@@ -687,11 +687,12 @@ struct WinOut { int status; unsigned long long t_dp, t_bt, cells; int cig_pos; u
 // (not inlined, context by value: the row loop then only carries the dozen pointers it uses instead of the chain's whole
 //  context -- inlined, hipcc spilled the scalar registers of ~45 pointers into VGPR lanes and re-read them every row)
 template <int NT, bool BANDED>
-__device__ __attribute__((noinline)) int align_windowed(Ctx g, const unsigned ring_, const unsigned sq1_, const unsigned pd_ /* 0xffffffff: none */, const LcdScoring sc_, const int w_,
+__device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const unsigned ring_, const unsigned sq1_, const unsigned pd_ /* 0xffffffff: none */, const LcdScoring sc_, const int w_,
                               const int bi_, const int ei_, const int rem_beg_, const uint8_t *seq_hbm_, const int qlen_,
                               WinOut *wo_) {
     constexpr int NW = NT / 64, K = Cfg<NT>::K;
     Smem &sm = g_smem;
+    Ctx g = *usgpr(gp_); // (by pointer: a by-value context is 440 B of outgoing-argument stack per call site and per lane)
     ctx_to_sgpr(g);
     const unsigned ring = usgpr(ring_), sq1 = usgpr(sq1_), pd = usgpr(pd_);
     const int w = usgpr(w_), bi = usgpr(bi_), ei = usgpr(ei_), rem_beg = usgpr(rem_beg_), qlen = usgpr(qlen_);
@@ -974,11 +975,12 @@ __device__ __forceinline__ bool poll_ge(const int *p, const int v) { // p is in 
 }
 
 template <int NT>
-__device__ __attribute__((noinline)) int align_unbanded(Ctx g, const unsigned ring_, const unsigned pd_ /* 0xffffffff: none */, const LcdScoring sc_,
+__device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const unsigned ring_, const unsigned pd_ /* 0xffffffff: none */, const LcdScoring sc_,
                                                         const int bi_, const int ei_, const uint8_t *seq_hbm_, const int qlen_, WinOut *wo_) {
     constexpr int NW = NT / 64, K = Cfg<NT>::K;
     constexpr bool SYS = NW > 1;
     Smem &sm = g_smem;
+    Ctx g = *usgpr(gp_); // (by pointer: a by-value context is 440 B of outgoing-argument stack per call site and per lane)
     ctx_to_sgpr(g);
     const unsigned ring = usgpr(ring_), pd = usgpr(pd_);
     const int bi = usgpr(bi_), ei = usgpr(ei_), qlen = usgpr(qlen_);
@@ -1243,9 +1245,9 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0; wo.t_plan = wo.t_poll = 0;
         const int rem_beg = g.remain[beg_node] - remain_end;
         const unsigned pdo = pd ? lds_off(pd) : 0xffffffffu;
-        int nc = wb < 0 ? align_unbanded<NT>(g, lds_off(ring), pdo, sc, bi, ei, seq_hbm, qlen, &wo)
-                        : align_windowed<NT, true>(g, lds_off(ring), lds_off(sseq), pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
-        if (nc < 0 && wb < 0) { __syncthreads(); nc = align_windowed<NT, false>(g, lds_off(ring), lds_off(sseq), pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+        int nc = wb < 0 ? align_unbanded<NT>(&g, lds_off(ring), pdo, sc, bi, ei, seq_hbm, qlen, &wo)
+                        : align_windowed<NT, true>(&g, lds_off(ring), lds_off(sseq), pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+        if (nc < 0 && wb < 0) { __syncthreads(); nc = align_windowed<NT, false>(&g, lds_off(ring), lds_off(sseq), pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
         if (nc >= 0) {
             g.status = wo.status; g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells; g.t_plan += wo.t_plan; g.t_poll += wo.t_poll;
             g.cig_node = g.cig_node0 + wo.cig_pos; g.cig_qpos = g.cig_qpos0 + wo.cig_pos;
@@ -1839,15 +1841,18 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
 // CU; if the thousands of 64-thread chains of the same step are dispatched at the same time they take a few wavefront slots on every
 // CU and the wide chains -- the longest ones, the step's critical path -- wait for a CU to drain completely (measured: 1.09 s instead
 // of 0.39 s for the wide launch).  The narrow classes' streams therefore start with this one-lane kernel.
-__global__ void lcd_gate_kernel(const int *ctr, int target0, int target1) {
+__global__ void lcd_gate_kernel(int *ctr, int target0, int target1) {
     // bounded (about 2 s): the gate is a scheduling hint, never a correctness condition -- if the wide launches failed or are held
     // back by something else the narrow classes simply start
     for (int spins = 0; spins < (1 << 21); ++spins) {
-        if (__atomic_load_n(ctr, __ATOMIC_RELAXED) >= target0 && __atomic_load_n(ctr + 1, __ATOMIC_RELAXED) >= target1) break;
+        // (read with a device-scope compare-and-swap that can never succeed: the counters are bumped from all 8 XCDs, whose L2s are not
+        //  coherent with each other; a relaxed load -- and atomicAdd(p, 0), which the compiler folds into one -- is served from this XCD's L2
+        //  and saw the counters ~100 ms late)
+        if (atomicCAS(ctr, -1, -1) >= target0 && atomicCAS(ctr + 1, -1, -1) >= target1) { if (spins > ctr[4]) ctr[4] = spins; break; } // (ctr[4]: longest wait in polls, LCD_GATE_DEBUG)
         __builtin_amdgcn_s_sleep(32);
     }
 }
-void lcd_launch_gate(const int *ctr, int target0, int target1, hipStream_t stream) { hipLaunchKernelGGL(lcd_gate_kernel, dim3(1), dim3(1), 0, stream, ctr, target0, target1); }
+void lcd_launch_gate(int *ctr, int target0, int target1, hipStream_t stream) { hipLaunchKernelGGL(lcd_gate_kernel, dim3(1), dim3(1), 0, stream, ctr, target0, target1); }
 
 void lcd_launch_poa(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool, uint8_t *arena, uint8_t *outpool,
                     PoaChainOut *outs, LcdScoring sc, int n_chains, int threads, int lds_bytes, hipStream_t stream, int *gate) {

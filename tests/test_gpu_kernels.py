@@ -211,3 +211,25 @@ def test_poa_generic_rows_agree_with_windowed(lcd, monkeypatch):
             assert (r == q).all()
         for c in range(x["n_cons"]):
             assert (x["cons"][c] == y["cons"][c]).all() and (x["clu"][c] == y["clu"][c]).all()
+
+
+def test_poa_k2_longer_than_the_window(lcd):
+    """K2 on reads longer than the widest window (4 096 columns): the unbanded rows go through the generic HBM rows.  Too large for the
+    oracle in test time; size-independent properties instead: every MSA row de-gaps to its read, consensus rows de-gap to the consensus,
+    clusters partition the reads, and the two haplotypes are separated"""
+    rng = np.random.default_rng(700)
+    h1 = rng.integers(0, 4, 4600).astype(np.uint8)
+    h2 = h1.copy()
+    for p in range(40, 4560, 300):
+        h2[p] = (h2[p] + 1) % 4
+    reads = [mutate(rng, h1 if i % 2 == 0 else h2, 0.001) for i in range(10)]
+    g = lcd.poa_batch([dict(mode=1, reads=reads)])[0]
+    assert g["status"] == 0 and g["n_cons"] == 2
+    for r, row in zip(reads, g["msa"]):
+        assert (row[row != 5] == r).all()
+    for c in range(2):
+        crow = g["msa"][len(reads) + c]
+        assert (crow[crow != 5] == g["cons"][c]).all()
+    members = sorted(int(x) for c in range(2) for x in g["clu"][c])
+    assert members == list(range(len(reads)))
+    assert {int(x) % 2 for x in g["clu"][0]} in ({0}, {1}) and {int(x) % 2 for x in g["clu"][1]} in ({0}, {1})
