@@ -149,7 +149,7 @@ struct lcd_batch_s {
     std::vector<WfaJob> wfa_jobs;
     // device
     DevBuf d_in, d_chains, d_preads, d_poa_arena, d_poa_out, d_poa_outs, d_ed_jobs, d_ed_arena, d_ed_outs, d_wfa_jobs, d_wfa_arena,
-        d_wfa_out, d_wfa_outs, d_str_jobs, d_str_outs, d_final, d_gate;
+        d_wfa_out, d_wfa_outs, d_str_jobs, d_str_outs, d_final, d_gate, d_cmp_jobs, d_cmp_outs, d_cmp_seg, d_cmp_segres, d_seg_out, d_rr;
     bool uploaded = false, ran = false, downloaded = false;
     // results (host)
     std::vector<PoaChainOut> couts;
@@ -159,6 +159,8 @@ struct lcd_batch_s {
     std::vector<StrJob> str_jobs; std::vector<StrOut> str_outs;
     std::vector<int> str_region, str_clu, str_k;
     std::vector<uint8_t> h_final; std::vector<uint8_t> h_poa_out; std::vector<uint8_t> h_cig;
+    // ref<->read strings (opt.collect_ref_read_aln_str): per string job, rows in d_rr at rr_off (target row, query row at +rr_stride)
+    std::vector<uint64_t> rr_off; std::vector<int> rr_len, rr_stride; std::vector<uint8_t> h_rr; uint64_t rr_bytes = 0;
     uint64_t final_bytes = 0;
     lcd_batch_stats_t st;
 };
@@ -327,7 +329,6 @@ int lcd_batch_add_region(lcd_batch_t *b, int64_t reg_len, int n_reads, const int
                          const uint8_t *const *quals, const int *fully_covers, const int *haps, const int64_t *phase_sets,
                          const uint8_t *ref_seq, int ref_seq_len) {
     const lcd_opt_t &opt = b->opt;
-    if (opt.collect_ref_read_aln_str) return set_err(-2, "collect_ref_read_aln_str (--refine-aln -b / -s) is not implemented on the device path yet");
     b->uploaded = b->ran = b->downloaded = false;
     RegionRec R;
     R.reg_len = reg_len; R.n_reads = n_reads; R.branch = 0; R.chain[0] = R.chain[1] = -1;
@@ -880,6 +881,68 @@ int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
     }
     HIPCHK(hipEventRecord(L->ev[5], st));
     HIPCHK(hipStreamSynchronize(st));
+    // ---------------- S5 (only with opt.collect_ref_read_aln_str): ref<->read strings, src/align.c:1056-1146 ----------------
+    for (int k = 0; k < nb; ++k) { bs[k]->rr_off.clear(); bs[k]->rr_len.clear(); bs[k]->rr_stride.clear(); bs[k]->rr_bytes = 0; }
+    if (L->opt.collect_ref_read_aln_str && !str_all.empty()) {
+        std::vector<CmpJob> cj(str_all.size());
+        uint64_t seg_tot = 0;
+        for (int k = 0; k < nb; ++k) {
+            lcd_batch_t *b = bs[k];
+            std::map<std::pair<int, int>, size_t> rc_of;
+            for (size_t i = 0; i < b->rc_jobs.size(); ++i) rc_of[{b->rc_region[i], b->rc_clu[i]}] = i;
+            uint64_t rr_tot = 0;
+            b->rr_off.resize(b->str_jobs.size()); b->rr_len.assign(b->str_jobs.size(), 0); b->rr_stride.resize(b->str_jobs.size());
+            for (size_t j = 0; j < b->str_jobs.size(); ++j) {
+                const size_t r = rc_of.at({b->str_region[j], b->str_clu[j]});
+                const WfaJob &wj = b->rc_jobs[r]; const StrJob &sj = b->str_jobs[j]; const StrOut &so = str_outs[str_base[k] + j];
+                CmpJob &c = cj[str_base[k] + j];
+                c.rc_t = wj.out_off; c.rc_q = wj.out_off + (uint64_t)(wj.plen + wj.tlen + 1); c.rc_len = b->rc_outs[r].aln_len;
+                c.cr_t = sj.out_off + so.shift; c.cr_q = sj.out_off + sj.msa_len + so.shift; c.cr_len = so.aln_len > 0 ? so.aln_len : 0;
+                c.seg_cap = (std::min(c.rc_len, c.cr_len) + 1) / 2 + 1; c.seg_off = seg_tot * 16; seg_tot += c.seg_cap; c.seg_first = 0;
+                b->rr_stride[j] = c.rc_len + c.cr_len; b->rr_off[j] = rr_tot; rr_tot += lcd_align_up(2ull * (c.rc_len + c.cr_len) + 16, 16);
+            }
+            if (b->d_rr.ensure(rr_tot + 64)) return -11;
+            b->rr_bytes = rr_tot;
+            for (size_t j = 0; j < b->str_jobs.size(); ++j) cj[str_base[k] + j].out_off = b->d_rr.addr() + b->rr_off[j];
+        }
+        if (L->d_cmp_jobs.ensure(cj.size() * sizeof(CmpJob)) || L->d_cmp_outs.ensure(cj.size() * sizeof(CmpOut)) || L->d_cmp_seg.ensure(seg_tot * 16 + 64)) return -11;
+        for (auto &c : cj) c.seg_off += L->d_cmp_seg.addr();
+        HIPCHK(hipMemcpyAsync(L->d_cmp_jobs.p, cj.data(), cj.size() * sizeof(CmpJob), hipMemcpyHostToDevice, st));
+        lcd_launch_compose((const CmpJob *)L->d_cmp_jobs.p, (CmpOut *)L->d_cmp_outs.p, nullptr, (int)cj.size(), 0, st);
+        HIPCHK(hipGetLastError());
+        std::vector<CmpOut> co(cj.size());
+        std::vector<int> hseg(seg_tot * 4);
+        HIPCHK(hipMemcpyAsync(co.data(), L->d_cmp_outs.p, cj.size() * sizeof(CmpOut), hipMemcpyDeviceToHost, st));
+        if (seg_tot) HIPCHK(hipMemcpyAsync(hseg.data(), L->d_cmp_seg.p, seg_tot * 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        // the both-gap segments become one WFA stage (their rows go to a buffer of their own: d_wfa_out still holds the ref<->cons rows)
+        std::vector<WfaJob> sj2; std::vector<CmpSeg> sres;
+        for (size_t i = 0; i < cj.size(); ++i) {
+            if (co[i].n_seg > cj[i].seg_cap) return set_err(-22, "ref<->read composition: segment list overflow");
+            cj[i].seg_first = (int)sj2.size();
+            const int *sg = hseg.data() + (cj[i].seg_off - L->d_cmp_seg.addr()) / 4;
+            for (int q = 0; q < co[i].n_seg; ++q) {
+                WfaJob w; w.p_off = cj[i].rc_t + sg[4 * q]; w.plen = sg[4 * q + 1]; w.t_off = cj[i].cr_q + sg[4 * q + 2]; w.tlen = sg[4 * q + 3];
+                w.gap_aln = L->opt.gap_aln; w.want = 2; w.s_cap = wfa_default_scap(w.plen, w.tlen); w.ws_off = w.ws_bytes = w.out_off = 0;
+                sj2.push_back(w);
+            }
+        }
+        if (!sj2.empty()) {
+            std::vector<WfaOut> so2;
+            int rc2 = run_wfa_stage(st, sj2, L->d_wfa_jobs, L->d_wfa_arena, L->d_seg_out, L->d_wfa_outs, so2, sc, nullptr);
+            if (rc2) return rc2;
+            sres.resize(sj2.size());
+            for (size_t q = 0; q < sj2.size(); ++q) { sres[q].rows_off = sj2[q].out_off; sres[q].aln_len = so2[q].aln_len; sres[q].row_stride = sj2[q].plen + sj2[q].tlen + 1; }
+            if (L->d_cmp_segres.ensure(sres.size() * sizeof(CmpSeg))) return -11;
+            HIPCHK(hipMemcpyAsync(L->d_cmp_segres.p, sres.data(), sres.size() * sizeof(CmpSeg), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(L->d_cmp_jobs.p, cj.data(), cj.size() * sizeof(CmpJob), hipMemcpyHostToDevice, st));
+        }
+        lcd_launch_compose((const CmpJob *)L->d_cmp_jobs.p, (CmpOut *)L->d_cmp_outs.p, (const CmpSeg *)L->d_cmp_segres.p, (int)cj.size(), 1, st);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(co.data(), L->d_cmp_outs.p, cj.size() * sizeof(CmpOut), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int k = 0; k < nb; ++k) for (size_t j = 0; j < bs[k]->str_jobs.size(); ++j) bs[k]->rr_len[j] = co[str_base[k] + j].aln_len;
+    }
     float ms_anchor = 0, ms_poa = 0, ms_wfa = 0, ms_str = 0, ms_tot = 0;
     hipEventElapsedTime(&ms_anchor, L->ev[0], L->ev[1]); hipEventElapsedTime(&ms_poa, L->ev[1], L->ev[2]);
     hipEventElapsedTime(&ms_wfa, L->ev[3], L->ev[4]); hipEventElapsedTime(&ms_str, L->ev[4], L->ev[5]); hipEventElapsedTime(&ms_tot, L->ev[0], L->ev[5]);
@@ -947,6 +1010,8 @@ int lcd_batch_download(lcd_batch_t *b) {
     for (size_t i = 0; i < b->rc_jobs.size(); ++i)
         HIPCHK(hipMemcpyAsync(b->h_final.data() + rc_off[i], (void *)(uintptr_t)b->rc_jobs[i].out_off, 2ull * (b->rc_jobs[i].plen + b->rc_jobs[i].tlen + 1), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    b->h_rr.resize(b->rr_bytes);
+    if (b->rr_bytes) HIPCHK(hipMemcpyAsync(b->h_rr.data(), b->d_rr.p, b->rr_bytes, hipMemcpyDeviceToHost, st));
     // cluster id lists of the K2 chains, for lcd_batch_region_result: stored as [ch:int][n:int][ids...]
     {
         const int nC = (int)b->pchains.size();
@@ -1041,6 +1106,14 @@ int lcd_batch_region_result(lcd_batch_t *b, int region, int *clu_n_seqs, int **c
             s.target_aln = mem; s.query_aln = mem + sj.msa_len;
         }
         s.aln_len = so.aln_len; s.target_beg = so.target_beg; s.target_end = so.target_end; s.query_beg = so.query_beg; s.query_end = so.query_end;
+        if (!b->rr_len.empty()) { // ref<->read string, src/align.c:1056-1062 layout: one block of 2 * (rc_len + cr_len), query row at + max_len
+            const int ml = b->rr_stride[j];
+            uint8_t *mem = (uint8_t *)malloc((size_t)ml * 2 + 1);
+            memcpy(mem, b->h_rr.data() + b->rr_off[j], (size_t)b->rr_len[j]); memcpy(mem + ml, b->h_rr.data() + b->rr_off[j] + ml, (size_t)b->rr_len[j]);
+            lcd_aln_str_t &r2 = aln_strs[c][2 * k + 2];
+            r2.target_aln = mem; r2.query_aln = mem + ml; r2.aln_len = b->rr_len[j];
+            r2.target_beg = r2.target_end = r2.query_beg = r2.query_end = -1;
+        }
     }
     return R.n_cons;
 }

@@ -164,6 +164,20 @@ struct StrOut {
     int shift;                   // right-cover trim: rows start at +shift (the reference re-allocates, :541-549)
 };
 
+// ---------------- ref<->read string by composing ref<->cons with cons<->read (make_ref_read_aln_str, src/align.c:1056-1146) ----------------
+// Two passes around one WFA stage: the scan pass finds the stretches where BOTH alignments have a gap on the consensus side (the reference
+// aligns the two inserted segments with wfa_end2end_aln, :1083) and records them; the emit pass writes the rows, splicing in the WFA rows.
+struct CmpJob {
+    uint64_t rc_t, rc_q;   // ref<->cons rows (ref row, cons row), absolute device addresses
+    uint64_t cr_t, cr_q;   // cons<->read rows (cons row, read row)
+    int rc_len, cr_len;
+    uint64_t seg_off;      // int4 per segment: (i, ref_len, j, read_len)
+    int seg_cap, seg_first; // capacity of the segment list; index of this job's first segment in the WFA stage (emit pass)
+    uint64_t out_off;      // target row at out_off, query row at out_off + rc_len + cr_len (:1060-1061)
+};
+struct CmpOut { int n_seg, aln_len; };
+struct CmpSeg { uint64_t rows_off; int aln_len, row_stride; }; // WFA rows of one segment: pattern row at rows_off, text row at + row_stride
+
 // ---------------- K5: haplotype assignment (src/assign_hap.c:473-547) ----------------
 // bam_chunk_t / cand_var_t / read_var_profile_t flattened; every pointer is an absolute device address.
 struct HapProb {

@@ -67,3 +67,43 @@ void lcd_launch_strings(const StrJob *jobs, uint8_t *pool, StrOut *outs, int n_j
     if (n_jobs <= 0) return;
     hipLaunchKernelGGL(lcd_strings_kernel, dim3(n_jobs), dim3(64), 0, stream, jobs, pool, outs, n_jobs);
 }
+
+
+// ---- make_ref_read_aln_str (src/align.c:1056-1146): one lane per (cluster, read); the walk is inherently serial per pair ----
+// emit == 0: scan pass (records the both-gap segments, counts the rest of the output); emit == 1: writes the rows.
+__global__ void __launch_bounds__(64) lcd_compose_kernel(const CmpJob *jobs, CmpOut *outs, const CmpSeg *segs, int n_jobs, int emit) {
+    const int jid = blockIdx.x * 64 + threadIdx.x;
+    if (jid >= n_jobs) return;
+    const CmpJob jb = jobs[jid];
+    const uint8_t *rt = (const uint8_t *)(uintptr_t)jb.rc_t, *rq = (const uint8_t *)(uintptr_t)jb.rc_q;
+    const uint8_t *ct = (const uint8_t *)(uintptr_t)jb.cr_t, *cq = (const uint8_t *)(uintptr_t)jb.cr_q;
+    int4 *seg = (int4 *)(uintptr_t)jb.seg_off;
+    uint8_t *ot = (uint8_t *)(uintptr_t)jb.out_off, *oq = ot + (jb.rc_len + jb.cr_len);
+    int i = 0, j = 0, n = 0, nseg = 0;
+    while (i < jb.rc_len && j < jb.cr_len) {
+        const bool g1 = rq[i] == 5, g2 = ct[j] == 5;
+        if (g1 && g2) { // both are gaps on the consensus: the reference aligns the ref segment with the read segment (:1065-1090)
+            int rd = 1, qd = 1;
+            while (i + rd < jb.rc_len && rq[i + rd] == 5) ++rd;
+            while (j + qd < jb.cr_len && ct[j + qd] == 5) ++qd;
+            if (!emit) { if (nseg < jb.seg_cap) seg[nseg] = make_int4(i, rd, j, qd); }
+            else {
+                const CmpSeg sg = segs[jb.seg_first + nseg];
+                const uint8_t *pr = (const uint8_t *)(uintptr_t)sg.rows_off, *tr = pr + sg.row_stride;
+                for (int k = 0; k < sg.aln_len; ++k) { ot[n + k] = pr[k]; oq[n + k] = tr[k]; }
+                n += sg.aln_len;
+            }
+            ++nseg; i += rd; j += qd;
+        } else if (!g1 && !g2) { if (emit) { ot[n] = rt[i]; oq[n] = cq[j]; } ++n; ++i; ++j; }
+        else if (g1) { if (emit) { ot[n] = rt[i]; oq[n] = 5; } ++n; ++i; }
+        else { if (emit) { ot[n] = 5; oq[n] = cq[j]; } ++n; ++j; }
+    }
+    for (; i < jb.rc_len; ++i, ++n) if (emit) { ot[n] = rt[i]; oq[n] = 5; }
+    for (; j < jb.cr_len; ++j, ++n) if (emit) { ot[n] = 5; oq[n] = cq[j]; }
+    outs[jid].n_seg = nseg; outs[jid].aln_len = n;
+}
+
+void lcd_launch_compose(const CmpJob *jobs, CmpOut *outs, const CmpSeg *segs, int n_jobs, int emit, hipStream_t stream) {
+    if (n_jobs <= 0) return;
+    hipLaunchKernelGGL(lcd_compose_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, stream, jobs, outs, segs, n_jobs, emit);
+}

@@ -8,8 +8,8 @@ from conftest import same_result
 pytestmark = pytest.mark.gpu
 
 
-def _run_batch(lcd, regs):
-    b = lcd.RegionBatch()
+def _run_batch(lcd, regs, opt=None):
+    b = lcd.RegionBatch(opt)
     for r in regs:
         b.add_region(r)
     b.upload(); b.run(); b.download()
@@ -76,6 +76,24 @@ def test_run_is_idempotent_and_order_independent(lcd):
     assert d1 == d2 and d1 != 0
     got, _, _, _ = _run_batch(lcd, [regs[5]])
     same_result(one, got[0])
+
+
+@pytest.mark.parametrize("shape,seed,n", [("hifi", 41, 20), ("ont", 42, 8)])
+def test_ref_read_strings_match_oracle(lcd, oracle, shape, seed, n):
+    """collect_ref_read_aln_str (--refine-aln -b / -s): make_ref_read_aln_str (src/align.c:1056-1146) composes ref<->cons with cons<->read
+    and re-aligns the stretches where both have an insertion against the consensus -- every aln_strs[c][2k+2] == oracle"""
+    from longcalld_amd import jobs
+    regs = jobs.make_regions(seed, n, jobs.HIFI if shape == "hifi" else jobs.ONT)
+    o_dev = lcd.default_opt(); o_dev.collect_ref_read_aln_str = 1
+    o_cpu = oracle.default_opt(); o_cpu.collect_ref_read_aln_str = 1
+    got, _, _, _ = _run_batch(lcd, regs, o_dev)
+    n_rr = 0
+    for r, g in zip(regs, got):
+        exp = oracle.collect_noisy_reg_aln_strs(r, o_cpu)
+        same_result(exp, g)
+        for c in range(g["n_cons"]):
+            n_rr += sum(1 for j, a in enumerate(g["aln_strs"][c]) if j >= 2 and j % 2 == 0 and a is not None)
+    assert n_rr > 0
 
 
 def test_run_many_equals_separate_runs(lcd):
