@@ -852,6 +852,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
         if (overflow) return -1;
         if (np > 256) { wo->status = LCD_ERR_NODES; return 0; } // ordinals are 8 bits
         const int h0 = imax(n0, imax(u0, v0)), h1 = imax(n1, imax(u1, v1)), h2 = imax(n2, imax(u2, v2)), h3 = imax(n3, imax(u3, v3)); // Hpre
+        const int sp0 = n0 == h0 ? 0 : u0 == h0 ? 1 : 2, sp1 = n1 == h1 ? 0 : u1 == h1 ? 1 : 2, sp2 = n2 == h2 ? 0 : u2 == h2 ? 1 : 2, sp3 = n3 == h3 ? 0 : u3 == h3 ? 1 : 2;
         // ---- F: A[k] = Hpre[k] + k*e; in-lane inclusive prefix, then one scan pair over the lane totals ----
         const int je1 = jb * e1, je2 = jb * e2;
         const int a10 = i0 ? h0 + je1 : LCD_GUARD, a11 = i1 ? h1 + je1 + e1 : LCD_GUARD, a12 = i2 ? h2 + je1 + 2 * e1 : LCD_GUARD, a13 = i3 ? h3 + je1 + 3 * e1 : LCD_GUARD;
@@ -877,26 +878,26 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
             const int h = imax(hp, imax(f1, f2));                                                                           \
             int eo1 = imax(h - oe1, (ev1) - e1), eo2 = imax(h - oe2, (ev2) - e2);                                           \
             if (BANDED) { eo1 = imax(eo1, LCD_NEG); eo2 = imax(eo2, LCD_NEG); }                                             \
-            const int hs = (mxv) == h ? 0 : (ev1) == h ? 1 : (ev2) == h ? 2 : f1 == h ? (f2 == h ? 5 : 3) : 4;              \
+            const int fk = f1 == h ? (f2 == h ? 5 : 3) : 4;                                                                 \
+            const int hs = (hp) == h ? (mxv) : fk; /* (mxv): which of match / E1 / E2 gives Hpre, the oracle's priority */   \
             const unsigned cd = (unsigned)hs | ((pf1) > (ak1) ? CB_Y1 : 0) | ((pf2) > (ak2) ? CB_Y2 : 0) |                  \
                                 (h - oe1 >= (ev1) - e1 ? CB_O1 : 0) | (h - oe2 >= (ev2) - e2 ? CB_O2 : 0) |                 \
                                 (((om >> (8 * (k))) & 255) ? CB_PM : 0);                                                    \
             code |= cd << (8 * (k));                                                                                        \
             HO = (inb) ? h : LCD_GUARD; AO = (inb) ? eo1 : LCD_GUARD; BO = (inb) ? eo2 : LCD_GUARD;                         \
         }
-        LCD_CELL(0, i0, h0, n0, u0, v0, x1, x2, a10, a20, hh0, ea0, eb0)
-        LCD_CELL(1, i1, h1, n1, u1, v1, imax(x1, p10), imax(x2, p20), a11, a21, hh1, ea1, eb1)
-        LCD_CELL(2, i2, h2, n2, u2, v2, imax(x1, p11), imax(x2, p21), a12, a22, hh2, ea2, eb2)
-        LCD_CELL(3, i3, h3, n3, u3, v3, imax(x1, p12), imax(x2, p22), a13, a23, hh3, ea3, eb3)
+        LCD_CELL(0, i0, h0, sp0, u0, v0, x1, x2, a10, a20, hh0, ea0, eb0)
+        LCD_CELL(1, i1, h1, sp1, u1, v1, imax(x1, p10), imax(x2, p20), a11, a21, hh1, ea1, eb1)
+        LCD_CELL(2, i2, h2, sp2, u2, v2, imax(x1, p11), imax(x2, p21), a12, a22, hh2, ea2, eb2)
+        LCD_CELL(3, i3, h3, sp3, u3, v3, imax(x1, p12), imax(x2, p22), a13, a23, hh3, ea3, eb3)
 #undef LCD_CELL
         // ---- row maximum, leftmost / rightmost column (banded rows only: w = qlen never consumes them) ----
         int ml = 0, mr = 0;
         if (BANDED) {
-            int hb = LCD_GUARD, bl = 0, brr = 0;
-            if (i0) { hb = hh0; bl = jb; brr = jb; }
-            if (i1) { if (hh1 > hb) { hb = hh1; bl = jb + 1; brr = jb + 1; } else if (hh1 == hb) brr = jb + 1; }
-            if (i2) { if (hh2 > hb) { hb = hh2; bl = jb + 2; brr = jb + 2; } else if (hh2 == hb) brr = jb + 2; }
-            if (i3) { if (hh3 > hb) { hb = hh3; bl = jb + 3; brr = jb + 3; } else if (hh3 == hb) brr = jb + 3; }
+            // (the out-of-band cells already hold LCD_GUARD, below every real H)
+            const int hb = imax(imax(hh0, hh1), imax(hh2, hh3));
+            const int bl = hh0 == hb ? jb : hh1 == hb ? jb + 1 : hh2 == hb ? jb + 2 : jb + 3;
+            const int brr = hh3 == hb ? jb + 3 : hh2 == hb ? jb + 2 : hh1 == hb ? jb + 1 : jb;
             const int wm = lane63(scan_max(hb));
             const unsigned long long mk = __ballot(hb == wm && hb > LCD_GUARD);
             int wl = 1 << 30, wr = -1;
