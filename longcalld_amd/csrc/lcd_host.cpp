@@ -10,6 +10,7 @@
 // stage can live in its own grow-only hipMalloc buffer.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <array>
 #include <chrono>
 #include <cmath>
@@ -517,6 +518,7 @@ int lcd_batch_upload(lcd_batch_t *b) {
     return 0;
 }
 
+static std::atomic<int> g_cell_hint[2] = {{0}, {0}}; // per mode (K1, K2): 0..2, see chain_caps
 static void chain_class(PoaChain &pc);
 static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vector<PoaRead> &preads, int scale, PoaChain &pc) {
     const int n = (int)C.members.size();
@@ -535,9 +537,14 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     // rows actually visited ~ graph size ~ a small multiple of the backbone; band ~ 2w+1 plus drift.  Overflow is detected
     // in-kernel (LCD_ERR_CELLS) and the chain is re-run with `scale` x more, up to the worst case.
     const long long rows_worst = pc.node_cap;
-    const long long rows_est = std::min<long long>(rows_worst, (long long)(1.3 * maxl) + 64);
+    // g_cell_hint[mode]: learned from the overflow retries of earlier submissions (noisy reads: every read adds ~error-rate new nodes,
+    // and the row-max columns that steer the adaptive band drift further) -- a chain that overflows is re-run from scratch, so data that
+    // keeps overflowing is given the larger estimate up front
+    const int hint = g_cell_hint[C.mode ? 1 : 0].load();
+    static const double rows_f[3] = {1.3, 2.2, 3.2}; static const int band_x[3] = {64, 128, 192};
+    const long long rows_est = std::min<long long>(rows_worst, (long long)(rows_f[hint] * maxl) + 64);
     long long band;
-    if (C.mode == 0) band = std::min<long long>(maxl + 1, 2ll * (10 + maxl / 100) + 1 + 64);
+    if (C.mode == 0) band = std::min<long long>(maxl + 1, 2ll * (10 + maxl / 100) + 1 + band_x[hint]);
     else band = maxl + 1;
     long long cells = rows_est * band;
     const long long worst = rows_worst * (long long)(maxl + 1);
@@ -798,6 +805,12 @@ int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
                 bs[k]->couts[which[i] - chain_base[k]] = tmp[i];
                 if (tmp[i].status == LCD_ERR_CELLS) again.push_back(which[i]);
                 else if (tmp[i].status != LCD_OK) return set_err(-20, "POA kernel status " + std::to_string(tmp[i].status) + " on chain " + std::to_string(which[i] - chain_base[k]));
+            }
+            if (round == 0) { // learn: more than 5 % of a mode's chains overflowed their DP region -> start from the next estimate next time
+                int tot[2] = {0, 0}, ovf[2] = {0, 0};
+                for (size_t g = 0; g < nC_all; ++g) tot[PC(g).mode ? 1 : 0]++;
+                for (size_t g : again) ovf[PC(g).mode ? 1 : 0]++;
+                for (int m = 0; m < 2; ++m) if (tot[m] && ovf[m] * 20 > tot[m] && g_cell_hint[m].load() < 2) g_cell_hint[m]++;
             }
             if (!again.empty()) { for (int k = 0; k < nb; ++k) bs[k]->st.poa_retries++; scale *= 2; }
             which.swap(again);
