@@ -997,7 +997,8 @@ int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
             for (size_t g = 0; g < nC_all; ++g) { if (chain_threads(PC(g)) != cls) continue; const PoaChainOut &o = bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]]; ++cnt;
                 tt += o.t_total; td += o.t_dp; tb += o.t_bt; tg += o.t_graph; to += o.t_out; ts += o.t_sub; if (o.t_total >= mx) { mx = o.t_total; mxc = g; } }
             if (!cnt) continue;
-            fprintf(stderr, "[lcd] class %4d: %5d chains  sum ticks total %.3e dp %.3e bt %.3e graph %.3e sub %.3e out %.3e\n", cls, cnt, (double)tt, (double)td, (double)tb, (double)tg, (double)ts, (double)to);
+            { double tk = 0; for (size_t g = 0; g < nC_all; ++g) if (chain_threads(PC(g)) == cls) tk += (double)bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]].t_poll;
+              fprintf(stderr, "[lcd] class %4d: %5d chains  sum ticks total %.3e dp %.3e bt %.3e graph %.3e (of which serial Kahn walk %.3e) sub %.3e out %.3e\n", cls, cnt, (double)tt, (double)td, (double)tb, (double)tg, tk, (double)ts, (double)to); }
             const PoaChainOut &o = bs[chain_batch[mxc]]->couts[mxc - chain_base[chain_batch[mxc]]];
             fprintf(stderr, "[lcd]   slowest chain %zu: mode %d reads %d maxlen %d nodes %d  total %.3e dp %.3e bt %.3e graph %.3e sub %.3e out %.3e cells %llu\n", mxc, PC(mxc).mode,
                     PC(mxc).n_reads, PC(mxc).max_len, o.n_node, (double)o.t_total, (double)o.t_dp, (double)o.t_bt, (double)o.t_graph, (double)o.t_sub, (double)o.t_out, o.cells);

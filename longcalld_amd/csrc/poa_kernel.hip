@@ -71,7 +71,7 @@ struct Ctx {
     int n_node, n_edge, node_cap, edge_cap, rid_words;
     unsigned long long cell_cap;
     int status;
-    unsigned long long t_dp, t_bt, t_plan, t_poll;
+    unsigned long long t_dp, t_bt, t_plan, t_poll, t_kahn;
 };
 
 __device__ __forceinline__ int ilog2_32(int v) { return 31 - __clz(v); }
@@ -253,12 +253,13 @@ __device__ int block_excl_scan(int v, Smem &sm, int *total) { // exclusive prefi
     return woff + incl - v;
 }
 
+// returns 0: nothing changed, 1: only edge weights / read sets changed (the topological order stands, `remain` may not), 2: nodes or edges were added
 template <int NT>
-__device__ bool add_alignment_block(Ctx &g, Smem &sm, int beg_node, int end_node, const uint8_t *seq, int len, int n_cig, int read_id) {
+__device__ int add_alignment_block(Ctx &g, Smem &sm, int beg_node, int end_node, const uint8_t *seq, int len, int n_cig, int read_id) {
     const int tid = threadIdx.x;
     const int rw = read_id >> 6; const unsigned long long rbit = 1ull << (read_id & 63);
     if (g.n_node == 2) { // first read: a chain source -> bases -> sink (abpoa_add_graph_sequence)
-        if (len + 2 > g.node_cap || len + 1 > g.edge_cap) { g.status = LCD_ERR_NODES; return false; }
+        if (len + 2 > g.node_cap || len + 1 > g.edge_cap) { g.status = LCD_ERR_NODES; return 0; }
         for (int i = tid; i < len; i += NT) {
             const int id = 2 + i;
             g.base[id] = seq[i]; g.in_head[id] = g.in_tail[id] = i; g.out_head[id] = g.out_tail[id] = i + 1; g.nin[id] = 1; g.aligned[id] = id;
@@ -270,9 +271,9 @@ __device__ bool add_alignment_block(Ctx &g, Smem &sm, int beg_node, int end_node
         if (tid == 0) { g.out_head[0] = g.out_tail[0] = 0; g.in_head[1] = g.in_tail[1] = len; g.nin[1] = 1; }
         g.n_node = len + 2; g.n_edge = len + 1;
         __syncthreads();
-        return true;
+        return 2;
     }
-    if (n_cig == 0) return false;
+    if (n_cig == 0) return 0;
     // phase 1: the node each entry lands on: existing (>= 0), new and aligned to an anchor, or plain new
     int carry = 0;
     for (int base = 0; base < n_cig; base += NT) {
@@ -296,7 +297,7 @@ __device__ bool add_alignment_block(Ctx &g, Smem &sm, int beg_node, int end_node
         carry += tot;
     }
     const int n_new = carry;
-    if (g.n_node + n_new > g.node_cap) { g.status = LCD_ERR_NODES; return false; }
+    if (g.n_node + n_new > g.node_cap) { g.status = LCD_ERR_NODES; return 0; }
     __syncthreads();
     // phase 2: new nodes
     for (int i = tid; i < n_cig; i += NT) {
@@ -325,7 +326,7 @@ __device__ bool add_alignment_block(Ctx &g, Smem &sm, int beg_node, int end_node
         carry += tot;
     }
     const int n_newe = carry;
-    if (g.n_edge + n_newe > g.edge_cap) { g.status = LCD_ERR_EDGES; return false; }
+    if (g.n_edge + n_newe > g.edge_cap) { g.status = LCD_ERR_EDGES; return 0; }
     __syncthreads(); // new-node fields (phase 2) and edge numbers are visible
     // phase 4: create + link the new edges
     for (int j = tid; j <= n_cig; j += NT) {
@@ -343,7 +344,7 @@ __device__ bool add_alignment_block(Ctx &g, Smem &sm, int beg_node, int end_node
     }
     g.n_node += n_new; g.n_edge += n_newe;
     __syncthreads();
-    return true;
+    return (n_new || n_newe) ? 2 : 1;
 }
 
 // Kahn BFS order + remain for the whole workgroup: the pointer-chasing part still runs on one lane (the FIFO order is
@@ -366,27 +367,37 @@ __device__ void topo_sort_block(Ctx &g, Smem &sm, int *lds_pool) {
         __syncthreads();
         return;
     }
-    unsigned short *deg = (unsigned short *)lds_pool, *queue = deg + n, *oh = queue + n, *al = oh + n;
-    unsigned short *en = al + n, *et = en + E;
-    for (int i = tid; i < n; i += NT) { deg[i] = (unsigned short)g.nin[i]; oh[i] = (unsigned short)(g.out_head[i] + 1); al[i] = (unsigned short)g.aligned[i]; }
-    for (int e = tid; e < E; e += NT) { en[e] = (unsigned short)(g.e_next_out[e] + 1); et[e] = (unsigned short)g.e_to[e]; }
+    // node word = out_head + 1 (low 16 bits) | next node of the aligned ring (high 16); edge word = to (low) | next out-edge + 1 (high):
+    // one LDS read per node / edge instead of two on the serial walk's dependency chain
+    unsigned short *deg = (unsigned short *)lds_pool, *queue = deg + n;
+    unsigned *nw = (unsigned *)(queue + n + (n & 1)), *ew = nw + n; // (4-byte aligned: the pool is, and 2n + (n & 1) halfwords are even)
+    for (int i = tid; i < n; i += NT) { deg[i] = (unsigned short)g.nin[i]; nw[i] = (unsigned)(g.out_head[i] + 1) | ((unsigned)g.aligned[i] << 16); }
+    for (int e = tid; e < E; e += NT) ew[e] = (unsigned)g.e_to[e] | ((unsigned)(g.e_next_out[e] + 1) << 16);
     __syncthreads();
+    const long long tk0 = clock64();
     if (tid == 0) {
         int qh = 0, qt = 0, index = 0;
         queue[qt++] = 0;
+        int cur = 0; // (the node at queue[qh] is kept in a register whenever it is the one just pushed: linear stretches never re-read the queue)
+        bool have = true;
         while (qh < qt) {
-            const int cur = queue[qh++];
+            if (!have) cur = queue[qh];
+            ++qh; have = false;
             g.node2idx[cur] = index; ++index; // (idx2node is the queue itself, copied out below)
             if (cur == 1) break;
-            for (int e = oh[cur]; e != 0; e = en[e - 1]) {
-                const int out = et[e - 1];
+            for (unsigned e = nw[cur] & 0xffffu; e != 0;) {
+                const unsigned w = ew[e - 1];
+                const int out = (int)(w & 0xffffu);
+                e = w >> 16;
                 const int d = deg[out] - 1; deg[out] = (unsigned short)d;
                 if (d == 0) {
                     bool ok = true;
-                    for (int a = al[out]; a != out; a = al[a]) if (deg[a] != 0) { ok = false; break; }
+                    const int a0 = (int)(nw[out] >> 16);
+                    for (int a = a0; a != out; a = (int)(nw[a] >> 16)) if (deg[a] != 0) { ok = false; break; }
                     if (!ok) continue;
+                    if (qh == qt) { cur = out; have = true; }
                     queue[qt++] = (unsigned short)out;
-                    for (int a = al[out]; a != out; a = al[a]) queue[qt++] = (unsigned short)a;
+                    for (int a = a0; a != out; a = (int)(nw[a] >> 16)) queue[qt++] = (unsigned short)a;
                 }
             }
         }
@@ -394,23 +405,59 @@ __device__ void topo_sort_block(Ctx &g, Smem &sm, int *lds_pool) {
         sm.bc[6] = g.status;
     }
     __syncthreads();
+    g.t_kahn += (unsigned long long)(clock64() - tk0);
     g.status = sm.bc[6];
     if (g.status == LCD_OK) {
-        // heaviest successor of every node (first maximum in out-edge order; 1 = the sink when there is no out-edge), in parallel
-        unsigned short *hs = al, *rem = deg;
+        // heaviest successor of every node (first maximum in out-edge order; 1 = the sink when there is no out-edge), in parallel; it
+        // replaces the ring pointer in the high half of the node's own word (nobody else reads that word in this loop)
+        unsigned short *rem = deg;
         for (int v = tid; v < n; v += NT) {
             int mw = -1, mid = 1;
-            for (int e = oh[v]; e != 0; e = en[e - 1]) { const int w = g.e_w[e - 1]; if (w > mw) { mw = w; mid = et[e - 1]; } }
-            hs[v] = (unsigned short)mid;
+            for (unsigned e = nw[v] & 0xffffu; e != 0;) { const unsigned w = ew[e - 1]; const int wt = g.e_w[e - 1]; if (wt > mw) { mw = wt; mid = (int)(w & 0xffffu); } e = w >> 16; }
+            nw[v] = (nw[v] & 0xffffu) | ((unsigned)mid << 16);
         }
         __syncthreads();
         if (tid == 0) {
             rem[1] = 0; // remain + 1
-            for (int i = n - 2; i >= 0; --i) { const int v = queue[i]; rem[v] = (unsigned short)(rem[hs[v]] + 1); }
+            for (int i = n - 2; i >= 0; --i) { const int v = queue[i]; rem[v] = (unsigned short)(rem[nw[v] >> 16] + 1); }
         }
         __syncthreads();
         for (int i = tid; i < n; i += NT) { g.idx2node[i] = queue[i]; g.remain[i] = (int)rem[i] - 1; }
     }
+    __syncthreads();
+}
+
+// The read changed edge weights only (no new node, no new edge): the topological order stands; `remain` follows the heaviest out-edge
+// and may not.  Same LDS sweep as above without the Kahn walk: heaviest successors in parallel, one serial pass over the order.
+template <int NT>
+__device__ void topo_remain_block(Ctx &g, Smem &sm, int *lds_pool) {
+    const int tid = threadIdx.x;
+    const int n = g.n_node;
+    if (n >= 65535 || (size_t)6 * n + 64 > (size_t)g.pool_words * 4) { // does not fit: serial on HBM (same arithmetic)
+        if (tid == 0) {
+            g.remain[1] = -1;
+            for (int i = n - 2; i >= 0; --i) {
+                const int v = g.idx2node[i]; int mw = -1, mid = 1;
+                for (int e = g.out_head[v]; e >= 0; e = g.e_next_out[e]) if (g.e_w[e] > mw) { mw = g.e_w[e]; mid = g.e_to[e]; }
+                g.remain[v] = g.remain[mid] + 1;
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    unsigned short *rem = (unsigned short *)lds_pool, *ord = rem + n, *hs = ord + n;
+    for (int v = tid; v < n; v += NT) {
+        int mw = -1, mid = 1;
+        for (int e = g.out_head[v]; e >= 0; e = g.e_next_out[e]) { const int wt = g.e_w[e]; if (wt > mw) { mw = wt; mid = g.e_to[e]; } }
+        hs[v] = (unsigned short)mid; ord[v] = (unsigned short)g.idx2node[v];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        rem[1] = 0;
+        for (int i = n - 2; i >= 0; --i) { const int v = ord[i]; rem[v] = (unsigned short)(rem[hs[v]] + 1); }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) g.remain[i] = (int)rem[i] - 1;
     __syncthreads();
 }
 
@@ -1621,7 +1668,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
     g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - Cfg<NT>::K * 3 * ch.wmax) * 4;
-    g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0;
+    g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0;
     const long long t_begin = clock64();
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
     unsigned long long t_graph = 0, t_sub = 0;
@@ -1660,9 +1707,10 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
         }
         // graph update + re-sort: serial pointer work on thread 0; results published through LDS
         const long long tg0 = clock64();
-        bool changed = false;
+        int changed = 0;
         if (len > 0 && g.status == LCD_OK) changed = add_alignment_block<NT>(g, sm, exc_beg, exc_end, seq, len, n_cig, i);
-        if (changed && g.status == LCD_OK) topo_sort_block<NT>(g, sm, lds_pool);
+        if (changed == 2 && g.status == LCD_OK) topo_sort_block<NT>(g, sm, lds_pool);
+        else if (changed == 1 && g.status == LCD_OK) topo_remain_block<NT>(g, sm, lds_pool);
         t_graph += (unsigned long long)(clock64() - tg0);
     }
     const long long t_out0 = clock64();
@@ -1830,7 +1878,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     }
     if (tid == 0) {
         const long long t_end = clock64();
-        out.t_total = (unsigned long long)(t_end - t_begin); out.t_dp = g.t_dp; out.t_bt = g.t_bt; out.t_graph = t_graph; out.t_sub = t_sub; out.t_plan = g.t_plan; out.t_poll = g.t_poll;
+        out.t_total = (unsigned long long)(t_end - t_begin); out.t_dp = g.t_dp; out.t_bt = g.t_bt; out.t_graph = t_graph; out.t_sub = t_sub; out.t_plan = g.t_plan; out.t_poll = g.t_kahn; /* (profiling: t_poll slot reports the serial Kahn walk) */
         out.hw_id = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); out.xcc_id = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
         out.rt_begin = rt_begin; out.rt_end = __builtin_amdgcn_s_memrealtime();
         out.t_out = (unsigned long long)(t_end - t_out0);
