@@ -62,6 +62,29 @@ def test_edge_regions(lcd, oracle):
     assert got[1]["n_cons"] == 0 and got[2]["n_cons"] == 0
 
 
+def test_long_region_sampling_path(lcd, oracle):
+    """regions >= min_noisy_reg_size_to_sample_reads (10 kb): the anchor step samples the full read slices with edlib first
+    (collect_partial_aln_beg_end, src/align.c:719-728) -- phased reads, some partially covering: == oracle"""
+    from longcalld_amd import jobs
+    rng = np.random.default_rng(77)
+    reg = jobs.make_region(rng, jobs.HIFI, length=10300, n_reads=10)
+    n = len(reg["seqs"])
+    reg["haps"][:] = np.arange(n) % 2 + 1
+    reg["phase_sets"][:] = 4242
+    for i in (2, 5):   # a left-cover and a right-cover read
+        s = reg["seqs"][i]
+        if i == 2:
+            reg["seqs"][i] = s[: len(s) * 2 // 3]; reg["covers"][i] = 8
+        else:
+            reg["seqs"][i] = s[len(s) // 3:]; reg["covers"][i] = 4
+        reg["quals"][i] = np.full(len(reg["seqs"][i]), 30, np.uint8)
+    got, ids, _, _ = _run_batch(lcd, [reg])
+    exp = oracle.collect_noisy_reg_aln_strs(reg)
+    assert (ids[0] == exp["sorted_ids"]).all()
+    same_result(exp, got[0])
+    assert got[0]["n_cons"] == 2
+
+
 def test_run_is_idempotent_and_order_independent(lcd):
     """size-independent properties: re-running a batch gives the same digest; a region's result does not depend on its batch mates"""
     from longcalld_amd import jobs
