@@ -289,3 +289,15 @@ def assign_hap_germline(prob, target_var_cate, state=None):
     s = _fill_hap_struct(LcdHapProblem, prob, state, keep)
     check(lib.lcd_assign_hap_germline(C.byref(s), int(target_var_cate)), lib)
     return state
+
+
+def assign_hap_batch(probs, target_var_cates, states=None):
+    """lcd_assign_hap_batch: K5 on several chunks in one launch (one wavefront per chunk); returns the mutated state dicts"""
+    from ._lib import LcdHapProblem
+    lib = load_library()
+    states = states or [_hap_state(p) for p in probs]
+    keep = []
+    arr = (LcdHapProblem * len(probs))(*[_fill_hap_struct(LcdHapProblem, p, st, keep) for p, st in zip(probs, states)])
+    cates = np.ascontiguousarray(target_var_cates, np.int32)
+    check(lib.lcd_assign_hap_batch(len(probs), arr, cates.ctypes.data_as(C.POINTER(C.c_int))), lib)
+    return states
