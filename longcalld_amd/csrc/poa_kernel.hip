@@ -355,22 +355,13 @@ __device__ int add_alignment_block(Ctx &g, Smem &sm, int beg_node, int end_node,
 // most of the work): deg | queue (= the topological order itself) | out_head | aligned ring ; edge next | edge to.  node2idx goes
 // straight to HBM (stores do not stall the walk); after the walk `aligned` is overwritten by each node's heaviest successor
 // (computed in parallel from the edge weights in HBM) and `deg` by remain + 1.
+// The walk on 16-bit packed words: `deg`, `queue` (n halfwords each), node words `nw` (n), edge words `ew` (E) live in LDS when the
+// graph fits the workgroup's pool, in HBM scratch (the row-plan arrays, free between two reads) when it does not -- the single-wavefront
+// chains are kept to a small LDS pool on purpose (more of them per CU is worth more than a fast re-sort, DESIGN "Submission").
 template <int NT>
-__device__ void topo_sort_block(Ctx &g, Smem &sm, int *lds_pool) {
+__device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned short *deg, unsigned short *queue, unsigned *nw, unsigned *ew) {
     const int tid = threadIdx.x;
     const int n = g.n_node, E = g.n_edge;
-    const bool fits = n < 65535 && E < 65535 && (size_t)8 * n + (size_t)4 * E + 64 <= (size_t)g.pool_words * 4;
-    if (!fits) {
-        if (tid == 0) { topo_sort(g); sm.bc[6] = g.status; }
-        __syncthreads();
-        g.status = sm.bc[6];
-        __syncthreads();
-        return;
-    }
-    // node word = out_head + 1 (low 16 bits) | next node of the aligned ring (high 16); edge word = to (low) | next out-edge + 1 (high):
-    // one LDS read per node / edge instead of two on the serial walk's dependency chain
-    unsigned short *deg = (unsigned short *)lds_pool, *queue = deg + n;
-    unsigned *nw = (unsigned *)(queue + n + (n & 1)), *ew = nw + n; // (4-byte aligned: the pool is, and 2n + (n & 1) halfwords are even)
     for (int i = tid; i < n; i += NT) { deg[i] = (unsigned short)g.nin[i]; nw[i] = (unsigned)(g.out_head[i] + 1) | ((unsigned)g.aligned[i] << 16); }
     for (int e = tid; e < E; e += NT) ew[e] = (unsigned)g.e_to[e] | ((unsigned)(g.e_next_out[e] + 1) << 16);
     __syncthreads();
@@ -425,6 +416,27 @@ __device__ void topo_sort_block(Ctx &g, Smem &sm, int *lds_pool) {
         for (int i = tid; i < n; i += NT) { g.idx2node[i] = queue[i]; g.remain[i] = (int)rem[i] - 1; }
     }
     __syncthreads();
+}
+
+template <int NT>
+__device__ void topo_sort_block(Ctx &g, Smem &sm, int *lds_pool) {
+    const int tid = threadIdx.x;
+    const int n = g.n_node, E = g.n_edge;
+    if (n >= 65535 || E >= 65535) { // ids do not fit 16 bits: plain serial walk on the graph arrays
+        if (tid == 0) { topo_sort(g); sm.bc[6] = g.status; }
+        __syncthreads();
+        g.status = sm.bc[6];
+        __syncthreads();
+        return;
+    }
+    // node word = out_head + 1 (low 16 bits) | next node of the aligned ring (high 16); edge word = to (low) | next out-edge + 1 (high):
+    // one read per node / edge instead of two on the serial walk's dependency chain
+    if ((size_t)8 * n + (size_t)4 * E + 64 <= (size_t)g.pool_words * 4) {
+        unsigned short *deg = (unsigned short *)lds_pool, *queue = deg + n;
+        unsigned *nw = (unsigned *)(queue + n + (n & 1)), *ew = nw + n; // (4-byte aligned: the pool is, and 2n + (n & 1) halfwords are even)
+        topo_sort_arrays<NT>(g, sm, deg, queue, nw, ew);
+    } else
+        topo_sort_arrays<NT>(g, sm, (unsigned short *)g.deg, (unsigned short *)g.queue, (unsigned *)g.pl_bonus, (unsigned *)g.pl_pidx);
 }
 
 // The read changed edge weights only (no new node, no new edge): the topological order stands; `remain` follows the heaviest out-edge
