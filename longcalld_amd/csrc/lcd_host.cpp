@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <memory>
 #include "../../include/lcd_hotpath.h"
 #include "lcd_kernels.h"
 #include "lcd_types.h"
@@ -162,6 +163,7 @@ struct lcd_batch_s {
     std::vector<uint8_t> h_final; std::vector<uint8_t> h_poa_out; std::vector<uint8_t> h_cig;
     // ref<->read strings (opt.collect_ref_read_aln_str): per string job, rows in d_rr at rr_off (target row, query row at +rr_stride)
     std::vector<uint64_t> rr_off; std::vector<int> rr_len, rr_stride; std::vector<uint8_t> h_rr; uint64_t rr_bytes = 0;
+    std::vector<std::unique_ptr<DevBuf>> retry_out; // output blocks of chains re-run with a larger graph capacity (live until the next run)
     uint64_t final_bytes = 0;
     lcd_batch_stats_t st;
 };
@@ -180,11 +182,14 @@ uint64_t wfa_arena_bytes(int plen, int tlen, int s_cap) {
     else tot = (s_sw + 1) * (s_sw + 3) + ((uint64_t)s_cap - s_sw) * wmax;
     return hdr + tot * 5 * 4 + 256;
 }
+std::atomic<int> g_wfa_hint{0}; // 0..2: learned from the overflow retries of earlier WFA stages (noisy reads), see wfa_default_scap
 int wfa_default_scap(int plen, int tlen) {
     int d = plen > tlen ? plen - tlen : tlen - plen;
     int m = plen < tlen ? plen : tlen;
-    // enough for the length difference as one long gap plus ~6% divergence; retried x4 on overflow
-    long long s = 24 + d + 64 + (long long)(m * 0.06) * 6;
+    // enough for the length difference as one long gap plus ~1.5 % divergence (the arena grows with the SQUARE of this bound: 6 % for
+    // everybody was 5-10 GB per 1 250 regions); jobs that overflow are retried with 4x, and data that keeps overflowing starts higher
+    static const double div[3] = {0.015, 0.06, 0.20};
+    long long s = 24 + d + 64 + (long long)(m * div[g_wfa_hint.load()]) * 6;
     return (int)std::min<long long>(s, 2000000);
 }
 uint64_t ed_arena_bytes(int qlen, int tlen) { return (uint64_t)52432 * 20 + (uint64_t)qlen * 8 + (uint64_t)tlen * 2 + 512; }
@@ -259,6 +264,7 @@ int run_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, DevBuf &d_jobs, Dev
             if (tmp[i].status == LCD_ERR_WF) { jobs[which[i]].s_cap = (int)std::min<long long>((long long)jobs[which[i]].s_cap * 4 + 64, 4000000); again.push_back(which[i]); }
             else if (tmp[i].status != LCD_OK) return set_err(-20, "WFA kernel status " + std::to_string(tmp[i].status));
         }
+        if (round == 0 && again.size() * 20 > which.size() && g_wfa_hint.load() < 2) g_wfa_hint++;
         if (!again.empty() && retries) (*retries)++;
         which.swap(again);
     }
@@ -519,17 +525,25 @@ int lcd_batch_upload(lcd_batch_t *b) {
 }
 
 static std::atomic<int> g_cell_hint[2] = {{0}, {0}}; // per mode (K1, K2): 0..2, see chain_caps
+static std::atomic<int> g_node_hint{0};                // 0..2: graph capacity estimate, see chain_caps
 static void chain_class(PoaChain &pc);
 static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vector<PoaRead> &preads, int scale, PoaChain &pc) {
     const int n = (int)C.members.size();
     long long sum = 0; int maxl = 0;
     for (int k = 0; k < n; ++k) { const PoaRead &r = preads[C.read0 + k]; sum += r.len; maxl = std::max(maxl, r.len); }
     pc.n_reads = n; pc.read0 = C.read0; pc.mode = C.mode;
-    pc.node_cap = (int)std::min<long long>(sum + 2, 2000000000ll);
-    pc.edge_cap = (int)std::min<long long>(sum + n + 2, 2000000000ll);
-    if (getenv("LCD_NODE_EST")) { // experiment: graph arrays sized from an estimate instead of the worst case
-        const long long est = (long long)(atof(getenv("LCD_NODE_EST")) * maxl) + 64;
-        pc.node_cap = (int)std::min<long long>(pc.node_cap, est); pc.edge_cap = (int)std::min<long long>(pc.edge_cap, est + est / 2);
+    // graph capacity: the worst case is one node per base of every read (sum), the usual case a little more than the longest read.  Sized
+    // from an estimate (a few per cent of new nodes per read on top of the backbone; g_node_hint learns noisier data); a chain that runs
+    // out (LCD_ERR_NODES / LCD_ERR_EDGES) is re-run with 4x more per retry, up to the worst case.  The worst case for everybody was
+    // 10 GB of arena per 1 250 regions, nearly all of it never touched.
+    const long long node_worst = std::min<long long>(sum + 2, 2000000000ll), edge_worst = std::min<long long>(sum + n + 2, 2000000000ll);
+    {
+        static const double nf[3] = {1.25, 2.0, 4.0}, sf[3] = {0.03, 0.10, 0.30};
+        const int nh = g_node_hint.load();
+        long long est = (long long)(nf[nh] * maxl + sf[nh] * (double)sum) + 64;
+        for (int sc2 = 1; sc2 < scale; sc2 *= 2) est *= 4;
+        pc.node_cap = (int)std::min(node_worst, est);
+        pc.edge_cap = (int)std::min(edge_worst, est + est / 4 + n);
     }
     pc.rid_words = (n + 63) / 64; pc.max_len = maxl;
     int mw = (int)(n * opt.min_af); if (mw < 2) mw = 2;
@@ -781,15 +795,31 @@ int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
             if (PC(a).cell_cap != PC(c2).cell_cap) return PC(a).cell_cap > PC(c2).cell_cap;
             return a < c2; });
         int scale = 1;
+        std::map<size_t, uint64_t> retry_out_off; // chains whose output block moved to a retry buffer
+        for (int k = 0; k < nb; ++k) bs[k]->retry_out.clear();
         for (int round = 0; round < 12 && !which.empty(); ++round) {
             uint64_t tot = 0;
             std::vector<PoaChain> sub(which.size());
             for (size_t i = 0; i < which.size(); ++i) {
                 const int k = chain_batch[which[i]]; const size_t c = which[i] - chain_base[k];
                 PoaChain &pc = bs[k]->pchains[c];
-                if (round) chain_caps(bs[k]->opt, bs[k]->chains[c], preads[k], scale, pc), pc.out_off = bs[k]->d_poa_out.addr() + out_rel[k][c];
+                if (round) {
+                    const int old_cap = pc.node_cap;
+                    chain_caps(bs[k]->opt, bs[k]->chains[c], preads[k], scale, pc);
+                    if (pc.node_cap > old_cap) { // the chain's output block (cons + MSA rows of node_cap columns) grows with it: a fresh block
+                        lcd_batch_t *b = bs[k];
+                        b->retry_out.emplace_back(new DevBuf());
+                        if (b->retry_out.back()->ensure(poa_out_bytes(pc.node_cap, pc.n_reads) + 256)) return -11;
+                        pc.out_off = b->retry_out.back()->addr(); retry_out_off[which[i]] = pc.out_off;
+                    } else pc.out_off = retry_out_off.count(which[i]) ? retry_out_off[which[i]] : bs[k]->d_poa_out.addr() + out_rel[k][c];
+                }
                 PoaLayout Lay = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads);
                 pc.ws_off = tot; tot += Lay.total;
+            }
+            if (getenv("LCD_MEM_DEBUG")) {
+                double cellb = 0, nodeb = 0; double worstc = 0; size_t nbig = 0;
+                for (size_t i = 0; i < which.size(); ++i) { const PoaChain &pc = PC(which[i]); cellb += 4.0 * pc.cell_cap; PoaLayout Lay = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, 0, pc.n_reads); nodeb += (double)Lay.total; if (4.0 * pc.cell_cap > worstc) worstc = 4.0 * pc.cell_cap; nbig += 4.0 * pc.cell_cap > 64e6; }
+                fprintf(stderr, "[mem] round %d: %zu chains, arena %.2f GB = DP regions %.2f GB (largest %.1f MB, %zu above 64 MB) + graph/plan arrays %.2f GB\n", round, which.size(), tot / 1e9, cellb / 1e9, worstc / 1e6, nbig, nodeb / 1e9);
             }
             if (L->d_poa_arena.ensure(tot)) return -11;
             for (size_t i = 0; i < which.size(); ++i) {
@@ -805,13 +835,14 @@ int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
             HIPCHK(hipMemcpyAsync(tmp.data(), L->d_poa_outs.p, sub.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             { float kms = 0; hipEventElapsedTime(&kms, L->ev[6], L->ev[7]); for (int k = 0; k < nb; ++k) { bs[k]->st.ms_poa_kernel += kms; bs[k]->st.n_poa_launches++; } }
-            std::vector<size_t> again;
+            std::vector<size_t> again; size_t n_node_ovf = 0;
             for (size_t i = 0; i < which.size(); ++i) {
                 const int k = chain_batch[which[i]];
                 bs[k]->couts[which[i] - chain_base[k]] = tmp[i];
-                if (tmp[i].status == LCD_ERR_CELLS) again.push_back(which[i]);
+                if (tmp[i].status == LCD_ERR_CELLS || tmp[i].status == LCD_ERR_NODES || tmp[i].status == LCD_ERR_EDGES) { again.push_back(which[i]); n_node_ovf += tmp[i].status != LCD_ERR_CELLS; }
                 else if (tmp[i].status != LCD_OK) return set_err(-20, "POA kernel status " + std::to_string(tmp[i].status) + " on chain " + std::to_string(which[i] - chain_base[k]));
             }
+            if (round == 0 && n_node_ovf * 20 > nC_all && g_node_hint.load() < 2) g_node_hint++;
             if (round == 0) { // learn: more than 5 % of a mode's chains overflowed their DP region -> start from the next estimate next time
                 int tot[2] = {0, 0}, ovf[2] = {0, 0};
                 for (size_t g = 0; g < nC_all; ++g) tot[PC(g).mode ? 1 : 0]++;
@@ -1268,13 +1299,23 @@ int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int
     std::vector<int> which(n_chains);
     for (int c = 0; c < n_chains; ++c) which[c] = c;
     int scale = 1;
+    std::vector<std::unique_ptr<DevBuf>> retry_out;
     const LcdScoring sc = scoring_of(*opt);
     for (int round = 0; round < 12 && !which.empty(); ++round) {
         uint64_t tot = 0; std::vector<PoaChain> sub(which.size());
         for (size_t i = 0; i < which.size(); ++i) {
             PoaChain &pc = pch[which[i]];
-            if (round) chain_caps(*opt, crec[which[i]], preads, scale, pc);
-            pc.out_off = d_out.addr() + out_rel[which[i]];
+            if (!round) pc.out_off = d_out.addr() + out_rel[which[i]];
+            else {
+                const int old_cap = pc.node_cap; const uint64_t keep = pc.out_off;
+                chain_caps(*opt, crec[which[i]], preads, scale, pc);
+                pc.out_off = keep;
+                if (pc.node_cap > old_cap) { // larger graph capacity -> larger output block
+                    retry_out.emplace_back(new DevBuf());
+                    if (retry_out.back()->ensure(poa_out_bytes(pc.node_cap, pc.n_reads) + 256)) return -11;
+                    pc.out_off = retry_out.back()->addr();
+                }
+            }
             PoaLayout L = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads);
             pc.ws_off = tot; tot += L.total;
         }
@@ -1285,7 +1326,7 @@ int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int
         HIPCHK(hipMemcpyAsync(tmp.data(), d_outs.p, sub.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         std::vector<int> again;
-        for (size_t i = 0; i < which.size(); ++i) { couts[which[i]] = tmp[i]; if (tmp[i].status == LCD_ERR_CELLS) again.push_back(which[i]); }
+        for (size_t i = 0; i < which.size(); ++i) { couts[which[i]] = tmp[i]; if (tmp[i].status == LCD_ERR_CELLS || tmp[i].status == LCD_ERR_NODES || tmp[i].status == LCD_ERR_EDGES) again.push_back(which[i]); }
         if (!again.empty()) scale *= 2;
         which.swap(again);
     }

@@ -31,7 +31,7 @@ struct LcdScoring {
 };
 
 // status codes written by kernels (0 = ok). Anything else makes the host fail loudly or retry with a bigger arena.
-enum { LCD_OK = 0, LCD_ERR_CELLS = 1, LCD_ERR_NODES = 2, LCD_ERR_EDGES = 3, LCD_ERR_BACKTRACK = 4, LCD_ERR_WF = 5, LCD_ERR_TOPO = 6, LCD_ERR_SYNC = 7 };
+enum { LCD_OK = 0, LCD_ERR_CELLS = 1, LCD_ERR_NODES = 2, LCD_ERR_EDGES = 3, LCD_ERR_BACKTRACK = 4, LCD_ERR_WF = 5, LCD_ERR_TOPO = 6, LCD_ERR_SYNC = 7, LCD_ERR_LDS = 8, LCD_FALLBACK = 100 /* internal: take the generic rows */ };
 
 // ---------------- POA chain (one graph build = one abpoa_t life, src/align.c:762 / :872) ----------------
 struct PoaRead {

@@ -909,7 +909,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
             }
         }
         if (overflow) return -1;
-        if (np > 256) { wo->status = LCD_ERR_NODES; return 0; } // ordinals are 8 bits
+        if (np > 256) return -1; // ordinals are 8 bits: such a row goes through the generic rows
         const int h0 = imax(n0, imax(u0, v0)), h1 = imax(n1, imax(u1, v1)), h2 = imax(n2, imax(u2, v2)), h3 = imax(n3, imax(u3, v3)); // Hpre
         const int sp0 = n0 == h0 ? 0 : u0 == h0 ? 1 : 2, sp1 = n1 == h1 ? 0 : u1 == h1 ? 1 : 2, sp2 = n2 == h2 ? 0 : u2 == h2 ? 1 : 2, sp3 = n3 == h3 ? 0 : u3 == h3 ? 1 : 2;
         // ---- F: A[k] = Hpre[k] + k*e; in-lane inclusive prefix, then one scan pair over the lane totals ----
@@ -1128,7 +1128,7 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
             }
             // every wavefront takes the same decisions from the same plan, so an error leaves the loop in all of them at the same row
             if (cused + cw4 > code_cap || (np > 1 && oused + cw4 > ord_cap) || (spf && nsp >= spill_rows)) { err = LCD_ERR_CELLS; break; }
-            if (np > 256) { err = LCD_ERR_NODES; break; } // ordinals are 8 bits (and the packed plan word holds 16)
+            if (np > 256) { err = LCD_FALLBACK; break; } // ordinals are 8 bits (and the packed plan word holds 16): generic rows
             const int s = (idx - bi) & (K - 1);
             const long long tq0 = clock64();
             if (SYS) {
@@ -1256,7 +1256,7 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
     }
     if (tid == 0 && err != LCD_OK) sm.bc[7] = err;
     __syncthreads();
-    if (sm.bc[7] != LCD_OK) { wo->status = sm.bc[7]; __syncthreads(); return 0; }
+    if (sm.bc[7] != LCD_OK) { const int e = sm.bc[7]; __syncthreads(); if (e == LCD_FALLBACK) return -1; wo->status = e; return 0; }
     wo->cells = ncell;
     if (tid == (AW - 1) * 64) { sm.prof[0] = t_plan; sm.prof[1] = t_poll; } // (profiling aid: the LAST active wavefront's view)
     const long long t_bt0 = clock64();
@@ -1298,7 +1298,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
     const uint8_t *seq = seq_hbm;
     // LDS after the ring: [query cache | first-predecessor distances]
     const int QB = (qlen + 12 + 15) & ~15;
-    if (QB > g.seq_cap) { g.status = LCD_ERR_NODES; return 0; } // read slice longer than the LDS query cache (host sizes the class)
+    if (QB > g.seq_cap) { g.status = LCD_ERR_LDS; return 0; } // read slice longer than the LDS query cache (host sizes the class)
     uint8_t *pd = (QB + (ei - bi) + 16 <= g.seq_cap) ? sseq + QB : nullptr;
     build_plan<NT>(g, sm, bi, ei, remain_end, pd, K);
     if (!(sc.dbg & 8) && WMAX <= NT * 4 && (WMAX & (WMAX - 1)) == 0) {
