@@ -27,7 +27,7 @@
 // scoring, src/align.h:21-26 via call_var_opt_t
 struct LcdScoring {
     int match, mismatch, o1, e1, o2, e2;
-    int dbg; // profiling ablation bits (env LCD_DBG; 0 in production): 1 = skip the HBM row stores of the unbanded path
+    int dbg; // test switch (env LCD_DBG; 0 in production): 8 = force the generic rows of the POA kernel (tests/test_gpu_kernels.py)
 };
 
 // status codes written by kernels (0 = ok). Anything else makes the host fail loudly or retry with a bigger arena.

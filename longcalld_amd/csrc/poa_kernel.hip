@@ -5,16 +5,21 @@
 // and keeps the whole graph build device-resident: align read -> backtrack -> add alignment -> re-sort ->
 // next read, then MSA / clustering / consensus.  No host round trip inside a chain.
 //
-// Workgroup size follows the DP row width: 64 threads for banded HiFi rows (<=128 columns), 256 / 1024 for
-// the unbanded K2 rows, so a 4 000-column row is 4 rounds of 16 wavefronts instead of 63 serial chunks.
-// Integer DP only (no MFMA):
-//   * per read a "row plan" (CSR of the usable predecessors + edge bonus of every row) is built in parallel,
-//     so a row costs one dependent load level instead of a linked-list walk;
-//   * a row's predecessor metadata is staged once in LDS and shared by all wavefronts;
-//   * the horizontal-gap recurrence is a wave-level exclusive prefix max with an LDS carry across wavefronts
+// Workgroup size = window / 4: 64 threads for the banded K1 rows and short K2 rows (256-column window), 128 ... 1024 threads for the
+// unbanded K2 rows (up to 4 096 columns); a lane owns four consecutive columns.  Integer DP only (no MFMA):
+//   * per read a "row plan" (CSR of the usable predecessors + edge bonus of every row) is built in parallel, so a row costs one
+//     dependent load level instead of a linked-list walk; rows take it from a 64-row register window by v_readlane;
+//   * H / E1 / E2 values live only in a K-slot LDS row ring (and, for the few rows that a far successor or the end node reads, in a
+//     small HBM spill area); what is streamed to HBM is a 1-byte direction code per cell that replays the oracle's backtrack;
+//   * the horizontal-gap recurrence is an in-lane prefix + one DPP wave prefix-max pair per 256 cells
 //     (F[j] = max_k<j Hpre[k] - o - (j-k)e  ==  prefixmax(Hpre[k]+k e) - o - j e);
-//   * the adaptive band is pulled from the predecessors' row-max columns (no scatter);
-//   * only H, E1, E2 are stored (12 B/cell); the insertion run is re-derived from H in the backtrack.
+//   * banded rows (align_windowed): the adaptive band is pulled from the predecessors' row-max columns (no scatter), the window is
+//     addressed column mod WIN so shifted windows need no per-cell bounds test;
+//   * unbanded rows (align_unbanded) run systolic across the wavefronts: mailboxes + progress counters, no workgroup barrier per row;
+//   * the backtrack (wavefront 0) speculates runs of matches 64 steps at a time;
+//   * the graph update is parallel (prefix sums), the re-sort's serial Kahn walk runs on packed 16-bit words in LDS (or HBM for graphs
+//     that do not fit the chain's pool);
+//   * rows wider than the window fall back to the generic rows of align_to_subgraph (int32 H/E1/E2 planes in HBM, value backtrack).
 // Semantics are defined by oracle/poa.c (see its header); this file must match it bit for bit.
 #include <hip/hip_runtime.h>
 #include "lcd_types.h"
@@ -1229,7 +1234,7 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
                 const unsigned S = ring + 4u * (unsigned)(s * SLOTW);
                 lds_st4(S + lofs, H4); lds_st4(S + PL + lofs, A4); lds_st4(S + 2 * PL + lofs, B4);
                 if (spf) { int *G = g.spill + (size_t)nsp * SLOTW; glb_st4(G + jb, H4); glb_st4(G + WIN + jb, A4); glb_st4(G + 2 * WIN + jb, B4); }
-                if (jb < cw4 && !(sc.dbg & 16)) {
+                if (jb < cw4) {
                     glb_st(g.code8 + cused + jb, (int)code);
                     if (np > 1) glb_st4(g.ord + oused + jb, make_int4((om & 255) | ((oa & 255) << 8) | ((ob & 255) << 16),
                                                                          ((om >> 8) & 255) | (((oa >> 8) & 255) << 8) | (((ob >> 8) & 255) << 16),
@@ -1237,7 +1242,7 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
                                                                          ((om >> 24) & 255) | (((oa >> 24) & 255) << 8) | (((ob >> 24) & 255) << 16)));
                 }
             }
-            if (tid == 0 && !(sc.dbg & 16)) {
+            if (tid == 0) {
                 glb_st(g.rbeg + idx, 0); glb_st(g.rend + idx, qlen); glb_st(g.roff + idx, (int)cused); glb_st(g.ooff + idx, (int)oused);
                 if (spf) { glb_st(g.ml + idx, 0); glb_st(g.mr + idx, 0); glb_st(g.spoff + idx, nsp); }
             }
@@ -1261,7 +1266,7 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
     if (tid == (AW - 1) * 64) { sm.prof[0] = t_plan; sm.prof[1] = t_poll; } // (profiling aid: the LAST active wavefront's view)
     const long long t_bt0 = clock64();
     wo->t_dp = (unsigned long long)(t_bt0 - t_dp0);
-    if (wave == 0) { if (sc.dbg & 16) { if (lane == 0) { sm.bc[0] = 0; sm.bc[1] = LCD_OK; sm.bc[4] = qlen; } } else code_backtrack(g, sm, pd, bi, ei, qlen, SLOTW, WM, lane); }
+    if (wave == 0) code_backtrack(g, sm, pd, bi, ei, qlen, SLOTW, WM, lane);
     __syncthreads();
     const int n_cig = sm.bc[0];
     wo->status = sm.bc[1];
@@ -1569,7 +1574,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
                 if (c > best) { best = c; br = pi; }
             }
         }
-        if (br >= 0 && best > LCD_NEG / 2 && !(sc.dbg & 5)) {
+        if (br >= 0 && best > LCD_NEG / 2) {
             int pos = qlen;
             int i = br, j = qlen, st = 0;
 #define CELLH(pi, jj) g.H[g.roff[pi] + ((jj) - g.rbeg[pi])]
