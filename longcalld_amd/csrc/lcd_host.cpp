@@ -627,20 +627,21 @@ static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, 
     // hardware queue, and with many queues holding runnable kernels the queue scheduler time-slices them -- measured on MI355X: the
     // same 48 wide chains take 1.09 s next to 8 other active queues and 0.42 s with 4 queues in total.  Groups are dealt to the
     // streams longest-first by their DP work (LPT); a stream runs its groups back to back.
-    struct Grp { size_t i, j; double cost; };
+    struct Grp { size_t i, j; double cost, tail; };
     std::vector<Grp> grps;
     for (size_t i = 0; i < sub.size();) {
         const long long key = chain_group_key(sub[i]);
         size_t j = i; double cost = 0;
         // a group's demand in CU-time: a chain runs ~ reads x rows (a row costs about the same few thousand cycles in every class), and
         // `per_cu` chains of this (threads, LDS) shape share a CU (160 KB LDS, 16 wavefronts at 128 VGPRs)
-        while (j < sub.size() && chain_group_key(sub[j]) == key) { cost += (double)sub[j].n_reads * (sub[j].max_len + 64); ++j; }
+        double tail = 0;
+        while (j < sub.size() && chain_group_key(sub[j]) == key) { const double t = (double)sub[j].n_reads * (sub[j].max_len + 64); cost += t; tail = std::max(tail, t); ++j; }
         {
             const int lds = sub[i].lds_words * 4, thr = sub[i].threads;
             const int per_cu = std::max(1, std::min((160 * 1024) / (lds + (thr == 64 ? 1 : 6) * 1024), 1024 / thr));
             cost /= per_cu;
         }
-        grps.push_back({i, j, cost});
+        grps.push_back({i, j, cost, tail});
         i = j;
     }
     const int ns = side ? n_streams : 1;
@@ -649,7 +650,9 @@ static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, 
     // launch order: 1 024-thread groups, then 512-thread groups, then the rest (a gate only ever waits for kernels enqueued before it, so it
     // cannot deadlock whatever the stream -> hardware-queue mapping is); longest first inside a class
     auto rank = [&](size_t k) { const int t = chain_threads(sub[grps[k].i]); return t >= 1024 ? 0 : t >= 512 ? 1 : 2; };
-    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t c) { return rank(a) != rank(c) ? rank(a) < rank(c) : grps[a].cost > grps[c].cost; });
+    // inside a class rank: the group with the longest single chain first (its duration is that chain whatever else runs); the groups of
+    // many short chains come last and fill the machine while the long ones finish
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t c) { return rank(a) != rank(c) ? rank(a) < rank(c) : grps[a].tail > grps[c].tail; });
     std::vector<double> load(ns, 0.0);
     std::vector<bool> used(ns, false);
     for (size_t k : order) {

@@ -568,6 +568,11 @@ __device__ __forceinline__ void glb_st4(int *p, const int4 v) { lcd_v4i t; t.x =
 // s_waitcnt vmcnt(0) at the join, where it also waits (in-order vmcnt) for the row stores of every iteration that did not
 // take the branch -- a full HBM store round trip (~2 us) per DP row.
 #define LCD_PIN(x) asm volatile("" : "+v"(x))
+// acc = (acc << 1) | (a OP b): a compare into VCC and an add-with-carry of acc to itself -- two instructions per flag and no VCC -> VALU
+// wait states, against v_cmp + s_nop + v_cndmask + (a share of) v_or3 with constants materialised by v_mov in the compiler's version
+// (the direction code is ~40 % of a DP row's instructions).
+#define LCD_PUSH_GT(acc, a, b) asm("v_cmp_gt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc")
+#define LCD_PUSH_GE(acc, a, b) asm("v_cmp_ge_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc")
 constexpr int CB_Y1 = 8, CB_Y2 = 16, CB_O1 = 32, CB_O2 = 64, CB_PM = 128;
 constexpr int LCD_GUARD = LCD_NEG * 2; // out-of-band filler: (guard + anything a cell can add) stays below LCD_NEG, so it never wins a max
 
@@ -944,9 +949,10 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
             if (BANDED) { eo1 = imax(eo1, LCD_NEG); eo2 = imax(eo2, LCD_NEG); }                                             \
             const int fk = f1 == h ? (f2 == h ? 5 : 3) : 4;                                                                 \
             const int hs = (hp) == h ? (mxv) : fk; /* (mxv): which of match / E1 / E2 gives Hpre, the oracle's priority */   \
-            const unsigned cd = (unsigned)hs | ((pf1) > (ak1) ? CB_Y1 : 0) | ((pf2) > (ak2) ? CB_Y2 : 0) |                  \
-                                (h - oe1 >= (ev1) - e1 ? CB_O1 : 0) | (h - oe2 >= (ev2) - e2 ? CB_O2 : 0) |                 \
-                                (((om >> (8 * (k))) & 255) ? CB_PM : 0);                                                    \
+            unsigned fl = 0; /* O2, O1, Y2, Y1 pushed in this order = bits 6, 5, 4, 3 of the code */                        \
+            { const int t2 = h - oe2, w2 = (ev2) - e2, t1 = h - oe1, w1 = (ev1) - e1, q2 = (pf2), r2 = (ak2), q1 = (pf1), r1 = (ak1); \
+              LCD_PUSH_GE(fl, t2, w2); LCD_PUSH_GE(fl, t1, w1); LCD_PUSH_GT(fl, q2, r2); LCD_PUSH_GT(fl, q1, r1); }         \
+            const unsigned cd = (unsigned)hs | (fl << 3) | (((om >> (8 * (k))) & 255) ? CB_PM : 0);                         \
             code |= cd << (8 * (k));                                                                                        \
             HO = (inb) ? h : LCD_GUARD; AO = (inb) ? eo1 : LCD_GUARD; BO = (inb) ? eo2 : LCD_GUARD;                         \
         }
@@ -1218,8 +1224,10 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
                 const int h = imax(hp, imax(f1, f2));                                                                       \
                 const int ho1 = h - o1, ho2 = h - o2;                                                                       \
                 const int fk = f1 == h ? (f2 == h ? 5 : 3) : 4;                                                             \
-                const unsigned cd = (unsigned)((hp) == h ? (spk) : fk) | ((pf1) > (ak1) ? CB_Y1 : 0) | ((pf2) > (ak2) ? CB_Y2 : 0) | \
-                                    (ho1 >= (ev1) ? CB_O1 : 0) | (ho2 >= (ev2) ? CB_O2 : 0) | (((om >> (8 * (k))) & 255) ? CB_PM : 0); \
+                unsigned fl = 0; /* O2, O1, Y2, Y1 pushed in this order = bits 6, 5, 4, 3 of the code */                    \
+                { const int w2 = (ev2), w1 = (ev1), q2 = (pf2), r2 = (ak2), q1 = (pf1), r1 = (ak1);                         \
+                  LCD_PUSH_GE(fl, ho2, w2); LCD_PUSH_GE(fl, ho1, w1); LCD_PUSH_GT(fl, q2, r2); LCD_PUSH_GT(fl, q1, r1); }   \
+                const unsigned cd = (unsigned)((hp) == h ? (spk) : fk) | (fl << 3) | (((om >> (8 * (k))) & 255) ? CB_PM : 0); \
                 code |= cd << (8 * (k));                                                                                    \
                 HO = h; AO = imax(ho1, ev1); BO = imax(ho2, ev2);                                                           \
             }
