@@ -577,14 +577,18 @@ static void chain_class(PoaChain &pc) {
     int threads, K, wmax; // wmax: window / ring-slot width in columns, a power of two <= 4 * threads (poa_kernel.hip align_windowed)
     // one lane per four columns of the window: 64 / 128 / 256 / 512 / 1024 threads, so that no wavefront of a workgroup idles
     // (a 2 048-column chain in a 1 024-thread workgroup would hold a whole CU's registers with half of its wavefronts parked)
-    if (width <= 256) { threads = 64; K = 2; wmax = 256; }
+    if (width <= 256) { // single wavefront; banded chains prefer the narrowest window their band fits (1, 2 or 4 cells per lane, align_windowed)
+        threads = 64; K = 2;
+        const long long bw = 2ll * (10 + pc.max_len / 100) + 1 + 24; // adaptive band + a little drift; a band that outgrows it is re-run wider
+        wmax = pc.mode == 1 ? 256 : bw <= 60 ? 64 : bw <= 124 ? 128 : 256;
+    }
     else if (width <= 512) { threads = 128; K = 2; wmax = 512; }
     else if (width <= 1024) { threads = 256; K = 2; wmax = 1024; }
     else if (width <= 2048) { threads = 512; K = 2; wmax = 2048; }
     else { threads = 1024; K = 2; wmax = 4096; } // wider rows take the generic (HBM) rows of the kernel
     const long long est_nodes = (long long)(pc.max_len * 1.15) + 64;
     const long long seq_bytes = lcd_align_up((long long)pc.max_len + 28, 16) + lcd_align_up(est_nodes + 16, 16); // query cache + first-predecessor distances
-    const long long dp_bytes = (long long)K * 3 * wmax * 4 + seq_bytes;
+    const long long dp_bytes = (long long)K * 3 * (4 * threads) * 4 + seq_bytes; // the ring is sized for the widest window of the class
     // the re-sort's LDS copy of the graph: 8 B per node + 4 B per edge (topo_sort_block); edges ~ nodes + a few per bubble
     long long need = std::max(dp_bytes, est_nodes * 8 + (est_nodes + est_nodes / 8) * 4 + 64);
     { // the single-wavefront class is kept to a small pool (LCD_LDS_CAP_KB, default 16): 9+ such chains per CU instead of 2-6 is worth

@@ -675,7 +675,7 @@ __device__ void ctx_to_sgpr(Ctx &g) {
 // End node (best predecessor at column qlen; its values are in the spill area) + the code-driven backtrack, on wavefront 0.
 // Results through sm.bc[0] = #cigar entries, [1] = status, [4] = first cigar slot.
 __device__ __forceinline__ void code_backtrack(const Ctx &g, Smem &sm, const unsigned pd, const int bi, const int ei, const int qlen, const int SLOTW, const int WM,
-                                               const int lane) {
+                                               const int lane, const int amask /* rows start at their band's first column rounded down to the lane's cell group: ~(C - 1) */) {
         int best = LCD_NEG, br = -1;
         {
             const int p0 = g.pl_start[ei], np = g.pl_start[ei + 1] - p0;
@@ -709,7 +709,7 @@ __device__ __forceinline__ void code_backtrack(const Ctx &g, Smem &sm, const uns
                     const int jj = j - lane;
                     if (my_i >= 0 && my_nx >= 0) {
                         const int rb = g.rbeg[my_i], re = g.rend[my_i];
-                        if (jj >= rb && jj <= re) good = (g.code8[(size_t)g.roff[my_i] + (jj - (rb & ~3))] & (7 | CB_PM)) == 0;
+                        if (jj >= rb && jj <= re) good = (g.code8[(size_t)g.roff[my_i] + (jj - (rb & amask))] & (7 | CB_PM)) == 0;
                     }
                     const unsigned long long bad = __ballot(!good);
                     const int m = bad ? __ffsll((long long)bad) - 1 : 64;
@@ -721,7 +721,7 @@ __device__ __forceinline__ void code_backtrack(const Ctx &g, Smem &sm, const uns
                     }
                 }
                 // one step, replaying the oracle's decision from the code
-                const int rb = g.rbeg[i], rb4 = rb & ~3;
+                const int rb = g.rbeg[i], rb4 = rb & amask;
                 const size_t ro = g.roff[i];
                 const int c = g.code8[ro + (j - rb4)];
                 const int p0 = g.pl_start[i], np = g.pl_start[i + 1] - p0;
@@ -755,11 +755,38 @@ __device__ __forceinline__ void code_backtrack(const Ctx &g, Smem &sm, const uns
 struct WinOut { int status; unsigned long long t_dp, t_bt, cells; int cig_pos; unsigned long long t_plan, t_poll; };
 // (not inlined, context by value: the row loop then only carries the dozen pointers it uses instead of the chain's whole
 //  context -- inlined, hipcc spilled the scalar registers of ~45 pointers into VGPR lanes and re-read them every row)
-template <int NT, bool BANDED>
+// C consecutive ints from / to LDS (byte offset) or HBM: one ds_read_b128 / b64 / b32 (global_load_dwordx4 / x2 / dword)
+typedef int lcd_v2i __attribute__((ext_vector_type(2)));
+template <int C> __device__ __forceinline__ void lds_ldc(const unsigned o, int (&v)[C]) {
+    if constexpr (C == 4) { const lcd_v4i t = *(const lcd_lds_v4i *)(uintptr_t)o; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else if constexpr (C == 2) { const lcd_v2i t = *(const __attribute__((address_space(3))) lcd_v2i *)(uintptr_t)o; v[0] = t.x; v[1] = t.y; }
+    else v[0] = *(const lcd_lds_i32 *)(uintptr_t)o;
+}
+template <int C> __device__ __forceinline__ void lds_stc(const unsigned o, const int (&v)[C]) {
+    if constexpr (C == 4) { lcd_v4i t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; *(lcd_lds_v4i *)(uintptr_t)o = t; }
+    else if constexpr (C == 2) { lcd_v2i t; t.x = v[0]; t.y = v[1]; *(__attribute__((address_space(3))) lcd_v2i *)(uintptr_t)o = t; }
+    else *(lcd_lds_i32 *)(uintptr_t)o = v[0];
+}
+template <int C> __device__ __forceinline__ void glb_ldc(const int *p, int (&v)[C]) {
+    if constexpr (C == 4) { const lcd_v4i t = *(const lcd_glb_v4i *)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else if constexpr (C == 2) { const lcd_v2i t = *(const __attribute__((address_space(1))) lcd_v2i *)p; v[0] = t.x; v[1] = t.y; }
+    else v[0] = *(const lcd_glb_i32 *)p;
+}
+template <int C> __device__ __forceinline__ void glb_stc(int *p, const int (&v)[C]) {
+    if constexpr (C == 4) { lcd_v4i t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; *(lcd_glb_v4i *)p = t; }
+    else if constexpr (C == 2) { lcd_v2i t; t.x = v[0]; t.y = v[1]; *(__attribute__((address_space(1))) lcd_v2i *)p = t; }
+    else *(lcd_glb_i32 *)p = v[0];
+}
+
+// C = cells per lane = WIN / NT.  C = 4 is the general shape; the single-wavefront class also has C = 2 and C = 1 for narrow bands
+// (a 40-column HiFi band uses 10 of 64 lanes at four cells per lane, and every lane pays the cell code four times: fewer cells per
+// lane means proportionally fewer instructions per row for the same band).
+template <int NT, bool BANDED, int C>
 __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const unsigned ring_, const unsigned sq1_, const unsigned pd_ /* 0xffffffff: none */, const LcdScoring sc_, const int w_,
                               const int bi_, const int ei_, const int rem_beg_, const uint8_t *seq_hbm_, const int qlen_,
                               WinOut *wo_) {
     constexpr int NW = NT / 64, K = Cfg<NT>::K;
+    constexpr int WIN = NT * C, WM = WIN - 1, SLOTW = 3 * WIN, CM = ~(C - 1);
     Smem &sm = g_smem;
     Ctx g = *usgpr(gp_); // (by pointer: a by-value context is 440 B of outgoing-argument stack per call site and per lane)
     ctx_to_sgpr(g);
@@ -767,10 +794,8 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
     const int w = usgpr(w_), bi = usgpr(bi_), ei = usgpr(ei_), rem_beg = usgpr(rem_beg_), qlen = usgpr(qlen_);
     const uint8_t *seq_hbm = usgpr(seq_hbm_); WinOut *wo = usgpr(wo_);
     LcdScoring sc; sc.match = usgpr(sc_.match); sc.mismatch = usgpr(sc_.mismatch); sc.o1 = usgpr(sc_.o1); sc.e1 = usgpr(sc_.e1); sc.o2 = usgpr(sc_.o2); sc.e2 = usgpr(sc_.e2); sc.dbg = usgpr(sc_.dbg);
-    const int WIN = g.wmax, WM = WIN - 1, SLOTW = 3 * WIN;
     const int tid = threadIdx.x, lane = tid & 63, wave = usgpr(tid >> 6); // (wave in an SGPR: branches on it are scalar)
     const int o1 = sc.o1, e1 = sc.e1, o2 = sc.o2, e2 = sc.e2, oe1 = o1 + e1, oe2 = o2 + e2;
-    const bool act = 4 * tid < WIN;
     const int QB = (qlen + 12 + 15) & ~15;
     for (int j = tid; j < QB; j += NT) lds_st_u8(sq1 + j, (j >= 1 && j <= qlen) ? seq_hbm[j - 1] : 4); // shifted: sq1[j] = q[j-1]
     const int qclamp = QB - 4;
@@ -783,21 +808,18 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
     {
         const bool spf = (g.imap[bi] & 2) != 0;
         if (spf && spill_rows < 1) { wo->status = LCD_ERR_CELLS; return 0; }
-        if (act) {
-            int hh[4], aa[4], bb[4];
+        int hh[C], aa[C], bb[C];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int j = 4 * tid + k;
-                if (j <= end0) {
-                    const int f1 = j ? -(o1 + e1 * j) : LCD_NEG, f2 = j ? -(o2 + e2 * j) : LCD_NEG;
-                    const int h = j ? imax(f1, f2) : 0;
-                    hh[k] = h; aa[k] = h - oe1; bb[k] = h - oe2;
-                } else { hh[k] = LCD_GUARD; aa[k] = LCD_GUARD; bb[k] = LCD_GUARD; }
-            }
-            const int4 H4 = make_int4(hh[0], hh[1], hh[2], hh[3]), A4 = make_int4(aa[0], aa[1], aa[2], aa[3]), B4 = make_int4(bb[0], bb[1], bb[2], bb[3]);
-            lds_st4(ring + 16 * tid, H4); lds_st4(ring + 4 * (WIN + 4 * tid), A4); lds_st4(ring + 4 * (2 * WIN + 4 * tid), B4);
-            if (spf) { int *G = g.spill; glb_st4(G + 4 * tid, H4); glb_st4(G + WIN + 4 * tid, A4); glb_st4(G + 2 * WIN + 4 * tid, B4); }
+        for (int k = 0; k < C; ++k) {
+            const int j = C * tid + k;
+            if (j <= end0) {
+                const int f1 = j ? -(o1 + e1 * j) : LCD_NEG, f2 = j ? -(o2 + e2 * j) : LCD_NEG;
+                const int h = j ? imax(f1, f2) : 0;
+                hh[k] = h; aa[k] = h - oe1; bb[k] = h - oe2;
+            } else { hh[k] = LCD_GUARD; aa[k] = LCD_GUARD; bb[k] = LCD_GUARD; }
         }
+        lds_stc<C>(ring + 4 * (C * tid), hh); lds_stc<C>(ring + 4 * (WIN + C * tid), aa); lds_stc<C>(ring + 4 * (2 * WIN + C * tid), bb);
+        if (spf) { int *G = g.spill; glb_stc<C>(G + C * tid, hh); glb_stc<C>(G + WIN + C * tid, aa); glb_stc<C>(G + 2 * WIN + C * tid, bb); }
         if (tid == 0) { g.rbeg[bi] = 0; g.rend[bi] = end0; g.roff[bi] = 0; g.ml[bi] = 0; g.mr[bi] = 0; g.spoff[bi] = 0; }
         if (spf) nsp = 1;
     }
@@ -859,25 +881,26 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
                 if (tid == 0) { glb_st(g.rbeg + idx, 1); glb_st(g.rend + idx, 0); }
                 continue;
             }
-            if (end - (beg & ~3) + 2 > WIN) return -1;
+            if (end - (beg & CM) + 2 > WIN) return -1;
         }
-        const int beg4 = beg & ~3;
-        const int jb = beg4 + 4 * tid;
+        const int begc = beg & CM;
+        const int jb = begc + C * tid;
         const int x = jb & WM, xm = (jb - 1) & WM;
-        const bool i0 = act && jb >= beg && jb <= end, i1 = act && jb + 1 >= beg && jb + 1 <= end;
-        const bool i2 = act && jb + 2 >= beg && jb + 2 <= end, i3 = act && jb + 3 >= beg && jb + 3 <= end;
-        int s0, s1, s2, s3;
+        bool inb[C]; int sk[C];
         {
-            const unsigned qw = (unsigned)lds_ld(sq1 + imin(jb, qclamp)); // q[jb-1], q[jb], q[jb+1], q[jb+2]
-            const int q0 = qw & 255, q1 = (qw >> 8) & 255, q2 = (qw >> 16) & 255, q3 = qw >> 24;
-            s0 = (vb >= 4 || q0 >= 4) ? 0 : (vb == q0 ? sc.match : -sc.mismatch);
-            s1 = (vb >= 4 || q1 >= 4) ? 0 : (vb == q1 ? sc.match : -sc.mismatch);
-            s2 = (vb >= 4 || q2 >= 4) ? 0 : (vb == q2 ? sc.match : -sc.mismatch);
-            s3 = (vb >= 4 || q3 >= 4) ? 0 : (vb == q3 ? sc.match : -sc.mismatch);
+            const int jq = imin(jb, qclamp);
+            const unsigned qw = (unsigned)lds_ld(sq1 + (jq & ~3)) >> (8 * (jq & 3)); // q[jb-1], q[jb], ...: C <= 4 bytes from one aligned word
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                inb[k] = jb + k >= beg && jb + k <= end;
+                const int q = (qw >> (8 * k)) & 255;
+                sk[k] = (vb >= 4 || q >= 4) ? 0 : (vb == q ? sc.match : -sc.mismatch);
+            }
         }
-        // ---- phase A: best match / E1 / E2 input of the four cells over the predecessors (first maximum keeps its ordinal) ----
-        int n0 = LCD_NEG, n1 = LCD_NEG, n2 = LCD_NEG, n3 = LCD_NEG, u0 = LCD_NEG, u1 = LCD_NEG, u2 = LCD_NEG, u3 = LCD_NEG;
-        int v0 = LCD_NEG, v1 = LCD_NEG, v2 = LCD_NEG, v3 = LCD_NEG;
+        // ---- phase A: best match / E1 / E2 input of the cells over the predecessors (first maximum keeps its ordinal) ----
+        int nn[C], uu[C], vv[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) { nn[k] = LCD_NEG; uu[k] = LCD_NEG; vv[k] = LCD_NEG; }
         int om = 0, oa = 0, ob = 0; // ordinals, one byte per cell
         bool overflow = false;
         for (int t = 0; t < np; ++t) {
@@ -891,44 +914,43 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
                 if (pb > pe) continue;
                 if (pe - beg + 2 >= WIN || end - pb + 1 >= WIN) { overflow = true; break; }
             }
-            int hm = LCD_GUARD; int4 hv = make_int4(LCD_GUARD, LCD_GUARD, LCD_GUARD, LCD_GUARD), av = hv, bv = hv;
+            int hm, hv[C], av[C], bv[C];
             if (near) {
                 const unsigned S = ring + 4 * sp * SLOTW;
-                if (act) { hm = lds_ld(S + 4 * xm); hv = lds_ld4(S + 4 * x); av = lds_ld4(S + 4 * (WIN + x)); bv = lds_ld4(S + 4 * (2 * WIN + x)); }
+                hm = lds_ld(S + 4 * xm); lds_ldc<C>(S + 4 * x, hv); lds_ldc<C>(S + 4 * (WIN + x), av); lds_ldc<C>(S + 4 * (2 * WIN + x), bv);
             } else {
                 if (!synced) { __syncthreads(); synced = true; }
                 const int *G = g.spill + (size_t)g.spoff[pi] * SLOTW;
-                if (act) { hm = glb_ld(G + xm); hv = glb_ld4(G + x); av = glb_ld4(G + WIN + x); bv = glb_ld4(G + 2 * WIN + x); }
-                LCD_PIN(hm); LCD_PIN(hv.x); LCD_PIN(hv.y); LCD_PIN(hv.z); LCD_PIN(hv.w); LCD_PIN(av.x); LCD_PIN(av.y); LCD_PIN(av.z); LCD_PIN(av.w);
-                LCD_PIN(bv.x); LCD_PIN(bv.y); LCD_PIN(bv.z); LCD_PIN(bv.w);
+                hm = glb_ld(G + xm); glb_ldc<C>(G + x, hv); glb_ldc<C>(G + WIN + x, av); glb_ldc<C>(G + 2 * WIN + x, bv);
+                LCD_PIN(hm);
+#pragma unroll
+                for (int k = 0; k < C; ++k) { LCD_PIN(hv[k]); LCD_PIN(av[k]); LCD_PIN(bv[k]); }
             }
-            const int c0 = hm + s0 + bz, c1 = hv.x + s1 + bz, c2 = hv.y + s2 + bz, c3 = hv.z + s3 + bz;
-            const int a0 = av.x + bz, a1 = av.y + bz, a2 = av.z + bz, a3 = av.w + bz;
-            const int b0 = bv.x + bz, b1 = bv.y + bz, b2 = bv.z + bz, b3 = bv.w + bz;
-            if (t == 0) {
-                n0 = imax(n0, c0); n1 = imax(n1, c1); n2 = imax(n2, c2); n3 = imax(n3, c3);
-                u0 = imax(u0, a0); u1 = imax(u1, a1); u2 = imax(u2, a2); u3 = imax(u3, a3);
-                v0 = imax(v0, b0); v1 = imax(v1, b1); v2 = imax(v2, b2); v3 = imax(v3, b3);
-            } else {
-                const int tt = t > 255 ? 255 : t;
-#define LCD_UPD(cur, cand, ordv, sh) if ((cand) > (cur)) { cur = (cand); ordv = (ordv & ~(255 << (sh))) | (tt << (sh)); }
-                LCD_UPD(n0, c0, om, 0) LCD_UPD(n1, c1, om, 8) LCD_UPD(n2, c2, om, 16) LCD_UPD(n3, c3, om, 24)
-                LCD_UPD(u0, a0, oa, 0) LCD_UPD(u1, a1, oa, 8) LCD_UPD(u2, a2, oa, 16) LCD_UPD(u3, a3, oa, 24)
-                LCD_UPD(v0, b0, ob, 0) LCD_UPD(v1, b1, ob, 8) LCD_UPD(v2, b2, ob, 16) LCD_UPD(v3, b3, ob, 24)
-#undef LCD_UPD
+            const int tt = t > 255 ? 255 : t;
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const int c = (k == 0 ? hm : hv[k - 1]) + sk[k] + bz, a = av[k] + bz, b = bv[k] + bz;
+                if (t == 0) { nn[k] = imax(nn[k], c); uu[k] = imax(uu[k], a); vv[k] = imax(vv[k], b); }
+                else {
+                    if (c > nn[k]) { nn[k] = c; om = (om & ~(255 << (8 * k))) | (tt << (8 * k)); }
+                    if (a > uu[k]) { uu[k] = a; oa = (oa & ~(255 << (8 * k))) | (tt << (8 * k)); }
+                    if (b > vv[k]) { vv[k] = b; ob = (ob & ~(255 << (8 * k))) | (tt << (8 * k)); }
+                }
             }
         }
         if (overflow) return -1;
         if (np > 256) return -1; // ordinals are 8 bits: such a row goes through the generic rows
-        const int h0 = imax(n0, imax(u0, v0)), h1 = imax(n1, imax(u1, v1)), h2 = imax(n2, imax(u2, v2)), h3 = imax(n3, imax(u3, v3)); // Hpre
-        const int sp0 = n0 == h0 ? 0 : u0 == h0 ? 1 : 2, sp1 = n1 == h1 ? 0 : u1 == h1 ? 1 : 2, sp2 = n2 == h2 ? 0 : u2 == h2 ? 1 : 2, sp3 = n3 == h3 ? 0 : u3 == h3 ? 1 : 2;
         // ---- F: A[k] = Hpre[k] + k*e; in-lane inclusive prefix, then one scan pair over the lane totals ----
+        int hp[C], spk[C], a1[C], a2[C], p1[C], p2[C];
         const int je1 = jb * e1, je2 = jb * e2;
-        const int a10 = i0 ? h0 + je1 : LCD_GUARD, a11 = i1 ? h1 + je1 + e1 : LCD_GUARD, a12 = i2 ? h2 + je1 + 2 * e1 : LCD_GUARD, a13 = i3 ? h3 + je1 + 3 * e1 : LCD_GUARD;
-        const int a20 = i0 ? h0 + je2 : LCD_GUARD, a21 = i1 ? h1 + je2 + e2 : LCD_GUARD, a22 = i2 ? h2 + je2 + 2 * e2 : LCD_GUARD, a23 = i3 ? h3 + je2 + 3 * e2 : LCD_GUARD;
-        const int p10 = a10, p11 = imax(p10, a11), p12 = imax(p11, a12);
-        const int p20 = a20, p21 = imax(p20, a21), p22 = imax(p21, a22);
-        int t1 = imax(p12, a13), t2 = imax(p22, a23);
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            hp[k] = imax(nn[k], imax(uu[k], vv[k]));                     // Hpre
+            spk[k] = nn[k] == hp[k] ? 0 : uu[k] == hp[k] ? 1 : 2;        // which of match / E1 / E2 gives it (the oracle's priority)
+            a1[k] = inb[k] ? hp[k] + je1 + k * e1 : LCD_GUARD; a2[k] = inb[k] ? hp[k] + je2 + k * e2 : LCD_GUARD;
+            p1[k] = k ? imax(p1[k - 1], a1[k]) : a1[k]; p2[k] = k ? imax(p2[k - 1], a2[k]) : a2[k];
+        }
+        int t1 = p1[C - 1], t2 = p2[C - 1];
         scan_max2(t1, t2);
         int x1 = shr1(LCD_GUARD, t1), x2 = shr1(LCD_GUARD, t2); // exclusive prefix over the lanes of this wavefront
         if (NW > 1) {
@@ -938,36 +960,37 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
 #pragma unroll
             for (int k = 0; k < NW; ++k) if (k < wave) { x1 = imax(x1, sm.tot1[buf][k]); x2 = imax(x2, sm.tot2[buf][k]); }
         }
-        // ---- phase B: F, H, E-out, direction code of the four cells ----
-        int hh0, hh1, hh2, hh3, ea0, ea1, ea2, ea3, eb0, eb1, eb2, eb3;
+        // ---- phase B: F, H, E-out, direction code of the cells ----
+        int hh[C], ea[C], eb[C];
         unsigned code = 0;
-#define LCD_CELL(k, inb, hp, mxv, ev1, ev2, pf1, pf2, ak1, ak2, HO, AO, BO)                                                \
-        {                                                                                                                   \
-            const int f1 = imax(LCD_NEG, (pf1) - o1 - je1 - (k) * e1), f2 = imax(LCD_NEG, (pf2) - o2 - je2 - (k) * e2);     \
-            const int h = imax(hp, imax(f1, f2));                                                                           \
-            int eo1 = imax(h - oe1, (ev1) - e1), eo2 = imax(h - oe2, (ev2) - e2);                                           \
-            if (BANDED) { eo1 = imax(eo1, LCD_NEG); eo2 = imax(eo2, LCD_NEG); }                                             \
-            const int fk = f1 == h ? (f2 == h ? 5 : 3) : 4;                                                                 \
-            const int hs = (hp) == h ? (mxv) : fk; /* (mxv): which of match / E1 / E2 gives Hpre, the oracle's priority */   \
-            unsigned fl = 0; /* O2, O1, Y2, Y1 pushed in this order = bits 6, 5, 4, 3 of the code */                        \
-            { const int t2 = h - oe2, w2 = (ev2) - e2, t1 = h - oe1, w1 = (ev1) - e1, q2 = (pf2), r2 = (ak2), q1 = (pf1), r1 = (ak1); \
-              LCD_PUSH_GE(fl, t2, w2); LCD_PUSH_GE(fl, t1, w1); LCD_PUSH_GT(fl, q2, r2); LCD_PUSH_GT(fl, q1, r1); }         \
-            const unsigned cd = (unsigned)hs | (fl << 3) | (((om >> (8 * (k))) & 255) ? CB_PM : 0);                         \
-            code |= cd << (8 * (k));                                                                                        \
-            HO = (inb) ? h : LCD_GUARD; AO = (inb) ? eo1 : LCD_GUARD; BO = (inb) ? eo2 : LCD_GUARD;                         \
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int pf1 = k ? imax(x1, p1[k - 1]) : x1, pf2 = k ? imax(x2, p2[k - 1]) : x2;
+            const int f1 = imax(LCD_NEG, pf1 - o1 - je1 - k * e1), f2 = imax(LCD_NEG, pf2 - o2 - je2 - k * e2);
+            const int h = imax(hp[k], imax(f1, f2));
+            int eo1 = imax(h - oe1, uu[k] - e1), eo2 = imax(h - oe2, vv[k] - e2);
+            if (BANDED) { eo1 = imax(eo1, LCD_NEG); eo2 = imax(eo2, LCD_NEG); }
+            const int fk = f1 == h ? (f2 == h ? 5 : 3) : 4;
+            const int hs = hp[k] == h ? spk[k] : fk;
+            unsigned fl = 0; // O2, O1, Y2, Y1 pushed in this order = bits 6, 5, 4, 3 of the code
+            { const int q2 = h - oe2, w2 = vv[k] - e2, q1 = h - oe1, w1 = uu[k] - e1, r2 = a2[k], r1 = a1[k];
+              LCD_PUSH_GE(fl, q2, w2); LCD_PUSH_GE(fl, q1, w1); LCD_PUSH_GT(fl, pf2, r2); LCD_PUSH_GT(fl, pf1, r1); }
+            const unsigned cd = (unsigned)hs | (fl << 3) | (((om >> (8 * k)) & 255) ? CB_PM : 0);
+            code |= cd << (8 * k);
+            hh[k] = inb[k] ? h : LCD_GUARD; ea[k] = inb[k] ? eo1 : LCD_GUARD; eb[k] = inb[k] ? eo2 : LCD_GUARD;
         }
-        LCD_CELL(0, i0, h0, sp0, u0, v0, x1, x2, a10, a20, hh0, ea0, eb0)
-        LCD_CELL(1, i1, h1, sp1, u1, v1, imax(x1, p10), imax(x2, p20), a11, a21, hh1, ea1, eb1)
-        LCD_CELL(2, i2, h2, sp2, u2, v2, imax(x1, p11), imax(x2, p21), a12, a22, hh2, ea2, eb2)
-        LCD_CELL(3, i3, h3, sp3, u3, v3, imax(x1, p12), imax(x2, p22), a13, a23, hh3, ea3, eb3)
-#undef LCD_CELL
         // ---- row maximum, leftmost / rightmost column (banded rows only: w = qlen never consumes them) ----
         int ml = 0, mr = 0;
         if (BANDED) {
             // (the out-of-band cells already hold LCD_GUARD, below every real H)
-            const int hb = imax(imax(hh0, hh1), imax(hh2, hh3));
-            const int bl = hh0 == hb ? jb : hh1 == hb ? jb + 1 : hh2 == hb ? jb + 2 : jb + 3;
-            const int brr = hh3 == hb ? jb + 3 : hh2 == hb ? jb + 2 : hh1 == hb ? jb + 1 : jb;
+            int hb = hh[0];
+#pragma unroll
+            for (int k = 1; k < C; ++k) hb = imax(hb, hh[k]);
+            int bl = jb + C - 1, brr = jb;
+#pragma unroll
+            for (int k = C - 2; k >= 0; --k) bl = hh[k] == hb ? jb + k : bl;
+#pragma unroll
+            for (int k = 1; k < C; ++k) brr = hh[k] == hb ? jb + k : brr;
             const int wm = lane63(scan_max(hb));
             const unsigned long long mk = __ballot(hb == wm && hb > LCD_GUARD);
             int wl = 1 << 30, wr = -1;
@@ -987,19 +1010,23 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
             } else { ml = wl; mr = wr; }
         }
         // ---- stores: ring slot (values), HBM (codes; values only for rows a far successor / the end node will read) ----
-        const int cw4 = (((end - beg4) >> 2) + 1) << 2; // cells of this row in HBM, padded to the lanes' 4-cell groups
+        const int cw4 = ((end - begc) + 4) & ~3; // cells of this row in HBM, padded to a multiple of 4 (rows stay dword-aligned for every C)
         if (cused + cw4 > code_cap || (np > 1 && oused + cw4 > ord_cap) || (spf && nsp >= spill_rows)) { wo->status = LCD_ERR_CELLS; return 0; }
-        if (act) {
+        {
             const unsigned S = ring + 4 * s * SLOTW;
-            const int4 H4 = make_int4(hh0, hh1, hh2, hh3), A4 = make_int4(ea0, ea1, ea2, ea3), B4 = make_int4(eb0, eb1, eb2, eb3);
-            lds_st4(S + 4 * x, H4); lds_st4(S + 4 * (WIN + x), A4); lds_st4(S + 4 * (2 * WIN + x), B4);
-            if (spf) { int *G = g.spill + (size_t)nsp * SLOTW; glb_st4(G + x, H4); glb_st4(G + WIN + x, A4); glb_st4(G + 2 * WIN + x, B4); }
-            if (4 * tid < cw4) {
-                glb_st(g.code8 + cused + 4 * tid, (int)code);
-                if (np > 1) glb_st4(g.ord + oused + 4 * tid, make_int4((om & 255) | ((oa & 255) << 8) | ((ob & 255) << 16),
-                                                                           ((om >> 8) & 255) | (((oa >> 8) & 255) << 8) | (((ob >> 8) & 255) << 16),
-                                                                           ((om >> 16) & 255) | (((oa >> 16) & 255) << 8) | (((ob >> 16) & 255) << 16),
-                                                                           ((om >> 24) & 255) | (((oa >> 24) & 255) << 8) | (((ob >> 24) & 255) << 16)));
+            lds_stc<C>(S + 4 * x, hh); lds_stc<C>(S + 4 * (WIN + x), ea); lds_stc<C>(S + 4 * (2 * WIN + x), eb);
+            if (spf) { int *G = g.spill + (size_t)nsp * SLOTW; glb_stc<C>(G + x, hh); glb_stc<C>(G + WIN + x, ea); glb_stc<C>(G + 2 * WIN + x, eb); }
+            if (C * tid < cw4) {
+                uint8_t *cp = g.code8 + cused + C * tid;
+                if constexpr (C == 4) glb_st(cp, (int)code);
+                else if constexpr (C == 2) *(__attribute__((address_space(1))) unsigned short *)cp = (unsigned short)code;
+                else *(__attribute__((address_space(1))) uint8_t *)cp = (uint8_t)code;
+                if (np > 1) {
+                    int ow[C];
+#pragma unroll
+                    for (int k = 0; k < C; ++k) ow[k] = ((om >> (8 * k)) & 255) | (((oa >> (8 * k)) & 255) << 8) | (((ob >> (8 * k)) & 255) << 16);
+                    glb_stc<C>(g.ord + oused + C * tid, ow);
+                }
             }
         }
         if (tid == 0) {
@@ -1015,7 +1042,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
     wo->cells = ncell;
     const long long t_bt0 = clock64();
     wo->t_dp = (unsigned long long)(t_bt0 - t_dp0);
-    if (wave == 0) code_backtrack(g, sm, pd, bi, ei, qlen, SLOTW, WM, lane);
+    if (wave == 0) code_backtrack(g, sm, pd, bi, ei, qlen, SLOTW, WM, lane, CM);
     __syncthreads();
     const int n_cig = sm.bc[0];
     wo->status = sm.bc[1];
@@ -1057,7 +1084,7 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
     const int bi = usgpr(bi_), ei = usgpr(ei_), qlen = usgpr(qlen_);
     const uint8_t *seq_hbm = usgpr(seq_hbm_); WinOut *wo = usgpr(wo_);
     LcdScoring sc; sc.match = usgpr(sc_.match); sc.mismatch = usgpr(sc_.mismatch); sc.o1 = usgpr(sc_.o1); sc.e1 = usgpr(sc_.e1); sc.o2 = usgpr(sc_.o2); sc.e2 = usgpr(sc_.e2); sc.dbg = usgpr(sc_.dbg);
-    const int WIN = g.wmax, WM = WIN - 1, SLOTW = 3 * WIN;
+    constexpr int WIN = 4 * NT, WM = WIN - 1, SLOTW = 3 * WIN;
     const int tid = threadIdx.x, lane = tid & 63, wave = usgpr(tid >> 6); // (wave in an SGPR: branches on it are scalar)
     const int o1 = sc.o1, e1 = sc.e1, o2 = sc.o2, e2 = sc.e2;
     if (qlen + 2 > WIN) return -1;
@@ -1274,7 +1301,7 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
     if (tid == (AW - 1) * 64) { sm.prof[0] = t_plan; sm.prof[1] = t_poll; } // (profiling aid: the LAST active wavefront's view)
     const long long t_bt0 = clock64();
     wo->t_dp = (unsigned long long)(t_bt0 - t_dp0);
-    if (wave == 0) code_backtrack(g, sm, pd, bi, ei, qlen, SLOTW, WM, lane);
+    if (wave == 0) code_backtrack(g, sm, pd, bi, ei, qlen, SLOTW, WM, lane, ~3);
     __syncthreads();
     const int n_cig = sm.bc[0];
     wo->status = sm.bc[1];
@@ -1298,7 +1325,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
                                  const uint8_t *seq_hbm, int qlen, unsigned long long *cells_acc) {
     constexpr int NW = NT / 64, K = Cfg<NT>::K;
     constexpr int MP = NW == 1 ? 0 : MAXP; // predecessors staged in LDS per row (single-wavefront rows keep them in registers or read the plan)
-    const int WMAX = g.wmax; // ring slot capacity in columns: chosen per launch from the chains' lengths (dynamic LDS)
+    constexpr int WMAX = 4 * NT; // ring slot capacity in columns (the widest window of the class)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     g.cig_node = g.cig_node0; g.cig_qpos = g.cig_qpos0;
     if (qlen <= 0) return 0;
@@ -1314,13 +1341,23 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
     if (QB > g.seq_cap) { g.status = LCD_ERR_LDS; return 0; } // read slice longer than the LDS query cache (host sizes the class)
     uint8_t *pd = (QB + (ei - bi) + 16 <= g.seq_cap) ? sseq + QB : nullptr;
     build_plan<NT>(g, sm, bi, ei, remain_end, pd, K);
-    if (!(sc.dbg & 8) && WMAX <= NT * 4 && (WMAX & (WMAX - 1)) == 0) {
+    if (!(sc.dbg & 8)) {
         WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0; wo.t_plan = wo.t_poll = 0;
         const int rem_beg = g.remain[beg_node] - remain_end;
-        const unsigned pdo = pd ? lds_off(pd) : 0xffffffffu;
-        int nc = wb < 0 ? align_unbanded<NT>(&g, lds_off(ring), pdo, sc, bi, ei, seq_hbm, qlen, &wo)
-                        : align_windowed<NT, true>(&g, lds_off(ring), lds_off(sseq), pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
-        if (nc < 0 && wb < 0) { __syncthreads(); nc = align_windowed<NT, false>(&g, lds_off(ring), lds_off(sseq), pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+        const unsigned pdo = pd ? lds_off(pd) : 0xffffffffu, ro = lds_off(ring), so = lds_off(sseq);
+        int nc = -1;
+        if (wb < 0) {
+            nc = align_unbanded<NT>(&g, ro, pdo, sc, bi, ei, seq_hbm, qlen, &wo);
+            if (nc < 0) { __syncthreads(); nc = align_windowed<NT, false, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+        } else {
+            // the host's preferred window (PoaChain.wmax) first; a band that outgrows it is re-run in the next wider one
+            if constexpr (NT == 64) {
+                if (g.wmax <= 64) nc = align_windowed<NT, true, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+                if (nc < 0 && g.wmax <= 128) { __syncthreads(); nc = align_windowed<NT, true, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                if (nc < 0) __syncthreads();
+            }
+            if (nc < 0) nc = align_windowed<NT, true, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+        }
         if (nc >= 0) {
             g.status = wo.status; g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells; g.t_plan += wo.t_plan; g.t_poll += wo.t_poll;
             g.cig_node = g.cig_node0 + wo.cig_pos; g.cig_qpos = g.cig_qpos0 + wo.cig_pos;
@@ -1665,7 +1702,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     int *ring = lds_pool;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const PoaChain ch = chains[cid];
-    uint8_t *sseq = (uint8_t *)(lds_pool + Cfg<NT>::K * 3 * ch.wmax);
+    uint8_t *sseq = (uint8_t *)(lds_pool + Cfg<NT>::K * 3 * (4 * NT)); // the ring is sized for the widest window of the class
     const PoaLayout L = poa_layout(ch.node_cap, ch.edge_cap, ch.rid_words, ch.max_len, ch.cell_cap, ch.n_reads);
     uint8_t *ws = arena + ch.ws_off;
     Ctx g;
@@ -1692,7 +1729,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.pl_rem = (int *)(ws + L.pl_rem); g.pl_base = ws + L.pl_base;
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
-    g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - Cfg<NT>::K * 3 * ch.wmax) * 4;
+    g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - Cfg<NT>::K * 3 * (4 * NT)) * 4;
     g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0;
     const long long t_begin = clock64();
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
