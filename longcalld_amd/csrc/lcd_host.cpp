@@ -579,7 +579,8 @@ static void chain_class(PoaChain &pc) {
     // (a 2 048-column chain in a 1 024-thread workgroup would hold a whole CU's registers with half of its wavefronts parked)
     if (width <= 256) { // single wavefront; banded chains prefer the narrowest window their band fits (1, 2 or 4 cells per lane, align_windowed)
         threads = 64; K = 2;
-        const long long bw = 2ll * (10 + pc.max_len / 100) + 1 + 24; // adaptive band + a little drift; a band that outgrows it is re-run wider
+        static const int margin = getenv("LCD_BAND_MARGIN") ? atoi(getenv("LCD_BAND_MARGIN")) : 12;
+        const long long bw = 2ll * (10 + pc.max_len / 100) + 1 + margin; // adaptive band + a little drift; a band that outgrows it is re-run wider
         wmax = pc.mode == 1 ? 256 : bw <= 60 ? 64 : bw <= 124 ? 128 : 256;
     }
     else if (width <= 512) { threads = 128; K = 2; wmax = 512; }
