@@ -182,14 +182,14 @@ uint64_t wfa_arena_bytes(int plen, int tlen, int s_cap) {
     else tot = (s_sw + 1) * (s_sw + 3) + ((uint64_t)s_cap - s_sw) * wmax;
     return hdr + tot * 5 * 4 + 256;
 }
-std::atomic<int> g_wfa_hint{0}; // 0..2: learned from the overflow retries of earlier WFA stages (noisy reads), see wfa_default_scap
-int wfa_default_scap(int plen, int tlen) {
+std::atomic<int> g_wfa_hint{0}; // 0..2: learned from the overflow retries of earlier ANCHOR stages (read vs read windows of noisy reads)
+int wfa_default_scap(int plen, int tlen, bool anchor = false) {
     int d = plen > tlen ? plen - tlen : tlen - plen;
     int m = plen < tlen ? plen : tlen;
     // enough for the length difference as one long gap plus ~1.5 % divergence (the arena grows with the SQUARE of this bound: 6 % for
     // everybody was 5-10 GB per 1 250 regions); jobs that overflow are retried with 4x, and data that keeps overflowing starts higher
     static const double div[3] = {0.015, 0.06, 0.20};
-    long long s = 24 + d + 64 + (long long)(m * div[g_wfa_hint.load()]) * 6;
+    long long s = 24 + d + 64 + (long long)(m * div[anchor ? g_wfa_hint.load() : 0]) * 6; // (ref<->cons and segment jobs are clean: no hint)
     return (int)std::min<long long>(s, 2000000);
 }
 uint64_t ed_arena_bytes(int qlen, int tlen) { return (uint64_t)52432 * 20 + (uint64_t)qlen * 8 + (uint64_t)tlen * 2 + 512; }
@@ -229,6 +229,7 @@ int launch_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, const std::vecto
         WfaJob &j = jobs[which[i]];
         j.ws_bytes = lcd_align_up(wfa_arena_bytes(j.plen, j.tlen, j.s_cap), 256); j.ws_off = tot; tot += j.ws_bytes;
     }
+    if (getenv("LCD_MEM_DEBUG")) fprintf(stderr, "[mem] WFA stage: %d jobs, arena %.2f GB (hint %d)\n", n, tot / 1e9, g_wfa_hint.load());
     if (d_arena.ensure(tot)) return -11;
     for (int i = 0; i < n; ++i) { jobs[which[i]].ws_off += d_arena.addr(); sub[i] = jobs[which[i]]; }
     if (d_jobs.ensure(n * sizeof(WfaJob)) || d_outs.ensure(n * sizeof(WfaOut))) return -11;
@@ -240,7 +241,7 @@ int launch_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, const std::vecto
 }
 // full WFA stage with the overflow retry ladder (s_cap x4)
 int run_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, DevBuf &d_jobs, DevBuf &d_arena, DevBuf &d_out, DevBuf &d_outs,
-                  std::vector<WfaOut> &outs, LcdScoring sc, int *retries) {
+                  std::vector<WfaOut> &outs, LcdScoring sc, int *retries, bool learn = false) {
     const int n = (int)jobs.size();
     outs.assign(n, WfaOut());
     if (n == 0) return 0;
@@ -264,7 +265,7 @@ int run_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, DevBuf &d_jobs, Dev
             if (tmp[i].status == LCD_ERR_WF) { jobs[which[i]].s_cap = (int)std::min<long long>((long long)jobs[which[i]].s_cap * 4 + 64, 4000000); again.push_back(which[i]); }
             else if (tmp[i].status != LCD_OK) return set_err(-20, "WFA kernel status " + std::to_string(tmp[i].status));
         }
-        if (round == 0 && again.size() * 20 > which.size() && g_wfa_hint.load() < 2) g_wfa_hint++;
+        if (learn && round == 0 && again.size() * 20 > which.size() && g_wfa_hint.load() < 2) g_wfa_hint++;
         if (!again.empty() && retries) (*retries)++;
         which.swap(again);
     }
@@ -422,7 +423,7 @@ int lcd_batch_add_region(lcd_batch_t *b, int64_t reg_len, int n_reads, const int
                 if (ext == 1) { ej.t_off = toff; ej.q_off = qoff; } else { ej.t_off = toff + tlen - min_len; ej.q_off = qoff + qlen - min_len; }
                 A.ed_job = (int)b->ed_jobs.size(); b->ed_jobs.push_back(ej);
                 WfaJob wj; wj.p_off = toff; wj.plen = tlen; wj.t_off = qoff; wj.tlen = qlen; wj.gap_aln = gap_aln; wj.want = 1;
-                wj.s_cap = wfa_default_scap(tlen, qlen); wj.ws_off = 0; wj.ws_bytes = 0; wj.out_off = 0;
+                wj.s_cap = wfa_default_scap(tlen, qlen, true); wj.ws_off = 0; wj.ws_bytes = 0; wj.out_off = 0;
                 A.wfa_job = (int)b->wfa_jobs.size(); b->wfa_jobs.push_back(wj);
                 b->anchors.push_back(A);
             }
@@ -722,7 +723,7 @@ int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
             std::vector<EdOut> eo; std::vector<WfaOut> wo;
             int rc = run_edlib_stage(st, ej, L->d_ed_jobs, L->d_ed_arena, L->d_ed_outs, eo);
             if (rc) return rc;
-            rc = run_wfa_stage(st, wj, L->d_wfa_jobs, L->d_wfa_arena, L->d_wfa_out, L->d_wfa_outs, wo, sc, nullptr);
+            rc = run_wfa_stage(st, wj, L->d_wfa_jobs, L->d_wfa_arena, L->d_wfa_out, L->d_wfa_outs, wo, sc, nullptr, true);
             if (rc) return rc;
             HIPCHK(hipStreamSynchronize(st));
             // cigars of the anchor jobs: ONE device->host copy of the output span of all of them (a copy per job costs more in
