@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import LcdAlnStr, LcdBatchStats, LcdOpt, check, load_library
+from ._lib import LcdAlnStr, LcdBatchStats, LcdDigar1, LcdOpt, LcdReadView, check, load_library
 
 _libc = C.CDLL(None)
 _libc.free.argtypes = [C.c_void_p]
@@ -192,6 +192,16 @@ class RegionBatch:
         self.n_reads.append(n)
         return idx
 
+    def add_region_from_chunk(self, views, reg_beg, reg_end, noisy_reads, ref_slice):
+        """region [reg_beg, reg_end] (1-based, flanks included) of a chunk whose reads are `views` (make_read_views): the digar walk of
+        collect_noisy_read_info (src/align.c:1377-1461) runs inside the library; noisy_reads = chunk read ids overlapping the region"""
+        ids = np.ascontiguousarray(noisy_reads, np.int32)
+        ref = np.ascontiguousarray(ref_slice, np.uint8)
+        idx = check(self.lib.lcd_batch_add_region_from_chunk(self.h, views[0], int(reg_beg), int(reg_end), len(ids), ids.ctypes.data_as(i32p),
+                                                             _p8(ref), len(ref)), self.lib)
+        self.n_reads.append(len(ids))
+        return idx
+
     def upload(self):
         check(self.lib.lcd_batch_upload(self.h), self.lib)
 
@@ -250,6 +260,24 @@ class RegionBatch:
                                                query_beg=s.query_beg, query_end=s.query_end))
                 _libc.free(s.target_aln)
         return res
+
+
+def make_read_views(digars, bseqs, quals, qlens, haps, phase_sets):
+    """lcd_read_view_t[] over numpy storage: digars[i] = (n, 4) int64 rows (pos, type, len, qi) as digar1_t (src/bam_utils.h:27-33),
+    bseqs[i] = 4-bit BAM-packed bases, quals[i] = phred bytes.  Returns (ctypes array, keep-alive list)."""
+    n = len(digars)
+    arr = (LcdReadView * n)()
+    keep = []
+    for i in range(n):
+        d = np.asarray(digars[i], np.int64)
+        da = (LcdDigar1 * max(len(d), 1))()
+        for k in range(len(d)):
+            da[k].pos, da[k].type, da[k].len, da[k].qi = int(d[k, 0]), int(d[k, 1]), int(d[k, 2]), int(d[k, 3])
+        bs = np.ascontiguousarray(bseqs[i], np.uint8); ql = np.ascontiguousarray(quals[i], np.uint8)
+        arr[i].digars = da; arr[i].n_digar = len(d); arr[i].qlen = int(qlens[i])
+        arr[i].bseq = _p8(bs); arr[i].qual = _p8(ql); arr[i].hap = int(haps[i]); arr[i].phase_set = int(phase_sets[i])
+        keep += [da, bs, ql]
+    return arr, keep
 
 
 def _hap_state(prob):

@@ -247,6 +247,24 @@ def collect_noisy_reg_aln_strs(reg, opt=None):
     return res
 
 
+class Digar1(C.Structure):
+    _fields_ = [("pos", C.c_int64), ("type", C.c_int), ("len", C.c_int), ("qi", C.c_int)]
+
+
+def read_region_slice(digars, qlen, reg_beg, reg_end, flank=10):
+    """one read of collect_noisy_read_info (src/align.c:1392-1458): digars = (n, 4) rows (pos, type, len, qi) -> (read_beg, read_end, cover)"""
+    d = np.asarray(digars, np.int64)
+    da = (Digar1 * max(len(d), 1))()
+    for k in range(len(d)):
+        da[k].pos, da[k].type, da[k].len, da[k].qi = int(d[k, 0]), int(d[k, 1]), int(d[k, 2]), int(d[k, 3])
+    rb, re, cv = C.c_int(), C.c_int(), C.c_int()
+    L = lib()
+    L.lcdo_read_region_slice.argtypes = [C.POINTER(Digar1), C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, i32p, i32p, i32p]
+    L.lcdo_read_region_slice.restype = None
+    L.lcdo_read_region_slice(da, len(d), int(qlen), int(reg_beg), int(reg_end), int(flank), C.byref(rb), C.byref(re), C.byref(cv))
+    return rb.value, re.value, cv.value
+
+
 class HapProblem(C.Structure):
     _i64p = C.POINTER(C.c_int64)
     _fields_ = [("n_reads", C.c_int), ("n_vars", C.c_int), ("is_ont", C.c_int), ("var_pos", _i64p), ("var_type", i32p), ("var_cate", i32p),

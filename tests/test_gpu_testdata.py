@@ -1,0 +1,59 @@
+"""SURVEY 8d config 1 on the GPU: the reference's bundled real chunk (tests/golden/testdata_chunk.npz) through the HIP path --
+K5 on the real read x variant profile, then every noisy region through the chunk-view entry (digar walk + 4-bit unpacking in the library)
+with the haplotypes K5 produced -- bit-identical to the oracle and to the committed expected digests."""
+import numpy as np
+import pytest
+
+import testdata_common as tc
+from conftest import same_result
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("haps", "phase_sets", "n_clean_agree_snps", "n_clean_conflict_snps", "var_phase_set", "hap_to_cons_alle")
+
+
+def test_k5_real_profile(lcd):
+    from longcalld_amd import jobs
+    ch = tc.Chunk()
+    got = lcd.assign_hap_germline(ch.hap_problem(), jobs.GERMLINE_CLEAN)
+    for k in KEYS:
+        assert (got[k] == ch.z["exp_" + k]).all(), k
+
+
+def _run_chunk(lcd, ch, haps, pss):
+    views, keep = lcd.make_read_views(ch.digars, ch.bseq, ch.qual, ch.qlen, haps, pss)
+    b = lcd.RegionBatch()
+    for k, (beg, end) in enumerate(ch.regions):
+        b.add_region_from_chunk(views, beg, end, ch.reg_reads(k), ch.ref_slice(k))
+    b.upload(); b.run(); b.download()
+    out = [b.result(k) for k in range(len(ch.regions))]
+    ids = [b.sorted_ids(k) for k in range(len(ch.regions))]
+    b.close()
+    del keep
+    return out, ids
+
+
+def test_real_regions_with_k5_haplotypes(lcd, oracle):
+    from longcalld_amd import jobs
+    ch = tc.Chunk()
+    st = lcd.assign_hap_germline(ch.hap_problem(), jobs.GERMLINE_CLEAN)     # K5 on the GPU feeds K1, as in the reference's pass loop
+    got, ids = _run_chunk(lcd, ch, st["haps"], st["phase_sets"])
+    for k, g in enumerate(got):
+        exp = oracle.collect_noisy_reg_aln_strs(ch.region_dict(oracle, k, st["haps"], st["phase_sets"]))
+        assert (ids[k] == exp["sorted_ids"]).all()
+        same_result(exp, g)
+        assert tc.result_digest(g) == int(ch.z["exp_region_digest"][k]), k
+
+
+def test_real_regions_unphased(lcd, oracle):
+    """the same regions before any read is phased (first pass on a chunk without clean het variants): K2 de-novo MSA + 2 clusters"""
+    ch = tc.Chunk()
+    haps = np.zeros(ch.n_reads, np.int32); pss = np.full(ch.n_reads, -1, np.int64)
+    got, ids = _run_chunk(lcd, ch, haps, pss)
+    n_res = 0
+    for k, g in enumerate(got):
+        exp = oracle.collect_noisy_reg_aln_strs(ch.region_dict(oracle, k, haps, pss))
+        assert (ids[k] == exp["sorted_ids"]).all()
+        same_result(exp, g)
+        n_res += g["n_cons"] > 0
+    assert n_res >= len(ch.regions) // 2

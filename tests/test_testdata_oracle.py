@@ -1,0 +1,46 @@
+"""SURVEY 8d config 1 (the reference's bundled test_data, one real HG002 HiFi chunk) on the CPU: the oracle reproduces the committed
+expected outputs of tests/golden/testdata_chunk.npz (K5 haplotypes / phase sets on the real read x variant profile; one digest per noisy
+region for collect_noisy_reg_aln_strs) -- a regression pin of the oracle on real reads; the oracle itself stays "parity unpinned"."""
+import numpy as np
+
+import testdata_common as tc
+
+
+def test_fixture_shape():
+    ch = tc.Chunk()
+    assert ch.n_reads > 300 and len(ch.regions) >= 20
+    assert all(e > b for b, e in ch.regions)
+    for i in (0, ch.n_reads // 2, ch.n_reads - 1):   # digars tile the read: qi of the last op + its query length == qlen
+        d = ch.digars[i]
+        qlen = sum(int(l) for _, t, l, _ in d if t in (7, 8, 1, 4))
+        assert qlen == ch.qlen[i]
+
+
+def test_k5_on_real_profile(oracle):
+    from longcalld_amd import jobs
+    ch = tc.Chunk()
+    st = oracle.assign_hap_germline(ch.hap_problem(), jobs.GERMLINE_CLEAN)
+    assert (st["haps"] == ch.z["exp_haps"]).all() and (st["phase_sets"] == ch.z["exp_phase_sets"]).all()
+    for k in ("n_clean_agree_snps", "n_clean_conflict_snps", "var_phase_set", "hap_to_cons_alle"):
+        assert (st[k] == ch.z["exp_" + k]).all(), k
+    assert (st["haps"] > 0).mean() > 0.9     # a 30x HiFi chunk phases nearly every read
+
+
+def test_regions_on_real_reads(oracle):
+    ch = tc.Chunk()
+    haps, pss = ch.z["exp_haps"], ch.z["exp_phase_sets"]
+    n_two = 0
+    for k in range(len(ch.regions)):
+        reg = ch.region_dict(oracle, k, haps, pss)
+        res = oracle.collect_noisy_reg_aln_strs(reg)
+        assert res["n_cons"] == ch.z["exp_n_cons"][k]
+        assert tc.result_digest(res) == int(ch.z["exp_region_digest"][k]), k
+        n_two += res["n_cons"] == 2
+        pool = {bytes(x.tobytes()) for x in reg["seqs"]}
+        for c in range(res["n_cons"]):       # every full-cover cons<->read row de-gaps to one of the region's read slices
+            for j in range(res["clu_n_seqs"][c]):
+                s = res["aln_strs"][c][2 * j + 1]
+                if s is not None and s["query_beg"] == 0:
+                    q = s["query"][s["query"] != 5].tobytes()
+                    assert any(q == x or (len(q) < len(x) and q in x) for x in pool), (k, c, j)
+    assert n_two >= len(ch.regions) // 2
