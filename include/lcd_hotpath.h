@@ -37,6 +37,11 @@ typedef struct lcd_opt_t {
     int min_hap_full_reads, min_hap_reads;
     int collect_ref_read_aln_str; /* (refine_bam && out_aln_fp) || out_somatic, src/align.c:1785-1786 */
     int is_ont;
+    /* additive: 1 = also run make_vars_from_msa_cons_aln (src/collect_var.c:2279) on the device after the strings are
+     * built and return it through lcd_batch_region_vars; 2 = the same, and lcd_batch_download leaves the alignment strings in HBM
+     * (lcd_batch_region_result then fails): only variants and alleles cross PCIe */
+    int collect_noisy_vars;
+    int min_sv_len;               /* call_var_opt_t.min_sv_len (50), src/call_var_main.h:175 */
 } lcd_opt_t;
 
 /* == aln_str_t, src/collect_var.h:106-112 */
@@ -128,6 +133,7 @@ typedef struct lcd_batch_stats_t {
     double ms_poa_kernel;   /* HIP events tight around the POA chain kernel launch(es) only */
     int n_poa_launches;
     int poa_retries;
+    double ms_vars;         /* stage S6 (opt.collect_noisy_vars) */
 } lcd_batch_stats_t;
 
 lcd_batch_t *lcd_batch_create(const lcd_opt_t *opt);
@@ -151,6 +157,27 @@ int lcd_batch_run_many(lcd_batch_t **batches, int n);
 int lcd_batch_download(lcd_batch_t *b);/* HBM -> host */
 /* region results; clu_read_ids[c] and aln_strs[c][j].target_aln are malloc()'d (aln_strs[c] must hold 1+2*n_reads zeroed entries) */
 int lcd_batch_region_result(lcd_batch_t *b, int region, int *clu_n_seqs, int **clu_read_ids, lcd_aln_str_t **aln_strs);
+/* ---- candidate variants of a region + the read x variant allele profile (opt.collect_noisy_vars) ----
+ * == make_vars_from_msa_cons_aln (src/collect_var.c:2279-2347: make_cand_vars_from_msa :1855, update_cand_var_profile_from_cons_aln_str1/2
+ * :2164/:2206) computed on the device from the strings of lcd_batch_run.  What stays with the caller, as host code in the reference too:
+ * TSD / polyA / TE annotation of gaps >= min_sv_len (collect_te_info_from_cons, :1815/:1834) and merge_var_profile (:2712). */
+typedef struct lcd_noisy_var_t {   /* the cand_var_t fields make_cand_vars0 (src/collect_var.c:1746) and the profile update fill */
+    int64_t pos;
+    int var_type, ref_len, alt_len; /* BAM_CDIFF 8 / BAM_CINS 1 / BAM_CDEL 2 */
+    int cate;                       /* LONGCALLD_NOISY_CAND_HET_VAR 0x100 / LONGCALLD_NOISY_CAND_HOM_VAR 0x200 */
+    int from_cons;                  /* var_from_cons_idx: 1 | 2 | 3 (:2216-2226) */
+    int is_homopolymer_indel;       /* var_is_homopolymer_indel (:1720), from chunk_ref_seq; 0 for gaps >= min_sv_len */
+    int ref_base, alt_ref_base;
+    int total_cov, alle_covs[2];
+    uint8_t *alt_seq;               /* malloc()'d alt_len bytes, NULL for deletions */
+} lcd_noisy_var_t;
+/* returns n_vars (>= 0) or < 0.  Rows of the profile = the reads of cluster 0 then cluster 1 in clu_read_ids order (row_read_ids);
+ * prof_start/prof_end = read_var_profile_t.start_var_idx/end_var_idx (-1/-2: none); prof_alleles = n_rows x n_vars, -1 where unset.
+ * chunk_ref_seq[k] = base code at reference position chunk_ref_beg + k (chunk->ref_seq / ref_beg); may be NULL (flag stays 0).
+ * Every output array is malloc()'d (free vars[i].alt_seq, vars, row_read_ids, prof_*). */
+int lcd_batch_region_vars(lcd_batch_t *b, int region, int64_t noisy_reg_beg, const uint8_t *chunk_ref_seq, int64_t chunk_ref_beg,
+                          int64_t chunk_ref_len, lcd_noisy_var_t **vars, int *n_rows, int **row_read_ids, int **prof_start,
+                          int **prof_end, int **prof_alleles);
 int lcd_batch_region_sorted_ids(lcd_batch_t *b, int region, int *read_ids_out); /* the in-place permutation of noisy_reads */
 int lcd_batch_get_stats(lcd_batch_t *b, lcd_batch_stats_t *st);
 /* a 64-bit FNV-1a digest over every region's results (n_cons, clusters, all alignment rows) -- cheap whole-batch parity check */

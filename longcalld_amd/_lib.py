@@ -15,7 +15,7 @@ class LcdOpt(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("match", "mismatch", "gap_open1", "gap_ext1", "gap_open2", "gap_ext2", "gap_aln")] + [
         ("min_af", C.c_double), ("min_dp", C.c_int), ("partial_aln_ratio", C.c_double)] + [
         (n, C.c_int) for n in ("min_noisy_reg_size_to_sample_reads", "max_noisy_reg_len", "noisy_reg_flank_len",
-                               "min_hap_full_reads", "min_hap_reads", "collect_ref_read_aln_str", "is_ont")]
+                               "min_hap_full_reads", "min_hap_reads", "collect_ref_read_aln_str", "is_ont", "collect_noisy_vars", "min_sv_len")]
 
 
 class LcdAlnStr(C.Structure):
@@ -28,6 +28,13 @@ class LcdDigar1(C.Structure):
     _fields_ = [("pos", C.c_int64), ("type", C.c_int), ("len", C.c_int), ("qi", C.c_int)]
 
 
+class LcdNoisyVar(C.Structure):
+    """lcd_noisy_var_t (include/lcd_hotpath.h): the cand_var_t fields of a noisy-region variant"""
+    _fields_ = [("pos", C.c_int64)] + [(n, C.c_int) for n in ("var_type", "ref_len", "alt_len", "cate", "from_cons", "is_homopolymer_indel",
+                                                               "ref_base", "alt_ref_base", "total_cov")] + [("alle_covs", C.c_int * 2),
+                                                                                                              ("alt_seq", C.POINTER(C.c_uint8))]
+
+
 class LcdReadView(C.Structure):
     _fields_ = [("digars", C.POINTER(LcdDigar1)), ("n_digar", C.c_int), ("qlen", C.c_int), ("bseq", C.POINTER(C.c_uint8)),
                 ("qual", C.POINTER(C.c_uint8)), ("hap", C.c_int), ("phase_set", C.c_int64)]
@@ -37,7 +44,7 @@ class LcdBatchStats(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("n_regions", "n_regions_resolved", "n_chains", "n_anchor_jobs", "n_wfa_jobs", "n_edlib_jobs")] + [
         (n, C.c_uint64) for n in ("poa_aligned_bases", "poa_cells", "wfa_offsets", "edlib_blocks", "poa_alg_bytes")] + [
         (n, C.c_double) for n in ("ms_total", "ms_anchor", "ms_poa", "ms_wfa", "ms_strings", "ms_upload", "ms_download", "ms_host", "ms_poa_kernel")] + [
-        ("n_poa_launches", C.c_int), ("poa_retries", C.c_int)]
+        ("n_poa_launches", C.c_int), ("poa_retries", C.c_int), ("ms_vars", C.c_double)]
 
 
 class LcdHapProblem(C.Structure):
@@ -56,7 +63,7 @@ _lib = None
 EXPORTS = [
     "lcd_opt_default", "lcd_init", "lcd_last_error", "lcd_version", "lcd_wfa_end2end_aln", "lcd_edlib_end2end_aln",
     "lcd_edlib_xgaps", "lcd_edlib_edit_distance", "lcd_collect_noisy_reg_aln_strs", "lcd_batch_create", "lcd_batch_destroy",
-    "lcd_batch_clear", "lcd_batch_add_region", "lcd_batch_add_region_from_chunk", "lcd_batch_upload", "lcd_batch_run", "lcd_batch_run_many",
+    "lcd_batch_clear", "lcd_batch_region_vars", "lcd_batch_add_region", "lcd_batch_add_region_from_chunk", "lcd_batch_upload", "lcd_batch_run", "lcd_batch_run_many",
     "lcd_batch_download", "lcd_batch_region_result", "lcd_batch_region_sorted_ids", "lcd_batch_get_stats", "lcd_batch_digest",
     "lcd_edlib_batch", "lcd_wfa_batch", "lcd_poa_batch", "lcd_assign_hap_germline", "lcd_assign_hap_batch",
 ]
@@ -89,6 +96,8 @@ def load_library():
         getattr(lib, f).argtypes = [C.c_void_p]
     lib.lcd_batch_run_many.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     lib.lcd_batch_region_result.argtypes = [C.c_void_p, C.c_int, i32p, C.POINTER(i32p), C.POINTER(C.POINTER(LcdAlnStr))]
+    lib.lcd_batch_region_vars.argtypes = [C.c_void_p, C.c_int, C.c_int64, u8p, C.c_int64, C.c_int64, C.POINTER(C.POINTER(LcdNoisyVar)), i32p,
+                                          C.POINTER(i32p), C.POINTER(i32p), C.POINTER(i32p), C.POINTER(i32p)]
     lib.lcd_batch_region_sorted_ids.argtypes = [C.c_void_p, C.c_int, i32p]
     lib.lcd_batch_get_stats.argtypes = [C.c_void_p, C.POINTER(LcdBatchStats)]
     lib.lcd_batch_digest.argtypes = [C.c_void_p]

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import LcdAlnStr, LcdBatchStats, LcdDigar1, LcdOpt, LcdReadView, check, load_library
+from ._lib import LcdAlnStr, LcdBatchStats, LcdDigar1, LcdNoisyVar, LcdOpt, LcdReadView, check, load_library
 
 _libc = C.CDLL(None)
 _libc.free.argtypes = [C.c_void_p]
@@ -231,6 +231,31 @@ class RegionBatch:
         out = np.zeros(max(self.n_reads[region], 1), np.int32)
         n = self.lib.lcd_batch_region_sorted_ids(self.h, region, out.ctypes.data_as(i32p))
         return out[:n].copy()
+
+    def region_vars(self, region, noisy_reg_beg, chunk_ref, chunk_ref_beg):
+        """make_vars_from_msa_cons_aln (src/collect_var.c:2279) of one region, computed in stage S6 (opt.collect_noisy_vars):
+        -> dict(n_vars, per-variant arrays, alle_covs (n, 2), alt_seqs, row_read_ids, prof_start, prof_end, prof_alleles (rows x n))"""
+        cref = np.ascontiguousarray(chunk_ref, np.uint8)
+        vp = C.POINTER(LcdNoisyVar)(); nrows = C.c_int(0)
+        ids, ps, pe, pa = i32p(), i32p(), i32p(), i32p()
+        n = check(self.lib.lcd_batch_region_vars(self.h, region, int(noisy_reg_beg), _p8(cref), int(chunk_ref_beg), len(cref), C.byref(vp), C.byref(nrows),
+                                                 C.byref(ids), C.byref(ps), C.byref(pe), C.byref(pa)), self.lib)
+        rows = nrows.value
+        out = dict(n_vars=n, n_rows=rows)
+        for k in ("pos", "var_type", "ref_len", "alt_len", "cate", "from_cons", "is_homopolymer_indel", "ref_base", "alt_ref_base", "total_cov"):
+            out[k] = np.array([getattr(vp[i], k) for i in range(n)], np.int64)
+        out["alle_covs"] = np.array([[vp[i].alle_covs[0], vp[i].alle_covs[1]] for i in range(n)], np.int32).reshape(n, 2)
+        out["alt_seqs"] = [np.array([vp[i].alt_seq[k] for k in range(vp[i].alt_len)], np.uint8) for i in range(n)]
+        as_arr = lambda p, m: np.ctypeslib.as_array(p, shape=(max(m, 1),))[:m].copy() if p else np.zeros(0, np.int32)
+        out["row_read_ids"] = as_arr(ids, rows); out["prof_start"] = as_arr(ps, rows); out["prof_end"] = as_arr(pe, rows)
+        out["prof_alleles"] = as_arr(pa, rows * n).reshape(rows, n)
+        for i in range(n):
+            if vp[i].alt_seq:
+                _libc.free(C.cast(vp[i].alt_seq, C.c_void_p))
+        for p in (vp, ids, ps, pe, pa):
+            if p:
+                _libc.free(C.cast(p, C.c_void_p))
+        return out
 
     def result(self, region):
         """-> dict(n_cons, clu_n_seqs, clu_read_ids, aln_strs[c][j] = None | dict(target, query, beg/end...)), freeing the C buffers"""

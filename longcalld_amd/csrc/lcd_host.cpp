@@ -129,6 +129,7 @@ struct RegionRec {
     int n_cons = 0;
 };
 
+struct VarRegionRec { int region, n_cons, rows[2], cap, n_vars, alt_bytes; uint64_t rec_off, alt_off, prof_off, se_off; };
 struct OutStr { // one aln_str in the final output pool
     uint64_t off; int stride; int aln_len, tb, te, qb, qe, shift; bool present;
 };
@@ -151,7 +152,8 @@ struct lcd_batch_s {
     std::vector<WfaJob> wfa_jobs;
     // device
     DevBuf d_in, d_chains, d_preads, d_poa_arena, d_poa_out, d_poa_outs, d_ed_jobs, d_ed_arena, d_ed_outs, d_wfa_jobs, d_wfa_arena,
-        d_wfa_out, d_wfa_outs, d_str_jobs, d_str_outs, d_final, d_gate, d_cmp_jobs, d_cmp_outs, d_cmp_seg, d_cmp_segres, d_seg_out, d_rr;
+        d_wfa_out, d_wfa_outs, d_str_jobs, d_str_outs, d_final, d_gate, d_cmp_jobs, d_cmp_outs, d_cmp_seg, d_cmp_segres, d_seg_out, d_rr,
+        d_var_jobs, d_var_outs, d_var_work, d_vreg_jobs, d_vreg_outs, d_var_out;
     bool uploaded = false, ran = false, downloaded = false;
     // results (host)
     std::vector<PoaChainOut> couts;
@@ -163,6 +165,8 @@ struct lcd_batch_s {
     std::vector<uint8_t> h_final; std::vector<uint8_t> h_poa_out; std::vector<uint8_t> h_cig;
     // ref<->read strings (opt.collect_ref_read_aln_str): per string job, rows in d_rr at rr_off (target row, query row at +rr_stride)
     std::vector<uint64_t> rr_off; std::vector<int> rr_len, rr_stride; std::vector<uint8_t> h_rr; uint64_t rr_bytes = 0;
+    // candidate variants (opt.collect_noisy_vars): per resolved region, offsets into d_var_out / h_var
+    std::vector<VarRegionRec> vregs; std::vector<int> vreg_of; std::vector<uint8_t> h_var; uint64_t var_bytes = 0;
     std::vector<std::unique_ptr<DevBuf>> retry_out; // output blocks of chains re-run with a larger graph capacity (live until the next run)
     uint64_t final_bytes = 0;
     lcd_batch_stats_t st;
@@ -282,7 +286,7 @@ void lcd_opt_default(lcd_opt_t *o) {
     o->match = 2; o->mismatch = 6; o->gap_open1 = 6; o->gap_ext1 = 2; o->gap_open2 = 24; o->gap_ext2 = 1;
     o->gap_aln = 1; o->min_af = 0.20; o->min_dp = 5; o->partial_aln_ratio = 1.1;
     o->min_noisy_reg_size_to_sample_reads = 10000; o->max_noisy_reg_len = 50000; o->noisy_reg_flank_len = 10;
-    o->min_hap_full_reads = 1; o->min_hap_reads = 2; o->collect_ref_read_aln_str = 0; o->is_ont = 0;
+    o->min_hap_full_reads = 1; o->min_hap_reads = 2; o->collect_ref_read_aln_str = 0; o->is_ont = 0; o->collect_noisy_vars = 0; o->min_sv_len = 50;
 }
 int lcd_init(int device) {
     {
@@ -1002,6 +1006,92 @@ int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
         HIPCHK(hipStreamSynchronize(st));
         for (int k = 0; k < nb; ++k) for (size_t j = 0; j < bs[k]->str_jobs.size(); ++j) bs[k]->rr_len[j] = co[str_base[k] + j].aln_len;
     }
+    // ---------------- S6 (opt.collect_noisy_vars): strings -> candidate variants + read x variant profile, SURVEY 8(f) f1 ----------------
+    // make_vars_from_msa_cons_aln, src/collect_var.c:2279: the strings are still in HBM; only variants and alleles go back to the host
+    for (int k = 0; k < nb; ++k) { bs[k]->vregs.clear(); bs[k]->vreg_of.assign(bs[k]->regs.size(), -1); bs[k]->var_bytes = 0; }
+    float ms_vars = 0;
+    if (L->opt.collect_noisy_vars && !rc_all.empty()) {
+        HIPCHK(hipEventRecord(L->ev[6], st));
+        const size_t nj = rc_all.size();
+        std::vector<VarScanJob> vj(nj);
+        uint64_t work_tot = 0;
+        for (int k = 0; k < nb; ++k) for (size_t i = 0; i < bs[k]->rc_jobs.size(); ++i) {
+            const WfaJob &wj = bs[k]->rc_jobs[i]; VarScanJob &v = vj[rc_base[k] + i];
+            v.rc_t = wj.out_off; v.rc_q = wj.out_off + (uint64_t)(wj.plen + wj.tlen + 1); v.rc_len = bs[k]->rc_outs[i].aln_len;
+            v.row_cap = (int)lcd_align_up((uint64_t)v.rc_len + 16, 16); v.work_off = work_tot; work_tot += 2ull * v.row_cap; v.rec_off = 0; v.rec_cap = 0; v.pad = 0;
+        }
+        if (L->d_var_jobs.ensure(nj * sizeof(VarScanJob)) || L->d_var_outs.ensure(nj * sizeof(VarScanOut)) || L->d_var_work.ensure(work_tot + 64)) return -11;
+        for (auto &v : vj) v.work_off += L->d_var_work.addr();
+        std::vector<VarScanOut> vo(nj);
+        for (int pass = 0; pass < 2; ++pass) { // pass 0 counts the variants of every consensus, pass 1 writes the records into exactly sized lists
+            HIPCHK(hipMemcpyAsync(L->d_var_jobs.p, vj.data(), nj * sizeof(VarScanJob), hipMemcpyHostToDevice, st));
+            lcd_launch_vars_scan((const VarScanJob *)L->d_var_jobs.p, (VarScanOut *)L->d_var_outs.p, (int)nj, st);
+            HIPCHK(hipGetLastError());
+            if (pass == 1) break;
+            HIPCHK(hipMemcpyAsync(vo.data(), L->d_var_outs.p, nj * sizeof(VarScanOut), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            uint64_t rec_tot = 0;
+            for (size_t g = 0; g < nj; ++g) { vj[g].rec_cap = vo[g].n_vars; vj[g].rec_off = rec_tot; rec_tot += (uint64_t)vo[g].n_vars * sizeof(VarRec); }
+            // the per-consensus lists live behind the compacted rows in the leader's work buffer (transient: consumed by the profile kernel below;
+            // ensure() may move the buffer -- nothing in it is live yet, pass 1 rewrites the rows)
+            const uint64_t rec_base = lcd_align_up(work_tot + 64, 64);
+            if (L->d_var_work.ensure(rec_base + rec_tot + 64)) return -11;
+            uint64_t wo = 0;
+            for (size_t g = 0; g < nj; ++g) { vj[g].work_off = L->d_var_work.addr() + wo; wo += 2ull * vj[g].row_cap; vj[g].rec_off += L->d_var_work.addr() + rec_base; }
+        }
+        std::vector<VarRegJob> rj; std::vector<std::pair<int, int>> rj_owner;
+        for (int k = 0; k < nb; ++k) {
+            lcd_batch_t *b = bs[k];
+            std::map<std::pair<int, int>, size_t> rc_of, str_first; std::map<std::pair<int, int>, int> str_n;
+            for (size_t i = 0; i < b->rc_jobs.size(); ++i) rc_of[{b->rc_region[i], b->rc_clu[i]}] = i;
+            for (size_t j = 0; j < b->str_jobs.size(); ++j) {
+                const std::pair<int, int> key{b->str_region[j], b->str_clu[j]};
+                if (!str_n.count(key)) { str_first[key] = j; str_n[key] = 0; }
+                str_n[key]++;
+            }
+            uint64_t tot = 0;
+            for (size_t ri = 0; ri < b->regs.size(); ++ri) {
+                const RegionRec &R = b->regs[ri];
+                if (R.n_cons <= 0) continue;
+                VarRegJob J; memset(&J, 0, sizeof(J)); VarRegionRec V; memset(&V, 0, sizeof(V));
+                J.n_cons = R.n_cons; V.region = (int)ri; V.n_cons = R.n_cons;
+                int cap = 0, cols = 0, rows = 0;
+                for (int c = 0; c < R.n_cons; ++c) {
+                    const size_t r = rc_of.at({(int)ri, c}); const size_t g = rc_base[k] + r;
+                    J.rec[c] = vj[g].rec_off; J.cons[c] = vj[g].work_off + vj[g].row_cap; J.n_rec[c] = vo[g].n_vars;
+                    J.rc_t[c] = vj[g].rc_t; J.rc_q[c] = vj[g].rc_q; J.rc_len[c] = vj[g].rc_len;
+                    const std::pair<int, int> key{(int)ri, c};
+                    J.n_rows[c] = str_n.count(key) ? str_n[key] : 0; J.str_first[c] = (int)(str_base[k] + (str_n.count(key) ? str_first[key] : 0));
+                    V.rows[c] = J.n_rows[c]; cap += vo[g].n_vars; cols += vo[g].n_cols; rows += J.n_rows[c];
+                }
+                V.cap = cap;
+                V.rec_off = tot; tot += lcd_align_up((uint64_t)cap * sizeof(VarRec) + 16, 16);
+                V.alt_off = tot; tot += lcd_align_up((uint64_t)cols + 16, 16);
+                V.prof_off = tot; tot += lcd_align_up((uint64_t)rows * cap + 16, 16);
+                V.se_off = tot; tot += lcd_align_up((uint64_t)rows * 8 + 16, 16);
+                b->vreg_of[ri] = (int)b->vregs.size(); b->vregs.push_back(V);
+                rj.push_back(J); rj_owner.push_back({k, (int)b->vregs.size() - 1});
+            }
+            if (b->d_var_out.ensure(tot + 64)) return -11;
+            b->var_bytes = tot;
+        }
+        for (size_t q = 0; q < rj.size(); ++q) {
+            lcd_batch_t *b = bs[rj_owner[q].first]; const VarRegionRec &V = b->vregs[rj_owner[q].second]; const uint64_t base = b->d_var_out.addr();
+            rj[q].out_rec = base + V.rec_off; rj[q].out_alt = base + V.alt_off; rj[q].out_prof = base + V.prof_off; rj[q].out_se = base + V.se_off;
+        }
+        if (!rj.empty()) {
+            if (L->d_vreg_jobs.ensure(rj.size() * sizeof(VarRegJob)) || L->d_vreg_outs.ensure(rj.size() * sizeof(VarRegOut))) return -11;
+            HIPCHK(hipMemcpyAsync(L->d_vreg_jobs.p, rj.data(), rj.size() * sizeof(VarRegJob), hipMemcpyHostToDevice, st));
+            lcd_launch_vars_profile((const VarRegJob *)L->d_vreg_jobs.p, (VarRegOut *)L->d_vreg_outs.p, (const StrJob *)L->d_str_jobs.p, (const StrOut *)L->d_str_outs.p, (int)rj.size(), st);
+            HIPCHK(hipGetLastError());
+            std::vector<VarRegOut> ro(rj.size());
+            HIPCHK(hipMemcpyAsync(ro.data(), L->d_vreg_outs.p, rj.size() * sizeof(VarRegOut), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipEventRecord(L->ev[7], st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (size_t q = 0; q < rj.size(); ++q) { VarRegionRec &V = bs[rj_owner[q].first]->vregs[rj_owner[q].second]; V.n_vars = ro[q].n_vars; V.alt_bytes = ro[q].alt_bytes; }
+            hipEventElapsedTime(&ms_vars, L->ev[6], L->ev[7]);
+        }
+    }
     float ms_anchor = 0, ms_poa = 0, ms_wfa = 0, ms_str = 0, ms_tot = 0;
     hipEventElapsedTime(&ms_anchor, L->ev[0], L->ev[1]); hipEventElapsedTime(&ms_poa, L->ev[1], L->ev[2]);
     hipEventElapsedTime(&ms_wfa, L->ev[3], L->ev[4]); hipEventElapsedTime(&ms_str, L->ev[4], L->ev[5]); hipEventElapsedTime(&ms_tot, L->ev[0], L->ev[5]);
@@ -1010,7 +1100,7 @@ int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
         lcd_batch_t *b = bs[k]; lcd_batch_stats_t &S = b->st;
         b->str_outs.assign(str_outs.begin() + str_base[k], str_outs.begin() + str_base[k + 1]);
         // stage times are those of the joint run (the same for every batch of the call)
-        S.ms_anchor = ms_anchor; S.ms_poa = ms_poa; S.ms_wfa = ms_wfa; S.ms_strings = ms_str; S.ms_total = ms_tot; S.ms_host = host_ms;
+        S.ms_anchor = ms_anchor; S.ms_poa = ms_poa; S.ms_wfa = ms_wfa; S.ms_strings = ms_str; S.ms_total = ms_tot + ms_vars; S.ms_host = host_ms - ms_vars; S.ms_vars = ms_vars;
         for (const PoaChainOut &o : b->couts) {
             S.poa_aligned_bases += o.aligned_bases; S.poa_cells += o.cells;
             // B_poa = q + 5*N_sub + C + (q + N_sub) per aligned read; N_sub ~ final graph size (upper bound per read)
@@ -1060,14 +1150,18 @@ int lcd_batch_download(lcd_batch_t *b) {
     if (!b->ran) return set_err(-3, "lcd_batch_download before lcd_batch_run");
     const double t0 = now_ms();
     hipStream_t st = b->stream;
+    b->h_var.resize(b->var_bytes);
+    if (b->var_bytes) HIPCHK(hipMemcpyAsync(b->h_var.data(), b->d_var_out.p, b->var_bytes, hipMemcpyDeviceToHost, st));
+    const bool vars_only = b->opt.collect_noisy_vars == 2; // the alignment strings stay in HBM: only variants + alleles cross PCIe
+    if (vars_only) b->final_bytes = 0;
     b->h_final.resize(b->final_bytes);
     if (b->final_bytes) HIPCHK(hipMemcpyAsync(b->h_final.data(), b->d_final.p, b->final_bytes, hipMemcpyDeviceToHost, st));
     // ref<->cons rows: append after the strings
     uint64_t extra = 0;
     std::vector<uint64_t> rc_off(b->rc_jobs.size());
-    for (size_t i = 0; i < b->rc_jobs.size(); ++i) { rc_off[i] = b->final_bytes + extra; extra += lcd_align_up(2ull * (b->rc_jobs[i].plen + b->rc_jobs[i].tlen + 1), 16); }
+    for (size_t i = 0; i < b->rc_jobs.size(); ++i) { rc_off[i] = b->final_bytes + extra; if (!vars_only) extra += lcd_align_up(2ull * (b->rc_jobs[i].plen + b->rc_jobs[i].tlen + 1), 16); }
     b->h_final.resize(b->final_bytes + extra);
-    for (size_t i = 0; i < b->rc_jobs.size(); ++i)
+    for (size_t i = 0; i < b->rc_jobs.size() && !vars_only; ++i)
         HIPCHK(hipMemcpyAsync(b->h_final.data() + rc_off[i], (void *)(uintptr_t)b->rc_jobs[i].out_off, 2ull * (b->rc_jobs[i].plen + b->rc_jobs[i].tlen + 1), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     b->h_rr.resize(b->rr_bytes);
@@ -1111,6 +1205,7 @@ static const std::vector<int> *clu_list(lcd_batch_t *b, int ch, std::vector<int>
 
 int lcd_batch_region_result(lcd_batch_t *b, int region, int *clu_n_seqs, int **clu_read_ids, lcd_aln_str_t **aln_strs) {
     if (!b->downloaded) return set_err(-3, "lcd_batch_region_result before lcd_batch_download");
+    if (b->opt.collect_noisy_vars == 2) return set_err(-5, "lcd_batch_region_result: the strings were left in HBM (opt.collect_noisy_vars == 2)");
     if (region < 0 || region >= (int)b->regs.size()) return set_err(-4, "bad region index");
     const RegionRec &R = b->regs[region];
     if (R.branch == 0) return 0;
@@ -1176,6 +1271,64 @@ int lcd_batch_region_result(lcd_batch_t *b, int region, int *clu_n_seqs, int **c
         }
     }
     return R.n_cons;
+}
+
+// the outputs of make_vars_from_msa_cons_aln (src/collect_var.c:2279) for one region, from the S6 stage
+int lcd_batch_region_vars(lcd_batch_t *b, int region, int64_t noisy_reg_beg, const uint8_t *chunk_ref_seq, int64_t chunk_ref_beg,
+                          int64_t chunk_ref_len, lcd_noisy_var_t **vars, int *n_rows, int **row_read_ids, int **prof_start, int **prof_end,
+                          int **prof_alleles) {
+    *vars = nullptr; *n_rows = 0; *row_read_ids = *prof_start = *prof_end = *prof_alleles = nullptr;
+    if (!b->downloaded) return set_err(-3, "lcd_batch_region_vars before lcd_batch_download");
+    if (!b->opt.collect_noisy_vars) return set_err(-5, "lcd_batch_region_vars needs opt.collect_noisy_vars");
+    if (region < 0 || region >= (int)b->regs.size()) return set_err(-4, "bad region index");
+    const RegionRec &R = b->regs[region];
+    const int vi = b->vreg_of[region];
+    if (R.n_cons <= 0 || vi < 0) return 0;
+    const VarRegionRec &V = b->vregs[vi];
+    const int rows = V.rows[0] + (V.n_cons == 2 ? V.rows[1] : 0), n = V.n_vars;
+    { // rows = the reads of cluster 0, then of cluster 1, in clu_read_ids order (the same lists lcd_batch_region_result returns)
+        int *ids = (int *)malloc((rows > 0 ? rows : 1) * sizeof(int)); int w = 0; std::vector<int> tmp;
+        if (R.branch == 1) {
+            for (int c = 0; c < 2; ++c) { const ChainRec &C = b->chains[R.chain[c]]; for (size_t k = 0; k < C.members.size(); ++k) ids[w++] = R.reads[C.members[k]].id; }
+        } else {
+            const ChainRec &C = b->chains[R.chain[0]]; const PoaChainOut &co = b->couts[R.chain[0]];
+            if (co.n_cons == 2) {
+                const std::vector<int> *cl = clu_list(b, R.chain[0], tmp);
+                for (int c = 0; c < 2; ++c) for (int k = 0; k < co.clu_n[c]; ++k) ids[w++] = R.reads[C.members[(*cl)[(size_t)c * C.members.size() + k]]].id;
+            } else for (size_t k = 0; k < C.members.size(); ++k) ids[w++] = R.reads[C.members[k]].id;
+        }
+        if (w != rows) { free(ids); return set_err(-23, "candidate variants: cluster rows do not match the string jobs"); }
+        *row_read_ids = ids; *n_rows = rows;
+    }
+    int *ps = (int *)malloc((rows > 0 ? rows : 1) * sizeof(int)), *pe = (int *)malloc((rows > 0 ? rows : 1) * sizeof(int));
+    int *pa = (int *)malloc(((size_t)rows * n + 1) * sizeof(int));
+    const int *se = (const int *)(b->h_var.data() + V.se_off); const int8_t *prof = (const int8_t *)(b->h_var.data() + V.prof_off);
+    for (int r = 0; r < rows; ++r) { ps[r] = se[2 * r]; pe[r] = se[2 * r + 1]; }
+    for (size_t q = 0; q < (size_t)rows * n; ++q) pa[q] = prof[q] == -2 ? -1 : prof[q]; // init_read_var_profile: 0xFF fill (src/bam_utils.c:26)
+    *prof_start = ps; *prof_end = pe; *prof_alleles = pa;
+    lcd_noisy_var_t *out = (lcd_noisy_var_t *)calloc(n > 0 ? n : 1, sizeof(lcd_noisy_var_t));
+    const VarRec *rec = (const VarRec *)(b->h_var.data() + V.rec_off); const uint8_t *pool = b->h_var.data() + V.alt_off;
+    for (int i = 0; i < n; ++i) {
+        const VarRec &v = rec[i]; lcd_noisy_var_t &o = out[i];
+        o.pos = noisy_reg_beg + v.ref_off; o.var_type = v.type; o.ref_len = v.ref_len; o.alt_len = v.alt_len; o.cate = v.cate; o.from_cons = v.from_cons;
+        o.ref_base = v.ref_base; o.alt_ref_base = v.alt_ref_base; o.total_cov = v.total_cov; o.alle_covs[0] = v.alle_cov0; o.alle_covs[1] = v.alle_cov1;
+        if (v.alt_len > 0) { o.alt_seq = (uint8_t *)malloc(v.alt_len); memcpy(o.alt_seq, pool + v.alt_off, v.alt_len); }
+        // var_is_homopolymer_indel, src/collect_var.c:1720-1744 (reads chunk reference bases beyond the region: host side, 5 bytes per indel);
+        // gaps >= min_sv_len go to collect_te_info_from_cons instead (:1815, :1834 -- SURVEY a14, the caller's host code)
+        o.is_homopolymer_indel = 0;
+        const int gap = v.type == 1 ? v.alt_len : v.ref_len;
+        const int64_t off = o.pos - chunk_ref_beg;
+        if (v.type != 8 && gap < b->opt.min_sv_len && chunk_ref_seq && off >= 0 && off + 5 <= chunk_ref_len && (v.type == 1 || off + v.ref_len <= chunk_ref_len)) {
+            const uint8_t b0 = v.type == 1 ? o.alt_seq[0] : chunk_ref_seq[off];
+            int hp = 1;
+            if (v.type == 1) { for (int k = 1; k < v.alt_len; ++k) hp &= o.alt_seq[k] == b0; }
+            else { for (int k = 1; k < v.ref_len; ++k) hp &= chunk_ref_seq[off + k] == b0; }
+            for (int k = 0; k < 5; ++k) hp &= chunk_ref_seq[off + k] == b0;
+            o.is_homopolymer_indel = hp;
+        }
+    }
+    *vars = out;
+    return n;
 }
 
 int lcd_batch_region_sorted_ids(lcd_batch_t *b, int region, int *out) {

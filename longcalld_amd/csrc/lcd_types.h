@@ -178,6 +178,33 @@ struct CmpJob {
 struct CmpOut { int n_seg, aln_len; };
 struct CmpSeg { uint64_t rows_off; int aln_len, row_stride; }; // WFA rows of one segment: pattern row at rows_off, text row at + row_stride
 
+// ---------------- alignment strings -> candidate variants + read x variant profile (src/collect_var.c:1784-2347) ----------------
+struct VarRec {
+    int ref_off;                 // cand_var_t.pos - noisy_reg_beg
+    int col;                     // column of the variant in the compacted cons row (alt_seq = cons[col .. col+alt_len))
+    int type, ref_len, alt_len;  // BAM_CDIFF 8 / BAM_CINS 1 / BAM_CDEL 2
+    int ref_base, alt_ref_base;
+    int from_cons, cate, src;    // var_from_cons_idx (1 | 2 | 3), LONGCALLD_NOISY_CAND_HET/HOM_VAR, cluster whose cons row holds alt_seq
+    int total_cov, alle_cov0, alle_cov1;
+    int delta0, delta1;          // delta_ref_alt seen by the reads of cluster 0 / 1 when they reach this variant (:2180, :2194-2203)
+    int alt_off;                 // alt_seq in the region's alt pool
+};
+struct VarScanJob {
+    uint64_t rc_t, rc_q;         // ref row, cons row of the ref<->cons string
+    int rc_len, row_cap;
+    uint64_t work_off;           // compacted rows: ref at work_off, cons at work_off + row_cap
+    uint64_t rec_off; int rec_cap, pad;
+};
+struct VarScanOut { int n_vars, n_cols; };
+struct VarRegJob {
+    int n_cons, pad;
+    uint64_t rec[2], cons[2];    // per consensus: VarRec list, compacted cons row
+    int n_rec[2], n_rows[2], str_first[2]; // reads of each cluster = StrJob/StrOut [str_first, str_first + n_rows)
+    uint64_t rc_t[2], rc_q[2]; int rc_len[2];
+    uint64_t out_rec, out_alt, out_prof, out_se; // merged VarRec[], alt pool, int8 profile rows x n_vars (-2 = not covered), int2 (start, end) per row
+};
+struct VarRegOut { int n_vars, alt_bytes; };
+
 // ---------------- K5: haplotype assignment (src/assign_hap.c:473-547) ----------------
 // bam_chunk_t / cand_var_t / read_var_profile_t flattened; every pointer is an absolute device address.
 struct HapProb {

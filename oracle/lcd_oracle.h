@@ -165,6 +165,24 @@ typedef struct {
 void lcdo_read_region_slice(const lcdo_digar1_t *digars, int n_digar, int qlen, int64_t reg_beg, int64_t reg_end,
                             int noisy_reg_flank_len, int *reg_read_beg, int *reg_read_end, int *cover);
 
+/* ---------------- region alignment strings -> candidate variants + read x variant profile ---------------- */
+typedef struct {
+    int64_t pos;                 /* cand_var_t.pos (1-based reference position) */
+    int var_type, ref_len, alt_len; /* BAM_CDIFF 8 / BAM_CINS 1 / BAM_CDEL 2 */
+    int cate;                    /* LONGCALLD_NOISY_CAND_HET_VAR 0x100 / _HOM_VAR 0x200 */
+    int from_cons;               /* 1: consensus 1, 2: consensus 2, 3: both (var_from_cons_idx) */
+    int is_homopolymer_indel;
+    int ref_base, alt_ref_base;
+    int total_cov, alle_covs[2];
+    int alt_off;                 /* alt_seq = alt_pool + alt_off, alt_len bytes */
+} lcdo_noisy_var_t;
+/* make_vars_from_msa_cons_aln, src/collect_var.c:2279.  Profile rows: the reads of cluster 0, then those of cluster 1, in
+ * clu_read_ids order; prof_alleles is n_rows x n_vars (row-major), -1 where the read does not fully cover the variant. Returns n_vars;
+ * all outputs are malloc()'d (NULL when there is nothing). */
+int lcdo_make_vars_from_msa_cons_aln(int min_sv_len, const uint8_t *chunk_ref, int64_t chunk_ref_beg, int64_t chunk_ref_len,
+                                     int64_t noisy_reg_beg, int n_cons, const int *clu_n_seqs, lcdo_aln_str_t **aln_strs,
+                                     lcdo_noisy_var_t **vars, uint8_t **alt_pool, int **prof_start, int **prof_end, int **prof_alleles);
+
 /* ---------------- K5: hap assignment (src/assign_hap.c:473-547) ---------------- */
 /* bam_chunk_t / cand_var_t / read_var_profile_t flattened (src/collect_var.h:71-104, src/bam_utils.h:45-92).
  * Identical field list to lcd_hap_problem_t in include/lcd_hotpath.h (kept separate on purpose: the oracle never includes

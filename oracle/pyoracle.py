@@ -247,6 +247,59 @@ def collect_noisy_reg_aln_strs(reg, opt=None):
     return res
 
 
+class NoisyVar(C.Structure):
+    _fields_ = [("pos", C.c_int64)] + [(n, C.c_int) for n in ("var_type", "ref_len", "alt_len", "cate", "from_cons", "is_homopolymer_indel",
+                                                               "ref_base", "alt_ref_base", "total_cov")] + [("alle_covs", C.c_int * 2), ("alt_off", C.c_int)]
+
+
+VAR_KEYS = ("pos", "var_type", "ref_len", "alt_len", "cate", "from_cons", "is_homopolymer_indel", "ref_base", "alt_ref_base", "total_cov")
+
+
+def make_vars_from_msa_cons_aln(res, noisy_reg_beg, chunk_ref, chunk_ref_beg, min_sv_len=50):
+    """SURVEY 8(f) f1 oracle (oracle/cand_vars.c) on a region result dict (collect_noisy_reg_aln_strs above or RegionBatch.result):
+    -> dict(n_vars, <VAR_KEYS arrays>, alle_covs (n,2), alt_seqs [arrays], prof_start, prof_end, prof_alleles (rows x n_vars))"""
+    nc = res["n_cons"]
+    keep, arrs = [], []
+    for c in range(2):
+        m = len(res["aln_strs"][c])
+        a = (AlnStr * max(m, 1))()
+        for j, s in enumerate(res["aln_strs"][c] if c < nc else []):
+            if s is None:
+                continue
+            t = _c8(s["target"]); q = _c8(s["query"])
+            keep += [t, q]
+            a[j].target_aln, a[j].query_aln, a[j].aln_len = _p(t), _p(q), int(s["aln_len"])
+            a[j].target_beg, a[j].target_end, a[j].query_beg, a[j].query_end = (int(s[k]) for k in ("target_beg", "target_end", "query_beg", "query_end"))
+        arrs.append(a)
+    pa = (C.POINTER(AlnStr) * 2)(C.cast(arrs[0], C.POINTER(AlnStr)), C.cast(arrs[1], C.POINTER(AlnStr)))
+    clu_n = (C.c_int * 2)(*[int(x) for x in res["clu_n_seqs"]])
+    cref = _c8(chunk_ref)
+    vars_p, pool_p = C.POINTER(NoisyVar)(), u8p()
+    ps, pe, pal = i32p(), i32p(), i32p()
+    L = lib()
+    L.lcdo_make_vars_from_msa_cons_aln.argtypes = [C.c_int, u8p, C.c_int64, C.c_int64, C.c_int64, C.c_int, i32p, C.POINTER(C.POINTER(AlnStr)),
+                                                   C.POINTER(C.POINTER(NoisyVar)), C.POINTER(u8p), C.POINTER(i32p), C.POINTER(i32p), C.POINTER(i32p)]
+    n = L.lcdo_make_vars_from_msa_cons_aln(int(min_sv_len), _p(cref), int(chunk_ref_beg), len(cref), int(noisy_reg_beg), nc, clu_n, pa,
+                                           C.byref(vars_p), C.byref(pool_p), C.byref(ps), C.byref(pe), C.byref(pal))
+    rows = sum(int(res["clu_n_seqs"][c]) for c in range(nc))
+    out = dict(n_vars=n, n_rows=rows)
+    for k in VAR_KEYS:
+        out[k] = np.array([getattr(vars_p[i], k) for i in range(n)], np.int64)
+    out["alle_covs"] = np.array([[vars_p[i].alle_covs[0], vars_p[i].alle_covs[1]] for i in range(n)], np.int32).reshape(n, 2)
+    out["alt_seqs"] = [np.array([pool_p[vars_p[i].alt_off + k] for k in range(vars_p[i].alt_len)], np.uint8) for i in range(n)]
+    if n > 0 and rows > 0:
+        out["prof_start"] = np.ctypeslib.as_array(ps, shape=(rows,)).copy()
+        out["prof_end"] = np.ctypeslib.as_array(pe, shape=(rows,)).copy()
+        out["prof_alleles"] = np.ctypeslib.as_array(pal, shape=(rows * n,)).copy().reshape(rows, n)
+    else:
+        out["prof_start"] = np.full(rows, -1, np.int32); out["prof_end"] = np.full(rows, -2, np.int32)
+        out["prof_alleles"] = np.full((rows, n), -1, np.int32)
+    for p in (vars_p, pool_p, ps, pe, pal):
+        if p:
+            _libc.free(C.cast(p, C.c_void_p))
+    return out
+
+
 class Digar1(C.Structure):
     _fields_ = [("pos", C.c_int64), ("type", C.c_int), ("len", C.c_int), ("qi", C.c_int)]
 

@@ -252,12 +252,14 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import testdata_common as tc
     chunk = tc.Chunk(out)
-    digs, ncons, mlen = [], [], []
+    digs, ncons, mlen, nvar = [], [], [], 0
     for k in range(len(regs)):
         reg = chunk.region_dict(orc, k, haps, pss)
         res = orc.collect_noisy_reg_aln_strs(reg)
         digs.append(tc.result_digest(res)); ncons.append(res["n_cons"])
         mlen.append(res["aln_strs"][0][0]["aln_len"] if res["n_cons"] else 0)
+        nvar += orc.make_vars_from_msa_cons_aln(res, regs[k][0], out["ref"], int(out["ref_beg"]))["n_vars"]
+    out["exp_n_noisy_vars"] = np.int64(nvar)
     out["exp_region_digest"] = np.array(digs, np.uint64); out["exp_n_cons"] = np.array(ncons, np.int32); out["exp_ref_cons_len"] = np.array(mlen, np.int32)
     np.savez_compressed(OUT, **out)
     print("regions (len, reads, n_cons):", [(int(e - b + 1), len(x), n) for (b, e), x, n in zip(regs, reg_reads, ncons)])

@@ -44,3 +44,24 @@ def test_regions_on_real_reads(oracle):
                     q = s["query"][s["query"] != 5].tobytes()
                     assert any(q == x or (len(q) < len(x) and q in x) for x in pool), (k, c, j)
     assert n_two >= len(ch.regions) // 2
+
+
+def test_noisy_region_variants_on_real_reads(oracle):
+    """SURVEY 8(f) f1 oracle (oracle/cand_vars.c) on the real regions: variant count pinned; het variants split the reads by haplotype"""
+    ch = tc.Chunk()
+    haps, pss = ch.z["exp_haps"], ch.z["exp_phase_sets"]
+    o = int(ch.z["ref_beg"])
+    tot = split = het = 0
+    for k, (beg, end) in enumerate(ch.regions):
+        res = oracle.collect_noisy_reg_aln_strs(ch.region_dict(oracle, k, haps, pss))
+        v = oracle.make_vars_from_msa_cons_aln(res, beg, ch.z["ref"], o)
+        tot += v["n_vars"]
+        assert (v["pos"] >= beg).all() and (v["pos"] <= end + 1).all()
+        assert (v["total_cov"] >= v["alle_covs"].sum(1)).all()
+        for i in range(v["n_vars"]):
+            if v["cate"][i] == 0x100 and v["total_cov"][i] >= 10:
+                het += 1
+                split += min(v["alle_covs"][i]) >= 2
+            if v["var_type"][i] == 1:
+                assert len(v["alt_seqs"][i]) == v["alt_len"][i] > 0
+    assert tot == int(ch.z["exp_n_noisy_vars"]) and het > 20 and split > 0.8 * het
