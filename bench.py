@@ -51,6 +51,9 @@ def main():
                     help="concurrent submission lanes per GPU (host threads, one lcd_batch_t + HIP stream each) -- the reference's own "
                          "execution model: kt_for runs n_threads chunk workers concurrently (src/call_var_main.c:773); the K steps are "
                          "dealt round-robin to the lanes and ALL of them complete inside the timed region")
+    ap.add_argument("--vars", type=int, default=0, choices=[0, 1, 2],
+                    help="SURVEY 8(f) f1: also run the candidate-variant stage S6 inside the timed step (1), and leave the alignment strings "
+                         "in HBM at download (2); 0 = the headline path exactly as collect_noisy_reg_aln_strs defines it")
     ap.add_argument("--coalesce", type=int, default=16,
                     help="steps (batches) submitted together through lcd_batch_run_many: one set of launches per stage over the chains of "
                          "all of them, so that the GPU's workgroup dispatcher -- not HIP streams -- packs several chunks' chains onto the CUs")
@@ -76,6 +79,8 @@ def main():
     shape = jobs.HIFI if args.shape == "hifi" else jobs.ONT
     n_regions = jobs.regions_for_ref_mb(args.ref_mb)
     regs = jobs.make_regions(args.seed + 1000 * rank, n_regions, shape)   # weak scaling: same work per GPU, different seed
+    bench_opt = align.default_opt()
+    bench_opt.collect_noisy_vars = args.vars
     import threading
     # a step = one batch (the configs[1] workload).  `coalesce` steps are submitted together through lcd_batch_run_many (one set of
     # launches per stage over all their chains), `lanes` host threads keep that many such submissions in flight.
@@ -86,7 +91,7 @@ def main():
     for _ in range(n_lanes):
         grp = []
         for _ in range(n_co):
-            bt = align.RegionBatch()
+            bt = align.RegionBatch(bench_opt)
             for r in regs:
                 bt.add_region(r)
             t_up0 = time.perf_counter()
@@ -217,7 +222,8 @@ def main():
                        "lanes_per_gpu": n_lanes, "coalesced_steps_per_submission": n_co},
             "poa_aligned_bases_per_sec": round(tot_bases * args.steps / elapsed, 1),
             "regions_resolved": int(st["n_regions_resolved"]),
-            "stage_ms": {k: round(st[k], 3) for k in ("ms_anchor", "ms_poa", "ms_wfa", "ms_strings", "ms_total", "ms_host", "ms_poa_kernel")},
+            "stage_ms": {k: round(st[k], 3) for k in ("ms_anchor", "ms_poa", "ms_wfa", "ms_strings", "ms_vars", "ms_total", "ms_host", "ms_poa_kernel")},
+            "noisy_vars_stage": args.vars,
             "pcie_inclusive": {"upload_s": round(t_up, 4), "download_and_digest_s": round(t_dl, 4),
                                "regions_per_sec": round(tot_regions / max(world, 1) / (t_up + ms_step / 1e3 + t_dl), 2)},
             "digest": f"{digest:016x}",

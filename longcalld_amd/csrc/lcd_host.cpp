@@ -1042,11 +1042,12 @@ int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
         std::vector<VarRegJob> rj; std::vector<std::pair<int, int>> rj_owner;
         for (int k = 0; k < nb; ++k) {
             lcd_batch_t *b = bs[k];
-            std::map<std::pair<int, int>, size_t> rc_of, str_first; std::map<std::pair<int, int>, int> str_n;
-            for (size_t i = 0; i < b->rc_jobs.size(); ++i) rc_of[{b->rc_region[i], b->rc_clu[i]}] = i;
+            const size_t nk = b->regs.size() * 2; // (region, cluster) -> ref<->cons job, first string job, number of string jobs
+            std::vector<int> rc_of(nk, -1), str_first(nk, 0), str_n(nk, 0);
+            for (size_t i = 0; i < b->rc_jobs.size(); ++i) rc_of[(size_t)b->rc_region[i] * 2 + b->rc_clu[i]] = (int)i;
             for (size_t j = 0; j < b->str_jobs.size(); ++j) {
-                const std::pair<int, int> key{b->str_region[j], b->str_clu[j]};
-                if (!str_n.count(key)) { str_first[key] = j; str_n[key] = 0; }
+                const size_t key = (size_t)b->str_region[j] * 2 + b->str_clu[j];
+                if (!str_n[key]) str_first[key] = (int)j;
                 str_n[key]++;
             }
             uint64_t tot = 0;
@@ -1057,11 +1058,12 @@ int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
                 J.n_cons = R.n_cons; V.region = (int)ri; V.n_cons = R.n_cons;
                 int cap = 0, cols = 0, rows = 0;
                 for (int c = 0; c < R.n_cons; ++c) {
-                    const size_t r = rc_of.at({(int)ri, c}); const size_t g = rc_base[k] + r;
+                    const size_t key = ri * 2 + c;
+                    if (rc_of[key] < 0) return set_err(-23, "candidate variants: a resolved region has no ref<->cons string");
+                    const size_t g = rc_base[k] + rc_of[key];
                     J.rec[c] = vj[g].rec_off; J.cons[c] = vj[g].work_off + vj[g].row_cap; J.n_rec[c] = vo[g].n_vars;
                     J.rc_t[c] = vj[g].rc_t; J.rc_q[c] = vj[g].rc_q; J.rc_len[c] = vj[g].rc_len;
-                    const std::pair<int, int> key{(int)ri, c};
-                    J.n_rows[c] = str_n.count(key) ? str_n[key] : 0; J.str_first[c] = (int)(str_base[k] + (str_n.count(key) ? str_first[key] : 0));
+                    J.n_rows[c] = str_n[key]; J.str_first[c] = (int)(str_base[k] + str_first[key]);
                     V.rows[c] = J.n_rows[c]; cap += vo[g].n_vars; cols += vo[g].n_cols; rows += J.n_rows[c];
                 }
                 V.cap = cap;
@@ -1350,8 +1352,13 @@ uint64_t lcd_batch_digest(lcd_batch_t *b) {
         std::vector<lcd_aln_str_t> a0(1 + 2 * (size_t)std::max(R.n_reads, 0)), a1(a0.size());
         memset(a0.data(), 0, a0.size() * sizeof(lcd_aln_str_t)); memset(a1.data(), 0, a1.size() * sizeof(lcd_aln_str_t));
         lcd_aln_str_t *as[2] = {a0.data(), a1.data()};
-        int nc = lcd_batch_region_result(b, (int)ri, cn.data(), ids.data(), as);
+        int nc = b->opt.collect_noisy_vars == 2 ? R.n_cons : lcd_batch_region_result(b, (int)ri, cn.data(), ids.data(), as);
         mix(&nc, 4);
+        if (b->opt.collect_noisy_vars && b->vreg_of[ri] >= 0) { // stage S6 outputs: merged variants, alt pool, profile rows
+            const VarRegionRec &V = b->vregs[b->vreg_of[ri]]; const int rows = V.rows[0] + (V.n_cons == 2 ? V.rows[1] : 0);
+            mix(&V.n_vars, 4); mix(b->h_var.data() + V.rec_off, (size_t)V.n_vars * sizeof(VarRec)); mix(b->h_var.data() + V.alt_off, (size_t)V.alt_bytes);
+            mix(b->h_var.data() + V.prof_off, (size_t)rows * V.n_vars); mix(b->h_var.data() + V.se_off, (size_t)rows * 8);
+        }
         for (int c = 0; c < 2; ++c) {
             if (nc > 0 && c < nc) { mix(&cn[c], 4); mix(ids[c], (size_t)cn[c] * 4); }
             free(ids[c]);
