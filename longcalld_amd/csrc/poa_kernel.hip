@@ -1955,12 +1955,12 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
 __global__ void lcd_gate_kernel(int *ctr, int target0, int target1) {
     // bounded (about 2 s): the gate is a scheduling hint, never a correctness condition -- if the wide launches failed or are held
     // back by something else the narrow classes simply start
-    for (int spins = 0; spins < (1 << 21); ++spins) {
+    for (int spins = 0; spins < (1 << 18); ++spins) {
         // (read with a device-scope compare-and-swap that can never succeed: the counters are bumped from all 8 XCDs, whose L2s are not
         //  coherent with each other; a relaxed load -- and atomicAdd(p, 0), which the compiler folds into one -- is served from this XCD's L2
         //  and saw the counters ~100 ms late)
         if (atomicCAS(ctr, -1, -1) >= target0 && atomicCAS(ctr + 1, -1, -1) >= target1) { if (spins > ctr[4]) ctr[4] = spins; break; } // (ctr[4]: longest wait in polls, LCD_GATE_DEBUG)
-        __builtin_amdgcn_s_sleep(32);
+        __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); // ~7 us between polls: the counters move on a millisecond scale
     }
 }
 void lcd_launch_gate(int *ctr, int target0, int target1, hipStream_t stream) { hipLaunchKernelGGL(lcd_gate_kernel, dim3(1), dim3(1), 0, stream, ctr, target0, target1); }

@@ -12,3 +12,6 @@ rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch_$tag -o f -- $CMD1 > gpurun_o
 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write_$tag -o w -- $CMD1 > gpurun_out/pmc_write_$tag.log 2>&1
 grep -h '"metric"' gpurun_out/prof_$tag.log | tail -1 | cut -c1-200
 ls -R gpurun_out | grep -c results.db
+# LDS / issue counters of the same single step (SQ block, its own pass)
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES -d gpurun_out/pmc_sq_$tag -o s -- $CMD1 > gpurun_out/pmc_sq_$tag.log 2>&1
+ls gpurun_out/pmc_sq_$tag 2>/dev/null | head -3; tail -3 gpurun_out/pmc_sq_$tag.log

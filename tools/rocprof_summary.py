@@ -55,6 +55,26 @@ def main(tag, title):
                 poa += b
             o.write(f"{k[:30]:30s} {fk[0]:10d} {fk[1]:14.1f} {wk[1]:14.1f} {b:22.0f}\n")
         o.write(f"# lcd_poa_chain_kernel (all workgroup classes of one step): {poa:.0f} bytes\n")
+    try:   # SQ block pass (LDS / issue counters), summed per kernel over the dispatches of the same single step
+        cur = sqlite3.connect(f"gpurun_out/pmc_sq_{tag}/s_results.db").cursor()
+        acc = {}
+        for name, cn, val in cur.execute("select name, counter_name, counter_value from pmc_events"):
+            acc.setdefault(name.split("(")[0], {}).setdefault(cn, 0.0)
+            acc[name.split("(")[0]][cn] += val
+        with open(f"profiles/{tag}_pmc_sq_lds.txt", "w") as o:
+            o.write(f"# {title}\n# rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES\n")
+            o.write("# over ONE bench step (python bench.py --steps 1 --warmup 0 --lanes 1 --coalesce 1); sums over all dispatches of a kernel\n")
+            for k in sorted(acc):
+                c = acc[k]
+                o.write(k[:60] + "\n")
+                for cn in sorted(c):
+                    o.write(f"    {cn:24s} {c[cn]:18.0f}\n")
+                if c.get("SQ_LDS_IDX_ACTIVE"):
+                    o.write(f"    LDS bank-conflict cycles / LDS active cycles = {c.get('SQ_LDS_BANK_CONFLICT', 0) / c['SQ_LDS_IDX_ACTIVE']:.4f}\n")
+                if c.get("SQ_WAVES"):
+                    o.write(f"    VALU / SALU / LDS instructions per wavefront = {c.get('SQ_INSTS_VALU', 0) / c['SQ_WAVES']:.0f} / {c.get('SQ_INSTS_SALU', 0) / c['SQ_WAVES']:.0f} / {c.get('SQ_INSTS_LDS', 0) / c['SQ_WAVES']:.0f}\n")
+    except Exception as e:  # noqa
+        print("no SQ pass:", e)
     json.dump({"tag": tag, "kernel": "lcd_poa_chain_kernel", "hbm_bytes_per_step": poa,
                "source": f"profiles/{tag}_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)"},
               open(f"profiles/{tag}_traffic.json", "w"), indent=1)
