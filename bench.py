@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--vars", type=int, default=0, choices=[0, 1, 2],
                     help="SURVEY 8(f) f1: also run the candidate-variant stage S6 inside the timed step (1), and leave the alignment strings "
                          "in HBM at download (2); 0 = the headline path exactly as collect_noisy_reg_aln_strs defines it")
-    ap.add_argument("--coalesce", type=int, default=16,
+    ap.add_argument("--coalesce", type=int, default=0,
                     help="steps (batches) submitted together through lcd_batch_run_many: one set of launches per stage over the chains of "
                          "all of them, so that the GPU's workgroup dispatcher -- not HIP streams -- packs several chunks' chains onto the CUs")
     args = ap.parse_args()
@@ -81,9 +81,12 @@ def main():
     regs = jobs.make_regions(args.seed + 1000 * rank, n_regions, shape)   # weak scaling: same work per GPU, different seed
     bench_opt = align.default_opt()
     bench_opt.collect_noisy_vars = args.vars
+    bench_opt.is_ont = 1 if args.shape == "ont" else 0   # the reference's --ont / --hifi switch (src/call_var_main.h:128)
     import threading
     # a step = one batch (the configs[1] workload).  `coalesce` steps are submitted together through lcd_batch_run_many (one set of
     # launches per stage over all their chains), `lanes` host threads keep that many such submissions in flight.
+    if args.coalesce <= 0:   # default: 32 HiFi-shape batches per submission; the ONT shape's arenas (noisy reads: 4x graph / WFA estimates) allow 16
+        args.coalesce = 32 if args.shape == "hifi" else 16
     n_co = max(1, min(args.coalesce, args.steps))
     n_lanes = max(1, min(args.lanes, (args.steps + n_co - 1) // n_co))
     groups = []
@@ -174,7 +177,9 @@ def main():
         traffic, traffic_src = None, None
         if args.ref_mb == 10 and shape["name"] == "hifi" and world == 1:
             import glob
-            cand = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")))
+            import re
+            cand = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")),
+                          key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])   # r01_v9 < r01_v10
             if cand:
                 tj = json.load(open(cand[-1]))
                 traffic, traffic_src = float(tj["hbm_bytes_per_step"]) * n_co, tj["source"] + f" x {n_co} coalesced steps"

@@ -531,7 +531,7 @@ int lcd_batch_upload(lcd_batch_t *b) {
 
 static std::atomic<int> g_cell_hint[2] = {{0}, {0}}; // per mode (K1, K2): 0..2, see chain_caps
 static std::atomic<int> g_node_hint{0};                // 0..2: graph capacity estimate, see chain_caps
-static void chain_class(PoaChain &pc);
+static void chain_class(PoaChain &pc, bool noisy);
 static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vector<PoaRead> &preads, int scale, PoaChain &pc) {
     const int n = (int)C.members.size();
     long long sum = 0; int maxl = 0;
@@ -570,13 +570,13 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     for (int s = 1; s < scale && cells < worst; s *= 2) cells *= 8;
     cells = std::min(cells, worst);
     pc.cell_cap = (uint64_t)std::max<long long>(cells, maxl + 64);
-    chain_class(pc);
+    chain_class(pc, opt.is_ont != 0);
 }
 
 // Workgroup size class + LDS budget of a chain (poa_kernel.hip): threads follow the DP row width; the dynamic LDS pool holds
 // K ring slots of `wmax` columns + the query cache during the DP and the 16-bit graph copy of the re-sort (about 22 B per node)
 // afterwards.  Chains are launched in groups of equal (threads, LDS bucket) so that short chains do not pay a long chain's LDS.
-static void chain_class(PoaChain &pc) {
+static void chain_class(PoaChain &pc, bool noisy) {
     // DP row width: K2 rows span the whole read (+2 guard columns of the window); K1 rows are the adaptive band plus drift
     const long long width = pc.mode == 1 ? (long long)pc.max_len + 2 : 2ll * (10 + pc.max_len / 100) + 1 + 48;
     int threads, K, wmax; // wmax: window / ring-slot width in columns, a power of two <= 4 * threads (poa_kernel.hip align_windowed)
@@ -594,13 +594,15 @@ static void chain_class(PoaChain &pc) {
     else { threads = 1024; K = 2; wmax = 4096; } // wider rows take the generic (HBM) rows of the kernel
     const long long est_nodes = (long long)(pc.max_len * 1.15) + 64;
     const long long seq_bytes = lcd_align_up((long long)pc.max_len + 28, 16) + lcd_align_up(est_nodes + 16, 16); // query cache + first-predecessor distances
-    const long long dp_bytes = (long long)K * 3 * (4 * threads) * 4 + seq_bytes; // the ring is sized for the widest window of the class
+    const long long dp_bytes = (long long)K * 3 * wmax * 4 + seq_bytes; // the ring holds `wmax` columns per slot (4 * threads, or the narrower preferred window of a single-wavefront banded chain)
     // the re-sort's LDS copy of the graph: 8 B per node + 4 B per edge (topo_sort_block); edges ~ nodes + a few per bubble
     long long need = std::max(dp_bytes, est_nodes * 8 + (est_nodes + est_nodes / 8) * 4 + 64);
-    { // the single-wavefront class is kept to a small pool (LCD_LDS_CAP_KB, default 16): 9+ such chains per CU instead of 2-6 is worth
-      // more than a fast re-sort -- bigger graphs do their Kahn walk on the same packed words in HBM (measured +17 % regions/s; the
-      // re-sort's share of a chain goes from 15 % to 20 %)
-        static const int cap_kb = getenv("LCD_LDS_CAP_KB") ? atoi(getenv("LCD_LDS_CAP_KB")) : 16;
+    { // the single-wavefront class is kept to a small pool: 16 such chains per CU (8 KB each, the wavefront limit at 128 VGPRs) instead of 2-9
+      // is worth more than a fast re-sort -- bigger graphs do their Kahn walk on the same packed words in HBM (16 KB: +17 % regions/s over
+      // uncapped pools; 8 KB with the ring laid out for the preferred window: another +7 %).  Noisy reads (the learned hints say so) have
+      // graphs twice the size and re-sort after nearly every read: 16 KB there (8 KB costs them 11 %); noisy = opt.is_ont (the reference's --ont) or learned.  LCD_LDS_CAP_KB overrides.
+        static const int cap_env = getenv("LCD_LDS_CAP_KB") ? atoi(getenv("LCD_LDS_CAP_KB")) : -1;
+        const int cap_kb = cap_env >= 0 ? cap_env : ((noisy || g_node_hint.load() > 0 || g_cell_hint[0].load() > 0) ? 16 : 8);
         if (cap_kb > 0 && threads == 64) need = std::max(dp_bytes, std::min<long long>(need, (long long)cap_kb << 10));
     }
     // LDS per workgroup decides how many single-wavefront chains share a CU (160 KB, 16 wavefronts at 128 VGPRs), and those chains are

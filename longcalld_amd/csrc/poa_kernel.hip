@@ -790,13 +790,23 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
     Smem &sm = g_smem;
     Ctx g = *usgpr(gp_); // (by pointer: a by-value context is 440 B of outgoing-argument stack per call site and per lane)
     ctx_to_sgpr(g);
-    const unsigned ring = usgpr(ring_), sq1 = usgpr(sq1_), pd = usgpr(pd_);
+    const unsigned ring = usgpr(ring_); unsigned sq1 = usgpr(sq1_), pd = usgpr(pd_);
     const int w = usgpr(w_), bi = usgpr(bi_), ei = usgpr(ei_), rem_beg = usgpr(rem_beg_), qlen = usgpr(qlen_);
     const uint8_t *seq_hbm = usgpr(seq_hbm_); WinOut *wo = usgpr(wo_);
     LcdScoring sc; sc.match = usgpr(sc_.match); sc.mismatch = usgpr(sc_.mismatch); sc.o1 = usgpr(sc_.o1); sc.e1 = usgpr(sc_.e1); sc.o2 = usgpr(sc_.o2); sc.e2 = usgpr(sc_.e2); sc.dbg = usgpr(sc_.dbg);
     const int tid = threadIdx.x, lane = tid & 63, wave = usgpr(tid >> 6); // (wave in an SGPR: branches on it are scalar)
     const int o1 = sc.o1, e1 = sc.e1, o2 = sc.o2, e2 = sc.e2, oe1 = o1 + e1, oe2 = o2 + e2;
     const int QB = (qlen + 12 + 15) & ~15;
+    if constexpr (NT == 64 && BANDED) {
+        // the pool of a single-wavefront chain is laid out for the window the host expects (PoaChain.wmax columns per ring slot); a wider
+        // window moves the query cache up and gives up the first-predecessor distances -- or, if the pool is too small for that, leaves
+        // the read to the next wider window / the generic rows
+        const unsigned ring_bytes = (unsigned)(K * SLOTW * 4);
+        if (sq1 < ring + ring_bytes) {
+            if (ring_bytes + (unsigned)QB > (unsigned)g.pool_words * 4u) return -1;
+            sq1 = ring + ring_bytes; pd = 0xffffffffu;
+        }
+    }
     for (int j = tid; j < QB; j += NT) lds_st_u8(sq1 + j, (j >= 1 && j <= qlen) ? seq_hbm[j - 1] : 4); // shifted: sq1[j] = q[j-1]
     const int qclamp = QB - 4;
     const unsigned long long code_cap = g.cell_cap, ord_cap = g.cell_cap / 4; // bytes / ints (arena partition: see the kernel prologue)
@@ -1365,6 +1375,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         }
         __syncthreads();
     }
+    const bool ring_ok = g.wmax >= WMAX; // (single-wavefront chains laid out for a narrower ring: every row goes through HBM)
     for (int i = tid; i < qlen; i += NT) sseq[i] = seq_hbm[i];
     __syncthreads();
     unsigned long long used = 0;
@@ -1380,7 +1391,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         int r = g.remain[beg_node] - remain_end;
         int end = qlen - r; if (end < 0) end = 0; end += w; if (end > qlen) end = qlen;
         if ((unsigned long long)end + 1 > g.cell_cap / 3) { g.status = LCD_ERR_CELLS; return 0; }
-        const bool fits = end + 1 <= WMAX;
+        const bool fits = ring_ok && end + 1 <= WMAX;
         if (tid == 0) { g.rbeg[bi] = 0; g.rend[bi] = end; g.roff[bi] = 0; g.ml[bi] = 0; g.mr[bi] = 0; }
         for (int j = tid; j <= end; j += NT) {
             int f1 = j ? -(o1 + e1 * j) : LCD_NEG, f2 = j ? -(o2 + e2 * j) : LCD_NEG;
@@ -1491,7 +1502,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         if (used > g.cell_cap / 3) { g.status = LCD_ERR_CELLS; return 0; }
         if (tid == 0) { g.rbeg[idx] = beg; g.rend[idx] = end; g.roff[idx] = (uint32_t)off; }
         const int nchunks = (width + 63) >> 6;
-        const bool fits = width <= WMAX;
+        const bool fits = ring_ok && width <= WMAX;
         const int slot = fits ? next_slot : -1;
         int *rH = ring + (size_t)(slot < 0 ? 0 : slot) * 3 * WMAX, *rE1 = rH + WMAX, *rE2 = rH + 2 * WMAX;
         int carry1 = LCD_NEG * 2, carry2 = LCD_NEG * 2; // running max over the sweeps already done (rows wider than WMAX)
@@ -1702,7 +1713,10 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     int *ring = lds_pool;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const PoaChain ch = chains[cid];
-    uint8_t *sseq = (uint8_t *)(lds_pool + Cfg<NT>::K * 3 * (4 * NT)); // the ring is sized for the widest window of the class
+    // ring slots hold PoaChain.wmax columns: the class's widest window (4 * NT), or -- single-wavefront banded chains -- the narrower
+    // window the host expects the band to fit (64 / 128 columns: LDS per chain is what limits how many of them share a CU)
+    const int ring_cols = NT == 64 ? ch.wmax : 4 * NT;
+    uint8_t *sseq = (uint8_t *)(lds_pool + Cfg<NT>::K * 3 * ring_cols);
     const PoaLayout L = poa_layout(ch.node_cap, ch.edge_cap, ch.rid_words, ch.max_len, ch.cell_cap, ch.n_reads);
     uint8_t *ws = arena + ch.ws_off;
     Ctx g;
@@ -1729,7 +1743,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.pl_rem = (int *)(ws + L.pl_rem); g.pl_base = ws + L.pl_base;
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
-    g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - Cfg<NT>::K * 3 * (4 * NT)) * 4;
+    g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - Cfg<NT>::K * 3 * ring_cols) * 4;
     g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0;
     const long long t_begin = clock64();
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
