@@ -51,17 +51,34 @@ int ensure_init() {
     return 0;
 }
 
+// Device memory budget: the library keeps its grow-only buffers under ~85 % of the device (the HIP runtime allocates kernel scratch and
+// queue resources lazily at dispatch time -- with HBM full a launch aborts the queue with HSA_STATUS_ERROR_OUT_OF_RESOURCES instead of
+// returning an error).  A request over the budget fails like an out-of-memory hipMalloc (-11); lcd_batch_run_many then splits.
+std::atomic<long long> g_dev_bytes{0};
+long long g_dev_budget = -1;
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
     int ensure(size_t n) {
         if (n <= cap) return 0;
-        if (p) hipFree(p);
-        size_t want = n + n / 4 + 256;
-        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; cap = 0; return set_err(-11, "hipMalloc failed for " + std::to_string(want) + " bytes"); }
-        cap = want; return 0;
+        if (p) { hipFree(p); g_dev_bytes -= (long long)cap; p = nullptr; cap = 0; }
+        if (g_dev_budget < 0) {
+            size_t fr = 0, tot = 0;
+            g_dev_budget = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) ? (long long)((double)tot * (getenv("LCD_MEM_FRACTION") ? atof(getenv("LCD_MEM_FRACTION")) : 0.85)) : (1ll << 62);
+            (void)hipGetLastError();
+        }
+        size_t want = n + n / 4 + 256; // (headroom: the buffers only grow, a slightly larger next batch does not reallocate)
+        if (g_dev_bytes.load() + (long long)want > g_dev_budget) want = n + 256;
+        if (g_dev_bytes.load() + (long long)want > g_dev_budget)
+            return set_err(-11, "device memory budget: " + std::to_string(want) + " more bytes on top of " + std::to_string(g_dev_bytes.load()));
+        if (hipMalloc(&p, want) != hipSuccess) {
+            (void)hipGetLastError(); // out-of-memory is not sticky, but the "last error" slot is read after every launch
+            p = nullptr; cap = 0; return set_err(-11, "hipMalloc failed for " + std::to_string(want) + " bytes");
+        }
+        cap = want; g_dev_bytes += (long long)cap; return 0;
     }
+    void release() { if (p) { hipFree(p); g_dev_bytes -= (long long)cap; p = nullptr; cap = 0; } }
     uint64_t addr() const { return (uint64_t)(uintptr_t)p; }
-    ~DevBuf() { if (p) hipFree(p); }
+    ~DevBuf() { if (p) { hipFree(p); g_dev_bytes -= (long long)cap; } }
 };
 struct PinBuf {
     void *p = nullptr; size_t cap = 0;
@@ -691,7 +708,25 @@ static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, 
 // one CU; one batch of configs[1] size cannot fill 256 CUs, and separate streams per batch serialise on shared hardware queues).
 // The leader (batches[0]) lends its stream and its job / arena buffers; inputs, chain outputs and final strings stay per batch.
 // Results of batch k must be downloaded before the same leader runs again (the ref<->cons rows live in the leader's WFA buffer).
+static int run_many_once(lcd_batch_t **bs, int nb);
 int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
+    // a joint submission whose arenas do not fit the device (the estimates of noisy reads are 4x those of clean ones) is split in halves,
+    // each led by its own first batch; results are the same either way
+    const int rc = run_many_once(bs, nb);
+    if (rc != -11 || nb <= 1) return rc;
+    // the work arenas (DP cells, wavefronts, edlib columns) are transient: dropped around each half so that the halves do not add up;
+    // the outputs of a half stay in its leader's buffers until they are downloaded
+    auto drop = [](lcd_batch_t *b) { b->d_poa_arena.release(); b->d_wfa_arena.release(); b->d_ed_arena.release(); b->d_var_work.release(); };
+    const int h = nb / 2;
+    drop(bs[0]);
+    const int r1 = lcd_batch_run_many(bs, h);
+    drop(bs[0]);
+    if (r1) return r1;
+    const int r2 = lcd_batch_run_many(bs + h, nb - h);
+    drop(bs[h]);
+    return r2;
+}
+static int run_many_once(lcd_batch_t **bs, int nb) {
     if (nb <= 0) return 0;
     for (int k = 0; k < nb; ++k) {
         if (!bs[k]->uploaded) return set_err(-3, "lcd_batch_run before lcd_batch_upload");
