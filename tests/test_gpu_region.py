@@ -223,3 +223,104 @@ def test_per_call_mirror(lcd, oracle):
         s = (a0, a1)[c][0]
         t = np.ctypeslib.as_array(s.target_aln, shape=(s.aln_len,))
         assert (t == exp["aln_strs"][c][0]["target"]).all()
+
+
+def _check_invariants(reg, res):
+    """size-independent properties of a region result: clusters partition reads, every string de-gaps to its inputs"""
+    if res["n_cons"] == 0:
+        return 0
+    ids = list(reg["read_ids"])
+    seen = []
+    n_str = 0
+    for c in range(res["n_cons"]):
+        rc = res["aln_strs"][c][0]
+        assert rc is not None and len(rc["target"]) == rc["aln_len"] == len(rc["query"])
+        assert (rc["target"][rc["target"] != 5] == reg["ref"]).all()          # ref row of ref<->cons de-gaps to the reference slice
+        cons = rc["query"][rc["query"] != 5]
+        assert not ((rc["target"] == 5) & (rc["query"] == 5)).any()
+        members = res["clu_read_ids"][c]
+        assert len(members) == res["clu_n_seqs"][c]
+        seen += list(members)
+        for j, rid in enumerate(members):
+            s = res["aln_strs"][c][2 * j + 1]
+            if s is None:
+                continue
+            n_str += 1
+            read = reg["seqs"][ids.index(rid)]
+            q = s["query"][s["query"] != 5]
+            t = s["target"][s["target"] != 5]
+            assert len(s["target"]) == s["aln_len"]
+            if reg["covers"][ids.index(rid)] == 12:                            # full cover: the rows are the whole consensus and the whole read
+                assert q.tobytes() == read.tobytes() and t.tobytes() == cons.tobytes()
+            else:   # partial cover: the row may carry the anchor node's base at either end (the sub-graph alignment labels the edge out of
+                    # the anchor node with the read, src/align.c:797-803), everything between is the read
+                assert q[1:-1].tobytes() in read.tobytes() and t.tobytes() in cons.tobytes()
+    assert len(seen) == len(set(seen)) and set(seen) <= set(ids)
+    return n_str
+
+
+def test_full_size_batch_properties(lcd):
+    """BASELINE configs[1] at full size (1 250 regions, ~37 000 strings): invariants on every region, and the digest does not depend on
+    how the batch is submitted (alone / jointly with a copy of itself)"""
+    from longcalld_amd import jobs
+    regs = jobs.make_regions(1000, jobs.regions_for_ref_mb(10), jobs.HIFI)
+    bs = []
+    for _ in range(2):
+        b = lcd.RegionBatch()
+        for r in regs:
+            b.add_region(r)
+        b.upload(); bs.append(b)
+    bs[0].run(); bs[0].download()
+    d0 = bs[0].digest()
+    n_str = sum(_check_invariants(r, bs[0].result(k)) for k, r in enumerate(regs))
+    assert n_str > 30000 and bs[0].stats()["n_regions_resolved"] > 1200
+    lcd.RegionBatch.run_many(bs)
+    for b in bs:
+        b.download()
+    assert bs[0].digest() == d0 and bs[1].digest() == d0
+    for b in reversed(bs):
+        b.close()
+
+
+def test_sv_region_ont_60x(lcd, oracle):
+    """SURVEY 8d config 5 shape: one 4 kb region, 60 noisy reads, a 1.2 kb insertion on one haplotype and a 700 bp deletion on the other:
+    long ref<->cons gaps (K3 scores in the thousands), wide POA bands -- == oracle"""
+    from longcalld_amd import jobs
+    from conftest import mutate
+    rng = np.random.default_rng(505)
+    ref = rng.integers(0, 4, 4000).astype(np.uint8)
+    ins = rng.integers(0, 4, 1200).astype(np.uint8)
+    hap = [np.concatenate([ref[:1500], ins, ref[1500:]]), np.concatenate([ref[:2200], ref[2900:]])]
+    seqs, haps, covers = [], [], []
+    for i in range(60):
+        h = i % 2
+        s = mutate(rng, hap[h], 0.05)
+        cv = 12
+        if i % 11 == 5:
+            s, cv = s[: len(s) * 3 // 5], 8
+        elif i % 13 == 7:
+            s, cv = s[len(s) // 2:], 4
+        seqs.append(s); haps.append(h + 1); covers.append(cv)
+    n = len(seqs)
+    reg = dict(reg_len=len(ref), read_ids=np.arange(n, dtype=np.int32), seqs=seqs, quals=[np.full(len(s), 20, np.uint8) for s in seqs],
+               covers=np.array(covers, np.int32), haps=np.array(haps, np.int32), phase_sets=np.full(n, 777, np.int64), ref=ref)
+    o = lcd.default_opt(); o.is_ont = 1; o.collect_noisy_vars = 1
+    got, ids, _, _ = _run_batch(lcd, [reg], o)
+    exp = oracle.collect_noisy_reg_aln_strs(reg)
+    assert (ids[0] == exp["sorted_ids"]).all()
+    same_result(exp, got[0])
+    assert got[0]["n_cons"] == 2
+    lens = sorted(len(got[0]["aln_strs"][c][0]["query"][got[0]["aln_strs"][c][0]["query"] != 5]) for c in range(2))
+    assert abs(lens[0] - 3300) < 60 and abs(lens[1] - 5200) < 80      # the two consensus sequences carry the deletion / the insertion
+
+
+def test_full_size_batch_equals_oracle(lcd, oracle):
+    """BASELINE configs[1] at full size against the oracle itself, region by region (the scalar oracle needs ~35 s for the 1 250 regions)"""
+    from longcalld_amd import jobs
+    regs = jobs.make_regions(2000, jobs.regions_for_ref_mb(10), jobs.HIFI)
+    got, ids, st, _ = _run_batch(lcd, regs)
+    for r, g, sid in zip(regs, got, ids):
+        exp = oracle.collect_noisy_reg_aln_strs(r)
+        assert (sid == exp["sorted_ids"]).all()
+        same_result(exp, g)
+    assert st["n_regions"] == len(regs)
