@@ -369,9 +369,30 @@ __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned shor
     const int n = g.n_node, E = g.n_edge;
     for (int i = tid; i < n; i += NT) { deg[i] = (unsigned short)g.nin[i]; nw[i] = (unsigned)(g.out_head[i] + 1) | ((unsigned)g.aligned[i] << 16); }
     for (int e = tid; e < E; e += NT) ew[e] = (unsigned)g.e_to[e] | ((unsigned)(g.e_next_out[e] + 1) << 16);
+    // Chain links for the walk below: link(v) = w when v's only out-edge goes to w, w has no other in-edge and no aligned ring -- when v is
+    // popped with nothing else queued, w is the next node whatever else happens.  POA graphs are mostly such chains (the backbone between
+    // bubbles), so the walk takes them 64 nodes at a time: jump tables J1 = link, J4 = link^4, J16 = link^16 (self-loops at chain ends) let
+    // lane t of wavefront 0 reach link^t(v) in <= 9 loads.  The tables live in the row-plan arrays (HBM, free between two reads).
+    unsigned short *J1 = (unsigned short *)g.pl_start, *J4 = J1 + n, *J16 = (unsigned short *)g.pl_rem;
+    __syncthreads();
+    for (int v = tid; v < n; v += NT) {
+        const unsigned e = nw[v] & 0xffffu;
+        int l = v;
+        if (e != 0) {
+            const unsigned w = ew[e - 1];
+            const int to = (int)(w & 0xffffu);
+            if ((w >> 16) == 0 && deg[to] == 1 && (int)(nw[to] >> 16) == to) l = to;
+        }
+        J1[v] = (unsigned short)l;
+    }
+    __syncthreads();
+    for (int v = tid; v < n; v += NT) { int x = J1[v]; x = J1[x]; x = J1[x]; x = J1[x]; J4[v] = (unsigned short)x; }
+    __syncthreads();
+    for (int v = tid; v < n; v += NT) { int x = J4[v]; x = J4[x]; x = J4[x]; x = J4[x]; J16[v] = (unsigned short)x; }
     __syncthreads();
     const long long tk0 = clock64();
-    if (tid == 0) {
+    if (tid < 64) { // wavefront 0, every lane with the same scalars (loads broadcast, identical stores coincide); lanes differ only in the chain step
+        const int lane = tid;
         int qh = 0, qt = 0, index = 0;
         queue[qt++] = 0;
         int cur = 0; // (the node at queue[qh] is kept in a register whenever it is the one just pushed: linear stretches never re-read the queue)
@@ -379,6 +400,23 @@ __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned shor
         while (qh < qt) {
             if (!have) cur = queue[qh];
             ++qh; have = false;
+            while (qh == qt) { // nothing else queued: follow the chain that starts at cur, 64 nodes per step
+                int x = cur;
+                const int c16 = lane >> 4, c4 = (lane >> 2) & 3, c1 = lane & 3;
+                for (int i = 0; i < 3; ++i) if (i < c16) x = J16[x];
+                for (int i = 0; i < 3; ++i) if (i < c4) x = J4[x];
+                for (int i = 0; i < 3; ++i) if (i < c1) x = J1[x];
+                const int prev = __shfl_up(x, 1);
+                const unsigned long long adv = __ballot(lane == 0 || x != prev); // lanes still advancing: a prefix (a chain end is a self-loop)
+                const int L = __popcll(adv);
+                if (L <= 1) break;
+                // x_0 .. x_{L-2} are complete (their one out-edge leads to the next node, which nothing else waits for); x_{L-1} goes on
+                if (lane < L - 1) g.node2idx[x] = index + lane;
+                if (lane >= 1 && lane < L) queue[qh - 1 + lane] = (unsigned short)x;
+                index += L - 1; qh += L - 1; qt = qh;
+                cur = __shfl(x, L - 1);
+                if (L < 64) break;
+            }
             g.node2idx[cur] = index; ++index; // (idx2node is the queue itself, copied out below)
             if (cur == 1) break;
             for (unsigned e = nw[cur] & 0xffffu; e != 0;) {
@@ -398,7 +436,7 @@ __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned shor
             }
         }
         if (index != n) g.status = LCD_ERR_TOPO;
-        sm.bc[6] = g.status;
+        if (lane == 0) sm.bc[6] = g.status;
     }
     __syncthreads();
     g.t_kahn += (unsigned long long)(clock64() - tk0);
