@@ -363,6 +363,27 @@ __device__ int add_alignment_block(Ctx &g, Smem &sm, int beg_node, int end_node,
 // The walk on 16-bit packed words: `deg`, `queue` (n halfwords each), node words `nw` (n), edge words `ew` (E) live in LDS when the
 // graph fits the workgroup's pool, in HBM scratch (the row-plan arrays, free between two reads) when it does not -- the single-wavefront
 // chains are kept to a small LDS pool on purpose (more of them per CU is worth more than a fast re-sort, DESIGN "Submission").
+// remain[v] = number of nodes on the heaviest path from v to the sink = depth of v in the tree "v -> heaviest successor" (root: the sink).
+// Serial in topological order it is one dependent load chain of length n; by pointer jumping it is ceil(log2 n) rounds over all nodes:
+// (P, D) <- (P[P], D + D[P]).  Two (P, D) buffers of 16-bit entries in the row-plan arrays (HBM, free between two reads); the caller has
+// filled buffer 0: P = heaviest successor (the sink points to itself), D = 1 (sink: 0).
+template <int NT>
+__device__ __forceinline__ void remain_by_jumping(Ctx &g, const int n) {
+    const int tid = threadIdx.x;
+    unsigned short *buf[2] = {(unsigned short *)g.pl_start, (unsigned short *)g.pl_rem}; // each: P[n] | D[n]
+    const int rounds = n > 2 ? 32 - __clz(n - 1) : 1;
+    int src = 0;
+    for (int r = 0; r < rounds; ++r) {
+        const unsigned short *Ps = buf[src], *Ds = Ps + n;
+        unsigned short *Pd = buf[src ^ 1], *Dd = Pd + n;
+        for (int v = tid; v < n; v += NT) { const int p = Ps[v]; Pd[v] = Ps[p]; Dd[v] = (unsigned short)(Ds[v] + Ds[p]); }
+        __syncthreads();
+        src ^= 1;
+    }
+    const unsigned short *D = buf[src] + n;
+    for (int v = tid; v < n; v += NT) g.remain[v] = (int)D[v] - 1;
+}
+
 template <int NT>
 __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned short *deg, unsigned short *queue, unsigned *nw, unsigned *ew) {
     const int tid = threadIdx.x;
@@ -444,19 +465,15 @@ __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned shor
     if (g.status == LCD_OK) {
         // heaviest successor of every node (first maximum in out-edge order; 1 = the sink when there is no out-edge), in parallel; it
         // replaces the ring pointer in the high half of the node's own word (nobody else reads that word in this loop)
-        unsigned short *rem = deg;
+        unsigned short *P0 = (unsigned short *)g.pl_start, *D0 = P0 + n; // (the jump tables of the walk are dead now)
         for (int v = tid; v < n; v += NT) {
             int mw = -1, mid = 1;
             for (unsigned e = nw[v] & 0xffffu; e != 0;) { const unsigned w = ew[e - 1]; const int wt = g.e_w[e - 1]; if (wt > mw) { mw = wt; mid = (int)(w & 0xffffu); } e = w >> 16; }
-            nw[v] = (nw[v] & 0xffffu) | ((unsigned)mid << 16);
+            P0[v] = (unsigned short)mid; D0[v] = (unsigned short)(v == 1 ? 0 : 1);
+            g.idx2node[v] = queue[v];
         }
         __syncthreads();
-        if (tid == 0) {
-            rem[1] = 0; // remain + 1
-            for (int i = n - 2; i >= 0; --i) { const int v = queue[i]; rem[v] = (unsigned short)(rem[nw[v] >> 16] + 1); }
-        }
-        __syncthreads();
-        for (int i = tid; i < n; i += NT) { g.idx2node[i] = queue[i]; g.remain[i] = (int)rem[i] - 1; }
+        remain_by_jumping<NT>(g, n);
     }
     __syncthreads();
 }
@@ -488,7 +505,7 @@ template <int NT>
 __device__ void topo_remain_block(Ctx &g, Smem &sm, int *lds_pool) {
     const int tid = threadIdx.x;
     const int n = g.n_node;
-    if (n >= 65535 || (size_t)6 * n + 64 > (size_t)g.pool_words * 4) { // does not fit: serial on HBM (same arithmetic)
+    if (n >= 65535) { // ids do not fit 16 bits: serial (same arithmetic)
         if (tid == 0) {
             g.remain[1] = -1;
             for (int i = n - 2; i >= 0; --i) {
@@ -500,19 +517,14 @@ __device__ void topo_remain_block(Ctx &g, Smem &sm, int *lds_pool) {
         __syncthreads();
         return;
     }
-    unsigned short *rem = (unsigned short *)lds_pool, *ord = rem + n, *hs = ord + n;
+    unsigned short *P0 = (unsigned short *)g.pl_start, *D0 = P0 + n;
     for (int v = tid; v < n; v += NT) {
         int mw = -1, mid = 1;
         for (int e = g.out_head[v]; e >= 0; e = g.e_next_out[e]) { const int wt = g.e_w[e]; if (wt > mw) { mw = wt; mid = g.e_to[e]; } }
-        hs[v] = (unsigned short)mid; ord[v] = (unsigned short)g.idx2node[v];
+        P0[v] = (unsigned short)mid; D0[v] = (unsigned short)(v == 1 ? 0 : 1);
     }
     __syncthreads();
-    if (tid == 0) {
-        rem[1] = 0;
-        for (int i = n - 2; i >= 0; --i) { const int v = ord[i]; rem[v] = (unsigned short)(rem[hs[v]] + 1); }
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += NT) g.remain[i] = (int)rem[i] - 1;
+    remain_by_jumping<NT>(g, n);
     __syncthreads();
 }
 
