@@ -86,7 +86,7 @@ def main():
     # a step = one batch (the configs[1] workload).  `coalesce` steps are submitted together through lcd_batch_run_many (one set of
     # launches per stage over all their chains), `lanes` host threads keep that many such submissions in flight.
     if args.coalesce <= 0:   # default: 32 HiFi-shape batches per submission; the ONT shape's arenas (noisy reads: 4x graph / WFA estimates) allow 16
-        args.coalesce = 32 if args.shape == "hifi" else 16
+        args.coalesce = 32 if args.shape == "hifi" else 16   # (16 ONT-shape batches: ~250 GB of arenas with the retry round)
     n_co = max(1, min(args.coalesce, args.steps))
     n_lanes = max(1, min(args.lanes, (args.steps + n_co - 1) // n_co))
     groups = []
