@@ -183,10 +183,22 @@ def main():
             if cand:
                 tj = json.load(open(cand[-1]))
                 traffic, traffic_src = float(tj["hbm_bytes_per_step"]) * n_co, tj["source"] + f" x {n_co} coalesced steps"
+        # secondary roofline: integer VALU issue.  Wavefront instructions of the POA kernels per step from the committed SQ counter
+        # pass (same rule as `traffic`), x 64 lanes, over the live launch time; peak = 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 Tops/s
+        valu = None
+        if traffic is not None:
+            cand2 = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_sq.json")),
+                           key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+            if cand2 and mean_launch_s > 0:
+                sj = json.load(open(cand2[-1]))
+                ops = float(sj["valu_wave_insts_per_step"]) * 64 * n_co
+                valu = {"achieved": round(ops / mean_launch_s / 1e12, 3), "peak": 78.6, "unit": "Tops/s (int32 lane-ops)", "frac": round(ops / mean_launch_s / 78.6e12, 4),
+                        "source": sj["source"]}
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                     "traffic": traffic, "traffic_source": traffic_src, "kernel": "lcd_poa_chain_kernel", "ms_per_launch": round(mean_launch_s * 1e3, 4),
                     "alg_bytes_per_launch": alg_bytes, "cells_per_launch": int(acc["cells"] / max(poa_launches, 1)),
-                    "gcups": round(acc["cells"] / max(poa_launches, 1) / mean_launch_s / 1e9, 3) if mean_launch_s > 0 else 0.0}
+                    "gcups": round(acc["cells"] / max(poa_launches, 1) / mean_launch_s / 1e9, 3) if mean_launch_s > 0 else 0.0,
+                    "valu": valu}
         cpu = None
         if world == 1 and args.cpu_sample > 0:
             # the reference runs this path on kt_for worker threads (src/call_var_main.c:773): time the CPU port the same way, one
@@ -227,6 +239,8 @@ def main():
                        "lanes_per_gpu": n_lanes, "coalesced_steps_per_submission": n_co},
             "poa_aligned_bases_per_sec": round(tot_bases * args.steps / elapsed, 1),
             "regions_resolved": int(st["n_regions_resolved"]),
+            "wfa_offsets_per_sec": round(float(st["wfa_offsets"]) * n_co / max((st["ms_wfa"] + st["ms_anchor"]) * 1e-3, 1e-9), 1),
+            "edlib_blocks_per_sec": round(float(st["edlib_blocks"]) * n_co / max(st["ms_anchor"] * 1e-3, 1e-9), 1),
             "stage_ms": {k: round(st[k], 3) for k in ("ms_anchor", "ms_poa", "ms_wfa", "ms_strings", "ms_vars", "ms_total", "ms_host", "ms_poa_kernel")},
             "noisy_vars_stage": args.vars,
             "pcie_inclusive": {"upload_s": round(t_up, 4), "download_and_digest_s": round(t_dl, 4),

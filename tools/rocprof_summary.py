@@ -73,6 +73,12 @@ def main(tag, title):
                     o.write(f"    LDS bank-conflict cycles / LDS active cycles = {c.get('SQ_LDS_BANK_CONFLICT', 0) / c['SQ_LDS_IDX_ACTIVE']:.4f}\n")
                 if c.get("SQ_WAVES"):
                     o.write(f"    VALU / SALU / LDS instructions per wavefront = {c.get('SQ_INSTS_VALU', 0) / c['SQ_WAVES']:.0f} / {c.get('SQ_INSTS_SALU', 0) / c['SQ_WAVES']:.0f} / {c.get('SQ_INSTS_LDS', 0) / c['SQ_WAVES']:.0f}\n")
+        poa_valu = sum(c.get("SQ_INSTS_VALU", 0) for k, c in acc.items() if "lcd_poa_chain_kernel" in k)
+        poa_salu = sum(c.get("SQ_INSTS_SALU", 0) for k, c in acc.items() if "lcd_poa_chain_kernel" in k)
+        poa_lds = sum(c.get("SQ_INSTS_LDS", 0) for k, c in acc.items() if "lcd_poa_chain_kernel" in k)
+        json.dump({"tag": tag, "kernel": "lcd_poa_chain_kernel", "valu_wave_insts_per_step": poa_valu, "salu_wave_insts_per_step": poa_salu,
+                   "lds_wave_insts_per_step": poa_lds, "source": f"profiles/{tag}_pmc_sq_lds.txt (rocprofv3 --pmc SQ_INSTS_VALU ...)"},
+                  open(f"profiles/{tag}_sq.json", "w"), indent=1)
     except Exception as e:  # noqa
         print("no SQ pass:", e)
     json.dump({"tag": tag, "kernel": "lcd_poa_chain_kernel", "hbm_bytes_per_step": poa,
