@@ -583,9 +583,10 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     if (C.mode == 0) band = std::min<long long>(maxl + 1, 2ll * (10 + maxl / 100) + 1 + band_x[hint]);
     else band = maxl + 1;
     long long cells = rows_est * band;
-    // (K2 chains of noisy reads still overflow at the worst-case cell count: it is the spilled value rows -- 12 KB each in the wide classes --
-    //  that run out when a third of the rows have a far successor; they are re-run with 4x the graph capacity.  A spill row of the read's
-    //  width instead of the window's is the fix, future work)
+    // Known inefficiency (noisy reads only): EVERY K2 chain of 5 %-error reads runs out of spilled value rows at this size (a spilled row is 12
+    // bytes per window column; most rows of such graphs have a successor more than K rows away) and is re-run with a 4x graph.  Scaling the
+    // whole region x4 up front removes the retries but costs 58 GB per 8 batches; the fix is a spill area sized on its own (and arena
+    // slots per resident workgroup instead of per chain) -- future work, DESIGN section 5.
     const long long worst = rows_worst * (long long)(maxl + 1);
     for (int s = 1; s < scale && cells < worst; s *= 2) cells *= 8;
     cells = std::min(cells, worst);
@@ -898,6 +899,8 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             if (getenv("LCD_MEM_DEBUG")) {
                 int c[2][3] = {{0, 0, 0}, {0, 0, 0}};
                 for (size_t g : again) { const PoaChainOut &o = bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]]; c[PC(g).mode ? 1 : 0][o.status == LCD_ERR_CELLS ? 0 : o.status == LCD_ERR_NODES ? 1 : 2]++; }
+                { std::map<int, std::pair<int, int>> byc; for (size_t g : which) if (PC(g).mode) byc[chain_threads(PC(g))].second++; for (size_t g : again) if (PC(g).mode) byc[chain_threads(PC(g))].first++;
+                  for (auto &kv : byc) fprintf(stderr, "[mem]   K2 class %4d: %d of %d overflow\n", kv.first, kv.second.first, kv.second.second); }
                 fprintf(stderr, "[mem] round %d overflows: K1 cells %d nodes %d edges %d | K2 cells %d nodes %d edges %d (hints: cells %d/%d nodes %d)\n", round, c[0][0], c[0][1], c[0][2], c[1][0], c[1][1], c[1][2],
                         g_cell_hint[0].load(), g_cell_hint[1].load(), g_node_hint.load());
             }
