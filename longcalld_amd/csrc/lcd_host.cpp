@@ -583,10 +583,12 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     if (C.mode == 0) band = std::min<long long>(maxl + 1, 2ll * (10 + maxl / 100) + 1 + band_x[hint]);
     else band = maxl + 1;
     long long cells = rows_est * band;
-    // Known inefficiency (noisy reads only): EVERY K2 chain of 5 %-error reads runs out of spilled value rows at this size (a spilled row is 12
-    // bytes per window column; most rows of such graphs have a successor more than K rows away) and is re-run with a 4x graph.  Scaling the
-    // whole region x4 up front removes the retries but costs 58 GB per 8 batches; the fix is a spill area sized on its own (and arena
-    // slots per resident workgroup instead of per chain) -- future work, DESIGN section 5.
+    // K2 chains of noisy reads: at one code byte per worst-case cell EVERY such chain ran out of spilled value rows (a spilled row is 12 bytes
+    // per window column; clean graphs spill a few per cent of their rows, but in the graphs of 5 %-error reads most rows have a successor more
+    // than K rows away, and nearly every row has >= 2 usable predecessors, i.e. an ordinal word per cell) and was re-run with a 4x graph.
+    // Once the hint says the K2 chains overflow, their region is code | 4 ordinal planes | 8 planes of spilled rows (13 x cell_cap, not 4 x)
+    pc.spill_x = C.mode == 1 && hint >= 1 ? 8 : 2; // (a spilled row is 12 B per WINDOW column, 12-24x a code row: half of the rows spilled = 6-12x the code plane)
+    if (C.mode == 1 && hint >= 1) pc.edge_cap = (int)std::min<long long>(edge_worst, 2ll * pc.edge_cap); // (and their graphs have more bubbles per node)
     const long long worst = rows_worst * (long long)(maxl + 1);
     for (int s = 1; s < scale && cells < worst; s *= 2) cells *= 8;
     cells = std::min(cells, worst);
@@ -867,12 +869,12 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                         pc.out_off = b->retry_out.back()->addr(); retry_out_off[which[i]] = pc.out_off;
                     } else pc.out_off = retry_out_off.count(which[i]) ? retry_out_off[which[i]] : bs[k]->d_poa_out.addr() + out_rel[k][c];
                 }
-                PoaLayout Lay = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads);
+                PoaLayout Lay = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads, pc.spill_x);
                 pc.ws_off = tot; tot += Lay.total;
             }
             if (getenv("LCD_MEM_DEBUG")) {
                 double cellb = 0, nodeb = 0; double worstc = 0; size_t nbig = 0;
-                for (size_t i = 0; i < which.size(); ++i) { const PoaChain &pc = PC(which[i]); cellb += 4.0 * pc.cell_cap; PoaLayout Lay = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, 0, pc.n_reads); nodeb += (double)Lay.total; if (4.0 * pc.cell_cap > worstc) worstc = 4.0 * pc.cell_cap; nbig += 4.0 * pc.cell_cap > 64e6; }
+                for (size_t i = 0; i < which.size(); ++i) { const PoaChain &pc = PC(which[i]); cellb += (pc.spill_x > 2 ? 5.0 + pc.spill_x : 4.0) * pc.cell_cap; PoaLayout Lay = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, 0, pc.n_reads); nodeb += (double)Lay.total; if (4.0 * pc.cell_cap > worstc) worstc = 4.0 * pc.cell_cap; nbig += 4.0 * pc.cell_cap > 64e6; }
                 fprintf(stderr, "[mem] round %d: %zu chains, arena %.2f GB = DP regions %.2f GB (largest %.1f MB, %zu above 64 MB) + graph/plan arrays %.2f GB\n", round, which.size(), tot / 1e9, cellb / 1e9, worstc / 1e6, nbig, nodeb / 1e9);
             }
             if (L->d_poa_arena.ensure(tot)) return -11;
@@ -905,11 +907,11 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                         g_cell_hint[0].load(), g_cell_hint[1].load(), g_node_hint.load());
             }
             if (round == 0 && n_node_ovf * 20 > nC_all && g_node_hint.load() < 2) g_node_hint++;
-            if (round == 0) { // learn: more than 5 % of a mode's chains overflowed their DP region -> start from the next estimate next time
+            if (round == 0) { // learn: more than 1 % of a mode's chains overflowed their DP region -> start from the next estimate next time
                 int tot[2] = {0, 0}, ovf[2] = {0, 0};
                 for (size_t g = 0; g < nC_all; ++g) tot[PC(g).mode ? 1 : 0]++;
                 for (size_t g : again) ovf[PC(g).mode ? 1 : 0]++;
-                for (int m = 0; m < 2; ++m) if (tot[m] && ovf[m] * 20 > tot[m] && g_cell_hint[m].load() < 2) g_cell_hint[m]++;
+                for (int m = 0; m < 2; ++m) if (tot[m] && ovf[m] * 100 > tot[m] && g_cell_hint[m].load() < 2) g_cell_hint[m]++;
             }
             if (!again.empty()) { for (int k = 0; k < nb; ++k) bs[k]->st.poa_retries++; scale *= 2; }
             which.swap(again);
@@ -1534,7 +1536,7 @@ int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int
                     pc.out_off = retry_out.back()->addr();
                 }
             }
-            PoaLayout L = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads);
+            PoaLayout L = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads, pc.spill_x);
             pc.ws_off = tot; tot += L.total;
         }
         if (d_arena.ensure(tot)) return -11;

@@ -50,6 +50,8 @@ struct PoaChain {
     int threads;      // workgroup size class: 64 / 256 / 1024 (by DP row width)
     int wmax;         // columns per LDS ring slot
     int lds_words;    // dynamic LDS of the launch this chain is in (ring + query cache, re-used by the re-sort)
+    int spill_x;      // DP region = cell_cap x (1 code plane + ord_x ordinal planes + spill_x of spilled value rows) bytes; spill_x 2 -> ord_x 1 (clean
+                      // reads: one row in four has >= 2 usable predecessors), spill_x > 2 -> ord_x 4 (K2 chains of noisy reads: nearly every row has)
     uint32_t min_w;   // (int)(n*min_af) clipped below at 2 (cluster threshold)
     uint64_t cell_cap;
     uint64_t ws_off;  // byte offset of this chain's arena
@@ -90,11 +92,11 @@ struct PoaLayout {
 
 static inline LCD_HD uint64_t lcd_align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
-static inline LCD_HD PoaLayout poa_layout(int node_cap, int edge_cap, int rid_words, int max_len, uint64_t cell_cap, int n_reads) {
+static inline LCD_HD PoaLayout poa_layout(int node_cap, int edge_cap, int rid_words, int max_len, uint64_t cell_cap, int n_reads, int spill_x = 2) {
     PoaLayout L;
     uint64_t o = 0;
 #define LCD_TAKE(field, bytes) do { L.field = o; o = lcd_align_up(o + (uint64_t)(bytes), 16); } while (0)
-    LCD_TAKE(H, cell_cap * 4 + 64); L.E1 = L.E2 = L.H; // DP region, partitioned by the kernel (poa_kernel.hip prologue)
+    LCD_TAKE(H, lcd_align_up(cell_cap, 16) * (uint64_t)(spill_x > 2 ? 1 + 4 + spill_x : 4) + 64); L.E1 = L.E2 = L.H; // DP region, partitioned by the kernel (poa_kernel.hip prologue)
     LCD_TAKE(rbeg, (uint64_t)node_cap * 4); LCD_TAKE(rend, (uint64_t)node_cap * 4); LCD_TAKE(roff, (uint64_t)node_cap * 4);
     LCD_TAKE(ooff, (uint64_t)node_cap * 4); LCD_TAKE(spoff, (uint64_t)node_cap * 4);
     LCD_TAKE(mpl, (uint64_t)node_cap * 4); LCD_TAKE(mpr, (uint64_t)node_cap * 4);

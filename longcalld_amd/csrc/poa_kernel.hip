@@ -72,7 +72,7 @@ struct Ctx {
     int *het, *clu, *nclu; uint8_t *prof;
     int *pl_start, *pl_pidx, *pl_bonus, *pl_rem; uint8_t *pl_base;
     int *aa_node, *aa_flag, *aa_eid;
-    int wmax, seq_cap, pool_words;
+    int wmax, seq_cap, pool_words, spill_x;
     int n_node, n_edge, node_cap, edge_cap, rid_words;
     unsigned long long cell_cap;
     int status;
@@ -720,7 +720,7 @@ __device__ void ctx_to_sgpr(Ctx &g) {
     g.ml = usgpr(g.ml); g.mr = usgpr(g.mr); g.idx2node = usgpr(g.idx2node);
     g.cig_node0 = usgpr(g.cig_node0); g.cig_qpos0 = usgpr(g.cig_qpos0); g.imap = usgpr(g.imap);
     g.pl_start = usgpr(g.pl_start); g.pl_pidx = usgpr(g.pl_pidx); g.pl_bonus = usgpr(g.pl_bonus); g.pl_rem = usgpr(g.pl_rem); g.pl_base = usgpr(g.pl_base);
-    g.wmax = usgpr(g.wmax); g.cell_cap = usgpr(g.cell_cap); g.status = usgpr(g.status);
+    g.wmax = usgpr(g.wmax); g.cell_cap = usgpr(g.cell_cap); g.status = usgpr(g.status); g.spill_x = usgpr(g.spill_x);
 }
 // End node (best predecessor at column qlen; its values are in the spill area) + the code-driven backtrack, on wavefront 0.
 // Results through sm.bc[0] = #cigar entries, [1] = status, [4] = first cigar slot.
@@ -859,8 +859,8 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
     }
     for (int j = tid; j < QB; j += NT) lds_st_u8(sq1 + j, (j >= 1 && j <= qlen) ? seq_hbm[j - 1] : 4); // shifted: sq1[j] = q[j-1]
     const int qclamp = QB - 4;
-    const unsigned long long code_cap = g.cell_cap, ord_cap = g.cell_cap / 4; // bytes / ints (arena partition: see the kernel prologue)
-    const long long spill_rows = g.cell_cap * 2 > 64 ? (long long)((g.cell_cap * 2 - 64) / ((unsigned long long)SLOTW * 4)) : 0;
+    const unsigned long long code_cap = g.cell_cap, ord_cap = g.spill_x > 2 ? g.cell_cap : g.cell_cap / 4; // bytes / ints (arena partition: see the kernel prologue)
+    const long long spill_rows = g.cell_cap * g.spill_x > 64 ? (long long)((g.cell_cap * g.spill_x - 64) / ((unsigned long long)SLOTW * 4)) : 0;
     // ---- source row (slot 0, window at column 0) ----
     int end0 = qlen - rem_beg; if (end0 < 0) end0 = 0; end0 += w; if (end0 > qlen) end0 = qlen;
     if (end0 + 2 > WIN) return -1;
@@ -1151,8 +1151,8 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
     const int jb = 4 * tid;
     const int AW = imin(NW, (qlen >> 8) + 1); // wavefronts that own a column <= qlen
     const int cw4 = ((qlen >> 2) + 1) << 2;  // cells of a row in HBM, padded to the lanes' 4-cell groups
-    const unsigned long long code_cap = g.cell_cap, ord_cap = g.cell_cap / 4;
-    const long long spill_rows = g.cell_cap * 2 > 64 ? (long long)((g.cell_cap * 2 - 64) / ((unsigned long long)SLOTW * 4)) : 0;
+    const unsigned long long code_cap = g.cell_cap, ord_cap = g.spill_x > 2 ? g.cell_cap : g.cell_cap / 4;
+    const long long spill_rows = g.cell_cap * g.spill_x > 64 ? (long long)((g.cell_cap * g.spill_x - 64) / ((unsigned long long)SLOTW * 4)) : 0;
     // per-lane constants of this read
     // (one packed register: q[jb-1], q[jb], q[jb+1], q[jb+2] in bytes 0..3; columns outside the read get 15, which matches no base)
     unsigned qpk = 0; int has_n = 0;
@@ -1767,14 +1767,14 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     // window the host expects the band to fit (64 / 128 columns: LDS per chain is what limits how many of them share a CU)
     const int ring_cols = NT == 64 ? ch.wmax : 4 * NT;
     uint8_t *sseq = (uint8_t *)(lds_pool + Cfg<NT>::K * 3 * ring_cols);
-    const PoaLayout L = poa_layout(ch.node_cap, ch.edge_cap, ch.rid_words, ch.max_len, ch.cell_cap, ch.n_reads);
+    const PoaLayout L = poa_layout(ch.node_cap, ch.edge_cap, ch.rid_words, ch.max_len, ch.cell_cap, ch.n_reads, ch.spill_x);
     uint8_t *ws = arena + ch.ws_off;
     Ctx g;
     // DP region: 4 * cell_cap bytes.  Windowed / systolic rows: [direction codes: cell_cap B | predecessor ordinals: cell_cap B (one row
     // in four may have >= 2 predecessors) | spilled value rows: 2 * cell_cap B].  Generic rows: int32 H, E1, E2 planes of cell_cap / 3
     // cells.  Whatever does not fit ends the chain with LCD_ERR_CELLS and the host re-runs it with a larger arena.
     g.H = (int *)(ws + L.H); g.E1 = g.H + ch.cell_cap / 3; g.E2 = g.E1 + ch.cell_cap / 3;
-    g.code8 = ws + L.H; g.ord = (int *)(ws + L.H + lcd_align_up(ch.cell_cap, 16)); g.spill = (int *)(ws + L.H + 2 * lcd_align_up(ch.cell_cap, 16));
+    g.code8 = ws + L.H; g.ord = (int *)(ws + L.H + lcd_align_up(ch.cell_cap, 16)); g.spill = (int *)(ws + L.H + (ch.spill_x > 2 ? 5 : 2) * lcd_align_up(ch.cell_cap, 16));
     g.ooff = (uint32_t *)(ws + L.ooff); g.spoff = (uint32_t *)(ws + L.spoff);
     g.rbeg = (int *)(ws + L.rbeg); g.rend = (int *)(ws + L.rend); g.roff = (uint32_t *)(ws + L.roff);
     g.ml = (int *)(ws + L.mpl); g.mr = (int *)(ws + L.mpr);
@@ -1793,7 +1793,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.pl_rem = (int *)(ws + L.pl_rem); g.pl_base = ws + L.pl_base;
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
-    g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - Cfg<NT>::K * 3 * ring_cols) * 4;
+    g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - Cfg<NT>::K * 3 * ring_cols) * 4;
     g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0;
     const long long t_begin = clock64();
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
