@@ -324,3 +324,18 @@ def test_full_size_batch_equals_oracle(lcd, oracle):
         assert (sid == exp["sorted_ids"]).all()
         same_result(exp, g)
     assert st["n_regions"] == len(regs)
+
+
+def test_ont_batch_at_scale_equals_oracle(lcd, oracle):
+    """BASELINE configs[2] shape: 200 regions of 5 %-error reads in one batch, run twice -- the first run meets the overflow / retry rounds
+    (capacities start from the clean-read estimates), the second runs with what the library learned; both == oracle region by region"""
+    from longcalld_amd import jobs
+    regs = jobs.make_regions(3000, 200, jobs.ONT)
+    o = lcd.default_opt(); o.is_ont = 1
+    exp = [oracle.collect_noisy_reg_aln_strs(r) for r in regs]
+    for attempt in range(2):
+        got, ids, st, _ = _run_batch(lcd, regs, o)
+        for e, g, sid in zip(exp, got, ids):
+            assert (sid == e["sorted_ids"]).all()
+            same_result(e, g)
+        assert st["n_regions_resolved"] == sum(e["n_cons"] > 0 for e in exp)
