@@ -920,7 +920,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
             int mplv = 1 << 30, mprv = 0, minpb = 1 << 30, maxpe = -1;
             for (int t = 0; t < np; ++t) {
                 int pi = t == 0 ? pi0 : pi1;
-                if (t > 1) { pi = g.pl_pidx[p0 + t]; LCD_PIN(pi); }
+                if (t > 1) { pi = glb_ld(g.pl_pidx + p0 + t); LCD_PIN(pi); }
                 int pb, pe, pml, pmr;
                 if (idx - pi <= K) { const int sp = (pi - bi) & (K - 1); pb = LCD_RL(m_beg, sp); pe = LCD_RL(m_end, sp); pml = LCD_RL(m_ml, sp); pmr = LCD_RL(m_mr, sp); }
                 else {
@@ -965,7 +965,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
         bool overflow = false;
         for (int t = 0; t < np; ++t) {
             int pi = t == 0 ? pi0 : pi1, bz = t == 0 ? bz0 : bz1;
-            if (t > 1) { pi = g.pl_pidx[p0 + t]; bz = g.pl_bonus[p0 + t]; LCD_PIN(pi); LCD_PIN(bz); }
+            if (t > 1) { pi = glb_ld(g.pl_pidx + p0 + t); bz = glb_ld(g.pl_bonus + p0 + t); LCD_PIN(pi); LCD_PIN(bz); }
             const bool near = idx - pi <= K;
             const int sp = (pi - bi) & (K - 1);
             if (BANDED) {
@@ -980,7 +980,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
                 hm = lds_ld(S + 4 * xm); lds_ldc<C>(S + 4 * x, hv); lds_ldc<C>(S + 4 * (WIN + x), av); lds_ldc<C>(S + 4 * (2 * WIN + x), bv);
             } else {
                 if (!synced) { __syncthreads(); synced = true; }
-                const int *G = g.spill + (size_t)g.spoff[pi] * SLOTW;
+                const int *G = g.spill + (size_t)(unsigned)glb_ld((const int *)g.spoff + pi) * SLOTW;
                 hm = glb_ld(G + xm); glb_ldc<C>(G + x, hv); glb_ldc<C>(G + WIN + x, av); glb_ldc<C>(G + 2 * WIN + x, bv);
                 LCD_PIN(hm);
 #pragma unroll
@@ -1253,7 +1253,7 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
                 if (lane == 0) hm = wave == 0 ? LCD_GUARD : (SYS ? g_wide.bndH[pi & (SYS_D - 1)][wave - 1] : hm);
             };
             auto far_row = [&](const int pi, int &hm, int4 &hv, int4 &av, int4 &bv) {
-                const int *G = g.spill + (size_t)g.spoff[pi] * SLOTW;
+                const int *G = g.spill + (size_t)(unsigned)glb_ld((const int *)g.spoff + pi) * SLOTW;
                 hm = tid ? glb_ld(G + jb - 1) : LCD_GUARD; hv = glb_ld4(G + jb); av = glb_ld4(G + WIN + jb); bv = glb_ld4(G + 2 * WIN + jb);
                 LCD_PIN(hm); LCD_PIN(hv.x); LCD_PIN(hv.y); LCD_PIN(hv.z); LCD_PIN(hv.w); LCD_PIN(av.x); LCD_PIN(av.y); LCD_PIN(av.z); LCD_PIN(av.w);
                 LCD_PIN(bv.x); LCD_PIN(bv.y); LCD_PIN(bv.z); LCD_PIN(bv.w);
@@ -1271,10 +1271,10 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
                 }
                 n0 = n1 = n2 = n3 = u0 = u1 = u2 = u3 = v0 = v1 = v2 = v3 = LCD_NEG;
                 int p0 = 0;
-                if (np > 2) { p0 = g.pl_start[idx]; LCD_PIN(p0); }
+                if (np > 2) { p0 = glb_ld(g.pl_start + idx); LCD_PIN(p0); }
                 for (int t = 0; t < np; ++t) {
                     int pi = t == 0 ? pi0 : pi1, bz = t == 0 ? bz0 : bz1;
-                    if (t > 1) { pi = g.pl_pidx[p0 + t]; bz = g.pl_bonus[p0 + t]; LCD_PIN(pi); LCD_PIN(bz); }
+                    if (t > 1) { pi = glb_ld(g.pl_pidx + p0 + t); bz = glb_ld(g.pl_bonus + p0 + t); LCD_PIN(pi); LCD_PIN(bz); }
                     int hm; int4 hv, av, bv;
                     if (idx - pi <= K) near_row(pi, hm, hv, av, bv); else far_row(pi, hm, hv, av, bv);
                     const int be1 = bz - e1, be2 = bz - e2;
