@@ -649,8 +649,12 @@ static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, 
     static const int n_streams = std::max(1, std::min(LCD_NSIDE + 1, getenv("LCD_STREAMS") ? atoi(getenv("LCD_STREAMS")) : 4));
     int n1024 = 0, n512 = 0; bool any_narrow = false;
     for (const PoaChain &pc : sub) { if (pc.threads >= 1024) ++n1024; else if (pc.threads >= 512) ++n512; else any_narrow = true; }
-    const int cap = (int)(0.80 * g_n_cus); // leave a share of the CUs to the narrow classes from the start
-    const int target0 = std::min(n1024, cap), target1 = std::min(n512, std::max(0, 2 * (cap - target0)));
+    static const double gate_frac = getenv("LCD_GATE_FRAC") ? atof(getenv("LCD_GATE_FRAC")) : 0.80;
+    const int cap = (int)(gate_frac * g_n_cus); // leave a share of the CUs to the narrow classes from the start
+    // the narrow launches are also held until all but `keep` of the 512-thread workgroups have started: chains of that class beyond one round
+    // of residency (2 per CU) otherwise become the tail of the submission, two per CU on half-empty CUs (+3.5 % at 32 batches per submission)
+    const int keep512 = getenv("LCD_GATE512_KEEP") ? atoi(getenv("LCD_GATE512_KEEP")) : 2 * g_n_cus; // one round of residency
+    const int target0 = std::min(n1024, cap), target1 = std::min(n512, std::max(n512 - keep512, std::max(0, 2 * (cap - target0))));
     int *gate = nullptr;
     if (side && d_gate && n_streams > 1 && (n1024 + n512) > 0 && (any_narrow || (n1024 && n512))) {
         if (d_gate->ensure(256)) return -11;
