@@ -39,6 +39,9 @@ int g_n_cus = 256; // compute units of the device (MI355X: 256)
 int ensure_init() {
     std::lock_guard<std::mutex> lk(g_init_mu);
     if (g_device >= 0) { hipSetDevice(g_device); return 0; }
+    // a submission uses a pool of 4 streams; with more hardware queues holding runnable kernels the queue scheduler time-slices them (DESIGN
+    // section 4 "Submission").  Effective only if this is the process's first HIP call; a host that initialised HIP itself sets it beforehand.
+    setenv("GPU_MAX_HW_QUEUES", "4", 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return set_err(-1, "liblcd_hotpath: no HIP device visible (this library has no CPU path)");
     int dev = 0;
