@@ -183,6 +183,26 @@ int lcd_batch_get_stats(lcd_batch_t *b, lcd_batch_stats_t *st);
 /* a 64-bit FNV-1a digest over every region's results (n_cons, clusters, all alignment rows) -- cheap whole-batch parity check */
 uint64_t lcd_batch_digest(lcd_batch_t *b);
 
+/* ---- SURVEY 8(f) f2, first part: EQX CIGARs -> digar lists + each read's noisy windows (additive) ----
+ * == collect_digar_from_eqx_cigar (src/bam_utils.c:701-842, with push_xid_size_queue_win :161-200) for all reads of a chunk in one launch.
+ * Inputs are what bam1_t holds: 0-based position, CIGAR words (bam_get_cigar), qualities; pal_flags bit0 / bit1 = is_ont_palindrome_clip
+ * for the left / right clip (the caller reads the SA tag; 0 for HiFi).  Outputs (all malloc()'d, CSR over the reads):
+ *   digars[digar_off[r] .. digar_off[r+1])   digar1_t fields (alt_seq copies are not made: bases stay in the packed read);
+ *   ivs[iv_off[r] .. iv_off[r+1])            the read's digar->noisy_regs in cr_index order: start (= first position - 1), end, label;
+ *   iv_in_chunk[k]                           1 if interval k is added to chunk->chunk_noisy_regs (read not skipped, overlaps [reg_beg, reg_end]);
+ *   status[r] 0 / -1 (the function's return value: read skipped as too noisy) / -2 ('M' operation); beg/end = digar->beg/end; n_cand_vars. */
+typedef struct lcd_digar_opt_t {
+    int min_bq, noisy_reg_max_xgaps, noisy_reg_slide_win, end_clip_reg, end_clip_reg_flank_win; /* src/call_var_main.h:19-38: 10, 5, 100 | 25, 30, 100 */
+    double max_noisy_frac_per_read, max_var_ratio_per_read;                                     /* 0.5, 0.05 */
+} lcd_digar_opt_t;
+typedef struct lcd_digar_t { int64_t pos; int type, len, qi, is_low_qual; } lcd_digar_t;
+typedef struct lcd_noisy_iv_t { int64_t start, end; int label, pad; } lcd_noisy_iv_t;
+void lcd_digar_opt_default(lcd_digar_opt_t *o, int is_ont);
+int lcd_digar_batch(const lcd_digar_opt_t *opt, int n_reads, const int64_t *pos0, const uint32_t *cigar_pool, const uint64_t *cigar_off,
+                    const int *n_cigar, const uint8_t *qual_pool, const uint64_t *qual_off, const int *qlen, const uint8_t *pal_flags,
+                    int64_t reg_beg, int64_t reg_end, int64_t whole_ref_len, uint64_t **digar_off, lcd_digar_t **digars, uint64_t **iv_off,
+                    lcd_noisy_iv_t **ivs, uint8_t **iv_in_chunk, int *status, int64_t *beg, int64_t *end, int *n_cand_vars);
+
 /* ---- kernel-level batches (also what the per-call mirrors above run on) ---- */
 int lcd_edlib_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *q_off, const int *qlen,
                     const uint64_t *t_off, const int *tlen, int *dist, int *xgaps, int *n_eq, int *n_xid);

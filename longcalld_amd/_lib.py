@@ -35,6 +35,19 @@ class LcdNoisyVar(C.Structure):
                                                                                                               ("alt_seq", C.POINTER(C.c_uint8))]
 
 
+class LcdDigarOpt(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("min_bq", "noisy_reg_max_xgaps", "noisy_reg_slide_win", "end_clip_reg", "end_clip_reg_flank_win")] + [
+        ("max_noisy_frac_per_read", C.c_double), ("max_var_ratio_per_read", C.c_double)]
+
+
+class LcdDigar(C.Structure):
+    _fields_ = [("pos", C.c_int64), ("type", C.c_int), ("len", C.c_int), ("qi", C.c_int), ("is_low_qual", C.c_int)]
+
+
+class LcdNoisyIv(C.Structure):
+    _fields_ = [("start", C.c_int64), ("end", C.c_int64), ("label", C.c_int), ("pad", C.c_int)]
+
+
 class LcdReadView(C.Structure):
     _fields_ = [("digars", C.POINTER(LcdDigar1)), ("n_digar", C.c_int), ("qlen", C.c_int), ("bseq", C.POINTER(C.c_uint8)),
                 ("qual", C.POINTER(C.c_uint8)), ("hap", C.c_int), ("phase_set", C.c_int64)]
@@ -63,7 +76,7 @@ _lib = None
 EXPORTS = [
     "lcd_opt_default", "lcd_init", "lcd_last_error", "lcd_version", "lcd_wfa_end2end_aln", "lcd_edlib_end2end_aln",
     "lcd_edlib_xgaps", "lcd_edlib_edit_distance", "lcd_collect_noisy_reg_aln_strs", "lcd_batch_create", "lcd_batch_destroy",
-    "lcd_batch_clear", "lcd_batch_region_vars", "lcd_batch_add_region", "lcd_batch_add_region_from_chunk", "lcd_batch_upload", "lcd_batch_run", "lcd_batch_run_many",
+    "lcd_batch_clear", "lcd_batch_region_vars", "lcd_digar_opt_default", "lcd_digar_batch", "lcd_batch_add_region", "lcd_batch_add_region_from_chunk", "lcd_batch_upload", "lcd_batch_run", "lcd_batch_run_many",
     "lcd_batch_download", "lcd_batch_region_result", "lcd_batch_region_sorted_ids", "lcd_batch_get_stats", "lcd_batch_digest",
     "lcd_edlib_batch", "lcd_wfa_batch", "lcd_poa_batch", "lcd_assign_hap_germline", "lcd_assign_hap_batch",
 ]
@@ -98,6 +111,11 @@ def load_library():
     lib.lcd_batch_region_result.argtypes = [C.c_void_p, C.c_int, i32p, C.POINTER(i32p), C.POINTER(C.POINTER(LcdAlnStr))]
     lib.lcd_batch_region_vars.argtypes = [C.c_void_p, C.c_int, C.c_int64, u8p, C.c_int64, C.c_int64, C.POINTER(C.POINTER(LcdNoisyVar)), i32p,
                                           C.POINTER(i32p), C.POINTER(i32p), C.POINTER(i32p), C.POINTER(i32p)]
+    i64p, u64p_ = C.POINTER(C.c_int64), C.POINTER(C.c_uint64)
+    lib.lcd_digar_opt_default.argtypes = [C.POINTER(LcdDigarOpt), C.c_int]
+    lib.lcd_digar_opt_default.restype = None
+    lib.lcd_digar_batch.argtypes = [C.POINTER(LcdDigarOpt), C.c_int, i64p, C.POINTER(C.c_uint32), u64p_, i32p, u8p, u64p_, i32p, u8p, C.c_int64, C.c_int64, C.c_int64,
+                                    C.POINTER(u64p_), C.POINTER(C.POINTER(LcdDigar)), C.POINTER(u64p_), C.POINTER(C.POINTER(LcdNoisyIv)), C.POINTER(u8p), i32p, i64p, i64p, i32p]
     lib.lcd_batch_region_sorted_ids.argtypes = [C.c_void_p, C.c_int, i32p]
     lib.lcd_batch_get_stats.argtypes = [C.c_void_p, C.POINTER(LcdBatchStats)]
     lib.lcd_batch_digest.argtypes = [C.c_void_p]

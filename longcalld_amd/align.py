@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import LcdAlnStr, LcdBatchStats, LcdDigar1, LcdNoisyVar, LcdOpt, LcdReadView, check, load_library
+from ._lib import LcdAlnStr, LcdBatchStats, LcdDigar, LcdDigar1, LcdDigarOpt, LcdNoisyIv, LcdNoisyVar, LcdOpt, LcdReadView, check, load_library
 
 _libc = C.CDLL(None)
 _libc.free.argtypes = [C.c_void_p]
@@ -303,6 +303,42 @@ def make_read_views(digars, bseqs, quals, qlens, haps, phase_sets):
         arr[i].bseq = _p8(bs); arr[i].qual = _p8(ql); arr[i].hap = int(haps[i]); arr[i].phase_set = int(phase_sets[i])
         keep += [da, bs, ql]
     return arr, keep
+
+
+def digar_batch(pos0, cigars, quals, reg_beg, reg_end, whole_ref_len, is_ont=0, pal_flags=None, opt=None):
+    """collect_digar_from_eqx_cigar (src/bam_utils.c:701) for a list of reads on the GPU: cigars[i] = uint32 BAM CIGAR words, quals[i] = phred bytes.
+    -> list of dict(rc, digars (n,5), noisy (m,3), chunk_noisy (k,3), beg, end, n_cand), the layout of the oracle's wrapper"""
+    lib = load_library()
+    if opt is None:
+        opt = LcdDigarOpt(); lib.lcd_digar_opt_default(C.byref(opt), int(is_ont))
+    n = len(cigars)
+    cg = [np.ascontiguousarray(c, np.uint32) for c in cigars]; ql = [np.ascontiguousarray(q, np.uint8) for q in quals]
+    coff = np.concatenate([[0], np.cumsum([len(c) for c in cg])]).astype(np.uint64); qoff = np.concatenate([[0], np.cumsum([len(q) for q in ql])]).astype(np.uint64)
+    cpool = np.concatenate(cg + [np.zeros(1, np.uint32)]); qpool = np.concatenate(ql + [np.zeros(1, np.uint8)])
+    ncig = np.array([len(c) for c in cg], np.int32); qlen = np.array([len(q) for q in ql], np.int32)
+    p0 = np.ascontiguousarray(pos0, np.int64)
+    pf = np.ascontiguousarray(pal_flags if pal_flags is not None else np.zeros(n, np.uint8), np.uint8)
+    status = np.zeros(n, np.int32); beg = np.zeros(n, np.int64); end = np.zeros(n, np.int64); ncand = np.zeros(n, np.int32)
+    u64p_, i64p = C.POINTER(C.c_uint64), C.POINTER(C.c_int64)
+    doff, ioff = u64p_(), u64p_(); dg = C.POINTER(LcdDigar)(); iv = C.POINTER(LcdNoisyIv)(); inc = u8p()
+    check(lib.lcd_digar_batch(C.byref(opt), n, p0.ctypes.data_as(i64p), cpool.ctypes.data_as(C.POINTER(C.c_uint32)), coff.ctypes.data_as(u64p_), ncig.ctypes.data_as(i32p),
+                              _p8(qpool), qoff.ctypes.data_as(u64p_), qlen.ctypes.data_as(i32p), _p8(pf), int(reg_beg), int(reg_end), int(whole_ref_len),
+                              C.byref(doff), C.byref(dg), C.byref(ioff), C.byref(iv), C.byref(inc), status.ctypes.data_as(i32p), beg.ctypes.data_as(i64p),
+                              end.ctypes.data_as(i64p), ncand.ctypes.data_as(i32p)), lib)
+    out = []
+    nd_tot, ni_tot = int(doff[n]), int(ioff[n])
+    D = np.frombuffer((C.c_char * (24 * max(nd_tot, 1))).from_address(C.addressof(dg.contents)), dtype=np.dtype([("pos", "<i8"), ("type", "<i4"), ("len", "<i4"), ("qi", "<i4"), ("lq", "<i4")]), count=nd_tot).copy() if nd_tot else np.zeros(0, [("pos", "<i8"), ("type", "<i4"), ("len", "<i4"), ("qi", "<i4"), ("lq", "<i4")])
+    I = np.frombuffer((C.c_char * (24 * max(ni_tot, 1))).from_address(C.addressof(iv.contents)), dtype=np.dtype([("st", "<i8"), ("en", "<i8"), ("label", "<i4"), ("pad", "<i4")]), count=ni_tot).copy() if ni_tot else np.zeros(0, [("st", "<i8"), ("en", "<i8"), ("label", "<i4"), ("pad", "<i4")])
+    INC = np.array([inc[k] for k in range(ni_tot)], np.uint8)
+    for r in range(n):
+        d = D[int(doff[r]):int(doff[r + 1])]; v = I[int(ioff[r]):int(ioff[r + 1])]; m = INC[int(ioff[r]):int(ioff[r + 1])]
+        noisy = np.stack([v["st"], v["en"], v["label"].astype(np.int64)], 1).reshape(-1, 3) if len(v) else np.zeros((0, 3), np.int64)
+        out.append(dict(rc=int(status[r]), digars=np.stack([d["pos"], d["type"].astype(np.int64), d["len"].astype(np.int64), d["qi"].astype(np.int64), d["lq"].astype(np.int64)], 1).reshape(-1, 5),
+                        noisy=noisy, chunk_noisy=noisy[m.astype(bool)].reshape(-1, 3), beg=int(beg[r]), end=int(end[r]), n_cand=int(ncand[r])))
+    for p in (doff, ioff, dg, iv, inc):
+        if p:
+            _libc.free(C.cast(p, C.c_void_p))
+    return out
 
 
 def _hap_state(prob):

@@ -1499,6 +1499,88 @@ int lcd_wfa_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t 
     return 0;
 }
 
+// SURVEY 8(f) f2, first part: collect_digar_from_eqx_cigar (src/bam_utils.c:701-842) for all reads of a chunk
+void lcd_digar_opt_default(lcd_digar_opt_t *o, int is_ont) {
+    o->min_bq = 10; o->noisy_reg_max_xgaps = 5; o->noisy_reg_slide_win = is_ont ? 25 : 100; o->end_clip_reg = 30; o->end_clip_reg_flank_win = 100;
+    o->max_noisy_frac_per_read = 0.5; o->max_var_ratio_per_read = 0.05;
+}
+int lcd_digar_batch(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, const uint32_t *cigar_pool, const uint64_t *cigar_off, const int *n_cigar,
+                    const uint8_t *qual_pool, const uint64_t *qual_off, const int *qlen, const uint8_t *pal_flags, int64_t reg_beg, int64_t reg_end,
+                    int64_t whole_ref_len, uint64_t **digar_off_out, lcd_digar_t **digars_out, uint64_t **iv_off_out, lcd_noisy_iv_t **ivs_out,
+                    uint8_t **iv_in_chunk_out, int *status, int64_t *beg, int64_t *end, int *n_cand_vars) {
+    *digar_off_out = *iv_off_out = nullptr; *digars_out = nullptr; *ivs_out = nullptr; *iv_in_chunk_out = nullptr;
+    if (ensure_init()) return -1;
+    if (n <= 0) return 0;
+    static_assert(sizeof(lcd_digar_t) == sizeof(DigarRec) && sizeof(lcd_noisy_iv_t) == sizeof(IvRec), "ABI structs mirror the device records");
+    hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    // capacities from one pass over the CIGAR words (the host has them in hand anyway)
+    std::vector<DigarJob> jobs(n);
+    uint64_t cig_words = 0, qual_bytes = 0, dtot = 0, itot = 0, etot = 0;
+    for (int r = 0; r < n; ++r) { cig_words = std::max<uint64_t>(cig_words, cigar_off[r] + n_cigar[r]); qual_bytes = std::max<uint64_t>(qual_bytes, qual_off[r] + qlen[r]); }
+    for (int r = 0; r < n; ++r) {
+        DigarJob &j = jobs[r];
+        long long nd = 0, nev = 0;
+        for (int i = 0; i < n_cigar[r]; ++i) { const uint32_t c = cigar_pool[cigar_off[r] + i]; const int op = c & 0xf, len = (int)(c >> 4); if (op == 8) { nd += len; nev += len; } else if (op != 3) { ++nd; if (op == 1 || op == 2) ++nev; } }
+        j.n_cigar = n_cigar[r]; j.qlen = qlen[r]; j.pos0 = pos0[r]; j.left_pal = pal_flags ? pal_flags[r] & 1 : 0; j.right_pal = pal_flags ? (pal_flags[r] >> 1) & 1 : 0;
+        j.digar_cap = (int)nd; j.ev_cap = (int)nev + 1; j.iv_cap = (int)(nev / (opt->noisy_reg_max_xgaps + 1)) + 4; j.pad = 0;
+        j.cigar_off = cigar_off[r] * 4; j.qual_off = qual_off[r];
+        j.digar_off = dtot * sizeof(DigarRec); dtot += nd; j.iv_off = itot * sizeof(IvRec); itot += j.iv_cap; j.ev_off = etot * 16; etot += j.ev_cap;
+    }
+    DevBuf d_cig, d_qual, d_jobs, d_outs, d_dig, d_iv, d_ev;
+    if (d_cig.ensure(cig_words * 4 + 64) || d_qual.ensure(qual_bytes + 64) || d_jobs.ensure(n * sizeof(DigarJob)) || d_outs.ensure(n * sizeof(DigarOut)) ||
+        d_dig.ensure(dtot * sizeof(DigarRec) + 64) || d_iv.ensure(itot * sizeof(IvRec) + 64) || d_ev.ensure(etot * 16 + 64)) { hipStreamDestroy(st); return -11; }
+    for (DigarJob &j : jobs) { j.cigar_off += d_cig.addr(); j.qual_off += d_qual.addr(); j.digar_off += d_dig.addr(); j.iv_off += d_iv.addr(); j.ev_off += d_ev.addr(); }
+    HIPCHK(hipMemcpyAsync(d_cig.p, cigar_pool, cig_words * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_qual.p, qual_pool, qual_bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_jobs.p, jobs.data(), n * sizeof(DigarJob), hipMemcpyHostToDevice, st));
+    DigarOpt dopt; dopt.min_bq = opt->min_bq; dopt.max_xgaps = opt->noisy_reg_max_xgaps; dopt.win = opt->noisy_reg_slide_win; dopt.end_clip_reg = opt->end_clip_reg;
+    dopt.end_clip_flank = opt->end_clip_reg_flank_win; dopt.pad = 0; dopt.whole_ref_len = whole_ref_len;
+    lcd_launch_digar((const DigarJob *)d_jobs.p, (DigarOut *)d_outs.p, dopt, n, st);
+    HIPCHK(hipGetLastError());
+    std::vector<DigarOut> outs(n);
+    std::vector<DigarRec> hd(dtot + 1); std::vector<IvRec> hiv(itot + 1);
+    HIPCHK(hipMemcpyAsync(outs.data(), d_outs.p, n * sizeof(DigarOut), hipMemcpyDeviceToHost, st));
+    if (dtot) HIPCHK(hipMemcpyAsync(hd.data(), d_dig.p, dtot * sizeof(DigarRec), hipMemcpyDeviceToHost, st));
+    if (itot) HIPCHK(hipMemcpyAsync(hiv.data(), d_iv.p, itot * sizeof(IvRec), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    hipStreamDestroy(st);
+    uint64_t *doff = (uint64_t *)malloc((n + 1) * sizeof(uint64_t)), *ioff = (uint64_t *)malloc((n + 1) * sizeof(uint64_t));
+    uint64_t niv = 0;
+    for (int r = 0; r < n; ++r) { if (outs[r].status == -3) { free(doff); free(ioff); return set_err(-24, "digar batch: capacity estimate too small"); } niv += outs[r].n_iv; }
+    lcd_digar_t *dg = (lcd_digar_t *)malloc((dtot + 1) * sizeof(lcd_digar_t));
+    lcd_noisy_iv_t *iv = (lcd_noisy_iv_t *)malloc((niv + 1) * sizeof(lcd_noisy_iv_t)); uint8_t *inc = (uint8_t *)calloc(niv + 1, 1);
+    uint64_t dw = 0, iw = 0;
+    for (int r = 0; r < n; ++r) {
+        const DigarJob &j = jobs[r]; const DigarOut &o = outs[r];
+        doff[r] = dw; ioff[r] = iw;
+        memcpy(dg + dw, hd.data() + (j.digar_off - d_dig.addr()) / sizeof(DigarRec), (size_t)o.n_digar * sizeof(DigarRec)); dw += o.n_digar;
+        const IvRec *src = hiv.data() + (j.iv_off - d_iv.addr()) / sizeof(IvRec);
+        std::vector<IvRec> v(src, src + o.n_iv);
+        // cr_index (src/cgranges.c): intervals stay as added when their starts are non-decreasing, otherwise they are sorted by start --
+        // an insertion sort for up to 64 of them, i.e. stable (longer unsorted lists: radix passes whose tie order is not reproduced here;
+        // a tie needs a window starting exactly where the right-clip flank starts)
+        // (the key is cgranges' x = contig << 32 | start with the int32 start sign-extended: a negative start -- a clip flank reaching
+        //  below position 0 -- sorts after everything else)
+        auto key = [](const IvRec &a) { return (uint64_t)(long long)(int)a.st; };
+        bool sorted = true; for (int k = 1; k < o.n_iv; ++k) if (key(v[k]) < key(v[k - 1])) sorted = false;
+        if (!sorted) std::stable_sort(v.begin(), v.end(), [&](const IvRec &a, const IvRec &b) { return key(a) < key(b); });
+        long long total = 0;
+        for (const IvRec &x : v) total += x.en - x.st + 1;                     // collect_noisy_region_len (:631)
+        beg[r] = j.pos0 + 1; end[r] = j.pos0 + o.rlen; n_cand_vars[r] = o.n_cand;
+        const long long mapped = end[r] - beg[r] + 1;
+        const bool skip = (double)total > mapped * opt->max_noisy_frac_per_read || (double)o.n_cand > mapped * opt->max_var_ratio_per_read; // (:811)
+        status[r] = o.status == -2 ? -2 : skip ? -1 : 0;
+        for (int k = 0; k < o.n_iv; ++k) {
+            iv[iw + k].start = v[k].st; iv[iw + k].end = v[k].en; iv[iw + k].label = v[k].label; iv[iw + k].pad = 0;
+            inc[iw + k] = !skip && !(v[k].st + 1 > reg_end || v[k].en < reg_beg);    // is_overlap_reg(start + 1, end, ...) (:820)
+        }
+        iw += o.n_iv;
+    }
+    doff[n] = dw; ioff[n] = iw;
+    *digar_off_out = doff; *digars_out = dg; *iv_off_out = ioff; *ivs_out = iv; *iv_in_chunk_out = inc;
+    return 0;
+}
+
 int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int *chain_read0, const int *chain_n_reads, int n_reads_total,
                   const uint64_t *seq_off, const int *len, const int *skip, const int *anchors, const uint8_t *pool, uint64_t pool_len, int *status,
                   int *n_cons, int *cons_len, int *msa_len, int *clu_n, uint8_t *cons, int cons_stride, uint8_t *msa, int msa_stride, int max_reads,

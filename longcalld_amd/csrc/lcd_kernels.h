@@ -13,4 +13,5 @@ void lcd_launch_strings(const StrJob *jobs, uint8_t *pool, StrOut *outs, int n_j
 void lcd_launch_compose(const CmpJob *jobs, CmpOut *outs, const CmpSeg *segs, int n_jobs, int emit, hipStream_t stream);
 void lcd_launch_vars_scan(const VarScanJob *jobs, VarScanOut *outs, int n_jobs, hipStream_t stream);
 void lcd_launch_vars_profile(const VarRegJob *jobs, VarRegOut *outs, const StrJob *sjobs, const StrOut *souts, int n_jobs, hipStream_t stream);
+void lcd_launch_digar(const DigarJob *jobs, DigarOut *outs, DigarOpt opt, int n_jobs, hipStream_t stream);
 void lcd_launch_hap(const HapProb *probs, int n, hipStream_t stream);

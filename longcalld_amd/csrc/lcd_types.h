@@ -207,6 +207,20 @@ struct VarRegJob {
 };
 struct VarRegOut { int n_vars, alt_bytes; };
 
+// ---------------- SURVEY 8(f) f2 (first part): EQX CIGAR -> digars + per-read noisy windows (src/bam_utils.c:701-842) ----------------
+struct DigarRec { long long pos; int type, len, qi, is_low_qual; };   // digar1_t without the alt_seq copy
+struct IvRec { long long st, en; int label, pad; };                    // one cr_add(): [st, en), label
+struct DigarJob {
+    uint64_t cigar_off, qual_off;   // absolute device addresses: uint32[n_cigar], uint8[qlen]
+    int n_cigar, qlen;
+    long long pos0;                 // bam1_core_t.pos (0-based)
+    int left_pal, right_pal;        // is_ont_palindrome_clip for the left / right clip (caller-supplied)
+    uint64_t digar_off, iv_off, ev_off; // outputs DigarRec[digar_cap], IvRec[iv_cap]; scratch: the event queue (16 B x ev_cap)
+    int digar_cap, iv_cap, ev_cap, pad;
+};
+struct DigarOut { int status, n_digar, n_iv, n_cand, rlen; };
+struct DigarOpt { int min_bq, max_xgaps, win, end_clip_reg, end_clip_flank, pad; long long whole_ref_len; };
+
 // ---------------- K5: haplotype assignment (src/assign_hap.c:473-547) ----------------
 // bam_chunk_t / cand_var_t / read_var_profile_t flattened; every pointer is an absolute device address.
 struct HapProb {

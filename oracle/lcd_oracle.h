@@ -165,6 +165,25 @@ typedef struct {
 void lcdo_read_region_slice(const lcdo_digar1_t *digars, int n_digar, int qlen, int64_t reg_beg, int64_t reg_end,
                             int noisy_reg_flank_len, int *reg_read_beg, int *reg_read_end, int *cover);
 
+/* ---------------- SURVEY 8(f) f2 (first part): EQX CIGAR -> digars + the read's noisy windows (src/bam_utils.c:701-842) ---------------- */
+typedef struct {
+    int min_bq;                       /* 10 */
+    int noisy_reg_max_xgaps;          /* 5 */
+    int noisy_reg_slide_win;          /* 100 (HiFi) / 25 (ONT) */
+    int end_clip_reg, end_clip_reg_flank_win; /* 30, 100 */
+    double max_noisy_frac_per_read;   /* 0.5 */
+    double max_var_ratio_per_read;    /* 0.05 */
+} lcdo_digar_opt_t;
+typedef struct { int64_t pos; int type, len, qi, is_low_qual; } lcdo_digar_t; /* digar1_t without the alt_seq copy */
+/* returns 0, -1 (read skipped: too noisy) or -2 ('M' operation).  noisy / chunk_noisy: (start, end, label) triples as cr_add stores them
+ * (start = first position - 1), in cr_index order; chunk_noisy = those overlapping [reg_beg, reg_end] (none when skipped).  malloc()'d. */
+int lcdo_collect_digar_from_eqx_cigar(const lcdo_digar_opt_t *opt, int64_t read_pos0, const uint32_t *cigar, int n_cigar, const uint8_t *bseq,
+                                      const uint8_t *qual, int qlen, int64_t reg_beg, int64_t reg_end, int64_t whole_ref_len,
+                                      int left_clip_is_palindrome, int right_clip_is_palindrome, lcdo_digar_t **digars, int *n_digar,
+                                      int64_t **noisy, int *n_noisy, int64_t **chunk_noisy, int *n_chunk_noisy, int64_t *beg, int64_t *end,
+                                      int *n_total_cand_vars);
+void lcdo_cr_sorted_order(int n, const int *st, const int *en, int *order_out);
+
 /* ---------------- region alignment strings -> candidate variants + read x variant profile ---------------- */
 typedef struct {
     int64_t pos;                 /* cand_var_t.pos (1-based reference position) */

@@ -300,6 +300,43 @@ def make_vars_from_msa_cons_aln(res, noisy_reg_beg, chunk_ref, chunk_ref_beg, mi
     return out
 
 
+class DigarOpt(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("min_bq", "noisy_reg_max_xgaps", "noisy_reg_slide_win", "end_clip_reg", "end_clip_reg_flank_win")] + [
+        ("max_noisy_frac_per_read", C.c_double), ("max_var_ratio_per_read", C.c_double)]
+
+
+class DigarLQ(C.Structure):
+    _fields_ = [("pos", C.c_int64), ("type", C.c_int), ("len", C.c_int), ("qi", C.c_int), ("is_low_qual", C.c_int)]
+
+
+def digar_opt(is_ont=0):
+    """src/call_var_main.h:19-38 defaults"""
+    return DigarOpt(10, 5, 25 if is_ont else 100, 30, 100, 0.5, 0.05)
+
+
+def collect_digar_from_eqx_cigar(pos0, cigar, qual, reg_beg, reg_end, whole_ref_len, opt=None, left_pal=0, right_pal=0):
+    """SURVEY 8(f) f2 oracle (oracle/digar.c): -> dict(rc, digars (n,5), noisy (m,3), chunk_noisy (k,3), beg, end, n_cand)"""
+    opt = opt or digar_opt()
+    cg = np.ascontiguousarray(cigar, np.uint32); ql = _c8(qual)
+    dp, nz, cz = C.POINTER(DigarLQ)(), C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)()
+    nd, nn, nc, ncand = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    beg, end = C.c_int64(), C.c_int64()
+    L = lib()
+    L.lcdo_collect_digar_from_eqx_cigar.argtypes = [C.POINTER(DigarOpt), C.c_int64, C.POINTER(C.c_uint32), C.c_int, u8p, u8p, C.c_int, C.c_int64, C.c_int64, C.c_int64,
+                                                    C.c_int, C.c_int, C.POINTER(C.POINTER(DigarLQ)), i32p, C.POINTER(C.POINTER(C.c_int64)), i32p,
+                                                    C.POINTER(C.POINTER(C.c_int64)), i32p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), i32p]
+    rc = L.lcdo_collect_digar_from_eqx_cigar(C.byref(opt), int(pos0), cg.ctypes.data_as(C.POINTER(C.c_uint32)), len(cg), None, _p(ql), len(ql), int(reg_beg), int(reg_end),
+                                             int(whole_ref_len), int(left_pal), int(right_pal), C.byref(dp), C.byref(nd), C.byref(nz), C.byref(nn), C.byref(cz), C.byref(nc),
+                                             C.byref(beg), C.byref(end), C.byref(ncand))
+    dg = np.array([[dp[i].pos, dp[i].type, dp[i].len, dp[i].qi, dp[i].is_low_qual] for i in range(nd.value)], np.int64).reshape(-1, 5)
+    noisy = np.array([nz[i] for i in range(3 * nn.value)], np.int64).reshape(-1, 3)
+    cn = np.array([cz[i] for i in range(3 * nc.value)], np.int64).reshape(-1, 3)
+    for p in (dp, nz, cz):
+        if p:
+            _libc.free(C.cast(p, C.c_void_p))
+    return dict(rc=rc, digars=dg, noisy=noisy, chunk_noisy=cn, beg=beg.value, end=end.value, n_cand=ncand.value)
+
+
 class Digar1(C.Structure):
     _fields_ = [("pos", C.c_int64), ("type", C.c_int), ("len", C.c_int), ("qi", C.c_int)]
 

@@ -1,0 +1,96 @@
+"""SURVEY 8(f) f2, first part, on the GPU: EQX CIGARs -> digar lists + per-read noisy windows (digar_kernel.hip through lcd_digar_batch) vs the
+oracle's restatement of collect_digar_from_eqx_cigar (src/bam_utils.c:701): every digar, interval, flag and counter identical -- on the
+CIGARs of the reference's bundled HG002 chunk (rebuilt from the fixture's digar lists) and on seeded synthetic alignments with clips,
+reference skips, low-quality bases, long gaps and the 'M' error case."""
+import numpy as np
+import pytest
+
+import testdata_common as tc
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(exp, got):
+    assert exp["rc"] == got["rc"]
+    if exp["rc"] == -2:   # an 'M' operation: the reference exits the process (src/bam_utils.c:791); nothing else is defined
+        return
+    assert exp["digars"].shape == got["digars"].shape and (exp["digars"] == got["digars"]).all()
+    assert exp["noisy"].shape == got["noisy"].shape and (exp["noisy"] == got["noisy"]).all()
+    assert exp["chunk_noisy"].shape == got["chunk_noisy"].shape and (exp["chunk_noisy"] == got["chunk_noisy"]).all()
+    assert (exp["beg"], exp["end"], exp["n_cand"]) == (got["beg"], got["end"], got["n_cand"])
+
+
+def _cigar_of(digars):
+    out = []
+    for pos, t, l, qi in digars:
+        t, l = int(t), int(l)
+        if out and t == 8 and (out[-1] & 0xf) == 8:
+            out[-1] += 1 << 4
+        else:
+            out.append((l << 4) | t)
+    return np.array(out, np.uint32)
+
+
+def test_real_chunk_cigars(lcd, oracle):
+    ch = tc.Chunk()
+    rng = np.random.default_rng(7)
+    cigs = [_cigar_of(d) for d in ch.digars]
+    pos0 = [int(d[0][0]) - 1 for d in ch.digars]
+    o = int(ch.z["ref_beg"]); reg_beg, reg_end = o + 20000, o + 180000
+    for label, quals in (("high", [np.full(int(q), 40, np.uint8) for q in ch.qlen]),
+                         ("mixed", [rng.choice([3, 8, 12, 30, 40], int(q), p=[0.05, 0.05, 0.1, 0.3, 0.5]).astype(np.uint8) for q in ch.qlen])):
+        got = lcd.digar_batch(pos0, cigs, quals, reg_beg, reg_end, 135086622)
+        n_win = 0
+        for i in range(ch.n_reads):
+            exp = oracle.collect_digar_from_eqx_cigar(pos0[i], cigs[i], quals[i], reg_beg, reg_end, 135086622)
+            _same(exp, got[i])
+            if label == "high":   # the digars the fixture was built from come back (positions, types, lengths, query offsets)
+                assert (got[i]["digars"][:, :4] == ch.digars[i]).all()
+            n_win += len(got[i]["noisy"])
+        assert n_win > 100
+
+
+def _synthetic(rng, noisy):
+    ops, qlen = [], 0
+    def add(op, ln):
+        nonlocal qlen
+        ops.append((ln << 4) | op)
+        if op in (7, 8, 1, 4):
+            qlen += ln
+    if rng.random() < 0.4:
+        if rng.random() < 0.3:
+            add(5, int(rng.integers(1, 200)))
+        add(4, int(rng.integers(1, 120)))
+    for _ in range(int(rng.integers(20, 400))):
+        add(7, int(rng.integers(1, 300 if not noisy else 30)))
+        x = rng.random()
+        if x < 0.45:
+            add(8, int(rng.integers(1, 4)))
+        elif x < 0.7:
+            add(1, int(rng.integers(1, 60 if rng.random() < 0.1 else 5)))
+        elif x < 0.95:
+            add(2, int(rng.integers(1, 80 if rng.random() < 0.1 else 5)))
+        else:
+            add(3, int(rng.integers(10, 2000)))
+    add(7, int(rng.integers(5, 100)))
+    if rng.random() < 0.4:
+        add(4, int(rng.integers(1, 150)))
+    return np.array(ops, np.uint32), qlen
+
+
+def test_synthetic_alignments(lcd, oracle):
+    rng = np.random.default_rng(99)
+    cigs, quals, pos0, pal = [], [], [], []
+    for i in range(300):
+        c, ql = _synthetic(rng, noisy=i % 3 == 0)
+        cigs.append(c); quals.append(rng.choice([2, 9, 10, 25, 40], ql, p=[0.03, 0.04, 0.08, 0.35, 0.5]).astype(np.uint8))
+        pos0.append(int(rng.integers(0, 5)) if i % 17 == 0 else int(rng.integers(1000, 900000))); pal.append(int(rng.integers(0, 4)) if i % 5 == 0 else 0)
+    cigs.append(np.array([(50 << 4) | 7, (10 << 4) | 0, (20 << 4) | 7], np.uint32)); quals.append(np.full(80, 30, np.uint8)); pos0.append(5000); pal.append(0)   # 'M'
+    for is_ont in (0, 1):
+        got = lcd.digar_batch(pos0, cigs, quals, 200000, 700000, 1000000, is_ont=is_ont, pal_flags=np.array(pal, np.uint8))
+        n_skip = n_chunk = 0
+        for i in range(len(cigs)):
+            exp = oracle.collect_digar_from_eqx_cigar(pos0[i], cigs[i], quals[i], 200000, 700000, 1000000, oracle.digar_opt(is_ont), pal[i] & 1, (pal[i] >> 1) & 1)
+            _same(exp, got[i])
+            n_skip += got[i]["rc"] == -1; n_chunk += len(got[i]["chunk_noisy"])
+        assert got[-1]["rc"] == -2 and n_skip >= 1 and n_chunk > 50

@@ -65,3 +65,25 @@ def test_noisy_region_variants_on_real_reads(oracle):
             if v["var_type"][i] == 1:
                 assert len(v["alt_seqs"][i]) == v["alt_len"][i] > 0
     assert tot == int(ch.z["exp_n_noisy_vars"]) and het > 20 and split > 0.8 * het
+
+
+def test_digars_of_real_cigars(oracle):
+    """SURVEY 8(f) f2 oracle (oracle/digar.c) on the bundled reads: the digar lists equal the ones the fixture generator derived
+    independently (plain Python over the BAM records), and reads of a 30x HiFi chunk are not skipped as too noisy"""
+    ch = tc.Chunk()
+    n_skip = n_win = 0
+    for i in range(0, ch.n_reads, 3):
+        d = ch.digars[i]
+        cig = []
+        for pos, t, l, qi in d:
+            if cig and int(t) == 8 and (cig[-1] & 0xf) == 8:
+                cig[-1] += 1 << 4
+            else:
+                cig.append((int(l) << 4) | int(t))
+        r = oracle.collect_digar_from_eqx_cigar(int(d[0][0]) - 1, np.array(cig, np.uint32), np.full(int(ch.qlen[i]), 40, np.uint8), 0, 1 << 40, 135086622)
+        assert (r["digars"][:, :4] == d).all() and (r["digars"][:, 4] == 0).all()
+        assert r["beg"] == int(d[0][0]) and r["n_cand"] == int(((d[:, 1] == 8) | (d[:, 1] == 1) | (d[:, 1] == 2)).sum()) + int(((d[:, 1] == 4) & (d[:, 2] > 30)).sum())
+        n_skip += r["rc"] == -1; n_win += len(r["noisy"])
+        for st, en, label in r["noisy"]:
+            assert en > st and label >= 0
+    assert n_skip == 0 and n_win > 30
