@@ -339,3 +339,26 @@ def test_ont_batch_at_scale_equals_oracle(lcd, oracle):
             assert (sid == e["sorted_ids"]).all()
             same_result(e, g)
         assert st["n_regions_resolved"] == sum(e["n_cons"] > 0 for e in exp)
+
+
+def test_concurrent_callers(lcd):
+    """SURVEY 8b threading: kt_for workers call into the library concurrently, each on its own chunk; four host threads with their own batches
+    (ctypes releases the GIL during the calls) get the digests of the same batches run one after the other"""
+    import threading
+    from longcalld_amd import jobs
+    sets = [jobs.make_regions(700 + t, 24, jobs.HIFI if t % 2 == 0 else jobs.ONT) for t in range(4)]
+    serial = [_run_batch(lcd, s)[3] for s in sets]
+    got, errs = [None] * 4, []
+
+    def work(t):
+        try:
+            for _ in range(3):
+                got[t] = _run_batch(lcd, sets[t])[3]
+        except Exception as e:  # noqa
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs and got == serial

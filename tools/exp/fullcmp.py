@@ -7,11 +7,12 @@ from multiprocessing import get_context
 from longcalld_amd import jobs
 
 SEED, N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000, int(sys.argv[2]) if len(sys.argv) > 2 else 1250
+SHAPE = jobs.ONT if len(sys.argv) > 3 and sys.argv[3] == "ont" else jobs.HIFI
 
 
 def orc_region(k):
     from oracle import pyoracle as orc
-    regs = jobs.make_regions(SEED, N, jobs.HIFI)
+    regs = jobs.make_regions(SEED, N, SHAPE)
     return k, orc.collect_noisy_reg_aln_strs(regs[k])
 
 
@@ -20,8 +21,9 @@ def main():
     orc.build()
     from longcalld_amd import align as lcd
     from conftest import same_result
-    regs = jobs.make_regions(SEED, N, jobs.HIFI)
-    b = lcd.RegionBatch()
+    regs = jobs.make_regions(SEED, N, SHAPE)
+    o = lcd.default_opt(); o.is_ont = 1 if SHAPE is jobs.ONT else 0; o.collect_noisy_vars = 1; o.collect_ref_read_aln_str = 1
+    b = lcd.RegionBatch(o)
     for r in regs:
         b.add_region(r)
     b.upload(); b.run(); b.download()
@@ -30,7 +32,8 @@ def main():
     print("retries", st["poa_retries"], "resolved", st["n_regions_resolved"])
     bad = []
     for k in range(N):
-        exp = orc.collect_noisy_reg_aln_strs(regs[k])
+        oo = orc.default_opt(); oo.collect_ref_read_aln_str = 1
+        exp = orc.collect_noisy_reg_aln_strs(regs[k], oo)
         try:
             same_result(exp, got[k])
         except AssertionError as e:
