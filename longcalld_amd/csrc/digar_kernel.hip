@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(64) lcd_digar_kernel(const DigarJob *jobs, Dig
         int front = 0, rear = -1, count = 0, q_s = -1, q_e = -1;
         long long cur_s = -1, cur_e = -1;
         const int ndc = nd < jb.digar_cap ? nd : jb.digar_cap;
-        auto add_iv = [&](long long st, long long en, int label) { if (n_iv < jb.iv_cap) { IvRec r; r.st = st; r.en = en; r.label = label; r.pad = 0; iv[n_iv] = r; } ++n_iv; };
+        auto add_iv = [&](long long st, long long en, int label) { if (st < 0) st = 0; if (st > en) return; /* cr_add, src/cgranges.c:145-149 */ if (n_iv < jb.iv_cap) { IvRec r; r.st = st; r.en = en; r.label = label; r.pad = 0; iv[n_iv] = r; } ++n_iv; };
         for (int k = 0; k < ndc; ++k) {
             const DigarRec r = dg[k];
             if (r.type == 4 || r.type == 5) { // clipping: a long one marks the flank next to it (src/bam_utils.c:772-787)

@@ -1559,8 +1559,7 @@ int lcd_digar_batch(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, cons
         // cr_index (src/cgranges.c): intervals stay as added when their starts are non-decreasing, otherwise they are sorted by start --
         // an insertion sort for up to 64 of them, i.e. stable (longer unsorted lists: radix passes whose tie order is not reproduced here;
         // a tie needs a window starting exactly where the right-clip flank starts)
-        // (the key is cgranges' x = contig << 32 | start with the int32 start sign-extended: a negative start -- a clip flank reaching
-        //  below position 0 -- sorts after everything else)
+        // (starts are >= 0: the kernel clamps like cr_add does, src/cgranges.c:146)
         auto key = [](const IvRec &a) { return (uint64_t)(long long)(int)a.st; };
         bool sorted = true; for (int k = 1; k < o.n_iv; ++k) if (key(v[k]) < key(v[k - 1])) sorted = false;
         if (!sorted) std::stable_sort(v.begin(), v.end(), [&](const IvRec &a, const IvRec &b) { return key(a) < key(b); });

@@ -28,7 +28,9 @@ typedef struct { int64_t *pos; int *lens, *counts; int front, rear, count, max_s
 typedef struct { int64_t st, en; int label; } iv_t;
 typedef struct { iv_t *v; int n, cap; } ivlist_t;
 
-static void iv_add(ivlist_t *l, int64_t st, int64_t en, int label) {
+static void iv_add(ivlist_t *l, int64_t st, int64_t en, int label) { /* cr_add, src/cgranges.c:145-149: a negative start is clamped, st > en is dropped */
+    if (st < 0) st = 0;
+    if (st > en) return;
     if (l->n == l->cap) { l->cap = l->cap ? l->cap * 2 : 8; l->v = (iv_t *)realloc(l->v, sizeof(iv_t) * l->cap); }
     l->v[l->n].st = st; l->v[l->n].en = en; l->v[l->n].label = label; l->n++;
 }

@@ -105,6 +105,37 @@ def edlib_nw(query, target):
     return d, ops
 
 
+_ref_cg = None
+
+
+def ref_cgranges():
+    """the reference's own src/cgranges.c, compiled by oracle/Makefile into oracle/_ref (None if not built)"""
+    global _ref_cg
+    if _ref_cg is None:
+        p = os.path.join(_HERE, "_ref", "libcgranges_ref.so")
+        if not os.path.exists(p):
+            return None
+        _ref_cg = C.CDLL(p)
+        _ref_cg.ref_cr_sorted_labels.argtypes = [C.c_int, i32p, i32p, i32p]
+        _ref_cg.ref_cr_sorted_labels.restype = None
+        _ref_cg.ref_cr_overlap_labels.argtypes = [C.c_int, i32p, i32p, C.c_int, C.c_int, i32p, C.c_int]
+    return _ref_cg
+
+
+def ref_cr_sorted_order(st, en):
+    st = np.ascontiguousarray(st, np.int32); en = np.ascontiguousarray(en, np.int32)
+    out = np.zeros(len(st), np.int32)
+    ref_cgranges().ref_cr_sorted_labels(len(st), st.ctypes.data_as(i32p), en.ctypes.data_as(i32p), out.ctypes.data_as(i32p))
+    return out
+
+
+def ref_cr_overlap(st, en, qst, qen):
+    st = np.ascontiguousarray(st, np.int32); en = np.ascontiguousarray(en, np.int32)
+    out = np.zeros(len(st) + 1, np.int32)
+    k = ref_cgranges().ref_cr_overlap_labels(len(st), st.ctypes.data_as(i32p), en.ctypes.data_as(i32p), int(qst), int(qen), out.ctypes.data_as(i32p), len(out))
+    return out[:k].copy()
+
+
 def ref_edlib_nw(query, target):
     r = ref_edlib()
     q, t = _c8(query), _c8(target)

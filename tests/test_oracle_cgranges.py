@@ -1,0 +1,38 @@
+"""Pins the two cgranges behaviours the hot path depends on against the REFERENCE's own src/cgranges.c (compiled from where it lies into
+oracle/_ref/libcgranges_ref.so): the order cr_index() leaves the intervals in (restated as lcdo_cr_sorted_order: K5 seeds reads in it, a
+read's noisy windows are reported in it) and the order cr_overlap() reports hits in (the oracle's K5 assumes: index order of the sorted array)."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    if oracle.ref_cgranges() is None:
+        pytest.skip("oracle/_ref/libcgranges_ref.so not built (reference tree absent and no prebuilt copy)")
+    return oracle
+
+
+def test_sorted_order_matches_reference_cgranges(ref):
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 5, 40, 64, 65, 200, 3000):
+        for ties in (False, True):
+            st = rng.integers(0, 50 if ties else 1_000_000, n).astype(np.int32)
+            en = st + rng.integers(1, 500, n).astype(np.int32)
+            assert (ref.cr_sorted_order(st, en) == ref.ref_cr_sorted_order(st, en)).all(), (n, ties)
+    # cr_add clamps a negative start to 0 and drops st > en (src/cgranges.c:146-149) -- oracle/digar.c and the digar kernel do the same
+    assert ref.ref_cr_sorted_order(np.array([500, -100, 20], np.int32), np.array([510, 30, 25], np.int32)).tolist() == [1, 2, 0]
+    assert ref.ref_cr_overlap(np.array([-100], np.int32), np.array([-90], np.int32), -200, 10).tolist() == []
+    st = np.sort(rng.integers(0, 10000, 300)).astype(np.int32)   # already sorted: kept as added, ties included
+    assert (ref.ref_cr_sorted_order(st, st + 3) == np.arange(300)).all() and (ref.cr_sorted_order(st, st + 3) == np.arange(300)).all()
+
+
+def test_overlap_reports_in_sorted_index_order(ref):
+    rng = np.random.default_rng(12)
+    for n in (3, 50, 400):
+        st = rng.integers(0, 5000, n).astype(np.int32); en = st + rng.integers(1, 300, n).astype(np.int32)
+        order = ref.ref_cr_sorted_order(st, en)
+        for _ in range(40):
+            q0 = int(rng.integers(0, 5000)); q1 = q0 + int(rng.integers(1, 400))
+            hits = ref.ref_cr_overlap(st, en, q0, q1)
+            exp = [i for i in order if st[i] < q1 and q0 < en[i]]
+            assert hits.tolist() == exp
