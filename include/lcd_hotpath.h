@@ -203,6 +203,17 @@ int lcd_digar_batch(const lcd_digar_opt_t *opt, int n_reads, const int64_t *pos0
                     int64_t reg_beg, int64_t reg_end, int64_t whole_ref_len, uint64_t **digar_off, lcd_digar_t **digars, uint64_t **iv_off,
                     lcd_noisy_iv_t **ivs, uint8_t **iv_in_chunk, int *status, int64_t *beg, int64_t *end, int *n_cand_vars);
 
+/* ---- SURVEY 8(f) f2, chunk level: pre_process_noisy_regs (src/collect_var.c:557-638) ----
+ * chunk_noisy: the intervals cr_add()'ed to chunk->chunk_noisy_regs while the reads were loaded (lcd_digar_batch: ivs[k] with iv_in_chunk[k]), in
+ * that order; low_comp: chunk->low_comp_cr as (start, end) pairs (sdust output, may be empty); reads in ordered_read_ids order with the skipped
+ * ones left out: digar beg / end and each read's own noisy intervals (CSR, as lcd_digar_batch returns them).  Steps: cr_index, extension to the
+ * overlapping low-complexity intervals (:538-553), cr_merge with the label-dependent distance (src/cgranges.c:225-300, twice as the reference
+ * does), then per region the reads spanning it and the reads noisy in it (device), kept when noisy >= min_alt_dp and noisy / total >= min_af.
+ * Returns the number of surviving regions; *regs_out is malloc()'d, in index order (start = first position - 1, end, label). */
+int lcd_pre_process_noisy_regs(const lcd_noisy_iv_t *chunk_noisy, int n_noisy, const int64_t *low_comp, int n_low, int n_reads, const int64_t *read_beg,
+                               const int64_t *read_end, const uint64_t *read_iv_off, const lcd_noisy_iv_t *read_ivs, int min_alt_dp, float min_af,
+                               lcd_noisy_iv_t **regs_out);
+
 /* ---- kernel-level batches (also what the per-call mirrors above run on) ---- */
 int lcd_edlib_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *q_off, const int *qlen,
                     const uint64_t *t_off, const int *tlen, int *dist, int *xgaps, int *n_eq, int *n_xid);

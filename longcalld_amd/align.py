@@ -341,6 +341,37 @@ def digar_batch(pos0, cigars, quals, reg_beg, reg_end, whole_ref_len, is_ont=0, 
     return out
 
 
+def pre_process_noisy_regs(chunk_noisy, low_comp, read_beg, read_end, read_ivs, min_alt_dp=2, min_af=0.2):
+    """pre_process_noisy_regs (src/collect_var.c:557): chunk_noisy (n,3) in cr_add order, low_comp (m,2), per read beg/end and its own (k,>=2)
+    interval array -> surviving regions (r,3)"""
+    lib = load_library()
+    def ivarr(a):
+        a = np.asarray(a, np.int64).reshape(-1, a.shape[1] if hasattr(a, "shape") and a.ndim == 2 else 3) if len(a) else np.zeros((0, 3), np.int64)
+        arr = (LcdNoisyIv * max(len(a), 1))()
+        for i, row in enumerate(a):
+            arr[i].start, arr[i].end, arr[i].label = int(row[0]), int(row[1]), int(row[2]) if len(row) > 2 else 0
+        return arr, len(a)
+    cn, n_noisy = ivarr(np.asarray(chunk_noisy, np.int64).reshape(-1, 3))
+    lc = np.ascontiguousarray(np.asarray(low_comp, np.int64).reshape(-1, 2)); n_low = len(lc)
+    if n_low == 0:
+        lc = np.zeros((1, 2), np.int64)
+    rb = np.ascontiguousarray(read_beg, np.int64); re_ = np.ascontiguousarray(read_end, np.int64)
+    n_reads = len(rb)
+    off = np.concatenate([[0], np.cumsum([len(x) for x in read_ivs])]).astype(np.uint64) if n_reads else np.zeros(1, np.uint64)
+    flat = np.concatenate([np.asarray(x, np.int64).reshape(-1, 3) for x in read_ivs] + [np.zeros((0, 3), np.int64)]) if n_reads else np.zeros((0, 3), np.int64)
+    ri, _ = ivarr(flat)
+    i64p, u64p_ = C.POINTER(C.c_int64), C.POINTER(C.c_uint64)
+    out = C.POINTER(LcdNoisyIv)()
+    if n_reads == 0:
+        rb = np.zeros(1, np.int64); re_ = np.zeros(1, np.int64)
+    n = check(lib.lcd_pre_process_noisy_regs(cn, n_noisy, lc.ctypes.data_as(i64p), n_low, n_reads, rb.ctypes.data_as(i64p), re_.ctypes.data_as(i64p), off.ctypes.data_as(u64p_), ri,
+                                             int(min_alt_dp), float(min_af), C.byref(out)), lib)
+    res = np.array([[out[i].start, out[i].end, out[i].label] for i in range(n)], np.int64).reshape(-1, 3)
+    if out:
+        _libc.free(C.cast(out, C.c_void_p))
+    return res
+
+
 def _hap_state(prob):
     R, V, TA = prob["n_reads"], prob["n_vars"], int(prob["alle_off"][-1])
     return dict(haps=np.zeros(R, np.int32), phase_sets=np.full(R, -1, np.int64), n_clean_agree_snps=np.zeros(R, np.int32),

@@ -107,6 +107,32 @@ __global__ void __launch_bounds__(64) lcd_digar_kernel(const DigarJob *jobs, Dig
     }
 }
 
+// pre_process_noisy_regs, the read-support part (src/collect_var.c:584-602): per merged region, the reads spanning it and, among them, those
+// with a noisy window of their own inside it.  One wavefront per region, lanes over the chunk's reads (cr_overlap semantics: half-open
+// intervals, a.st < b.en && b.st < a.en), wave reduction of the two counters.
+__global__ void __launch_bounds__(64) lcd_region_support_kernel(const IvRec *regs, int n_regs, const long long *read_beg, const long long *read_end,
+                                                                const unsigned long long *iv_off, const IvRec *ivs, int n_reads, int *total, int *noisy) {
+    const int ri = blockIdx.x;
+    if (ri >= n_regs) return;
+    const int lane = threadIdx.x;
+    const long long rs = regs[ri].st, re = regs[ri].en;
+    int tot = 0, nz = 0;
+    for (int r = lane; r < n_reads; r += 64) {
+        const long long qb = read_beg[r] - 1, qe = read_end[r];
+        if (!(rs < qe && qb < re)) continue;
+        ++tot;
+        int hit = 0;
+        for (unsigned long long k = iv_off[r]; k < iv_off[r + 1] && !hit; ++k) hit = ivs[k].st < re && rs < ivs[k].en;
+        nz += hit;
+    }
+    for (int d = 32; d >= 1; d >>= 1) { tot += __shfl_xor(tot, d); nz += __shfl_xor(nz, d); }
+    if (lane == 0) { total[ri] = tot; noisy[ri] = nz; }
+}
+void lcd_launch_region_support(const IvRec *regs, int n_regs, const long long *read_beg, const long long *read_end, const unsigned long long *iv_off,
+                               const IvRec *ivs, int n_reads, int *total, int *noisy, hipStream_t stream) {
+    if (n_regs > 0) hipLaunchKernelGGL(lcd_region_support_kernel, dim3(n_regs), dim3(64), 0, stream, regs, n_regs, read_beg, read_end, iv_off, ivs, n_reads, total, noisy);
+}
+
 void lcd_launch_digar(const DigarJob *jobs, DigarOut *outs, DigarOpt opt, int n_jobs, hipStream_t stream) {
     if (n_jobs > 0) hipLaunchKernelGGL(lcd_digar_kernel, dim3(n_jobs), dim3(64), 0, stream, jobs, outs, opt, n_jobs);
 }

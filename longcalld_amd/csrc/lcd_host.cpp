@@ -1499,6 +1499,121 @@ int lcd_wfa_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t 
     return 0;
 }
 
+// ---- SURVEY 8(f) f2, chunk level: pre_process_noisy_regs (src/collect_var.c:557-638) ----
+namespace {
+struct NIv { uint64_t x; long long en; int label; }; // x: the interval index's sort key (contig 0: the start)
+// cr_index's ordering (src/cgranges.c:13-86, :350-353): kept as added when the keys are non-decreasing, otherwise klib's in-place MSD radix sort
+// on the 64-bit key (8 bits per pass from bit 56, buckets of <= 64 entries by insertion sort) -- NOT stable, and windows found in many reads give
+// many equal starts, so the tie order of the real thing is reproduced, not approximated
+void niv_insertion(NIv *b, NIv *e) {
+    for (NIv *i = b + 1; i < e; ++i)
+        if (i->x < (i - 1)->x) { NIv t = *i, *j; for (j = i; j > b && t.x < (j - 1)->x; --j) *j = *(j - 1); *j = t; }
+}
+void niv_radix(NIv *beg, NIv *end, int s) {
+    struct Bk { NIv *b, *e; } bk[256];
+    for (auto &k : bk) k.b = k.e = beg;
+    for (NIv *i = beg; i != end; ++i) ++bk[(i->x >> s) & 255].e;
+    for (int k = 1; k < 256; ++k) { bk[k].e += bk[k - 1].e - beg; bk[k].b = bk[k - 1].e; }
+    for (Bk *k = bk; k != bk + 256;) {
+        if (k->b != k->e) {
+            Bk *l = bk + ((k->b->x >> s) & 255);
+            if (l != k) { NIv tmp = *k->b, sw; do { sw = tmp; tmp = *l->b; *l->b++ = sw; l = bk + ((tmp.x >> s) & 255); } while (l != k); *k->b++ = tmp; }
+            else ++k->b;
+        } else ++k;
+    }
+    bk[0].b = beg; for (int k = 1; k < 256; ++k) bk[k].b = bk[k - 1].e;
+    if (s) {
+        s = s > 8 ? s - 8 : 0;
+        for (auto &k : bk) { if (k.e - k.b > 64) niv_radix(k.b, k.e, s); else if (k.e - k.b > 1) niv_insertion(k.b, k.e); }
+    }
+}
+void niv_index(std::vector<NIv> &v) {
+    bool sorted = true; for (size_t i = 1; i < v.size(); ++i) if (v[i - 1].x > v[i].x) { sorted = false; break; }
+    if (sorted) return;
+    if (v.size() <= 64) niv_insertion(v.data(), v.data() + v.size()); else niv_radix(v.data(), v.data() + v.size(), 56);
+}
+void niv_add(std::vector<NIv> &v, long long st, long long en, int label) { if (st < 0) st = 0; if (st > en) return; v.push_back({(uint64_t)st, en, label}); } // cr_add :145-149
+// cr_merge(cr, -1, ...) (src/cgranges.c:225-300): passes of "merge every later interval that starts within min(label, label') of the running end"
+// until the number of intervals stops changing; each pass re-indexes
+void niv_merge(std::vector<NIv> &v) {
+    size_t cur = v.size();
+    for (;;) {
+        std::vector<NIv> out; std::vector<char> merged(v.size(), 0);
+        for (size_t j = 0; j < v.size(); ++j) {
+            if (merged[j]) continue;
+            uint64_t ms = v[j].x; long long me = v[j].en; int ml = v[j].label;
+            for (size_t k = j + 1; k < v.size(); ++k) {
+                if (merged[k]) continue;
+                const int win = ml < v[k].label ? ml : v[k].label;
+                if ((uint64_t)(me + win) >= v[k].x) { ml = std::max(ml, v[k].label); ms = std::min(ms, v[k].x); me = std::max(me, v[k].en); merged[k] = 1; }
+            }
+            niv_add(out, (long long)ms, me, ml);
+        }
+        niv_index(out);
+        v.swap(out);
+        if (v.size() == cur) break;
+        cur = v.size();
+    }
+}
+} // namespace
+
+int lcd_pre_process_noisy_regs(const lcd_noisy_iv_t *chunk_noisy, int n_noisy, const int64_t *low_comp, int n_low, int n_reads, const int64_t *read_beg,
+                               const int64_t *read_end, const uint64_t *read_iv_off, const lcd_noisy_iv_t *read_ivs, int min_alt_dp, float min_af,
+                               lcd_noisy_iv_t **regs_out) {
+    *regs_out = nullptr;
+    if (ensure_init()) return -1;
+    if (n_noisy <= 0) return 0;
+    std::vector<NIv> v;
+    for (int i = 0; i < n_noisy; ++i) niv_add(v, chunk_noisy[i].start, chunk_noisy[i].end, chunk_noisy[i].label);
+    niv_index(v);
+    if (n_low > 0) { // cr_extend_noisy_regs_with_low_comp / low_comp_cr_start_end (:466-478, :538-551): grow to every overlapping low-complexity interval
+        std::vector<NIv> w;
+        for (const NIv &a : v) {
+            const long long start = (long long)a.x + 1, end = a.en; long long ns = start, ne = end;
+            for (int k = 0; k < n_low; ++k) {
+                long long ls = low_comp[2 * k] < 0 ? 0 : low_comp[2 * k], le = low_comp[2 * k + 1];
+                if (ls > le) continue;
+                if (ls < end && start - 1 < le) { if (ls + 1 < ns) ns = ls + 1; if (le > ne) ne = le; }
+            }
+            niv_add(w, ns - 1, ne, a.label);
+        }
+        niv_index(w); v.swap(w);
+    }
+    niv_merge(v); niv_merge(v); // (:552 and :568)
+    const int nr = (int)v.size();
+    if (nr == 0) return 0;
+    // read support on the device
+    hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    std::vector<IvRec> regs(nr);
+    for (int i = 0; i < nr; ++i) { regs[i].st = (long long)v[i].x; regs[i].en = v[i].en; regs[i].label = v[i].label; regs[i].pad = 0; }
+    const uint64_t niv = n_reads > 0 ? read_iv_off[n_reads] : 0;
+    DevBuf d_regs, d_rb, d_re, d_off, d_iv, d_cnt;
+    if (d_regs.ensure(nr * sizeof(IvRec)) || d_rb.ensure((n_reads + 1) * 8) || d_re.ensure((n_reads + 1) * 8) || d_off.ensure((n_reads + 2) * 8) || d_iv.ensure((niv + 1) * sizeof(IvRec)) ||
+        d_cnt.ensure(2ull * nr * 4 + 64)) { hipStreamDestroy(st); return -11; }
+    HIPCHK(hipMemcpyAsync(d_regs.p, regs.data(), nr * sizeof(IvRec), hipMemcpyHostToDevice, st));
+    if (n_reads > 0) {
+        HIPCHK(hipMemcpyAsync(d_rb.p, read_beg, n_reads * 8, hipMemcpyHostToDevice, st)); HIPCHK(hipMemcpyAsync(d_re.p, read_end, n_reads * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_off.p, read_iv_off, (n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+        if (niv) HIPCHK(hipMemcpyAsync(d_iv.p, read_ivs, niv * sizeof(IvRec), hipMemcpyHostToDevice, st));
+    }
+    lcd_launch_region_support((const IvRec *)d_regs.p, nr, (const long long *)d_rb.p, (const long long *)d_re.p, (const unsigned long long *)d_off.p, (const IvRec *)d_iv.p, n_reads,
+                              (int *)d_cnt.p, (int *)d_cnt.p + nr, st);
+    HIPCHK(hipGetLastError());
+    std::vector<int> cnt(2 * (size_t)nr);
+    HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt.p, 2ull * nr * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    hipStreamDestroy(st);
+    lcd_noisy_iv_t *out = (lcd_noisy_iv_t *)malloc((nr + 1) * sizeof(lcd_noisy_iv_t));
+    int n_out = 0;
+    for (int i = 0; i < nr; ++i) {
+        const int tot = cnt[i], nz = cnt[nr + i];
+        if (nz < min_alt_dp || (float)nz / tot < min_af) continue; // (:609-610; 0 / 0 compares false, the first test already dropped it)
+        out[n_out].start = (long long)v[i].x; out[n_out].end = v[i].en; out[n_out].label = v[i].label; out[n_out].pad = 0; ++n_out;
+    }
+    *regs_out = out;
+    return n_out;
+}
+
 // SURVEY 8(f) f2, first part: collect_digar_from_eqx_cigar (src/bam_utils.c:701-842) for all reads of a chunk
 void lcd_digar_opt_default(lcd_digar_opt_t *o, int is_ont) {
     o->min_bq = 10; o->noisy_reg_max_xgaps = 5; o->noisy_reg_slide_win = is_ont ? 25 : 100; o->end_clip_reg = 30; o->end_clip_reg_flank_win = 100;

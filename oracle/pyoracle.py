@@ -136,6 +136,26 @@ def ref_cr_overlap(st, en, qst, qen):
     return out[:k].copy()
 
 
+def ref_pre_process_noisy_regs(chunk_noisy, low_comp, read_beg, read_end, read_ivs, min_alt_dp=2, min_af=0.2, merge_dis=500, min_sv_len=50):
+    """pre_process_noisy_regs with the REFERENCE's cgranges doing every interval operation (oracle/ref_cgranges_shim.c)"""
+    L = ref_cgranges()
+    L.ref_pre_process_noisy_regs.argtypes = [C.c_int, i32p, C.c_int, i32p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), i32p, i32p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                             i32p, C.c_int]
+    cn = np.ascontiguousarray(np.asarray(chunk_noisy, np.int64).reshape(-1, 3), np.int32)
+    lc = np.ascontiguousarray(np.asarray(low_comp, np.int64).reshape(-1, 2), np.int32)
+    rb = np.ascontiguousarray(read_beg, np.int64); re_ = np.ascontiguousarray(read_end, np.int64)
+    off = np.concatenate([[0], np.cumsum([len(x) for x in read_ivs])]).astype(np.int32) if len(rb) else np.zeros(1, np.int32)
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(x, np.int64).reshape(-1, 3)[:, :2] for x in read_ivs] + [np.zeros((0, 2), np.int64)]), np.int32) if len(rb) else np.zeros((1, 2), np.int32)
+    if len(flat) == 0:
+        flat = np.zeros((1, 2), np.int32)
+    out = np.zeros(3 * (len(cn) + 1), np.int32)
+    ll = C.POINTER(C.c_longlong)
+    n = L.ref_pre_process_noisy_regs(len(cn), cn.ctypes.data_as(i32p), len(lc), (lc if len(lc) else np.zeros((1, 2), np.int32)).ctypes.data_as(i32p), len(rb),
+                                     (rb if len(rb) else np.zeros(1, np.int64)).ctypes.data_as(ll), (re_ if len(rb) else np.zeros(1, np.int64)).ctypes.data_as(ll),
+                                     off.ctypes.data_as(i32p), flat.ctypes.data_as(i32p), int(merge_dis), int(min_sv_len), int(min_alt_dp), float(min_af), out.ctypes.data_as(i32p), len(cn) + 1)
+    return out[:3 * n].reshape(-1, 3).astype(np.int64)
+
+
 def ref_edlib_nw(query, target):
     r = ref_edlib()
     q, t = _c8(query), _c8(target)

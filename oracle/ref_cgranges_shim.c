@@ -31,3 +31,62 @@ int ref_cr_overlap_labels(int n, const int *st, const int *en, int qst, int qen,
     cr_destroy(cr);
     return (int)k;
 }
+
+/* pre_process_noisy_regs (src/collect_var.c:557-638) with cr_extend_noisy_regs_with_low_comp (:538-553) and low_comp_cr_start_end (:466-478):
+ * the control flow is restated here, every interval operation (cr_add / cr_index / cr_merge / cr_overlap) is the reference's own code.
+ * in:  chunk_noisy (st, en, label) triples in cr_add order; low_comp (st, en) pairs (chunk->low_comp_cr, may be empty); per read (in
+ *      ordered_read_ids order, skipped reads left out by the caller): digar beg / end and its own noisy intervals (CSR, st/en pairs).
+ * out: the surviving regions (st, en, label) in index order; returns their number. */
+int ref_pre_process_noisy_regs(int n_noisy, const int *noisy, int n_low, const int *low_comp, int n_reads, const long long *read_beg,
+                               const long long *read_end, const int *read_iv_off, const int *read_iv, int noisy_reg_merge_dis, int min_sv_len,
+                               int min_alt_dp, float min_af, int *out, int out_cap) {
+    if (n_noisy == 0) return 0;
+    cgranges_t *cr = cr_init();
+    for (int i = 0; i < n_noisy; ++i) cr_add(cr, "cr", noisy[3 * i], noisy[3 * i + 1], noisy[3 * i + 2]);
+    cr_index(cr);
+    if (n_low > 0) { /* cr_extend_noisy_regs_with_low_comp */
+        cgranges_t *lc = cr_init();
+        for (int i = 0; i < n_low; ++i) cr_add(lc, "cr", low_comp[2 * i], low_comp[2 * i + 1], 0);
+        cr_index(lc);
+        cgranges_t *nw = cr_init();
+        for (int64_t i = 0; i < cr->n_r; ++i) {
+            const int32_t start = cr_start(cr, i) + 1, end = cr_end(cr, i);
+            int32_t ns = start, ne = end;
+            int64_t *b = 0, m = 0;
+            const int64_t k = cr_overlap(lc, "cr", start - 1, end, &b, &m);
+            for (int64_t j = 0; j < k; ++j) { const int32_t s = cr_start(lc, b[j]) + 1, e = cr_end(lc, b[j]); if (s < ns) ns = s; if (e > ne) ne = e; }
+            free(b);
+            cr_add(nw, "cr", ns - 1, ne, cr_label(cr, i));
+        }
+        cr_index(nw); cr_destroy(cr); cr = nw; cr_destroy(lc);
+    }
+    cr = cr_merge(cr, -1, noisy_reg_merge_dis, min_sv_len); /* inside cr_extend_noisy_regs_with_low_comp (:552) */
+    cr = cr_merge(cr, -1, noisy_reg_merge_dis, min_sv_len); /* and again in pre_process_noisy_regs (:568) */
+    const int64_t nr = cr->n_r;
+    int *tot = (int *)calloc(nr + 1, sizeof(int)), *nz = (int *)calloc(nr + 1, sizeof(int));
+    int64_t *ob = 0, mb = 0;
+    for (int r = 0; r < n_reads; ++r) {
+        const int64_t on = cr_overlap(cr, "cr", (int32_t)(read_beg[r] - 1), (int32_t)read_end[r], &ob, &mb);
+        cgranges_t *rc = cr_init();
+        for (int k = read_iv_off[r]; k < read_iv_off[r + 1]; ++k) cr_add(rc, "cr", read_iv[2 * k], read_iv[2 * k + 1], 0);
+        cr_index(rc);
+        for (int64_t q = 0; q < on; ++q) {
+            const int ri = (int)ob[q];
+            tot[ri]++;
+            const int rs = cr_start(cr, ri) + 1, re = cr_end(cr, ri);
+            int64_t *nb = 0, nm = 0;
+            if (rc->n_r > 0 && cr_overlap(rc, "cr", rs - 1, re, &nb, &nm) > 0) nz[ri]++;
+            free(nb);
+        }
+        cr_destroy(rc);
+    }
+    free(ob);
+    int n_out = 0;
+    for (int64_t i = 0; i < nr; ++i) {
+        if (nz[i] < min_alt_dp || (float)nz[i] / tot[i] < min_af) continue;
+        if (n_out < out_cap) { out[3 * n_out] = cr_start(cr, i); out[3 * n_out + 1] = cr_end(cr, i); out[3 * n_out + 2] = cr_label(cr, i); }
+        ++n_out;
+    }
+    free(tot); free(nz); cr_destroy(cr);
+    return n_out;
+}

@@ -94,3 +94,41 @@ def test_synthetic_alignments(lcd, oracle):
             _same(exp, got[i])
             n_skip += got[i]["rc"] == -1; n_chunk += len(got[i]["chunk_noisy"])
         assert got[-1]["rc"] == -2 and n_skip >= 1 and n_chunk > 50
+
+
+def test_pre_process_noisy_regs(lcd, oracle):
+    """f2, chunk level: lcd_pre_process_noisy_regs vs the same control flow over the REFERENCE's own cgranges (cr_index / cr_merge / cr_overlap
+    compiled from /root/reference/src/cgranges.c into oracle/_ref): merged and filtered regions identical -- on the windows lcd_digar_batch
+    finds in the bundled reads and on synthetic chunks with many tied starts, > 64 intervals and label-dependent merge distances"""
+    if oracle.ref_cgranges() is None:
+        pytest.skip("oracle/_ref/libcgranges_ref.so not built")
+    ch = tc.Chunk()
+    cigs = [_cigar_of(d) for d in ch.digars]; pos0 = [int(d[0][0]) - 1 for d in ch.digars]
+    o = int(ch.z["ref_beg"])
+    got = lcd.digar_batch(pos0, cigs, [np.full(int(q), 40, np.uint8) for q in ch.qlen], o, o + 210000, 135086622)
+    keep = [g for g in got if g["rc"] == 0]
+    chunk_noisy = np.concatenate([g["chunk_noisy"] for g in keep])
+    rb = [g["beg"] for g in keep]; re_ = [g["end"] for g in keep]; ivs = [g["noisy"] for g in keep]
+    for low in (np.zeros((0, 2), np.int64), np.array([[chunk_noisy[5][0] - 40, chunk_noisy[5][1] + 25], [chunk_noisy[40][0] + 3, chunk_noisy[40][1] + 300]], np.int64)):
+        exp = oracle.ref_pre_process_noisy_regs(chunk_noisy, low, rb, re_, ivs)
+        res = lcd.pre_process_noisy_regs(chunk_noisy, low, rb, re_, ivs)
+        assert exp.shape == res.shape and (exp == res).all() and 10 < len(res) < len(chunk_noisy)
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        n_reads = int(rng.integers(5, 400))
+        centers = rng.integers(1000, 200000, int(rng.integers(3, 60)))
+        rb, re_, ivs, cn = [], [], [], []
+        for r in range(n_reads):
+            b = int(rng.integers(0, 180000)); e = b + int(rng.integers(2000, 30000))
+            mine = []
+            for c in centers:
+                if b < c < e and rng.random() < 0.5:
+                    s = int(c + rng.integers(-3, 4) * (trial % 2)); mine.append([s, s + int(rng.integers(5, 400)), int(rng.choice([6, 12, 60, 300, 700]))])
+            mine.sort()
+            rb.append(b + 1); re_.append(e); ivs.append(np.array(mine, np.int64).reshape(-1, 3)); cn += mine
+        cn = np.array(cn, np.int64).reshape(-1, 3)
+        low = np.stack([centers[:5] - 50, centers[:5] + 80], 1) if trial % 3 == 0 else np.zeros((0, 2), np.int64)
+        for min_dp, min_af in ((2, 0.2), (1, 0.0), (5, 0.5)):
+            exp = oracle.ref_pre_process_noisy_regs(cn, low, rb, re_, ivs, min_dp, min_af)
+            res = lcd.pre_process_noisy_regs(cn, low, rb, re_, ivs, min_dp, min_af)
+            assert exp.shape == res.shape and (exp == res).all(), (trial, min_dp)
