@@ -18,6 +18,9 @@ def kernel_stats(db_path, out_path, title):
         f.write(f"{'kernel':70s} {'calls':>8s} {'total_us':>16s} {'avg_us':>14s} {'pct':>7s}\n")
         for name, calls, tot, avg, pct in rows:
             f.write(f"{name.split('(')[0][:70]:70s} {calls:8d} {tot:16.0f} {avg:14.1f} {pct:7.2f}\n")
+        if any("lcd_gate_kernel" in r[0] for r in rows):
+            f.write("# note: lcd_gate_kernel is ONE lane that sleeps until the wide workgroups are resident (launch ordering, lcd_host.cpp launch_poa_grouped);\n"
+                    "#       its duration is waiting time on one wavefront slot and overlaps the chain kernels -- the percentages are of summed kernel time, not of wall time\n")
         try:
             for r in cur.execute("select name, grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count, scratch_size from kernels group by name"):
                 f.write(f"# {r[0].split('(')[0]}: grid={r[1]} wg={r[2]} lds={r[3]} vgpr={r[4]} sgpr={r[5]} scratch={r[6]}\n")
