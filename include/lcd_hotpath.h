@@ -214,6 +214,11 @@ int lcd_pre_process_noisy_regs(const lcd_noisy_iv_t *chunk_noisy, int n_noisy, c
                                const int64_t *read_end, const uint64_t *read_iv_off, const lcd_noisy_iv_t *read_ivs, int min_alt_dp, float min_af,
                                lcd_noisy_iv_t **regs_out);
 
+/* ---- low-complexity intervals of a chunk's reference: sdust (src/sdust.c), as chunk->low_comp_cr is filled (src/bam_utils.c:1573-1581) ----
+ * seq: raw codes 0..3 (4+ = N) or letters; T, W: LONGCALLD_SDUST_T 5 / LONGCALLD_SDUST_W 20 (src/call_var_main.h:82-83), W <= 64.
+ * *intervals_out: malloc()'d (start, finish) pairs exactly as sdust() returns them (0-based, half-open); returns their number or < 0. */
+int lcd_sdust(const uint8_t *seq, int64_t len, int T, int W, int64_t **intervals_out);
+
 /* ---- kernel-level batches (also what the per-call mirrors above run on) ---- */
 int lcd_edlib_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *q_off, const int *qlen,
                     const uint64_t *t_off, const int *tlen, int *dist, int *xgaps, int *n_eq, int *n_xid);

@@ -372,6 +372,18 @@ def pre_process_noisy_regs(chunk_noisy, low_comp, read_beg, read_end, read_ivs, 
     return res
 
 
+def sdust(seq, T=5, W=20):
+    """low-complexity intervals (src/sdust.c) of a code / letter sequence on the GPU -> (n, 2) array of (start, finish)"""
+    lib = load_library()
+    a = np.ascontiguousarray(seq, np.uint8)
+    out = C.POINTER(C.c_int64)()
+    n = check(lib.lcd_sdust(_p8(a), len(a), int(T), int(W), C.byref(out)), lib)
+    res = np.array([out[i] for i in range(2 * n)], np.int64).reshape(-1, 2)
+    if out:
+        _libc.free(C.cast(out, C.c_void_p))
+    return res
+
+
 def _hap_state(prob):
     R, V, TA = prob["n_reads"], prob["n_vars"], int(prob["alle_off"][-1])
     return dict(haps=np.zeros(R, np.int32), phase_sets=np.full(R, -1, np.int64), n_clean_agree_snps=np.zeros(R, np.int32),

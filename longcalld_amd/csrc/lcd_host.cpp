@@ -1499,6 +1499,58 @@ int lcd_wfa_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t 
     return 0;
 }
 
+// ---- sdust on the device (sdust_kernel.hip): segments on lanes, the host chains their reports with sdust's merge rule ----
+int lcd_sdust(const uint8_t *seq, int64_t len64, int T, int W, int64_t **intervals_out) {
+    *intervals_out = nullptr;
+    if (ensure_init()) return -1;
+    if (len64 <= 0) return 0;
+    if (W > 64 || W < 4 || len64 > 2000000000ll) return set_err(-4, "lcd_sdust: W must be in [4, 64] and the sequence below 2 Gb");
+    // segment length: the automaton is serial inside a segment (plus ~3W bases of lead-in and run-out), so short segments = more lanes, less latency
+    const int len = (int)len64, seg = W <= 32 ? 128 : 256, n_seg = (len + seg - 1) / seg, cap = seg + 8;
+    // where each segment's automaton starts: 2W + 4 triplet words before (segment start - W); a word ends at i when i-2..i are all A/C/G/T
+    auto code = [](uint8_t c) { return c < 4 ? (int)c : (c == 'A' || c == 'a') ? 0 : (c == 'C' || c == 'c') ? 1 : (c == 'G' || c == 'g') ? 2 : (c == 'T' || c == 't') ? 3 : 4; };
+    std::vector<int> from(n_seg, 0);
+    {
+        std::vector<int> ends; ends.reserve(2 * W + 8); // positions of the last word ends, as a sliding list
+        std::vector<int> ring(2 * W + 4, -1); size_t rn = 0; // ring of the last 2W+4 word-end positions
+        int l = 0, next = 0; // next segment whose anchor (a - W) we are waiting to pass
+        for (int i = 0; i < len && next < n_seg; ++i) {
+            while (next < n_seg && std::max(0, next * seg - W) == i) { // state needed exact from here on: start 2W+4 words back
+                from[next] = rn >= ring.size() ? std::max(0, ring[rn % ring.size()] - 2) : 0;
+                ++next;
+            }
+            if (code(seq[i]) < 4) { if (++l >= 3) { ring[rn % ring.size()] = i; ++rn; } } else l = 0;
+        }
+    }
+    hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const int pcap = W * W + 8;
+    DevBuf d_seq, d_from, d_n, d_out, d_p;
+    if (d_seq.ensure((size_t)len + 64) || d_from.ensure((size_t)n_seg * 4) || d_n.ensure((size_t)n_seg * 4) || d_out.ensure((size_t)n_seg * cap * 8) ||
+        d_p.ensure((size_t)n_seg * pcap * 16)) { hipStreamDestroy(st); return -11; }
+    HIPCHK(hipMemcpyAsync(d_seq.p, seq, len, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_from.p, from.data(), (size_t)n_seg * 4, hipMemcpyHostToDevice, st));
+    lcd_launch_sdust((const unsigned char *)d_seq.p, len, T, W, seg, n_seg, cap, (const int *)d_from.p, (int *)d_n.p, (int2 *)d_out.p, (int4 *)d_p.p, pcap, st);
+    HIPCHK(hipGetLastError());
+    std::vector<int> n(n_seg); std::vector<int> raw((size_t)n_seg * cap * 2);
+    HIPCHK(hipMemcpyAsync(n.data(), d_n.p, (size_t)n_seg * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(raw.data(), d_out.p, (size_t)n_seg * cap * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    hipStreamDestroy(st);
+    std::vector<int64_t> res; // save_masked_regions' merge (src/sdust.c:97-103) over the segments' reports in order
+    for (int s = 0; s < n_seg; ++s) {
+        if (n[s] < 0 || n[s] > cap) return set_err(-24, "lcd_sdust: per-segment capacity exceeded (segment " + std::to_string(s) + " of " + std::to_string(n_seg) + ": " + std::to_string(n[s]) + ", len " + std::to_string(len) + ")");
+        for (int k = 0; k < n[s]; ++k) {
+            const int64_t ps = raw[((size_t)s * cap + k) * 2], pf = raw[((size_t)s * cap + k) * 2 + 1];
+            if (!res.empty() && ps <= res.back()) { if (pf > res.back()) res.back() = pf; }
+            else { res.push_back(ps); res.push_back(pf); }
+        }
+    }
+    int64_t *out = (int64_t *)malloc((res.size() + 2) * sizeof(int64_t));
+    memcpy(out, res.data(), res.size() * sizeof(int64_t));
+    *intervals_out = out;
+    return (int)(res.size() / 2);
+}
+
 // ---- SURVEY 8(f) f2, chunk level: pre_process_noisy_regs (src/collect_var.c:557-638) ----
 namespace {
 struct NIv { uint64_t x; long long en; int label; }; // x: the interval index's sort key (contig 0: the start)

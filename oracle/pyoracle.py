@@ -156,6 +156,16 @@ def ref_pre_process_noisy_regs(chunk_noisy, low_comp, read_beg, read_end, read_i
     return out[:3 * n].reshape(-1, 3).astype(np.int64)
 
 
+def ref_sdust(seq, T=5, W=20):
+    """the reference's own sdust() (src/sdust.c) -> (n, 2) array of (start, finish)"""
+    L = ref_cgranges()
+    L.ref_sdust.argtypes = [u8p, C.c_int, C.c_int, C.c_int, i32p, C.c_int]
+    a = _c8(seq)
+    out = np.zeros(2 * (len(a) // 2 + 8), np.int32)
+    n = L.ref_sdust(_p(a), len(a), int(T), int(W), out.ctypes.data_as(i32p), len(out) // 2)
+    return out[:2 * n].reshape(-1, 2).astype(np.int64)
+
+
 def ref_edlib_nw(query, target):
     r = ref_edlib()
     q, t = _c8(query), _c8(target)

@@ -90,3 +90,14 @@ int ref_pre_process_noisy_regs(int n_noisy, const int *noisy, int n_low, const i
     free(tot); free(nz); cr_destroy(cr);
     return n_out;
 }
+
+/* the reference's own symmetric-DUST (src/sdust.c, compiled from where it lies): low-complexity intervals of a sequence, as chunk->low_comp_cr
+ * is filled (src/bam_utils.c:1573-1581).  out: (start, finish) pairs, 0-based half-open as sdust returns them; returns their number. */
+#include "sdust.h"
+int ref_sdust(const unsigned char *seq, int len, int T, int W, int *out, int cap) {
+    int n = 0;
+    uint64_t *r = sdust(0, seq, len, T, W, &n);
+    for (int i = 0; i < n && i < cap; ++i) { out[2 * i] = (int)(r[i] >> 32); out[2 * i + 1] = (int)(uint32_t)r[i]; }
+    free(r);
+    return n;
+}

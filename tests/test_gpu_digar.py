@@ -132,3 +132,40 @@ def test_pre_process_noisy_regs(lcd, oracle):
             exp = oracle.ref_pre_process_noisy_regs(cn, low, rb, re_, ivs, min_dp, min_af)
             res = lcd.pre_process_noisy_regs(cn, low, rb, re_, ivs, min_dp, min_af)
             assert exp.shape == res.shape and (exp == res).all(), (trial, min_dp)
+
+
+def _lowcomp_seq(rng, n, n_frac):
+    s = rng.integers(0, 4, n).astype(np.uint8)
+    for _ in range(n // 400):
+        p = int(rng.integers(0, n - 300)); k = int(rng.integers(1, 7)); ln = int(rng.integers(8, 250))
+        unit = rng.integers(0, 4, k).astype(np.uint8)
+        s[p:p + ln] = np.resize(unit, ln)
+        if rng.random() < 0.3:      # imperfect repeat
+            q = rng.integers(p, p + ln, max(1, ln // 15)); s[q] = rng.integers(0, 4, len(q))
+    for _ in range(int(n * n_frac / 50) + (1 if n_frac else 0)):
+        p = int(rng.integers(0, n - 10)); ln = int(rng.choice([1, 2, 3, 10, 60, 700, 3000]))
+        s[p:p + ln] = 4
+    return s
+
+
+def test_sdust_matches_reference(lcd, oracle):
+    """low-complexity intervals (chunk->low_comp_cr): the segmented device sdust vs the REFERENCE's own src/sdust.c on random sequences with
+    tandem repeats / homopolymers / runs of N of every size (windows share words across an N), several (T, W), lengths around the segment
+    size, and on the bundled chr11 slice"""
+    if oracle.ref_cgranges() is None:
+        pytest.skip("oracle/_ref/libcgranges_ref.so not built")
+    rng = np.random.default_rng(21)
+    n_iv = 0
+    for n, nf in ((0, 0), (2, 0), (3, 0), (40, 0), (511, 0), (512, 0.0), (513, 0.01), (5000, 0), (5000, 0.02), (60000, 0.0), (60000, 0.01), (300000, 0.002)):
+        s = _lowcomp_seq(rng, n, nf) if n > 400 else rng.integers(0, 2, n).astype(np.uint8)
+        for T, W in ((5, 20), (20, 64), (10, 33)) if n <= 5000 else ((5, 20), (10, 33)):   # (W = 64: thousands of perfect intervals per window, slow on a lane)
+            exp = oracle.ref_sdust(s, T, W); got = lcd.sdust(s, T, W)
+            assert exp.shape == got.shape and (exp == got).all(), (n, nf, T, W)
+            n_iv += len(got)
+    ch = tc.Chunk()
+    ref = ch.z["ref"]
+    exp = oracle.ref_sdust(ref, 5, 20); got = lcd.sdust(ref, 5, 20)
+    assert exp.shape == got.shape and (exp == got).all() and len(got) > 500
+    letters = np.frombuffer(b"ACGTN", np.uint8)[np.minimum(ref[:50000], 4)]      # faidx gives letters (src/bam_utils.c:1564): same intervals
+    assert (lcd.sdust(letters, 5, 20) == oracle.ref_sdust(ref[:50000], 5, 20)).all()
+    assert n_iv > 1000
