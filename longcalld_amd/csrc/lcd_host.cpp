@@ -1522,11 +1522,15 @@ int lcd_sdust(const uint8_t *seq, int64_t len64, int T, int W, int64_t **interva
             if (code(seq[i]) < 4) { if (++l >= 3) { ring[rn % ring.size()] = i; ++rn; } } else l = 0;
         }
     }
-    hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (getenv("LCD_MEM_DEBUG")) { long long tot = 0, mx = 0; for (int k = 0; k < n_seg; ++k) { const long long d = (long long)k * seg - from[k]; tot += d; mx = std::max(mx, d); } fprintf(stderr, "[sdust] %d segments of %d, lead-in mean %.1f max %lld\n", n_seg, seg, (double)tot / n_seg, mx); }
+    // (grow-only buffers and one stream kept across calls: five hipMalloc / hipFree pairs cost more than the kernel)
+    static std::mutex mu; std::lock_guard<std::mutex> lk(mu);
+    static hipStream_t st = nullptr;
+    if (!st) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     const int pcap = W * W + 8;
-    DevBuf d_seq, d_from, d_n, d_out, d_p;
+    static DevBuf d_seq, d_from, d_n, d_out, d_p;
     if (d_seq.ensure((size_t)len + 64) || d_from.ensure((size_t)n_seg * 4) || d_n.ensure((size_t)n_seg * 4) || d_out.ensure((size_t)n_seg * cap * 8) ||
-        d_p.ensure((size_t)n_seg * pcap * 16)) { hipStreamDestroy(st); return -11; }
+        d_p.ensure((size_t)n_seg * pcap * 16)) return -11;
     HIPCHK(hipMemcpyAsync(d_seq.p, seq, len, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_from.p, from.data(), (size_t)n_seg * 4, hipMemcpyHostToDevice, st));
     lcd_launch_sdust((const unsigned char *)d_seq.p, len, T, W, seg, n_seg, cap, (const int *)d_from.p, (int *)d_n.p, (int2 *)d_out.p, (int4 *)d_p.p, pcap, st);
@@ -1535,7 +1539,6 @@ int lcd_sdust(const uint8_t *seq, int64_t len64, int T, int W, int64_t **interva
     HIPCHK(hipMemcpyAsync(n.data(), d_n.p, (size_t)n_seg * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(raw.data(), d_out.p, (size_t)n_seg * cap * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    hipStreamDestroy(st);
     std::vector<int64_t> res; // save_masked_regions' merge (src/sdust.c:97-103) over the segments' reports in order
     for (int s = 0; s < n_seg; ++s) {
         if (n[s] < 0 || n[s] > cap) return set_err(-24, "lcd_sdust: per-segment capacity exceeded (segment " + std::to_string(s) + " of " + std::to_string(n_seg) + ": " + std::to_string(n[s]) + ", len " + std::to_string(len) + ")");

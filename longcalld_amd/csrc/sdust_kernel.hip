@@ -11,6 +11,7 @@
 #include "lcd_kernels.h"
 
 namespace {
+constexpr int SD_PL = 48;
 struct SdPerf { int start, finish, r, l; };
 __device__ __forceinline__ int sd_code(unsigned char c) { // seq_nt4_table, src/sdust.c:22-39: raw codes 0..3 and the letters ACGT / acgt
     if (c < 4) return c;
@@ -29,21 +30,28 @@ __global__ void __launch_bounds__(64) lcd_sdust_kernel(const unsigned char *seq,
     extern __shared__ int sd_lds[];
     int *const wq = sd_lds + threadIdx.x, *const cv = wq + 64 * 64, *const cw = cv + 64 * 64, *const c = cw + 64 * 64;
 #define SDX(k) ((k) * 64)
-    // the perfect intervals of the current window: at most one per (start inside the window, step it was found at) = W x W entries, in an HBM slab
-    SdPerf *P = (SdPerf *)(pbuf + (size_t)sid * pcap);
+    // the perfect intervals of the current window (descending start): at most one per (start inside the window, step it was found at) = W x W
+    // entries; the first SD_PL of them in LDS (lane-interleaved), the rest -- rare -- in an HBM slab
+    int4 *const Pl = (int4 *)(sd_lds + 4 * 64 * 64) + threadIdx.x; int4 *const Pg = pbuf + (size_t)sid * pcap;
+    // (macros, not lambdas: by-reference captures would put the whole automaton state into scratch memory -- measured 30x slower)
+#define Pget(j) ((j) < SD_PL ? Pl[(j) * 64] : Pg[(j)])   /* (x, y, z, w) = (start, finish, r, l) */
+#define Pset(j, v) do { const int4 v_ = (v); if ((j) < SD_PL) Pl[(j) * 64] = v_; else Pg[(j)] = v_; } while (0)
     int qfront = 0, qcount = 0, pn = 0, rv = 0, rw = 0, L = 0, l = 0, nout = 0, bad = 0;
     unsigned t = 0;
     for (int k = 0; k < 64; ++k) { cv[SDX(k)] = 0; cw[SDX(k)] = 0; }
     int2 *mine = out + (size_t)sid * cap;
-    auto at = [&](int i) { return wq[SDX((qfront + i) & 63)]; };
-    auto save = [&](int start) { // save_masked_regions :91-106, minus the merge into the previous result (done by the host over all segments)
-        if (pn == 0 || P[pn - 1].start >= start) return;
-        const SdPerf p = P[pn - 1];
-        if (p.start >= a && p.start < b) { if (nout < cap) mine[nout] = make_int2(p.start, p.finish); ++nout; }
-        int i = pn - 1;
-        while (i >= 0 && P[i].start < start) --i;
-        pn = i + 1;
-    };
+#define AT(i) (wq[SDX((qfront + (i)) & 63)])
+    /* save_masked_regions :91-106, minus the merge into the previous result (done by the host over all segments) */
+#define SD_SAVE(start_)                                                                                                    \
+    do {                                                                                                                   \
+        if (pn == 0) break;                                                                                                \
+        const int4 p_ = Pget(pn - 1);                                                                                      \
+        if (p_.x >= (start_)) break;                                                                                       \
+        if (p_.x >= a && p_.x < b) { if (nout < cap) mine[nout] = make_int2(p_.x, p_.y); ++nout; }                         \
+        int i_ = pn - 2;                                                                                                   \
+        while (i_ >= 0 && Pget(i_).x < (start_)) --i_;                                                                     \
+        pn = i_ + 1;                                                                                                       \
+    } while (0)
     for (int i = from; i <= to; ++i) {
         if (i == to && to < len) break;
         const int bcode = i < len ? sd_code(seq[i]) : 4;
@@ -51,29 +59,29 @@ __global__ void __launch_bounds__(64) lcd_sdust_kernel(const unsigned char *seq,
             ++l; t = (t << 2 | (unsigned)bcode) & 63u;
             if (l >= 3) {
                 const int start = (l - W > 0 ? l - W : 0) + (i + 1 - l);
-                save(start);
+                SD_SAVE(start);
                 { // shift_window :68-89
                     if (qcount >= W - 3 + 1) { const int s = wq[SDX(qfront)]; qfront = (qfront + 1) & 63; --qcount; rw -= --cw[SDX(s)]; if (L > qcount) { --L; rv -= --cv[SDX(s)]; } }
                     wq[SDX((qfront + qcount) & 63)] = (int)t; ++qcount;
                     ++L; rw += cw[SDX(t)]++; rv += cv[SDX(t)]++;
-                    if (cv[SDX(t)] * 10 > T << 1) { int s; do { s = at(qcount - L); rv -= --cv[SDX(s)]; --L; } while (s != (int)t); }
+                    if (cv[SDX(t)] * 10 > T << 1) { int s; do { s = AT(qcount - L); rv -= --cv[SDX(s)]; --L; } while (s != (int)t); }
                 }
                 if (rw * 10 > L * T) { // find_perfect :108-135
                     for (int k = 0; k < 64; ++k) c[SDX(k)] = cv[SDX(k)];
                     int r = rv, max_r = 0, max_l = 0;
                     for (int x = qcount - L - 1; x >= 0; --x) {
-                        const int tt = at(x);
+                        const int tt = AT(x);
                         r += c[SDX(tt)]++;
                         const int new_r = r, new_l = qcount - x - 1;
                         if (new_r * 10 > T * new_l) {
                             int j = 0;
-                            for (; j < pn && P[j].start >= x + start; ++j) if (max_r == 0 || P[j].r * max_l > max_r * P[j].l) { max_r = P[j].r; max_l = P[j].l; }
+                            for (; j < pn; ++j) { const int4 q = Pget(j); if (q.x < x + start) break; if (max_r == 0 || q.z * max_l > max_r * q.w) { max_r = q.z; max_l = q.w; } }
                             if (max_r == 0 || new_r * max_l >= max_r * new_l) {
                                 max_r = new_r; max_l = new_l;
                                 if (pn >= pcap) { bad = 1; break; }
-                                for (int m = pn; m > j; --m) P[m] = P[m - 1];
+                                for (int m = pn; m > j; --m) Pset(m, Pget(m - 1));
                                 ++pn;
-                                P[j].start = x + start; P[j].finish = qcount + 2 + start; P[j].r = new_r; P[j].l = new_l;
+                                Pset(j, make_int4(x + start, qcount + 2 + start, new_r, new_l));
                             }
                         }
                     }
@@ -81,15 +89,21 @@ __global__ void __launch_bounds__(64) lcd_sdust_kernel(const unsigned char *seq,
             }
         } else { // N or the end of the sequence: independent pieces (:152-156)
             int start = (l - W + 1 > 0 ? l - W + 1 : 0) + (i + 1 - l);
-            while (pn) save(start++);
+            while (pn) { SD_SAVE(start); ++start; }
             l = 0; t = 0;
             // (the reference keeps the window and its counters across an N: the next piece's first words see them; kept here as well)
         }
     }
 #undef SDX
+#undef AT
+#undef Pget
+#undef Pset
+#undef SD_SAVE
     n_out[sid] = bad ? -1 : nout;
 }
 
 void lcd_launch_sdust(const unsigned char *seq, int len, int T, int W, int seg, int n_seg, int cap, const int *seg_from, int *n_out, int2 *out, int4 *pbuf, int pcap, hipStream_t stream) {
-    if (n_seg > 0) hipLaunchKernelGGL(lcd_sdust_kernel, dim3((n_seg + 63) / 64), dim3(64), 4 * 64 * 64 * sizeof(int), stream, seq, len, T, W, seg, n_seg, cap, seg_from, n_out, out, pbuf, pcap);
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void *)lcd_sdust_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+    if (n_seg > 0) hipLaunchKernelGGL(lcd_sdust_kernel, dim3((n_seg + 63) / 64), dim3(64), 4 * 64 * 64 * sizeof(int) + 64 * SD_PL * sizeof(int4), stream, seq, len, T, W, seg, n_seg, cap, seg_from, n_out, out, pbuf, pcap);
 }
