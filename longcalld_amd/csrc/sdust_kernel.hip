@@ -11,7 +11,7 @@
 #include "lcd_kernels.h"
 
 namespace {
-constexpr int SD_PL = 48;
+constexpr int SD_LANES = 16; // lanes (segments) per workgroup: the kernel is latency-bound, and 16 lanes leave each of them 8 KB of LDS for its interval list
 struct SdPerf { int start, finish, r, l; };
 __device__ __forceinline__ int sd_code(unsigned char c) { // seq_nt4_table, src/sdust.c:22-39: raw codes 0..3 and the letters ACGT / acgt
     if (c < 4) return c;
@@ -19,23 +19,23 @@ __device__ __forceinline__ int sd_code(unsigned char c) { // seq_nt4_table, src/
 }
 }
 
-__global__ void __launch_bounds__(64) lcd_sdust_kernel(const unsigned char *seq, int len, int T, int W, int seg, int n_seg, int cap, const int *seg_from, int *n_out, int2 *out, int4 *pbuf, int pcap) {
-    const int sid = blockIdx.x * 64 + threadIdx.x;
+__global__ void __launch_bounds__(SD_LANES) lcd_sdust_kernel(const unsigned char *seq, int len, int T, int W, int seg, int n_seg, int cap, const int *seg_from, int *n_out, int2 *out, int4 *pbuf, int pcap, int SD_PL) {
+    const int sid = blockIdx.x * SD_LANES + threadIdx.x;
     if (sid >= n_seg) return;
     const int a = sid * seg, b = min(len, a + seg);
     // seg_from[sid]: where the automaton has to start so that its state is exact W bases before the segment (the host counts 2W + 4 triplet words
     // back from there: the window is made of words, and words on both sides of a run of N share it); i == len is the end-of-sequence flush
     const int from = seg_from[sid], to = min(len, b + 2 * W + 8);
-    // per-lane tables in LDS, lane-interleaved (entry k of lane t at [k * 64 + t]): window ring, the two triplet counters, find_perfect's copy
+    // per-lane tables in LDS, lane-interleaved (entry k of lane t at [k * SD_LANES + t]): window ring, the two triplet counters, find_perfect's copy
     extern __shared__ int sd_lds[];
-    int *const wq = sd_lds + threadIdx.x, *const cv = wq + 64 * 64, *const cw = cv + 64 * 64, *const c = cw + 64 * 64;
-#define SDX(k) ((k) * 64)
+    int *const wq = sd_lds + threadIdx.x, *const cv = wq + 64 * SD_LANES, *const cw = cv + 64 * SD_LANES, *const c = cw + 64 * SD_LANES;
+#define SDX(k) ((k) * SD_LANES)
     // the perfect intervals of the current window (descending start): at most one per (start inside the window, step it was found at) = W x W
-    // entries; the first SD_PL of them in LDS (lane-interleaved), the rest -- rare -- in an HBM slab
-    int4 *const Pl = (int4 *)(sd_lds + 4 * 64 * 64) + threadIdx.x; int4 *const Pg = pbuf + (size_t)sid * pcap;
+    // entries; the first SD_PL of them (all of them for W <= 22) in LDS, lane-interleaved, the rest in an HBM slab
+    int4 *const Pl = (int4 *)(sd_lds + 4 * 64 * SD_LANES) + threadIdx.x; int4 *const Pg = pbuf + (size_t)sid * pcap;
     // (macros, not lambdas: by-reference captures would put the whole automaton state into scratch memory -- measured 30x slower)
-#define Pget(j) ((j) < SD_PL ? Pl[(j) * 64] : Pg[(j)])   /* (x, y, z, w) = (start, finish, r, l) */
-#define Pset(j, v) do { const int4 v_ = (v); if ((j) < SD_PL) Pl[(j) * 64] = v_; else Pg[(j)] = v_; } while (0)
+#define Pget(j) ((j) < SD_PL ? Pl[(j) * SD_LANES] : Pg[(j)])   /* (x, y, z, w) = (start, finish, r, l) */
+#define Pset(j, v) do { const int4 v_ = (v); if ((j) < SD_PL) Pl[(j) * SD_LANES] = v_; else Pg[(j)] = v_; } while (0)
     int qfront = 0, qcount = 0, pn = 0, rv = 0, rw = 0, L = 0, l = 0, nout = 0, bad = 0;
     unsigned t = 0;
     for (int k = 0; k < 64; ++k) { cv[SDX(k)] = 0; cw[SDX(k)] = 0; }
@@ -104,6 +104,8 @@ __global__ void __launch_bounds__(64) lcd_sdust_kernel(const unsigned char *seq,
 
 void lcd_launch_sdust(const unsigned char *seq, int len, int T, int W, int seg, int n_seg, int cap, const int *seg_from, int *n_out, int2 *out, int4 *pbuf, int pcap, hipStream_t stream) {
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void *)lcd_sdust_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
-    if (n_seg > 0) hipLaunchKernelGGL(lcd_sdust_kernel, dim3((n_seg + 63) / 64), dim3(64), 4 * 64 * 64 * sizeof(int) + 64 * SD_PL * sizeof(int4), stream, seq, len, T, W, seg, n_seg, cap, seg_from, n_out, out, pbuf, pcap);
+    if (!attr) { (void)hipFuncSetAttribute((const void *)lcd_sdust_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+    const int pl = pcap < 512 ? pcap : 512;
+    const size_t lds = (size_t)SD_LANES * (4 * 64 * sizeof(int) + (size_t)pl * sizeof(int4));
+    if (n_seg > 0) hipLaunchKernelGGL(lcd_sdust_kernel, dim3((n_seg + SD_LANES - 1) / SD_LANES), dim3(SD_LANES), lds, stream, seq, len, T, W, seg, n_seg, cap, seg_from, n_out, out, pbuf, pcap, pl);
 }
