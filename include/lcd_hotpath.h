@@ -214,6 +214,13 @@ int lcd_pre_process_noisy_regs(const lcd_noisy_iv_t *chunk_noisy, int n_noisy, c
                                const int64_t *read_end, const uint64_t *read_iv_off, const lcd_noisy_iv_t *read_ivs, int min_alt_dp, float min_af,
                                lcd_noisy_iv_t **regs_out);
 
+/* post_process_noisy_regs (src/collect_var.c:640-660, collect_noisy_reg_start_end :481-536): every region is grown by noisy_reg_flank_len and
+ * further while a candidate variant (categories outside LONGCALLD_NOT_CAND_VAR_CATE, src/collect_var.h:28) sits within the flank, then overlapping /
+ * touching regions are merged (cr_merge(cr, 0, -1, -1)).  Host code, as in the reference (a two-pointer walk over tens of regions); it closes the
+ * region pipeline lcd_digar_batch -> lcd_pre_process_noisy_regs -> here.  regs in index order; vars in chunk order.  *regs_out malloc()'d. */
+int lcd_post_process_noisy_regs(const lcd_noisy_iv_t *regs, int n_regs, int n_vars, const int64_t *var_pos, const int *var_ref_len, const int *var_cate,
+                                int noisy_reg_flank_len, lcd_noisy_iv_t **regs_out);
+
 /* ---- low-complexity intervals of a chunk's reference: sdust (src/sdust.c), as chunk->low_comp_cr is filled (src/bam_utils.c:1573-1581) ----
  * seq: raw codes 0..3 (4+ = N) or letters; T, W: LONGCALLD_SDUST_T 5 / LONGCALLD_SDUST_W 20 (src/call_var_main.h:82-83), W <= 64.
  * *intervals_out: malloc()'d (start, finish) pairs exactly as sdust() returns them (0-based, half-open); returns their number or < 0. */

@@ -76,7 +76,7 @@ _lib = None
 EXPORTS = [
     "lcd_opt_default", "lcd_init", "lcd_last_error", "lcd_version", "lcd_wfa_end2end_aln", "lcd_edlib_end2end_aln",
     "lcd_edlib_xgaps", "lcd_edlib_edit_distance", "lcd_collect_noisy_reg_aln_strs", "lcd_batch_create", "lcd_batch_destroy",
-    "lcd_batch_clear", "lcd_batch_region_vars", "lcd_digar_opt_default", "lcd_digar_batch", "lcd_pre_process_noisy_regs", "lcd_sdust", "lcd_batch_add_region", "lcd_batch_add_region_from_chunk", "lcd_batch_upload", "lcd_batch_run", "lcd_batch_run_many",
+    "lcd_batch_clear", "lcd_batch_region_vars", "lcd_digar_opt_default", "lcd_digar_batch", "lcd_pre_process_noisy_regs", "lcd_post_process_noisy_regs", "lcd_sdust", "lcd_batch_add_region", "lcd_batch_add_region_from_chunk", "lcd_batch_upload", "lcd_batch_run", "lcd_batch_run_many",
     "lcd_batch_download", "lcd_batch_region_result", "lcd_batch_region_sorted_ids", "lcd_batch_get_stats", "lcd_batch_digest",
     "lcd_edlib_batch", "lcd_wfa_batch", "lcd_poa_batch", "lcd_assign_hap_germline", "lcd_assign_hap_batch",
 ]
@@ -118,6 +118,7 @@ def load_library():
                                     C.POINTER(u64p_), C.POINTER(C.POINTER(LcdDigar)), C.POINTER(u64p_), C.POINTER(C.POINTER(LcdNoisyIv)), C.POINTER(u8p), i32p, i64p, i64p, i32p]
     lib.lcd_pre_process_noisy_regs.argtypes = [C.POINTER(LcdNoisyIv), C.c_int, i64p, C.c_int, C.c_int, i64p, i64p, u64p_, C.POINTER(LcdNoisyIv), C.c_int, C.c_float,
                                                C.POINTER(C.POINTER(LcdNoisyIv))]
+    lib.lcd_post_process_noisy_regs.argtypes = [C.POINTER(LcdNoisyIv), C.c_int, C.c_int, i64p, i32p, i32p, C.c_int, C.POINTER(C.POINTER(LcdNoisyIv))]
     lib.lcd_sdust.argtypes = [u8p, C.c_int64, C.c_int, C.c_int, C.POINTER(i64p)]
     lib.lcd_batch_region_sorted_ids.argtypes = [C.c_void_p, C.c_int, i32p]
     lib.lcd_batch_get_stats.argtypes = [C.c_void_p, C.POINTER(LcdBatchStats)]

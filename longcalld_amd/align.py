@@ -372,6 +372,26 @@ def pre_process_noisy_regs(chunk_noisy, low_comp, read_beg, read_end, read_ivs, 
     return res
 
 
+def post_process_noisy_regs(regs, var_pos, var_ref_len, var_cate, flank=10):
+    """post_process_noisy_regs (src/collect_var.c:640): regs (n,3) -> flank-extended, merged regions (m,3)"""
+    lib = load_library()
+    r = np.asarray(regs, np.int64).reshape(-1, 3)
+    arr = (LcdNoisyIv * max(len(r), 1))()
+    for i, row in enumerate(r):
+        arr[i].start, arr[i].end, arr[i].label = int(row[0]), int(row[1]), int(row[2])
+    vp = np.ascontiguousarray(var_pos, np.int64); vl = np.ascontiguousarray(var_ref_len, np.int32); vc = np.ascontiguousarray(var_cate, np.int32)
+    if len(vp) == 0:
+        vp = np.zeros(1, np.int64); vl = np.zeros(1, np.int32); vc = np.zeros(1, np.int32); nv = 0
+    else:
+        nv = len(vp)
+    out = C.POINTER(LcdNoisyIv)()
+    n = check(lib.lcd_post_process_noisy_regs(arr, len(r), nv, vp.ctypes.data_as(C.POINTER(C.c_int64)), vl.ctypes.data_as(i32p), vc.ctypes.data_as(i32p), int(flank), C.byref(out)), lib)
+    res = np.array([[out[i].start, out[i].end, out[i].label] for i in range(n)], np.int64).reshape(-1, 3)
+    if out:
+        _libc.free(C.cast(out, C.c_void_p))
+    return res
+
+
 def sdust(seq, T=5, W=20):
     """low-complexity intervals (src/sdust.c) of a code / letter sequence on the GPU -> (n, 2) array of (start, finish)"""
     lib = load_library()

@@ -1669,6 +1669,68 @@ int lcd_pre_process_noisy_regs(const lcd_noisy_iv_t *chunk_noisy, int n_noisy, c
     return n_out;
 }
 
+// post_process_noisy_regs (src/collect_var.c:640-660) -- host glue, see include/lcd_hotpath.h
+int lcd_post_process_noisy_regs(const lcd_noisy_iv_t *regs, int n_regs, int n_vars, const int64_t *var_pos, const int *var_ref_len, const int *var_cate,
+                                int flank, lcd_noisy_iv_t **regs_out) {
+    *regs_out = nullptr;
+    if (n_regs <= 0) return 0;
+    const int NOT_CAND = 0x800 | 0x001 | 0x002; // LONGCALLD_NOT_CAND_VAR_CATE
+    std::vector<NIv> v;
+    for (int i = 0; i < n_regs; ++i) niv_add(v, regs[i].start, regs[i].end, regs[i].label);
+    niv_index(v);
+    const int n = (int)v.size();
+    std::vector<int> maxl(n, -1), minr(n, -1);
+    auto cand = [&](int vi) { return !(var_cate[vi] & NOT_CAND); };
+    for (int ri = 0, vi = 0; ri < n && vi < n_vars;) { // (:488-503) last candidate left of each region, first one right of it
+        if (!cand(vi)) { ++vi; continue; }
+        const long long vs = var_pos[vi], ve = var_pos[vi] + var_ref_len[vi] - 1, rs = (long long)v[ri].x + 1, re = v[ri].en;
+        if (vs > re) { if (minr[ri] == -1) minr[ri] = vi; ++ri; }
+        else if (ve < rs) { maxl[ri] = vi; ++vi; }
+        else ++vi;
+    }
+    std::vector<NIv> w;
+    for (int ri = 0; ri < n; ++ri) { // (:505-533)
+        if (maxl[ri] == -1) maxl[ri] = std::min(n_vars - 1, 0);
+        if (minr[ri] == -1) minr[ri] = std::max(0, n_vars - 1);
+        long long cs = (long long)v[ri].x + 1 - flank, ce = v[ri].en + flank;
+        for (int vi = maxl[ri]; vi >= 0; --vi) {
+            if (!cand(vi)) continue;
+            const long long vs = var_pos[vi], ve = var_pos[vi] + var_ref_len[vi] - 1;
+            if (ve < cs - 1) break;
+            if (vs - flank < cs) cs = vs - flank;
+        }
+        for (int vi = minr[ri]; vi < n_vars; ++vi) {
+            if (!cand(vi)) continue;
+            const long long vs = var_pos[vi], ve = var_pos[vi] + var_ref_len[vi] - 1;
+            if (vs > ce + 1) break;
+            if (ve + flank > ce) ce = ve + flank;
+        }
+        niv_add(w, cs, ce, v[ri].label); // (the reference stores the 1-based start as the interval start here, :648)
+    }
+    niv_index(w);
+    // cr_merge(cr, 0, -1, -1): fixed window 0 -- join while the running end reaches the next start (src/cgranges.c:225-300)
+    size_t cur = w.size();
+    for (;;) {
+        std::vector<NIv> out; std::vector<char> merged(w.size(), 0);
+        for (size_t j = 0; j < w.size(); ++j) {
+            if (merged[j]) continue;
+            uint64_t ms = w[j].x; long long me = w[j].en; int ml = w[j].label;
+            for (size_t k = j + 1; k < w.size(); ++k) {
+                if (merged[k]) continue;
+                if ((uint64_t)me >= w[k].x) { ml = std::max(ml, w[k].label); ms = std::min(ms, w[k].x); me = std::max(me, w[k].en); merged[k] = 1; }
+            }
+            niv_add(out, (long long)ms, me, ml);
+        }
+        niv_index(out); w.swap(out);
+        if (w.size() == cur) break;
+        cur = w.size();
+    }
+    lcd_noisy_iv_t *o = (lcd_noisy_iv_t *)malloc((w.size() + 1) * sizeof(lcd_noisy_iv_t));
+    for (size_t i = 0; i < w.size(); ++i) { o[i].start = (long long)w[i].x; o[i].end = w[i].en; o[i].label = w[i].label; o[i].pad = 0; }
+    *regs_out = o;
+    return (int)w.size();
+}
+
 // SURVEY 8(f) f2, first part: collect_digar_from_eqx_cigar (src/bam_utils.c:701-842) for all reads of a chunk
 void lcd_digar_opt_default(lcd_digar_opt_t *o, int is_ont) {
     o->min_bq = 10; o->noisy_reg_max_xgaps = 5; o->noisy_reg_slide_win = is_ont ? 25 : 100; o->end_clip_reg = 30; o->end_clip_reg_flank_win = 100;

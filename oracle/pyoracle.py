@@ -156,6 +156,19 @@ def ref_pre_process_noisy_regs(chunk_noisy, low_comp, read_beg, read_end, read_i
     return out[:3 * n].reshape(-1, 3).astype(np.int64)
 
 
+def ref_post_process_noisy_regs(regs, var_pos, var_ref_len, var_cate, flank=10):
+    L = ref_cgranges()
+    L.ref_post_process_noisy_regs.argtypes = [C.c_int, i32p, C.c_int, i32p, i32p, i32p, C.c_int, i32p, C.c_int]
+    r = np.ascontiguousarray(np.asarray(regs, np.int64).reshape(-1, 3), np.int32)
+    vp = np.ascontiguousarray(var_pos, np.int32); vl = np.ascontiguousarray(var_ref_len, np.int32); vc = np.ascontiguousarray(var_cate, np.int32)
+    nv = len(vp)
+    if nv == 0:
+        vp = np.zeros(1, np.int32); vl = np.zeros(1, np.int32); vc = np.zeros(1, np.int32)
+    out = np.zeros(3 * (len(r) + 1), np.int32)
+    n = L.ref_post_process_noisy_regs(len(r), r.ctypes.data_as(i32p), nv, vp.ctypes.data_as(i32p), vl.ctypes.data_as(i32p), vc.ctypes.data_as(i32p), int(flank), out.ctypes.data_as(i32p), len(r) + 1)
+    return out[:3 * n].reshape(-1, 3).astype(np.int64)
+
+
 def ref_sdust(seq, T=5, W=20):
     """the reference's own sdust() (src/sdust.c) -> (n, 2) array of (start, finish)"""
     L = ref_cgranges()

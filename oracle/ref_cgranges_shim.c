@@ -101,3 +101,50 @@ int ref_sdust(const unsigned char *seq, int len, int T, int W, int *out, int cap
     free(r);
     return n;
 }
+
+/* post_process_noisy_regs (src/collect_var.c:640-660) with collect_noisy_reg_start_end (:481-536): regions grown to flanks free of candidate
+ * variants, then merged (cr_merge(cr, 0, -1, -1)).  Control flow restated, interval operations by the reference's cgranges.
+ * in: regions (st, en, label) in index order; candidate variants (pos, ref_len, cate) in chunk order.  out: (st, en, label); returns the number. */
+int ref_post_process_noisy_regs(int n_regs, const int *regs, int n_vars, const int *var_pos, const int *var_ref_len, const int *var_cate, int flank_len,
+                                int *out, int out_cap) {
+    const int NOT_CAND = 0x800 | 0x001 | 0x002;
+    cgranges_t *cr = cr_init();
+    for (int i = 0; i < n_regs; ++i) cr_add(cr, "cr", regs[3 * i], regs[3 * i + 1], regs[3 * i + 2]);
+    cr_index(cr);
+    const int n = (int)cr->n_r;
+    int *maxl = (int *)malloc(sizeof(int) * (n + 1)), *minr = (int *)malloc(sizeof(int) * (n + 1)), *st = (int *)malloc(sizeof(int) * (n + 1)), *en = (int *)malloc(sizeof(int) * (n + 1));
+    for (int i = 0; i < n; ++i) maxl[i] = minr[i] = -1;
+    for (int ri = 0, vi = 0; ri < n && vi < n_vars;) {
+        if (var_cate[vi] & NOT_CAND) { vi++; continue; }
+        const int vs = var_pos[vi], ve = var_pos[vi] + var_ref_len[vi] - 1;
+        const int rs = cr_start(cr, ri) + 1, re = cr_end(cr, ri);
+        if (vs > re) { if (minr[ri] == -1) minr[ri] = vi; ri++; }
+        else if (ve < rs) { maxl[ri] = vi; vi++; }
+        else vi++;
+    }
+    for (int ri = 0; ri < n; ++ri) {
+        if (maxl[ri] == -1) maxl[ri] = n_vars - 1 < 0 ? n_vars - 1 : 0;
+        if (minr[ri] == -1) minr[ri] = 0 > n_vars - 1 ? 0 : n_vars - 1;
+        const int os = cr_start(cr, ri) + 1, oe = cr_end(cr, ri);
+        int cs = os - flank_len, ce = oe + flank_len;
+        for (int vi = maxl[ri]; vi >= 0; --vi) {
+            if (var_cate[vi] & NOT_CAND) continue;
+            const int vs = var_pos[vi], ve = var_pos[vi] + var_ref_len[vi] - 1;
+            if (ve < cs - 1) break; else if (vs - flank_len < cs) cs = vs - flank_len;
+        }
+        for (int vi = minr[ri]; vi < n_vars; ++vi) {
+            if (var_cate[vi] & NOT_CAND) continue;
+            const int vs = var_pos[vi], ve = var_pos[vi] + var_ref_len[vi] - 1;
+            if (vs > ce + 1) break; else if (ve + flank_len > ce) ce = ve + flank_len;
+        }
+        st[ri] = cs; en[ri] = ce;
+    }
+    cgranges_t *nw = cr_init();
+    for (int ri = 0; ri < n; ++ri) cr_add(nw, "cr", st[ri], en[ri], cr_label(cr, ri));
+    cr_index(nw); cr_destroy(cr);
+    nw = cr_merge(nw, 0, -1, -1);
+    int m = 0;
+    for (int64_t i = 0; i < nw->n_r; ++i, ++m) if (m < out_cap) { out[3 * m] = cr_start(nw, i); out[3 * m + 1] = cr_end(nw, i); out[3 * m + 2] = cr_label(nw, i); }
+    cr_destroy(nw); free(maxl); free(minr); free(st); free(en);
+    return m;
+}

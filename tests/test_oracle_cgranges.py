@@ -36,3 +36,20 @@ def test_overlap_reports_in_sorted_index_order(ref):
             hits = ref.ref_cr_overlap(st, en, q0, q1)
             exp = [i for i in order if st[i] < q1 and q0 < en[i]]
             assert hits.tolist() == exp
+
+
+def test_post_process_noisy_regs_host_glue(ref):
+    """post_process_noisy_regs (src/collect_var.c:640): the library's host glue (no device work in it, as in the reference) vs the same control
+    flow over the reference's own cgranges -- flank growth along candidate variants, non-candidate categories skipped, touching regions merged"""
+    from longcalld_amd import align as lcd
+    rng = np.random.default_rng(31)
+    for trial in range(40):
+        n = int(rng.integers(1, 40))
+        st = np.sort(rng.integers(1000, 100000, n)); regs = np.stack([st, st + rng.integers(5, 400, n), rng.integers(6, 300, n)], 1)
+        nv = int(rng.integers(0, 200))
+        vp = np.sort(rng.integers(900, 101000, nv)); vl = rng.choice([0, 1, 1, 1, 12, 40], nv); vc = rng.choice([0x004, 0x008, 0x080, 0x800, 0x001, 0x002, 0x100], nv)
+        for flank in (10, 0, 50):
+            exp = ref.ref_post_process_noisy_regs(regs, vp, vl, vc, flank)
+            got = lcd.post_process_noisy_regs(regs, vp, vl, vc, flank)
+            assert exp.shape == got.shape and (exp == got).all(), (trial, flank)
+    assert len(lcd.post_process_noisy_regs(np.zeros((0, 3), np.int64), [], [], [])) == 0
