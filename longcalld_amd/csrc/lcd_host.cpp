@@ -625,10 +625,11 @@ static void chain_class(PoaChain &pc, bool noisy) {
     long long need = std::max(dp_bytes, est_nodes * 8 + (est_nodes + est_nodes / 8) * 4 + 64);
     { // the single-wavefront class is kept to a small pool: 16 such chains per CU (8 KB each, the wavefront limit at 128 VGPRs) instead of 2-9
       // is worth more than a fast re-sort -- bigger graphs do their Kahn walk on the same packed words in HBM (16 KB: +17 % regions/s over
-      // uncapped pools; 8 KB with the ring laid out for the preferred window: another +7 %).  Noisy reads (the learned hints say so) have
-      // graphs twice the size and re-sort after nearly every read: 16 KB there (8 KB costs them 11 %); noisy = opt.is_ont (the reference's --ont) or learned.  LCD_LDS_CAP_KB overrides.
+      // uncapped pools; 8 KB with the ring laid out for the preferred window: another +7 %).  Noisy reads (graphs twice the size, a re-sort after
+      // nearly every read) preferred 16 KB while the Kahn walk was a serial pass over every node; since it jumps chains (v12) 8 KB is best for them
+      // too (+6 % over 16 KB).  LCD_LDS_CAP_KB overrides.
         static const int cap_env = getenv("LCD_LDS_CAP_KB") ? atoi(getenv("LCD_LDS_CAP_KB")) : -1;
-        const int cap_kb = cap_env >= 0 ? cap_env : ((noisy || g_node_hint.load() > 0 || g_cell_hint[0].load() > 0) ? 16 : 8);
+        const int cap_kb = cap_env >= 0 ? cap_env : 8; (void)noisy;
         if (cap_kb > 0 && threads == 64) need = std::max(dp_bytes, std::min<long long>(need, (long long)cap_kb << 10));
     }
     // LDS per workgroup decides how many single-wavefront chains share a CU (160 KB, 16 wavefronts at 128 VGPRs), and those chains are
