@@ -407,9 +407,20 @@ __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned shor
         J1[v] = (unsigned short)l;
     }
     __syncthreads();
-    for (int v = tid; v < n; v += NT) { int x = J1[v]; x = J1[x]; x = J1[x]; x = J1[x]; J4[v] = (unsigned short)x; }
+    // RL[v] = length of the chain that starts at v, capped at 16: a jump costs up to 9 dependent loads, so chains shorter than 4 are walked
+    // node by node (graphs of noisy reads are bubbles every few nodes: probing every node for a chain cost more than it saved)
+    unsigned char *RL = (unsigned char *)(J16 + n), *R4 = RL + n; // (second half of pl_rem: 2n bytes)
+    for (int v = tid; v < n; v += NT) {
+        int x = v, r = 0;
+        for (int k = 0; k < 4; ++k) { const int y = J1[x]; r += y != x; x = y; }
+        J4[v] = (unsigned short)x; R4[v] = (unsigned char)r;
+    }
     __syncthreads();
-    for (int v = tid; v < n; v += NT) { int x = J4[v]; x = J4[x]; x = J4[x]; x = J4[x]; J16[v] = (unsigned short)x; }
+    for (int v = tid; v < n; v += NT) {
+        int x = v, r = 0;
+        for (int k = 0; k < 4; ++k) { r += R4[x]; x = J4[x]; }
+        J16[v] = (unsigned short)x; RL[v] = (unsigned char)r;
+    }
     __syncthreads();
     const long long tk0 = clock64();
     if (tid < 64) { // wavefront 0, every lane with the same scalars (loads broadcast, identical stores coincide); lanes differ only in the chain step
@@ -422,6 +433,7 @@ __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned shor
             if (!have) cur = queue[qh];
             ++qh; have = false;
             while (qh == qt) { // nothing else queued: follow the chain that starts at cur, 64 nodes per step
+                if (RL[cur] < 4) break;
                 int x = cur;
                 const int c16 = lane >> 4, c4 = (lane >> 2) & 3, c1 = lane & 3;
                 for (int i = 0; i < 3; ++i) if (i < c16) x = J16[x];
