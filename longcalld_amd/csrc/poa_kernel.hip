@@ -752,13 +752,17 @@ __device__ __forceinline__ void code_backtrack(const Ctx &g, Smem &sm, const uns
         int status = g.status;
         if (br >= 0 && best > LCD_NEG / 2 && status == LCD_OK) {
             int i = br, j = qlen, st = 0;
+            // speculation width: 64 steps of the first-predecessor chain per attempt while the runs of matches are long (clean reads: hundreds
+            // of columns); halved down to 8 when they turn out short (noisy reads: a difference every ~20 columns) -- the chain is followed
+            // lane-serially through LDS before the codes can be fetched, so a 64-step look-ahead for a 3-step run was most of the backtrack there
+            int sw = 64;
             while (i != bi && j > 0 && status == LCD_OK) {
                 if (st == 0 && pd != 0xffffffffu) {
                     // speculate a run of matches along first predecessors: lane t looks at the cell t steps up the diagonal
                     int my_i = -1, my_nx = -1;
                     {
                         int cur = i; bool alive = true;
-                        for (int t = 0; t < 64; ++t) {
+                        for (int t = 0; t < sw; ++t) {
                             const bool ok = alive && cur != bi && j - t > 0;
                             const int d = ok ? lds_ld_u8(pd + (cur - bi)) : 255;
                             if (lane == t) { my_i = ok ? cur : -1; my_nx = d != 255 ? cur - d : -1; }
@@ -775,6 +779,7 @@ __device__ __forceinline__ void code_backtrack(const Ctx &g, Smem &sm, const uns
                     }
                     const unsigned long long bad = __ballot(!good);
                     const int m = bad ? __ffsll((long long)bad) - 1 : 64;
+                    if (m >= sw) sw = sw < 64 ? sw * 2 : 64; else if (m * 4 < sw && sw > 8) sw >>= 1;
                     if (m > 0) {
                         if (lane < m) { g.cig_node0[pos - 1 - lane] = g.idx2node[my_i]; g.cig_qpos0[pos - 1 - lane] = jj - 1; }
                         i = LCD_RL(my_nx, __builtin_amdgcn_readfirstlane(m - 1));
