@@ -740,11 +740,11 @@ __device__ __forceinline__ void code_backtrack(const Ctx &g, Smem &sm, const uns
                                                const int lane, const int amask /* rows start at their band's first column rounded down to the lane's cell group: ~(C - 1) */) {
         int best = LCD_NEG, br = -1;
         {
-            const int p0 = g.pl_start[ei], np = g.pl_start[ei + 1] - p0;
+            const int p0 = glb_ld(g.pl_start + (ei)), np = glb_ld(g.pl_start + (ei + 1)) - p0;
             for (int t = 0; t < np; ++t) {
-                const int pi = g.pl_pidx[p0 + t];
-                if (qlen < g.rbeg[pi] || qlen > g.rend[pi]) continue;
-                const int c = g.spill[(size_t)g.spoff[pi] * SLOTW + (qlen & WM)] + g.pl_bonus[p0 + t];
+                const int pi = glb_ld(g.pl_pidx + (p0 + t));
+                if (qlen < glb_ld(g.rbeg + (pi)) || qlen > glb_ld(g.rend + (pi))) continue;
+                const int c = glb_ld(g.spill + ((size_t)(unsigned)glb_ld((const int *)g.spoff + (pi)) * SLOTW + (qlen & WM))) + glb_ld(g.pl_bonus + (p0 + t));
                 if (c > best) { best = c; br = pi; }
             }
         }
@@ -774,43 +774,43 @@ __device__ __forceinline__ void code_backtrack(const Ctx &g, Smem &sm, const uns
                     bool good = false;
                     const int jj = j - lane;
                     if (my_i >= 0 && my_nx >= 0) {
-                        const int rb = g.rbeg[my_i], re = g.rend[my_i];
-                        if (jj >= rb && jj <= re) good = (g.code8[(size_t)g.roff[my_i] + (jj - (rb & amask))] & (7 | CB_PM)) == 0;
+                        const int rb = glb_ld(g.rbeg + (my_i)), re = glb_ld(g.rend + (my_i));
+                        if (jj >= rb && jj <= re) good = (glb_ld_u8(g.code8 + ((size_t)(unsigned)glb_ld((const int *)g.roff + (my_i)) + (jj - (rb & amask)))) & (7 | CB_PM)) == 0;
                     }
                     const unsigned long long bad = __ballot(!good);
                     const int m = bad ? __ffsll((long long)bad) - 1 : 64;
                     if (m >= sw) sw = sw < 64 ? sw * 2 : 64; else if (m * 4 < sw && sw > 8) sw >>= 1;
                     if (m > 0) {
-                        if (lane < m) { g.cig_node0[pos - 1 - lane] = g.idx2node[my_i]; g.cig_qpos0[pos - 1 - lane] = jj - 1; }
+                        if (lane < m) { g.cig_node0[pos - 1 - lane] = glb_ld(g.idx2node + (my_i)); g.cig_qpos0[pos - 1 - lane] = jj - 1; }
                         i = LCD_RL(my_nx, __builtin_amdgcn_readfirstlane(m - 1));
                         pos -= m; j -= m;
                         continue;
                     }
                 }
                 // one step, replaying the oracle's decision from the code
-                const int rb = g.rbeg[i], rb4 = rb & amask;
-                const size_t ro = g.roff[i];
-                const int c = g.code8[ro + (j - rb4)];
-                const int p0 = g.pl_start[i], np = g.pl_start[i + 1] - p0;
-                const int ow = np > 1 ? g.ord[(size_t)g.ooff[i] + (j - rb4)] : 0;
+                const int rb = glb_ld(g.rbeg + (i)), rb4 = rb & amask;
+                const size_t ro = (unsigned)glb_ld((const int *)g.roff + (i));
+                const int c = glb_ld_u8(g.code8 + (ro + (j - rb4)));
+                const int p0 = glb_ld(g.pl_start + (i)), np = glb_ld(g.pl_start + (i + 1)) - p0;
+                const int ow = np > 1 ? glb_ld(g.ord + ((size_t)(unsigned)glb_ld((const int *)g.ooff + (i)) + (j - rb4))) : 0;
                 if (st == 0) {
                     const int hs = c & 7;
                     if (hs == 0) {
-                        if (lane == 0) { g.cig_node0[pos - 1] = g.idx2node[i]; g.cig_qpos0[pos - 1] = j - 1; }
-                        --pos; i = g.pl_pidx[p0 + (ow & 255)]; --j;
+                        if (lane == 0) { g.cig_node0[pos - 1] = glb_ld(g.idx2node + (i)); g.cig_qpos0[pos - 1] = j - 1; }
+                        --pos; i = glb_ld(g.pl_pidx + (p0 + (ow & 255))); --j;
                     } else if (hs <= 2) {
-                        i = g.pl_pidx[p0 + ((ow >> (8 * hs)) & 255)]; st = hs;
+                        i = glb_ld(g.pl_pidx + (p0 + ((ow >> (8 * hs)) & 255))); st = hs;
                     } else if (hs <= 5) { // insertion run: back to the closest opening column of a matching gap piece
                         int k = -1;
-                        if (hs != 4) { int p = j - 1; while (p > rb && (g.code8[ro + (p - rb4)] & CB_Y1)) --p; k = p; }
-                        if (hs != 3) { int p = j - 1; while (p > rb && (g.code8[ro + (p - rb4)] & CB_Y2)) --p; k = imax(k, p); }
+                        if (hs != 4) { int p = j - 1; while (p > rb && (glb_ld_u8(g.code8 + (ro + (p - rb4))) & CB_Y1)) --p; k = p; }
+                        if (hs != 3) { int p = j - 1; while (p > rb && (glb_ld_u8(g.code8 + (ro + (p - rb4))) & CB_Y2)) --p; k = imax(k, p); }
                         const int nins = j - k;
                         for (int u = lane; u < nins; u += 64) { g.cig_node0[pos - nins + u] = -1; g.cig_qpos0[pos - nins + u] = k + u; }
                         pos -= nins; j = k;
                     } else status = LCD_ERR_BACKTRACK;
                 } else {
                     if (c & (st == 1 ? CB_O1 : CB_O2)) st = 0;
-                    else i = g.pl_pidx[p0 + ((ow >> (8 * st)) & 255)];
+                    else i = glb_ld(g.pl_pidx + (p0 + ((ow >> (8 * st)) & 255)));
                 }
             }
             for (int u = lane; u < j; u += 64) { g.cig_node0[pos - j + u] = -1; g.cig_qpos0[pos - j + u] = u; }
