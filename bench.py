@@ -142,7 +142,9 @@ def main():
         if lane_errors:
             raise lane_errors[0]
 
-    run_steps(max(args.warmup, n_lanes * n_co if args.warmup else 0), False)   # every lane warms its buffers at least once
+    # every lane warms its buffers at least once; the noisy-read shape needs three submissions: the capacity hints (graph, DP region, WFA score
+    # bound) rise one level per submission that overflowed, and a timed run that still re-runs overflowed chains measures the learning, not the path
+    run_steps(max(args.warmup, (n_lanes * n_co * (3 if args.shape == "ont" else 1)) if args.warmup else 0), False)
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps, True)
