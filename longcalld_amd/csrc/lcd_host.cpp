@@ -294,6 +294,11 @@ int run_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, DevBuf &d_jobs, Dev
         which.swap(again);
     }
     if (!which.empty()) return set_err(-21, "WFA arena exhausted after retries");
+    if (learn && getenv("LCD_MEM_DEBUG")) { // anchor stage: how the optimal scores compare with the first score bound
+        double r_sum = 0; int cnt = 0, over = 0; double worst = 0;
+        for (int i = 0; i < n; ++i) { const int m = std::min(jobs[i].plen, jobs[i].tlen); if (m < 50) continue; const double r = (double)outs[i].score / m; r_sum += r; ++cnt; worst = std::max(worst, r); over += outs[i].score > wfa_default_scap(jobs[i].plen, jobs[i].tlen, true); }
+        fprintf(stderr, "[mem] anchor WFA: %d jobs >= 50 bp, score / min(len) mean %.3f max %.3f; %d above the current first bound\n", cnt, cnt ? r_sum / cnt : 0.0, worst, over);
+    }
     return 0;
 }
 
@@ -1169,6 +1174,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         }
         b->ran = true; b->downloaded = false;
     }
+    if (getenv("LCD_MEM_DEBUG")) fprintf(stderr, "[mem] device buffers of this process after the submission: %.2f GB (budget %.2f GB)\n", g_dev_bytes.load() / 1e9, g_dev_budget / 1e9);
     if (getenv("LCD_PLACEMENT")) { // experiment: which CU did every wide chain run on, and when
         for (size_t g = 0; g < nC_all; ++g) { if (chain_threads(PC(g)) < 512) continue; const PoaChainOut &o = bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]];
             fprintf(stderr, "[place] thr %d xcc %u se %u sh %u cu %u simd %u  t %.1f..%.1f ms ticks %.3e\n", chain_threads(PC(g)), o.xcc_id & 15, (o.hw_id >> 13) & 7, (o.hw_id >> 12) & 1, (o.hw_id >> 8) & 15, (o.hw_id >> 4) & 3,
