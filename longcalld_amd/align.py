@@ -312,6 +312,8 @@ def digar_batch(pos0, cigars, quals, reg_beg, reg_end, whole_ref_len, is_ont=0, 
     if opt is None:
         opt = LcdDigarOpt(); lib.lcd_digar_opt_default(C.byref(opt), int(is_ont))
     n = len(cigars)
+    if n == 0:
+        return []
     cg = [np.ascontiguousarray(c, np.uint32) for c in cigars]; ql = [np.ascontiguousarray(q, np.uint8) for q in quals]
     coff = np.concatenate([[0], np.cumsum([len(c) for c in cg])]).astype(np.uint64); qoff = np.concatenate([[0], np.cumsum([len(q) for q in ql])]).astype(np.uint64)
     cpool = np.concatenate(cg + [np.zeros(1, np.uint32)]); qpool = np.concatenate(ql + [np.zeros(1, np.uint8)])

@@ -169,3 +169,26 @@ def test_sdust_matches_reference(lcd, oracle):
     letters = np.frombuffer(b"ACGTN", np.uint8)[np.minimum(ref[:50000], 4)]      # faidx gives letters (src/bam_utils.c:1564): same intervals
     assert (lcd.sdust(letters, 5, 20) == oracle.ref_sdust(ref[:50000], 5, 20)).all()
     assert n_iv > 1000
+
+
+def test_f2_edge_inputs(lcd, oracle):
+    """empty and degenerate inputs of the f2 entry points: no reads, a read that is one clip + one match, all-N / very short sequences, no
+    windows at all, regions nobody supports"""
+    assert lcd.digar_batch([], [], [], 0, 100, 1000) == []
+    cig = [np.array([(40 << 4) | 4, (25 << 4) | 7], np.uint32), np.array([(5 << 4) | 7], np.uint32), np.array([(3 << 4) | 5, (9 << 4) | 7, (2 << 4) | 5], np.uint32)]
+    ql = [np.full(65, 30, np.uint8), np.full(5, 30, np.uint8), np.full(9, 30, np.uint8)]
+    got = lcd.digar_batch([100, 0, 7], cig, ql, 0, 1000, 5000)
+    for i in range(3):
+        exp = oracle.collect_digar_from_eqx_cigar([100, 0, 7][i], cig[i], ql[i], 0, 1000, 5000)
+        _same(exp, got[i])
+    assert len(got[0]["noisy"]) == 1 and got[1]["digars"].shape == (1, 5)      # the 40-base soft clip marks its flank; a 5-base read is one digar
+    for s in (np.zeros(0, np.uint8), np.array([1], np.uint8), np.array([0, 0], np.uint8), np.full(300, 4, np.uint8), np.zeros(1000, np.uint8)):
+        got_s = lcd.sdust(s, 5, 20)
+        if oracle.ref_cgranges() is not None and len(s):
+            assert (got_s == oracle.ref_sdust(s, 5, 20)).all()
+    assert len(lcd.sdust(np.zeros(1000, np.uint8), 5, 20)) == 1                  # a homopolymer is one interval
+    assert len(lcd.pre_process_noisy_regs(np.zeros((0, 3), np.int64), np.zeros((0, 2), np.int64), [], [], [])) == 0
+    one = np.array([[500, 560, 20]], np.int64)
+    assert len(lcd.pre_process_noisy_regs(one, np.zeros((0, 2), np.int64), [], [], [])) == 0                       # no read spans it
+    assert len(lcd.pre_process_noisy_regs(one, np.zeros((0, 2), np.int64), [1, 1], [2000, 2000], [one, one])) == 1   # two noisy reads: kept
+    assert len(lcd.pre_process_noisy_regs(one, np.zeros((0, 2), np.int64), [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1], [2000] * 11, [one] + [np.zeros((0, 3), np.int64)] * 10)) == 0  # 1 of 11: below min_alt_dp
