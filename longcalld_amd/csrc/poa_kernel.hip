@@ -933,8 +933,15 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
         }
         bool synced = false;
         int beg = 0, end = qlen;
+        const bool fast1 = BANDED && np == 1 && idx - pi0 <= K;
+        const int f_sp = (pi0 - bi) & (K - 1);
+        int f_pb = 1, f_pe = 0;
+        if (fast1) { f_pb = LCD_RL(m_beg, f_sp); f_pe = LCD_RL(m_end, f_sp); }
         if (BANDED) { // band: pulled from the predecessors' row-max columns (same values the oracle pushes to successors)
             int mplv = 1 << 30, mprv = 0, minpb = 1 << 30, maxpe = -1;
+            if (fast1) { // the usual row: one usable predecessor whose values are still in the ring (its slot metadata read once, here)
+                if (f_pb <= f_pe) { minpb = f_pb; maxpe = f_pe; mplv = LCD_RL(m_ml, f_sp) + 1; mprv = LCD_RL(m_mr, f_sp) + 1; }
+            } else
             for (int t = 0; t < np; ++t) {
                 int pi = t == 0 ? pi0 : pi1;
                 if (t > 1) { pi = glb_ld(g.pl_pidx + p0 + t); LCD_PIN(pi); }
@@ -980,6 +987,16 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
         for (int k = 0; k < C; ++k) { nn[k] = LCD_NEG; uu[k] = LCD_NEG; vv[k] = LCD_NEG; }
         int om = 0, oa = 0, ob = 0; // ordinals, one byte per cell
         bool overflow = false;
+        if (fast1) {
+            if (f_pb <= f_pe) {
+                if (f_pe - beg + 2 >= WIN || end - f_pb + 1 >= WIN) return -1;
+                const unsigned S = ring + 4 * f_sp * SLOTW;
+                int hv[C], av[C], bv[C];
+                const int hm = lds_ld(S + 4 * xm); lds_ldc<C>(S + 4 * x, hv); lds_ldc<C>(S + 4 * (WIN + x), av); lds_ldc<C>(S + 4 * (2 * WIN + x), bv);
+#pragma unroll
+                for (int k = 0; k < C; ++k) { nn[k] = imax(LCD_NEG, (k == 0 ? hm : hv[k - 1]) + sk[k] + bz0); uu[k] = imax(LCD_NEG, av[k] + bz0); vv[k] = imax(LCD_NEG, bv[k] + bz0); }
+            }
+        } else
         for (int t = 0; t < np; ++t) {
             int pi = t == 0 ? pi0 : pi1, bz = t == 0 ? bz0 : bz1;
             if (t > 1) { pi = glb_ld(g.pl_pidx + p0 + t); bz = glb_ld(g.pl_bonus + p0 + t); LCD_PIN(pi); LCD_PIN(bz); }
