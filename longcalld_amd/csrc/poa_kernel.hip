@@ -922,9 +922,12 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
             LCD_PIN(w_p0); LCD_PIN(w_np); LCD_PIN(w_rem); LCD_PIN(w_vb); LCD_PIN(w_sp); LCD_PIN(w_pi0); LCD_PIN(w_b0); LCD_PIN(w_pi1); LCD_PIN(w_b1);
         }
         const int wk = idx - wbase;
-        const int p0 = LCD_RL(w_p0, wk), np = LCD_RL(w_np, wk), rem = LCD_RL(w_rem, wk), vb = LCD_RL(w_vb, wk);
-        const int pi0 = LCD_RL(w_pi0, wk), bz0 = LCD_RL(w_b0, wk), pi1 = LCD_RL(w_pi1, wk), bz1 = LCD_RL(w_b1, wk);
+        const int np = LCD_RL(w_np, wk), rem = LCD_RL(w_rem, wk), vb = LCD_RL(w_vb, wk);
+        const int pi0 = LCD_RL(w_pi0, wk), bz0 = LCD_RL(w_b0, wk);
         const bool spf = LCD_RL(w_sp, wk) != 0;
+        // (second predecessor and the plan offset: only rows with more than one predecessor read them)
+        int p0 = 0, pi1 = 0, bz1 = 0;
+        if (np > 1) { p0 = LCD_RL(w_p0, wk); pi1 = LCD_RL(w_pi1, wk); bz1 = LCD_RL(w_b1, wk); }
         const int s = (idx - bi) & (K - 1);
         if (rem == (1 << 30)) { // not reachable
             if (lane == s) { m_beg = 1; m_end = 0; }
