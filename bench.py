@@ -40,14 +40,14 @@ def _cpu_worker(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ref-mb", type=float, default=10.0, help="synthetic reference size per GPU (10 Mb = configs[1])")
     ap.add_argument("--shape", default="hifi", choices=["hifi", "ont"])
     ap.add_argument("--cpu-sample", type=int, default=200, help="cap on regions per CPU worker of the cpu_baseline leg, which is bounded to ~12 s (rank 0, N=1 only; 0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU worker processes of the cpu_baseline leg (0 = all host cores)")
     ap.add_argument("--seed", type=int, default=20250928)
-    ap.add_argument("--lanes", type=int, default=1,
+    ap.add_argument("--lanes", type=int, default=0,
                     help="concurrent submission lanes per GPU (host threads, one lcd_batch_t + HIP stream each) -- the reference's own "
                          "execution model: kt_for runs n_threads chunk workers concurrently (src/call_var_main.c:773); the K steps are "
                          "dealt round-robin to the lanes and ALL of them complete inside the timed region")
@@ -85,8 +85,15 @@ def main():
     import threading
     # a step = one batch (the configs[1] workload).  `coalesce` steps are submitted together through lcd_batch_run_many (one set of
     # launches per stage over all their chains), `lanes` host threads keep that many such submissions in flight.
-    if args.coalesce <= 0:   # default: 32 HiFi-shape batches per submission; the ONT shape's arenas (noisy reads: 4x graph / WFA estimates) allow 16
-        args.coalesce = 32 if args.shape == "hifi" else 16   # (16 ONT-shape batches: ~250 GB of arenas with the retry round)
+    # defaults (measured): HiFi shape = two lanes of 20 batches per submission when there are enough steps for each lane to
+    # have two submissions (one lane's anchor / WFA / string stages and the tail of its chain launches overlap the other lane's chains:
+    # 40 000 regions/s against 38 000 for one lane of 32; 2 x 20 batches hold ~230 GB of the 284 GB arena budget, 2 x 28 no longer fit and
+    # fall into the split-and-retry path), else one lane of up to 32; the ONT shape's arenas (noisy reads: 4x graph / WFA estimates) allow
+    # one lane of 16 (~250 GB with the retry round)
+    if args.lanes <= 0:
+        args.lanes = 2 if (args.shape == "hifi" and args.coalesce <= 0 and args.steps >= 80) else 1
+    if args.coalesce <= 0:
+        args.coalesce = (20 if args.lanes == 2 else 32) if args.shape == "hifi" else 16
     n_co = max(1, min(args.coalesce, args.steps))
     n_lanes = max(1, min(args.lanes, (args.steps + n_co - 1) // n_co))
     groups = []
@@ -196,11 +203,19 @@ def main():
                 ops = float(sj["valu_wave_insts_per_step"]) * 64 * n_co
                 valu = {"achieved": round(ops / mean_launch_s / 1e12, 3), "peak": 78.6, "unit": "Tops/s (int32 lane-ops)", "frac": round(ops / mean_launch_s / 78.6e12, 4),
                         "source": sj["source"]}
+                if n_lanes > 1 and world == 1:   # chip-wide rate over the wall clock of the timed region (see roofline.achieved_wall)
+                    ops_all = float(sj["valu_wave_insts_per_step"]) * 64 * args.steps
+                    valu["achieved_wall"] = round(ops_all / elapsed / 1e12, 3); valu["frac_wall"] = round(ops_all / elapsed / 78.6e12, 4)
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                     "traffic": traffic, "traffic_source": traffic_src, "kernel": "lcd_poa_chain_kernel", "ms_per_launch": round(mean_launch_s * 1e3, 4),
                     "alg_bytes_per_launch": alg_bytes, "cells_per_launch": int(acc["cells"] / max(poa_launches, 1)),
                     "gcups": round(acc["cells"] / max(poa_launches, 1) / mean_launch_s / 1e9, 3) if mean_launch_s > 0 else 0.0,
                     "valu": valu}
+        if n_lanes > 1 and world == 1:
+            # `achieved` prices ONE lane's launch set against its own duration while the other lanes' chains share the CUs; the chip-wide rate is
+            # all algorithmic bytes of the timed region over its wall clock (conservative: the non-POA stages are inside that time)
+            roofline["concurrent_launch_sets"] = n_lanes
+            roofline["achieved_wall"] = round(acc["alg"] / elapsed / 1e9, 3); roofline["frac_wall"] = round(acc["alg"] / elapsed / 1e9 / HBM_PEAK_GBS, 6)
         cpu = None
         if world == 1 and args.cpu_sample > 0:
             # the reference runs this path on kt_for worker threads (src/call_var_main.c:773): time the CPU port the same way, one
