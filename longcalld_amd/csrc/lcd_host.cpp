@@ -781,9 +781,11 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         ej_base[nb] = ej.size(); wj_base[nb] = wj.size();
         if (!ej.empty() || !wj.empty()) {
             std::vector<EdOut> eo; std::vector<WfaOut> wo;
-            int rc = run_edlib_stage(st, ej, L->d_ed_jobs, L->d_ed_arena, L->d_ed_outs, eo);
+            // (ONE transient arena per leader for every stage's workspace -- edlib blocks, WFA wavefronts, the chains' DP regions: the stages of a
+            // submission follow each other on the leader's stream and none of them reads another's workspace, so the arena is their maximum, not their sum)
+            int rc = run_edlib_stage(st, ej, L->d_ed_jobs, L->d_poa_arena, L->d_ed_outs, eo);
             if (rc) return rc;
-            rc = run_wfa_stage(st, wj, L->d_wfa_jobs, L->d_wfa_arena, L->d_wfa_out, L->d_wfa_outs, wo, sc, nullptr, true);
+            rc = run_wfa_stage(st, wj, L->d_wfa_jobs, L->d_poa_arena, L->d_wfa_out, L->d_wfa_outs, wo, sc, nullptr, true);
             if (rc) return rc;
             HIPCHK(hipStreamSynchronize(st));
             // cigars of the anchor jobs: ONE device->host copy of the output span of all of them (a copy per job costs more in
@@ -987,7 +989,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     {
         int wret = 0;
         std::vector<WfaOut> rc_outs;
-        int rc = run_wfa_stage(st, rc_all, L->d_wfa_jobs, L->d_wfa_arena, L->d_wfa_out, L->d_wfa_outs, rc_outs, sc, &wret);
+        int rc = run_wfa_stage(st, rc_all, L->d_wfa_jobs, L->d_poa_arena, L->d_wfa_out, L->d_wfa_outs, rc_outs, sc, &wret);
         if (rc) return rc;
         for (int k = 0; k < nb; ++k) {
             lcd_batch_t *b = bs[k];
@@ -1056,7 +1058,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         }
         if (!sj2.empty()) {
             std::vector<WfaOut> so2;
-            int rc2 = run_wfa_stage(st, sj2, L->d_wfa_jobs, L->d_wfa_arena, L->d_seg_out, L->d_wfa_outs, so2, sc, nullptr);
+            int rc2 = run_wfa_stage(st, sj2, L->d_wfa_jobs, L->d_poa_arena, L->d_seg_out, L->d_wfa_outs, so2, sc, nullptr);
             if (rc2) return rc2;
             sres.resize(sj2.size());
             for (size_t q = 0; q < sj2.size(); ++q) { sres[q].rows_off = sj2[q].out_off; sres[q].aln_len = so2[q].aln_len; sres[q].row_stride = sj2[q].plen + sj2[q].tlen + 1; }
