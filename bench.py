@@ -40,7 +40,7 @@ def _cpu_worker(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--steps", type=int, default=192)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ref-mb", type=float, default=10.0, help="synthetic reference size per GPU (10 Mb = configs[1])")
     ap.add_argument("--shape", default="hifi", choices=["hifi", "ont"])
@@ -85,15 +85,14 @@ def main():
     import threading
     # a step = one batch (the configs[1] workload).  `coalesce` steps are submitted together through lcd_batch_run_many (one set of
     # launches per stage over all their chains), `lanes` host threads keep that many such submissions in flight.
-    # defaults (measured): HiFi shape = two lanes of 20 batches per submission when there are enough steps for each lane to
+    # defaults (measured): HiFi shape = two lanes of 32 batches per submission when there are enough steps for each lane to
     # have two submissions (one lane's anchor / WFA / string stages and the tail of its chain launches overlap the other lane's chains:
-    # 40 000 regions/s against 38 000 for one lane of 32; 2 x 20 batches hold ~230 GB of the 284 GB arena budget, 2 x 28 no longer fit and
-    # fall into the split-and-retry path), else one lane of up to 32; the ONT shape's arenas (noisy reads: 4x graph / WFA estimates) allow
-    # one lane of 16 (~250 GB with the retry round)
+    # 42 500 regions/s against 38 000 for one lane of 32; 2 x 32 batches hold ~180 GB of the 284 GB arena budget; three lanes lose: 38 600),
+    # else one lane of up to 32; the ONT shape's arenas (noisy reads: 4x graph / WFA estimates) keep one lane of 16
     if args.lanes <= 0:
-        args.lanes = 2 if (args.shape == "hifi" and args.coalesce <= 0 and args.steps >= 80) else 1
+        args.lanes = 2 if (args.shape == "hifi" and args.coalesce <= 0 and args.steps >= 128) else 1
     if args.coalesce <= 0:
-        args.coalesce = (20 if args.lanes == 2 else 32) if args.shape == "hifi" else 16
+        args.coalesce = 32 if args.shape == "hifi" else 16
     n_co = max(1, min(args.coalesce, args.steps))
     n_lanes = max(1, min(args.lanes, (args.steps + n_co - 1) // n_co))
     groups = []

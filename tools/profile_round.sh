@@ -5,7 +5,7 @@ tag=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-CMD="python bench.py --cpu-sample 0"   # the default bench command (two lanes of 20 batches, 120 steps)
+CMD="python bench.py --cpu-sample 0"   # the default bench command (two lanes of 32 batches, 192 steps)
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o kt -- $CMD > gpurun_out/prof_$tag.log 2>&1
 CMD1="python bench.py --steps 1 --warmup 0 --lanes 1 --coalesce 1 --cpu-sample 0"
 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch_$tag -o f -- $CMD1 > gpurun_out/pmc_fetch_$tag.log 2>&1
