@@ -88,11 +88,12 @@ def main():
     # defaults (measured): HiFi shape = two lanes of 32 batches per submission when there are enough steps for each lane to
     # have two submissions (one lane's anchor / WFA / string stages and the tail of its chain launches overlap the other lane's chains:
     # 42 500 regions/s against 38 000 for one lane of 32; 2 x 32 batches hold ~180 GB of the 284 GB arena budget; three lanes lose: 38 600),
-    # else one lane of up to 32; the ONT shape's arenas (noisy reads: 4x graph / WFA estimates) keep one lane of 16
+    # else one lane of up to 32; the ONT shape (noisy reads: 4x graph / WFA estimates, ~8 GB per batch in flight) runs one lane of 24:
+    # 13 900 regions/s at 191 GB (16: 13 000; 32: 15 200 but 254 GB of the 284 GB budget with the retry rounds; two lanes of 16: 14 900)
     if args.lanes <= 0:
         args.lanes = 2 if (args.shape == "hifi" and args.coalesce <= 0 and args.steps >= 128) else 1
     if args.coalesce <= 0:
-        args.coalesce = 32 if args.shape == "hifi" else 16
+        args.coalesce = 32 if args.shape == "hifi" else 24
     n_co = max(1, min(args.coalesce, args.steps))
     n_lanes = max(1, min(args.lanes, (args.steps + n_co - 1) // n_co))
     groups = []
