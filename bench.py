@@ -151,7 +151,8 @@ def main():
 
     # every lane warms its buffers at least once; the noisy-read shape needs three submissions: the capacity hints (graph, DP region, WFA score
     # bound) rise one level per submission that overflowed, and a timed run that still re-runs overflowed chains measures the learning, not the path
-    run_steps(max(args.warmup, (n_lanes * n_co * (3 if args.shape == "ont" else 1)) if args.warmup else 0), False)
+    n_warm = max(args.warmup, (n_lanes * n_co * (3 if args.shape == "ont" else 1)) if args.warmup else 0)
+    run_steps(n_warm, False)
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps, True)
@@ -247,7 +248,7 @@ def main():
                              f"{wall:.1f} s with process start-up), oracle/ C restatement (-O3 scalar, not upstream SIMD abPOA/WFA2: those submodules are "
                              f"absent); one worker alone: {one[0] / one[1]:.1f} regions/s"}
         out = {
-            "metric": "regions_per_sec", "value": round(value, 2), "unit": "regions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "regions_per_sec", "value": round(value, 2), "unit": "regions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": n_warm,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic",
             "config": {"workload": f"configs[1]: synthetic 30x {shape['name']} region jobs over {args.ref_mb:g} Mb reference per GPU "
