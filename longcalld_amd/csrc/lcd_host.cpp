@@ -171,7 +171,8 @@ struct lcd_batch_s {
     std::vector<EdJob> ed_jobs;          // offsets relative to h_pool until run()
     std::vector<WfaJob> wfa_jobs;
     // device
-    DevBuf d_in, d_chains, d_preads, d_poa_arena, d_poa_out, d_poa_outs, d_ed_jobs, d_ed_arena, d_ed_outs, d_wfa_jobs, d_wfa_arena,
+    // (d_poa_arena: the ONE transient workspace of a submission led by this batch -- chain arenas, WFA wavefronts and edlib blocks in turn)
+    DevBuf d_in, d_chains, d_preads, d_poa_arena, d_poa_out, d_poa_outs, d_ed_jobs, d_ed_outs, d_wfa_jobs,
         d_wfa_out, d_wfa_outs, d_str_jobs, d_str_outs, d_final, d_gate, d_cmp_jobs, d_cmp_outs, d_cmp_seg, d_cmp_segres, d_seg_out, d_rr,
         d_var_jobs, d_var_outs, d_var_work, d_vreg_jobs, d_vreg_outs, d_var_out;
     bool uploaded = false, ran = false, downloaded = false;
@@ -735,7 +736,7 @@ int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
     if (rc != -11 || nb <= 1) return rc;
     // the work arenas (DP cells, wavefronts, edlib columns) are transient: dropped around each half so that the halves do not add up;
     // the outputs of a half stay in its leader's buffers until they are downloaded
-    auto drop = [](lcd_batch_t *b) { b->d_poa_arena.release(); b->d_wfa_arena.release(); b->d_ed_arena.release(); b->d_var_work.release(); };
+    auto drop = [](lcd_batch_t *b) { b->d_poa_arena.release(); b->d_var_work.release(); };
     const int h = nb / 2;
     drop(bs[0]);
     const int r1 = lcd_batch_run_many(bs, h);
