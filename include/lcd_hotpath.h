@@ -152,7 +152,10 @@ int lcd_batch_run(lcd_batch_t *b);     /* anchors -> POA chains -> ref/cons WFA 
 /* the same for n uploaded batches JOINTLY (one set of launches per stage over the jobs / chains of all of them: a chain is a
  * sequential object that occupies at most one CU, so several chunks' regions in flight are what fills 256 CUs -- the reference's
  * kt_for workers, src/call_var_main.c:321, are the natural source of such concurrent batches).  batches[0] lends its stream and work
- * buffers; every batch must be downloaded before batches[0] runs again or is destroyed.  Results are those of n separate lcd_batch_run calls. */
+ * buffers; every batch must be downloaded before batches[0] runs again or is destroyed.  Results are those of n separate lcd_batch_run calls.
+ * Thread-safe for submissions with different batches[0]: two submitter threads with ~32 batches each is the measured optimum on one MI355X
+ * (one submission's anchor / ref-cons / string stages run under the other's chains); a submission that exceeds the device
+ * memory budget (LCD_MEM_FRACTION, default 0.92) is split in halves and retried. */
 int lcd_batch_run_many(lcd_batch_t **batches, int n);
 int lcd_batch_download(lcd_batch_t *b);/* HBM -> host */
 /* region results; clu_read_ids[c] and aln_strs[c][j].target_aln are malloc()'d (aln_strs[c] must hold 1+2*n_reads zeroed entries) */
