@@ -68,7 +68,11 @@ typedef struct lcd_read_view_t {
 } lcd_read_view_t;
 
 void lcd_opt_default(lcd_opt_t *opt);          /* src/call_var_main.c:140-224 */
-int lcd_init(int device);                      /* 0 ok; <0: no usable gfx950 device */
+int lcd_init(int device);                      /* process default device; 0 ok; <0: no usable gfx950 device */
+/* One process, many GPUs (the reference's kt_for workers are threads of one process, src/call_var_main.c:773): a device belongs to an
+ * lcd_batch_t (lcd_batch_create_on) or, for the per-call mirrors and K5, to the calling thread (lcd_set_thread_device; < 0 = process default). */
+int lcd_device_count(void);
+int lcd_set_thread_device(int device);
 const char *lcd_last_error(void);
 const char *lcd_version(void);
 
@@ -136,7 +140,8 @@ typedef struct lcd_batch_stats_t {
     double ms_vars;         /* stage S6 (opt.collect_noisy_vars) */
 } lcd_batch_stats_t;
 
-lcd_batch_t *lcd_batch_create(const lcd_opt_t *opt);
+lcd_batch_t *lcd_batch_create(const lcd_opt_t *opt);                 /* on the calling thread's device */
+lcd_batch_t *lcd_batch_create_on(const lcd_opt_t *opt, int device);  /* batches of one lcd_batch_run_many call share a device */
 void lcd_batch_destroy(lcd_batch_t *b);
 void lcd_batch_clear(lcd_batch_t *b);
 /* add one region AFTER read slicing (the outputs of collect_noisy_read_info, src/align.c:1377): returns region index */

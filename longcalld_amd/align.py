@@ -148,10 +148,11 @@ def poa_batch(chains, opt=None):
 class RegionBatch:
     """Batched collect_noisy_reg_aln_strs (src/align.c:1760) over many independent regions of one pass (SURVEY CS-2)."""
 
-    def __init__(self, opt=None):
+    def __init__(self, opt=None, device=-1):
+        """device: the GPU this batch lives on (lcd_batch_create_on); -1 = the calling thread's / process default device"""
         self.lib = load_library()
         self.opt = opt or default_opt()
-        self.h = self.lib.lcd_batch_create(C.byref(self.opt))
+        self.h = self.lib.lcd_batch_create_on(C.byref(self.opt), int(device))
         if not self.h:
             raise RuntimeError("lcd_batch_create failed: " + self.lib.lcd_last_error().decode())
         self.n_reads = []

@@ -33,55 +33,84 @@ int set_err(int code, const std::string &m) { g_err = m; return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { return set_err(-10, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
 
 std::mutex g_init_mu;
-int g_device = -1;
+#define LCD_MAX_DEV 16
+int g_device = -1;                 // the process default device (lcd_init, else LOCAL_RANK % n, else 0)
+int g_n_devices = 0;
+thread_local int t_device = -1;    // lcd_set_thread_device: the device of this thread's per-call entry points and of the batches it creates
 
 int g_n_cus = 256; // compute units of the device (MI355X: 256)
-int ensure_init() {
+// One process may drive every GPU of the node (the reference's kt_for workers are threads of ONE process, src/call_var_main.c:773): a device belongs
+// to an lcd_batch_t (lcd_batch_create_on) or, for the per-call mirrors, to the calling thread (lcd_set_thread_device); nothing is process-global
+// except the default.  HIP's current device is per host thread, so every entry point selects its device first.
+// GPU_MAX_HW_QUEUES: a submission uses a pool of 4 streams; with more hardware queues holding runnable kernels the queue scheduler time-slices
+// them (DESIGN section 4 "Submission").  The host sets GPU_MAX_HW_QUEUES=4 in its environment before its first HIP call; the library
+// does not touch the environment of the process it is loaded into.
+int init_default_device() {
     std::lock_guard<std::mutex> lk(g_init_mu);
-    if (g_device >= 0) { hipSetDevice(g_device); return 0; }
-    // a submission uses a pool of 4 streams; with more hardware queues holding runnable kernels the queue scheduler time-slices them (DESIGN
-    // section 4 "Submission").  Effective only if this is the process's first HIP call; a host that initialised HIP itself sets it beforehand.
-    setenv("GPU_MAX_HW_QUEUES", "4", 0);
+    if (g_device >= 0) return 0;
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return set_err(-1, "liblcd_hotpath: no HIP device visible (this library has no CPU path)");
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return set_err(-1, "liblcd_hotpath: no HIP device visible (this library has no CPU path)"); }
     int dev = 0;
     const char *lr = getenv("LOCAL_RANK");
     if (lr) dev = atoi(lr) % n;
-    if (hipSetDevice(dev) != hipSuccess) return set_err(-1, "hipSetDevice failed");
-    g_device = dev;
+    g_n_devices = n;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) g_n_cus = prop.multiProcessorCount;
+    g_device = dev;
     return 0;
 }
+int use_device(int dev) {
+    if (init_default_device()) return -1;
+    if (dev < 0) dev = t_device >= 0 ? t_device : g_device;
+    if (dev >= g_n_devices) return set_err(-1, "bad device index " + std::to_string(dev));
+    if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return set_err(-1, "hipSetDevice failed"); }
+    return 0;
+}
+int ensure_init() { return use_device(-1); }
+int cur_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; } return d < LCD_MAX_DEV ? d : 0; }
 
-// Device memory budget: the library keeps its grow-only buffers under ~92 % of the device (the HIP runtime allocates kernel scratch and
+// Device memory budget: the library keeps its grow-only buffers under ~92 % of each device (the HIP runtime allocates kernel scratch and
 // queue resources lazily at dispatch time -- with HBM full a launch aborts the queue with HSA_STATUS_ERROR_OUT_OF_RESOURCES instead of
 // returning an error).  A request over the budget fails like an out-of-memory hipMalloc (-11); lcd_batch_run_many then splits.
-std::atomic<long long> g_dev_bytes{0};
-long long g_dev_budget = -1;
+std::atomic<long long> g_dev_bytes[LCD_MAX_DEV];
+std::atomic<long long> g_dev_budget[LCD_MAX_DEV];
+std::once_flag g_budget_once[LCD_MAX_DEV];
+long long dev_budget(int d) {
+    std::call_once(g_budget_once[d], [d] {
+        size_t fr = 0, tot = 0;
+        g_dev_budget[d] = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) ? (long long)((double)tot * (getenv("LCD_MEM_FRACTION") ? atof(getenv("LCD_MEM_FRACTION")) : 0.92)) : (1ll << 62);
+        (void)hipGetLastError();
+    });
+    return g_dev_budget[d].load();
+}
 struct DevBuf {
-    void *p = nullptr; size_t cap = 0;
+    void *p = nullptr; size_t cap = 0; int dev = 0;
     int ensure(size_t n) {
         if (n <= cap) return 0;
-        if (p) { hipFree(p); g_dev_bytes -= (long long)cap; p = nullptr; cap = 0; }
-        if (g_dev_budget < 0) {
-            size_t fr = 0, tot = 0;
-            g_dev_budget = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) ? (long long)((double)tot * (getenv("LCD_MEM_FRACTION") ? atof(getenv("LCD_MEM_FRACTION")) : 0.92)) : (1ll << 62);
-            (void)hipGetLastError();
-        }
+        release();
+        dev = cur_device();
+        const long long budget = dev_budget(dev);
         size_t want = n + n / 4 + 256; // (headroom: the buffers only grow, a slightly larger next batch does not reallocate)
-        if (g_dev_bytes.load() + (long long)want > g_dev_budget) want = n + 256;
-        if (g_dev_bytes.load() + (long long)want > g_dev_budget)
-            return set_err(-11, "device memory budget: " + std::to_string(want) + " more bytes on top of " + std::to_string(g_dev_bytes.load()));
+        if (g_dev_bytes[dev].load() + (long long)want > budget) want = n + 256;
+        if (g_dev_bytes[dev].load() + (long long)want > budget)
+            return set_err(-11, "device memory budget: " + std::to_string(want) + " more bytes on top of " + std::to_string(g_dev_bytes[dev].load()));
         if (hipMalloc(&p, want) != hipSuccess) {
             (void)hipGetLastError(); // out-of-memory is not sticky, but the "last error" slot is read after every launch
             p = nullptr; cap = 0; return set_err(-11, "hipMalloc failed for " + std::to_string(want) + " bytes");
         }
-        cap = want; g_dev_bytes += (long long)cap; return 0;
+        cap = want; g_dev_bytes[dev] += (long long)cap; return 0;
     }
-    void release() { if (p) { hipFree(p); g_dev_bytes -= (long long)cap; p = nullptr; cap = 0; } }
+    void release() { if (p) { hipFree(p); g_dev_bytes[dev] -= (long long)cap; p = nullptr; cap = 0; } }
     uint64_t addr() const { return (uint64_t)(uintptr_t)p; }
-    ~DevBuf() { if (p) { hipFree(p); g_dev_bytes -= (long long)cap; } }
+    ~DevBuf() { release(); }
+    DevBuf() = default; DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
+};
+// an ad-hoc stream of a per-call entry point: destroyed on every return path
+struct StreamGuard {
+    hipStream_t s = nullptr;
+    int create() { return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess ? 0 : set_err(-10, "hipStreamCreate failed"); }
+    ~StreamGuard() { if (s) hipStreamDestroy(s); }
+    operator hipStream_t() const { return s; }
 };
 struct PinBuf {
     void *p = nullptr; size_t cap = 0;
@@ -159,6 +188,7 @@ struct OutStr { // one aln_str in the final output pool
 #define LCD_NSIDE 12
 struct lcd_batch_s {
     lcd_opt_t opt;
+    int device = 0;                      // every entry point on this batch selects it (HIP's current device is per host thread)
     hipStream_t stream = nullptr;
     hipStream_t side[LCD_NSIDE] = {};
     hipEvent_t ev[10];
@@ -314,25 +344,30 @@ void lcd_opt_default(lcd_opt_t *o) {
     o->min_noisy_reg_size_to_sample_reads = 10000; o->max_noisy_reg_len = 50000; o->noisy_reg_flank_len = 10;
     o->min_hap_full_reads = 1; o->min_hap_reads = 2; o->collect_ref_read_aln_str = 0; o->is_ont = 0; o->collect_noisy_vars = 0; o->min_sv_len = 50;
 }
-int lcd_init(int device) {
-    {
-        std::lock_guard<std::mutex> lk(g_init_mu);
-        int n = 0;
-        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return set_err(-1, "liblcd_hotpath: no HIP device visible (this library has no CPU path)");
-        if (device < 0 || device >= n) return set_err(-1, "bad device index");
-        if (hipSetDevice(device) != hipSuccess) return set_err(-1, "hipSetDevice failed");
-        g_device = device;
-    }
+int lcd_init(int device) { // the process default device (bench.py: LOCAL_RANK); batches and threads may choose another one
+    if (init_default_device()) return -1;
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    if (device < 0 || device >= g_n_devices) return set_err(-1, "bad device index");
+    if (hipSetDevice(device) != hipSuccess) return set_err(-1, "hipSetDevice failed");
+    g_device = device;
     return 0;
+}
+int lcd_device_count(void) { return init_default_device() ? 0 : g_n_devices; }
+int lcd_set_thread_device(int device) {
+    if (init_default_device()) return -1;
+    if (device >= g_n_devices) return set_err(-1, "bad device index");
+    t_device = device; // < 0: back to the process default
+    return use_device(-1);
 }
 const char *lcd_last_error(void) { return g_err.c_str(); }
 const char *lcd_version(void) { return "longcalld_amd hot path 0.1 (gfx950)"; }
 
 // ---------------------------------------------------------------------------------------------------
-lcd_batch_t *lcd_batch_create(const lcd_opt_t *opt) {
-    if (ensure_init()) return nullptr;
+lcd_batch_t *lcd_batch_create(const lcd_opt_t *opt) { return lcd_batch_create_on(opt, -1); }
+lcd_batch_t *lcd_batch_create_on(const lcd_opt_t *opt, int device) {
+    if (use_device(device)) return nullptr;
     lcd_batch_t *b = new lcd_batch_s();
-    b->opt = *opt;
+    b->opt = *opt; b->device = cur_device();
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { set_err(-10, "hipStreamCreate failed"); delete b; return nullptr; }
     for (auto &e : b->ev) hipEventCreate(&e);
     for (auto &e : b->sev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
@@ -342,7 +377,7 @@ lcd_batch_t *lcd_batch_create(const lcd_opt_t *opt) {
 }
 void lcd_batch_destroy(lcd_batch_t *b) {
     if (!b) return;
-    hipSetDevice(g_device);
+    hipSetDevice(b->device);
     for (auto &e : b->ev) hipEventDestroy(e);
     for (auto &e : b->sev) hipEventDestroy(e);
     for (auto &s : b->side) if (s) hipStreamDestroy(s);
@@ -545,7 +580,7 @@ int lcd_batch_add_region_from_chunk(lcd_batch_t *b, const lcd_read_view_t *cr, i
 }
 
 int lcd_batch_upload(lcd_batch_t *b) {
-    if (ensure_init()) return -1;
+    if (use_device(b->device)) return -1;
     const double t0 = now_ms();
     if (b->d_in.ensure(b->h_pool.size() + 64)) return -11;
     HIPCHK(hipMemcpyAsync(b->d_in.p, b->h_pool.data(), b->h_pool.size(), hipMemcpyHostToDevice, b->stream));
@@ -751,8 +786,9 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     for (int k = 0; k < nb; ++k) {
         if (!bs[k]->uploaded) return set_err(-3, "lcd_batch_run before lcd_batch_upload");
         if (memcmp(&bs[k]->opt, &bs[0]->opt, sizeof(lcd_opt_t)) != 0) return set_err(-4, "lcd_batch_run_many: batches with different options");
+        if (bs[k]->device != bs[0]->device) return set_err(-4, "lcd_batch_run_many: batches on different devices");
     }
-    if (ensure_init()) return -1;
+    if (use_device(bs[0]->device)) return -1;
     lcd_batch_t *L = bs[0];
     hipStream_t st = L->stream;
     const LcdScoring sc = scoring_of(L->opt);
@@ -1177,7 +1213,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         }
         b->ran = true; b->downloaded = false;
     }
-    if (getenv("LCD_MEM_DEBUG")) fprintf(stderr, "[mem] device buffers of this process after the submission: %.2f GB (budget %.2f GB)\n", g_dev_bytes.load() / 1e9, g_dev_budget / 1e9);
+    if (getenv("LCD_MEM_DEBUG")) fprintf(stderr, "[mem] device buffers of this process after the submission: %.2f GB (budget %.2f GB)\n", g_dev_bytes[L->device].load() / 1e9, dev_budget(L->device) / 1e9);
     if (getenv("LCD_PLACEMENT")) { // experiment: which CU did every wide chain run on, and when
         for (size_t g = 0; g < nC_all; ++g) { if (chain_threads(PC(g)) < 512) continue; const PoaChainOut &o = bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]];
             fprintf(stderr, "[place] thr %d xcc %u se %u sh %u cu %u simd %u  t %.1f..%.1f ms ticks %.3e\n", chain_threads(PC(g)), o.xcc_id & 15, (o.hw_id >> 13) & 7, (o.hw_id >> 12) & 1, (o.hw_id >> 8) & 15, (o.hw_id >> 4) & 3,
@@ -1218,19 +1254,20 @@ int lcd_batch_run(lcd_batch_t *b) { return lcd_batch_run_many(&b, 1); }
 
 int lcd_batch_download(lcd_batch_t *b) {
     if (!b->ran) return set_err(-3, "lcd_batch_download before lcd_batch_run");
+    if (use_device(b->device)) return -1;
     const double t0 = now_ms();
     hipStream_t st = b->stream;
     b->h_var.resize(b->var_bytes);
     if (b->var_bytes) HIPCHK(hipMemcpyAsync(b->h_var.data(), b->d_var_out.p, b->var_bytes, hipMemcpyDeviceToHost, st));
     const bool vars_only = b->opt.collect_noisy_vars == 2; // the alignment strings stay in HBM: only variants + alleles cross PCIe
     if (vars_only) b->final_bytes = 0;
-    b->h_final.resize(b->final_bytes);
-    if (b->final_bytes) HIPCHK(hipMemcpyAsync(b->h_final.data(), b->d_final.p, b->final_bytes, hipMemcpyDeviceToHost, st));
-    // ref<->cons rows: append after the strings
+    // ref<->cons rows are appended after the strings: size the host block ONCE, before any copy is queued into it (a resize between two
+    // asynchronous copies would free the destination of the first)
     uint64_t extra = 0;
     std::vector<uint64_t> rc_off(b->rc_jobs.size());
     for (size_t i = 0; i < b->rc_jobs.size(); ++i) { rc_off[i] = b->final_bytes + extra; if (!vars_only) extra += lcd_align_up(2ull * (b->rc_jobs[i].plen + b->rc_jobs[i].tlen + 1), 16); }
     b->h_final.resize(b->final_bytes + extra);
+    if (b->final_bytes) HIPCHK(hipMemcpyAsync(b->h_final.data(), b->d_final.p, b->final_bytes, hipMemcpyDeviceToHost, st));
     for (size_t i = 0; i < b->rc_jobs.size() && !vars_only; ++i)
         HIPCHK(hipMemcpyAsync(b->h_final.data() + rc_off[i], (void *)(uintptr_t)b->rc_jobs[i].out_off, 2ull * (b->rc_jobs[i].plen + b->rc_jobs[i].tlen + 1), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1446,7 +1483,7 @@ uint64_t lcd_batch_digest(lcd_batch_t *b) {
 int lcd_edlib_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *q_off, const int *qlen, const uint64_t *t_off,
                     const int *tlen, int *dist, int *xgaps, int *n_eq, int *n_xid) {
     if (ensure_init()) return -1;
-    hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    StreamGuard st; if (st.create()) return -10;
     DevBuf d_pool, d_jobs, d_arena, d_outs;
     if (d_pool.ensure(pool_len + 64)) return -11;
     HIPCHK(hipMemcpyAsync(d_pool.p, pool, pool_len, hipMemcpyHostToDevice, st));
@@ -1454,9 +1491,8 @@ int lcd_edlib_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_
     for (int i = 0; i < n; ++i) { jobs[i].q_off = d_pool.addr() + q_off[i]; jobs[i].t_off = d_pool.addr() + t_off[i]; jobs[i].qlen = qlen[i]; jobs[i].tlen = tlen[i]; }
     std::vector<EdOut> outs;
     int rc = run_edlib_stage(st, jobs, d_jobs, d_arena, d_outs, outs);
-    if (rc) { hipStreamDestroy(st); return rc; }
+    if (rc) return rc;
     HIPCHK(hipStreamSynchronize(st));
-    hipStreamDestroy(st);
     for (int i = 0; i < n; ++i) {
         if (outs[i].status != LCD_OK) return set_err(-20, "edlib kernel status " + std::to_string(outs[i].status));
         if (dist) dist[i] = outs[i].dist;
@@ -1471,7 +1507,7 @@ int lcd_wfa_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t 
                   const int *gap_aln, int b, int q, int e, int q2, int e2, int want, int *score, uint32_t *cigars, int cigar_stride, int *n_cigar,
                   uint8_t *rows, int row_stride, int *aln_len) {
     if (ensure_init()) return -1;
-    hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    StreamGuard st; if (st.create()) return -10;
     DevBuf d_pool, d_jobs, d_arena, d_out, d_outs;
     if (d_pool.ensure(pool_len + 64)) return -11;
     HIPCHK(hipMemcpyAsync(d_pool.p, pool, pool_len, hipMemcpyHostToDevice, st));
@@ -1484,20 +1520,20 @@ int lcd_wfa_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t 
     LcdScoring sc; sc.dbg = 0; sc.match = 0; sc.mismatch = b; sc.o1 = q; sc.e1 = e; sc.o2 = q2; sc.e2 = e2;
     std::vector<WfaOut> outs;
     int rc = run_wfa_stage(st, jobs, d_jobs, d_arena, d_out, d_outs, outs, sc, nullptr);
-    if (rc) { hipStreamDestroy(st); return rc; }
+    if (rc) return rc;
     for (int i = 0; i < n; ++i) {
         const uint64_t maxl = (uint64_t)plen[i] + tlen[i] + 1;
         uint64_t o = 0;
         if (score) score[i] = outs[i].score;
         if (want & 1) {
             if (n_cigar) n_cigar[i] = outs[i].n_cigar;
-            if (outs[i].n_cigar > cigar_stride) { hipStreamDestroy(st); return set_err(-5, "cigar_stride too small"); }
+            if (outs[i].n_cigar > cigar_stride) { return set_err(-5, "cigar_stride too small"); }
             if (outs[i].n_cigar) HIPCHK(hipMemcpyAsync(cigars + (size_t)i * cigar_stride, (void *)(uintptr_t)jobs[i].out_off, (size_t)outs[i].n_cigar * 4, hipMemcpyDeviceToHost, st));
             o = lcd_align_up(maxl * 4, 16);
         }
         if (want & 2) {
             if (aln_len) aln_len[i] = outs[i].aln_len;
-            if (outs[i].aln_len > row_stride) { hipStreamDestroy(st); return set_err(-5, "row_stride too small"); }
+            if (outs[i].aln_len > row_stride) { return set_err(-5, "row_stride too small"); }
             if (outs[i].aln_len) {
                 HIPCHK(hipMemcpyAsync(rows + (size_t)i * 2 * row_stride, (void *)(uintptr_t)(jobs[i].out_off + o), outs[i].aln_len, hipMemcpyDeviceToHost, st));
                 HIPCHK(hipMemcpyAsync(rows + (size_t)i * 2 * row_stride + row_stride, (void *)(uintptr_t)(jobs[i].out_off + o + maxl), outs[i].aln_len, hipMemcpyDeviceToHost, st));
@@ -1505,7 +1541,6 @@ int lcd_wfa_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t 
         }
     }
     HIPCHK(hipStreamSynchronize(st));
-    hipStreamDestroy(st);
     return 0;
 }
 
@@ -1648,13 +1683,13 @@ int lcd_pre_process_noisy_regs(const lcd_noisy_iv_t *chunk_noisy, int n_noisy, c
     const int nr = (int)v.size();
     if (nr == 0) return 0;
     // read support on the device
-    hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    StreamGuard st; if (st.create()) return -10;
     std::vector<IvRec> regs(nr);
     for (int i = 0; i < nr; ++i) { regs[i].st = (long long)v[i].x; regs[i].en = v[i].en; regs[i].label = v[i].label; regs[i].pad = 0; }
     const uint64_t niv = n_reads > 0 ? read_iv_off[n_reads] : 0;
     DevBuf d_regs, d_rb, d_re, d_off, d_iv, d_cnt;
     if (d_regs.ensure(nr * sizeof(IvRec)) || d_rb.ensure((n_reads + 1) * 8) || d_re.ensure((n_reads + 1) * 8) || d_off.ensure((n_reads + 2) * 8) || d_iv.ensure((niv + 1) * sizeof(IvRec)) ||
-        d_cnt.ensure(2ull * nr * 4 + 64)) { hipStreamDestroy(st); return -11; }
+        d_cnt.ensure(2ull * nr * 4 + 64)) return -11;
     HIPCHK(hipMemcpyAsync(d_regs.p, regs.data(), nr * sizeof(IvRec), hipMemcpyHostToDevice, st));
     if (n_reads > 0) {
         HIPCHK(hipMemcpyAsync(d_rb.p, read_beg, n_reads * 8, hipMemcpyHostToDevice, st)); HIPCHK(hipMemcpyAsync(d_re.p, read_end, n_reads * 8, hipMemcpyHostToDevice, st));
@@ -1667,7 +1702,6 @@ int lcd_pre_process_noisy_regs(const lcd_noisy_iv_t *chunk_noisy, int n_noisy, c
     std::vector<int> cnt(2 * (size_t)nr);
     HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt.p, 2ull * nr * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    hipStreamDestroy(st);
     lcd_noisy_iv_t *out = (lcd_noisy_iv_t *)malloc((nr + 1) * sizeof(lcd_noisy_iv_t));
     int n_out = 0;
     for (int i = 0; i < nr; ++i) {
@@ -1754,7 +1788,7 @@ int lcd_digar_batch(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, cons
     if (ensure_init()) return -1;
     if (n <= 0) return 0;
     static_assert(sizeof(lcd_digar_t) == sizeof(DigarRec) && sizeof(lcd_noisy_iv_t) == sizeof(IvRec), "ABI structs mirror the device records");
-    hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    StreamGuard st; if (st.create()) return -10;
     // capacities from one pass over the CIGAR words (the host has them in hand anyway)
     std::vector<DigarJob> jobs(n);
     uint64_t cig_words = 0, qual_bytes = 0, dtot = 0, itot = 0, etot = 0;
@@ -1770,7 +1804,7 @@ int lcd_digar_batch(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, cons
     }
     DevBuf d_cig, d_qual, d_jobs, d_outs, d_dig, d_iv, d_ev;
     if (d_cig.ensure(cig_words * 4 + 64) || d_qual.ensure(qual_bytes + 64) || d_jobs.ensure(n * sizeof(DigarJob)) || d_outs.ensure(n * sizeof(DigarOut)) ||
-        d_dig.ensure(dtot * sizeof(DigarRec) + 64) || d_iv.ensure(itot * sizeof(IvRec) + 64) || d_ev.ensure(etot * 16 + 64)) { hipStreamDestroy(st); return -11; }
+        d_dig.ensure(dtot * sizeof(DigarRec) + 64) || d_iv.ensure(itot * sizeof(IvRec) + 64) || d_ev.ensure(etot * 16 + 64)) return -11;
     for (DigarJob &j : jobs) { j.cigar_off += d_cig.addr(); j.qual_off += d_qual.addr(); j.digar_off += d_dig.addr(); j.iv_off += d_iv.addr(); j.ev_off += d_ev.addr(); }
     HIPCHK(hipMemcpyAsync(d_cig.p, cigar_pool, cig_words * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_qual.p, qual_pool, qual_bytes, hipMemcpyHostToDevice, st));
@@ -1785,7 +1819,6 @@ int lcd_digar_batch(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, cons
     if (dtot) HIPCHK(hipMemcpyAsync(hd.data(), d_dig.p, dtot * sizeof(DigarRec), hipMemcpyDeviceToHost, st));
     if (itot) HIPCHK(hipMemcpyAsync(hiv.data(), d_iv.p, itot * sizeof(IvRec), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    hipStreamDestroy(st);
     uint64_t *doff = (uint64_t *)malloc((n + 1) * sizeof(uint64_t)), *ioff = (uint64_t *)malloc((n + 1) * sizeof(uint64_t));
     uint64_t niv = 0;
     for (int r = 0; r < n; ++r) { if (outs[r].status == -3) { free(doff); free(ioff); return set_err(-24, "digar batch: capacity estimate too small"); } niv += outs[r].n_iv; }
@@ -1827,7 +1860,7 @@ int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int
                   int *n_cons, int *cons_len, int *msa_len, int *clu_n, uint8_t *cons, int cons_stride, uint8_t *msa, int msa_stride, int max_reads,
                   int *clu_ids) {
     if (ensure_init()) return -1;
-    hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    StreamGuard st; if (st.create()) return -10;
     DevBuf d_pool, d_chains, d_reads, d_arena, d_out, d_outs;
     if (d_pool.ensure(pool_len + 64)) return -11;
     HIPCHK(hipMemcpyAsync(d_pool.p, pool, pool_len, hipMemcpyHostToDevice, st));
@@ -1885,7 +1918,7 @@ int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int
         status[c] = o.status; n_cons[c] = o.n_cons; cons_len[2 * c] = o.cons_len[0]; cons_len[2 * c + 1] = o.cons_len[1]; msa_len[c] = o.msa_len;
         clu_n[2 * c] = o.clu_n[0]; clu_n[2 * c + 1] = o.clu_n[1];
         if (o.status != LCD_OK) continue;
-        if (o.msa_len > msa_stride || o.cons_len[0] > cons_stride || o.cons_len[1] > cons_stride || pc.n_reads > max_reads) { hipStreamDestroy(st); return set_err(-5, "output strides too small"); }
+        if (o.msa_len > msa_stride || o.cons_len[0] > cons_stride || o.cons_len[1] > cons_stride || pc.n_reads > max_reads) { return set_err(-5, "output strides too small"); }
         for (int k = 0; k < o.n_cons; ++k)
             if (o.cons_len[k]) HIPCHK(hipMemcpyAsync(cons + ((size_t)2 * c + k) * cons_stride, (void *)(uintptr_t)(pc.out_off + (uint64_t)k * pc.node_cap), o.cons_len[k], hipMemcpyDeviceToHost, st));
         for (int r = 0; r < pc.n_reads + o.n_cons; ++r)
@@ -1895,7 +1928,6 @@ int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int
             if (o.clu_n[k]) HIPCHK(hipMemcpyAsync(clu_ids + ((size_t)2 * c + k) * max_reads, (void *)(uintptr_t)(clu_addr + (uint64_t)k * pc.n_reads * 4), (size_t)o.clu_n[k] * 4, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(hipStreamSynchronize(st));
-    hipStreamDestroy(st);
     return 0;
 }
 
@@ -1904,7 +1936,7 @@ int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int
 int lcd_assign_hap_batch(int n, lcd_hap_problem_t *probs, const int *targets) {
     if (ensure_init()) return -1;
     if (n <= 0) return 0;
-    hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    StreamGuard st; if (st.create()) return -10;
     std::vector<uint8_t> hb; // host staging; offsets become device addresses
     auto put = [&](const void *p, size_t bytes) { size_t o = lcd_align_up(hb.size(), 16); hb.resize(o + bytes); if (p && bytes) memcpy(hb.data() + o, p, bytes); return (uint64_t)o; };
     struct Off { uint64_t var_pos, var_type, var_cate, is_hp, total_cov, alle_off, alle_covs, start_var, end_var, allele_off, alleles, ordered, cr_read, is_skipped,
@@ -1949,7 +1981,6 @@ int lcd_assign_hap_batch(int n, lcd_hap_problem_t *probs, const int *targets) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(hb.data(), d_buf.p, hb.size(), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    hipStreamDestroy(st);
     for (int i = 0; i < n; ++i) {
         lcd_hap_problem_t &p = probs[i]; const Off &o = offs[i];
         const int R = p.n_reads, V = p.n_vars, TA = V ? p.alle_off[V] : 0;

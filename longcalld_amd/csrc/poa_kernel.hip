@@ -22,6 +22,7 @@
 //   * rows wider than the window fall back to the generic rows of align_to_subgraph (int32 H/E1/E2 planes in HBM, value backtrack).
 // Semantics are defined by oracle/poa.c (see its header); this file must match it bit for bit.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include "lcd_types.h"
 #include "lcd_kernels.h"
 
@@ -2069,15 +2070,15 @@ void lcd_launch_gate(int *ctr, int target0, int target1, hipStream_t stream) { h
 void lcd_launch_poa(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool, uint8_t *arena, uint8_t *outpool,
                     PoaChainOut *outs, LcdScoring sc, int n_chains, int threads, int lds_bytes, hipStream_t stream, int *gate) {
     if (n_chains <= 0) return;
-    static bool attr_set = false;
-    if (!attr_set) { // allow > 64 KB of dynamic LDS (gfx950 has 160 KB per CU)
+    static std::once_flag attr_once[16]; // (concurrent submitters: lcd_batch_run_many is thread-safe; function attributes are per device)
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    std::call_once(attr_once[dev], [] { // allow > 64 KB of dynamic LDS (gfx950 has 160 KB per CU)
         hipFuncSetAttribute((const void *)lcd_poa_chain_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         hipFuncSetAttribute((const void *)lcd_poa_chain_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         hipFuncSetAttribute((const void *)lcd_poa_chain_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         hipFuncSetAttribute((const void *)lcd_poa_chain_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         hipFuncSetAttribute((const void *)lcd_poa_chain_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
-    }
+    });
 #define LCD_LAUNCH(NT) hipLaunchKernelGGL(lcd_poa_chain_kernel<NT>, dim3(n_chains), dim3(NT), lds_bytes, stream, chains, reads, pool, arena, outpool, outs, sc, n_chains, gate)
     if (threads <= 64) LCD_LAUNCH(64);
     else if (threads <= 128) LCD_LAUNCH(128);
