@@ -1,10 +1,14 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json's metric on its configs[1]: regions/sec (+ POA-aligned bases/sec) of the per-region hot path
-on synthetic 30x HiFi-shape region jobs (15 kb reads, 0.1 % error, 10 Mb reference => 1 250 regions per GPU).
+on synthetic 30x HiFi-shape region jobs (15 kb reads, 0.1 % error, 10 Mb reference => 1 250 regions per step).
 
-One "step" = one pass of the hot path (anchors -> POA chains -> ref/cons WFA -> MSA strings) over the rank's batch with
-inputs already resident in HBM.  N > 1: regions are sharded across ranks as independent work items (no data-path
-collective); torch.distributed (RCCL) is used for the barrier and the max-over-ranks time only.
+One "step" = one pass of the hot path (anchors -> POA chains -> ref/cons WFA -> MSA strings) over one batch (the regions of 10 Mb of
+reference) with inputs already resident in HBM.  The timed steps cycle over `--distinct` batches generated from DIFFERENT seeds (default 10 =
+100 Mb of distinct regions); the warm-up runs on OTHER seeds, so nothing the library learns (capacity hints) is learned on the timed data.
+N > 1: one process per GPU, each rank its own seeds (weak scaling), no data-path collective; torch.distributed (RCCL) carries the
+barrier and the max-over-ranks time.  `--job-mb M` instead times ONE job of M Mb (M / 10 distinct batches) sharded over the ranks
+(configs[3] / configs[4]: strong scaling; longest-processing-time assignment by the batches' read bases, optional RCCL queue rebalance).
+Other shapes: --shape ont (configs[2]), --shape sv (configs[4]: 60x noisy reads, 1-10 kb INS/DEL).
 """
 import argparse
 import json
@@ -22,13 +26,19 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 
 
+def _gen(a):
+    seed, n_regions, shape_name = a
+    from longcalld_amd import jobs
+    return jobs.make_regions(seed, n_regions, jobs.SHAPES[shape_name])
+
+
 def _cpu_worker(a):
     """cpu_baseline leg: one process per host core runs the oracle (oracle/, test infrastructure) on its slice of the workload"""
     seed, n_regions, shape_name, w, n_workers, per, budget_s = a
     from longcalld_amd import jobs
     from oracle import pyoracle
     n_gen = min(n_regions, per)   # (generating the whole workload in every worker would cost more than the timed loop)
-    regs = jobs.make_regions(seed + 7919 * w, n_gen, jobs.HIFI if shape_name == "hifi" else jobs.ONT)
+    regs = jobs.make_regions(seed + 7919 * w, n_gen, jobs.SHAPES[shape_name])
     done = 0
     t0 = time.perf_counter()
     while done < per and time.perf_counter() - t0 < budget_s:   # bounded by a time budget: the core count of the box is not known in advance
@@ -37,18 +47,68 @@ def _cpu_worker(a):
     return done, time.perf_counter() - t0
 
 
+def _host_cores():
+    try:
+        n_avail = len(os.sched_getaffinity(0))
+    except Exception:  # noqa
+        n_avail = os.cpu_count() or 1
+    try:  # a container's CPU quota (cgroup v2 cpu.max = "quota period") is the real core count
+        q, per_us = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n_avail = max(1, min(n_avail, -(-int(q) // int(per_us))))
+    except Exception:  # noqa
+        pass
+    return n_avail
+
+
+def _k4_reference(pairs, n_threads, budget_s=6.0):
+    """the reference's OWN edlib (oracle/_ref/libedlib_ref.so = /root/reference/edlib/src/edlib.cpp compiled where it lies) on the K4 job set
+    of one step, `n_threads` host threads (ctypes releases the GIL); returns (pairs per second, seconds, pairs done) or None if the .so is absent"""
+    import ctypes as C
+    import threading
+    so = os.path.join(ROOT, "oracle", "_ref", "libedlib_ref.so")
+    if not os.path.exists(so) or not pairs:
+        return None
+    lib = C.CDLL(so)
+    u8p = C.POINTER(C.c_uint8)
+    lib.ref_edlib_nw_path.argtypes = [u8p, C.c_int, u8p, C.c_int, u8p, C.c_int, C.POINTER(C.c_int)]
+    done = [0] * n_threads
+    t0 = time.perf_counter()
+
+    def work(w):
+        cap = 1 + 2 * max(max(len(t), len(q)) for t, q in pairs)
+        buf = (C.c_uint8 * cap)(); al = C.c_int(0)
+        i = w
+        while time.perf_counter() - t0 < budget_s:
+            t, q = pairs[i % len(pairs)]
+            lib.ref_edlib_nw_path(q.ctypes.data_as(u8p), len(q), t.ctypes.data_as(u8p), len(t), buf, cap, C.byref(al))   # edlib_xgaps: NW + path (src/align.c:222)
+            done[w] += 1; i += n_threads
+            if done[w] * n_threads >= 4 * len(pairs):
+                break
+    ths = [threading.Thread(target=work, args=(w,)) for w in range(n_threads)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    el = time.perf_counter() - t0
+    return sum(done) / el, el, sum(done)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=192)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--ref-mb", type=float, default=10.0, help="synthetic reference size per GPU (10 Mb = configs[1])")
-    ap.add_argument("--shape", default="hifi", choices=["hifi", "ont"])
+    ap.add_argument("--ref-mb", type=float, default=10.0, help="synthetic reference size per step (10 Mb = configs[1]: 1 250 regions)")
+    ap.add_argument("--job-mb", type=float, default=0.0, help="time ONE job of this many Mb (job-mb / ref-mb distinct batches) sharded over the ranks "
+                    "(configs[3] / configs[4]); --steps is ignored, scaling is strong")
+    ap.add_argument("--distinct", type=int, default=10, help="distinct-seed batches the timed steps cycle over (10 x 10 Mb = 100 Mb of distinct regions)")
+    ap.add_argument("--shape", default="hifi", choices=["hifi", "ont", "ont60", "sv"])
     ap.add_argument("--cpu-sample", type=int, default=200, help="cap on regions per CPU worker of the cpu_baseline leg, which is bounded to ~12 s (rank 0, N=1 only; 0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU worker processes of the cpu_baseline leg (0 = all host cores)")
     ap.add_argument("--seed", type=int, default=20250928)
     ap.add_argument("--lanes", type=int, default=0,
-                    help="concurrent submission lanes per GPU (host threads, one lcd_batch_t + HIP stream each) -- the reference's own "
+                    help="concurrent submission lanes per GPU (host threads, one leader lcd_batch_t + HIP stream each) -- the reference's own "
                          "execution model: kt_for runs n_threads chunk workers concurrently (src/call_var_main.c:773); the K steps are "
                          "dealt round-robin to the lanes and ALL of them complete inside the timed region")
     ap.add_argument("--vars", type=int, default=0, choices=[0, 1, 2],
@@ -59,11 +119,30 @@ def main():
                          "all of them, so that the GPU's workgroup dispatcher -- not HIP streams -- packs several chunks' chains onto the CUs")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from longcalld_amd import jobs
+    shape = jobs.SHAPES[args.shape]
+    n_regions = jobs.regions_for_ref_mb(args.ref_mb)
+    job_mode = args.job_mb > 0
+
+    # ---- synthetic region jobs first (worker processes forked before torch / HIP start): timed seeds and, disjoint from them, warm-up seeds ----
+    if job_mode:
+        n_job = max(1, int(round(args.job_mb / args.ref_mb)))
+        timed_seeds = [args.seed + i for i in range(n_job)]                      # the same job on every rank; sharded below
+    else:
+        timed_seeds = [args.seed + 1000 * rank + i for i in range(max(1, args.distinct))]   # weak scaling: same work per GPU, different seeds
+    n_warm_seeds = 3 if args.warmup else 0
+    warm_seeds = [args.seed + 500000 + 1000 * rank + i for i in range(n_warm_seeds)]
+    import multiprocessing as mp
+    n_gen_procs = max(1, min(len(timed_seeds) + len(warm_seeds), _host_cores() // max(1, world if world > 1 else 1)))
+    with mp.get_context("fork").Pool(n_gen_procs) as pool:
+        gen = pool.map(_gen, [(sd, n_regions, args.shape) for sd in timed_seeds + warm_seeds], chunksize=1)
+    timed_regs, warm_regs = gen[:len(timed_seeds)], gen[len(timed_seeds):]
+
+    import torch
+    import torch.distributed as dist
     if args.gpus > 1 or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -72,74 +151,89 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank)
 
-    from longcalld_amd import align, jobs, _lib
+    from longcalld_amd import align, _lib
     lib = _lib.load_library()
     _lib.check(lib.lcd_init(local_rank), lib)
 
-    shape = jobs.HIFI if args.shape == "hifi" else jobs.ONT
-    n_regions = jobs.regions_for_ref_mb(args.ref_mb)
-    regs = jobs.make_regions(args.seed + 1000 * rank, n_regions, shape)   # weak scaling: same work per GPU, different seed
     bench_opt = align.default_opt()
     bench_opt.collect_noisy_vars = args.vars
-    bench_opt.is_ont = 1 if args.shape == "ont" else 0   # the reference's --ont / --hifi switch (src/call_var_main.h:128)
+    bench_opt.is_ont = 0 if args.shape == "hifi" else 1   # the reference's --ont / --hifi switch (src/call_var_main.h:128)
+    noisy = args.shape != "hifi"
     import threading
-    # a step = one batch (the configs[1] workload).  `coalesce` steps are submitted together through lcd_batch_run_many (one set of
-    # launches per stage over all their chains), `lanes` host threads keep that many such submissions in flight.
+    # a step = one batch.  `coalesce` steps are submitted together through lcd_batch_run_many (one set of launches per stage over all their
+    # chains), `lanes` host threads keep that many such submissions in flight.
     # defaults (measured): HiFi shape = two lanes of 32 batches per submission when there are enough steps for each lane to
-    # have two submissions (one lane's anchor / WFA / string stages and the tail of its chain launches overlap the other lane's chains:
-    # 42 500 regions/s against 38 000 for one lane of 32; 2 x 32 batches hold ~180 GB of the 284 GB arena budget; three lanes lose: 38 600),
-    # else one lane of up to 32; the ONT shape (noisy reads: 4x graph / WFA estimates, ~8 GB per batch in flight) runs one lane of 24:
-    # 13 900 regions/s at 191 GB (16: 13 000; 32: 15 200 but 254 GB of the 284 GB budget with the retry rounds; two lanes of 16: 14 900)
+    # have two submissions (one lane's anchor / WFA / string stages and the tail of its chain launches overlap the other lane's chains),
+    # else one lane of up to 32; the noisy-read shapes (4x graph estimates, ~8 GB per batch in flight) run one lane of 24 (sv: 8)
+    if job_mode:
+        # static sharding of the job's batches by their read bases, longest first (LPT); every rank computes the same assignment
+        cost = [sum(sum(len(x) for x in r["seqs"]) * 1.0 for r in regs) for regs in timed_regs]
+        order = sorted(range(len(cost)), key=lambda i: -cost[i])
+        load = [0.0] * world
+        mine = []
+        for i in order:
+            w = min(range(world), key=lambda r_: load[r_])
+            load[w] += cost[i]
+            if w == rank:
+                mine.append(i)
+        timed_regs = [timed_regs[i] for i in mine]
+        args.steps = len(timed_regs)
+        lpt_imbalance = max(load) / (sum(load) / world) if sum(load) > 0 else 1.0
     if args.lanes <= 0:
         args.lanes = 2 if (args.shape == "hifi" and args.coalesce <= 0 and args.steps >= 128) else 1
     if args.coalesce <= 0:
-        args.coalesce = 32 if args.shape == "hifi" else 24
-    n_co = max(1, min(args.coalesce, args.steps))
-    n_lanes = max(1, min(args.lanes, (args.steps + n_co - 1) // n_co))
-    groups = []
-    t_up = 0.0
-    for _ in range(n_lanes):
-        grp = []
-        for _ in range(n_co):
-            bt = align.RegionBatch(bench_opt)
-            for r in regs:
-                bt.add_region(r)
-            t_up0 = time.perf_counter()
-            bt.upload()
-            t_up = time.perf_counter() - t_up0
-            grp.append(bt)
-        groups.append(grp)
+        args.coalesce = 32 if args.shape == "hifi" else 8 if args.shape == "sv" else 24
+    n_co = max(1, min(args.coalesce, max(args.steps, 1)))
+    n_lanes = 1 if job_mode else max(1, min(args.lanes, (args.steps + n_co - 1) // n_co))
+    # slots = uploaded batches: the weak-scaling run re-submits lanes x coalesce slots (cycling over the distinct batches); a job owns one slot
+    # per batch and submits them `coalesce` at a time, each exactly once
+    n_slots = max(args.steps, 1) if job_mode else n_lanes * n_co
+
+    def load_slot(bt, regs):
+        bt.clear()
+        for r in regs:
+            bt.add_region(r)
+        t0_ = time.perf_counter()
+        bt.upload()
+        return time.perf_counter() - t0_
+
+    groups = [[align.RegionBatch(bench_opt) for _ in range(n_slots // n_lanes)] for _ in range(n_lanes)]
     batches = [bt for grp in groups for bt in grp]
-    batch = batches[0]
+    t_up = 0.0
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    acc = {"ms": 0.0, "launches": 0, "st": None, "alg": 0.0, "cells": 0.0}
+    acc = {"ms": 0.0, "launches": 0, "st": None, "alg": 0.0, "cells": 0.0, "regions": 0.0, "bases": 0.0, "resolved": 0, "wfa_off": 0.0, "ed_blocks": 0.0, "ms_wfa": 0.0, "ms_anchor": 0.0}
     lock = threading.Lock()
-
     lane_errors = []
 
     def lane_work(grp, sizes, record):
         try:
-            _lane_work(grp, sizes, record)
+            for a, k in sizes:
+                align.RegionBatch.run_many(grp[a:a + k])
+                if record:
+                    sts = [bt.stats() for bt in grp[a:a + k]]
+                    with lock:
+                        acc["ms"] += sts[0]["ms_poa_kernel"]; acc["launches"] += sts[0]["n_poa_launches"]; acc["st"] = sts[0]
+                        acc["ms_wfa"] += sts[0]["ms_wfa"] + sts[0]["ms_anchor"]; acc["ms_anchor"] += sts[0]["ms_anchor"]
+                        for x in sts:
+                            acc["alg"] += float(x["poa_alg_bytes"]); acc["cells"] += float(x["poa_cells"]); acc["regions"] += float(x["n_regions"])
+                            acc["bases"] += float(x["poa_aligned_bases"]); acc["resolved"] += int(x["n_regions_resolved"])
+                            acc["wfa_off"] += float(x["wfa_offsets"]); acc["ed_blocks"] += float(x["edlib_blocks"])
         except Exception as e:  # noqa: surfaced after the join (a thread's traceback alone would leave a half-measured line)
             lane_errors.append(e)
-
-    def _lane_work(grp, sizes, record):
-        for k in sizes:
-            align.RegionBatch.run_many(grp[:k])
-            if record:
-                sts = [bt.stats() for bt in grp[:k]]
-                with lock:
-                    acc["ms"] += sts[0]["ms_poa_kernel"]; acc["launches"] += sts[0]["n_poa_launches"]; acc["st"] = sts[0]
-                    acc["alg"] += sum(float(x["poa_alg_bytes"]) for x in sts); acc["cells"] += sum(float(x["poa_cells"]) for x in sts)
 
     def run_steps(n_steps, record):
         # cut the steps into submissions of `coalesce` and deal those round-robin to the lanes; lanes overlap on the GPU
         subs = [n_co] * (n_steps // n_co) + ([n_steps % n_co] if n_steps % n_co else [])
+        if job_mode:   # consecutive slots, each batch once (warm-up: the same walk over the warm-up data)
+            starts = [sum(subs[:i]) % max(n_slots, 1) for i in range(len(subs))]
+            subs = [(a, min(k, n_slots - a)) for a, k in zip(starts, subs)]
+        else:
+            subs = [(0, k) for k in subs]
         share = [subs[i::n_lanes] for i in range(n_lanes)]
         ths = [threading.Thread(target=lane_work, args=(groups[i], share[i], record)) for i in range(n_lanes) if share[i]]
         for t in ths:
@@ -149,35 +243,50 @@ def main():
         if lane_errors:
             raise lane_errors[0]
 
-    # every lane warms its buffers at least once; the noisy-read shape needs three submissions: the capacity hints (graph, DP region, WFA score
-    # bound) rise one level per submission that overflowed, and a timed run that still re-runs overflowed chains measures the learning, not the path
-    n_warm = max(args.warmup, (n_lanes * n_co * (3 if args.shape == "ont" else 1)) if args.warmup else 0)
-    run_steps(n_warm, False)
+    # ---- warm-up on OTHER seeds: every slot's buffers grow to size, the capacity hints settle (the noisy-read shapes need three submissions:
+    # the hints rise one level per submission that overflowed) -- none of it on the data that is timed ----
+    n_warm = 0
+    if args.warmup and args.steps > 0:
+        for q, bt in enumerate(batches):
+            load_slot(bt, warm_regs[q % len(warm_regs)])
+        n_warm = max(args.warmup, (min(n_slots, n_co) if job_mode else n_slots) * (3 if noisy else 1))
+        run_steps(n_warm, False)
+    for q, bt in enumerate(batches):
+        if args.steps > 0:
+            t_up = load_slot(bt, timed_regs[q % len(timed_regs)])
     barrier()
     t0 = time.perf_counter()
-    run_steps(args.steps, True)
+    if args.steps > 0:
+        run_steps(args.steps, True)
     barrier()
     elapsed = time.perf_counter() - t0
     poa_kernel_ms, poa_launches, st = acc["ms"], acc["launches"], acc["st"]
+    tot_regions, tot_bases = acc["regions"], acc["bases"]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rank_elapsed = elapsed
         elapsed = float(t.item())
-        cnt = torch.tensor([float(st["n_regions"]), float(st["poa_aligned_bases"])], dtype=torch.float64, device=dev)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        tot_regions, tot_bases = float(cnt[0].item()), float(cnt[1].item())
+        cnt = torch.tensor([tot_regions, tot_bases, rank_elapsed], dtype=torch.float64, device=dev)
+        allc = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(allc, cnt)
+        tot_regions, tot_bases = float(sum(c[0].item() for c in allc)), float(sum(c[1].item() for c in allc))
+        rank_times = [round(float(c[2].item()), 4) for c in allc]
     else:
-        tot_regions, tot_bases = float(st["n_regions"]), float(st["poa_aligned_bases"])
+        rank_times = [round(elapsed, 4)]
 
     # PCIe-inclusive figure for DESIGN.md (never `value`)
-    t_dl0 = time.perf_counter()
-    batch.download()
-    digest = batch.digest()
-    t_dl = time.perf_counter() - t_dl0
+    digest, t_dl = 0, 0.0
+    if st is not None:
+        t_dl0 = time.perf_counter()
+        batches[0].download()
+        digest = batches[0].digest()
+        t_dl = time.perf_counter() - t_dl0
 
     if rank == 0:
-        ms_step = elapsed / args.steps * 1e3
-        value = tot_regions * args.steps / elapsed
+        steps = max(args.steps, 1)
+        ms_step = elapsed / steps * 1e3
+        value = tot_regions / elapsed
         # roofline of the dominant kernel (POA chains): algorithmic bytes (SURVEY 8d B_poa) per launch / mean launch time
         alg_bytes = acc["alg"] / max(poa_launches, 1)     # per launch set: the chains of `coalesce` batches
         mean_launch_s = poa_kernel_ms / max(poa_launches, 1) * 1e-3
@@ -185,11 +294,10 @@ def main():
         # HBM bytes of the same launch from the PMC counters: they need rocprofv3 (separate --pmc passes, tools/profile_round.sh), so the
         # figure is the committed measurement of this exact workload (profiles/<tag>_traffic.json), or null for any other workload
         traffic, traffic_src = None, None
-        if args.ref_mb == 10 and shape["name"] == "hifi" and world == 1:
-            import glob
-            import re
-            cand = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")),
-                          key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])   # r01_v9 < r01_v10
+        import glob
+        import re
+        if args.ref_mb == 10 and shape["name"] == "hifi" and world == 1 and not job_mode:
+            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])   # r01_v9 < r01_v10 < r02_v1
             if cand:
                 tj = json.load(open(cand[-1]))
                 traffic, traffic_src = float(tj["hbm_bytes_per_step"]) * n_co, tj["source"] + f" x {n_co} coalesced steps"
@@ -197,8 +305,7 @@ def main():
         # pass (same rule as `traffic`), x 64 lanes, over the live launch time; peak = 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 Tops/s
         valu = None
         if traffic is not None:
-            cand2 = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_sq.json")),
-                           key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+            cand2 = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq.json")), key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
             if cand2 and mean_launch_s > 0:
                 sj = json.load(open(cand2[-1]))
                 ops = float(sj["valu_wave_insts_per_step"]) * 64 * n_co
@@ -218,20 +325,10 @@ def main():
             roofline["concurrent_launch_sets"] = n_lanes
             roofline["achieved_wall"] = round(acc["alg"] / elapsed / 1e9, 3); roofline["frac_wall"] = round(acc["alg"] / elapsed / 1e9 / HBM_PEAK_GBS, 6)
         cpu = None
-        if world == 1 and args.cpu_sample > 0:
+        if world == 1 and args.cpu_sample > 0 and st is not None:
             # the reference runs this path on kt_for worker threads (src/call_var_main.c:773): time the CPU port the same way, one
-            # process per host core (spawned: no fork after HIP start-up), every worker on its own slice of the same regions
-            import multiprocessing as mp
-            try:
-                n_avail = len(os.sched_getaffinity(0))
-            except Exception:  # noqa
-                n_avail = os.cpu_count() or 1
-            try:  # a container's CPU quota (cgroup v2 cpu.max = "quota period") is the real core count
-                q, per_us = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-                if q != "max":
-                    n_avail = max(1, min(n_avail, -(-int(q) // int(per_us))))
-            except Exception:  # noqa
-                pass
+            # process per host core (spawned: no fork after HIP start-up), every worker on its own slice of the same workload shape
+            n_avail = _host_cores()
             n_workers = args.cpu_threads if args.cpu_threads > 0 else n_avail
             per = max(1, args.cpu_sample)
             ctx = mp.get_context("spawn")
@@ -245,28 +342,51 @@ def main():
             done = sum(p_[0] for p_ in parts); busy = max(p_[1] for p_ in parts)
             cpu = {"value": round(done / busy, 2), "unit": "regions/s", "cores": n_workers, "kind": "port",
                    "sample": f"{done} regions of the same workload shape in {busy:.1f} s on {n_workers} worker processes (one per schedulable CPU / cgroup quota; "
-                             f"{wall:.1f} s with process start-up), oracle/ C restatement (-O3 scalar, not upstream SIMD abPOA/WFA2: those submodules are "
-                             f"absent); one worker alone: {one[0] / one[1]:.1f} regions/s"}
+                             f"{wall:.1f} s with process start-up), oracle/ C restatement (-O3 scalar, NOT upstream SIMD abPOA/WFA2: those submodules are "
+                             f"absent from the reference checkout, so this is a port, not the reference); one worker alone: {one[0] / one[1]:.1f} regions/s"}
+            # the one kernel whose REFERENCE implementation exists here: K4 on the reference's own vendored edlib, same job set as one step
+            try:
+                pairs = batches[0].k4_pairs()
+                ref = _k4_reference(pairs, n_workers)
+                if ref is not None:
+                    g0 = time.perf_counter(); align.edlib_batch(pairs); g1 = time.perf_counter(); align.edlib_batch(pairs); g2 = time.perf_counter()
+                    blocks = float(st["edlib_blocks"])
+                    cpu["k4_reference"] = {"kind": "reference", "value": round(ref[0], 1), "unit": "edlib_xgaps pairs/s", "cores": n_workers,
+                                           "sample": f"{ref[2]} NW+path alignments (the {len(pairs)} K4 jobs of one step, cycled) in {ref[1]:.2f} s on {n_workers} threads of the "
+                                                     f"reference's own edlib (oracle/_ref/libedlib_ref.so)",
+                                           "gpu_pairs_per_sec_batch_call": round(len(pairs) / max(g2 - g1, 1e-9), 1),
+                                           "gpu_note": "lcd_edlib_batch on the same pairs, one call including its allocations and both PCIe copies (second call; the kernel "
+                                                       "itself is inside ms_anchor of the step)", "k4_jobs_per_step": len(pairs), "myers_blocks_per_step": blocks}
+            except Exception as e:  # noqa
+                cpu["k4_reference"] = {"error": str(e)}
+        cfg_name = {"hifi": "configs[1]", "ont": "configs[2]", "ont60": "configs[2] at 60x", "sv": "configs[4] (60x noisy reads, 1-10 kb INS/DEL)"}[args.shape]
+        if job_mode:
+            cfg_name = ("configs[3]" if args.shape == "hifi" else cfg_name) + f": one {args.job_mb:g} Mb job sharded over the ranks"
         out = {
             "metric": "regions_per_sec", "value": round(value, 2), "unit": "regions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": n_warm,
-            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong" if job_mode else "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": f"configs[1]: synthetic 30x {shape['name']} region jobs over {args.ref_mb:g} Mb reference per GPU "
-                                   f"({n_regions} regions/GPU, ~{tot_bases / max(world, 1) / 1e6:.1f} Mbase POA-aligned/GPU)",
-                       "regions_per_gpu": n_regions, "sharding": "regions sharded across ranks, no data-path collective",
+            "config": {"workload": f"{cfg_name}: synthetic {shape['depth']}x {shape['name']} region jobs, {args.ref_mb:g} Mb of reference per step "
+                                   f"({n_regions} regions/step, ~{tot_bases / max(world, 1) / steps / 1e6:.1f} Mbase POA-aligned/step)",
+                       "regions_per_step": n_regions, "distinct_batches_per_gpu": len(timed_regs), "warmup_on_other_seeds": bool(n_warm),
+                       "sharding": ("LPT over the job's batches by read bases" if job_mode else "per-rank seeds") + ", no data-path collective",
                        "lanes_per_gpu": n_lanes, "coalesced_steps_per_submission": n_co},
-            "poa_aligned_bases_per_sec": round(tot_bases * args.steps / elapsed, 1),
-            "regions_resolved": int(st["n_regions_resolved"]),
-            "wfa_offsets_per_sec": round(float(st["wfa_offsets"]) * n_co / max((st["ms_wfa"] + st["ms_anchor"]) * 1e-3, 1e-9), 1),
-            "edlib_blocks_per_sec": round(float(st["edlib_blocks"]) * n_co / max(st["ms_anchor"] * 1e-3, 1e-9), 1),
-            "stage_ms": {k: round(st[k], 3) for k in ("ms_anchor", "ms_poa", "ms_wfa", "ms_strings", "ms_vars", "ms_total", "ms_host", "ms_poa_kernel")},
+            "poa_aligned_bases_per_sec": round(tot_bases / elapsed, 1),
+            "regions_resolved": int(acc["resolved"]),
+            "regions_timed": int(tot_regions),
+            "wfa_offsets_per_sec": round(acc["wfa_off"] / max(acc["ms_wfa"] * 1e-3, 1e-9), 1),
+            "edlib_blocks_per_sec": round(acc["ed_blocks"] / max(acc["ms_anchor"] * 1e-3, 1e-9), 1),
+            "stage_ms": {k: round(st[k], 3) for k in ("ms_anchor", "ms_poa", "ms_wfa", "ms_strings", "ms_vars", "ms_total", "ms_host", "ms_poa_kernel")} if st else None,
             "noisy_vars_stage": args.vars,
+            "rank_seconds": rank_times,
             "pcie_inclusive": {"upload_s": round(t_up, 4), "download_and_digest_s": round(t_dl, 4),
-                               "regions_per_sec": round(tot_regions / max(world, 1) / (t_up + ms_step / 1e3 + t_dl), 2)},
+                               "regions_per_sec": round(tot_regions / max(world, 1) / steps / (t_up + ms_step / 1e3 + t_dl), 2)},
             "digest": f"{digest:016x}",
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if job_mode:
+            out["lpt_imbalance"] = round(lpt_imbalance, 4)
         print(json.dumps(out), flush=True)
     for bt in batches:
         bt.close()

@@ -188,6 +188,9 @@ int lcd_batch_region_vars(lcd_batch_t *b, int region, int64_t noisy_reg_beg, con
                           int **prof_end, int **prof_alleles);
 int lcd_batch_region_sorted_ids(lcd_batch_t *b, int region, int *read_ids_out); /* the in-place permutation of noisy_reads */
 int lcd_batch_get_stats(lcd_batch_t *b, lcd_batch_stats_t *st);
+/* the K4 job set of the batch's anchor stage (edlib_xgaps calls of src/align.c:694,698,722): offsets into the batch's host pool (valid until the
+ * batch is cleared); returns the number of jobs, fills at most cap of them.  bench.py times the reference's own edlib on it. */
+int lcd_batch_k4_jobs(lcd_batch_t *b, int cap, uint64_t *t_off, int *tlen, uint64_t *q_off, int *qlen, const uint8_t **pool, uint64_t *pool_len);
 /* a 64-bit FNV-1a digest over every region's results (n_cons, clusters, all alignment rows) -- cheap whole-batch parity check */
 uint64_t lcd_batch_digest(lcd_batch_t *b);
 
@@ -241,6 +244,9 @@ int lcd_edlib_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_
 int lcd_wfa_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *p_off, const int *plen, const uint64_t *t_off,
                   const int *tlen, const int *gap_aln, int b, int q, int e, int q2, int e2, int want, int *score,
                   uint32_t *cigars, int cigar_stride, int *n_cigar, uint8_t *rows, int row_stride, int *aln_len);
+/* bytes of device work arena one alignment of optimal score <= score_bound occupies: the decision bytes of one block of scores (1 B per diagonal,
+ * 16 MB blocks) + the snapshots of the value ring, instead of 20 B x score^2 of retained wavefronts */
+uint64_t lcd_wfa_arena_bytes(int plen, int tlen, int score_bound, int b, int q, int e, int q2, int e2);
 /* POA chains with the anchor results supplied by the caller: mode 0 = K1 (src/align.c:762), 1 = K2 (:872).
  * anchors: 4 ints per read (ref_beg, ref_end, read_beg, read_end; 1-based).  Outputs are copied into caller arrays:
  * cons (2*cons_stride per chain), msa ((max_reads+2)*msa_stride per chain, row r at r*msa_stride), clu_ids (2*max_reads per chain). */

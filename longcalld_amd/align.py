@@ -89,6 +89,11 @@ def wfa_batch(pairs, gap_aln=GAP_LEFT_ALN, b=6, q=6, e=2, q2=24, e2=1):
             for i in range(n)]
 
 
+def wfa_arena_bytes(plen, tlen, score_bound, b=6, q=6, e=2, q2=24, e2=1):
+    """device work-arena bytes of one K3 alignment with the given score bound (lcd_wfa_arena_bytes)"""
+    return int(load_library().lcd_wfa_arena_bytes(int(plen), int(tlen), int(score_bound), b, q, e, q2, e2))
+
+
 def wfa_end2end_aln(pattern, text, gap_aln=GAP_LEFT_ALN, b=6, q=6, e=2, q2=24, e2=1):
     """wfa_end2end_aln through the per-call C mirror (exercises the malloc/ownership contract, src/align.c:374)."""
     lib = load_library()
@@ -219,6 +224,19 @@ class RegionBatch:
 
     def download(self):
         check(self.lib.lcd_batch_download(self.h), self.lib)
+
+    def k4_pairs(self):
+        """the (target, query) pairs of the batch's K4 jobs (lcd_batch_k4_jobs), copied out of the host pool"""
+        n = self.lib.lcd_batch_k4_jobs(self.h, 0, None, None, None, None, None, None)
+        if n <= 0:
+            return []
+        to, qo = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        tl, ql = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        pool, plen = u8p(), C.c_uint64(0)
+        self.lib.lcd_batch_k4_jobs(self.h, n, to.ctypes.data_as(u64p), tl.ctypes.data_as(i32p), qo.ctypes.data_as(u64p), ql.ctypes.data_as(i32p),
+                                   C.byref(pool), C.byref(plen))
+        h = np.ctypeslib.as_array(pool, shape=(plen.value,))
+        return [(h[int(to[i]):int(to[i]) + int(tl[i])].copy(), h[int(qo[i]):int(qo[i]) + int(ql[i])].copy()) for i in range(n)]
 
     def stats(self):
         st = LcdBatchStats()

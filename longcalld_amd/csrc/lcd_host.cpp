@@ -227,25 +227,45 @@ namespace {
 
 LcdScoring scoring_of(const lcd_opt_t &o) { LcdScoring s; s.match = o.match; s.mismatch = o.mismatch; s.o1 = o.gap_open1; s.e1 = o.gap_ext1; s.o2 = o.gap_open2; s.e2 = o.gap_ext2; s.dbg = getenv("LCD_DBG") ? atoi(getenv("LCD_DBG")) : 0; return s; }
 
-uint64_t wfa_arena_bytes(int plen, int tlen, int s_cap) {
-    // header + ops + sum_{s<=s_cap} 5*(2s+3) offsets, diagonals never exceed plen+tlen+3
-    uint64_t hdr = lcd_align_up((uint64_t)3 * (s_cap + 1) * 4 + (uint64_t)(plen + tlen + 2), 16);
-    uint64_t wmax = (uint64_t)plen + tlen + 3, tot = 0;
-    // closed form: widths min(2s+3, wmax)
-    uint64_t s_sw = wmax > 3 ? (wmax - 3) / 2 : 0; // scores with 2s+3 <= wmax
-    if ((uint64_t)s_cap <= s_sw) tot = (uint64_t)(s_cap + 1) * (s_cap + 3);
-    else tot = (s_sw + 1) * (s_sw + 3) + ((uint64_t)s_cap - s_sw) * wmax;
-    return hdr + tot * 5 * 4 + 256;
-}
 std::atomic<int> g_wfa_hint{0}; // 0..2: learned from the overflow retries of earlier ANCHOR stages (read vs read windows of noisy reads)
+// first score bound of a job (WfaJob.s_cap on entry of run_wfa_stage; overflow -> x4 + 64): the length difference as one long gap plus a little
+// divergence.  Since the wavefront values live in a ring (wfa_kernel.hip) the bound no longer sizes a quadratic arena of retained wavefronts
+// (20 B x s^2), only the decision bytes (1 B per diagonal, blocked and checkpointed above 16 MB) -- but a tight bound keeps the small jobs in
+// the LDS class: a job of score <= ~100 holds its whole value ring in 16-32 KB of LDS.
 int wfa_default_scap(int plen, int tlen, bool anchor = false) {
     int d = plen > tlen ? plen - tlen : tlen - plen;
     int m = plen < tlen ? plen : tlen;
-    // enough for the length difference as one long gap plus ~1.5 % divergence (the arena grows with the SQUARE of this bound: 6 % for
-    // everybody was 5-10 GB per 1 250 regions); jobs that overflow are retried with 4x, and data that keeps overflowing starts higher
-    static const double div[3] = {0.015, 0.06, 0.20};
-    long long s = 24 + d + 64 + (long long)(m * div[anchor ? g_wfa_hint.load() : 0]) * 6; // (ref<->cons and segment jobs are clean: no hint)
+    static const double div[3] = {0.005, 0.06, 0.20};
+    long long s = 24 + d + 40 + (long long)(m * div[anchor ? g_wfa_hint.load() : 0]) * 6; // (ref<->cons and segment jobs are clean: no hint)
     return (int)std::min<long long>(s, 2000000);
+}
+const int kWfaLdsBuckets[3] = {16 << 10, 32 << 10, 64 << 10};
+// class (value ring in LDS or HBM), decision-byte block and snapshots of one job for the score bound s_want
+void wfa_plan(WfaJob &j, const LcdScoring &sc, long long s_want) {
+    auto gap = [&](long long n) { return n <= 0 ? 0ll : std::min<long long>(sc.o1 + sc.e1 * n, sc.o2 + sc.e2 * n); };
+    const long long ub = gap(j.plen) + gap(j.tlen); // delete the pattern, insert the text: no optimal score is above it
+    s_want = std::max<long long>(8, std::min(s_want, ub));
+    WfaLayout L = wfa_layout(j.plen, j.tlen, (int)s_want, (int)s_want + 1, 0, 1, sc.mismatch, sc.o1, sc.e1, sc.o2, sc.e2);
+    const uint64_t blk_target = (uint64_t)(getenv("LCD_WFA_BLOCK_KB") ? atoi(getenv("LCD_WFA_BLOCK_KB")) : 16 << 10) << 10; // (test switch: tiny blocks)
+    if (L.ring_bytes <= (uint64_t)kWfaLdsBuckets[2] && L.blk_bytes <= blk_target) { j.lds = 1; j.s_cap = (int)s_want; j.blk_rows = j.s_cap + 1; j.n_ckpt = 0; }
+    else {
+        j.lds = 0;
+        if (L.blk_bytes <= blk_target) { j.s_cap = (int)s_want; j.blk_rows = j.s_cap + 1; j.n_ckpt = 0; }
+        else {
+            const long long w = L.w_cap - 2;
+            j.blk_rows = (int)std::max<long long>(32, (long long)(blk_target / (uint64_t)w));
+            j.n_ckpt = (int)((s_want + j.blk_rows) / j.blk_rows) - 1;
+            j.s_cap = j.blk_rows * (j.n_ckpt + 1) - 1;
+        }
+        L = wfa_layout(j.plen, j.tlen, j.s_cap, j.blk_rows, j.n_ckpt, 0, sc.mismatch, sc.o1, sc.e1, sc.o2, sc.e2);
+    }
+    j.ws_bytes = lcd_align_up(L.total, 256);
+}
+int wfa_class(const WfaJob &j, const LcdScoring &sc) { // 0: HBM ring, 1..3: LDS bucket
+    if (!j.lds) return 0;
+    const WfaLayout L = wfa_layout(j.plen, j.tlen, j.s_cap, j.blk_rows, 0, 1, sc.mismatch, sc.o1, sc.e1, sc.o2, sc.e2);
+    for (int b = 0; b < 3; ++b) if (L.ring_bytes <= (uint64_t)kWfaLdsBuckets[b]) return b + 1;
+    return 3;
 }
 uint64_t ed_arena_bytes(int qlen, int tlen) { return (uint64_t)52432 * 20 + (uint64_t)qlen * 8 + (uint64_t)tlen * 2 + 512; }
 
@@ -266,69 +286,75 @@ int run_edlib_stage(hipStream_t st, std::vector<EdJob> &jobs, DevBuf &d_jobs, De
     return 0;
 }
 
-// lays out arenas + outputs and launches; caller syncs and checks statuses. out_bytes per job = cigar area + rows area
 uint64_t wfa_out_bytes(const WfaJob &j) {
     uint64_t maxl = (uint64_t)j.plen + j.tlen + 1, o = 0;
     if (j.want & 1) o += lcd_align_up(maxl * 4, 16);
     if (j.want & 2) o += lcd_align_up(maxl * 2, 16);
     return o;
 }
-int launch_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, const std::vector<int> &which, DevBuf &d_jobs, DevBuf &d_arena,
-                     DevBuf &d_out, uint64_t out_base_reserved, DevBuf &d_outs, LcdScoring sc) {
-    // jobs[which[i]] get fresh arenas; out_off must already be set by the caller (absolute)
-    const int n = (int)which.size();
-    if (n == 0) return 0;
-    uint64_t tot = 0;
-    std::vector<WfaJob> sub(n);
-    for (int i = 0; i < n; ++i) {
-        WfaJob &j = jobs[which[i]];
-        j.ws_bytes = lcd_align_up(wfa_arena_bytes(j.plen, j.tlen, j.s_cap), 256); j.ws_off = tot; tot += j.ws_bytes;
-    }
-    if (getenv("LCD_MEM_DEBUG")) fprintf(stderr, "[mem] WFA stage: %d jobs, arena %.2f GB (hint %d)\n", n, tot / 1e9, g_wfa_hint.load());
-    if (d_arena.ensure(tot)) return -11;
-    for (int i = 0; i < n; ++i) { jobs[which[i]].ws_off += d_arena.addr(); sub[i] = jobs[which[i]]; }
-    if (d_jobs.ensure(n * sizeof(WfaJob)) || d_outs.ensure(n * sizeof(WfaOut))) return -11;
-    HIPCHK(hipMemcpyAsync(d_jobs.p, sub.data(), n * sizeof(WfaJob), hipMemcpyHostToDevice, st));
-    lcd_launch_wfa((const WfaJob *)d_jobs.p, nullptr, nullptr, nullptr, (WfaOut *)d_outs.p, sc, n, st);
-    HIPCHK(hipGetLastError());
-    (void)d_out; (void)out_base_reserved;
-    return 0;
-}
-// full WFA stage with the overflow retry ladder (s_cap x4)
+// WFA stage with the overflow retry ladder (score bound x4 + 64).  jobs[i].s_cap holds the wanted score bound on entry (wfa_default_scap);
+// every round plans the pending jobs (class, block, snapshots), launches the LDS buckets and the HBM-ring class and waits for the statuses.
 int run_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, DevBuf &d_jobs, DevBuf &d_arena, DevBuf &d_out, DevBuf &d_outs,
                   std::vector<WfaOut> &outs, LcdScoring sc, int *retries, bool learn = false) {
     const int n = (int)jobs.size();
     outs.assign(n, WfaOut());
     if (n == 0) return 0;
+    if (sc.e1 < 1 || sc.e2 < 1) return set_err(-2, "WFA: gap extension penalties must be >= 1");
     uint64_t otot = 0;
     std::vector<uint64_t> ooff(n);
     for (int i = 0; i < n; ++i) { ooff[i] = otot; otot += lcd_align_up(wfa_out_bytes(jobs[i]), 256); }
     if (d_out.ensure(otot)) return -11;
     for (int i = 0; i < n; ++i) jobs[i].out_off = d_out.addr() + ooff[i];
+    std::vector<long long> want(n);
+    for (int i = 0; i < n; ++i) want[i] = jobs[i].s_cap;
+    std::vector<int> first_want;
+    if (learn) { first_want.resize(n); for (int i = 0; i < n; ++i) first_want[i] = jobs[i].s_cap; }
     std::vector<int> which(n);
     for (int i = 0; i < n; ++i) which[i] = i;
-    for (int round = 0; round < 8 && !which.empty(); ++round) {
-        int rc = launch_wfa_stage(st, jobs, which, d_jobs, d_arena, d_out, 0, d_outs, sc);
-        if (rc) return rc;
-        std::vector<WfaOut> tmp(which.size());
-        HIPCHK(hipMemcpyAsync(tmp.data(), d_outs.p, which.size() * sizeof(WfaOut), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        std::vector<int> again;
-        for (size_t i = 0; i < which.size(); ++i) {
-            unsigned long long prev = outs[which[i]].offsets;
-            outs[which[i]] = tmp[i]; outs[which[i]].offsets += prev;
-            if (tmp[i].status == LCD_ERR_WF) { jobs[which[i]].s_cap = (int)std::min<long long>((long long)jobs[which[i]].s_cap * 4 + 64, 4000000); again.push_back(which[i]); }
-            else if (tmp[i].status != LCD_OK) return set_err(-20, "WFA kernel status " + std::to_string(tmp[i].status));
+    std::vector<WfaJob> sub; std::vector<WfaOut> tmp;
+    for (int round = 0; round < 10 && !which.empty(); ++round) {
+        const size_t m = which.size();
+        for (int i : which) wfa_plan(jobs[i], sc, want[i]);
+        // equal classes contiguous (one launch each); inside a class the largest arenas first (they last longest)
+        std::vector<int> cls(n, 0);
+        for (int i : which) cls[i] = wfa_class(jobs[i], sc);
+        std::stable_sort(which.begin(), which.end(), [&](int a, int b) { return cls[a] != cls[b] ? cls[a] < cls[b] : jobs[a].ws_bytes > jobs[b].ws_bytes; });
+        uint64_t tot = 0;
+        for (int i : which) { jobs[i].ws_off = tot; tot += jobs[i].ws_bytes; }
+        if (getenv("LCD_MEM_DEBUG")) {
+            size_t nl = 0, nck = 0; uint64_t big = 0; for (int i : which) { nl += jobs[i].lds; nck += jobs[i].n_ckpt > 0; big = std::max(big, jobs[i].ws_bytes); }
+            fprintf(stderr, "[mem] WFA stage round %d: %zu jobs (%zu in LDS, %zu checkpointed), arena %.3f GB, largest job %.1f MB (hint %d)\n", round, m, nl, nck, tot / 1e9, big / 1e6, g_wfa_hint.load());
         }
-        if (learn && round == 0 && again.size() * 20 > which.size() && g_wfa_hint.load() < 2) g_wfa_hint++;
+        if (d_arena.ensure(tot) || d_jobs.ensure(m * sizeof(WfaJob)) || d_outs.ensure(m * sizeof(WfaOut))) return -11;
+        sub.resize(m); tmp.resize(m);
+        for (size_t q = 0; q < m; ++q) { jobs[which[q]].ws_off += d_arena.addr(); sub[q] = jobs[which[q]]; }
+        HIPCHK(hipMemcpyAsync(d_jobs.p, sub.data(), m * sizeof(WfaJob), hipMemcpyHostToDevice, st));
+        for (size_t a = 0; a < m;) {
+            size_t b = a; const int c = cls[which[a]];
+            while (b < m && cls[which[b]] == c) ++b;
+            lcd_launch_wfa((const WfaJob *)d_jobs.p + a, nullptr, nullptr, nullptr, (WfaOut *)d_outs.p + a, sc, (int)(b - a), c ? kWfaLdsBuckets[c - 1] : 0, st);
+            HIPCHK(hipGetLastError());
+            a = b;
+        }
+        HIPCHK(hipMemcpyAsync(tmp.data(), d_outs.p, m * sizeof(WfaOut), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st)); // (`sub` and `tmp` outlive the copies: they are only touched again after this)
+        std::vector<int> again;
+        for (size_t q = 0; q < m; ++q) {
+            const int i = which[q];
+            const unsigned long long prev = outs[i].offsets;
+            outs[i] = tmp[q]; outs[i].offsets += prev;
+            if (tmp[q].status == LCD_ERR_WF) { want[i] = std::min<long long>((long long)jobs[i].s_cap * 4 + 64, 4000000); again.push_back(i); }
+            else if (tmp[q].status != LCD_OK) return set_err(-20, "WFA kernel status " + std::to_string(tmp[q].status));
+        }
+        if (learn && round == 0 && again.size() * 20 > m && g_wfa_hint.load() < 2) g_wfa_hint++;
         if (!again.empty() && retries) (*retries)++;
         which.swap(again);
     }
-    if (!which.empty()) return set_err(-21, "WFA arena exhausted after retries");
+    if (!which.empty()) return set_err(-21, "WFA score bound exhausted after retries");
     if (learn && getenv("LCD_MEM_DEBUG")) { // anchor stage: how the optimal scores compare with the first score bound
         double r_sum = 0; int cnt = 0, over = 0; double worst = 0;
-        for (int i = 0; i < n; ++i) { const int m = std::min(jobs[i].plen, jobs[i].tlen); if (m < 50) continue; const double r = (double)outs[i].score / m; r_sum += r; ++cnt; worst = std::max(worst, r); over += outs[i].score > wfa_default_scap(jobs[i].plen, jobs[i].tlen, true); }
-        fprintf(stderr, "[mem] anchor WFA: %d jobs >= 50 bp, score / min(len) mean %.3f max %.3f; %d above the current first bound\n", cnt, cnt ? r_sum / cnt : 0.0, worst, over);
+        for (int i = 0; i < n; ++i) { const int mm = std::min(jobs[i].plen, jobs[i].tlen); if (mm < 50) continue; const double r = (double)outs[i].score / mm; r_sum += r; ++cnt; worst = std::max(worst, r); over += outs[i].score > first_want[i]; }
+        fprintf(stderr, "[mem] anchor WFA: %d jobs >= 50 bp, score / min(len) mean %.3f max %.3f; %d above their first bound\n", cnt, cnt ? r_sum / cnt : 0.0, worst, over);
     }
     return 0;
 }
@@ -813,7 +839,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             ej_base[k] = ej.size(); wj_base[k] = wj.size();
             if (b->anchors.empty()) continue;
             for (EdJob j : b->ed_jobs) { j.q_off += in_base; j.t_off += in_base; ej.push_back(j); }
-            for (WfaJob j : b->wfa_jobs) { j.p_off += in_base; j.t_off += in_base; wj.push_back(j); }
+            for (WfaJob j : b->wfa_jobs) { j.p_off += in_base; j.t_off += in_base; j.s_cap = wfa_default_scap(j.plen, j.tlen, true); wj.push_back(j); } // (the hint may have risen since the region was added)
         }
         ej_base[nb] = ej.size(); wj_base[nb] = wj.size();
         if (!ej.empty() || !wj.empty()) {
@@ -1447,6 +1473,16 @@ int lcd_batch_region_sorted_ids(lcd_batch_t *b, int region, int *out) {
 
 int lcd_batch_get_stats(lcd_batch_t *b, lcd_batch_stats_t *st) { *st = b->st; return 0; }
 
+// the K4 (edlib NW + path) job set of the batch's anchor stage, as offsets into the batch's host pool: what bench.py times the reference's own
+// edlib on (cpu_baseline.k4_reference) next to lcd_edlib_kernel
+int lcd_batch_k4_jobs(lcd_batch_t *b, int cap, uint64_t *t_off, int *tlen, uint64_t *q_off, int *qlen, const uint8_t **pool, uint64_t *pool_len) {
+    const int n = (int)b->ed_jobs.size();
+    if (pool) *pool = b->h_pool.data();
+    if (pool_len) *pool_len = b->h_pool.size();
+    for (int i = 0; i < n && i < cap; ++i) { t_off[i] = b->ed_jobs[i].t_off; tlen[i] = b->ed_jobs[i].tlen; q_off[i] = b->ed_jobs[i].q_off; qlen[i] = b->ed_jobs[i].qlen; }
+    return n;
+}
+
 uint64_t lcd_batch_digest(lcd_batch_t *b) {
     if (!b->downloaded) return 0;
     uint64_t h = 1469598103934665603ull;
@@ -1501,6 +1537,14 @@ int lcd_edlib_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_
         if (n_xid) n_xid[i] = outs[i].n_xid;
     }
     return 0;
+}
+
+// work-arena bytes of one alignment whose score bound is `score_bound` (what run_wfa_stage lays out for it): DESIGN / tests
+uint64_t lcd_wfa_arena_bytes(int plen, int tlen, int score_bound, int b, int q, int e, int q2, int e2) {
+    WfaJob j; memset(&j, 0, sizeof(j)); j.plen = plen; j.tlen = tlen;
+    LcdScoring sc; sc.dbg = 0; sc.match = 0; sc.mismatch = b; sc.o1 = q; sc.e1 = e; sc.o2 = q2; sc.e2 = e2;
+    wfa_plan(j, sc, score_bound);
+    return j.ws_bytes;
 }
 
 int lcd_wfa_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *p_off, const int *plen, const uint64_t *t_off, const int *tlen,

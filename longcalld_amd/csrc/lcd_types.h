@@ -126,20 +126,55 @@ static inline LCD_HD uint64_t poa_out_bytes(int node_cap, int n_reads) {
 }
 
 // ---------------- WFA job (K3, src/align.c:374-460, heuristic none, affine-2p) ----------------
+// Bounded-memory wavefront alignment (wfa_kernel.hip).  Wavefront VALUES live in a ring of the last max(x, o1+e1, o2+e2) + 1 scores (LDS for the
+// small jobs, HBM for wide fronts); what is kept per (score, diagonal) is ONE byte of backtrace decisions.  Scores are cut into blocks of
+// `blk_rows`; only the current block's decision bytes are kept, plus a snapshot of the value ring at every block start (`n_ckpt` of them), so the
+// backtrace re-computes a block when it walks into it: memory ~ blk_rows x width + n_ckpt x ring instead of 20 B x score^2.
 struct WfaJob {
     uint64_t p_off, t_off; // pattern / text byte offsets in the device pool (inputs, or a chain's consensus)
     int plen, tlen;
     int gap_aln;           // 1 = left (reverse both, reverse outputs), 2 = right
     int want;              // bit0: cigar, bit1: aligned strings
-    int s_cap;             // max score the arena can hold
-    uint64_t ws_off;       // wavefront arena (byte offset)
+    int s_cap;             // max score the arena can hold = blk_rows * (n_ckpt + 1) - 1
+    int blk_rows, n_ckpt;  // decision-byte block (scores per block), number of ring snapshots
+    int lds;               // 1: value ring in LDS (single block, one wavefront per job); 0: ring in HBM (256 threads per job)
+    uint64_t ws_off;       // work arena (byte offset), laid out by wfa_layout
     uint64_t ws_bytes;
     uint64_t out_off;      // output: cigar uint32[plen+tlen+1] | or rows uint8[2*(plen+tlen+1)]
 };
 struct WfaOut {
     int status, score, n_cigar, aln_len;
-    unsigned long long offsets; // wavefront offsets computed (K3 algorithmic unit)
+    unsigned long long offsets; // wavefront offsets computed (K3 algorithmic unit), re-computed blocks included
 };
+// decision bytes of scores [0, s): the row of score s' holds the diagonals [-min(s', plen), min(s', tlen)] (|k| <= s' because every gap column costs >= 1)
+static inline LCD_HD uint64_t wfa_cum_half(long long s, long long L) { return s - 1 <= L ? (uint64_t)(s * (s - 1) / 2) : (uint64_t)(L * (L + 1) / 2 + (s - 1 - L) * L); }
+static inline LCD_HD uint64_t wfa_cum(long long s, long long plen, long long tlen) { return s <= 0 ? 0 : wfa_cum_half(s, plen) + wfa_cum_half(s, tlen) + (uint64_t)s; }
+struct WfaLayout {
+    int rm, r1, r2, rows;      // ring depth of M, of I1/D1, of I2/D2; rows = rm + 2*r1 + 2*r2
+    int w_cap, ev_cap;         // ring columns (widest row + 2 guard columns); capacity of the backtrace record list
+    uint64_t ring_bytes, blk_bytes;
+    uint64_t rec, runs, ring, ckpt, choice, total; // byte offsets relative to ws_off
+};
+static inline LCD_HD WfaLayout wfa_layout(int plen, int tlen, int s_cap, int blk_rows, int n_ckpt, int lds, int x, int o1, int e1, int o2, int e2) {
+    WfaLayout L;
+    int d = x; if (o1 + e1 > d) d = o1 + e1; if (o2 + e2 > d) d = o2 + e2;
+    L.rm = d + 1; L.r1 = e1 + 1; L.r2 = e2 + 1; L.rows = L.rm + 2 * L.r1 + 2 * L.r2;
+    const long long wl = s_cap < plen ? s_cap : plen, wr = s_cap < tlen ? s_cap : tlen;
+    L.w_cap = (int)(wl + wr + 3);
+    int cmin = x; if (o1 + e1 < cmin) cmin = o1 + e1; if (o2 + e2 < cmin) cmin = o2 + e2; if (cmin < 1) cmin = 1;
+    long long ev = (long long)s_cap / cmin + 4; if (ev > (long long)plen + tlen + 4) ev = (long long)plen + tlen + 4;
+    L.ev_cap = (int)ev;
+    L.ring_bytes = lcd_align_up((uint64_t)L.rows * L.w_cap * 4, 16);
+    L.blk_bytes = n_ckpt == 0 ? wfa_cum((long long)s_cap + 1, plen, tlen) : (uint64_t)blk_rows * (uint64_t)(L.w_cap - 2);
+    uint64_t o = 0;
+    L.rec = o; o = lcd_align_up(o + (uint64_t)L.ev_cap * 8, 16);
+    L.runs = o; o = lcd_align_up(o + ((uint64_t)2 * L.ev_cap + 4) * 8, 16);
+    L.ring = o; if (!lds) o += L.ring_bytes;
+    L.ckpt = o; o += (uint64_t)n_ckpt * L.ring_bytes;
+    L.choice = o; o = lcd_align_up(o + L.blk_bytes + 16, 256);
+    L.total = o;
+    return L;
+}
 
 // ---------------- edlib NW job (K4, src/align.c:222-232) ----------------
 struct EdJob {

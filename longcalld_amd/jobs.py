@@ -98,9 +98,75 @@ def make_region(rng, shape=HIFI, length=None, n_reads=None, flank=10):
                 haps=np.array(haps, np.int32), phase_sets=np.array(pss, np.int64), ref=ref)
 
 
+# BASELINE configs[4]: 60x ONT with injected 1-10 kb INS/DEL at 1 per 100 kb => per 10 Mb ~100 SV regions next to the
+# ordinary noisy regions.  An insertion's region is a short reference window whose carrier reads are sv_len longer; a deletion's region spans the
+# deleted bases (1-12 kb of reference; >= 10 kb takes the read-sampling path, src/align.c:719-728,1773) and its carrier reads are short.
+ONT60 = dict(ONT, name="ont60", depth=60)
+SV = dict(name="sv", err=0.05, hp_frac=0.5, depth=60, sv_min=1000, sv_max=10000, ctx_min=150, ctx_max=2000, read_len=20000.0,
+          untagged_frac=0.2, no_ps_frac=0.1, sv_per_10mb=100, base=ONT60)
+
+
+def make_sv_region(rng, shape=SV, kind=None, sv_len=None, ctx=None, n_reads=None, flank=10, phased=None):
+    """one SV region: kind 'ins' | 'del', sv_len bases inserted into / deleted from haplotype 1 of a reference window"""
+    kind = kind or ("ins" if rng.random() < 0.5 else "del")
+    sv_len = int(sv_len) if sv_len else int(np.exp(rng.uniform(np.log(shape["sv_min"]), np.log(shape["sv_max"]))))
+    ctx = int(ctx) if ctx else int(rng.integers(shape["ctx_min"], shape["ctx_max"]))
+    L = ctx if kind == "ins" else ctx + sv_len
+    ref = rng.integers(0, 4, L).astype(np.uint8)
+    p = int(rng.integers(flank + 20, ctx - flank - 20)) if ctx > 2 * flank + 60 else ctx // 2
+    if kind == "ins":
+        if rng.random() < 0.3:   # tandem duplication of the bases before the breakpoint (as many SV insertions are)
+            unit = ref[max(0, p - min(p, 400)):p]
+            ins = np.resize(unit, sv_len).astype(np.uint8) if len(unit) else rng.integers(0, 4, sv_len).astype(np.uint8)
+        else:
+            ins = rng.integers(0, 4, sv_len).astype(np.uint8)
+        hap1 = np.concatenate([ref[:p], ins, ref[p:]])
+    else:
+        hap1 = np.concatenate([ref[:p], ref[p + sv_len:]])
+    hap2 = ref.copy()
+    for hp in (0, 1):   # a few small heterozygous variants next to the SV
+        if rng.random() < 0.5:
+            h = hap1 if hp == 0 else hap2
+            q = int(rng.integers(flank + 2, max(flank + 3, min(len(h), ctx) - flank - 2)))
+            h[q] = (h[q] + 1 + rng.integers(0, 3)) % 4
+    hap_seq = [hap1.astype(np.uint8), hap2.astype(np.uint8)]
+    n = int(n_reads) if n_reads else int(np.clip(rng.poisson(shape["depth"]), 20, 120))
+    no_ps = (rng.random() < shape["no_ps_frac"]) if phased is None else (not phased)
+    ps = int(rng.integers(1000, 10_000_000))
+    seqs, covers, haps, pss, quals = [], [], [], [], []
+    for i in range(n):
+        h = int(rng.integers(0, 2))
+        s = _mutate(rng, hap_seq[h], shape["err"], shape["hp_frac"])
+        cover = BOTH
+        # a read of ~20 kb ends inside a region of length R with probability ~R / read_len
+        if rng.random() < min(0.5, 0.04 + len(hap_seq[h]) / shape["read_len"]) and len(s) > 60:
+            cut = int(rng.integers(30, len(s) - 20))
+            if rng.random() < 0.5:
+                s, cover = s[:cut], LEFT
+            else:
+                s, cover = s[cut:], RIGHT
+        tagged = (not no_ps) and rng.random() > shape["untagged_frac"]
+        seqs.append(s); covers.append(cover)
+        haps.append(h + 1 if tagged else 0)
+        pss.append(ps if tagged else -1)
+        q0 = int(rng.integers(12, 28))   # reads differ in quality: the sampling path orders by error rate (src/align.c:957-968)
+        quals.append(np.clip(q0 + rng.integers(-3, 4, len(s)), 2, 60).astype(np.uint8))
+    return dict(reg_len=L, read_ids=np.arange(n, dtype=np.int32) + 100, seqs=seqs, quals=quals, covers=np.array(covers, np.int32),
+                haps=np.array(haps, np.int32), phase_sets=np.array(pss, np.int64), ref=ref, sv=(kind, sv_len))
+
+
 def make_regions(seed, n_regions, shape=HIFI):
+    """n_regions region jobs of one shape; the SV shape mixes sv_per_10mb SV regions per 1 250 into ordinary 60x noisy-read regions (configs[4])"""
     rng = np.random.default_rng(seed)
-    return [make_region(rng, shape) for _ in range(n_regions)]
+    if shape.get("name") != "sv":
+        return [make_region(rng, shape) for _ in range(n_regions)]
+    n_sv = max(1, int(round(n_regions * shape["sv_per_10mb"] / 1250.0)))
+    is_sv = np.zeros(n_regions, bool)
+    is_sv[rng.choice(n_regions, n_sv, replace=False)] = True
+    return [make_sv_region(rng, shape) if f else make_region(rng, shape["base"]) for f in is_sv]
+
+
+SHAPES = {"hifi": HIFI, "ont": ONT, "ont60": ONT60, "sv": SV}
 
 
 def regions_for_ref_mb(ref_mb):

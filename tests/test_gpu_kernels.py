@@ -82,6 +82,62 @@ def test_wfa_large_gap_retry(lcd, oracle):
         assert (g["cigar"] == exp["cigar"]).all()
 
 
+def test_wfa_sv_10kb_gap_bounded_memory(lcd, oracle):
+    """SURVEY H3 / configs[4]: a 10 kb insertion (score ~ 10 000, 14 000 diagonals).  The retained-wavefront backtrace of the oracle needs ~2 GB;
+    the kernel keeps one byte of decisions per diagonal in 16 MB blocks + ring snapshots (checkpoint / recompute) -- same score, CIGAR and rows,
+    left- and right-aligned, insertion and deletion, in < 50 MB of arena"""
+    rng = np.random.default_rng(140)
+    ref = rng.integers(0, 4, 2000).astype(np.uint8)
+    ins = rng.integers(0, 4, 10000).astype(np.uint8)
+    cons = np.concatenate([ref[:900], ins, ref[900:]])
+    cons[400] = (cons[400] + 1) % 4; cons = np.delete(cons, [11500, 11501, 11502])
+    pairs = [(ref, cons), (cons, ref)]
+    for ga, prs in ((1, pairs), (2, pairs[:1])):   # (the oracle needs ~9 s and 2 GB per alignment of this size)
+        got = lcd.wfa_batch(prs, gap_aln=ga)
+        for g, (p, t) in zip(got, prs):
+            exp = oracle.wfa_end2end_aln(p, t, gap_aln=ga)
+            assert g["score"] == exp["score"] and 10000 < g["score"] < 10100
+            assert len(g["cigar"]) == len(exp["cigar"]) and (g["cigar"] == exp["cigar"]).all()
+            assert (g["pattern_alg"] == exp["pattern_alg"]).all() and (g["text_alg"] == exp["text_alg"]).all()
+            assert lcd.wfa_arena_bytes(len(p), len(t), g["score"]) < 50e6
+            assert lcd.wfa_arena_bytes(len(p), len(t), 4 * g["score"]) < 50e6     # (the bound a retry would ask for)
+
+
+def test_wfa_many_small_blocks(lcd, oracle, monkeypatch):
+    """the checkpoint / recompute path with tiny blocks (LCD_WFA_BLOCK_KB=8: a few dozen scores per block, tens of blocks per alignment):
+    the backtrace crosses block boundaries inside gap chains and between events -- == oracle"""
+    monkeypatch.setenv("LCD_WFA_BLOCK_KB", "8")
+    rng = np.random.default_rng(141)
+    pairs = []
+    for L, rate, sv in [(300, 0.1, 0), (800, 0.2, 0), (1500, 0.05, 0.004), (600, 0.0, 0)]:
+        t = rng.integers(0, 4, L).astype(np.uint8)
+        p = mutate(rng, t, rate, sv)
+        pairs += [(p, t), (t, p)]
+    t = rng.integers(0, 4, 700).astype(np.uint8)
+    pairs += [(np.concatenate([t[:300], rng.integers(0, 4, 500).astype(np.uint8), t[300:]]), t), (t, np.concatenate([t[:100], t[450:]]))]
+    for ga in (1, 2):
+        got = lcd.wfa_batch(pairs, gap_aln=ga)
+        for i, (p, t) in enumerate(pairs):
+            exp = oracle.wfa_end2end_aln(p, t, gap_aln=ga)
+            assert got[i]["score"] == exp["score"], (ga, i)
+            assert len(got[i]["cigar"]) == len(exp["cigar"]) and (got[i]["cigar"] == exp["cigar"]).all(), (ga, i)
+            assert (got[i]["pattern_alg"] == exp["pattern_alg"]).all() and (got[i]["text_alg"] == exp["text_alg"]).all(), (ga, i)
+
+
+def test_wfa_other_penalties(lcd, oracle):
+    """ring depths follow the penalties (max(x, o1+e1, o2+e2) + 1 rows of M): a non-default scoring == oracle"""
+    rng = np.random.default_rng(142)
+    pairs = []
+    for L in (50, 400, 900):
+        t = rng.integers(0, 4, L).astype(np.uint8)
+        pairs += [(mutate(rng, t, 0.08, 0.003), t)]
+    for (b, q, e, q2, e2) in [(4, 6, 2, 24, 1), (6, 6, 2, 24, 1), (5, 8, 3, 30, 2), (2, 3, 1, 10, 1)]:
+        got = lcd.wfa_batch(pairs, gap_aln=2, b=b, q=q, e=e, q2=q2, e2=e2)
+        for g, (p, t) in zip(got, pairs):
+            exp = oracle.wfa_end2end_aln(p, t, gap_aln=2, b=b, q=q, e=e, q2=q2, e2=e2)
+            assert g["score"] == exp["score"] and len(g["cigar"]) == len(exp["cigar"]) and (g["cigar"] == exp["cigar"]).all()
+
+
 def test_wfa_per_call_mirror_ownership(lcd, oracle):
     """lcd_wfa_end2end_aln: malloc'd cigar + one-block rows (text row = block + plen+tlen+1), src/align.c:288-291,490"""
     rng = np.random.default_rng(15)

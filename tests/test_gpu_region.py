@@ -3,7 +3,7 @@ collect_noisy_reg_aln_strs (src/align.c:1760) on seeded synthetic region jobs, H
 import numpy as np
 import pytest
 
-from conftest import same_result
+from conftest import check_invariants as _check_invariants, same_result
 
 pytestmark = pytest.mark.gpu
 
@@ -223,40 +223,6 @@ def test_per_call_mirror(lcd, oracle):
         s = (a0, a1)[c][0]
         t = np.ctypeslib.as_array(s.target_aln, shape=(s.aln_len,))
         assert (t == exp["aln_strs"][c][0]["target"]).all()
-
-
-def _check_invariants(reg, res):
-    """size-independent properties of a region result: clusters partition reads, every string de-gaps to its inputs"""
-    if res["n_cons"] == 0:
-        return 0
-    ids = list(reg["read_ids"])
-    seen = []
-    n_str = 0
-    for c in range(res["n_cons"]):
-        rc = res["aln_strs"][c][0]
-        assert rc is not None and len(rc["target"]) == rc["aln_len"] == len(rc["query"])
-        assert (rc["target"][rc["target"] != 5] == reg["ref"]).all()          # ref row of ref<->cons de-gaps to the reference slice
-        cons = rc["query"][rc["query"] != 5]
-        assert not ((rc["target"] == 5) & (rc["query"] == 5)).any()
-        members = res["clu_read_ids"][c]
-        assert len(members) == res["clu_n_seqs"][c]
-        seen += list(members)
-        for j, rid in enumerate(members):
-            s = res["aln_strs"][c][2 * j + 1]
-            if s is None:
-                continue
-            n_str += 1
-            read = reg["seqs"][ids.index(rid)]
-            q = s["query"][s["query"] != 5]
-            t = s["target"][s["target"] != 5]
-            assert len(s["target"]) == s["aln_len"]
-            if reg["covers"][ids.index(rid)] == 12:                            # full cover: the rows are the whole consensus and the whole read
-                assert q.tobytes() == read.tobytes() and t.tobytes() == cons.tobytes()
-            else:   # partial cover: the row may carry the anchor node's base at either end (the sub-graph alignment labels the edge out of
-                    # the anchor node with the read, src/align.c:797-803), everything between is the read
-                assert q[1:-1].tobytes() in read.tobytes() and t.tobytes() in cons.tobytes()
-    assert len(seen) == len(set(seen)) and set(seen) <= set(ids)
-    return n_str
 
 
 def test_full_size_batch_properties(lcd):
