@@ -6,6 +6,13 @@
  * INTEGRATION.md shows the few lines a longcallD maintainer adds to src/align.c / src/assign_hap.c /
  * src/collect_var.c to route the reference's own symbols here.
  *
+ * PARITY STATUS (read before relying on byte identity with a real longcallD build):
+ *   pinned to the reference's own code compiled in this project's container: K4 (edlib: distance, path, xgaps), the cgranges interval order, sdust;
+ *   PARITY UNPINNED for K1/K2 (abPOA) and K3 (WFA2): the abPOA / WFA2-lib submodules are empty in the reference checkout, so consensus, MSA and CIGAR
+ *   tie-breaks follow this project's restatement of the published algorithms (oracle/poa.c, oracle/wfa2p.c), pinned at score level only;
+ *   K5, the align.c glue, f1 and f2 are line-by-line restatements of source that IS present, but no reference binary can be built here to confirm them.
+ *   tests/test_replay_reference_dump.py replays `longcallD call -V 3` dumps of a real build once one is available (skipped until then).
+ *
  * Conventions kept from the reference:
  *   - byte codes A0 C1 G2 T3 N4, gap 5 (src/seq.c:14-31, src/align.c:316,321);
  *   - buffers handed back are libc malloc()'d and owned by the caller, with the reference's interior
@@ -88,6 +95,15 @@ int lcd_wfa_end2end_aln(uint8_t *pattern, int plen, uint8_t *text, int tlen, int
 int lcd_edlib_end2end_aln(uint8_t *target, int tlen, uint8_t *query, int qlen, int *n_eq, int *n_xid);
 int lcd_edlib_xgaps(uint8_t *target, int tlen, uint8_t *query, int qlen);
 int lcd_edlib_edit_distance(uint8_t *target, int tlen, uint8_t *query, int qlen);
+
+/* replaces end2end_aln (src/align.c:610; exported src/align.h:56, no caller in src) and wfa_collect_diff_ins_seq (src/align.c:463; callers
+ * src/collect_var.c:203 and, with -s, src/assign_hap.c:1280): both are thin wrappers over the 2-piece WFA above */
+int lcd_end2end_aln(const lcd_opt_t *opt, char *tseq, int tlen, uint8_t *qseq, int qlen, uint32_t **cigar_buf);
+int lcd_wfa_collect_diff_ins_seq(const lcd_opt_t *opt, uint8_t *large_seq, int large_len, uint8_t *small_seq, int small_len, uint8_t **diff_seq);
+/* src/align.h:54,60: edlib_infix_aln (edlib HW mode; every caller is somatic-mode code) and wfa_heuristic_aln (x-drop; no caller) are exported
+ * so that longcallD links against this library alone; they return -2, set lcd_last_error() and print to stderr -- never a silent result */
+int lcd_edlib_infix_aln(uint8_t *target, int tlen, uint8_t *query, int qlen, int *n_eq, int *n_xid);
+int lcd_wfa_heuristic_aln(uint8_t *pattern, int plen, uint8_t *text, int tlen, int a, int b, int q, int e, int q2, int e2, int *n_eq, int *n_xid);
 
 /* replaces collect_noisy_reg_aln_strs (src/align.c:1760) with bam_chunk_t flattened to per-read views.
  * noisy_reads[] is permuted in place exactly as the reference does (src/align.c:1774). */

@@ -75,7 +75,7 @@ _lib = None
 # every symbol include/lcd_hotpath.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "lcd_opt_default", "lcd_init", "lcd_device_count", "lcd_set_thread_device", "lcd_batch_create_on", "lcd_last_error", "lcd_version", "lcd_wfa_end2end_aln", "lcd_edlib_end2end_aln",
-    "lcd_edlib_xgaps", "lcd_edlib_edit_distance", "lcd_collect_noisy_reg_aln_strs", "lcd_batch_create", "lcd_batch_destroy",
+    "lcd_edlib_xgaps", "lcd_edlib_edit_distance", "lcd_end2end_aln", "lcd_wfa_collect_diff_ins_seq", "lcd_edlib_infix_aln", "lcd_wfa_heuristic_aln", "lcd_collect_noisy_reg_aln_strs", "lcd_batch_create", "lcd_batch_destroy",
     "lcd_batch_clear", "lcd_batch_region_vars", "lcd_digar_opt_default", "lcd_digar_batch", "lcd_pre_process_noisy_regs", "lcd_post_process_noisy_regs", "lcd_sdust", "lcd_batch_add_region", "lcd_batch_add_region_from_chunk", "lcd_batch_upload", "lcd_batch_run", "lcd_batch_run_many",
     "lcd_batch_download", "lcd_batch_region_result", "lcd_batch_region_sorted_ids", "lcd_batch_get_stats", "lcd_batch_k4_jobs", "lcd_batch_digest",
     "lcd_edlib_batch", "lcd_wfa_batch", "lcd_wfa_arena_bytes", "lcd_poa_batch", "lcd_assign_hap_germline", "lcd_assign_hap_batch",
@@ -99,6 +99,10 @@ def load_library():
     lib.lcd_batch_create.restype = C.c_void_p
     lib.lcd_batch_create.argtypes = [C.POINTER(LcdOpt)]
     lib.lcd_batch_k4_jobs.argtypes = [C.c_void_p, C.c_int, u64p, i32p, u64p, i32p, C.POINTER(u8p), u64p]
+    lib.lcd_end2end_aln.argtypes = [C.POINTER(LcdOpt), C.c_char_p, C.c_int, u8p, C.c_int, C.POINTER(u32p)]
+    lib.lcd_wfa_collect_diff_ins_seq.argtypes = [C.POINTER(LcdOpt), u8p, C.c_int, u8p, C.c_int, C.POINTER(u8p)]
+    lib.lcd_edlib_infix_aln.argtypes = [u8p, C.c_int, u8p, C.c_int, i32p, i32p]
+    lib.lcd_wfa_heuristic_aln.argtypes = [u8p, C.c_int, u8p, C.c_int] + [C.c_int] * 6 + [i32p, i32p]
     lib.lcd_wfa_arena_bytes.restype = C.c_uint64
     lib.lcd_wfa_arena_bytes.argtypes = [C.c_int] * 8
     lib.lcd_batch_create_on.restype = C.c_void_p

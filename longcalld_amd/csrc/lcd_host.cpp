@@ -2062,6 +2062,51 @@ int lcd_wfa_end2end_aln(uint8_t *pattern, int plen, uint8_t *text, int tlen, int
     return 0;
 }
 
+// end2end_aln (src/align.c:610-628): target given as letters, mapped with nst_nt4_table (src/seq.c:14-31: ACGT / acgt -> 0..3, '-' -> 5, else 4;
+// the bytes 0..3 map to themselves), then the 2-piece WFA with opt's penalties; returns the CIGAR length, *cigar_buf malloc()'d
+int lcd_end2end_aln(const lcd_opt_t *opt, char *tseq, int tlen, uint8_t *qseq, int qlen, uint32_t **cigar_buf) {
+    if (qlen <= 0 || tlen <= 0) return 0;
+    std::vector<uint8_t> t2((size_t)tlen);
+    for (int i = 0; i < tlen; ++i) {
+        const uint8_t c = (uint8_t)tseq[i];
+        t2[i] = c < 4 ? c : (c == 'A' || c == 'a') ? 0 : (c == 'C' || c == 'c') ? 1 : (c == 'G' || c == 'g') ? 2 : (c == 'T' || c == 't') ? 3 : c == '-' ? 5 : 4;
+    }
+    int cigar_len = 0;
+    const int rc = lcd_wfa_end2end_aln(t2.data(), tlen, qseq, qlen, opt->gap_aln, opt->mismatch, opt->gap_open1, opt->gap_ext1, opt->gap_open2, opt->gap_ext2, 0, 1,
+                                       cigar_buf, &cigar_len, nullptr, nullptr, nullptr);
+    return rc < 0 ? rc : cigar_len;
+}
+// wfa_collect_diff_ins_seq (src/align.c:463-494): align large vs small, return the longest run of large-only columns (first one on ties)
+int lcd_wfa_collect_diff_ins_seq(const lcd_opt_t *opt, uint8_t *large_seq, int large_len, uint8_t *small_seq, int small_len, uint8_t **diff_seq) {
+    uint8_t *la = nullptr, *sa = nullptr; int aln_len = 0;
+    const int rc = lcd_wfa_end2end_aln(large_seq, large_len, small_seq, small_len, opt->gap_aln, opt->mismatch, opt->gap_open1, opt->gap_ext1, opt->gap_open2, opt->gap_ext2, 0, 1,
+                                       nullptr, nullptr, &la, &sa, &aln_len);
+    if (rc < 0) return rc;
+    int best_len = 0, best_pos = -1;
+    for (int i = 0; i < aln_len; ++i) {
+        if (sa[i] == 5 && la[i] != 5) {
+            int j = i; while (j < aln_len && sa[j] == 5 && la[j] != 5) ++j;
+            if (j - i > best_len) { best_len = j - i; best_pos = i; }
+            i = j - 1;
+        }
+    }
+    if (best_len > 0) { *diff_seq = (uint8_t *)malloc((size_t)best_len); memcpy(*diff_seq, la + best_pos, (size_t)best_len); }
+    free(la);
+    return best_len;
+}
+// The two exports of src/align.h that the germline path never reaches (edlib_infix_aln is only called from somatic-mode code,
+// wfa_heuristic_aln has no caller at all): present so that a longcallD built against this library links, and loud when reached
+int lcd_edlib_infix_aln(uint8_t *, int, uint8_t *, int, int *n_eq, int *n_xid) {
+    if (n_eq) *n_eq = -1; if (n_xid) *n_xid = -1;
+    fprintf(stderr, "liblcd_hotpath: edlib_infix_aln (edlib HW mode, src/align.c:256) is a somatic-mode (-s) call and is not implemented\n");
+    return set_err(-2, "edlib_infix_aln (HW mode) is not implemented: somatic mode (-s) is out of scope");
+}
+int lcd_wfa_heuristic_aln(uint8_t *, int, uint8_t *, int, int, int, int, int, int, int, int *n_eq, int *n_xid) {
+    if (n_eq) *n_eq = -1; if (n_xid) *n_xid = -1;
+    fprintf(stderr, "liblcd_hotpath: wfa_heuristic_aln (x-drop WFA, src/align.c:332) has no caller in longcallD and is not implemented\n");
+    return set_err(-2, "wfa_heuristic_aln (x-drop heuristic) is not implemented");
+}
+
 static int ed1(uint8_t *target, int tlen, uint8_t *query, int qlen, int *dist, int *xg, int *neq, int *nxid) {
     std::vector<uint8_t> pool((size_t)lcd_align_up(qlen, 16) + tlen + 32, 4);
     if (qlen) memcpy(pool.data(), query, qlen);

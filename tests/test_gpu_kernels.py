@@ -46,6 +46,65 @@ def test_edlib_hirschberg_regime(lcd, oracle):
         assert (got["dist"][i], got["n_eq"][i], got["n_xid"][i]) == (d, neq, nxid), i
 
 
+def test_edlib_kernel_matches_reference_golden_vectors(lcd):
+    """the HIP K4 kernel itself against tests/golden/edlib_golden.json -- vectors produced by the REFERENCE's own edlib
+    (tests/golden/make_edlib_golden.py): distance, the path-dependent xgaps and the =/XID counts, both traceback regimes (edlib.cpp:1188)"""
+    import json
+    import os
+    from conftest import ROOT
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "edlib_golden.json")))["cases"]
+    arr = lambda s: np.frombuffer(s.encode(), np.uint8) - ord("0")
+    pairs = [(arr(c["target"]), arr(c["query"])) for c in cases]
+    got = lcd.edlib_batch(pairs)
+    assert len(cases) >= 70
+    for i, c in enumerate(cases):
+        assert got["dist"][i] == c["dist"] and got["xgaps"][i] == c["xgaps"], i
+        assert got["n_eq"][i] == c["n_eq"] and got["n_xid"][i] == c["n_xid"], i
+
+
+def test_align_h_wrappers(lcd, oracle):
+    """the remaining exports of src/align.h: end2end_aln (:610, letters -> codes -> 2-piece WFA CIGAR) and wfa_collect_diff_ins_seq (:463, the longest
+    run of large-only columns) == the same composition over the oracle's WFA; edlib_infix_aln / wfa_heuristic_aln exist and fail loudly"""
+    import ctypes as C
+    from longcalld_amd import _lib
+    lib = _lib.load_library()
+    rng = np.random.default_rng(31)
+    opt = lcd.default_opt()
+    u8p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
+    libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]
+    t = rng.integers(0, 4, 400).astype(np.uint8)
+    q = mutate(rng, t, 0.03, 0.004)
+    letters = bytes(b"ACGT"[x] for x in t)
+    cb = u32p()
+    n = lib.lcd_end2end_aln(C.byref(opt), letters, len(letters), q.ctypes.data_as(u8p), len(q), C.byref(cb))
+    exp = oracle.wfa_end2end_aln(t, q, gap_aln=opt.gap_aln)
+    assert n == len(exp["cigar"]) and (np.ctypeslib.as_array(cb, shape=(n,)) == exp["cigar"]).all()
+    libc.free(cb)
+    small = rng.integers(0, 4, 300).astype(np.uint8)
+    large = np.concatenate([small[:120], rng.integers(0, 4, 75).astype(np.uint8), small[120:200], rng.integers(0, 4, 20).astype(np.uint8), small[200:]])
+    ds = u8p()
+    n = lib.lcd_wfa_collect_diff_ins_seq(C.byref(opt), large.ctypes.data_as(u8p), len(large), small.ctypes.data_as(u8p), len(small), C.byref(ds))
+    e = oracle.wfa_end2end_aln(large, small, gap_aln=opt.gap_aln)
+    la, sa = e["pattern_alg"], e["text_alg"]
+    best, pos, i = 0, -1, 0
+    while i < len(la):
+        if sa[i] == 5 and la[i] != 5:
+            j = i
+            while j < len(la) and sa[j] == 5 and la[j] != 5:
+                j += 1
+            if j - i > best:
+                best, pos = j - i, i
+            i = j
+        else:
+            i += 1
+    assert n == best == 75 and (np.ctypeslib.as_array(ds, shape=(n,)) == la[pos:pos + best]).all()
+    libc.free(ds)
+    a, b = C.c_int(7), C.c_int(7)
+    assert lib.lcd_edlib_infix_aln(t.ctypes.data_as(u8p), len(t), q.ctypes.data_as(u8p), len(q), C.byref(a), C.byref(b)) == -2 and a.value == -1
+    assert b"not implemented" in lib.lcd_last_error()
+    assert lib.lcd_wfa_heuristic_aln(t.ctypes.data_as(u8p), len(t), q.ctypes.data_as(u8p), len(q), 0, 6, 6, 2, 24, 1, C.byref(a), C.byref(b)) == -2
+
+
 def test_edlib_empty(lcd):
     got = lcd.edlib_batch([(np.zeros(0, np.uint8), np.zeros(5, np.uint8)), (np.zeros(7, np.uint8), np.zeros(0, np.uint8))])
     assert list(got["dist"]) == [5, 7] and list(got["xgaps"]) == [0, 0]  # edlib.cpp:166-173: no alignment is produced

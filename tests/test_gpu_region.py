@@ -328,3 +328,34 @@ def test_concurrent_callers(lcd):
     for t in ths:
         t.join()
     assert not errs and got == serial
+
+
+def test_device_per_batch_and_per_thread(lcd):
+    """one process drives every GPU (SURVEY 8b threading; the reference's kt_for workers are threads): a batch is created ON a device, a worker
+    thread selects its device for the per-call mirrors; same results, bad indices fail"""
+    import threading
+    from longcalld_amd import jobs, _lib
+    lib = _lib.load_library()
+    n = lib.lcd_device_count()
+    assert n >= 1
+    regs = jobs.make_regions(55, 8)
+    ref = _run_batch(lcd, regs)[3]
+    got = {}
+
+    def work(dev):
+        assert lib.lcd_set_thread_device(dev) == 0
+        b = lcd.RegionBatch(device=dev)
+        for r in regs:
+            b.add_region(r)
+        b.upload(); b.run(); b.download(); got[dev] = b.digest(); b.close()
+        t = np.random.default_rng(1).integers(0, 4, 200).astype(np.uint8)
+        got[("ed", dev)] = lcd.edlib_xgaps(t, np.delete(t, [7, 8, 90]))
+    ths = [threading.Thread(target=work, args=(d,)) for d in range(n)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert all(got[d] == ref for d in range(n)) and all(got[("ed", d)] == 2 for d in range(n))
+    assert lib.lcd_set_thread_device(n) != 0
+    with pytest.raises(Exception):
+        lcd.RegionBatch(device=n)
