@@ -27,9 +27,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured co
 
 
 def _gen(a):
-    seed, n_regions, shape_name = a
+    seed, n_regions, shape_name = a[:3]
     from longcalld_amd import jobs
-    return jobs.make_regions(seed, n_regions, jobs.SHAPES[shape_name])
+    return jobs.make_regions(seed, n_regions, jobs.SHAPES[shape_name], poisson_sv=len(a) > 3 and a[3])
 
 
 def _cpu_worker(a):
@@ -100,8 +100,11 @@ def main():
     ap.add_argument("--steps", type=int, default=192)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ref-mb", type=float, default=10.0, help="synthetic reference size per step (10 Mb = configs[1]: 1 250 regions)")
-    ap.add_argument("--job-mb", type=float, default=0.0, help="time ONE job of this many Mb (job-mb / ref-mb distinct batches) sharded over the ranks "
-                    "(configs[3] / configs[4]); --steps is ignored, scaling is strong")
+    ap.add_argument("--job-mb", type=float, default=0.0, help="time ONE job of this many Mb sharded over the ranks (configs[3] / configs[4]): 500 kb chunks "
+                    "(the reference's unit of work, src/bam_utils.h:10) in contiguous blocks per rank, rebalanced, then submitted ref-mb at a time; "
+                    "--steps is ignored, scaling is strong")
+    ap.add_argument("--rebalance", type=int, default=1, help="--job-mb with N > 1: one RCCL epoch of queue rebalancing before the timed run "
+                    "(longcalld_amd/rebalance.py: all_gather of the queues, whole packed chunks sent from the deepest to the shallowest); 0 = keep the contiguous blocks")
     ap.add_argument("--distinct", type=int, default=10, help="distinct-seed batches the timed steps cycle over (10 x 10 Mb = 100 Mb of distinct regions)")
     ap.add_argument("--shape", default="hifi", choices=["hifi", "ont", "ont60", "sv"])
     ap.add_argument("--cpu-sample", type=int, default=200, help="cap on regions per CPU worker of the cpu_baseline leg, which is bounded to ~12 s (rank 0, N=1 only; 0 = skip)")
@@ -128,17 +131,22 @@ def main():
     job_mode = args.job_mb > 0
 
     # ---- synthetic region jobs first (worker processes forked before torch / HIP start): timed seeds and, disjoint from them, warm-up seeds ----
+    CHUNK_MB = 0.5
     if job_mode:
-        n_job = max(1, int(round(args.job_mb / args.ref_mb)))
-        timed_seeds = [args.seed + i for i in range(n_job)]                      # the same job on every rank; sharded below
+        # the job's chunks in genome order; this rank generates only its contiguous block, the rebalance epoch below moves whole chunks
+        n_chunks = max(1, int(round(args.job_mb / CHUNK_MB)))
+        lo, hi = rank * n_chunks // world, (rank + 1) * n_chunks // world
+        timed_seeds = [args.seed + i for i in range(lo, hi)]
+        regs_per_unit = jobs.regions_for_ref_mb(CHUNK_MB)
     else:
         timed_seeds = [args.seed + 1000 * rank + i for i in range(max(1, args.distinct))]   # weak scaling: same work per GPU, different seeds
+        regs_per_unit = n_regions
     n_warm_seeds = 3 if args.warmup else 0
     warm_seeds = [args.seed + 500000 + 1000 * rank + i for i in range(n_warm_seeds)]
     import multiprocessing as mp
-    n_gen_procs = max(1, min(len(timed_seeds) + len(warm_seeds), _host_cores() // max(1, world if world > 1 else 1)))
+    n_gen_procs = max(1, min(len(timed_seeds) + len(warm_seeds), _host_cores() // max(1, world)))
     with mp.get_context("fork").Pool(n_gen_procs) as pool:
-        gen = pool.map(_gen, [(sd, n_regions, args.shape) for sd in timed_seeds + warm_seeds], chunksize=1)
+        gen = pool.map(_gen, [(sd, regs_per_unit, args.shape, job_mode) for sd in timed_seeds] + [(sd, n_regions, args.shape) for sd in warm_seeds], chunksize=1)
     timed_regs, warm_regs = gen[:len(timed_seeds)], gen[len(timed_seeds):]
 
     import torch
@@ -165,20 +173,27 @@ def main():
     # defaults (measured): HiFi shape = two lanes of 32 batches per submission when there are enough steps for each lane to
     # have two submissions (one lane's anchor / WFA / string stages and the tail of its chain launches overlap the other lane's chains),
     # else one lane of up to 32; the noisy-read shapes (4x graph estimates, ~8 GB per batch in flight) run one lane of 24 (sv: 8)
+    rb_stats = None
     if job_mode:
-        # static sharding of the job's batches by their read bases, longest first (LPT); every rank computes the same assignment
-        cost = [sum(sum(len(x) for x in r["seqs"]) * 1.0 for r in regs) for regs in timed_regs]
-        order = sorted(range(len(cost)), key=lambda i: -cost[i])
-        load = [0.0] * world
-        mine = []
-        for i in order:
-            w = min(range(world), key=lambda r_: load[r_])
-            load[w] += cost[i]
-            if w == rank:
-                mine.append(i)
-        timed_regs = [timed_regs[i] for i in mine]
+        from longcalld_amd import rebalance as rb
+        queue = [(sum(rb.region_cost(r) for r in regs), rb.pack_regions(regs)) for regs in timed_regs]
+        if world > 1 and args.rebalance:
+            t_rb = time.perf_counter()
+            queue, rb_stats = rb.rebalance(queue, device=dev)
+            rb_stats["seconds"] = round(time.perf_counter() - t_rb, 4)
+        else:
+            loads = [sum(c for c, _ in queue)]
+            if world > 1:
+                lt = torch.tensor(loads, dtype=torch.float64, device=dev); al = [torch.zeros_like(lt) for _ in range(world)]
+                dist.all_gather(al, lt); loads = [float(x.item()) for x in al]
+            rb_stats = {"n_moves": 0, "moved_bytes": 0, "imbalance_before": max(loads) / (sum(loads) / len(loads)) if sum(loads) > 0 else 1.0, "loads_before": loads}
+            rb_stats["imbalance_after"] = rb_stats["imbalance_before"]
+        # this rank's chunks, heaviest first, ref-mb of them per batch (= one step)
+        queue.sort(key=lambda q: -q[0])
+        per = max(1, int(round(args.ref_mb / CHUNK_MB)))
+        chunks = [rb.unpack_regions(b) for _, b in queue]
+        timed_regs = [[r for ch in chunks[i:i + per] for r in ch] for i in range(0, len(chunks), per)]
         args.steps = len(timed_regs)
-        lpt_imbalance = max(load) / (sum(load) / world) if sum(load) > 0 else 1.0
     if args.lanes <= 0:
         args.lanes = 2 if (args.shape == "hifi" and args.coalesce <= 0 and args.steps >= 128) else 1
     if args.coalesce <= 0:
@@ -369,7 +384,7 @@ def main():
             "config": {"workload": f"{cfg_name}: synthetic {shape['depth']}x {shape['name']} region jobs, {args.ref_mb:g} Mb of reference per step "
                                    f"({n_regions} regions/step, ~{tot_bases / max(world, 1) / steps / 1e6:.1f} Mbase POA-aligned/step)",
                        "regions_per_step": n_regions, "distinct_batches_per_gpu": len(timed_regs), "warmup_on_other_seeds": bool(n_warm),
-                       "sharding": ("LPT over the job's batches by read bases" if job_mode else "per-rank seeds") + ", no data-path collective",
+                       "sharding": "per-rank seeds, no data-path collective",
                        "lanes_per_gpu": n_lanes, "coalesced_steps_per_submission": n_co},
             "poa_aligned_bases_per_sec": round(tot_bases / elapsed, 1),
             "regions_resolved": int(acc["resolved"]),
@@ -386,7 +401,9 @@ def main():
             "cpu_baseline": cpu,
         }
         if job_mode:
-            out["lpt_imbalance"] = round(lpt_imbalance, 4)
+            out["queue_rebalance"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in (rb_stats or {}).items() if not k.startswith("loads")}
+            out["config"]["sharding"] = (f"{int(round(args.job_mb / CHUNK_MB))} chunks of {CHUNK_MB} Mb in contiguous blocks per rank"
+                                         + (", one RCCL rebalance epoch (whole packed chunks moved)" if world > 1 and args.rebalance else "") + ", no data-path collective")
         print(json.dumps(out), flush=True)
     for bt in batches:
         bt.close()

@@ -156,8 +156,11 @@ typedef struct lcd_batch_stats_t {
     double ms_vars;         /* stage S6 (opt.collect_noisy_vars) */
 } lcd_batch_stats_t;
 
+#define LCD_DEVICE_ANY (-2)
 lcd_batch_t *lcd_batch_create(const lcd_opt_t *opt);                 /* on the calling thread's device */
-lcd_batch_t *lcd_batch_create_on(const lcd_opt_t *opt, int device);  /* batches of one lcd_batch_run_many call share a device */
+/* device >= 0: that GPU; -1: the calling thread's; LCD_DEVICE_ANY: a host-only job buffer whose device is chosen at upload / dispatch time.
+ * Batches of one lcd_batch_run_many call share a device. */
+lcd_batch_t *lcd_batch_create_on(const lcd_opt_t *opt, int device);
 void lcd_batch_destroy(lcd_batch_t *b);
 void lcd_batch_clear(lcd_batch_t *b);
 /* add one region AFTER read slicing (the outputs of collect_noisy_read_info, src/align.c:1377): returns region index */
@@ -179,6 +182,19 @@ int lcd_batch_run(lcd_batch_t *b);     /* anchors -> POA chains -> ref/cons WFA 
  * memory budget (LCD_MEM_FRACTION, default 0.92) is split in halves and retried. */
 int lcd_batch_run_many(lcd_batch_t **batches, int n);
 int lcd_batch_download(lcd_batch_t *b);/* HBM -> host */
+/* ---- one process, all GPUs of the node (the GPU-side analogue of kt_for's work stealing, src/kthread.c:24-64, src/call_var_main.c:773) ----
+ * lcd_dispatch_run orders the batches (job buffers created with LCD_DEVICE_ANY, regions added, not uploaded) by estimated DP work, longest first; one
+ * submitter thread per device takes the next `coalesce` of them whenever its previous submission is done: bind + upload, lcd_batch_run_many, download.
+ * Returns when every batch is downloaded (results through lcd_batch_region_result / _vars as usual); device_of[i] (optional) = the GPU batch i ran on.
+ * Chunks are independent until stitch_var_main: no data-path exchange between devices. */
+typedef struct lcd_dispatch_s lcd_dispatch_t;
+lcd_dispatch_t *lcd_dispatch_create(int n_devices, const int *devices, int coalesce); /* n_devices <= 0: every visible GPU; coalesce <= 0: 16 */
+void lcd_dispatch_destroy(lcd_dispatch_t *d);
+int lcd_dispatch_n_devices(const lcd_dispatch_t *d);
+int lcd_dispatch_run(lcd_dispatch_t *d, lcd_batch_t **batches, int n, int *device_of);
+double lcd_batch_cost(const lcd_batch_t *b);   /* the work estimate the queue is ordered by (DP cells of the batch's chains) */
+/* longest-processing-time assignment of n costs to n_bins bins (static sharding across processes / ranks: bench.py --job-mb) */
+void lcd_lpt_assign(int n, const double *cost, int n_bins, int *bin_of, double *bin_load);
 /* region results; clu_read_ids[c] and aln_strs[c][j].target_aln are malloc()'d (aln_strs[c] must hold 1+2*n_reads zeroed entries) */
 int lcd_batch_region_result(lcd_batch_t *b, int region, int *clu_n_seqs, int **clu_read_ids, lcd_aln_str_t **aln_strs);
 /* ---- candidate variants of a region + the read x variant allele profile (opt.collect_noisy_vars) ----

@@ -150,6 +150,49 @@ def poa_batch(chains, opt=None):
     return out
 
 
+DEVICE_ANY = -2  # LCD_DEVICE_ANY: a host-only job buffer, bound to a GPU at upload / dispatch time
+
+
+def lpt_assign(costs, n_bins):
+    """lcd_lpt_assign: longest-processing-time assignment -> (bin of every item, load per bin); pure host code (no GPU needed)"""
+    lib = load_library()
+    c = np.ascontiguousarray(costs, np.float64)
+    out = np.zeros(max(len(c), 1), np.int32); load = np.zeros(max(n_bins, 1), np.float64)
+    lib.lcd_lpt_assign(len(c), c.ctypes.data_as(C.POINTER(C.c_double)), int(n_bins), out.ctypes.data_as(i32p), load.ctypes.data_as(C.POINTER(C.c_double)))
+    return out[:len(c)].copy(), load[:n_bins].copy()
+
+
+class Dispatcher:
+    """lcd_dispatch_*: one process driving every GPU of the node -- per-device submitter threads pulling job buffers from one cost-ordered queue
+    (the GPU-side analogue of kt_for, src/kthread.c:24-64)"""
+
+    def __init__(self, devices=None, coalesce=16):
+        self.lib = load_library()
+        if devices is None:
+            self.h = self.lib.lcd_dispatch_create(0, None, int(coalesce))
+        else:
+            d = np.ascontiguousarray(devices, np.int32)
+            self.h = self.lib.lcd_dispatch_create(len(d), d.ctypes.data_as(i32p), int(coalesce))
+        if not self.h:
+            raise RuntimeError("lcd_dispatch_create failed: " + self.lib.lcd_last_error().decode())
+
+    @property
+    def n_devices(self):
+        return int(self.lib.lcd_dispatch_n_devices(self.h))
+
+    def run(self, batches):
+        """uploads, runs and downloads every batch; returns the device each batch ran on"""
+        arr = (C.c_void_p * len(batches))(*[b.h for b in batches])
+        dev = np.full(max(len(batches), 1), -1, np.int32)
+        check(self.lib.lcd_dispatch_run(self.h, arr, len(batches), dev.ctypes.data_as(i32p)), self.lib)
+        return dev[:len(batches)].copy()
+
+    def close(self):
+        if self.h:
+            self.lib.lcd_dispatch_destroy(self.h)
+            self.h = None
+
+
 class RegionBatch:
     """Batched collect_noisy_reg_aln_strs (src/align.c:1760) over many independent regions of one pass (SURVEY CS-2)."""
 
@@ -207,6 +250,10 @@ class RegionBatch:
                                                              _p8(ref), len(ref)), self.lib)
         self.n_reads.append(len(ids))
         return idx
+
+    def cost(self):
+        """the work estimate queues and shards are ordered by (DP cells of the batch's chains; host only)"""
+        return float(self.lib.lcd_batch_cost(self.h))
 
     def upload(self):
         check(self.lib.lcd_batch_upload(self.h), self.lib)

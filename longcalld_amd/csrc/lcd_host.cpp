@@ -19,6 +19,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include <map>
 #include <memory>
@@ -390,24 +391,35 @@ const char *lcd_version(void) { return "longcalld_amd hot path 0.1 (gfx950)"; }
 
 // ---------------------------------------------------------------------------------------------------
 lcd_batch_t *lcd_batch_create(const lcd_opt_t *opt) { return lcd_batch_create_on(opt, -1); }
-lcd_batch_t *lcd_batch_create_on(const lcd_opt_t *opt, int device) {
-    if (use_device(device)) return nullptr;
-    lcd_batch_t *b = new lcd_batch_s();
-    b->opt = *opt; b->device = cur_device();
-    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { set_err(-10, "hipStreamCreate failed"); delete b; return nullptr; }
+// streams and events of a batch live on its device: created when the batch is bound to one
+static int bind_batch(lcd_batch_t *b, int device) {
+    if (use_device(device)) return -1;
+    b->device = cur_device();
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { b->stream = nullptr; b->device = -1; return set_err(-10, "hipStreamCreate failed"); }
     for (auto &e : b->ev) hipEventCreate(&e);
     for (auto &e : b->sev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     for (auto &s : b->side) hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    return 0;
+}
+lcd_batch_t *lcd_batch_create_on(const lcd_opt_t *opt, int device) {
+    if (init_default_device()) return nullptr;
+    lcd_batch_t *b = new lcd_batch_s();
+    b->opt = *opt; b->device = -1;
     memset(&b->st, 0, sizeof(b->st));
+    // LCD_DEVICE_ANY: a host-only job buffer; the device is chosen when it is uploaded (lcd_batch_upload: the calling thread's; lcd_dispatch_run: the
+    // device whose queue takes it)
+    if (device != LCD_DEVICE_ANY && bind_batch(b, device)) { delete b; return nullptr; }
     return b;
 }
 void lcd_batch_destroy(lcd_batch_t *b) {
     if (!b) return;
-    hipSetDevice(b->device);
-    for (auto &e : b->ev) hipEventDestroy(e);
-    for (auto &e : b->sev) hipEventDestroy(e);
-    for (auto &s : b->side) if (s) hipStreamDestroy(s);
-    if (b->stream) hipStreamDestroy(b->stream);
+    if (b->device >= 0) {
+        hipSetDevice(b->device);
+        for (auto &e : b->ev) hipEventDestroy(e);
+        for (auto &e : b->sev) hipEventDestroy(e);
+        for (auto &s : b->side) if (s) hipStreamDestroy(s);
+        if (b->stream) hipStreamDestroy(b->stream);
+    }
     delete b;
 }
 void lcd_batch_clear(lcd_batch_t *b) {
@@ -606,6 +618,7 @@ int lcd_batch_add_region_from_chunk(lcd_batch_t *b, const lcd_read_view_t *cr, i
 }
 
 int lcd_batch_upload(lcd_batch_t *b) {
+    if (b->device < 0 && bind_batch(b, -1)) return -1; // a job buffer created with LCD_DEVICE_ANY: the calling thread's device
     if (use_device(b->device)) return -1;
     const double t0 = now_ms();
     if (b->d_in.ensure(b->h_pool.size() + 64)) return -11;
@@ -1277,6 +1290,90 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
 }
 
 int lcd_batch_run(lcd_batch_t *b) { return lcd_batch_run_many(&b, 1); }
+
+// ---- one process, every GPU of the node: per-device submitter threads pulling from ONE cost-ordered queue of job buffers ----
+// The reference's parallel strategy is kt_for: n_threads workers of one process taking the next chunk whenever they are free (work stealing,
+// src/kthread.c:24-64, src/call_var_main.c:773).  Here the workers are the GPUs: the batches (host-only job buffers, LCD_DEVICE_ANY) are ordered by
+// estimated DP work, longest first, and every device thread takes the next `coalesce` of them whenever its previous submission is done --
+// upload, lcd_batch_run_many, download.  Chunks are independent until stitch_var_main: no device ever talks to another.
+struct lcd_dispatch_s { std::vector<int> devs; int coalesce; };
+static double batch_cost(const lcd_batch_t *b) { // DP cells, roughly: K1 chains = reads x length x band, K2 chains = reads x length^2
+    double c = 0;
+    for (const ChainRec &C : b->chains) {
+        double sum = 0, maxl = 0;
+        for (size_t k = 0; k < C.members.size(); ++k) { const double l = b->preads[C.read0 + k].len; sum += l; maxl = std::max(maxl, l); }
+        c += sum * (C.mode == 0 ? std::min(maxl + 1, 2 * (10 + maxl / 100) + 1 + 64) : maxl + 1);
+    }
+    return c;
+}
+lcd_dispatch_t *lcd_dispatch_create(int n_devices, const int *devices, int coalesce) {
+    if (init_default_device()) return nullptr;
+    lcd_dispatch_t *d = new lcd_dispatch_s();
+    if (n_devices <= 0) { for (int i = 0; i < g_n_devices; ++i) d->devs.push_back(i); }
+    else for (int i = 0; i < n_devices; ++i) {
+        const int dev = devices ? devices[i] : i;
+        if (dev < 0 || dev >= g_n_devices) { set_err(-1, "lcd_dispatch_create: bad device index " + std::to_string(dev)); delete d; return nullptr; }
+        d->devs.push_back(dev);
+    }
+    d->coalesce = coalesce > 0 ? coalesce : 16;
+    return d;
+}
+void lcd_dispatch_destroy(lcd_dispatch_t *d) { delete d; }
+int lcd_dispatch_n_devices(const lcd_dispatch_t *d) { return (int)d->devs.size(); }
+double lcd_batch_cost(const lcd_batch_t *b) { return batch_cost(b); }
+// the deterministic part, also used by the tests and by the multi-process sharding of bench.py: longest-processing-time assignment of costs to bins
+void lcd_lpt_assign(int n, const double *cost, int n_bins, int *bin_of, double *bin_load) {
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    std::vector<double> load(n_bins, 0.0);
+    for (int i : order) { int best = 0; for (int t = 1; t < n_bins; ++t) if (load[t] < load[best]) best = t; bin_of[i] = best; load[best] += cost[i]; }
+    if (bin_load) for (int t = 0; t < n_bins; ++t) bin_load[t] = load[t];
+}
+int lcd_dispatch_run(lcd_dispatch_t *d, lcd_batch_t **bs, int n, int *device_of) {
+    if (n <= 0) return 0;
+    for (int i = 0; i < n; ++i) {
+        if (bs[i]->device >= 0 && std::find(d->devs.begin(), d->devs.end(), bs[i]->device) == d->devs.end()) return set_err(-4, "lcd_dispatch_run: a batch is bound to a device outside the dispatcher");
+        if (memcmp(&bs[i]->opt, &bs[0]->opt, sizeof(lcd_opt_t)) != 0) return set_err(-4, "lcd_dispatch_run: batches with different options");
+    }
+    std::vector<int> order(n);
+    std::vector<double> cost(n);
+    for (int i = 0; i < n; ++i) { order[i] = i; cost[i] = batch_cost(bs[i]); }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    std::mutex mu; size_t next = 0; int first_err = 0; std::string err_msg;
+    const int n_dev = (int)d->devs.size();
+    auto worker = [&](int dev) {
+        std::vector<lcd_batch_t *> grp;
+        for (;;) {
+            grp.clear();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (first_err) return;
+                // a batch already bound to another device stays there: skip over it; take up to `coalesce`, but never more than this device's
+                // fair share of what is left (the tail of the queue is what balances the devices)
+                const size_t left = n - next;
+                const size_t take = std::max<size_t>(1, std::min<size_t>((size_t)d->coalesce, (left + n_dev - 1) / n_dev));
+                while (next < (size_t)n && grp.size() < take) {
+                    lcd_batch_t *b = bs[order[next]];
+                    if (b->device >= 0 && b->device != dev) break; // bound to another GPU of the dispatcher: its thread takes it
+                    grp.push_back(b); if (device_of) device_of[order[next]] = dev; ++next;
+                }
+                if (grp.empty()) { if (next >= (size_t)n) return; /* head is bound elsewhere: let its device take it */ }
+            }
+            if (grp.empty()) { std::this_thread::yield(); continue; }
+            int rc = 0;
+            for (lcd_batch_t *b : grp) { if (b->device < 0 && (rc = bind_batch(b, dev))) break; if (!b->uploaded && (rc = lcd_batch_upload(b))) break; }
+            if (!rc) rc = lcd_batch_run_many(grp.data(), (int)grp.size());
+            for (size_t i = 0; i < grp.size() && !rc; ++i) rc = lcd_batch_download(grp[i]);
+            if (rc) { std::lock_guard<std::mutex> lk(mu); if (!first_err) { first_err = rc; err_msg = g_err; } return; }
+        }
+    };
+    std::vector<std::thread> ths;
+    for (int dev : d->devs) ths.emplace_back(worker, dev);
+    for (auto &t : ths) t.join();
+    if (first_err) return set_err(first_err, err_msg);
+    return 0;
+}
 
 int lcd_batch_download(lcd_batch_t *b) {
     if (!b->ran) return set_err(-3, "lcd_batch_download before lcd_batch_run");

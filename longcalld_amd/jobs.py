@@ -155,12 +155,15 @@ def make_sv_region(rng, shape=SV, kind=None, sv_len=None, ctx=None, n_reads=None
                 haps=np.array(haps, np.int32), phase_sets=np.array(pss, np.int64), ref=ref, sv=(kind, sv_len))
 
 
-def make_regions(seed, n_regions, shape=HIFI):
-    """n_regions region jobs of one shape; the SV shape mixes sv_per_10mb SV regions per 1 250 into ordinary 60x noisy-read regions (configs[4])"""
+def make_regions(seed, n_regions, shape=HIFI, poisson_sv=False):
+    """n_regions region jobs of one shape; the SV shape mixes sv_per_10mb SV regions per 1 250 into ordinary 60x noisy-read regions (configs[4]);
+    poisson_sv: the number of SV regions is Poisson-distributed (a 500 kb chunk holds 5 on average, some chunks none, some a dozen)"""
     rng = np.random.default_rng(seed)
     if shape.get("name") != "sv":
         return [make_region(rng, shape) for _ in range(n_regions)]
     n_sv = max(1, int(round(n_regions * shape["sv_per_10mb"] / 1250.0)))
+    if poisson_sv:
+        n_sv = int(min(n_regions, rng.poisson(n_regions * shape["sv_per_10mb"] / 1250.0)))
     is_sv = np.zeros(n_regions, bool)
     is_sv[rng.choice(n_regions, n_sv, replace=False)] = True
     return [make_sv_region(rng, shape) if f else make_region(rng, shape["base"]) for f in is_sv]

@@ -1,44 +1,87 @@
-"""N > 1 path on CPU (gloo, world_size 2): the region sharding is a partition (every region on exactly one rank, no data-path
-collective) and the aggregate uses the max-over-ranks time -- the same arithmetic bench.py does with RCCL on the GPUs."""
+"""N > 1 path on CPU (gloo, world_size 2): the PRODUCT's host-side sharding / queue code -- contiguous blocks of chunks per rank, one epoch of
+longcalld_amd/rebalance.py (all_gather of the queues, common plan, point-to-point transfer of whole packed job buffers; RCCL on the GPU node, gloo
+here), lcd_lpt_assign from liblcd_hotpath.so -- and the max-over-ranks / sum-over-ranks arithmetic bench.py does.  No GPU compute."""
+import json
 import os
 import subprocess
 import sys
 
+import numpy as np
+
 from conftest import ROOT
 
 WORKER = r'''
-import os, sys, json
+import hashlib, json, os, sys
 sys.path.insert(0, sys.argv[1])
+import numpy as np
 import torch, torch.distributed as dist
-from longcalld_amd import jobs
-from oracle import pyoracle
+from longcalld_amd import jobs, rebalance as rb
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-regs = jobs.make_regions(31, 10)
-mine = list(range(len(regs)))[rank::world]                 # static shard, independent work items
-done = [pyoracle.collect_noisy_reg_aln_strs(regs[i])["n_cons"] for i in mine]
+# a 6 Mb configs[4]-shaped job = 12 chunks of 500 kb in genome order; SV-heavy chunks make the contiguous blocks unequal
+n_chunks = 12
+lo, hi = rank * n_chunks // world, (rank + 1) * n_chunks // world
+chunks = {i: jobs.make_regions(4000 + i, 6 if i < 6 else 3, jobs.SV if i in (0, 1, 2, 4) else jobs.HIFI, poisson_sv=False) for i in range(lo, hi)}
+queue = [(sum(rb.region_cost(r) for r in regs), rb.pack_regions(regs)) for _, regs in sorted(chunks.items())]
+dig = lambda b: hashlib.sha1(np.ascontiguousarray(b).tobytes()).hexdigest()
+before = [dig(b) for _, b in queue]
+new_q, st = rb.rebalance(queue, tol=0.05)
+after = [dig(b) for _, b in new_q]
+for _, b in new_q:                       # every buffer that arrived is a valid job buffer
+    assert len(rb.unpack_regions(b)) in (3, 6)
 t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)   # pretend per-rank elapsed
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-cnt = torch.tensor([float(len(mine)), float(sum(done))], dtype=torch.float64)
+cnt = torch.tensor([float(sum(len(rb.unpack_regions(b)) for _, b in new_q))], dtype=torch.float64)
 dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
 gathered = [None] * world
-dist.all_gather_object(gathered, mine)
+dist.all_gather_object(gathered, dict(before=before, after=after, load=sum(c for c, _ in new_q), st={k: v for k, v in st.items()}))
 if rank == 0:
-    print(json.dumps({"t": t.item(), "n": cnt[0].item(), "cons": cnt[1].item(), "shards": gathered}))
+    print(json.dumps({"t": t.item(), "n": cnt[0].item(), "ranks": gathered}))
 dist.destroy_process_group()
 '''
 
 
-def test_two_rank_sharding_gloo(tmp_path):
+def test_two_rank_queue_rebalance_gloo(tmp_path):
     w = tmp_path / "worker.py"
     w.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29517", str(w), ROOT], env=env, capture_output=True, text=True, timeout=240)
-    assert out.returncode == 0, out.stderr[-2000:]
-    import json
+                          "--master-port", "29517", str(w), ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     r = json.loads(line)
-    assert r["n"] == 10 and abs(r["t"] - 0.2) < 1e-9
-    flat = sorted(i for s in r["shards"] for i in s)
-    assert flat == list(range(10))
+    assert r["n"] == 6 * 6 + 6 * 3 and abs(r["t"] - 0.2) < 1e-9          # every region on exactly one rank; max-over-ranks time
+    before = sorted(d for k in r["ranks"] for d in k["before"])
+    after = sorted(d for k in r["ranks"] for d in k["after"])
+    assert before == after and len(set(after)) == 12                          # the job buffers are a partition before and after, byte-identical
+    st = r["ranks"][0]["st"]
+    assert st == r["ranks"][1]["st"]                                          # both ranks computed the same plan
+    assert st["n_moves"] >= 1 and st["moved_bytes"] > 0
+    assert st["imbalance_before"] > 1.3 and st["imbalance_after"] < st["imbalance_before"]
+    loads = [k["load"] for k in r["ranks"]]
+    assert abs(loads[0] - st["loads_after"][0]) < 1e-6 * max(loads) and abs(loads[1] - st["loads_after"][1]) < 1e-6 * max(loads)
+
+
+def test_plan_is_deterministic_and_never_moves_a_job_twice():
+    from longcalld_amd import rebalance as rb
+    rng = np.random.default_rng(5)
+    costs = [list(rng.lognormal(0, 1.2, n)) for n in (40, 5, 25, 0, 12, 30, 8, 20)]
+    m1, before, after = rb.plan_moves(costs, tol=0.02)
+    m2, _, _ = rb.plan_moves(costs, tol=0.02)
+    assert m1 == m2 and len({(s, i) for s, i, _ in m1}) == len(m1)
+    mean = sum(before) / 8
+    assert max(after) / mean < 1.05 < max(before) / mean
+    assert abs(sum(after) - sum(before)) < 1e-9 * sum(before)
+
+
+def test_lpt_assign_matches_definition():
+    """lcd_lpt_assign (liblcd_hotpath.so, host only): items in decreasing cost, each to the currently least loaded bin"""
+    from longcalld_amd import align
+    rng = np.random.default_rng(6)
+    cost = rng.lognormal(0, 1.0, 200)
+    bins, load = align.lpt_assign(cost, 8)
+    exp_load = np.zeros(8); exp = np.zeros(200, int)
+    for i in sorted(range(200), key=lambda i: -cost[i]):
+        b = int(np.argmin(exp_load)); exp[i] = b; exp_load[b] += cost[i]
+    assert (bins == exp).all() and np.allclose(load, exp_load)
+    assert load.max() / load.mean() < 1.02                                    # 200 chunks on 8 GPUs: LPT is within 2 % of balanced

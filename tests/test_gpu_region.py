@@ -359,3 +359,26 @@ def test_device_per_batch_and_per_thread(lcd):
     assert lib.lcd_set_thread_device(n) != 0
     with pytest.raises(Exception):
         lcd.RegionBatch(device=n)
+
+
+def test_dispatcher_one_process_all_gpus(lcd):
+    """lcd_dispatch_run: job buffers created without a device (LCD_DEVICE_ANY), ordered by estimated work, pulled by one submitter thread per GPU;
+    every batch's digest equals its stand-alone run, every batch ran on a device of the dispatcher"""
+    from longcalld_amd import jobs
+    sets = [jobs.make_regions(900 + i, n, jobs.HIFI if i % 3 else jobs.ONT) for i, n in enumerate([30, 6, 18, 2, 40, 11, 25])]
+    alone = [_run_batch(lcd, s)[3] for s in sets]
+    d = lcd.Dispatcher(coalesce=3)
+    bs = []
+    for s in sets:
+        b = lcd.RegionBatch(device=lcd.DEVICE_ANY)
+        for r in s:
+            b.add_region(r)
+        bs.append(b)
+    costs = [b.cost() for b in bs]
+    assert costs[4] == max(costs) and costs[3] == min(costs) and min(costs) > 0
+    dev = d.run(bs)
+    assert ((dev >= 0) & (dev < d.n_devices)).all()
+    assert [b.digest() for b in bs] == alone
+    for b in bs:
+        b.close()
+    d.close()
