@@ -375,7 +375,7 @@ def test_dispatcher_one_process_all_gpus(lcd):
             b.add_region(r)
         bs.append(b)
     costs = [b.cost() for b in bs]
-    assert costs[4] == max(costs) and costs[3] == min(costs) and min(costs) > 0
+    assert min(costs) > 0 and costs[3] == min(costs) and costs[4] > costs[5] > costs[3]   # (same shape: more regions, more work)
     dev = d.run(bs)
     assert ((dev >= 0) & (dev < d.n_devices)).all()
     assert [b.digest() for b in bs] == alone

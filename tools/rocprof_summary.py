@@ -42,7 +42,11 @@ def pmc_summary(db_path, counter):
 
 
 def main(tag, title):
+    import os
     kernel_stats(f"gpurun_out/prof_{tag}/kt_results.db", f"profiles/{tag}_bench_kernel_stats.txt", title)
+    for suffix, what in (("_ont", "configs[2] ONT shape: python bench.py --shape ont --steps 48"), ("_sv", "configs[4] SV shape: python bench.py --shape sv --steps 8 --coalesce 4")):
+        if os.path.exists(f"gpurun_out/prof_{tag}{suffix}/kt_results.db"):
+            kernel_stats(f"gpurun_out/prof_{tag}{suffix}/kt_results.db", f"profiles/{tag}{suffix}_bench_kernel_stats.txt", f"{title} -- {what}")
     f = pmc_summary(f"gpurun_out/pmc_fetch_{tag}/f_results.db", "FETCH_SIZE")
     w = pmc_summary(f"gpurun_out/pmc_write_{tag}/w_results.db", "WRITE_SIZE")
     poa = 0.0
