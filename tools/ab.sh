@@ -1,8 +1,7 @@
-# A/B of two builds of the library on the same box: gpurun_out/libs/lib_<tag>.so copied over the in-tree one
+# A/B of library builds on the same box: tools/ablibs/lib_<tag>.so copied over the in-tree one, plain bench value per build
 for tag in "$@"; do
-  cp gpurun_out/libs/lib_$tag.so longcalld_amd/liblcd_hotpath.so
-  for c in 16 8; do
-    echo "== $tag cap $c"
-    LCD_LDS_CAP_KB=$c LCD_PROFILE_CHAINS=1 python bench.py --cpu-sample 0 --steps 16 --warmup 16 2>&1 | grep -E "group thr   64|\] total|class   64|\"value\"" | tail -6 | cut -c1-230
+  cp tools/ablibs/lib_$tag.so longcalld_amd/liblcd_hotpath.so
+  for rep in 1 2; do
+    echo "== $tag: $(python bench.py --cpu-sample 0 --steps 64 --lanes 1 --coalesce 32 2>/dev/null | tail -1 | python -c 'import sys,json; j=json.load(sys.stdin); print(j["value"], j["stage_ms"]["ms_poa_kernel"])')"
   done
 done
