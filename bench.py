@@ -272,11 +272,14 @@ def main():
         if args.steps > 0:
             t_up = load_slot(bt, timed_regs[q % len(timed_regs)])
     barrier()
+    allocs0 = lib.lcd_alloc_events()
     t0 = time.perf_counter()
     if args.steps > 0:
         run_steps(args.steps, True)
     barrier()
     elapsed = time.perf_counter() - t0
+    allocs_timed = lib.lcd_alloc_events() - allocs0
+    dev_gb = lib.lcd_device_bytes(local_rank) / 1e9
     poa_kernel_ms, poa_launches, st = acc["ms"], acc["launches"], acc["st"]
     tot_regions, tot_bases = acc["regions"], acc["bases"]
     if world > 1:
@@ -432,6 +435,7 @@ def main():
             "stage_ms": {k: round(st[k], 3) for k in ("ms_anchor", "ms_poa", "ms_wfa", "ms_strings", "ms_vars", "ms_total", "ms_host", "ms_poa_kernel")} if st else None,
             "noisy_vars_stage": args.vars,
             "rank_seconds": rank_times,
+            "device_memory": {"library_buffers_gb": round(dev_gb, 2), "allocations_inside_timed_region": int(allocs_timed)},
             "pcie_inclusive": {"upload_s": round(t_up, 4), "download_and_digest_s": round(t_dl, 4),
                                "regions_per_sec": round(tot_regions / max(world, 1) / steps / (t_up + ms_step / 1e3 + t_dl), 2), "overlapped": e2e},
             "digest": f"{digest:016x}",

@@ -79,6 +79,8 @@ int lcd_init(int device);                      /* process default device; 0 ok; 
 /* One process, many GPUs (the reference's kt_for workers are threads of one process, src/call_var_main.c:773): a device belongs to an
  * lcd_batch_t (lcd_batch_create_on) or, for the per-call mirrors and K5, to the calling thread (lcd_set_thread_device; < 0 = process default). */
 int lcd_device_count(void);
+long long lcd_alloc_events(void);           /* device allocations made so far by the library's grow-only buffers (a steady state makes none) */
+long long lcd_device_bytes(int device);     /* bytes those buffers hold on a device right now */
 int lcd_set_thread_device(int device);
 const char *lcd_last_error(void);
 const char *lcd_version(void);

@@ -76,6 +76,7 @@ int cur_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGet
 std::atomic<long long> g_dev_bytes[LCD_MAX_DEV];
 std::atomic<long long> g_dev_budget[LCD_MAX_DEV];
 std::once_flag g_budget_once[LCD_MAX_DEV];
+std::atomic<long long> g_alloc_events{0}; // hipMalloc calls of the grow-only buffers (bench.py reports how many fell into its timed region)
 long long dev_budget(int d) {
     std::call_once(g_budget_once[d], [d] {
         size_t fr = 0, tot = 0;
@@ -86,12 +87,12 @@ long long dev_budget(int d) {
 }
 struct DevBuf {
     void *p = nullptr; size_t cap = 0; int dev = 0;
-    int ensure(size_t n) {
+    int ensure(size_t n, int headroom_shift = 2) {
         if (n <= cap) return 0;
         release();
         dev = cur_device();
         const long long budget = dev_budget(dev);
-        size_t want = n + n / 4 + 256; // (headroom: the buffers only grow, a slightly larger next batch does not reallocate)
+        size_t want = n + (n >> headroom_shift) + 256; // (headroom: the buffers only grow, a slightly larger next batch does not reallocate)
         if (g_dev_bytes[dev].load() + (long long)want > budget) want = n + 256;
         if (g_dev_bytes[dev].load() + (long long)want > budget)
             return set_err(-11, "device memory budget: " + std::to_string(want) + " more bytes on top of " + std::to_string(g_dev_bytes[dev].load()));
@@ -99,7 +100,7 @@ struct DevBuf {
             (void)hipGetLastError(); // out-of-memory is not sticky, but the "last error" slot is read after every launch
             p = nullptr; cap = 0; return set_err(-11, "hipMalloc failed for " + std::to_string(want) + " bytes");
         }
-        cap = want; g_dev_bytes[dev] += (long long)cap; return 0;
+        cap = want; g_dev_bytes[dev] += (long long)cap; ++g_alloc_events; return 0;
     }
     void release() { if (p) { hipFree(p); g_dev_bytes[dev] -= (long long)cap; p = nullptr; cap = 0; } }
     uint64_t addr() const { return (uint64_t)(uintptr_t)p; }
@@ -205,7 +206,7 @@ struct lcd_batch_s {
     // (d_poa_arena: the ONE transient workspace of a submission led by this batch -- chain arenas, WFA wavefronts and edlib blocks in turn)
     DevBuf d_in, d_chains, d_preads, d_poa_arena, d_poa_out, d_poa_outs, d_ed_jobs, d_ed_outs, d_wfa_jobs,
         d_wfa_out, d_wfa_outs, d_str_jobs, d_str_outs, d_final, d_gate, d_cmp_jobs, d_cmp_outs, d_cmp_seg, d_cmp_segres, d_seg_out, d_rr,
-        d_var_jobs, d_var_outs, d_var_work, d_vreg_jobs, d_vreg_outs, d_var_out;
+        d_var_jobs, d_var_outs, d_var_work, d_vreg_jobs, d_vreg_outs, d_var_out, d_slot_flags;
     bool uploaded = false, ran = false, downloaded = false;
     // results (host)
     std::vector<PoaChainOut> couts;
@@ -379,6 +380,8 @@ int lcd_init(int device) { // the process default device (bench.py: LOCAL_RANK);
     g_device = device;
     return 0;
 }
+long long lcd_alloc_events(void) { return g_alloc_events.load(); }
+long long lcd_device_bytes(int device) { return device >= 0 && device < LCD_MAX_DEV ? g_dev_bytes[device].load() : 0; }
 int lcd_device_count(void) { return init_default_device() ? 0 : g_n_devices; }
 int lcd_set_thread_device(int device) {
     if (init_default_device()) return -1;
@@ -802,6 +805,30 @@ static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, 
 // one CU; one batch of configs[1] size cannot fill 256 CUs, and separate streams per batch serialise on shared hardware queues).
 // The leader (batches[0]) lends its stream and its job / arena buffers; inputs, chain outputs and final strings stay per batch.
 // Results of batch k must be downloaded before the same leader runs again (the ref<->cons rows live in the leader's WFA buffer).
+// compact CU index of the arena slots: one probe launch per device records which (XCC, SE, SH, CU) ids exist (poa_kernel.hip lcd_cu_probe_kernel)
+static DevBuf *g_cu_rank[LCD_MAX_DEV]; static int g_cu_n[LCD_MAX_DEV]; static std::mutex g_cu_mu;
+static int cu_rank_table(hipStream_t st, uint64_t *addr, int *n_cu) {
+    const int dev = cur_device();
+    std::lock_guard<std::mutex> lk(g_cu_mu);
+    if (!g_cu_rank[dev]) {
+        std::unique_ptr<DevBuf> seen(new DevBuf()), rank(new DevBuf());
+        if (seen->ensure(4096 * 4) || rank->ensure(4096 * 4)) return -11;
+        HIPCHK(hipMemsetAsync(seen->p, 0, 4096 * 4, st));
+        lcd_launch_cu_probe((int *)seen->p, st);
+        HIPCHK(hipGetLastError());
+        std::vector<int> h(4096);
+        HIPCHK(hipMemcpyAsync(h.data(), seen->p, 4096 * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        int n = 0;
+        for (int &x : h) x = x ? n++ : -1;
+        HIPCHK(hipMemcpyAsync(rank->p, h.data(), 4096 * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (getenv("LCD_MEM_DEBUG")) fprintf(stderr, "[mem] device %d: %d compute units seen by the probe (%d reported)\n", dev, n, g_n_cus);
+        g_cu_n[dev] = std::max(n, 1); g_cu_rank[dev] = rank.release();
+    }
+    *addr = g_cu_rank[dev]->addr(); *n_cu = std::max(g_cu_n[dev], g_n_cus); // (a CU the probe missed hashes into the table: never fewer slots than CUs)
+    return 0;
+}
 static int run_many_once(lcd_batch_t **bs, int nb);
 int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
     // a joint submission whose arenas do not fit the device (the estimates of noisy reads are 4x those of clean ones) is split in halves,
@@ -944,9 +971,14 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         int scale = 1;
         std::map<size_t, uint64_t> retry_out_off; // chains whose output block moved to a retry buffer
         for (int k = 0; k < nb; ++k) bs[k]->retry_out.clear();
+        static const bool use_slots = !(getenv("LCD_ARENA_SLOTS") && atoi(getenv("LCD_ARENA_SLOTS")) == 0);
+        uint64_t cu_rank_addr = 0; int n_cu = g_n_cus;
+        if (use_slots) { const int rc3 = cu_rank_table(st, &cu_rank_addr, &n_cu); if (rc3) return rc3; }
+        if (getenv("LCD_ARENA_SLOT_CUS")) n_cu = std::max(1, atoi(getenv("LCD_ARENA_SLOT_CUS"))); // test switch: far fewer slots than resident workgroups (claims must wait)
         for (int round = 0; round < 12 && !which.empty(); ++round) {
             uint64_t tot = 0;
             std::vector<PoaChain> sub(which.size());
+            std::vector<uint64_t> need(which.size());
             for (size_t i = 0; i < which.size(); ++i) {
                 const int k = chain_batch[which[i]]; const size_t c = which[i] - chain_base[k];
                 PoaChain &pc = bs[k]->pchains[c];
@@ -960,19 +992,70 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                         pc.out_off = b->retry_out.back()->addr(); retry_out_off[which[i]] = pc.out_off;
                     } else pc.out_off = retry_out_off.count(which[i]) ? retry_out_off[which[i]] : bs[k]->d_poa_out.addr() + out_rel[k][c];
                 }
-                PoaLayout Lay = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads, pc.spill_x);
-                pc.ws_off = tot; tot += Lay.total;
+                need[i] = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads, pc.spill_x).total;
+            }
+            // Work arenas.  A chain's arena is live only while its workgroup is resident, and a CU holds at most per_cu workgroups of a launch group:
+            // runs of chains of one launch group and one size class (half octaves of the arena size) that outnumber the chip's capacity share a pool of
+            // n_cu x per_cu SLOTS claimed at workgroup start (poa_kernel.hip); the others keep private arenas.  Memory then scales with resident
+            // workgroups, not with the number of chains in flight.
+            uint64_t flag_ints = 0; size_t n_pooled = 0, n_pools = 0; uint64_t private_bytes = 0, pool_bytes = 0;
+            for (size_t i = 0; i < which.size();) {
+                const long long key = chain_group_key(PC(which[i]));
+                size_t j = i;
+                while (j < which.size() && chain_group_key(PC(which[j])) == key) ++j;
+                const PoaChain &p0 = PC(which[i]);
+                const int lds = p0.lds_words * 4, thr = p0.threads;
+                const int per_cu = std::max(1, std::min((160 * 1024) / (lds + (thr == 64 ? 912 : 6096)), 1024 / thr));
+                const uint64_t R = (uint64_t)n_cu * per_cu;
+                // the group's chains by arena size, largest first, cut into segments at breakpoints where the size has dropped by >= 1.3x; a segment
+                // either keeps private arenas (cost: the sum of its sizes) or, if it has more than R chains, shares R slots of its largest size
+                // (cost R x size).  The cheapest segmentation is a shortest path over the <= ~40 breakpoints (sizes of a group span two orders of magnitude).
+                std::vector<size_t> ord(j - i);
+                for (size_t q = 0; q < ord.size(); ++q) ord[q] = i + q;
+                std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b2) { return need[a] > need[b2]; });
+                const size_t n = ord.size();
+                std::vector<size_t> bp(1, 0);
+                for (size_t q = 1; q < n; ++q) if ((double)need[ord[q]] * 1.3 <= (double)need[ord[bp.back()]]) bp.push_back(q);
+                bp.push_back(n);
+                std::vector<uint64_t> pre(n + 1, 0);
+                for (size_t q = 0; q < n; ++q) pre[q + 1] = pre[q] + need[ord[q]];
+                const size_t nbp = bp.size();
+                std::vector<uint64_t> cost(nbp, ~0ull); std::vector<size_t> nxt(nbp, nbp - 1);
+                cost[nbp - 1] = 0;
+                auto seg_pooled = [&](size_t a, size_t b2) { return use_slots && bp[b2] - bp[a] > R && R * lcd_align_up(need[ord[bp[a]]], 256) < pre[bp[b2]] - pre[bp[a]]; };
+                for (size_t a = nbp - 1; a-- > 0;)
+                    for (size_t b2 = a + 1; b2 < nbp; ++b2) {
+                        const uint64_t c = (seg_pooled(a, b2) ? R * lcd_align_up(need[ord[bp[a]]], 256) : pre[bp[b2]] - pre[bp[a]]) + cost[b2];
+                        if (c < cost[a]) { cost[a] = c; nxt[a] = b2; }
+                    }
+                for (size_t a = 0; a + 1 < nbp; a = nxt[a]) {
+                    const size_t b2 = nxt[a];
+                    if (seg_pooled(a, b2)) {
+                        const uint64_t slot = lcd_align_up(need[ord[bp[a]]], 256);
+                        for (size_t q = bp[a]; q < bp[b2]; ++q) { PoaChain &pc = PC(which[ord[q]]); pc.ws_off = tot; pc.slot_flags = 1 + flag_ints; pc.slot_bytes = slot; pc.n_slots = (int)R; pc.per_cu = per_cu; pc.cu_rank = cu_rank_addr; }
+                        tot += R * slot; flag_ints += R; n_pooled += bp[b2] - bp[a]; ++n_pools; pool_bytes += R * slot;
+                    } else
+                        for (size_t q = bp[a]; q < bp[b2]; ++q) { PoaChain &pc = PC(which[ord[q]]); pc.ws_off = tot; pc.slot_flags = 0; pc.slot_bytes = 0; pc.n_slots = 0; pc.per_cu = 0; pc.cu_rank = 0; tot += need[ord[q]]; private_bytes += need[ord[q]]; }
+                }
+                i = j;
+            }
+            if (getenv("LCD_MEM_DEBUG")) fprintf(stderr, "[mem] round %d arenas: %zu chains in %zu slot pools (%.2f GB), %zu with private arenas (%.2f GB)\n", round, n_pooled, n_pools, pool_bytes / 1e9, which.size() - n_pooled, private_bytes / 1e9);
+            if (flag_ints) {
+                if (L->d_slot_flags.ensure(flag_ints * 4 + 64)) return -11;
+                HIPCHK(hipMemsetAsync(L->d_slot_flags.p, 0, flag_ints * 4, st));
             }
             if (getenv("LCD_MEM_DEBUG")) {
                 double cellb = 0, nodeb = 0; double worstc = 0; size_t nbig = 0;
                 for (size_t i = 0; i < which.size(); ++i) { const PoaChain &pc = PC(which[i]); cellb += (pc.spill_x > 2 ? 5.0 + pc.spill_x : 4.0) * pc.cell_cap; PoaLayout Lay = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, 0, pc.n_reads); nodeb += (double)Lay.total; if (4.0 * pc.cell_cap > worstc) worstc = 4.0 * pc.cell_cap; nbig += 4.0 * pc.cell_cap > 64e6; }
                 fprintf(stderr, "[mem] round %d: %zu chains, arena %.2f GB = DP regions %.2f GB (largest %.1f MB, %zu above 64 MB) + graph/plan arrays %.2f GB\n", round, which.size(), tot / 1e9, cellb / 1e9, worstc / 1e6, nbig, nodeb / 1e9);
             }
-            if (L->d_poa_arena.ensure(tot)) return -11;
+            // (the one multi-GB buffer: re-allocating it costs more than a submission, so it grows by half -- distinct chunks differ by a few per cent)
+            if (L->d_poa_arena.ensure(tot, 1)) return -11;
             for (size_t i = 0; i < which.size(); ++i) {
                 const int k = chain_batch[which[i]];
                 PoaChain &pc = PC(which[i]);
                 pc.ws_off += L->d_poa_arena.addr();
+                if (pc.slot_flags) pc.slot_flags = L->d_slot_flags.addr() + (pc.slot_flags - 1) * 4;
                 sub[i] = pc; sub[i].read0 += (int)pread_base[k]; // the device read table is the concatenation of the batches' tables
             }
             HIPCHK(hipEventRecord(L->ev[6], st));

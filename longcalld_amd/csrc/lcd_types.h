@@ -54,8 +54,15 @@ struct PoaChain {
                       // reads: one row in four has >= 2 usable predecessors), spill_x > 2 -> ord_x 4 (K2 chains of noisy reads: nearly every row has)
     uint32_t min_w;   // (int)(n*min_af) clipped below at 2 (cluster threshold)
     uint64_t cell_cap;
-    uint64_t ws_off;  // byte offset of this chain's arena
+    uint64_t ws_off;  // byte offset of this chain's arena -- or, with slot_flags != 0, of its pool of arena SLOTS
     uint64_t out_off; // byte offset in the chain-output pool: cons[2][node_cap] + msa[(n_reads+2)][node_cap] + clu[2][n_reads] ints
+    // Arena slots (lcd_host.cpp run_many_once): a chain's work arena is only live while its workgroup is resident, and a CU holds at most per_cu
+    // workgroups of a launch.  Launches with more chains than the chip can hold share a pool of n_slots = (CUs x per_cu) slots of slot_bytes each; a
+    // starting workgroup claims one with a compare-and-swap on flags[] (its own CU's per_cu slots first) and releases it when the chain is done.
+    uint64_t slot_flags;  // 0: private arena at ws_off; else device address of int flags[n_slots] (0 free, 1 taken)
+    uint64_t slot_bytes;
+    uint64_t cu_rank;     // device address of int[4096]: raw (XCC, SE, SH, CU) id -> compact CU index, -1 unknown; 0: none
+    int n_slots, per_cu;
 };
 
 struct PoaChainOut {

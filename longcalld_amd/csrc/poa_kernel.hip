@@ -1807,6 +1807,35 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     uint8_t *sseq = (uint8_t *)(lds_pool + Cfg<NT>::K * 3 * ring_cols);
     const PoaLayout L = poa_layout(ch.node_cap, ch.edge_cap, ch.rid_words, ch.max_len, ch.cell_cap, ch.n_reads, ch.spill_x);
     uint8_t *ws = arena + ch.ws_off;
+    int my_slot = -1;
+    if (ch.slot_flags) { // pooled arenas: claim a slot (this CU's own ones first; anything free otherwise; wait if the pool is exhausted)
+        if (tid == 0) {
+            int *flags = (int *)(uintptr_t)ch.slot_flags;
+            const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), xc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+            const unsigned raw = ((xc & 15) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15);
+            const int *rank = (const int *)(uintptr_t)ch.cu_rank;
+            int r = rank ? rank[raw] : -1;
+            if (r < 0) r = (int)raw;
+            const unsigned ns = (unsigned)ch.n_slots, start = ((unsigned)r * (unsigned)ch.per_cu) % ns;
+            int slot = -1;
+            for (unsigned sweeps = 0; slot < 0 && sweeps < (1u << 20); ++sweeps) {
+                for (unsigned t = 0; t < ns; ++t) {
+                    const unsigned q = (start + t) % ns;
+                    if (atomicCAS(flags + q, 0, 1) == 0) { slot = (int)q; break; }
+                }
+                if (slot < 0) __builtin_amdgcn_s_sleep(64);
+            }
+            sm.bc[0] = slot;
+        }
+        __syncthreads();
+        my_slot = sm.bc[0];
+        __syncthreads();
+        if (my_slot < 0) { // cannot happen while slot holders make progress; never run on somebody else's arena
+            if (tid == 0) { PoaChainOut o = PoaChainOut(); o.status = LCD_ERR_SYNC; outs[cid] = o; }
+            return;
+        }
+        ws = (uint8_t *)(uintptr_t)ch.ws_off + (uint64_t)my_slot * ch.slot_bytes;
+    }
     Ctx g;
     // DP region: 4 * cell_cap bytes.  Windowed / systolic rows: [direction codes: cell_cap B | predecessor ordinals: cell_cap B (one row
     // in four may have >= 2 predecessors) | spilled value rows: 2 * cell_cap B].  Generic rows: int32 H, E1, E2 planes of cell_cap / 3
@@ -2048,7 +2077,21 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
         out.t_out = (unsigned long long)(t_end - t_out0);
         outs[cid] = out;
     }
+    if (my_slot >= 0) { // every store of this workgroup into the slot has completed (barrier = vmcnt(0) per wavefront) before the next owner may start
+        __syncthreads();
+        if (tid == 0) { __threadfence(); atomicExch((int *)(uintptr_t)ch.slot_flags + my_slot, 0); }
+    }
 }
+
+// One pass over the chip recording which (XCC, SE, SH, CU) ids exist: the host turns it into the compact CU index of the arena slots.
+__global__ void lcd_cu_probe_kernel(int *seen) {
+    if (threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), xc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+        seen[((xc & 15) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)] = 1;
+        for (int i = 0; i < 200; ++i) __builtin_amdgcn_s_sleep(127); // stay resident long enough for the dispatcher to reach every CU
+    }
+}
+void lcd_launch_cu_probe(int *seen, hipStream_t stream) { hipLaunchKernelGGL(lcd_cu_probe_kernel, dim3(16384), dim3(64), 0, stream, seen); }
 
 // Holds a stream until `target` workgroups of the wide classes have started.  A 1 024-thread chain needs ALL the vector registers of a
 // CU; if the thousands of 64-thread chains of the same step are dispatched at the same time they take a few wavefront slots on every

@@ -382,3 +382,15 @@ def test_dispatcher_one_process_all_gpus(lcd):
     for b in bs:
         b.close()
     d.close()
+
+
+def test_arena_slots_under_contention(lcd, monkeypatch):
+    """arena slots (poa_kernel.hip / run_many_once): with LCD_ARENA_SLOT_CUS=2 a launch group of a full-size batch has 10-50x more chains than slots
+    and far more resident workgroups than slots, so workgroups wait for a slot, run on whatever arena they get and release it -- the digest is that
+    of private arenas"""
+    from longcalld_amd import jobs
+    regs = jobs.make_regions(1234, 600, jobs.HIFI)
+    ref = _run_batch(lcd, regs)[3]
+    monkeypatch.setenv("LCD_ARENA_SLOT_CUS", "2")
+    got = _run_batch(lcd, regs)[3]
+    assert got == ref and ref != 0
