@@ -48,7 +48,7 @@ typedef struct lcd_opt_t {
      * built and return it through lcd_batch_region_vars; 2 = the same, and lcd_batch_download leaves the alignment strings in HBM
      * (lcd_batch_region_result then fails): only variants and alleles cross PCIe */
     int collect_noisy_vars;
-    int min_sv_len;               /* call_var_opt_t.min_sv_len (50), src/call_var_main.h:175 */
+    int min_sv_len;               /* call_var_opt_t.min_sv_len (LONGCALLD_MIN_SV_LEN 30, src/call_var_main.h:54,175) */
 } lcd_opt_t;
 
 /* == aln_str_t, src/collect_var.h:106-112 */
@@ -270,6 +270,47 @@ int lcd_post_process_noisy_regs(const lcd_noisy_iv_t *regs, int n_regs, int n_va
  * seq: raw codes 0..3 (4+ = N) or letters; T, W: LONGCALLD_SDUST_T 5 / LONGCALLD_SDUST_W 20 (src/call_var_main.h:82-83), W <= 64.
  * *intervals_out: malloc()'d (start, finish) pairs exactly as sdust() returns them (0-based, half-open); returns their number or < 0. */
 int lcd_sdust(const uint8_t *seq, int64_t len, int T, int W, int64_t **intervals_out);
+
+/* ---- cross-chunk stitching, genotype emission, tag values (host code in the reference and here: small and serial) ----
+ * lcd_flip_variant_hap == flip_variant_hap + update_chunk_{var,read}_hap_phase_set1 (src/collect_var.c:1565-1680): the reads that overlap both chunks
+ * vote (same haplotype in both: -1, different: +1); a non-zero score joins the phase sets (cur's smallest read PS becomes pre's largest) and, if
+ * positive, swaps haplotypes 1 / 2 of the current chunk's variants (and reads, when update_reads: opt->out_aln_fp != NULL) in that phase set.
+ * Overlap lists are the concatenation over the input BAMs of up_ovlp_read_i / down_ovlp_read_i (src/bam_utils.h:64-65). */
+typedef struct lcd_chunk_phase_t {
+    int tid, n_reads, n_vars;
+    const int *ordered_read_ids;
+    const uint8_t *is_skipped;
+    int *haps; int64_t *phase_sets;                    /* in/out, n_reads */
+    int64_t *var_phase_set; int *hap_to_cons_alle;     /* in/out, n_vars and n_vars*3 */
+    int n_up_ovlp, n_down_ovlp;
+    const int *up_ovlp_read_i, *down_ovlp_read_i;
+    int flip_hap; int64_t flip_pre_PS, flip_cur_PS;    /* out (flip_hap starts at 0, src/bam_utils.c:1368) */
+} lcd_chunk_phase_t;
+int lcd_flip_variant_hap(lcd_chunk_phase_t *pre, lcd_chunk_phase_t *cur, int update_reads);  /* 0, or -6 when the overlap counts disagree (the reference exits) */
+int lcd_stitch_chunks(lcd_chunk_phase_t *chunks, int n_chunks, int update_reads);            /* stitch_var_main, src/collect_var.c:2983-2989 */
+/* lcd_make_variants == make_variants (src/collect_var.c:1465-1601), germline fields: candidate variants of the output categories inside [reg_beg, reg_end]
+ * -> VCF-ready records.  p supplies the chunk state K5 works on (positions, types, categories, coverages, the read x variant profile, var_phase_set,
+ * hap_to_cons_alle); var_ref_len / var_alt_len / alt_off + alt_pool / alt_ref_base are the remaining cand_var_t fields; ref_seq is chunk->ref_seq (letters
+ * or codes, nst_nt4_table applies) starting at ref_beg.  Returns the number of records; *vars_out malloc()'d (free with lcd_free_variants). */
+typedef struct lcd_call_opt_t { double log_p, log_1p, log_2; int max_gq, max_qual, min_sv_len, min_dp, min_alt_dp, out_amb_base; } lcd_call_opt_t;
+typedef struct lcd_var1_t {          /* var1_t, src/call_var_main.h:108-121 (retrotransposon / somatic fields left out) */
+    int64_t pos, PS;
+    int type, ref_len, n_alt_allele, alt_len[2];
+    uint8_t *ref_bases, *alt_bases[2];
+    int GT[2], DP, AD[2], QUAL, GQ, is_sv, is_clean, n_alt_reads;
+    int *alt_read_i;
+} lcd_var1_t;
+void lcd_call_opt_default(lcd_call_opt_t *o);   /* src/call_var_main.c:156-157,209,217-219 */
+int lcd_make_variants(const lcd_call_opt_t *opt, const lcd_hap_problem_t *p, const int *var_ref_len, const int *var_alt_len, const uint64_t *alt_off,
+                      const uint8_t *alt_pool, const uint8_t *alt_ref_base, const char *ref_seq, int64_t ref_beg, int64_t reg_beg, int64_t reg_end,
+                      lcd_var1_t **vars_out);
+void lcd_free_variants(lcd_var1_t *vars, int n);
+/* the VCF body lines write_var_to_vcf (src/vcf_utils.c:97-268) emits for these records (filters DP / AD / ambiguous bases applied); *text_out malloc()'d,
+ * NUL-terminated; returns the number of lines */
+int lcd_format_vcf(const lcd_call_opt_t *opt, const char *chrom, const lcd_var1_t *vars, int n_vars, char **text_out);
+/* HP / PS aux tags of write_processed_read_to_bam (src/bam_utils.c:1955-2006): HP:i is written iff hap != 0, PS:i iff phase set > 0 (an existing tag with
+ * another value is replaced, one that should not be there is deleted): has_hp / has_ps say whether the record ends up carrying the tag */
+void lcd_read_tags(int n_reads, const int *haps, const int64_t *phase_sets, uint8_t *has_hp, int *hp, uint8_t *has_ps, int64_t *ps);
 
 /* ---- kernel-level batches (also what the per-call mirrors above run on) ---- */
 int lcd_edlib_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *q_off, const int *qlen,

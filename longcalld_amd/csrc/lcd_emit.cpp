@@ -1,0 +1,197 @@
+// lcd_emit.cpp -- SURVEY 8(f) f4: what turns the hot path's per-chunk results into the caller-visible output: cross-chunk stitching of phase sets
+// (flip_variant_hap, src/collect_var.c:1618-1680), genotype records (make_variants :1465-1601, cal_sample_GQ :1435, cal_var_QUAL1 :1455), the VCF body
+// lines (write_var_to_vcf, src/vcf_utils.c:97-268) and the HP / PS tag policy (src/bam_utils.c:1955-2006).  Host code, as in the reference: serial,
+// tens of microseconds per chunk; it lives here so that a caller of the library gets from K5 + noisy-region variants to VCF text without the reference's
+// htslib-typed structs.  Germline fields only (retrotransposon annotation a14 and somatic mode a20 are out of scope).
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/lcd_hotpath.h"
+
+namespace {
+enum { CLEAN_HET_SNP = 0x004, CLEAN_HET_INDEL = 0x008, CLEAN_HOM = 0x080, NOISY_HET = 0x100, NOISY_HOM = 0x200 };
+const int kOutCate = CLEAN_HET_SNP | CLEAN_HET_INDEL | CLEAN_HOM | NOISY_HET | NOISY_HOM; // src/collect_var.c:1479
+const int kCleanCate = CLEAN_HET_SNP | CLEAN_HET_INDEL | CLEAN_HOM;                           // LONGCALLD_CAND_GERMLINE_CLEAN_VAR_CATE
+inline uint8_t nt4(unsigned char c) { return c < 4 ? c : (c == 'A' || c == 'a') ? 0 : (c == 'C' || c == 'c') ? 1 : (c == 'G' || c == 'g') ? 2 : (c == 'T' || c == 't') ? 3 : c == '-' ? 5 : 4; }
+
+void join_var_phase(lcd_chunk_phase_t &c) { // update_chunk_var_hap_phase_set1, src/collect_var.c:1589-1611
+    if (c.flip_hap && c.flip_cur_PS != -1)
+        for (int i = 0; i < c.n_vars; ++i)
+            if (c.var_phase_set[i] == c.flip_cur_PS) std::swap(c.hap_to_cons_alle[3 * i + 1], c.hap_to_cons_alle[3 * i + 2]);
+    if (c.flip_pre_PS != -1 && c.flip_cur_PS != INT64_MAX)
+        for (int i = 0; i < c.n_vars; ++i)
+            if (c.var_phase_set[i] != -1 && c.var_phase_set[i] == c.flip_cur_PS) c.var_phase_set[i] = c.flip_pre_PS;
+}
+void join_read_phase(lcd_chunk_phase_t &c) { // update_chunk_read_hap_phase_set1, :1566-1587
+    if (c.flip_hap && c.flip_cur_PS != -1)
+        for (int i = 0; i < c.n_reads; ++i) {
+            const int r = c.ordered_read_ids[i];
+            if (c.haps[r] != 0 && c.phase_sets[r] == c.flip_cur_PS) c.haps[r] = 3 - c.haps[r];
+        }
+    if (c.flip_pre_PS != -1 && c.flip_cur_PS != INT64_MAX)
+        for (int i = 0; i < c.n_reads; ++i) {
+            const int r = c.ordered_read_ids[i];
+            if (c.phase_sets[r] != -1 && c.phase_sets[r] == c.flip_cur_PS) c.phase_sets[r] = c.flip_pre_PS;
+        }
+}
+void free_members(lcd_var1_t *vars, int n) { for (int i = 0; i < n; ++i) { free(vars[i].ref_bases); free(vars[i].alt_bases[0]); free(vars[i].alt_bases[1]); free(vars[i].alt_read_i); } }
+} // namespace
+
+extern "C" {
+
+int lcd_flip_variant_hap(lcd_chunk_phase_t *pre, lcd_chunk_phase_t *cur, int update_reads) {
+    if (cur->tid != pre->tid) return 0;
+    if (cur->n_up_ovlp != pre->n_down_ovlp) return -6; // the reference exits here (:1627-1630)
+    if (cur->n_up_ovlp <= 0 || pre->n_vars <= 0 || cur->n_vars <= 0) return 0;
+    int score = 0; int64_t max_pre = -1, min_cur = INT64_MAX;
+    for (int j = 0; j < cur->n_up_ovlp; ++j) {
+        const int cr = cur->up_ovlp_read_i[j], pr = pre->down_ovlp_read_i[j];
+        if (pre->is_skipped[pr] || pre->haps[pr] == 0 || cur->is_skipped[cr] || cur->haps[cr] == 0) continue;
+        score += pre->haps[pr] == cur->haps[cr] ? -1 : 1;
+        max_pre = std::max(max_pre, pre->phase_sets[pr]); min_cur = std::min(min_cur, cur->phase_sets[cr]);
+    }
+    if (score == 0) return 0;
+    cur->flip_pre_PS = max_pre; cur->flip_cur_PS = min_cur; cur->flip_hap = score > 0;
+    join_var_phase(*cur);
+    if (update_reads) join_read_phase(*cur);
+    return 0;
+}
+int lcd_stitch_chunks(lcd_chunk_phase_t *chunks, int n, int update_reads) {
+    for (int i = 1; i < n; ++i) { const int rc = lcd_flip_variant_hap(chunks + i - 1, chunks + i, update_reads); if (rc) return rc; }
+    return 0;
+}
+
+void lcd_call_opt_default(lcd_call_opt_t *o) {
+    o->log_p = -3.0; o->log_1p = -0.00043451177401769168 /* log10(1 - 0.001) */; o->log_2 = 0.301023; o->max_gq = 60; o->max_qual = 60;
+    o->min_sv_len = 30; o->min_dp = 5; o->min_alt_dp = 2; o->out_amb_base = 0;
+}
+
+int lcd_make_variants(const lcd_call_opt_t *opt, const lcd_hap_problem_t *p, const int *var_ref_len, const int *var_alt_len, const uint64_t *alt_off,
+                      const uint8_t *alt_pool, const uint8_t *alt_ref_base, const char *ref_seq, int64_t ref_beg, int64_t reg_beg, int64_t reg_end,
+                      lcd_var1_t **vars_out) {
+    *vars_out = nullptr;
+    const int V = p->n_vars;
+    if (V <= 0) return 0;
+    std::vector<lcd_var1_t> out;
+    for (int ci = 0; ci < V; ++ci) {
+        if ((p->var_cate[ci] & kOutCate) == 0) continue;
+        lcd_var1_t v; memset(&v, 0, sizeof(v));
+        const bool gap = p->var_type[ci] == 2 || p->var_type[ci] == 1; // BAM_CDEL / BAM_CINS: the VCF record starts one base earlier
+        v.pos = p->var_pos[ci] - (gap ? 1 : 0); v.ref_len = var_ref_len[ci] + (gap ? 1 : 0);
+        if (v.pos < reg_beg || v.pos > reg_end) continue;
+        int a1 = p->hap_to_cons_alle[3 * ci + 1], a2 = p->hap_to_cons_alle[3 * ci + 2];
+        const int hom = p->hap_to_cons_alle[3 * ci];
+        bool is_hom = false;
+        if (a1 == -1 && a2 == -1) { is_hom = true; a1 = a2 = hom; } else if (a1 == a2) is_hom = true;
+        if (a1 == -1) a1 = 0;
+        if (a2 == -1) a2 = 0;
+        v.type = p->var_type[ci]; v.PS = p->var_phase_set[ci];
+        v.ref_bases = (uint8_t *)malloc((size_t)v.ref_len + 1);
+        for (int j = 0; j < v.ref_len; ++j) v.ref_bases[j] = nt4((unsigned char)ref_seq[v.pos - ref_beg + j]);
+        v.is_clean = (p->var_cate[ci] & kCleanCate) != 0;
+        bool hom_set = false;
+        for (int hap = 1; hap <= 2; ++hap) {
+            const int al = hap == 1 ? a1 : a2;
+            if (al == 0) { v.GT[hap - 1] = 0; continue; }
+            if (is_hom && hom_set) { v.GT[hap - 1] = v.n_alt_allele; continue; }
+            int alen = var_alt_len[ci];
+            uint8_t *ab = (uint8_t *)malloc((size_t)alen + 2);
+            const uint8_t *as = alt_pool + alt_off[ci];
+            if (gap) {
+                ab[0] = alt_ref_base[ci] != 4 ? alt_ref_base[ci] : nt4((unsigned char)ref_seq[v.pos - ref_beg]);
+                for (int j = 0; j < alen; ++j) ab[1 + j] = as[j];
+                alen += 1;
+            } else
+                for (int j = 0; j < alen; ++j) ab[j] = as[j];
+            v.alt_bases[v.n_alt_allele] = ab; v.alt_len[v.n_alt_allele] = alen;
+            if (std::abs(alen - v.ref_len) >= opt->min_sv_len) v.is_sv = 1;
+            v.GT[hap - 1] = ++v.n_alt_allele;
+            if (is_hom) hom_set = true;
+        }
+        v.DP = p->total_cov[ci];
+        const int na = p->alle_off[ci + 1] - p->alle_off[ci];
+        const int *cov = p->alle_covs + p->alle_off[ci];
+        v.AD[0] = na > 0 ? cov[0] : 0; v.AD[1] = na > 1 ? cov[1] : 0;
+        // var1_t declares `int DP, AD[2]; uint8_t GT[2];` and the reference stores EVERY allele's coverage through AD[j] (:1567): a third allele
+        // (the "minor alt") lands on the two GT bytes, which follow AD in the struct -- reproduced, since it is what the reference writes to the VCF
+        // (a fourth one lands on QUAL, which is assigned afterwards)
+        if (na > 2) { v.GT[0] = cov[2] & 0xff; v.GT[1] = (cov[2] >> 8) & 0xff; }
+        if (v.AD[1] > 0) {
+            v.alt_read_i = (int *)malloc((size_t)v.AD[1] * sizeof(int));
+            int k2 = 0;
+            for (int k = 0; k < p->n_reads; ++k) {
+                const int r = p->ordered_read_ids[k];
+                if (p->is_skipped[r]) continue;
+                const int s = p->start_var_idx[r], e = p->end_var_idx[r];
+                if (s < 0 || e < 0 || ci < s || ci > e) continue;
+                if (p->alleles[p->allele_off[r] + (ci - s)] == 1) { if (k2 >= v.AD[1]) { free_members(out.data(), (int)out.size()); free_members(&v, 1); return -6; /* the reference exits, :1579 */ } v.alt_read_i[k2++] = r; }
+            }
+            v.AD[1] = k2; v.n_alt_reads = k2;
+        }
+        v.QUAL = std::min(opt->max_qual, (int)(-10 * (v.AD[0] * opt->log_1p + v.AD[1] * opt->log_p)));
+        {
+            const int PL[3] = {(int)(-10 * (v.AD[0] * opt->log_1p + v.AD[1] * opt->log_p)), (int)(10 * (v.AD[0] + v.AD[1]) * opt->log_2), (int)(-10 * (v.AD[0] * opt->log_p + v.AD[1] * opt->log_1p))};
+            int lo = INT_MAX, sec = INT_MAX;
+            for (int x : PL) { if (x < lo) { sec = lo; lo = x; } else if (x < sec) sec = x; }
+            v.GQ = std::min(opt->max_gq, sec - lo);
+        }
+        out.push_back(v);
+    }
+    lcd_var1_t *res = (lcd_var1_t *)malloc((out.size() + 1) * sizeof(lcd_var1_t));
+    memcpy(res, out.data(), out.size() * sizeof(lcd_var1_t));
+    *vars_out = res;
+    return (int)out.size();
+}
+void lcd_free_variants(lcd_var1_t *vars, int n) {
+    if (!vars) return;
+    free_members(vars, n);
+    free(vars);
+}
+
+int lcd_format_vcf(const lcd_call_opt_t *opt, const char *chrom, const lcd_var1_t *vars, int n, char **text_out) {
+    std::string t; int n_out = 0; char num[64];
+    for (int i = 0; i < n; ++i) {
+        const lcd_var1_t &v = vars[i];
+        if (v.n_alt_allele == 0 || v.DP < opt->min_dp || v.AD[1] < opt->min_alt_dp) continue;
+        if (!opt->out_amb_base) {
+            bool bad = false;
+            for (int j = 0; j < v.ref_len && !bad; ++j) bad = v.ref_bases[j] >= 4;
+            for (int a = 0; a < v.n_alt_allele && !bad; ++a) for (int k = 0; k < v.alt_len[a] && !bad; ++k) bad = v.alt_bases[a][k] >= 4;
+            if (bad) continue;
+        }
+        t += chrom; t += '\t'; t += std::to_string((long long)v.pos); t += "\t.\t";
+        for (int j = 0; j < v.ref_len; ++j) t += "ACGTN"[v.ref_bases[j]];
+        t += '\t';
+        for (int a = 0; a < v.n_alt_allele; ++a) { for (int k = 0; k < v.alt_len[a]; ++k) t += "ACGTN"[v.alt_bases[a][k]]; if (a + 1 < v.n_alt_allele) t += ','; }
+        std::string svlen = "SVLEN=", svtype = "SVTYPE=";
+        if (v.is_sv) for (int a = 0; a < v.n_alt_allele; ++a) { if (a) { svlen += ','; svtype += ','; } svlen += std::to_string(v.alt_len[a] - v.ref_len); svtype += v.alt_len[a] > v.ref_len ? "INS" : "DEL"; }
+        t += '\t'; t += std::to_string(v.QUAL); t += "\tPASS\t";
+        if (v.is_clean) t += "CLEAN;";
+        t += "END="; t += std::to_string((long long)(v.pos + v.ref_len - 1));
+        if (v.is_sv) { t += ';'; t += svtype; t += ';'; t += svlen; }
+        t += '\t';
+        int g1 = v.GT[0], g2 = v.GT[1]; const bool hom = g1 == g2; char sep = '|';
+        if (v.PS == 0) { sep = '/'; if (g1 > g2) std::swap(g1, g2); }
+        t += "GT:DP:AD:VAF:GQ";
+        if (!hom && v.PS != 0) t += ":PS";
+        t += '\t'; t += std::to_string(g1); t += sep; t += std::to_string(g2); t += ':'; t += std::to_string(v.DP); t += ':';
+        for (int a = 0; a < 1 + v.n_alt_allele; ++a) { if (a) t += ','; t += std::to_string(v.AD[a]); }
+        for (int a = 0; a < v.n_alt_allele; ++a) { t += a ? ',' : ':'; snprintf(num, sizeof(num), "%.3f", (float)v.AD[a + 1] / v.DP); t += num; }
+        t += ':'; t += std::to_string(v.GQ);
+        if (!hom && v.PS != 0) { t += ':'; t += std::to_string((long long)v.PS); }
+        t += '\n'; ++n_out;
+    }
+    char *o = (char *)malloc(t.size() + 1);
+    memcpy(o, t.c_str(), t.size() + 1);
+    *text_out = o;
+    return n_out;
+}
+
+void lcd_read_tags(int n, const int *haps, const int64_t *ps, uint8_t *has_hp, int *hp, uint8_t *has_ps, int64_t *ps_out) {
+    for (int i = 0; i < n; ++i) { has_hp[i] = haps[i] != 0; hp[i] = haps[i]; has_ps[i] = ps[i] > 0; ps_out[i] = ps[i]; }
+}
+}

@@ -370,7 +370,7 @@ void lcd_opt_default(lcd_opt_t *o) {
     o->match = 2; o->mismatch = 6; o->gap_open1 = 6; o->gap_ext1 = 2; o->gap_open2 = 24; o->gap_ext2 = 1;
     o->gap_aln = 1; o->min_af = 0.20; o->min_dp = 5; o->partial_aln_ratio = 1.1;
     o->min_noisy_reg_size_to_sample_reads = 10000; o->max_noisy_reg_len = 50000; o->noisy_reg_flank_len = 10;
-    o->min_hap_full_reads = 1; o->min_hap_reads = 2; o->collect_ref_read_aln_str = 0; o->is_ont = 0; o->collect_noisy_vars = 0; o->min_sv_len = 50;
+    o->min_hap_full_reads = 1; o->min_hap_reads = 2; o->collect_ref_read_aln_str = 0; o->is_ont = 0; o->collect_noisy_vars = 0; o->min_sv_len = 30; // LONGCALLD_MIN_SV_LEN, src/call_var_main.h:54
 }
 int lcd_init(int device) { // the process default device (bench.py: LOCAL_RANK); batches and threads may choose another one
     if (init_default_device()) return -1;

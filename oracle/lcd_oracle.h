@@ -234,6 +234,29 @@ typedef struct {
     int *hap_to_alle_profile;        /* 3 planes of alle_off[n_vars] ints: [h*total + alle_off[v] + a] */
 } lcdo_hap_problem_t;
 int lcdo_assign_hap_germline(lcdo_hap_problem_t *p, int target_var_cate);
+
+/* ---------------- stitching, genotype records, VCF body text (oracle/emit.c) ---------------- */
+typedef struct { double log_p, log_1p, log_2; int max_gq, max_qual, min_sv_len, min_dp, min_alt_dp, out_amb_base; } lcdo_call_opt_t;
+typedef struct {
+    int64_t pos, PS;
+    int type, ref_len, n_alt_allele, alt_len[2];
+    uint8_t *ref_bases, *alt_bases[2];
+    int GT[2], DP, AD[2], QUAL, GQ, is_sv, is_clean, n_alt_reads;
+    int *alt_read_i;
+} lcdo_var1_t;
+typedef struct {
+    int tid, n_reads, n_vars;
+    const int *ordered_read_ids; const uint8_t *is_skipped;
+    int *haps; int64_t *phase_sets; int64_t *var_phase_set; int *hap_to_cons_alle;
+    int n_up_ovlp, n_down_ovlp; const int *up_ovlp_read_i, *down_ovlp_read_i;
+    int flip_hap; int64_t flip_pre_PS, flip_cur_PS;
+} lcdo_chunk_phase_t;
+int lcdo_make_variants(const lcdo_call_opt_t *opt, const lcdo_hap_problem_t *p, const int *var_ref_len, const int *var_alt_len, const uint64_t *alt_off,
+                       const uint8_t *alt_pool, const uint8_t *alt_ref_base, const char *ref_seq, int64_t ref_beg, int64_t reg_beg, int64_t reg_end,
+                       lcdo_var1_t **vars_out);
+void lcdo_free_variants(lcdo_var1_t *v, int n);
+int lcdo_flip_variant_hap(lcdo_chunk_phase_t *pre_chunk, lcdo_chunk_phase_t *cur_chunk, int out_aln);
+int lcdo_format_vcf(const lcdo_call_opt_t *opt, const char *chrom, const lcdo_var1_t *vars, int n_vars, char **text_out);
 /* order of intervals (st[i], en[i], label i) after cr_index(): cr_is_sorted / radix_sort_cr_intv (src/cgranges.c:13-86,162,350) */
 void lcdo_cr_sorted_order(int n, const int *st, const int *en, int *order_out);
 

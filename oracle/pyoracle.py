@@ -136,7 +136,7 @@ def ref_cr_overlap(st, en, qst, qen):
     return out[:k].copy()
 
 
-def ref_pre_process_noisy_regs(chunk_noisy, low_comp, read_beg, read_end, read_ivs, min_alt_dp=2, min_af=0.2, merge_dis=500, min_sv_len=50):
+def ref_pre_process_noisy_regs(chunk_noisy, low_comp, read_beg, read_end, read_ivs, min_alt_dp=2, min_af=0.2, merge_dis=500, min_sv_len=30):
     """pre_process_noisy_regs with the REFERENCE's cgranges doing every interval operation (oracle/ref_cgranges_shim.c)"""
     L = ref_cgranges()
     L.ref_pre_process_noisy_regs.argtypes = [C.c_int, i32p, C.c_int, i32p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), i32p, i32p, C.c_int, C.c_int, C.c_int, C.c_float,
@@ -329,7 +329,7 @@ class NoisyVar(C.Structure):
 VAR_KEYS = ("pos", "var_type", "ref_len", "alt_len", "cate", "from_cons", "is_homopolymer_indel", "ref_base", "alt_ref_base", "total_cov")
 
 
-def make_vars_from_msa_cons_aln(res, noisy_reg_beg, chunk_ref, chunk_ref_beg, min_sv_len=50):
+def make_vars_from_msa_cons_aln(res, noisy_reg_beg, chunk_ref, chunk_ref_beg, min_sv_len=30):
     """SURVEY 8(f) f1 oracle (oracle/cand_vars.c) on a region result dict (collect_noisy_reg_aln_strs above or RegionBatch.result):
     -> dict(n_vars, <VAR_KEYS arrays>, alle_covs (n,2), alt_seqs [arrays], prof_start, prof_end, prof_alleles (rows x n_vars))"""
     nc = res["n_cons"]

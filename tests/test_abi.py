@@ -31,7 +31,7 @@ def test_opt_defaults_match_reference():
     assert (o.match, o.mismatch, o.gap_open1, o.gap_ext1, o.gap_open2, o.gap_ext2) == (2, 6, 6, 2, 24, 1)
     assert o.gap_aln == 1 and o.min_dp == 5 and abs(o.min_af - 0.2) < 1e-12 and abs(o.partial_aln_ratio - 1.1) < 1e-12
     assert (o.min_noisy_reg_size_to_sample_reads, o.max_noisy_reg_len, o.noisy_reg_flank_len) == (10000, 50000, 10)
-    assert (o.min_hap_full_reads, o.min_hap_reads) == (1, 2)
+    assert (o.min_hap_full_reads, o.min_hap_reads) == (1, 2) and o.min_sv_len == 30   # LONGCALLD_MIN_SV_LEN
 
 
 def test_no_cpu_fallback_without_gpu():
