@@ -93,6 +93,7 @@ struct PoaLayout {
     uint64_t n_base, imap;                               // uint8[node_cap]
     uint64_t het, clu, nclu, prof;                       // int32[node_cap], int32[n_reads] x2, uint8[2*node_cap]
     uint64_t aa_node, aa_flag, aa_eid;                   // int32[max_len+2] x3: per-cigar-entry scratch of the parallel graph update
+    uint64_t tb;                                         // int32[4*node_cap]: column-tile boundaries of the unbanded rows (poa_kernel.hip align_unbanded)
     uint64_t pl_start, pl_pidx, pl_bonus, pl_rem, pl_base; // row plan: int32[node_cap+4], int32[edge_cap] x2, int32[node_cap], u8[node_cap]
     uint64_t total;
 };
@@ -122,6 +123,7 @@ static inline LCD_HD PoaLayout poa_layout(int node_cap, int edge_cap, int rid_wo
     LCD_TAKE(pl_start, (uint64_t)(node_cap + 4) * 4); LCD_TAKE(pl_pidx, (uint64_t)edge_cap * 4); LCD_TAKE(pl_bonus, (uint64_t)edge_cap * 4);
     LCD_TAKE(pl_rem, (uint64_t)node_cap * 4); LCD_TAKE(pl_base, (uint64_t)node_cap);
     LCD_TAKE(aa_node, (uint64_t)(max_len + 2) * 4); LCD_TAKE(aa_flag, (uint64_t)(max_len + 2) * 4); LCD_TAKE(aa_eid, (uint64_t)(max_len + 2) * 4);
+    LCD_TAKE(tb, max_len + 2 > 4096 ? (uint64_t)node_cap * 16 : 16); // (only reads longer than one 4 096-column tile use it)
 #undef LCD_TAKE
     L.total = lcd_align_up(o, 256);
     return L;

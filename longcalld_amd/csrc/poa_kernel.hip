@@ -73,6 +73,7 @@ struct Ctx {
     int *het, *clu, *nclu; uint8_t *prof;
     int *pl_start, *pl_pidx, *pl_bonus, *pl_rem; uint8_t *pl_base;
     int *aa_node, *aa_flag, *aa_eid;
+    int *tb;                          // column-tile boundaries of the unbanded rows: 4 x node_cap ints (H of the last column, by tile parity; F carries)
     int wmax, seq_cap, pool_words, spill_x;
     int n_node, n_edge, node_cap, edge_cap, rid_words;
     unsigned long long cell_cap;
@@ -732,6 +733,7 @@ __device__ void ctx_to_sgpr(Ctx &g) {
     g.rbeg = usgpr(g.rbeg); g.rend = usgpr(g.rend); g.roff = usgpr(g.roff); g.ooff = usgpr(g.ooff); g.spoff = usgpr(g.spoff);
     g.ml = usgpr(g.ml); g.mr = usgpr(g.mr); g.idx2node = usgpr(g.idx2node);
     g.cig_node0 = usgpr(g.cig_node0); g.cig_qpos0 = usgpr(g.cig_qpos0); g.imap = usgpr(g.imap);
+    g.tb = usgpr(g.tb);
     g.pl_start = usgpr(g.pl_start); g.pl_pidx = usgpr(g.pl_pidx); g.pl_bonus = usgpr(g.pl_bonus); g.pl_rem = usgpr(g.pl_rem); g.pl_base = usgpr(g.pl_base);
     g.wmax = usgpr(g.wmax); g.cell_cap = usgpr(g.cell_cap); g.status = usgpr(g.status); g.spill_x = usgpr(g.spill_x);
 }
@@ -1185,26 +1187,43 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
     constexpr int WIN = 4 * NT, WM = WIN - 1, SLOTW = 3 * WIN;
     const int tid = threadIdx.x, lane = tid & 63, wave = usgpr(tid >> 6); // (wave in an SGPR: branches on it are scalar)
     const int o1 = sc.o1, e1 = sc.e1, o2 = sc.o2, e2 = sc.e2;
-    if (qlen + 2 > WIN) return -1;
-    const int jb = 4 * tid;
-    const int AW = imin(NW, (qlen >> 8) + 1); // wavefronts that own a column <= qlen
+    // Reads longer than the window are swept in COLUMN TILES of WIN columns (1 024-thread class only): tile t runs every row over the columns
+    // [t * WIN, (t + 1) * WIN); what crosses a tile boundary is, per row, H of the tile's last column (the diagonal input of the next tile's first
+    // column) and the two running F prefixes -- three ints per row through HBM (g.tb), exactly what the wavefronts of one tile hand each other
+    // through the LDS mailboxes.  Codes / ordinals are stored row-major over the WHOLE read, so the code-driven backtrack does not know about
+    // tiles; spilled value rows are per tile and only the last tile's are read afterwards (the end node looks at column qlen).
+    const int n_tiles = qlen + 2 > WIN ? (qlen >> (NT == 1024 ? 12 : 30)) + 1 : 1;
+    if (n_tiles > 1 && NT != 1024) return -1;
+    const int jl = 4 * tid;                  // first of this lane's four columns inside the tile
     const int cw4 = ((qlen >> 2) + 1) << 2;  // cells of a row in HBM, padded to the lanes' 4-cell groups
     const unsigned long long code_cap = g.cell_cap, ord_cap = g.spill_x > 2 ? g.cell_cap : g.cell_cap / 4;
     const long long spill_rows = g.cell_cap * g.spill_x > 64 ? (long long)((g.cell_cap * g.spill_x - 64) / ((unsigned long long)SLOTW * 4)) : 0;
+    {
+        int has_n = 0;
+        for (int j = tid; j < qlen; j += NT) has_n |= seq_hbm[j] >= 4;
+        if (__syncthreads_or(has_n)) return -1; // reads with N bases (score 0 against everything) take the windowed rows
+    }
+    int *const tb_h[2] = {g.tb, g.tb + g.node_cap}; int *const tb_c1 = g.tb + 2 * (size_t)g.node_cap, *const tb_c2 = g.tb + 3 * (size_t)g.node_cap;
+    unsigned long long ncell = 0, t_plan = 0, t_poll = 0;
+    int AW = 1;
+    const long long t_dp0 = clock64();
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    const int tbase = tile * WIN, jb = tbase + jl, par = tile & 1;
+    const bool more = tile + 1 < n_tiles;
+    AW = imin(NW, ((imin(qlen, tbase + WIN - 1) - tbase) >> 8) + 1); // wavefronts that own a column <= qlen in this tile
     // per-lane constants of this read
     // (one packed register: q[jb-1], q[jb], q[jb+1], q[jb+2] in bytes 0..3; columns outside the read get 15, which matches no base)
-    unsigned qpk = 0; int has_n = 0;
+    unsigned qpk = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int j = jb + k;
         int b = 15;
-        if (j >= 1 && j <= qlen) { b = seq_hbm[j - 1]; has_n |= b >= 4; }
+        if (j >= 1 && j <= qlen) b = seq_hbm[j - 1];
         qpk |= (unsigned)b << (8 * k);
     }
-    if (__syncthreads_or(has_n)) return -1; // reads with N bases (score 0 against everything) take the windowed rows
     const int je1 = jb * e1, je2 = jb * e2;            // A[k] = Hpre[k] + (jb + k) * e
     const int noj1 = -(o1 + je1), noj2 = -(o2 + je2);  // F[k] = prefix + noj - k * e
-    const unsigned lofs = 16u * (unsigned)tid;         // this lane's 4 cells inside a plane (bytes)
+    const unsigned lofs = 16u * (unsigned)tid;         // this lane's 4 cells inside a plane (bytes; tile-local)
     const unsigned PL = 4u * (unsigned)WIN;            // plane stride (bytes)
     int nsp = 0;
     // ---- source row (slot 0) ----
@@ -1220,19 +1239,20 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
         }
         const int4 H4 = make_int4(hh[0], hh[1], hh[2], hh[3]);
         const int4 A4 = make_int4(hh[0] - o1, hh[1] - o1, hh[2] - o1, hh[3] - o1), B4 = make_int4(hh[0] - o2, hh[1] - o2, hh[2] - o2, hh[3] - o2);
-        if (jb < WIN) {
+        {
             lds_st4(ring + lofs, H4); lds_st4(ring + PL + lofs, A4); lds_st4(ring + 2 * PL + lofs, B4);
-            if (spf) { int *G = g.spill; glb_st4(G + jb, H4); glb_st4(G + WIN + jb, A4); glb_st4(G + 2 * WIN + jb, B4); }
+            if (spf) { int *G = g.spill; glb_st4(G + jl, H4); glb_st4(G + WIN + jl, A4); glb_st4(G + 2 * WIN + jl, B4); }
         }
         if (SYS && lane == 63) { g_wide.bndH[bi & (SYS_D - 1)][wave] = H4.w; g_wide.prog[wave] = bi; }
+        if (more && tid == NT - 1) glb_st(tb_h[par] + bi, H4.w); // the source row's H at the tile's last column
         if (tid == 0) { g.rbeg[bi] = 0; g.rend[bi] = qlen; g.roff[bi] = 0; g.ml[bi] = 0; g.mr[bi] = 0; g.spoff[bi] = 0; sm.bc[7] = LCD_OK; }
         if (spf) nsp = 1;
     }
-    unsigned long long cused = 0, oused = 0, ncell = (unsigned long long)qlen + 1;
+    unsigned long long cused = 0, oused = 0;
+    const unsigned long long tcols = (unsigned long long)(imin(qlen, tbase + WIN - 1) - tbase + 1);
+    ncell += tcols;
     __syncthreads();
-    const long long t_dp0 = clock64();
     int err = LCD_OK;
-    unsigned long long t_plan = 0, t_poll = 0;
     if (wave < AW) {
         int wbase = -(1 << 20);
         int w_pk = 0, w_pi0 = 0, w_pi1 = 0; // w_pk: #preds (16 bits) | base << 16 | spill << 19 | unreachable << 20 | bonus0 << 21 | bonus1 << 26
@@ -1288,11 +1308,11 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
             auto near_row = [&](const int pi, int &hm, int4 &hv, int4 &av, int4 &bv) {
                 const unsigned S = ring + 4u * (unsigned)(((pi - bi) & (K - 1)) * SLOTW);
                 hm = lds_ld(S + lofs - 4); hv = lds_ld4(S + lofs); av = lds_ld4(S + PL + lofs); bv = lds_ld4(S + 2 * PL + lofs);
-                if (lane == 0) hm = wave == 0 ? LCD_GUARD : (SYS ? g_wide.bndH[pi & (SYS_D - 1)][wave - 1] : hm);
+                if (lane == 0) hm = wave == 0 ? (tile ? glb_ld(tb_h[par ^ 1] + pi) : LCD_GUARD) : (SYS ? g_wide.bndH[pi & (SYS_D - 1)][wave - 1] : hm);
             };
             auto far_row = [&](const int pi, int &hm, int4 &hv, int4 &av, int4 &bv) {
                 const int *G = g.spill + (size_t)(unsigned)glb_ld((const int *)g.spoff + pi) * SLOTW;
-                hm = tid ? glb_ld(G + jb - 1) : LCD_GUARD; hv = glb_ld4(G + jb); av = glb_ld4(G + WIN + jb); bv = glb_ld4(G + 2 * WIN + jb);
+                hm = tid ? glb_ld(G + jl - 1) : (tile ? glb_ld(tb_h[par ^ 1] + pi) : LCD_GUARD); hv = glb_ld4(G + jl); av = glb_ld4(G + WIN + jl); bv = glb_ld4(G + 2 * WIN + jl);
                 LCD_PIN(hm); LCD_PIN(hv.x); LCD_PIN(hv.y); LCD_PIN(hv.z); LCD_PIN(hv.w); LCD_PIN(av.x); LCD_PIN(av.y); LCD_PIN(av.z); LCD_PIN(av.w);
                 LCD_PIN(bv.x); LCD_PIN(bv.y); LCD_PIN(bv.z); LCD_PIN(bv.w);
             };
@@ -1340,6 +1360,7 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
             int x1 = shr1(LCD_GUARD, t1), x2 = shr1(LCD_GUARD, t2); // exclusive prefix over the lanes of this wavefront
             int cin1 = LCD_GUARD, cin2 = LCD_GUARD;
             if (SYS && wave > 0) { cin1 = g_wide.carry1[idx & (SYS_D - 1)][wave - 1]; cin2 = g_wide.carry2[idx & (SYS_D - 1)][wave - 1]; x1 = imax(x1, cin1); x2 = imax(x2, cin2); }
+            else if (tile) { cin1 = glb_ld(tb_c1 + idx); cin2 = glb_ld(tb_c2 + idx); LCD_PIN(cin1); LCD_PIN(cin2); x1 = imax(x1, cin1); x2 = imax(x2, cin2); } // the row's F prefixes over the tiles before
             // ---- phase B: F, H, E-out, direction code of the four cells ----
             int hh0, hh1, hh2, hh3, ea0, ea1, ea2, ea3, eb0, eb1, eb2, eb3;
             unsigned code = 0;
@@ -1363,10 +1384,10 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
 #undef LCD_CELL
             // ---- stores: ring slot (values), HBM (codes; values only for rows a far successor / the end node will read) ----
             const int4 H4 = make_int4(hh0, hh1, hh2, hh3), A4 = make_int4(ea0, ea1, ea2, ea3), B4 = make_int4(eb0, eb1, eb2, eb3);
-            if (jb < WIN) {
+            {
                 const unsigned S = ring + 4u * (unsigned)(s * SLOTW);
                 lds_st4(S + lofs, H4); lds_st4(S + PL + lofs, A4); lds_st4(S + 2 * PL + lofs, B4);
-                if (spf) { int *G = g.spill + (size_t)nsp * SLOTW; glb_st4(G + jb, H4); glb_st4(G + WIN + jb, A4); glb_st4(G + 2 * WIN + jb, B4); }
+                if (spf) { int *G = g.spill + (size_t)nsp * SLOTW; glb_st4(G + jl, H4); glb_st4(G + WIN + jl, A4); glb_st4(G + 2 * WIN + jl, B4); }
                 if (jb < cw4) {
                     glb_st(g.code8 + cused + jb, (int)code);
                     if (np > 1) glb_st4(g.ord + oused + jb, make_int4((om & 255) | ((oa & 255) << 8) | ((ob & 255) << 16),
@@ -1383,18 +1404,20 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
                 if (lane == 63) {
                     g_wide.bndH[idx & (SYS_D - 1)][wave] = hh3;
                     g_wide.carry1[idx & (SYS_D - 1)][wave] = imax(cin1, t1); g_wide.carry2[idx & (SYS_D - 1)][wave] = imax(cin2, t2);
+                    if (more && wave == NW - 1) { glb_st(tb_h[par] + idx, hh3); glb_st(tb_c1 + idx, imax(cin1, t1)); glb_st(tb_c2 + idx, imax(cin2, t2)); } // -> the next tile
                 }
                 // the row is complete in LDS (and, for a spilled row, in HBM) before the neighbours may look at it
                 if (spf) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 63) *(volatile lcd_lds_i32 *)(uintptr_t)lds_off(&g_wide.prog[wave]) = idx; // (LDS-typed: a generic volatile store is a flat store + vmcnt(0))
             }
             cused += cw4; if (np > 1) oused += cw4; if (spf) ++nsp;
-            ncell += (unsigned long long)qlen + 1;
+            ncell += tcols;
         }
     }
     if (tid == 0 && err != LCD_OK) sm.bc[7] = err;
-    __syncthreads();
+    __syncthreads(); // (also: every store of this tile -- boundary columns, spilled rows -- has landed before the next tile reads them)
     if (sm.bc[7] != LCD_OK) { const int e = sm.bc[7]; __syncthreads(); if (e == LCD_FALLBACK) return -1; wo->status = e; return 0; }
+  } // tiles
     wo->cells = ncell;
     if (tid == (AW - 1) * 64) { sm.prof[0] = t_plan; sm.prof[1] = t_poll; } // (profiling aid: the LAST active wavefront's view)
     const long long t_bt0 = clock64();
@@ -1859,6 +1882,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.pl_start = (int *)(ws + L.pl_start); g.pl_pidx = (int *)(ws + L.pl_pidx); g.pl_bonus = (int *)(ws + L.pl_bonus);
     g.pl_rem = (int *)(ws + L.pl_rem); g.pl_base = ws + L.pl_base;
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
+    g.tb = (int *)(ws + L.tb);
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
     g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - Cfg<NT>::K * 3 * ring_cols) * 4;
     g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0;

@@ -348,3 +348,32 @@ def test_poa_k2_longer_than_the_window(lcd):
     members = sorted(int(x) for c in range(2) for x in g["clu"][c])
     assert members == list(range(len(reads)))
     assert {int(x) % 2 for x in g["clu"][0]} in ({0}, {1}) and {int(x) % 2 for x in g["clu"][1]} in ({0}, {1})
+
+
+def test_poa_k2_column_tiles_agree_with_generic_rows_and_oracle(lcd, oracle, monkeypatch):
+    """K2 reads longer than the 4 096-column window are swept in column tiles (align_unbanded: per-row boundary H + F carries through HBM, codes
+    row-major over the whole read).  Two and three tiles, clean and noisy reads, an SV between the haplotypes: identical to the generic HBM rows
+    (LCD_DBG=8) bit for bit, and -- at the size the scalar oracle still does in seconds -- identical to the oracle"""
+    rng = np.random.default_rng(710)
+    jobs = []
+    for L, rate, n in [(4300, 0.002, 6), (8700, 0.01, 6), (6100, 0.05, 8), (4095, 0.001, 5), (4096, 0.001, 5)]:
+        h1 = rng.integers(0, 4, L).astype(np.uint8)
+        h2 = np.concatenate([h1[:L // 3], rng.integers(0, 4, 150).astype(np.uint8), h1[L // 3:]])
+        h2[L // 2] = (h2[L // 2] + 1) % 4
+        jobs.append(dict(mode=1, reads=[mutate(rng, h1 if i % 2 == 0 else h2, rate) for i in range(n)]))
+    a = lcd.poa_batch(jobs)
+    monkeypatch.setenv("LCD_DBG", "8")
+    b = lcd.poa_batch(jobs)
+    monkeypatch.delenv("LCD_DBG")
+    for x, y in zip(a, b):
+        assert x["status"] == 0 and y["status"] == 0 and x["n_cons"] == y["n_cons"] and x["msa_len"] == y["msa_len"]
+        for r, q in zip(x["msa"], y["msa"]):
+            assert (r == q).all()
+        for c in range(x["n_cons"]):
+            assert (x["cons"][c] == y["cons"][c]).all() and (x["clu"][c] == y["clu"][c]).all()
+    exp = oracle.poa_aln_msa_cons(jobs[0]["reads"])
+    assert a[0]["n_cons"] == exp["n_cons"] and a[0]["msa_len"] == exp["msa_len"]
+    for c in range(exp["n_cons"]):
+        assert (a[0]["cons"][c] == exp["cons"][c]).all()
+    for r, q in zip(a[0]["msa"], exp["msa"]):
+        assert (r == q).all()
