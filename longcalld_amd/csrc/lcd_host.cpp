@@ -669,6 +669,8 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     if (C.mode == 0) band = std::min<long long>(maxl + 1, 2ll * (10 + maxl / 100) + 1 + band_x[hint]);
     else band = maxl + 1;
     long long cells = rows_est * band;
+    // (tried: 3x the estimate up front for the long K1 chains of noisy reads, which overflow most -- 5 instead of 60 re-runs per 4 SV-shape batches, but
+    // the POA stage got 20 % LONGER: an overflowing chain gives up early and its re-run shares the chip with ~50 others instead of 9 000)
     // K2 chains of noisy reads: at one code byte per worst-case cell EVERY such chain ran out of spilled value rows (a spilled row is 12 bytes
     // per window column; clean graphs spill a few per cent of their rows, but in the graphs of 5 %-error reads most rows have a successor more
     // than K rows away, and nearly every row has >= 2 usable predecessors, i.e. an ordinal word per cell) and was re-run with a 4x graph.
