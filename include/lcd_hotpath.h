@@ -312,6 +312,32 @@ int lcd_format_vcf(const lcd_call_opt_t *opt, const char *chrom, const lcd_var1_
  * another value is replaced, one that should not be there is deleted): has_hp / has_ps say whether the record ends up carrying the tag */
 void lcd_read_tags(int n_reads, const int *haps, const int64_t *phase_sets, uint8_t *has_hp, int *hp, uint8_t *has_ps, int64_t *ps);
 
+/* ---- the data formats in front of the path, without htslib (host code; lcd_io.cpp) ----
+ * lcd_bam_load_region == the record loop of collect_ref_seq_bam_main (src/bam_utils.c:1672-1706) for one input BAM: reads of `chrom` overlapping
+ * [reg_beg, reg_end] (1-based, i.e. sam_itr_queryi on (reg_beg - 1, reg_end]) that are mapped, primary (not BAM_FSECONDARY / BAM_FSUPPLEMENTARY) and of
+ * MAPQ >= min_mapq (opt->min_mq, 30), in file order, as the flat arrays lcd_digar_batch (pos0, cigar_pool / cigar_off / n_cigar, qual_pool / qual_off, qlen)
+ * and lcd_read_view_t (seq_pool + seq_off[r] = bam_get_seq: BAM 4-bit bases) take.  BGZF blocks are inflated in parallel on n_threads host threads
+ * (0 = all); the region is a scan of the sorted file (no .bai).  Returns n_reads or < 0 (lcd_io_last_error()); free with lcd_bam_reads_free. */
+typedef struct lcd_bam_reads_t {
+    int n_reads, tid, n_targets; int64_t target_len;
+    int64_t *pos0, *end_pos;               /* bam1_core_t.pos ; bam_endpos (0-based, exclusive) */
+    int *mapq, *flag, *n_cigar, *qlen;
+    uint64_t *cigar_off; uint32_t *cigar_pool;   /* words, bam_get_cigar */
+    uint64_t *seq_off; uint8_t *seq_pool;        /* bytes, bam_get_seq */
+    uint64_t *qual_off; uint8_t *qual_pool;      /* bytes, bam_get_qual */
+    uint64_t *name_off; char *name_pool;         /* NUL-terminated, bam_get_qname */
+} lcd_bam_reads_t;
+int lcd_bam_load_region(const char *bam_path, const char *chrom, int64_t reg_beg, int64_t reg_end, int min_mapq, int n_threads, lcd_bam_reads_t *out);
+void lcd_bam_reads_free(lcd_bam_reads_t *r);
+/* faidx_fetch_seq of chrom:[beg, end] (1-based inclusive, clipped to the contig) through <fa_path>.fai, as byte codes A0 C1 G2 T3 N4 (get_bam_chunk_reg_ref_seq0,
+ * src/bam_utils.c:1558); returns the length, *codes_out malloc()'d */
+int64_t lcd_fasta_fetch(const char *fa_path, const char *chrom, int64_t beg, int64_t end, uint8_t **codes_out);
+/* the header lines write_vcf_header appends (src/vcf_utils.c:17-96) + the column line.  htslib's bcf_hdr_write decides the final order / ##fileformat line of
+ * the real tool and is absent from the reference checkout: this text is not pinned (the body lines, lcd_format_vcf, are). */
+int lcd_vcf_header(const char *source_version, const char *cmdline, const char *date_yyyymmdd, int n_contigs, const char *const *contig_names,
+                   const int64_t *contig_lens, const char *sample_name, char **text_out);
+const char *lcd_io_last_error(void);
+
 /* ---- kernel-level batches (also what the per-call mirrors above run on) ---- */
 int lcd_edlib_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *q_off, const int *qlen,
                     const uint64_t *t_off, const int *tlen, int *dist, int *xgaps, int *n_eq, int *n_xid);

@@ -1,0 +1,172 @@
+"""SURVEY 8(f) f3 -- BGZF / BAM / FASTA in front of the hot path, without htslib (liblcd_hotpath.so, lcd_io.cpp; host code, no GPU needed).
+The checker is an independent Python writer / reader (zlib + struct): a seeded BAM is written block by block, the library reads the region back;
+where the reference's bundled test BAM exists (build container only) it is read too and compared with a plain gzip + struct decoding."""
+import ctypes as C
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+i32p, i64p, u8p, u32p, u64p = C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+
+
+class BamReads(C.Structure):
+    _fields_ = [("n_reads", C.c_int), ("tid", C.c_int), ("n_targets", C.c_int), ("target_len", C.c_int64), ("pos0", i64p), ("end_pos", i64p), ("mapq", i32p),
+                ("flag", i32p), ("n_cigar", i32p), ("qlen", i32p), ("cigar_off", u64p), ("cigar_pool", u32p), ("seq_off", u64p), ("seq_pool", u8p),
+                ("qual_off", u64p), ("qual_pool", u8p), ("name_off", u64p), ("name_pool", C.POINTER(C.c_char))]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from longcalld_amd import _lib
+    L = C.CDLL(_lib.LIB_PATH)
+    L.lcd_bam_load_region.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(BamReads)]
+    L.lcd_fasta_fetch.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.POINTER(u8p)]
+    L.lcd_fasta_fetch.restype = C.c_int64
+    L.lcd_io_last_error.restype = C.c_char_p
+    return L
+
+
+def _bgzf(data, block=4000):
+    out = b""
+    for o in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if o is None else data[o:o + block]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = co.compress(chunk) + co.flush()
+        bsize = len(comp) + 25
+        out += struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, bsize) + comp + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk))
+    return out
+
+
+def _make_bam(rng, path, n=300):
+    refs = [("chrA", 50000), ("chr11", 2000000)]
+    hdr = b"@HD\tVN:1.6\tSO:coordinate\n"
+    d = b"BAM\x01" + struct.pack("<i", len(hdr)) + hdr + struct.pack("<i", len(refs))
+    for nm, ln in refs:
+        d += struct.pack("<i", len(nm) + 1) + nm.encode() + b"\0" + struct.pack("<i", ln)
+    recs = []
+    pos = np.sort(rng.integers(1000, 1200000, n))
+    for i in range(n):
+        qlen = int(rng.integers(50, 3000))
+        ops = []
+        left = qlen
+        if rng.random() < 0.3:
+            c = int(rng.integers(1, 20)); ops.append((4, c)); left -= c
+        while left > 0:
+            ln = int(min(left, rng.integers(1, 400))); ops.append((7, ln)); left -= ln
+            if left > 0 and rng.random() < 0.5:
+                op = int(rng.choice([8, 1, 2]))
+                ln = int(rng.integers(1, 30))
+                if op == 2:
+                    ops.append((2, ln))
+                else:
+                    ln = min(ln, left); ops.append((op, ln)); left -= ln
+        flag = int(rng.choice([0, 16, 256, 2048, 4], p=[0.45, 0.4, 0.05, 0.05, 0.05]))
+        mapq = int(rng.choice([60, 10, 30, 0], p=[0.7, 0.1, 0.15, 0.05]))
+        tid = 1 if i >= 5 else 0
+        seq = rng.integers(0, 16, qlen).astype(np.uint8)
+        packed = ((np.append(seq, 0)[0:2 * ((qlen + 1) // 2):2] << 4) | np.append(seq, 0)[1:2 * ((qlen + 1) // 2):2]).astype(np.uint8)
+        qual = rng.integers(0, 60, qlen).astype(np.uint8)
+        name = f"read/{i}/ccs".encode() + b"\0"
+        cig = np.array([(ln << 4) | op for op, ln in ops], "<u4")
+        body = struct.pack("<iiBBHHHiiii", tid, int(pos[i]), len(name), mapq, 4680, len(cig), flag, qlen, -1, -1, 0) + name + cig.tobytes() + packed.tobytes() + qual.tobytes()
+        if rng.random() < 0.5:
+            body += b"NMi" + struct.pack("<i", 3)
+        d += struct.pack("<i", len(body)) + body
+        rl = sum(ln for op, ln in ops if op in (0, 2, 3, 7, 8))
+        recs.append(dict(tid=tid, pos=int(pos[i]), end=int(pos[i]) + max(rl, 1), mapq=mapq, flag=flag, cig=cig, seq=packed, qual=qual, name=name[:-1].decode(), qlen=qlen))
+    open(path, "wb").write(_bgzf(d, block=int(rng.integers(2000, 60000))))
+    return recs
+
+
+def _check(lib, path, chrom, tid, recs, beg, end, min_mq):
+    r = BamReads()
+    n = lib.lcd_bam_load_region(path.encode(), chrom, beg, end, min_mq, 3, C.byref(r))
+    assert n >= 0, lib.lcd_io_last_error()
+    exp = [x for x in recs if x["tid"] == tid and x["pos"] < end and x["end"] > beg - 1 and not (x["flag"] & (4 | 256 | 2048)) and x["mapq"] >= min_mq]
+    assert n == len(exp)
+    for i, x in enumerate(exp):
+        assert r.pos0[i] == x["pos"] and r.end_pos[i] == x["end"] and r.mapq[i] == x["mapq"] and r.flag[i] == x["flag"] and r.qlen[i] == x["qlen"]
+        assert r.n_cigar[i] == len(x["cig"]) and [r.cigar_pool[r.cigar_off[i] + k] for k in range(len(x["cig"]))] == list(x["cig"])
+        nb = (x["qlen"] + 1) // 2
+        assert bytes(r.seq_pool[r.seq_off[i] + k] for k in range(nb)) == x["seq"].tobytes()
+        assert bytes(r.qual_pool[r.qual_off[i] + k] for k in range(0, x["qlen"], 7)) == x["qual"][::7].tobytes()
+        assert C.string_at(C.addressof(r.name_pool.contents) + r.name_off[i]).decode() == x["name"]
+    lib.lcd_bam_reads_free(C.byref(r))
+    return n
+
+
+def test_bam_region_loader_matches_python_writer(lib, tmp_path):
+    rng = np.random.default_rng(11)
+    path = str(tmp_path / "t.bam")
+    recs = _make_bam(rng, path)
+    assert _check(lib, path, b"chr11", 1, recs, 1, 2000000, 30) > 100
+    assert _check(lib, path, b"chr11", 1, recs, 300001, 800000, 30) > 20         # a 500 kb chunk (src/bam_utils.h:10): boundary reads on both sides
+    _check(lib, path, b"chr11", 1, recs, 300001, 800000, 0)
+    _check(lib, path, b"chrA", 0, recs, 1, 50000, 30)
+    assert _check(lib, path, b"chr11", 1, recs, 1900000, 2000000, 30) == 0      # empty region
+    r = BamReads()
+    assert lib.lcd_bam_load_region(path.encode(), b"chrX", 1, 10, 30, 1, C.byref(r)) < 0 and b"contig" in lib.lcd_io_last_error()
+    assert lib.lcd_bam_load_region(str(tmp_path / "nope.bam").encode(), b"chr11", 1, 10, 30, 1, C.byref(r)) < 0
+
+
+def test_fasta_fetch_matches_python(lib, tmp_path):
+    rng = np.random.default_rng(12)
+    seqs = {"chrA": "".join(rng.choice(list("ACGTNacgt"), 1234)), "chr11": "".join(rng.choice(list("ACGT"), 9001))}
+    fa, lw = str(tmp_path / "r.fa"), 60
+    with open(fa, "w") as f, open(fa + ".fai", "w") as fi:
+        for nm, s in seqs.items():
+            f.write(f">{nm} test\n"); off = f.tell()
+            for o in range(0, len(s), lw):
+                f.write(s[o:o + lw] + "\n")
+            fi.write(f"{nm}\t{len(s)}\t{off}\t{lw}\t{lw + 1}\n")
+    code = {c: i for i, c in enumerate("ACGT")}
+    for nm, beg, end in [("chr11", 1, 9001), ("chr11", 61, 120), ("chr11", 59, 62), ("chrA", 1000, 5000), ("chrA", 1, 1)]:
+        p = u8p()
+        n = lib.lcd_fasta_fetch(fa.encode(), nm.encode(), beg, end, C.byref(p))
+        e = min(end, len(seqs[nm]))
+        assert n == e - beg + 1
+        assert [p[i] for i in range(n)] == [code.get(c.upper(), 4) for c in seqs[nm][beg - 1:e]]
+    p = u8p()
+    assert lib.lcd_fasta_fetch(fa.encode(), b"chrZ", 1, 5, C.byref(p)) < 0
+
+
+def test_vcf_header_lines(lib):
+    names = (C.c_char_p * 2)(b"chr1", b"chr11"); lens = (C.c_int64 * 2)(248956422, 135086622)
+    t = C.c_void_p()
+    lib.lcd_vcf_header.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_char_p, C.POINTER(C.c_void_p)]
+    n = lib.lcd_vcf_header(b"0.0.11", b"longcallD call ref.fa in.bam --hifi", b"20260928", 2, names, lens, b"HG002", C.byref(t))
+    text = C.string_at(t).decode().splitlines()
+    assert n == len(text) and text[0] == "##fileformat=VCFv4.2" and "##contig=<ID=chr11,length=135086622>" in text
+    assert text[-1].split("\t") == ["#CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT", "HG002"]
+    assert sum(l.startswith("##FORMAT=") for l in text) == 8 and sum(l.startswith("##INFO=") for l in text) == 12 and sum(l.startswith("##FILTER=") for l in text) == 4
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/test_data/HG002_chr11_hifi_test.bam"), reason="the reference's bundled test BAM exists in the build container only")
+def test_real_test_bam_matches_plain_gzip_decoding(lib):
+    """SURVEY 8d config 1 input: every primary chr11 read of the bundled BAM, against a gzip + struct decoding of the same file"""
+    import gzip
+    path = "/root/reference/test_data/HG002_chr11_hifi_test.bam"
+    d = gzip.open(path).read()
+    lt, = struct.unpack_from("<i", d, 4); o = 8 + lt
+    nref, = struct.unpack_from("<i", d, o); o += 4
+    names = []
+    for _ in range(nref):
+        ln, = struct.unpack_from("<i", d, o); o += 4
+        names.append(d[o:o + ln - 1].decode()); o += ln + 4
+    recs = []
+    while o < len(d):
+        bs, = struct.unpack_from("<i", d, o); o += 4
+        refid, pos, lname, mapq, _bin, ncig, flag, lseq = struct.unpack_from("<iiBBHHHi", d, o)
+        p = o + 32 + lname
+        cig = np.frombuffer(d, "<u4", ncig, p); p += 4 * ncig
+        seq = np.frombuffer(d, np.uint8, (lseq + 1) // 2, p); p += (lseq + 1) // 2
+        qual = np.frombuffer(d, np.uint8, lseq, p)
+        rl = int(sum(int(c >> 4) for c in cig if int(c & 15) in (0, 2, 3, 7, 8)))
+        recs.append(dict(tid=refid, pos=pos, end=pos + max(rl, 1), mapq=mapq, flag=flag, cig=cig, seq=seq, qual=qual, name=d[o + 32:o + 32 + lname - 1].decode(), qlen=lseq))
+        o += bs
+    tid = names.index("chr11")
+    assert _check(lib, path, b"chr11", tid, recs, 1, 2000000, 30) >= 350
+    _check(lib, path, b"chr11", tid, recs, 1236832, 1441808, 30)
