@@ -221,6 +221,9 @@ int lcd_batch_region_vars(lcd_batch_t *b, int region, int64_t noisy_reg_beg, con
                           int64_t chunk_ref_len, lcd_noisy_var_t **vars, int *n_rows, int **row_read_ids, int **prof_start,
                           int **prof_end, int **prof_alleles);
 int lcd_batch_region_sorted_ids(lcd_batch_t *b, int region, int *read_ids_out); /* the in-place permutation of noisy_reads */
+/* per read of a region in its sorted order: chunk read id, cover flag and the read's slice read_reg_beg / read_reg_end as collect_noisy_read_info computed
+ * them (src/align.c:1392-1458; -1 / -2 for regions added after slicing): what update_digars_from_aln_str (:1745) hands to lcd_update_digars_from_msa1 */
+int lcd_batch_region_read_slices(lcd_batch_t *b, int region, int *read_ids, int *covers, int *read_beg, int *read_end);
 int lcd_batch_get_stats(lcd_batch_t *b, lcd_batch_stats_t *st);
 /* the K4 job set of the batch's anchor stage (edlib_xgaps calls of src/align.c:694,698,722): offsets into the batch's host pool (valid until the
  * batch is cleared); returns the number of jobs, fills at most cap of them.  bench.py times the reference's own edlib on it. */
@@ -311,6 +314,16 @@ int lcd_format_vcf(const lcd_call_opt_t *opt, const char *chrom, const lcd_var1_
 /* HP / PS aux tags of write_processed_read_to_bam (src/bam_utils.c:1955-2006): HP:i is written iff hap != 0, PS:i iff phase set > 0 (an existing tag with
  * another value is replaced, one that should not be there is deleted): has_hp / has_ps say whether the record ends up carrying the tag */
 void lcd_read_tags(int n_reads, const int *haps, const int64_t *phase_sets, uint8_t *has_hp, int *hp, uint8_t *has_ps, int64_t *ps);
+
+/* ---- update_digars_from_msa1 (src/align.c:1701-1743; only with --refine-aln -b / -s, host code in the reference too) ----
+ * rebuilds one read's digar list around a noisy region from its ref<->read alignment string (aln_strs[c][2k+2], opt.collect_ref_read_aln_str): the old
+ * digars left / right of the region (collect_left_digars :1463, collect_right_digars :1500) around per-column digars of the string (collect_full / left /
+ * right_msa_digars :1543-1699, by cover flag), joined with the reference's push rule (same_digar1, src/bam_utils.c:557).  digars as lcd_digar_batch returns
+ * them (alt_seq is implicit: the read's bases [qi, qi + len)); read_beg / read_end = the read's slice of the region (collect_noisy_read_info's
+ * read_reg_beg / read_reg_end).  Returns 0 and the new list (malloc()'d; *n_out may be 0), 1 when double_check_digar rejects the result (the read keeps its
+ * old digars, as in the reference), 2 for a read that covers neither end (untouched). */
+int lcd_update_digars_from_msa1(const lcd_digar_t *digars, int n_digar, int qlen, int msa_len, const uint8_t *ref_str, const uint8_t *read_str, int full_cover,
+                                int64_t noisy_reg_beg, int64_t noisy_reg_end, int read_beg, int read_end, lcd_digar_t **out, int *n_out);
 
 /* ---- the data formats in front of the path, without htslib (host code; lcd_io.cpp) ----
  * lcd_bam_load_region == the record loop of collect_ref_seq_bam_main (src/bam_utils.c:1672-1706) for one input BAM: reads of `chrom` overlapping

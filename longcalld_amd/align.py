@@ -251,6 +251,13 @@ class RegionBatch:
         self.n_reads.append(len(ids))
         return idx
 
+    def read_slices(self, region):
+        """-> dict(read_ids, covers, read_beg, read_end) of a region's reads in sorted order (lcd_batch_region_read_slices)"""
+        n = max(self.n_reads[region], 1)
+        ids, cov, rb, re = (np.zeros(n, np.int32) for _ in range(4))
+        k = check(self.lib.lcd_batch_region_read_slices(self.h, region, ids.ctypes.data_as(i32p), cov.ctypes.data_as(i32p), rb.ctypes.data_as(i32p), re.ctypes.data_as(i32p)), self.lib)
+        return dict(read_ids=ids[:k].copy(), covers=cov[:k].copy(), read_beg=rb[:k].copy(), read_end=re[:k].copy())
+
     def cost(self):
         """the work estimate queues and shards are ordered by (DP cells of the batch's chains; host only)"""
         return float(self.lib.lcd_batch_cost(self.h))

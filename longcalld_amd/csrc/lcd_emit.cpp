@@ -191,6 +191,94 @@ int lcd_format_vcf(const lcd_call_opt_t *opt, const char *chrom, const lcd_var1_
     return n_out;
 }
 
+// ---- update_digars_from_msa1 (src/align.c:1701-1743) ----
+// A read's digar list is rebuilt around one noisy region from its ref<->read alignment string: the old digars left of the region
+// (collect_left_digars :1463), per-column digars of the string (collect_full / left / right_msa_digars :1543-1699), the old digars right of it
+// (collect_right_digars :1500), merged by the reference's push rule (same_digar1, src/bam_utils.c:557: consecutive '=', I or D of equal
+// is_low_qual join; X never does).  alt_seq is not materialised: for X and I it is the read's bases [qi, qi + len) by construction.
+namespace {
+struct DG { long long pos; int type, len, qi, lq; };
+void push(std::vector<DG> &v, DG d) {
+    if (d.len <= 0) return;
+    if (!v.empty()) { const DG &l = v.back(); if ((l.type == 7 || l.type == 1 || l.type == 2) && l.type == d.type && l.lq == d.lq) { v.back().len += d.len; return; } }
+    v.push_back(d);
+}
+void msa_cols(std::vector<DG> &v, const uint8_t *ref, const uint8_t *read, int from, int to, int read_pos, long long ref_pos) {
+    for (int i = from; i <= to; ++i) {
+        const bool r = read[i] != 5, f = ref[i] != 5;
+        if (!r && !f) continue;
+        if (r && f) { push(v, {ref_pos, read[i] == ref[i] ? 7 : 8, 1, read_pos, 0}); ++read_pos; ++ref_pos; }
+        else if (r) { push(v, {ref_pos, 1, 1, read_pos, 0}); ++read_pos; }
+        else { push(v, {ref_pos, 2, 1, read_pos, 0}); ++ref_pos; }
+    }
+}
+} // namespace
+
+int lcd_update_digars_from_msa1(const lcd_digar_t *dg, int n_digar, int qlen, int msa_len, const uint8_t *ref_str, const uint8_t *read_str, int full_cover,
+                                int64_t noisy_reg_beg, int64_t noisy_reg_end, int read_beg, int read_end, lcd_digar_t **out, int *n_out) {
+    *out = nullptr; *n_out = 0;
+    const bool lc = (full_cover & 8) != 0, rc = (full_cover & 4) != 0, lg = (full_cover & 2) != 0, rg = (full_cover & 1) != 0;
+    if (!lc && !rc) return 2; // LONGCALLD_NOISY_IS_NOT_COVER: untouched
+    const bool whole = (lc && rc) || (lc && !rc && rg) || (!lc && rc && lg);
+    std::vector<DG> left, right, mid, nu;
+    auto qend = [](const lcd_digar_t &d) { return (d.type == 8 || d.type == 7 || d.type == 1) ? d.qi + d.len - 1 : d.qi; };
+    auto rend = [](const lcd_digar_t &d) { return (d.type == 8 || d.type == 7 || d.type == 2) ? d.pos + d.len - 1 : d.pos; };
+    if (whole || lc) // collect_left_digars
+        for (int i = 0; i < n_digar; ++i) {
+            const lcd_digar_t &d = dg[i];
+            if (i == 0 && (d.type == 4 || d.type == 5)) { push(left, {d.pos, d.type, d.len, d.qi, d.is_low_qual}); continue; }
+            if (d.qi >= read_beg && d.pos >= noisy_reg_beg) break;
+            if (qend(d) < read_beg && rend(d) < noisy_reg_beg) push(left, {d.pos, d.type, d.len, d.qi, d.is_low_qual});
+            else {
+                if (d.type == 1 || d.type == 7 || d.type == 8) push(left, {d.pos, d.type, read_beg - d.qi, d.qi, d.is_low_qual});
+                else if (d.type == 2) push(left, {d.pos, d.type, (int)(noisy_reg_beg - d.pos), d.qi, d.is_low_qual});
+                break;
+            }
+        }
+    if (whole || (!lc && rc)) // collect_right_digars
+        for (int i = 0; i < n_digar; ++i) {
+            const lcd_digar_t &d = dg[i];
+            if (i == n_digar - 1 && (d.type == 4 || d.type == 5)) { push(right, {d.pos, d.type, d.len, d.qi, d.is_low_qual}); continue; }
+            if (qend(d) <= read_end && rend(d) <= noisy_reg_end) continue;
+            if (d.qi > read_end && d.pos > noisy_reg_end) push(right, {d.pos, d.type, d.len, d.qi, d.is_low_qual});
+            else if (d.type == 1 || d.type == 7 || d.type == 8) push(right, {d.type == 1 ? d.pos : noisy_reg_end + 1, d.type, qend(d) - read_end, read_end + 1, d.is_low_qual});
+            else if (d.type == 2) push(right, {noisy_reg_end + 1, d.type, (int)(rend(d) - noisy_reg_end), d.qi, d.is_low_qual});
+        }
+    if (msa_len > 0) {
+        if (whole) msa_cols(mid, ref_str, read_str, 0, msa_len - 1, read_beg, noisy_reg_beg);
+        else if (lc) { // collect_left_msa_digars: columns up to the last read base that still faces the reference; the rest of the read becomes a soft clip
+            int last = msa_len - 1, skipped = 0, end_pos = read_beg - 1; bool cov = false;
+            for (int i = msa_len - 1; i >= 0; --i) { if (ref_str[i] != 5) cov = true; if (cov && read_str[i] != 5) { last = i; break; } else if (!cov && read_str[i] != 5) ++skipped; }
+            for (int i = 0; i < msa_len; ++i) end_pos += read_str[i] != 5;
+            msa_cols(mid, ref_str, read_str, 0, last, read_beg, noisy_reg_beg);
+            if (end_pos < qlen - 1 || skipped > 0) {
+                long long ref_pos = noisy_reg_beg; // the reference position after ALL columns (the loop at :1592-1619 advances it outside the window too)
+                for (int i = 0; i < msa_len; ++i) ref_pos += (ref_str[i] != 5);
+                push(mid, {ref_pos, 4, qlen - 1 - end_pos + skipped, end_pos + 1, 0});
+            }
+        } else { // collect_right_msa_digars: a leading soft clip, then the columns from the first read base that faces the reference
+            int first = 0, skipped = 0, read_pos = read_end + 1; long long rp = noisy_reg_end + 1, ref_pos = noisy_reg_beg; bool cov = false;
+            for (int i = 0; i < msa_len; ++i) { if (ref_str[i] != 5) cov = true; if (cov && read_str[i] != 5) { first = i; break; } else if (!cov && read_str[i] != 5) ++skipped; }
+            for (int i = msa_len - 1; i >= 0; --i) { if (ref_str[i] != 5) --rp; if (read_str[i] != 5) { --read_pos; ref_pos = rp; } }
+            if (read_pos > 0 || skipped > 0) push(mid, {ref_pos, 4, read_pos + skipped, 0, 0});
+            msa_cols(mid, ref_str, read_str, first, msa_len - 1, read_pos + skipped, ref_pos);
+        }
+    }
+    for (const DG &d : left) push(nu, d);
+    for (const DG &d : mid) push(nu, d);
+    for (const DG &d : right) push(nu, d);
+    // double_check_digar (src/bam_utils.h:102-120): query offsets must chain; otherwise the read keeps its old digars
+    for (size_t i = nu.size(); i-- > 1;) {
+        const DG &l = nu[i - 1];
+        const int q = (l.type == 7 || l.type == 0 || l.type == 8 || l.type == 1 || l.type == 4 || l.type == 5) ? l.qi + l.len : l.qi;
+        if (q != nu[i].qi) return 1; // rejected: *out stays NULL, keep the old list
+    }
+    lcd_digar_t *o = (lcd_digar_t *)malloc((nu.size() + 1) * sizeof(lcd_digar_t));
+    for (size_t i = 0; i < nu.size(); ++i) { o[i].pos = nu[i].pos; o[i].type = nu[i].type; o[i].len = nu[i].len; o[i].qi = nu[i].qi; o[i].is_low_qual = nu[i].lq; }
+    *out = o; *n_out = (int)nu.size();
+    return 0;
+}
+
 void lcd_read_tags(int n, const int *haps, const int64_t *ps, uint8_t *has_hp, int *hp, uint8_t *has_ps, int64_t *ps_out) {
     for (int i = 0; i < n; ++i) { has_hp[i] = haps[i] != 0; hp[i] = haps[i]; has_ps[i] = ps[i] > 0; ps_out[i] = ps[i]; }
 }

@@ -155,6 +155,7 @@ bool is_homopolymer(const uint8_t *seq, int seq_len, int flank) { // src/align.c
 
 struct RegRead { // one read of a region, in sorted order after add
     int id, len, cover, hap; int64_t ps; uint64_t off; double err;
+    int rb = -1, re = -2; // read_reg_beg / read_reg_end of collect_noisy_read_info (chunk-view entry only)
 };
 struct ChainRec {
     int region, clu;              // clu: hap-1 for K1, 0 for K2 (clusters come out of the kernel)
@@ -572,7 +573,7 @@ int lcd_batch_add_region_from_chunk(lcd_batch_t *b, const lcd_read_view_t *cr, i
                                     const uint8_t *ref_seq, int ref_seq_len) {
     // collect_noisy_read_info, src/align.c:1377-1461
     static const uint8_t nt16_int[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4}; // htslib seq_nt16_int
-    std::vector<int> ids(n), lens(n), covers(n), haps(n); std::vector<int64_t> pss(n);
+    std::vector<int> ids(n), lens(n), covers(n), haps(n), rbs(n), res(n); std::vector<int64_t> pss(n);
     std::vector<std::vector<uint8_t>> seqs(n), quals(n);
     std::vector<const uint8_t *> sp(n), qp(n);
     for (int i = 0; i < n; ++i) {
@@ -606,6 +607,7 @@ int lcd_batch_add_region_from_chunk(lcd_batch_t *b, const lcd_read_view_t *cr, i
         } else if (rdb == reg_beg) cover = beg_is_del ? LCD_LEFT_GAP : LCD_LEFT_COVER;
         else if (rde == reg_end) cover = end_is_del ? LCD_RIGHT_GAP : LCD_RIGHT_COVER;
         const int L = re - rb + 1;
+        rbs[i] = rb; res[i] = re;
         ids[i] = noisy_reads[i]; lens[i] = L; covers[i] = cover; haps[i] = rv.hap; pss[i] = rv.phase_set;
         if (L > 0) {
             seqs[i].resize(L); quals[i].resize(L);
@@ -616,8 +618,19 @@ int lcd_batch_add_region_from_chunk(lcd_batch_t *b, const lcd_read_view_t *cr, i
         }
         sp[i] = seqs[i].data(); qp[i] = quals[i].data();
     }
-    return lcd_batch_add_region(b, reg_end - reg_beg + 1, n, ids.data(), lens.data(), sp.data(), qp.data(), covers.data(), haps.data(),
-                                pss.data(), ref_seq, ref_seq_len);
+    const int ri = lcd_batch_add_region(b, reg_end - reg_beg + 1, n, ids.data(), lens.data(), sp.data(), qp.data(), covers.data(), haps.data(),
+                                        pss.data(), ref_seq, ref_seq_len);
+    if (ri >= 0) // remember each read's slice (the caller of update_digars_from_aln_str needs read_reg_beg / read_reg_end, src/align.c:1748)
+        for (RegRead &r : b->regs[ri].reads)
+            for (int i = 0; i < n; ++i) if (noisy_reads[i] == r.id) { r.rb = rbs[i]; r.re = res[i]; break; }
+    return ri;
+}
+// per read of a region in its sorted order: chunk read id, cover flag, read_reg_beg / read_reg_end (-1 / -2 unless the region came from chunk views)
+int lcd_batch_region_read_slices(lcd_batch_t *b, int region, int *read_ids, int *covers, int *read_beg, int *read_end) {
+    if (region < 0 || region >= (int)b->regs.size()) return set_err(-4, "bad region index");
+    const RegionRec &R = b->regs[region];
+    for (size_t i = 0; i < R.reads.size(); ++i) { read_ids[i] = R.reads[i].id; covers[i] = R.reads[i].cover; read_beg[i] = R.reads[i].rb; read_end[i] = R.reads[i].re; }
+    return (int)R.reads.size();
 }
 
 int lcd_batch_upload(lcd_batch_t *b) {

@@ -235,6 +235,10 @@ typedef struct {
 } lcdo_hap_problem_t;
 int lcdo_assign_hap_germline(lcdo_hap_problem_t *p, int target_var_cate);
 
+/* ---------------- update_digars_from_msa1 (oracle/digar_rewrite.c) ---------------- */
+int lcdo_update_digars_from_msa1(const lcdo_digar_t *digars, int n_digar, int qlen, int msa_len, const uint8_t *ref_str, const uint8_t *read_str, int full_cover,
+                                 int64_t noisy_reg_beg, int64_t noisy_reg_end, int read_beg, int read_end, lcdo_digar_t **out, int *n_out);
+
 /* ---------------- stitching, genotype records, VCF body text (oracle/emit.c) ---------------- */
 typedef struct { double log_p, log_1p, log_2; int max_gq, max_qual, min_sv_len, min_dp, min_alt_dp, out_amb_base; } lcdo_call_opt_t;
 typedef struct {

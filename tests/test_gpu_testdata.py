@@ -57,3 +57,38 @@ def test_real_regions_unphased(lcd, oracle):
         same_result(exp, g)
         n_res += g["n_cons"] > 0
     assert n_res >= len(ch.regions) // 2
+
+
+def test_digar_rewrite_on_real_regions(lcd, oracle):
+    """SURVEY a13 end to end on the bundled chunk (--refine-aln -b path): regions run with collect_ref_read_aln_str, then every read's digar list is rebuilt
+    from its ref<->read string (lcd_update_digars_from_msa1 with the slices the library reports) == the oracle's update_digars_from_msa1 on the same string"""
+    import ctypes as C
+    from longcalld_amd import _lib, jobs
+    from test_digar_rewrite import _call
+    ch = tc.Chunk()
+    st = lcd.assign_hap_germline(ch.hap_problem(), jobs.GERMLINE_CLEAN)
+    views, keep = lcd.make_read_views(ch.digars, ch.bseq, ch.qual, ch.qlen, st["haps"], st["phase_sets"])
+    o = lcd.default_opt(); o.collect_ref_read_aln_str = 1
+    b = lcd.RegionBatch(o)
+    for k, (beg, end) in enumerate(ch.regions):
+        b.add_region_from_chunk(views, beg, end, ch.reg_reads(k), ch.ref_slice(k))
+    b.upload(); b.run(); b.download()
+    prod, orc = C.CDLL(_lib.LIB_PATH), oracle.lib()
+    n_new = n_rej = 0
+    for k, (beg, end) in enumerate(ch.regions):
+        res, sl = b.result(k), b.read_slices(k)
+        by_id = {int(r): i for i, r in enumerate(sl["read_ids"])}
+        for c in range(res["n_cons"]):
+            for j, rid in enumerate(res["clu_read_ids"][c]):
+                s = res["aln_strs"][c][2 * j + 2]
+                if s is None:
+                    continue
+                i = by_id[int(rid)]
+                digs = [(int(d[0]), int(d[1]), int(d[2]), int(d[3]), 0) for d in ch.digars[int(rid)]]
+                args = (digs, int(ch.qlen[int(rid)]), s["target"], s["query"], int(sl["covers"][i]), int(beg), int(end), int(sl["read_beg"][i]), int(sl["read_end"][i]))
+                a, e = _call(prod, "lcd_update_digars_from_msa1", *args), _call(orc, "lcdo_update_digars_from_msa1", *args)
+                assert a == e, (k, c, j)
+                n_new += a[0] == 0; n_rej += a[0] == 1
+    b.close()
+    del keep
+    assert n_new > 200
