@@ -222,6 +222,9 @@ struct lcd_batch_s {
     // candidate variants (opt.collect_noisy_vars): per resolved region, offsets into d_var_out / h_var
     std::vector<VarRegionRec> vregs; std::vector<int> vreg_of; std::vector<uint8_t> h_var; uint64_t var_bytes = 0;
     std::vector<std::unique_ptr<DevBuf>> retry_out; // output blocks of chains re-run with a larger graph capacity (live until the next run)
+    // the chains' work arenas live in d_poa_arena and, when a later submission needs more, in additional chunks: growing by a chunk costs the difference,
+    // re-allocating tens of GB costs seconds (and the pools' slot sizes make the total jump by a third from one set of chunks to the next)
+    std::vector<std::unique_ptr<DevBuf>> arena_extra;
     uint64_t final_bytes = 0;
     lcd_batch_stats_t st;
 };
@@ -852,7 +855,7 @@ int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
     if (rc != -11 || nb <= 1) return rc;
     // the work arenas (DP cells, wavefronts, edlib columns) are transient: dropped around each half so that the halves do not add up;
     // the outputs of a half stay in its leader's buffers until they are downloaded
-    auto drop = [](lcd_batch_t *b) { b->d_poa_arena.release(); b->d_var_work.release(); };
+    auto drop = [](lcd_batch_t *b) { b->d_poa_arena.release(); b->arena_extra.clear(); b->d_var_work.release(); };
     const int h = nb / 2;
     drop(bs[0]);
     const int r1 = lcd_batch_run_many(bs, h);
@@ -1014,6 +1017,8 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             // n_cu x per_cu SLOTS claimed at workgroup start (poa_kernel.hip); the others keep private arenas.  Memory then scales with resident
             // workgroups, not with the number of chains in flight.
             uint64_t flag_ints = 0; size_t n_pooled = 0, n_pools = 0; uint64_t private_bytes = 0, pool_bytes = 0;
+            struct Item { uint64_t start, bytes, phys; };
+            std::vector<Item> items; std::vector<uint32_t> item_of(which.size(), 0);
             for (size_t i = 0; i < which.size();) {
                 const long long key = chain_group_key(PC(which[i]));
                 size_t j = i;
@@ -1047,10 +1052,11 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                     const size_t b2 = nxt[a];
                     if (seg_pooled(a, b2)) {
                         const uint64_t slot = lcd_align_up(need[ord[bp[a]]], 256);
-                        for (size_t q = bp[a]; q < bp[b2]; ++q) { PoaChain &pc = PC(which[ord[q]]); pc.ws_off = tot; pc.slot_flags = 1 + flag_ints; pc.slot_bytes = slot; pc.n_slots = (int)R; pc.per_cu = per_cu; pc.cu_rank = cu_rank_addr; }
+                        for (size_t q = bp[a]; q < bp[b2]; ++q) { PoaChain &pc = PC(which[ord[q]]); pc.ws_off = tot; pc.slot_flags = 1 + flag_ints; pc.slot_bytes = slot; pc.n_slots = (int)R; pc.per_cu = per_cu; pc.cu_rank = cu_rank_addr; item_of[ord[q]] = (uint32_t)items.size(); }
+                        items.push_back({tot, R * slot, 0});
                         tot += R * slot; flag_ints += R; n_pooled += bp[b2] - bp[a]; ++n_pools; pool_bytes += R * slot;
                     } else
-                        for (size_t q = bp[a]; q < bp[b2]; ++q) { PoaChain &pc = PC(which[ord[q]]); pc.ws_off = tot; pc.slot_flags = 0; pc.slot_bytes = 0; pc.n_slots = 0; pc.per_cu = 0; pc.cu_rank = 0; tot += need[ord[q]]; private_bytes += need[ord[q]]; }
+                        for (size_t q = bp[a]; q < bp[b2]; ++q) { PoaChain &pc = PC(which[ord[q]]); pc.ws_off = tot; pc.slot_flags = 0; pc.slot_bytes = 0; pc.n_slots = 0; pc.per_cu = 0; pc.cu_rank = 0; item_of[ord[q]] = (uint32_t)items.size(); items.push_back({tot, need[ord[q]], 0}); tot += need[ord[q]]; private_bytes += need[ord[q]]; }
                 }
                 i = j;
             }
@@ -1064,12 +1070,26 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                 for (size_t i = 0; i < which.size(); ++i) { const PoaChain &pc = PC(which[i]); cellb += (pc.spill_x > 2 ? 5.0 + pc.spill_x : 4.0) * pc.cell_cap; PoaLayout Lay = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, 0, pc.n_reads); nodeb += (double)Lay.total; if (4.0 * pc.cell_cap > worstc) worstc = 4.0 * pc.cell_cap; nbig += 4.0 * pc.cell_cap > 64e6; }
                 fprintf(stderr, "[mem] round %d: %zu chains, arena %.2f GB = DP regions %.2f GB (largest %.1f MB, %zu above 64 MB) + graph/plan arrays %.2f GB\n", round, which.size(), tot / 1e9, cellb / 1e9, worstc / 1e6, nbig, nodeb / 1e9);
             }
-            // (the one multi-GB buffer: re-allocating it costs more than a submission, so it grows by half -- distinct chunks differ by a few per cent)
-            if (L->d_poa_arena.ensure(tot, 1)) return -11;
+            { // placement: first fit over [d_poa_arena, extra chunks...] in item order; one more chunk (what is left of this submission) when they are full
+                if (L->d_poa_arena.cap == 0 && L->d_poa_arena.ensure(tot, 3)) return -11;
+                std::vector<DevBuf *> ch(1, &L->d_poa_arena);
+                for (auto &c : L->arena_extra) ch.push_back(c.get());
+                size_t k = 0; uint64_t off = 0, left = tot;
+                for (Item &it : items) {
+                    while (k < ch.size() && off + it.bytes > ch[k]->cap) { ++k; off = 0; }
+                    if (k == ch.size()) {
+                        L->arena_extra.emplace_back(new DevBuf());
+                        if (L->arena_extra.back()->ensure(left, 3)) { L->arena_extra.pop_back(); return -11; }
+                        ch.push_back(L->arena_extra.back().get());
+                        if (getenv("LCD_MEM_DEBUG")) fprintf(stderr, "[mem] arena chunk %zu: %.2f GB\n", ch.size() - 1, ch.back()->cap / 1e9);
+                    }
+                    it.phys = ch[k]->addr() + off; off += it.bytes; left -= it.bytes;
+                }
+            }
             for (size_t i = 0; i < which.size(); ++i) {
                 const int k = chain_batch[which[i]];
                 PoaChain &pc = PC(which[i]);
-                pc.ws_off += L->d_poa_arena.addr();
+                pc.ws_off = items[item_of[i]].phys + (pc.ws_off - items[item_of[i]].start);
                 if (pc.slot_flags) pc.slot_flags = L->d_slot_flags.addr() + (pc.slot_flags - 1) * 4;
                 sub[i] = pc; sub[i].read0 += (int)pread_base[k]; // the device read table is the concatenation of the batches' tables
             }
