@@ -273,6 +273,9 @@ int lcd_post_process_noisy_regs(const lcd_noisy_iv_t *regs, int n_regs, int n_va
  * seq: raw codes 0..3 (4+ = N) or letters; T, W: LONGCALLD_SDUST_T 5 / LONGCALLD_SDUST_W 20 (src/call_var_main.h:82-83), W <= 64.
  * *intervals_out: malloc()'d (start, finish) pairs exactly as sdust() returns them (0-based, half-open); returns their number or < 0. */
 int lcd_sdust(const uint8_t *seq, int64_t len, int T, int W, int64_t **intervals_out);
+/* the same for the references of many chunks in ONE launch (the recommended form: a single sequence is latency-bound -- 21 ms per 500 kb chunk against 9 ms
+ * for the reference's sdust() on one core -- while a pipeline step's worth of chunks shares that latency).  intervals_out[q] malloc()'d, n_out[q] pairs. */
+int lcd_sdust_batch(int n_seqs, const uint8_t *const *seqs, const int64_t *lens, int T, int W, int64_t **intervals_out, int *n_out);
 
 /* ---- cross-chunk stitching, genotype emission, tag values (host code in the reference and here: small and serial) ----
  * lcd_flip_variant_hap == flip_variant_hap + update_chunk_{var,read}_hap_phase_set1 (src/collect_var.c:1565-1680): the reads that overlap both chunks

@@ -479,6 +479,23 @@ def sdust(seq, T=5, W=20):
     return res
 
 
+def sdust_batch(seqs, T=5, W=20):
+    """lcd_sdust_batch: the low-complexity intervals of many sequences in one launch -> list of (n, 2) arrays"""
+    lib = load_library()
+    arrs = [np.ascontiguousarray(x, np.uint8) for x in seqs]
+    n = len(arrs)
+    ptrs = (u8p * n)(*[_p8(a) for a in arrs])
+    lens = (C.c_int64 * n)(*[len(a) for a in arrs])
+    outs = (C.POINTER(C.c_int64) * n)(); cnt = (C.c_int * n)()
+    check(lib.lcd_sdust_batch(n, ptrs, lens, int(T), int(W), outs, cnt), lib)
+    res = []
+    for q in range(n):
+        res.append(np.array([outs[q][i] for i in range(2 * cnt[q])], np.int64).reshape(-1, 2))
+        if outs[q]:
+            _libc.free(C.cast(outs[q], C.c_void_p))
+    return res
+
+
 def _hap_state(prob):
     R, V, TA = prob["n_reads"], prob["n_vars"], int(prob["alle_off"][-1])
     return dict(haps=np.zeros(R, np.int32), phase_sets=np.full(R, -1, np.int64), n_clean_agree_snps=np.zeros(R, np.int32),

@@ -1804,58 +1804,75 @@ int lcd_wfa_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t 
 }
 
 // ---- sdust on the device (sdust_kernel.hip): segments on lanes, the host chains their reports with sdust's merge rule ----
-int lcd_sdust(const uint8_t *seq, int64_t len64, int T, int W, int64_t **intervals_out) {
-    *intervals_out = nullptr;
+// lcd_sdust_batch: the references of MANY chunks in one launch.  A lane's automaton is serial and latency-bound (21 ms for one 500 kb chunk against 9 ms
+// for the reference's sdust() on one core), but the chip holds ~60 000 lanes: the chunk workers' references of one pipeline step go in together.
+int lcd_sdust_batch(int n_seqs, const uint8_t *const *seqs, const int64_t *lens, int T, int W, int64_t **intervals_out, int *n_out) {
+    for (int q = 0; q < n_seqs; ++q) { intervals_out[q] = nullptr; n_out[q] = 0; }
     if (ensure_init()) return -1;
-    if (len64 <= 0) return 0;
-    if (W > 64 || W < 4 || len64 > 2000000000ll) return set_err(-4, "lcd_sdust: W must be in [4, 64] and the sequence below 2 Gb");
+    if (n_seqs <= 0) return 0;
+    if (W > 64 || W < 4) return set_err(-4, "lcd_sdust: W must be in [4, 64]");
     // segment length: the automaton is serial inside a segment (plus ~3W bases of lead-in and run-out), so short segments = more lanes, less latency
-    const int len = (int)len64, seg = W <= 32 ? 128 : 256, n_seg = (len + seg - 1) / seg, cap = seg + 8;
-    // where each segment's automaton starts: 2W + 4 triplet words before (segment start - W); a word ends at i when i-2..i are all A/C/G/T
+    const int seg = W <= 32 ? 128 : 256, cap = seg + 8;
     auto code = [](uint8_t c) { return c < 4 ? (int)c : (c == 'A' || c == 'a') ? 0 : (c == 'C' || c == 'c') ? 1 : (c == 'G' || c == 'g') ? 2 : (c == 'T' || c == 't') ? 3 : 4; };
-    std::vector<int> from(n_seg, 0);
-    {
-        std::vector<int> ends; ends.reserve(2 * W + 8); // positions of the last word ends, as a sliding list
+    std::vector<SdSeg> segs; std::vector<size_t> first(n_seqs + 1, 0);
+    uint64_t pool_bytes = 0;
+    for (int q = 0; q < n_seqs; ++q) {
+        first[q] = segs.size();
+        if (lens[q] <= 0) continue;
+        if (lens[q] > 2000000000ll) return set_err(-4, "lcd_sdust: sequences below 2 Gb");
+        const int len = (int)lens[q], n_seg = (len + seg - 1) / seg;
+        const uint8_t *seq = seqs[q];
+        // where each segment's automaton starts: 2W + 4 triplet words before (segment start - W); a word ends at i when i-2..i are all A/C/G/T
         std::vector<int> ring(2 * W + 4, -1); size_t rn = 0; // ring of the last 2W+4 word-end positions
-        int l = 0, next = 0; // next segment whose anchor (a - W) we are waiting to pass
+        int l = 0, next = 0;
+        std::vector<int> from(n_seg, 0);
         for (int i = 0; i < len && next < n_seg; ++i) {
-            while (next < n_seg && std::max(0, next * seg - W) == i) { // state needed exact from here on: start 2W+4 words back
-                from[next] = rn >= ring.size() ? std::max(0, ring[rn % ring.size()] - 2) : 0;
-                ++next;
-            }
+            while (next < n_seg && std::max(0, next * seg - W) == i) { from[next] = rn >= ring.size() ? std::max(0, ring[rn % ring.size()] - 2) : 0; ++next; }
             if (code(seq[i]) < 4) { if (++l >= 3) { ring[rn % ring.size()] = i; ++rn; } } else l = 0;
         }
+        for (int k = 0; k < n_seg; ++k) { SdSeg sg; sg.seq_off = pool_bytes; sg.len = len; sg.a = k * seg; sg.from = from[k]; sg.pad = 0; segs.push_back(sg); }
+        pool_bytes += lcd_align_up((uint64_t)len + 16, 16);
     }
-    if (getenv("LCD_MEM_DEBUG")) { long long tot = 0, mx = 0; for (int k = 0; k < n_seg; ++k) { const long long d = (long long)k * seg - from[k]; tot += d; mx = std::max(mx, d); } fprintf(stderr, "[sdust] %d segments of %d, lead-in mean %.1f max %lld\n", n_seg, seg, (double)tot / n_seg, mx); }
+    first[n_seqs] = segs.size();
+    const size_t n_seg = segs.size();
+    if (n_seg == 0) return 0;
     // (grow-only buffers and one stream kept across calls: five hipMalloc / hipFree pairs cost more than the kernel)
     static std::mutex mu; std::lock_guard<std::mutex> lk(mu);
-    static hipStream_t st = nullptr;
-    if (!st) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    static hipStream_t st[LCD_MAX_DEV] = {};
+    static DevBuf d_seq[LCD_MAX_DEV], d_segs[LCD_MAX_DEV], d_n[LCD_MAX_DEV], d_out[LCD_MAX_DEV], d_p[LCD_MAX_DEV];
+    const int dv = cur_device();
+    if (!st[dv]) HIPCHK(hipStreamCreateWithFlags(&st[dv], hipStreamNonBlocking));
     const int pcap = W * W + 8;
-    static DevBuf d_seq, d_from, d_n, d_out, d_p;
-    if (d_seq.ensure((size_t)len + 64) || d_from.ensure((size_t)n_seg * 4) || d_n.ensure((size_t)n_seg * 4) || d_out.ensure((size_t)n_seg * cap * 8) ||
-        d_p.ensure((size_t)n_seg * pcap * 16)) return -11;
-    HIPCHK(hipMemcpyAsync(d_seq.p, seq, len, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_from.p, from.data(), (size_t)n_seg * 4, hipMemcpyHostToDevice, st));
-    lcd_launch_sdust((const unsigned char *)d_seq.p, len, T, W, seg, n_seg, cap, (const int *)d_from.p, (int *)d_n.p, (int2 *)d_out.p, (int4 *)d_p.p, pcap, st);
+    if (d_seq[dv].ensure(pool_bytes + 64) || d_segs[dv].ensure(n_seg * sizeof(SdSeg)) || d_n[dv].ensure(n_seg * 4) || d_out[dv].ensure(n_seg * (size_t)cap * 8) ||
+        d_p[dv].ensure(n_seg * (size_t)pcap * 16)) return -11;
+    { uint64_t o = 0; for (int q = 0; q < n_seqs; ++q) if (lens[q] > 0) { HIPCHK(hipMemcpyAsync((uint8_t *)d_seq[dv].p + o, seqs[q], (size_t)lens[q], hipMemcpyHostToDevice, st[dv])); o += lcd_align_up((uint64_t)lens[q] + 16, 16); } }
+    HIPCHK(hipMemcpyAsync(d_segs[dv].p, segs.data(), n_seg * sizeof(SdSeg), hipMemcpyHostToDevice, st[dv]));
+    lcd_launch_sdust((const unsigned char *)d_seq[dv].p, (const SdSeg *)d_segs[dv].p, T, W, seg, (int)n_seg, cap, (int *)d_n[dv].p, (int2 *)d_out[dv].p, (int4 *)d_p[dv].p, pcap, st[dv]);
     HIPCHK(hipGetLastError());
-    std::vector<int> n(n_seg); std::vector<int> raw((size_t)n_seg * cap * 2);
-    HIPCHK(hipMemcpyAsync(n.data(), d_n.p, (size_t)n_seg * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(raw.data(), d_out.p, (size_t)n_seg * cap * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    std::vector<int64_t> res; // save_masked_regions' merge (src/sdust.c:97-103) over the segments' reports in order
-    for (int s = 0; s < n_seg; ++s) {
-        if (n[s] < 0 || n[s] > cap) return set_err(-24, "lcd_sdust: per-segment capacity exceeded (segment " + std::to_string(s) + " of " + std::to_string(n_seg) + ": " + std::to_string(n[s]) + ", len " + std::to_string(len) + ")");
-        for (int k = 0; k < n[s]; ++k) {
-            const int64_t ps = raw[((size_t)s * cap + k) * 2], pf = raw[((size_t)s * cap + k) * 2 + 1];
-            if (!res.empty() && ps <= res.back()) { if (pf > res.back()) res.back() = pf; }
-            else { res.push_back(ps); res.push_back(pf); }
+    std::vector<int> n(n_seg); std::vector<int> raw(n_seg * (size_t)cap * 2);
+    HIPCHK(hipMemcpyAsync(n.data(), d_n[dv].p, n_seg * 4, hipMemcpyDeviceToHost, st[dv]));
+    HIPCHK(hipMemcpyAsync(raw.data(), d_out[dv].p, n_seg * (size_t)cap * 8, hipMemcpyDeviceToHost, st[dv]));
+    HIPCHK(hipStreamSynchronize(st[dv]));
+    for (int q = 0; q < n_seqs; ++q) {
+        std::vector<int64_t> res; // save_masked_regions' merge (src/sdust.c:97-103) over the segments' reports in order
+        for (size_t s = first[q]; s < first[q + 1]; ++s) {
+            if (n[s] < 0 || n[s] > cap) return set_err(-24, "lcd_sdust: per-segment capacity exceeded (sequence " + std::to_string(q) + ", segment " + std::to_string(s - first[q]) + ": " + std::to_string(n[s]) + ")");
+            for (int k = 0; k < n[s]; ++k) {
+                const int64_t ps = raw[(s * cap + k) * 2], pf = raw[(s * cap + k) * 2 + 1];
+                if (!res.empty() && ps <= res.back()) { if (pf > res.back()) res.back() = pf; }
+                else { res.push_back(ps); res.push_back(pf); }
+            }
         }
+        int64_t *out = (int64_t *)malloc((res.size() + 2) * sizeof(int64_t));
+        memcpy(out, res.data(), res.size() * sizeof(int64_t));
+        intervals_out[q] = out; n_out[q] = (int)(res.size() / 2);
     }
-    int64_t *out = (int64_t *)malloc((res.size() + 2) * sizeof(int64_t));
-    memcpy(out, res.data(), res.size() * sizeof(int64_t));
-    *intervals_out = out;
-    return (int)(res.size() / 2);
+    return 0;
+}
+int lcd_sdust(const uint8_t *seq, int64_t len, int T, int W, int64_t **intervals_out) {
+    int n = 0;
+    const int rc = lcd_sdust_batch(1, &seq, &len, T, W, intervals_out, &n);
+    return rc ? rc : n;
 }
 
 // ---- SURVEY 8(f) f2, chunk level: pre_process_noisy_regs (src/collect_var.c:557-638) ----

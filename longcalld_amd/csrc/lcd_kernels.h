@@ -18,5 +18,5 @@ void lcd_launch_vars_profile(const VarRegJob *jobs, VarRegOut *outs, const StrJo
 void lcd_launch_digar(const DigarJob *jobs, DigarOut *outs, DigarOpt opt, int n_jobs, hipStream_t stream);
 void lcd_launch_region_support(const IvRec *regs, int n_regs, const long long *read_beg, const long long *read_end, const unsigned long long *iv_off,
                                const IvRec *ivs, int n_reads, int *total, int *noisy, hipStream_t stream);
-void lcd_launch_sdust(const unsigned char *seq, int len, int T, int W, int seg, int n_seg, int cap, const int *seg_from, int *n_out, int2 *out, int4 *pbuf, int pcap, hipStream_t stream);
+void lcd_launch_sdust(const unsigned char *pool, const SdSeg *segs, int T, int W, int seg, int n_seg, int cap, int *n_out, int2 *out, int4 *pbuf, int pcap, hipStream_t stream);
 void lcd_launch_hap(const HapProb *probs, int n, hipStream_t stream);

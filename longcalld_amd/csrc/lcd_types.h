@@ -265,6 +265,9 @@ struct DigarJob {
 struct DigarOut { int status, n_digar, n_iv, n_cand, rlen; };
 struct DigarOpt { int min_bq, max_xgaps, win, end_clip_reg, end_clip_flank, pad; long long whole_ref_len; };
 
+// ---------------- sdust segments (sdust_kernel.hip): one lane per segment, segments of many sequences per launch ----------------
+struct SdSeg { uint64_t seq_off; int len, a, from, pad; }; // sequence (offset in the pool, length), segment start, where the lane's automaton starts
+
 // ---------------- K5: haplotype assignment (src/assign_hap.c:473-547) ----------------
 // bam_chunk_t / cand_var_t / read_var_profile_t flattened; every pointer is an absolute device address.
 struct HapProb {

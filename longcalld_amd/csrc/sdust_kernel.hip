@@ -7,6 +7,7 @@
 // reports only the intervals that START in its segment, unmerged; the host chains the reports in order with sdust's own merge rule (adjacent or
 // overlapping intervals are joined).  Checked byte for byte against the reference's sdust.c itself (oracle/_ref), tests/test_gpu_digar.py.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include "lcd_types.h"
 #include "lcd_kernels.h"
 
@@ -19,13 +20,16 @@ __device__ __forceinline__ int sd_code(unsigned char c) { // seq_nt4_table, src/
 }
 }
 
-__global__ void __launch_bounds__(SD_LANES) lcd_sdust_kernel(const unsigned char *seq, int len, int T, int W, int seg, int n_seg, int cap, const int *seg_from, int *n_out, int2 *out, int4 *pbuf, int pcap, int SD_PL) {
+__global__ void __launch_bounds__(SD_LANES) lcd_sdust_kernel(const unsigned char *pool, const SdSeg *segs, int T, int W, int seg, int n_seg, int cap, int *n_out, int2 *out, int4 *pbuf, int pcap, int SD_PL) {
     const int sid = blockIdx.x * SD_LANES + threadIdx.x;
     if (sid >= n_seg) return;
-    const int a = sid * seg, b = min(len, a + seg);
-    // seg_from[sid]: where the automaton has to start so that its state is exact W bases before the segment (the host counts 2W + 4 triplet words
+    // one launch serves the segments of MANY sequences (a lane is latency-bound on its own automaton: throughput comes from lanes, i.e. from chunks in flight)
+    const SdSeg sg = segs[sid];
+    const unsigned char *seq = pool + sg.seq_off;
+    const int len = sg.len, a = sg.a, b = min(len, a + seg);
+    // sg.from: where the automaton has to start so that its state is exact W bases before the segment (the host counts 2W + 4 triplet words
     // back from there: the window is made of words, and words on both sides of a run of N share it); i == len is the end-of-sequence flush
-    const int from = seg_from[sid], to = min(len, b + 2 * W + 8);
+    const int from = sg.from, to = min(len, b + 2 * W + 8);
     // per-lane tables in LDS, lane-interleaved (entry k of lane t at [k * SD_LANES + t]): window ring, the two triplet counters, find_perfect's copy
     extern __shared__ int sd_lds[];
     int *const wq = sd_lds + threadIdx.x, *const cv = wq + 64 * SD_LANES, *const cw = cv + 64 * SD_LANES, *const c = cw + 64 * SD_LANES;
@@ -102,10 +106,11 @@ __global__ void __launch_bounds__(SD_LANES) lcd_sdust_kernel(const unsigned char
     n_out[sid] = bad ? -1 : nout;
 }
 
-void lcd_launch_sdust(const unsigned char *seq, int len, int T, int W, int seg, int n_seg, int cap, const int *seg_from, int *n_out, int2 *out, int4 *pbuf, int pcap, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)lcd_sdust_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+void lcd_launch_sdust(const unsigned char *pool, const SdSeg *segs, int T, int W, int seg, int n_seg, int cap, int *n_out, int2 *out, int4 *pbuf, int pcap, hipStream_t stream) {
+    static std::once_flag attr_once[16]; // (function attributes are per device)
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    std::call_once(attr_once[dev], [] { (void)hipFuncSetAttribute((const void *)lcd_sdust_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
     const int pl = pcap < 512 ? pcap : 512;
     const size_t lds = (size_t)SD_LANES * (4 * 64 * sizeof(int) + (size_t)pl * sizeof(int4));
-    if (n_seg > 0) hipLaunchKernelGGL(lcd_sdust_kernel, dim3((n_seg + SD_LANES - 1) / SD_LANES), dim3(SD_LANES), lds, stream, seq, len, T, W, seg, n_seg, cap, seg_from, n_out, out, pbuf, pcap, pl);
+    if (n_seg > 0) hipLaunchKernelGGL(lcd_sdust_kernel, dim3((n_seg + SD_LANES - 1) / SD_LANES), dim3(SD_LANES), lds, stream, pool, segs, T, W, seg, n_seg, cap, n_out, out, pbuf, pcap, pl);
 }

@@ -171,6 +171,21 @@ def test_sdust_matches_reference(lcd, oracle):
     assert n_iv > 1000
 
 
+def test_sdust_batch_many_chunks_one_launch(lcd, oracle):
+    """lcd_sdust_batch: the references of many chunks in one launch (sequences of different lengths, an empty one, an all-N one) -- every
+    sequence's intervals equal its own single-sequence result and the reference's sdust()"""
+    if oracle.ref_cgranges() is None:
+        pytest.skip("oracle/_ref/libcgranges_ref.so not built")
+    rng = np.random.default_rng(23)
+    seqs = [_lowcomp_seq(rng, n, nf) for n, nf in ((50000, 0.0), (500, 0.0), (120000, 0.01), (700, 0.02), (33333, 0.0))] + [np.zeros(0, np.uint8), np.full(400, 4, np.uint8)]
+    got = lcd.sdust_batch(seqs, 5, 20)
+    assert len(got) == len(seqs)
+    for s, g in zip(seqs, got):
+        exp = oracle.ref_sdust(s, 5, 20) if len(s) else np.zeros((0, 2), np.int64)
+        assert exp.shape == g.shape and (exp == g).all()
+    assert sum(len(g) for g in got) > 100
+
+
 def test_f2_edge_inputs(lcd, oracle):
     """empty and degenerate inputs of the f2 entry points: no reads, a read that is one clip + one match, all-N / very short sequences, no
     windows at all, regions nobody supports"""
