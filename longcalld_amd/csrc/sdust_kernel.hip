@@ -12,7 +12,9 @@
 #include "lcd_kernels.h"
 
 namespace {
-constexpr int SD_LANES = 16; // lanes (segments) per workgroup: the kernel is latency-bound, and 16 lanes leave each of them 8 KB of LDS for its interval list
+constexpr int SD_LANES = 16; // lanes (segments) per workgroup.  The kernel is latency-bound per lane, so what counts is lanes resident per CU: the window ring and the
+                             // triplet counters are BYTES (a count never exceeds W <= 64), 256 B per lane, and the first 32 perfect intervals sit in LDS (512 B per
+                             // lane; segments inside a tandem repeat spill the rest of their list to the HBM slab): 12 KB per workgroup = 13 workgroups per CU
 struct SdPerf { int start, finish, r, l; };
 __device__ __forceinline__ int sd_code(unsigned char c) { // seq_nt4_table, src/sdust.c:22-39: raw codes 0..3 and the letters ACGT / acgt
     if (c < 4) return c;
@@ -32,11 +34,11 @@ __global__ void __launch_bounds__(SD_LANES) lcd_sdust_kernel(const unsigned char
     const int from = sg.from, to = min(len, b + 2 * W + 8);
     // per-lane tables in LDS, lane-interleaved (entry k of lane t at [k * SD_LANES + t]): window ring, the two triplet counters, find_perfect's copy
     extern __shared__ int sd_lds[];
-    int *const wq = sd_lds + threadIdx.x, *const cv = wq + 64 * SD_LANES, *const cw = cv + 64 * SD_LANES, *const c = cw + 64 * SD_LANES;
+    unsigned char *const wq = (unsigned char *)sd_lds + threadIdx.x, *const cv = wq + 64 * SD_LANES, *const cw = cv + 64 * SD_LANES, *const c = cw + 64 * SD_LANES;
 #define SDX(k) ((k) * SD_LANES)
     // the perfect intervals of the current window (descending start): at most one per (start inside the window, step it was found at) = W x W
     // entries; the first SD_PL of them (all of them for W <= 22) in LDS, lane-interleaved, the rest in an HBM slab
-    int4 *const Pl = (int4 *)(sd_lds + 4 * 64 * SD_LANES) + threadIdx.x; int4 *const Pg = pbuf + (size_t)sid * pcap;
+    int4 *const Pl = (int4 *)((unsigned char *)sd_lds + 4 * 64 * SD_LANES) + threadIdx.x; int4 *const Pg = pbuf + (size_t)sid * pcap;
     // (macros, not lambdas: by-reference captures would put the whole automaton state into scratch memory -- measured 30x slower)
 #define Pget(j) ((j) < SD_PL ? Pl[(j) * SD_LANES] : Pg[(j)])   /* (x, y, z, w) = (start, finish, r, l) */
 #define Pset(j, v) do { const int4 v_ = (v); if ((j) < SD_PL) Pl[(j) * SD_LANES] = v_; else Pg[(j)] = v_; } while (0)
@@ -66,7 +68,7 @@ __global__ void __launch_bounds__(SD_LANES) lcd_sdust_kernel(const unsigned char
                 SD_SAVE(start);
                 { // shift_window :68-89
                     if (qcount >= W - 3 + 1) { const int s = wq[SDX(qfront)]; qfront = (qfront + 1) & 63; --qcount; rw -= --cw[SDX(s)]; if (L > qcount) { --L; rv -= --cv[SDX(s)]; } }
-                    wq[SDX((qfront + qcount) & 63)] = (int)t; ++qcount;
+                    wq[SDX((qfront + qcount) & 63)] = (unsigned char)t; ++qcount;
                     ++L; rw += cw[SDX(t)]++; rv += cv[SDX(t)]++;
                     if (cv[SDX(t)] * 10 > T << 1) { int s; do { s = AT(qcount - L); rv -= --cv[SDX(s)]; --L; } while (s != (int)t); }
                 }
@@ -110,7 +112,7 @@ void lcd_launch_sdust(const unsigned char *pool, const SdSeg *segs, int T, int W
     static std::once_flag attr_once[16]; // (function attributes are per device)
     int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
     std::call_once(attr_once[dev], [] { (void)hipFuncSetAttribute((const void *)lcd_sdust_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
-    const int pl = pcap < 512 ? pcap : 512;
-    const size_t lds = (size_t)SD_LANES * (4 * 64 * sizeof(int) + (size_t)pl * sizeof(int4));
+    const int pl = pcap < 32 ? pcap : 32;
+    const size_t lds = (size_t)SD_LANES * (4 * 64 + (size_t)pl * sizeof(int4));
     if (n_seg > 0) hipLaunchKernelGGL(lcd_sdust_kernel, dim3((n_seg + SD_LANES - 1) / SD_LANES), dim3(SD_LANES), lds, stream, pool, segs, T, W, seg, n_seg, cap, n_out, out, pbuf, pcap, pl);
 }
