@@ -250,6 +250,26 @@ int lcd_digar_batch(const lcd_digar_opt_t *opt, int n_reads, const int64_t *pos0
                     const int *n_cigar, const uint8_t *qual_pool, const uint64_t *qual_off, const int *qlen, const uint8_t *pal_flags,
                     int64_t reg_beg, int64_t reg_end, int64_t whole_ref_len, uint64_t **digar_off, lcd_digar_t **digars, uint64_t **iv_off,
                     lcd_noisy_iv_t **ivs, uint8_t **iv_in_chunk, int *status, int64_t *beg, int64_t *end, int *n_cand_vars);
+/* the reference's three other digar sources (src/collect_var.c:1072-1079 picks one per read: EQX CIGAR, else cs tag, else MD tag, else the reference
+ * bases); same outputs as lcd_digar_batch.
+ *   lcd_digar_batch_tags, mode LCD_DIGAR_CS == collect_digar_from_cs_tag (src/bam_utils.c:844-1008): tags[r] = the read's cs:Z string (short or long
+ *     form); clips come from the first / last CIGAR operation, with that function's own clip rule (:884-888, :969-972);
+ *   lcd_digar_batch_tags, mode LCD_DIGAR_MD == collect_digar_from_MD_tag (:1010-1177): tags[r] = the MD:Z string, the CIGAR has 'M';
+ *   lcd_digar_batch_ref == collect_digar_from_ref_seq (:1179-1328): seq_pool + seq_off[r] = bam_get_seq (4-bit bases), ref_seq[0] is reference position
+ *     ref_beg (1-based), ref_end inclusive (chunk->ref_seq / ref_beg / ref_end); the base comparison runs on the device.
+ * The tag strings are parsed on the host (they are as long as the read has events) into EQX-shaped operations for the same kernel.  A tag that does
+ * not fit its CIGAR, an unknown cs character or '=' / 'X' next to an MD tag -- where the reference stops the program -- gives status[r] = -2. */
+#define LCD_DIGAR_CS 1
+#define LCD_DIGAR_MD 2
+int lcd_digar_batch_tags(const lcd_digar_opt_t *opt, int mode, int n_reads, const int64_t *pos0, const uint32_t *cigar_pool, const uint64_t *cigar_off,
+                         const int *n_cigar, const char *const *tags, const uint8_t *qual_pool, const uint64_t *qual_off, const int *qlen,
+                         const uint8_t *pal_flags, int64_t reg_beg, int64_t reg_end, int64_t whole_ref_len, uint64_t **digar_off, lcd_digar_t **digars,
+                         uint64_t **iv_off, lcd_noisy_iv_t **ivs, uint8_t **iv_in_chunk, int *status, int64_t *beg, int64_t *end, int *n_cand_vars);
+int lcd_digar_batch_ref(const lcd_digar_opt_t *opt, int n_reads, const int64_t *pos0, const uint32_t *cigar_pool, const uint64_t *cigar_off,
+                        const int *n_cigar, const uint8_t *seq_pool, const uint64_t *seq_off, const uint8_t *qual_pool, const uint64_t *qual_off,
+                        const int *qlen, const uint8_t *pal_flags, const char *ref_seq, int64_t ref_beg, int64_t ref_end, int64_t reg_beg,
+                        int64_t reg_end, int64_t whole_ref_len, uint64_t **digar_off, lcd_digar_t **digars, uint64_t **iv_off, lcd_noisy_iv_t **ivs,
+                        uint8_t **iv_in_chunk, int *status, int64_t *beg, int64_t *end, int *n_cand_vars);
 
 /* ---- SURVEY 8(f) f2, chunk level: pre_process_noisy_regs (src/collect_var.c:557-638) ----
  * chunk_noisy: the intervals cr_add()'ed to chunk->chunk_noisy_regs while the reads were loaded (lcd_digar_batch: ivs[k] with iv_in_chunk[k]), in

@@ -378,8 +378,10 @@ def make_read_views(digars, bseqs, quals, qlens, haps, phase_sets):
     return arr, keep
 
 
-def digar_batch(pos0, cigars, quals, reg_beg, reg_end, whole_ref_len, is_ont=0, pal_flags=None, opt=None):
+def digar_batch(pos0, cigars, quals, reg_beg, reg_end, whole_ref_len, is_ont=0, pal_flags=None, opt=None, cs=None, md=None, seqs=None, ref=None):
     """collect_digar_from_eqx_cigar (src/bam_utils.c:701) for a list of reads on the GPU: cigars[i] = uint32 BAM CIGAR words, quals[i] = phred bytes.
+    The reference's three other sources (src/collect_var.c:1072-1079): cs=[bytes, ...] -> collect_digar_from_cs_tag (:844), md=[bytes, ...] ->
+    collect_digar_from_MD_tag (:1010), seqs=[4-bit packed bases, ...] + ref=(ref_seq bytes, ref_beg, ref_end) -> collect_digar_from_ref_seq (:1179).
     -> list of dict(rc, digars (n,5), noisy (m,3), chunk_noisy (k,3), beg, end, n_cand), the layout of the oracle's wrapper"""
     lib = load_library()
     if opt is None:
@@ -396,10 +398,20 @@ def digar_batch(pos0, cigars, quals, reg_beg, reg_end, whole_ref_len, is_ont=0, 
     status = np.zeros(n, np.int32); beg = np.zeros(n, np.int64); end = np.zeros(n, np.int64); ncand = np.zeros(n, np.int32)
     u64p_, i64p = C.POINTER(C.c_uint64), C.POINTER(C.c_int64)
     doff, ioff = u64p_(), u64p_(); dg = C.POINTER(LcdDigar)(); iv = C.POINTER(LcdNoisyIv)(); inc = u8p()
-    check(lib.lcd_digar_batch(C.byref(opt), n, p0.ctypes.data_as(i64p), cpool.ctypes.data_as(C.POINTER(C.c_uint32)), coff.ctypes.data_as(u64p_), ncig.ctypes.data_as(i32p),
-                              _p8(qpool), qoff.ctypes.data_as(u64p_), qlen.ctypes.data_as(i32p), _p8(pf), int(reg_beg), int(reg_end), int(whole_ref_len),
-                              C.byref(doff), C.byref(dg), C.byref(ioff), C.byref(iv), C.byref(inc), status.ctypes.data_as(i32p), beg.ctypes.data_as(i64p),
-                              end.ctypes.data_as(i64p), ncand.ctypes.data_as(i32p)), lib)
+    head = (C.byref(opt), n, p0.ctypes.data_as(i64p), cpool.ctypes.data_as(C.POINTER(C.c_uint32)), coff.ctypes.data_as(u64p_), ncig.ctypes.data_as(i32p))
+    quals_ = (_p8(qpool), qoff.ctypes.data_as(u64p_), qlen.ctypes.data_as(i32p), _p8(pf))
+    tail = (int(reg_beg), int(reg_end), int(whole_ref_len), C.byref(doff), C.byref(dg), C.byref(ioff), C.byref(iv), C.byref(inc), status.ctypes.data_as(i32p),
+            beg.ctypes.data_as(i64p), end.ctypes.data_as(i64p), ncand.ctypes.data_as(i32p))
+    if cs is not None or md is not None:
+        tags = (C.c_char_p * n)(*[bytes(t) for t in (cs if cs is not None else md)])
+        check(lib.lcd_digar_batch_tags(head[0], 1 if cs is not None else 2, *head[1:], tags, *quals_, *tail), lib)
+    elif seqs is not None:
+        sq = [np.ascontiguousarray(x, np.uint8) for x in seqs]
+        soff = np.concatenate([[0], np.cumsum([len(x) for x in sq])]).astype(np.uint64); spool = np.concatenate(sq + [np.zeros(1, np.uint8)])
+        ref_seq, ref_beg, ref_end = ref
+        check(lib.lcd_digar_batch_ref(*head, _p8(spool), soff.ctypes.data_as(u64p_), *quals_, C.c_char_p(bytes(ref_seq)), int(ref_beg), int(ref_end), *tail), lib)
+    else:
+        check(lib.lcd_digar_batch(*head, *quals_, *tail), lib)
     out = []
     nd_tot, ni_tot = int(doff[n]), int(ioff[n])
     D = np.frombuffer((C.c_char * (24 * max(nd_tot, 1))).from_address(C.addressof(dg.contents)), dtype=np.dtype([("pos", "<i8"), ("type", "<i4"), ("len", "<i4"), ("qi", "<i4"), ("lq", "<i4")]), count=nd_tot).copy() if nd_tot else np.zeros(0, [("pos", "<i8"), ("type", "<i4"), ("len", "<i4"), ("qi", "<i4"), ("lq", "<i4")])

@@ -36,8 +36,10 @@ __global__ void __launch_bounds__(64) lcd_digar_kernel(const DigarJob *jobs, Dig
         const int i = c0 + lane;
         int op = -1, len = 0;
         if (i < jb.n_cigar) { const unsigned c = cig[i]; op = (int)(c & 0xf); len = (int)(c >> 4); }
-        const int radv = (op == 7 || op == 8 || op == 2 || op == 3 || op == 0) ? len : 0;
-        const int qadv = (op == 7 || op == 8 || op == 1 || op == 4) ? len : 0;
+        // op 9 (LCD_OP_SKIP) never comes from a BAM: the converters in front of this kernel use it for bases the reference steps over without a
+        // digar (collect_digar_from_ref_seq outside [ref_beg, ref_end], src/bam_utils.c:1206-1212)
+        const int radv = (op == 7 || op == 8 || op == 2 || op == 3 || op == 0 || op == 9) ? len : 0;
+        const int qadv = (op == 7 || op == 8 || op == 1 || op == 4 || op == 9) ? len : 0;
         const int ndig = op == 8 ? len : (op == 7 || op == 2 || op == 1 || op == 4 || op == 5) ? 1 : 0;
         bad |= op == 0;
         const long long rinc = wave_incl_scan64(radv, lane);
@@ -72,6 +74,14 @@ __global__ void __launch_bounds__(64) lcd_digar_kernel(const DigarJob *jobs, Dig
             if (r.type == 4 || r.type == 5) { // clipping: a long one marks the flank next to it (src/bam_utils.c:772-787)
                 const unsigned c = k == 0 ? cig[0] : cig[jb.n_cigar - 1];
                 const bool first = k == 0 && ((c & 0xf) == 4 || (c & 0xf) == 5);
+                if (jb.clip_rule == 1) { // collect_digar_from_cs_tag's variant (src/bam_utils.c:884-888, :969-972): no outer position test, the palindrome first
+                    if (r.len > opt.end_clip_reg && !(first ? jb.left_pal : jb.right_pal)) {
+                        if (first) { if (r.pos > 10) add_iv(r.pos - 1, r.pos + opt.end_clip_flank, 0); }
+                        else if (r.pos < opt.whole_ref_len - 10) add_iv(r.pos - 1 - opt.end_clip_flank, r.pos, 0);
+                        ++n_cand;
+                    }
+                    continue;
+                }
                 if ((first && r.pos > 10) || (!first && r.pos < opt.whole_ref_len - 10)) {
                     if (r.len > opt.end_clip_reg) {
                         if (first && !jb.left_pal) { if (r.pos > 1) add_iv(r.pos - 1, r.pos + opt.end_clip_flank, 0); ++n_cand; }
@@ -105,6 +115,95 @@ __global__ void __launch_bounds__(64) lcd_digar_kernel(const DigarJob *jobs, Dig
         DigarOut o; o.status = (bad & 1) ? -2 : (nd > jb.digar_cap || n_iv > jb.iv_cap || (bad & 2)) ? -3 : 0; o.n_digar = nd; o.n_iv = n_iv; o.n_cand = n_cand; o.rlen = (int)rlen;
         outs[jid] = o;
     }
+}
+
+// ---- collect_digar_from_ref_seq's base comparison (src/bam_utils.c:1201-1235) as a CIGAR rewrite: M / = / X operations -> '=' runs, one 'X' per
+// differing base and LCD_OP_SKIP for bases outside the loaded reference window, everything else passed through; the result feeds lcd_digar_kernel.
+// One wavefront per read, 64 bases per step: the three base classes are ballots, every mismatching lane finds the run in front of it with popcounts
+// of the ballots and writes its own operations ([skip] [=] X; the reference flushes a pending '=' run at pos - eq_len, i.e. AFTER the stepped-over
+// bases, hence the order).  Two passes of the same code: COUNT sizes the output (operations, digars, window events), EMIT writes it.
+// Bytes per base: 1 (reference char) + 1/2 (BAM 4-bit base), per pass.
+namespace {
+__device__ __forceinline__ int nt4_of_char(const unsigned char c) { // nst_nt4_table, src/seq.c:14-31
+    if (c < 4) return c;
+    if (c == '-') return 5;
+    const unsigned char u = c | 32;
+    return u == 'a' ? 0 : u == 'c' ? 1 : u == 'g' ? 2 : u == 't' ? 3 : 4;
+}
+__device__ __forceinline__ int nt4_of_bam4(const int b) { return b == 1 ? 0 : b == 2 ? 1 : b == 4 ? 2 : b == 8 ? 3 : 4; } // seq_nt16_int (htslib)
+}
+template <bool EMIT>
+__global__ void __launch_bounds__(64) lcd_refcmp_kernel(const RefCmpJob *jobs, RefCmpOut *outs, const char *ref, long long ref_beg, long long ref_end, int n_jobs) {
+    const int jid = blockIdx.x;
+    if (jid >= n_jobs) return;
+    const int lane = threadIdx.x;
+    const RefCmpJob jb = jobs[jid];
+    const unsigned *cig = (const unsigned *)jb.cigar_off;
+    const uint8_t *seq = (const uint8_t *)jb.seq_off;
+    unsigned *out = (unsigned *)jb.out_off;
+    long long pos = jb.pos0 + 1;
+    int qi = 0, w = 0, nd = 0, nev = 0;
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    for (int c0 = 0; c0 < jb.n_cigar; c0 += 64) {
+        const unsigned cw = c0 + lane < jb.n_cigar ? cig[c0 + lane] : 0u;
+        const int nc = jb.n_cigar - c0 < 64 ? jb.n_cigar - c0 : 64;
+        for (int ci = 0; ci < nc; ++ci) {
+            const unsigned c = __shfl(cw, ci);
+            const int op = (int)(c & 0xf), len = (int)(c >> 4);
+            if (op == 0 || op == 7 || op == 8) {
+                int e_carry = 0, s_carry = 0;
+                for (int b0 = 0; b0 < len; b0 += 64) {
+                    const int j = b0 + lane;
+                    int cls = 3;
+                    if (j < len) {
+                        const long long p = pos + j; const int q = qi + j;
+                        if (p < ref_beg || p > ref_end) cls = 2;
+                        else cls = nt4_of_char((unsigned char)ref[p - ref_beg]) != nt4_of_bam4((seq[q >> 1] >> ((~q & 1) << 2)) & 0xf);
+                    }
+                    const unsigned long long mm = __ballot(cls == 1), eqm = __ballot(cls == 0), skm = __ballot(cls == 2);
+                    int e = 0, s = 0, nops = 0;
+                    if (cls == 1) {
+                        const unsigned long long prev = mm & below;
+                        const int lo = prev ? 64 - __clzll(prev) : 0;
+                        const unsigned long long between = below & ~((1ull << lo) - 1);
+                        e = __popcll(eqm & between) + (prev ? 0 : e_carry); s = __popcll(skm & between) + (prev ? 0 : s_carry);
+                        nops = 1 + (e > 0) + (s > 0);
+                    }
+                    const int incl = wave_incl_scan(nops, lane);
+                    if (EMIT && cls == 1) {
+                        int t = w + incl - nops;
+                        if (s > 0) out[t++] = ((unsigned)s << 4) | 9u;
+                        if (e > 0) out[t++] = ((unsigned)e << 4) | 7u;
+                        out[t] = (1u << 4) | 8u;
+                    }
+                    w += __shfl(incl, 63);
+                    const int nmm = __popcll(mm);
+                    nd += nmm + __popcll(__ballot(cls == 1 && e > 0)); nev += nmm;
+                    if (mm) {
+                        const int hi = 64 - __clzll(mm);
+                        const unsigned long long tail = hi == 64 ? 0ull : ~((1ull << hi) - 1);
+                        e_carry = __popcll(eqm & tail); s_carry = __popcll(skm & tail);
+                    } else { e_carry += __popcll(eqm); s_carry += __popcll(skm); }
+                }
+                if (EMIT && lane == 0) { int t = w; if (s_carry > 0) out[t++] = ((unsigned)s_carry << 4) | 9u; if (e_carry > 0) out[t] = ((unsigned)e_carry << 4) | 7u; }
+                w += (s_carry > 0) + (e_carry > 0); nd += e_carry > 0;
+                pos += len; qi += len;
+            } else {
+                if (EMIT && lane == 0) out[w] = c;
+                ++w;
+                if (op == 2 || op == 3) pos += len;
+                if (op == 1 || op == 4) qi += len;
+                if (op == 1 || op == 2 || op == 4 || op == 5) ++nd;
+                if (op == 1 || op == 2) ++nev;
+            }
+        }
+    }
+    if (!EMIT && lane == 0) { RefCmpOut o; o.n_ops = w; o.nd = nd; o.nev = nev; o.pad = 0; outs[jid] = o; }
+}
+void lcd_launch_refcmp(bool emit, const RefCmpJob *jobs, RefCmpOut *outs, const char *ref, long long ref_beg, long long ref_end, int n_jobs, hipStream_t stream) {
+    if (n_jobs <= 0) return;
+    if (emit) hipLaunchKernelGGL(lcd_refcmp_kernel<true>, dim3(n_jobs), dim3(64), 0, stream, jobs, outs, ref, ref_beg, ref_end, n_jobs);
+    else hipLaunchKernelGGL(lcd_refcmp_kernel<false>, dim3(n_jobs), dim3(64), 0, stream, jobs, outs, ref, ref_beg, ref_end, n_jobs);
 }
 
 // pre_process_noisy_regs, the read-support part (src/collect_var.c:584-602): per merged region, the reads spanning it and, among them, those

@@ -2056,33 +2056,41 @@ void lcd_digar_opt_default(lcd_digar_opt_t *o, int is_ont) {
     o->min_bq = 10; o->noisy_reg_max_xgaps = 5; o->noisy_reg_slide_win = is_ont ? 25 : 100; o->end_clip_reg = 30; o->end_clip_reg_flank_win = 100;
     o->max_noisy_frac_per_read = 0.5; o->max_var_ratio_per_read = 0.05;
 }
-int lcd_digar_batch(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, const uint32_t *cigar_pool, const uint64_t *cigar_off, const int *n_cigar,
+// the four collect_digar_from_* entry points share everything behind the CIGAR-shaped operation words: `words` are host words (h_pool) or words already in
+// HBM (d_words: the reference-comparison rewrite) with their per-read digar / event counts; clip_rule as DigarJob; rlen_true: bam_cigar2rlen of the BAM
+// CIGAR where the words were derived from a tag instead (digar->end = bam_endpos(read), src/bam_utils.c:852)
+namespace {
+struct DigarWords {
+    const uint32_t *h_pool = nullptr; const uint64_t *off = nullptr; const int *n_cigar = nullptr;
+    const DevBuf *d_words = nullptr; const RefCmpOut *counts = nullptr;
+    int clip_rule = 0; const int64_t *rlen_true = nullptr; const int *pre_status = nullptr;
+};
+int digar_batch_core(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, const DigarWords &W,
                     const uint8_t *qual_pool, const uint64_t *qual_off, const int *qlen, const uint8_t *pal_flags, int64_t reg_beg, int64_t reg_end,
                     int64_t whole_ref_len, uint64_t **digar_off_out, lcd_digar_t **digars_out, uint64_t **iv_off_out, lcd_noisy_iv_t **ivs_out,
-                    uint8_t **iv_in_chunk_out, int *status, int64_t *beg, int64_t *end, int *n_cand_vars) {
-    *digar_off_out = *iv_off_out = nullptr; *digars_out = nullptr; *ivs_out = nullptr; *iv_in_chunk_out = nullptr;
-    if (ensure_init()) return -1;
-    if (n <= 0) return 0;
+                    uint8_t **iv_in_chunk_out, int *status, int64_t *beg, int64_t *end, int *n_cand_vars, hipStream_t st) {
+    const uint32_t *cigar_pool = W.h_pool; const uint64_t *cigar_off = W.off; const int *n_cigar = W.n_cigar;
     static_assert(sizeof(lcd_digar_t) == sizeof(DigarRec) && sizeof(lcd_noisy_iv_t) == sizeof(IvRec), "ABI structs mirror the device records");
-    StreamGuard st; if (st.create()) return -10;
-    // capacities from one pass over the CIGAR words (the host has them in hand anyway)
+    // capacities from one pass over the CIGAR words (the host has them in hand anyway), or from the rewrite's count pass
     std::vector<DigarJob> jobs(n);
     uint64_t cig_words = 0, qual_bytes = 0, dtot = 0, itot = 0, etot = 0;
     for (int r = 0; r < n; ++r) { cig_words = std::max<uint64_t>(cig_words, cigar_off[r] + n_cigar[r]); qual_bytes = std::max<uint64_t>(qual_bytes, qual_off[r] + qlen[r]); }
     for (int r = 0; r < n; ++r) {
         DigarJob &j = jobs[r];
         long long nd = 0, nev = 0;
-        for (int i = 0; i < n_cigar[r]; ++i) { const uint32_t c = cigar_pool[cigar_off[r] + i]; const int op = c & 0xf, len = (int)(c >> 4); if (op == 8) { nd += len; nev += len; } else if (op != 3) { ++nd; if (op == 1 || op == 2) ++nev; } }
+        if (W.counts) { nd = W.counts[r].nd; nev = W.counts[r].nev; }
+        else for (int i = 0; i < n_cigar[r]; ++i) { const uint32_t c = cigar_pool[cigar_off[r] + i]; const int op = c & 0xf, len = (int)(c >> 4); if (op == 8) { nd += len; nev += len; } else if (op != 3 && op != 9) { ++nd; if (op == 1 || op == 2) ++nev; } }
         j.n_cigar = n_cigar[r]; j.qlen = qlen[r]; j.pos0 = pos0[r]; j.left_pal = pal_flags ? pal_flags[r] & 1 : 0; j.right_pal = pal_flags ? (pal_flags[r] >> 1) & 1 : 0;
-        j.digar_cap = (int)nd; j.ev_cap = (int)nev + 1; j.iv_cap = (int)(nev / (opt->noisy_reg_max_xgaps + 1)) + 4; j.pad = 0;
+        j.digar_cap = (int)nd; j.ev_cap = (int)nev + 1; j.iv_cap = (int)(nev / (opt->noisy_reg_max_xgaps + 1)) + 4; j.clip_rule = W.clip_rule;
         j.cigar_off = cigar_off[r] * 4; j.qual_off = qual_off[r];
         j.digar_off = dtot * sizeof(DigarRec); dtot += nd; j.iv_off = itot * sizeof(IvRec); itot += j.iv_cap; j.ev_off = etot * 16; etot += j.ev_cap;
     }
     DevBuf d_cig, d_qual, d_jobs, d_outs, d_dig, d_iv, d_ev;
-    if (d_cig.ensure(cig_words * 4 + 64) || d_qual.ensure(qual_bytes + 64) || d_jobs.ensure(n * sizeof(DigarJob)) || d_outs.ensure(n * sizeof(DigarOut)) ||
+    if ((!W.d_words && d_cig.ensure(cig_words * 4 + 64)) || d_qual.ensure(qual_bytes + 64) || d_jobs.ensure(n * sizeof(DigarJob)) || d_outs.ensure(n * sizeof(DigarOut)) ||
         d_dig.ensure(dtot * sizeof(DigarRec) + 64) || d_iv.ensure(itot * sizeof(IvRec) + 64) || d_ev.ensure(etot * 16 + 64)) return -11;
-    for (DigarJob &j : jobs) { j.cigar_off += d_cig.addr(); j.qual_off += d_qual.addr(); j.digar_off += d_dig.addr(); j.iv_off += d_iv.addr(); j.ev_off += d_ev.addr(); }
-    HIPCHK(hipMemcpyAsync(d_cig.p, cigar_pool, cig_words * 4, hipMemcpyHostToDevice, st));
+    const uint64_t cig_base = W.d_words ? W.d_words->addr() : d_cig.addr();
+    for (DigarJob &j : jobs) { j.cigar_off += cig_base; j.qual_off += d_qual.addr(); j.digar_off += d_dig.addr(); j.iv_off += d_iv.addr(); j.ev_off += d_ev.addr(); }
+    if (!W.d_words) HIPCHK(hipMemcpyAsync(d_cig.p, cigar_pool, cig_words * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_qual.p, qual_pool, qual_bytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_jobs.p, jobs.data(), n * sizeof(DigarJob), hipMemcpyHostToDevice, st));
     DigarOpt dopt; dopt.min_bq = opt->min_bq; dopt.max_xgaps = opt->noisy_reg_max_xgaps; dopt.win = opt->noisy_reg_slide_win; dopt.end_clip_reg = opt->end_clip_reg;
@@ -2116,10 +2124,10 @@ int lcd_digar_batch(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, cons
         if (!sorted) std::stable_sort(v.begin(), v.end(), [&](const IvRec &a, const IvRec &b) { return key(a) < key(b); });
         long long total = 0;
         for (const IvRec &x : v) total += x.en - x.st + 1;                     // collect_noisy_region_len (:631)
-        beg[r] = j.pos0 + 1; end[r] = j.pos0 + o.rlen; n_cand_vars[r] = o.n_cand;
+        beg[r] = j.pos0 + 1; end[r] = j.pos0 + (W.rlen_true ? W.rlen_true[r] : o.rlen); n_cand_vars[r] = o.n_cand;
         const long long mapped = end[r] - beg[r] + 1;
         const bool skip = (double)total > mapped * opt->max_noisy_frac_per_read || (double)o.n_cand > mapped * opt->max_var_ratio_per_read; // (:811)
-        status[r] = o.status == -2 ? -2 : skip ? -1 : 0;
+        status[r] = (o.status == -2 || (W.pre_status && W.pre_status[r])) ? -2 : skip ? -1 : 0;
         for (int k = 0; k < o.n_iv; ++k) {
             iv[iw + k].start = v[k].st; iv[iw + k].end = v[k].en; iv[iw + k].label = v[k].label; iv[iw + k].pad = 0;
             inc[iw + k] = !skip && !(v[k].st + 1 > reg_end || v[k].en < reg_beg);    // is_overlap_reg(start + 1, end, ...) (:820)
@@ -2129,6 +2137,142 @@ int lcd_digar_batch(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, cons
     doff[n] = dw; ioff[n] = iw;
     *digar_off_out = doff; *digars_out = dg; *iv_off_out = ioff; *ivs_out = iv; *iv_in_chunk_out = inc;
     return 0;
+}
+
+// ---- host side of the cs / MD paths: the tag strings are O(events) long, so they are parsed here into EQX-shaped operation words ----
+inline bool is_alpha(char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
+inline bool is_digit(char c) { return c >= '0' && c <= '9'; }
+inline uint32_t opw(long long len, int op) { return ((uint32_t)len << 4) | (uint32_t)op; }
+// collect_digar_from_cs_tag, src/bam_utils.c:876-976: clips from the first / last CIGAR operation, everything else from the cs string
+bool cs_to_words(const uint32_t *cig, int n_cigar, const char *cs, std::vector<uint32_t> &w) {
+    if (n_cigar <= 0 || !cs) return false;
+    if ((cig[0] & 0xf) == 4 || (cig[0] & 0xf) == 5) w.push_back(cig[0]);
+    while (*cs) {
+        if (*cs == ':') { char *e; const long len = strtol(cs + 1, &e, 10); if (e == cs + 1 || len < 0) return false; cs = e; w.push_back(opw(len, 7)); }
+        else if (*cs == '=' || *cs == '+' || *cs == '-') { const int op = *cs == '=' ? 7 : *cs == '+' ? 1 : 2; ++cs; long len = 0; while (is_alpha(*cs)) { ++len; ++cs; } w.push_back(opw(len, op)); }
+        else if (*cs == '*') { if (!cs[1] || !cs[2]) return false; w.push_back(opw(1, 8)); cs += 3; }
+        else if (*cs == '~') { ++cs; while (is_alpha(*cs) || is_digit(*cs)) ++cs; }   // intron: stepped over without moving pos (:951-953)
+        else return false;                                                             // the reference exits (:955)
+    }
+    const uint32_t last = cig[n_cigar - 1];
+    if ((last & 0xf) == 4 || (last & 0xf) == 5) w.push_back(last);
+    return true;
+}
+// collect_digar_from_MD_tag, src/bam_utils.c:1035-1134: 'M' operations split by the MD string ('=' runs that may continue over an insertion into the
+// next 'M', one 'X' per letter), deletions step over "^LETTERS", a "0" after either is skipped
+bool md_to_words(const uint32_t *cig, int n_cigar, const char *md0, std::vector<uint32_t> &w) {
+    if (!md0) return false;
+    const char *md = md0, *md_end = md0 + strlen(md0); long md_i = 0;
+    auto at = [&](long k) -> char { const char *q = md + k; return (q >= md0 && q < md_end) ? *q : '\0'; };
+    long last_eq = 0;
+    for (int i = 0; i < n_cigar; ++i) {
+        const int op = cig[i] & 0xf; const long len = cig[i] >> 4;
+        if (op == 0) {
+            long m = len;
+            while (1) {
+                if (last_eq > 0) {
+                    if (last_eq >= m) { w.push_back(opw(m, 7)); last_eq -= m; m = 0; }
+                    else { w.push_back(opw(last_eq, 7)); m -= last_eq; md_i = 0; last_eq = 0; }
+                } else if (is_digit(at(md_i))) {
+                    char *e; long eq = strtol(md + md_i, &e, 10); md = e;
+                    bool emit = true;
+                    if (eq > m) { last_eq = eq - m; eq = m; }
+                    else if (eq == 0) { md_i = 0; emit = false; }
+                    if (emit) { w.push_back(opw(eq, 7)); m -= eq; md_i = 0; }
+                    else continue;
+                } else if (is_alpha(at(md_i))) {
+                    w.push_back(opw(1, 8)); m -= 1;
+                    if (at(md_i + 1) == '\0' || at(md_i + 1) != '0') md_i++; else md_i += 2;
+                } else return false;                                                   // "MD and CIGAR do not match": the reference exits (:1088)
+                if (m <= 0) break;
+            }
+        } else if (op == 2) {
+            w.push_back(cig[i]);
+            md_i++;
+            while (at(md_i) && is_alpha(at(md_i))) md_i++;
+            if (at(md_i) == '0') md_i++;
+        } else if (op == 1 || op == 4 || op == 5 || op == 3) w.push_back(cig[i]);
+        else if (op == 7 || op == 8) return false;                                     // '=' / 'X' next to an MD tag: the reference exits (:1134)
+    }
+    return true;
+}
+} // namespace
+
+int lcd_digar_batch(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, const uint32_t *cigar_pool, const uint64_t *cigar_off, const int *n_cigar,
+                    const uint8_t *qual_pool, const uint64_t *qual_off, const int *qlen, const uint8_t *pal_flags, int64_t reg_beg, int64_t reg_end,
+                    int64_t whole_ref_len, uint64_t **digar_off_out, lcd_digar_t **digars_out, uint64_t **iv_off_out, lcd_noisy_iv_t **ivs_out,
+                    uint8_t **iv_in_chunk_out, int *status, int64_t *beg, int64_t *end, int *n_cand_vars) {
+    *digar_off_out = *iv_off_out = nullptr; *digars_out = nullptr; *ivs_out = nullptr; *iv_in_chunk_out = nullptr;
+    if (ensure_init()) return -1;
+    if (n <= 0) return 0;
+    StreamGuard st; if (st.create()) return -10;
+    DigarWords W; W.h_pool = cigar_pool; W.off = cigar_off; W.n_cigar = n_cigar;
+    return digar_batch_core(opt, n, pos0, W, qual_pool, qual_off, qlen, pal_flags, reg_beg, reg_end, whole_ref_len, digar_off_out, digars_out, iv_off_out, ivs_out,
+                            iv_in_chunk_out, status, beg, end, n_cand_vars, st);
+}
+
+int lcd_digar_batch_tags(const lcd_digar_opt_t *opt, int mode, int n, const int64_t *pos0, const uint32_t *cigar_pool, const uint64_t *cigar_off, const int *n_cigar,
+                         const char *const *tags, const uint8_t *qual_pool, const uint64_t *qual_off, const int *qlen, const uint8_t *pal_flags, int64_t reg_beg,
+                         int64_t reg_end, int64_t whole_ref_len, uint64_t **digar_off_out, lcd_digar_t **digars_out, uint64_t **iv_off_out,
+                         lcd_noisy_iv_t **ivs_out, uint8_t **iv_in_chunk_out, int *status, int64_t *beg, int64_t *end, int *n_cand_vars) {
+    *digar_off_out = *iv_off_out = nullptr; *digars_out = nullptr; *ivs_out = nullptr; *iv_in_chunk_out = nullptr;
+    if (mode != LCD_DIGAR_CS && mode != LCD_DIGAR_MD) return set_err(-2, "lcd_digar_batch_tags: mode is LCD_DIGAR_CS or LCD_DIGAR_MD");
+    if (ensure_init()) return -1;
+    if (n <= 0) return 0;
+    StreamGuard st; if (st.create()) return -10;
+    std::vector<uint32_t> words; std::vector<uint64_t> off(n); std::vector<int> cnt(n), pre(n, 0); std::vector<int64_t> rlen(n);
+    for (int r = 0; r < n; ++r) {
+        const uint32_t *cig = cigar_pool + cigar_off[r];
+        off[r] = words.size();
+        const bool ok = mode == LCD_DIGAR_CS ? cs_to_words(cig, n_cigar[r], tags[r], words) : md_to_words(cig, n_cigar[r], tags[r], words);
+        if (!ok) { pre[r] = 1; words.resize(off[r]); }           // the reference stops the program here; the read comes back with status -2 and no digars
+        cnt[r] = (int)(words.size() - off[r]);
+        long long rl = 0;
+        for (int i = 0; i < n_cigar[r]; ++i) { const int op = cig[i] & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += cig[i] >> 4; }
+        rlen[r] = rl;
+    }
+    words.push_back(0);
+    DigarWords W; W.h_pool = words.data(); W.off = off.data(); W.n_cigar = cnt.data(); W.clip_rule = mode == LCD_DIGAR_CS ? 1 : 0; W.rlen_true = rlen.data(); W.pre_status = pre.data();
+    return digar_batch_core(opt, n, pos0, W, qual_pool, qual_off, qlen, pal_flags, reg_beg, reg_end, whole_ref_len, digar_off_out, digars_out, iv_off_out, ivs_out,
+                            iv_in_chunk_out, status, beg, end, n_cand_vars, st);
+}
+
+int lcd_digar_batch_ref(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, const uint32_t *cigar_pool, const uint64_t *cigar_off, const int *n_cigar,
+                        const uint8_t *seq_pool, const uint64_t *seq_off, const uint8_t *qual_pool, const uint64_t *qual_off, const int *qlen, const uint8_t *pal_flags,
+                        const char *ref_seq, int64_t ref_beg, int64_t ref_end, int64_t reg_beg, int64_t reg_end, int64_t whole_ref_len, uint64_t **digar_off_out,
+                        lcd_digar_t **digars_out, uint64_t **iv_off_out, lcd_noisy_iv_t **ivs_out, uint8_t **iv_in_chunk_out, int *status, int64_t *beg,
+                        int64_t *end, int *n_cand_vars) {
+    *digar_off_out = *iv_off_out = nullptr; *digars_out = nullptr; *ivs_out = nullptr; *iv_in_chunk_out = nullptr;
+    if (ensure_init()) return -1;
+    if (n <= 0) return 0;
+    if (ref_end < ref_beg) return set_err(-2, "lcd_digar_batch_ref: empty reference window");
+    StreamGuard st; if (st.create()) return -10;
+    uint64_t cig_words = 0, seq_bytes = 0;
+    for (int r = 0; r < n; ++r) { cig_words = std::max<uint64_t>(cig_words, cigar_off[r] + n_cigar[r]); seq_bytes = std::max<uint64_t>(seq_bytes, seq_off[r] + (uint64_t)(qlen[r] + 1) / 2); }
+    const uint64_t ref_len = (uint64_t)(ref_end - ref_beg + 1);
+    DevBuf d_cig, d_seq, d_ref, d_jobs, d_cnt, d_words;
+    if (d_cig.ensure(cig_words * 4 + 64) || d_seq.ensure(seq_bytes + 64) || d_ref.ensure(ref_len + 64) || d_jobs.ensure(n * sizeof(RefCmpJob)) || d_cnt.ensure(n * sizeof(RefCmpOut))) return -11;
+    std::vector<RefCmpJob> jobs(n);
+    for (int r = 0; r < n; ++r) { RefCmpJob &j = jobs[r]; j.cigar_off = d_cig.addr() + cigar_off[r] * 4; j.seq_off = d_seq.addr() + seq_off[r]; j.out_off = 0; j.n_cigar = n_cigar[r]; j.pad = 0; j.pos0 = pos0[r]; }
+    HIPCHK(hipMemcpyAsync(d_cig.p, cigar_pool, cig_words * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_seq.p, seq_pool, seq_bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_ref.p, ref_seq, ref_len, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_jobs.p, jobs.data(), n * sizeof(RefCmpJob), hipMemcpyHostToDevice, st));
+    lcd_launch_refcmp(false, (const RefCmpJob *)d_jobs.p, (RefCmpOut *)d_cnt.p, (const char *)d_ref.p, ref_beg, ref_end, n, st);
+    HIPCHK(hipGetLastError());
+    std::vector<RefCmpOut> cnt(n);
+    HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt.p, n * sizeof(RefCmpOut), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<uint64_t> off(n); std::vector<int> nw(n); uint64_t tot = 0;
+    for (int r = 0; r < n; ++r) { off[r] = tot; nw[r] = cnt[r].n_ops; tot += (uint64_t)cnt[r].n_ops; }
+    if (d_words.ensure(tot * 4 + 64)) return -11;
+    for (int r = 0; r < n; ++r) jobs[r].out_off = d_words.addr() + off[r] * 4;
+    HIPCHK(hipMemcpyAsync(d_jobs.p, jobs.data(), n * sizeof(RefCmpJob), hipMemcpyHostToDevice, st));
+    lcd_launch_refcmp(true, (const RefCmpJob *)d_jobs.p, (RefCmpOut *)d_cnt.p, (const char *)d_ref.p, ref_beg, ref_end, n, st);
+    HIPCHK(hipGetLastError());
+    DigarWords W; W.off = off.data(); W.n_cigar = nw.data(); W.d_words = &d_words; W.counts = cnt.data();
+    return digar_batch_core(opt, n, pos0, W, qual_pool, qual_off, qlen, pal_flags, reg_beg, reg_end, whole_ref_len, digar_off_out, digars_out, iv_off_out, ivs_out,
+                            iv_in_chunk_out, status, beg, end, n_cand_vars, st);
 }
 
 int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int *chain_read0, const int *chain_n_reads, int n_reads_total,

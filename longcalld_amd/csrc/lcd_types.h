@@ -260,8 +260,10 @@ struct DigarJob {
     long long pos0;                 // bam1_core_t.pos (0-based)
     int left_pal, right_pal;        // is_ont_palindrome_clip for the left / right clip (caller-supplied)
     uint64_t digar_off, iv_off, ev_off; // outputs DigarRec[digar_cap], IvRec[iv_cap]; scratch: the event queue (16 B x ev_cap)
-    int digar_cap, iv_cap, ev_cap, pad;
+    int digar_cap, iv_cap, ev_cap, clip_rule; // clip_rule 0: the EQX / MD / reference paths (src/bam_utils.c:772-787), 1: the cs path (:884-888, :969-972)
 };
+struct RefCmpJob { uint64_t cigar_off, seq_off, out_off; int n_cigar, pad; long long pos0; }; // BAM CIGAR words, 4-bit bases, rewritten words
+struct RefCmpOut { int n_ops, nd, nev, pad; };                                               // rewritten operations, digars, window events
 struct DigarOut { int status, n_digar, n_iv, n_cand, rlen; };
 struct DigarOpt { int min_bq, max_xgaps, win, end_clip_reg, end_clip_flank, pad; long long whole_ref_len; };
 

@@ -183,6 +183,20 @@ int lcdo_collect_digar_from_eqx_cigar(const lcdo_digar_opt_t *opt, int64_t read_
                                       int64_t **noisy, int *n_noisy, int64_t **chunk_noisy, int *n_chunk_noisy, int64_t *beg, int64_t *end,
                                       int *n_total_cand_vars);
 void lcdo_cr_sorted_order(int n, const int *st, const int *en, int *order_out);
+/* oracle/digar_tags.c: the same outputs from a cs:Z tag (src/bam_utils.c:844), an MD:Z tag (:1010) or the reference bases (:1179; bseq = BAM 4-bit bases,
+ * ref_seq[0] = position ref_beg, ref_end inclusive); -2 where the reference stops the program */
+int lcdo_collect_digar_from_cs_tag(const lcdo_digar_opt_t *opt, int64_t read_pos0, const uint32_t *cigar, int n_cigar, const char *cs, const uint8_t *qual, int qlen,
+                                   int64_t reg_beg, int64_t reg_end, int64_t whole_ref_len, int left_clip_is_palindrome, int right_clip_is_palindrome,
+                                   lcdo_digar_t **digars, int *n_digar, int64_t **noisy, int *n_noisy, int64_t **chunk_noisy, int *n_chunk_noisy, int64_t *beg,
+                                   int64_t *end, int *n_total_cand_vars);
+int lcdo_collect_digar_from_MD_tag(const lcdo_digar_opt_t *opt, int64_t read_pos0, const uint32_t *cigar, int n_cigar, const char *md, const uint8_t *qual, int qlen,
+                                   int64_t reg_beg, int64_t reg_end, int64_t whole_ref_len, int left_clip_is_palindrome, int right_clip_is_palindrome,
+                                   lcdo_digar_t **digars, int *n_digar, int64_t **noisy, int *n_noisy, int64_t **chunk_noisy, int *n_chunk_noisy, int64_t *beg,
+                                   int64_t *end, int *n_total_cand_vars);
+int lcdo_collect_digar_from_ref_seq(const lcdo_digar_opt_t *opt, int64_t read_pos0, const uint32_t *cigar, int n_cigar, const uint8_t *bseq, const uint8_t *qual, int qlen,
+                                    const char *ref_seq, int64_t ref_beg, int64_t ref_end, int64_t reg_beg, int64_t reg_end, int64_t whole_ref_len,
+                                    int left_clip_is_palindrome, int right_clip_is_palindrome, lcdo_digar_t **digars, int *n_digar, int64_t **noisy, int *n_noisy,
+                                    int64_t **chunk_noisy, int *n_chunk_noisy, int64_t *beg, int64_t *end, int *n_total_cand_vars);
 
 /* ---------------- region alignment strings -> candidate variants + read x variant profile ---------------- */
 typedef struct {
@@ -263,6 +277,20 @@ int lcdo_flip_variant_hap(lcdo_chunk_phase_t *pre_chunk, lcdo_chunk_phase_t *cur
 int lcdo_format_vcf(const lcdo_call_opt_t *opt, const char *chrom, const lcdo_var1_t *vars, int n_vars, char **text_out);
 /* order of intervals (st[i], en[i], label i) after cr_index(): cr_is_sorted / radix_sort_cr_intv (src/cgranges.c:13-86,162,350) */
 void lcdo_cr_sorted_order(int n, const int *st, const int *en, int *order_out);
+/* oracle/digar_tags.c: the same outputs from a cs:Z tag (src/bam_utils.c:844), an MD:Z tag (:1010) or the reference bases (:1179; bseq = BAM 4-bit bases,
+ * ref_seq[0] = position ref_beg, ref_end inclusive); -2 where the reference stops the program */
+int lcdo_collect_digar_from_cs_tag(const lcdo_digar_opt_t *opt, int64_t read_pos0, const uint32_t *cigar, int n_cigar, const char *cs, const uint8_t *qual, int qlen,
+                                   int64_t reg_beg, int64_t reg_end, int64_t whole_ref_len, int left_clip_is_palindrome, int right_clip_is_palindrome,
+                                   lcdo_digar_t **digars, int *n_digar, int64_t **noisy, int *n_noisy, int64_t **chunk_noisy, int *n_chunk_noisy, int64_t *beg,
+                                   int64_t *end, int *n_total_cand_vars);
+int lcdo_collect_digar_from_MD_tag(const lcdo_digar_opt_t *opt, int64_t read_pos0, const uint32_t *cigar, int n_cigar, const char *md, const uint8_t *qual, int qlen,
+                                   int64_t reg_beg, int64_t reg_end, int64_t whole_ref_len, int left_clip_is_palindrome, int right_clip_is_palindrome,
+                                   lcdo_digar_t **digars, int *n_digar, int64_t **noisy, int *n_noisy, int64_t **chunk_noisy, int *n_chunk_noisy, int64_t *beg,
+                                   int64_t *end, int *n_total_cand_vars);
+int lcdo_collect_digar_from_ref_seq(const lcdo_digar_opt_t *opt, int64_t read_pos0, const uint32_t *cigar, int n_cigar, const uint8_t *bseq, const uint8_t *qual, int qlen,
+                                    const char *ref_seq, int64_t ref_beg, int64_t ref_end, int64_t reg_beg, int64_t reg_end, int64_t whole_ref_len,
+                                    int left_clip_is_palindrome, int right_clip_is_palindrome, lcdo_digar_t **digars, int *n_digar, int64_t **noisy, int *n_noisy,
+                                    int64_t **chunk_noisy, int *n_chunk_noisy, int64_t *beg, int64_t *end, int *n_total_cand_vars);
 
 #ifdef __cplusplus
 }

@@ -388,20 +388,19 @@ def digar_opt(is_ont=0):
     return DigarOpt(10, 5, 25 if is_ont else 100, 30, 100, 0.5, 0.05)
 
 
-def collect_digar_from_eqx_cigar(pos0, cigar, qual, reg_beg, reg_end, whole_ref_len, opt=None, left_pal=0, right_pal=0):
-    """SURVEY 8(f) f2 oracle (oracle/digar.c): -> dict(rc, digars (n,5), noisy (m,3), chunk_noisy (k,3), beg, end, n_cand)"""
+def _collect_digar(fn, mid_types, mid_args, pos0, cigar, qual, reg_beg, reg_end, whole_ref_len, opt, left_pal, right_pal, pre_types=(), pre_args=()):
     opt = opt or digar_opt()
     cg = np.ascontiguousarray(cigar, np.uint32); ql = _c8(qual)
     dp, nz, cz = C.POINTER(DigarLQ)(), C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)()
     nd, nn, nc, ncand = C.c_int(), C.c_int(), C.c_int(), C.c_int()
     beg, end = C.c_int64(), C.c_int64()
-    L = lib()
-    L.lcdo_collect_digar_from_eqx_cigar.argtypes = [C.POINTER(DigarOpt), C.c_int64, C.POINTER(C.c_uint32), C.c_int, u8p, u8p, C.c_int, C.c_int64, C.c_int64, C.c_int64,
-                                                    C.c_int, C.c_int, C.POINTER(C.POINTER(DigarLQ)), i32p, C.POINTER(C.POINTER(C.c_int64)), i32p,
-                                                    C.POINTER(C.POINTER(C.c_int64)), i32p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), i32p]
-    rc = L.lcdo_collect_digar_from_eqx_cigar(C.byref(opt), int(pos0), cg.ctypes.data_as(C.POINTER(C.c_uint32)), len(cg), None, _p(ql), len(ql), int(reg_beg), int(reg_end),
-                                             int(whole_ref_len), int(left_pal), int(right_pal), C.byref(dp), C.byref(nd), C.byref(nz), C.byref(nn), C.byref(cz), C.byref(nc),
-                                             C.byref(beg), C.byref(end), C.byref(ncand))
+    f = getattr(lib(), fn)
+    f.argtypes = [C.POINTER(DigarOpt), C.c_int64, C.POINTER(C.c_uint32), C.c_int] + list(pre_types) + [u8p, C.c_int] + list(mid_types) + [C.c_int64, C.c_int64, C.c_int64,
+                  C.c_int, C.c_int, C.POINTER(C.POINTER(DigarLQ)), i32p, C.POINTER(C.POINTER(C.c_int64)), i32p,
+                  C.POINTER(C.POINTER(C.c_int64)), i32p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), i32p]
+    rc = f(C.byref(opt), int(pos0), cg.ctypes.data_as(C.POINTER(C.c_uint32)), len(cg), *pre_args, _p(ql), len(ql), *mid_args, int(reg_beg), int(reg_end),
+           int(whole_ref_len), int(left_pal), int(right_pal), C.byref(dp), C.byref(nd), C.byref(nz), C.byref(nn), C.byref(cz), C.byref(nc),
+           C.byref(beg), C.byref(end), C.byref(ncand))
     dg = np.array([[dp[i].pos, dp[i].type, dp[i].len, dp[i].qi, dp[i].is_low_qual] for i in range(nd.value)], np.int64).reshape(-1, 5)
     noisy = np.array([nz[i] for i in range(3 * nn.value)], np.int64).reshape(-1, 3)
     cn = np.array([cz[i] for i in range(3 * nc.value)], np.int64).reshape(-1, 3)
@@ -409,6 +408,28 @@ def collect_digar_from_eqx_cigar(pos0, cigar, qual, reg_beg, reg_end, whole_ref_
         if p:
             _libc.free(C.cast(p, C.c_void_p))
     return dict(rc=rc, digars=dg, noisy=noisy, chunk_noisy=cn, beg=beg.value, end=end.value, n_cand=ncand.value)
+
+
+def collect_digar_from_eqx_cigar(pos0, cigar, qual, reg_beg, reg_end, whole_ref_len, opt=None, left_pal=0, right_pal=0):
+    """SURVEY 8(f) f2 oracle (oracle/digar.c): -> dict(rc, digars (n,5), noisy (m,3), chunk_noisy (k,3), beg, end, n_cand)"""
+    return _collect_digar("lcdo_collect_digar_from_eqx_cigar", (), (), pos0, cigar, qual, reg_beg, reg_end, whole_ref_len, opt, left_pal, right_pal, (u8p,), (None,))
+
+
+def collect_digar_from_cs_tag(pos0, cigar, cs, qual, reg_beg, reg_end, whole_ref_len, opt=None, left_pal=0, right_pal=0):
+    """oracle/digar_tags.c: collect_digar_from_cs_tag (src/bam_utils.c:844)"""
+    return _collect_digar("lcdo_collect_digar_from_cs_tag", (), (), pos0, cigar, qual, reg_beg, reg_end, whole_ref_len, opt, left_pal, right_pal, (C.c_char_p,), (bytes(cs),))
+
+
+def collect_digar_from_MD_tag(pos0, cigar, md, qual, reg_beg, reg_end, whole_ref_len, opt=None, left_pal=0, right_pal=0):
+    """oracle/digar_tags.c: collect_digar_from_MD_tag (src/bam_utils.c:1010)"""
+    return _collect_digar("lcdo_collect_digar_from_MD_tag", (), (), pos0, cigar, qual, reg_beg, reg_end, whole_ref_len, opt, left_pal, right_pal, (C.c_char_p,), (bytes(md),))
+
+
+def collect_digar_from_ref_seq(pos0, cigar, bseq, qual, ref_seq, ref_beg, ref_end, reg_beg, reg_end, whole_ref_len, opt=None, left_pal=0, right_pal=0):
+    """oracle/digar_tags.c: collect_digar_from_ref_seq (src/bam_utils.c:1179); bseq = BAM 4-bit packed bases"""
+    bs = _c8(bseq)
+    return _collect_digar("lcdo_collect_digar_from_ref_seq", (C.c_char_p, C.c_int64, C.c_int64), (bytes(ref_seq), int(ref_beg), int(ref_end)), pos0, cigar, qual,
+                          reg_beg, reg_end, whole_ref_len, opt, left_pal, right_pal, (u8p,), (_p(bs),))
 
 
 class Digar1(C.Structure):

@@ -207,3 +207,98 @@ def test_f2_edge_inputs(lcd, oracle):
     assert len(lcd.pre_process_noisy_regs(one, np.zeros((0, 2), np.int64), [], [], [])) == 0                       # no read spans it
     assert len(lcd.pre_process_noisy_regs(one, np.zeros((0, 2), np.int64), [1, 1], [2000, 2000], [one, one])) == 1   # two noisy reads: kept
     assert len(lcd.pre_process_noisy_regs(one, np.zeros((0, 2), np.int64), [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1], [2000] * 11, [one] + [np.zeros((0, 3), np.int64)] * 10)) == 0  # 1 of 11: below min_alt_dp
+
+
+# ---- the reference's three other digar sources (src/collect_var.c:1072-1079): cs tag, MD tag, reference bases ----
+def _tag_inputs(rng, n, n_skip, pads=(0, 50)):
+    import digar_inputs as di
+    al, qs, pal = [], [], []
+    for i in range(n):
+        a = di.build(rng, di.eqx_ops(rng, noisy=i % 3 == 0, n_skip=n_skip), int(rng.integers(0, 12)) if i % 13 == 0 else int(rng.integers(1000, 900000)),
+                     ref_pad=(int(rng.integers(*pads)), int(rng.integers(*pads))), lower=i % 2 == 0)
+        al.append(a); qs.append(di.quals(rng, a["qlen"])); pal.append(int(rng.integers(0, 4)) if i % 5 == 0 else 0)
+    return al, qs, np.array(pal, np.uint8)
+
+
+def test_cs_and_md_tags(lcd, oracle):
+    """lcd_digar_batch_tags vs oracle/digar_tags.c (collect_digar_from_cs_tag src/bam_utils.c:844, collect_digar_from_MD_tag :1010): short and long cs
+    forms, MD runs carried over insertions, clips next to the contig ends (where the cs function's own clip rule shows), palindromic clips, both window
+    sizes; malformed tags come back as -2"""
+    rng = np.random.default_rng(21)
+    al, qs, pal = _tag_inputs(rng, 200, n_skip=False)
+    pos0 = [a["pos0"] for a in al]
+    bad_cs = dict(al[3]); bad_cs["cs"] = al[3]["cs"][:40] + b"!" + al[3]["cs"][40:]
+    for is_ont in (0, 1):
+        opt = oracle.digar_opt(is_ont)
+        tlen = 1000000
+        for form, cig in (("cs", "eqx"), ("cs_long", "mcig")):
+            got = lcd.digar_batch(pos0, [a[cig] for a in al], qs, 200000, 700000, tlen, is_ont=is_ont, pal_flags=pal, cs=[a[form] for a in al])
+            for i, a in enumerate(al):
+                _same(oracle.collect_digar_from_cs_tag(a["pos0"], a[cig], a[form], qs[i], 200000, 700000, tlen, opt, pal[i] & 1, (pal[i] >> 1) & 1), got[i])
+        got = lcd.digar_batch(pos0, [a["mcig"] for a in al], qs, 200000, 700000, tlen, is_ont=is_ont, pal_flags=pal, md=[a["md"] for a in al])
+        n_win = 0
+        for i, a in enumerate(al):
+            _same(oracle.collect_digar_from_MD_tag(a["pos0"], a["mcig"], a["md"], qs[i], 200000, 700000, tlen, opt, pal[i] & 1, (pal[i] >> 1) & 1), got[i])
+            n_win += len(got[i]["noisy"])
+        assert n_win > 100
+    # reads with 'N' (MD only), and the error exits
+    al2, qs2, _ = _tag_inputs(rng, 40, n_skip=True)
+    got = lcd.digar_batch([a["pos0"] for a in al2], [a["mcig"] for a in al2], qs2, 1, 10 ** 6, 10 ** 7, md=[a["md"] for a in al2])
+    for i, a in enumerate(al2):
+        _same(oracle.collect_digar_from_MD_tag(a["pos0"], a["mcig"], a["md"], qs2[i], 1, 10 ** 6, 10 ** 7), got[i])
+    a = al[3]
+    got = lcd.digar_batch([a["pos0"]] * 3, [a["eqx"], a["mcig"], a["eqx"]], [qs[3]] * 3, 1, 10 ** 6, 10 ** 7, cs=[bad_cs["cs"], a["cs"], a["cs"]])
+    assert [g["rc"] for g in got] == [-2, got[1]["rc"], got[1]["rc"]] and got[1]["rc"] in (0, -1)
+    got = lcd.digar_batch([a["pos0"]] * 3, [a["mcig"], a["eqx"], a["mcig"]], [qs[3]] * 3, 1, 10 ** 6, 10 ** 7, md=[a["md"][:-3], a["md"], a["md"]])
+    assert got[0]["rc"] == -2 and got[1]["rc"] == -2 and got[2]["rc"] in (0, -1)     # a tag shorter than its CIGAR; '=' / 'X' next to an MD tag
+    for bad, g in ((a["md"][:-3], got[0]), ):
+        assert oracle.collect_digar_from_MD_tag(a["pos0"], a["mcig"], bad, qs[3], 1, 10 ** 6, 10 ** 7)["rc"] == -2
+
+
+def test_reference_comparison(lcd, oracle):
+    """lcd_digar_batch_ref (base comparison + CIGAR rewrite on the device, then the same digar kernel) vs collect_digar_from_ref_seq (src/bam_utils.c:1179):
+    'M' and '=' / 'X' CIGARs, lower-case reference, 'N' operations, reference windows that end inside the reads (bases stepped over, runs flushed late)"""
+    rng = np.random.default_rng(22)
+    for pads, n_skip in (((0, 50), False), ((-120, 30), True)):
+        al, qs, pal = _tag_inputs(rng, 150, n_skip=n_skip, pads=pads)
+        # lcd_digar_batch_ref takes ONE reference window per call (the chunk's): place every read in a common window by giving each call one read group
+        for is_ont in (0, 1):
+            opt = oracle.digar_opt(is_ont)
+            n_win = 0
+            for i, a in enumerate(al):
+                for cig in ("mcig", "eqx") if i % 4 == 0 else ("mcig",):
+                    got = lcd.digar_batch([a["pos0"]], [a[cig]], [qs[i]], 200000, 700000, 1000000, is_ont=is_ont, pal_flags=pal[i:i + 1], seqs=[a["bseq"]],
+                                          ref=(a["ref_seq"], a["ref_beg"], a["ref_end"]))[0]
+                    _same(oracle.collect_digar_from_ref_seq(a["pos0"], a[cig], a["bseq"], qs[i], a["ref_seq"], a["ref_beg"], a["ref_end"], 200000, 700000, 1000000, opt,
+                                                            pal[i] & 1, (pal[i] >> 1) & 1), got)
+                    n_win += len(got["noisy"])
+            assert n_win > 50
+
+
+def test_reference_comparison_real_chunk(lcd, oracle):
+    """the bundled HG002 chunk: its reads' CIGARs with '=' / 'X' folded into 'M', the 4-bit bases the fixture keeps (only the stretches inside noisy regions
+    are stored, the rest is 0 = 'N': tens of thousands of mismatching bases per read, i.e. a dense stress of the rewrite) against the chunk's reference
+    slice, ONE launch for all reads; every read against the oracle, and inside the stored stretches the fixture's own digars come back"""
+    ch = tc.Chunk()
+    cigs = [_cigar_of(d) for d in ch.digars]
+    mc = []
+    for c in cigs:
+        m = []
+        for w in c:
+            o = int(w) & 0xf; l = int(w) >> 4; o2 = 0 if o in (7, 8) else o
+            if m and o2 == 0 and (m[-1] & 0xf) == 0:
+                m[-1] += l << 4
+            else:
+                m.append((l << 4) | o2)
+        mc.append(np.array(m, np.uint32))
+    pos0 = [int(d[0][0]) - 1 for d in ch.digars]
+    o = int(ch.z["ref_beg"]); ref = bytes(b"ACGTN"[b] for b in ch.z["ref"]) if ch.z["ref"].dtype == np.uint8 and ch.z["ref"].max() < 8 else bytes(ch.z["ref"])
+    ref_end = o + len(ref) - 1
+    quals = [np.full(int(q), 40, np.uint8) for q in ch.qlen]
+    got = lcd.digar_batch(pos0, mc, quals, o + 20000, o + 180000, 135086622, seqs=ch.bseq, ref=(ref, o, ref_end))
+    n_dig = 0
+    for i in range(ch.n_reads):
+        exp = oracle.collect_digar_from_ref_seq(pos0[i], mc[i], ch.bseq[i], quals[i], ref, o, ref_end, o + 20000, o + 180000, 135086622)
+        _same(exp, got[i])
+        n_dig += len(got[i]["digars"])
+    assert n_dig > 100000
