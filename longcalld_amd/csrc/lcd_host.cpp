@@ -162,6 +162,7 @@ struct ChainRec {
     int mode;
     std::vector<int> members;     // indices into the region's sorted read list
     int read0;                    // first PoaRead
+    int cert_fail_round = -1;     // K2: the round in which the certified band did not fit the single-wavefront window (the chain then runs with full rows)
 };
 struct AnchorRec {
     int pread;                    // index into preads
@@ -656,6 +657,11 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     long long sum = 0; int maxl = 0;
     for (int k = 0; k < n; ++k) { const PoaRead &r = preads[C.read0 + k]; sum += r.len; maxl = std::max(maxl, r.len); }
     pc.n_reads = n; pc.read0 = C.read0; pc.mode = C.mode;
+    // K2 chains of clean reads run in the single-wavefront class with rows restricted to the CERTIFIED band (poa_kernel.hip align_certified: same
+    // alignments as the full rows, ~20x fewer cells on HiFi-shape regions); noisy reads' bounds are too loose for a 256-column window (LCD_CERT=2 forces
+    // them through it, 0 switches the path off).  A chain whose band outgrows the window comes back with LCD_ERR_CERT and is re-run with full rows.
+    const int cert_mode = getenv("LCD_CERT") ? atoi(getenv("LCD_CERT")) : 1; // (read per call: the tests switch it)
+    pc.cert = (C.mode == 1 && C.cert_fail_round < 0 && maxl < 65536 && (cert_mode == 2 || (cert_mode == 1 && !opt.is_ont))) ? 1 : 0; pc.pad_ = 0;
     // graph capacity: the worst case is one node per base of every read (sum), the usual case a little more than the longest read.  Sized
     // from an estimate (a few per cent of new nodes per read on top of the backbone; g_node_hint learns noisier data); a chain that runs
     // out (LCD_ERR_NODES / LCD_ERR_EDGES) is re-run with 4x more per retry, up to the worst case.  The worst case for everybody was
@@ -683,6 +689,7 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     const long long rows_est = std::min<long long>(rows_worst, (long long)(rows_f[hint] * maxl) + 64);
     long long band;
     if (C.mode == 0) band = std::min<long long>(maxl + 1, 2ll * (10 + maxl / 100) + 1 + band_x[hint]);
+    else if (pc.cert) band = std::min<long long>(maxl + 1, 260);
     else band = maxl + 1;
     long long cells = rows_est * band;
     // (tried: 3x the estimate up front for the long K1 chains of noisy reads, which overflow most -- 5 instead of 60 re-runs per 4 SV-shape batches, but
@@ -705,7 +712,7 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
 // afterwards.  Chains are launched in groups of equal (threads, LDS bucket) so that short chains do not pay a long chain's LDS.
 static void chain_class(PoaChain &pc, bool noisy) {
     // DP row width: K2 rows span the whole read (+2 guard columns of the window); K1 rows are the adaptive band plus drift
-    const long long width = pc.mode == 1 ? (long long)pc.max_len + 2 : 2ll * (10 + pc.max_len / 100) + 1 + 48;
+    const long long width = pc.cert ? 256 : pc.mode == 1 ? (long long)pc.max_len + 2 : 2ll * (10 + pc.max_len / 100) + 1 + 48;
     int threads, K, wmax; // wmax: window / ring-slot width in columns, a power of two <= 4 * threads (poa_kernel.hip align_windowed)
     // one lane per four columns of the window: 64 / 128 / 256 / 512 / 1024 threads, so that no wavefront of a workgroup idles
     // (a 2 048-column chain in a 1 024-thread workgroup would hold a whole CU's registers with half of its wavefronts parked)
@@ -1002,7 +1009,8 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                 PoaChain &pc = bs[k]->pchains[c];
                 if (round) {
                     const int old_cap = pc.node_cap;
-                    chain_caps(bs[k]->opt, bs[k]->chains[c], preads[k], scale, pc);
+                    const ChainRec &CR = bs[k]->chains[c];   // (a chain sent back by the certified band starts its capacity ladder in the round after)
+                    chain_caps(bs[k]->opt, CR, preads[k], CR.cert_fail_round < 0 ? scale : std::max(1, scale >> (CR.cert_fail_round + 1)), pc);
                     if (pc.node_cap > old_cap) { // the chain's output block (cons + MSA rows of node_cap columns) grows with it: a fresh block
                         lcd_batch_t *b = bs[k];
                         b->retry_out.emplace_back(new DevBuf());
@@ -1010,7 +1018,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                         pc.out_off = b->retry_out.back()->addr(); retry_out_off[which[i]] = pc.out_off;
                     } else pc.out_off = retry_out_off.count(which[i]) ? retry_out_off[which[i]] : bs[k]->d_poa_out.addr() + out_rel[k][c];
                 }
-                need[i] = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads, pc.spill_x).total;
+                need[i] = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads, pc.spill_x, pc.cert).total;
             }
             // Work arenas.  A chain's arena is live only while its workgroup is resident, and a CU holds at most per_cu workgroups of a launch group:
             // runs of chains of one launch group and one size class (half octaves of the arena size) that outnumber the chip's capacity share a pool of
@@ -1100,14 +1108,16 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             HIPCHK(hipMemcpyAsync(tmp.data(), L->d_poa_outs.p, sub.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             { float kms = 0; hipEventElapsedTime(&kms, L->ev[6], L->ev[7]); for (int k = 0; k < nb; ++k) { bs[k]->st.ms_poa_kernel += kms; bs[k]->st.n_poa_launches++; } }
-            std::vector<size_t> again; size_t n_node_ovf = 0;
+            std::vector<size_t> again; size_t n_node_ovf = 0, n_cert_fail = 0;
             for (size_t i = 0; i < which.size(); ++i) {
                 const int k = chain_batch[which[i]];
                 bs[k]->couts[which[i] - chain_base[k]] = tmp[i];
                 if (tmp[i].status == LCD_ERR_CELLS || tmp[i].status == LCD_ERR_NODES || tmp[i].status == LCD_ERR_EDGES) { again.push_back(which[i]); n_node_ovf += tmp[i].status != LCD_ERR_CELLS; }
+                else if (tmp[i].status == LCD_ERR_CERT && bs[k]->chains[which[i] - chain_base[k]].cert_fail_round < 0) { bs[k]->chains[which[i] - chain_base[k]].cert_fail_round = round; again.push_back(which[i]); ++n_cert_fail; }
                 else if (tmp[i].status != LCD_OK) return set_err(-20, "POA kernel status " + std::to_string(tmp[i].status) + " on chain " + std::to_string(which[i] - chain_base[k]));
             }
             if (getenv("LCD_MEM_DEBUG")) {
+                { size_t nc = 0; for (size_t g : which) nc += PC(g).cert != 0; fprintf(stderr, "[mem] round %d: %zu chains with a certified band, %zu sent back for full rows\n", round, nc, n_cert_fail); }
                 int c[2][3] = {{0, 0, 0}, {0, 0, 0}};
                 for (size_t g : again) { const PoaChainOut &o = bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]]; c[PC(g).mode ? 1 : 0][o.status == LCD_ERR_CELLS ? 0 : o.status == LCD_ERR_NODES ? 1 : 2]++; }
                 { std::map<int, std::pair<int, int>> byc; for (size_t g : which) if (PC(g).mode) byc[chain_threads(PC(g))].second++; for (size_t g : again) if (PC(g).mode) byc[chain_threads(PC(g))].first++;
@@ -1119,7 +1129,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             if (round == 0) { // learn: more than 1 % of a mode's chains overflowed their DP region -> start from the next estimate next time
                 int tot[2] = {0, 0}, ovf[2] = {0, 0};
                 for (size_t g = 0; g < nC_all; ++g) tot[PC(g).mode ? 1 : 0]++;
-                for (size_t g : again) ovf[PC(g).mode ? 1 : 0]++;
+                for (size_t g : again) if (bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]].status != LCD_ERR_CERT) ovf[PC(g).mode ? 1 : 0]++;
                 for (int m = 0; m < 2; ++m) if (tot[m] && ovf[m] * 100 > tot[m] && g_cell_hint[m].load() < 2) g_cell_hint[m]++;
             }
             if (!again.empty()) { for (int k = 0; k < nb; ++k) bs[k]->st.poa_retries++; scale *= 2; }
@@ -2311,7 +2321,7 @@ int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int
             if (!round) pc.out_off = d_out.addr() + out_rel[which[i]];
             else {
                 const int old_cap = pc.node_cap; const uint64_t keep = pc.out_off;
-                chain_caps(*opt, crec[which[i]], preads, scale, pc);
+                chain_caps(*opt, crec[which[i]], preads, crec[which[i]].cert_fail_round < 0 ? scale : std::max(1, scale >> (crec[which[i]].cert_fail_round + 1)), pc);
                 pc.out_off = keep;
                 if (pc.node_cap > old_cap) { // larger graph capacity -> larger output block
                     retry_out.emplace_back(new DevBuf());
@@ -2319,7 +2329,7 @@ int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int
                     pc.out_off = retry_out.back()->addr();
                 }
             }
-            PoaLayout L = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads, pc.spill_x);
+            PoaLayout L = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads, pc.spill_x, pc.cert);
             pc.ws_off = tot; tot += L.total;
         }
         if (d_arena.ensure(tot)) return -11;
@@ -2329,7 +2339,11 @@ int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int
         HIPCHK(hipMemcpyAsync(tmp.data(), d_outs.p, sub.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         std::vector<int> again;
-        for (size_t i = 0; i < which.size(); ++i) { couts[which[i]] = tmp[i]; if (tmp[i].status == LCD_ERR_CELLS || tmp[i].status == LCD_ERR_NODES || tmp[i].status == LCD_ERR_EDGES) again.push_back(which[i]); }
+        for (size_t i = 0; i < which.size(); ++i) {
+            couts[which[i]] = tmp[i];
+            if (tmp[i].status == LCD_ERR_CELLS || tmp[i].status == LCD_ERR_NODES || tmp[i].status == LCD_ERR_EDGES) again.push_back(which[i]);
+            else if (tmp[i].status == LCD_ERR_CERT && crec[which[i]].cert_fail_round < 0) { crec[which[i]].cert_fail_round = round; again.push_back(which[i]); }
+        }
         if (!again.empty()) scale *= 2;
         which.swap(again);
     }

@@ -31,7 +31,8 @@ struct LcdScoring {
 };
 
 // status codes written by kernels (0 = ok). Anything else makes the host fail loudly or retry with a bigger arena.
-enum { LCD_OK = 0, LCD_ERR_CELLS = 1, LCD_ERR_NODES = 2, LCD_ERR_EDGES = 3, LCD_ERR_BACKTRACK = 4, LCD_ERR_WF = 5, LCD_ERR_TOPO = 6, LCD_ERR_SYNC = 7, LCD_ERR_LDS = 8, LCD_FALLBACK = 100 /* internal: take the generic rows */ };
+enum { LCD_OK = 0, LCD_ERR_CELLS = 1, LCD_ERR_NODES = 2, LCD_ERR_EDGES = 3, LCD_ERR_BACKTRACK = 4, LCD_ERR_WF = 5, LCD_ERR_TOPO = 6, LCD_ERR_SYNC = 7, LCD_ERR_LDS = 8,
+       LCD_ERR_CERT = 9 /* a K2 chain's certified band did not fit the single-wavefront window: the host re-runs the chain with full rows */, LCD_FALLBACK = 100 /* internal: take the generic rows */ };
 
 // ---------------- POA chain (one graph build = one abpoa_t life, src/align.c:762 / :872) ----------------
 struct PoaRead {
@@ -63,6 +64,7 @@ struct PoaChain {
     uint64_t slot_bytes;
     uint64_t cu_rank;     // device address of int[4096]: raw (XCC, SE, SH, CU) id -> compact CU index, -1 unknown; 0: none
     int n_slots, per_cu;
+    int cert, pad_;       // cert 1: K2 chain in the single-wavefront class, rows restricted to the certified band (poa_kernel.hip align_certified)
 };
 
 struct PoaChainOut {
@@ -94,13 +96,14 @@ struct PoaLayout {
     uint64_t het, clu, nclu, prof;                       // int32[node_cap], int32[n_reads] x2, uint8[2*node_cap]
     uint64_t aa_node, aa_flag, aa_eid;                   // int32[max_len+2] x3: per-cigar-entry scratch of the parallel graph update
     uint64_t tb;                                         // int32[4*node_cap]: column-tile boundaries of the unbanded rows (poa_kernel.hip align_unbanded)
+    uint64_t cert;                                       // int32[7*node_cap]: path-length ranges / bonus sums per node and the rows' certified column intervals (cert chains only)
     uint64_t pl_start, pl_pidx, pl_bonus, pl_rem, pl_base; // row plan: int32[node_cap+4], int32[edge_cap] x2, int32[node_cap], u8[node_cap]
     uint64_t total;
 };
 
 static inline LCD_HD uint64_t lcd_align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
-static inline LCD_HD PoaLayout poa_layout(int node_cap, int edge_cap, int rid_words, int max_len, uint64_t cell_cap, int n_reads, int spill_x = 2) {
+static inline LCD_HD PoaLayout poa_layout(int node_cap, int edge_cap, int rid_words, int max_len, uint64_t cell_cap, int n_reads, int spill_x = 2, int cert = 0) {
     PoaLayout L;
     uint64_t o = 0;
 #define LCD_TAKE(field, bytes) do { L.field = o; o = lcd_align_up(o + (uint64_t)(bytes), 16); } while (0)
@@ -123,7 +126,8 @@ static inline LCD_HD PoaLayout poa_layout(int node_cap, int edge_cap, int rid_wo
     LCD_TAKE(pl_start, (uint64_t)(node_cap + 4) * 4); LCD_TAKE(pl_pidx, (uint64_t)edge_cap * 4); LCD_TAKE(pl_bonus, (uint64_t)edge_cap * 4);
     LCD_TAKE(pl_rem, (uint64_t)node_cap * 4); LCD_TAKE(pl_base, (uint64_t)node_cap);
     LCD_TAKE(aa_node, (uint64_t)(max_len + 2) * 4); LCD_TAKE(aa_flag, (uint64_t)(max_len + 2) * 4); LCD_TAKE(aa_eid, (uint64_t)(max_len + 2) * 4);
-    LCD_TAKE(tb, max_len + 2 > 4096 ? (uint64_t)node_cap * 16 : 16); // (only reads longer than one 4 096-column tile use it)
+    LCD_TAKE(tb, max_len + 2 > 4096 && !cert ? (uint64_t)node_cap * 16 : 16); // (only reads longer than one 4 096-column tile use it)
+    LCD_TAKE(cert, cert ? (uint64_t)node_cap * 28 : 16);
 #undef LCD_TAKE
     L.total = lcd_align_up(o, 256);
     return L;

@@ -74,6 +74,7 @@ struct Ctx {
     int *pl_start, *pl_pidx, *pl_bonus, *pl_rem; uint8_t *pl_base;
     int *aa_node, *aa_flag, *aa_eid;
     int *tb;                          // column-tile boundaries of the unbanded rows: 4 x node_cap ints (H of the last column, by tile parity; F carries)
+    int *cert; int cert_on, cert_hist; // certified band of a K2 chain (align_certified): 7 x node_cap ints; largest bound-to-score slack of the chain's reads so far
     int wmax, seq_cap, pool_words, spill_x;
     int n_node, n_edge, node_cap, edge_cap, rid_words;
     unsigned long long cell_cap;
@@ -733,7 +734,7 @@ __device__ void ctx_to_sgpr(Ctx &g) {
     g.rbeg = usgpr(g.rbeg); g.rend = usgpr(g.rend); g.roff = usgpr(g.roff); g.ooff = usgpr(g.ooff); g.spoff = usgpr(g.spoff);
     g.ml = usgpr(g.ml); g.mr = usgpr(g.mr); g.idx2node = usgpr(g.idx2node);
     g.cig_node0 = usgpr(g.cig_node0); g.cig_qpos0 = usgpr(g.cig_qpos0); g.imap = usgpr(g.imap);
-    g.tb = usgpr(g.tb);
+    g.tb = usgpr(g.tb); g.cert = usgpr(g.cert); g.node_cap = usgpr(g.node_cap);
     g.pl_start = usgpr(g.pl_start); g.pl_pidx = usgpr(g.pl_pidx); g.pl_bonus = usgpr(g.pl_bonus); g.pl_rem = usgpr(g.pl_rem); g.pl_base = usgpr(g.pl_base);
     g.wmax = usgpr(g.wmax); g.cell_cap = usgpr(g.cell_cap); g.status = usgpr(g.status); g.spill_x = usgpr(g.spill_x);
 }
@@ -819,10 +820,10 @@ __device__ __forceinline__ void code_backtrack(const Ctx &g, Smem &sm, const uns
             for (int u = lane; u < j; u += 64) { g.cig_node0[pos - j + u] = -1; g.cig_qpos0[pos - j + u] = u; }
             pos -= j;
         }
-        if (lane == 0) { sm.bc[0] = qlen - pos; sm.bc[1] = status; sm.bc[4] = pos; }
+        if (lane == 0) { sm.bc[0] = qlen - pos; sm.bc[1] = status; sm.bc[4] = pos; sm.bc[5] = best; }
     }
 
-struct WinOut { int status; unsigned long long t_dp, t_bt, cells; int cig_pos; unsigned long long t_plan, t_poll; };
+struct WinOut { int status; unsigned long long t_dp, t_bt, cells; int cig_pos; unsigned long long t_plan, t_poll; int score; };
 // (not inlined, context by value: the row loop then only carries the dozen pointers it uses instead of the chain's whole
 //  context -- inlined, hipcc spilled the scalar registers of ~45 pointers into VGPR lanes and re-read them every row)
 // C consecutive ints from / to LDS (byte offset) or HBM: one ds_read_b128 / b64 / b32 (global_load_dwordx4 / x2 / dword)
@@ -851,12 +852,15 @@ template <int C> __device__ __forceinline__ void glb_stc(int *p, const int (&v)[
 // C = cells per lane = WIN / NT.  C = 4 is the general shape; the single-wavefront class also has C = 2 and C = 1 for narrow bands
 // (a 40-column HiFi band uses 10 of 64 lanes at four cells per lane, and every lane pays the cell code four times: fewer cells per
 // lane means proportionally fewer instructions per row for the same band).
-template <int NT, bool BANDED, int C>
+// MODE 0: rows span the whole window (w = qlen); 1: the oracle's adaptive band; 2: the rows' column intervals come from a table (g.cert hull, see
+// align_certified: cells outside an interval count as unreachable, exactly like cells outside an adaptive band)
+template <int NT, int MODE, int C>
 __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const unsigned ring_, const unsigned sq1_, const unsigned pd_ /* 0xffffffff: none */, const LcdScoring sc_, const int w_,
                               const int bi_, const int ei_, const int rem_beg_, const uint8_t *seq_hbm_, const int qlen_,
                               WinOut *wo_) {
     constexpr int NW = NT / 64, K = Cfg<NT>::K;
     constexpr int WIN = NT * C, WM = WIN - 1, SLOTW = 3 * WIN, CM = ~(C - 1);
+    constexpr bool BANDED = MODE == 1, FIXED = MODE == 2, BND = MODE != 0;
     Smem &sm = g_smem;
     Ctx g = *usgpr(gp_); // (by pointer: a by-value context is 440 B of outgoing-argument stack per call site and per lane)
     ctx_to_sgpr(g);
@@ -867,7 +871,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
     const int tid = threadIdx.x, lane = tid & 63, wave = usgpr(tid >> 6); // (wave in an SGPR: branches on it are scalar)
     const int o1 = sc.o1, e1 = sc.e1, o2 = sc.o2, e2 = sc.e2, oe1 = o1 + e1, oe2 = o2 + e2;
     const int QB = (qlen + 12 + 15) & ~15;
-    if constexpr (NT == 64 && BANDED) {
+    if constexpr (NT == 64 && BND) {
         // the pool of a single-wavefront chain is laid out for the window the host expects (PoaChain.wmax columns per ring slot); a wider
         // window moves the query cache up and gives up the first-predecessor distances -- or, if the pool is too small for that, leaves
         // the read to the next wider window / the generic rows
@@ -883,6 +887,8 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
     const long long spill_rows = g.cell_cap * g.spill_x > 64 ? (long long)((g.cell_cap * g.spill_x - 64) / ((unsigned long long)SLOTW * 4)) : 0;
     // ---- source row (slot 0, window at column 0) ----
     int end0 = qlen - rem_beg; if (end0 < 0) end0 = 0; end0 += w; if (end0 > qlen) end0 = qlen;
+    const int *const hull = g.cert + 6 * (size_t)g.node_cap;
+    if (FIXED) { const int hw = glb_ld(hull + bi); end0 = hw >> 16; if ((hw & 65535) != 0) return -1; } // (the source row's interval starts at column 0)
     if (end0 + 2 > WIN) return -1;
     int nsp = 0;
     {
@@ -910,7 +916,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
     __syncthreads();
     const long long t_dp0 = clock64();
     int wbase = -(1 << 20);
-    int w_p0 = 0, w_np = 0, w_rem = 1 << 30, w_vb = 4, w_pi0 = 0, w_b0 = 0, w_pi1 = 0, w_b1 = 0, w_sp = 0;
+    int w_p0 = 0, w_np = 0, w_rem = 1 << 30, w_vb = 4, w_pi0 = 0, w_b0 = 0, w_pi1 = 0, w_b1 = 0, w_sp = 0, w_hull = 1;
     for (int idx = bi + 1; idx < ei; ++idx) {
         if (idx - wbase >= 64) { // plan window: each lane loads the plan of one upcoming row; rows then take it by v_readlane
             wbase = idx;
@@ -919,6 +925,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
             if (ri < ei) {
                 const int s0 = glb_ld(g.pl_start + ri), s1 = glb_ld(g.pl_start + ri + 1);
                 w_p0 = s0; w_np = s1 - s0; w_rem = glb_ld(g.pl_rem + ri); w_vb = glb_ld_u8(g.pl_base + ri); w_sp = glb_ld_u8(g.imap + ri) & 2;
+                if (FIXED) { w_hull = glb_ld(hull + ri); LCD_PIN(w_hull); }
                 if (w_np > 0) { w_pi0 = glb_ld(g.pl_pidx + s0); w_b0 = glb_ld(g.pl_bonus + s0); }
                 if (w_np > 1) { w_pi1 = glb_ld(g.pl_pidx + s0 + 1); w_b1 = glb_ld(g.pl_bonus + s0 + 1); }
             }
@@ -939,7 +946,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
         }
         bool synced = false;
         int beg = 0, end = qlen;
-        const bool fast1 = BANDED && np == 1 && idx - pi0 <= K;
+        const bool fast1 = BND && np == 1 && idx - pi0 <= K;
         const int f_sp = (pi0 - bi) & (K - 1);
         int f_pb = 1, f_pe = 0;
         if (fast1) { f_pb = LCD_RL(m_beg, f_sp); f_pe = LCD_RL(m_end, f_sp); }
@@ -967,6 +974,16 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
             if (beg < minpb) beg = minpb;
             if (end > maxpe + 1) end = maxpe + 1;
             if (beg > end) { // empty row
+                if (lane == s) { m_beg = 1; m_end = 0; }
+                if (tid == 0) { glb_st(g.rbeg + idx, 1); glb_st(g.rend + idx, 0); }
+                continue;
+            }
+            if (end - (beg & CM) + 2 > WIN) return -1;
+        }
+        if (FIXED) { // the row's certified interval (lo | hi << 16; lo > hi: no cell of the row can lie on an optimal path)
+            const int hw = LCD_RL(w_hull, wk);
+            beg = hw & 65535; end = hw >> 16;
+            if (beg > end) {
                 if (lane == s) { m_beg = 1; m_end = 0; }
                 if (tid == 0) { glb_st(g.rbeg + idx, 1); glb_st(g.rend + idx, 0); }
                 continue;
@@ -1008,7 +1025,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
             if (t > 1) { pi = glb_ld(g.pl_pidx + p0 + t); bz = glb_ld(g.pl_bonus + p0 + t); LCD_PIN(pi); LCD_PIN(bz); }
             const bool near = idx - pi <= K;
             const int sp = (pi - bi) & (K - 1);
-            if (BANDED) {
+            if (BND) {
                 int pb, pe;
                 if (near) { pb = LCD_RL(m_beg, sp); pe = LCD_RL(m_end, sp); } else { pb = g.rbeg[pi]; pe = g.rend[pi]; LCD_PIN(pb); LCD_PIN(pe); }
                 if (pb > pe) continue;
@@ -1069,7 +1086,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
             const int f1 = imax(LCD_NEG, pf1 - o1 - je1 - k * e1), f2 = imax(LCD_NEG, pf2 - o2 - je2 - k * e2);
             const int h = imax(hp[k], imax(f1, f2));
             int eo1 = imax(h - oe1, uu[k] - e1), eo2 = imax(h - oe2, vv[k] - e2);
-            if (BANDED) { eo1 = imax(eo1, LCD_NEG); eo2 = imax(eo2, LCD_NEG); }
+            if (BND) { eo1 = imax(eo1, LCD_NEG); eo2 = imax(eo2, LCD_NEG); }
             const int fk = f1 == h ? (f2 == h ? 5 : 3) : 4;
             const int hs = hp[k] == h ? spk[k] : fk;
             unsigned fl = 0; // O2, O1, Y2, Y1 pushed in this order = bits 6, 5, 4, 3 of the code
@@ -1147,6 +1164,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
     const int n_cig = sm.bc[0];
     wo->status = sm.bc[1];
     wo->cig_pos = sm.bc[4];
+    wo->score = sm.bc[5];
     __syncthreads();
     wo->t_bt = (unsigned long long)(clock64() - t_bt0);
     return n_cig;
@@ -1433,6 +1451,206 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
     return n_cig;
 }
 
+// ================= certified band for the unbanded K2 alignments (single-wavefront class) =================
+// The oracle's K2 rows span the whole read (wb = -1).  Its backtrack, though, only ever visits cells that lie on an OPTIMAL alignment path, and it takes
+// the same decisions there in any DP that (a) contains every cell of every optimal path and (b) treats the cells it leaves out as unreachable: a value
+// on an optimal path is reached through predecessors on optimal paths, a candidate that loses a comparison in the full DP can only lose by more when it
+// is under-estimated, and a candidate that ties is on an optimal path itself (DESIGN.md "Certified band" has the argument incl. the insertion-run flags).
+// A cell (v, j) is provably on NO optimal path if an upper bound on every alignment through it is below the score S of some alignment:
+//   UB(v, j) = Bp(v) + Bs(v) + max(o1, o2)
+//            + M * min(j, maxD(v)) - G(j - maxD(v)) - G(minD(v) - j)                      (prefix: j bases against a source..v path of minD..maxD nodes)
+//            + M * min(r, maxR(v)) - G(r - maxR(v)) - G(minR(v) - r),   r = qlen - j       (suffix)
+// with M the match score, G(k) = min(o1 + e1 k, o2 + e2 k) for k > 0 (the cheapest way to pay k forced gap columns; G is concave, so splitting them costs
+// more -- except for ONE run cut in two by the cell itself, hence the max(o1, o2)), Bp / Bs the largest sums of edge bonuses (ilog2 of the weight,
+// inc_path_score) over source..v / v..sink paths.  The rows' intervals [lo, hi] = hull{j : UB(v, j) >= S_est} are computed BEFORE the DP from a guess
+// S_est (the bound at the end cell minus the largest slack the chain's earlier reads needed, plus a margin); the DP over the intervals returns S.  If
+// S >= S_est the guess was a true lower bound of the optimum and the alignment is the oracle's; otherwise S itself is one and the read is redone with
+// S_est = S, which cannot fail.  oracle/poa.c carries the same bound as a checker (LCDO_CERT_STATS; tests/test_oracle_poa.py).
+// Node arrays by topological index in g.cert: minD | maxD | Bp | minR | maxR | Bs | hull (lo | hi << 16).
+constexpr int CERT_INF = 1 << 29;
+__device__ __forceinline__ int wlane(const int val, const int l, int old) { // old with lane l replaced by val (both wave-uniform)
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(l) : "m0"); // (gfx9: one SGPR per VALU instruction; the lane select goes through M0)
+    return old;
+}
+__device__ __forceinline__ int cert_G(const int k, const int o1, const int e1, const int o2, const int e2) { return k <= 0 ? 0 : imin(o1 + e1 * k, o2 + e2 * k); }
+// forward / backward passes over the rows.  One wavefront; the rows are walked one by one with the values of the current and the previous 64-row block in
+// registers (lane = row - block base), so a predecessor / successor within 64..127 rows costs a v_readlane / v_writelane and only far ones go to HBM
+__device__ __attribute__((noinline)) void cert_node_arrays(const Ctx *gp_, const int bi_, const int ei_) {
+    Ctx g = *usgpr(gp_); ctx_to_sgpr(g);
+    const int bi = usgpr(bi_), ei = usgpr(ei_);
+    const int lane = threadIdx.x & 63;
+    const size_t cap = (size_t)g.node_cap;
+    int *const dmin = g.cert, *const dmax = g.cert + cap, *const bp = g.cert + 2 * cap, *const rmin = g.cert + 3 * cap, *const rmax = g.cert + 4 * cap, *const bs = g.cert + 5 * cap;
+    // ---- source side ----
+    int prev_mn = CERT_INF, prev_mx = -1, prev_b = LCD_NEG;
+    for (int base = bi; base < ei; base += 64) {
+        const int ri = base + lane;
+        int w_np = 0, w_p0 = 0, w_pi0 = 0, w_b0 = 0, w_pi1 = 0, w_b1 = 0;
+        if (ri < ei) {
+            const int s0 = glb_ld(g.pl_start + ri), s1 = glb_ld(g.pl_start + ri + 1);
+            w_p0 = s0; w_np = s1 - s0;
+            if (w_np > 0) { w_pi0 = glb_ld(g.pl_pidx + s0); w_b0 = glb_ld(g.pl_bonus + s0); }
+            if (w_np > 1) { w_pi1 = glb_ld(g.pl_pidx + s0 + 1); w_b1 = glb_ld(g.pl_bonus + s0 + 1); }
+        }
+        LCD_PIN(w_np); LCD_PIN(w_p0); LCD_PIN(w_pi0); LCD_PIN(w_b0); LCD_PIN(w_pi1); LCD_PIN(w_b1);
+        int cur_mn = CERT_INF, cur_mx = -1, cur_b = LCD_NEG;
+        const int nrow = imin(64, ei - base);
+        for (int k = 0; k < nrow; ++k) {
+            int mn = CERT_INF, mx = -1, bb = LCD_NEG;
+            if (base + k == bi) { mn = 0; mx = 0; bb = 0; }
+            else {
+                const int np = LCD_RL(w_np, k);
+                int p0 = 0;
+                if (np > 2) p0 = LCD_RL(w_p0, k);
+                for (int t = 0; t < np; ++t) {
+                    int pi = t == 0 ? LCD_RL(w_pi0, k) : LCD_RL(w_pi1, k), bz = t == 0 ? LCD_RL(w_b0, k) : LCD_RL(w_b1, k);
+                    if (t > 1) { pi = usgpr(glb_ld(g.pl_pidx + p0 + t)); bz = usgpr(glb_ld(g.pl_bonus + p0 + t)); }
+                    int pm, px, pb;
+                    if (pi >= base) { pm = LCD_RL(cur_mn, pi - base); px = LCD_RL(cur_mx, pi - base); pb = LCD_RL(cur_b, pi - base); }
+                    else if (pi >= base - 64) { pm = LCD_RL(prev_mn, pi - base + 64); px = LCD_RL(prev_mx, pi - base + 64); pb = LCD_RL(prev_b, pi - base + 64); }
+                    else { pm = usgpr(glb_ld(dmin + pi)); px = usgpr(glb_ld(dmax + pi)); pb = usgpr(glb_ld(bp + pi)); }
+                    if (px >= 0) { mn = imin(mn, pm + 1); mx = imax(mx, px + 1); bb = imax(bb, pb + bz); }
+                }
+            }
+            cur_mn = wlane(mn, k, cur_mn); cur_mx = wlane(mx, k, cur_mx); cur_b = wlane(bb, k, cur_b);
+        }
+        if (ri < ei) { glb_st(dmin + ri, cur_mn); glb_st(dmax + ri, cur_mx); glb_st(bp + ri, cur_b); }
+        prev_mn = cur_mn; prev_mx = cur_mx; prev_b = cur_b;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // a far successor reads these back
+    }
+    // ---- sink side: every row pushes (minR + 1, maxR + 1, Bs + bonus) to its predecessors, rows in descending order; the sink itself counts no node ----
+    for (int i = bi + lane; i < ei; i += 64) { glb_st(rmin + i, CERT_INF); glb_st(rmax + i, -1); glb_st(bs + i, LCD_NEG); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int top = bi + ((ei - 1 - bi) >> 6 << 6);
+    int cur_mn = CERT_INF, cur_mx = -1, cur_b = LCD_NEG, nxt_mn = CERT_INF, nxt_mx = -1, nxt_b = LCD_NEG; // accumulators of the block's rows / of the block below
+    int base = top;
+    auto push = [&](const int pi, const int cm, const int cx, const int cb) {
+        if (pi >= base) {
+            const int l = pi - base;
+            cur_mn = wlane(imin(LCD_RL(cur_mn, l), cm), l, cur_mn); cur_mx = wlane(imax(LCD_RL(cur_mx, l), cx), l, cur_mx);
+            cur_b = wlane(imax(LCD_RL(cur_b, l), cb), l, cur_b);
+        } else if (pi >= base - 64) {
+            const int l = pi - base + 64;
+            nxt_mn = wlane(imin(LCD_RL(nxt_mn, l), cm), l, nxt_mn); nxt_mx = wlane(imax(LCD_RL(nxt_mx, l), cx), l, nxt_mx);
+            nxt_b = wlane(imax(LCD_RL(nxt_b, l), cb), l, nxt_b);
+        } else { // far predecessor: read-modify-write in HBM (one wavefront, program order; drained before anything reads it back)
+            const int om = usgpr(glb_ld(rmin + pi)), ox = usgpr(glb_ld(rmax + pi)), ob = usgpr(glb_ld(bs + pi));
+            if (lane == 0) { glb_st(rmin + pi, imin(om, cm)); glb_st(rmax + pi, imax(ox, cx)); glb_st(bs + pi, imax(ob, cb)); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    { // the sink's predecessors: nothing left to align after them
+        const int p0 = usgpr(glb_ld(g.pl_start + ei)), np = usgpr(glb_ld(g.pl_start + ei + 1)) - p0;
+        for (int t = 0; t < np; ++t) { const int pi = usgpr(glb_ld(g.pl_pidx + p0 + t)), bz = usgpr(glb_ld(g.pl_bonus + p0 + t)); push(pi, 0, 0, bz); }
+    }
+    for (; base >= bi; base -= 64) {
+        const int ri = base + lane;
+        int w_np = 0, w_p0 = 0, w_pi0 = 0, w_b0 = 0, w_pi1 = 0, w_b1 = 0;
+        if (ri < ei) {
+            const int s0 = glb_ld(g.pl_start + ri), s1 = glb_ld(g.pl_start + ri + 1);
+            w_p0 = s0; w_np = s1 - s0;
+            if (w_np > 0) { w_pi0 = glb_ld(g.pl_pidx + s0); w_b0 = glb_ld(g.pl_bonus + s0); }
+            if (w_np > 1) { w_pi1 = glb_ld(g.pl_pidx + s0 + 1); w_b1 = glb_ld(g.pl_bonus + s0 + 1); }
+            // far pushes that went through HBM
+            cur_mn = imin(cur_mn, glb_ld(rmin + ri)); cur_mx = imax(cur_mx, glb_ld(rmax + ri)); cur_b = imax(cur_b, glb_ld(bs + ri));
+        }
+        LCD_PIN(w_np); LCD_PIN(w_p0); LCD_PIN(w_pi0); LCD_PIN(w_b0); LCD_PIN(w_pi1); LCD_PIN(w_b1); LCD_PIN(cur_mn); LCD_PIN(cur_mx); LCD_PIN(cur_b);
+        const int nrow = imin(64, ei - base);
+        for (int k = nrow - 1; k >= 0; --k) {
+            const int mx = LCD_RL(cur_mx, k);
+            if (mx < 0 || base + k == bi) continue; // the sink cannot be reached from this row / the source has no predecessor
+            const int mn = LCD_RL(cur_mn, k), bb = LCD_RL(cur_b, k);
+            const int np = LCD_RL(w_np, k);
+            int p0 = 0;
+            if (np > 2) p0 = LCD_RL(w_p0, k);
+            for (int t = 0; t < np; ++t) {
+                int pi = t == 0 ? LCD_RL(w_pi0, k) : LCD_RL(w_pi1, k), bz = t == 0 ? LCD_RL(w_b0, k) : LCD_RL(w_b1, k);
+                if (t > 1) { pi = usgpr(glb_ld(g.pl_pidx + p0 + t)); bz = usgpr(glb_ld(g.pl_bonus + p0 + t)); }
+                push(pi, mn + 1, mx + 1, bb + bz);
+            }
+        }
+        if (ri < ei) { glb_st(rmin + ri, cur_mn); glb_st(rmax + ri, cur_mx); glb_st(bs + ri, cur_b); }
+        cur_mn = nxt_mn; cur_mx = nxt_mx; cur_b = nxt_b; nxt_mn = CERT_INF; nxt_mx = -1; nxt_b = LCD_NEG;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+// the bound at the end cell: the best any alignment of the whole read can score (the guess S_est is taken below it)
+__device__ int cert_ubtop(const Ctx &g, const int ei, const int qlen, const LcdScoring &sc) {
+    const size_t cap = (size_t)g.node_cap;
+    const int *dmin = g.cert, *dmax = g.cert + cap, *bp = g.cert + 2 * cap;
+    const int p0 = g.pl_start[ei], np = g.pl_start[ei + 1] - p0;
+    int ub = LCD_NEG;
+    for (int t = 0; t < np; ++t) {
+        const int pi = g.pl_pidx[p0 + t], mx = dmax[pi], mn = dmin[pi];
+        if (mx < 0) continue;
+        ub = imax(ub, bp[pi] + g.pl_bonus[p0 + t] + sc.match * imin(qlen, mx) - cert_G(qlen - mx, sc.o1, sc.e1, sc.o2, sc.e2) - cert_G(mn - qlen, sc.o1, sc.e1, sc.o2, sc.e2));
+    }
+    return ub;
+}
+// rows' intervals for the score bound `sest`, lane = row.  On every segment between two consecutive breakpoints {minD, maxD, qlen - maxR, qlen - minR} the
+// bound is a linear function minus concave functions of linear functions, i.e. CONVEX: its super-level set on a segment is a prefix and / or a suffix of
+// it, so the hull's ends are found by one bisection each, on the first / last segment that has an end point at or above the bound.
+// Returns the widest window a row needs (columns from lo rounded down to the lane's 4-cell group to hi, + 2), or -1 when the source row has no interval
+// starting at column 0 (the guess was above the optimum).
+__device__ __attribute__((noinline)) int cert_hull(const Ctx *gp_, const int bi_, const int ei_, const int qlen_, const int sest_, const LcdScoring sc_) {
+    Ctx g = *usgpr(gp_); ctx_to_sgpr(g);
+    const int bi = usgpr(bi_), ei = usgpr(ei_), qlen = usgpr(qlen_), sest = usgpr(sest_);
+    const int M = usgpr(sc_.match), o1 = usgpr(sc_.o1), e1 = usgpr(sc_.e1), o2 = usgpr(sc_.o2), e2 = usgpr(sc_.e2);
+    const int lane = threadIdx.x & 63;
+    const size_t cap = (size_t)g.node_cap;
+    const int *dmin = g.cert, *dmax = g.cert + cap, *bp = g.cert + 2 * cap, *rmin = g.cert + 3 * cap, *rmax = g.cert + 4 * cap, *bs = g.cert + 5 * cap;
+    int *hull = g.cert + 6 * cap;
+    const int O = imax(o1, o2);
+    int maxw = 0, src_ok = 1;
+    for (int base = bi; base < ei; base += 64) {
+        const int ri = base + lane;
+        int lo = 1, hi = 0;
+        if (ri < ei) {
+            const int dn = glb_ld(dmin + ri), dx = glb_ld(dmax + ri), rn = glb_ld(rmin + ri), rx = glb_ld(rmax + ri);
+            if (dx >= 0 && rx >= 0) {
+                const int K0 = glb_ld(bp + ri) + glb_ld(bs + ri) + O - sest; // UB(j) - sest >= 0 <=> keep
+                auto ub = [&](const int j) {
+                    const int r = qlen - j;
+                    return K0 + M * (imin(j, dx) + imin(r, rx)) - cert_G(j - dx, o1, e1, o2, e2) - cert_G(dn - j, o1, e1, o2, e2) - cert_G(r - rx, o1, e1, o2, e2) - cert_G(rn - r, o1, e1, o2, e2);
+                };
+                auto clampq = [&](const int v) { return imax(0, imin(qlen, v)); };
+                int a = clampq(dn), b = clampq(dx), c = clampq(qlen - rx), d = clampq(qlen - rn); // a <= b, c <= d: merge the two sorted pairs
+                int p1 = imin(a, c), t1 = imax(a, c), t2 = imin(b, d), p4 = imax(b, d);
+                int p2 = imin(t1, t2), p3 = imax(t1, t2);
+                const int p0 = 0, p5 = qlen;
+                const int f0 = ub(p0), f1 = ub(p1), f2 = ub(p2), f3 = ub(p3), f4 = ub(p4), f5 = ub(p5);
+                // first / last breakpoint at or above the bound
+                int fl = -1, fh = -1, ll = -1, lh = -1; bool any = false;
+#define LCD_SEG_LO(fa, pa, fb, pb) if (fl < 0 && (fb) >= 0) { fl = ((fa) >= 0) ? (pa) : (pa); fh = (pb); any = true; if ((fa) >= 0) fh = (pa); }
+                // walk the breakpoints left to right: the hull's left end lies in the segment that ends at the first qualifying breakpoint
+                if (f0 >= 0) { lo = 0; any = true; }
+                else if (f1 >= 0) { fl = p0; fh = p1; any = true; }
+                else if (f2 >= 0) { fl = p1; fh = p2; any = true; }
+                else if (f3 >= 0) { fl = p2; fh = p3; any = true; }
+                else if (f4 >= 0) { fl = p3; fh = p4; any = true; }
+                else if (f5 >= 0) { fl = p4; fh = p5; any = true; }
+#undef LCD_SEG_LO
+                if (any) {
+                    if (f0 < 0) { int l = fl, h = fh; while (h - l > 1) { const int m = (l + h) >> 1; if (ub(m) >= 0) h = m; else l = m; } lo = h; } // ub(l) < 0 <= ub(h)
+                    if (f5 >= 0) hi = qlen;
+                    else {
+                        if (f4 >= 0) { ll = p4; lh = p5; } else if (f3 >= 0) { ll = p3; lh = p4; } else if (f2 >= 0) { ll = p2; lh = p3; } else if (f1 >= 0) { ll = p1; lh = p2; } else { ll = p0; lh = p1; }
+                        int l = ll, h = lh; while (h - l > 1) { const int m = (l + h) >> 1; if (ub(m) >= 0) l = m; else h = m; } hi = l; // ub(l) >= 0 > ub(h)
+                    }
+                }
+            }
+            glb_st(hull + ri, lo <= hi ? (lo | (hi << 16)) : 1);
+            if (ri == bi && !(lo == 0 && hi >= 0)) src_ok = 0;
+        }
+        const int wd = lo <= hi ? hi - (lo & ~3) + 2 : 0;
+        maxw = imax(maxw, wd);
+    }
+    maxw = lane63(scan_max(maxw));
+    const int bad = __builtin_amdgcn_readfirstlane((int)(__ballot(!src_ok) != 0));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return bad ? -1 : maxw;
+}
+
 // banded convex-gap global alignment of seq[0..qlen) to the sub-graph (beg_node,end_node); returns #cigar
 // entries written to g.cig_node/g.cig_qpos in start->end order (block-uniform result).
 //
@@ -1467,17 +1685,48 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         const int rem_beg = g.remain[beg_node] - remain_end;
         const unsigned pdo = pd ? lds_off(pd) : 0xffffffffu, ro = lds_off(ring), so = lds_off(sseq);
         int nc = -1;
+        if constexpr (NT == 64) if (wb < 0 && g.cert_on) { // K2 in the single-wavefront class: rows restricted to the certified band
+            if (qlen >= 65536 || ei - bi < 2) { g.status = LCD_ERR_CERT; return 0; }
+            cert_node_arrays(&g, bi, ei);
+            __syncthreads();
+            const int ubtop = cert_ubtop(g, ei, qlen, sc);
+            int delta = g.cert_hist < 0 ? 64 + qlen / 8 : g.cert_hist + g.cert_hist / 4 + 32;
+            int sest = ubtop - delta;
+            bool done = false;
+            for (int attempt = 0; attempt < 4 && !done; ++attempt) {
+                const int mw = cert_hull(&g, bi, ei, qlen, sest, sc);
+                __syncthreads();
+                int S = LCD_NEG;
+                if (mw >= 0) {
+                    if (mw > 256) { g.status = LCD_ERR_CERT; return 0; } // wider than the window of this class: the host re-runs the chain with full rows
+                    wo.status = g.status; wo.score = LCD_NEG;
+                    nc = align_windowed<NT, 2, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+                    if (nc < 0) { g.status = LCD_ERR_CERT; return 0; }
+                    if (wo.status != LCD_OK) { g.status = wo.status; return 0; }
+                    g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells;
+                    S = wo.score;
+                }
+                if (S > LCD_NEG / 2 && S >= sest) { done = true; g.cert_hist = imax(g.cert_hist, ubtop - S); }
+                else if (S > LCD_NEG / 2) sest = S;                 // a true lower bound of the optimum: the next attempt is certain
+                else { delta *= 4; sest = ubtop - delta; }            // no alignment inside the intervals at all: the guess was far too high
+                __syncthreads();
+            }
+            if (!done) { g.status = LCD_ERR_CERT; return 0; }
+            g.status = wo.status;
+            g.cig_node = g.cig_node0 + wo.cig_pos; g.cig_qpos = g.cig_qpos0 + wo.cig_pos;
+            return nc;
+        }
         if (wb < 0) {
             nc = align_unbanded<NT>(&g, ro, pdo, sc, bi, ei, seq_hbm, qlen, &wo);
-            if (nc < 0) { __syncthreads(); nc = align_windowed<NT, false, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+            if (nc < 0) { __syncthreads(); nc = align_windowed<NT, 0, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
         } else {
             // the host's preferred window (PoaChain.wmax) first; a band that outgrows it is re-run in the next wider one
             if constexpr (NT == 64) {
-                if (g.wmax <= 64) nc = align_windowed<NT, true, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
-                if (nc < 0 && g.wmax <= 128) { __syncthreads(); nc = align_windowed<NT, true, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                if (g.wmax <= 64) nc = align_windowed<NT, 1, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+                if (nc < 0 && g.wmax <= 128) { __syncthreads(); nc = align_windowed<NT, 1, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
                 if (nc < 0) __syncthreads();
             }
-            if (nc < 0) nc = align_windowed<NT, true, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+            if (nc < 0) nc = align_windowed<NT, 1, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
         }
         if (nc >= 0) {
             g.status = wo.status; g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells; g.t_plan += wo.t_plan; g.t_poll += wo.t_poll;
@@ -1828,7 +2077,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     // window the host expects the band to fit (64 / 128 columns: LDS per chain is what limits how many of them share a CU)
     const int ring_cols = NT == 64 ? ch.wmax : 4 * NT;
     uint8_t *sseq = (uint8_t *)(lds_pool + Cfg<NT>::K * 3 * ring_cols);
-    const PoaLayout L = poa_layout(ch.node_cap, ch.edge_cap, ch.rid_words, ch.max_len, ch.cell_cap, ch.n_reads, ch.spill_x);
+    const PoaLayout L = poa_layout(ch.node_cap, ch.edge_cap, ch.rid_words, ch.max_len, ch.cell_cap, ch.n_reads, ch.spill_x, ch.cert);
     uint8_t *ws = arena + ch.ws_off;
     int my_slot = -1;
     if (ch.slot_flags) { // pooled arenas: claim a slot (this CU's own ones first; anything free otherwise; wait if the pool is exhausted)
@@ -1882,7 +2131,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.pl_start = (int *)(ws + L.pl_start); g.pl_pidx = (int *)(ws + L.pl_pidx); g.pl_bonus = (int *)(ws + L.pl_bonus);
     g.pl_rem = (int *)(ws + L.pl_rem); g.pl_base = ws + L.pl_base;
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
-    g.tb = (int *)(ws + L.tb);
+    g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = NT == 64 ? ch.cert : 0; g.cert_hist = -1;
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
     g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - Cfg<NT>::K * 3 * ring_cols) * 4;
     g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0;

@@ -126,6 +126,11 @@ int lcdo_poa_aln_msa_cons(const lcdo_opt_t *opt, int n_reads, uint8_t **read_seq
 /* score-level pin: unbanded optimum of aligning seq to the CURRENT graph of a chain built from the first n reads.
  * (used by tests only) */
 int lcdo_poa_debug_last_scores(int *banded, int *unbanded);
+/* counters of the certified-band checker (env LCDO_CERT_STATS=1 while lcdo_poa_aln_msa_cons runs; oracle/poa.c): out[0] rows, [1] cells of the full rows,
+ * [2] cells inside the intervals for the true lower bound, [3] reads, [4] cells whose H exceeds the prefix bound (must be 0), [5] matched backtrack cells outside
+ * their row's interval (must be 0), [6] widest interval, [7] rows wider than the 256-column window, [11] cells under the product's guessing policy (a retried
+ * read counted twice), [12] retries, [13] reads with a row wider than the window under the policy, [14] same for the true bound, [15] / [16] regions without / all */
+void lcdo_poa_cert_stats(long long *out);
 
 /* ---------------- align.c glue ---------------- */
 typedef struct {

@@ -213,6 +213,20 @@ static inline int sc_mat(const lcdo_opt_t *o, uint8_t a, uint8_t b) {
 
 /* banded (wb,wf) convex-gap global alignment of seq[0..qlen) to the sub-graph (beg_node, end_node) exclusive.
  * returns number of cigar entries (start->end order) in *cig (malloc'd). */
+
+/* ---- checker of the product's CERTIFIED BAND for K2 (poa_kernel.hip align_certified; DESIGN.md "Certified band"), switched on by LCDO_CERT_STATS:
+ * upper bounds on the score of any alignment through a cell, from per-node path-length ranges (minD..maxD nodes from the source, minR..maxR to the sink) and
+ * maximal edge-bonus sums; a cell whose bound is below a known alignment score cannot lie on an optimal path.  Inside the unbanded DP below the checker
+ *   - tests the prefix half of the bound against EVERY cell's H (g_cert_viol_prefix),
+ *   - builds each row's interval for the score of a banded alignment of the same read and tests that every matched cell of the backtrack is inside
+ *     (g_cert_viol_path),
+ *   - replays the product's guessing policy (bound at the end cell minus the largest slack seen so far in the chain + a margin) and counts cells, retries and
+ *     rows wider than the 256-column window.
+ * lcdo_poa_cert_stats returns the counters (tests/test_oracle_poa.py::test_band_certificate). ---- */
+static int g_cert_on = -1, g_cert_slb = NEG;
+static long long g_cert_cells_full, g_cert_cells_hull, g_cert_rows, g_cert_reads, g_cert_viol_prefix, g_cert_viol_path, g_cert_maxw, g_cert_wide;
+static int g_cert_hist_delta = -1; static long long g_cert_est_cells, g_cert_est_retry, g_cert_est_ovf_reads, g_cert_true_ovf_reads, g_cert_regions_allok, g_cert_regions, g_cert_region_bad;
+static inline int cert_G(const lcdo_opt_t *o, int k) { if (k <= 0) return 0; int a = o->gap_open1 + o->gap_ext1 * k, b = o->gap_open2 + o->gap_ext2 * k; return a < b ? a : b; }
 static int align_to_subgraph(lcdo_poa_t *g, const lcdo_opt_t *opt, int wb, double wf, int beg_node, int end_node,
                              const uint8_t *seq, int qlen, gcig_t **cig_out, int *score_out) {
     *cig_out = NULL; if (score_out) *score_out = NEG;
@@ -376,6 +390,74 @@ static int align_to_subgraph(lcdo_poa_t *g, const lcdo_opt_t *opt, int wb, doubl
         while (j > 0) { cig[--pos] = (gcig_t){1, -1, j - 1}; --j; }
         n = qlen - pos;
         memmove(cig, cig + pos, (size_t)n * sizeof(gcig_t));
+    }
+
+    if (g_cert_on > 0 && wb < 0 && br >= 0 && best > NEG / 2 && g_cert_slb > NEG / 2) {
+        const int M = opt->match, O = opt->gap_open1 > opt->gap_open2 ? opt->gap_open1 : opt->gap_open2;
+        int *minD = (int *)malloc(sizeof(int) * (nrow + 1)), *maxD = (int *)malloc(sizeof(int) * (nrow + 1)), *Bp = (int *)malloc(sizeof(int) * (nrow + 1));
+        int *minR = (int *)malloc(sizeof(int) * (nrow + 1)), *maxR = (int *)malloc(sizeof(int) * (nrow + 1)), *Bs = (int *)malloc(sizeof(int) * (nrow + 1));
+        int *lo = (int *)malloc(sizeof(int) * (nrow + 1)), *hi = (int *)malloc(sizeof(int) * (nrow + 1));
+        minD[0] = maxD[0] = 0; Bp[0] = 0;
+        for (int r = 1; r < nrow; ++r) {
+            minD[r] = 1 << 29; maxD[r] = -1; Bp[r] = NEG;
+            if (!imap[r]) continue;
+            int v = g->idx2node[bi + r];
+            for (int e = g->node[v].in_head; e >= 0; e = g->edge[e].next_in) {
+                int pr = g->node2idx[g->edge[e].from] - bi;
+                if (pr < 0 || pr >= nrow || !imap[pr] || maxD[pr] < 0) continue;
+                if (minD[pr] + 1 < minD[r]) minD[r] = minD[pr] + 1;
+                if (maxD[pr] + 1 > maxD[r]) maxD[r] = maxD[pr] + 1;
+                int b = Bp[pr] + ilog2_32(g->edge[e].w); if (b > Bp[r]) Bp[r] = b;
+            }
+        }
+        for (int r = nrow - 1; r >= 0; --r) {
+            minR[r] = 1 << 29; maxR[r] = -1; Bs[r] = NEG;
+            if (!imap[r]) continue;
+            int v = g->idx2node[bi + r];
+            for (int e = g->node[v].out_head; e >= 0; e = g->edge[e].next_out) {
+                int to = g->edge[e].to, bz = ilog2_32(g->edge[e].w);
+                if (to == end_node) { if (0 < minR[r]) minR[r] = 0; if (0 > maxR[r]) maxR[r] = 0; if (bz > Bs[r]) Bs[r] = bz; continue; }
+                int x = g->node2idx[to] - bi;
+                if (x <= r || x >= nrow || !imap[x] || maxR[x] < 0) continue;
+                if (minR[x] + 1 < minR[r]) minR[r] = minR[x] + 1;
+                if (maxR[x] + 1 > maxR[r]) maxR[r] = maxR[x] + 1;
+                if (Bs[x] + bz > Bs[r]) Bs[r] = Bs[x] + bz;
+            }
+        }
+#define UBP(r, j) (Bp[r] + M * ((j) < maxD[r] ? (j) : maxD[r]) - cert_G(opt, (j) - maxD[r]) - cert_G(opt, minD[r] - (j)))
+#define UBS(r, j) (Bs[r] + M * ((qlen - (j)) < maxR[r] ? (qlen - (j)) : maxR[r]) - cert_G(opt, (qlen - (j)) - maxR[r]) - cert_G(opt, minR[r] - (qlen - (j))))
+        for (int r = 0; r < nrow; ++r) {
+            lo[r] = 1; hi[r] = 0;
+            if (!imap[r] || rbeg[r] > rend[r] || maxD[r] < 0 || maxR[r] < 0) continue;
+            ++g_cert_rows; g_cert_cells_full += rend[r] - rbeg[r] + 1;
+            for (int j = rbeg[r]; j <= rend[r]; ++j) {
+                if (CELL(r, j, 0) > UBP(r, j)) ++g_cert_viol_prefix;       /* the prefix half of the bound, checked on every cell of the full DP */
+                if (UBP(r, j) + UBS(r, j) + O >= g_cert_slb) { if (lo[r] > hi[r]) lo[r] = j; hi[r] = j; }
+            }
+            if (lo[r] <= hi[r]) { g_cert_cells_hull += hi[r] - lo[r] + 1; if (hi[r] - lo[r] + 1 > g_cert_maxw) g_cert_maxw = hi[r] - lo[r] + 1; if (hi[r] - lo[r] + 4 > 256) ++g_cert_wide; }
+        }
+        /* every cell the backtrack visited must be inside its row's hull: matched cells from the cigar */
+        for (int t = 0; t < n; ++t) if (cig[t].op == 0) { int r = g->node2idx[cig[t].node] - bi, j = cig[t].qpos + 1; if (j < lo[r] || j > hi[r]) ++g_cert_viol_path; }
+        { /* policy: S_est = UB at the end cell - (largest slack seen in this chain so far + margin) */
+          int ubtop = NEG;
+          for (int e = g->node[end_node].in_head; e >= 0; e = g->edge[e].next_in) { int pr = g->node2idx[g->edge[e].from] - bi; if (pr < 0 || pr >= nrow || !imap[pr] || maxD[pr] < 0) continue; int u = UBP(pr, qlen) + ilog2_32(g->edge[e].w); if (u > ubtop) ubtop = u; }
+          const int margin = getenv("LCDO_CERT_MARGIN") ? atoi(getenv("LCDO_CERT_MARGIN")) : 32;
+          int delta = g_cert_hist_delta < 0 ? 64 + qlen / 8 : g_cert_hist_delta + g_cert_hist_delta / 4 + margin;
+          int sest = ubtop - delta, retry = 0;
+          if (sest > best) { retry = 1; sest = best; ++g_cert_est_retry; }     /* the first pass would come back with S' < S_est (pessimistically: S' = S*) */
+          int ovf = 0, tovf = 0;
+          for (int r = 0; r < nrow; ++r) {
+              if (!imap[r] || rbeg[r] > rend[r] || maxD[r] < 0 || maxR[r] < 0) continue;
+              int l2 = 1, h2 = 0;
+              for (int j = rbeg[r]; j <= rend[r]; ++j) if (UBP(r, j) + UBS(r, j) + O >= sest) { if (l2 > h2) l2 = j; h2 = j; }
+              if (l2 <= h2) { g_cert_est_cells += (h2 - l2 + 1) * (retry ? 2 : 1); if (h2 - (l2 & ~3) + 2 > 256) ovf = 1; }
+              if (lo[r] <= hi[r] && hi[r] - (lo[r] & ~3) + 2 > 256) tovf = 1;
+          }
+          g_cert_est_ovf_reads += ovf; g_cert_true_ovf_reads += tovf; if (ovf) g_cert_region_bad = 1;
+          if (ubtop - best > g_cert_hist_delta) g_cert_hist_delta = ubtop - best;
+        }
+        ++g_cert_reads;
+        free(minD); free(maxD); free(Bp); free(minR); free(maxR); free(Bs); free(lo); free(hi);
     }
 #undef CELL
 #undef INBAND
@@ -627,9 +709,12 @@ int lcdo_poa_partial_aln_msa_cons(const lcdo_opt_t *opt, int sampling_reads, int
 int lcdo_poa_aln_msa_cons(const lcdo_opt_t *opt, int n_reads, uint8_t **read_seqs, const int *read_lens, int max_n_cons,
                           lcdo_poa_result_t *res) {
     lcdo_poa_t *g = poa_init(n_reads);
+    g_cert_hist_delta = -1; if (g_cert_regions) g_cert_regions_allok += !g_cert_region_bad; ++g_cert_regions; g_cert_region_bad = 0;
     for (int i = 0; i < n_reads; ++i) {
         gcig_t *cig = NULL; int n_cig = 0, sc = NEG;
         if (g->n_node > 2) {
+            g_cert_on = getenv("LCDO_CERT_STATS") ? 1 : 0;
+            if (g_cert_on) { gcig_t *c1 = NULL; int s1 = NEG; align_to_subgraph(g, opt, 10, 0.01, 0, 1, read_seqs[i], read_lens[i], &c1, &s1); free(c1); g_cert_slb = s1; }
             n_cig = align_to_subgraph(g, opt, -1, 0.0, 0, 1, read_seqs[i], read_lens[i], &cig, &sc);
             g_dbg_banded = sc;
             if (getenv("LCDO_POA_CHECK_UNBANDED")) g_dbg_unbanded = dag_dp_score(g, opt, 0, 1, read_seqs[i], read_lens[i]);
@@ -644,6 +729,9 @@ int lcdo_poa_aln_msa_cons(const lcdo_opt_t *opt, int n_reads, uint8_t **read_seq
     return n_cons;
 }
 
+void lcdo_poa_cert_stats(long long *out) { /* experiment: rows, full cells, hull cells, reads, prefix-bound violations, path violations, widest hull, rows wider than 252 */
+    out[0] = g_cert_rows; out[1] = g_cert_cells_full; out[2] = g_cert_cells_hull; out[3] = g_cert_reads; out[4] = g_cert_viol_prefix; out[5] = g_cert_viol_path; out[6] = g_cert_maxw; out[7] = g_cert_wide; out[8] = 0; out[9] = 0; out[10] = 0; out[11] = g_cert_est_cells; out[12] = g_cert_est_retry; out[13] = g_cert_est_ovf_reads; out[14] = g_cert_true_ovf_reads; out[15] = g_cert_regions_allok; out[16] = g_cert_regions;
+}
 int lcdo_poa_debug_last_scores(int *banded, int *unbanded) {
     *banded = g_dbg_banded; *unbanded = g_dbg_unbanded;
     return 0;

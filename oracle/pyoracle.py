@@ -257,6 +257,17 @@ def poa_partial_aln_msa_cons(reads, covers, opt=None, sampling=0):
     return _poa_unpack(res, n, nc)
 
 
+def poa_cert_stats():
+    """counters of oracle/poa.c's certified-band checker (run poa_aln_msa_cons with LCDO_CERT_STATS=1 in the environment first)"""
+    L = lib()
+    out = (C.c_longlong * 20)()
+    L.lcdo_poa_cert_stats.argtypes = [C.POINTER(C.c_longlong)]; L.lcdo_poa_cert_stats.restype = None
+    L.lcdo_poa_cert_stats(out)
+    o = list(out)
+    return dict(rows=o[0], full_cells=o[1], hull_cells=o[2], reads=o[3], prefix_violations=o[4], path_violations=o[5], widest=o[6], wide_rows=o[7],
+                policy_cells=o[11], policy_retries=o[12], policy_wide_reads=o[13], true_wide_reads=o[14])
+
+
 def poa_aln_msa_cons(reads, max_n_cons=2, opt=None):
     """K2, src/align.c:872"""
     opt = opt or default_opt()

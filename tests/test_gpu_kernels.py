@@ -287,13 +287,42 @@ def _check_k2(got, exp):
 
 
 @pytest.mark.parametrize("L", [230, 900, 2600])
-def test_poa_k2_bubbles_all_workgroup_classes(lcd, oracle, L):
-    """K2 on het-SV regions in the 64-, 256- and 1024-thread classes (the last two run the systolic rows): == oracle"""
+def test_poa_k2_bubbles_all_workgroup_classes(lcd, oracle, L, monkeypatch):
+    """K2 on het-SV regions in the 64-, 256- and 1024-thread classes (the last two run the systolic rows): == oracle.  (LCD_CERT=0: full rows; the
+    certified band of the single-wavefront class has its own test below)"""
+    monkeypatch.setenv("LCD_CERT", "0")
     rng = np.random.default_rng(400 + L)
     h1, h2 = _sv_haps(rng, L)
     reads = [mutate(rng, h1 if i % 2 == 0 else h2, 0.002) for i in range(10)]
     got = lcd.poa_batch([dict(mode=1, reads=reads)])[0]
     _check_k2(got, oracle.poa_aln_msa_cons(reads, 2))
+
+
+@pytest.mark.parametrize("L,rate,sv", [(300, 0.002, 12), (900, 0.001, 40), (900, 0.02, 25), (2600, 0.002, 60), (2600, 0.003, 400), (1500, 0.06, 30)])
+def test_poa_k2_certified_band(lcd, oracle, L, rate, sv, monkeypatch):
+    """K2 with rows restricted to the certified band (single-wavefront class, poa_kernel.hip align_certified) == full rows == oracle: clean and noisy reads,
+    small and large het insertions (a 400-base one needs more than the 256-column window: the chain comes back with LCD_ERR_CERT and is re-run with
+    full rows -- same result, status 0), reads of very different lengths in one chain"""
+    rng = np.random.default_rng(4500 + L + sv)
+    h1 = rng.integers(0, 4, L).astype(np.uint8)
+    p = L // 3
+    h2 = np.concatenate([h1[:p], rng.integers(0, 4, sv).astype(np.uint8), h1[p:]])
+    h2[L // 2 + sv] = (h2[L // 2 + sv] + 1) % 4
+    reads = [mutate(rng, h1 if i % 2 == 0 else h2, rate) for i in range(12)]
+    reads[5] = reads[5][: len(reads[5]) * 2 // 3]       # a read that stops early: forced gap columns at the end
+    jobs = [dict(mode=1, reads=reads), dict(mode=1, reads=reads[::-1])]
+    monkeypatch.setenv("LCD_CERT", "2")                  # (2: noisy reads as well)
+    a = lcd.poa_batch(jobs)
+    monkeypatch.setenv("LCD_CERT", "0")
+    b = lcd.poa_batch(jobs)
+    for x, y, j in zip(a, b, jobs):
+        assert x["status"] == 0 and y["status"] == 0 and x["n_cons"] == y["n_cons"] and x["msa_len"] == y["msa_len"]
+        for r, q in zip(x["msa"], y["msa"]):
+            assert (r == q).all()
+        for c in range(x["n_cons"]):
+            assert (x["cons"][c] == y["cons"][c]).all() and (x["clu"][c] == y["clu"][c]).all()
+        if L <= 1500:
+            _check_k2(x, oracle.poa_aln_msa_cons(j["reads"], 2))
 
 
 def test_poa_reads_with_n(lcd, oracle):

@@ -79,3 +79,22 @@ def test_glue_sort_phase_set_trim(oracle):
             s = res["aln_strs"][c][2 * k + 1]
             assert s is not None and len(s["target"]) == s["aln_len"]
             assert not ((s["target"] == 5) & (s["query"] == 5)).any()                    # gap/gap columns dropped (src/align.c:1034-1040)
+
+
+def test_band_certificate(oracle, monkeypatch):
+    """the bound behind the product's certified band for K2 (poa_kernel.hip align_certified), checked inside the oracle's unbanded DP (oracle/poa.c,
+    LCDO_CERT_STATS): no cell's H exceeds the prefix half of the bound, every matched cell of the backtrack lies inside its row's interval -- on clean reads
+    with het insertions, on noisy reads, on reads of different lengths -- and the intervals are a small fraction of the full rows for clean reads"""
+    monkeypatch.setenv("LCDO_CERT_STATS", "1")
+    rng = np.random.default_rng(77)
+    before = oracle.poa_cert_stats()
+    for L, rate, sv in ((400, 0.002, 15), (800, 0.001, 60), (600, 0.05, 20), (700, 0.01, 250)):
+        h1 = rng.integers(0, 4, L).astype(np.uint8)
+        h2 = np.concatenate([h1[: L // 3], rng.integers(0, 4, sv).astype(np.uint8), h1[L // 3:]])
+        reads = [mutate(rng, h1 if i % 2 == 0 else h2, rate) for i in range(10)]
+        reads[3] = reads[3][: len(reads[3]) // 2]
+        oracle.poa_aln_msa_cons(reads, 2)
+    st = oracle.poa_cert_stats()
+    d = {k: st[k] - before[k] for k in st if k != "widest"}
+    assert d["reads"] >= 36 and d["prefix_violations"] == 0 and d["path_violations"] == 0
+    assert d["hull_cells"] * 3 < d["full_cells"]
