@@ -223,7 +223,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    acc = {"ms": 0.0, "launches": 0, "st": None, "alg": 0.0, "cells": 0.0, "regions": 0.0, "bases": 0.0, "resolved": 0, "wfa_off": 0.0, "ed_blocks": 0.0, "ms_wfa": 0.0, "ms_anchor": 0.0}
+    acc = {"ms": 0.0, "launches": 0, "st": None, "alg": 0.0, "cells": 0.0, "regions": 0.0, "bases": 0.0, "resolved": 0, "wfa_off": 0.0, "ed_blocks": 0.0, "ms_wfa": 0.0, "ms_anchor": 0.0, "cells_computed": 0.0}
     lock = threading.Lock()
     lane_errors = []
 
@@ -237,7 +237,7 @@ def main():
                         acc["ms"] += sts[0]["ms_poa_kernel"]; acc["launches"] += sts[0]["n_poa_launches"]; acc["st"] = sts[0]
                         acc["ms_wfa"] += sts[0]["ms_wfa"] + sts[0]["ms_anchor"]; acc["ms_anchor"] += sts[0]["ms_anchor"]
                         for x in sts:
-                            acc["alg"] += float(x["poa_alg_bytes"]); acc["cells"] += float(x["poa_cells"]); acc["regions"] += float(x["n_regions"])
+                            acc["alg"] += float(x["poa_alg_bytes"]); acc["cells"] += float(x["poa_cells"]); acc["cells_computed"] += float(x["poa_cells_computed"]); acc["regions"] += float(x["n_regions"])
                             acc["bases"] += float(x["poa_aligned_bases"]); acc["resolved"] += int(x["n_regions_resolved"])
                             acc["wfa_off"] += float(x["wfa_offsets"]); acc["ed_blocks"] += float(x["edlib_blocks"])
         except Exception as e:  # noqa: surfaced after the join (a thread's traceback alone would leave a half-measured line)
@@ -374,6 +374,11 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_src, "kernel": "lcd_poa_chain_kernel", "ms_per_launch": round(mean_launch_s * 1e3, 4),
                     "alg_bytes_per_launch": alg_bytes, "cells_per_launch": int(acc["cells"] / max(poa_launches, 1)),
                     "gcups": round(acc["cells"] / max(poa_launches, 1) / mean_launch_s / 1e9, 3) if mean_launch_s > 0 else 0.0,
+                    # cells / bytes above are those of the REFERENCE's algorithm (K1 adaptive band, K2 full rows).  K2 chains of clean reads run
+                    # over a certified band (same alignments): what the kernels actually computed / streamed is the smaller figure below
+                    "cells_computed_per_launch": int(acc["cells_computed"] / max(poa_launches, 1)),
+                    "gcups_computed": round(acc["cells_computed"] / max(poa_launches, 1) / mean_launch_s / 1e9, 3) if mean_launch_s > 0 else 0.0,
+                    "achieved_computed": round((acc["alg"] - acc["cells"] + acc["cells_computed"]) / max(poa_launches, 1) / mean_launch_s / 1e9, 3) if mean_launch_s > 0 else 0.0,
                     "valu": valu}
         if n_lanes > 1 and world == 1:
             # `achieved` prices ONE lane's launch set against its own duration while the other lanes' chains share the CUs; the chip-wide rate is

@@ -148,14 +148,15 @@ typedef struct lcd_batch_s lcd_batch_t;
 typedef struct lcd_batch_stats_t {
     int n_regions, n_regions_resolved; /* regions reaching K1/K2 ; regions with n_cons > 0 */
     int n_chains, n_anchor_jobs, n_wfa_jobs, n_edlib_jobs;
-    uint64_t poa_aligned_bases, poa_cells, wfa_offsets, edlib_blocks;
-    uint64_t poa_alg_bytes; /* SURVEY 8d B_poa summed over aligned reads */
+    uint64_t poa_aligned_bases, poa_cells, wfa_offsets, edlib_blocks; /* poa_cells: DP cells of the reference's algorithm (K1: adaptive band, K2: full rows) */
+    uint64_t poa_alg_bytes; /* SURVEY 8d B_poa summed over aligned reads (C = poa_cells) */
     double ms_total, ms_anchor, ms_poa, ms_wfa, ms_strings; /* HIP-event times on the batch stream */
     double ms_upload, ms_download, ms_host;
     double ms_poa_kernel;   /* HIP events tight around the POA chain kernel launch(es) only */
     int n_poa_launches;
     int poa_retries;
     double ms_vars;         /* stage S6 (opt.collect_noisy_vars) */
+    uint64_t poa_cells_computed; /* cells the kernels actually computed: < poa_cells where K2 ran over a certified band (same alignments) */
 } lcd_batch_stats_t;
 
 #define LCD_DEVICE_ANY (-2)

@@ -692,6 +692,8 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     else if (pc.cert) band = std::min<long long>(maxl + 1, 260);
     else band = maxl + 1;
     long long cells = rows_est * band;
+    // (tried: the single-wavefront class compiled for 64 VGPRs (__launch_bounds__(64, 8): 32 instead of 16 wavefronts per CU, 4 - 8 KB pools): 34 - 37 k instead of
+    // 51 k regions/s -- the row loops spill (40 - 170 B of scratch per lane inside align_windowed) and the graph phases' scratch grows from 924 to 1 336 B)
     // (tried: 3x the estimate up front for the long K1 chains of noisy reads, which overflow most -- 5 instead of 60 re-runs per 4 SV-shape batches, but
     // the POA stage got 20 % LONGER: an overflowing chain gives up early and its re-run shares the chip with ~50 others instead of 9 000)
     // K2 chains of noisy reads: at one code byte per worst-case cell EVERY such chain ran out of spilled value rows (a spilled row is 12 bytes
@@ -1118,6 +1120,9 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             }
             if (getenv("LCD_MEM_DEBUG")) {
                 { size_t nc = 0; for (size_t g : which) nc += PC(g).cert != 0; fprintf(stderr, "[mem] round %d: %zu chains with a certified band, %zu sent back for full rows\n", round, nc, n_cert_fail); }
+                if (getenv("LCD_CERT_DEBUG")) for (size_t i = 0; i < which.size(); ++i) { const PoaChain &pc = PC(which[i]); if (!pc.cert) continue; const int k = chain_batch[which[i]];
+                    std::vector<int> ls; for (int r = 0; r < pc.n_reads; ++r) ls.push_back(preads[k][pc.read0 + r].len); std::sort(ls.begin(), ls.end());
+                    fprintf(stderr, "[cert] %s n %d max %d p75 %d med %d p25 %d min %d nodes %d\n", tmp[i].status == LCD_ERR_CERT ? "FAIL" : "ok  ", pc.n_reads, ls.back(), ls[ls.size() * 3 / 4], ls[ls.size() / 2], ls[ls.size() / 4], ls[0], tmp[i].n_node); if (tmp[i].status == LCD_ERR_CERT) fprintf(stderr, "[cert]    why %llu  attempt/qlen %llu  aligned reads %d hist?\n", tmp[i].t_plan, tmp[i].t_poll, tmp[i].n_aligned_reads); }
                 int c[2][3] = {{0, 0, 0}, {0, 0, 0}};
                 for (size_t g : again) { const PoaChainOut &o = bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]]; c[PC(g).mode ? 1 : 0][o.status == LCD_ERR_CELLS ? 0 : o.status == LCD_ERR_NODES ? 1 : 2]++; }
                 { std::map<int, std::pair<int, int>> byc; for (size_t g : which) if (PC(g).mode) byc[chain_threads(PC(g))].second++; for (size_t g : again) if (PC(g).mode) byc[chain_threads(PC(g))].first++;
@@ -1374,9 +1379,9 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         // stage times are those of the joint run (the same for every batch of the call)
         S.ms_anchor = ms_anchor; S.ms_poa = ms_poa; S.ms_wfa = ms_wfa; S.ms_strings = ms_str; S.ms_total = ms_tot + ms_vars; S.ms_host = host_ms - ms_vars; S.ms_vars = ms_vars;
         for (const PoaChainOut &o : b->couts) {
-            S.poa_aligned_bases += o.aligned_bases; S.poa_cells += o.cells;
+            S.poa_aligned_bases += o.aligned_bases; S.poa_cells += o.cells_alg; S.poa_cells_computed += o.cells;
             // B_poa = q + 5*N_sub + C + (q + N_sub) per aligned read; N_sub ~ final graph size (upper bound per read)
-            S.poa_alg_bytes += 2 * o.aligned_bases + o.cells + 6ull * (uint64_t)o.n_node * (uint64_t)o.n_aligned_reads;
+            S.poa_alg_bytes += 2 * o.aligned_bases + o.cells_alg + 6ull * (uint64_t)o.n_node * (uint64_t)o.n_aligned_reads;
         }
         b->ran = true; b->downloaded = false;
     }

@@ -75,7 +75,8 @@ struct PoaChainOut {
     int clu_n[2];
     int n_node, n_edge;
     int n_aligned_reads;
-    unsigned long long cells;          // DP cells computed (K1/K2 algorithmic unit)
+    unsigned long long cells;          // DP cells computed
+    unsigned long long cells_alg;      // DP cells of the reference's algorithm (K1: the adaptive band, K2: full rows) -- SURVEY 8d's unit; == cells unless a certified band was used
     unsigned long long aligned_bases;  // POA-aligned bases (BASELINE metric)
     unsigned long long t_total, t_dp, t_bt, t_graph, t_out, t_sub; // shader-clock ticks per phase (profiling aid)
     unsigned long long rt_begin, rt_end; unsigned hw_id, xcc_id;    // placement probe: s_memrealtime (100 MHz) at start / end, HW_ID, XCC_ID

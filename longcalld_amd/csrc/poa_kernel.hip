@@ -74,6 +74,7 @@ struct Ctx {
     int *pl_start, *pl_pidx, *pl_bonus, *pl_rem; uint8_t *pl_base;
     int *aa_node, *aa_flag, *aa_eid;
     int *tb;                          // column-tile boundaries of the unbanded rows: 4 x node_cap ints (H of the last column, by tile parity; F carries)
+    long long alg_adjust;             // cells of the reference's algorithm minus cells computed (certified band: full rows minus the intervals, attempts included)
     int *cert; int cert_on, cert_hist; // certified band of a K2 chain (align_certified): 7 x node_cap ints; largest bound-to-score slack of the chain's reads so far
     int wmax, seq_cap, pool_words, spill_x;
     int n_node, n_edge, node_cap, edge_cap, rid_words;
@@ -1689,29 +1690,34 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
             if (qlen >= 65536 || ei - bi < 2) { g.status = LCD_ERR_CERT; return 0; }
             cert_node_arrays(&g, bi, ei);
             __syncthreads();
+            const unsigned long long cells_before = *cells_acc;
             const int ubtop = cert_ubtop(g, ei, qlen, sc);
-            int delta = g.cert_hist < 0 ? 64 + qlen / 8 : g.cert_hist + g.cert_hist / 4 + 32;
-            int sest = ubtop - delta;
+            // the guess: the bound at the end cell minus a slack -- the largest one an earlier read of this chain needed (+ 25 % + 32), or a small one for
+            // the first alignment.  An attempt that comes back below its guess doubles the slack; the best score seen so far is a TRUE lower bound of the
+            // optimum and takes over as soon as it is the tighter of the two (that attempt cannot fail)
+            int delta = g.cert_hist < 0 ? 48 + qlen / 32 : g.cert_hist + g.cert_hist / 4 + 32;
+            int sbest = LCD_NEG;
             bool done = false;
-            for (int attempt = 0; attempt < 4 && !done; ++attempt) {
+            for (int attempt = 0; attempt < 10 && !done; ++attempt, delta *= 2) {
+                const int sest = imax(sbest, ubtop - delta);
                 const int mw = cert_hull(&g, bi, ei, qlen, sest, sc);
                 __syncthreads();
-                int S = LCD_NEG;
-                if (mw >= 0) {
-                    if (mw > 256) { g.status = LCD_ERR_CERT; return 0; } // wider than the window of this class: the host re-runs the chain with full rows
-                    wo.status = g.status; wo.score = LCD_NEG;
-                    nc = align_windowed<NT, 2, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
-                    if (nc < 0) { g.status = LCD_ERR_CERT; return 0; }
-                    if (wo.status != LCD_OK) { g.status = wo.status; return 0; }
-                    g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells;
-                    S = wo.score;
+                if (mw < 0) continue;                                  // not even the source row qualifies: the guess is above the optimum
+                if (mw > 256) { g.status = LCD_ERR_CERT; g.t_plan = 1000000ull + mw; g.t_kahn = (unsigned long long)attempt * 1000000ull + (unsigned)qlen; return 0; } // wider than this class's window: the host re-runs the chain with full rows
+                wo.status = g.status; wo.score = LCD_NEG;
+                nc = align_windowed<NT, 2, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+                if (nc < 0) { g.status = LCD_ERR_CERT; g.t_plan = 2000000ull + mw; g.t_kahn = (unsigned long long)attempt * 1000000ull + (unsigned)qlen; return 0; }
+                if (wo.status != LCD_OK) { g.status = wo.status; return 0; }
+                g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells;
+                const int S = wo.score;
+                if (S > LCD_NEG / 2) {
+                    sbest = imax(sbest, S);
+                    if (S >= sest) { done = true; g.cert_hist = imax(g.cert_hist, ubtop - S); }
                 }
-                if (S > LCD_NEG / 2 && S >= sest) { done = true; g.cert_hist = imax(g.cert_hist, ubtop - S); }
-                else if (S > LCD_NEG / 2) sest = S;                 // a true lower bound of the optimum: the next attempt is certain
-                else { delta *= 4; sest = ubtop - delta; }            // no alignment inside the intervals at all: the guess was far too high
                 __syncthreads();
             }
-            if (!done) { g.status = LCD_ERR_CERT; return 0; }
+            if (!done) { g.status = LCD_ERR_CERT; g.t_plan = 3000000ull; return 0; }
+            g.alg_adjust += (long long)(ei - bi) * (qlen + 1) - (long long)(*cells_acc - cells_before); // what align_unbanded would have counted for this read
             g.status = wo.status;
             g.cig_node = g.cig_node0 + wo.cig_pos; g.cig_qpos = g.cig_qpos0 + wo.cig_pos;
             return nc;
@@ -2131,7 +2137,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.pl_start = (int *)(ws + L.pl_start); g.pl_pidx = (int *)(ws + L.pl_pidx); g.pl_bonus = (int *)(ws + L.pl_bonus);
     g.pl_rem = (int *)(ws + L.pl_rem); g.pl_base = ws + L.pl_base;
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
-    g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = NT == 64 ? ch.cert : 0; g.cert_hist = -1;
+    g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = NT == 64 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0;
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
     g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - Cfg<NT>::K * 3 * ring_cols) * 4;
     g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0;
@@ -2183,7 +2189,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     // ---------------- output: MSA rank, rows, clusters, consensus (oracle/poa.c poa_output) ----------------
     PoaChainOut out;
     out.status = g.status; out.n_cons = 0; out.cons_len[0] = out.cons_len[1] = 0; out.msa_len = 0; out.clu_n[0] = out.clu_n[1] = 0;
-    out.n_node = g.n_node; out.n_edge = g.n_edge; out.n_aligned_reads = n_aligned_reads; out.cells = cells; out.aligned_bases = aligned_bases;
+    out.n_node = g.n_node; out.n_edge = g.n_edge; out.n_aligned_reads = n_aligned_reads; out.cells = cells; out.cells_alg = (unsigned long long)((long long)cells + g.alg_adjust); out.aligned_bases = aligned_bases;
     uint8_t *ob = outpool + ch.out_off;
     const int nc_cap = ch.node_cap;
     uint8_t *cons0 = ob, *cons1 = ob + nc_cap;
