@@ -162,7 +162,8 @@ struct ChainRec {
     int mode;
     std::vector<int> members;     // indices into the region's sorted read list
     int read0;                    // first PoaRead
-    int cert_fail_round = -1;     // K2: the round in which the certified band did not fit the single-wavefront window (the chain then runs with full rows)
+    int cert_fail_round = -1;     // K2: the last round in which the certified band did not fit its class's window (the chain then moves one class up)
+    int cert_level = -1;          // -1: not chosen yet; 1 / 2 / 3: certified band in the 64- / 128- / 256-thread class (256 / 512 / 1 024 columns); 0: full rows
 };
 struct AnchorRec {
     int pread;                    // index into preads
@@ -652,6 +653,14 @@ int lcd_batch_upload(lcd_batch_t *b) {
 static std::atomic<int> g_cell_hint[2] = {{0}, {0}}; // per mode (K1, K2): 0..2, see chain_caps
 static std::atomic<int> g_node_hint{0};                // 0..2: graph capacity estimate, see chain_caps
 static void chain_class(PoaChain &pc, bool noisy);
+// where a K2 chain goes when its certified band outgrew its class's window.  The kernel can run the band in the 128- / 256-thread classes too (512 / 1 024
+// columns; LCD_CERT_LADDER=1), but their windowed rows meet at a workgroup barrier twice per row and measured SLOWER than the systolic full rows they would
+// replace (configs[1]: 46.9 k instead of 52.5 k regions/s with three such chains per batch; ONT shape with every K2 chain there: 6.6 k instead of 13.1 k),
+// so the default is straight to full rows
+static int cert_next_level(const PoaChain &pc) {
+    static const bool ladder = getenv("LCD_CERT_LADDER") && atoi(getenv("LCD_CERT_LADDER")) != 0;
+    return ladder && pc.cert < 3 && (256 << pc.cert) < pc.max_len ? pc.cert + 1 : 0;
+}
 static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vector<PoaRead> &preads, int scale, PoaChain &pc) {
     const int n = (int)C.members.size();
     long long sum = 0; int maxl = 0;
@@ -661,7 +670,9 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     // alignments as the full rows, ~20x fewer cells on HiFi-shape regions); noisy reads' bounds are too loose for a 256-column window (LCD_CERT=2 forces
     // them through it, 0 switches the path off).  A chain whose band outgrows the window comes back with LCD_ERR_CERT and is re-run with full rows.
     const int cert_mode = getenv("LCD_CERT") ? atoi(getenv("LCD_CERT")) : 1; // (read per call: the tests switch it)
-    pc.cert = (C.mode == 1 && C.cert_fail_round < 0 && maxl < 65536 && (cert_mode == 2 || (cert_mode == 1 && !opt.is_ont))) ? 1 : 0; pc.pad_ = 0;
+    int lvl = C.cert_level;
+    if (lvl < 0) lvl = (C.mode == 1 && maxl < 65536 && (cert_mode == 2 || (cert_mode == 1 && !opt.is_ont))) ? 1 : 0;
+    pc.cert = C.mode == 1 ? lvl : 0; pc.pad_ = 0;
     // graph capacity: the worst case is one node per base of every read (sum), the usual case a little more than the longest read.  Sized
     // from an estimate (a few per cent of new nodes per read on top of the backbone; g_node_hint learns noisier data); a chain that runs
     // out (LCD_ERR_NODES / LCD_ERR_EDGES) is re-run with 4x more per retry, up to the worst case.  The worst case for everybody was
@@ -689,7 +700,7 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     const long long rows_est = std::min<long long>(rows_worst, (long long)(rows_f[hint] * maxl) + 64);
     long long band;
     if (C.mode == 0) band = std::min<long long>(maxl + 1, 2ll * (10 + maxl / 100) + 1 + band_x[hint]);
-    else if (pc.cert) band = std::min<long long>(maxl + 1, 260);
+    else if (pc.cert) band = std::min<long long>(maxl + 1, (256 << (pc.cert - 1)) + 4);
     else band = maxl + 1;
     long long cells = rows_est * band;
     // (tried: the single-wavefront class compiled for 64 VGPRs (__launch_bounds__(64, 8): 32 instead of 16 wavefronts per CU, 4 - 8 KB pools): 34 - 37 k instead of
@@ -714,7 +725,7 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
 // afterwards.  Chains are launched in groups of equal (threads, LDS bucket) so that short chains do not pay a long chain's LDS.
 static void chain_class(PoaChain &pc, bool noisy) {
     // DP row width: K2 rows span the whole read (+2 guard columns of the window); K1 rows are the adaptive band plus drift
-    const long long width = pc.cert ? 256 : pc.mode == 1 ? (long long)pc.max_len + 2 : 2ll * (10 + pc.max_len / 100) + 1 + 48;
+    const long long width = pc.cert ? (256 << (pc.cert - 1)) : pc.mode == 1 ? (long long)pc.max_len + 2 : 2ll * (10 + pc.max_len / 100) + 1 + 48;
     int threads, K, wmax; // wmax: window / ring-slot width in columns, a power of two <= 4 * threads (poa_kernel.hip align_windowed)
     // one lane per four columns of the window: 64 / 128 / 256 / 512 / 1024 threads, so that no wavefront of a workgroup idles
     // (a 2 048-column chain in a 1 024-thread workgroup would hold a whole CU's registers with half of its wavefronts parked)
@@ -975,6 +986,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         out_rel[k].resize(nC);
         uint64_t out_tot = 0;
         for (int c = 0; c < nC; ++c) {
+            b->chains[c].cert_level = -1; b->chains[c].cert_fail_round = -1; // (nothing about the certified band is remembered from an earlier run of the same batch)
             chain_caps(b->opt, b->chains[c], preads[k], 1, b->pchains[c]);
             out_rel[k][c] = out_tot; out_tot += lcd_align_up(poa_out_bytes(b->pchains[c].node_cap, b->pchains[c].n_reads), 256);
         }
@@ -1115,7 +1127,11 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                 const int k = chain_batch[which[i]];
                 bs[k]->couts[which[i] - chain_base[k]] = tmp[i];
                 if (tmp[i].status == LCD_ERR_CELLS || tmp[i].status == LCD_ERR_NODES || tmp[i].status == LCD_ERR_EDGES) { again.push_back(which[i]); n_node_ovf += tmp[i].status != LCD_ERR_CELLS; }
-                else if (tmp[i].status == LCD_ERR_CERT && bs[k]->chains[which[i] - chain_base[k]].cert_fail_round < 0) { bs[k]->chains[which[i] - chain_base[k]].cert_fail_round = round; again.push_back(which[i]); ++n_cert_fail; }
+                else if (tmp[i].status == LCD_ERR_CERT && PC(which[i]).cert > 0) { // one class up (512, 1 024 columns), then full rows
+                    ChainRec &CR = bs[k]->chains[which[i] - chain_base[k]];
+                    CR.cert_fail_round = round; CR.cert_level = cert_next_level(PC(which[i]));
+                    again.push_back(which[i]); ++n_cert_fail;
+                }
                 else if (tmp[i].status != LCD_OK) return set_err(-20, "POA kernel status " + std::to_string(tmp[i].status) + " on chain " + std::to_string(which[i] - chain_base[k]));
             }
             if (getenv("LCD_MEM_DEBUG")) {
@@ -2347,7 +2363,11 @@ int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int
         for (size_t i = 0; i < which.size(); ++i) {
             couts[which[i]] = tmp[i];
             if (tmp[i].status == LCD_ERR_CELLS || tmp[i].status == LCD_ERR_NODES || tmp[i].status == LCD_ERR_EDGES) again.push_back(which[i]);
-            else if (tmp[i].status == LCD_ERR_CERT && crec[which[i]].cert_fail_round < 0) { crec[which[i]].cert_fail_round = round; again.push_back(which[i]); }
+            else if (tmp[i].status == LCD_ERR_CERT && pch[which[i]].cert > 0) {
+                ChainRec &CR = crec[which[i]];
+                CR.cert_fail_round = round; CR.cert_level = cert_next_level(pch[which[i]]);
+                again.push_back(which[i]);
+            }
         }
         if (!again.empty()) scale *= 2;
         which.swap(again);

@@ -1686,9 +1686,10 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         const int rem_beg = g.remain[beg_node] - remain_end;
         const unsigned pdo = pd ? lds_off(pd) : 0xffffffffu, ro = lds_off(ring), so = lds_off(sseq);
         int nc = -1;
-        if constexpr (NT == 64) if (wb < 0 && g.cert_on) { // K2 in the single-wavefront class: rows restricted to the certified band
+        if constexpr (NT <= 256) if (wb < 0 && g.cert_on) { // K2 in a narrow class: rows restricted to the certified band (window of 4 * NT columns)
+            constexpr int WINC = 4 * NT;
             if (qlen >= 65536 || ei - bi < 2) { g.status = LCD_ERR_CERT; return 0; }
-            cert_node_arrays(&g, bi, ei);
+            if (wave == 0) cert_node_arrays(&g, bi, ei);   // (wavefront 0; the others only meet the barriers)
             __syncthreads();
             const unsigned long long cells_before = *cells_acc;
             const int ubtop = cert_ubtop(g, ei, qlen, sc);
@@ -1700,12 +1701,21 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
             bool done = false;
             for (int attempt = 0; attempt < 10 && !done; ++attempt, delta *= 2) {
                 const int sest = imax(sbest, ubtop - delta);
-                const int mw = cert_hull(&g, bi, ei, qlen, sest, sc);
+                if (wave == 0) { const int m = cert_hull(&g, bi, ei, qlen, sest, sc); if (lane == 0) sm.bc[6] = m; }
+                __syncthreads();
+                const int mw = sm.bc[6];
                 __syncthreads();
                 if (mw < 0) continue;                                  // not even the source row qualifies: the guess is above the optimum
-                if (mw > 256) { g.status = LCD_ERR_CERT; g.t_plan = 1000000ull + mw; g.t_kahn = (unsigned long long)attempt * 1000000ull + (unsigned)qlen; return 0; } // wider than this class's window: the host re-runs the chain with full rows
+                if (mw > WINC) { g.status = LCD_ERR_CERT; g.t_plan = 1000000ull + mw; g.t_kahn = (unsigned long long)attempt * 1000000ull + (unsigned)qlen; return 0; } // wider than this class's window: the host re-runs the chain one class up
                 wo.status = g.status; wo.score = LCD_NEG;
-                nc = align_windowed<NT, 2, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+                // one, two or four cells per lane by the widest interval (hull widths are computed for 4-cell groups: the narrower variants keep a margin)
+                nc = -1;
+                if constexpr (NT == 64) {
+                    if (mw <= 60) nc = align_windowed<NT, 2, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+                    if (nc < 0 && mw <= 124) { __syncthreads(); nc = align_windowed<NT, 2, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                    if (nc < 0) __syncthreads();
+                }
+                if (nc < 0) nc = align_windowed<NT, 2, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
                 if (nc < 0) { g.status = LCD_ERR_CERT; g.t_plan = 2000000ull + mw; g.t_kahn = (unsigned long long)attempt * 1000000ull + (unsigned)qlen; return 0; }
                 if (wo.status != LCD_OK) { g.status = wo.status; return 0; }
                 g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells;
@@ -2137,7 +2147,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.pl_start = (int *)(ws + L.pl_start); g.pl_pidx = (int *)(ws + L.pl_pidx); g.pl_bonus = (int *)(ws + L.pl_bonus);
     g.pl_rem = (int *)(ws + L.pl_rem); g.pl_base = ws + L.pl_base;
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
-    g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = NT == 64 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0;
+    g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0;
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
     g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - Cfg<NT>::K * 3 * ring_cols) * 4;
     g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0;
