@@ -1010,13 +1010,20 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
 #pragma unroll
         for (int k = 0; k < C; ++k) { nn[k] = LCD_NEG; uu[k] = LCD_NEG; vv[k] = LCD_NEG; }
         int om = 0, oa = 0, ob = 0; // ordinals, one byte per cell
-        bool overflow = false;
         if (fast1) {
             if (f_pb <= f_pe) {
-                if (f_pe - beg + 2 >= WIN || end - f_pb + 1 >= WIN) return -1;
+                // a ring slot is addressed by (column mod WIN): columns of this row that lie a full window away from the predecessor's band would read
+                // that band's values instead of the filler -- rare (bands close to the window's width, shifted against each other), so those rows mask
+                // the loaded values by the predecessor's [beg, end] explicitly instead of giving the whole read up
+                const bool risk = f_pe - beg + 2 >= WIN || end - f_pb + 1 >= WIN;
                 const unsigned S = ring + 4 * f_sp * SLOTW;
                 int hv[C], av[C], bv[C];
-                const int hm = lds_ld(S + 4 * xm); lds_ldc<C>(S + 4 * x, hv); lds_ldc<C>(S + 4 * (WIN + x), av); lds_ldc<C>(S + 4 * (2 * WIN + x), bv);
+                int hm = lds_ld(S + 4 * xm); lds_ldc<C>(S + 4 * x, hv); lds_ldc<C>(S + 4 * (WIN + x), av); lds_ldc<C>(S + 4 * (2 * WIN + x), bv);
+                if (risk) {
+                    if (jb - 1 < f_pb || jb - 1 > f_pe) hm = LCD_GUARD;
+#pragma unroll
+                    for (int k = 0; k < C; ++k) if (jb + k < f_pb || jb + k > f_pe) { hv[k] = LCD_GUARD; av[k] = LCD_GUARD; bv[k] = LCD_GUARD; }
+                }
 #pragma unroll
                 for (int k = 0; k < C; ++k) { nn[k] = imax(LCD_NEG, (k == 0 ? hm : hv[k - 1]) + sk[k] + bz0); uu[k] = imax(LCD_NEG, av[k] + bz0); vv[k] = imax(LCD_NEG, bv[k] + bz0); }
             }
@@ -1026,11 +1033,11 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
             if (t > 1) { pi = glb_ld(g.pl_pidx + p0 + t); bz = glb_ld(g.pl_bonus + p0 + t); LCD_PIN(pi); LCD_PIN(bz); }
             const bool near = idx - pi <= K;
             const int sp = (pi - bi) & (K - 1);
+            bool risk = false; int pb = 0, pe = 0;
             if (BND) {
-                int pb, pe;
                 if (near) { pb = LCD_RL(m_beg, sp); pe = LCD_RL(m_end, sp); } else { pb = g.rbeg[pi]; pe = g.rend[pi]; LCD_PIN(pb); LCD_PIN(pe); }
                 if (pb > pe) continue;
-                if (pe - beg + 2 >= WIN || end - pb + 1 >= WIN) { overflow = true; break; }
+                risk = pe - beg + 2 >= WIN || end - pb + 1 >= WIN; // (see the single-predecessor rows above: masked, not given up)
             }
             int hm, hv[C], av[C], bv[C];
             if (near) {
@@ -1044,6 +1051,11 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
 #pragma unroll
                 for (int k = 0; k < C; ++k) { LCD_PIN(hv[k]); LCD_PIN(av[k]); LCD_PIN(bv[k]); }
             }
+            if (risk) {
+                if (jb - 1 < pb || jb - 1 > pe) hm = LCD_GUARD;
+#pragma unroll
+                for (int k = 0; k < C; ++k) if (jb + k < pb || jb + k > pe) { hv[k] = LCD_GUARD; av[k] = LCD_GUARD; bv[k] = LCD_GUARD; }
+            }
             const int tt = t > 255 ? 255 : t;
 #pragma unroll
             for (int k = 0; k < C; ++k) {
@@ -1056,7 +1068,6 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
                 }
             }
         }
-        if (overflow) return -1;
         if (np > 256) return -1; // ordinals are 8 bits: such a row goes through the generic rows
         // ---- F: A[k] = Hpre[k] + k*e; in-lane inclusive prefix, then one scan pair over the lane totals ----
         int hp[C], spk[C], a1[C], a2[C], p1[C], p2[C];
@@ -1699,14 +1710,29 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
             int delta = g.cert_hist < 0 ? 48 + qlen / 32 : g.cert_hist + g.cert_hist / 4 + 32;
             int sbest = LCD_NEG;
             bool done = false;
-            for (int attempt = 0; attempt < 10 && !done; ++attempt, delta *= 2) {
-                const int sest = imax(sbest, ubtop - delta);
+            auto hull_of = [&](const int sest) { // every row's interval for this score bound (table in g.cert); the widest window a row needs, or -1
                 if (wave == 0) { const int m = cert_hull(&g, bi, ei, qlen, sest, sc); if (lane == 0) sm.bc[6] = m; }
                 __syncthreads();
-                const int mw = sm.bc[6];
+                const int m = sm.bc[6];
                 __syncthreads();
-                if (mw < 0) continue;                                  // not even the source row qualifies: the guess is above the optimum
-                if (mw > WINC) { g.status = LCD_ERR_CERT; g.t_plan = 1000000ull + mw; g.t_kahn = (unsigned long long)attempt * 1000000ull + (unsigned)qlen; return 0; } // wider than this class's window: the host re-runs the chain one class up
+                return m;
+            };
+            for (int attempt = 0; attempt < 10 && !done; ++attempt, delta *= 2) {
+                int sest = imax(sbest, ubtop - delta);
+                int mw = hull_of(sest);
+                bool fitted = false;
+                if (mw > WINC) {
+                    // the intervals of this guess do not fit the window: take the LARGEST slack whose intervals do (they grow with the slack; bisection,
+                    // ~16 instructions per row and step) -- if the alignment over those verifies, nothing wider was needed
+                    int fit = 0, wide = ubtop - sest;
+                    while (wide - fit > 4) { const int mid = (fit + wide) >> 1; const int m = hull_of(ubtop - mid); if (m > WINC) wide = mid; else fit = mid; }
+                    sest = ubtop - fit; mw = hull_of(sest); fitted = true;
+                    if (mw > WINC) { g.status = LCD_ERR_CERT; g.t_plan = 1000000ull + mw; g.t_kahn = (unsigned long long)attempt * 1000000ull + (unsigned)qlen; return 0; }
+                }
+                if (mw < 0) { // not even the source row qualifies: the guess is above the optimum
+                    if (fitted) { g.status = LCD_ERR_CERT; g.t_plan = 4000000ull; return 0; }
+                    continue;
+                }
                 wo.status = g.status; wo.score = LCD_NEG;
                 // one, two or four cells per lane by the widest interval (hull widths are computed for 4-cell groups: the narrower variants keep a margin)
                 nc = -1;
@@ -1725,6 +1751,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
                     if (S >= sest) { done = true; g.cert_hist = imax(g.cert_hist, ubtop - S); }
                 }
                 __syncthreads();
+                if (!done && fitted) { g.status = LCD_ERR_CERT; g.t_plan = 5000000ull + mw; return 0; } // the optimum is below every bound whose intervals fit: the window is too narrow for this read
             }
             if (!done) { g.status = LCD_ERR_CERT; g.t_plan = 3000000ull; return 0; }
             g.alg_adjust += (long long)(ei - bi) * (qlen + 1) - (long long)(*cells_acc - cells_before); // what align_unbanded would have counted for this read
