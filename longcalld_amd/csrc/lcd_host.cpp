@@ -751,7 +751,10 @@ static void chain_class(PoaChain &pc, bool noisy) {
       // too (+6 % over 16 KB).  LCD_LDS_CAP_KB overrides.
         static const int cap_env = getenv("LCD_LDS_CAP_KB") ? atoi(getenv("LCD_LDS_CAP_KB")) : -1;
         const int cap_kb = cap_env >= 0 ? cap_env : 8; (void)noisy;
-        if (cap_kb > 0 && threads == 64) need = std::max(dp_bytes, std::min<long long>(need, (long long)cap_kb << 10));
+        // (tried: certified-band K2 chains -- few, some long: 35 reads x 3.7 kb is the critical path of a submission, a quarter of it re-sorts -- with the pool
+        //  the re-sort wants (32 / 64 KB instead of the cap): more launch groups of fewer chains each, 42 k / 30 k instead of 43 k regions/s at 20 batches)
+        const int cap_here = cap_kb;
+        if (cap_here > 0 && threads == 64) need = std::max(dp_bytes, std::min<long long>(need, (long long)cap_here << 10));
     }
     // LDS per workgroup decides how many single-wavefront chains share a CU (160 KB, 16 wavefronts at 128 VGPRs), and those chains are
     // most of the work: fine-grained buckets; every (threads, bucket) group is one launch, a few streams run the groups (launch_poa_grouped)
