@@ -752,7 +752,8 @@ static void chain_class(PoaChain &pc, bool noisy) {
         static const int cap_env = getenv("LCD_LDS_CAP_KB") ? atoi(getenv("LCD_LDS_CAP_KB")) : -1;
         const int cap_kb = cap_env >= 0 ? cap_env : 8; (void)noisy;
         // (tried: certified-band K2 chains -- few, some long: 35 reads x 3.7 kb is the critical path of a submission, a quarter of it re-sorts -- with the pool
-        //  the re-sort wants (32 / 64 KB instead of the cap): more launch groups of fewer chains each, 42 k / 30 k instead of 43 k regions/s at 20 batches)
+        //  the re-sort wants (32 / 64 KB instead of the cap): 42 k / 30 k instead of 43 k regions/s at 20 batches; the same for the long ones only (>= 1 000 /
+        //  1 500 bases): 30 k / 28 k)
         const int cap_here = cap_kb;
         if (cap_here > 0 && threads == 64) need = std::max(dp_bytes, std::min<long long>(need, (long long)cap_here << 10));
     }
@@ -1124,7 +1125,8 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             std::vector<PoaChainOut> tmp(sub.size());
             HIPCHK(hipMemcpyAsync(tmp.data(), L->d_poa_outs.p, sub.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            { float kms = 0; hipEventElapsedTime(&kms, L->ev[6], L->ev[7]); for (int k = 0; k < nb; ++k) { bs[k]->st.ms_poa_kernel += kms; bs[k]->st.n_poa_launches++; } }
+            { float kms = 0; hipEventElapsedTime(&kms, L->ev[6], L->ev[7]); for (int k = 0; k < nb; ++k) { bs[k]->st.ms_poa_kernel += kms; bs[k]->st.n_poa_launches++; }
+              if (getenv("LCD_MEM_DEBUG")) fprintf(stderr, "[mem] round %d: %zu chains, POA kernels %.1f ms\n", round, which.size(), kms); }
             std::vector<size_t> again; size_t n_node_ovf = 0, n_cert_fail = 0;
             for (size_t i = 0; i < which.size(); ++i) {
                 const int k = chain_batch[which[i]];
