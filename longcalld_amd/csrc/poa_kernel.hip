@@ -1507,6 +1507,14 @@ __device__ __attribute__((noinline)) void cert_node_arrays(const Ctx *gp_, const
         LCD_PIN(w_np); LCD_PIN(w_p0); LCD_PIN(w_pi0); LCD_PIN(w_b0); LCD_PIN(w_pi1); LCD_PIN(w_b1);
         int cur_mn = CERT_INF, cur_mx = -1, cur_b = LCD_NEG;
         const int nrow = imin(64, ei - base);
+        // a block whose rows all hang on the row before them (the backbone between two bubbles: most blocks) is three prefix sums
+        const bool chain_row = ri >= ei || ri == bi || (w_np == 1 && w_pi0 == ri - 1);
+        if (__ballot(!chain_row) == 0) {
+            const int first = base == bi ? 1 : 0; // (lane 0 of the first block is the source itself)
+            const int s_mn = first ? 0 : LCD_RL(prev_mn, 63), s_mx = first ? 0 : LCD_RL(prev_mx, 63), s_b = first ? 0 : LCD_RL(prev_b, 63);
+            const int cb = scan_add(lane >= first && ri < ei ? w_b0 : 0);
+            if (s_mx >= 0 && ri < ei) { cur_mn = s_mn + lane + 1 - first; cur_mx = s_mx + lane + 1 - first; cur_b = s_b + cb; }
+        } else
         for (int k = 0; k < nrow; ++k) {
             int mn = CERT_INF, mx = -1, bb = LCD_NEG;
             if (base + k == bi) { mn = 0; mx = 0; bb = 0; }
@@ -1568,6 +1576,20 @@ __device__ __attribute__((noinline)) void cert_node_arrays(const Ctx *gp_, const
         }
         LCD_PIN(w_np); LCD_PIN(w_p0); LCD_PIN(w_pi0); LCD_PIN(w_b0); LCD_PIN(w_pi1); LCD_PIN(w_b1); LCD_PIN(cur_mn); LCD_PIN(cur_mx); LCD_PIN(cur_b);
         const int nrow = imin(64, ei - base);
+        const bool chain_row = ri >= ei || ri == bi || (w_np == 1 && w_pi0 == ri - 1);
+        if (__ballot(!chain_row) == 0) {
+            // every row's only predecessor is the row before it: what was pushed into a row from outside the block reaches the rows below it along the
+            // backbone -- (min, +) / (max, +) suffix scans over the lanes (lane order reversed, prefix scan, reversed back)
+            const int rl = 63 - lane;
+            const int cbl = scan_add(ri < ei && ri != bi ? w_b0 : 0);                      // bonus of the backbone edges up to this row
+            const int kmn = cur_mn + lane, kmx = cur_mx >= 0 ? cur_mx + lane : -CERT_INF, kb = cur_mx >= 0 ? cur_b + cbl : 2 * LCD_NEG;
+            const int smn = __shfl(scan_min(__shfl(kmn, rl)), rl), smx = __shfl(scan_max(__shfl(kmx, rl)), rl), sb = __shfl(scan_max(__shfl(kb, rl)), rl);
+            if (smx > -CERT_INF / 2 && ri < ei) { cur_mn = smn - lane; cur_mx = smx - lane; cur_b = sb - cbl; } else { cur_mn = CERT_INF; cur_mx = -1; cur_b = LCD_NEG; }
+            if (base > bi) { // the block's first row pushes to the last row of the block below
+                const int mx0 = LCD_RL(cur_mx, 0);
+                if (mx0 >= 0) push(base - 1, LCD_RL(cur_mn, 0) + 1, mx0 + 1, LCD_RL(cur_b, 0) + LCD_RL(w_b0, 0));
+            }
+        } else
         for (int k = nrow - 1; k >= 0; --k) {
             const int mx = LCD_RL(cur_mx, k);
             if (mx < 0 || base + k == bi) continue; // the sink cannot be reached from this row / the source has no predecessor
