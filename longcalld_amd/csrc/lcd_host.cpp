@@ -163,7 +163,7 @@ struct ChainRec {
     std::vector<int> members;     // indices into the region's sorted read list
     int read0;                    // first PoaRead
     int cert_fail_round = -1;     // K2: the last round in which the certified band did not fit its class's window (the chain then moves one class up)
-    int cert_level = -1;          // -1: not chosen yet; 1 / 2 / 3: certified band in the 64- / 128- / 256-thread class (256 / 512 / 1 024 columns); 0: full rows
+    int cert_level = -1;          // -1: not chosen yet; 1: certified band in the 64-thread class; 2: in the 256-thread class, rows on wavefront 0 (long chains); 0: full rows
 };
 struct AnchorRec {
     int pread;                    // index into preads
@@ -653,14 +653,10 @@ int lcd_batch_upload(lcd_batch_t *b) {
 static std::atomic<int> g_cell_hint[2] = {{0}, {0}}; // per mode (K1, K2): 0..2, see chain_caps
 static std::atomic<int> g_node_hint{0};                // 0..2: graph capacity estimate, see chain_caps
 static void chain_class(PoaChain &pc, bool noisy);
-// where a K2 chain goes when its certified band outgrew its class's window.  The kernel can run the band in the 128- / 256-thread classes too (512 / 1 024
-// columns; LCD_CERT_LADDER=1), but their windowed rows meet at a workgroup barrier twice per row and measured SLOWER than the systolic full rows they would
-// replace (configs[1]: 46.9 k instead of 52.5 k regions/s with three such chains per batch; ONT shape with every K2 chain there: 6.6 k instead of 13.1 k),
-// so the default is straight to full rows
-static int cert_next_level(const PoaChain &pc) {
-    static const bool ladder = getenv("LCD_CERT_LADDER") && atoi(getenv("LCD_CERT_LADDER")) != 0;
-    return ladder && pc.cert < 3 && (256 << pc.cert) < pc.max_len ? pc.cert + 1 : 0;
-}
+// where a K2 chain goes when its certified band outgrew the window: full rows.  (Tried: the band in multi-wavefront windowed rows of 512 / 1 024 columns first;
+// their rows meet at a workgroup barrier twice per row and measured SLOWER than the systolic full rows they would replace -- configs[1]: 46.9 k instead of
+// 52.5 k regions/s with three such chains per batch; ONT shape with every K2 chain there: 6.6 k instead of 13.1 k)
+static int cert_next_level(const PoaChain &) { return 0; }
 static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vector<PoaRead> &preads, int scale, PoaChain &pc) {
     const int n = (int)C.members.size();
     long long sum = 0; int maxl = 0;
@@ -671,7 +667,12 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     // them through it, 0 switches the path off).  A chain whose band outgrows the window comes back with LCD_ERR_CERT and is re-run with full rows.
     const int cert_mode = getenv("LCD_CERT") ? atoi(getenv("LCD_CERT")) : 1; // (read per call: the tests switch it)
     int lvl = C.cert_level;
-    if (lvl < 0) lvl = (C.mode == 1 && maxl < 65536 && (cert_mode == 2 || (cert_mode == 1 && !opt.is_ont))) ? 1 : 0;
+    // (Long chains are the critical path of a submission, and in a 64-thread workgroup a third to a half of such a chain is the per-read work around the rows --
+    // graph update, re-sort, plan: parallel over the nodes.  LCD_CERT_SOLO_LEN=n gives chains of reads >= n bases a 256-thread workgroup whose wavefront 0 runs
+    // the same rows (poa_kernel.hip align_windowed<.., SOLO>).  Measured slower at every threshold -- 20 batches: 36 - 42 k instead of 45 k regions/s, 2 x 32
+    // batches: 52 k instead of 66 k -- so it is off by default.)
+    static const int solo_len = getenv("LCD_CERT_SOLO_LEN") ? atoi(getenv("LCD_CERT_SOLO_LEN")) : 0;
+    if (lvl < 0) lvl = (C.mode == 1 && maxl < 65536 && (cert_mode == 2 || (cert_mode == 1 && !opt.is_ont))) ? (solo_len > 0 && maxl >= solo_len ? 2 : 1) : 0;
     pc.cert = C.mode == 1 ? lvl : 0; pc.pad_ = 0;
     // graph capacity: the worst case is one node per base of every read (sum), the usual case a little more than the longest read.  Sized
     // from an estimate (a few per cent of new nodes per read on top of the backbone; g_node_hint learns noisier data); a chain that runs
@@ -700,7 +701,7 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     const long long rows_est = std::min<long long>(rows_worst, (long long)(rows_f[hint] * maxl) + 64);
     long long band;
     if (C.mode == 0) band = std::min<long long>(maxl + 1, 2ll * (10 + maxl / 100) + 1 + band_x[hint]);
-    else if (pc.cert) band = std::min<long long>(maxl + 1, (256 << (pc.cert - 1)) + 4);
+    else if (pc.cert) band = std::min<long long>(maxl + 1, 260);
     else band = maxl + 1;
     long long cells = rows_est * band;
     // (tried: the single-wavefront class compiled for 64 VGPRs (__launch_bounds__(64, 8): 32 instead of 16 wavefronts per CU, 4 - 8 KB pools): 34 - 37 k instead of
@@ -725,7 +726,7 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
 // afterwards.  Chains are launched in groups of equal (threads, LDS bucket) so that short chains do not pay a long chain's LDS.
 static void chain_class(PoaChain &pc, bool noisy) {
     // DP row width: K2 rows span the whole read (+2 guard columns of the window); K1 rows are the adaptive band plus drift
-    const long long width = pc.cert ? (256 << (pc.cert - 1)) : pc.mode == 1 ? (long long)pc.max_len + 2 : 2ll * (10 + pc.max_len / 100) + 1 + 48;
+    const long long width = pc.cert == 1 ? 256 : pc.cert >= 2 ? 1024 : pc.mode == 1 ? (long long)pc.max_len + 2 : 2ll * (10 + pc.max_len / 100) + 1 + 48;
     int threads, K, wmax; // wmax: window / ring-slot width in columns, a power of two <= 4 * threads (poa_kernel.hip align_windowed)
     // one lane per four columns of the window: 64 / 128 / 256 / 512 / 1024 threads, so that no wavefront of a workgroup idles
     // (a 2 048-column chain in a 1 024-thread workgroup would hold a whole CU's registers with half of its wavefronts parked)

@@ -855,7 +855,12 @@ template <int C> __device__ __forceinline__ void glb_stc(int *p, const int (&v)[
 // lane means proportionally fewer instructions per row for the same band).
 // MODE 0: rows span the whole window (w = qlen); 1: the oracle's adaptive band; 2: the rows' column intervals come from a table (g.cert hull, see
 // align_certified: cells outside an interval count as unreachable, exactly like cells outside an adaptive band)
-template <int NT, int MODE, int C>
+template <bool SOLO> __device__ __forceinline__ void win_sync() {
+    if (SOLO) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else __syncthreads();
+}
+// SOLO: the function is run by wavefront 0 of a WIDER workgroup (NT = 64 here, the others wait at a barrier of their own): its workgroup barriers become waits
+// of the one wavefront on its own memory operations
+template <int NT, int MODE, int C, bool SOLO = false>
 __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const unsigned ring_, const unsigned sq1_, const unsigned pd_ /* 0xffffffff: none */, const LcdScoring sc_, const int w_,
                               const int bi_, const int ei_, const int rem_beg_, const uint8_t *seq_hbm_, const int qlen_,
                               WinOut *wo_) {
@@ -914,7 +919,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
     int m_beg = 1, m_end = 0, m_ml = 0, m_mr = 0;
     if (lane == 0) { m_beg = 0; m_end = end0; }
     unsigned long long cused = 0, oused = 0, ncell = (unsigned long long)end0 + 1;
-    __syncthreads();
+    win_sync<SOLO>();
     const long long t_dp0 = clock64();
     int wbase = -(1 << 20);
     int w_p0 = 0, w_np = 0, w_rem = 1 << 30, w_vb = 4, w_pi0 = 0, w_b0 = 0, w_pi1 = 0, w_b1 = 0, w_sp = 0, w_hull = 1;
@@ -962,7 +967,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
                 int pb, pe, pml, pmr;
                 if (idx - pi <= K) { const int sp = (pi - bi) & (K - 1); pb = LCD_RL(m_beg, sp); pe = LCD_RL(m_end, sp); pml = LCD_RL(m_ml, sp); pmr = LCD_RL(m_mr, sp); }
                 else {
-                    if (!synced) { __syncthreads(); synced = true; } // far row: its metadata / spilled values were stored to HBM earlier
+                    if (!synced) { win_sync<SOLO>(); synced = true; } // far row: its metadata / spilled values were stored to HBM earlier
                     pb = g.rbeg[pi]; pe = g.rend[pi]; pml = g.ml[pi]; pmr = g.mr[pi];
                     LCD_PIN(pb); LCD_PIN(pe); LCD_PIN(pml); LCD_PIN(pmr);
                 }
@@ -1044,7 +1049,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
                 const unsigned S = ring + 4 * sp * SLOTW;
                 hm = lds_ld(S + 4 * xm); lds_ldc<C>(S + 4 * x, hv); lds_ldc<C>(S + 4 * (WIN + x), av); lds_ldc<C>(S + 4 * (2 * WIN + x), bv);
             } else {
-                if (!synced) { __syncthreads(); synced = true; }
+                if (!synced) { win_sync<SOLO>(); synced = true; }
                 const int *G = g.spill + (size_t)(unsigned)glb_ld((const int *)g.spoff + pi) * SLOTW;
                 hm = glb_ld(G + xm); glb_ldc<C>(G + x, hv); glb_ldc<C>(G + WIN + x, av); glb_ldc<C>(G + 2 * WIN + x, bv);
                 LCD_PIN(hm);
@@ -1167,17 +1172,17 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
         ncell += (unsigned long long)(end - beg + 1);
         lds_barrier<NT>(); // publish the ring slot to the other wavefronts before the next row's phase A
     }
-    __syncthreads();
+    win_sync<SOLO>();
     wo->cells = ncell;
     const long long t_bt0 = clock64();
     wo->t_dp = (unsigned long long)(t_bt0 - t_dp0);
     if (wave == 0) code_backtrack(g, sm, pd, bi, ei, qlen, SLOTW, WM, lane, CM);
-    __syncthreads();
+    win_sync<SOLO>();
     const int n_cig = sm.bc[0];
     wo->status = sm.bc[1];
     wo->cig_pos = sm.bc[4];
     wo->score = sm.bc[5];
-    __syncthreads();
+    win_sync<SOLO>();
     wo->t_bt = (unsigned long long)(clock64() - t_bt0);
     return n_cig;
 }
@@ -1719,8 +1724,12 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         const int rem_beg = g.remain[beg_node] - remain_end;
         const unsigned pdo = pd ? lds_off(pd) : 0xffffffffu, ro = lds_off(ring), so = lds_off(sseq);
         int nc = -1;
-        if constexpr (NT <= 256) if (wb < 0 && g.cert_on) { // K2 in a narrow class: rows restricted to the certified band (window of 4 * NT columns)
-            constexpr int WINC = 4 * NT;
+        if constexpr (NT <= 256) if (wb < 0 && g.cert_on) { // K2 with rows restricted to the certified band (256-column window of ONE wavefront)
+            // 64-thread class: the workgroup IS that wavefront.  256-thread class (long chains: the critical path of a submission): wavefront 0 runs the same
+            // rows while the others wait; the per-read phases around them (graph update, re-sort, plan), a third to a half of such a chain in a 64-thread
+            // workgroup, run on all four wavefronts
+            constexpr int WINC = 256;
+            constexpr bool SOLO = NT > 64;
             if (qlen >= 65536 || ei - bi < 2) { g.status = LCD_ERR_CERT; return 0; }
             if (wave == 0) cert_node_arrays(&g, bi, ei);   // (wavefront 0; the others only meet the barriers)
             __syncthreads();
@@ -1758,12 +1767,17 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
                 wo.status = g.status; wo.score = LCD_NEG;
                 // one, two or four cells per lane by the widest interval (hull widths are computed for 4-cell groups: the narrower variants keep a margin)
                 nc = -1;
-                if constexpr (NT == 64) {
-                    if (mw <= 60) nc = align_windowed<NT, 2, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
-                    if (nc < 0 && mw <= 124) { __syncthreads(); nc = align_windowed<NT, 2, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
-                    if (nc < 0) __syncthreads();
+                if (!SOLO || wave == 0) {
+                    if (mw <= 60) nc = align_windowed<64, 2, 1, SOLO>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+                    if (nc < 0 && mw <= 124) { win_sync<SOLO>(); nc = align_windowed<64, 2, 2, SOLO>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                    if (nc < 0) { win_sync<SOLO>(); nc = align_windowed<64, 2, 4, SOLO>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                    if (SOLO && lane == 0) { g_wide.ppi[0] = nc; g_wide.ppi[1] = wo.status; g_wide.ppi[2] = wo.score; g_wide.ppi[3] = wo.cig_pos; g_wide.po[0] = (unsigned)wo.cells; g_wide.po[1] = (unsigned)(wo.cells >> 32); }
                 }
-                if (nc < 0) nc = align_windowed<NT, 2, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+                if (SOLO) { // the result of wavefront 0 to everybody
+                    __syncthreads();
+                    nc = g_wide.ppi[0]; wo.status = g_wide.ppi[1]; wo.score = g_wide.ppi[2]; wo.cig_pos = g_wide.ppi[3]; wo.cells = g_wide.po[0] | ((unsigned long long)g_wide.po[1] << 32); wo.t_dp = wo.t_bt = 0;
+                    __syncthreads();
+                }
                 if (nc < 0) { g.status = LCD_ERR_CERT; g.t_plan = 2000000ull + mw; g.t_kahn = (unsigned long long)attempt * 1000000ull + (unsigned)qlen; return 0; }
                 if (wo.status != LCD_OK) { g.status = wo.status; return 0; }
                 g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells;
