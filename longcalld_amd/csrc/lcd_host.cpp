@@ -671,7 +671,7 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     // graph update, re-sort, plan: parallel over the nodes.  LCD_CERT_SOLO_LEN=n gives chains of reads >= n bases a 256-thread workgroup whose wavefront 0 runs
     // the same rows (poa_kernel.hip align_windowed<.., SOLO>).  Measured slower at every threshold -- 20 batches: 36 - 42 k instead of 45 k regions/s, 2 x 32
     // batches: 52 k instead of 66 k -- so it is off by default.)
-    static const int solo_len = getenv("LCD_CERT_SOLO_LEN") ? atoi(getenv("LCD_CERT_SOLO_LEN")) : 0;
+    const int solo_len = getenv("LCD_CERT_SOLO_LEN") ? atoi(getenv("LCD_CERT_SOLO_LEN")) : 0; // (read per call: a test switches it)
     if (lvl < 0) lvl = (C.mode == 1 && maxl < 65536 && (cert_mode == 2 || (cert_mode == 1 && !opt.is_ont))) ? (solo_len > 0 && maxl >= solo_len ? 2 : 1) : 0;
     pc.cert = C.mode == 1 ? lvl : 0; pc.pad_ = 0;
     // graph capacity: the worst case is one node per base of every read (sum), the usual case a little more than the longest read.  Sized
