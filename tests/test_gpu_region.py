@@ -394,3 +394,17 @@ def test_arena_slots_under_contention(lcd, monkeypatch):
     monkeypatch.setenv("LCD_ARENA_SLOT_CUS", "2")
     got = _run_batch(lcd, regs)[3]
     assert got == ref and ref != 0
+
+
+def test_certified_band_equals_full_rows_at_scale(lcd, monkeypatch):
+    """600 HiFi-shape regions (the phase-set-less ones run K2: ~90 chains of 20-50 reads) with the certified band (default) and with full rows (LCD_CERT=0):
+    the same digest over every consensus, cluster and alignment string, fewer cells computed, the same cells of the reference's algorithm accounted"""
+    from longcalld_amd import jobs
+    regs = jobs.make_regions(777, 600, jobs.HIFI)
+    monkeypatch.setenv("LCD_CERT", "1")
+    _, _, st1, d1 = _run_batch(lcd, regs)
+    monkeypatch.setenv("LCD_CERT", "0")
+    _, _, st0, d0 = _run_batch(lcd, regs)
+    assert d1 == d0
+    assert st1["poa_cells"] == st0["poa_cells"] == st0["poa_cells_computed"]
+    assert st1["poa_cells_computed"] * 2 < st0["poa_cells_computed"]
