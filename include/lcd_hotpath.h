@@ -231,6 +231,9 @@ int lcd_batch_get_stats(lcd_batch_t *b, lcd_batch_stats_t *st);
 int lcd_batch_k4_jobs(lcd_batch_t *b, int cap, uint64_t *t_off, int *tlen, uint64_t *q_off, int *qlen, const uint8_t **pool, uint64_t *pool_len);
 /* a 64-bit FNV-1a digest over every region's results (n_cons, clusters, all alignment rows) -- cheap whole-batch parity check */
 uint64_t lcd_batch_digest(lcd_batch_t *b);
+/* lcd_batch_region_result for every region of a downloaded batch, results freed again: the host-side cost of holding every result the way the per-call
+ * mirror hands it over (malloc()'d rows), without the digest's hashing; returns the bytes of alignment rows handed out */
+uint64_t lcd_batch_materialize(lcd_batch_t *b);
 
 /* ---- SURVEY 8(f) f2, first part: EQX CIGARs -> digar lists + each read's noisy windows (additive) ----
  * == collect_digar_from_eqx_cigar (src/bam_utils.c:701-842, with push_xid_size_queue_win :161-200) for all reads of a chunk in one launch.

@@ -300,6 +300,10 @@ class RegionBatch:
     def digest(self):
         return int(self.lib.lcd_batch_digest(self.h))
 
+    def materialize(self):
+        """every region's results as the per-call mirror returns them (malloc()'d), freed again -> bytes of alignment rows"""
+        return int(self.lib.lcd_batch_materialize(self.h))
+
     def sorted_ids(self, region):
         out = np.zeros(max(self.n_reads[region], 1), np.int32)
         n = self.lib.lcd_batch_region_sorted_ids(self.h, region, out.ctypes.data_as(i32p))

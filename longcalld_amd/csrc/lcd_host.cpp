@@ -1735,6 +1735,27 @@ int lcd_batch_k4_jobs(lcd_batch_t *b, int cap, uint64_t *t_off, int *tlen, uint6
     return n;
 }
 
+// what a caller pays after lcd_batch_download to hold every result the way lcd_collect_noisy_reg_aln_strs hands it over: lcd_batch_region_result for every
+// region (malloc()'d cluster id lists and aln_str_t rows), freed again; returns the bytes of alignment rows that were handed out.  (lcd_batch_digest does the same
+// AND hashes every byte, which is most of its time: bench.py's PCIe-inclusive figures use this one for the clock and the digest for the check.)
+uint64_t lcd_batch_materialize(lcd_batch_t *b) {
+    if (!b->downloaded) return 0;
+    uint64_t bytes = 0;
+    for (size_t ri = 0; ri < b->regs.size(); ++ri) {
+        const RegionRec &R = b->regs[ri];
+        if (b->opt.collect_noisy_vars == 2) continue; // the strings stay in HBM: the variant records are already in the host block lcd_batch_download filled
+        std::vector<int> cn(2, 0); std::vector<int *> ids(2, nullptr);
+        std::vector<lcd_aln_str_t> a0(1 + 2 * (size_t)std::max(R.n_reads, 0)), a1(a0.size());
+        memset(a0.data(), 0, a0.size() * sizeof(lcd_aln_str_t)); memset(a1.data(), 0, a1.size() * sizeof(lcd_aln_str_t));
+        lcd_aln_str_t *as[2] = {a0.data(), a1.data()};
+        lcd_batch_region_result(b, (int)ri, cn.data(), ids.data(), as);
+        for (int c = 0; c < 2; ++c) {
+            free(ids[c]);
+            for (size_t j = 0; j < a0.size(); ++j) { lcd_aln_str_t &s = as[c][j]; if (!s.target_aln) continue; bytes += 2ull * (uint64_t)std::max(s.aln_len, 0); free(s.target_aln); }
+        }
+    }
+    return bytes;
+}
 uint64_t lcd_batch_digest(lcd_batch_t *b) {
     if (!b->downloaded) return 0;
     uint64_t h = 1469598103934665603ull;
