@@ -223,7 +223,8 @@ struct lcd_batch_s {
     std::vector<uint64_t> rr_off; std::vector<int> rr_len, rr_stride; std::vector<uint8_t> h_rr; uint64_t rr_bytes = 0;
     // candidate variants (opt.collect_noisy_vars): per resolved region, offsets into d_var_out / h_var
     std::vector<VarRegionRec> vregs; std::vector<int> vreg_of; std::vector<uint8_t> h_var; uint64_t var_bytes = 0;
-    std::vector<std::unique_ptr<DevBuf>> retry_out; // output blocks of chains re-run with a larger graph capacity (live until the next run)
+    std::vector<std::unique_ptr<DevBuf>> retry_out; // output blocks of chains re-run with a larger graph capacity (live until the next run; the buffers
+    size_t retry_out_used = 0;                      // themselves are kept and re-used: freeing ~60 of them per noisy-read submission synchronised the device each time)
     // the chains' work arenas live in d_poa_arena and, when a later submission needs more, in additional chunks: growing by a chunk costs the difference,
     // re-allocating tens of GB costs seconds (and the pools' slot sizes make the total jump by a third from one set of chunks to the next)
     std::vector<std::unique_ptr<DevBuf>> arena_extra;
@@ -1014,7 +1015,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             return a < c2; });
         int scale = 1;
         std::map<size_t, uint64_t> retry_out_off; // chains whose output block moved to a retry buffer
-        for (int k = 0; k < nb; ++k) bs[k]->retry_out.clear();
+        for (int k = 0; k < nb; ++k) bs[k]->retry_out_used = 0;
         static const bool use_slots = !(getenv("LCD_ARENA_SLOTS") && atoi(getenv("LCD_ARENA_SLOTS")) == 0);
         uint64_t cu_rank_addr = 0; int n_cu = g_n_cus;
         if (use_slots) { const int rc3 = cu_rank_table(st, &cu_rank_addr, &n_cu); if (rc3) return rc3; }
@@ -1032,9 +1033,10 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                     chain_caps(bs[k]->opt, CR, preads[k], CR.cert_fail_round < 0 ? scale : std::max(1, scale >> (CR.cert_fail_round + 1)), pc);
                     if (pc.node_cap > old_cap) { // the chain's output block (cons + MSA rows of node_cap columns) grows with it: a fresh block
                         lcd_batch_t *b = bs[k];
-                        b->retry_out.emplace_back(new DevBuf());
-                        if (b->retry_out.back()->ensure(poa_out_bytes(pc.node_cap, pc.n_reads) + 256)) return -11;
-                        pc.out_off = b->retry_out.back()->addr(); retry_out_off[which[i]] = pc.out_off;
+                        if (b->retry_out_used == b->retry_out.size()) b->retry_out.emplace_back(new DevBuf());
+                        DevBuf *ro2 = b->retry_out[b->retry_out_used++].get();
+                        if (ro2->ensure(poa_out_bytes(pc.node_cap, pc.n_reads) + 256)) return -11;
+                        pc.out_off = ro2->addr(); retry_out_off[which[i]] = pc.out_off;
                     } else pc.out_off = retry_out_off.count(which[i]) ? retry_out_off[which[i]] : bs[k]->d_poa_out.addr() + out_rel[k][c];
                 }
                 need[i] = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads, pc.spill_x, pc.cert).total;

@@ -1690,6 +1690,89 @@ __device__ __attribute__((noinline)) int cert_hull(const Ctx *gp_, const int bi_
     return bad ? -1 : maxw;
 }
 
+// The certified-band alignment of one read (see the comment block above cert_node_arrays).  Not inlined: inside align_to_subgraph -- i.e. inside the chain
+// kernel's body -- its loops and lambdas cost every chain of every class another 50 - 110 B of scratch (the kernel body is what spills).
+// Returns the number of cigar entries (status LCD_OK), or 0 with gp->status = LCD_ERR_CERT / an error.
+template <int NT>
+__device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned ro, const unsigned so, const unsigned pdo, const LcdScoring sc, const int w, const int bi, const int ei,
+                                                         const int rem_beg, const uint8_t *seq_hbm, const int qlen, unsigned long long *cells_acc) {
+    Smem &sm = g_smem;
+    Ctx &g = *gp; // (the caller's context itself: the few fields this function changes are changed in place)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0; wo.t_plan = wo.t_poll = 0; wo.score = LCD_NEG;
+    int nc = -1;
+    auto leave = [&](const int r) { return r; };
+            // 64-thread class: the workgroup IS that wavefront.  256-thread class (long chains: the critical path of a submission): wavefront 0 runs the same
+            // rows while the others wait; the per-read phases around them (graph update, re-sort, plan), a third to a half of such a chain in a 64-thread
+            // workgroup, run on all four wavefronts
+            constexpr int WINC = 256;
+            constexpr bool SOLO = NT > 64;
+            if (qlen >= 65536 || ei - bi < 2) { g.status = LCD_ERR_CERT; return leave(0); }
+            if (wave == 0) cert_node_arrays(&g, bi, ei);   // (wavefront 0; the others only meet the barriers)
+            __syncthreads();
+            const unsigned long long cells_before = *cells_acc;
+            const int ubtop = cert_ubtop(g, ei, qlen, sc);
+            // the guess: the bound at the end cell minus a slack -- the largest one an earlier read of this chain needed (+ 25 % + 32), or a small one for
+            // the first alignment.  An attempt that comes back below its guess doubles the slack; the best score seen so far is a TRUE lower bound of the
+            // optimum and takes over as soon as it is the tighter of the two (that attempt cannot fail)
+            int delta = g.cert_hist < 0 ? 48 + qlen / 32 : g.cert_hist + g.cert_hist / 4 + 32;
+            int sbest = LCD_NEG;
+            bool done = false;
+            auto hull_of = [&](const int sest) { // every row's interval for this score bound (table in g.cert); the widest window a row needs, or -1
+                if (wave == 0) { const int m = cert_hull(&g, bi, ei, qlen, sest, sc); if (lane == 0) sm.bc[6] = m; }
+                __syncthreads();
+                const int m = sm.bc[6];
+                __syncthreads();
+                return m;
+            };
+            for (int attempt = 0; attempt < 10 && !done; ++attempt, delta *= 2) {
+                int sest = imax(sbest, ubtop - delta);
+                int mw = hull_of(sest);
+                bool fitted = false;
+                if (mw > WINC) {
+                    // the intervals of this guess do not fit the window: take the LARGEST slack whose intervals do (they grow with the slack; bisection,
+                    // ~16 instructions per row and step) -- if the alignment over those verifies, nothing wider was needed
+                    int fit = 0, wide = ubtop - sest;
+                    while (wide - fit > 4) { const int mid = (fit + wide) >> 1; const int m = hull_of(ubtop - mid); if (m > WINC) wide = mid; else fit = mid; }
+                    sest = ubtop - fit; mw = hull_of(sest); fitted = true;
+                    if (mw > WINC) { g.status = LCD_ERR_CERT; g.t_plan = 1000000ull + mw; g.t_kahn = (unsigned long long)attempt * 1000000ull + (unsigned)qlen; return leave(0); }
+                }
+                if (mw < 0) { // not even the source row qualifies: the guess is above the optimum
+                    if (fitted) { g.status = LCD_ERR_CERT; g.t_plan = 4000000ull; return leave(0); }
+                    continue;
+                }
+                wo.status = g.status; wo.score = LCD_NEG;
+                // one, two or four cells per lane by the widest interval (hull widths are computed for 4-cell groups: the narrower variants keep a margin)
+                nc = -1;
+                if (!SOLO || wave == 0) {
+                    if (mw <= 60) nc = align_windowed<64, 2, 1, SOLO>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+                    if (nc < 0 && mw <= 124) { win_sync<SOLO>(); nc = align_windowed<64, 2, 2, SOLO>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                    if (nc < 0) { win_sync<SOLO>(); nc = align_windowed<64, 2, 4, SOLO>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                    if (SOLO && lane == 0) { g_wide.ppi[0] = nc; g_wide.ppi[1] = wo.status; g_wide.ppi[2] = wo.score; g_wide.ppi[3] = wo.cig_pos; g_wide.po[0] = (unsigned)wo.cells; g_wide.po[1] = (unsigned)(wo.cells >> 32); }
+                }
+                if (SOLO) { // the result of wavefront 0 to everybody
+                    __syncthreads();
+                    nc = g_wide.ppi[0]; wo.status = g_wide.ppi[1]; wo.score = g_wide.ppi[2]; wo.cig_pos = g_wide.ppi[3]; wo.cells = g_wide.po[0] | ((unsigned long long)g_wide.po[1] << 32); wo.t_dp = wo.t_bt = 0;
+                    __syncthreads();
+                }
+                if (nc < 0) { g.status = LCD_ERR_CERT; g.t_plan = 2000000ull + mw; g.t_kahn = (unsigned long long)attempt * 1000000ull + (unsigned)qlen; return leave(0); }
+                if (wo.status != LCD_OK) { g.status = wo.status; return leave(0); }
+                g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells;
+                const int S = wo.score;
+                if (S > LCD_NEG / 2) {
+                    sbest = imax(sbest, S);
+                    if (S >= sest) { done = true; g.cert_hist = imax(g.cert_hist, ubtop - S); }
+                }
+                __syncthreads();
+                if (!done && fitted) { g.status = LCD_ERR_CERT; g.t_plan = 5000000ull + mw; return leave(0); } // the optimum is below every bound whose intervals fit: the window is too narrow for this read
+            }
+            if (!done) { g.status = LCD_ERR_CERT; g.t_plan = 3000000ull; return leave(0); }
+            g.alg_adjust += (long long)(ei - bi) * (qlen + 1) - (long long)(*cells_acc - cells_before); // what align_unbanded would have counted for this read
+            g.status = wo.status;
+            g.cig_node = g.cig_node0 + wo.cig_pos; g.cig_qpos = g.cig_qpos0 + wo.cig_pos;
+            return leave(nc);
+}
+
 // banded convex-gap global alignment of seq[0..qlen) to the sub-graph (beg_node,end_node); returns #cigar
 // entries written to g.cig_node/g.cig_qpos in start->end order (block-uniform result).
 //
@@ -1724,77 +1807,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         const int rem_beg = g.remain[beg_node] - remain_end;
         const unsigned pdo = pd ? lds_off(pd) : 0xffffffffu, ro = lds_off(ring), so = lds_off(sseq);
         int nc = -1;
-        if constexpr (NT <= 256) if (wb < 0 && g.cert_on) { // K2 with rows restricted to the certified band (256-column window of ONE wavefront)
-            // 64-thread class: the workgroup IS that wavefront.  256-thread class (long chains: the critical path of a submission): wavefront 0 runs the same
-            // rows while the others wait; the per-read phases around them (graph update, re-sort, plan), a third to a half of such a chain in a 64-thread
-            // workgroup, run on all four wavefronts
-            constexpr int WINC = 256;
-            constexpr bool SOLO = NT > 64;
-            if (qlen >= 65536 || ei - bi < 2) { g.status = LCD_ERR_CERT; return 0; }
-            if (wave == 0) cert_node_arrays(&g, bi, ei);   // (wavefront 0; the others only meet the barriers)
-            __syncthreads();
-            const unsigned long long cells_before = *cells_acc;
-            const int ubtop = cert_ubtop(g, ei, qlen, sc);
-            // the guess: the bound at the end cell minus a slack -- the largest one an earlier read of this chain needed (+ 25 % + 32), or a small one for
-            // the first alignment.  An attempt that comes back below its guess doubles the slack; the best score seen so far is a TRUE lower bound of the
-            // optimum and takes over as soon as it is the tighter of the two (that attempt cannot fail)
-            int delta = g.cert_hist < 0 ? 48 + qlen / 32 : g.cert_hist + g.cert_hist / 4 + 32;
-            int sbest = LCD_NEG;
-            bool done = false;
-            auto hull_of = [&](const int sest) { // every row's interval for this score bound (table in g.cert); the widest window a row needs, or -1
-                if (wave == 0) { const int m = cert_hull(&g, bi, ei, qlen, sest, sc); if (lane == 0) sm.bc[6] = m; }
-                __syncthreads();
-                const int m = sm.bc[6];
-                __syncthreads();
-                return m;
-            };
-            for (int attempt = 0; attempt < 10 && !done; ++attempt, delta *= 2) {
-                int sest = imax(sbest, ubtop - delta);
-                int mw = hull_of(sest);
-                bool fitted = false;
-                if (mw > WINC) {
-                    // the intervals of this guess do not fit the window: take the LARGEST slack whose intervals do (they grow with the slack; bisection,
-                    // ~16 instructions per row and step) -- if the alignment over those verifies, nothing wider was needed
-                    int fit = 0, wide = ubtop - sest;
-                    while (wide - fit > 4) { const int mid = (fit + wide) >> 1; const int m = hull_of(ubtop - mid); if (m > WINC) wide = mid; else fit = mid; }
-                    sest = ubtop - fit; mw = hull_of(sest); fitted = true;
-                    if (mw > WINC) { g.status = LCD_ERR_CERT; g.t_plan = 1000000ull + mw; g.t_kahn = (unsigned long long)attempt * 1000000ull + (unsigned)qlen; return 0; }
-                }
-                if (mw < 0) { // not even the source row qualifies: the guess is above the optimum
-                    if (fitted) { g.status = LCD_ERR_CERT; g.t_plan = 4000000ull; return 0; }
-                    continue;
-                }
-                wo.status = g.status; wo.score = LCD_NEG;
-                // one, two or four cells per lane by the widest interval (hull widths are computed for 4-cell groups: the narrower variants keep a margin)
-                nc = -1;
-                if (!SOLO || wave == 0) {
-                    if (mw <= 60) nc = align_windowed<64, 2, 1, SOLO>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
-                    if (nc < 0 && mw <= 124) { win_sync<SOLO>(); nc = align_windowed<64, 2, 2, SOLO>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
-                    if (nc < 0) { win_sync<SOLO>(); nc = align_windowed<64, 2, 4, SOLO>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
-                    if (SOLO && lane == 0) { g_wide.ppi[0] = nc; g_wide.ppi[1] = wo.status; g_wide.ppi[2] = wo.score; g_wide.ppi[3] = wo.cig_pos; g_wide.po[0] = (unsigned)wo.cells; g_wide.po[1] = (unsigned)(wo.cells >> 32); }
-                }
-                if (SOLO) { // the result of wavefront 0 to everybody
-                    __syncthreads();
-                    nc = g_wide.ppi[0]; wo.status = g_wide.ppi[1]; wo.score = g_wide.ppi[2]; wo.cig_pos = g_wide.ppi[3]; wo.cells = g_wide.po[0] | ((unsigned long long)g_wide.po[1] << 32); wo.t_dp = wo.t_bt = 0;
-                    __syncthreads();
-                }
-                if (nc < 0) { g.status = LCD_ERR_CERT; g.t_plan = 2000000ull + mw; g.t_kahn = (unsigned long long)attempt * 1000000ull + (unsigned)qlen; return 0; }
-                if (wo.status != LCD_OK) { g.status = wo.status; return 0; }
-                g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells;
-                const int S = wo.score;
-                if (S > LCD_NEG / 2) {
-                    sbest = imax(sbest, S);
-                    if (S >= sest) { done = true; g.cert_hist = imax(g.cert_hist, ubtop - S); }
-                }
-                __syncthreads();
-                if (!done && fitted) { g.status = LCD_ERR_CERT; g.t_plan = 5000000ull + mw; return 0; } // the optimum is below every bound whose intervals fit: the window is too narrow for this read
-            }
-            if (!done) { g.status = LCD_ERR_CERT; g.t_plan = 3000000ull; return 0; }
-            g.alg_adjust += (long long)(ei - bi) * (qlen + 1) - (long long)(*cells_acc - cells_before); // what align_unbanded would have counted for this read
-            g.status = wo.status;
-            g.cig_node = g.cig_node0 + wo.cig_pos; g.cig_qpos = g.cig_qpos0 + wo.cig_pos;
-            return nc;
-        }
+        if constexpr (NT <= 256) if (wb < 0 && g.cert_on) return align_certified<NT>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, cells_acc);
         if (wb < 0) {
             nc = align_unbanded<NT>(&g, ro, pdo, sc, bi, ei, seq_hbm, qlen, &wo);
             if (nc < 0) { __syncthreads(); nc = align_windowed<NT, 0, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
