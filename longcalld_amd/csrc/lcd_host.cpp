@@ -984,7 +984,8 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     std::vector<int> chain_batch(nC_all);
     for (int k = 0; k < nb; ++k) for (size_t g = chain_base[k]; g < chain_base[k + 1]; ++g) chain_batch[g] = k;
     std::vector<std::vector<uint64_t>> out_rel(nb);
-    for (int k = 0; k < nb; ++k) {
+    std::vector<uint64_t> out_tots(nb, 0);
+    auto size_chains = [&](const int k) { // capacities, class and output offsets of a batch's chains (independent of the other batches: host threads)
         lcd_batch_t *b = bs[k];
         const int nC = (int)b->chains.size();
         b->couts.assign(nC, PoaChainOut());
@@ -996,7 +997,22 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             chain_caps(b->opt, b->chains[c], preads[k], 1, b->pchains[c]);
             out_rel[k][c] = out_tot; out_tot += lcd_align_up(poa_out_bytes(b->pchains[c].node_cap, b->pchains[c].n_reads), 256);
         }
-        if (nC && b->d_poa_out.ensure(out_tot)) return -11;
+        out_tots[k] = out_tot;
+    };
+    {
+        const int nth = std::max(1, std::min(nb, 8));
+        if (nth == 1) size_chains(0);
+        else {
+            std::atomic<int> next{0};
+            std::vector<std::thread> ths;
+            for (int t = 0; t < nth; ++t) ths.emplace_back([&]() { for (int k; (k = next.fetch_add(1)) < nb;) size_chains(k); });
+            for (auto &t : ths) t.join();
+        }
+    }
+    for (int k = 0; k < nb; ++k) {
+        lcd_batch_t *b = bs[k];
+        const int nC = (int)b->chains.size();
+        if (nC && b->d_poa_out.ensure(out_tots[k])) return -11;
         for (int c = 0; c < nC; ++c) b->pchains[c].out_off = b->d_poa_out.addr() + out_rel[k][c];
     }
     auto PC = [&](size_t g) -> PoaChain & { const int k = chain_batch[g]; return bs[k]->pchains[g - chain_base[k]]; };
