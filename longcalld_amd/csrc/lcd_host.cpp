@@ -702,7 +702,11 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     const long long rows_est = std::min<long long>(rows_worst, (long long)(rows_f[hint] * maxl) + 64);
     long long band;
     if (C.mode == 0) band = std::min<long long>(maxl + 1, 2ll * (10 + maxl / 100) + 1 + band_x[hint]);
-    else if (pc.cert) band = std::min<long long>(maxl + 1, 260);
+    else if (pc.cert) { // windowed rows of <= 260 columns at 1 B of code per cell -- and room for a few reads through the generic rows (12 B per cell of intervals wider
+        // than the window, poa_kernel.hip align_certified): LCD_CERT_BAND columns per row
+        static const long long cert_band = getenv("LCD_CERT_BAND") ? atoll(getenv("LCD_CERT_BAND")) : 1040;
+        band = std::min<long long>(maxl + 1, cert_band);
+    }
     else band = maxl + 1;
     long long cells = rows_est * band;
     // (tried: the single-wavefront class compiled for 64 VGPRs (__launch_bounds__(64, 8): 32 instead of 16 wavefronts per CU, 4 - 8 KB pools): 34 - 37 k instead of

@@ -75,6 +75,7 @@ struct Ctx {
     int *aa_node, *aa_flag, *aa_eid;
     int *tb;                          // column-tile boundaries of the unbanded rows: 4 x node_cap ints (H of the last column, by tile parity; F carries)
     long long alg_adjust;             // cells of the reference's algorithm minus cells computed (certified band: full rows minus the intervals, attempts included)
+    int cert_generic, cert_sest, cert_ubtop; unsigned long long cert_cells0; // the read at hand goes through the generic rows over its intervals (align_certified)
     int *cert; int cert_on, cert_hist; // certified band of a K2 chain (align_certified): 7 x node_cap ints; largest bound-to-score slack of the chain's reads so far
     int wmax, seq_cap, pool_words, spill_x;
     int n_node, n_edge, node_cap, edge_cap, rid_words;
@@ -1725,6 +1726,15 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                 __syncthreads();
                 return m;
             };
+            // A read whose intervals do not fit the window goes through the GENERIC rows (any width, values in HBM, 2 - 3x slower per row) over the intervals of
+            // a looser guess -- a dozen reads of a chain at most, and the chain stays inside its round instead of coming back with full rows in the next one
+            auto to_generic = [&](const int slack) {
+                const int sest = imax(sbest, ubtop - slack);
+                const int m = hull_of(sest);
+                if (m < 0) { g.status = LCD_ERR_CERT; g.t_plan = 6000000ull; return 0; }
+                g.cert_generic = 1; g.cert_sest = sest; g.cert_ubtop = ubtop; g.cert_cells0 = cells_before;
+                return -2;
+            };
             for (int attempt = 0; attempt < 10 && !done; ++attempt, delta *= 2) {
                 int sest = imax(sbest, ubtop - delta);
                 int mw = hull_of(sest);
@@ -1735,7 +1745,7 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                     int fit = 0, wide = ubtop - sest;
                     while (wide - fit > 4) { const int mid = (fit + wide) >> 1; const int m = hull_of(ubtop - mid); if (m > WINC) wide = mid; else fit = mid; }
                     sest = ubtop - fit; mw = hull_of(sest); fitted = true;
-                    if (mw > WINC) { g.status = LCD_ERR_CERT; g.t_plan = 1000000ull + mw; g.t_kahn = (unsigned long long)attempt * 1000000ull + (unsigned)qlen; return leave(0); }
+                    if (mw > WINC) return leave(to_generic(2 * (ubtop - sest) + 64));
                 }
                 if (mw < 0) { // not even the source row qualifies: the guess is above the optimum
                     if (fitted) { g.status = LCD_ERR_CERT; g.t_plan = 4000000ull; return leave(0); }
@@ -1755,7 +1765,7 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                     nc = g_wide.ppi[0]; wo.status = g_wide.ppi[1]; wo.score = g_wide.ppi[2]; wo.cig_pos = g_wide.ppi[3]; wo.cells = g_wide.po[0] | ((unsigned long long)g_wide.po[1] << 32); wo.t_dp = wo.t_bt = 0;
                     __syncthreads();
                 }
-                if (nc < 0) { g.status = LCD_ERR_CERT; g.t_plan = 2000000ull + mw; g.t_kahn = (unsigned long long)attempt * 1000000ull + (unsigned)qlen; return leave(0); }
+                if (nc < 0) return leave(to_generic(2 * (ubtop - sest) + 64)); // (the window's alias checks: rare)
                 if (wo.status != LCD_OK) { g.status = wo.status; return leave(0); }
                 g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells;
                 const int S = wo.score;
@@ -1764,7 +1774,7 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                     if (S >= sest) { done = true; g.cert_hist = imax(g.cert_hist, ubtop - S); }
                 }
                 __syncthreads();
-                if (!done && fitted) { g.status = LCD_ERR_CERT; g.t_plan = 5000000ull + mw; return leave(0); } // the optimum is below every bound whose intervals fit: the window is too narrow for this read
+                if (!done && fitted) return leave(to_generic(2 * (ubtop - sest) + 64)); // the optimum is below every bound whose intervals fit: the window is too narrow for this read
             }
             if (!done) { g.status = LCD_ERR_CERT; g.t_plan = 3000000ull; return leave(0); }
             g.alg_adjust += (long long)(ei - bi) * (qlen + 1) - (long long)(*cells_acc - cells_before); // what align_unbanded would have counted for this read
@@ -1807,7 +1817,13 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         const int rem_beg = g.remain[beg_node] - remain_end;
         const unsigned pdo = pd ? lds_off(pd) : 0xffffffffu, ro = lds_off(ring), so = lds_off(sseq);
         int nc = -1;
-        if constexpr (NT <= 256) if (wb < 0 && g.cert_on) return align_certified<NT>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, cells_acc);
+        bool to_generic_rows = false;
+        if constexpr (NT <= 256) if (wb < 0 && g.cert_on) {
+            const int r = align_certified<NT>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, cells_acc);
+            if (r != -2) return r;
+            to_generic_rows = true; // (g.cert_generic is set: the rows below take their intervals from the table)
+        }
+        if (!to_generic_rows) {
         if (wb < 0) {
             nc = align_unbanded<NT>(&g, ro, pdo, sc, bi, ei, seq_hbm, qlen, &wo);
             if (nc < 0) { __syncthreads(); nc = align_windowed<NT, 0, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
@@ -1825,8 +1841,12 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
             g.cig_node = g.cig_node0 + wo.cig_pos; g.cig_qpos = g.cig_qpos0 + wo.cig_pos;
             return nc;
         }
+        }
         __syncthreads();
     }
+    const bool fixedg = g.cert_generic != 0;   // certified band, intervals from the table (wider than the windowed rows hold)
+    const int *const hullg = g.cert + 6 * (size_t)g.node_cap;
+    g.cert_generic = 0;
     const bool ring_ok = g.wmax >= WMAX; // (single-wavefront chains laid out for a narrower ring: every row goes through HBM)
     for (int i = tid; i < qlen; i += NT) sseq[i] = seq_hbm[i];
     __syncthreads();
@@ -1842,6 +1862,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
     {
         int r = g.remain[beg_node] - remain_end;
         int end = qlen - r; if (end < 0) end = 0; end += w; if (end > qlen) end = qlen;
+        if (fixedg) end = hullg[bi] >> 16;
         if ((unsigned long long)end + 1 > g.cell_cap / 3) { g.status = LCD_ERR_CELLS; return 0; }
         const bool fits = ring_ok && end + 1 <= WMAX;
         if (tid == 0) { g.rbeg[bi] = 0; g.rend[bi] = end; g.roff[bi] = 0; g.ml[bi] = 0; g.mr[bi] = 0; }
@@ -1943,6 +1964,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         int end = imax(mprv, qlen - rem) + w; if (end > qlen) end = qlen;
         if (beg < minpb) beg = minpb;
         if (end > maxpe + 1) end = maxpe + 1;
+        if (fixedg) { const int hw = hullg[idx]; beg = hw & 65535; end = hw >> 16; } // (lo > hi: no cell of the row can be on an optimal path)
         if (beg > end) {
             if (tid == 0) { g.rbeg[idx] = 1; g.rend[idx] = 0; g.roff[idx] = (uint32_t)used; g.ml[idx] = 0; g.mr[idx] = 0; }
             lds_barrier<NT>();
@@ -2082,6 +2104,8 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
                 if (c > best) { best = c; br = pi; }
             }
         }
+        if (fixedg && (br < 0 || best < g.cert_sest)) { g.status = LCD_ERR_CERT; br = -1; } // the guess was above the optimum: the host re-runs the chain with full rows
+        sm.bc[5] = best;
         if (br >= 0 && best > LCD_NEG / 2) {
             int pos = qlen;
             int i = br, j = qlen, st = 0;
@@ -2146,6 +2170,10 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
     __syncthreads();
     const int n_cig = sm.bc[0];
     g.status = sm.bc[1];
+    if (fixedg && g.status == LCD_OK) { // certified: the slack this read needed, and what full rows would have counted
+        g.cert_hist = imax(g.cert_hist, g.cert_ubtop - sm.bc[5]);
+        g.alg_adjust += (long long)(ei - bi) * (qlen + 1) - (long long)(*cells_acc - g.cert_cells0);
+    }
     __syncthreads();
     g.t_bt += (unsigned long long)(clock64() - t_bt0);
     return n_cig;
@@ -2223,7 +2251,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.pl_start = (int *)(ws + L.pl_start); g.pl_pidx = (int *)(ws + L.pl_pidx); g.pl_bonus = (int *)(ws + L.pl_bonus);
     g.pl_rem = (int *)(ws + L.pl_rem); g.pl_base = ws + L.pl_base;
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
-    g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0;
+    g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0; g.cert_generic = 0; g.cert_sest = 0; g.cert_ubtop = 0; g.cert_cells0 = 0;
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
     g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - Cfg<NT>::K * 3 * ring_cols) * 4;
     g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0;
