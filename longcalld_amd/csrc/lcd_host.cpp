@@ -739,7 +739,8 @@ static void chain_class(PoaChain &pc, bool noisy) {
         threads = 64; K = 2;
         static const int margin = getenv("LCD_BAND_MARGIN") ? atoi(getenv("LCD_BAND_MARGIN")) : 12;
         const long long bw = 2ll * (10 + pc.max_len / 100) + 1 + margin; // adaptive band + a little drift; a band that outgrows it is re-run wider
-        wmax = pc.mode == 1 ? 256 : bw <= 60 ? 64 : bw <= 124 ? 128 : 256;
+        static const int cert_ring = getenv("LCD_CERT_RING") ? atoi(getenv("LCD_CERT_RING")) : 384; // (certified-band chains: ring slots wide enough for the reads that take the generic rows)
+        wmax = pc.cert ? std::max(256, cert_ring) : pc.mode == 1 ? 256 : bw <= 60 ? 64 : bw <= 124 ? 128 : 256;
     }
     else if (width <= 512) { threads = 128; K = 2; wmax = 512; }
     else if (width <= 1024) { threads = 256; K = 2; wmax = 1024; }

@@ -75,7 +75,7 @@ struct Ctx {
     int *aa_node, *aa_flag, *aa_eid;
     int *tb;                          // column-tile boundaries of the unbanded rows: 4 x node_cap ints (H of the last column, by tile parity; F carries)
     long long alg_adjust;             // cells of the reference's algorithm minus cells computed (certified band: full rows minus the intervals, attempts included)
-    int cert_generic, cert_sest, cert_ubtop; unsigned long long cert_cells0; // the read at hand goes through the generic rows over its intervals (align_certified)
+    int cert_generic, cert_generic_seen, cert_sest, cert_ubtop; unsigned long long cert_cells0; // the read at hand goes through the generic rows over its intervals (align_certified)
     int *cert; int cert_on, cert_hist; // certified band of a K2 chain (align_certified): 7 x node_cap ints; largest bound-to-score slack of the chain's reads so far
     int wmax, seq_cap, pool_words, spill_x;
     int n_node, n_edge, node_cap, edge_cap, rid_words;
@@ -1732,20 +1732,21 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                 const int sest = imax(sbest, ubtop - slack);
                 const int m = hull_of(sest);
                 if (m < 0) { g.status = LCD_ERR_CERT; g.t_plan = 6000000ull; return 0; }
-                g.cert_generic = 1; g.cert_sest = sest; g.cert_ubtop = ubtop; g.cert_cells0 = cells_before;
+                g.cert_generic = 1; g.cert_generic_seen = 1; g.cert_sest = sest; g.cert_ubtop = ubtop; g.cert_cells0 = cells_before;
                 return -2;
             };
             for (int attempt = 0; attempt < 10 && !done; ++attempt, delta *= 2) {
                 int sest = imax(sbest, ubtop - delta);
                 int mw = hull_of(sest);
                 bool fitted = false;
+                if (mw > WINC && g.cert_generic_seen) return leave(to_generic(ubtop - sest)); // (an earlier read of the chain already had to: no windowed attempt at a tighter guess first)
                 if (mw > WINC) {
                     // the intervals of this guess do not fit the window: take the LARGEST slack whose intervals do (they grow with the slack; bisection,
                     // ~16 instructions per row and step) -- if the alignment over those verifies, nothing wider was needed
                     int fit = 0, wide = ubtop - sest;
                     while (wide - fit > 4) { const int mid = (fit + wide) >> 1; const int m = hull_of(ubtop - mid); if (m > WINC) wide = mid; else fit = mid; }
                     sest = ubtop - fit; mw = hull_of(sest); fitted = true;
-                    if (mw > WINC) return leave(to_generic(2 * (ubtop - sest) + 64));
+                    if (mw > WINC) return leave(to_generic((ubtop - sest) + (ubtop - sest) / 2 + 48));
                 }
                 if (mw < 0) { // not even the source row qualifies: the guess is above the optimum
                     if (fitted) { g.status = LCD_ERR_CERT; g.t_plan = 4000000ull; return leave(0); }
@@ -1765,7 +1766,7 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                     nc = g_wide.ppi[0]; wo.status = g_wide.ppi[1]; wo.score = g_wide.ppi[2]; wo.cig_pos = g_wide.ppi[3]; wo.cells = g_wide.po[0] | ((unsigned long long)g_wide.po[1] << 32); wo.t_dp = wo.t_bt = 0;
                     __syncthreads();
                 }
-                if (nc < 0) return leave(to_generic(2 * (ubtop - sest) + 64)); // (the window's alias checks: rare)
+                if (nc < 0) return leave(to_generic((ubtop - sest) + (ubtop - sest) / 2 + 48)); // (the window's alias checks: rare)
                 if (wo.status != LCD_OK) { g.status = wo.status; return leave(0); }
                 g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells;
                 const int S = wo.score;
@@ -1774,7 +1775,7 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                     if (S >= sest) { done = true; g.cert_hist = imax(g.cert_hist, ubtop - S); }
                 }
                 __syncthreads();
-                if (!done && fitted) return leave(to_generic(2 * (ubtop - sest) + 64)); // the optimum is below every bound whose intervals fit: the window is too narrow for this read
+                if (!done && fitted) return leave(to_generic((ubtop - sest) + (ubtop - sest) / 2 + 48)); // the optimum is below every bound whose intervals fit: the window is too narrow for this read
             }
             if (!done) { g.status = LCD_ERR_CERT; g.t_plan = 3000000ull; return leave(0); }
             g.alg_adjust += (long long)(ei - bi) * (qlen + 1) - (long long)(*cells_acc - cells_before); // what align_unbanded would have counted for this read
@@ -1847,7 +1848,11 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
     const bool fixedg = g.cert_generic != 0;   // certified band, intervals from the table (wider than the windowed rows hold)
     const int *const hullg = g.cert + 6 * (size_t)g.node_cap;
     g.cert_generic = 0;
-    const bool ring_ok = g.wmax >= WMAX; // (single-wavefront chains laid out for a narrower ring: every row goes through HBM)
+    // ring slots of the generic rows: RW columns each -- the class's widest window, or what the host laid the pool out for in the single-wavefront class
+    // (64 / 128 columns for banded chains, 384 for certified-band chains: their few reads that come here have intervals of 260 - 380 columns, and a row that
+    // fits its slot needs neither the HBM round trip nor the store drain of a row that does not)
+    const int RW = NT == 64 ? g.wmax : WMAX;
+    const bool ring_ok = RW >= 64;
     for (int i = tid; i < qlen; i += NT) sseq[i] = seq_hbm[i];
     __syncthreads();
     unsigned long long used = 0;
@@ -1864,13 +1869,13 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         int end = qlen - r; if (end < 0) end = 0; end += w; if (end > qlen) end = qlen;
         if (fixedg) end = hullg[bi] >> 16;
         if ((unsigned long long)end + 1 > g.cell_cap / 3) { g.status = LCD_ERR_CELLS; return 0; }
-        const bool fits = ring_ok && end + 1 <= WMAX;
+        const bool fits = ring_ok && end + 1 <= RW;
         if (tid == 0) { g.rbeg[bi] = 0; g.rend[bi] = end; g.roff[bi] = 0; g.ml[bi] = 0; g.mr[bi] = 0; }
         for (int j = tid; j <= end; j += NT) {
             int f1 = j ? -(o1 + e1 * j) : LCD_NEG, f2 = j ? -(o2 + e2 * j) : LCD_NEG;
             int h = j ? imax(f1, f2) : 0;
             g.H[j] = h; g.E1[j] = h - oe1; g.E2[j] = h - oe2;
-            if (fits) { ring[j] = h; ring[WMAX + j] = h - oe1; ring[2 * WMAX + j] = h - oe2; }
+            if (fits) { ring[j] = h; ring[RW + j] = h - oe1; ring[2 * RW + j] = h - oe2; }
         }
         used = end + 1;
         last_idx = bi; last_beg = 0; last_end = end; last_ml = 0; last_mr = 0; last_off = 0; last_slot = fits ? 0 : -1;
@@ -1976,9 +1981,9 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         if (used > g.cell_cap / 3) { g.status = LCD_ERR_CELLS; return 0; }
         if (tid == 0) { g.rbeg[idx] = beg; g.rend[idx] = end; g.roff[idx] = (uint32_t)off; }
         const int nchunks = (width + 63) >> 6;
-        const bool fits = ring_ok && width <= WMAX;
+        const bool fits = ring_ok && width <= RW;
         const int slot = fits ? next_slot : -1;
-        int *rH = ring + (size_t)(slot < 0 ? 0 : slot) * 3 * WMAX, *rE1 = rH + WMAX, *rE2 = rH + 2 * WMAX;
+        int *rH = ring + (size_t)(slot < 0 ? 0 : slot) * 3 * RW, *rE1 = rH + RW, *rE2 = rH + 2 * RW;
         int carry1 = LCD_NEG * 2, carry2 = LCD_NEG * 2; // running max over the sweeps already done (rows wider than WMAX)
         int best_h = LCD_NEG - 64, best_l = 1 << 30, best_r = -1;
         int sweep = 0;
@@ -2004,9 +2009,9 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
                     else { const int pi = g.pl_pidx[p0 + t]; pb = g.rbeg[pi]; pe = g.rend[pi]; po = g.roff[pi]; bonus = g.pl_bonus[p0 + t]; ps = -1; }
                     if (!act) continue;
                     if (ps >= 0) {
-                        const int *qH = ring + (size_t)ps * 3 * WMAX;
+                        const int *qH = ring + (size_t)ps * 3 * RW;
                         if (j >= 1 && j - 1 >= pb && j - 1 <= pe) mx = imax(mx, qH[j - 1 - pb] + s + bonus);
-                        if (j >= pb && j <= pe) { e1i = imax(e1i, qH[WMAX + (j - pb)] + bonus); e2i = imax(e2i, qH[2 * WMAX + (j - pb)] + bonus); }
+                        if (j >= pb && j <= pe) { e1i = imax(e1i, qH[RW + (j - pb)] + bonus); e2i = imax(e2i, qH[2 * RW + (j - pb)] + bonus); }
                     } else {
                         if (j >= 1 && j - 1 >= pb && j - 1 <= pe) mx = imax(mx, g.H[po + (j - 1 - pb)] + s + bonus);
                         if (j >= pb && j <= pe) { e1i = imax(e1i, g.E1[po + (j - pb)] + bonus); e2i = imax(e2i, g.E2[po + (j - pb)] + bonus); }
@@ -2251,7 +2256,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.pl_start = (int *)(ws + L.pl_start); g.pl_pidx = (int *)(ws + L.pl_pidx); g.pl_bonus = (int *)(ws + L.pl_bonus);
     g.pl_rem = (int *)(ws + L.pl_rem); g.pl_base = ws + L.pl_base;
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
-    g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0; g.cert_generic = 0; g.cert_sest = 0; g.cert_ubtop = 0; g.cert_cells0 = 0;
+    g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0; g.cert_generic = 0; g.cert_generic_seen = 0; g.cert_sest = 0; g.cert_ubtop = 0; g.cert_cells0 = 0;
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
     g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - Cfg<NT>::K * 3 * ring_cols) * 4;
     g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0;
