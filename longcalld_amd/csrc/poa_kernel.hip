@@ -1671,11 +1671,29 @@ __device__ __attribute__((noinline)) int cert_hull(const Ctx *gp_, const int bi_
                 else if (f5 >= 0) { fl = p4; fh = p5; any = true; }
 #undef LCD_SEG_LO
                 if (any) {
-                    if (f0 < 0) { int l = fl, h = fh; while (h - l > 1) { const int m = (l + h) >> 1; if (ub(m) >= 0) h = m; else l = m; } lo = h; } // ub(l) < 0 <= ub(h)
+                    // bracket search with an invariant (ub(l) < 0 <= ub(h)): the first steps guess the crossing by interpolation -- the bound is piecewise
+                    // linear with a handful of pieces, so two or three of them usually close the bracket -- then plain bisection; exact either way
+                    if (f0 < 0) {
+                        int l = fl, h = fh, vl = f1 >= 0 ? f0 : f2 >= 0 ? f1 : f3 >= 0 ? f2 : f4 >= 0 ? f3 : f4, vh = f1 >= 0 ? f1 : f2 >= 0 ? f2 : f3 >= 0 ? f3 : f4 >= 0 ? f4 : f5;
+                        for (int it = 0; h - l > 1; ++it) {
+                            int m = (l + h) >> 1;
+                            if (it < 5) { m = l + (int)((float)(h - l) * (float)(-vl) / (float)(vh - vl)); m = imax(l + 1, imin(h - 1, m)); }
+                            const int v = ub(m);
+                            if (v >= 0) { h = m; vh = v; } else { l = m; vl = v; }
+                        }
+                        lo = h;
+                    }
                     if (f5 >= 0) hi = qlen;
                     else {
                         if (f4 >= 0) { ll = p4; lh = p5; } else if (f3 >= 0) { ll = p3; lh = p4; } else if (f2 >= 0) { ll = p2; lh = p3; } else if (f1 >= 0) { ll = p1; lh = p2; } else { ll = p0; lh = p1; }
-                        int l = ll, h = lh; while (h - l > 1) { const int m = (l + h) >> 1; if (ub(m) >= 0) l = m; else h = m; } hi = l; // ub(l) >= 0 > ub(h)
+                        int l = ll, h = lh, vl = f4 >= 0 ? f4 : f3 >= 0 ? f3 : f2 >= 0 ? f2 : f1 >= 0 ? f1 : f0, vh = f4 >= 0 ? f5 : f3 >= 0 ? f4 : f2 >= 0 ? f3 : f1 >= 0 ? f2 : f1; // ub(l) >= 0 > ub(h)
+                        for (int it = 0; h - l > 1; ++it) {
+                            int m = (l + h) >> 1;
+                            if (it < 5) { m = l + (int)((float)(h - l) * (float)vl / (float)(vl - vh)); m = imax(l + 1, imin(h - 1, m)); }
+                            const int v = ub(m);
+                            if (v >= 0) { l = m; vl = v; } else { h = m; vh = v; }
+                        }
+                        hi = l;
                     }
                 }
             }
@@ -1709,8 +1727,10 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
             constexpr int WINC = 256;
             constexpr bool SOLO = NT > 64;
             if (qlen >= 65536 || ei - bi < 2) { g.status = LCD_ERR_CERT; return leave(0); }
+            const long long tca0 = clock64();
             if (wave == 0) cert_node_arrays(&g, bi, ei);   // (wavefront 0; the others only meet the barriers)
             __syncthreads();
+            g.t_plan += (unsigned long long)(clock64() - tca0); // (profiling: the bound's node arrays)
             const unsigned long long cells_before = *cells_acc;
             const int ubtop = cert_ubtop(g, ei, qlen, sc);
             // the guess: the bound at the end cell minus a slack -- the largest one an earlier read of this chain needed (+ 25 % + 32), or a small one for
@@ -1720,10 +1740,12 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
             int sbest = LCD_NEG;
             bool done = false;
             auto hull_of = [&](const int sest) { // every row's interval for this score bound (table in g.cert); the widest window a row needs, or -1
+                const long long th0 = clock64();
                 if (wave == 0) { const int m = cert_hull(&g, bi, ei, qlen, sest, sc); if (lane == 0) sm.bc[6] = m; }
                 __syncthreads();
                 const int m = sm.bc[6];
                 __syncthreads();
+                g.t_poll += (unsigned long long)(clock64() - th0); // (profiling: the rows' intervals)
                 return m;
             };
             // A read whose intervals do not fit the window goes through the GENERIC rows (any width, values in HBM, 2 - 3x slower per row) over the intervals of
@@ -2469,7 +2491,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     }
     if (tid == 0) {
         const long long t_end = clock64();
-        out.t_total = (unsigned long long)(t_end - t_begin); out.t_dp = g.t_dp; out.t_bt = g.t_bt; out.t_graph = t_graph; out.t_sub = t_sub; out.t_plan = g.t_plan; out.t_poll = g.t_kahn; /* (profiling: t_poll slot reports the serial Kahn walk) */
+        out.t_total = (unsigned long long)(t_end - t_begin); out.t_dp = g.t_dp; out.t_bt = g.t_bt; out.t_graph = t_graph; out.t_sub = t_sub; out.t_plan = g.t_plan; out.t_poll = NT == 64 && ch.cert ? g.t_poll : g.t_kahn; /* (profiling: t_poll slot reports the serial Kahn walk; certified-band chains: t_plan / t_poll = node arrays / intervals) */
         out.hw_id = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); out.xcc_id = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
         out.rt_begin = rt_begin; out.rt_end = __builtin_amdgcn_s_memrealtime();
         out.t_out = (unsigned long long)(t_end - t_out0);
