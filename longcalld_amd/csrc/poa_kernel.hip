@@ -1513,15 +1513,21 @@ __device__ __attribute__((noinline)) void cert_node_arrays(const Ctx *gp_, const
         LCD_PIN(w_np); LCD_PIN(w_p0); LCD_PIN(w_pi0); LCD_PIN(w_b0); LCD_PIN(w_pi1); LCD_PIN(w_b1);
         int cur_mn = CERT_INF, cur_mx = -1, cur_b = LCD_NEG;
         const int nrow = imin(64, ei - base);
-        // a block whose rows all hang on the row before them (the backbone between two bubbles: most blocks) is three prefix sums
-        const bool chain_row = ri >= ei || ri == bi || (w_np == 1 && w_pi0 == ri - 1);
-        if (__ballot(!chain_row) == 0) {
-            const int first = base == bi ? 1 : 0; // (lane 0 of the first block is the source itself)
-            const int s_mn = first ? 0 : LCD_RL(prev_mn, 63), s_mx = first ? 0 : LCD_RL(prev_mx, 63), s_b = first ? 0 : LCD_RL(prev_b, 63);
-            const int cb = scan_add(lane >= first && ri < ei ? w_b0 : 0);
-            if (s_mx >= 0 && ri < ei) { cur_mn = s_mn + lane + 1 - first; cur_mx = s_mx + lane + 1 - first; cur_b = s_b + cb; }
-        } else
-        for (int k = 0; k < nrow; ++k) {
+        // Rows that hang on the row before them (the backbone between two bubbles: ~97 % of the rows) are taken a RUN at a time -- path lengths count up, the
+        // bonus is a prefix sum -- and only the others (several predecessors, or one that is not the row before) one by one
+        const bool chain_row = ri >= ei || (ri != bi && w_np == 1 && w_pi0 == ri - 1);
+        const unsigned long long odd = __ballot(!chain_row) & (nrow == 64 ? ~0ull : (1ull << nrow) - 1);   // rows to take one by one
+        const int cbw = scan_add(ri < ei && ri != bi ? w_b0 : 0);
+        for (int k = 0; k < nrow;) {
+            if (!((odd >> k) & 1)) { // a run of backbone rows [k, k1)
+                const unsigned long long rest = odd >> k;
+                const int k1 = rest ? k + __builtin_ctzll(rest) : nrow;
+                const int s_mn = k ? LCD_RL(cur_mn, k - 1) : LCD_RL(prev_mn, 63), s_mx = k ? LCD_RL(cur_mx, k - 1) : LCD_RL(prev_mx, 63), s_b = k ? LCD_RL(cur_b, k - 1) : LCD_RL(prev_b, 63);
+                const int c0 = k ? LCD_RL(cbw, k - 1) : 0;
+                if (s_mx >= 0 && lane >= k && lane < k1) { cur_mn = s_mn + (lane - k + 1); cur_mx = s_mx + (lane - k + 1); cur_b = s_b + (cbw - c0); }
+                k = k1;
+                continue;
+            }
             int mn = CERT_INF, mx = -1, bb = LCD_NEG;
             if (base + k == bi) { mn = 0; mx = 0; bb = 0; }
             else {
@@ -1539,6 +1545,7 @@ __device__ __attribute__((noinline)) void cert_node_arrays(const Ctx *gp_, const
                 }
             }
             cur_mn = wlane(mn, k, cur_mn); cur_mx = wlane(mx, k, cur_mx); cur_b = wlane(bb, k, cur_b);
+            ++k;
         }
         if (ri < ei) { glb_st(dmin + ri, cur_mn); glb_st(dmax + ri, cur_mx); glb_st(bp + ri, cur_b); }
         prev_mn = cur_mn; prev_mx = cur_mx; prev_b = cur_b;
@@ -1582,32 +1589,39 @@ __device__ __attribute__((noinline)) void cert_node_arrays(const Ctx *gp_, const
         }
         LCD_PIN(w_np); LCD_PIN(w_p0); LCD_PIN(w_pi0); LCD_PIN(w_b0); LCD_PIN(w_pi1); LCD_PIN(w_b1); LCD_PIN(cur_mn); LCD_PIN(cur_mx); LCD_PIN(cur_b);
         const int nrow = imin(64, ei - base);
-        const bool chain_row = ri >= ei || ri == bi || (w_np == 1 && w_pi0 == ri - 1);
-        if (__ballot(!chain_row) == 0) {
-            // every row's only predecessor is the row before it: what was pushed into a row from outside the block reaches the rows below it along the
-            // backbone -- (min, +) / (max, +) suffix scans over the lanes (lane order reversed, prefix scan, reversed back)
-            const int rl = 63 - lane;
-            const int cbl = scan_add(ri < ei && ri != bi ? w_b0 : 0);                      // bonus of the backbone edges up to this row
-            const int kmn = cur_mn + lane, kmx = cur_mx >= 0 ? cur_mx + lane : -CERT_INF, kb = cur_mx >= 0 ? cur_b + cbl : 2 * LCD_NEG;
-            const int smn = __shfl(scan_min(__shfl(kmn, rl)), rl), smx = __shfl(scan_max(__shfl(kmx, rl)), rl), sb = __shfl(scan_max(__shfl(kb, rl)), rl);
-            if (smx > -CERT_INF / 2 && ri < ei) { cur_mn = smn - lane; cur_mx = smx - lane; cur_b = sb - cbl; } else { cur_mn = CERT_INF; cur_mx = -1; cur_b = LCD_NEG; }
-            if (base > bi) { // the block's first row pushes to the last row of the block below
-                const int mx0 = LCD_RL(cur_mx, 0);
-                if (mx0 >= 0) push(base - 1, LCD_RL(cur_mn, 0) + 1, mx0 + 1, LCD_RL(cur_b, 0) + LCD_RL(w_b0, 0));
+        // descending: a run of backbone rows [a, k] first lets what was pushed into its rows (from rows above it, in or outside the block) flow down the
+        // backbone -- (min, +) / (max, +) suffix scans over the run's lanes (lane order reversed, prefix scan, reversed back) -- and then its first row
+        // pushes to the row before it; the other rows push to their predecessors one by one
+        const bool chain_row = ri < ei && ri != bi && w_np == 1 && w_pi0 == ri - 1;
+        const unsigned long long cm = __ballot(chain_row);
+        const int cbl = scan_add(chain_row ? w_b0 : 0);                                    // bonus of the backbone edges up to this row (inside a run)
+        const int rl = 63 - lane;
+        for (int k = nrow - 1; k >= 0;) {
+            if ((cm >> k) & 1) {
+                const unsigned long long below = ~cm & ((k == 63 ? ~0ull : (1ull << (k + 1)) - 1)); // rows <= k that are NOT backbone rows
+                const int a = below ? 64 - __builtin_clzll(below) : 0;                               // the run is [a, k]
+                const bool in = lane >= a && lane <= k;
+                const int kmn = in ? cur_mn + lane : (1 << 30), kmx = in && cur_mx >= 0 ? cur_mx + lane : -CERT_INF, kb = in && cur_mx >= 0 ? cur_b + cbl : 2 * LCD_NEG;
+                const int smn = __shfl(scan_min(__shfl(kmn, rl)), rl), smx = __shfl(scan_max(__shfl(kmx, rl)), rl), sb = __shfl(scan_max(__shfl(kb, rl)), rl);
+                if (in) { if (smx > -CERT_INF / 2) { cur_mn = smn - lane; cur_mx = smx - lane; cur_b = sb - cbl; } else { cur_mn = CERT_INF; cur_mx = -1; cur_b = LCD_NEG; } }
+                const int mx0 = LCD_RL(cur_mx, a);
+                if (mx0 >= 0) push(base + a - 1, LCD_RL(cur_mn, a) + 1, mx0 + 1, LCD_RL(cur_b, a) + LCD_RL(w_b0, a)); // (a backbone row is never the source: base + a - 1 >= bi)
+                k = a - 1;
+                continue;
             }
-        } else
-        for (int k = nrow - 1; k >= 0; --k) {
             const int mx = LCD_RL(cur_mx, k);
-            if (mx < 0 || base + k == bi) continue; // the sink cannot be reached from this row / the source has no predecessor
-            const int mn = LCD_RL(cur_mn, k), bb = LCD_RL(cur_b, k);
-            const int np = LCD_RL(w_np, k);
-            int p0 = 0;
-            if (np > 2) p0 = LCD_RL(w_p0, k);
-            for (int t = 0; t < np; ++t) {
-                int pi = t == 0 ? LCD_RL(w_pi0, k) : LCD_RL(w_pi1, k), bz = t == 0 ? LCD_RL(w_b0, k) : LCD_RL(w_b1, k);
-                if (t > 1) { pi = usgpr(glb_ld(g.pl_pidx + p0 + t)); bz = usgpr(glb_ld(g.pl_bonus + p0 + t)); }
-                push(pi, mn + 1, mx + 1, bb + bz);
+            if (!(mx < 0 || base + k == bi)) { // (the sink cannot be reached from this row / the source has no predecessor: nothing to push)
+                const int mn = LCD_RL(cur_mn, k), bb = LCD_RL(cur_b, k);
+                const int np = LCD_RL(w_np, k);
+                int p0 = 0;
+                if (np > 2) p0 = LCD_RL(w_p0, k);
+                for (int t = 0; t < np; ++t) {
+                    int pi = t == 0 ? LCD_RL(w_pi0, k) : LCD_RL(w_pi1, k), bz = t == 0 ? LCD_RL(w_b0, k) : LCD_RL(w_b1, k);
+                    if (t > 1) { pi = usgpr(glb_ld(g.pl_pidx + p0 + t)); bz = usgpr(glb_ld(g.pl_bonus + p0 + t)); }
+                    push(pi, mn + 1, mx + 1, bb + bz);
+                }
             }
+            --k;
         }
         if (ri < ei) { glb_st(rmin + ri, cur_mn); glb_st(rmax + ri, cur_mx); glb_st(bs + ri, cur_b); }
         cur_mn = nxt_mn; cur_mx = nxt_mx; cur_b = nxt_b; nxt_mn = CERT_INF; nxt_mx = -1; nxt_b = LCD_NEG;
@@ -1761,7 +1775,7 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                 int sest = imax(sbest, ubtop - delta);
                 int mw = hull_of(sest);
                 bool fitted = false;
-                if (mw > WINC && g.cert_generic_seen) return leave(to_generic(ubtop - sest)); // (an earlier read of the chain already had to: no windowed attempt at a tighter guess first)
+                if (mw > WINC && g.cert_generic_seen) return leave(to_generic(ubtop - sest)); // (an earlier read of the chain already had to: no windowed attempt at a tighter guess first -- tried: 39.6 k instead of 56.2 k regions/s at 20 batches)
                 if (mw > WINC) {
                     // the intervals of this guess do not fit the window: take the LARGEST slack whose intervals do (they grow with the slack; bisection,
                     // ~16 instructions per row and step) -- if the alignment over those verifies, nothing wider was needed
