@@ -1765,6 +1765,7 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
             // A read whose intervals do not fit the window goes through the GENERIC rows (any width, values in HBM, 2 - 3x slower per row) over the intervals of
             // a looser guess -- a dozen reads of a chain at most, and the chain stays inside its round instead of coming back with full rows in the next one
             auto to_generic = [&](const int slack) {
+                if (sc.dbg & 16) { g.status = LCD_ERR_CERT; return 0; } // (test switch: give the chain up instead, so that the host's re-run with full rows is exercised)
                 const int sest = imax(sbest, ubtop - slack);
                 const int m = hull_of(sest);
                 if (m < 0) { g.status = LCD_ERR_CERT; g.t_plan = 6000000ull; return 0; }
