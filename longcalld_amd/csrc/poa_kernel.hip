@@ -2018,7 +2018,10 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
         if (used > g.cell_cap / 3) { g.status = LCD_ERR_CELLS; return 0; }
         if (tid == 0) { g.rbeg[idx] = beg; g.rend[idx] = end; g.roff[idx] = (uint32_t)off; }
         const int nchunks = (width + 63) >> 6;
-        const bool fits = ring_ok && width <= RW;
+        bool fits = ring_ok && width <= RW;
+        // a row of more than one sweep (slots wider than NW * RMAX * 64 columns exist in the single-wavefront class only) writes its first sweep into its slot before the
+        // second sweep has read the predecessors: it may not take the slot of a row it still reads (a predecessor K rows back)
+        if (fits && width > NW * RMAX * 64) { if (!regstage) fits = false; else if (__any(lane < np && r_slot == next_slot)) fits = false; }
         const int slot = fits ? next_slot : -1;
         int *rH = ring + (size_t)(slot < 0 ? 0 : slot) * 3 * RW, *rE1 = rH + RW, *rE2 = rH + 2 * RW;
         int carry1 = LCD_NEG * 2, carry2 = LCD_NEG * 2; // running max over the sweeps already done (rows wider than WMAX)
@@ -2186,7 +2189,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
                             }
                         }
                     }
-                    if (!hit) g.status = LCD_ERR_BACKTRACK;
+                    if (!hit) { g.status = LCD_ERR_BACKTRACK; if (sc.dbg & 32) printf("[bt] H-state no hit i %d j %d hv %d rb %d re %d np %d fixed %d qlen %d bi %d\n", i, j, hv, g.rbeg[i], g.rend[i], np, (int)fixedg, qlen, bi); for (int t = 0; t < np; ++t) { const int pi = g.pl_pidx[p0 + t]; printf("[bt]  pred %d idx %d rb %d re %d bonus %d  H[j-1] %d E1[j] %d E2[j] %d\n", t, pi, g.rbeg[pi], g.rend[pi], g.pl_bonus[p0 + t], INB(pi, j - 1) ? CELLH(pi, j - 1) : -1, INB(pi, j) ? g.E1[g.roff[pi] + (j - g.rbeg[pi])] : -1, INB(pi, j) ? g.E2[g.roff[pi] + (j - g.rbeg[pi])] : -1); } for (int k = j - 1; k >= j - 4 && k >= g.rbeg[i]; --k) printf("[bt]  row H[%d] %d\n", k, CELLH(i, k)); printf("[bt]  s %d base %d q %d hull %d %d\n", s, (int)vb, (int)qb, hullg[i] & 65535, hullg[i] >> 16); }
                 } else {
                     const int oe = st == 1 ? oe1 : oe2, ee = st == 1 ? e1 : e2;
                     const int *E = st == 1 ? g.E1 : g.E2;
@@ -2198,7 +2201,7 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
                         if (!INB(pi, j)) continue;
                         if (E[g.roff[pi] + (j - g.rbeg[pi])] + g.pl_bonus[p0 + t] - ee == ev) { i = pi; hit = true; }
                     }
-                    if (!hit) g.status = LCD_ERR_BACKTRACK;
+                    if (!hit) { g.status = LCD_ERR_BACKTRACK; if (sc.dbg & 32) printf("[bt] E-state no hit st %d i %d j %d ev %d h %d rb %d re %d np %d\n", st, i, j, ev, CELLH(i, j), g.rbeg[i], g.rend[i], np); }
                 }
             }
 #undef CELLH
