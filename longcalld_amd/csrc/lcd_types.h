@@ -28,8 +28,7 @@
 struct LcdScoring {
     int match, mismatch, o1, e1, o2, e2;
     int dbg; // test switches (env LCD_DBG; 0 in production): 8 = force the generic rows of the POA kernel, 16 = a certified-band read that outgrows the window ends its
-             // chain (LCD_ERR_CERT, re-run with full rows) instead of taking the generic rows (tests/test_gpu_kernels.py), 32 = the generic rows' value backtrack prints the
-             // cell it cannot explain
+             // chain (LCD_ERR_CERT, re-run with full rows) instead of taking the generic rows (tests/test_gpu_kernels.py)
 };
 
 // status codes written by kernels (0 = ok). Anything else makes the host fail loudly or retry with a bigger arena.

@@ -1821,6 +1821,88 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
             return leave(nc);
 }
 
+// the generic rows' end node + value backtrack (one thread, serial): a function of its own -- inlined, its loops were part of the chain kernel's body, which is what
+// spills (the same build with a call inside this block had 70 instead of 400 spilled VGPRs in the 64-thread kernel and ran 5 % faster).  Returns the
+// number of cigar entries; *best_out = the end cell's score.
+__device__ __attribute__((noinline)) int generic_backtrack(Ctx *gp, const uint8_t *seq, const LcdScoring sc, const int bi, const int ei, const int qlen, const int fixedg_, int *best_out) {
+    Ctx &g = *gp;
+    const bool fixedg = fixedg_ != 0;
+    const int o1 = sc.o1, e1 = sc.e1, o2 = sc.o2, e2 = sc.e2, oe1 = o1 + e1, oe2 = o2 + e2;
+        int n_cig = 0;
+        int best = LCD_NEG, br = -1;
+        {
+            const int p0 = g.pl_start[ei], np = g.pl_start[ei + 1] - p0;
+            for (int t = 0; t < np; ++t) {
+                const int pi = g.pl_pidx[p0 + t];
+                if (qlen < g.rbeg[pi] || qlen > g.rend[pi]) continue;
+                int c = g.H[g.roff[pi] + (qlen - g.rbeg[pi])] + g.pl_bonus[p0 + t];
+                if (c > best) { best = c; br = pi; }
+            }
+        }
+        if (fixedg && (br < 0 || best < g.cert_sest)) { g.status = LCD_ERR_CERT; br = -1; } // the guess was above the optimum: the host re-runs the chain with full rows
+        *best_out = best;
+        if (br >= 0 && best > LCD_NEG / 2) {
+            int pos = qlen;
+            int i = br, j = qlen, st = 0;
+#define CELLH(pi, jj) g.H[g.roff[pi] + ((jj) - g.rbeg[pi])]
+#define INB(pi, jj) ((jj) >= g.rbeg[pi] && (jj) <= g.rend[pi])
+            while (i != bi && j > 0 && g.status == LCD_OK) {
+                const int v = g.idx2node[i];
+                const int p0 = g.pl_start[i], np = g.pl_start[i + 1] - p0;
+                if (st == 0) {
+                    const int hv = CELLH(i, j);
+                    bool hit = false;
+                    const uint8_t vb = g.base[v], qb = seq[j - 1];
+                    const int s = (vb >= 4 || qb >= 4) ? 0 : (vb == qb ? sc.match : -sc.mismatch);
+                    for (int t = 0; t < np && !hit; ++t) {
+                        const int pi = g.pl_pidx[p0 + t];
+                        if (!INB(pi, j - 1)) continue;
+                        if (CELLH(pi, j - 1) + s + g.pl_bonus[p0 + t] == hv) {
+                            --pos; g.cig_node[pos] = v; g.cig_qpos[pos] = j - 1; i = pi; --j; hit = true;
+                        }
+                    }
+                    for (int c = 1; c <= 2 && !hit; ++c) {
+                        const int *E = c == 1 ? g.E1 : g.E2;
+                        for (int t = 0; t < np && !hit; ++t) {
+                            const int pi = g.pl_pidx[p0 + t];
+                            if (!INB(pi, j)) continue;
+                            if (E[g.roff[pi] + (j - g.rbeg[pi])] + g.pl_bonus[p0 + t] == hv) { i = pi; st = c; hit = true; }
+                        }
+                    }
+                    if (!hit) {
+                        const int rb = g.rbeg[i];
+                        for (int k = j - 1; k >= rb && !hit; --k) {
+                            int len = j - k, hk = CELLH(i, k);
+                            if (hk - o1 - len * e1 == hv || hk - o2 - len * e2 == hv) {
+                                for (int t = j; t > k; --t) { --pos; g.cig_node[pos] = -1; g.cig_qpos[pos] = t - 1; }
+                                j = k; hit = true;
+                            }
+                        }
+                    }
+                    if (!hit) g.status = LCD_ERR_BACKTRACK;
+                } else {
+                    const int oe = st == 1 ? oe1 : oe2, ee = st == 1 ? e1 : e2;
+                    const int *E = st == 1 ? g.E1 : g.E2;
+                    const int ev = E[g.roff[i] + (j - g.rbeg[i])];
+                    if (CELLH(i, j) - oe == ev) { st = 0; continue; }
+                    bool hit = false;
+                    for (int t = 0; t < np && !hit; ++t) {
+                        const int pi = g.pl_pidx[p0 + t];
+                        if (!INB(pi, j)) continue;
+                        if (E[g.roff[pi] + (j - g.rbeg[pi])] + g.pl_bonus[p0 + t] - ee == ev) { i = pi; hit = true; }
+                    }
+                    if (!hit) g.status = LCD_ERR_BACKTRACK;
+                }
+            }
+#undef CELLH
+#undef INB
+            while (j > 0) { --pos; g.cig_node[pos] = -1; g.cig_qpos[pos] = j - 1; --j; }
+            n_cig = qlen - pos;
+            if (pos > 0) for (int t = 0; t < n_cig; ++t) { g.cig_node[t] = g.cig_node[t + pos]; g.cig_qpos[t] = g.cig_qpos[t + pos]; }
+        }
+    return n_cig;
+}
+
 // banded convex-gap global alignment of seq[0..qlen) to the sub-graph (beg_node,end_node); returns #cigar
 // entries written to g.cig_node/g.cig_qpos in start->end order (block-uniform result).
 //
@@ -1830,7 +1912,7 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
 // it fits, into the K-slot LDS ring.  HBM rows are only read once a full barrier has drained the stores issued before it
 // (tracked with last_full).
 template <int NT>
-__device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, const LcdScoring &sc, const int wb, int wf_milli, int beg_node, int end_node,
+__device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, const LcdScoring &sc, const int wb, int wf_milli, int beg_node, int end_node,
                                  const uint8_t *seq_hbm, int qlen, unsigned long long *cells_acc) {
     constexpr int NW = NT / 64, K = Cfg<NT>::K;
     constexpr int MP = NW == 1 ? 0 : MAXP; // predecessors staged in LDS per row (single-wavefront rows keep them in registers or read the plan)
@@ -2138,78 +2220,9 @@ __device__ int align_to_subgraph(Ctx &g, Smem &sm, int *ring, uint8_t *sseq, con
     g.t_dp += (unsigned long long)(t_bt0 - t_dp0);
     // ---- end node: best predecessor at column qlen, then backtrack (thread 0) ----
     if (tid == 0) {
-        int n_cig = 0;
-        int best = LCD_NEG, br = -1;
-        {
-            const int p0 = g.pl_start[ei], np = g.pl_start[ei + 1] - p0;
-            for (int t = 0; t < np; ++t) {
-                const int pi = g.pl_pidx[p0 + t];
-                if (qlen < g.rbeg[pi] || qlen > g.rend[pi]) continue;
-                int c = g.H[g.roff[pi] + (qlen - g.rbeg[pi])] + g.pl_bonus[p0 + t];
-                if (c > best) { best = c; br = pi; }
-            }
-        }
-        if (fixedg && (br < 0 || best < g.cert_sest)) { g.status = LCD_ERR_CERT; br = -1; } // the guess was above the optimum: the host re-runs the chain with full rows
+        int best = LCD_NEG;
+        const int n_cig = generic_backtrack(&g, seq, sc, bi, ei, qlen, fixedg ? 1 : 0, &best);
         sm.bc[5] = best;
-        if (br >= 0 && best > LCD_NEG / 2) {
-            int pos = qlen;
-            int i = br, j = qlen, st = 0;
-#define CELLH(pi, jj) g.H[g.roff[pi] + ((jj) - g.rbeg[pi])]
-#define INB(pi, jj) ((jj) >= g.rbeg[pi] && (jj) <= g.rend[pi])
-            while (i != bi && j > 0 && g.status == LCD_OK) {
-                const int v = g.idx2node[i];
-                const int p0 = g.pl_start[i], np = g.pl_start[i + 1] - p0;
-                if (st == 0) {
-                    const int hv = CELLH(i, j);
-                    bool hit = false;
-                    const uint8_t vb = g.base[v], qb = seq[j - 1];
-                    const int s = (vb >= 4 || qb >= 4) ? 0 : (vb == qb ? sc.match : -sc.mismatch);
-                    for (int t = 0; t < np && !hit; ++t) {
-                        const int pi = g.pl_pidx[p0 + t];
-                        if (!INB(pi, j - 1)) continue;
-                        if (CELLH(pi, j - 1) + s + g.pl_bonus[p0 + t] == hv) {
-                            --pos; g.cig_node[pos] = v; g.cig_qpos[pos] = j - 1; i = pi; --j; hit = true;
-                        }
-                    }
-                    for (int c = 1; c <= 2 && !hit; ++c) {
-                        const int *E = c == 1 ? g.E1 : g.E2;
-                        for (int t = 0; t < np && !hit; ++t) {
-                            const int pi = g.pl_pidx[p0 + t];
-                            if (!INB(pi, j)) continue;
-                            if (E[g.roff[pi] + (j - g.rbeg[pi])] + g.pl_bonus[p0 + t] == hv) { i = pi; st = c; hit = true; }
-                        }
-                    }
-                    if (!hit) {
-                        const int rb = g.rbeg[i];
-                        for (int k = j - 1; k >= rb && !hit; --k) {
-                            int len = j - k, hk = CELLH(i, k);
-                            if (hk - o1 - len * e1 == hv || hk - o2 - len * e2 == hv) {
-                                for (int t = j; t > k; --t) { --pos; g.cig_node[pos] = -1; g.cig_qpos[pos] = t - 1; }
-                                j = k; hit = true;
-                            }
-                        }
-                    }
-                    if (!hit) { g.status = LCD_ERR_BACKTRACK; if (sc.dbg & 32) printf("[bt] H-state no hit i %d j %d hv %d rb %d re %d np %d fixed %d qlen %d bi %d\n", i, j, hv, g.rbeg[i], g.rend[i], np, (int)fixedg, qlen, bi); for (int t = 0; t < np; ++t) { const int pi = g.pl_pidx[p0 + t]; printf("[bt]  pred %d idx %d rb %d re %d bonus %d  H[j-1] %d E1[j] %d E2[j] %d\n", t, pi, g.rbeg[pi], g.rend[pi], g.pl_bonus[p0 + t], INB(pi, j - 1) ? CELLH(pi, j - 1) : -1, INB(pi, j) ? g.E1[g.roff[pi] + (j - g.rbeg[pi])] : -1, INB(pi, j) ? g.E2[g.roff[pi] + (j - g.rbeg[pi])] : -1); } for (int k = j - 1; k >= j - 4 && k >= g.rbeg[i]; --k) printf("[bt]  row H[%d] %d\n", k, CELLH(i, k)); printf("[bt]  s %d base %d q %d hull %d %d\n", s, (int)vb, (int)qb, hullg[i] & 65535, hullg[i] >> 16); }
-                } else {
-                    const int oe = st == 1 ? oe1 : oe2, ee = st == 1 ? e1 : e2;
-                    const int *E = st == 1 ? g.E1 : g.E2;
-                    const int ev = E[g.roff[i] + (j - g.rbeg[i])];
-                    if (CELLH(i, j) - oe == ev) { st = 0; continue; }
-                    bool hit = false;
-                    for (int t = 0; t < np && !hit; ++t) {
-                        const int pi = g.pl_pidx[p0 + t];
-                        if (!INB(pi, j)) continue;
-                        if (E[g.roff[pi] + (j - g.rbeg[pi])] + g.pl_bonus[p0 + t] - ee == ev) { i = pi; hit = true; }
-                    }
-                    if (!hit) { g.status = LCD_ERR_BACKTRACK; if (sc.dbg & 32) printf("[bt] E-state no hit st %d i %d j %d ev %d h %d rb %d re %d np %d\n", st, i, j, ev, CELLH(i, j), g.rbeg[i], g.rend[i], np); }
-                }
-            }
-#undef CELLH
-#undef INB
-            while (j > 0) { --pos; g.cig_node[pos] = -1; g.cig_qpos[pos] = j - 1; --j; }
-            n_cig = qlen - pos;
-            if (pos > 0) for (int t = 0; t < n_cig; ++t) { g.cig_node[t] = g.cig_node[t + pos]; g.cig_qpos[t] = g.cig_qpos[t + pos]; }
-        }
         sm.bc[0] = n_cig; sm.bc[1] = g.status;
     }
     __syncthreads();
