@@ -265,7 +265,7 @@ __device__ int block_excl_scan(int v, Smem &sm, int *total) { // exclusive prefi
 
 // returns 0: nothing changed, 1: only edge weights / read sets changed (the topological order stands, `remain` may not), 2: nodes or edges were added
 template <int NT>
-__device__ int add_alignment_block(Ctx &g, Smem &sm, int beg_node, int end_node, const uint8_t *seq, int len, int n_cig, int read_id) {
+__device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, int beg_node, int end_node, const uint8_t *seq, int len, int n_cig, int read_id) {
     const int tid = threadIdx.x;
     const int rw = read_id >> 6; const unsigned long long rbit = 1ull << (read_id & 63);
     if (g.n_node == 2) { // first read: a chain source -> bases -> sink (abpoa_add_graph_sequence)
@@ -496,7 +496,7 @@ __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned shor
 }
 
 template <int NT>
-__device__ void topo_sort_block(Ctx &g, Smem &sm, int *lds_pool) {
+__device__ __attribute__((noinline)) void topo_sort_block(Ctx &g, Smem &sm, int *lds_pool) {
     const int tid = threadIdx.x;
     const int n = g.n_node, E = g.n_edge;
     if (n >= 65535 || E >= 65535) { // ids do not fit 16 bits: plain serial walk on the graph arrays
@@ -519,7 +519,7 @@ __device__ void topo_sort_block(Ctx &g, Smem &sm, int *lds_pool) {
 // The read changed edge weights only (no new node, no new edge): the topological order stands; `remain` follows the heaviest out-edge
 // and may not.  Same LDS sweep as above without the Kahn walk: heaviest successors in parallel, one serial pass over the order.
 template <int NT>
-__device__ void topo_remain_block(Ctx &g, Smem &sm, int *lds_pool) {
+__device__ __attribute__((noinline)) void topo_remain_block(Ctx &g, Smem &sm, int *lds_pool) {
     const int tid = threadIdx.x;
     const int n = g.n_node;
     if (n >= 65535) { // ids do not fit 16 bits: serial (same arithmetic)
