@@ -2237,131 +2237,13 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
     return n_cig;
 }
 
-} // namespace
-
+// the output phase of a chain (MSA rank, rows, clusters, consensus: oracle/poa.c poa_output): a function of its own, like the per-read phases (the chain kernel's body
+// is what spills)
 template <int NT>
-__global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool,
-                                                           uint8_t *arena, uint8_t *outpool, PoaChainOut *outs, LcdScoring sc,
-                                                           int n_chains, int *gate) {
-    const int cid = blockIdx.x;
-    if (cid >= n_chains) return;
-    if (gate && threadIdx.x == 0) atomicAdd(gate, 1); // "this workgroup is resident" (see lcd_gate_kernel)
-    Smem &sm = g_smem;
-    extern __shared__ int lds_pool[]; // [row ring | query cache], re-used by the re-sort; sized per launch (PoaChain.lds_words)
-    int *ring = lds_pool;
+__device__ __attribute__((noinline)) void chain_output(Ctx &g, Smem &sm, const PoaChain &ch, uint8_t *outpool, PoaChainOut &out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const PoaChain ch = chains[cid];
-    // ring slots hold PoaChain.wmax columns: the class's widest window (4 * NT), or -- single-wavefront banded chains -- the narrower
-    // window the host expects the band to fit (64 / 128 columns: LDS per chain is what limits how many of them share a CU)
-    const int ring_cols = NT == 64 ? ch.wmax : 4 * NT;
-    uint8_t *sseq = (uint8_t *)(lds_pool + Cfg<NT>::K * 3 * ring_cols);
-    const PoaLayout L = poa_layout(ch.node_cap, ch.edge_cap, ch.rid_words, ch.max_len, ch.cell_cap, ch.n_reads, ch.spill_x, ch.cert);
-    uint8_t *ws = arena + ch.ws_off;
-    int my_slot = -1;
-    if (ch.slot_flags) { // pooled arenas: claim a slot (this CU's own ones first; anything free otherwise; wait if the pool is exhausted)
-        if (tid == 0) {
-            int *flags = (int *)(uintptr_t)ch.slot_flags;
-            const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), xc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
-            const unsigned raw = ((xc & 15) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15);
-            const int *rank = (const int *)(uintptr_t)ch.cu_rank;
-            int r = rank ? rank[raw] : -1;
-            if (r < 0) r = (int)raw;
-            const unsigned ns = (unsigned)ch.n_slots, start = ((unsigned)r * (unsigned)ch.per_cu) % ns;
-            int slot = -1;
-            for (unsigned sweeps = 0; slot < 0 && sweeps < (1u << 20); ++sweeps) {
-                for (unsigned t = 0; t < ns; ++t) {
-                    const unsigned q = (start + t) % ns;
-                    if (atomicCAS(flags + q, 0, 1) == 0) { slot = (int)q; break; }
-                }
-                if (slot < 0) __builtin_amdgcn_s_sleep(64);
-            }
-            sm.bc[0] = slot;
-        }
-        __syncthreads();
-        my_slot = sm.bc[0];
-        __syncthreads();
-        if (my_slot < 0) { // cannot happen while slot holders make progress; never run on somebody else's arena
-            if (tid == 0) { PoaChainOut o = PoaChainOut(); o.status = LCD_ERR_SYNC; outs[cid] = o; }
-            return;
-        }
-        ws = (uint8_t *)(uintptr_t)ch.ws_off + (uint64_t)my_slot * ch.slot_bytes;
-    }
-    Ctx g;
-    // DP region: 4 * cell_cap bytes.  Windowed / systolic rows: [direction codes: cell_cap B | predecessor ordinals: cell_cap B (one row
-    // in four may have >= 2 predecessors) | spilled value rows: 2 * cell_cap B].  Generic rows: int32 H, E1, E2 planes of cell_cap / 3
-    // cells.  Whatever does not fit ends the chain with LCD_ERR_CELLS and the host re-runs it with a larger arena.
-    g.H = (int *)(ws + L.H); g.E1 = g.H + ch.cell_cap / 3; g.E2 = g.E1 + ch.cell_cap / 3;
-    g.code8 = ws + L.H; g.ord = (int *)(ws + L.H + lcd_align_up(ch.cell_cap, 16)); g.spill = (int *)(ws + L.H + (ch.spill_x > 2 ? 5 : 2) * lcd_align_up(ch.cell_cap, 16));
-    g.ooff = (uint32_t *)(ws + L.ooff); g.spoff = (uint32_t *)(ws + L.spoff);
-    g.rbeg = (int *)(ws + L.rbeg); g.rend = (int *)(ws + L.rend); g.roff = (uint32_t *)(ws + L.roff);
-    g.ml = (int *)(ws + L.mpl); g.mr = (int *)(ws + L.mpr);
-    g.idx2node = (int *)(ws + L.idx2node); g.node2idx = (int *)(ws + L.node2idx); g.remain = (int *)(ws + L.remain);
-    g.deg = (int *)(ws + L.deg); g.queue = (int *)(ws + L.queue);
-    g.out_head = (int *)(ws + L.n_out_head); g.out_tail = (int *)(ws + L.n_out_tail);
-    g.in_head = (int *)(ws + L.n_in_head); g.in_tail = (int *)(ws + L.n_in_tail);
-    g.nin = (int *)(ws + L.n_nin); g.aligned = (int *)(ws + L.n_aligned);
-    g.e_from = (int *)(ws + L.e_from); g.e_to = (int *)(ws + L.e_to); g.e_w = (int *)(ws + L.e_w);
-    g.e_next_out = (int *)(ws + L.e_next_out); g.e_next_in = (int *)(ws + L.e_next_in);
-    g.rid = (unsigned long long *)(ws + L.rid);
-    g.cig_node0 = g.cig_node = (int *)(ws + L.cig_node); g.cig_qpos0 = g.cig_qpos = (int *)(ws + L.cig_qpos);
-    g.base = ws + L.n_base; g.imap = ws + L.imap;
-    g.het = (int *)(ws + L.het); g.clu = (int *)(ws + L.clu); g.nclu = (int *)(ws + L.nclu); g.prof = ws + L.prof;
-    g.pl_start = (int *)(ws + L.pl_start); g.pl_pidx = (int *)(ws + L.pl_pidx); g.pl_bonus = (int *)(ws + L.pl_bonus);
-    g.pl_rem = (int *)(ws + L.pl_rem); g.pl_base = ws + L.pl_base;
-    g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
-    g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0; g.cert_generic = 0; g.cert_generic_seen = 0; g.cert_sest = 0; g.cert_ubtop = 0; g.cert_cells0 = 0;
-    g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
-    g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - Cfg<NT>::K * 3 * ring_cols) * 4;
-    g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0;
-    const long long t_begin = clock64();
-    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
-    unsigned long long t_graph = 0, t_sub = 0;
-    if (tid == 0)
-        for (int i = 0; i < 2; ++i) {
-            g.base[i] = 4; g.out_head[i] = g.out_tail[i] = g.in_head[i] = g.in_tail[i] = -1; g.nin[i] = 0; g.aligned[i] = i;
-        }
-    __syncthreads();
-    unsigned long long cells = 0, aligned_bases = 0;
-    int n_aligned_reads = 0;
     const int n_seq = ch.n_reads;
-    const PoaRead *rd = reads + ch.read0;
-    for (int i = 0; i < n_seq && g.status == LCD_OK; ++i) {
-        const PoaRead r = rd[i];
-        if (r.skip) continue;
-        int exc_beg = 0, exc_end = 1, beg_cut = 0, end_cut = 0;
-        if (ch.mode == 0 && i != 0) {
-            const long long ts0 = clock64();
-            beg_cut = r.read_beg - 1; end_cut = r.len - r.read_end;
-            if (wave == 0) {
-                int eb, ee;
-                subgraph_nodes_wave0(g, lane, r.ref_beg + 1, r.ref_end + 1, &eb, &ee);
-                if (lane == 0) { sm.bc[2] = eb; sm.bc[3] = ee; }
-            }
-            __syncthreads();
-            exc_beg = sm.bc[2]; exc_end = sm.bc[3];
-            __syncthreads();
-            t_sub += (unsigned long long)(clock64() - ts0);
-        }
-        const uint8_t *seq = pool + r.seq_off + beg_cut;
-        const int len = r.len - beg_cut - end_cut;
-        int n_cig = 0;
-        if (g.n_node > 2) {
-            n_cig = align_to_subgraph<NT>(g, sm, ring, sseq, sc, ch.mode == 0 ? 10 : -1, ch.mode == 0 ? 10 : 0, exc_beg, exc_end, seq, len, &cells);
-            if (len > 0) { aligned_bases += len; n_aligned_reads++; }
-        }
-        // graph update + re-sort: serial pointer work on thread 0; results published through LDS
-        const long long tg0 = clock64();
-        int changed = 0;
-        if (len > 0 && g.status == LCD_OK) changed = add_alignment_block<NT>(g, sm, exc_beg, exc_end, seq, len, n_cig, i);
-        if (changed == 2 && g.status == LCD_OK) topo_sort_block<NT>(g, sm, lds_pool);
-        else if (changed == 1 && g.status == LCD_OK) topo_remain_block<NT>(g, sm, lds_pool);
-        t_graph += (unsigned long long)(clock64() - tg0);
-    }
-    const long long t_out0 = clock64();
-    // ---------------- output: MSA rank, rows, clusters, consensus (oracle/poa.c poa_output) ----------------
-    PoaChainOut out;
-    out.status = g.status; out.n_cons = 0; out.cons_len[0] = out.cons_len[1] = 0; out.msa_len = 0; out.clu_n[0] = out.clu_n[1] = 0;
-    out.n_node = g.n_node; out.n_edge = g.n_edge; out.n_aligned_reads = n_aligned_reads; out.cells = cells; out.cells_alg = (unsigned long long)((long long)cells + g.alg_adjust); out.aligned_bases = aligned_bases;
+    (void)wave;
     uint8_t *ob = outpool + ch.out_off;
     const int nc_cap = ch.node_cap;
     uint8_t *cons0 = ob, *cons1 = ob + nc_cap;
@@ -2520,6 +2402,134 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
             __syncthreads();
         }
     }
+}
+
+} // namespace
+
+template <int NT>
+__global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool,
+                                                           uint8_t *arena, uint8_t *outpool, PoaChainOut *outs, LcdScoring sc,
+                                                           int n_chains, int *gate) {
+    const int cid = blockIdx.x;
+    if (cid >= n_chains) return;
+    if (gate && threadIdx.x == 0) atomicAdd(gate, 1); // "this workgroup is resident" (see lcd_gate_kernel)
+    Smem &sm = g_smem;
+    extern __shared__ int lds_pool[]; // [row ring | query cache], re-used by the re-sort; sized per launch (PoaChain.lds_words)
+    int *ring = lds_pool;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const PoaChain ch = chains[cid];
+    // ring slots hold PoaChain.wmax columns: the class's widest window (4 * NT), or -- single-wavefront banded chains -- the narrower
+    // window the host expects the band to fit (64 / 128 columns: LDS per chain is what limits how many of them share a CU)
+    const int ring_cols = NT == 64 ? ch.wmax : 4 * NT;
+    uint8_t *sseq = (uint8_t *)(lds_pool + Cfg<NT>::K * 3 * ring_cols);
+    const PoaLayout L = poa_layout(ch.node_cap, ch.edge_cap, ch.rid_words, ch.max_len, ch.cell_cap, ch.n_reads, ch.spill_x, ch.cert);
+    uint8_t *ws = arena + ch.ws_off;
+    int my_slot = -1;
+    if (ch.slot_flags) { // pooled arenas: claim a slot (this CU's own ones first; anything free otherwise; wait if the pool is exhausted)
+        if (tid == 0) {
+            int *flags = (int *)(uintptr_t)ch.slot_flags;
+            const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), xc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+            const unsigned raw = ((xc & 15) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15);
+            const int *rank = (const int *)(uintptr_t)ch.cu_rank;
+            int r = rank ? rank[raw] : -1;
+            if (r < 0) r = (int)raw;
+            const unsigned ns = (unsigned)ch.n_slots, start = ((unsigned)r * (unsigned)ch.per_cu) % ns;
+            int slot = -1;
+            for (unsigned sweeps = 0; slot < 0 && sweeps < (1u << 20); ++sweeps) {
+                for (unsigned t = 0; t < ns; ++t) {
+                    const unsigned q = (start + t) % ns;
+                    if (atomicCAS(flags + q, 0, 1) == 0) { slot = (int)q; break; }
+                }
+                if (slot < 0) __builtin_amdgcn_s_sleep(64);
+            }
+            sm.bc[0] = slot;
+        }
+        __syncthreads();
+        my_slot = sm.bc[0];
+        __syncthreads();
+        if (my_slot < 0) { // cannot happen while slot holders make progress; never run on somebody else's arena
+            if (tid == 0) { PoaChainOut o = PoaChainOut(); o.status = LCD_ERR_SYNC; outs[cid] = o; }
+            return;
+        }
+        ws = (uint8_t *)(uintptr_t)ch.ws_off + (uint64_t)my_slot * ch.slot_bytes;
+    }
+    Ctx g;
+    // DP region: 4 * cell_cap bytes.  Windowed / systolic rows: [direction codes: cell_cap B | predecessor ordinals: cell_cap B (one row
+    // in four may have >= 2 predecessors) | spilled value rows: 2 * cell_cap B].  Generic rows: int32 H, E1, E2 planes of cell_cap / 3
+    // cells.  Whatever does not fit ends the chain with LCD_ERR_CELLS and the host re-runs it with a larger arena.
+    g.H = (int *)(ws + L.H); g.E1 = g.H + ch.cell_cap / 3; g.E2 = g.E1 + ch.cell_cap / 3;
+    g.code8 = ws + L.H; g.ord = (int *)(ws + L.H + lcd_align_up(ch.cell_cap, 16)); g.spill = (int *)(ws + L.H + (ch.spill_x > 2 ? 5 : 2) * lcd_align_up(ch.cell_cap, 16));
+    g.ooff = (uint32_t *)(ws + L.ooff); g.spoff = (uint32_t *)(ws + L.spoff);
+    g.rbeg = (int *)(ws + L.rbeg); g.rend = (int *)(ws + L.rend); g.roff = (uint32_t *)(ws + L.roff);
+    g.ml = (int *)(ws + L.mpl); g.mr = (int *)(ws + L.mpr);
+    g.idx2node = (int *)(ws + L.idx2node); g.node2idx = (int *)(ws + L.node2idx); g.remain = (int *)(ws + L.remain);
+    g.deg = (int *)(ws + L.deg); g.queue = (int *)(ws + L.queue);
+    g.out_head = (int *)(ws + L.n_out_head); g.out_tail = (int *)(ws + L.n_out_tail);
+    g.in_head = (int *)(ws + L.n_in_head); g.in_tail = (int *)(ws + L.n_in_tail);
+    g.nin = (int *)(ws + L.n_nin); g.aligned = (int *)(ws + L.n_aligned);
+    g.e_from = (int *)(ws + L.e_from); g.e_to = (int *)(ws + L.e_to); g.e_w = (int *)(ws + L.e_w);
+    g.e_next_out = (int *)(ws + L.e_next_out); g.e_next_in = (int *)(ws + L.e_next_in);
+    g.rid = (unsigned long long *)(ws + L.rid);
+    g.cig_node0 = g.cig_node = (int *)(ws + L.cig_node); g.cig_qpos0 = g.cig_qpos = (int *)(ws + L.cig_qpos);
+    g.base = ws + L.n_base; g.imap = ws + L.imap;
+    g.het = (int *)(ws + L.het); g.clu = (int *)(ws + L.clu); g.nclu = (int *)(ws + L.nclu); g.prof = ws + L.prof;
+    g.pl_start = (int *)(ws + L.pl_start); g.pl_pidx = (int *)(ws + L.pl_pidx); g.pl_bonus = (int *)(ws + L.pl_bonus);
+    g.pl_rem = (int *)(ws + L.pl_rem); g.pl_base = ws + L.pl_base;
+    g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
+    g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0; g.cert_generic = 0; g.cert_generic_seen = 0; g.cert_sest = 0; g.cert_ubtop = 0; g.cert_cells0 = 0;
+    g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
+    g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - Cfg<NT>::K * 3 * ring_cols) * 4;
+    g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0;
+    const long long t_begin = clock64();
+    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_graph = 0, t_sub = 0;
+    if (tid == 0)
+        for (int i = 0; i < 2; ++i) {
+            g.base[i] = 4; g.out_head[i] = g.out_tail[i] = g.in_head[i] = g.in_tail[i] = -1; g.nin[i] = 0; g.aligned[i] = i;
+        }
+    __syncthreads();
+    unsigned long long cells = 0, aligned_bases = 0;
+    int n_aligned_reads = 0;
+    const int n_seq = ch.n_reads;
+    const PoaRead *rd = reads + ch.read0;
+    for (int i = 0; i < n_seq && g.status == LCD_OK; ++i) {
+        const PoaRead r = rd[i];
+        if (r.skip) continue;
+        int exc_beg = 0, exc_end = 1, beg_cut = 0, end_cut = 0;
+        if (ch.mode == 0 && i != 0) {
+            const long long ts0 = clock64();
+            beg_cut = r.read_beg - 1; end_cut = r.len - r.read_end;
+            if (wave == 0) {
+                int eb, ee;
+                subgraph_nodes_wave0(g, lane, r.ref_beg + 1, r.ref_end + 1, &eb, &ee);
+                if (lane == 0) { sm.bc[2] = eb; sm.bc[3] = ee; }
+            }
+            __syncthreads();
+            exc_beg = sm.bc[2]; exc_end = sm.bc[3];
+            __syncthreads();
+            t_sub += (unsigned long long)(clock64() - ts0);
+        }
+        const uint8_t *seq = pool + r.seq_off + beg_cut;
+        const int len = r.len - beg_cut - end_cut;
+        int n_cig = 0;
+        if (g.n_node > 2) {
+            n_cig = align_to_subgraph<NT>(g, sm, ring, sseq, sc, ch.mode == 0 ? 10 : -1, ch.mode == 0 ? 10 : 0, exc_beg, exc_end, seq, len, &cells);
+            if (len > 0) { aligned_bases += len; n_aligned_reads++; }
+        }
+        // graph update + re-sort: serial pointer work on thread 0; results published through LDS
+        const long long tg0 = clock64();
+        int changed = 0;
+        if (len > 0 && g.status == LCD_OK) changed = add_alignment_block<NT>(g, sm, exc_beg, exc_end, seq, len, n_cig, i);
+        if (changed == 2 && g.status == LCD_OK) topo_sort_block<NT>(g, sm, lds_pool);
+        else if (changed == 1 && g.status == LCD_OK) topo_remain_block<NT>(g, sm, lds_pool);
+        t_graph += (unsigned long long)(clock64() - tg0);
+    }
+    const long long t_out0 = clock64();
+    // ---------------- output: MSA rank, rows, clusters, consensus (oracle/poa.c poa_output) ----------------
+    PoaChainOut out;
+    out.status = g.status; out.n_cons = 0; out.cons_len[0] = out.cons_len[1] = 0; out.msa_len = 0; out.clu_n[0] = out.clu_n[1] = 0;
+    out.n_node = g.n_node; out.n_edge = g.n_edge; out.n_aligned_reads = n_aligned_reads; out.cells = cells; out.cells_alg = (unsigned long long)((long long)cells + g.alg_adjust); out.aligned_bases = aligned_bases;
+    chain_output<NT>(g, sm, ch, outpool, out);
     if (tid == 0) {
         const long long t_end = clock64();
         out.t_total = (unsigned long long)(t_end - t_begin); out.t_dp = g.t_dp; out.t_bt = g.t_bt; out.t_graph = t_graph; out.t_sub = t_sub; out.t_plan = g.t_plan; out.t_poll = NT == 64 && ch.cert ? g.t_poll : g.t_kahn; /* (profiling: t_poll slot reports the serial Kahn walk; certified-band chains: t_plan / t_poll = node arrays / intervals) */
