@@ -157,6 +157,7 @@ typedef struct lcd_batch_stats_t {
     int poa_retries;
     double ms_vars;         /* stage S6 (opt.collect_noisy_vars) */
     uint64_t poa_cells_computed; /* cells the kernels actually computed: < poa_cells where K2 ran over a certified band (same alignments) */
+    int poa_grown;               /* DP regions enlarged in place by a chain whose estimate was too small for a read (spare DP memory); such a chain is not re-run */
 } lcd_batch_stats_t;
 
 #define LCD_DEVICE_ANY (-2)

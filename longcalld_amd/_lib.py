@@ -57,7 +57,7 @@ class LcdBatchStats(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("n_regions", "n_regions_resolved", "n_chains", "n_anchor_jobs", "n_wfa_jobs", "n_edlib_jobs")] + [
         (n, C.c_uint64) for n in ("poa_aligned_bases", "poa_cells", "wfa_offsets", "edlib_blocks", "poa_alg_bytes")] + [
         (n, C.c_double) for n in ("ms_total", "ms_anchor", "ms_poa", "ms_wfa", "ms_strings", "ms_upload", "ms_download", "ms_host", "ms_poa_kernel")] + [
-        ("n_poa_launches", C.c_int), ("poa_retries", C.c_int), ("ms_vars", C.c_double), ("poa_cells_computed", C.c_uint64)]
+        ("n_poa_launches", C.c_int), ("poa_retries", C.c_int), ("ms_vars", C.c_double), ("poa_cells_computed", C.c_uint64), ("poa_grown", C.c_int)]
 
 
 class LcdHapProblem(C.Structure):

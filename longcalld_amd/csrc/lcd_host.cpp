@@ -209,7 +209,7 @@ struct lcd_batch_s {
     // (d_poa_arena: the ONE transient workspace of a submission led by this batch -- chain arenas, WFA wavefronts and edlib blocks in turn)
     DevBuf d_in, d_chains, d_preads, d_poa_arena, d_poa_out, d_poa_outs, d_ed_jobs, d_ed_outs, d_wfa_jobs,
         d_wfa_out, d_wfa_outs, d_str_jobs, d_str_outs, d_final, d_gate, d_cmp_jobs, d_cmp_outs, d_cmp_seg, d_cmp_segres, d_seg_out, d_rr,
-        d_var_jobs, d_var_outs, d_var_work, d_vreg_jobs, d_vreg_outs, d_var_out, d_slot_flags;
+        d_var_jobs, d_var_outs, d_var_work, d_vreg_jobs, d_vreg_outs, d_var_out, d_slot_flags, d_spare;
     bool uploaded = false, ran = false, downloaded = false;
     // results (host)
     std::vector<PoaChainOut> couts;
@@ -709,6 +709,7 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     }
     else band = maxl + 1;
     long long cells = rows_est * band;
+    if (const char *shrink = getenv("LCD_CELL_SHRINK")) cells = std::max<long long>(cells / std::max(1, atoi(shrink)), 1); // test switch: estimates far too small, so that the chains have to grow their regions (tests/test_gpu_region.py)
     // (tried: the single-wavefront class compiled for 64 VGPRs (__launch_bounds__(64, 8): 32 instead of 16 wavefronts per CU, 4 - 8 KB pools): 34 - 37 k instead of
     // 51 k regions/s -- the row loops spill (40 - 170 B of scratch per lane inside align_windowed) and the graph phases' scratch grows from 924 to 1 336 B)
     // (tried: 3x the estimate up front for the long K1 chains of noisy reads, which overflow most -- 5 instead of 60 re-runs per 4 SV-shape batches, but
@@ -776,7 +777,7 @@ static long long chain_group_key(const PoaChain &pc) { return (long long)pc.thre
 // uploads `sub` (already ordered so that equal classes are contiguous) and launches one kernel per class
 // (different classes go to side streams so a long wide chain does not hold back the narrow ones)
 static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, DevBuf &d_chains, const PoaRead *d_reads, DevBuf &d_outs, LcdScoring sc,
-                              hipStream_t *side = nullptr, hipEvent_t *sev = nullptr, DevBuf *d_gate = nullptr) {
+                              hipStream_t *side = nullptr, hipEvent_t *sev = nullptr, DevBuf *d_gate = nullptr, PoaSpare *spare = nullptr) {
     HIPCHK(hipMemcpyAsync(d_chains.p, sub.data(), sub.size() * sizeof(PoaChain), hipMemcpyHostToDevice, st));
     // The wide classes start first, widest first: a 1 024-thread chain needs ALL the vector registers of a CU and a 512-thread chain half of
     // them, so once narrower workgroups are spread over the chip they wait for a CU to drain completely -- and they are the longest
@@ -833,7 +834,10 @@ static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, 
     for (size_t k : order) {
         int best = 0;
         for (int t = 1; t < ns; ++t) if (load[t] < load[best]) best = t;
-        load[best] += grps[k].cost;
+        // a stream runs its kernels one after the other, and a kernel lasts at least as long as its longest chain whatever else shares the chip: what adds up on a
+        // stream is tail + share of the chip's work, not the work alone (two groups of a few long chains each on one stream were the whole tail of an
+        // SV-shape submission: 7.8 s before the last group could start, with 0.9 s of work for 256 CUs)
+        load[best] += grps[k].tail + grps[k].cost / std::max(1, g_n_cus);
         // stream 0 is the caller's; the others are side streams that first wait for the chain table to be uploaded
         hipStream_t s = best == 0 ? st : side[best - 1];
         if (best != 0 && !used[best]) HIPCHK(hipStreamWaitEvent(s, sev[0], 0));
@@ -841,7 +845,7 @@ static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, 
         const int cls = chain_threads(sub[grps[k].i]);
         if (gate && cls < 1024 && (target0 > 0 || (cls < 512 && target1 > 0))) lcd_launch_gate(gate, target0, cls < 512 ? target1 : 0, s);
         lcd_launch_poa((const PoaChain *)d_chains.p + grps[k].i, d_reads, nullptr, nullptr, nullptr, (PoaChainOut *)d_outs.p + grps[k].i, sc, (int)(grps[k].j - grps[k].i), cls,
-                       sub[grps[k].i].lds_words * 4, s, !gate ? nullptr : cls >= 1024 ? gate : cls >= 512 ? gate + 1 : nullptr);
+                       sub[grps[k].i].lds_words * 4, s, !gate ? nullptr : cls >= 1024 ? gate : cls >= 512 ? gate + 1 : nullptr, spare);
         HIPCHK(hipGetLastError());
     }
     for (int t = 1; t < ns; ++t) if (used[t]) { HIPCHK(hipEventRecord(sev[t], side[t - 1])); HIPCHK(hipStreamWaitEvent(st, sev[t], 0)); }
@@ -886,7 +890,7 @@ int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
     if (rc != -11 || nb <= 1) return rc;
     // the work arenas (DP cells, wavefronts, edlib columns) are transient: dropped around each half so that the halves do not add up;
     // the outputs of a half stay in its leader's buffers until they are downloaded
-    auto drop = [](lcd_batch_t *b) { b->d_poa_arena.release(); b->arena_extra.clear(); b->d_var_work.release(); };
+    auto drop = [](lcd_batch_t *b) { b->d_poa_arena.release(); b->arena_extra.clear(); b->d_var_work.release(); b->d_spare.release(); };
     const int h = nb / 2;
     drop(bs[0]);
     const int r1 = lcd_batch_run_many(bs, h);
@@ -1143,12 +1147,36 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                 if (pc.slot_flags) pc.slot_flags = L->d_slot_flags.addr() + (pc.slot_flags - 1) * 4;
                 sub[i] = pc; sub[i].read0 += (int)pread_base[k]; // the device read table is the concatenation of the batches' tables
             }
+            // Spare DP memory (PoaSpare, poa_kernel.hip grow_dp_region): what a chain whose estimate was too small for one of its reads continues in.  Taken
+            // after the arenas have their memory, from what the budget leaves (LCD_SPARE_GB caps it, 0 switches it off); without it -- or once it is used
+            // up -- such a chain comes back with LCD_ERR_CELLS and is re-run from its first read in the next round, as before.
+            PoaSpare *d_spare = nullptr;
+            {
+                const double spare_gb = getenv("LCD_SPARE_GB") ? atof(getenv("LCD_SPARE_GB")) : 16.0; // (read per call: tests switch it)
+                if (spare_gb <= 0) L->d_spare.release();
+                else if (L->d_spare.cap == 0) {
+                    const long long room = (dev_budget(L->device) - g_dev_bytes[L->device].load() - (4ll << 30)) / 2;
+                    const long long want = std::min<long long>((long long)(spare_gb * (double)(1ll << 30)), room);
+                    if (want >= (64ll << 20) && L->d_spare.ensure((size_t)want, 40)) { /* no spare pool this time */ }
+                }
+                if (L->d_spare.cap > 4096) {
+                    PoaSpare hdr; hdr.used = 0; hdr.cap = L->d_spare.cap - 256; hdr.base = L->d_spare.addr() + 256; hdr.n_grown = hdr.n_refused = 0;
+                    HIPCHK(hipMemcpyAsync(L->d_spare.p, &hdr, sizeof(hdr), hipMemcpyHostToDevice, st));
+                    d_spare = (PoaSpare *)L->d_spare.p;
+                }
+            }
             HIPCHK(hipEventRecord(L->ev[6], st));
-            { int rc2 = launch_poa_grouped(st, sub, L->d_chains, (const PoaRead *)L->d_preads.p, L->d_poa_outs, sc, L->side, L->sev, &L->d_gate); if (rc2) return rc2; }
+            { int rc2 = launch_poa_grouped(st, sub, L->d_chains, (const PoaRead *)L->d_preads.p, L->d_poa_outs, sc, L->side, L->sev, &L->d_gate, d_spare); if (rc2) return rc2; }
             HIPCHK(hipEventRecord(L->ev[7], st));
             std::vector<PoaChainOut> tmp(sub.size());
             HIPCHK(hipMemcpyAsync(tmp.data(), L->d_poa_outs.p, sub.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, st));
+            PoaSpare spare_seen; spare_seen.used = 0; spare_seen.n_grown = spare_seen.n_refused = 0;
+            if (d_spare) HIPCHK(hipMemcpyAsync(&spare_seen, d_spare, sizeof(PoaSpare), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
+            if (d_spare) {
+                for (int k = 0; k < nb; ++k) bs[k]->st.poa_grown += (int)spare_seen.n_grown;
+                if (getenv("LCD_MEM_DEBUG")) fprintf(stderr, "[mem] round %d: spare DP memory %.2f GB: %u regions grown in place (%.2f GB), %u refused\n", round, L->d_spare.cap / 1e9, spare_seen.n_grown, spare_seen.used / 1e9, spare_seen.n_refused);
+            }
             { float kms = 0; hipEventElapsedTime(&kms, L->ev[6], L->ev[7]); for (int k = 0; k < nb; ++k) { bs[k]->st.ms_poa_kernel += kms; bs[k]->st.n_poa_launches++; }
               if (getenv("LCD_MEM_DEBUG")) fprintf(stderr, "[mem] round %d: %zu chains, POA kernels %.1f ms\n", round, which.size(), kms); }
             std::vector<size_t> again; size_t n_node_ovf = 0, n_cert_fail = 0;
@@ -1454,6 +1482,15 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                     o.rt_begin / 1e5, o.rt_end / 1e5, (double)o.t_total); }
     }
     if (getenv("LCD_PROFILE_CHAINS")) {
+        { // the chains that end last: the tail of the submission (times on the device's 100 MHz clock, relative to the first chain's start)
+            std::vector<size_t> ord(nC_all); unsigned long long t0 = ~0ull;
+            for (size_t g = 0; g < nC_all; ++g) { ord[g] = g; t0 = std::min(t0, bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]].rt_begin); }
+            auto O = [&](size_t g) -> const PoaChainOut & { return bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]]; };
+            std::sort(ord.begin(), ord.end(), [&](size_t a, size_t c) { return O(a).rt_end > O(c).rt_end; });
+            for (size_t q = 0; q < std::min<size_t>(10, ord.size()); ++q) { const size_t g = ord[q]; const PoaChainOut &o = O(g);
+                fprintf(stderr, "[tail] thr %4d lds %3dK mode %d reads %3d maxlen %5d nodes %6d: %.1f .. %.1f ms  (dp %.0f%% bt %.0f%% graph %.0f%% out %.0f%%)  cells %.2e\n", chain_threads(PC(g)), PC(g).lds_words * 4 >> 10, PC(g).mode, PC(g).n_reads, PC(g).max_len, o.n_node,
+                        (o.rt_begin - t0) / 1e5, (o.rt_end - t0) / 1e5, 100.0 * o.t_dp / o.t_total, 100.0 * o.t_bt / o.t_total, 100.0 * o.t_graph / o.t_total, 100.0 * o.t_out / o.t_total, (double)o.cells); }
+        }
         { // CU-seconds per launch group: sum of chain ticks / workgroups that fit a CU (LDS- or register-limited)
             std::map<long long, std::pair<double, int>> gsum;
             for (size_t g = 0; g < nC_all; ++g) { const PoaChainOut &o = bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]]; auto &e = gsum[chain_group_key(PC(g))]; e.first += (double)o.t_total; e.second++; }

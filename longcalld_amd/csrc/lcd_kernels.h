@@ -4,7 +4,7 @@
 #include "lcd_types.h"
 
 void lcd_launch_poa(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool, uint8_t *arena, uint8_t *outpool,
-                    PoaChainOut *outs, LcdScoring sc, int n_chains, int threads, int lds_bytes, hipStream_t stream, int *gate = nullptr);
+                    PoaChainOut *outs, LcdScoring sc, int n_chains, int threads, int lds_bytes, hipStream_t stream, int *gate = nullptr, PoaSpare *spare = nullptr);
 void lcd_launch_cu_probe(int *seen /* int[4096], zeroed */, hipStream_t stream);
 void lcd_launch_gate(int *ctr, int target0, int target1, hipStream_t stream);
 // lds_bytes > 0: the jobs keep their value ring in that much dynamic LDS (one wavefront per job); 0: ring in HBM, 256 threads per job

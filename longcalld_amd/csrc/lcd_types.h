@@ -84,6 +84,11 @@ struct PoaChainOut {
     unsigned long long t_plan, t_poll;                             // inside t_dp: plan-window refreshes / mailbox polls of one wavefront (unbanded rows)
 };
 
+// Spare DP memory of a launch set (lcd_host.cpp round loop): a chain whose DP region is too small for the read at hand (LCD_ERR_CELLS) takes a region four
+// times larger from here and repeats THAT read (poa_kernel.hip grow_dp_region) instead of ending; only when the pool is exhausted does the chain come back to
+// the host to be re-run from its first read with larger estimates.  Bump allocation, reset by the host between rounds.
+struct PoaSpare { unsigned long long used, cap, base; unsigned n_grown, n_refused; };
+
 // arena layout (byte offsets relative to ws_off); identical on host and device
 struct PoaLayout {
     uint64_t H, E1, E2;                                  // DP region of 4*cell_cap bytes (codes | ordinals | spilled rows, or H/E1/E2 planes)

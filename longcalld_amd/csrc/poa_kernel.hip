@@ -2237,6 +2237,42 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
     return n_cig;
 }
 
+// A chain's DP region (code / ordinal / spilled-row planes, or the H / E1 / E2 planes of the generic rows) is sized by the host from an estimate.  When a read's rows
+// do not fit, the workgroup takes a region four times larger (up to the worst case: every node a row of the longest read) from the launch set's spare pool and the
+// caller repeats the read: nothing of the chain is lost, where a re-run by the host starts again from the first read -- and a submission's re-runs, a few long
+// chains, were a second round as long as the first on the SV shape.  The graph arrays stay where they are; the old region is simply left behind (bump
+// allocation; the host resets the pool between rounds).  false: no pool, pool exhausted, or the region already at its worst case.
+template <int NT>
+__device__ __attribute__((noinline)) bool grow_dp_region(Ctx &g, Smem &sm, const PoaChain &ch, PoaSpare *sp) {
+    if (!sp || ch.cert) return false;
+    const unsigned long long worst = (unsigned long long)g.node_cap * (unsigned long long)(ch.max_len + 1);
+    if (g.cell_cap >= worst) return false;
+    unsigned long long nc = g.cell_cap * 4ull; if (nc > worst) nc = worst;
+    const unsigned long long a = lcd_align_up(nc, 16), bytes = lcd_align_up(a * (unsigned long long)(g.spill_x > 2 ? 1 + 4 + g.spill_x : 4) + 64, 256);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long old = __hip_atomic_load(&sp->used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), off = ~0ull;
+        const unsigned long long cap = sp->cap;
+        for (;;) {
+            if (old + bytes > cap) break;
+            const unsigned long long seen = atomicCAS(&sp->used, old, old + bytes);
+            if (seen == old) { off = old; break; }
+            old = seen;
+        }
+        atomicAdd(off != ~0ull ? &sp->n_grown : &sp->n_refused, 1u);
+        sm.bc[6] = (int)(unsigned)(off & 0xffffffffu); sm.bc[7] = (int)(unsigned)(off >> 32);
+    }
+    __syncthreads();
+    const unsigned long long off = (unsigned long long)(unsigned)sm.bc[6] | ((unsigned long long)(unsigned)sm.bc[7] << 32);
+    __syncthreads();
+    if (off == ~0ull) return false;
+    uint8_t *p = (uint8_t *)(uintptr_t)sp->base + off;
+    g.H = (int *)p; g.E1 = g.H + nc / 3; g.E2 = g.E1 + nc / 3;
+    g.code8 = p; g.ord = (int *)(p + a); g.spill = (int *)(p + (g.spill_x > 2 ? 5 : 2) * a);
+    g.cell_cap = nc;
+    return true;
+}
+
 // the output phase of a chain (MSA rank, rows, clusters, consensus: oracle/poa.c poa_output): a function of its own, like the per-read phases (the chain kernel's body
 // is what spills)
 template <int NT>
@@ -2409,7 +2445,7 @@ __device__ __attribute__((noinline)) void chain_output(Ctx &g, Smem &sm, const P
 template <int NT>
 __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool,
                                                            uint8_t *arena, uint8_t *outpool, PoaChainOut *outs, LcdScoring sc,
-                                                           int n_chains, int *gate) {
+                                                           int n_chains, int *gate, PoaSpare *spare) {
     const int cid = blockIdx.x;
     if (cid >= n_chains) return;
     if (gate && threadIdx.x == 0) atomicAdd(gate, 1); // "this workgroup is resident" (see lcd_gate_kernel)
@@ -2513,7 +2549,12 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
         const int len = r.len - beg_cut - end_cut;
         int n_cig = 0;
         if (g.n_node > 2) {
-            n_cig = align_to_subgraph<NT>(g, sm, ring, sseq, sc, ch.mode == 0 ? 10 : -1, ch.mode == 0 ? 10 : 0, exc_beg, exc_end, seq, len, &cells);
+            for (;;) { // (a read whose rows outgrow the chain's DP region is repeated in a larger one from the launch set's spare pool: grow_dp_region)
+                const unsigned long long cells0 = cells; const long long adj0 = g.alg_adjust;
+                n_cig = align_to_subgraph<NT>(g, sm, ring, sseq, sc, ch.mode == 0 ? 10 : -1, ch.mode == 0 ? 10 : 0, exc_beg, exc_end, seq, len, &cells);
+                if (g.status != LCD_ERR_CELLS || !grow_dp_region<NT>(g, sm, ch, spare)) break;
+                cells = cells0; g.alg_adjust = adj0; g.status = LCD_OK;
+            }
             if (len > 0) { aligned_bases += len; n_aligned_reads++; }
         }
         // graph update + re-sort: serial pointer work on thread 0; results published through LDS
@@ -2572,7 +2613,7 @@ __global__ void lcd_gate_kernel(int *ctr, int target0, int target1) {
 void lcd_launch_gate(int *ctr, int target0, int target1, hipStream_t stream) { hipLaunchKernelGGL(lcd_gate_kernel, dim3(1), dim3(1), 0, stream, ctr, target0, target1); }
 
 void lcd_launch_poa(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool, uint8_t *arena, uint8_t *outpool,
-                    PoaChainOut *outs, LcdScoring sc, int n_chains, int threads, int lds_bytes, hipStream_t stream, int *gate) {
+                    PoaChainOut *outs, LcdScoring sc, int n_chains, int threads, int lds_bytes, hipStream_t stream, int *gate, PoaSpare *spare) {
     if (n_chains <= 0) return;
     static std::once_flag attr_once[16]; // (concurrent submitters: lcd_batch_run_many is thread-safe; function attributes are per device)
     int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
@@ -2583,7 +2624,7 @@ void lcd_launch_poa(const PoaChain *chains, const PoaRead *reads, const uint8_t 
         hipFuncSetAttribute((const void *)lcd_poa_chain_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         hipFuncSetAttribute((const void *)lcd_poa_chain_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     });
-#define LCD_LAUNCH(NT) hipLaunchKernelGGL(lcd_poa_chain_kernel<NT>, dim3(n_chains), dim3(NT), lds_bytes, stream, chains, reads, pool, arena, outpool, outs, sc, n_chains, gate)
+#define LCD_LAUNCH(NT) hipLaunchKernelGGL(lcd_poa_chain_kernel<NT>, dim3(n_chains), dim3(NT), lds_bytes, stream, chains, reads, pool, arena, outpool, outs, sc, n_chains, gate, spare)
     if (threads <= 64) LCD_LAUNCH(64);
     else if (threads <= 128) LCD_LAUNCH(128);
     else if (threads <= 256) LCD_LAUNCH(256);

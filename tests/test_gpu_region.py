@@ -408,3 +408,30 @@ def test_certified_band_equals_full_rows_at_scale(lcd, monkeypatch):
     assert d1 == d0
     assert st1["poa_cells"] == st0["poa_cells"] == st0["poa_cells_computed"]
     assert st1["poa_cells_computed"] * 2 < st0["poa_cells_computed"]
+
+
+@pytest.mark.parametrize("shape", ["hifi", "ont", "sv"])
+def test_dp_regions_grow_in_place(lcd, oracle, monkeypatch, shape):
+    """DP regions sized far too small (test switch LCD_CELL_SHRINK): a chain whose read does not fit takes a larger region from the launch set's spare pool and
+    repeats that read (poa_kernel.hip grow_dp_region) -- every class of rows, with and without the certified band; without a pool (LCD_SPARE_GB=0) the same
+    chains come back and are re-run by the host.  Both == the unshrunk run's digest, and (hifi, ont) region by region == oracle"""
+    from longcalld_amd import jobs
+    if shape == "sv":
+        regs = jobs.make_regions(41, 24, jobs.SV)     # (wide classes, systolic full rows, long K1 bands; compared with the unshrunk run, which tests/test_gpu_sv.py holds against the oracle)
+    else:
+        regs = jobs.make_regions(40, 60 if shape == "hifi" else 24, jobs.HIFI if shape == "hifi" else jobs.ONT)
+    o = lcd.default_opt(); o.is_ont = 0 if shape == "hifi" else 1
+    monkeypatch.setenv("LCD_CERT", "0" if shape == "hifi" else "1")
+    _, _, st_ref, d_ref = _run_batch(lcd, regs, o)
+    monkeypatch.setenv("LCD_CELL_SHRINK", "24")
+    got, ids, st, d = _run_batch(lcd, regs, o)
+    assert d == d_ref and st["poa_grown"] > 0 and st["poa_cells"] == st_ref["poa_cells"]
+    for r, g, sid in zip(regs, got, ids):
+        if shape == "sv":
+            break
+        exp = oracle.collect_noisy_reg_aln_strs(r)
+        assert (sid == exp["sorted_ids"]).all()
+        same_result(exp, g)
+    monkeypatch.setenv("LCD_SPARE_GB", "0")
+    _, _, st0, d0 = _run_batch(lcd, regs, o)
+    assert d0 == d_ref and st0["poa_grown"] == 0 and st0["poa_retries"] > 0
