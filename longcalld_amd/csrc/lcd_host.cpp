@@ -674,7 +674,7 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     // batches: 52 k instead of 66 k -- so it is off by default.)
     const int solo_len = getenv("LCD_CERT_SOLO_LEN") ? atoi(getenv("LCD_CERT_SOLO_LEN")) : 0; // (read per call: a test switches it)
     if (lvl < 0) lvl = (C.mode == 1 && maxl < 65536 && (cert_mode == 2 || (cert_mode == 1 && !opt.is_ont))) ? (solo_len > 0 && maxl >= solo_len ? 2 : 1) : 0;
-    pc.cert = C.mode == 1 ? lvl : 0; pc.pad_ = 0;
+    pc.cert = C.mode == 1 ? lvl : 0; pc.ring_k = 0;
     // graph capacity: the worst case is one node per base of every read (sum), the usual case a little more than the longest read.  Sized
     // from an estimate (a few per cent of new nodes per read on top of the backbone; g_node_hint learns noisier data); a chain that runs
     // out (LCD_ERR_NODES / LCD_ERR_EDGES) is re-run with 4x more per retry, up to the worst case.  The worst case for everybody was
@@ -749,6 +749,13 @@ static void chain_class(PoaChain &pc, bool noisy) {
     else { threads = 1024; K = 2; wmax = 4096; } // wider rows take the generic (HBM) rows of the kernel
     const long long est_nodes = (long long)(pc.max_len * 1.15) + 64;
     const long long seq_bytes = lcd_align_up((long long)pc.max_len + 28, 16) + lcd_align_up(est_nodes + 16, 16); // query cache + first-predecessor distances
+    // ring slots of the single-wavefront class: 2, except long K1 chains of noisy reads -- their graphs interleave the alternatives of every column, a row's
+    // predecessors sit 3 - 6 rows back as often as not, and a predecessor that has left the ring costs the row two dependent trips to HBM (its metadata, then
+    // its spilled values); those chains are few and they are the latency of an SV-shape submission, so they get LCD_RING_K (8) slots and the LDS that takes
+    if (threads == 64 && pc.mode == 0 && noisy) {
+        static const int rk_env = getenv("LCD_RING_K") ? atoi(getenv("LCD_RING_K")) : 8, rk_len = getenv("LCD_RING_K_LEN") ? atoi(getenv("LCD_RING_K_LEN")) : 1500;
+        if (pc.max_len >= rk_len && rk_env >= 2 && (rk_env & (rk_env - 1)) == 0 && rk_env <= 32) K = rk_env;
+    }
     const long long dp_bytes = (long long)K * 3 * wmax * 4 + seq_bytes; // the ring holds `wmax` columns per slot (4 * threads, or the narrower preferred window of a single-wavefront banded chain)
     // the re-sort's LDS copy of the graph: 8 B per node + 4 B per edge (topo_sort_block); edges ~ nodes + a few per bubble
     long long need = std::max(dp_bytes, est_nodes * 8 + (est_nodes + est_nodes / 8) * 4 + 64);
@@ -758,7 +765,7 @@ static void chain_class(PoaChain &pc, bool noisy) {
       // nearly every read) preferred 16 KB while the Kahn walk was a serial pass over every node; since it jumps chains (v12) 8 KB is best for them
       // too (+6 % over 16 KB).  LCD_LDS_CAP_KB overrides.
         static const int cap_env = getenv("LCD_LDS_CAP_KB") ? atoi(getenv("LCD_LDS_CAP_KB")) : -1;
-        const int cap_kb = cap_env >= 0 ? cap_env : 8; (void)noisy;
+        const int cap_kb = cap_env >= 0 ? cap_env : 8;
         // (tried: certified-band K2 chains -- few, some long: 35 reads x 3.7 kb is the critical path of a submission, a quarter of it re-sorts -- with the pool
         //  the re-sort wants (32 / 64 KB instead of the cap): 42 k / 30 k instead of 43 k regions/s at 20 batches; the same for the long ones only (>= 1 000 /
         //  1 500 bases): 30 k / 28 k)
@@ -770,7 +777,7 @@ static void chain_class(PoaChain &pc, bool noisy) {
     static const int buckets[] = {8 << 10, 12 << 10, 16 << 10, 24 << 10, 32 << 10, 48 << 10, 64 << 10, 96 << 10, 148 << 10};
     int lds = buckets[8];
     for (int b : buckets) if (need <= b) { lds = b; break; }
-    pc.threads = threads; pc.wmax = wmax; pc.lds_words = lds / 4;
+    pc.threads = threads; pc.wmax = wmax; pc.lds_words = lds / 4; pc.ring_k = threads == 64 ? K : 0;
 }
 static int chain_threads(const PoaChain &pc) { return pc.threads; }
 static long long chain_group_key(const PoaChain &pc) { return (long long)pc.threads * (1 << 20) + pc.lds_words; }

@@ -65,7 +65,7 @@ struct PoaChain {
     uint64_t slot_bytes;
     uint64_t cu_rank;     // device address of int[4096]: raw (XCC, SE, SH, CU) id -> compact CU index, -1 unknown; 0: none
     int n_slots, per_cu;
-    int cert, pad_;       // cert 1: K2 chain in the single-wavefront class, rows restricted to the certified band (poa_kernel.hip align_certified)
+    int cert, ring_k;     // ring_k: ring slots of the single-wavefront class's windowed rows (a power of two >= 2, 0 = 2; the other classes: 2), lcd_host.cpp chain_class;  cert 1: K2 chain in the single-wavefront class, rows restricted to the certified band (poa_kernel.hip align_certified)
 };
 
 struct PoaChainOut {
