@@ -768,7 +768,9 @@ static void chain_class(PoaChain &pc, bool noisy) {
         const int cap_kb = cap_env >= 0 ? cap_env : 8;
         // (tried: certified-band K2 chains -- few, some long: 35 reads x 3.7 kb is the critical path of a submission, a quarter of it re-sorts -- with the pool
         //  the re-sort wants (32 / 64 KB instead of the cap): 42 k / 30 k instead of 43 k regions/s at 20 batches; the same for the long ones only (>= 1 000 /
-        //  1 500 bases): 30 k / 28 k)
+        //  1 500 bases): 30 k / 28 k; again after the streams learned to count a group's longest chain, so that the extra launch group is not queued behind
+        //  another: 41 k / 44 k / 48 k for chains >= 1 500 / 2 500 / 3 000 bases against 60.8 k -- it is the chains themselves that get slower with the
+        //  re-sort's LDS path, not their place in the queue)
         const int cap_here = cap_kb;
         if (cap_here > 0 && threads == 64) need = std::max(dp_bytes, std::min<long long>(need, (long long)cap_here << 10));
     }
