@@ -175,6 +175,12 @@ int lcd_batch_add_region(lcd_batch_t *b, int64_t reg_len, int n_reads, const int
 int lcd_batch_add_region_from_chunk(lcd_batch_t *b, const lcd_read_view_t *chunk_reads, int64_t noisy_reg_beg,
                                     int64_t noisy_reg_end, int n_noisy_reg_reads, const int *noisy_reads,
                                     const uint8_t *ref_seq, int ref_seq_len);
+/* the same region with the reads' bases left as they are in their BAM records (4 bits per base): the host copies the slices' bytes, lcd_batch_upload unpacks them
+ * on the device (seq_nt16_int[bam_seqi()], src/align.c:1445-1448) into the batch's input pool -- no per-base loop on the host, half the bytes over PCIe for the
+ * reads.  Same results as lcd_batch_add_region_from_chunk. */
+int lcd_batch_add_region_from_chunk_packed(lcd_batch_t *b, const lcd_read_view_t *chunk_reads, int64_t noisy_reg_beg,
+                                    int64_t noisy_reg_end, int n_noisy_reg_reads, const int *noisy_reads,
+                                    const uint8_t *ref_seq, int ref_seq_len);
 int lcd_batch_upload(lcd_batch_t *b);  /* host -> HBM (not part of the timed hot path) */
 int lcd_batch_run(lcd_batch_t *b);     /* anchors -> POA chains -> ref/cons WFA -> strings; inputs and outputs stay in HBM */
 /* the same for n uploaded batches JOINTLY (one set of launches per stage over the jobs / chains of all of them: a chain is a

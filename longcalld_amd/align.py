@@ -241,13 +241,14 @@ class RegionBatch:
         self.n_reads.append(n)
         return idx
 
-    def add_region_from_chunk(self, views, reg_beg, reg_end, noisy_reads, ref_slice):
+    def add_region_from_chunk(self, views, reg_beg, reg_end, noisy_reads, ref_slice, packed=False):
         """region [reg_beg, reg_end] (1-based, flanks included) of a chunk whose reads are `views` (make_read_views): the digar walk of
-        collect_noisy_read_info (src/align.c:1377-1461) runs inside the library; noisy_reads = chunk read ids overlapping the region"""
+        collect_noisy_read_info (src/align.c:1377-1461) runs inside the library; noisy_reads = chunk read ids overlapping the region.
+        packed: the reads' bases stay 4-bit packed on the host and are unpacked on the device by upload() (lcd_batch_add_region_from_chunk_packed)"""
         ids = np.ascontiguousarray(noisy_reads, np.int32)
         ref = np.ascontiguousarray(ref_slice, np.uint8)
-        idx = check(self.lib.lcd_batch_add_region_from_chunk(self.h, views[0], int(reg_beg), int(reg_end), len(ids), ids.ctypes.data_as(i32p),
-                                                             _p8(ref), len(ref)), self.lib)
+        fn = self.lib.lcd_batch_add_region_from_chunk_packed if packed else self.lib.lcd_batch_add_region_from_chunk
+        idx = check(fn(self.h, views[0], int(reg_beg), int(reg_end), len(ids), ids.ctypes.data_as(i32p), _p8(ref), len(ref)), self.lib)
         self.n_reads.append(len(ids))
         return idx
 

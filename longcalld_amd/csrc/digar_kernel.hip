@@ -232,6 +232,28 @@ void lcd_launch_region_support(const IvRec *regs, int n_regs, const long long *r
     if (n_regs > 0) hipLaunchKernelGGL(lcd_region_support_kernel, dim3(n_regs), dim3(64), 0, stream, regs, n_regs, read_beg, read_end, iv_off, ivs, n_reads, total, noisy);
 }
 
+// Read slices of noisy regions, 4-bit packed -> 1 B/base codes in the batch's input pool (the per-base loop of collect_noisy_read_info, src/align.c:1445-1448:
+// seq_nt16_int[bam_seqi(bseq, j)]).  One workgroup per slice, four bases per lane and step: two or three packed bytes in, one 32-bit store out (the pool's
+// slices start 16-byte aligned).  HBM-bound and small: 0.5 B read + 1 B written per base, ~20 MB per configs[1] batch.
+__global__ void __launch_bounds__(256) lcd_unpack_kernel(const UnpackJob *jobs, const uint8_t *packed, uint8_t *pool) {
+    const UnpackJob j = jobs[blockIdx.x];
+    const uint8_t *s = packed + j.src; uint8_t *d = pool + j.dst;
+    auto code = [](unsigned c) -> unsigned { return c == 1 ? 0u : c == 2 ? 1u : c == 4 ? 2u : c == 8 ? 3u : 4u; }; // htslib seq_nt16_int: A C G T, everything else 4
+    const int n4 = j.len & ~3;
+    for (int k = threadIdx.x * 4; k < n4; k += blockDim.x * 4) {
+        const int q = j.first + k; // nibble index of the first of four bases
+        const unsigned b0 = s[q >> 1], b1 = s[(q >> 1) + 1], b2 = (q & 1) ? s[(q >> 1) + 2] : 0u;
+        const unsigned w = (b0 << 16) | (b1 << 8) | b2; // nibbles 0..5, high first
+        const int sh = (q & 1) ? 16 : 20;                // first base: nibble 1 or 0 of w's 24 bits
+        const unsigned o = code((w >> sh) & 15) | (code((w >> (sh - 4)) & 15) << 8) | (code((w >> (sh - 8)) & 15) << 16) | (code((w >> (sh - 12)) & 15) << 24);
+        *(unsigned *)(d + k) = o;
+    }
+    for (int k = n4 + threadIdx.x; k < j.len; k += blockDim.x) { const int q = j.first + k; d[k] = (uint8_t)code((s[q >> 1] >> ((~q & 1) << 2)) & 15); }
+}
+void lcd_launch_unpack(const UnpackJob *jobs, int n_jobs, const uint8_t *packed, uint8_t *pool, hipStream_t stream) {
+    if (n_jobs > 0) hipLaunchKernelGGL(lcd_unpack_kernel, dim3(n_jobs), dim3(256), 0, stream, jobs, packed, pool);
+}
+
 void lcd_launch_digar(const DigarJob *jobs, DigarOut *outs, DigarOpt opt, int n_jobs, hipStream_t stream) {
     if (n_jobs > 0) hipLaunchKernelGGL(lcd_digar_kernel, dim3(n_jobs), dim3(64), 0, stream, jobs, outs, opt, n_jobs);
 }

@@ -199,6 +199,7 @@ struct lcd_batch_s {
     hipEvent_t ev[10];
     hipEvent_t sev[LCD_NSIDE + 1];
     std::vector<uint8_t> h_pool;
+    std::vector<uint8_t> h_packed; std::vector<UnpackJob> unpack_jobs; // read slices handed over 4-bit packed: unpacked into d_in after the upload
     std::vector<RegionRec> regs;
     std::vector<ChainRec> chains;
     std::vector<PoaRead> preads;         // seq_off relative to h_pool until run()
@@ -209,7 +210,7 @@ struct lcd_batch_s {
     // (d_poa_arena: the ONE transient workspace of a submission led by this batch -- chain arenas, WFA wavefronts and edlib blocks in turn)
     DevBuf d_in, d_chains, d_preads, d_poa_arena, d_poa_out, d_poa_outs, d_ed_jobs, d_ed_outs, d_wfa_jobs,
         d_wfa_out, d_wfa_outs, d_str_jobs, d_str_outs, d_final, d_gate, d_cmp_jobs, d_cmp_outs, d_cmp_seg, d_cmp_segres, d_seg_out, d_rr,
-        d_var_jobs, d_var_outs, d_var_work, d_vreg_jobs, d_vreg_outs, d_var_out, d_slot_flags, d_spare;
+        d_var_jobs, d_var_outs, d_var_work, d_vreg_jobs, d_vreg_outs, d_var_out, d_slot_flags, d_spare, d_packed, d_unpack;
     bool uploaded = false, ran = false, downloaded = false;
     // results (host)
     std::vector<PoaChainOut> couts;
@@ -433,14 +434,15 @@ void lcd_batch_destroy(lcd_batch_t *b) {
     delete b;
 }
 void lcd_batch_clear(lcd_batch_t *b) {
-    b->h_pool.clear(); b->regs.clear(); b->chains.clear(); b->preads.clear(); b->anchors.clear(); b->ed_jobs.clear(); b->wfa_jobs.clear();
+    b->h_pool.clear(); b->h_packed.clear(); b->unpack_jobs.clear(); b->regs.clear(); b->chains.clear(); b->preads.clear(); b->anchors.clear(); b->ed_jobs.clear(); b->wfa_jobs.clear();
     b->uploaded = b->ran = b->downloaded = false;
     memset(&b->st, 0, sizeof(b->st));
 }
 
 static uint64_t pool_push(std::vector<uint8_t> &pool, const uint8_t *p, int n) {
     uint64_t off = pool.size();
-    pool.insert(pool.end(), p, p + n);
+    if (p) pool.insert(pool.end(), p, p + n);
+    else pool.resize(pool.size() + n, (uint8_t)4); // a hole: filled on the device (lcd_batch_add_region_from_chunk_packed)
     size_t pad = (16 - (pool.size() & 15)) & 15;
     pool.insert(pool.end(), pad, (uint8_t)4);
     return off;
@@ -575,8 +577,8 @@ int lcd_batch_add_region(lcd_batch_t *b, int64_t reg_len, int n_reads, const int
     return region_idx;
 }
 
-int lcd_batch_add_region_from_chunk(lcd_batch_t *b, const lcd_read_view_t *cr, int64_t reg_beg, int64_t reg_end, int n, const int *noisy_reads,
-                                    const uint8_t *ref_seq, int ref_seq_len) {
+static int add_region_from_chunk(lcd_batch_t *b, const lcd_read_view_t *cr, int64_t reg_beg, int64_t reg_end, int n, const int *noisy_reads,
+                                 const uint8_t *ref_seq, int ref_seq_len, const bool packed) {
     // collect_noisy_read_info, src/align.c:1377-1461
     static const uint8_t nt16_int[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4}; // htslib seq_nt16_int
     std::vector<int> ids(n), lens(n), covers(n), haps(n), rbs(n), res(n); std::vector<int64_t> pss(n);
@@ -615,21 +617,42 @@ int lcd_batch_add_region_from_chunk(lcd_batch_t *b, const lcd_read_view_t *cr, i
         const int L = re - rb + 1;
         rbs[i] = rb; res[i] = re;
         ids[i] = noisy_reads[i]; lens[i] = L; covers[i] = cover; haps[i] = rv.hap; pss[i] = rv.phase_set;
-        if (L > 0) {
+        if (L > 0 && !packed) {
             seqs[i].resize(L); quals[i].resize(L);
             for (int j = rb; j <= re; ++j) {
                 seqs[i][j - rb] = nt16_int[(rv.bseq[j >> 1] >> ((~j & 1) << 2)) & 0xf]; // bam_seqi
                 quals[i][j - rb] = rv.qual ? rv.qual[j] : 0;
             }
         }
-        sp[i] = seqs[i].data(); qp[i] = quals[i].data();
+        if (!packed) { sp[i] = seqs[i].data(); qp[i] = quals[i].data(); }
+        else { sp[i] = nullptr; qp[i] = rv.qual && L > 0 ? rv.qual + rb : nullptr; } // (the qualities are only read on the host: the sampling rule of long regions)
     }
     const int ri = lcd_batch_add_region(b, reg_end - reg_beg + 1, n, ids.data(), lens.data(), sp.data(), qp.data(), covers.data(), haps.data(),
                                         pss.data(), ref_seq, ref_seq_len);
     if (ri >= 0) // remember each read's slice (the caller of update_digars_from_aln_str needs read_reg_beg / read_reg_end, src/align.c:1748)
         for (RegRead &r : b->regs[ri].reads)
-            for (int i = 0; i < n; ++i) if (noisy_reads[i] == r.id) { r.rb = rbs[i]; r.re = res[i]; break; }
+            for (int i = 0; i < n; ++i) if (noisy_reads[i] == r.id) {
+                r.rb = rbs[i]; r.re = res[i];
+                if (packed && r.len > 0) { // the slice's bytes as they are in the record; its place in the pool is a hole until lcd_batch_upload has run lcd_unpack_kernel
+                    const lcd_read_view_t &rv = cr[r.id];
+                    UnpackJob j; j.src = b->h_packed.size(); j.dst = r.off; j.first = rbs[i] & 1; j.len = r.len;
+                    b->h_packed.insert(b->h_packed.end(), rv.bseq + (rbs[i] >> 1), rv.bseq + (res[i] >> 1) + 1);
+                    b->h_packed.push_back(0); // (the kernel's four-base steps read one byte past an odd start)
+                    b->unpack_jobs.push_back(j);
+                }
+                break;
+            }
     return ri;
+}
+int lcd_batch_add_region_from_chunk(lcd_batch_t *b, const lcd_read_view_t *cr, int64_t reg_beg, int64_t reg_end, int n, const int *noisy_reads,
+                                    const uint8_t *ref_seq, int ref_seq_len) {
+    return add_region_from_chunk(b, cr, reg_beg, reg_end, n, noisy_reads, ref_seq, ref_seq_len, false);
+}
+// the same region, with the reads' bases left 4-bit packed: the host copies each slice's bytes as they are in the BAM record (half a byte per base, no per-base
+// loop) and lcd_batch_upload unpacks them on the device into the places add_region reserved.  Results are those of lcd_batch_add_region_from_chunk.
+int lcd_batch_add_region_from_chunk_packed(lcd_batch_t *b, const lcd_read_view_t *cr, int64_t reg_beg, int64_t reg_end, int n, const int *noisy_reads,
+                                           const uint8_t *ref_seq, int ref_seq_len) {
+    return add_region_from_chunk(b, cr, reg_beg, reg_end, n, noisy_reads, ref_seq, ref_seq_len, true);
 }
 // per read of a region in its sorted order: chunk read id, cover flag, read_reg_beg / read_reg_end (-1 / -2 unless the region came from chunk views)
 int lcd_batch_region_read_slices(lcd_batch_t *b, int region, int *read_ids, int *covers, int *read_beg, int *read_end) {
@@ -645,6 +668,13 @@ int lcd_batch_upload(lcd_batch_t *b) {
     const double t0 = now_ms();
     if (b->d_in.ensure(b->h_pool.size() + 64)) return -11;
     HIPCHK(hipMemcpyAsync(b->d_in.p, b->h_pool.data(), b->h_pool.size(), hipMemcpyHostToDevice, b->stream));
+    if (!b->unpack_jobs.empty()) { // slices that came 4-bit packed: unpacked here, into their holes in the pool
+        if (b->d_packed.ensure(b->h_packed.size() + 64) || b->d_unpack.ensure(b->unpack_jobs.size() * sizeof(UnpackJob))) return -11;
+        HIPCHK(hipMemcpyAsync(b->d_packed.p, b->h_packed.data(), b->h_packed.size(), hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipMemcpyAsync(b->d_unpack.p, b->unpack_jobs.data(), b->unpack_jobs.size() * sizeof(UnpackJob), hipMemcpyHostToDevice, b->stream));
+        lcd_launch_unpack((const UnpackJob *)b->d_unpack.p, (int)b->unpack_jobs.size(), (const uint8_t *)b->d_packed.p, (uint8_t *)b->d_in.p, b->stream);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipStreamSynchronize(b->stream));
     b->uploaded = true; b->ran = false; b->downloaded = false;
     b->st.ms_upload = now_ms() - t0;

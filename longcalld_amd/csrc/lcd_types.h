@@ -276,6 +276,9 @@ struct DigarJob {
 struct RefCmpJob { uint64_t cigar_off, seq_off, out_off; int n_cigar, pad; long long pos0; }; // BAM CIGAR words, 4-bit bases, rewritten words
 struct RefCmpOut { int n_ops, nd, nev, pad; };                                               // rewritten operations, digars, window events
 struct DigarOut { int status, n_digar, n_iv, n_cand, rlen; };
+// a read's slice of a noisy region, still 4-bit packed as in its BAM record (bam_get_seq), to be written as 1 B/base codes 0-4 (seq_nt16_int) into a batch's
+// input pool on the device: lcd_host.cpp lcd_batch_add_region_from_chunk_packed / digar_kernel.hip lcd_unpack_kernel
+struct UnpackJob { uint64_t src, dst; int first, len; }; // src: byte offset in the packed staging pool; first: 0 / 1 = the slice starts at the high / low nibble of that byte
 struct DigarOpt { int min_bq, max_xgaps, win, end_clip_reg, end_clip_flank, pad; long long whole_ref_len; };
 
 // ---------------- sdust segments (sdust_kernel.hip): one lane per segment, segments of many sequences per launch ----------------

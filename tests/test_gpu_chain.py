@@ -57,7 +57,7 @@ def test_bam_records_to_variants(lcd, oracle):
         ids = np.array([i for i in kept if dg[i]["beg"] <= end and dg[i]["end"] >= beg], np.int32)
         if len(ids) < 5:
             continue
-        b.add_region_from_chunk(views, beg, end, ids, ref[beg - o:end - o + 1])
+        b.add_region_from_chunk(views, beg, end, ids, ref[beg - o:end - o + 1], packed=True)   # (bases stay 4-bit packed; unpacked on the device by upload())
         used.append((beg, end, ids))
     assert len(used) >= 8
     b.upload(); b.run(); b.download()

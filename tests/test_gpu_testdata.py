@@ -20,17 +20,40 @@ def test_k5_real_profile(lcd):
         assert (got[k] == ch.z["exp_" + k]).all(), k
 
 
-def _run_chunk(lcd, ch, haps, pss):
+def _run_chunk(lcd, ch, haps, pss, packed=False, digest=False):
     views, keep = lcd.make_read_views(ch.digars, ch.bseq, ch.qual, ch.qlen, haps, pss)
     b = lcd.RegionBatch()
     for k, (beg, end) in enumerate(ch.regions):
-        b.add_region_from_chunk(views, beg, end, ch.reg_reads(k), ch.ref_slice(k))
+        b.add_region_from_chunk(views, beg, end, ch.reg_reads(k), ch.ref_slice(k), packed=packed)
     b.upload(); b.run(); b.download()
     out = [b.result(k) for k in range(len(ch.regions))]
     ids = [b.sorted_ids(k) for k in range(len(ch.regions))]
+    dg = b.digest()
     b.close()
     del keep
-    return out, ids
+    return (out, ids, dg) if digest else (out, ids)
+
+
+def test_packed_read_slices_equal_unpacked(lcd):
+    """SURVEY f2, the step into the region jobs: the reads' slices handed over 4-bit packed as they are in the BAM records and unpacked on the device
+    (lcd_batch_add_region_from_chunk_packed, digar_kernel.hip lcd_unpack_kernel) give the results of the host's per-base loop -- every region of the bundled
+    real chunk, slices starting at even and odd read positions, same digest and same strings"""
+    from longcalld_amd import jobs
+    ch = tc.Chunk()
+    st = lcd.assign_hap_germline(ch.hap_problem(), jobs.GERMLINE_CLEAN)
+    a, ida, da = _run_chunk(lcd, ch, st["haps"], st["phase_sets"], packed=False, digest=True)
+    p, idp, dp = _run_chunk(lcd, ch, st["haps"], st["phase_sets"], packed=True, digest=True)
+    assert da == dp and len(a) == len(p) > 0
+    n_res = 0
+    for x, y, i1, i2 in zip(a, p, ida, idp):
+        assert (i1 == i2).all() and x["n_cons"] == y["n_cons"]
+        for c in range(x["n_cons"]):
+            for sx, sy in zip(x["aln_strs"][c], y["aln_strs"][c]):
+                assert (sx is None) == (sy is None)
+                if sx is not None:
+                    assert (sx["target"] == sy["target"]).all() and (sx["query"] == sy["query"]).all()
+        n_res += x["n_cons"] > 0
+    assert n_res > 0
 
 
 def test_real_regions_with_k5_haplotypes(lcd, oracle):
