@@ -282,6 +282,14 @@ int lcd_digar_batch_ref(const lcd_digar_opt_t *opt, int n_reads, const int64_t *
                         int64_t reg_end, int64_t whole_ref_len, uint64_t **digar_off, lcd_digar_t **digars, uint64_t **iv_off, lcd_noisy_iv_t **ivs,
                         uint8_t **iv_in_chunk, int *status, int64_t *beg, int64_t *end, int *n_cand_vars);
 
+/* ---- SURVEY 8(f) f2 -> region jobs: collect_noisy_read_info's digar walk (src/align.c:1392-1456) for many (region, read) pairs in one launch ----
+ * pair i = read pair_read[i] (index into digar_off / qlen) against the region [pair_reg_beg[i], pair_reg_end[i]] (1-based, flanks included); digars as
+ * lcd_digar_batch returns them.  Out per pair: read_reg_beg / read_reg_end (the read's query interval over the region, src/align.c:1458) and the cover flag
+ * (LONGCALLD_NOISY_{LEFT,RIGHT}_{COVER,GAP}; a deletion longer than noisy_reg_flank_len at a region end makes that end a gap). */
+int lcd_region_read_slices_batch(int n_pairs, const int *pair_read, const int64_t *pair_reg_beg, const int64_t *pair_reg_end, int n_reads,
+                                 const uint64_t *digar_off, const lcd_digar_t *digars, const int *qlen, int noisy_reg_flank_len,
+                                 int *read_beg, int *read_end, int *cover);
+
 /* ---- SURVEY 8(f) f2, chunk level: pre_process_noisy_regs (src/collect_var.c:557-638) ----
  * chunk_noisy: the intervals cr_add()'ed to chunk->chunk_noisy_regs while the reads were loaded (lcd_digar_batch: ivs[k] with iv_in_chunk[k]), in
  * that order; low_comp: chunk->low_comp_cr as (start, end) pairs (sdust output, may be empty); reads in ordered_read_ids order with the skipped

@@ -76,7 +76,7 @@ _lib = None
 EXPORTS = [
     "lcd_opt_default", "lcd_init", "lcd_device_count", "lcd_alloc_events", "lcd_device_bytes", "lcd_set_thread_device", "lcd_batch_create_on", "lcd_last_error", "lcd_version", "lcd_wfa_end2end_aln", "lcd_edlib_end2end_aln",
     "lcd_edlib_xgaps", "lcd_edlib_edit_distance", "lcd_end2end_aln", "lcd_wfa_collect_diff_ins_seq", "lcd_edlib_infix_aln", "lcd_wfa_heuristic_aln", "lcd_collect_noisy_reg_aln_strs", "lcd_batch_create", "lcd_batch_destroy",
-    "lcd_batch_clear", "lcd_batch_region_vars", "lcd_digar_opt_default", "lcd_digar_batch", "lcd_digar_batch_tags", "lcd_digar_batch_ref", "lcd_pre_process_noisy_regs", "lcd_post_process_noisy_regs", "lcd_sdust", "lcd_sdust_batch", "lcd_batch_add_region", "lcd_batch_add_region_from_chunk", "lcd_batch_add_region_from_chunk_packed", "lcd_batch_upload", "lcd_batch_run", "lcd_batch_run_many",
+    "lcd_batch_clear", "lcd_batch_region_vars", "lcd_digar_opt_default", "lcd_digar_batch", "lcd_digar_batch_tags", "lcd_digar_batch_ref", "lcd_region_read_slices_batch", "lcd_pre_process_noisy_regs", "lcd_post_process_noisy_regs", "lcd_sdust", "lcd_sdust_batch", "lcd_batch_add_region", "lcd_batch_add_region_from_chunk", "lcd_batch_add_region_from_chunk_packed", "lcd_batch_upload", "lcd_batch_run", "lcd_batch_run_many",
     "lcd_batch_download", "lcd_dispatch_create", "lcd_dispatch_destroy", "lcd_dispatch_n_devices", "lcd_dispatch_run", "lcd_batch_cost", "lcd_lpt_assign", "lcd_batch_region_result", "lcd_batch_region_sorted_ids", "lcd_batch_region_read_slices", "lcd_batch_get_stats", "lcd_batch_k4_jobs", "lcd_batch_digest", "lcd_batch_materialize",
     "lcd_edlib_batch", "lcd_wfa_batch", "lcd_wfa_arena_bytes", "lcd_poa_batch", "lcd_assign_hap_germline", "lcd_assign_hap_batch", "lcd_flip_variant_hap", "lcd_stitch_chunks", "lcd_call_opt_default", "lcd_make_variants", "lcd_free_variants", "lcd_format_vcf", "lcd_read_tags", "lcd_update_digars_from_msa1", "lcd_bam_load_region", "lcd_bam_reads_free", "lcd_fasta_fetch", "lcd_vcf_header", "lcd_io_last_error",
 ]
@@ -145,6 +145,7 @@ def load_library():
     _dg_tail = [C.c_int64, C.c_int64, C.c_int64, C.POINTER(u64p_), C.POINTER(C.POINTER(LcdDigar)), C.POINTER(u64p_), C.POINTER(C.POINTER(LcdNoisyIv)), C.POINTER(u8p), i32p, i64p, i64p, i32p]
     lib.lcd_digar_batch_tags.argtypes = [_dg_head[0], C.c_int] + _dg_head[1:] + [C.POINTER(C.c_char_p), u8p, u64p_, i32p, u8p] + _dg_tail
     lib.lcd_digar_batch_ref.argtypes = _dg_head + [u8p, u64p_, u8p, u64p_, i32p, u8p, C.c_char_p, C.c_int64, C.c_int64] + _dg_tail
+    lib.lcd_region_read_slices_batch.argtypes = [C.c_int, i32p, i64p, i64p, C.c_int, u64p_, C.POINTER(LcdDigar), i32p, C.c_int, i32p, i32p, i32p]
     lib.lcd_pre_process_noisy_regs.argtypes = [C.POINTER(LcdNoisyIv), C.c_int, i64p, C.c_int, C.c_int, i64p, i64p, u64p_, C.POINTER(LcdNoisyIv), C.c_int, C.c_float,
                                                C.POINTER(C.POINTER(LcdNoisyIv))]
     lib.lcd_post_process_noisy_regs.argtypes = [C.POINTER(LcdNoisyIv), C.c_int, C.c_int, i64p, i32p, i32p, C.c_int, C.POINTER(C.POINTER(LcdNoisyIv))]

@@ -433,6 +433,32 @@ def digar_batch(pos0, cigars, quals, reg_beg, reg_end, whole_ref_len, is_ont=0, 
     return out
 
 
+def region_read_slices_batch(pair_read, pair_reg_beg, pair_reg_end, digars, qlens, flank=10):
+    """collect_noisy_read_info's digar walk (src/align.c:1392-1456) for many (region, read) pairs in one launch (lcd_region_read_slices_batch):
+    digars[r] = (n, >= 4) rows (pos, type, len, qi) of read r -> (read_beg, read_end, cover) arrays, one entry per pair"""
+    lib = load_library()
+    u64p_, i64p = C.POINTER(C.c_uint64), C.POINTER(C.c_int64)
+    n_reads = len(digars)
+    off = np.zeros(n_reads + 1, np.uint64)
+    for r in range(n_reads):
+        off[r + 1] = off[r] + len(digars[r])
+    pool = np.zeros((max(int(off[-1]), 1), 3), np.int64)      # lcd_digar_t: int64 pos | int32 type, len | int32 qi, is_low_qual
+    v32 = pool.view(np.int32).reshape(len(pool), 6)
+    for r in range(n_reads):
+        d = np.asarray(digars[r], np.int64)
+        if len(d):
+            a, b = int(off[r]), int(off[r + 1])
+            pool[a:b, 0] = d[:, 0]; v32[a:b, 2] = d[:, 1]; v32[a:b, 3] = d[:, 2]; v32[a:b, 4] = d[:, 3]
+    pr = np.ascontiguousarray(pair_read, np.int32); pb = np.ascontiguousarray(pair_reg_beg, np.int64); pe = np.ascontiguousarray(pair_reg_end, np.int64)
+    ql = np.ascontiguousarray(qlens, np.int32)
+    n = len(pr)
+    rb, re, cv = (np.zeros(max(n, 1), np.int32) for _ in range(3))
+    check(lib.lcd_region_read_slices_batch(n, pr.ctypes.data_as(i32p), pb.ctypes.data_as(i64p), pe.ctypes.data_as(i64p), n_reads, off.ctypes.data_as(u64p_),
+                                           C.cast(pool.ctypes.data, C.POINTER(LcdDigar)), ql.ctypes.data_as(i32p), int(flank), rb.ctypes.data_as(i32p),
+                                           re.ctypes.data_as(i32p), cv.ctypes.data_as(i32p)), lib)
+    return rb[:n], re[:n], cv[:n]
+
+
 def pre_process_noisy_regs(chunk_noisy, low_comp, read_beg, read_end, read_ivs, min_alt_dp=2, min_af=0.2):
     """pre_process_noisy_regs (src/collect_var.c:557): chunk_noisy (n,3) in cr_add order, low_comp (m,2), per read beg/end and its own (k,>=2)
     interval array -> surviving regions (r,3)"""

@@ -232,6 +232,63 @@ void lcd_launch_region_support(const IvRec *regs, int n_regs, const long long *r
     if (n_regs > 0) hipLaunchKernelGGL(lcd_region_support_kernel, dim3(n_regs), dim3(64), 0, stream, regs, n_regs, read_beg, read_end, iv_off, ivs, n_reads, total, noisy);
 }
 
+// collect_noisy_read_info's digar walk (src/align.c:1392-1441), one wavefront per (region, read) pair: which query interval of the read lies over the region,
+// and does the read cover the region's ends (a deletion longer than the flank at an end counts as a gap).  The reference walks the list in order and lets a
+// later digar overwrite what an earlier one set -- an insertion AT the region's first position is followed by the '=' run that starts there, so the run wins --
+// and stops at the first digar that begins behind the region.  Here 64 digars are looked at per step: the stop is the first lane whose digar begins behind the
+// region, "later overwrites earlier" is the highest matching lane below it (and of the steps so far), the deletion flags are set-only in the reference and so an OR.
+__global__ void __launch_bounds__(64) lcd_slice_kernel(const SliceJob *jobs, SliceOut *outs, const DigarRec *digars, const int flank, const int n_jobs) {
+    const int ji = blockIdx.x, lane = threadIdx.x;
+    if (ji >= n_jobs) return;
+    const SliceJob j = jobs[ji];
+    const DigarRec *d = digars + j.digar_off;
+    const int nd = j.n_digar;
+    int rb = 0, re = j.qlen - 1;
+    if (nd > 0) { if (d[0].type == 5) rb = d[0].len; if (d[nd - 1].type == 5) re = d[nd - 1].qi - 1; }
+    bool hit_b = false, hit_e = false; int beg_del = 0, end_del = 0;
+    for (int base = 0; base < nd; base += 64) {
+        const int k = base + lane;
+        bool cand = false, stop = false; long long db = 0, de = 0; int op = 0, len = 0, qi = 0;
+        if (k < nd) {
+            const DigarRec r = d[k];
+            op = r.type; len = r.len; qi = r.qi; db = r.pos;
+            if (op != 4 && op != 5) {
+                de = (op == 8 || op == 7 || op == 2) ? db + len - 1 : db;
+                stop = db > j.reg_end;
+                cand = !stop && de >= j.reg_beg;
+            }
+        }
+        const unsigned long long sm = __ballot(stop);
+        const unsigned long long below = sm ? ((1ull << __builtin_ctzll(sm)) - 1ull) : ~0ull; // lanes before the first stop
+        const unsigned long long mb = __ballot(cand && db <= j.reg_beg && de >= j.reg_beg) & below;
+        const unsigned long long me = __ballot(cand && db <= j.reg_end && de >= j.reg_end) & below;
+        if (mb) {
+            const int src = 63 - __builtin_clzll(mb);
+            const int sop = __shfl(op, src), sqi = __shfl(qi, src); const long long sdb = __shfl(db, src);
+            rb = sop == 2 ? sqi : sqi + (int)(j.reg_beg - sdb); hit_b = true;
+            beg_del |= (__ballot(op == 2 && len > flank) & mb) != 0;
+        }
+        if (me) {
+            const int src = 63 - __builtin_clzll(me);
+            const int sop = __shfl(op, src), sqi = __shfl(qi, src); const long long sdb = __shfl(db, src);
+            re = sop == 2 ? sqi - 1 : sqi + (int)(j.reg_end - sdb); hit_e = true;
+            end_del |= (__ballot(op == 2 && len > flank) & me) != 0;
+        }
+        if (sm) break;
+    }
+    if (lane == 0) {
+        int cover = 0; // LONGCALLD_NOISY_{LEFT,RIGHT}_{COVER,GAP} (src/align.c:1442-1456; lcd_types.h LCD_LEFT_COVER ...)
+        if (hit_b && hit_e) cover = (beg_del ? LCD_LEFT_GAP : LCD_LEFT_COVER) | (end_del ? LCD_RIGHT_GAP : LCD_RIGHT_COVER);
+        else if (hit_b) cover = beg_del ? LCD_LEFT_GAP : LCD_LEFT_COVER;
+        else if (hit_e) cover = end_del ? LCD_RIGHT_GAP : LCD_RIGHT_COVER;
+        SliceOut o; o.read_beg = rb; o.read_end = re; o.cover = cover; o.pad = 0;
+        outs[ji] = o;
+    }
+}
+void lcd_launch_slices(const SliceJob *jobs, SliceOut *outs, const DigarRec *digars, int flank, int n_jobs, hipStream_t stream) {
+    if (n_jobs > 0) hipLaunchKernelGGL(lcd_slice_kernel, dim3(n_jobs), dim3(64), 0, stream, jobs, outs, digars, flank, n_jobs);
+}
+
 // Read slices of noisy regions, 4-bit packed -> 1 B/base codes in the batch's input pool (the per-base loop of collect_noisy_read_info, src/align.c:1445-1448:
 // seq_nt16_int[bam_seqi(bseq, j)]).  One workgroup per slice, four bases per lane and step: two or three packed bytes in, one 32-bit store out (the pool's
 // slices start 16-byte aligned).  HBM-bound and small: 0.5 B read + 1 B written per base, ~20 MB per configs[1] batch.

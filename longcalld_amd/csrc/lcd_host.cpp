@@ -2112,6 +2112,37 @@ void niv_merge(std::vector<NIv> &v) {
 }
 } // namespace
 
+// collect_noisy_read_info's digar walk (src/align.c:1392-1456) for many (region, read) pairs in one launch, on digars as lcd_digar_batch returns them: which
+// query interval of each read lies over its region and how the read covers the region's ends.  The per-region form of the same walk is the host loop of
+// lcd_batch_add_region_from_chunk; this is the chunk-level form of SURVEY f2 (all regions of a chunk against all their reads: tens of thousands of pairs).
+int lcd_region_read_slices_batch(int n_pairs, const int *pair_read, const int64_t *pair_reg_beg, const int64_t *pair_reg_end, int n_reads,
+                                 const uint64_t *digar_off, const lcd_digar_t *digars, const int *qlen, int noisy_reg_flank_len,
+                                 int *read_beg, int *read_end, int *cover) {
+    static_assert(sizeof(lcd_digar_t) == sizeof(DigarRec), "lcd_digar_t is DigarRec");
+    if (ensure_init()) return -1;
+    if (n_pairs <= 0) return 0;
+    if (n_reads <= 0) return set_err(-4, "lcd_region_read_slices_batch: no reads");
+    std::vector<SliceJob> jobs(n_pairs);
+    for (int i = 0; i < n_pairs; ++i) {
+        const int r = pair_read[i];
+        if (r < 0 || r >= n_reads) return set_err(-4, "lcd_region_read_slices_batch: read index out of range");
+        SliceJob &j = jobs[i]; j.digar_off = digar_off[r]; j.n_digar = (int)(digar_off[r + 1] - digar_off[r]); j.qlen = qlen[r]; j.reg_beg = pair_reg_beg[i]; j.reg_end = pair_reg_end[i];
+    }
+    const uint64_t nd = digar_off[n_reads];
+    StreamGuard st; if (st.create()) return -10;
+    DevBuf d_dig, d_jobs, d_outs;
+    if (d_dig.ensure((nd + 1) * sizeof(DigarRec)) || d_jobs.ensure(n_pairs * sizeof(SliceJob)) || d_outs.ensure(n_pairs * sizeof(SliceOut))) return -11;
+    if (nd) HIPCHK(hipMemcpyAsync(d_dig.p, digars, nd * sizeof(DigarRec), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_jobs.p, jobs.data(), n_pairs * sizeof(SliceJob), hipMemcpyHostToDevice, st));
+    lcd_launch_slices((const SliceJob *)d_jobs.p, (SliceOut *)d_outs.p, (const DigarRec *)d_dig.p, noisy_reg_flank_len, n_pairs, st);
+    HIPCHK(hipGetLastError());
+    std::vector<SliceOut> outs(n_pairs);
+    HIPCHK(hipMemcpyAsync(outs.data(), d_outs.p, n_pairs * sizeof(SliceOut), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < n_pairs; ++i) { read_beg[i] = outs[i].read_beg; read_end[i] = outs[i].read_end; cover[i] = outs[i].cover; }
+    return 0;
+}
+
 int lcd_pre_process_noisy_regs(const lcd_noisy_iv_t *chunk_noisy, int n_noisy, const int64_t *low_comp, int n_low, int n_reads, const int64_t *read_beg,
                                const int64_t *read_end, const uint64_t *read_iv_off, const lcd_noisy_iv_t *read_ivs, int min_alt_dp, float min_af,
                                lcd_noisy_iv_t **regs_out) {

@@ -16,6 +16,7 @@ void lcd_launch_compose(const CmpJob *jobs, CmpOut *outs, const CmpSeg *segs, in
 void lcd_launch_vars_scan(const VarScanJob *jobs, VarScanOut *outs, int n_jobs, hipStream_t stream);
 void lcd_launch_vars_profile(const VarRegJob *jobs, VarRegOut *outs, const StrJob *sjobs, const StrOut *souts, int n_jobs, hipStream_t stream);
 void lcd_launch_digar(const DigarJob *jobs, DigarOut *outs, DigarOpt opt, int n_jobs, hipStream_t stream);
+void lcd_launch_slices(const SliceJob *jobs, SliceOut *outs, const DigarRec *digars, int flank, int n_jobs, hipStream_t stream);
 void lcd_launch_unpack(const UnpackJob *jobs, int n_jobs, const uint8_t *packed, uint8_t *pool, hipStream_t stream);
 void lcd_launch_refcmp(bool emit, const RefCmpJob *jobs, RefCmpOut *outs, const char *ref, long long ref_beg, long long ref_end, int n_jobs, hipStream_t stream);
 void lcd_launch_region_support(const IvRec *regs, int n_regs, const long long *read_beg, const long long *read_end, const unsigned long long *iv_off,

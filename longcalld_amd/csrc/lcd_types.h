@@ -278,6 +278,9 @@ struct RefCmpOut { int n_ops, nd, nev, pad; };                                  
 struct DigarOut { int status, n_digar, n_iv, n_cand, rlen; };
 // a read's slice of a noisy region, still 4-bit packed as in its BAM record (bam_get_seq), to be written as 1 B/base codes 0-4 (seq_nt16_int) into a batch's
 // input pool on the device: lcd_host.cpp lcd_batch_add_region_from_chunk_packed / digar_kernel.hip lcd_unpack_kernel
+// one (region, read) pair of collect_noisy_read_info's digar walk (digar_kernel.hip lcd_slice_kernel)
+struct SliceJob { uint64_t digar_off; int n_digar, qlen; long long reg_beg, reg_end; }; // digar_off: index of the read's first DigarRec
+struct SliceOut { int read_beg, read_end, cover, pad; };
 struct UnpackJob { uint64_t src, dst; int first, len; }; // src: byte offset in the packed staging pool; first: 0 / 1 = the slice starts at the high / low nibble of that byte
 struct DigarOpt { int min_bq, max_xgaps, win, end_clip_reg, end_clip_flank, pad; long long whole_ref_len; };
 

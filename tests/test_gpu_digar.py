@@ -302,3 +302,42 @@ def test_reference_comparison_real_chunk(lcd, oracle):
         _same(exp, got[i])
         n_dig += len(got[i]["digars"])
     assert n_dig > 100000
+
+
+@pytest.mark.gpu
+def test_region_read_slices_batch_equals_oracle(lcd, oracle):
+    """SURVEY f2 -> region jobs: collect_noisy_read_info's digar walk for many (region, read) pairs in one launch (lcd_region_read_slices_batch,
+    digar_kernel.hip lcd_slice_kernel) == the oracle's walk (oracle lcdo_read_region_slice, src/align.c:1392-1456) -- region ends inside '=' runs, on
+    mismatches, inside short and long deletions (the flank rule), at insertions, in clips, outside the read; lists longer than one 64-digar step"""
+    import digar_inputs as di
+    rng = np.random.default_rng(31)
+    digs, qlens, pairs = [], [], []
+    for r in range(60):
+        ops = di.eqx_ops(rng, noisy=r % 3 == 0, n_skip=False, n_ev=int(rng.integers(3, 400)))
+        if r % 7 == 0:
+            ops = [(5, 30)] + [o for o in ops if o[0] not in (4, 5)] + [(5, 12)]          # hard clips at both ends
+        if r % 5 == 0:
+            ops.insert(len(ops) // 2, (2, 40)); ops.insert(len(ops) // 2, (7, 9))      # a deletion longer than the flank
+        a = di.build(rng, ops, 5000 + 13 * r)
+        d = oracle.collect_digar_from_eqx_cigar(a["pos0"], a["eqx"], np.full(a["qlen"], 40, np.uint8), 1, 10 ** 7, 10 ** 7, oracle.DigarOpt(10, 5, 100, 30, 100, 4.0, 4.0))
+        assert d["rc"] == 0 and len(d["digars"]) > 0
+        digs.append(d["digars"][:, :4]); qlens.append(a["qlen"])
+        lo, hi = int(d["digars"][0][0]), int(d["digars"][-1][0]) + 50
+        cand = [int(x[0]) for x in d["digars"]] + [int(x[0]) + int(x[2]) - 1 for x in d["digars"]]   # digar starts and ends: the boundary cases
+        for _ in range(25):
+            if rng.random() < 0.6:
+                b = int(rng.choice(cand)) + int(rng.integers(-1, 2))
+            else:
+                b = int(rng.integers(lo - 200, hi + 200))
+            e = b + int(rng.integers(0, 600)) if rng.random() < 0.7 else int(rng.choice(cand)) + int(rng.integers(-1, 2))
+            if e < b:
+                b, e = e, b
+            pairs.append((r, b, e))
+    pr = np.array([p[0] for p in pairs], np.int32); pb = np.array([p[1] for p in pairs], np.int64); pe = np.array([p[2] for p in pairs], np.int64)
+    rb, re, cv = lcd.region_read_slices_batch(pr, pb, pe, digs, qlens, flank=10)
+    kinds = set()
+    for i, (r, b, e) in enumerate(pairs):
+        exp = oracle.read_region_slice(digs[r], qlens[r], b, e, 10)
+        assert (int(rb[i]), int(re[i]), int(cv[i])) == exp, (i, r, b, e)
+        kinds.add(exp[2])
+    assert len(kinds) >= 5 and max(len(d) for d in digs) > 64
