@@ -809,7 +809,8 @@ static void chain_class(PoaChain &pc, bool noisy) {
     static const int buckets[] = {8 << 10, 12 << 10, 16 << 10, 24 << 10, 32 << 10, 48 << 10, 64 << 10, 96 << 10, 148 << 10};
     int lds = buckets[8];
     for (int b : buckets) if (need <= b) { lds = b; break; }
-    // (noisy K1 chains below that length: as many slots as the bucket they have anyway leaves room for -- LCD_RING_K_FREE=0 keeps them at 2)
+    // (noisy K1 chains below that length: as many slots as the bucket they have anyway leaves room for -- LCD_RING_K_FREE=0 keeps them at 2.  Tried for the K1
+    //  chains of clean reads too: no change at 2 x 32 batches, 47 k instead of 60 k regions/s at one submission of 20)
     if (threads == 64 && pc.mode == 0 && noisy && K == 2) {
         static const bool rk_free = !(getenv("LCD_RING_K_FREE") && atoi(getenv("LCD_RING_K_FREE")) == 0);
         while (rk_free && K < 8 && (long long)(2 * K) * 3 * wmax * 4 + seq_bytes <= lds) K *= 2;
