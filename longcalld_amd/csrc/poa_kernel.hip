@@ -77,7 +77,7 @@ struct Ctx {
     long long alg_adjust;             // cells of the reference's algorithm minus cells computed (certified band: full rows minus the intervals, attempts included)
     int cert_generic, cert_generic_seen, cert_sest, cert_ubtop; unsigned long long cert_cells0; // the read at hand goes through the generic rows over its intervals (align_certified)
     int *cert; int cert_on, cert_hist; // certified band of a K2 chain (align_certified): 7 x node_cap ints; largest bound-to-score slack of the chain's reads so far
-    int wmax, seq_cap, pool_words, spill_x, ring_k;
+    int wmax, seq_cap, pool_words, spill_x, ring_k, plan_k;
     int n_node, n_edge, node_cap, edge_cap, rid_words;
     unsigned long long cell_cap;
     int status;
@@ -738,7 +738,7 @@ __device__ void ctx_to_sgpr(Ctx &g) {
     g.cig_node0 = usgpr(g.cig_node0); g.cig_qpos0 = usgpr(g.cig_qpos0); g.imap = usgpr(g.imap);
     g.tb = usgpr(g.tb); g.cert = usgpr(g.cert); g.node_cap = usgpr(g.node_cap);
     g.pl_start = usgpr(g.pl_start); g.pl_pidx = usgpr(g.pl_pidx); g.pl_bonus = usgpr(g.pl_bonus); g.pl_rem = usgpr(g.pl_rem); g.pl_base = usgpr(g.pl_base);
-    g.wmax = usgpr(g.wmax); g.cell_cap = usgpr(g.cell_cap); g.status = usgpr(g.status); g.spill_x = usgpr(g.spill_x); g.ring_k = usgpr(g.ring_k);
+    g.wmax = usgpr(g.wmax); g.cell_cap = usgpr(g.cell_cap); g.status = usgpr(g.status); g.spill_x = usgpr(g.spill_x); g.ring_k = usgpr(g.ring_k); g.plan_k = usgpr(g.plan_k);
 }
 // End node (best predecessor at column qlen; its values are in the spill area) + the code-driven backtrack, on wavefront 0.
 // Results through sm.bc[0] = #cigar entries, [1] = status, [4] = first cigar slot.
@@ -873,7 +873,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
     ctx_to_sgpr(g);
     // ring slots: per class, except the single-wavefront class whose slot metadata lives in lanes -- there the host gives long chains of noisy reads more
     // (PoaChain.ring_k: a predecessor further back than the ring costs two dependent trips to HBM, metadata then values)
-    const int K = NT == 64 ? g.ring_k : Cfg<NT>::K;
+    int K = NT == 64 ? g.ring_k : Cfg<NT>::K;
     const unsigned ring = usgpr(ring_); unsigned sq1 = usgpr(sq1_), pd = usgpr(pd_);
     const int w = usgpr(w_), bi = usgpr(bi_), ei = usgpr(ei_), rem_beg = usgpr(rem_beg_), qlen = usgpr(qlen_);
     const uint8_t *seq_hbm = usgpr(seq_hbm_); WinOut *wo = usgpr(wo_);
@@ -885,10 +885,13 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
         // the pool of a single-wavefront chain is laid out for the window the host expects (PoaChain.wmax columns per ring slot); a wider
         // window moves the query cache up and gives up the first-predecessor distances -- or, if the pool is too small for that, leaves
         // the read to the next wider window / the generic rows
-        const unsigned ring_bytes = (unsigned)(K * SLOTW * 4);
+        unsigned ring_bytes = (unsigned)(K * SLOTW * 4);
         if (sq1 < ring + ring_bytes) {
+            if (ring_bytes + (unsigned)QB > (unsigned)g.pool_words * 4u && K > g.plan_k) { // the extra slots were room the narrower window left: this one runs with
+                K = g.plan_k; ring_bytes = (unsigned)(K * SLOTW * 4);                        // the slots the plan's spill flags were made for
+            }
             if (ring_bytes + (unsigned)QB > (unsigned)g.pool_words * 4u) return -1;
-            sq1 = ring + ring_bytes; pd = 0xffffffffu;
+            if (sq1 < ring + ring_bytes) { sq1 = ring + ring_bytes; pd = 0xffffffffu; }
         }
     }
     for (int j = tid; j < QB; j += NT) lds_st_u8(sq1 + j, (j >= 1 && j <= qlen) ? seq_hbm[j - 1] : 4); // shifted: sq1[j] = q[j-1]
@@ -1934,7 +1937,7 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
     const int QB = (qlen + 12 + 15) & ~15;
     if (QB > g.seq_cap) { g.status = LCD_ERR_LDS; return 0; } // read slice longer than the LDS query cache (host sizes the class)
     uint8_t *pd = (QB + (ei - bi) + 16 <= g.seq_cap) ? sseq + QB : nullptr;
-    build_plan<NT>(g, sm, bi, ei, remain_end, pd, NT == 64 ? g.ring_k : K); // (rows to spill: those with a successor further away than the windowed rows' ring)
+    build_plan<NT>(g, sm, bi, ei, remain_end, pd, NT == 64 ? g.plan_k : K); // (rows to spill: those with a successor further away than the windowed rows' ring -- the smallest ring a window of this chain may run with)
     if (!(sc.dbg & 8)) {
         WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0; wo.t_plan = wo.t_poll = 0;
         const int rem_beg = g.remain[beg_node] - remain_end;
@@ -2518,7 +2521,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
     g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0; g.cert_generic = 0; g.cert_generic_seen = 0; g.cert_sest = 0; g.cert_ubtop = 0; g.cert_cells0 = 0;
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
-    g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - ring_k * 3 * ring_cols) * 4; g.ring_k = ring_k;
+    g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - ring_k * 3 * ring_cols) * 4; g.ring_k = ring_k; g.plan_k = NT == 64 && ring_k > 2 && ch.wmax < 256 ? 2 : ring_k; // (slots beyond 2 of a chain laid out for a narrow window: not there when a read needs a wider one)
     g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0;
     const long long t_begin = clock64();
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
