@@ -1196,6 +1196,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             // after the arenas have their memory, from what the budget leaves (LCD_SPARE_GB caps it, 0 switches it off); without it -- or once it is used
             // up -- such a chain comes back with LCD_ERR_CELLS and is re-run from its first read in the next round, as before.
             PoaSpare *d_spare = nullptr;
+            PoaSpare spare_hdr; // (lives until the round's stream synchronisation below: the source of an asynchronous copy)
             {
                 const double spare_gb = getenv("LCD_SPARE_GB") ? atof(getenv("LCD_SPARE_GB")) : 16.0; // (read per call: tests switch it)
                 if (spare_gb <= 0) L->d_spare.release();
@@ -1205,8 +1206,8 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                     if (want >= (64ll << 20) && L->d_spare.ensure((size_t)want, 40)) { /* no spare pool this time */ }
                 }
                 if (L->d_spare.cap > 4096) {
-                    PoaSpare hdr; hdr.used = 0; hdr.cap = L->d_spare.cap - 256; hdr.base = L->d_spare.addr() + 256; hdr.n_grown = hdr.n_refused = 0;
-                    HIPCHK(hipMemcpyAsync(L->d_spare.p, &hdr, sizeof(hdr), hipMemcpyHostToDevice, st));
+                    spare_hdr.used = 0; spare_hdr.cap = L->d_spare.cap - 256; spare_hdr.base = L->d_spare.addr() + 256; spare_hdr.n_grown = spare_hdr.n_refused = 0;
+                    HIPCHK(hipMemcpyAsync(L->d_spare.p, &spare_hdr, sizeof(spare_hdr), hipMemcpyHostToDevice, st));
                     d_spare = (PoaSpare *)L->d_spare.p;
                 }
             }
