@@ -210,7 +210,8 @@ int lcd_batch_region_result(lcd_batch_t *b, int region, int *clu_n_seqs, int **c
 /* ---- candidate variants of a region + the read x variant allele profile (opt.collect_noisy_vars) ----
  * == make_vars_from_msa_cons_aln (src/collect_var.c:2279-2347: make_cand_vars_from_msa :1855, update_cand_var_profile_from_cons_aln_str1/2
  * :2164/:2206) computed on the device from the strings of lcd_batch_run.  What stays with the caller, as host code in the reference too:
- * TSD / polyA / TE annotation of gaps >= min_sv_len (collect_te_info_from_cons, :1815/:1834) and merge_var_profile (:2712). */
+ * TSD / polyA / TE annotation of gaps >= min_sv_len (collect_te_info_from_cons, :1815/:1834, SURVEY a14: lcd_collect_te_info_from_cons below, applied by the
+ * caller to the INS / DEL records it gets) and merge_var_profile (:2712). */
 typedef struct lcd_noisy_var_t {   /* the cand_var_t fields make_cand_vars0 (src/collect_var.c:1746) and the profile update fill */
     int64_t pos;
     int var_type, ref_len, alt_len; /* BAM_CDIFF 8 / BAM_CINS 1 / BAM_CDEL 2 */
@@ -281,6 +282,32 @@ int lcd_digar_batch_ref(const lcd_digar_opt_t *opt, int n_reads, const int64_t *
                         const int *qlen, const uint8_t *pal_flags, const char *ref_seq, int64_t ref_beg, int64_t ref_end, int64_t reg_beg,
                         int64_t reg_end, int64_t whole_ref_len, uint64_t **digar_off, lcd_digar_t **digars, uint64_t **iv_off, lcd_noisy_iv_t **ivs,
                         uint8_t **iv_in_chunk, int *status, int64_t *beg, int64_t *end, int *n_cand_vars);
+
+/* ---- retrotransposon annotation of SV-size gaps (host code in the reference: src/align.c:32-163, src/kmer.c; host code here) ----
+ * The variant builder calls collect_te_info_from_cons for every INS / DEL of at least min_sv_len bases (src/collect_var.c:1817,1834; :801 for a candidate
+ * variant through collect_te_info_from_var); its results are cand_var_t.tsd_len / tsd_seq / tsd_pos1 / tsd_pos2 / polya_len / te_seq_i / te_is_rev.
+ *   lcd_te_lib_create      == make_te_kmer_idx (src/kmer.c:120-150) without the file reading: per TE sequence the set of its overlapping k-mers and the set of
+ *                             their reverse complements (kmer_len = opt->te_kmer_len, 15; 1..15), "simple" k-mers left out by the reference's own rule (:16-24);
+ *   lcd_check_te_seq       == check_te_seq (:218-253): index of the TE sequence sharing most of seq's non-overlapping k-mers (>= 3), -1 if none; *is_rev
+ *                             untouched when seq yields no k-mer;
+ *   lcd_collect_te_info    == collect_te_info (src/align.c:32-83): returns the target-site-duplication length (0: not a TE candidate) and, if > 0, its bases
+ *                             in tsd_seq (caller's buffer of opt->max_tsd_len bytes), its positions, the poly-A (> 0) / poly-T (< 0) length and the TE hit;
+ *                             bases are codes 0-4; var_type 1 = BAM_CINS, 2 = BAM_CDEL; lib may be NULL (opt->n_te_seqs == 0);
+ *   lcd_collect_te_info_from_cons == collect_te_info_from_cons (:139-163): the gap and the reference behind it taken from the consensus row / the chunk's reference
+ *                             (ref_seq[0] = position ref_beg, letters or codes; outside [ref_beg, ref_end] = N); with cons_msa_seq = alt_seq and
+ *                             msa_gap_start = 0 it is collect_te_info_from_var (:87-131). */
+typedef struct lcd_te_lib_t lcd_te_lib_t;
+typedef struct lcd_te_opt_t { int min_tsd_len, max_tsd_len, min_polya_len; float min_polya_ratio; } lcd_te_opt_t;   /* 2, 100, 10, 0.8 (src/call_var_main.h:55-58) */
+void lcd_te_opt_default(lcd_te_opt_t *o);
+lcd_te_lib_t *lcd_te_lib_create(int n_seqs, const char *const *seqs, const int *lens, int kmer_len);
+void lcd_te_lib_destroy(lcd_te_lib_t *lib);
+int lcd_te_lib_n_seqs(const lcd_te_lib_t *lib);
+int lcd_check_te_seq(const lcd_te_lib_t *lib, const uint8_t *seq, int len, int *is_rev);
+int lcd_collect_te_info(const lcd_te_opt_t *opt, const lcd_te_lib_t *lib, int var_type, const uint8_t *gap_seq, const uint8_t *flank_ref_seq, int gap_len,
+                        int64_t gap_pos, uint8_t *tsd_seq, int64_t *tsd_pos1, int64_t *tsd_pos2, int *tsd_polya_len, int *te_seq_i, int *te_is_rev);
+int lcd_collect_te_info_from_cons(const lcd_te_opt_t *opt, const lcd_te_lib_t *lib, const char *ref_seq, int64_t ref_beg, int64_t ref_end, int64_t gap_ref_start,
+                                  int msa_gap_start, int var_type, int gap_len, const uint8_t *cons_msa_seq, uint8_t *tsd_seq, int64_t *tsd_pos1, int64_t *tsd_pos2,
+                                  int *tsd_polya_len, int *te_seq_i, int *te_is_rev);
 
 /* ---- SURVEY 8(f) f2 -> region jobs: collect_noisy_read_info's digar walk (src/align.c:1392-1456) for many (region, read) pairs in one launch ----
  * pair i = read pair_read[i] (index into digar_off / qlen) against the region [pair_reg_beg[i], pair_reg_end[i]] (1-based, flanks included); digars as

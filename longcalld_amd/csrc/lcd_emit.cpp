@@ -2,13 +2,14 @@
 // (flip_variant_hap, src/collect_var.c:1618-1680), genotype records (make_variants :1465-1601, cal_sample_GQ :1435, cal_var_QUAL1 :1455), the VCF body
 // lines (write_var_to_vcf, src/vcf_utils.c:97-268) and the HP / PS tag policy (src/bam_utils.c:1955-2006).  Host code, as in the reference: serial,
 // tens of microseconds per chunk; it lives here so that a caller of the library gets from K5 + noisy-region variants to VCF text without the reference's
-// htslib-typed structs.  Germline fields only (retrotransposon annotation a14 and somatic mode a20 are out of scope).
+// htslib-typed structs.  Germline fields only (somatic mode a20 is out of scope); the retrotransposon annotation of SV-size gaps (a14) is at the end of the file.
 #include <algorithm>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_set>
 #include <vector>
 #include "../../include/lcd_hotpath.h"
 
@@ -282,4 +283,105 @@ int lcd_update_digars_from_msa1(const lcd_digar_t *dg, int n_digar, int qlen, in
 void lcd_read_tags(int n, const int *haps, const int64_t *ps, uint8_t *has_hp, int *hp, uint8_t *has_ps, int64_t *ps_out) {
     for (int i = 0; i < n; ++i) { has_hp[i] = haps[i] != 0; hp[i] = haps[i]; has_ps[i] = ps[i] > 0; ps_out[i] = ps[i]; }
 }
+}
+
+// ---- retrotransposon annotation of SV-size gaps (host code in the reference and here) ----
+// collect_te_info (src/align.c:32-83): a gap (INS: the inserted bases, DEL: the deleted ones) is a candidate insertion of a transposable element when the bases
+// that follow it on the reference repeat its first bases (target-site duplication, one mismatch allowed) and it ends in poly-A or starts, behind the
+// duplication, with poly-T.  check_te_seq (src/kmer.c:218-253): which of the user's TE sequences (make_te_kmer_idx :120-150: all overlapping k-mers of each,
+// forward and reverse-complemented, as two sets per sequence) shares the most of the gap's non-overlapping k-mers.
+struct lcd_te_lib_t { int k; std::vector<std::unordered_set<uint32_t>> fwd, rev; };
+
+static inline int te_nt4(uint8_t c) { // nst_nt4_table, src/seq.c:14-31: codes 0-3 and the letters ACGT / acgt; everything else ends a k-mer
+    switch (c) { case 0: case 'A': case 'a': return 0; case 1: case 'C': case 'c': return 1; case 2: case 'G': case 'g': return 2; case 3: case 'T': case 't': return 3; default: return 4; }
+}
+// not_simple_kmer (src/kmer.c:16-24) as written there: the word is shifted down two bits per step and its lowest base compared with itself shifted UP by 2i bits,
+// which for i >= 1 differs exactly when that base is not A.  So a k-mer is "simple" -- and left out -- only if every base above its last one is A.
+static inline bool te_kmer_kept(uint32_t kmer, int k) {
+    for (int i = 0; i < k; ++i) { if ((kmer & 3u) != ((kmer & 3u) << (2 * i))) return true; kmer >>= 2; }
+    return false;
+}
+lcd_te_lib_t *lcd_te_lib_create(int n_seqs, const char *const *seqs, const int *lens, int kmer_len) {
+    if (n_seqs < 0 || kmer_len < 1 || kmer_len > 15) return nullptr; // (the reference's mask (1 << 2k) - 1 is an int: k <= 15; its default is 15)
+    lcd_te_lib_t *L = new lcd_te_lib_t(); L->k = kmer_len; L->fwd.resize(n_seqs); L->rev.resize(n_seqs);
+    const uint32_t mask = (1u << (2 * kmer_len)) - 1u; const int shift1 = 2 * (kmer_len - 1);
+    for (int s = 0; s < n_seqs; ++s) {
+        uint32_t f = 0, r = 0; int l = 0;
+        for (int i = 0; i < lens[s]; ++i) {
+            const int c = te_nt4((uint8_t)seqs[s][i]);
+            if (c >= 4) { l = 0; continue; }
+            f = (f << 2) | (uint32_t)c; r = (r >> 2) | ((uint32_t)(c ^ 3) << shift1); // collect_kmer :52-75, collect_rev_kmer :27-50
+            if (++l >= kmer_len) {
+                if (te_kmer_kept(f & mask, kmer_len)) L->fwd[s].insert(f & mask);
+                if (te_kmer_kept(r, kmer_len)) L->rev[s].insert(r);
+            }
+        }
+    }
+    return L;
+}
+void lcd_te_lib_destroy(lcd_te_lib_t *lib) { delete lib; }
+int lcd_te_lib_n_seqs(const lcd_te_lib_t *lib) { return lib ? (int)lib->fwd.size() : 0; }
+
+int lcd_check_te_seq(const lcd_te_lib_t *lib, const uint8_t *seq, int len, int *is_rev) {
+    if (!lib) return -1;
+    const int k = lib->k; const uint32_t mask = (1u << (2 * k)) - 1u;
+    std::vector<uint32_t> q; // collect_query_kmer :153-176: k-mers at 0, k, 2k, ... of every stretch of valid bases
+    { uint32_t h = 0; int l = 0;
+      for (int i = 0; i < len; ++i) { const int c = te_nt4(seq[i]); if (c >= 4) { l = 0; continue; } h = (h << 2) | (uint32_t)c; if (++l == k) { if (te_kmer_kept(h & mask, k)) q.push_back(h & mask); l = 0; } } }
+    if (q.empty()) return -1;
+    int max_for = 0, max_rev = 0, for_i = -1, rev_i = -1;
+    for (size_t s = 0; s < lib->fwd.size(); ++s) {
+        int fc = 0, rc = 0;
+        for (uint32_t x : q) { fc += lib->fwd[s].count(x) != 0; rc += lib->rev[s].count(x) != 0; }
+        if (fc > max_for) { max_for = fc; for_i = (int)s; }
+        if (rc > max_rev) { max_rev = rc; rev_i = (int)s; }
+    }
+    const int min_count = 3;
+    if (max_for > max_rev) { *is_rev = 0; return max_for >= min_count ? for_i : -1; }
+    *is_rev = 1; return max_rev >= min_count ? rev_i : -1; // (a tie, 0 : 0 included, reports the reverse strand, as the reference does)
+}
+
+void lcd_te_opt_default(lcd_te_opt_t *o) { o->min_tsd_len = 2; o->max_tsd_len = 100; o->min_polya_len = 10; o->min_polya_ratio = 0.8f; } // src/call_var_main.h:55-58
+
+int lcd_collect_te_info(const lcd_te_opt_t *opt, const lcd_te_lib_t *lib, int var_type, const uint8_t *gap_seq, const uint8_t *flank_ref_seq, int gap_len,
+                        int64_t gap_pos, uint8_t *tsd_seq, int64_t *tsd_pos1, int64_t *tsd_pos2, int *tsd_polya_len, int *te_seq_i, int *te_is_rev) {
+    *tsd_pos1 = -1; *tsd_pos2 = -1; *tsd_polya_len = -1; *te_seq_i = -1; *te_is_rev = 0;
+    int tsd_len = 0, n_mis = 0;
+    for (int i = 0; i < gap_len; ++i) { // target-site duplication: the gap's first bases against the reference behind the gap, one mismatch allowed
+        if (gap_seq[i] == flank_ref_seq[i]) tsd_len = i + 1;
+        else if (++n_mis > 1) break;
+        if (tsd_len > opt->max_tsd_len) break;
+    }
+    if (tsd_len < opt->min_tsd_len || tsd_len > opt->max_tsd_len) return 0;
+    bool has_polya = false; const int max_search = 20;
+    for (int n = 0, a = 0, i = gap_len - 1; i >= 0; --i) { // poly-A at the gap's end: the longest suffix (searched while A's keep coming within 20 bases) that is >= 80 % A
+        ++n;
+        if (gap_seq[i] == 0) { if (++a, n >= opt->min_polya_len && (float)a >= opt->min_polya_ratio * (float)n) { has_polya = true; *tsd_polya_len = n; } }
+        else if (n > max_search) break;
+    }
+    if (!has_polya)
+        for (int n = 0, t = 0, i = tsd_len; i < gap_len; ++i) { // poly-T behind the duplication: reported as a negative length
+            ++n;
+            if (gap_seq[i] == 3) { if (++t, n >= opt->min_polya_len && (float)t >= opt->min_polya_ratio * (float)n) { has_polya = true; *tsd_polya_len = -n; } }
+            else if (n > max_search) break;
+        }
+    if (!has_polya) return 0;
+    if (lib && !lib->fwd.empty()) *te_seq_i = lcd_check_te_seq(lib, gap_seq, gap_len, te_is_rev);
+    for (int i = 0; i < tsd_len; ++i) tsd_seq[i] = flank_ref_seq[i];
+    *tsd_pos1 = gap_pos; *tsd_pos2 = var_type == 2 /* BAM_CDEL */ ? gap_pos + gap_len : -1;
+    return tsd_len;
+}
+
+// collect_te_info_from_cons (src/align.c:139-163; with cons_msa_seq = the variant's alt_seq and msa_gap_start = 0 also collect_te_info_from_var :87-131)
+int lcd_collect_te_info_from_cons(const lcd_te_opt_t *opt, const lcd_te_lib_t *lib, const char *ref_seq, int64_t ref_beg, int64_t ref_end, int64_t gap_ref_start,
+                                  int msa_gap_start, int var_type, int gap_len, const uint8_t *cons_msa_seq, uint8_t *tsd_seq, int64_t *tsd_pos1, int64_t *tsd_pos2,
+                                  int *tsd_polya_len, int *te_seq_i, int *te_is_rev) {
+    if (var_type != 1 && var_type != 2) return -4; // (the reference asserts INS / DEL)
+    auto bseq1 = [&](int64_t pos) -> uint8_t { return pos < ref_beg || pos > ref_end ? 4 : (uint8_t)te_nt4((uint8_t)ref_seq[pos - ref_beg]); }; // get_bseq1, src/seq.c:101
+    std::vector<uint8_t> gap(gap_len > 0 ? gap_len : 0), flank(gap_len > 0 ? gap_len : 0);
+    for (int i = 0; i < gap_len; ++i) {
+        if (var_type == 1) { gap[i] = cons_msa_seq[msa_gap_start + i]; flank[i] = bseq1(gap_ref_start + i); }
+        else { gap[i] = bseq1(gap_ref_start + i); flank[i] = bseq1(gap_ref_start + i + gap_len); }
+    }
+    return lcd_collect_te_info(opt, lib, var_type, gap.data(), flank.data(), gap_len, gap_ref_start, tsd_seq, tsd_pos1, tsd_pos2, tsd_polya_len, te_seq_i, te_is_rev);
 }

@@ -297,6 +297,19 @@ int lcdo_collect_digar_from_ref_seq(const lcdo_digar_opt_t *opt, int64_t read_po
                                     int left_clip_is_palindrome, int right_clip_is_palindrome, lcdo_digar_t **digars, int *n_digar, int64_t **noisy, int *n_noisy,
                                     int64_t **chunk_noisy, int *n_chunk_noisy, int64_t *beg, int64_t *end, int *n_total_cand_vars);
 
+/* ---- SURVEY a14 (oracle/te_info.c): collect_te_info (src/align.c:32-83), collect_te_info_from_cons (:139-163), check_te_seq and the k-mer sets (src/kmer.c) ---- */
+typedef struct lcdo_te_lib lcdo_te_lib_t;
+lcdo_te_lib_t *lcdo_te_lib_create(int n_seqs, const char *const *seqs, const int *lens, int k);
+void lcdo_te_lib_destroy(lcdo_te_lib_t *L);
+int lcdo_check_te_seq(const lcdo_te_lib_t *L, const uint8_t *seq, int len, int *is_rev);
+int lcdo_collect_te_info(int min_tsd_len, int max_tsd_len, int min_polya_len, float min_polya_ratio, const lcdo_te_lib_t *lib, int var_type,
+                         const uint8_t *gap_seq, const uint8_t *flank_ref_seq, int gap_len, int64_t gap_pos, uint8_t *tsd_seq, int64_t *tsd_pos1,
+                         int64_t *tsd_pos2, int *tsd_polya_len, int *te_seq_i, int *te_is_rev);
+int lcdo_collect_te_info_from_cons(int min_tsd_len, int max_tsd_len, int min_polya_len, float min_polya_ratio, const lcdo_te_lib_t *lib, const char *ref_seq,
+                                   int64_t ref_beg, int64_t ref_end, int64_t gap_ref_start, int msa_gap_start, int var_type, int gap_len,
+                                   const uint8_t *cons_msa_seq, uint8_t *tsd_seq, int64_t *tsd_pos1, int64_t *tsd_pos2, int *tsd_polya_len, int *te_seq_i,
+                                   int *te_is_rev);
+
 #ifdef __cplusplus
 }
 #endif
