@@ -365,12 +365,16 @@ int lcd_stitch_chunks(lcd_chunk_phase_t *chunks, int n_chunks, int update_reads)
  * hap_to_cons_alle); var_ref_len / var_alt_len / alt_off + alt_pool / alt_ref_base are the remaining cand_var_t fields; ref_seq is chunk->ref_seq (letters
  * or codes, nst_nt4_table applies) starting at ref_beg.  Returns the number of records; *vars_out malloc()'d (free with lcd_free_variants). */
 typedef struct lcd_call_opt_t { double log_p, log_1p, log_2; int max_gq, max_qual, min_sv_len, min_dp, min_alt_dp, out_amb_base; } lcd_call_opt_t;
-typedef struct lcd_var1_t {          /* var1_t, src/call_var_main.h:108-121 (retrotransposon / somatic fields left out) */
+typedef struct lcd_var1_t {          /* var1_t, src/call_var_main.h:108-121 (somatic fields left out) */
     int64_t pos, PS;
     int type, ref_len, n_alt_allele, alt_len[2];
     uint8_t *ref_bases, *alt_bases[2];
     int GT[2], DP, AD[2], QUAL, GQ, is_sv, is_clean, n_alt_reads;
     int *alt_read_i;
+    int cand_i;                          /* the candidate (index into the lcd_hap_problem_t) the record was made from */
+    int tsd_len, polya_len, te_seq_i, te_is_rev;   /* SURVEY a14 (var1_t's retrotransposon members): 0 / 0 / -1 / 0 from lcd_make_variants, filled by lcd_annotate_te */
+    int64_t tsd_pos1, tsd_pos2;          /* -1 until then */
+    uint8_t *tsd_seq;                    /* malloc()'d, tsd_len codes; freed by lcd_free_variants */
 } lcd_var1_t;
 void lcd_call_opt_default(lcd_call_opt_t *o);   /* src/call_var_main.c:156-157,209,217-219 */
 int lcd_make_variants(const lcd_call_opt_t *opt, const lcd_hap_problem_t *p, const int *var_ref_len, const int *var_alt_len, const uint64_t *alt_off,
@@ -380,6 +384,14 @@ void lcd_free_variants(lcd_var1_t *vars, int n);
 /* the VCF body lines write_var_to_vcf (src/vcf_utils.c:97-268) emits for these records (filters DP / AD / ambiguous bases applied); *text_out malloc()'d,
  * NUL-terminated; returns the number of lines */
 int lcd_format_vcf(const lcd_call_opt_t *opt, const char *chrom, const lcd_var1_t *vars, int n_vars, char **text_out);
+/* SURVEY a14 in the output records.  The reference computes the annotation when a candidate is made (collect_te_info_from_cons, src/collect_var.c:1817,1834) and copies
+ * it into the record (:1504-1520); the values depend only on the candidate's own position, type, length and inserted bases, so here they are computed for the
+ * finished records: every INS / DEL record whose gap (without the anchor base) has at least opt->min_sv_len bases.  te_lib may be NULL.  Returns the number of
+ * records that got a target-site duplication.  lcd_format_vcf_te == lcd_format_vcf plus the INFO keys write_var_to_vcf adds for them (src/vcf_utils.c:184-195: MEI,
+ * TSD, TSDLEN, POLYALEN, TSDPOS1, TSDPOS2, REPNAME = strand + te_names[te_seq_i]); te_names may be NULL (no REPNAME). */
+int lcd_annotate_te(const lcd_call_opt_t *opt, const lcd_te_opt_t *te_opt, const lcd_te_lib_t *te_lib, const char *ref_seq, int64_t ref_beg, int64_t ref_end,
+                    lcd_var1_t *vars, int n_vars);
+int lcd_format_vcf_te(const lcd_call_opt_t *opt, const char *chrom, const lcd_var1_t *vars, int n_vars, const char *const *te_names, char **text_out);
 /* HP / PS aux tags of write_processed_read_to_bam (src/bam_utils.c:1955-2006): HP:i is written iff hap != 0, PS:i iff phase set > 0 (an existing tag with
  * another value is replaced, one that should not be there is deleted): has_hp / has_ps say whether the record ends up carrying the tag */
 void lcd_read_tags(int n_reads, const int *haps, const int64_t *phase_sets, uint8_t *has_hp, int *hp, uint8_t *has_ps, int64_t *ps);

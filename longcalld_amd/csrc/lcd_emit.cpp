@@ -39,7 +39,7 @@ void join_read_phase(lcd_chunk_phase_t &c) { // update_chunk_read_hap_phase_set1
             if (c.phase_sets[r] != -1 && c.phase_sets[r] == c.flip_cur_PS) c.phase_sets[r] = c.flip_pre_PS;
         }
 }
-void free_members(lcd_var1_t *vars, int n) { for (int i = 0; i < n; ++i) { free(vars[i].ref_bases); free(vars[i].alt_bases[0]); free(vars[i].alt_bases[1]); free(vars[i].alt_read_i); } }
+void free_members(lcd_var1_t *vars, int n) { for (int i = 0; i < n; ++i) { free(vars[i].ref_bases); free(vars[i].alt_bases[0]); free(vars[i].alt_bases[1]); free(vars[i].alt_read_i); free(vars[i].tsd_seq); } }
 } // namespace
 
 extern "C" {
@@ -81,6 +81,7 @@ int lcd_make_variants(const lcd_call_opt_t *opt, const lcd_hap_problem_t *p, con
     for (int ci = 0; ci < V; ++ci) {
         if ((p->var_cate[ci] & kOutCate) == 0) continue;
         lcd_var1_t v; memset(&v, 0, sizeof(v));
+        v.cand_i = ci; v.te_seq_i = -1; v.tsd_pos1 = v.tsd_pos2 = -1; // (retrotransposon members: unset until lcd_annotate_te, src/collect_var.c:1504-1520)
         const bool gap = p->var_type[ci] == 2 || p->var_type[ci] == 1; // BAM_CDEL / BAM_CINS: the VCF record starts one base earlier
         v.pos = p->var_pos[ci] - (gap ? 1 : 0); v.ref_len = var_ref_len[ci] + (gap ? 1 : 0);
         if (v.pos < reg_beg || v.pos > reg_end) continue;
@@ -153,7 +154,8 @@ void lcd_free_variants(lcd_var1_t *vars, int n) {
     free(vars);
 }
 
-int lcd_format_vcf(const lcd_call_opt_t *opt, const char *chrom, const lcd_var1_t *vars, int n, char **text_out) {
+int lcd_format_vcf(const lcd_call_opt_t *opt, const char *chrom, const lcd_var1_t *vars, int n, char **text_out) { return lcd_format_vcf_te(opt, chrom, vars, n, nullptr, text_out); }
+int lcd_format_vcf_te(const lcd_call_opt_t *opt, const char *chrom, const lcd_var1_t *vars, int n, const char *const *te_names, char **text_out) {
     std::string t; int n_out = 0; char num[64];
     for (int i = 0; i < n; ++i) {
         const lcd_var1_t &v = vars[i];
@@ -172,8 +174,17 @@ int lcd_format_vcf(const lcd_call_opt_t *opt, const char *chrom, const lcd_var1_
         if (v.is_sv) for (int a = 0; a < v.n_alt_allele; ++a) { if (a) { svlen += ','; svtype += ','; } svlen += std::to_string(v.alt_len[a] - v.ref_len); svtype += v.alt_len[a] > v.ref_len ? "INS" : "DEL"; }
         t += '\t'; t += std::to_string(v.QUAL); t += "\tPASS\t";
         if (v.is_clean) t += "CLEAN;";
+        if (v.te_seq_i >= 0) t += "MEI;"; // src/vcf_utils.c:184
         t += "END="; t += std::to_string((long long)(v.pos + v.ref_len - 1));
-        if (v.is_sv) { t += ';'; t += svtype; t += ';'; t += svlen; }
+        if (v.is_sv) {
+            t += ';'; t += svtype; t += ';'; t += svlen;
+            if (v.tsd_len > 0) { // :188-193
+                t += ";TSD="; for (int k = 0; k < v.tsd_len; ++k) t += "ACGTN"[v.tsd_seq[k]];
+                t += ";TSDLEN="; t += std::to_string(v.tsd_len); t += ";POLYALEN="; t += std::to_string(v.polya_len); t += ";TSDPOS1="; t += std::to_string((long long)v.tsd_pos1);
+                if (v.tsd_pos2 > 0) { t += ";TSDPOS2="; t += std::to_string((long long)v.tsd_pos2); }
+            }
+            if (v.te_seq_i >= 0 && te_names) { t += ";REPNAME="; t += "+-"[v.te_is_rev ? 1 : 0]; t += te_names[v.te_seq_i]; } // :194
+        }
         t += '\t';
         int g1 = v.GT[0], g2 = v.GT[1]; const bool hom = g1 == g2; char sep = '|';
         if (v.PS == 0) { sep = '/'; if (g1 > g2) std::swap(g1, g2); }
@@ -384,4 +395,29 @@ int lcd_collect_te_info_from_cons(const lcd_te_opt_t *opt, const lcd_te_lib_t *l
         else { gap[i] = bseq1(gap_ref_start + i); flank[i] = bseq1(gap_ref_start + i + gap_len); }
     }
     return lcd_collect_te_info(opt, lib, var_type, gap.data(), flank.data(), gap_len, gap_ref_start, tsd_seq, tsd_pos1, tsd_pos2, tsd_polya_len, te_seq_i, te_is_rev);
+}
+
+// the annotation in the output records: see include/lcd_hotpath.h.  The record of a gap starts one base before it (the anchor): gap position = pos + 1, an
+// insertion's bases = alt_bases[0] + 1.
+int lcd_annotate_te(const lcd_call_opt_t *opt, const lcd_te_opt_t *te_opt, const lcd_te_lib_t *te_lib, const char *ref_seq, int64_t ref_beg, int64_t ref_end,
+                    lcd_var1_t *vars, int n_vars) {
+    int n_tsd = 0;
+    std::vector<uint8_t> tsd((size_t)std::max(te_opt->max_tsd_len, 1) + 1);
+    for (int i = 0; i < n_vars; ++i) {
+        lcd_var1_t &v = vars[i];
+        if ((v.type != 1 && v.type != 2) || v.n_alt_allele < 1) continue;
+        const int gap_len = v.type == 1 ? v.alt_len[0] - 1 : v.ref_len - 1;
+        if (gap_len < opt->min_sv_len) continue;
+        int64_t p1, p2; int pa, ti, tr;
+        const int tl = lcd_collect_te_info_from_cons(te_opt, te_lib, ref_seq, ref_beg, ref_end, v.pos + 1, 0, v.type, gap_len, v.type == 1 ? v.alt_bases[0] + 1 : nullptr,
+                                                     tsd.data(), &p1, &p2, &pa, &ti, &tr);
+        free(v.tsd_seq); v.tsd_seq = nullptr; v.tsd_len = 0; v.polya_len = 0; v.tsd_pos1 = v.tsd_pos2 = -1; v.te_seq_i = -1; v.te_is_rev = 0;
+        if (tl > 0) { // make_cand_vars0, src/collect_var.c:1765-1777
+            v.tsd_len = tl; v.polya_len = pa; v.tsd_pos1 = p1; v.tsd_pos2 = p2;
+            v.tsd_seq = (uint8_t *)malloc((size_t)tl); memcpy(v.tsd_seq, tsd.data(), (size_t)tl);
+            if (ti >= 0) { v.te_seq_i = ti; v.te_is_rev = tr; }
+            ++n_tsd;
+        }
+    }
+    return n_tsd;
 }

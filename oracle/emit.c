@@ -55,6 +55,7 @@ int lcdo_make_variants(const lcdo_call_opt_t *opt, const lcdo_hap_problem_t *p, 
         if ((p->var_cate[cand_i] & target_var_cate) == 0) continue;
         lcdo_var1_t *v = vars + i;
         memset(v, 0, sizeof(*v));
+        v->cand_i = cand_i; v->te_seq_i = -1; v->tsd_pos1 = -1; v->tsd_pos2 = -1;
         if (p->var_type[cand_i] == 2 || p->var_type[cand_i] == 1) { v->pos = p->var_pos[cand_i] - 1; v->ref_len = var_ref_len[cand_i] + 1; }
         else { v->pos = p->var_pos[cand_i]; v->ref_len = var_ref_len[cand_i]; }
         if (v->pos < reg_beg || v->pos > reg_end) continue;
@@ -129,7 +130,7 @@ int lcdo_make_variants(const lcdo_call_opt_t *opt, const lcdo_hap_problem_t *p, 
 
 void lcdo_free_variants(lcdo_var1_t *v, int n) {
     if (!v) return;
-    for (int i = 0; i < n; ++i) { free(v[i].ref_bases); free(v[i].alt_bases[0]); free(v[i].alt_bases[1]); free(v[i].alt_read_i); }
+    for (int i = 0; i < n; ++i) { free(v[i].ref_bases); free(v[i].alt_bases[0]); free(v[i].alt_bases[1]); free(v[i].alt_read_i); free(v[i].tsd_seq); }
     free(v);
 }
 
@@ -190,6 +191,9 @@ int lcdo_flip_variant_hap(lcdo_chunk_phase_t *pre_chunk, lcdo_chunk_phase_t *cur
 }
 
 int lcdo_format_vcf(const lcdo_call_opt_t *opt, const char *chrom, const lcdo_var1_t *vars, int n_vars, char **text_out) {
+    return lcdo_format_vcf_te(opt, chrom, vars, n_vars, NULL, text_out);
+}
+int lcdo_format_vcf_te(const lcdo_call_opt_t *opt, const char *chrom, const lcdo_var1_t *vars, int n_vars, const char *const *te_names, char **text_out) {
     size_t cap = 1 << 16, tot = 0; char *text = (char *)malloc(cap);
     int n_output_vars = 0;
     int buf_m = 50000; char *buffer = (char *)malloc(buf_m);
@@ -232,8 +236,18 @@ int lcdo_format_vcf(const lcdo_call_opt_t *opt, const char *chrom, const lcdo_va
         }
         len += snprintf(buffer + len, buf_m - len, "\t%d\tPASS\t", var.QUAL);
         if (var.is_clean) len += snprintf(buffer + len, buf_m - len, "CLEAN;");
+        if (var.te_seq_i >= 0) len += snprintf(buffer + len, buf_m - len, "MEI;");
         len += snprintf(buffer + len, buf_m - len, "END=%lld", (long long)(var.pos + var.ref_len - 1));
-        if (var.is_sv) len += snprintf(buffer + len, buf_m - len, ";%s;%s", SVTYPE, SVLEN);
+        if (var.is_sv) {
+            len += snprintf(buffer + len, buf_m - len, ";%s;%s", SVTYPE, SVLEN);
+            if (var.tsd_len > 0) {
+                len += snprintf(buffer + len, buf_m - len, ";TSD=");
+                for (int i = 0; i < var.tsd_len; ++i) len += snprintf(buffer + len, buf_m - len, "%c", "ACGTN"[var.tsd_seq[i]]);
+                len += snprintf(buffer + len, buf_m - len, ";TSDLEN=%d;POLYALEN=%d;TSDPOS1=%lld", var.tsd_len, var.polya_len, (long long)var.tsd_pos1);
+                if (var.tsd_pos2 > 0) len += snprintf(buffer + len, buf_m - len, ";TSDPOS2=%lld", (long long)var.tsd_pos2);
+            }
+            if (var.te_seq_i >= 0 && te_names) len += snprintf(buffer + len, buf_m - len, ";REPNAME=%c%s", "+-"[var.te_is_rev], te_names[var.te_seq_i]);
+        }
         len += snprintf(buffer + len, buf_m - len, "\t");
         int gt1 = var.GT[0], gt2 = var.GT[1];
         int is_hom = gt1 == gt2; int gt_seperator = '|';
@@ -263,4 +277,31 @@ int lcdo_format_vcf(const lcdo_call_opt_t *opt, const char *chrom, const lcdo_va
     free(buffer);
     *text_out = text;
     return n_output_vars;
+}
+
+/* the candidate behind a record: position pos + 1 (the record starts at the anchor base), an insertion's bases alt_bases[0] + 1; annotated when the gap has at
+ * least min_sv_len bases (src/collect_var.c:1817,1834), values into the record as make_cand_vars0 / make_variants do (:1765-1777, :1504-1520) */
+int lcdo_annotate_te(const lcdo_call_opt_t *opt, int min_tsd_len, int max_tsd_len, int min_polya_len, float min_polya_ratio, const struct lcdo_te_lib *te_lib,
+                     const char *ref_seq, int64_t ref_beg, int64_t ref_end, lcdo_var1_t *vars, int n_vars) {
+    int n = 0;
+    uint8_t *buf = (uint8_t *)malloc((size_t)(max_tsd_len > 0 ? max_tsd_len : 1) + 1);
+    for (int i = 0; i < n_vars; ++i) {
+        lcdo_var1_t *v = vars + i;
+        if (v->n_alt_allele < 1) continue;
+        int gap_len;
+        if (v->type == 1) gap_len = v->alt_len[0] - 1; else if (v->type == 2) gap_len = v->ref_len - 1; else continue;
+        if (gap_len < opt->min_sv_len) continue;
+        int64_t p1 = -1, p2 = -1; int polya = 0, te_i = -1, te_rev = 0;
+        int tsd_len = lcdo_collect_te_info_from_cons(min_tsd_len, max_tsd_len, min_polya_len, min_polya_ratio, te_lib, ref_seq, ref_beg, ref_end, v->pos + 1, 0, v->type,
+                                                     gap_len, v->type == 1 ? v->alt_bases[0] + 1 : NULL, buf, &p1, &p2, &polya, &te_i, &te_rev);
+        free(v->tsd_seq); v->tsd_seq = NULL;
+        if (tsd_len > 0) {
+            v->tsd_len = tsd_len; v->polya_len = polya; v->tsd_pos1 = p1; v->tsd_pos2 = p2;
+            v->tsd_seq = (uint8_t *)malloc(tsd_len); memcpy(v->tsd_seq, buf, tsd_len);
+            n++;
+        } else { v->tsd_len = 0; v->polya_len = 0; v->tsd_pos1 = -1; v->tsd_pos2 = -1; }
+        if (te_i >= 0) { v->te_seq_i = te_i; v->te_is_rev = te_rev; } else { v->te_seq_i = -1; v->te_is_rev = 0; }
+    }
+    free(buf);
+    return n;
 }

@@ -266,6 +266,10 @@ typedef struct {
     uint8_t *ref_bases, *alt_bases[2];
     int GT[2], DP, AD[2], QUAL, GQ, is_sv, is_clean, n_alt_reads;
     int *alt_read_i;
+    int cand_i;
+    int tsd_len, polya_len, te_seq_i, te_is_rev;   /* var1_t's retrotransposon members (src/collect_var.c:1504-1520), filled by lcdo_annotate_te */
+    int64_t tsd_pos1, tsd_pos2;
+    uint8_t *tsd_seq;
 } lcdo_var1_t;
 typedef struct {
     int tid, n_reads, n_vars;
@@ -280,6 +284,12 @@ int lcdo_make_variants(const lcdo_call_opt_t *opt, const lcdo_hap_problem_t *p, 
 void lcdo_free_variants(lcdo_var1_t *v, int n);
 int lcdo_flip_variant_hap(lcdo_chunk_phase_t *pre_chunk, lcdo_chunk_phase_t *cur_chunk, int out_aln);
 int lcdo_format_vcf(const lcdo_call_opt_t *opt, const char *chrom, const lcdo_var1_t *vars, int n_vars, char **text_out);
+/* the same with the INFO keys of annotated records (src/vcf_utils.c:184-195); te_names may be NULL */
+int lcdo_format_vcf_te(const lcdo_call_opt_t *opt, const char *chrom, const lcdo_var1_t *vars, int n_vars, const char *const *te_names, char **text_out);
+struct lcdo_te_lib;
+/* collect_te_info_from_cons for the candidates behind finished records (oracle/te_info.c); te_lib may be NULL */
+int lcdo_annotate_te(const lcdo_call_opt_t *opt, int min_tsd_len, int max_tsd_len, int min_polya_len, float min_polya_ratio, const struct lcdo_te_lib *te_lib,
+                     const char *ref_seq, int64_t ref_beg, int64_t ref_end, lcdo_var1_t *vars, int n_vars);
 /* order of intervals (st[i], en[i], label i) after cr_index(): cr_is_sorted / radix_sort_cr_intv (src/cgranges.c:13-86,162,350) */
 void lcdo_cr_sorted_order(int n, const int *st, const int *en, int *order_out);
 /* oracle/digar_tags.c: the same outputs from a cs:Z tag (src/bam_utils.c:844), an MD:Z tag (:1010) or the reference bases (:1179; bseq = BAM 4-bit bases,

@@ -129,3 +129,64 @@ def test_read_tags_policy(libs):
     prod.lcd_read_tags(5, haps.ctypes.data_as(ec.i32p), ps.ctypes.data_as(ec.i64p), has_hp.ctypes.data_as(ec.u8p), hp.ctypes.data_as(ec.i32p),
                        has_ps.ctypes.data_as(ec.u8p), pso.ctypes.data_as(ec.i64p))
     assert list(has_hp) == [0, 1, 1, 0, 1] and list(has_ps) == [0, 1, 0, 1, 0] and list(hp[[1, 2, 4]]) == [1, 2, 1] and pso[1] == 500
+
+
+def test_te_annotation_in_records_and_vcf_text(libs):
+    """SURVEY a14 in f4: SV-size insertions / deletions built to look like retrotransposon insertions (target-site duplication, TE body, poly-A or poly-T) next to
+    ordinary ones: lcd_annotate_te + lcd_format_vcf_te == the oracle's (oracle/emit.c, oracle/te_info.c) record by record and byte by byte, and the text carries
+    the keys write_var_to_vcf adds (src/vcf_utils.c:184-195)"""
+    prod, orc = libs
+    p, st, extra, ref, ref_beg = _chunk(21, nv=400, nr=300)
+    rng = np.random.default_rng(99)
+    tes = [bytes(rng.choice(list(b"ACGT"), 700).astype(np.uint8)), bytes(rng.choice(list(b"ACGT"), 500).astype(np.uint8))]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    refa = bytearray(ref)
+    V = p["n_vars"]; vtype = p["var_type"]; pos = p["var_pos"]
+    alt_len = extra["var_alt_len"].copy(); ref_len = extra["var_ref_len"].copy()
+    alts = [extra["alt_pool"][int(extra["alt_off"][i]):int(extra["alt_off"][i]) + int(alt_len[i])].copy() for i in range(V)]
+    code = {65: 0, 67: 1, 71: 2, 84: 3, 78: 4}
+    n_made = 0
+    for i in range(V):
+        o = int(pos[i]) - ref_beg
+        if vtype[i] == 1 and i % 2 == 0 and o + 40 < len(refa):          # insertion: TSD copied from the reference behind it, TE piece, tail
+            t = int(rng.integers(4, 16)); te = tes[i % 4 // 2]; a = int(rng.integers(0, len(te) - 130)); piece = te[a:a + 120]
+            if i % 8 >= 4:
+                piece = piece.translate(comp)[::-1]
+            body = [code[c] for c in piece]
+            tsd = [code.get(c, 4) for c in refa[o:o + t]]
+            seq = tsd + ([3] * 14 + body if i % 3 == 0 else body + [0] * 14)
+            alts[i] = np.array(seq, np.uint8); alt_len[i] = len(seq); n_made += 1
+        elif vtype[i] == 2 and i % 2 == 0 and o + 2 * 70 < len(refa):   # deletion of 60 bases: the bases behind it repeat its first ones, it ends in poly-A
+            ref_len[i] = 60; t = int(rng.integers(4, 16))
+            refa[o + 60 - 13:o + 60] = b"A" * 13
+            refa[o + 60:o + 60 + t] = refa[o:o + t]
+            n_made += 1
+    off = np.concatenate([[0], np.cumsum(alt_len)]).astype(np.uint64)
+    extra2 = dict(var_ref_len=ref_len, var_alt_len=alt_len, alt_off=off[:-1].copy(), alt_pool=np.concatenate(alts + [np.zeros(1, np.uint8)]), alt_ref_base=extra["alt_ref_base"])
+    ref2 = bytes(refa)
+    import test_te_info as tt
+    prod.lcd_te_lib_create.restype = C.c_void_p; orc.lcdo_te_lib_create.restype = C.c_void_p
+    prod.lcd_te_lib_create.argtypes = orc.lcdo_te_lib_create.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int]
+    Lp, Lo = tt._mk_lib(prod.lcd_te_lib_create, tes, 15), tt._mk_lib(orc.lcdo_te_lib_create, tes, 15)
+    opt = ec.default_call_opt()
+    keep = []
+    hs = _hap_struct(p, st, keep)
+    reg_beg, reg_end = int(pos[2]), int(pos[-3])
+    names = [b"AluYa5", b"L1HS"]
+    ta, tb = dict(lib=Lp, names=names), dict(lib=Lo, names=names)
+    a_recs, a_txt = ec.make_variants(prod, "lcd_", hs, opt, extra2, ref2, ref_beg, reg_beg, reg_end, te=ta)
+    b_recs, b_txt = ec.make_variants(orc, "lcdo_", hs, opt, extra2, ref2, ref_beg, reg_beg, reg_end, te=tb)
+    assert len(a_recs) == len(b_recs) and all(x == y for x, y in zip(a_recs, b_recs))
+    assert a_txt == b_txt and ta["n_annotated"] == tb["n_annotated"] >= 10 and n_made >= 20
+    lines = a_txt.splitlines()
+    mei = [l for l in lines if "\tCLEAN;MEI;" in l or "\tMEI;" in l]
+    assert len(mei) >= 5 and all(";TSD=" in l and ";TSDLEN=" in l and ";POLYALEN=" in l and ";TSDPOS1=" in l and ";REPNAME=" in l for l in mei)
+    assert any(";REPNAME=+AluYa5" in l or ";REPNAME=+L1HS" in l for l in mei) and any(";REPNAME=-" in l for l in mei)
+    assert any(";POLYALEN=-" in l for l in lines)                                   # poly-T behind the duplication
+    assert any(";TSDPOS2=" in l for l in lines)                                     # deletions carry the second position
+    assert any(";SVTYPE=" in l and ";TSD=" not in l for l in lines)                 # ordinary SVs stay as they were
+    # without the annotation step the text is that of lcd_format_vcf
+    plain = ec.make_variants(prod, "lcd_", hs, opt, extra2, ref2, ref_beg, reg_beg, reg_end)[1]
+    assert "TSD=" not in plain and plain.count("\n") == a_txt.count("\n")
+    prod.lcd_te_lib_destroy.argtypes = [C.c_void_p]; orc.lcdo_te_lib_destroy.argtypes = [C.c_void_p]
+    prod.lcd_te_lib_destroy(Lp); orc.lcdo_te_lib_destroy(Lo)
