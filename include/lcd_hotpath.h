@@ -411,7 +411,7 @@ int lcd_update_digars_from_msa1(const lcd_digar_t *digars, int n_digar, int qlen
  * [reg_beg, reg_end] (1-based, i.e. sam_itr_queryi on (reg_beg - 1, reg_end]) that are mapped, primary (not BAM_FSECONDARY / BAM_FSUPPLEMENTARY) and of
  * MAPQ >= min_mapq (opt->min_mq, 30), in file order, as the flat arrays lcd_digar_batch (pos0, cigar_pool / cigar_off / n_cigar, qual_pool / qual_off, qlen)
  * and lcd_read_view_t (seq_pool + seq_off[r] = bam_get_seq: BAM 4-bit bases) take.  BGZF blocks are inflated in parallel on n_threads host threads
- * (0 = all); the region is a scan of the sorted file (no .bai).  Returns n_reads or < 0 (lcd_io_last_error()); free with lcd_bam_reads_free. */
+ * (0 = all); the region is a scan of the sorted file.  Returns n_reads or < 0 (lcd_io_last_error()); free with lcd_bam_reads_free. */
 typedef struct lcd_bam_reads_t {
     int n_reads, tid, n_targets; int64_t target_len;
     int64_t *pos0, *end_pos;               /* bam1_core_t.pos ; bam_endpos (0-based, exclusive) */
@@ -422,6 +422,9 @@ typedef struct lcd_bam_reads_t {
     uint64_t *name_off; char *name_pool;         /* NUL-terminated, bam_get_qname */
 } lcd_bam_reads_t;
 int lcd_bam_load_region(const char *bam_path, const char *chrom, int64_t reg_beg, int64_t reg_end, int min_mapq, int n_threads, lcd_bam_reads_t *out);
+/* the same records through the BAM's .bai (bins of the region + the linear index's offset, SAM specification 5.2-5.3): only the BGZF blocks of the region's
+ * chunks are read and inflated -- what sam_itr_queryi does for the reference (src/bam_utils.c:1673) */
+int lcd_bam_load_region_indexed(const char *bam_path, const char *bai_path, const char *chrom, int64_t reg_beg, int64_t reg_end, int min_mapq, lcd_bam_reads_t *out);
 void lcd_bam_reads_free(lcd_bam_reads_t *r);
 /* faidx_fetch_seq of chrom:[beg, end] (1-based inclusive, clipped to the contig) through <fa_path>.fai, as byte codes A0 C1 G2 T3 N4 (get_bam_chunk_reg_ref_seq0,
  * src/bam_utils.c:1558); returns the length, *codes_out malloc()'d */

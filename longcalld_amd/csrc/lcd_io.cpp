@@ -2,8 +2,9 @@
 //   * BGZF container + BAM records: what collect_ref_seq_bam_main (src/bam_utils.c:1659-1716) loads for one region -- primary, mapped reads of
 //     MAPQ >= min_mq overlapping [reg_beg, reg_end], in file order -- flattened to exactly the arrays lcd_digar_batch and lcd_read_view_t take
 //     (0-based position, CIGAR words, BAM 4-bit bases, qualities).  BGZF blocks are independent deflate streams: block boundaries come from the
-//     BSIZE fields, the blocks are inflated on host threads in parallel (zlib), records are decoded from the concatenation.  No .bai: a
-//     region is a scan (the index only saves I/O; results are those of sam_itr_queryi on (reg_beg - 1, reg_end]).
+//     BSIZE fields, the blocks are inflated on host threads in parallel (zlib), records are decoded from the concatenation.  lcd_bam_load_region scans the
+//     file; lcd_bam_load_region_indexed reads only the blocks the .bai points to (bins + linear index, SAM specification 5.2-5.3); both give what
+//     sam_itr_queryi on (reg_beg - 1, reg_end] gives.
 //   * FASTA + .fai: faidx_fetch_seq of a region as byte codes (nst_nt4_table).
 //   * the VCF header lines of write_vcf_header (src/vcf_utils.c:17-96).  htslib's bcf_hdr_write decides their final order and adds
 //     ##fileformat itself; that library is absent, so the header text is this project's rendering (the BODY lines are lcd_format_vcf's, exact).
@@ -82,6 +83,97 @@ int bgzf_inflate_all(const std::vector<uint8_t> &f, std::vector<uint8_t> &out, i
 inline int32_t le32(const uint8_t *p) { return (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)); }
 inline uint8_t nt4c(unsigned char c) { return (c == 'A' || c == 'a') ? 0 : (c == 'C' || c == 'c') ? 1 : (c == 'G' || c == 'g') ? 2 : (c == 'T' || c == 't') ? 3 : 4; }
 template <typename T> T *dup_vec(const std::vector<T> &v) { T *p = (T *)malloc((v.size() + 1) * sizeof(T)); if (!v.empty()) memcpy(p, v.data(), v.size() * sizeof(T)); return p; }
+
+// one region's records, filtered as collect_ref_seq_bam_main does (src/bam_utils.c:1672-1706), flattened; shared by the scan and the indexed loader
+struct Collector {
+    const int tid; const int64_t reg_beg, reg_end; const int min_mapq;
+    std::vector<int64_t> pos0, endp; std::vector<int> mapq, flag, ncig, qlen;
+    std::vector<uint64_t> coff, soff, qoff, noff; std::vector<uint32_t> cpool; std::vector<uint8_t> spool, qpool; std::vector<char> npool;
+    Collector(int t, int64_t b, int64_t e, int mq) : tid(t), reg_beg(b), reg_end(e), min_mapq(mq) {}
+    // r: the record behind its block_size word.  1 taken, 0 skipped, -1 nothing further can overlap (sorted input)
+    int take(const uint8_t *r) {
+        const int refid = le32(r), p = le32(r + 4), lname = r[8], mq = r[9], nc = r[12] | (r[13] << 8), fl = r[14] | (r[15] << 8), lseq = le32(r + 16);
+        if (refid != tid) return (refid > tid || refid < 0) && !pos0.empty() ? -1 : 0;
+        const uint8_t *cg = r + 32 + lname;
+        int64_t rl = 0;
+        for (int k = 0; k < nc; ++k) { const uint32_t c = (uint32_t)le32(cg + 4 * k); const int op = c & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += c >> 4; }
+        const int64_t e0 = p + (rl > 0 ? rl : 1); // bam_endpos: 0-based exclusive end (an alignment without reference bases spans one)
+        if (p >= reg_end) return -1;               // sorted input: nothing further overlaps (reg_beg - 1, reg_end]
+        if (e0 <= reg_beg - 1) return 0;
+        if ((fl & (0x4 | 0x100 | 0x800)) || mq < min_mapq) return 0; // BAM_FUNMAP | BAM_FSECONDARY | BAM_FSUPPLEMENTARY, src/bam_utils.c:1683
+        pos0.push_back(p); endp.push_back(e0); mapq.push_back(mq); flag.push_back(fl); ncig.push_back(nc); qlen.push_back(lseq);
+        coff.push_back(cpool.size()); for (int k = 0; k < nc; ++k) cpool.push_back((uint32_t)le32(cg + 4 * k));
+        const uint8_t *sq = cg + 4 * (size_t)nc, *ql = sq + (lseq + 1) / 2;
+        soff.push_back(spool.size()); spool.insert(spool.end(), sq, sq + (lseq + 1) / 2);
+        qoff.push_back(qpool.size()); qpool.insert(qpool.end(), ql, ql + lseq);
+        noff.push_back(npool.size()); npool.insert(npool.end(), (const char *)r + 32, (const char *)r + 32 + lname);
+        return 1;
+    }
+    int finish(lcd_bam_reads_t *out, int tid_, int64_t tlen, int n_ref) {
+        out->n_reads = (int)pos0.size(); out->tid = tid_; out->target_len = tlen; out->n_targets = n_ref;
+        out->pos0 = dup_vec(pos0); out->end_pos = dup_vec(endp); out->mapq = dup_vec(mapq); out->flag = dup_vec(flag); out->n_cigar = dup_vec(ncig); out->qlen = dup_vec(qlen);
+        out->cigar_off = dup_vec(coff); out->cigar_pool = dup_vec(cpool); out->seq_off = dup_vec(soff); out->seq_pool = dup_vec(spool);
+        out->qual_off = dup_vec(qoff); out->qual_pool = dup_vec(qpool); out->name_off = dup_vec(noff); out->name_pool = dup_vec(npool);
+        return out->n_reads;
+    }
+};
+
+// BGZF as a stream with virtual offsets (compressed offset of the block << 16 | offset inside the inflated block), for the indexed loader: seek to a chunk's
+// start, read records across block boundaries, ask where the next byte is
+struct BgzfStream {
+    FILE *f = nullptr; uint64_t coff = 0, next_coff = 0; std::vector<uint8_t> blk; size_t at = 0; bool eof = false;
+    ~BgzfStream() { if (f) fclose(f); }
+    int load(uint64_t c) { // the block at compressed offset c
+        uint8_t h[18];
+        if (fseek(f, (long)c, SEEK_SET) != 0 || fread(h, 1, 18, f) != 18) { eof = true; blk.clear(); at = 0; coff = c; next_coff = c; return 0; }
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return io_err(-31, "not a BGZF block");
+        const unsigned xlen = h[10] | (h[11] << 8);
+        std::vector<uint8_t> x(xlen);
+        memcpy(x.data(), h + 12, std::min<size_t>(6, xlen));
+        if (xlen > 6 && fread(x.data() + 6, 1, xlen - 6, f) != xlen - 6) return io_err(-31, "truncated BGZF header");
+        unsigned bsize = 0; bool found = false;
+        for (size_t q = 0; q + 4 <= xlen;) { const unsigned slen = x[q + 2] | (x[q + 3] << 8); if (x[q] == 'B' && x[q + 1] == 'C' && slen == 2 && q + 6 <= xlen) { bsize = x[q + 4] | (x[q + 5] << 8); found = true; } q += 4 + slen; }
+        if (!found) return io_err(-31, "BGZF block without BSIZE");
+        const size_t clen = (size_t)bsize + 1 - 12 - xlen; // deflate data + CRC32 + ISIZE
+        std::vector<uint8_t> cd(clen);
+        if (xlen < 6) { if (fseek(f, (long)(c + 12 + xlen), SEEK_SET) != 0) return io_err(-31, "seek failed"); }
+        if (clen < 8 || fread(cd.data(), 1, clen, f) != clen) return io_err(-31, "truncated BGZF block");
+        const unsigned isize = cd[clen - 4] | (cd[clen - 3] << 8) | (cd[clen - 2] << 16) | ((unsigned)cd[clen - 1] << 24);
+        blk.resize(isize);
+        if (isize) {
+            z_stream zs; memset(&zs, 0, sizeof(zs));
+            if (inflateInit2(&zs, -15) != Z_OK) return io_err(-32, "inflateInit2 failed");
+            zs.next_in = cd.data(); zs.avail_in = (uInt)(clen - 8); zs.next_out = blk.data(); zs.avail_out = isize;
+            const int r = inflate(&zs, Z_FINISH); const bool ok = r == Z_STREAM_END && zs.total_out == isize;
+            inflateEnd(&zs);
+            if (!ok) return io_err(-32, "inflate failed on a BGZF block");
+        }
+        coff = c; next_coff = c + bsize + 1; at = 0; eof = false;
+        return 0;
+    }
+    int seek(uint64_t v) { if (int rc = load(v >> 16)) return rc; at = std::min<size_t>(v & 0xffff, blk.size()); return 0; }
+    int settle() { while (!eof && at >= blk.size()) if (int rc = load(next_coff)) return rc; return 0; } // at a block's end the position is the next block's start
+    uint64_t tell() { return (coff << 16) | (uint64_t)at; }
+    int read(uint8_t *dst, size_t n) { // 0 ok, 1 end of file, < 0 error
+        while (n) {
+            if (int rc = settle()) return rc;
+            if (eof) return 1;
+            const size_t k = std::min(n, blk.size() - at);
+            memcpy(dst, blk.data() + at, k); dst += k; at += k; n -= k;
+        }
+        return 0;
+    }
+};
+// the bins a region may have records in (SAM specification 5.3, reg2bins; [beg, end) 0-based)
+void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t> &bins) {
+    --end; bins.push_back(0);
+    for (int64_t k = 1 + (beg >> 26); k <= 1 + (end >> 26); ++k) bins.push_back((uint32_t)k);
+    for (int64_t k = 9 + (beg >> 23); k <= 9 + (end >> 23); ++k) bins.push_back((uint32_t)k);
+    for (int64_t k = 73 + (beg >> 20); k <= 73 + (end >> 20); ++k) bins.push_back((uint32_t)k);
+    for (int64_t k = 585 + (beg >> 17); k <= 585 + (end >> 17); ++k) bins.push_back((uint32_t)k);
+    for (int64_t k = 4681 + (beg >> 14); k <= 4681 + (end >> 14); ++k) bins.push_back((uint32_t)k);
+}
+inline uint64_t le64(const uint8_t *p) { uint64_t v = 0; for (int i = 7; i >= 0; --i) v = (v << 8) | p[i]; return v; }
 } // namespace
 
 extern "C" {
@@ -105,38 +197,94 @@ int lcd_bam_load_region(const char *bam_path, const char *chrom, int64_t reg_beg
         if (names.back() == chrom) { tid = i; tlen = lens.back(); }
     }
     if (tid < 0) return io_err(-34, std::string("contig not in the BAM header: ") + chrom);
-    std::vector<int64_t> pos0, endp; std::vector<int> mapq, flag, ncig, qlen;
-    std::vector<uint64_t> coff, soff, qoff, noff; std::vector<uint32_t> cpool; std::vector<uint8_t> spool, qpool; std::vector<char> npool;
+    Collector col(tid, reg_beg, reg_end, min_mapq);
     while (o + 36 <= d.size()) {
         const int bs = le32(d.data() + o); const uint8_t *r = d.data() + o + 4;
         if (bs < 32 || o + 4 + (size_t)bs > d.size()) return io_err(-33, "truncated BAM record");
         o += 4 + (size_t)bs;
-        const int refid = le32(r), p = le32(r + 4), lname = r[8], mq = r[9], nc = r[12] | (r[13] << 8), fl = r[14] | (r[15] << 8), lseq = le32(r + 16);
-        if (refid != tid) { if (refid > tid && !pos0.empty()) break; continue; }
-        const uint8_t *cg = r + 32 + lname;
-        int64_t rl = 0;
-        for (int k = 0; k < nc; ++k) { const uint32_t c = (uint32_t)le32(cg + 4 * k); const int op = c & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += c >> 4; }
-        const int64_t e0 = p + (rl > 0 ? rl : 1); // bam_endpos: 0-based exclusive end (an alignment without reference bases spans one)
-        if (p >= reg_end) break;                  // sorted input: nothing further overlaps (reg_beg - 1, reg_end]
-        if (e0 <= reg_beg - 1) continue;
-        if ((fl & (0x4 | 0x100 | 0x800)) || mq < min_mapq) continue; // BAM_FUNMAP | BAM_FSECONDARY | BAM_FSUPPLEMENTARY, src/bam_utils.c:1683
-        pos0.push_back(p); endp.push_back(e0); mapq.push_back(mq); flag.push_back(fl); ncig.push_back(nc); qlen.push_back(lseq);
-        coff.push_back(cpool.size()); for (int k = 0; k < nc; ++k) cpool.push_back((uint32_t)le32(cg + 4 * k));
-        const uint8_t *sq = cg + 4 * (size_t)nc, *ql = sq + (lseq + 1) / 2;
-        soff.push_back(spool.size()); spool.insert(spool.end(), sq, sq + (lseq + 1) / 2);
-        qoff.push_back(qpool.size()); qpool.insert(qpool.end(), ql, ql + lseq);
-        noff.push_back(npool.size()); npool.insert(npool.end(), (const char *)r + 32, (const char *)r + 32 + lname);
+        if (col.take(r) < 0) break;
     }
-    out->n_reads = (int)pos0.size(); out->tid = tid; out->target_len = tlen; out->n_targets = n_ref;
-    out->pos0 = dup_vec(pos0); out->end_pos = dup_vec(endp); out->mapq = dup_vec(mapq); out->flag = dup_vec(flag); out->n_cigar = dup_vec(ncig); out->qlen = dup_vec(qlen);
-    out->cigar_off = dup_vec(coff); out->cigar_pool = dup_vec(cpool); out->seq_off = dup_vec(soff); out->seq_pool = dup_vec(spool);
-    out->qual_off = dup_vec(qoff); out->qual_pool = dup_vec(qpool); out->name_off = dup_vec(noff); out->name_pool = dup_vec(npool);
-    return out->n_reads;
+    return col.finish(out, tid, tlen, n_ref);
 }
 void lcd_bam_reads_free(lcd_bam_reads_t *r) {
     free(r->pos0); free(r->end_pos); free(r->mapq); free(r->flag); free(r->n_cigar); free(r->qlen); free(r->cigar_off); free(r->cigar_pool);
     free(r->seq_off); free(r->seq_pool); free(r->qual_off); free(r->qual_pool); free(r->name_off); free(r->name_pool);
     memset(r, 0, sizeof(*r));
+}
+
+// The same region through the .bai (SAM specification 5.2): the chunks of the bins that can hold overlapping records, cut at the linear index's offset for
+// the region's first 16 kb window, merged, and read in file order -- only those BGZF blocks are read and inflated.  Records, filters and order are those of
+// lcd_bam_load_region (what sam_itr_queryi + the loop of collect_ref_seq_bam_main, src/bam_utils.c:1672-1706, see).
+int lcd_bam_load_region_indexed(const char *bam_path, const char *bai_path, const char *chrom, int64_t reg_beg, int64_t reg_end, int min_mapq, lcd_bam_reads_t *out) {
+    memset(out, 0, sizeof(*out));
+    BgzfStream bz; bz.f = fopen(bam_path, "rb");
+    if (!bz.f) return io_err(-30, std::string("cannot open ") + bam_path);
+    if (int rc = bz.seek(0)) return rc;
+    uint8_t w[8];
+    if (bz.read(w, 8) != 0 || memcmp(w, "BAM\1", 4) != 0) return io_err(-33, "not a BAM file");
+    { std::vector<uint8_t> text((size_t)std::max(le32(w + 4), 0)); if (!text.empty() && bz.read(text.data(), text.size()) != 0) return io_err(-33, "truncated BAM header"); }
+    if (bz.read(w, 4) != 0) return io_err(-33, "truncated BAM header");
+    const int n_ref = le32(w);
+    int tid = -1; int64_t tlen = 0;
+    for (int i = 0; i < n_ref; ++i) {
+        if (bz.read(w, 4) != 0) return io_err(-33, "truncated BAM header");
+        const int ln = le32(w);
+        std::vector<uint8_t> nm((size_t)std::max(ln, 0) + 4);
+        if (bz.read(nm.data(), (size_t)ln + 4) != 0) return io_err(-33, "truncated BAM header");
+        if (std::string((const char *)nm.data(), (size_t)std::max(ln - 1, 0)) == chrom) { tid = i; tlen = le32(nm.data() + ln); }
+    }
+    if (tid < 0) return io_err(-34, std::string("contig not in the BAM header: ") + chrom);
+    std::vector<uint8_t> ix;
+    if (int rc = read_file(bai_path, ix)) return rc;
+    if (ix.size() < 8 || memcmp(ix.data(), "BAI\1", 4) != 0 || le32(ix.data() + 4) <= tid) return io_err(-35, "not a .bai of this BAM");
+    int64_t qb = reg_beg - 1, qe = reg_end; // 0-based half-open, as sam_itr_queryi(idx, tid, reg_beg - 1, reg_end)
+    if (qb < 0) qb = 0;
+    if (qe > (1ll << 29)) qe = 1ll << 29;
+    Collector col(tid, reg_beg, reg_end, min_mapq);
+    if (qe <= qb) return col.finish(out, tid, tlen, n_ref);
+    std::vector<uint32_t> want; reg2bins(qb, qe, want);
+    std::vector<std::pair<uint64_t, uint64_t>> chunks; uint64_t min_off = 0;
+    size_t o = 8;
+    for (int t = 0; t <= tid; ++t) { // walk to the reference's section
+        if (o + 4 > ix.size()) return io_err(-35, "truncated .bai");
+        const int n_bin = le32(ix.data() + o); o += 4;
+        for (int b = 0; b < n_bin; ++b) {
+            if (o + 8 > ix.size()) return io_err(-35, "truncated .bai");
+            const uint32_t bin = (uint32_t)le32(ix.data() + o); const int n_chunk = le32(ix.data() + o + 4); o += 8;
+            if (o + 16ull * (size_t)n_chunk > ix.size()) return io_err(-35, "truncated .bai");
+            if (t == tid && bin != 37450 && std::find(want.begin(), want.end(), bin) != want.end())
+                for (int c = 0; c < n_chunk; ++c) chunks.emplace_back(le64(ix.data() + o + 16 * (size_t)c), le64(ix.data() + o + 16 * (size_t)c + 8));
+            o += 16 * (size_t)n_chunk;
+        }
+        if (o + 4 > ix.size()) return io_err(-35, "truncated .bai");
+        const int n_intv = le32(ix.data() + o); o += 4;
+        if (o + 8ull * (size_t)n_intv > ix.size()) return io_err(-35, "truncated .bai");
+        if (t == tid && n_intv > 0) min_off = le64(ix.data() + o + 8 * (size_t)std::min<int64_t>(qb >> 14, n_intv - 1));
+        o += 8 * (size_t)n_intv;
+    }
+    std::vector<std::pair<uint64_t, uint64_t>> keep;
+    for (auto &c : chunks) if (c.second > min_off) keep.push_back(c);
+    std::sort(keep.begin(), keep.end());
+    std::vector<std::pair<uint64_t, uint64_t>> merged;
+    for (auto &c : keep) { if (!merged.empty() && c.first <= merged.back().second) merged.back().second = std::max(merged.back().second, c.second); else merged.push_back(c); }
+    std::vector<uint8_t> rec;
+    bool done = false;
+    for (size_t m = 0; m < merged.size() && !done; ++m) {
+        if (int rc = bz.seek(merged[m].first)) return rc;
+        for (;;) {
+            if (int rc = bz.settle()) return rc;
+            if (bz.eof || bz.tell() >= merged[m].second) break;
+            const int r4 = bz.read(w, 4);
+            if (r4 == 1) break;
+            if (r4 < 0) return r4;
+            const int bs = le32(w);
+            if (bs < 32) return io_err(-33, "truncated BAM record");
+            rec.resize((size_t)bs);
+            if (bz.read(rec.data(), (size_t)bs) != 0) return io_err(-33, "truncated BAM record");
+            if (col.take(rec.data()) < 0) { done = true; break; }
+        }
+    }
+    return col.finish(out, tid, tlen, n_ref);
 }
 
 // faidx_fetch_seq([beg, end], 1-based inclusive) through the .fai next to the FASTA, as byte codes

@@ -23,21 +23,60 @@ def lib():
     from longcalld_amd import _lib
     L = C.CDLL(_lib.LIB_PATH)
     L.lcd_bam_load_region.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(BamReads)]
+    L.lcd_bam_load_region_indexed.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int, C.POINTER(BamReads)]
     L.lcd_fasta_fetch.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.POINTER(u8p)]
     L.lcd_fasta_fetch.restype = C.c_int64
     L.lcd_io_last_error.restype = C.c_char_p
     return L
 
 
-def _bgzf(data, block=4000):
+def _bgzf(data, block=4000, offsets=None):
     out = b""
     for o in list(range(0, len(data), block)) + [None]:
         chunk = b"" if o is None else data[o:o + block]
         co = zlib.compressobj(6, zlib.DEFLATED, -15)
         comp = co.compress(chunk) + co.flush()
         bsize = len(comp) + 25
+        if offsets is not None and o is not None:
+            offsets.append(len(out))                     # compressed offset of the block that holds uncompressed bytes [o, o + block)
         out += struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, bsize) + comp + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk))
     return out
+
+
+def _reg2bin(beg, end):                                  # SAM specification 5.3
+    end -= 1
+    for sh, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> sh == end >> sh:
+            return base + (beg >> sh)
+    return 0
+
+
+def _write_bai(path, n_ref, recs_with_voff):
+    """a .bai as samtools index writes it (SAM specification 5.2): per reference the bins with their chunks and the 16 kb linear index (unset windows take the
+    previous window's offset, as htslib's hts_idx_finish fills them)"""
+    out = b"BAI\x01" + struct.pack("<i", n_ref)
+    for t in range(n_ref):
+        bins, lin = {}, {}
+        for x in recs_with_voff:
+            if x["tid"] != t:
+                continue
+            b = _reg2bin(x["pos"], x["end"])
+            ch = bins.setdefault(b, [])
+            if ch and ch[-1][1] == x["vbeg"]:
+                ch[-1][1] = x["vend"]
+            else:
+                ch.append([x["vbeg"], x["vend"]])
+            for w in range(x["pos"] >> 14, ((x["end"] - 1) >> 14) + 1):
+                lin[w] = min(lin.get(w, x["vbeg"]), x["vbeg"])
+        out += struct.pack("<i", len(bins))
+        for b in sorted(bins):
+            out += struct.pack("<Ii", b, len(bins[b])) + b"".join(struct.pack("<QQ", c[0], c[1]) for c in bins[b])
+        n_intv = max(lin) + 1 if lin else 0
+        offs, prev = [], 0
+        for w in range(n_intv):
+            prev = lin.get(w, prev); offs.append(prev)
+        out += struct.pack("<i", n_intv) + b"".join(struct.pack("<Q", o) for o in offs)
+    open(path, "wb").write(out)
 
 
 def _make_bam(rng, path, n=300):
@@ -74,10 +113,18 @@ def _make_bam(rng, path, n=300):
         body = struct.pack("<iiBBHHHiiii", tid, int(pos[i]), len(name), mapq, 4680, len(cig), flag, qlen, -1, -1, 0) + name + cig.tobytes() + packed.tobytes() + qual.tobytes()
         if rng.random() < 0.5:
             body += b"NMi" + struct.pack("<i", 3)
+        u0 = len(d)
         d += struct.pack("<i", len(body)) + body
         rl = sum(ln for op, ln in ops if op in (0, 2, 3, 7, 8))
-        recs.append(dict(tid=tid, pos=int(pos[i]), end=int(pos[i]) + max(rl, 1), mapq=mapq, flag=flag, cig=cig, seq=packed, qual=qual, name=name[:-1].decode(), qlen=qlen))
-    open(path, "wb").write(_bgzf(d, block=int(rng.integers(2000, 60000))))
+        recs.append(dict(tid=tid, pos=int(pos[i]), end=int(pos[i]) + max(rl, 1), mapq=mapq, flag=flag, cig=cig, seq=packed, qual=qual, name=name[:-1].decode(), qlen=qlen,
+                         u0=u0, u1=len(d)))
+    block = int(rng.integers(2000, 60000)); coffs = []
+    open(path, "wb").write(_bgzf(d, block=block, offsets=coffs))
+    coffs.append(coffs[-1] + 1)        # (never used as a block: an end offset exactly at the data's end is normalised below)
+    for x in recs:                     # virtual offsets: compressed offset of the block << 16 | offset inside it; a position at a block's end is the next block's start
+        x["vbeg"] = (coffs[x["u0"] // block] << 16) | (x["u0"] % block)
+        x["vend"] = (coffs[x["u1"] // block] << 16) | (x["u1"] % block) if x["u1"] < len(d) else ((coffs[(len(d) - 1) // block] << 16) | ((len(d) - 1) % block + 1))
+    _write_bai(path + ".bai", len(refs), recs)
     return recs
 
 
@@ -95,6 +142,16 @@ def _check(lib, path, chrom, tid, recs, beg, end, min_mq):
         assert bytes(r.qual_pool[r.qual_off[i] + k] for k in range(0, x["qlen"], 7)) == x["qual"][::7].tobytes()
         assert C.string_at(C.addressof(r.name_pool.contents) + r.name_off[i]).decode() == x["name"]
     lib.lcd_bam_reads_free(C.byref(r))
+    if os.path.exists(path + ".bai"):   # the same records through the index
+        q = BamReads()
+        m = lib.lcd_bam_load_region_indexed(path.encode(), (path + ".bai").encode(), chrom, beg, end, min_mq, C.byref(q))
+        assert m == len(exp), lib.lcd_io_last_error()
+        for i, x in enumerate(exp):
+            assert q.pos0[i] == x["pos"] and q.end_pos[i] == x["end"] and q.flag[i] == x["flag"] and q.qlen[i] == x["qlen"] and q.n_cigar[i] == len(x["cig"])
+            assert C.string_at(C.addressof(q.name_pool.contents) + q.name_off[i]).decode() == x["name"]
+            nb = (x["qlen"] + 1) // 2
+            assert bytes(q.seq_pool[q.seq_off[i] + k] for k in range(0, nb, 5)) == x["seq"].tobytes()[::5]
+        lib.lcd_bam_reads_free(C.byref(q))
     return n
 
 
@@ -170,3 +227,38 @@ def test_real_test_bam_matches_plain_gzip_decoding(lib):
     tid = names.index("chr11")
     assert _check(lib, path, b"chr11", tid, recs, 1, 2000000, 30) >= 350
     _check(lib, path, b"chr11", tid, recs, 1236832, 1441808, 30)
+
+
+def test_indexed_loader_equals_scan_on_the_reference_bam(lib):
+    """the reference's bundled HG002 BAM with the .bai samtools wrote for it (build container only: /root/reference is absent elsewhere): every region through
+    the index == the same region by scanning the file -- chunk boundaries, linear-index cut, records spanning BGZF blocks, regions without reads"""
+    bam = "/root/reference/test_data/HG002_chr11_hifi_test.bam"
+    if not os.path.exists(bam):
+        pytest.skip("reference test data not present")
+    rng = np.random.default_rng(3)
+    full = BamReads()
+    n_all = lib.lcd_bam_load_region(bam.encode(), b"chr11", 1, 1 << 28, 0, 4, C.byref(full))
+    assert n_all > 100
+    lo, hi = int(full.pos0[0]), int(max(full.end_pos[i] for i in range(n_all)))
+    lib.lcd_bam_reads_free(C.byref(full))
+    regs = [(1, 1 << 28), (lo + 1, lo + 1), (hi, hi + 1000), (hi + 1, hi + 5000), (1, lo)] + [(int(b), int(b + w)) for b, w in zip(rng.integers(max(lo - 20000, 1), hi + 20000, 40), rng.integers(1, 120000, 40))]
+    n_nonempty = 0
+    for beg, end in regs:
+        for mq in (0, 30):
+            a, b = BamReads(), BamReads()
+            na = lib.lcd_bam_load_region(bam.encode(), b"chr11", beg, end, mq, 4, C.byref(a))
+            nb = lib.lcd_bam_load_region_indexed(bam.encode(), (bam + ".bai").encode(), b"chr11", beg, end, mq, C.byref(b))
+            assert na == nb >= 0, (beg, end, lib.lcd_io_last_error())
+            for i in range(na):
+                assert a.pos0[i] == b.pos0[i] and a.end_pos[i] == b.end_pos[i] and a.qlen[i] == b.qlen[i] and a.flag[i] == b.flag[i] and a.n_cigar[i] == b.n_cigar[i]
+                assert C.string_at(C.addressof(a.name_pool.contents) + a.name_off[i]) == C.string_at(C.addressof(b.name_pool.contents) + b.name_off[i])
+            if na:
+                k = na - 1; nbytes = (a.qlen[k] + 1) // 2
+                assert bytes(a.seq_pool[a.seq_off[k] + j] for j in range(nbytes)) == bytes(b.seq_pool[b.seq_off[k] + j] for j in range(nbytes))
+                assert [a.cigar_pool[a.cigar_off[k] + j] for j in range(a.n_cigar[k])] == [b.cigar_pool[b.cigar_off[k] + j] for j in range(b.n_cigar[k])]
+            n_nonempty += na > 0
+            lib.lcd_bam_reads_free(C.byref(a)); lib.lcd_bam_reads_free(C.byref(b))
+    assert n_nonempty > 20
+    r = BamReads()
+    assert lib.lcd_bam_load_region_indexed(bam.encode(), b"/nonexistent.bai", b"chr11", 1, 10, 0, C.byref(r)) < 0
+    assert lib.lcd_bam_load_region_indexed(bam.encode(), bam.encode(), b"chr11", 1, 10, 0, C.byref(r)) < 0 and b".bai" in lib.lcd_io_last_error()
