@@ -44,6 +44,10 @@ def test_no_cpu_fallback_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(Exception):
         align.edlib_xgaps(np.zeros(10, np.uint8), np.zeros(10, np.uint8))
+    with pytest.raises(Exception):   # the digar walk of collect_noisy_read_info for a chunk's pairs runs on the device or not at all
+        align.region_read_slices_batch([0], [100], [200], [np.array([[90, 7, 200, 0]], np.int64)], [200])
+    with pytest.raises(Exception):
+        align.RegionBatch()
 
 
 def test_product_does_not_import_oracle():
