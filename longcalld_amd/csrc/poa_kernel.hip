@@ -738,7 +738,7 @@ __device__ void ctx_to_sgpr(Ctx &g) {
     g.cig_node0 = usgpr(g.cig_node0); g.cig_qpos0 = usgpr(g.cig_qpos0); g.imap = usgpr(g.imap);
     g.tb = usgpr(g.tb); g.cert = usgpr(g.cert); g.node_cap = usgpr(g.node_cap);
     g.pl_start = usgpr(g.pl_start); g.pl_pidx = usgpr(g.pl_pidx); g.pl_bonus = usgpr(g.pl_bonus); g.pl_rem = usgpr(g.pl_rem); g.pl_base = usgpr(g.pl_base);
-    g.wmax = usgpr(g.wmax); g.cell_cap = usgpr(g.cell_cap); g.status = usgpr(g.status); g.spill_x = usgpr(g.spill_x); g.ring_k = usgpr(g.ring_k); g.plan_k = usgpr(g.plan_k);
+    g.wmax = usgpr(g.wmax); g.pool_words = usgpr(g.pool_words); g.seq_cap = usgpr(g.seq_cap); g.cell_cap = usgpr(g.cell_cap); g.status = usgpr(g.status); g.spill_x = usgpr(g.spill_x); g.ring_k = usgpr(g.ring_k); g.plan_k = usgpr(g.plan_k);
 }
 // End node (best predecessor at column qlen; its values are in the spill area) + the code-driven backtrack, on wavefront 0.
 // Results through sm.bc[0] = #cigar entries, [1] = status, [4] = first cigar slot.
@@ -1190,6 +1190,448 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
     wo->cig_pos = sm.bc[4];
     wo->score = sm.bc[5];
     win_sync<SOLO>();
+    wo->t_bt = (unsigned long long)(clock64() - t_bt0);
+    return n_cig;
+}
+
+// ================= lean single-wavefront rows (round 3) =================
+// The rows of the single-wavefront class are ~90 % of a HiFi-shape step, and in align_windowed<64, ...> a row cost ~450 instructions for 64 - 256 cells:
+// the compiler kept half of the row's uniform state (ring slot count, band, predecessor kinds) in vector registers, so uniform decisions became exec-mask
+// juggling, uniform HBM reads became flat loads with per-lane 64-bit addresses, and every row took two LDS round trips (predecessor values, query bases) on
+// its critical path.  This is the same recurrence (bit-identical codes / ordinals / row metadata: the code-driven backtrack is shared) written for one
+// wavefront only:
+//   * every uniform value lives in an SGPR by construction (readlane / readfirstlane at the source), the band arithmetic is scalar;
+//   * the row plan of 64 rows is ONE packed word per row in a lane window (+ remain / interval, first two predecessors), taken by v_readlane;
+//   * BACKBONE rows (one usable predecessor = the row before: 97 % of the rows of a clean-read graph) take the previous row's H / E1 / E2 from REGISTERS:
+//     lanes are relative to the row's first column, so the previous row is either in the same lanes or one lane to the left (wave_shl:1 DPP) -- no LDS on
+//     the critical path; the LDS ring slot is still written (fire and forget) for the rows that need it: several predecessors, a predecessor further back;
+//   * query bases are prefetched one row ahead for the predicted window (same / next lane group);
+//   * rbeg / rend / roff go to a 64-row lane window (v_writelane) and are flushed as three coalesced stores per 64 rows instead of four scalar stores per
+//     row; rows a far successor or the end node reads (plan flag) store theirs at once.
+// MODE 1: the oracle's adaptive band; MODE 2: certified intervals from the table (align_certified).  C cells per lane, window 64 * C columns.
+// Returns the number of cigar entries, 0 with wo->status set, or -1 = not representable here (window too narrow / > 254 predecessors / read >= 65 536 bases).
+template <int C> struct LeanCells { int v[C]; };
+__device__ __forceinline__ int lean_wlane(const int val, const int l, int old) { // old with lane l replaced by val (both wave-uniform; the lane select goes through M0)
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(__builtin_amdgcn_readfirstlane(val)), "s"(__builtin_amdgcn_readfirstlane(l)) : "m0");
+    return old;
+}
+// scalar min / max that stay on the scalar ALU: imax(imax(a, b), c) becomes v_max3_i32, which exists on the vector ALU only, and drags a whole chain of
+// uniform band arithmetic (and everything derived from it: window base, offsets, loop-carried state) into VGPRs
+__device__ __forceinline__ int smax(const int a, const int b) { int r; asm("s_max_i32 %0, %1, %2" : "=s"(r) : "s"(__builtin_amdgcn_readfirstlane(a)), "s"(__builtin_amdgcn_readfirstlane(b)) : "scc"); return r; }
+__device__ __forceinline__ int smin(const int a, const int b) { int r; asm("s_min_i32 %0, %1, %2" : "=s"(r) : "s"(__builtin_amdgcn_readfirstlane(a)), "s"(__builtin_amdgcn_readfirstlane(b)) : "scc"); return r; }
+__device__ __forceinline__ int dpp_shl1(const int old, const int v) { return __builtin_amdgcn_update_dpp(old, v, 0x130, 0xf, 0xf, false); } // lane i <- lane i + 1 (lane 63 keeps `old`)
+template <int MODE, int C>
+__device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsigned ring_, const unsigned sq1_, const unsigned pd_ /* 0xffffffff: none */, const LcdScoring sc_, const int w_,
+                                                    const int bi_, const int ei_, const int rem_beg_, const uint8_t *seq_hbm_, const int qlen_, WinOut *wo_) {
+    constexpr int WIN = 64 * C, WM = WIN - 1, SLOTW = 3 * WIN, CM = ~(C - 1);
+    constexpr bool BANDED = MODE == 1, FIXED = MODE == 2;
+    Smem &sm = g_smem;
+    Ctx g = *usgpr(gp_);
+    ctx_to_sgpr(g);
+    int K = usgpr(g.ring_k);
+    const unsigned ring = usgpr(ring_); unsigned sq1 = usgpr(sq1_), pd = usgpr(pd_);
+    const int w = usgpr(w_), bi = usgpr(bi_), ei = usgpr(ei_), rem_beg = usgpr(rem_beg_), qlen = usgpr(qlen_);
+    const uint8_t *seq_hbm = usgpr(seq_hbm_); WinOut *wo = usgpr(wo_);
+    const int s_match = usgpr(sc_.match), s_mism = -usgpr(sc_.mismatch);
+    const int o1 = usgpr(sc_.o1), e1 = usgpr(sc_.e1), o2 = usgpr(sc_.o2), e2 = usgpr(sc_.e2), oe1 = o1 + e1, oe2 = o2 + e2;
+    const int lane = threadIdx.x & 63;
+    if (qlen >= 65535) return -1; // (beg | end << 16 words)
+    const int QB = (qlen + 12 + 15) & ~15;
+    {
+        // the pool of a single-wavefront chain is laid out for the window the host expects (PoaChain.wmax columns per ring slot); a wider window moves the
+        // query cache up and gives up the first-predecessor distances -- or, if the pool is too small for that, leaves the read to the next wider window
+        unsigned ring_bytes = (unsigned)(K * SLOTW * 4);
+        if (sq1 < ring + ring_bytes) {
+            if (ring_bytes + (unsigned)QB > (unsigned)g.pool_words * 4u && K > g.plan_k) { K = usgpr(g.plan_k); ring_bytes = (unsigned)(K * SLOTW * 4); }
+            if (ring_bytes + (unsigned)QB > (unsigned)g.pool_words * 4u) return -1;
+            if (sq1 < ring + ring_bytes) { sq1 = ring + ring_bytes; pd = 0xffffffffu; }
+        }
+    }
+    const int KM = K - 1;
+    for (int j = lane; j < QB; j += 64) lds_st_u8(sq1 + j, (j >= 1 && j <= qlen) ? glb_ld_u8(seq_hbm + (j - 1)) : 4); // shifted: sq1[j] = q[j-1]
+    const int qclamp = QB - 4;
+    const unsigned code_cap = (unsigned)(g.cell_cap > 0xfffffff0ull ? 0xfffffff0ull : g.cell_cap);
+    const unsigned ord_cap = g.spill_x > 2 ? code_cap : (unsigned)((g.cell_cap / 4) > 0xfffffff0ull ? 0xfffffff0ull : (g.cell_cap / 4));
+    const long long spill_rows_ll = g.cell_cap * g.spill_x > 64 ? (long long)((g.cell_cap * g.spill_x - 64) / ((unsigned long long)SLOTW * 4)) : 0;
+    const int spill_rows = (int)(spill_rows_ll > 0x7fffffffll ? 0x7fffffffll : spill_rows_ll);
+    const int *const hull = g.cert + 6 * (size_t)g.node_cap;
+    // ---- source row (slot 0, window at column 0) ----
+    int end0 = qlen - rem_beg; if (end0 < 0) end0 = 0; end0 += w; if (end0 > qlen) end0 = qlen;
+    if (FIXED) { const int hw = usgpr(glb_ld(hull + bi)); end0 = hw >> 16; if ((hw & 65535) != 0) return -1; } // (the source row's interval starts at column 0)
+    if (end0 + 2 > WIN) return -1;
+    int nsp = 0;
+    int pvh[C], pva[C], pvb[C]; // the previous row's values, lane = (column - pv_begc) / C
+    const int cl = C * lane;
+    {
+        const bool spf = (usgpr(glb_ld_u8(g.imap + bi)) & 2) != 0;
+        if (spf && spill_rows < 1) { wo->status = LCD_ERR_CELLS; return 0; }
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int j = cl + k;
+            const int f1 = j ? -(o1 + e1 * j) : LCD_NEG, f2 = j ? -(o2 + e2 * j) : LCD_NEG;
+            const int h = j ? imax(f1, f2) : 0;
+            const bool in = j <= end0;
+            pvh[k] = in ? h : LCD_GUARD; pva[k] = in ? h - oe1 : LCD_GUARD; pvb[k] = in ? h - oe2 : LCD_GUARD;
+        }
+        lds_stc<C>(ring + 4 * cl, pvh); lds_stc<C>(ring + 4 * (WIN + cl), pva); lds_stc<C>(ring + 4 * (2 * WIN + cl), pvb);
+        if (spf) { int *G = g.spill; glb_stc<C>(G + cl, pvh); glb_stc<C>(G + WIN + cl, pva); glb_stc<C>(G + 2 * WIN + cl, pvb); nsp = 1; }
+        if (lane == 0) { glb_st(g.rbeg + bi, 0); glb_st(g.rend + bi, end0); glb_st(g.roff + bi, 0); glb_st(g.ml + bi, 0); glb_st(g.mr + bi, 0); glb_st(g.spoff + bi, 0); }
+    }
+    // ring slot meta: lane s holds (beg | end << 16, ml | mr << 16) of slot s; an empty slot is beg 1, end 0
+    int m_be = 1, m_mm = 0;
+    if (lane == 0) m_be = end0 << 16;
+    int pv_begc = 0, pv_beg = 0, pv_end = end0, pv_ml = 0, pv_mr = 0; bool pv_ok = true;
+    unsigned cused = 0, oused = 0; unsigned long long ncell = (unsigned long long)end0 + 1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const long long t_dp0 = clock64();
+    // plan window (lane = row - wbase) and the rows' metadata window
+    int w_pk = 0, w_x = 0, w_pi0 = 0, w_pi1 = 0, w_p0 = 0; // w_x: remain (MODE 1) / interval (MODE 2)
+    int r_be = 1, r_off = 0;
+    int wbase = bi + 1;
+    // packed plan word: #preds (8 bits, 255 = more) | base << 8 | spill << 11 | unreachable << 12 | backbone << 13 | bonus0 << 14 | bonus1 << 19
+    auto load_plan = [&](const int base) {
+        const int ri = base + lane;
+        w_pk = 1 << 12;
+        if (ri < ei) {
+            const int s0 = glb_ld(g.pl_start + ri), s1 = glb_ld(g.pl_start + ri + 1);
+            const int cnt = s1 - s0;
+            int b0 = 0, b1 = 0;
+            w_p0 = s0;
+            if (cnt > 0) { w_pi0 = glb_ld(g.pl_pidx + s0); b0 = glb_ld(g.pl_bonus + s0); }
+            if (cnt > 1) { w_pi1 = glb_ld(g.pl_pidx + s0 + 1); b1 = glb_ld(g.pl_bonus + s0 + 1); }
+            const int rem = glb_ld(g.pl_rem + ri);
+            w_x = FIXED ? glb_ld(hull + ri) : rem;
+            w_pk = imin(cnt, 255) | (glb_ld_u8(g.pl_base + ri) << 8) | ((glb_ld_u8(g.imap + ri) & 2) << 10) | (rem == (1 << 30) ? 1 << 12 : 0)
+                 | ((cnt == 1 && w_pi0 == ri - 1) ? 1 << 13 : 0) | (b0 << 14) | (b1 << 19);
+        }
+        LCD_PIN(w_pk); LCD_PIN(w_x); LCD_PIN(w_pi0); LCD_PIN(w_pi1); LCD_PIN(w_p0);
+    };
+    auto flush_meta = [&](const int base, const int n) { // rows base .. base + n - 1
+        if (lane < n) { glb_st(g.rbeg + base + lane, r_be & 65535); glb_st(g.rend + base + lane, (int)((unsigned)r_be >> 16)); glb_st(g.roff + base + lane, r_off); }
+    };
+    load_plan(wbase);
+    // query bases of the lanes' cells for the window that starts at column b: sq1[b + cl + k], k < C, in the low bytes of one word
+    // (one LDS load of exactly C bytes -- jq is a multiple of C -- so that a prefetched word needs no arithmetic before the row that uses it)
+    auto q_of = [&](const int b) {
+        const unsigned a = sq1 + (unsigned)imin(b + cl, qclamp);
+        if constexpr (C == 1) return (unsigned)*(const lcd_lds_u8 *)(uintptr_t)a;
+        else if constexpr (C == 2) return (unsigned)*(const __attribute__((address_space(3))) unsigned short *)(uintptr_t)a;
+        else return (unsigned)lds_ld(a);
+    };
+    unsigned q_cur = 0, q_nxt = 0; int q_ok = 0; // windows at pv_begc and pv_begc + C, valid while q_ok (the run loop keeps them; a general row drops them)
+    // per-lane constants: (cl + k) * e and -(o + (cl + k) * e)
+    int ce1[C], ce2[C], nf1[C], nf2[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) { ce1[k] = (cl + k) * e1; ce2[k] = (cl + k) * e2; nf1[k] = -(o1 + ce1[k]); nf2[k] = -(o2 + ce2[k]); }
+    int idx = bi + 1;
+    while (idx < ei) {
+        if (idx - wbase == 64) { flush_meta(wbase, 64); wbase = idx; load_plan(wbase); }
+        int wk = idx - wbase;
+        // ===== a run of PLAIN rows: reachable, one usable predecessor = the row before (whose values are in registers), not spilled, window on the same lanes
+        // or one lane group further.  Anything else leaves the loop with the row untouched and is handled by the general row below. =====
+        if (pv_ok) {
+            if (!q_ok) { q_cur = q_of(pv_begc); q_nxt = q_of(pv_begc + C); q_ok = 1; }
+            unsigned run_cells = 0;
+            // (the run's loop-carried scalars are locals initialised through readfirstlane: as phis of the outer loop the compiler keeps them in VGPRs)
+            int l_begc = usgpr(pv_begc), l_beg = usgpr(pv_beg), l_end = usgpr(pv_end), l_ml = usgpr(pv_ml), l_mr = usgpr(pv_mr);
+            while (wk < 64) {
+                const int pk = LCD_RL(w_pk, wk);
+                if ((pk & 0x38ff) != 0x2001) break; // #preds == 1, not spilled, reachable, backbone
+                const int xw = LCD_RL(w_x, wk);
+                int beg, end;
+                if (BANDED) {
+                    const int diag = qlen - xw;
+                    beg = smax(smax(smin(l_ml + 1, diag) - w, 0), l_beg);
+                    end = smin(smin(smax(l_mr + 1, diag) + w, qlen), l_end + 1);
+                } else { beg = xw & 65535; end = (int)((unsigned)xw >> 16); }
+                const int begc = beg & CM;
+                const int sh = begc - l_begc;
+                const int cw4 = ((end - begc) + 4) & ~3;
+                if (beg > end || end - begc + 2 > WIN || (unsigned)sh > (unsigned)C || cused + (unsigned)cw4 > code_cap) break;
+                const int vb = (pk >> 8) & 7, bz0 = (pk >> 14) & 31;
+                const int s = (idx - bi) & KM;
+                const int mt = vb >= 4 ? 0 : s_match, mm = vb >= 4 ? 0 : s_mism;
+                // previous row: same lanes (sh == 0) or one lane to the left (sh == C)
+                int hm, av[C], bv[C], hd[C]; // hd[k]: H of the previous row at this cell's column - 1
+                if (sh == 0) {
+                    hm = shr1(LCD_GUARD, pvh[C - 1]);
+#pragma unroll
+                    for (int k = 0; k < C; ++k) { hd[k] = k ? pvh[k - 1] : hm; av[k] = pva[k]; bv[k] = pvb[k]; }
+                } else {
+                    q_cur = q_nxt; q_nxt = q_of(begc + C);
+#pragma unroll
+                    for (int k = 0; k < C; ++k) { hd[k] = k ? dpp_shl1(LCD_GUARD, pvh[k - 1]) : pvh[C - 1]; av[k] = dpp_shl1(LCD_GUARD, pva[k]); bv[k] = dpp_shl1(LCD_GUARD, pvb[k]); }
+                }
+                const int be1 = begc * e1, be2 = begc * e2, lo = beg - begc, span = end - beg;
+                int hp[C], spk[C], a1[C], a2[C], p1[C], p2[C], uu[C], vv[C]; bool inb[C];
+#pragma unroll
+                for (int k = 0; k < C; ++k) {
+                    const int q = (q_cur >> (8 * k)) & 255;
+                    const int sk = q >= 4 ? 0 : (q == vb ? mt : mm);
+                    const int nn = imax(LCD_NEG, hd[k] + sk + bz0);
+                    uu[k] = imax(LCD_NEG, av[k] + bz0); vv[k] = imax(LCD_NEG, bv[k] + bz0);
+                    inb[k] = (unsigned)(cl + k - lo) <= (unsigned)span;
+                    hp[k] = imax(nn, imax(uu[k], vv[k]));
+                    spk[k] = nn == hp[k] ? 0 : uu[k] == hp[k] ? 1 : 2;
+                    a1[k] = inb[k] ? hp[k] + ce1[k] + be1 : LCD_GUARD; a2[k] = inb[k] ? hp[k] + ce2[k] + be2 : LCD_GUARD;
+                    p1[k] = k ? imax(p1[k - 1], a1[k]) : a1[k]; p2[k] = k ? imax(p2[k - 1], a2[k]) : a2[k];
+                }
+                int t1 = p1[C - 1], t2 = p2[C - 1];
+                scan_max2(t1, t2);
+                const int x1 = shr1(LCD_GUARD, t1), x2 = shr1(LCD_GUARD, t2);
+                unsigned code = 0;
+#pragma unroll
+                for (int k = 0; k < C; ++k) {
+                    const int pf1 = k ? imax(x1, p1[k - 1]) : x1, pf2 = k ? imax(x2, p2[k - 1]) : x2;
+                    const int f1 = imax(LCD_NEG, pf1 + nf1[k] - be1), f2 = imax(LCD_NEG, pf2 + nf2[k] - be2);
+                    const int h = imax(hp[k], imax(f1, f2));
+                    const int q1 = h - oe1, w1 = uu[k] - e1, q2 = h - oe2, w2 = vv[k] - e2;
+                    const int eo1 = imax(imax(q1, w1), LCD_NEG), eo2 = imax(imax(q2, w2), LCD_NEG);
+                    const int fk = f1 == h ? (f2 == h ? 5 : 3) : 4;
+                    const int hs = hp[k] == h ? spk[k] : fk;
+                    unsigned fl = 0; // O2, O1, Y2, Y1 pushed in this order = bits 6, 5, 4, 3 of the code
+                    { const int r2 = a2[k], r1 = a1[k]; LCD_PUSH_GE(fl, q2, w2); LCD_PUSH_GE(fl, q1, w1); LCD_PUSH_GT(fl, pf2, r2); LCD_PUSH_GT(fl, pf1, r1); }
+                    code |= ((unsigned)hs | (fl << 3)) << (8 * k);
+                    pvh[k] = inb[k] ? h : LCD_GUARD; pva[k] = inb[k] ? eo1 : LCD_GUARD; pvb[k] = inb[k] ? eo2 : LCD_GUARD;
+                }
+                int ml = 0, mr = 0;
+                if (BANDED) {
+                    int hb = pvh[0];
+#pragma unroll
+                    for (int k = 1; k < C; ++k) hb = imax(hb, pvh[k]);
+                    const int wm = lane63(scan_max(hb));
+                    const unsigned long long mk = __ballot(hb == wm); // (the row is not empty: its in-band cells are >= LCD_NEG > the filler)
+                    const int fl = usgpr((int)__builtin_ctzll(mk)), ll = usgpr(63 - (int)__builtin_clzll(mk));
+                    if (C == 1) { ml = begc + fl; mr = begc + ll; }
+                    else {
+                        int bl = C - 1, brr = 0;
+#pragma unroll
+                        for (int k = C - 2; k >= 0; --k) bl = pvh[k] == hb ? k : bl;
+#pragma unroll
+                        for (int k = 1; k < C; ++k) brr = pvh[k] == hb ? k : brr;
+                        ml = begc + C * fl + LCD_RL(bl, fl); mr = begc + C * ll + LCD_RL(brr, ll);
+                    }
+                }
+                {
+                    const int x = (begc + cl) & WM;
+                    const unsigned S = ring + 4 * s * SLOTW;
+                    lds_stc<C>(S + 4 * x, pvh); lds_stc<C>(S + 4 * (WIN + x), pva); lds_stc<C>(S + 4 * (2 * WIN + x), pvb);
+                    if (cl < cw4) {
+                        uint8_t *cp = g.code8 + (size_t)(cused + (unsigned)cl);
+                        if constexpr (C == 4) glb_st(cp, (int)code);
+                        else if constexpr (C == 2) *(__attribute__((address_space(1))) unsigned short *)cp = (unsigned short)code;
+                        else *(__attribute__((address_space(1))) uint8_t *)cp = (uint8_t)code;
+                    }
+                }
+                const int be = beg | (end << 16);
+                r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)cused, wk, r_off);
+                m_be = lean_wlane(be, s, m_be); m_mm = lean_wlane(ml | (mr << 16), s, m_mm);
+                l_begc = begc; l_beg = beg; l_end = end; l_ml = ml; l_mr = mr;
+                cused += (unsigned)cw4; run_cells += (unsigned)(span + 1);
+                ++idx; ++wk;
+            }
+            pv_begc = l_begc; pv_beg = l_beg; pv_end = l_end; pv_ml = l_ml; pv_mr = l_mr;
+            ncell += run_cells;
+            if (wk == 64 || idx >= ei) continue;
+        }
+        // ===== general row =====
+        q_ok = 0;
+        do {
+        const int pk = LCD_RL(w_pk, wk);
+        const int s = (idx - bi) & KM;
+        if (pk & (1 << 12)) { // not reachable from the begin node
+            m_be = lean_wlane(1, s, m_be); r_be = lean_wlane(1, wk, r_be);
+            pv_ok = false;
+            break;
+        }
+        const int np = pk & 255, vb = (pk >> 8) & 7, bz0 = (pk >> 14) & 31;
+        const bool spf = (pk >> 11) & 1;
+        if (np == 255) return -1;
+        const int xw = LCD_RL(w_x, wk);
+        int pi0 = LCD_RL(w_pi0, wk), pi1 = 0, bz1 = 0, p0 = 0;
+        if (np > 1) { pi1 = LCD_RL(w_pi1, wk); bz1 = (pk >> 19) & 31; p0 = LCD_RL(w_p0, wk); }
+        bool synced = false;
+        int beg, end;
+        if (BANDED) { // band: pulled from the predecessors' row-max columns (same values the oracle pushes to successors)
+            int mplv = 1 << 30, mprv = 0, minpb = 1 << 30, maxpe = -1;
+            for (int t = 0; t < np; ++t) {
+                int pi = t == 0 ? pi0 : pi1;
+                if (t > 1) pi = usgpr(glb_ld(g.pl_pidx + p0 + t));
+                int pb, pe, pml, pmr;
+                if (idx - pi <= K) { const int sp = (pi - bi) & KM; const int be = LCD_RL(m_be, sp), mm = LCD_RL(m_mm, sp); pb = be & 65535; pe = (int)((unsigned)be >> 16); pml = mm & 65535; pmr = (int)((unsigned)mm >> 16); }
+                else {
+                    if (!synced) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); synced = true; } // far row: its metadata / spilled values were stored to HBM earlier
+                    pb = usgpr(glb_ld(g.rbeg + pi)); pe = usgpr(glb_ld(g.rend + pi)); pml = usgpr(glb_ld(g.ml + pi)); pmr = usgpr(glb_ld(g.mr + pi));
+                }
+                if (pb > pe) continue;
+                minpb = smin(minpb, pb); maxpe = smax(maxpe, pe);
+                mplv = smin(mplv, pml + 1); mprv = smax(mprv, pmr + 1);
+            }
+            const int diag = qlen - xw;
+            beg = smax(smax(smin(mplv, diag) - w, 0), minpb);
+            end = smin(smin(smax(mprv, diag) + w, qlen), maxpe + 1);
+        } else { beg = xw & 65535; end = (int)((unsigned)xw >> 16); } // the row's certified interval (lo > hi: no cell of the row can lie on an optimal path)
+        if (beg > end) { // empty row
+            m_be = lean_wlane(1, s, m_be); r_be = lean_wlane(1, wk, r_be);
+            if (spf && lane == 0) { glb_st(g.rbeg + idx, 1); glb_st(g.rend + idx, 0); }
+            pv_ok = false;
+            break;
+        }
+        const int begc = beg & CM;
+        if (end - begc + 2 > WIN) return -1;
+        const int jb = begc + cl;
+        const unsigned qw = q_of(begc);
+        bool inb[C]; int sk[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            inb[k] = jb + k >= beg && jb + k <= end;
+            const int q = (qw >> (8 * k)) & 255;
+            sk[k] = (vb >= 4 || q >= 4) ? 0 : (vb == q ? s_match : s_mism);
+        }
+        // ---- phase A: best match / E1 / E2 input of the cells over the predecessors (first maximum keeps its ordinal) ----
+        int nn[C], uu[C], vv[C];
+        int om = 0, oa = 0, ob = 0; // ordinals, one byte per cell
+        {
+#pragma unroll
+            for (int k = 0; k < C; ++k) { nn[k] = LCD_NEG; uu[k] = LCD_NEG; vv[k] = LCD_NEG; }
+            const int x = jb & WM, xm = (jb - 1) & WM;
+            for (int t = 0; t < np; ++t) {
+                int pi = t == 0 ? pi0 : pi1, bz = t == 0 ? bz0 : bz1;
+                if (t > 1) { pi = usgpr(glb_ld(g.pl_pidx + p0 + t)); bz = usgpr(glb_ld(g.pl_bonus + p0 + t)); }
+                const bool near = idx - pi <= K;
+                const int sp = (pi - bi) & KM;
+                int pb, pe;
+                if (near) { const int be = LCD_RL(m_be, sp); pb = be & 65535; pe = (int)((unsigned)be >> 16); }
+                else {
+                    if (!synced) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); synced = true; }
+                    pb = usgpr(glb_ld(g.rbeg + pi)); pe = usgpr(glb_ld(g.rend + pi));
+                }
+                if (pb > pe) continue;
+                // a ring slot is addressed by (column mod WIN): columns of this row that lie a full window away from the predecessor's band would read that
+                // band's values instead of the filler -- rare, so those rows mask the loaded values by the predecessor's [beg, end] explicitly
+                const bool risk = pe - beg + 2 >= WIN || end - pb + 1 >= WIN;
+                int hm, hv[C], av[C], bv[C];
+                if (near) {
+                    const unsigned S = ring + 4 * sp * SLOTW;
+                    hm = lds_ld(S + 4 * xm); lds_ldc<C>(S + 4 * x, hv); lds_ldc<C>(S + 4 * (WIN + x), av); lds_ldc<C>(S + 4 * (2 * WIN + x), bv);
+                } else {
+                    const int *G = g.spill + (size_t)(unsigned)usgpr(glb_ld((const int *)g.spoff + pi)) * SLOTW;
+                    hm = glb_ld(G + xm); glb_ldc<C>(G + x, hv); glb_ldc<C>(G + WIN + x, av); glb_ldc<C>(G + 2 * WIN + x, bv);
+                    LCD_PIN(hm);
+#pragma unroll
+                    for (int k = 0; k < C; ++k) { LCD_PIN(hv[k]); LCD_PIN(av[k]); LCD_PIN(bv[k]); }
+                }
+                if (risk) {
+                    if (jb - 1 < pb || jb - 1 > pe) hm = LCD_GUARD;
+#pragma unroll
+                    for (int k = 0; k < C; ++k) if (jb + k < pb || jb + k > pe) { hv[k] = LCD_GUARD; av[k] = LCD_GUARD; bv[k] = LCD_GUARD; }
+                }
+                const int tt = t > 255 ? 255 : t;
+#pragma unroll
+                for (int k = 0; k < C; ++k) {
+                    const int c = (k == 0 ? hm : hv[k - 1]) + sk[k] + bz, a = av[k] + bz, b = bv[k] + bz;
+                    if (t == 0) { nn[k] = imax(nn[k], c); uu[k] = imax(uu[k], a); vv[k] = imax(vv[k], b); }
+                    else {
+                        if (c > nn[k]) { nn[k] = c; om = (om & ~(255 << (8 * k))) | (tt << (8 * k)); }
+                        if (a > uu[k]) { uu[k] = a; oa = (oa & ~(255 << (8 * k))) | (tt << (8 * k)); }
+                        if (b > vv[k]) { vv[k] = b; ob = (ob & ~(255 << (8 * k))) | (tt << (8 * k)); }
+                    }
+                }
+            }
+        }
+        // ---- F: A[k] = Hpre[k] + k*e; in-lane inclusive prefix, then one scan pair over the lane totals ----
+        int hp[C], spk[C], a1[C], a2[C], p1[C], p2[C];
+        const int je1 = begc * e1, je2 = begc * e2;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            hp[k] = imax(nn[k], imax(uu[k], vv[k]));                     // Hpre
+            spk[k] = nn[k] == hp[k] ? 0 : uu[k] == hp[k] ? 1 : 2;        // which of match / E1 / E2 gives it (the oracle's priority)
+            a1[k] = inb[k] ? hp[k] + je1 + ce1[k] : LCD_GUARD; a2[k] = inb[k] ? hp[k] + je2 + ce2[k] : LCD_GUARD;
+            p1[k] = k ? imax(p1[k - 1], a1[k]) : a1[k]; p2[k] = k ? imax(p2[k - 1], a2[k]) : a2[k];
+        }
+        int t1 = p1[C - 1], t2 = p2[C - 1];
+        scan_max2(t1, t2);
+        const int x1 = shr1(LCD_GUARD, t1), x2 = shr1(LCD_GUARD, t2); // exclusive prefix over the lanes
+        // ---- phase B: F, H, E-out, direction code of the cells ----
+        unsigned code = 0;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int pf1 = k ? imax(x1, p1[k - 1]) : x1, pf2 = k ? imax(x2, p2[k - 1]) : x2;
+            const int f1 = imax(LCD_NEG, pf1 + nf1[k] - je1), f2 = imax(LCD_NEG, pf2 + nf2[k] - je2);
+            const int h = imax(hp[k], imax(f1, f2));
+            const int eo1 = imax(imax(h - oe1, uu[k] - e1), LCD_NEG), eo2 = imax(imax(h - oe2, vv[k] - e2), LCD_NEG);
+            const int fk = f1 == h ? (f2 == h ? 5 : 3) : 4;
+            const int hs = hp[k] == h ? spk[k] : fk;
+            unsigned fl = 0; // O2, O1, Y2, Y1 pushed in this order = bits 6, 5, 4, 3 of the code
+            { const int q2 = h - oe2, w2 = vv[k] - e2, q1 = h - oe1, w1 = uu[k] - e1, r2 = a2[k], r1 = a1[k];
+              LCD_PUSH_GE(fl, q2, w2); LCD_PUSH_GE(fl, q1, w1); LCD_PUSH_GT(fl, pf2, r2); LCD_PUSH_GT(fl, pf1, r1); }
+            const unsigned cd = (unsigned)hs | (fl << 3) | (((om >> (8 * k)) & 255) ? CB_PM : 0);
+            code |= cd << (8 * k);
+            pvh[k] = inb[k] ? h : LCD_GUARD; pva[k] = inb[k] ? eo1 : LCD_GUARD; pvb[k] = inb[k] ? eo2 : LCD_GUARD;
+        }
+        // ---- row maximum, leftmost / rightmost column (adaptive band only) ----
+        int ml = 0, mr = 0;
+        if (BANDED) {
+            int hb = pvh[0];
+#pragma unroll
+            for (int k = 1; k < C; ++k) hb = imax(hb, pvh[k]);
+            int bl = C - 1, brr = 0;
+#pragma unroll
+            for (int k = C - 2; k >= 0; --k) bl = pvh[k] == hb ? k : bl;
+#pragma unroll
+            for (int k = 1; k < C; ++k) brr = pvh[k] == hb ? k : brr;
+            const int wm = lane63(scan_max(hb));
+            const unsigned long long mk = __ballot(hb == wm); // (the row is not empty: its in-band cells are >= LCD_NEG > the filler)
+            const int fl = usgpr((int)__builtin_ctzll(mk)), ll = usgpr(63 - (int)__builtin_clzll(mk));
+            if (C == 1) { ml = begc + fl; mr = begc + ll; }
+            else { ml = begc + C * fl + LCD_RL(bl, fl); mr = begc + C * ll + LCD_RL(brr, ll); }
+        }
+        // ---- stores: ring slot (values), HBM (codes; values only for rows a far successor / the end node will read) ----
+        const int cw4 = ((end - begc) + 4) & ~3; // cells of this row in HBM, padded to a multiple of 4 (rows stay dword-aligned for every C)
+        if (cused + (unsigned)cw4 > code_cap || (np > 1 && oused + (unsigned)cw4 > ord_cap) || (spf && nsp >= spill_rows)) { wo->status = LCD_ERR_CELLS; return 0; }
+        {
+            const int x = jb & WM;
+            const unsigned S = ring + 4 * s * SLOTW;
+            lds_stc<C>(S + 4 * x, pvh); lds_stc<C>(S + 4 * (WIN + x), pva); lds_stc<C>(S + 4 * (2 * WIN + x), pvb);
+            if (spf) { int *G = g.spill + (size_t)nsp * SLOTW; glb_stc<C>(G + x, pvh); glb_stc<C>(G + WIN + x, pva); glb_stc<C>(G + 2 * WIN + x, pvb); }
+            if (cl < cw4) {
+                uint8_t *cp = g.code8 + (size_t)(cused + (unsigned)cl);
+                if constexpr (C == 4) glb_st(cp, (int)code);
+                else if constexpr (C == 2) *(__attribute__((address_space(1))) unsigned short *)cp = (unsigned short)code;
+                else *(__attribute__((address_space(1))) uint8_t *)cp = (uint8_t)code;
+                if (np > 1) {
+                    int ow[C];
+#pragma unroll
+                    for (int k = 0; k < C; ++k) ow[k] = ((om >> (8 * k)) & 255) | (((oa >> (8 * k)) & 255) << 8) | (((ob >> (8 * k)) & 255) << 16);
+                    glb_stc<C>(g.ord + (size_t)(oused + (unsigned)cl), ow);
+                }
+            }
+        }
+        const int be = beg | (end << 16);
+        r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)cused, wk, r_off);
+        m_be = lean_wlane(be, s, m_be); m_mm = lean_wlane(ml | (mr << 16), s, m_mm);
+        if ((np > 1 || spf) && lane == 0) {
+            if (np > 1) glb_st(g.ooff + idx, (int)oused);
+            if (spf) { glb_st(g.rbeg + idx, beg); glb_st(g.rend + idx, end); glb_st(g.ml + idx, ml); glb_st(g.mr + idx, mr); glb_st(g.spoff + idx, nsp); }
+        }
+        pv_begc = begc; pv_beg = beg; pv_end = end; pv_ml = ml; pv_mr = mr; pv_ok = true;
+        cused += (unsigned)cw4; if (np > 1) oused += (unsigned)cw4; if (spf) ++nsp;
+        ncell += (unsigned long long)(end - beg + 1);
+        } while (0);
+        ++idx;
+    }
+    flush_meta(wbase, ei - wbase);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    wo->cells = ncell;
+    const long long t_bt0 = clock64();
+    wo->t_dp = (unsigned long long)(t_bt0 - t_dp0);
+    code_backtrack(g, sm, pd, bi, ei, qlen, SLOTW, WM, lane, CM);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const int n_cig = sm.bc[0];
+    wo->status = sm.bc[1];
+    wo->cig_pos = sm.bc[4];
+    wo->score = sm.bc[5];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     wo->t_bt = (unsigned long long)(clock64() - t_bt0);
     return n_cig;
 }
@@ -1799,9 +2241,15 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                 // one, two or four cells per lane by the widest interval (hull widths are computed for 4-cell groups: the narrower variants keep a margin)
                 nc = -1;
                 if (!SOLO || wave == 0) {
+                    if constexpr (!SOLO) {
+                        if (mw <= 60) nc = align_lean<2, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+                        if (nc < 0 && mw <= 124) { win_sync<SOLO>(); nc = align_lean<2, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                        if (nc < 0) { win_sync<SOLO>(); nc = align_lean<2, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                    } else {
                     if (mw <= 60) nc = align_windowed<64, 2, 1, SOLO>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
                     if (nc < 0 && mw <= 124) { win_sync<SOLO>(); nc = align_windowed<64, 2, 2, SOLO>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
                     if (nc < 0) { win_sync<SOLO>(); nc = align_windowed<64, 2, 4, SOLO>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                    }
                     if (SOLO && lane == 0) { g_wide.ppi[0] = nc; g_wide.ppi[1] = wo.status; g_wide.ppi[2] = wo.score; g_wide.ppi[3] = wo.cig_pos; g_wide.po[0] = (unsigned)wo.cells; g_wide.po[1] = (unsigned)(wo.cells >> 32); }
                 }
                 if (SOLO) { // the result of wavefront 0 to everybody
@@ -1955,12 +2403,11 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
             if (nc < 0) { __syncthreads(); nc = align_windowed<NT, 0, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
         } else {
             // the host's preferred window (PoaChain.wmax) first; a band that outgrows it is re-run in the next wider one
-            if constexpr (NT == 64) {
-                if (g.wmax <= 64) nc = align_windowed<NT, 1, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
-                if (nc < 0 && g.wmax <= 128) { __syncthreads(); nc = align_windowed<NT, 1, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
-                if (nc < 0) __syncthreads();
-            }
-            if (nc < 0) nc = align_windowed<NT, 1, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+            if constexpr (NT == 64) { // single wavefront: the lean rows (align_lean); a band that outgrows 256 columns takes the generic rows below
+                if (g.wmax <= 64) nc = align_lean<1, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+                if (nc < 0 && g.wmax <= 128) { __syncthreads(); nc = align_lean<1, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                if (nc < 0) { __syncthreads(); nc = align_lean<1, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+            } else nc = align_windowed<NT, 1, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
         }
         if (nc >= 0) {
             g.status = wo.status; g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells; g.t_plan += wo.t_plan; g.t_poll += wo.t_poll;
