@@ -703,8 +703,16 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     // the same rows (poa_kernel.hip align_windowed<.., SOLO>).  Measured slower at every threshold -- 20 batches: 36 - 42 k instead of 45 k regions/s, 2 x 32
     // batches: 52 k instead of 66 k -- so it is off by default.)
     const int solo_len = getenv("LCD_CERT_SOLO_LEN") ? atoi(getenv("LCD_CERT_SOLO_LEN")) : 0; // (read per call: a test switches it)
-    if (lvl < 0) lvl = (C.mode == 1 && maxl < 65536 && (cert_mode == 2 || (cert_mode == 1 && !opt.is_ont))) ? (solo_len > 0 && maxl >= solo_len ? 2 : 1) : 0;
+    if (lvl < 0) lvl = (C.mode == 1 && maxl < 65536 && (cert_mode == 2 || (cert_mode == 1 && !opt.is_ont))) ? 1 : 0;
     pc.cert = C.mode == 1 ? lvl : 0; pc.ring_k = 0;
+    // LONG chains -- the critical path of a submission, and of a single batch: 34 reads x 4 kb run 0.28 s on one wavefront, more than half of it the per-read phases around
+    // the rows (row plan, graph update, re-sort, backtrack: latency chains through L2 with 64 loads in flight) -- get a 256-thread workgroup: wavefront 0 runs the same
+    // lean rows, all four the phases around them (4x the loads in flight).  LCD_SOLO_RL: reads x longest read from which on (0 = off); LCD_CERT_SOLO_LEN: certified-band
+    // chains by read length (test switch)
+    {
+        static const long long solo_rl = getenv("LCD_SOLO_RL") ? atoll(getenv("LCD_SOLO_RL")) : 100000;
+        pc.solo = ((solo_rl > 0 && (long long)n * maxl >= solo_rl) || (solo_len > 0 && pc.cert && maxl >= solo_len)) ? 1 : 0;
+    }
     // graph capacity: the worst case is one node per base of every read (sum), the usual case a little more than the longest read.  Sized
     // from an estimate (a few per cent of new nodes per read on top of the backbone; g_node_hint learns noisier data); a chain that runs
     // out (LCD_ERR_NODES / LCD_ERR_EDGES) is re-run with 4x more per retry, up to the worst case.  The worst case for everybody was
@@ -762,16 +770,18 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
 // afterwards.  Chains are launched in groups of equal (threads, LDS bucket) so that short chains do not pay a long chain's LDS.
 static void chain_class(PoaChain &pc, bool noisy) {
     // DP row width: K2 rows span the whole read (+2 guard columns of the window); K1 rows are the adaptive band plus drift
-    const long long width = pc.cert == 1 ? 256 : pc.cert >= 2 ? 1024 : pc.mode == 1 ? (long long)pc.max_len + 2 : 2ll * (10 + pc.max_len / 100) + 1 + 48;
+    const long long width = pc.cert ? 256 : pc.mode == 1 ? (long long)pc.max_len + 2 : 2ll * (10 + pc.max_len / 100) + 1 + 48;
     int threads, K, wmax; // wmax: window / ring-slot width in columns, a power of two <= 4 * threads (poa_kernel.hip align_windowed)
+    if (width > 256) pc.solo = 0; // (the wide classes have their own rows)
     // one lane per four columns of the window: 64 / 128 / 256 / 512 / 1024 threads, so that no wavefront of a workgroup idles
     // (a 2 048-column chain in a 1 024-thread workgroup would hold a whole CU's registers with half of its wavefronts parked)
     if (width <= 256) { // single wavefront; banded chains prefer the narrowest window their band fits (1, 2 or 4 cells per lane, align_windowed)
         threads = 64; K = 2;
         static const int margin = getenv("LCD_BAND_MARGIN") ? atoi(getenv("LCD_BAND_MARGIN")) : 12;
         const long long bw = 2ll * (10 + pc.max_len / 100) + 1 + margin; // adaptive band + a little drift; a band that outgrows it is re-run wider
-        static const int cert_ring = getenv("LCD_CERT_RING") ? atoi(getenv("LCD_CERT_RING")) : 384; // (certified-band chains: ring slots wide enough for the reads that take the generic rows)
+        static const int cert_ring = getenv("LCD_CERT_RING") ? atoi(getenv("LCD_CERT_RING")) : 512; // (certified-band chains: ring slots wide enough for the reads that take the generic rows)
         wmax = pc.cert ? std::max(256, cert_ring) : pc.mode == 1 ? 256 : bw <= 60 ? 64 : bw <= 124 ? 128 : 256;
+        if (pc.solo) threads = 256; // (same rows, same ring layout: only the per-read phases see the other three wavefronts)
     }
     else if (width <= 512) { threads = 128; K = 2; wmax = 512; }
     else if (width <= 1024) { threads = 256; K = 2; wmax = 1024; }
@@ -782,7 +792,7 @@ static void chain_class(PoaChain &pc, bool noisy) {
     // ring slots of the single-wavefront class: 2, except long K1 chains of noisy reads -- their graphs interleave the alternatives of every column, a row's
     // predecessors sit 3 - 6 rows back as often as not, and a predecessor that has left the ring costs the row two dependent trips to HBM (its metadata, then
     // its spilled values); those chains are few and they are the latency of an SV-shape submission, so they get LCD_RING_K (8) slots and the LDS that takes
-    if (threads == 64 && pc.mode == 0 && noisy) {
+    if ((threads == 64 || pc.solo) && pc.mode == 0 && noisy) {
         static const int rk_env = getenv("LCD_RING_K") ? atoi(getenv("LCD_RING_K")) : 8, rk_len = getenv("LCD_RING_K_LEN") ? atoi(getenv("LCD_RING_K_LEN")) : 1500;
         if (pc.max_len >= rk_len && rk_env >= 2 && (rk_env & (rk_env - 1)) == 0 && rk_env <= 32) K = rk_env;
     }
@@ -809,13 +819,24 @@ static void chain_class(PoaChain &pc, bool noisy) {
     static const int buckets[] = {8 << 10, 12 << 10, 16 << 10, 24 << 10, 32 << 10, 48 << 10, 64 << 10, 96 << 10, 148 << 10};
     int lds = buckets[8];
     for (int b : buckets) if (need <= b) { lds = b; break; }
+    // the long chains of a submission are ONE launch group (one LDS size): kernels of a stream run one after the other, and every group of a few long chains lasts as
+    // long as its longest chain -- four such groups on the four streams held everything else back for 0.2 s
+    if (pc.solo) { static const int solo_kb = getenv("LCD_SOLO_KB") ? atoi(getenv("LCD_SOLO_KB")) : 64; lds = std::max(std::min(lds, 148 << 10), solo_kb << 10); if (lds > (solo_kb << 10)) lds = 148 << 10; }
+    // The longest single-wavefront chains are the critical path of a submission (34 reads x 4 kb: 0.28 s against 0.20 s of work for the whole chip), and next to 15
+    // other chains of its CU such a wavefront issues one instruction per ~7 cycles.  Chains above LCD_ISO_RL read-bases ask for LCD_ISO_KB of LDS: three of them fill
+    // a CU's LDS, so each has a SIMD (nearly) to itself -- and a pool its re-sort runs in.
+    if (threads == 64) {
+        static const long long iso_rl = getenv("LCD_ISO_RL") ? atoll(getenv("LCD_ISO_RL")) : 90000;
+        static const int iso_kb = getenv("LCD_ISO_KB") ? atoi(getenv("LCD_ISO_KB")) : 0; // (measured: the isolated chain is 8 % faster, the submission 10 % slower -- the extra launch group costs more than it gives; off)
+        if (iso_kb > 0 && (long long)pc.n_reads * pc.max_len >= iso_rl) lds = std::max(lds, iso_kb << 10);
+    }
     // (noisy K1 chains below that length: as many slots as the bucket they have anyway leaves room for -- LCD_RING_K_FREE=0 keeps them at 2.  Tried for the K1
     //  chains of clean reads too: no change at 2 x 32 batches, 47 k instead of 60 k regions/s at one submission of 20)
-    if (threads == 64 && pc.mode == 0 && noisy && K == 2) {
+    if ((threads == 64 || pc.solo) && pc.mode == 0 && noisy && K == 2) {
         static const bool rk_free = !(getenv("LCD_RING_K_FREE") && atoi(getenv("LCD_RING_K_FREE")) == 0);
         while (rk_free && K < 8 && (long long)(2 * K) * 3 * wmax * 4 + seq_bytes <= lds) K *= 2;
     }
-    pc.threads = threads; pc.wmax = wmax; pc.lds_words = lds / 4; pc.ring_k = threads == 64 ? K : 0;
+    pc.threads = threads; pc.wmax = wmax; pc.lds_words = lds / 4; pc.ring_k = (threads == 64 || pc.solo) ? K : 0;
 }
 static int chain_threads(const PoaChain &pc) { return pc.threads; }
 static long long chain_group_key(const PoaChain &pc) { return (long long)pc.threads * (1 << 20) + pc.lds_words; }
@@ -1077,6 +1098,27 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                 HIPCHK(hipMemcpyAsync((PoaRead *)L->d_preads.p + pread_base[k], preads[k].data(), preads[k].size() * sizeof(PoaRead), hipMemcpyHostToDevice, st));
         std::vector<size_t> which(nC_all);
         for (size_t g = 0; g < nC_all; ++g) which[g] = g;
+        // No more launch groups than streams: a stream runs its kernels one after the other, so a fifth group starts only when some other group's LAST chain has
+        // ended -- with the bulk of the work (40 000 short chains in the smallest LDS bucket) queued behind a group of a few hundred long chains the chip idled for a
+        // third of the stage.  The single-wavefront group with the fewest chains moves up into the next larger LDS bucket in use (a bigger pool is always valid).
+        {
+            static const int n_streams = std::max(1, std::min(LCD_NSIDE + 1, getenv("LCD_STREAMS") ? atoi(getenv("LCD_STREAMS")) : 4));
+            for (;;) {
+                std::map<long long, size_t> cnt;
+                for (size_t g = 0; g < nC_all; ++g) cnt[chain_group_key(PC(g))]++;
+                if ((int)cnt.size() <= n_streams) break;
+                long long from = -1, to = -1; size_t fewest = ~(size_t)0;
+                for (auto it = cnt.begin(); it != cnt.end(); ++it) {
+                    if ((it->first >> 20) != 64) continue;
+                    auto nx = std::next(it);
+                    if (nx == cnt.end() || (nx->first >> 20) != 64) continue;
+                    if (it->second < fewest) { fewest = it->second; from = it->first; to = nx->first; }
+                }
+                if (from < 0) break;
+                const int lw = (int)(to & ((1 << 20) - 1));
+                for (size_t g = 0; g < nC_all; ++g) if (chain_group_key(PC(g)) == from) PC(g).lds_words = lw;
+            }
+        }
         // widest / largest-LDS group first, then biggest first so the long chains start early (LPT)
         std::sort(which.begin(), which.end(), [&](size_t a, size_t c2) {
             const long long ta = chain_group_key(PC(a)), tc = chain_group_key(PC(c2));
@@ -1311,7 +1353,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         str_tots[k] = str_tot;
     };
     {
-        const int nth = std::max(1, std::min(nb, 8));
+        const int nth = std::max(1, std::min(nb, 16));
         if (nth == 1) build_jobs(0);
         else {
             std::atomic<int> next{0};
@@ -1552,16 +1594,18 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         }
         // per-phase shader-clock ticks, summed per workgroup class and for the slowest chain
         for (int cls : {64, 128, 256, 512, 1024}) {
-            unsigned long long tt = 0, td = 0, tb = 0, tg = 0, to = 0, ts = 0, mx = 0; int cnt = 0; size_t mxc = 0;
+            unsigned long long tt = 0, td = 0, tb = 0, tg = 0, to = 0, ts = 0, mx = 0, tbp = 0, tad = 0, tso = 0, tse = 0, tpl = 0; int cnt = 0; size_t mxc = 0;
             for (size_t g = 0; g < nC_all; ++g) { if (chain_threads(PC(g)) != cls) continue; const PoaChainOut &o = bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]]; ++cnt;
-                tt += o.t_total; td += o.t_dp; tb += o.t_bt; tg += o.t_graph; to += o.t_out; ts += o.t_sub; if (o.t_total >= mx) { mx = o.t_total; mxc = g; } }
+                tt += o.t_total; td += o.t_dp; tb += o.t_bt; tg += o.t_graph; to += o.t_out; ts += o.t_sub; tbp += o.t_bp; tad += o.t_add; tso += o.t_sort; tse += o.t_setup; tpl += o.t_plan; if (o.t_total >= mx) { mx = o.t_total; mxc = g; } }
             if (!cnt) continue;
+            fprintf(stderr, "[lcd] class %4d: row plan %.3e  graph update %.3e  re-sort %.3e  row setup %.3e  bound arrays %.3e\n", cls, (double)tbp, (double)tad, (double)tso, (double)tse, (double)tpl);
             { double tk = 0; for (size_t g = 0; g < nC_all; ++g) if (chain_threads(PC(g)) == cls) tk += (double)bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]].t_poll;
               fprintf(stderr, "[lcd] class %4d: %5d chains  sum ticks total %.3e dp %.3e bt %.3e graph %.3e (of which serial Kahn walk %.3e) sub %.3e out %.3e\n", cls, cnt, (double)tt, (double)td, (double)tb, (double)tg, tk, (double)ts, (double)to); }
             const PoaChainOut &o = bs[chain_batch[mxc]]->couts[mxc - chain_base[chain_batch[mxc]]];
             fprintf(stderr, "[lcd]   slowest chain %zu: mode %d reads %d maxlen %d nodes %d  total %.3e dp %.3e bt %.3e graph %.3e sub %.3e out %.3e cells %llu\n", mxc, PC(mxc).mode,
                     PC(mxc).n_reads, PC(mxc).max_len, o.n_node, (double)o.t_total, (double)o.t_dp, (double)o.t_bt, (double)o.t_graph, (double)o.t_sub, (double)o.t_out, o.cells);
             fprintf(stderr, "[lcd]     of its dp: plan-window refreshes %.3e  mailbox polls %.3e (one wavefront)\n", (double)o.t_plan, (double)o.t_poll);
+            fprintf(stderr, "[lcd]     row plan %.3e  graph update %.3e  re-sort %.3e  row setup %.3e\n", (double)o.t_bp, (double)o.t_add, (double)o.t_sort, (double)o.t_setup);
         }
     }
     return 0;

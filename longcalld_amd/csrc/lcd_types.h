@@ -65,6 +65,7 @@ struct PoaChain {
     uint64_t slot_bytes;
     uint64_t cu_rank;     // device address of int[4096]: raw (XCC, SE, SH, CU) id -> compact CU index, -1 unknown; 0: none
     int n_slots, per_cu;
+    int solo;             // 1: a long single-wavefront chain in a 256-thread workgroup -- wavefront 0 runs the rows (align_lean), all four the per-read graph phases
     int cert, ring_k;     // ring_k: ring slots of the single-wavefront class's windowed rows (a power of two >= 2, 0 = 2; the other classes: 2), lcd_host.cpp chain_class;  cert 1: K2 chain in the single-wavefront class, rows restricted to the certified band (poa_kernel.hip align_certified)
 };
 
@@ -82,6 +83,7 @@ struct PoaChainOut {
     unsigned long long t_total, t_dp, t_bt, t_graph, t_out, t_sub; // shader-clock ticks per phase (profiling aid)
     unsigned long long rt_begin, rt_end; unsigned hw_id, xcc_id;    // placement probe: s_memrealtime (100 MHz) at start / end, HW_ID, XCC_ID
     unsigned long long t_plan, t_poll;                             // inside t_dp: plan-window refreshes / mailbox polls of one wavefront (unbanded rows)
+    unsigned long long t_bp, t_add, t_sort, t_setup;               // row plan; graph update; re-sort (inside t_graph, with t_add); query staging + first row of the lean rows (profiling aid)
 };
 
 // Spare DP memory of a launch set (lcd_host.cpp round loop): a chain whose DP region is too small for the read at hand (LCD_ERR_CELLS) takes a region four

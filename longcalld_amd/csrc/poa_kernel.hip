@@ -77,11 +77,11 @@ struct Ctx {
     long long alg_adjust;             // cells of the reference's algorithm minus cells computed (certified band: full rows minus the intervals, attempts included)
     int cert_generic, cert_generic_seen, cert_sest, cert_ubtop; unsigned long long cert_cells0; // the read at hand goes through the generic rows over its intervals (align_certified)
     int *cert; int cert_on, cert_hist; // certified band of a K2 chain (align_certified): 7 x node_cap ints; largest bound-to-score slack of the chain's reads so far
-    int wmax, seq_cap, pool_words, spill_x, ring_k, plan_k;
+    int wmax, seq_cap, pool_words, spill_x, ring_k, plan_k, solo;
     int n_node, n_edge, node_cap, edge_cap, rid_words;
     unsigned long long cell_cap;
     int status;
-    unsigned long long t_dp, t_bt, t_plan, t_poll, t_kahn;
+    unsigned long long t_dp, t_bt, t_plan, t_poll, t_kahn, t_bp, t_setup;
 };
 
 __device__ __forceinline__ int ilog2_32(int v) { return 31 - __clz(v); }
@@ -372,24 +372,26 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
 // Serial in topological order it is one dependent load chain of length n; by pointer jumping it is ceil(log2 n) rounds over all nodes:
 // (P, D) <- (P[P], D + D[P]).  Two (P, D) buffers of 16-bit entries in the row-plan arrays (HBM, free between two reads); the caller has
 // filled buffer 0: P = heaviest successor (the sink points to itself), D = 1 (sink: 0).
-template <int NT>
-__device__ __forceinline__ void remain_by_jumping(Ctx &g, const int n) {
+template <int NT, typename U16P /* unsigned short * in HBM or in LDS (address space 3) */>
+__device__ __forceinline__ void remain_by_jumping(Ctx &g, const int n, U16P b0, U16P b1) {
     const int tid = threadIdx.x;
-    unsigned short *buf[2] = {(unsigned short *)g.pl_start, (unsigned short *)g.pl_rem}; // each: P[n] | D[n]
+    U16P buf[2] = {b0, b1}; // each: P[n] | D[n]
     const int rounds = n > 2 ? 32 - __clz(n - 1) : 1;
     int src = 0;
     for (int r = 0; r < rounds; ++r) {
-        const unsigned short *Ps = buf[src], *Ds = Ps + n;
-        unsigned short *Pd = buf[src ^ 1], *Dd = Pd + n;
+        U16P Ps = buf[src], Ds = Ps + n;
+        U16P Pd = buf[src ^ 1], Dd = Pd + n;
         for (int v = tid; v < n; v += NT) { const int p = Ps[v]; Pd[v] = Ps[p]; Dd[v] = (unsigned short)(Ds[v] + Ds[p]); }
         __syncthreads();
         src ^= 1;
     }
-    const unsigned short *D = buf[src] + n;
+    U16P D = buf[src] + n;
     for (int v = tid; v < n; v += NT) g.remain[v] = (int)D[v] - 1;
 }
+typedef __attribute__((address_space(3))) unsigned short *lcd_lds_u16p;
+__device__ __forceinline__ lcd_lds_u16p lds_u16(const void *p) { return (lcd_lds_u16p)(uintptr_t)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)p; }
 
-template <int NT>
+template <int NT, bool INLDS>
 __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned short *deg, unsigned short *queue, unsigned *nw, unsigned *ew) {
     const int tid = threadIdx.x;
     const int n = g.n_node, E = g.n_edge;
@@ -482,15 +484,18 @@ __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned shor
     if (g.status == LCD_OK) {
         // heaviest successor of every node (first maximum in out-edge order; 1 = the sink when there is no out-edge), in parallel; it
         // replaces the ring pointer in the high half of the node's own word (nobody else reads that word in this loop)
-        unsigned short *P0 = (unsigned short *)g.pl_start, *D0 = P0 + n; // (the jump tables of the walk are dead now)
+        // (P, D) buffers of the pointer jumping: with the walk's arrays in LDS, buffer 0 takes the place of deg | queue (dead after this loop; thread v alone touches
+        // slot v) and buffer 1 that of the node words -- every round is then an LDS pass instead of a round trip to HBM; otherwise the row-plan arrays in HBM
+        unsigned short *P0 = INLDS ? deg : (unsigned short *)g.pl_start, *D0 = INLDS ? queue : P0 + n; // (the jump tables of the walk are dead now)
         for (int v = tid; v < n; v += NT) {
             int mw = -1, mid = 1;
             for (unsigned e = nw[v] & 0xffffu; e != 0;) { const unsigned w = ew[e - 1]; const int wt = g.e_w[e - 1]; if (wt > mw) { mw = wt; mid = (int)(w & 0xffffu); } e = w >> 16; }
-            P0[v] = (unsigned short)mid; D0[v] = (unsigned short)(v == 1 ? 0 : 1);
             g.idx2node[v] = queue[v];
+            P0[v] = (unsigned short)mid; D0[v] = (unsigned short)(v == 1 ? 0 : 1);
         }
         __syncthreads();
-        remain_by_jumping<NT>(g, n);
+        if (INLDS) remain_by_jumping<NT, lcd_lds_u16p>(g, n, lds_u16(deg), lds_u16(nw));
+        else remain_by_jumping<NT, unsigned short *>(g, n, (unsigned short *)g.pl_start, (unsigned short *)g.pl_rem);
     }
     __syncthreads();
 }
@@ -511,9 +516,9 @@ __device__ __attribute__((noinline)) void topo_sort_block(Ctx &g, Smem &sm, int 
     if ((size_t)8 * n + (size_t)4 * E + 64 <= (size_t)g.pool_words * 4) {
         unsigned short *deg = (unsigned short *)lds_pool, *queue = deg + n;
         unsigned *nw = (unsigned *)(queue + n + (n & 1)), *ew = nw + n; // (4-byte aligned: the pool is, and 2n + (n & 1) halfwords are even)
-        topo_sort_arrays<NT>(g, sm, deg, queue, nw, ew);
+        topo_sort_arrays<NT, true>(g, sm, deg, queue, nw, ew);
     } else
-        topo_sort_arrays<NT>(g, sm, (unsigned short *)g.deg, (unsigned short *)g.queue, (unsigned *)g.pl_bonus, (unsigned *)g.pl_pidx);
+        topo_sort_arrays<NT, false>(g, sm, (unsigned short *)g.deg, (unsigned short *)g.queue, (unsigned *)g.pl_bonus, (unsigned *)g.pl_pidx);
 }
 
 // The read changed edge weights only (no new node, no new edge): the topological order stands; `remain` follows the heaviest out-edge
@@ -534,14 +539,26 @@ __device__ __attribute__((noinline)) void topo_remain_block(Ctx &g, Smem &sm, in
         __syncthreads();
         return;
     }
-    unsigned short *P0 = (unsigned short *)g.pl_start, *D0 = P0 + n;
-    for (int v = tid; v < n; v += NT) {
-        int mw = -1, mid = 1;
-        for (int e = g.out_head[v]; e >= 0; e = g.e_next_out[e]) { const int wt = g.e_w[e]; if (wt > mw) { mw = wt; mid = g.e_to[e]; } }
-        P0[v] = (unsigned short)mid; D0[v] = (unsigned short)(v == 1 ? 0 : 1);
+    const bool inlds = (size_t)8 * n + 64 <= (size_t)g.pool_words * 4; // both (P, D) buffers in the workgroup's LDS pool (free between two reads)
+    if (inlds) {
+        const lcd_lds_u16p P0 = lds_u16(lds_pool), D0 = P0 + n;
+        for (int v = tid; v < n; v += NT) {
+            int mw = -1, mid = 1;
+            for (int e = g.out_head[v]; e >= 0; e = g.e_next_out[e]) { const int wt = g.e_w[e]; if (wt > mw) { mw = wt; mid = g.e_to[e]; } }
+            P0[v] = (unsigned short)mid; D0[v] = (unsigned short)(v == 1 ? 0 : 1);
+        }
+        __syncthreads();
+        remain_by_jumping<NT, lcd_lds_u16p>(g, n, P0, P0 + 2 * n);
+    } else {
+        unsigned short *P0 = (unsigned short *)g.pl_start, *D0 = P0 + n;
+        for (int v = tid; v < n; v += NT) {
+            int mw = -1, mid = 1;
+            for (int e = g.out_head[v]; e >= 0; e = g.e_next_out[e]) { const int wt = g.e_w[e]; if (wt > mw) { mw = wt; mid = g.e_to[e]; } }
+            P0[v] = (unsigned short)mid; D0[v] = (unsigned short)(v == 1 ? 0 : 1);
+        }
+        __syncthreads();
+        remain_by_jumping<NT, unsigned short *>(g, n, (unsigned short *)g.pl_start, (unsigned short *)g.pl_rem);
     }
-    __syncthreads();
-    remain_by_jumping<NT>(g, n);
     __syncthreads();
 }
 
@@ -825,28 +842,32 @@ __device__ __forceinline__ void code_backtrack(const Ctx &g, Smem &sm, const uns
         if (lane == 0) { sm.bc[0] = qlen - pos; sm.bc[1] = status; sm.bc[4] = pos; sm.bc[5] = best; }
     }
 
-struct WinOut { int status; unsigned long long t_dp, t_bt, cells; int cig_pos; unsigned long long t_plan, t_poll; int score; };
+struct WinOut { int status; unsigned long long t_dp, t_bt, cells; int cig_pos; unsigned long long t_plan, t_poll; int score; unsigned long long t_setup; };
 // (not inlined, context by value: the row loop then only carries the dozen pointers it uses instead of the chain's whole
 //  context -- inlined, hipcc spilled the scalar registers of ~45 pointers into VGPR lanes and re-read them every row)
 // C consecutive ints from / to LDS (byte offset) or HBM: one ds_read_b128 / b64 / b32 (global_load_dwordx4 / x2 / dword)
 typedef int lcd_v2i __attribute__((ext_vector_type(2)));
 template <int C> __device__ __forceinline__ void lds_ldc(const unsigned o, int (&v)[C]) {
-    if constexpr (C == 4) { const lcd_v4i t = *(const lcd_lds_v4i *)(uintptr_t)o; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    if constexpr (C == 8) { const lcd_v4i t = *(const lcd_lds_v4i *)(uintptr_t)o, u = *(const lcd_lds_v4i *)(uintptr_t)(o + 16); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; v[4] = u.x; v[5] = u.y; v[6] = u.z; v[7] = u.w; }
+    else if constexpr (C == 4) { const lcd_v4i t = *(const lcd_lds_v4i *)(uintptr_t)o; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
     else if constexpr (C == 2) { const lcd_v2i t = *(const __attribute__((address_space(3))) lcd_v2i *)(uintptr_t)o; v[0] = t.x; v[1] = t.y; }
     else v[0] = *(const lcd_lds_i32 *)(uintptr_t)o;
 }
 template <int C> __device__ __forceinline__ void lds_stc(const unsigned o, const int (&v)[C]) {
-    if constexpr (C == 4) { lcd_v4i t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; *(lcd_lds_v4i *)(uintptr_t)o = t; }
+    if constexpr (C == 8) { lcd_v4i t, u; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; u.x = v[4]; u.y = v[5]; u.z = v[6]; u.w = v[7]; *(lcd_lds_v4i *)(uintptr_t)o = t; *(lcd_lds_v4i *)(uintptr_t)(o + 16) = u; }
+    else if constexpr (C == 4) { lcd_v4i t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; *(lcd_lds_v4i *)(uintptr_t)o = t; }
     else if constexpr (C == 2) { lcd_v2i t; t.x = v[0]; t.y = v[1]; *(__attribute__((address_space(3))) lcd_v2i *)(uintptr_t)o = t; }
     else *(lcd_lds_i32 *)(uintptr_t)o = v[0];
 }
 template <int C> __device__ __forceinline__ void glb_ldc(const int *p, int (&v)[C]) {
-    if constexpr (C == 4) { const lcd_v4i t = *(const lcd_glb_v4i *)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    if constexpr (C == 8) { const lcd_v4i t = *(const lcd_glb_v4i *)p, u = *(const lcd_glb_v4i *)(p + 4); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; v[4] = u.x; v[5] = u.y; v[6] = u.z; v[7] = u.w; }
+    else if constexpr (C == 4) { const lcd_v4i t = *(const lcd_glb_v4i *)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
     else if constexpr (C == 2) { const lcd_v2i t = *(const __attribute__((address_space(1))) lcd_v2i *)p; v[0] = t.x; v[1] = t.y; }
     else v[0] = *(const lcd_glb_i32 *)p;
 }
 template <int C> __device__ __forceinline__ void glb_stc(int *p, const int (&v)[C]) {
-    if constexpr (C == 4) { lcd_v4i t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; *(lcd_glb_v4i *)p = t; }
+    if constexpr (C == 8) { lcd_v4i t, u; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; u.x = v[4]; u.y = v[5]; u.z = v[6]; u.w = v[7]; *(lcd_glb_v4i *)p = t; *(lcd_glb_v4i *)(p + 4) = u; }
+    else if constexpr (C == 4) { lcd_v4i t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; *(lcd_glb_v4i *)p = t; }
     else if constexpr (C == 2) { lcd_v2i t; t.x = v[0]; t.y = v[1]; *(__attribute__((address_space(1))) lcd_v2i *)p = t; }
     else *(lcd_glb_i32 *)p = v[0];
 }
@@ -1210,7 +1231,8 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
 //     row; rows a far successor or the end node reads (plan flag) store theirs at once.
 // MODE 1: the oracle's adaptive band; MODE 2: certified intervals from the table (align_certified).  C cells per lane, window 64 * C columns.
 // Returns the number of cigar entries, 0 with wo->status set, or -1 = not representable here (window too narrow / > 254 predecessors / read >= 65 536 bases).
-template <int C> struct LeanCells { int v[C]; };
+template <int C> struct LeanT { typedef unsigned word; };   // one byte per cell of a lane: direction codes, ordinals, query bases
+template <> struct LeanT<8> { typedef unsigned long long word; };
 __device__ __forceinline__ int lean_wlane(const int val, const int l, int old) { // old with lane l replaced by val (both wave-uniform; the lane select goes through M0)
     asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(__builtin_amdgcn_readfirstlane(val)), "s"(__builtin_amdgcn_readfirstlane(l)) : "m0");
     return old;
@@ -1223,8 +1245,11 @@ __device__ __forceinline__ int dpp_shl1(const int old, const int v) { return __b
 template <int MODE, int C>
 __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsigned ring_, const unsigned sq1_, const unsigned pd_ /* 0xffffffff: none */, const LcdScoring sc_, const int w_,
                                                     const int bi_, const int ei_, const int rem_beg_, const uint8_t *seq_hbm_, const int qlen_, WinOut *wo_) {
+    const long long t_in0 = clock64();
     constexpr int WIN = 64 * C, WM = WIN - 1, SLOTW = 3 * WIN, CM = ~(C - 1);
+    constexpr int CP = C > 4 ? C : 4; // a row's cells in HBM are padded to the lanes' cell groups (and to 4: rows stay dword-aligned for every C)
     constexpr bool BANDED = MODE == 1, FIXED = MODE == 2;
+    typedef typename LeanT<C>::word word;
     Smem &sm = g_smem;
     Ctx g = *usgpr(gp_);
     ctx_to_sgpr(g);
@@ -1249,7 +1274,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     }
     const int KM = K - 1;
     for (int j = lane; j < QB; j += 64) lds_st_u8(sq1 + j, (j >= 1 && j <= qlen) ? glb_ld_u8(seq_hbm + (j - 1)) : 4); // shifted: sq1[j] = q[j-1]
-    const int qclamp = QB - 4;
+    const int qclamp = QB - CP;
     const unsigned code_cap = (unsigned)(g.cell_cap > 0xfffffff0ull ? 0xfffffff0ull : g.cell_cap);
     const unsigned ord_cap = g.spill_x > 2 ? code_cap : (unsigned)((g.cell_cap / 4) > 0xfffffff0ull ? 0xfffffff0ull : (g.cell_cap / 4));
     const long long spill_rows_ll = g.cell_cap * g.spill_x > 64 ? (long long)((g.cell_cap * g.spill_x - 64) / ((unsigned long long)SLOTW * 4)) : 0;
@@ -1284,6 +1309,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     unsigned cused = 0, oused = 0; unsigned long long ncell = (unsigned long long)end0 + 1;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const long long t_dp0 = clock64();
+    wo->t_setup = (unsigned long long)(t_dp0 - t_in0);
     // plan window (lane = row - wbase) and the rows' metadata window
     int w_pk = 0, w_x = 0, w_pi0 = 0, w_pi1 = 0, w_p0 = 0; // w_x: remain (MODE 1) / interval (MODE 2)
     int r_be = 1, r_off = 0;
@@ -1314,15 +1340,14 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     // (one LDS load of exactly C bytes -- jq is a multiple of C -- so that a prefetched word needs no arithmetic before the row that uses it)
     auto q_of = [&](const int b) {
         const unsigned a = sq1 + (unsigned)imin(b + cl, qclamp);
-        if constexpr (C == 1) return (unsigned)*(const lcd_lds_u8 *)(uintptr_t)a;
-        else if constexpr (C == 2) return (unsigned)*(const __attribute__((address_space(3))) unsigned short *)(uintptr_t)a;
-        else return (unsigned)lds_ld(a);
+        if constexpr (C == 1) return (word)*(const lcd_lds_u8 *)(uintptr_t)a;
+        else if constexpr (C == 2) return (word)*(const __attribute__((address_space(3))) unsigned short *)(uintptr_t)a;
+        else if constexpr (C == 4) return (word)(unsigned)lds_ld(a);
+        else return *(const __attribute__((address_space(3))) unsigned long long *)(uintptr_t)a;
     };
-    unsigned q_cur = 0, q_nxt = 0; int q_ok = 0; // windows at pv_begc and pv_begc + C, valid while q_ok (the run loop keeps them; a general row drops them)
+    word q_cur = 0, q_nxt = 0; int q_ok = 0; // windows at pv_begc and pv_begc + C, valid while q_ok (the run loop keeps them; a general row drops them)
     // per-lane constants: (cl + k) * e and -(o + (cl + k) * e)
-    int ce1[C], ce2[C], nf1[C], nf2[C];
-#pragma unroll
-    for (int k = 0; k < C; ++k) { ce1[k] = (cl + k) * e1; ce2[k] = (cl + k) * e2; nf1[k] = -(o1 + ce1[k]); nf2[k] = -(o2 + ce2[k]); }
+    const int cle1 = cl * e1, cle2 = cl * e2, ncle1 = -cle1, ncle2 = -cle2; // (the cells' k * e and the window's begc * e are added on the scalar side)
     int idx = bi + 1;
     while (idx < ei) {
         if (idx - wbase == 64) { flush_meta(wbase, 64); wbase = idx; load_plan(wbase); }
@@ -1346,7 +1371,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                 } else { beg = xw & 65535; end = (int)((unsigned)xw >> 16); }
                 const int begc = beg & CM;
                 const int sh = begc - l_begc;
-                const int cw4 = ((end - begc) + 4) & ~3;
+                const int cw4 = ((end - begc) + CP) & ~(CP - 1);
                 if (beg > end || end - begc + 2 > WIN || (unsigned)sh > (unsigned)C || cused + (unsigned)cw4 > code_cap) break;
                 const int vb = (pk >> 8) & 7, bz0 = (pk >> 14) & 31;
                 const int s = (idx - bi) & KM;
@@ -1366,24 +1391,24 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                 int hp[C], spk[C], a1[C], a2[C], p1[C], p2[C], uu[C], vv[C]; bool inb[C];
 #pragma unroll
                 for (int k = 0; k < C; ++k) {
-                    const int q = (q_cur >> (8 * k)) & 255;
+                    const int q = (int)(q_cur >> (8 * k)) & 255;
                     const int sk = q >= 4 ? 0 : (q == vb ? mt : mm);
                     const int nn = imax(LCD_NEG, hd[k] + sk + bz0);
                     uu[k] = imax(LCD_NEG, av[k] + bz0); vv[k] = imax(LCD_NEG, bv[k] + bz0);
                     inb[k] = (unsigned)(cl + k - lo) <= (unsigned)span;
                     hp[k] = imax(nn, imax(uu[k], vv[k]));
                     spk[k] = nn == hp[k] ? 0 : uu[k] == hp[k] ? 1 : 2;
-                    a1[k] = inb[k] ? hp[k] + ce1[k] + be1 : LCD_GUARD; a2[k] = inb[k] ? hp[k] + ce2[k] + be2 : LCD_GUARD;
+                    a1[k] = inb[k] ? hp[k] + cle1 + (be1 + k * e1) : LCD_GUARD; a2[k] = inb[k] ? hp[k] + cle2 + (be2 + k * e2) : LCD_GUARD;
                     p1[k] = k ? imax(p1[k - 1], a1[k]) : a1[k]; p2[k] = k ? imax(p2[k - 1], a2[k]) : a2[k];
                 }
                 int t1 = p1[C - 1], t2 = p2[C - 1];
                 scan_max2(t1, t2);
                 const int x1 = shr1(LCD_GUARD, t1), x2 = shr1(LCD_GUARD, t2);
-                unsigned code = 0;
+                word code = 0;
 #pragma unroll
                 for (int k = 0; k < C; ++k) {
                     const int pf1 = k ? imax(x1, p1[k - 1]) : x1, pf2 = k ? imax(x2, p2[k - 1]) : x2;
-                    const int f1 = imax(LCD_NEG, pf1 + nf1[k] - be1), f2 = imax(LCD_NEG, pf2 + nf2[k] - be2);
+                    const int f1 = imax(LCD_NEG, pf1 + ncle1 - (o1 + be1 + k * e1)), f2 = imax(LCD_NEG, pf2 + ncle2 - (o2 + be2 + k * e2));
                     const int h = imax(hp[k], imax(f1, f2));
                     const int q1 = h - oe1, w1 = uu[k] - e1, q2 = h - oe2, w2 = vv[k] - e2;
                     const int eo1 = imax(imax(q1, w1), LCD_NEG), eo2 = imax(imax(q2, w2), LCD_NEG);
@@ -1391,7 +1416,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                     const int hs = hp[k] == h ? spk[k] : fk;
                     unsigned fl = 0; // O2, O1, Y2, Y1 pushed in this order = bits 6, 5, 4, 3 of the code
                     { const int r2 = a2[k], r1 = a1[k]; LCD_PUSH_GE(fl, q2, w2); LCD_PUSH_GE(fl, q1, w1); LCD_PUSH_GT(fl, pf2, r2); LCD_PUSH_GT(fl, pf1, r1); }
-                    code |= ((unsigned)hs | (fl << 3)) << (8 * k);
+                    code |= (word)((unsigned)hs | (fl << 3)) << (8 * k);
                     pvh[k] = inb[k] ? h : LCD_GUARD; pva[k] = inb[k] ? eo1 : LCD_GUARD; pvb[k] = inb[k] ? eo2 : LCD_GUARD;
                 }
                 int ml = 0, mr = 0;
@@ -1418,7 +1443,8 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                     lds_stc<C>(S + 4 * x, pvh); lds_stc<C>(S + 4 * (WIN + x), pva); lds_stc<C>(S + 4 * (2 * WIN + x), pvb);
                     if (cl < cw4) {
                         uint8_t *cp = g.code8 + (size_t)(cused + (unsigned)cl);
-                        if constexpr (C == 4) glb_st(cp, (int)code);
+                        if constexpr (C == 8) *(__attribute__((address_space(1))) unsigned long long *)cp = code;
+                        else if constexpr (C == 4) glb_st(cp, (int)code);
                         else if constexpr (C == 2) *(__attribute__((address_space(1))) unsigned short *)cp = (unsigned short)code;
                         else *(__attribute__((address_space(1))) uint8_t *)cp = (uint8_t)code;
                     }
@@ -1480,17 +1506,17 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
         const int begc = beg & CM;
         if (end - begc + 2 > WIN) return -1;
         const int jb = begc + cl;
-        const unsigned qw = q_of(begc);
+        const word qw = q_of(begc);
         bool inb[C]; int sk[C];
 #pragma unroll
         for (int k = 0; k < C; ++k) {
             inb[k] = jb + k >= beg && jb + k <= end;
-            const int q = (qw >> (8 * k)) & 255;
+            const int q = (int)(qw >> (8 * k)) & 255;
             sk[k] = (vb >= 4 || q >= 4) ? 0 : (vb == q ? s_match : s_mism);
         }
         // ---- phase A: best match / E1 / E2 input of the cells over the predecessors (first maximum keeps its ordinal) ----
         int nn[C], uu[C], vv[C];
-        int om = 0, oa = 0, ob = 0; // ordinals, one byte per cell
+        word om = 0, oa = 0, ob = 0; // ordinals, one byte per cell
         {
 #pragma unroll
             for (int k = 0; k < C; ++k) { nn[k] = LCD_NEG; uu[k] = LCD_NEG; vv[k] = LCD_NEG; }
@@ -1532,9 +1558,9 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                     const int c = (k == 0 ? hm : hv[k - 1]) + sk[k] + bz, a = av[k] + bz, b = bv[k] + bz;
                     if (t == 0) { nn[k] = imax(nn[k], c); uu[k] = imax(uu[k], a); vv[k] = imax(vv[k], b); }
                     else {
-                        if (c > nn[k]) { nn[k] = c; om = (om & ~(255 << (8 * k))) | (tt << (8 * k)); }
-                        if (a > uu[k]) { uu[k] = a; oa = (oa & ~(255 << (8 * k))) | (tt << (8 * k)); }
-                        if (b > vv[k]) { vv[k] = b; ob = (ob & ~(255 << (8 * k))) | (tt << (8 * k)); }
+                        if (c > nn[k]) { nn[k] = c; om = (om & ~((word)255 << (8 * k))) | ((word)tt << (8 * k)); }
+                        if (a > uu[k]) { uu[k] = a; oa = (oa & ~((word)255 << (8 * k))) | ((word)tt << (8 * k)); }
+                        if (b > vv[k]) { vv[k] = b; ob = (ob & ~((word)255 << (8 * k))) | ((word)tt << (8 * k)); }
                     }
                 }
             }
@@ -1546,18 +1572,18 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
         for (int k = 0; k < C; ++k) {
             hp[k] = imax(nn[k], imax(uu[k], vv[k]));                     // Hpre
             spk[k] = nn[k] == hp[k] ? 0 : uu[k] == hp[k] ? 1 : 2;        // which of match / E1 / E2 gives it (the oracle's priority)
-            a1[k] = inb[k] ? hp[k] + je1 + ce1[k] : LCD_GUARD; a2[k] = inb[k] ? hp[k] + je2 + ce2[k] : LCD_GUARD;
+            a1[k] = inb[k] ? hp[k] + cle1 + (je1 + k * e1) : LCD_GUARD; a2[k] = inb[k] ? hp[k] + cle2 + (je2 + k * e2) : LCD_GUARD;
             p1[k] = k ? imax(p1[k - 1], a1[k]) : a1[k]; p2[k] = k ? imax(p2[k - 1], a2[k]) : a2[k];
         }
         int t1 = p1[C - 1], t2 = p2[C - 1];
         scan_max2(t1, t2);
         const int x1 = shr1(LCD_GUARD, t1), x2 = shr1(LCD_GUARD, t2); // exclusive prefix over the lanes
         // ---- phase B: F, H, E-out, direction code of the cells ----
-        unsigned code = 0;
+        word code = 0;
 #pragma unroll
         for (int k = 0; k < C; ++k) {
             const int pf1 = k ? imax(x1, p1[k - 1]) : x1, pf2 = k ? imax(x2, p2[k - 1]) : x2;
-            const int f1 = imax(LCD_NEG, pf1 + nf1[k] - je1), f2 = imax(LCD_NEG, pf2 + nf2[k] - je2);
+            const int f1 = imax(LCD_NEG, pf1 + ncle1 - (o1 + je1 + k * e1)), f2 = imax(LCD_NEG, pf2 + ncle2 - (o2 + je2 + k * e2));
             const int h = imax(hp[k], imax(f1, f2));
             const int eo1 = imax(imax(h - oe1, uu[k] - e1), LCD_NEG), eo2 = imax(imax(h - oe2, vv[k] - e2), LCD_NEG);
             const int fk = f1 == h ? (f2 == h ? 5 : 3) : 4;
@@ -1566,7 +1592,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
             { const int q2 = h - oe2, w2 = vv[k] - e2, q1 = h - oe1, w1 = uu[k] - e1, r2 = a2[k], r1 = a1[k];
               LCD_PUSH_GE(fl, q2, w2); LCD_PUSH_GE(fl, q1, w1); LCD_PUSH_GT(fl, pf2, r2); LCD_PUSH_GT(fl, pf1, r1); }
             const unsigned cd = (unsigned)hs | (fl << 3) | (((om >> (8 * k)) & 255) ? CB_PM : 0);
-            code |= cd << (8 * k);
+            code |= (word)cd << (8 * k);
             pvh[k] = inb[k] ? h : LCD_GUARD; pva[k] = inb[k] ? eo1 : LCD_GUARD; pvb[k] = inb[k] ? eo2 : LCD_GUARD;
         }
         // ---- row maximum, leftmost / rightmost column (adaptive band only) ----
@@ -1587,7 +1613,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
             else { ml = begc + C * fl + LCD_RL(bl, fl); mr = begc + C * ll + LCD_RL(brr, ll); }
         }
         // ---- stores: ring slot (values), HBM (codes; values only for rows a far successor / the end node will read) ----
-        const int cw4 = ((end - begc) + 4) & ~3; // cells of this row in HBM, padded to a multiple of 4 (rows stay dword-aligned for every C)
+        const int cw4 = ((end - begc) + CP) & ~(CP - 1); // cells of this row in HBM, padded to a multiple of 4 (rows stay dword-aligned for every C)
         if (cused + (unsigned)cw4 > code_cap || (np > 1 && oused + (unsigned)cw4 > ord_cap) || (spf && nsp >= spill_rows)) { wo->status = LCD_ERR_CELLS; return 0; }
         {
             const int x = jb & WM;
@@ -1596,13 +1622,14 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
             if (spf) { int *G = g.spill + (size_t)nsp * SLOTW; glb_stc<C>(G + x, pvh); glb_stc<C>(G + WIN + x, pva); glb_stc<C>(G + 2 * WIN + x, pvb); }
             if (cl < cw4) {
                 uint8_t *cp = g.code8 + (size_t)(cused + (unsigned)cl);
-                if constexpr (C == 4) glb_st(cp, (int)code);
+                if constexpr (C == 8) *(__attribute__((address_space(1))) unsigned long long *)cp = code;
+                else if constexpr (C == 4) glb_st(cp, (int)code);
                 else if constexpr (C == 2) *(__attribute__((address_space(1))) unsigned short *)cp = (unsigned short)code;
                 else *(__attribute__((address_space(1))) uint8_t *)cp = (uint8_t)code;
                 if (np > 1) {
                     int ow[C];
 #pragma unroll
-                    for (int k = 0; k < C; ++k) ow[k] = ((om >> (8 * k)) & 255) | (((oa >> (8 * k)) & 255) << 8) | (((ob >> (8 * k)) & 255) << 16);
+                    for (int k = 0; k < C; ++k) ow[k] = (int)((om >> (8 * k)) & 255) | ((int)((oa >> (8 * k)) & 255) << 8) | ((int)((ob >> (8 * k)) & 255) << 16);
                     glb_stc<C>(g.ord + (size_t)(oused + (unsigned)cl), ow);
                 }
             }
@@ -2180,14 +2207,14 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
     Smem &sm = g_smem;
     Ctx &g = *gp; // (the caller's context itself: the few fields this function changes are changed in place)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0; wo.t_plan = wo.t_poll = 0; wo.score = LCD_NEG;
+    WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0; wo.t_plan = wo.t_poll = 0; wo.score = LCD_NEG; wo.t_setup = 0;
     int nc = -1;
     auto leave = [&](const int r) { return r; };
             // 64-thread class: the workgroup IS that wavefront.  256-thread class (long chains: the critical path of a submission): wavefront 0 runs the same
             // rows while the others wait; the per-read phases around them (graph update, re-sort, plan), a third to a half of such a chain in a 64-thread
             // workgroup, run on all four wavefronts
-            constexpr int WINC = 256;
             constexpr bool SOLO = NT > 64;
+            constexpr int WINC = 504; // the widest window the rows below hold (8 cells per lane, intervals start on a multiple of 8: hull widths are counted from a multiple of 4)
             if (qlen >= 65536 || ei - bi < 2) { g.status = LCD_ERR_CERT; return leave(0); }
             const long long tca0 = clock64();
             if (wave == 0) cert_node_arrays(&g, bi, ei);   // (wavefront 0; the others only meet the barriers)
@@ -2241,15 +2268,10 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                 // one, two or four cells per lane by the widest interval (hull widths are computed for 4-cell groups: the narrower variants keep a margin)
                 nc = -1;
                 if (!SOLO || wave == 0) {
-                    if constexpr (!SOLO) {
-                        if (mw <= 60) nc = align_lean<2, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
-                        if (nc < 0 && mw <= 124) { win_sync<SOLO>(); nc = align_lean<2, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
-                        if (nc < 0) { win_sync<SOLO>(); nc = align_lean<2, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
-                    } else {
-                    if (mw <= 60) nc = align_windowed<64, 2, 1, SOLO>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
-                    if (nc < 0 && mw <= 124) { win_sync<SOLO>(); nc = align_windowed<64, 2, 2, SOLO>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
-                    if (nc < 0) { win_sync<SOLO>(); nc = align_windowed<64, 2, 4, SOLO>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
-                    }
+                    if (mw <= 60) nc = align_lean<2, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+                    if (nc < 0 && mw <= 124) { win_sync<SOLO>(); nc = align_lean<2, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                    if (nc < 0 && mw <= 256) { win_sync<SOLO>(); nc = align_lean<2, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                    if (nc < 0) { win_sync<SOLO>(); nc = align_lean<2, 8>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); } // (512 columns: a region whose reads differ by an SV-size indel)
                     if (SOLO && lane == 0) { g_wide.ppi[0] = nc; g_wide.ppi[1] = wo.status; g_wide.ppi[2] = wo.score; g_wide.ppi[3] = wo.cig_pos; g_wide.po[0] = (unsigned)wo.cells; g_wide.po[1] = (unsigned)(wo.cells >> 32); }
                 }
                 if (SOLO) { // the result of wavefront 0 to everybody
@@ -2259,7 +2281,7 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                 }
                 if (nc < 0) return leave(to_generic((ubtop - sest) + (ubtop - sest) / 2 + 48)); // (the window's alias checks: rare)
                 if (wo.status != LCD_OK) { g.status = wo.status; return leave(0); }
-                g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells;
+                g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells; g.t_setup += wo.t_setup; wo.t_setup = 0;
                 const int S = wo.score;
                 if (S > LCD_NEG / 2) {
                     sbest = imax(sbest, S);
@@ -2385,9 +2407,11 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
     const int QB = (qlen + 12 + 15) & ~15;
     if (QB > g.seq_cap) { g.status = LCD_ERR_LDS; return 0; } // read slice longer than the LDS query cache (host sizes the class)
     uint8_t *pd = (QB + (ei - bi) + 16 <= g.seq_cap) ? sseq + QB : nullptr;
-    build_plan<NT>(g, sm, bi, ei, remain_end, pd, NT == 64 ? g.plan_k : K); // (rows to spill: those with a successor further away than the windowed rows' ring -- the smallest ring a window of this chain may run with)
+    { const long long tb0 = clock64();
+    build_plan<NT>(g, sm, bi, ei, remain_end, pd, (NT == 64 || g.solo) ? g.plan_k : K);
+    g.t_bp += (unsigned long long)(clock64() - tb0); } // (rows to spill: those with a successor further away than the windowed rows' ring -- the smallest ring a window of this chain may run with)
     if (!(sc.dbg & 8)) {
-        WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0; wo.t_plan = wo.t_poll = 0;
+        WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0; wo.t_plan = wo.t_poll = 0; wo.t_setup = 0;
         const int rem_beg = g.remain[beg_node] - remain_end;
         const unsigned pdo = pd ? lds_off(pd) : 0xffffffffu, ro = lds_off(ring), so = lds_off(sseq);
         int nc = -1;
@@ -2407,10 +2431,23 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
                 if (g.wmax <= 64) nc = align_lean<1, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
                 if (nc < 0 && g.wmax <= 128) { __syncthreads(); nc = align_lean<1, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
                 if (nc < 0) { __syncthreads(); nc = align_lean<1, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+            } else if (NT == 256 && g.solo) { // a long K1 chain in a 256-thread workgroup: wavefront 0 runs the lean rows, the others wait for its result
+                if (wave == 0) {
+                    if (g.wmax <= 64) nc = align_lean<1, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+                    if (nc < 0 && g.wmax <= 128) { win_sync<true>(); nc = align_lean<1, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                    if (nc < 0 && g.wmax <= 256) { win_sync<true>(); nc = align_lean<1, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                    if (nc < 0) { win_sync<true>(); nc = align_lean<1, 8>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                    if (lane == 0) { g_wide.ppi[0] = nc; g_wide.ppi[1] = wo.status; g_wide.ppi[2] = wo.score; g_wide.ppi[3] = wo.cig_pos; g_wide.po[0] = (unsigned)wo.cells; g_wide.po[1] = (unsigned)(wo.cells >> 32);
+                                     g_wide.po[2] = (unsigned)wo.t_dp; g_wide.po[3] = (unsigned)(wo.t_dp >> 32); g_wide.po[4] = (unsigned)wo.t_bt; g_wide.po[5] = (unsigned)(wo.t_bt >> 32); }
+                }
+                __syncthreads();
+                nc = g_wide.ppi[0]; wo.status = g_wide.ppi[1]; wo.score = g_wide.ppi[2]; wo.cig_pos = g_wide.ppi[3]; wo.cells = g_wide.po[0] | ((unsigned long long)g_wide.po[1] << 32);
+                wo.t_dp = g_wide.po[2] | ((unsigned long long)g_wide.po[3] << 32); wo.t_bt = g_wide.po[4] | ((unsigned long long)g_wide.po[5] << 32); wo.t_setup = 0;
+                __syncthreads();
             } else nc = align_windowed<NT, 1, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
         }
         if (nc >= 0) {
-            g.status = wo.status; g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells; g.t_plan += wo.t_plan; g.t_poll += wo.t_poll;
+            g.status = wo.status; g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells; g.t_plan += wo.t_plan; g.t_poll += wo.t_poll; g.t_setup += wo.t_setup;
             g.cig_node = g.cig_node0 + wo.cig_pos; g.cig_qpos = g.cig_qpos0 + wo.cig_pos;
             return nc;
         }
@@ -2423,7 +2460,7 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
     // ring slots of the generic rows: RW columns each -- the class's widest window, or what the host laid the pool out for in the single-wavefront class
     // (64 / 128 columns for banded chains, 384 for certified-band chains: their few reads that come here have intervals of 260 - 380 columns, and a row that
     // fits its slot needs neither the HBM round trip nor the store drain of a row that does not)
-    const int RW = NT == 64 ? g.wmax : WMAX;
+    const int RW = (NT == 64 || g.solo) ? g.wmax : WMAX;
     const bool ring_ok = RW >= 64;
     for (int i = tid; i < qlen; i += NT) sseq[i] = seq_hbm[i];
     __syncthreads();
@@ -2909,8 +2946,8 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     const PoaChain ch = chains[cid];
     // ring slots hold PoaChain.wmax columns: the class's widest window (4 * NT), or -- single-wavefront banded chains -- the narrower
     // window the host expects the band to fit (64 / 128 columns: LDS per chain is what limits how many of them share a CU)
-    const int ring_cols = NT == 64 ? ch.wmax : 4 * NT;
-    const int ring_k = NT == 64 && ch.ring_k > 2 ? ch.ring_k : Cfg<NT>::K;
+    const int ring_cols = (NT == 64 || ch.solo) ? ch.wmax : 4 * NT;
+    const int ring_k = (NT == 64 || ch.solo) && ch.ring_k > 2 ? ch.ring_k : Cfg<NT>::K;
     uint8_t *sseq = (uint8_t *)(lds_pool + ring_k * 3 * ring_cols);
     const PoaLayout L = poa_layout(ch.node_cap, ch.edge_cap, ch.rid_words, ch.max_len, ch.cell_cap, ch.n_reads, ch.spill_x, ch.cert);
     uint8_t *ws = arena + ch.ws_off;
@@ -2968,11 +3005,11 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
     g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0; g.cert_generic = 0; g.cert_generic_seen = 0; g.cert_sest = 0; g.cert_ubtop = 0; g.cert_cells0 = 0;
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
-    g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - ring_k * 3 * ring_cols) * 4; g.ring_k = ring_k; g.plan_k = NT == 64 && ring_k > 2 && ch.wmax < 256 ? 2 : ring_k; // (slots beyond 2 of a chain laid out for a narrow window: not there when a read needs a wider one)
-    g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0;
+    g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - ring_k * 3 * ring_cols) * 4; g.ring_k = ring_k; g.plan_k = (NT == 64 || ch.solo) && ring_k > 2 && ch.wmax < 256 ? 2 : ring_k; // (slots beyond 2 of a chain laid out for a narrow window: not there when a read needs a wider one)
+    g.solo = NT == 256 ? ch.solo : 0; g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0; g.t_bp = 0; g.t_setup = 0;
     const long long t_begin = clock64();
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
-    unsigned long long t_graph = 0, t_sub = 0;
+    unsigned long long t_graph = 0, t_sub = 0, t_add = 0;
     if (tid == 0)
         for (int i = 0; i < 2; ++i) {
             g.base[i] = 4; g.out_head[i] = g.out_tail[i] = g.in_head[i] = g.in_tail[i] = -1; g.nin[i] = 0; g.aligned[i] = i;
@@ -3015,6 +3052,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
         const long long tg0 = clock64();
         int changed = 0;
         if (len > 0 && g.status == LCD_OK) changed = add_alignment_block<NT>(g, sm, exc_beg, exc_end, seq, len, n_cig, i);
+        t_add += (unsigned long long)(clock64() - tg0);
         if (changed == 2 && g.status == LCD_OK) topo_sort_block<NT>(g, sm, lds_pool);
         else if (changed == 1 && g.status == LCD_OK) topo_remain_block<NT>(g, sm, lds_pool);
         t_graph += (unsigned long long)(clock64() - tg0);
@@ -3031,6 +3069,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
         out.hw_id = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); out.xcc_id = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
         out.rt_begin = rt_begin; out.rt_end = __builtin_amdgcn_s_memrealtime();
         out.t_out = (unsigned long long)(t_end - t_out0);
+        out.t_bp = g.t_bp; out.t_add = t_add; out.t_sort = t_graph - t_add; out.t_setup = g.t_setup;
         outs[cid] = out;
     }
     if (my_slot >= 0) { // every store of this workgroup into the slot has completed (barrier = vmcnt(0) per wavefront) before the next owner may start
