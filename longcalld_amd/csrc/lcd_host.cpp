@@ -163,6 +163,7 @@ struct ChainRec {
     std::vector<int> members;     // indices into the region's sorted read list
     int read0;                    // first PoaRead
     int cert_fail_round = -1;     // K2: the last round in which the certified band did not fit its class's window (the chain then moves one class up)
+    int solo = -1;                // -1: by the fixed threshold (LCD_SOLO_RL); 0 / 1: decided for the submission at hand (run_many_once: the longest chains of what is in flight)
     int cert_level = -1;          // -1: not chosen yet; 1: certified band in the 64-thread class; 2: in the 256-thread class, rows on wavefront 0 (long chains); 0: full rows
 };
 struct AnchorRec {
@@ -711,7 +712,7 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     // chains by read length (test switch)
     {
         static const long long solo_rl = getenv("LCD_SOLO_RL") ? atoll(getenv("LCD_SOLO_RL")) : 100000;
-        pc.solo = ((solo_rl > 0 && (long long)n * maxl >= solo_rl) || (solo_len > 0 && pc.cert && maxl >= solo_len)) ? 1 : 0;
+        pc.solo = (C.solo >= 0 ? C.solo > 0 : (solo_rl > 0 && (long long)n * maxl >= solo_rl)) || (solo_len > 0 && pc.cert && maxl >= solo_len) ? 1 : 0;
     }
     // graph capacity: the worst case is one node per base of every read (sum), the usual case a little more than the longest read.  Sized
     // from an estimate (a few per cent of new nodes per read on top of the backbone; g_node_hint learns noisier data); a chain that runs
@@ -1060,6 +1061,24 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     for (int k = 0; k < nb; ++k) for (size_t g = chain_base[k]; g < chain_base[k + 1]; ++g) chain_batch[g] = k;
     std::vector<std::vector<uint64_t>> out_rel(nb);
     std::vector<uint64_t> out_tots(nb, 0);
+    // Which chains are LONG (256-thread workgroup: rows on wavefront 0, per-read phases on four) is decided for the submission at hand: at most LCD_SOLO_N
+    // (default: one per two CUs) of the longest chains in flight, and none below LCD_SOLO_MIN read-bases.  A lone batch leaves most of the chip idle and its
+    // longest chain IS its latency, so there the cut is low; twenty batches keep the wide workgroups for their top hundred.  LCD_SOLO_RL fixes the cut instead.
+    if (!getenv("LCD_SOLO_RL")) {
+        static const long long solo_min = getenv("LCD_SOLO_MIN") ? atoll(getenv("LCD_SOLO_MIN")) : 20000;
+        static const int solo_n_env = getenv("LCD_SOLO_N") ? atoi(getenv("LCD_SOLO_N")) : -1;
+        const size_t solo_n = (size_t)(solo_n_env >= 0 ? solo_n_env : std::max(1, g_n_cus / 2));
+        std::vector<long long> rls;
+        for (int k = 0; k < nb; ++k) for (ChainRec &C : bs[k]->chains) {
+            int maxl = 0; for (size_t q = 0; q < C.members.size(); ++q) maxl = std::max(maxl, preads[k][C.read0 + q].len);
+            rls.push_back((long long)C.members.size() * maxl);
+        }
+        long long cut = solo_min;
+        if (solo_n == 0) cut = 1ll << 62;
+        else if (rls.size() > solo_n) { std::vector<long long> t = rls; std::nth_element(t.begin(), t.begin() + (solo_n - 1), t.end(), std::greater<long long>()); cut = std::max(cut, t[solo_n - 1]); }
+        size_t q = 0;
+        for (int k = 0; k < nb; ++k) for (ChainRec &C : bs[k]->chains) C.solo = rls[q++] >= cut ? 1 : 0;
+    }
     auto size_chains = [&](const int k) { // capacities, class and output offsets of a batch's chains (independent of the other batches: host threads)
         lcd_batch_t *b = bs[k];
         const int nC = (int)b->chains.size();

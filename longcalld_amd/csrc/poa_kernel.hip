@@ -263,7 +263,8 @@ __device__ int block_excl_scan(int v, Smem &sm, int *total) { // exclusive prefi
     return woff + incl - v;
 }
 
-// returns 0: nothing changed, 1: only edge weights / read sets changed (the topological order stands, `remain` may not), 2: nodes or edges were added
+// returns 0: nothing changed, 1: only edge weights / read sets changed and some node's heaviest out-edge is another one now (the topological order stands, `remain`
+// does not), 3: only weights / read sets changed and every heaviest out-edge is the same (order and `remain` stand), 2: nodes or edges were added
 template <int NT>
 __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, int beg_node, int end_node, const uint8_t *seq, int len, int n_cig, int read_id) {
     const int tid = threadIdx.x;
@@ -319,6 +320,7 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
     }
     // phase 3: edges j = 0..n_cig (from path[j-1] to path[j]); existing ones gain weight + read id, the others are numbered
     carry = 0;
+    int heavy_moved = 0;
     for (int base = 0; base <= n_cig; base += NT) {
         const int j = base + tid;
         int need = 0;
@@ -326,9 +328,21 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
             const int from = j == 0 ? beg_node : g.aa_node[j - 1], to = j == n_cig ? end_node : g.aa_node[j];
             const bool from_new = j > 0 && g.aa_flag[j - 1] != -2, to_new = j < n_cig && g.aa_flag[j] != -2;
             need = 1;
-            if (!from_new && !to_new)
-                for (int e = g.out_head[from]; e >= 0; e = g.e_next_out[e])
-                    if (g.e_to[e] == to) { g.e_w[e] += 1; g.rid[(size_t)e * g.rid_words + rw] |= rbit; need = 0; break; }
+            if (!from_new && !to_new) {
+                // the edge exists: one more read on it.  `remain` follows every node's HEAVIEST out-edge (first maximum in list order): it only has to be
+                // recomputed if this increment changes which edge that is -- reads on the majority path never do
+                int found = -1, pos_found = 0, amax = -1, pos_amax = 0, wmax = -1, pos = 0;
+                for (int e = g.out_head[from]; e >= 0; e = g.e_next_out[e], ++pos) {
+                    const int wt = g.e_w[e];
+                    if (wt > wmax) { wmax = wt; amax = e; pos_amax = pos; }
+                    if (found < 0 && g.e_to[e] == to) { found = e; pos_found = pos; }
+                }
+                if (found >= 0) {
+                    const int wn = g.e_w[found] + 1;
+                    g.e_w[found] = wn; g.rid[(size_t)found * g.rid_words + rw] |= rbit; need = 0;
+                    if (found != amax && (wn > wmax || (wn == wmax && pos_found < pos_amax))) heavy_moved = 1;
+                }
+            }
         }
         int tot;
         const int rank = block_excl_scan<NT>(need, sm, &tot);
@@ -353,8 +367,8 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
         g.in_tail[to] = e; g.nin[to] += 1;
     }
     g.n_node += n_new; g.n_edge += n_newe;
-    __syncthreads();
-    return (n_new || n_newe) ? 2 : 1;
+    const int moved = __syncthreads_or(heavy_moved);
+    return (n_new || n_newe) ? 2 : moved ? 1 : 3;
 }
 
 // Kahn BFS order + remain for the whole workgroup: the pointer-chasing part still runs on one lane (the FIFO order is
@@ -783,7 +797,21 @@ __device__ __forceinline__ void code_backtrack(const Ctx &g, Smem &sm, const uns
                 if (st == 0 && pd != 0xffffffffu) {
                     // speculate a run of matches along first predecessors: lane t looks at the cell t steps up the diagonal
                     int my_i = -1, my_nx = -1;
+                    // the usual stretch is the backbone: every row's first predecessor is the row before it, so lane t's row is i - t and ONE parallel look at the
+                    // distances replaces the lane-serial walk through them (64 dependent LDS reads per 64 cells -- most of a clean read's backtrack)
+                    int nbb = 0;
                     {
+                        const int ci = i - lane;
+                        const bool okl = lane < sw && ci > bi && j - lane > 0;
+                        const int d = okl ? lds_ld_u8(pd + (ci - bi)) : 255;
+                        const unsigned long long one = __ballot(okl && d == 1);
+                        nbb = one == ~0ull ? 64 : (int)__builtin_ctzll(~one); // lanes 0 .. nbb - 1 step along the backbone
+                        if (nbb >= 16 || nbb >= sw) {
+                            if (lane < nbb) { my_i = ci; my_nx = ci - 1; }
+                            else if (lane == nbb && okl) { my_i = ci; my_nx = d != 255 ? ci - d : -1; }
+                        } else nbb = -1;
+                    }
+                    if (nbb < 0) {
                         int cur = i; bool alive = true;
                         for (int t = 0; t < sw; ++t) {
                             const bool ok = alive && cur != bi && j - t > 0;
@@ -2272,11 +2300,13 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                     if (nc < 0 && mw <= 124) { win_sync<SOLO>(); nc = align_lean<2, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
                     if (nc < 0 && mw <= 256) { win_sync<SOLO>(); nc = align_lean<2, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
                     if (nc < 0) { win_sync<SOLO>(); nc = align_lean<2, 8>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); } // (512 columns: a region whose reads differ by an SV-size indel)
-                    if (SOLO && lane == 0) { g_wide.ppi[0] = nc; g_wide.ppi[1] = wo.status; g_wide.ppi[2] = wo.score; g_wide.ppi[3] = wo.cig_pos; g_wide.po[0] = (unsigned)wo.cells; g_wide.po[1] = (unsigned)(wo.cells >> 32); }
+                    if (SOLO && lane == 0) { g_wide.ppi[0] = nc; g_wide.ppi[1] = wo.status; g_wide.ppi[2] = wo.score; g_wide.ppi[3] = wo.cig_pos; g_wide.po[0] = (unsigned)wo.cells; g_wide.po[1] = (unsigned)(wo.cells >> 32);
+                                             g_wide.po[2] = (unsigned)wo.t_dp; g_wide.po[3] = (unsigned)(wo.t_dp >> 32); g_wide.po[4] = (unsigned)wo.t_bt; g_wide.po[5] = (unsigned)(wo.t_bt >> 32); }
                 }
                 if (SOLO) { // the result of wavefront 0 to everybody
                     __syncthreads();
-                    nc = g_wide.ppi[0]; wo.status = g_wide.ppi[1]; wo.score = g_wide.ppi[2]; wo.cig_pos = g_wide.ppi[3]; wo.cells = g_wide.po[0] | ((unsigned long long)g_wide.po[1] << 32); wo.t_dp = wo.t_bt = 0;
+                    nc = g_wide.ppi[0]; wo.status = g_wide.ppi[1]; wo.score = g_wide.ppi[2]; wo.cig_pos = g_wide.ppi[3]; wo.cells = g_wide.po[0] | ((unsigned long long)g_wide.po[1] << 32);
+                    wo.t_dp = g_wide.po[2] | ((unsigned long long)g_wide.po[3] << 32); wo.t_bt = g_wide.po[4] | ((unsigned long long)g_wide.po[5] << 32); wo.t_setup = 0;
                     __syncthreads();
                 }
                 if (nc < 0) return leave(to_generic((ubtop - sest) + (ubtop - sest) / 2 + 48)); // (the window's alias checks: rare)
