@@ -221,6 +221,7 @@ struct lcd_batch_s {
     std::vector<StrJob> str_jobs; std::vector<StrOut> str_outs;
     std::vector<int> str_region, str_clu, str_k;
     std::vector<uint8_t> h_final; std::vector<uint8_t> h_poa_out; std::vector<uint8_t> h_cig;
+    std::vector<WfaJob> h_rc_all; std::vector<StrJob> h_str_all; std::vector<StrOut> h_str_outs; // leader: the joint job tables of a submission (kept between submissions: no reallocation, no first-touch page faults in the steady state)
     // ref<->read strings (opt.collect_ref_read_aln_str): per string job, rows in d_rr at rr_off (target row, query row at +rr_stride)
     std::vector<uint64_t> rr_off; std::vector<int> rr_len, rr_stride; std::vector<uint8_t> h_rr; uint64_t rr_bytes = 0;
     // candidate variants (opt.collect_noisy_vars): per resolved region, offsets into d_var_out / h_var
@@ -1053,6 +1054,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         }
     }
     HIPCHK(hipEventRecord(L->ev[1], st));
+    const double tp0 = now_ms();
     // ---------------- S2: POA chains ----------------
     std::vector<size_t> chain_base(nb + 1, 0), pread_base(nb + 1, 0);
     for (int k = 0; k < nb; ++k) { chain_base[k + 1] = chain_base[k] + bs[k]->chains.size(); pread_base[k + 1] = pread_base[k] + preads[k].size(); }
@@ -1272,6 +1274,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                     d_spare = (PoaSpare *)L->d_spare.p;
                 }
             }
+            if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host] POA stage: %.1f ms of host work before the launches of round %d\n", now_ms() - tp0, round);
             HIPCHK(hipEventRecord(L->ev[6], st));
             { int rc2 = launch_poa_grouped(st, sub, L->d_chains, (const PoaRead *)L->d_preads.p, L->d_poa_outs, sc, L->side, L->sev, &L->d_gate, d_spare); if (rc2) return rc2; }
             HIPCHK(hipEventRecord(L->ev[7], st));
@@ -1322,9 +1325,11 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         }
         if (!which.empty()) return set_err(-21, "POA DP arena exhausted after retries");
     }
+    if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host] POA stage ends %.1f ms after its start\n", now_ms() - tp0);
     HIPCHK(hipEventRecord(L->ev[2], st));
+    const double th0 = now_ms();
     // ---------------- S3: ref<->cons WFA, S4: MSA rows -> strings ----------------
-    std::vector<WfaJob> rc_all; std::vector<StrJob> str_all;
+    std::vector<WfaJob> &rc_all = L->h_rc_all; std::vector<StrJob> &str_all = L->h_str_all;
     std::vector<size_t> rc_base(nb + 1, 0), str_base(nb + 1, 0);
     // the job tables of the batches are independent: built on a few host threads (37 000 string jobs per configs[1] batch; serial, this was 30 ms of a 20-batch
     // submission), concatenated and given their device blocks afterwards
@@ -1381,16 +1386,36 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             for (auto &t : ths) t.join();
         }
     }
+    if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host]   per-batch tables built: %.1f ms\n", now_ms() - th0);
     for (int k = 0; k < nb; ++k) {
         lcd_batch_t *b = bs[k]; const uint64_t str_tot = str_tots[k];
         if (!b->str_jobs.empty() && b->d_final.ensure(str_tot)) return -11;
-        for (auto &j : b->str_jobs) j.out_off += b->d_final.addr();
         b->final_bytes = str_tot;
-        rc_base[k] = rc_all.size(); str_base[k] = str_all.size();
-        rc_all.insert(rc_all.end(), b->rc_jobs.begin(), b->rc_jobs.end());
-        str_all.insert(str_all.end(), b->str_jobs.begin(), b->str_jobs.end());
+        rc_base[k + 1] = rc_base[k] + b->rc_jobs.size(); str_base[k + 1] = str_base[k] + b->str_jobs.size();
     }
-    rc_base[nb] = rc_all.size(); str_base[nb] = str_all.size();
+    // (the joint tables: sized once, filled by the same host threads -- 670 000 string jobs per 20 batches; appended serially into fresh vectors this was 15 - 25 ms
+    //  of a 300 ms submission with the GPU idle)
+    if (rc_all.capacity() < rc_base[nb]) rc_all.reserve(rc_base[nb] + rc_base[nb] / 4 + 64); // (headroom: the next submission's tables are a few per cent larger or smaller)
+    if (str_all.capacity() < str_base[nb]) str_all.reserve(str_base[nb] + str_base[nb] / 4 + 64);
+    rc_all.resize(rc_base[nb]); str_all.resize(str_base[nb]);
+    {
+        auto fill = [&](const int k) {
+            lcd_batch_t *b = bs[k];
+            const uint64_t fin = b->d_final.addr();
+            for (auto &j : b->str_jobs) j.out_off += fin;
+            if (!b->rc_jobs.empty()) memcpy(rc_all.data() + rc_base[k], b->rc_jobs.data(), b->rc_jobs.size() * sizeof(WfaJob));
+            if (!b->str_jobs.empty()) memcpy(str_all.data() + str_base[k], b->str_jobs.data(), b->str_jobs.size() * sizeof(StrJob));
+        };
+        const int nth = std::max(1, std::min(nb, 16));
+        if (nth == 1) fill(0);
+        else {
+            std::atomic<int> next{0};
+            std::vector<std::thread> ths;
+            for (int t = 0; t < nth; ++t) ths.emplace_back([&]() { for (int k; (k = next.fetch_add(1)) < nb;) fill(k); });
+            for (auto &t : ths) t.join();
+        }
+    }
+    if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host] job tables of the WFA / string stages: %.1f ms (%zu + %zu jobs)\n", now_ms() - th0, rc_all.size(), str_all.size());
     HIPCHK(hipEventRecord(L->ev[3], st));
     {
         int wret = 0;
@@ -1406,7 +1431,9 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         }
     }
     HIPCHK(hipEventRecord(L->ev[4], st));
-    std::vector<StrOut> str_outs(str_all.size());
+    std::vector<StrOut> &str_outs = L->h_str_outs;
+    if (str_outs.capacity() < str_all.size()) str_outs.reserve(str_all.size() + str_all.size() / 4 + 64);
+    str_outs.resize(str_all.size());
     if (!str_all.empty()) {
         if (L->d_str_jobs.ensure(str_all.size() * sizeof(StrJob)) || L->d_str_outs.ensure(str_all.size() * sizeof(StrOut))) return -11;
         HIPCHK(hipMemcpyAsync(L->d_str_jobs.p, str_all.data(), str_all.size() * sizeof(StrJob), hipMemcpyHostToDevice, st));
