@@ -107,6 +107,7 @@ struct PoaLayout {
     uint64_t tb;                                         // int32[4*node_cap]: column-tile boundaries of the unbanded rows (poa_kernel.hip align_unbanded)
     uint64_t cert;                                       // int32[7*node_cap]: path-length ranges / bonus sums per node and the rows' certified column intervals (cert chains only)
     uint64_t pl_start, pl_pidx, pl_bonus, pl_rem, pl_base; // row plan: int32[node_cap+4], int32[edge_cap] x2, int32[node_cap], u8[node_cap]
+    uint64_t e_slot;                                     // int32[edge_cap]: the row-plan entry an edge has (-1: none): a read that only adds weight patches the plan instead of rebuilding it
     uint64_t total;
 };
 
@@ -134,6 +135,7 @@ static inline LCD_HD PoaLayout poa_layout(int node_cap, int edge_cap, int rid_wo
     LCD_TAKE(prof, (uint64_t)node_cap * 2);
     LCD_TAKE(pl_start, (uint64_t)(node_cap + 4) * 4); LCD_TAKE(pl_pidx, (uint64_t)edge_cap * 4); LCD_TAKE(pl_bonus, (uint64_t)edge_cap * 4);
     LCD_TAKE(pl_rem, (uint64_t)node_cap * 4); LCD_TAKE(pl_base, (uint64_t)node_cap);
+    LCD_TAKE(e_slot, (uint64_t)edge_cap * 4);
     LCD_TAKE(aa_node, (uint64_t)(max_len + 2) * 4); LCD_TAKE(aa_flag, (uint64_t)(max_len + 2) * 4); LCD_TAKE(aa_eid, (uint64_t)(max_len + 2) * 4);
     LCD_TAKE(tb, max_len + 2 > 4096 && !cert ? (uint64_t)node_cap * 16 : 16); // (only reads longer than one 4 096-column tile use it)
     LCD_TAKE(cert, cert ? (uint64_t)node_cap * 28 : 16);

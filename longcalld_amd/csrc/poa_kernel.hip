@@ -72,6 +72,7 @@ struct Ctx {
     uint8_t *base, *imap;
     int *het, *clu, *nclu; uint8_t *prof;
     int *pl_start, *pl_pidx, *pl_bonus, *pl_rem; uint8_t *pl_base;
+    int *e_slot; int plan_valid, plan_bi, plan_ei, plan_rend; // the plan in the arrays above is the one of (bi, ei, remain_end) and matches the graph (see build_plan)
     int *aa_node, *aa_flag, *aa_eid;
     int *tb;                          // column-tile boundaries of the unbanded rows: 4 x node_cap ints (H of the last column, by tile parity; F carries)
     long long alg_adjust;             // cells of the reference's algorithm minus cells computed (certified band: full rows minus the intervals, attempts included)
@@ -340,6 +341,7 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
                 if (found >= 0) {
                     const int wn = g.e_w[found] + 1;
                     g.e_w[found] = wn; g.rid[(size_t)found * g.rid_words + rw] |= rbit; need = 0;
+                    if (g.plan_valid && (wn & (wn - 1)) == 0) { const int sl = g.e_slot[found]; if (sl >= 0) g.pl_bonus[sl] = ilog2_32(wn); } // (the edge's bonus, ilog2 of its weight, went up)
                     if (found != amax && (wn > wmax || (wn == wmax && pos_found < pos_amax))) heavy_moved = 1;
                 }
             }
@@ -699,6 +701,7 @@ __device__ void build_plan(Ctx &g, Smem &sm, const int bi, const int ei, const i
             }
         }
     }
+    for (int e = tid; e < g.n_edge; e += NT) g.e_slot[e] = -1;
     __syncthreads();
     int carry = 0;
     for (int base = bi; base <= ei; base += NT) {
@@ -728,7 +731,7 @@ __device__ void build_plan(Ctx &g, Smem &sm, const int bi, const int ei, const i
                 for (int e = g.in_head[v]; e >= 0; e = g.e_next_in[e]) {
                     int pi = g.node2idx[g.e_from[e]];
                     if (pi >= bi && pi < ei && g.imap[pi]) {
-                        g.pl_pidx[k] = pi; g.pl_bonus[k] = ilog2_32(g.e_w[e]);
+                        g.pl_pidx[k] = pi; g.pl_bonus[k] = ilog2_32(g.e_w[e]); g.e_slot[e] = k;
                         if (k == start && idx - pi < 255) first = idx - pi;
                         if (idx == ei || idx - pi > K) g.imap[pi] = 3; // same value from every writer
                         ++k;
@@ -2438,7 +2441,15 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
     if (QB > g.seq_cap) { g.status = LCD_ERR_LDS; return 0; } // read slice longer than the LDS query cache (host sizes the class)
     uint8_t *pd = (QB + (ei - bi) + 16 <= g.seq_cap) ? sseq + QB : nullptr;
     { const long long tb0 = clock64();
-    build_plan<NT>(g, sm, bi, ei, remain_end, pd, (NT == 64 || g.solo) ? g.plan_k : K);
+    if (g.plan_valid && g.plan_bi == bi && g.plan_ei == ei && g.plan_rend == remain_end) {
+        // the graph has the nodes, edges, order and `remain` it had when this plan was built (the reads since only added weight, and add_alignment_block patched the
+        // bonuses): only the first-predecessor distances are made again -- they live in the LDS pool behind the query cache, whose place depends on the read
+        if (pd) for (int idx = bi + tid; idx <= ei; idx += NT) { const int p0 = g.pl_start[idx], np = g.pl_start[idx + 1] - p0; const int d = np > 0 ? idx - g.pl_pidx[p0] : 255; pd[idx - bi] = (uint8_t)(d < 255 ? d : 255); }
+        __syncthreads();
+    } else {
+        build_plan<NT>(g, sm, bi, ei, remain_end, pd, (NT == 64 || g.solo) ? g.plan_k : K);
+        g.plan_valid = 1; g.plan_bi = bi; g.plan_ei = ei; g.plan_rend = remain_end;
+    }
     g.t_bp += (unsigned long long)(clock64() - tb0); } // (rows to spill: those with a successor further away than the windowed rows' ring -- the smallest ring a window of this chain may run with)
     if (!(sc.dbg & 8)) {
         WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0; wo.t_plan = wo.t_poll = 0; wo.t_setup = 0;
@@ -3032,6 +3043,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.het = (int *)(ws + L.het); g.clu = (int *)(ws + L.clu); g.nclu = (int *)(ws + L.nclu); g.prof = ws + L.prof;
     g.pl_start = (int *)(ws + L.pl_start); g.pl_pidx = (int *)(ws + L.pl_pidx); g.pl_bonus = (int *)(ws + L.pl_bonus);
     g.pl_rem = (int *)(ws + L.pl_rem); g.pl_base = ws + L.pl_base;
+    g.e_slot = (int *)(ws + L.e_slot); g.plan_valid = 0; g.plan_bi = g.plan_ei = g.plan_rend = 0;
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
     g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0; g.cert_generic = 0; g.cert_generic_seen = 0; g.cert_sest = 0; g.cert_ubtop = 0; g.cert_cells0 = 0;
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
@@ -3083,6 +3095,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
         int changed = 0;
         if (len > 0 && g.status == LCD_OK) changed = add_alignment_block<NT>(g, sm, exc_beg, exc_end, seq, len, n_cig, i);
         t_add += (unsigned long long)(clock64() - tg0);
+        if (changed == 1 || changed == 2) g.plan_valid = 0; // (3: weights only, every heaviest out-edge the same -- order, remain and the plan's structure stand; its bonuses were patched)
         if (changed == 2 && g.status == LCD_OK) topo_sort_block<NT>(g, sm, lds_pool);
         else if (changed == 1 && g.status == LCD_OK) topo_remain_block<NT>(g, sm, lds_pool);
         t_graph += (unsigned long long)(clock64() - tg0);
