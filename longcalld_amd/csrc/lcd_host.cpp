@@ -1125,15 +1125,24 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         {
             static const int n_streams = std::max(1, std::min(LCD_NSIDE + 1, getenv("LCD_STREAMS") ? atoi(getenv("LCD_STREAMS")) : 4));
             for (;;) {
-                std::map<long long, size_t> cnt;
-                for (size_t g = 0; g < nC_all; ++g) cnt[chain_group_key(PC(g))]++;
+                // (only SMALL groups move -- less than 8 % of the submission's CU-time: a bigger pool means fewer chains per CU, and the bulk of the work must keep the
+                //  occupancy of its own bucket; noisy-read submissions have five wide classes besides, there is no getting down to four groups)
+                std::map<long long, std::pair<size_t, double>> cnt;
+                double tot_w = 0;
+                for (size_t g = 0; g < nC_all; ++g) {
+                    const PoaChain &pc = PC(g);
+                    const int lds = pc.lds_words * 4, thr = pc.threads;
+                    const int per_cu = std::max(1, std::min((160 * 1024) / (lds + (thr == 64 ? 1 : 6) * 1024), 1024 / thr));
+                    const double w = (double)pc.n_reads * (pc.max_len + 64) / per_cu;
+                    auto &e = cnt[chain_group_key(pc)]; e.first++; e.second += w; tot_w += w;
+                }
                 if ((int)cnt.size() <= n_streams) break;
-                long long from = -1, to = -1; size_t fewest = ~(size_t)0;
+                long long from = -1, to = -1; double least = 0.08 * tot_w;
                 for (auto it = cnt.begin(); it != cnt.end(); ++it) {
                     if ((it->first >> 20) != 64) continue;
                     auto nx = std::next(it);
                     if (nx == cnt.end() || (nx->first >> 20) != 64) continue;
-                    if (it->second < fewest) { fewest = it->second; from = it->first; to = nx->first; }
+                    if (it->second.second < least) { least = it->second.second; from = it->first; to = nx->first; }
                 }
                 if (from < 0) break;
                 const int lw = (int)(to & ((1 << 20) - 1));
