@@ -369,7 +369,8 @@ typedef struct lcd_var1_t {          /* var1_t, src/call_var_main.h:108-121 (som
     int64_t pos, PS;
     int type, ref_len, n_alt_allele, alt_len[2];
     uint8_t *ref_bases, *alt_bases[2];
-    int GT[2], DP, AD[2], QUAL, GQ, is_sv, is_clean, n_alt_reads;
+    int GT[2], DP, AD[3], QUAL, GQ, is_sv, is_clean, n_alt_reads; /* AD[2]: what the reference's formatter reads for a two-alt record -- var1_t has `int DP, AD[2]; uint8_t GT[2]`,
+                                                                    * so its AD[2] is the third allele's coverage when there is one (the store at src/collect_var.c:1561 runs on), else the GT bytes */
     int *alt_read_i;
     int cand_i;                          /* the candidate (index into the lcd_hap_problem_t) the record was made from */
     int tsd_len, polya_len, te_seq_i, te_is_rev;   /* SURVEY a14 (var1_t's retrotransposon members): 0 / 0 / -1 / 0 from lcd_make_variants, filled by lcd_annotate_te */

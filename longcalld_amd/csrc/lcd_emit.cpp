@@ -122,6 +122,7 @@ int lcd_make_variants(const lcd_call_opt_t *opt, const lcd_hap_problem_t *p, con
         // (the "minor alt") lands on the two GT bytes, which follow AD in the struct -- reproduced, since it is what the reference writes to the VCF
         // (a fourth one lands on QUAL, which is assigned afterwards)
         if (na > 2) { v.GT[0] = cov[2] & 0xff; v.GT[1] = (cov[2] >> 8) & 0xff; }
+        v.AD[2] = na > 2 ? cov[2] : ((v.GT[0] & 0xff) | ((v.GT[1] & 0xff) << 8)); // (what `AD[2]` reads in var1_t: the two GT bytes and the padding behind them, zero here)
         if (v.AD[1] > 0) {
             v.alt_read_i = (int *)malloc((size_t)v.AD[1] * sizeof(int));
             int k2 = 0;
@@ -174,7 +175,7 @@ int lcd_format_vcf_te(const lcd_call_opt_t *opt, const char *chrom, const lcd_va
         if (v.is_sv) for (int a = 0; a < v.n_alt_allele; ++a) { if (a) { svlen += ','; svtype += ','; } svlen += std::to_string(v.alt_len[a] - v.ref_len); svtype += v.alt_len[a] > v.ref_len ? "INS" : "DEL"; }
         t += '\t'; t += std::to_string(v.QUAL); t += "\tPASS\t";
         if (v.is_clean) t += "CLEAN;";
-        if (v.te_seq_i >= 0) t += "MEI;"; // src/vcf_utils.c:184
+        if (v.te_seq_i >= 0 && te_names) t += "MEI;"; // src/vcf_utils.c:184 (the reference always writes MEI and REPNAME together: without the TE names neither is written)
         t += "END="; t += std::to_string((long long)(v.pos + v.ref_len - 1));
         if (v.is_sv) {
             t += ';'; t += svtype; t += ';'; t += svlen;
@@ -406,6 +407,7 @@ int lcd_annotate_te(const lcd_call_opt_t *opt, const lcd_te_opt_t *te_opt, const
     for (int i = 0; i < n_vars; ++i) {
         lcd_var1_t &v = vars[i];
         if ((v.type != 1 && v.type != 2) || v.n_alt_allele < 1) continue;
+        if (v.is_clean) continue; // (the reference computes TSD / poly-A / TE only for candidates made from a noisy region's consensus, src/collect_var.c:1817,1834 -- never for clean-region ones)
         const int gap_len = v.type == 1 ? v.alt_len[0] - 1 : v.ref_len - 1;
         if (gap_len < opt->min_sv_len) continue;
         int64_t p1, p2; int pa, ti, tr;

@@ -1293,7 +1293,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             if (d_spare) HIPCHK(hipMemcpyAsync(&spare_seen, d_spare, sizeof(PoaSpare), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             if (d_spare) {
-                for (int k = 0; k < nb; ++k) bs[k]->st.poa_grown += (int)spare_seen.n_grown;
+                bs[0]->st.poa_grown += (int)spare_seen.n_grown; // (a count of the launch set: kept on the leader, so that the batches' statistics add up)
                 if (getenv("LCD_MEM_DEBUG")) fprintf(stderr, "[mem] round %d: spare DP memory %.2f GB: %u regions grown in place (%.2f GB), %u refused\n", round, L->d_spare.cap / 1e9, spare_seen.n_grown, spare_seen.used / 1e9, spare_seen.n_refused);
             }
             { float kms = 0; hipEventElapsedTime(&kms, L->ev[6], L->ev[7]); for (int k = 0; k < nb; ++k) { bs[k]->st.ms_poa_kernel += kms; bs[k]->st.n_poa_launches++; }
@@ -1717,7 +1717,8 @@ int lcd_dispatch_run(lcd_dispatch_t *d, lcd_batch_t **bs, int n, int *device_of)
     std::vector<double> cost(n);
     for (int i = 0; i < n; ++i) { order[i] = i; cost[i] = batch_cost(bs[i]); }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
-    std::mutex mu; size_t next = 0; int first_err = 0; std::string err_msg;
+    std::mutex mu; size_t n_left = (size_t)n; int first_err = 0; std::string err_msg;
+    std::vector<char> taken((size_t)n, 0);
     const int n_dev = (int)d->devs.size();
     auto worker = [&](int dev) {
         std::vector<lcd_batch_t *> grp;
@@ -1726,18 +1727,19 @@ int lcd_dispatch_run(lcd_dispatch_t *d, lcd_batch_t **bs, int n, int *device_of)
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (first_err) return;
-                // a batch already bound to another device stays there: skip over it; take up to `coalesce`, but never more than this device's
-                // fair share of what is left (the tail of the queue is what balances the devices)
-                const size_t left = n - next;
-                const size_t take = std::max<size_t>(1, std::min<size_t>((size_t)d->coalesce, (left + n_dev - 1) / n_dev));
-                while (next < (size_t)n && grp.size() < take) {
-                    lcd_batch_t *b = bs[order[next]];
-                    if (b->device >= 0 && b->device != dev) break; // bound to another GPU of the dispatcher: its thread takes it
-                    grp.push_back(b); if (device_of) device_of[order[next]] = dev; ++next;
+                // take, in cost order, up to `coalesce` batches that are free or bound to THIS device -- never more than this device's fair share of what is left
+                // (the tail of the queue is what balances the devices).  A batch bound to another GPU of the dispatcher is skipped: its own thread takes it, and a
+                // thread that finds nothing it may take is done (no waiting on another device's submission)
+                const size_t take = std::max<size_t>(1, std::min<size_t>((size_t)d->coalesce, (n_left + n_dev - 1) / n_dev));
+                for (size_t q = 0; q < (size_t)n && grp.size() < take; ++q) {
+                    if (taken[q]) continue;
+                    lcd_batch_t *b = bs[order[q]];
+                    if (b->device >= 0 && b->device != dev) continue;
+                    taken[q] = 1; --n_left;
+                    grp.push_back(b); if (device_of) device_of[order[q]] = dev;
                 }
-                if (grp.empty()) { if (next >= (size_t)n) return; /* head is bound elsewhere: let its device take it */ }
             }
-            if (grp.empty()) { std::this_thread::yield(); continue; }
+            if (grp.empty()) return;
             int rc = 0;
             for (lcd_batch_t *b : grp) { if (b->device < 0 && (rc = bind_batch(b, dev))) break; if (!b->uploaded && (rc = lcd_batch_upload(b))) break; }
             if (!rc) rc = lcd_batch_run_many(grp.data(), (int)grp.size());

@@ -90,11 +90,50 @@ struct Collector {
     std::vector<int64_t> pos0, endp; std::vector<int> mapq, flag, ncig, qlen;
     std::vector<uint64_t> coff, soff, qoff, noff; std::vector<uint32_t> cpool; std::vector<uint8_t> spool, qpool; std::vector<char> npool;
     Collector(int t, int64_t b, int64_t e, int mq) : tid(t), reg_beg(b), reg_end(e), min_mapq(mq) {}
-    // r: the record behind its block_size word.  1 taken, 0 skipped, -1 nothing further can overlap (sorted input)
-    int take(const uint8_t *r) {
-        const int refid = le32(r), p = le32(r + 4), lname = r[8], mq = r[9], nc = r[12] | (r[13] << 8), fl = r[14] | (r[15] << 8), lseq = le32(r + 16);
+    // the real CIGAR of a read with more than 65 535 operations (ultra-long ONT reads): BAM keeps the placeholder `<l_seq>S<ref_len>N` in the 16-bit field and the
+    // operations in the CG:B,I tag; htslib's bam_read1 (behind the reference's sam_itr_next) swaps them in.  Returns the tag's operations, or nullptr.
+    static const uint8_t *cg_tag(const uint8_t *aux, const uint8_t *end, uint32_t *n) {
+        while (aux + 3 <= end) {
+            const uint8_t t0 = aux[0], t1 = aux[1], ty = aux[2]; aux += 3;
+            size_t sz;
+            switch (ty) {
+                case 'A': case 'c': case 'C': sz = 1; break;
+                case 's': case 'S': sz = 2; break;
+                case 'i': case 'I': case 'f': sz = 4; break;
+                case 'Z': case 'H': { const uint8_t *q = aux; while (q < end && *q) ++q; if (q >= end) return nullptr; sz = (size_t)(q - aux) + 1; break; }
+                case 'B': {
+                    if (aux + 5 > end) return nullptr;
+                    const uint8_t sub = aux[0]; const uint32_t cnt = (uint32_t)le32(aux + 1);
+                    const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : 0;
+                    if (!es || (size_t)(end - (aux + 5)) < (size_t)cnt * es) return nullptr;
+                    if (t0 == 'C' && t1 == 'G' && sub == 'I') { *n = cnt; return aux + 5; }
+                    sz = 5 + (size_t)cnt * es; break;
+                }
+                default: return nullptr;
+            }
+            if ((size_t)(end - aux) < sz) return nullptr;
+            aux += sz;
+        }
+        return nullptr;
+    }
+    // r: the record behind its block_size word, bs bytes long.  1 taken, 0 skipped, -1 nothing further can overlap (sorted input), -2 malformed (a field runs past
+    // the record, or a placeholder CIGAR without its CG tag)
+    int take(const uint8_t *r, const size_t bs) {
+        const int refid = le32(r), p = le32(r + 4), lname = r[8], mq = r[9], fl = r[14] | (r[15] << 8), lseq = le32(r + 16);
+        int nc = r[12] | (r[13] << 8);
+        if (lseq < 0 || 32 + (size_t)lname + 4 * (size_t)nc + ((size_t)lseq + 1) / 2 + (size_t)lseq > bs) return -2;
         if (refid != tid) return (refid > tid || refid < 0) && !pos0.empty() ? -1 : 0;
         const uint8_t *cg = r + 32 + lname;
+        const uint8_t *const sq = cg + 4 * (size_t)nc, *const ql = sq + (lseq + 1) / 2;
+        if (nc == 2 && lseq > 0) { // `<l_seq>S<n>N`: the placeholder of a CIGAR that did not fit 16 bits
+            const uint32_t c0 = (uint32_t)le32(cg), c1 = (uint32_t)le32(cg + 4);
+            if ((c0 & 0xf) == 4 && (int)(c0 >> 4) == lseq && (c1 & 0xf) == 3) {
+                uint32_t n = 0;
+                const uint8_t *real = cg_tag(ql + lseq, r + bs, &n);
+                if (!real || n == 0) return -2;
+                cg = real; nc = (int)n;
+            }
+        }
         int64_t rl = 0;
         for (int k = 0; k < nc; ++k) { const uint32_t c = (uint32_t)le32(cg + 4 * k); const int op = c & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += c >> 4; }
         const int64_t e0 = p + (rl > 0 ? rl : 1); // bam_endpos: 0-based exclusive end (an alignment without reference bases spans one)
@@ -103,7 +142,6 @@ struct Collector {
         if ((fl & (0x4 | 0x100 | 0x800)) || mq < min_mapq) return 0; // BAM_FUNMAP | BAM_FSECONDARY | BAM_FSUPPLEMENTARY, src/bam_utils.c:1683
         pos0.push_back(p); endp.push_back(e0); mapq.push_back(mq); flag.push_back(fl); ncig.push_back(nc); qlen.push_back(lseq);
         coff.push_back(cpool.size()); for (int k = 0; k < nc; ++k) cpool.push_back((uint32_t)le32(cg + 4 * k));
-        const uint8_t *sq = cg + 4 * (size_t)nc, *ql = sq + (lseq + 1) / 2;
         soff.push_back(spool.size()); spool.insert(spool.end(), sq, sq + (lseq + 1) / 2);
         qoff.push_back(qpool.size()); qpool.insert(qpool.end(), ql, ql + lseq);
         noff.push_back(npool.size()); npool.insert(npool.end(), (const char *)r + 32, (const char *)r + 32 + lname);
@@ -202,7 +240,7 @@ int lcd_bam_load_region(const char *bam_path, const char *chrom, int64_t reg_beg
         const int bs = le32(d.data() + o); const uint8_t *r = d.data() + o + 4;
         if (bs < 32 || o + 4 + (size_t)bs > d.size()) return io_err(-33, "truncated BAM record");
         o += 4 + (size_t)bs;
-        if (col.take(r) < 0) break;
+        { const int tk = col.take(r, (size_t)bs); if (tk == -2) return io_err(-33, "malformed BAM record (a field runs past the record, or a placeholder CIGAR without its CG tag)"); if (tk < 0) break; }
     }
     return col.finish(out, tid, tlen, n_ref);
 }
@@ -281,7 +319,7 @@ int lcd_bam_load_region_indexed(const char *bam_path, const char *bai_path, cons
             if (bs < 32) return io_err(-33, "truncated BAM record");
             rec.resize((size_t)bs);
             if (bz.read(rec.data(), (size_t)bs) != 0) return io_err(-33, "truncated BAM record");
-            if (col.take(rec.data()) < 0) { done = true; break; }
+            { const int tk = col.take(rec.data(), (size_t)bs); if (tk == -2) return io_err(-33, "malformed BAM record (a field runs past the record, or a placeholder CIGAR without its CG tag)"); if (tk < 0) { done = true; break; } }
         }
     }
     return col.finish(out, tid, tlen, n_ref);

@@ -100,6 +100,8 @@ def rebalance(queue, group=None, device=None, tol=0.02):
     dist.all_gather_object(allq, mine, group=group)
     moves, before, after = plan_moves([[c for c, _ in q] for q in allq], tol)
     ops, recv_bufs, sent = [], [], set()
+    # the plan is in group-relative ranks (all_gather_object, get_rank(group)); the positional peer of a P2POp is a GLOBAL rank
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
     to_dev = (lambda t: t.to(device)) if device is not None else (lambda t: t)
     keep_alive = []
     for tag, (src, i, dst) in enumerate(moves):
@@ -107,11 +109,11 @@ def rebalance(queue, group=None, device=None, tol=0.02):
         if rank == src:
             t = to_dev(torch.from_numpy(np.ascontiguousarray(queue[i][1])))
             keep_alive.append(t); sent.add(i)
-            ops.append(dist.P2POp(dist.isend, t, dst, group=group))
+            ops.append(dist.P2POp(dist.isend, t, peer(dst), group=group))
         elif rank == dst:
             t = torch.empty(nbytes, dtype=torch.uint8, device=device if device is not None else "cpu")
             recv_bufs.append((allq[src][i][0], t))
-            ops.append(dist.P2POp(dist.irecv, t, src, group=group))
+            ops.append(dist.P2POp(dist.irecv, t, peer(src), group=group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()

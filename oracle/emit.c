@@ -122,6 +122,11 @@ int lcdo_make_variants(const lcdo_call_opt_t *opt, const lcdo_hap_problem_t *p, 
         tail.QUAL = cal_var_QUAL1(tail.AD[0], tail.AD[1], opt->log_p, opt->log_1p, opt->max_qual);
         tail.GQ = cal_sample_GQ(tail.AD[0], tail.AD[1], opt->log_p, opt->log_1p, opt->log_2, opt->max_gq);
         v->DP = tail.DP; v->AD[0] = tail.AD[0]; v->AD[1] = tail.AD[1]; v->GT[0] = tail.GT[0]; v->GT[1] = tail.GT[1]; v->QUAL = tail.QUAL; v->GQ = tail.GQ;
+        {   /* AD[2] as var1_t's memory reads: the bytes behind AD[1] are GT[0], GT[1] and two bytes of padding (taken as zero: the reference mallocs the records) --
+             * or the third allele's coverage, which the store above wrote over all four */
+            int n_uniq = p->alle_off[cand_i + 1] - p->alle_off[cand_i];
+            v->AD[2] = n_uniq > 2 ? p->alle_covs[p->alle_off[cand_i] + 2] : ((int)tail.GT[0] | ((int)tail.GT[1] << 8));
+        }
         i++;
     }
     *vars_out = vars;
@@ -236,7 +241,7 @@ int lcdo_format_vcf_te(const lcdo_call_opt_t *opt, const char *chrom, const lcdo
         }
         len += snprintf(buffer + len, buf_m - len, "\t%d\tPASS\t", var.QUAL);
         if (var.is_clean) len += snprintf(buffer + len, buf_m - len, "CLEAN;");
-        if (var.te_seq_i >= 0) len += snprintf(buffer + len, buf_m - len, "MEI;");
+        if (var.te_seq_i >= 0 && te_names) len += snprintf(buffer + len, buf_m - len, "MEI;"); /* (MEI and REPNAME go together, src/vcf_utils.c:184,194) */
         len += snprintf(buffer + len, buf_m - len, "END=%lld", (long long)(var.pos + var.ref_len - 1));
         if (var.is_sv) {
             len += snprintf(buffer + len, buf_m - len, ";%s;%s", SVTYPE, SVLEN);
@@ -288,6 +293,7 @@ int lcdo_annotate_te(const lcdo_call_opt_t *opt, int min_tsd_len, int max_tsd_le
     for (int i = 0; i < n_vars; ++i) {
         lcdo_var1_t *v = vars + i;
         if (v->n_alt_allele < 1) continue;
+        if (v->is_clean) continue; /* only candidates made from a noisy region's consensus carry TE fields (src/collect_var.c:1817,1834) */
         int gap_len;
         if (v->type == 1) gap_len = v->alt_len[0] - 1; else if (v->type == 2) gap_len = v->ref_len - 1; else continue;
         if (gap_len < opt->min_sv_len) continue;

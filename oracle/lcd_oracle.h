@@ -264,7 +264,7 @@ typedef struct {
     int64_t pos, PS;
     int type, ref_len, n_alt_allele, alt_len[2];
     uint8_t *ref_bases, *alt_bases[2];
-    int GT[2], DP, AD[2], QUAL, GQ, is_sv, is_clean, n_alt_reads;
+    int GT[2], DP, AD[3], QUAL, GQ, is_sv, is_clean, n_alt_reads; /* AD[2]: the int the reference's formatter finds behind AD[1] (third allele's coverage, else the GT bytes) */
     int *alt_read_i;
     int cand_i;
     int tsd_len, polya_len, te_seq_i, te_is_rev;   /* var1_t's retrotransposon members (src/collect_var.c:1504-1520), filled by lcdo_annotate_te */

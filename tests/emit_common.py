@@ -16,7 +16,7 @@ class CallOpt(C.Structure):
 
 class Var1(C.Structure):
     _fields_ = [("pos", C.c_int64), ("PS", C.c_int64), ("type", C.c_int), ("ref_len", C.c_int), ("n_alt_allele", C.c_int), ("alt_len", C.c_int * 2),
-                ("ref_bases", u8p), ("alt_bases", u8p * 2), ("GT", C.c_int * 2), ("DP", C.c_int), ("AD", C.c_int * 2), ("QUAL", C.c_int), ("GQ", C.c_int),
+                ("ref_bases", u8p), ("alt_bases", u8p * 2), ("GT", C.c_int * 2), ("DP", C.c_int), ("AD", C.c_int * 3), ("QUAL", C.c_int), ("GQ", C.c_int),
                 ("is_sv", C.c_int), ("is_clean", C.c_int), ("n_alt_reads", C.c_int), ("alt_read_i", i32p),
                 ("cand_i", C.c_int), ("tsd_len", C.c_int), ("polya_len", C.c_int), ("te_seq_i", C.c_int), ("te_is_rev", C.c_int), ("tsd_pos1", C.c_int64), ("tsd_pos2", C.c_int64),
                 ("tsd_seq", u8p)]

@@ -62,6 +62,46 @@ def test_two_rank_queue_rebalance_gloo(tmp_path):
     assert abs(loads[0] - st["loads_after"][0]) < 1e-6 * max(loads) and abs(loads[1] - st["loads_after"][1]) < 1e-6 * max(loads)
 
 
+WORKER_SUB = r'''
+import hashlib, json, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch, torch.distributed as dist
+from longcalld_amd import jobs, rebalance as rb
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+sub = dist.new_group([1, 2])          # group-relative ranks 0, 1 are the global ranks 1, 2
+res = None
+if rank in (1, 2):
+    g = rank - 1
+    regs = [jobs.make_regions(5000 + 10 * g + i, 6 if g == 0 else 2, jobs.SV if g == 0 else jobs.HIFI, poisson_sv=False) for i in range(5 if g == 0 else 3)]
+    queue = [(sum(rb.region_cost(r) for r in rs), rb.pack_regions(rs)) for rs in regs]
+    dig = lambda b: hashlib.sha1(np.ascontiguousarray(b).tobytes()).hexdigest()
+    before = [dig(b) for _, b in queue]
+    new_q, st = rb.rebalance(queue, group=sub, tol=0.05)
+    res = dict(before=before, after=[dig(b) for _, b in new_q], n_moves=st["n_moves"], imb=(st["imbalance_before"], st["imbalance_after"]))
+out = [None] * world
+dist.all_gather_object(out, res)
+if rank == 0:
+    print(json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
+def test_rebalance_inside_a_sub_group_gloo(tmp_path):
+    """the peers of the point-to-point transfers are GLOBAL ranks, the plan is in group ranks: a group that is not 0 .. world-1 must still exchange with itself"""
+    w = tmp_path / "worker_sub.py"
+    w.write_text(WORKER_SUB)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                          "--master-port", "29519", str(w), ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("[")][-1])
+    assert r[0] is None and r[1]["n_moves"] >= 1 and r[1]["n_moves"] == r[2]["n_moves"]
+    assert sorted(r[1]["before"] + r[2]["before"]) == sorted(r[1]["after"] + r[2]["after"])       # a partition before and after, byte-identical buffers
+    assert len(r[2]["after"]) != len(r[2]["before"]) and len(r[1]["after"]) + len(r[2]["after"]) == 8 and r[1]["imb"][1] < r[1]["imb"][0]
+
+
 def test_plan_is_deterministic_and_never_moves_a_job_twice():
     from longcalld_amd import rebalance as rb
     rng = np.random.default_rng(5)

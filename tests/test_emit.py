@@ -69,6 +69,36 @@ def test_make_variants_and_vcf_text_match_oracle(libs, seed):
     assert a2 == b2 and a2.count("\n") >= a_txt.count("\n")
 
 
+def test_two_alt_alleles_ad_field(libs):
+    """a record whose haplotypes carry two DIFFERENT alt alleles (GT 1|2): the formatter prints three AD values and two VAFs.  var1_t has AD[2] only -- its third
+    value is what the reference's store at src/collect_var.c:1561 left behind AD[1], the third allele's coverage -- so the product's and the oracle's records
+    carry that value as AD[2] (neither reads out of bounds) and the text agrees"""
+    prod, orc = libs
+    p, st, extra, ref, ref_beg = _chunk(7)
+    n_alle = p["alle_off"][1:] - p["alle_off"][:-1]
+    three = np.flatnonzero(n_alle > 2)
+    assert len(three) > 3
+    hc = st["hap_to_cons_alle"].reshape(-1, 3)
+    for v in three:
+        hc[v, 1], hc[v, 2] = 1, 2
+    opt = ec.default_call_opt()
+    opt.min_dp = 0; opt.min_alt_dp = 0
+    keep = []
+    hs = _hap_struct(p, st, keep)
+    reg_beg, reg_end = int(p["var_pos"][0]), int(p["var_pos"][-1])
+    a_recs, a_txt = ec.make_variants(prod, "lcd_", hs, opt, extra, ref, ref_beg, reg_beg, reg_end)
+    b_recs, b_txt = ec.make_variants(orc, "lcdo_", hs, opt, extra, ref, ref_beg, reg_beg, reg_end)
+    assert a_recs == b_recs and a_txt == b_txt
+    two = [r for r in a_recs if r["n_alt"] == 2]
+    assert len(two) > 3
+    for r in two:
+        cov = p["alle_covs"][p["alle_off"][r["cand_i"]]:p["alle_off"][r["cand_i"] + 1]]
+        assert r["AD"][2] == cov[2]                                                  # the third allele's coverage, as in the reference's memory
+    lines = [l.split("\t") for l in a_txt.splitlines()]
+    both = [l for l in lines if "," in l[4]]                                         # two ALT sequences
+    assert both and all(len(l[9].split(":")[2].split(",")) == 3 and len(l[9].split(":")[3].split(",")) == 2 for l in both)
+
+
 def test_call_opt_defaults(libs):
     prod, _ = libs
     o = ec.CallOpt()

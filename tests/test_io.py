@@ -169,6 +169,51 @@ def test_bam_region_loader_matches_python_writer(lib, tmp_path):
     assert lib.lcd_bam_load_region(str(tmp_path / "nope.bam").encode(), b"chr11", 1, 10, 30, 1, C.byref(r)) < 0
 
 
+def _one_record_bam(path, body_of):
+    refs = [("chr11", 2000000)]
+    hdr = b"@HD\tVN:1.6\tSO:coordinate\n"
+    d = b"BAM\x01" + struct.pack("<i", len(hdr)) + hdr + struct.pack("<i", len(refs))
+    for nm, ln in refs:
+        d += struct.pack("<i", len(nm) + 1) + nm.encode() + b"\0" + struct.pack("<i", ln)
+    for body in body_of:
+        d += struct.pack("<i", len(body)) + body
+    open(path, "wb").write(_bgzf(d, block=30000))
+
+
+def test_long_cigar_in_cg_tag_and_malformed_records(lib, tmp_path):
+    """a read with more than 65 535 CIGAR operations keeps `<l_seq>S<ref_len>N` in the record and the operations in CG:B,I (SAM specification 4.2.2); htslib's
+    bam_read1, behind the reference's sam_itr_next (src/bam_utils.c:1672), puts the real CIGAR back -- so does the loader.  A record whose fields run past its
+    block_size, or a placeholder without the tag, is an error and not an out-of-bounds read."""
+    rng = np.random.default_rng(5)
+    n_ops = 70001
+    ops = np.empty(n_ops, "<u4")
+    ops[0::2] = (np.uint32(3) << 4) | 7                       # 3=
+    ops[1::2] = (np.uint32(1) << 4) | 8                       # 1X
+    qlen = int((ops >> 4).sum()); rl = qlen
+    seq = rng.integers(1, 9, qlen).astype(np.uint8)
+    packed = ((np.append(seq, 0)[0:2 * ((qlen + 1) // 2):2] << 4) | np.append(seq, 0)[1:2 * ((qlen + 1) // 2):2]).astype(np.uint8)
+    qual = rng.integers(0, 60, qlen).astype(np.uint8)
+    name = b"ultralong\0"
+    placeholder = np.array([(qlen << 4) | 4, (rl << 4) | 3], "<u4")
+    head = struct.pack("<iiBBHHHiiii", 0, 5000, len(name), 60, 4680, 2, 0, qlen, -1, -1, 0) + name + placeholder.tobytes() + packed.tobytes() + qual.tobytes()
+    good = head + b"NMi" + struct.pack("<i", 3) + b"ZZZabc\0" + b"CGBI" + struct.pack("<i", n_ops) + ops.tobytes() + b"XXc\x01"
+    path = str(tmp_path / "cg.bam")
+    _one_record_bam(path, [good])
+    r = BamReads()
+    assert lib.lcd_bam_load_region(path.encode(), b"chr11", 1, 2000000, 30, 1, C.byref(r)) == 1, lib.lcd_io_last_error()
+    assert r.n_cigar[0] == n_ops and r.qlen[0] == qlen and r.end_pos[0] == 5000 + rl
+    got = np.ctypeslib.as_array(r.cigar_pool, shape=(n_ops,))
+    assert (got == ops).all()
+    lib.lcd_bam_reads_free(C.byref(r))
+    # the placeholder without its tag
+    _one_record_bam(path, [head + b"NMi" + struct.pack("<i", 3)])
+    assert lib.lcd_bam_load_region(path.encode(), b"chr11", 1, 2000000, 30, 1, C.byref(r)) < 0 and b"malformed" in lib.lcd_io_last_error()
+    # l_seq larger than the record holds
+    short = struct.pack("<iiBBHHHiiii", 0, 5000, len(name), 60, 4680, 1, 0, 100000, -1, -1, 0) + name + struct.pack("<I", (100000 << 4) | 7) + b"\x11" * 50
+    _one_record_bam(path, [short])
+    assert lib.lcd_bam_load_region(path.encode(), b"chr11", 1, 2000000, 30, 1, C.byref(r)) < 0 and b"malformed" in lib.lcd_io_last_error()
+
+
 def test_fasta_fetch_matches_python(lib, tmp_path):
     rng = np.random.default_rng(12)
     seqs = {"chrA": "".join(rng.choice(list("ACGTNacgt"), 1234)), "chr11": "".join(rng.choice(list("ACGT"), 9001))}
