@@ -105,7 +105,12 @@ def main():
                     "--steps is ignored, scaling is strong")
     ap.add_argument("--rebalance", type=int, default=1, help="--job-mb with N > 1: one RCCL epoch of queue rebalancing before the timed run "
                     "(longcalld_amd/rebalance.py: all_gather of the queues, whole packed chunks sent from the deepest to the shallowest); 0 = keep the contiguous blocks")
-    ap.add_argument("--distinct", type=int, default=10, help="distinct-seed batches the timed steps cycle over (10 x 10 Mb = 100 Mb of distinct regions)")
+    ap.add_argument("--distinct", type=int, default=0, help="distinct-seed batches the timed steps cycle over (0 = as many as one submission coalesces, at least 10: "
+                    "every batch of a submission is a different 10 Mb of regions)")
+    ap.add_argument("--repeats", type=int, default=0, help="how often the timed region (exactly --steps steps, barrier + synchronize on both sides) is run; `value` is the "
+                    "MEDIAN repeat, all of them are listed (0 = 5 when the region is a single submission -- the driver's flags: 0.3 s -- else 1)")
+    ap.add_argument("--depth-profile", type=int, default=-1, help="also time lone submissions of 1 / 4 / 16 batches (what a caller with fewer chunks in flight gets); "
+                    "-1 = on for the single-GPU HiFi run")
     ap.add_argument("--shape", default="hifi", choices=["hifi", "ont", "ont60", "sv"])
     ap.add_argument("--cpu-sample", type=int, default=200, help="cap on regions per CPU worker of the cpu_baseline leg, which is bounded to ~12 s (rank 0, N=1 only; 0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU worker processes of the cpu_baseline leg (0 = all host cores)")
@@ -141,9 +146,12 @@ def main():
         timed_seeds = [args.seed + i for i in range(lo, hi)]
         regs_per_unit = jobs.regions_for_ref_mb(CHUNK_MB)
     else:
+        if args.distinct <= 0:   # (the submission size is fixed further down from the same arguments)
+            co_guess = args.coalesce if args.coalesce > 0 else (32 if args.shape == "hifi" else 8 if args.shape == "sv" else 24)
+            args.distinct = max(10, min(co_guess, max(args.steps, 1), 32))
         timed_seeds = [args.seed + 1000 * rank + i for i in range(max(1, args.distinct))]   # weak scaling: same work per GPU, different seeds
         regs_per_unit = n_regions
-    n_warm_seeds = 3 if args.warmup else 0
+    n_warm_seeds = (6 if args.shape == "hifi" else 3) if args.warmup else 0   # (more warm-up data: the grow-only buffers see a wider sample of batch sizes before the clock starts)
     warm_seeds = [args.seed + 500000 + 1000 * rank + i for i in range(n_warm_seeds)]
     import multiprocessing as mp
     n_gen_procs = max(1, min(len(timed_seeds) + len(warm_seeds), _host_cores() // max(1, world)))
@@ -271,22 +279,34 @@ def main():
     for q, bt in enumerate(batches):
         if args.steps > 0:
             t_up = load_slot(bt, timed_regs[q % len(timed_regs)])
-    barrier()
-    allocs0 = lib.lcd_alloc_events()
-    t0 = time.perf_counter()
-    if args.steps > 0:
-        run_steps(args.steps, True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    allocs_timed = lib.lcd_alloc_events() - allocs0
+    # the timed region = exactly --steps steps between two (barrier + synchronize); a region that is ONE submission lasts a third of a second, so it is repeated
+    # and the MEDIAN repeat is the one reported (value, stage times, statistics all come from that repeat; every repeat's time is listed)
+    n_rep = args.repeats if args.repeats > 0 else (5 if (not job_mode and args.steps <= n_co * n_lanes) else 1)
+    reps = []
+    for _rep in range(n_rep):
+        for k_ in acc:
+            acc[k_] = None if k_ == "st" else 0.0 if isinstance(acc[k_], float) else 0
+        barrier()
+        allocs0 = lib.lcd_alloc_events()
+        t0 = time.perf_counter()
+        if args.steps > 0:
+            run_steps(args.steps, True)
+        barrier()
+        el = time.perf_counter() - t0
+        rank_el = el
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        reps.append({"elapsed": el, "rank_elapsed": rank_el, "allocs": int(lib.lcd_alloc_events() - allocs0), "acc": dict(acc)})
+    order = sorted(range(n_rep), key=lambda i: reps[i]["elapsed"])
+    med = reps[order[(n_rep - 1) // 2]]
+    elapsed, rank_elapsed, allocs_timed = med["elapsed"], med["rank_elapsed"], med["allocs"]
+    acc.update(med["acc"])
     dev_gb = lib.lcd_device_bytes(local_rank) / 1e9
     poa_kernel_ms, poa_launches, st = acc["ms"], acc["launches"], acc["st"]
     tot_regions, tot_bases = acc["regions"], acc["bases"]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        rank_elapsed = elapsed
-        elapsed = float(t.item())
         cnt = torch.tensor([tot_regions, tot_bases, rank_elapsed], dtype=torch.float64, device=dev)
         allc = [torch.zeros_like(cnt) for _ in range(world)]
         dist.all_gather(allc, cnt)
@@ -294,6 +314,24 @@ def main():
         rank_times = [round(float(c[2].item()), 4) for c in allc]
     else:
         rank_times = [round(elapsed, 4)]
+
+    # lone submissions of 1 / 4 / 16 batches: what a caller with fewer chunks in flight than the timed region's gets (kt_for offers n_threads chunks per pass,
+    # src/collect_var.c:2952-2969); never `value`
+    depth = None
+    if (args.depth_profile > 0 or (args.depth_profile < 0 and args.shape == "hifi" and not job_mode)) and world == 1 and args.steps > 0 and not args.vars:
+        depth = {}
+        for dsz, dn in ((1, 5), (4, 3), (16, 3)):
+            if dsz > len(groups[0]):
+                continue
+            ts = []
+            for q in range(dn + 1):   # (the first one is not timed: a submission of another size re-plans the leader's buffers)
+                torch.cuda.synchronize(); td0 = time.perf_counter()
+                align.RegionBatch.run_many(groups[0][:dsz])
+                torch.cuda.synchronize()
+                if q:
+                    ts.append(time.perf_counter() - td0)
+            ts.sort()
+            depth[str(dsz)] = {"regions_per_sec": round(dsz * n_regions / ts[len(ts) // 2], 1), "ms_per_submission": round(ts[len(ts) // 2] * 1e3, 2), "submissions": dn}
 
     # PCIe-inclusive with overlap (never `value`): E lanes, each upload -> run_many -> download -> digest (lcd_batch_digest materialises every
     # malloc()'d aln_str_t / variant record of the batch exactly as a caller would receive them) on its own group of slots
@@ -441,6 +479,8 @@ def main():
             "stage_ms": {k: round(st[k], 3) for k in ("ms_anchor", "ms_poa", "ms_wfa", "ms_strings", "ms_vars", "ms_total", "ms_host", "ms_poa_kernel")} if st else None,
             "noisy_vars_stage": args.vars,
             "rank_seconds": rank_times,
+            "repeats": {"n": n_rep, "seconds": [round(r_["elapsed"], 4) for r_ in reps], "reported": "median", "allocations_per_repeat": [r_["allocs"] for r_ in reps]},
+            "depth": depth,
             "device_memory": {"library_buffers_gb": round(dev_gb, 2), "allocations_inside_timed_region": int(allocs_timed)},
             "pcie_inclusive": {"upload_s": round(t_up, 4), "download_and_materialize_s": round(t_dl, 4),
                                "regions_per_sec": round(tot_regions / max(world, 1) / steps / (t_up + ms_step / 1e3 + t_dl), 2), "overlapped": e2e},

@@ -100,6 +100,7 @@ struct DevBuf {
             (void)hipGetLastError(); // out-of-memory is not sticky, but the "last error" slot is read after every launch
             p = nullptr; cap = 0; return set_err(-11, "hipMalloc failed for " + std::to_string(want) + " bytes");
         }
+        if (getenv("LCD_ALLOC_DEBUG")) fprintf(stderr, "[alloc] %zu bytes asked, %zu allocated (device %d now %.2f GB)\n", n, want, dev, (g_dev_bytes[dev].load() + (long long)want) / 1e9);
         cap = want; g_dev_bytes[dev] += (long long)cap; ++g_alloc_events; return 0;
     }
     void release() { if (p) { hipFree(p); g_dev_bytes[dev] -= (long long)cap; p = nullptr; cap = 0; } }
