@@ -102,9 +102,13 @@ int lcd_edlib_edit_distance(uint8_t *target, int tlen, uint8_t *query, int qlen)
  * src/collect_var.c:203 and, with -s, src/assign_hap.c:1280): both are thin wrappers over the 2-piece WFA above */
 int lcd_end2end_aln(const lcd_opt_t *opt, char *tseq, int tlen, uint8_t *qseq, int qlen, uint32_t **cigar_buf);
 int lcd_wfa_collect_diff_ins_seq(const lcd_opt_t *opt, uint8_t *large_seq, int large_len, uint8_t *small_seq, int small_len, uint8_t **diff_seq);
-/* src/align.h:54,60: edlib_infix_aln (edlib HW mode; every caller is somatic-mode code) and wfa_heuristic_aln (x-drop; no caller) are exported
- * so that longcallD links against this library alone; they return -2, set lcd_last_error() and print to stderr -- never a silent result */
+/* replaces edlib_infix_aln (src/align.c:256-275, src/align.h:54; every caller is somatic-mode code): edlibAlign(query, target, {k = -1, EDLIB_MODE_HW,
+ * EDLIB_TASK_PATH}) -- the query against the best-matching stretch of the target (free start and end in the target), the path on the first end position's
+ * stretch (edlib/src/edlib.cpp:146-280).  Returns the edit distance (-1 on error); *n_eq / *n_xid as edlibAlignmentToXID counts the path (:164).  Byte-pinned to
+ * the reference's own edlib (tests/golden/edlib_golden.json `hw_cases`). */
 int lcd_edlib_infix_aln(uint8_t *target, int tlen, uint8_t *query, int qlen, int *n_eq, int *n_xid);
+/* src/align.h:60: wfa_heuristic_aln (x-drop; NO caller in longcallD) is exported so that longcallD links against this library alone; it returns -2, sets
+ * lcd_last_error() and prints to stderr -- never a silent result */
 int lcd_wfa_heuristic_aln(uint8_t *pattern, int plen, uint8_t *text, int tlen, int a, int b, int q, int e, int q2, int e2, int *n_eq, int *n_xid);
 
 /* replaces collect_noisy_reg_aln_strs (src/align.c:1760) with bam_chunk_t flattened to per-read views.
@@ -439,6 +443,9 @@ const char *lcd_io_last_error(void);
 /* ---- kernel-level batches (also what the per-call mirrors above run on) ---- */
 int lcd_edlib_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *q_off, const int *qlen,
                     const uint64_t *t_off, const int *tlen, int *dist, int *xgaps, int *n_eq, int *n_xid);
+/* the same in HW (infix) mode; start / end (nullable): the target stretch [start, end] the path was taken on = edlib's startLocations[0] / endLocations[0] */
+int lcd_edlib_batch_hw(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *q_off, const int *qlen,
+                       const uint64_t *t_off, const int *tlen, int *dist, int *xgaps, int *n_eq, int *n_xid, int *start, int *end);
 /* want bit0: cigars into cigars[i*cigar_stride ..], bit1: rows into rows[i*2*row_stride ..] (pattern row, then text row at +row_stride) */
 int lcd_wfa_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *p_off, const int *plen, const uint64_t *t_off,
                   const int *tlen, const int *gap_aln, int b, int q, int e, int q2, int e2, int want, int *score,

@@ -57,6 +57,31 @@ def edlib_batch(pairs):
     return out
 
 
+def edlib_batch_hw(pairs):
+    """HW (infix) mode, edlib_infix_aln (src/align.c:256): pairs of (target, query) -> dict of int arrays dist/xgaps/n_eq/n_xid/start/end"""
+    lib = load_library()
+    n = len(pairs)
+    arrs = [np.ascontiguousarray(x, np.uint8) for p in pairs for x in (p[1], p[0])]  # query, target
+    pool, offs = _pool(arrs)
+    qo, to = np.ascontiguousarray(offs[0::2]), np.ascontiguousarray(offs[1::2])
+    ql = np.array([len(p[1]) for p in pairs], np.int32)
+    tl = np.array([len(p[0]) for p in pairs], np.int32)
+    keys = ("dist", "xgaps", "n_eq", "n_xid", "start", "end")
+    out = {k: np.zeros(n, np.int32) for k in keys}
+    check(lib.lcd_edlib_batch_hw(n, _p8(pool), pool.size, qo.ctypes.data_as(u64p), ql.ctypes.data_as(i32p), to.ctypes.data_as(u64p),
+                                 tl.ctypes.data_as(i32p), *[out[k].ctypes.data_as(i32p) for k in keys]), lib)
+    return out
+
+
+def edlib_infix_aln(target, query):
+    """edlib_infix_aln, src/align.c:256 -> (distance, n_eq, n_xid) through the per-call export"""
+    lib = load_library()
+    t, q = np.ascontiguousarray(target, np.uint8), np.ascontiguousarray(query, np.uint8)
+    a, b = C.c_int(), C.c_int()
+    d = lib.lcd_edlib_infix_aln(_p8(t), len(t), _p8(q), len(q), C.byref(a), C.byref(b))
+    return d, a.value, b.value
+
+
 def edlib_xgaps(target, query):
     """edlib_xgaps, src/align.c:222"""
     return int(edlib_batch([(target, query)])["xgaps"][0])

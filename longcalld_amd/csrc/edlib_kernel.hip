@@ -111,6 +111,63 @@ __device__ __forceinline__ int myers_pass(const Sub &sp, int ncols, bool rev, in
     return result;
 }
 
+// One semi-global pass (distance only) over `ncols` target columns: the score of the LAST query row at every column, reduced to its minimum and the first / last
+// column that reaches it.  HIN0 = 0: free start in the target (edlib HW, first DP row all zero); HIN0 = 1: the target stretch is anchored at its first
+// character (edlib SHW, first row 0, 1, 2, ...: the reverse pass that finds an alignment's start, edlib.cpp:230-262).  rev as in myers_pass.
+template <int HIN0>
+__device__ __forceinline__ void sg_pass(const Sub &sp, int ncols, bool rev, int lane, signed char *hcarry, unsigned long long *blocks_acc, int *best_out, int *first_out, int *last_out) {
+    const int qlen = sp.qlen, nb = (qlen + 63) >> 6;
+    int best = 1 << 30, first_c = -1, last_c = -1;
+    for (int tile0 = 0; tile0 < nb; tile0 += 64) {
+        const int b = tile0 + lane;
+        const bool act = b < nb;
+        Word peq[5] = {0, 0, 0, 0, 0};
+        if (act) {
+            const int base = b << 6, lim = imin(64, qlen - base);
+            for (int r = 0; r < lim; ++r) {
+                const int qi = base + r;
+                const uint8_t c = rev ? sp.q[qlen - 1 - qi] : sp.q[qi];
+                const Word bit = 1ull << r;
+                if (c == 0) peq[0] |= bit; else if (c == 1) peq[1] |= bit; else if (c == 2) peq[2] |= bit;
+                else if (c == 3) peq[3] |= bit; else peq[4] |= bit;
+            }
+        }
+        Word Pv = ~0ull, Mv = 0;
+        int score = (b + 1) << 6, hout = 0;
+        const bool more = tile0 + 64 < nb;
+        const bool is_last = b == nb - 1;
+        const int pos = (qlen - 1) & 63;
+        const int nsteps = ncols + 63;
+        for (int step = 0; step < nsteps; ++step) {
+            const int hleft = __shfl_up(hout, 1);
+            const int c = step - lane;
+            if (act && c >= 0 && c < ncols) {
+                const int hin = lane == 0 ? (tile0 == 0 ? HIN0 : (int)hcarry[c]) : hleft;
+                const uint8_t tc = rev ? sp.t[sp.tlen - 1 - c] : sp.t[c];
+                const Word Eq = tc == 0 ? peq[0] : tc == 1 ? peq[1] : tc == 2 ? peq[2] : tc == 3 ? peq[3] : peq[4];
+                hout = calc_block(Pv, Mv, Eq, hin, Pv, Mv);
+                score += hout;
+                if (more && lane == 63) hcarry[ncols + c] = (signed char)hout;
+                if (is_last) { // the last query row lives in this block: its score at this column
+                    int v = score;
+                    if (pos < 63) v += -__popcll(Pv >> (pos + 1)) + __popcll(Mv >> (pos + 1));
+                    if (v < best) { best = v; first_c = c; last_c = c; } else if (v == best) last_c = c;
+                }
+            }
+        }
+        __syncthreads();
+        if (more) {
+            for (int c = lane; c < ncols; c += 64) hcarry[c] = hcarry[ncols + c];
+            __syncthreads();
+        }
+        *blocks_acc += (unsigned long long)ncols * (unsigned long long)(imin(64, nb - tile0));
+        const int lastb = nb - 1;
+        if (lastb >= tile0 && lastb < tile0 + 64) { best = __shfl(best, lastb - tile0); first_c = __shfl(first_c, lastb - tile0); last_c = __shfl(last_c, lastb - tile0); }
+        __syncthreads();
+    }
+    *best_out = best; *first_out = first_c; *last_out = last_c;
+}
+
 struct Tally {
     int n_mis, n_eq, n_ins, n_del, runs;
     int last_op; // forward-order last op of everything tallied so far (-1 none)
@@ -123,7 +180,7 @@ __global__ void __launch_bounds__(64) lcd_edlib_kernel(const EdJob *jobs, const 
     if (jid >= n_jobs) return;
     const int lane = threadIdx.x;
     const EdJob jb = jobs[jid];
-    EdOut out; out.status = LCD_OK; out.dist = -1; out.xgaps = 0; out.n_eq = 0; out.n_xid = 0; out.blocks = 0;
+    EdOut out; out.status = LCD_OK; out.dist = -1; out.xgaps = 0; out.n_eq = 0; out.n_xid = 0; out.blocks = 0; out.start = 0; out.end = jb.tlen - 1;
     const uint8_t *q = pool + jb.q_off, *t = pool + jb.t_off;
     const int qlen = jb.qlen, tlen = jb.tlen;
     if (qlen == 0 || tlen == 0) { // edlib.cpp:166-173: distance only, no alignment
@@ -140,11 +197,23 @@ __global__ void __launch_bounds__(64) lcd_edlib_kernel(const EdJob *jobs, const 
     signed char *hcarry = (signed char *)(colR + qlen);
     unsigned long long blocks = 0;
     Sub top = {q, t, qlen, tlen};
-    const int dist = myers_pass<false, false>(top, tlen, false, lane, nullptr, nullptr, nullptr, nullptr, hcarry, &blocks);
+    int dist, t0 = 0, tl0 = tlen;
+    if (jb.mode == 1) {
+        // HW (infix, edlib.cpp:146-280): best score over all end positions with a free start; the FIRST end position; its start from the reversed problem on the
+        // prefix that ends there (anchored, the LAST position with the best score = the longest stretch); the path is then the NW path on that stretch
+        int best, endf, endl, best2, sf, sl;
+        sg_pass<0>(top, tlen, false, lane, hcarry, &blocks, &best, &endf, &endl);
+        Sub pre = {q, t, qlen, endf + 1};
+        sg_pass<1>(pre, endf + 1, true, lane, hcarry, &blocks, &best2, &sf, &sl);
+        if (best2 != best || endf < 0 || sl < 0) { out.status = LCD_ERR_BACKTRACK; if (lane == 0) outs[jid] = out; return; }
+        dist = best; t0 = endf - sl; tl0 = sl + 1;
+        out.start = t0; out.end = endf;
+    } else
+        dist = myers_pass<false, false>(top, tlen, false, lane, nullptr, nullptr, nullptr, nullptr, hcarry, &blocks);
     out.dist = dist;
     __shared__ int stk[64][5]; // qoff, qlen, toff, tlen, best
     int sp = 0;
-    if (lane == 0) { stk[0][0] = 0; stk[0][1] = qlen; stk[0][2] = 0; stk[0][3] = tlen; stk[0][4] = dist; }
+    if (lane == 0) { stk[0][0] = 0; stk[0][1] = qlen; stk[0][2] = t0; stk[0][3] = tl0; stk[0][4] = dist; }
     sp = 1;
     __syncthreads();
     Tally T = {0, 0, 0, 0, 0, -1};

@@ -518,7 +518,7 @@ int lcd_batch_add_region(lcd_batch_t *b, int64_t reg_len, int n_reads, const int
             if (LCD_IS_BOTH_COVER(qfc) || (LCD_IS_LEFT_COVER(qfc) && LCD_IS_RIGHT_GAP(qfc)) || (LCD_IS_RIGHT_COVER(qfc) && LCD_IS_LEFT_GAP(qfc))) {
                 if (R.sampling) {
                     AnchorRec A; A.pread = pidx; A.ext = 0; A.tlen_full = r0.len; A.qlen_full = r.len; A.wfa_job = -1; A.min_len = std::min(r0.len, r.len);
-                    EdJob ej; ej.t_off = r0.off; ej.tlen = r0.len; ej.q_off = r.off; ej.qlen = r.len; ej.ws_off = 0; ej.ws_bytes = 0;
+                    EdJob ej; ej.t_off = r0.off; ej.tlen = r0.len; ej.q_off = r.off; ej.qlen = r.len; ej.ws_off = 0; ej.ws_bytes = 0; ej.mode = 0; ej.pad_ = 0;
                     A.ed_job = (int)b->ed_jobs.size(); b->ed_jobs.push_back(ej); b->anchors.push_back(A);
                 }
             } else if (LCD_IS_LEFT_COVER(qfc) || LCD_IS_RIGHT_COVER(qfc)) {
@@ -537,7 +537,7 @@ int lcd_batch_add_region(lcd_batch_t *b, int64_t reg_len, int n_reads, const int
                 if (ext == 1) gap_aln = (gap_aln == 2) ? 1 : 2;
                 const int min_len = std::min(tlen, qlen);
                 AnchorRec A; A.pread = pidx; A.ext = ext; A.tlen_full = _tlen; A.qlen_full = _qlen; A.min_len = min_len;
-                EdJob ej; ej.qlen = min_len; ej.tlen = min_len; ej.ws_off = 0; ej.ws_bytes = 0;
+                EdJob ej; ej.qlen = min_len; ej.tlen = min_len; ej.ws_off = 0; ej.ws_bytes = 0; ej.mode = 0; ej.pad_ = 0;
                 if (ext == 1) { ej.t_off = toff; ej.q_off = qoff; } else { ej.t_off = toff + tlen - min_len; ej.q_off = qoff + qlen - min_len; }
                 A.ed_job = (int)b->ed_jobs.size(); b->ed_jobs.push_back(ej);
                 WfaJob wj; wj.p_off = toff; wj.plen = tlen; wj.t_off = qoff; wj.tlen = qlen; wj.gap_aln = gap_aln; wj.want = 1;
@@ -2014,15 +2014,25 @@ uint64_t lcd_batch_digest(lcd_batch_t *b) {
 
 // ---------------------------------------------------------------------------------------------------
 // kernel-level batches
+static int edlib_batch_mode(int mode, int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *q_off, const int *qlen, const uint64_t *t_off,
+                            const int *tlen, int *dist, int *xgaps, int *n_eq, int *n_xid, int *start, int *end);
 int lcd_edlib_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *q_off, const int *qlen, const uint64_t *t_off,
                     const int *tlen, int *dist, int *xgaps, int *n_eq, int *n_xid) {
+    return edlib_batch_mode(0, n, pool, pool_len, q_off, qlen, t_off, tlen, dist, xgaps, n_eq, n_xid, nullptr, nullptr);
+}
+int lcd_edlib_batch_hw(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *q_off, const int *qlen, const uint64_t *t_off,
+                       const int *tlen, int *dist, int *xgaps, int *n_eq, int *n_xid, int *start, int *end) {
+    return edlib_batch_mode(1, n, pool, pool_len, q_off, qlen, t_off, tlen, dist, xgaps, n_eq, n_xid, start, end);
+}
+static int edlib_batch_mode(int mode, int n, const uint8_t *pool, uint64_t pool_len, const uint64_t *q_off, const int *qlen, const uint64_t *t_off,
+                            const int *tlen, int *dist, int *xgaps, int *n_eq, int *n_xid, int *start, int *end) {
     if (ensure_init()) return -1;
     StreamGuard st; if (st.create()) return -10;
     DevBuf d_pool, d_jobs, d_arena, d_outs;
     if (d_pool.ensure(pool_len + 64)) return -11;
     HIPCHK(hipMemcpyAsync(d_pool.p, pool, pool_len, hipMemcpyHostToDevice, st));
     std::vector<EdJob> jobs(n);
-    for (int i = 0; i < n; ++i) { jobs[i].q_off = d_pool.addr() + q_off[i]; jobs[i].t_off = d_pool.addr() + t_off[i]; jobs[i].qlen = qlen[i]; jobs[i].tlen = tlen[i]; }
+    for (int i = 0; i < n; ++i) { jobs[i].q_off = d_pool.addr() + q_off[i]; jobs[i].t_off = d_pool.addr() + t_off[i]; jobs[i].qlen = qlen[i]; jobs[i].tlen = tlen[i]; jobs[i].mode = mode; jobs[i].pad_ = 0; }
     std::vector<EdOut> outs;
     int rc = run_edlib_stage(st, jobs, d_jobs, d_arena, d_outs, outs);
     if (rc) return rc;
@@ -2033,6 +2043,8 @@ int lcd_edlib_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_
         if (xgaps) xgaps[i] = outs[i].xgaps;
         if (n_eq) n_eq[i] = outs[i].n_eq;
         if (n_xid) n_xid[i] = outs[i].n_xid;
+        if (start) start[i] = outs[i].start;
+        if (end) end[i] = outs[i].end;
     }
     return 0;
 }
@@ -2794,11 +2806,19 @@ int lcd_wfa_collect_diff_ins_seq(const lcd_opt_t *opt, uint8_t *large_seq, int l
 }
 // The two exports of src/align.h that the germline path never reaches (edlib_infix_aln is only called from somatic-mode code,
 // wfa_heuristic_aln has no caller at all): present so that a longcallD built against this library links, and loud when reached
-int lcd_edlib_infix_aln(uint8_t *, int, uint8_t *, int, int *n_eq, int *n_xid) {
-    if (n_eq) *n_eq = -1; if (n_xid) *n_xid = -1;
-    fprintf(stderr, "liblcd_hotpath: edlib_infix_aln (edlib HW mode, src/align.c:256) is a somatic-mode (-s) call and is not implemented\n");
-    return set_err(-2, "edlib_infix_aln (HW mode) is not implemented: somatic mode (-s) is out of scope");
+// edlib_infix_aln (src/align.c:256-275): edlib's HW mode with the path -- a somatic-mode (-s) call in longcallD, implemented and pinned to the reference's own edlib
+// (tests/golden/edlib_golden.json, hw_cases).  Returns the edit distance, -1 on error; *n_eq / *n_xid from the path as edlibAlignmentToXID counts them.
+int lcd_edlib_infix_aln(uint8_t *target, int tlen, uint8_t *query, int qlen, int *n_eq, int *n_xid) {
+    std::vector<uint8_t> pool((size_t)lcd_align_up(qlen, 16) + tlen + 32, 4);
+    if (qlen) memcpy(pool.data(), query, qlen);
+    const uint64_t qo = 0, to = lcd_align_up(qlen, 16);
+    if (tlen) memcpy(pool.data() + to, target, tlen);
+    int d, x, a, c, s0, e0;
+    if (lcd_edlib_batch_hw(1, pool.data(), pool.size(), &qo, &qlen, &to, &tlen, &d, &x, &a, &c, &s0, &e0)) { if (n_eq) *n_eq = -1; if (n_xid) *n_xid = -1; return -1; }
+    if (n_eq && n_xid) { *n_eq = a; *n_xid = c; }
+    return d;
 }
+// The export of src/align.h that has no caller at all in longcallD: present so that a longcallD built against this library links, and loud when reached
 int lcd_wfa_heuristic_aln(uint8_t *, int, uint8_t *, int, int, int, int, int, int, int, int *n_eq, int *n_xid) {
     if (n_eq) *n_eq = -1; if (n_xid) *n_xid = -1;
     fprintf(stderr, "liblcd_hotpath: wfa_heuristic_aln (x-drop WFA, src/align.c:332) has no caller in longcallD and is not implemented\n");

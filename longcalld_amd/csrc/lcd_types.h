@@ -205,10 +205,12 @@ struct EdJob {
     uint64_t q_off, t_off;
     int qlen, tlen;
     uint64_t ws_off, ws_bytes;
+    int mode, pad_;   // 0: NW (edlib_xgaps / edlib_end2end_aln / edlib_edit_distance), 1: HW = infix (edlib_infix_aln, src/align.c:256)
 };
 struct EdOut {
     int status, dist, xgaps, n_eq, n_xid;
     unsigned long long blocks; // Myers block-columns computed
+    int start, end;            // HW mode: the target stretch [start, end] (0-based, inclusive) the path was taken on -- edlib's startLocations[0] / endLocations[0]; NW: 0 / tlen - 1
 };
 
 // ---------------- MSA row -> cons/read pairwise string (src/align.c:1029-1054 + wfa_trim_aln_str :496-562) ----------------

@@ -185,3 +185,67 @@ int lcdo_edlib_end2end_aln(const uint8_t *target, int tlen, const uint8_t *query
     free(aln);
     return d;
 }
+
+
+/* ---------------- HW (infix) mode: edlibAlign(query, target, {k = -1, EDLIB_MODE_HW, EDLIB_TASK_PATH}), src/align.c:256-275 ----------------
+ * edlib/src/edlib.cpp:146-280: (1) the best score over all end positions of the target with a free start (first DP row all zero) and the end positions that reach
+ * it, in increasing order; (2) for an end position the start: the SAME problem reversed -- reversed query against the reversed target prefix that ends there, this
+ * time with the prefix anchored (SHW: first row 0, 1, 2, ...) -- whose LAST position with the best score is taken (:243-262: `positionsSHW[numPositionsSHW - 1]`),
+ * i.e. the longest target stretch; (3) the path = the NW alignment (same traceback as above) of the query against target[start0 .. end0] for the FIRST end
+ * position.  Full matrices here: test infrastructure, sizes of a few thousand. */
+int lcdo_edlib_hw(const uint8_t *query, int qlen, const uint8_t *target, int tlen, int *start_out, int *end_out, uint8_t **aln, int *aln_len) {
+    if (aln) { *aln = NULL; *aln_len = 0; }
+    if (start_out) *start_out = -1;
+    if (end_out) *end_out = -1;
+    if (qlen == 0 || tlen == 0) return qlen > tlen ? qlen : tlen; /* edlib.cpp:166-173 (mode-independent): distance only */
+    int *prev = (int *)malloc((size_t)(tlen + 1) * sizeof(int)), *cur = (int *)malloc((size_t)(tlen + 1) * sizeof(int));
+    for (int j = 0; j <= tlen; ++j) prev[j] = 0;                       /* free start anywhere in the target */
+    for (int i = 1; i <= qlen; ++i) {
+        cur[0] = i;
+        for (int j = 1; j <= tlen; ++j) {
+            int d = prev[j - 1] + (query[i - 1] != target[j - 1]), u = prev[j] + 1, l = cur[j - 1] + 1;
+            cur[j] = d < u ? (d < l ? d : l) : (u < l ? u : l);
+        }
+        int *t = prev; prev = cur; cur = t;
+    }
+    int best = 1 << 30, end0 = -1;
+    for (int j = 1; j <= tlen; ++j) if (prev[j] < best) { best = prev[j]; end0 = j - 1; } /* the first end position with the best score */
+    /* start: reversed query vs the reversed prefix target[0 .. end0], anchored at its first character */
+    const int plen = end0 + 1;
+    for (int j = 0; j <= plen; ++j) prev[j] = j;
+    for (int i = 1; i <= qlen; ++i) {
+        cur[0] = i;
+        for (int j = 1; j <= plen; ++j) {
+            int d = prev[j - 1] + (query[qlen - i] != target[end0 - (j - 1)]), u = prev[j] + 1, l = cur[j - 1] + 1;
+            cur[j] = d < u ? (d < l ? d : l) : (u < l ? u : l);
+        }
+        int *t = prev; prev = cur; cur = t;
+    }
+    int best2 = 1 << 30, last = -1;
+    for (int j = 1; j <= plen; ++j) { if (prev[j] < best2) { best2 = prev[j]; last = j - 1; } else if (prev[j] == best2) last = j - 1; }
+    free(prev); free(cur);
+    if (best2 != best) return -1;
+    const int start0 = end0 - last;
+    if (start_out) *start_out = start0;
+    if (end_out) *end_out = end0;
+    if (aln) {
+        opbuf_t out = {0, 0, 0};
+        if (obtain_alignment(query, qlen, target + start0, end0 - start0 + 1, best, &out) < 0) { free(out.ops); return -1; }
+        *aln = out.ops; *aln_len = out.n;
+    }
+    return best;
+}
+
+/* src/align.c:256-275 with edlibAlignmentToXID :164-187 */
+int lcdo_edlib_infix_aln(const uint8_t *target, int tlen, const uint8_t *query, int qlen, int *n_eq, int *n_xid) {
+    uint8_t *aln; int n, s0, e0;
+    int d = lcdo_edlib_hw(query, qlen, target, tlen, &s0, &e0, &aln, &n);
+    if (d < 0) return -1;
+    if (n_eq && n_xid) {
+        int eq = 0, x = 0;
+        for (int i = 0; i < n; ++i) { if (aln[i] == LCDO_EDOP_MATCH) eq++; else x++; }
+        *n_eq = eq; *n_xid = x;
+    }
+    free(aln);
+    return d;
+}

@@ -91,6 +91,9 @@ int lcdo_edlib_nw(const uint8_t *query, int qlen, const uint8_t *target, int tle
 int lcdo_edlib_xgaps(const uint8_t *target, int tlen, const uint8_t *query, int qlen);        /* src/align.c:222 */
 int lcdo_edlib_edit_distance(const uint8_t *target, int tlen, const uint8_t *query, int qlen); /* src/align.c:210 */
 int lcdo_edlib_end2end_aln(const uint8_t *target, int tlen, const uint8_t *query, int qlen, int *n_eq, int *n_xid); /* :234 */
+/* HW (infix) mode, edlibAlign(.., EDLIB_MODE_HW, EDLIB_TASK_PATH): distance, the first end position and its start in the target, the NW path of the query against that stretch */
+int lcdo_edlib_hw(const uint8_t *query, int qlen, const uint8_t *target, int tlen, int *start_out, int *end_out, uint8_t **aln, int *aln_len);
+int lcdo_edlib_infix_aln(const uint8_t *target, int tlen, const uint8_t *query, int qlen, int *n_eq, int *n_xid);   /* src/align.c:256 */
 
 /* ---------------- K3: WFA gap-affine-2p (src/align.c:374-460) ---------------- */
 /* Mirrors wfa_end2end_aln for heuristic==NONE, affine_gap==2P. cigar_buf/pattern_alg malloc'd. returns 0. */

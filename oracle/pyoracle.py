@@ -77,6 +77,7 @@ def ref_edlib():
         _ref = C.CDLL(p)
         _ref.ref_edlib_nw_path.argtypes = [u8p, C.c_int, u8p, C.c_int, u8p, C.c_int, i32p]
         _ref.ref_edlib_distance.argtypes = [u8p, C.c_int, u8p, C.c_int]
+        _ref.ref_edlib_hw_path.argtypes = [u8p, C.c_int, u8p, C.c_int, u8p, C.c_int, i32p, i32p, i32p, i32p]
     return _ref
 
 
@@ -186,6 +187,38 @@ def ref_edlib_nw(query, target):
     n = C.c_int()
     d = r.ref_edlib_nw_path(_p(q), len(q), _p(t), len(t), _p(buf), len(buf), C.byref(n))
     return d, buf[:n.value].copy()
+
+
+def ref_edlib_hw(query, target):
+    """the reference's own edlib in HW (infix) mode with the path: -> (distance, start0, end0, ops)"""
+    r = ref_edlib()
+    q, t = _c8(query), _c8(target)
+    buf = np.zeros(len(q) + len(t) + 8, np.uint8)
+    n, s0, e0, nl = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    d = r.ref_edlib_hw_path(_p(q), len(q), _p(t), len(t), _p(buf), len(buf), C.byref(n), C.byref(s0), C.byref(e0), C.byref(nl))
+    return d, s0.value, e0.value, buf[:n.value].copy()
+
+
+def edlib_hw(query, target):
+    """oracle/edlib_nw.c lcdo_edlib_hw: -> (distance, start0, end0, ops)"""
+    q, t = _c8(query), _c8(target)
+    ap, n, s0, e0 = u8p(), C.c_int(), C.c_int(), C.c_int()
+    L = lib()
+    L.lcdo_edlib_hw.argtypes = [u8p, C.c_int, u8p, C.c_int, i32p, i32p, C.POINTER(u8p), i32p]
+    d = L.lcdo_edlib_hw(_p(q), len(q), _p(t), len(t), C.byref(s0), C.byref(e0), C.byref(ap), C.byref(n))
+    ops = np.ctypeslib.as_array(ap, shape=(max(n.value, 1),))[:n.value].copy() if n.value else np.zeros(0, np.uint8)
+    if ap:
+        _libc.free(ap)
+    return d, s0.value, e0.value, ops
+
+
+def edlib_infix_aln(target, query):
+    t, q = _c8(target), _c8(query)
+    a, b = C.c_int(), C.c_int()
+    L = lib()
+    L.lcdo_edlib_infix_aln.argtypes = [u8p, C.c_int, u8p, C.c_int, i32p, i32p]
+    d = L.lcdo_edlib_infix_aln(_p(t), len(t), _p(q), len(q), C.byref(a), C.byref(b))
+    return d, a.value, b.value
 
 
 def ops_to_xgaps(ops):

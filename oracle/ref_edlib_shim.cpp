@@ -26,6 +26,22 @@ int ref_edlib_nw_path(const unsigned char *query, int qlen, const unsigned char 
     return d;
 }
 
+/* HW (infix) mode + TASK_PATH, as src/align.c:256-275 calls it: distance; start / end locations [0]; the alignment */
+int ref_edlib_hw_path(const unsigned char *query, int qlen, const unsigned char *target, int tlen,
+                      unsigned char *aln_out, int aln_cap, int *aln_len, int *start0, int *end0, int *n_locations) {
+    EdlibAlignResult r = edlibAlign((const char *)query, qlen, (const char *)target, tlen,
+                                    edlibNewAlignConfig(-1, EDLIB_MODE_HW, EDLIB_TASK_PATH, NULL, 0));
+    if (r.status != EDLIB_STATUS_OK) { edlibFreeAlignResult(r); return -1; }
+    int d = r.editDistance;
+    *aln_len = r.alignmentLength;
+    *n_locations = r.numLocations;
+    *start0 = r.numLocations > 0 && r.startLocations ? r.startLocations[0] : -1;
+    *end0 = r.numLocations > 0 && r.endLocations ? r.endLocations[0] : -1;
+    if (aln_out && r.alignmentLength <= aln_cap && r.alignment) memcpy(aln_out, r.alignment, r.alignmentLength);
+    edlibFreeAlignResult(r);
+    return d;
+}
+
 int ref_edlib_distance(const unsigned char *query, int qlen, const unsigned char *target, int tlen) {
     EdlibAlignResult r = edlibAlign((const char *)query, qlen, (const char *)target, tlen,
                                     edlibNewAlignConfig(-1, EDLIB_MODE_NW, EDLIB_TASK_DISTANCE, NULL, 0));

@@ -40,9 +40,27 @@ def main():
         d, ops = pyoracle.ref_edlib_nw(q, t)
         cases.append(dict(target="".join(map(str, t)), query="".join(map(str, q)), dist=int(d), xgaps=int(pyoracle.ops_to_xgaps(ops)),
                           n_eq=int((ops == 0).sum()), n_xid=int((ops != 0).sum()), path_sha1=hashlib.sha1(ops.tobytes()).hexdigest()))
+    # HW (infix) mode, edlib_infix_aln (src/align.c:256-275): the query is a mutated stretch of a longer target (free start / end in the target)
+    hw_cases = []
+    rng2 = np.random.default_rng(20250929)
+    for L in [1, 2, 5, 30, 63, 64, 65, 130, 400, 900, 1500, 2600]:
+        for rate in [0.0, 0.02, 0.1, 0.3]:
+            t = rng2.integers(0, 4, 3 * L + int(rng2.integers(0, 70))).astype(np.uint8)
+            a = int(rng2.integers(0, max(1, len(t) - L)))
+            q = mutate(rng2, t[a:a + L], rate)
+            if len(q) == 0:
+                q = np.array([1], np.uint8)
+            d, s0, e0, ops = pyoracle.ref_edlib_hw(q, t)
+            hw_cases.append(dict(target="".join(map(str, t)), query="".join(map(str, q)), dist=int(d), start=int(s0), end=int(e0), xgaps=int(pyoracle.ops_to_xgaps(ops)),
+                                 n_eq=int((ops == 0).sum()), n_xid=int((ops != 0).sum()), path_sha1=hashlib.sha1(ops.tobytes()).hexdigest()))
+    for t, q in [(np.zeros(300, np.uint8), np.zeros(40, np.uint8)), (np.tile(np.array([0, 1], np.uint8), 200), np.tile(np.array([0, 1, 1], np.uint8), 30)),
+                 (np.tile(np.array([2, 2, 3], np.uint8), 300), np.tile(np.array([2, 3], np.uint8), 100)), (rng2.integers(0, 4, 50).astype(np.uint8), rng2.integers(0, 4, 300).astype(np.uint8))]:
+        d, s0, e0, ops = pyoracle.ref_edlib_hw(q, t)
+        hw_cases.append(dict(target="".join(map(str, t)), query="".join(map(str, q)), dist=int(d), start=int(s0), end=int(e0), xgaps=int(pyoracle.ops_to_xgaps(ops)),
+                             n_eq=int((ops == 0).sum()), n_xid=int((ops != 0).sum()), path_sha1=hashlib.sha1(ops.tobytes()).hexdigest()))
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "edlib_golden.json")
-    json.dump(dict(source="reference edlib (edlib/src/edlib.cpp) via oracle/_ref, NW + TASK_PATH, k=-1", cases=cases), open(out, "w"))
-    print(len(cases), "cases ->", out, os.path.getsize(out), "bytes")
+    json.dump(dict(source="reference edlib (edlib/src/edlib.cpp) via oracle/_ref, NW + TASK_PATH, k=-1; hw_cases: HW + TASK_PATH", cases=cases, hw_cases=hw_cases), open(out, "w"))
+    print(len(cases), "NW cases,", len(hw_cases), "HW cases ->", out, os.path.getsize(out), "bytes")
 
 
 if __name__ == "__main__":

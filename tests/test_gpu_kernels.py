@@ -64,7 +64,7 @@ def test_edlib_kernel_matches_reference_golden_vectors(lcd):
 
 def test_align_h_wrappers(lcd, oracle):
     """the remaining exports of src/align.h: end2end_aln (:610, letters -> codes -> 2-piece WFA CIGAR) and wfa_collect_diff_ins_seq (:463, the longest
-    run of large-only columns) == the same composition over the oracle's WFA; edlib_infix_aln / wfa_heuristic_aln exist and fail loudly"""
+    run of large-only columns) == the same composition over the oracle's WFA; edlib_infix_aln == the oracle's (pinned to real edlib); wfa_heuristic_aln exists and fails loudly"""
     import ctypes as C
     from longcalld_amd import _lib
     lib = _lib.load_library()
@@ -100,9 +100,39 @@ def test_align_h_wrappers(lcd, oracle):
     assert n == best == 75 and (np.ctypeslib.as_array(ds, shape=(n,)) == la[pos:pos + best]).all()
     libc.free(ds)
     a, b = C.c_int(7), C.c_int(7)
-    assert lib.lcd_edlib_infix_aln(t.ctypes.data_as(u8p), len(t), q.ctypes.data_as(u8p), len(q), C.byref(a), C.byref(b)) == -2 and a.value == -1
-    assert b"not implemented" in lib.lcd_last_error()
+    assert lib.lcd_edlib_infix_aln(t.ctypes.data_as(u8p), len(t), q.ctypes.data_as(u8p), len(q), C.byref(a), C.byref(b)) == oracle.edlib_infix_aln(t, q)[0]
+    assert (a.value, b.value) == oracle.edlib_infix_aln(t, q)[1:]
     assert lib.lcd_wfa_heuristic_aln(t.ctypes.data_as(u8p), len(t), q.ctypes.data_as(u8p), len(q), 0, 6, 6, 2, 24, 1, C.byref(a), C.byref(b)) == -2
+
+
+def test_edlib_hw_kernel_matches_reference_golden_vectors(lcd, oracle):
+    """edlib_infix_aln (src/align.c:256-275): the HIP kernel in HW (infix) mode against vectors from the REFERENCE's own edlib (EDLIB_MODE_HW + TASK_PATH):
+    distance, the target stretch (startLocations[0], endLocations[0]) and the path-dependent counts; then more pairs against the oracle (itself pinned to edlib)"""
+    import json
+    import os
+    from conftest import ROOT
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "edlib_golden.json")))["hw_cases"]
+    arr = lambda s: np.frombuffer(s.encode(), np.uint8) - ord("0")
+    pairs = [(arr(c["target"]), arr(c["query"])) for c in cases]
+    got = lcd.edlib_batch_hw(pairs)
+    assert len(cases) >= 50
+    for i, c in enumerate(cases):
+        assert (got["dist"][i], got["start"][i], got["end"][i]) == (c["dist"], c["start"], c["end"]), i
+        assert (got["xgaps"][i], got["n_eq"][i], got["n_xid"][i]) == (c["xgaps"], c["n_eq"], c["n_xid"]), i
+    rng = np.random.default_rng(9)
+    pairs = []
+    for L in [10, 300, 1500, 4200, 6000]:          # > 4 096 query rows: more than one tile of Myers blocks; long ones take the Hirschberg regime
+        for rate in [0.01, 0.15]:
+            t = rng.integers(0, 4, L + 900).astype(np.uint8)
+            a = int(rng.integers(0, 800))
+            q = mutate(rng, t[a:a + L], rate)
+            pairs.append((t, q))
+    got = lcd.edlib_batch_hw(pairs)
+    for i, (t, q) in enumerate(pairs):
+        d, s0, e0, ops = oracle.edlib_hw(q, t)
+        assert (got["dist"][i], got["start"][i], got["end"][i]) == (d, s0, e0), i
+        assert (got["n_eq"][i], got["n_xid"][i]) == (int((ops == 0).sum()), int((ops != 0).sum())), i
+        assert lcd.edlib_infix_aln(t, q) == oracle.edlib_infix_aln(t, q)
 
 
 def test_edlib_empty(lcd):
