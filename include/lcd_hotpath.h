@@ -246,6 +246,13 @@ uint64_t lcd_batch_digest(lcd_batch_t *b);
 /* lcd_batch_region_result for every region of a downloaded batch, results freed again: the host-side cost of holding every result the way the per-call
  * mirror hands it over (malloc()'d rows), without the digest's hashing; returns the bytes of alignment rows handed out */
 uint64_t lcd_batch_materialize(lcd_batch_t *b);
+/* Every region's results of a downloaded batch in ONE host block (additive entry; the reference's contract -- one malloc() per row, freed row by row,
+ * src/collect_var.c:2670-2724 -- stays with lcd_batch_region_result).  *results_out[r] describes region r exactly as lcd_batch_region_result fills the caller's
+ * arrays: n_cons, clu_n_seqs[2], clu_read_ids[2], aln_strs[2] (each an array of n_aln_strs = 1 + 2 * n_reads zero-initialised lcd_aln_str_t: [0] ref<->cons,
+ * [2i+1] cons<->read i, [2i+2] ref<->read i).  The table, the id lists, the aln_str_t arrays and every row are INTERIOR pointers into *arena_out:
+ * free(*arena_out) releases everything and nothing inside may be freed on its own.  Filled by host threads.  Returns the number of regions, < 0 on error. */
+typedef struct lcd_region_result_t { int n_cons, n_aln_strs; int clu_n_seqs[2]; int *clu_read_ids[2]; lcd_aln_str_t *aln_strs[2]; } lcd_region_result_t;
+int lcd_batch_region_results_arena(lcd_batch_t *b, lcd_region_result_t **results_out, void **arena_out, uint64_t *arena_bytes);
 
 /* ---- SURVEY 8(f) f2, first part: EQX CIGARs -> digar lists + each read's noisy windows (additive) ----
  * == collect_digar_from_eqx_cigar (src/bam_utils.c:701-842, with push_xid_size_queue_win :161-200) for all reads of a chunk in one launch.

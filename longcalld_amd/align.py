@@ -390,6 +390,36 @@ class RegionBatch:
         return res
 
 
+    def results_arena(self, parse=True):
+        """lcd_batch_region_results_arena: every region's results in ONE host block (interior pointers, one free).  parse=True -> list of dicts like result();
+        parse=False -> (n_regions, arena bytes) -- what bench.py times"""
+        from ._lib import LcdRegionResult
+        tab = C.POINTER(LcdRegionResult)(); arena = C.c_void_p(); nbytes = C.c_uint64()
+        fn = self.lib.lcd_batch_region_results_arena
+        fn.argtypes = [C.c_void_p, C.POINTER(C.POINTER(LcdRegionResult)), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        n = check(fn(self.h, C.byref(tab), C.byref(arena), C.byref(nbytes)), self.lib)
+        if not parse:
+            _libc.free(arena)
+            return n, int(nbytes.value)
+        out = []
+        for r in range(n):
+            rr = tab[r]
+            res = dict(n_cons=rr.n_cons, clu_n_seqs=[int(rr.clu_n_seqs[0]), int(rr.clu_n_seqs[1])], clu_read_ids=[], aln_strs=[[], []])
+            for c in range(2):
+                res["clu_read_ids"].append(np.ctypeslib.as_array(rr.clu_read_ids[c], shape=(max(rr.clu_n_seqs[c], 1),))[:rr.clu_n_seqs[c]].copy() if rr.clu_read_ids[c] else None)
+                for j in range(rr.n_aln_strs):
+                    s = rr.aln_strs[c][j]
+                    if not s.target_aln:
+                        res["aln_strs"][c].append(None)
+                        continue
+                    L = s.aln_len
+                    res["aln_strs"][c].append(dict(target=np.ctypeslib.as_array(s.target_aln, shape=(max(L, 1),))[:L].copy(), query=np.ctypeslib.as_array(s.query_aln, shape=(max(L, 1),))[:L].copy(),
+                                                   aln_len=L, target_beg=s.target_beg, target_end=s.target_end, query_beg=s.query_beg, query_end=s.query_end))
+            out.append(res)
+        _libc.free(arena)
+        return out
+
+
 def make_read_views(digars, bseqs, quals, qlens, haps, phase_sets):
     """lcd_read_view_t[] over numpy storage: digars[i] = (n, 4) int64 rows (pos, type, len, qi) as digar1_t (src/bam_utils.h:27-33),
     bseqs[i] = 4-bit BAM-packed bases, quals[i] = phred bytes.  Returns (ctypes array, keep-alive list)."""

@@ -85,6 +85,25 @@ long long dev_budget(int d) {
     });
     return g_dev_budget[d].load();
 }
+// grow-only PINNED host block (hipHostMalloc): the destination of a batch's result download -- a pageable destination is staged by the runtime at a few GB/s
+struct PinnedBuf {
+    uint8_t *p = nullptr; size_t n = 0, cap = 0;
+    void resize(size_t want) {
+        if (want > cap) {
+            if (p) hipHostFree(p);
+            p = nullptr; cap = 0;
+            const size_t c = want + (want >> 2) + 4096;
+            void *q = nullptr;
+            if (hipHostMalloc(&q, c, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); q = malloc(c); pageable = true; }
+            p = (uint8_t *)q; cap = c;
+        }
+        n = want;
+    }
+    bool pageable = false;
+    uint8_t *data() { return p; } const uint8_t *data() const { return p; } size_t size() const { return n; }
+    ~PinnedBuf() { if (p) { if (pageable) free(p); else hipHostFree(p); } }
+    PinnedBuf() = default; PinnedBuf(const PinnedBuf &) = delete; PinnedBuf &operator=(const PinnedBuf &) = delete;
+};
 struct DevBuf {
     void *p = nullptr; size_t cap = 0; int dev = 0;
     int ensure(size_t n, int headroom_shift = 2) {
@@ -219,9 +238,11 @@ struct lcd_batch_s {
     std::vector<PoaChain> pchains;
     std::vector<WfaJob> rc_jobs; std::vector<WfaOut> rc_outs; // ref<->cons
     std::vector<int> rc_region, rc_clu;
+    std::vector<uint32_t> reg_rc0, reg_str0;   // [n_regions + 1]: the ref<->cons / string jobs of region r are [reg_rc0[r], reg_rc0[r + 1]) and [reg_str0[r], reg_str0[r + 1]) (jobs are made region by region)
     std::vector<StrJob> str_jobs; std::vector<StrOut> str_outs;
     std::vector<int> str_region, str_clu, str_k;
-    std::vector<uint8_t> h_final; std::vector<uint8_t> h_poa_out; std::vector<uint8_t> h_cig;
+    PinnedBuf h_final; std::vector<uint8_t> h_poa_out; std::vector<uint8_t> h_cig;
+    DevBuf d_gather, d_gather_jobs; std::vector<std::pair<int, uint32_t>> clu_index;   // download: staging block of the scattered pieces; (chain, offset into h_poa_out) of the K2 cluster lists
     std::vector<WfaJob> h_rc_all; std::vector<StrJob> h_str_all; std::vector<StrOut> h_str_outs; // leader: the joint job tables of a submission (kept between submissions: no reallocation, no first-touch page faults in the steady state)
     // ref<->read strings (opt.collect_ref_read_aln_str): per string job, rows in d_rr at rr_off (target row, query row at +rr_stride)
     std::vector<uint64_t> rr_off; std::vector<int> rr_len, rr_stride; std::vector<uint8_t> h_rr; uint64_t rr_bytes = 0;
@@ -1350,8 +1371,10 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         b->rc_jobs.clear(); b->rc_region.clear(); b->rc_clu.clear();
         b->str_jobs.clear(); b->str_region.clear(); b->str_clu.clear(); b->str_k.clear();
         uint64_t str_tot = 0;
+        b->reg_rc0.assign(b->regs.size() + 1, 0); b->reg_str0.assign(b->regs.size() + 1, 0);
         for (size_t ri = 0; ri < b->regs.size(); ++ri) {
             RegionRec &R = b->regs[ri];
+            b->reg_rc0[ri] = (uint32_t)b->rc_jobs.size(); b->reg_str0[ri] = (uint32_t)b->str_jobs.size();
             R.n_cons = 0;
             if (R.branch == 0) continue;
             S.n_regions++;
@@ -1384,6 +1407,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                 }
             }
         }
+        b->reg_rc0[b->regs.size()] = (uint32_t)b->rc_jobs.size(); b->reg_str0[b->regs.size()] = (uint32_t)b->str_jobs.size();
         str_tots[k] = str_tot;
     };
     {
@@ -1766,35 +1790,55 @@ int lcd_batch_download(lcd_batch_t *b) {
     if (vars_only) b->final_bytes = 0;
     // ref<->cons rows are appended after the strings: size the host block ONCE, before any copy is queued into it (a resize between two
     // asynchronous copies would free the destination of the first)
+    // One staging block on the device for everything that is scattered -- the ref<->cons rows (one piece per region and cluster in the WFA output buffer) and the
+    // K2 chains' cluster lists (one piece per chain in the chain-output buffer) -- filled by a gather kernel and copied to the host in ONE transfer, behind the strings
+    // in the same pinned block.  (One hipMemcpyAsync per piece: 2 700 copies of ~1 KB per batch, 25 - 40 ms.)
     uint64_t extra = 0;
     std::vector<uint64_t> rc_off(b->rc_jobs.size());
-    for (size_t i = 0; i < b->rc_jobs.size(); ++i) { rc_off[i] = b->final_bytes + extra; if (!vars_only) extra += lcd_align_up(2ull * (b->rc_jobs[i].plen + b->rc_jobs[i].tlen + 1), 16); }
-    b->h_final.resize(b->final_bytes + extra);
-    if (b->final_bytes) HIPCHK(hipMemcpyAsync(b->h_final.data(), b->d_final.p, b->final_bytes, hipMemcpyDeviceToHost, st));
-    for (size_t i = 0; i < b->rc_jobs.size() && !vars_only; ++i)
-        HIPCHK(hipMemcpyAsync(b->h_final.data() + rc_off[i], (void *)(uintptr_t)b->rc_jobs[i].out_off, 2ull * (b->rc_jobs[i].plen + b->rc_jobs[i].tlen + 1), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    b->h_rr.resize(b->rr_bytes);
-    if (b->rr_bytes) HIPCHK(hipMemcpyAsync(b->h_rr.data(), b->d_rr.p, b->rr_bytes, hipMemcpyDeviceToHost, st));
-    // cluster id lists of the K2 chains, for lcd_batch_region_result: stored as [ch:int][n:int][ids...]
+    std::vector<GatherJob> gj;
+    for (size_t i = 0; i < b->rc_jobs.size(); ++i) {
+        rc_off[i] = b->final_bytes + extra;
+        if (!vars_only) { const uint64_t nbytes = 2ull * (b->rc_jobs[i].plen + b->rc_jobs[i].tlen + 1); gj.push_back({b->rc_jobs[i].out_off, extra, (uint32_t)nbytes, 0}); extra += lcd_align_up(nbytes, 16); }
+    }
+    const uint64_t clu_base = extra;
+    b->clu_index.clear();
     {
         const int nC = (int)b->pchains.size();
-        std::vector<std::vector<int>> clu_cache(nC);
+        std::vector<char> seen((size_t)nC, 0);
         for (const RegionRec &R : b->regs) {
             if (R.branch != 2) continue;
             const int ch = R.chain[0]; const PoaChain &pc = b->pchains[ch];
-            if (!clu_cache[ch].empty()) continue;
-            clu_cache[ch].resize(2 * (size_t)pc.n_reads);
+            if (seen[ch]) continue;
+            seen[ch] = 1;
             const uint64_t clu_addr = pc.out_off + lcd_align_up((uint64_t)(pc.n_reads + 4) * pc.node_cap, 16);
-            HIPCHK(hipMemcpyAsync(clu_cache[ch].data(), (void *)(uintptr_t)clu_addr, 2 * (size_t)pc.n_reads * 4, hipMemcpyDeviceToHost, st));
+            b->clu_index.push_back({ch, (uint32_t)(extra - clu_base)});
+            gj.push_back({clu_addr, extra, (uint32_t)(2 * (size_t)pc.n_reads * 4), 0}); extra += lcd_align_up(2ull * pc.n_reads * 4, 16);
         }
-        HIPCHK(hipStreamSynchronize(st));
+    }
+    b->h_final.resize(b->final_bytes + extra);
+    if (b->final_bytes) HIPCHK(hipMemcpyAsync(b->h_final.data(), b->d_final.p, b->final_bytes, hipMemcpyDeviceToHost, st));
+    if (!gj.empty()) {
+        if (b->d_gather.ensure(extra + 64) || b->d_gather_jobs.ensure(gj.size() * sizeof(GatherJob))) return -11;
+        for (auto &g : gj) g.dst += b->d_gather.addr();
+        HIPCHK(hipMemcpyAsync(b->d_gather_jobs.p, gj.data(), gj.size() * sizeof(GatherJob), hipMemcpyHostToDevice, st));
+        lcd_launch_gather((const GatherJob *)b->d_gather_jobs.p, (int)gj.size(), st);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(b->h_final.data() + b->final_bytes, b->d_gather.p, extra, hipMemcpyDeviceToHost, st));
+    }
+    b->h_rr.resize(b->rr_bytes);
+    if (b->rr_bytes) HIPCHK(hipMemcpyAsync(b->h_rr.data(), b->d_rr.p, b->rr_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    { // the cluster lists as lcd_batch_region_result reads them: [ch:int][n:int][ids...] per chain, found through clu_index
         b->h_poa_out.clear();
-        for (int ch = 0; ch < nC; ++ch) if (!clu_cache[ch].empty()) {
-            int hdr[2] = {ch, (int)clu_cache[ch].size()};
+        for (auto &ci : b->clu_index) {
+            const PoaChain &pc = b->pchains[ci.first];
+            int hdr[2] = {ci.first, 2 * pc.n_reads};
+            const uint32_t at = (uint32_t)b->h_poa_out.size();
             const uint8_t *p = (const uint8_t *)hdr; b->h_poa_out.insert(b->h_poa_out.end(), p, p + 8);
-            p = (const uint8_t *)clu_cache[ch].data(); b->h_poa_out.insert(b->h_poa_out.end(), p, p + clu_cache[ch].size() * 4);
+            p = b->h_final.data() + b->final_bytes + clu_base + ci.second; b->h_poa_out.insert(b->h_poa_out.end(), p, p + (size_t)hdr[1] * 4);
+            ci.second = at;
         }
+        std::sort(b->clu_index.begin(), b->clu_index.end());
     }
     // remember where the ref<->cons rows are
     for (size_t i = 0; i < b->rc_jobs.size(); ++i) b->rc_jobs[i].ws_off = rc_off[i];
@@ -1804,6 +1848,13 @@ int lcd_batch_download(lcd_batch_t *b) {
 }
 
 static const std::vector<int> *clu_list(lcd_batch_t *b, int ch, std::vector<int> &tmp) {
+    { // (binary search in the index lcd_batch_download made; the linear walk below is the fallback)
+        auto it = std::lower_bound(b->clu_index.begin(), b->clu_index.end(), std::make_pair(ch, (uint32_t)0));
+        if (it != b->clu_index.end() && it->first == ch && (size_t)it->second + 8 <= b->h_poa_out.size()) {
+            int hdr[2]; memcpy(hdr, b->h_poa_out.data() + it->second, 8);
+            if (hdr[0] == ch) { tmp.resize(hdr[1]); memcpy(tmp.data(), b->h_poa_out.data() + it->second + 8, (size_t)hdr[1] * 4); return &tmp; }
+        }
+    }
     const uint8_t *p = b->h_poa_out.data(), *e = p + b->h_poa_out.size();
     while (p < e) {
         int hdr[2]; memcpy(hdr, p, 8); p += 8;
@@ -1813,7 +1864,11 @@ static const std::vector<int> *clu_list(lcd_batch_t *b, int ch, std::vector<int>
     return nullptr;
 }
 
-int lcd_batch_region_result(lcd_batch_t *b, int region, int *clu_n_seqs, int **clu_read_ids, lcd_aln_str_t **aln_strs) {
+// One region's results in the reference's layout (src/collect_var.c:2670-2724).  `take(bytes, zero)` hands out the memory: libc malloc / calloc blocks the caller
+// frees one by one (lcd_batch_region_result: the reference's ownership contract), or slices of ONE block per batch (lcd_batch_region_results_arena)
+} // extern "C"
+template <class Take>
+static int region_result_impl(lcd_batch_t *b, int region, int *clu_n_seqs, int **clu_read_ids, lcd_aln_str_t **aln_strs, Take &&take) {
     if (!b->downloaded) return set_err(-3, "lcd_batch_region_result before lcd_batch_download");
     if (b->opt.collect_noisy_vars == 2) return set_err(-5, "lcd_batch_region_result: the strings were left in HBM (opt.collect_noisy_vars == 2)");
     if (region < 0 || region >= (int)b->regs.size()) return set_err(-4, "bad region index");
@@ -1825,7 +1880,7 @@ int lcd_batch_region_result(lcd_batch_t *b, int region, int *clu_n_seqs, int **c
         for (int c = 0; c < 2; ++c) {
             const ChainRec &C = b->chains[R.chain[c]];
             clu_n_seqs[c] = (int)C.members.size();
-            clu_read_ids[c] = (int *)malloc(C.members.size() * sizeof(int));
+            clu_read_ids[c] = (int *)take(C.members.size() * sizeof(int), false);
             for (size_t k = 0; k < C.members.size(); ++k) clu_read_ids[c][k] = R.reads[C.members[k]].id;
         }
     } else {
@@ -1834,21 +1889,24 @@ int lcd_batch_region_result(lcd_batch_t *b, int region, int *clu_n_seqs, int **c
         if (co.n_cons == 2) {
             for (int c = 0; c < 2; ++c) {
                 clu_n_seqs[c] = co.clu_n[c];
-                clu_read_ids[c] = (int *)malloc((co.clu_n[c] > 0 ? co.clu_n[c] : 1) * sizeof(int));
+                clu_read_ids[c] = (int *)take((co.clu_n[c] > 0 ? co.clu_n[c] : 1) * sizeof(int), false);
                 for (int k = 0; k < co.clu_n[c]; ++k) clu_read_ids[c][k] = R.reads[C.members[(*cl)[(size_t)c * C.members.size() + k]]].id;
             }
         } else {
             clu_n_seqs[0] = (int)C.members.size();
-            clu_read_ids[0] = (int *)malloc(C.members.size() * sizeof(int));
+            clu_read_ids[0] = (int *)take(C.members.size() * sizeof(int), false);
             for (size_t k = 0; k < C.members.size(); ++k) clu_read_ids[0][k] = R.reads[C.members[k]].id;
         }
     }
     if (R.n_cons == 0) return 0;
-    for (size_t i = 0; i < b->rc_jobs.size(); ++i) {
+    const bool have_ranges = b->reg_rc0.size() == b->regs.size() + 1;   // (job ranges per region: a scan over every job of the batch for every region was most of
+    const size_t rc_lo = have_ranges ? b->reg_rc0[region] : 0, rc_hi = have_ranges ? b->reg_rc0[region + 1] : b->rc_jobs.size();  //  the 55 - 70 ms a batch's results cost)
+    const size_t st_lo = have_ranges ? b->reg_str0[region] : 0, st_hi = have_ranges ? b->reg_str0[region + 1] : b->str_jobs.size();
+    for (size_t i = rc_lo; i < rc_hi; ++i) {
         if (b->rc_region[i] != region) continue;
         const int c = b->rc_clu[i]; const WfaJob &wj = b->rc_jobs[i]; const WfaOut &wo = b->rc_outs[i];
         const int maxl = wj.plen + wj.tlen + 1; // wfa_collect_pretty_alignment layout, src/align.c:288-291
-        uint8_t *mem = (uint8_t *)calloc(2 * (size_t)maxl, 1);
+        uint8_t *mem = (uint8_t *)take(2 * (size_t)maxl, true);
         memcpy(mem, b->h_final.data() + wj.ws_off, (size_t)wo.aln_len);
         memcpy(mem + maxl, b->h_final.data() + wj.ws_off + maxl, (size_t)wo.aln_len);
         lcd_aln_str_t &s = aln_strs[c][0];
@@ -1856,24 +1914,24 @@ int lcd_batch_region_result(lcd_batch_t *b, int region, int *clu_n_seqs, int **c
         s.target_beg = 0; s.target_end = wo.aln_len - 1; s.query_beg = 0; s.query_end = wo.aln_len - 1;
     }
     const uint64_t fbase = b->d_final.addr();
-    for (size_t j = 0; j < b->str_jobs.size(); ++j) {
+    for (size_t j = st_lo; j < st_hi; ++j) {
         if (b->str_region[j] != region) continue;
         const int c = b->str_clu[j], k = b->str_k[j]; const StrJob &sj = b->str_jobs[j]; const StrOut &so = b->str_outs[j];
         const uint8_t *src = b->h_final.data() + (sj.out_off - fbase);
         lcd_aln_str_t &s = aln_strs[c][2 * k + 1];
         if (so.shift != 0) { // src/align.c:541-549: re-allocated compact block
-            uint8_t *mem = (uint8_t *)malloc((size_t)so.aln_len * 2 + 1);
+            uint8_t *mem = (uint8_t *)take((size_t)so.aln_len * 2 + 1, false);
             memcpy(mem, src + so.shift, so.aln_len); memcpy(mem + so.aln_len, src + sj.msa_len + so.shift, so.aln_len);
             s.target_aln = mem; s.query_aln = mem + so.aln_len;
         } else {
-            uint8_t *mem = (uint8_t *)malloc((size_t)sj.msa_len * 2 + 1);
+            uint8_t *mem = (uint8_t *)take((size_t)sj.msa_len * 2 + 1, false);
             memcpy(mem, src, so.aln_len > 0 ? so.aln_len : 0); memcpy(mem + sj.msa_len, src + sj.msa_len, so.aln_len > 0 ? so.aln_len : 0);
             s.target_aln = mem; s.query_aln = mem + sj.msa_len;
         }
         s.aln_len = so.aln_len; s.target_beg = so.target_beg; s.target_end = so.target_end; s.query_beg = so.query_beg; s.query_end = so.query_end;
         if (!b->rr_len.empty()) { // ref<->read string, src/align.c:1056-1062 layout: one block of 2 * (rc_len + cr_len), query row at + max_len
             const int ml = b->rr_stride[j];
-            uint8_t *mem = (uint8_t *)malloc((size_t)ml * 2 + 1);
+            uint8_t *mem = (uint8_t *)take((size_t)ml * 2 + 1, false);
             memcpy(mem, b->h_rr.data() + b->rr_off[j], (size_t)b->rr_len[j]); memcpy(mem + ml, b->h_rr.data() + b->rr_off[j] + ml, (size_t)b->rr_len[j]);
             lcd_aln_str_t &r2 = aln_strs[c][2 * k + 2];
             r2.target_aln = mem; r2.query_aln = mem + ml; r2.aln_len = b->rr_len[j];
@@ -1881,6 +1939,64 @@ int lcd_batch_region_result(lcd_batch_t *b, int region, int *clu_n_seqs, int **c
         }
     }
     return R.n_cons;
+}
+
+extern "C" {
+int lcd_batch_region_result(lcd_batch_t *b, int region, int *clu_n_seqs, int **clu_read_ids, lcd_aln_str_t **aln_strs) {
+    return region_result_impl(b, region, clu_n_seqs, clu_read_ids, aln_strs, [](size_t n, bool zero) { return zero ? calloc(n ? n : 1, 1) : malloc(n ? n : 1); });
+}
+
+// Every region's results of a batch in ONE host block (additive; the per-region entry above keeps the reference's malloc-per-row ownership): the table of
+// lcd_region_result_t, the cluster id lists, the aln_str_t arrays (1 + 2 n_reads per cluster, zeroed like the caller's calloc at src/collect_var.c:2670-2679) and
+// every alignment row live inside *arena_out; target_aln / query_aln / clu_read_ids are INTERIOR pointers -- free(*arena_out) frees everything, nothing else may be
+// freed.  Two passes: sizes (the exact bytes region_result_impl asks for), then the regions filled by host threads.
+int lcd_batch_region_results_arena(lcd_batch_t *b, lcd_region_result_t **results_out, void **arena_out, uint64_t *arena_bytes) {
+    *results_out = nullptr; *arena_out = nullptr; if (arena_bytes) *arena_bytes = 0;
+    if (!b->downloaded) return set_err(-3, "lcd_batch_region_results_arena before lcd_batch_download");
+    if (b->opt.collect_noisy_vars == 2) return set_err(-5, "lcd_batch_region_results_arena: the strings were left in HBM (opt.collect_noisy_vars == 2)");
+    const size_t nr = b->regs.size();
+    auto up = [](size_t n) { return (n + 15) & ~(size_t)15; };
+    std::vector<uint64_t> off(nr + 1, 0);
+    const size_t table = up(nr * sizeof(lcd_region_result_t));
+    // pass 1: bytes per region (a dry run of the same code with a counting allocator that returns a scratch block)
+    std::vector<uint64_t> need(nr, 0);
+    auto run = [&](const bool dry, uint8_t *base, lcd_region_result_t *tab) {
+        const int nth = (int)std::max<size_t>(1, std::min<size_t>(16, nr / 64 + 1));
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            std::vector<uint8_t> scratch; std::vector<lcd_aln_str_t> dry_as;
+            for (size_t ri; (ri = next.fetch_add(1)) < nr;) {
+                const RegionRec &R = b->regs[ri];
+                const size_t nas = 1 + 2 * (size_t)std::max(R.n_reads, 0);
+                uint64_t used = 0;
+                uint8_t *p = dry ? nullptr : base + off[ri];
+                auto take = [&](size_t n, bool zero) -> void * {
+                    const size_t a = up(n ? n : 1);
+                    void *r;
+                    if (dry) { if (scratch.size() < a) scratch.resize(a); r = scratch.data(); }
+                    else { r = p + used; if (zero) memset(r, 0, a); }
+                    used += a; return r;
+                };
+                lcd_region_result_t rr; memset(&rr, 0, sizeof(rr));
+                lcd_aln_str_t *as[2];
+                if (dry) { dry_as.assign(2 * nas, lcd_aln_str_t()); memset(dry_as.data(), 0, dry_as.size() * sizeof(lcd_aln_str_t)); as[0] = dry_as.data(); as[1] = dry_as.data() + nas; used += 2 * up(nas * sizeof(lcd_aln_str_t)); }
+                else { as[0] = (lcd_aln_str_t *)take(nas * sizeof(lcd_aln_str_t), true); as[1] = (lcd_aln_str_t *)take(nas * sizeof(lcd_aln_str_t), true); }
+                rr.n_cons = region_result_impl(b, (int)ri, rr.clu_n_seqs, rr.clu_read_ids, as, take);
+                rr.aln_strs[0] = as[0]; rr.aln_strs[1] = as[1]; rr.n_aln_strs = (int)nas;
+                if (dry) need[ri] = used; else tab[ri] = rr;
+            }
+        };
+        if (nth == 1) work();
+        else { std::vector<std::thread> ths; for (int t = 0; t < nth; ++t) ths.emplace_back(work); for (auto &t : ths) t.join(); }
+    };
+    run(true, nullptr, nullptr);
+    off[0] = table;
+    for (size_t ri = 0; ri < nr; ++ri) off[ri + 1] = off[ri] + need[ri];
+    uint8_t *arena = (uint8_t *)malloc((size_t)off[nr] + 16);
+    if (!arena) return set_err(-12, "lcd_batch_region_results_arena: out of host memory");
+    run(false, arena, (lcd_region_result_t *)arena);
+    *results_out = (lcd_region_result_t *)arena; *arena_out = arena; if (arena_bytes) *arena_bytes = off[nr];
+    return (int)nr;
 }
 
 // the outputs of make_vars_from_msa_cons_aln (src/collect_var.c:2279) for one region, from the S6 stage

@@ -12,6 +12,7 @@ void lcd_launch_wfa(const WfaJob *jobs, const uint8_t *pool, uint8_t *arena, uin
                     int n_jobs, int lds_bytes, hipStream_t stream);
 void lcd_launch_edlib(const EdJob *jobs, const uint8_t *pool, uint8_t *arena, EdOut *outs, int n_jobs, hipStream_t stream);
 void lcd_launch_strings(const StrJob *jobs, uint8_t *pool, StrOut *outs, int n_jobs, hipStream_t stream);
+void lcd_launch_gather(const GatherJob *jobs, int n_jobs, hipStream_t stream);
 void lcd_launch_compose(const CmpJob *jobs, CmpOut *outs, const CmpSeg *segs, int n_jobs, int emit, hipStream_t stream);
 void lcd_launch_vars_scan(const VarScanJob *jobs, VarScanOut *outs, int n_jobs, hipStream_t stream);
 void lcd_launch_vars_profile(const VarRegJob *jobs, VarRegOut *outs, const StrJob *sjobs, const StrOut *souts, int n_jobs, hipStream_t stream);

@@ -201,6 +201,7 @@ static inline LCD_HD WfaLayout wfa_layout(int plen, int tlen, int s_cap, int blk
 }
 
 // ---------------- edlib NW job (K4, src/align.c:222-232) ----------------
+struct GatherJob { uint64_t src, dst; uint32_t bytes, pad_; };   // strings_kernel.hip lcd_gather_kernel
 struct EdJob {
     uint64_t q_off, t_off;
     int qlen, tlen;

@@ -107,3 +107,24 @@ void lcd_launch_compose(const CmpJob *jobs, CmpOut *outs, const CmpSeg *segs, in
     if (n_jobs <= 0) return;
     hipLaunchKernelGGL(lcd_compose_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, stream, jobs, outs, segs, n_jobs, emit);
 }
+
+
+// ---- gather: many small device segments -> one contiguous staging block (lcd_batch_download: the ref<->cons rows and the K2 cluster lists of a batch are a few
+// thousand pieces of ~1 KB scattered over the WFA / chain-output buffers; one copy per piece cost 10 - 20 us each through the runtime) ----
+__global__ void __launch_bounds__(64) lcd_gather_kernel(const GatherJob *jobs, int n_jobs) {
+    const int j = blockIdx.x;
+    if (j >= n_jobs) return;
+    const GatherJob g = jobs[j];
+    const uint8_t *src = (const uint8_t *)(uintptr_t)g.src; uint8_t *dst = (uint8_t *)(uintptr_t)g.dst;
+    const unsigned n = g.bytes;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 3) == 0) {
+        const unsigned nw = n >> 2;
+        for (unsigned i = threadIdx.x; i < nw; i += 64) ((unsigned *)dst)[i] = ((const unsigned *)src)[i];
+        for (unsigned i = (nw << 2) + threadIdx.x; i < n; i += 64) dst[i] = src[i];
+    } else
+        for (unsigned i = threadIdx.x; i < n; i += 64) dst[i] = src[i];
+}
+void lcd_launch_gather(const GatherJob *jobs, int n_jobs, hipStream_t stream) {
+    if (n_jobs <= 0) return;
+    hipLaunchKernelGGL(lcd_gather_kernel, dim3(n_jobs), dim3(64), 0, stream, jobs, n_jobs);
+}

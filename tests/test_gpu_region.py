@@ -151,6 +151,30 @@ def test_run_many_equals_separate_runs(lcd):
         b.close()
 
 
+def test_results_arena_equals_per_region_results(lcd):
+    """lcd_batch_region_results_arena (one host block per batch, interior pointers, filled by host threads) hands out exactly what lcd_batch_region_result
+    hands out region by region -- cluster id lists, every aln_str_t slot (set or NULL), rows and coordinates -- on phased (K1) and unphased (K2) regions, with and
+    without the ref<->read strings"""
+    from longcalld_amd import jobs
+    for rr_on in (0, 1):
+        opt = lcd.default_opt(); opt.collect_ref_read_aln_str = rr_on
+        regs = jobs.make_regions(77 + rr_on, 40)
+        b = lcd.RegionBatch(opt)
+        for r in regs:
+            b.add_region(r)
+        b.upload(); b.run(); b.download()
+        arena = b.results_arena()
+        assert len(arena) == len(regs)
+        n_rows = 0
+        for i in range(len(regs)):
+            same_result(b.result(i), arena[i])
+            n_rows += sum(x is not None for c in range(2) for x in arena[i]["aln_strs"][c])
+        assert n_rows > 500
+        n, nbytes = b.results_arena(parse=False)
+        assert n == len(regs) and nbytes > 100000
+        b.close()
+
+
 def test_per_call_mirror(lcd, oracle):
     """lcd_collect_noisy_reg_aln_strs through chunk views: digar walk (src/align.c:1392-1458) + 4-bit base unpacking + in-place permutation"""
     import ctypes as C
