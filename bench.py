@@ -94,6 +94,80 @@ def _k4_reference(pairs, n_threads, budget_s=6.0):
     return sum(done) / el, el, sum(done)
 
 
+def job_block(n_chunks, rank, world):
+    """--job-mb: the contiguous block of chunks (genome order, src/call_var_main.c:599-621) rank `rank` of `world` generates: [lo, hi)"""
+    return rank * n_chunks // world, (rank + 1) * n_chunks // world
+
+
+def job_batches(costs, per):
+    """--job-mb: this rank's chunks (by index into its queue) heaviest first, `per` of them per batch (= one step); returns the list of index lists"""
+    order = sorted(range(len(costs)), key=lambda i: -costs[i])
+    return [order[i:i + per] for i in range(0, len(order), per)]
+
+
+def _inproc(args, align, lib, timed_regs, warm_regs, n_regions, shape, torch):
+    """--inproc: the one-process model.  Every device gets --steps batches (weak scaling, the seeds its rank would have had), already uploaded; the timed region is one
+    lcd_dispatch_run over all of them -- one submitter thread per device taking `coalesce` batches at a time from the cost-ordered queue -- between two synchronisations
+    of every device; results stay on the devices (the same clock as the per-process run)."""
+    n_dev = max(1, args.gpus)
+    if torch.cuda.device_count() < n_dev:
+        raise SystemExit(f"--inproc --gpus {n_dev}: only {torch.cuda.device_count()} device(s) visible")
+    opt = align.default_opt(); opt.collect_noisy_vars = args.vars; opt.is_ont = 0 if args.shape == "hifi" else 1
+    n_co = args.coalesce if args.coalesce > 0 else (32 if args.shape == "hifi" else 8 if args.shape == "sv" else 24)
+    n_co = max(1, min(n_co, max(args.steps, 1)))
+    per_dev = len(timed_regs) // n_dev
+    slots = []   # (device, batch)
+    for d in range(n_dev):
+        for q in range(max(args.steps, 1)):
+            slots.append((d, align.RegionBatch(opt, device=d)))
+
+    def load(regs_of):
+        for i, (d, bt) in enumerate(slots):
+            bt.clear()
+            for r in regs_of(d, i % max(args.steps, 1)):
+                bt.add_region(r)
+            bt.upload()
+
+    def sync_all():
+        for d in range(n_dev):
+            torch.cuda.synchronize(d)
+    disp = align.Dispatcher(devices=list(range(n_dev)), coalesce=n_co)
+    disp.set_flags(1)
+    n_warm = 0
+    if args.warmup:
+        load(lambda d, q: warm_regs[q % len(warm_regs)])
+        disp.run([bt for _, bt in slots]); n_warm = len(slots)
+    load(lambda d, q: timed_regs[d * per_dev + q % per_dev])
+    n_rep = args.repeats if args.repeats > 0 else (5 if args.steps <= n_co else 1)
+    reps = []
+    for _ in range(n_rep):
+        sync_all(); a0 = lib.lcd_alloc_events(); t0 = time.perf_counter()
+        dev_of = disp.run([bt for _, bt in slots])
+        sync_all(); el = time.perf_counter() - t0
+        busy, nsub = disp.busy()
+        reps.append(dict(elapsed=el, allocs=int(lib.lcd_alloc_events() - a0), busy=[round(float(x), 2) for x in busy], nsub=[int(x) for x in nsub]))
+    med = sorted(reps, key=lambda r: r["elapsed"])[(n_rep - 1) // 2]
+    sts = [bt.stats() for _, bt in slots]
+    tot_regions = float(sum(x["n_regions"] for x in sts)); tot_bases = float(sum(x["poa_aligned_bases"] for x in sts))
+    assert all(int(dev_of[i]) == slots[i][0] for i in range(len(slots)))   # a batch bound to a device stays there
+    steps = max(args.steps, 1)
+    out = {"metric": "regions_per_sec", "value": round(tot_regions / med["elapsed"], 2), "unit": "regions/s", "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup,
+           "warmup_steps_run": n_warm, "ms_per_step": round(med["elapsed"] / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+           "data": "synthetic",
+           "config": {"workload": f"configs[1] shape {shape['name']}: {n_regions} regions/step, {steps} steps per device", "regions_per_step": n_regions,
+                      "process_model": "ONE process, lcd_dispatch_run: one submitter thread per device over a cost-ordered queue (the drop-in's kt_for model)",
+                      "coalesced_steps_per_submission": n_co, "distinct_batches_per_gpu": per_dev, "sharding": "per-device seeds, no data-path collective"},
+           "poa_aligned_bases_per_sec": round(tot_bases / med["elapsed"], 1), "regions_timed": int(tot_regions),
+           "repeats": {"n": n_rep, "seconds": [round(r["elapsed"], 4) for r in reps], "reported": "median", "allocations_per_repeat": [r["allocs"] for r in reps]},
+           "dispatcher": {"busy_ms_per_device": med["busy"], "submissions_per_device": med["nsub"],
+                          "busy_over_wall": [round(x / (med["elapsed"] * 1e3), 3) for x in med["busy"]]},
+           "roofline": None, "cpu_baseline": None}
+    print(json.dumps(out), flush=True)
+    for _, bt in slots:
+        bt.close()
+    disp.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +183,8 @@ def main():
                     "every batch of a submission is a different 10 Mb of regions)")
     ap.add_argument("--repeats", type=int, default=0, help="how often the timed region (exactly --steps steps, barrier + synchronize on both sides) is run; `value` is the "
                     "MEDIAN repeat, all of them are listed (0 = 5 when the region is a single submission -- the driver's flags: 0.3 s -- else 1)")
+    ap.add_argument("--inproc", type=int, default=0, help="1: ONE process drives all --gpus devices through lcd_dispatch_run (submitter threads over one cost-ordered queue: the "
+                    "drop-in's model -- kt_for workers of one longcallD process, src/call_var_main.c:773) instead of one process per GPU; not under torchrun")
     ap.add_argument("--depth-profile", type=int, default=-1, help="also time lone submissions of 1 / 4 / 16 batches (what a caller with fewer chunks in flight gets); "
                     "-1 = on for the single-GPU HiFi run")
     ap.add_argument("--shape", default="hifi", choices=["hifi", "ont", "ont60", "sv"])
@@ -142,7 +218,7 @@ def main():
     if job_mode:
         # the job's chunks in genome order; this rank generates only its contiguous block, the rebalance epoch below moves whole chunks
         n_chunks = max(1, int(round(args.job_mb / CHUNK_MB)))
-        lo, hi = rank * n_chunks // world, (rank + 1) * n_chunks // world
+        lo, hi = job_block(n_chunks, rank, world)
         timed_seeds = [args.seed + i for i in range(lo, hi)]
         regs_per_unit = jobs.regions_for_ref_mb(CHUNK_MB)
     else:
@@ -150,6 +226,8 @@ def main():
             co_guess = args.coalesce if args.coalesce > 0 else (32 if args.shape == "hifi" else 8 if args.shape == "sv" else 24)
             args.distinct = max(10, min(co_guess, max(args.steps, 1), 32))
         timed_seeds = [args.seed + 1000 * rank + i for i in range(max(1, args.distinct))]   # weak scaling: same work per GPU, different seeds
+        if args.inproc and world == 1 and args.gpus > 1:   # one process, N devices: device d's batches are the seeds rank d would have had
+            timed_seeds = [args.seed + 1000 * d + i for d in range(args.gpus) for i in range(max(1, args.distinct))]
         regs_per_unit = n_regions
     n_warm_seeds = (6 if args.shape == "hifi" else 3) if args.warmup else 0   # (more warm-up data: the grow-only buffers see a wider sample of batch sizes before the clock starts)
     warm_seeds = [args.seed + 500000 + 1000 * rank + i for i in range(n_warm_seeds)]
@@ -161,7 +239,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    if args.gpus > 1 or world > 1:
+    if (args.gpus > 1 and not args.inproc) or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -172,6 +250,8 @@ def main():
     from longcalld_amd import align, _lib
     lib = _lib.load_library()
     _lib.check(lib.lcd_init(local_rank), lib)
+    if args.inproc and world == 1 and not job_mode:
+        return _inproc(args, align, lib, timed_regs, warm_regs, n_regions, shape, torch)
 
     bench_opt = align.default_opt()
     bench_opt.collect_noisy_vars = args.vars
@@ -199,10 +279,9 @@ def main():
             rb_stats = {"n_moves": 0, "moved_bytes": 0, "imbalance_before": max(loads) / (sum(loads) / len(loads)) if sum(loads) > 0 else 1.0, "loads_before": loads}
             rb_stats["imbalance_after"] = rb_stats["imbalance_before"]
         # this rank's chunks, heaviest first, ref-mb of them per batch (= one step)
-        queue.sort(key=lambda q: -q[0])
         per = max(1, int(round(args.ref_mb / CHUNK_MB)))
         chunks = [rb.unpack_regions(b) for _, b in queue]
-        timed_regs = [[r for ch in chunks[i:i + per] for r in ch] for i in range(0, len(chunks), per)]
+        timed_regs = [[r for i in idxs for r in chunks[i]] for idxs in job_batches([c for c, _ in queue], per)]
         args.steps = len(timed_regs)
     if args.lanes <= 0:
         args.lanes = 2 if (args.shape == "hifi" and args.coalesce <= 0 and args.steps >= 128) else 1

@@ -206,6 +206,10 @@ lcd_dispatch_t *lcd_dispatch_create(int n_devices, const int *devices, int coale
 void lcd_dispatch_destroy(lcd_dispatch_t *d);
 int lcd_dispatch_n_devices(const lcd_dispatch_t *d);
 int lcd_dispatch_run(lcd_dispatch_t *d, lcd_batch_t **batches, int n, int *device_of);
+/* flags bit 0: no lcd_batch_download after a submission (results stay on the device) */
+void lcd_dispatch_set_flags(lcd_dispatch_t *d, int flags);
+/* per device (dispatcher order): ms its submitter thread spent inside submissions during the last lcd_dispatch_run, number of submissions; returns #devices */
+int lcd_dispatch_busy(const lcd_dispatch_t *d, double *busy_ms, int *n_submissions);
 double lcd_batch_cost(const lcd_batch_t *b);   /* the work estimate the queue is ordered by (DP cells of the batch's chains) */
 /* longest-processing-time assignment of n costs to n_bins bins (static sharding across processes / ranks: bench.py --job-mb) */
 void lcd_lpt_assign(int n, const double *cost, int n_bins, int *bin_of, double *bin_load);

@@ -212,6 +212,19 @@ class Dispatcher:
         check(self.lib.lcd_dispatch_run(self.h, arr, len(batches), dev.ctypes.data_as(i32p)), self.lib)
         return dev[:len(batches)].copy()
 
+    def set_flags(self, flags):
+        """bit 0: leave the results on the device (no download after a submission)"""
+        self.lib.lcd_dispatch_set_flags.argtypes = [C.c_void_p, C.c_int]
+        self.lib.lcd_dispatch_set_flags(self.h, int(flags))
+
+    def busy(self):
+        """-> (ms inside submissions, #submissions) per device of the dispatcher, for the last run()"""
+        n = self.n_devices
+        ms = np.zeros(max(n, 1), np.float64); ns = np.zeros(max(n, 1), np.int32)
+        self.lib.lcd_dispatch_busy.argtypes = [C.c_void_p, C.POINTER(C.c_double), i32p]
+        self.lib.lcd_dispatch_busy(self.h, ms.ctypes.data_as(C.POINTER(C.c_double)), ns.ctypes.data_as(i32p))
+        return ms[:n].copy(), ns[:n].copy()
+
     def close(self):
         if self.h:
             self.lib.lcd_dispatch_destroy(self.h)

@@ -1698,7 +1698,7 @@ int lcd_batch_run(lcd_batch_t *b) { return lcd_batch_run_many(&b, 1); }
 // src/kthread.c:24-64, src/call_var_main.c:773).  Here the workers are the GPUs: the batches (host-only job buffers, LCD_DEVICE_ANY) are ordered by
 // estimated DP work, longest first, and every device thread takes the next `coalesce` of them whenever its previous submission is done --
 // upload, lcd_batch_run_many, download.  Chunks are independent until stitch_var_main: no device ever talks to another.
-struct lcd_dispatch_s { std::vector<int> devs; int coalesce; };
+struct lcd_dispatch_s { std::vector<int> devs; int coalesce; int flags = 0; std::vector<double> busy_ms; std::vector<int> n_sub; };
 static double batch_cost(const lcd_batch_t *b) { // DP cells, roughly: K1 chains = reads x length x band, K2 chains = reads x length^2
     double c = 0;
     for (const ChainRec &C : b->chains) {
@@ -1732,6 +1732,14 @@ void lcd_lpt_assign(int n, const double *cost, int n_bins, int *bin_of, double *
     for (int i : order) { int best = 0; for (int t = 1; t < n_bins; ++t) if (load[t] < load[best]) best = t; bin_of[i] = best; load[best] += cost[i]; }
     if (bin_load) for (int t = 0; t < n_bins; ++t) bin_load[t] = load[t];
 }
+// flags: bit 0 = leave the results on the device (no lcd_batch_download after a submission: a caller that times the kernels, or one that takes variants only later)
+void lcd_dispatch_set_flags(lcd_dispatch_t *d, int flags) { if (d) d->flags = flags; }
+// per device of the dispatcher (in its device order): milliseconds its submitter thread spent inside submissions during the LAST lcd_dispatch_run, and how many it made
+int lcd_dispatch_busy(const lcd_dispatch_t *d, double *busy_ms, int *n_submissions) {
+    if (!d) return 0;
+    for (size_t q = 0; q < d->busy_ms.size(); ++q) { if (busy_ms) busy_ms[q] = d->busy_ms[q]; if (n_submissions) n_submissions[q] = d->n_sub[q]; }
+    return (int)d->busy_ms.size();
+}
 int lcd_dispatch_run(lcd_dispatch_t *d, lcd_batch_t **bs, int n, int *device_of) {
     if (n <= 0) return 0;
     for (int i = 0; i < n; ++i) {
@@ -1742,6 +1750,8 @@ int lcd_dispatch_run(lcd_dispatch_t *d, lcd_batch_t **bs, int n, int *device_of)
     std::vector<double> cost(n);
     for (int i = 0; i < n; ++i) { order[i] = i; cost[i] = batch_cost(bs[i]); }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    std::map<int, int> slot_of; for (size_t q = 0; q < d->devs.size(); ++q) slot_of[d->devs[q]] = (int)q;
+    d->busy_ms.assign(d->devs.size(), 0.0); d->n_sub.assign(d->devs.size(), 0);
     std::mutex mu; size_t n_left = (size_t)n; int first_err = 0; std::string err_msg;
     std::vector<char> taken((size_t)n, 0);
     const int n_dev = (int)d->devs.size();
@@ -1765,10 +1775,12 @@ int lcd_dispatch_run(lcd_dispatch_t *d, lcd_batch_t **bs, int n, int *device_of)
                 }
             }
             if (grp.empty()) return;
+            const double tw0 = now_ms();
             int rc = 0;
             for (lcd_batch_t *b : grp) { if (b->device < 0 && (rc = bind_batch(b, dev))) break; if (!b->uploaded && (rc = lcd_batch_upload(b))) break; }
             if (!rc) rc = lcd_batch_run_many(grp.data(), (int)grp.size());
-            for (size_t i = 0; i < grp.size() && !rc; ++i) rc = lcd_batch_download(grp[i]);
+            for (size_t i = 0; i < grp.size() && !rc && !(d->flags & 1); ++i) rc = lcd_batch_download(grp[i]);
+            { std::lock_guard<std::mutex> lk(mu); d->busy_ms[slot_of[dev]] += now_ms() - tw0; d->n_sub[slot_of[dev]] += 1; }
             if (rc) { std::lock_guard<std::mutex> lk(mu); if (!first_err) { first_err = rc; err_msg = g_err; } return; }
         }
     };

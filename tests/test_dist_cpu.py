@@ -125,3 +125,32 @@ def test_lpt_assign_matches_definition():
         b = int(np.argmin(exp_load)); exp[i] = b; exp_load[b] += cost[i]
     assert (bins == exp).all() and np.allclose(load, exp_load)
     assert load.max() / load.mean() < 1.02                                    # 200 chunks on 8 GPUs: LPT is within 2 % of balanced
+
+
+def test_job_mb_block_and_batch_arithmetic_of_bench():
+    """bench.py --job-mb: every chunk of the job is generated by exactly one rank (contiguous blocks in genome order), and a rank's queue -- whatever the
+    rebalance epoch left in it -- is cut into batches that hold every chunk exactly once, heaviest first"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    from longcalld_amd import rebalance as rb
+    rng = np.random.default_rng(3)
+    for n_chunks, world in ((200, 8), (20, 8), (7, 8), (200, 1), (13, 3)):
+        blocks = [bench.job_block(n_chunks, r, world) for r in range(world)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == n_chunks and all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
+        assert max(h - l for l, h in blocks) - min(h - l for l, h in blocks) <= 1
+        costs = [list(rng.lognormal(0, 1.0, h - l)) for l, h in blocks]
+        moves, before, after = rb.plan_moves(costs, 0.02)
+        queues = [list(enumerate(c)) for c in costs]                       # (original index, cost) per rank
+        tagged = [[(r, i, c) for i, c in q] for r, q in enumerate(queues)]
+        moved = {(s_, i) for s_, i, _ in moves}
+        new_q = [[x for x in tagged[r] if (x[0], x[1]) not in moved] for r in range(world)]
+        for s_, i, d in moves:
+            new_q[d].append((s_, i, costs[s_][i]))
+        assert sorted(x[:2] for q in new_q for x in q) == sorted((r, i) for r in range(world) for i in range(len(costs[r])))   # a partition of the job's chunks
+        for q in new_q:
+            bt = bench.job_batches([x[2] for x in q], 20)
+            flat = [i for b_ in bt for i in b_]
+            assert sorted(flat) == list(range(len(q))) and all(len(b_) <= 20 for b_ in bt)
+            cs = [q[i][2] for i in flat]
+            assert cs == sorted(cs, reverse=True)
