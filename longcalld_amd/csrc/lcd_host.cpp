@@ -734,7 +734,7 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     // lean rows, all four the phases around them (4x the loads in flight).  LCD_SOLO_RL: reads x longest read from which on (0 = off); LCD_CERT_SOLO_LEN: certified-band
     // chains by read length (test switch)
     {
-        static const long long solo_rl = getenv("LCD_SOLO_RL") ? atoll(getenv("LCD_SOLO_RL")) : 100000;
+        const long long solo_rl = getenv("LCD_SOLO_RL") ? atoll(getenv("LCD_SOLO_RL")) : 100000; // (read per call: tests switch it)
         pc.solo = (C.solo >= 0 ? C.solo > 0 : (solo_rl > 0 && (long long)n * maxl >= solo_rl)) || (solo_len > 0 && pc.cert && maxl >= solo_len) ? 1 : 0;
     }
     // graph capacity: the worst case is one node per base of every read (sum), the usual case a little more than the longest read.  Sized
@@ -1102,7 +1102,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         else if (rls.size() > solo_n) { std::vector<long long> t = rls; std::nth_element(t.begin(), t.begin() + (solo_n - 1), t.end(), std::greater<long long>()); cut = std::max(cut, t[solo_n - 1]); }
         size_t q = 0;
         for (int k = 0; k < nb; ++k) for (ChainRec &C : bs[k]->chains) C.solo = rls[q++] >= cut ? 1 : 0;
-    }
+    } else for (int k = 0; k < nb; ++k) for (ChainRec &C : bs[k]->chains) C.solo = -1;
     auto size_chains = [&](const int k) { // capacities, class and output offsets of a batch's chains (independent of the other batches: host threads)
         lcd_batch_t *b = bs[k];
         const int nC = (int)b->chains.size();

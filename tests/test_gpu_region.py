@@ -459,3 +459,89 @@ def test_dp_regions_grow_in_place(lcd, oracle, monkeypatch, shape):
     monkeypatch.setenv("LCD_SPARE_GB", "0")
     _, _, st0, d0 = _run_batch(lcd, regs, o)
     assert d0 == d_ref and st0["poa_grown"] == 0 and st0["poa_retries"] > 0
+
+
+def _rows_score2p(t_row, q_row, b=6, q=6, e=2, q2=24, e2=1):
+    """penalty of an alignment given as two gapped rows (gap = 5) under the 2-piece affine model of src/align.c:392-395: mismatch b, a gap run of L columns
+    min(q + e L, q2 + e2 L); a run is a maximal stretch of gaps in ONE row"""
+    pen, i, n = 0, 0, len(t_row)
+    while i < n:
+        if t_row[i] == 5 or q_row[i] == 5:
+            which = 0 if t_row[i] == 5 else 1
+            j = i
+            while j < n and ((t_row[j] == 5) if which == 0 else (q_row[j] == 5)):
+                j += 1
+            L = j - i
+            pen += min(q + e * L, q2 + e2 * L)
+            i = j
+        else:
+            pen += b if t_row[i] != q_row[i] else 0
+            i += 1
+    return pen
+
+
+@pytest.mark.parametrize("shape,n", [("hifi", 1250), ("sv", 60)])
+def test_ref_cons_alignments_are_optimal_by_an_independent_gotoh(lcd, oracle, shape, n):
+    """K3 against a truth that is NOT the restatement: every ref<->cons alignment of a full-size batch, re-scored from the rows the HIP kernel returned, costs
+    exactly what an independent O(nm) 2-piece Gotoh DP (oracle/wfa2p.c lcdo_gotoh2p_score: no wavefronts, no backtrace) says the optimum is -- and the rows
+    de-gap to the reference slice and the consensus.  (Tie-breaks between equally optimal alignments are what stays with the restatement.)"""
+    from longcalld_amd import jobs
+    regs = jobs.make_regions(4242, n, {"hifi": jobs.HIFI, "sv": jobs.SV}[shape])
+    o = lcd.default_opt(); o.is_ont = 0 if shape == "hifi" else 1
+    got, _, st, _ = _run_batch(lcd, regs, o)
+    n_jobs, worst = 0, 0
+    for r, g in zip(regs, got):
+        for c in range(g["n_cons"]):
+            rc = g["aln_strs"][c][0]
+            t_row, q_row = rc["target"], rc["query"]
+            ref, cons = t_row[t_row != 5], q_row[q_row != 5]
+            assert ref.tobytes() == r["ref"].tobytes() and not ((t_row == 5) & (q_row == 5)).any()
+            if len(ref) * len(cons) > 40_000_000:        # (keep the O(nm) check to seconds: the longest SV regions are covered by tests/test_gpu_kernels.py)
+                continue
+            pen = _rows_score2p(t_row, q_row)
+            assert pen == oracle.gotoh2p_score(ref, cons), (len(ref), len(cons), pen)
+            n_jobs += 1; worst = max(worst, pen)
+    assert n_jobs >= (2000 if shape == "hifi" else 60) and worst > 20
+    assert st["n_regions_resolved"] >= 0.95 * len(regs)
+
+
+def test_ont_batch_rows_degap_to_their_reads_at_full_size(lcd):
+    """configs[2] at the full 1 250 regions (K1 wide bands, K2 full rows in every workgroup class, anchors): every cons<->read string de-gaps to its read and to the
+    consensus, clusters partition the reads -- properties of the OUTPUT, independent of any restatement"""
+    from longcalld_amd import jobs
+    from conftest import check_invariants
+    regs = jobs.make_regions(99, 1250, jobs.ONT)
+    o = lcd.default_opt(); o.is_ont = 1
+    got, _, st, _ = _run_batch(lcd, regs, o)
+    n_str = sum(check_invariants(r, g) for r, g in zip(regs, got))
+    assert n_str > 20000 and st["n_regions_resolved"] > 1000
+
+
+def test_certified_band_and_long_chain_class_digest_at_job_scale(lcd, monkeypatch):
+    """a configs[3]-sized sample (5 batches = 6 250 distinct regions in ONE submission): the digest over every consensus, cluster and alignment string is the same
+    with the certified band on / off and with the long chains in the 256-thread class or not (LCD_SOLO_RL) -- the joint submission, the launch-group merge
+    and the per-submission choice of long chains included"""
+    from longcalld_amd import jobs
+    batches = [jobs.make_regions(31000 + i, 1250, jobs.HIFI) for i in range(5)]
+
+    def run():
+        bs = []
+        for regs in batches:
+            b = lcd.RegionBatch()
+            for r in regs:
+                b.add_region(r)
+            b.upload(); bs.append(b)
+        lcd.RegionBatch.run_many(bs)
+        out = []
+        for b in bs:
+            b.download(); out.append(b.digest())
+        for b in bs:        # (only now: the ref<->cons rows of every batch live in the LEADER's buffers until they are downloaded)
+            b.close()
+        return out
+    ref = run()
+    monkeypatch.setenv("LCD_CERT", "0")
+    assert run() == ref
+    monkeypatch.setenv("LCD_CERT", "1"); monkeypatch.setenv("LCD_SOLO_RL", "0")
+    assert run() == ref
+    monkeypatch.setenv("LCD_SOLO_RL", "30000")
+    assert run() == ref
