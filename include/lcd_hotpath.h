@@ -332,6 +332,27 @@ int lcd_region_read_slices_batch(int n_pairs, const int *pair_read, const int64_
                                  const uint64_t *digar_off, const lcd_digar_t *digars, const int *qlen, int noisy_reg_flank_len,
                                  int *read_beg, int *read_end, int *cover);
 
+/* ---- a DEVICE-RESIDENT chunk: records -> digars -> region slices -> a batch's read bases without host round trips ----
+ * lcd_chunk_create uploads a chunk's reads ONCE (CIGARs, qualities, the records' 4-bit bases: seq_pool / seq_off as lcd_bam_load_region returns them), makes the
+ * digars (lcd_digar_batch's kernel) and KEEPS them in HBM.  The host gets what its glue needs: lcd_chunk_read_info (status / digar->beg / end / #candidates /
+ * #digars per read), lcd_chunk_intervals (the noisy windows, pointers into the handle), lcd_chunk_region_slices (per (region, read) pair the query interval and the
+ * cover flag, computed on the digars in HBM) and lcd_batch_add_region_from_chunk_dev (a region job whose read bases are unpacked on the device from the chunk at
+ * lcd_batch_upload).  No digar and no base crosses PCIe after lcd_chunk_create (lcd_copy_counters: [0] digar bytes D2H, [1] digar bytes H2D, [2] read-base bytes H2D,
+ * [3] read-base bytes D2H since process start).  Results == the host path (lcd_digar_batch -> lcd_region_read_slices_batch -> lcd_batch_add_region_from_chunk). */
+typedef struct lcd_chunk_s lcd_chunk_t;
+lcd_chunk_t *lcd_chunk_create(const lcd_digar_opt_t *opt, int n_reads, const int64_t *pos0, const uint32_t *cigar_pool, const uint64_t *cigar_off, const int *n_cigar,
+                              const uint8_t *qual_pool, const uint64_t *qual_off, const int *qlen, const uint8_t *pal_flags, const uint8_t *seq_pool,
+                              const uint64_t *seq_off, int64_t reg_beg, int64_t reg_end, int64_t whole_ref_len);
+void lcd_chunk_destroy(lcd_chunk_t *c);
+int lcd_chunk_n_reads(const lcd_chunk_t *c);
+int lcd_chunk_read_info(const lcd_chunk_t *c, int *status, int64_t *beg, int64_t *end, int *n_cand_vars, int *n_digars);
+int lcd_chunk_intervals(const lcd_chunk_t *c, const uint64_t **iv_off, const lcd_noisy_iv_t **ivs, const uint8_t **iv_in_chunk);
+int lcd_chunk_region_slices(const lcd_chunk_t *c, int n_pairs, const int *pair_read, const int64_t *pair_reg_beg, const int64_t *pair_reg_end, int noisy_reg_flank_len,
+                            int *read_beg, int *read_end, int *cover);
+int lcd_batch_add_region_from_chunk_dev(lcd_batch_t *b, const lcd_chunk_t *c, int64_t reg_beg, int64_t reg_end, int n, const int *read_ids, const int *read_beg,
+                                        const int *read_end, const int *cover, const int *haps, const int64_t *phase_sets, const uint8_t *ref_seq, int ref_seq_len);
+void lcd_copy_counters(unsigned long long out[4]);
+
 /* ---- SURVEY 8(f) f2, chunk level: pre_process_noisy_regs (src/collect_var.c:557-638) ----
  * chunk_noisy: the intervals cr_add()'ed to chunk->chunk_noisy_regs while the reads were loaded (lcd_digar_batch: ivs[k] with iv_in_chunk[k]), in
  * that order; low_comp: chunk->low_comp_cr as (start, end) pairs (sdust output, may be empty); reads in ordered_read_ids order with the skipped

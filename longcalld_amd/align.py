@@ -451,6 +451,87 @@ def make_read_views(digars, bseqs, quals, qlens, haps, phase_sets):
     return arr, keep
 
 
+def copy_counters():
+    """lcd_copy_counters: bytes of [digars D2H, digars H2D, read bases H2D, read bases D2H] since process start"""
+    lib = load_library()
+    out = (C.c_ulonglong * 4)()
+    lib.lcd_copy_counters.argtypes = [C.POINTER(C.c_ulonglong)]
+    lib.lcd_copy_counters(out)
+    return [int(x) for x in out]
+
+
+class DeviceChunk:
+    """lcd_chunk_t: a chunk's reads uploaded once; digars made and kept in HBM; region slices cut there; a batch's read bases unpacked from there"""
+
+    def __init__(self, pos0, cigars, quals, bseqs, reg_beg, reg_end, whole_ref_len, is_ont=0, pal_flags=None):
+        self.lib = lib = load_library()
+        opt = LcdDigarOpt(); lib.lcd_digar_opt_default(C.byref(opt), int(is_ont))
+        n = self.n = len(cigars)
+        cg = [np.ascontiguousarray(c, np.uint32) for c in cigars]; ql = [np.ascontiguousarray(q, np.uint8) for q in quals]; sq = [np.ascontiguousarray(x, np.uint8) for x in bseqs]
+        off = lambda xs: np.concatenate([[0], np.cumsum([len(x) for x in xs])]).astype(np.uint64)
+        coff, qoff, soff = off(cg), off(ql), off(sq)
+        cpool = np.concatenate(cg + [np.zeros(1, np.uint32)]); qpool = np.concatenate(ql + [np.zeros(1, np.uint8)]); spool = np.concatenate(sq + [np.zeros(2, np.uint8)])
+        ncig = np.array([len(c) for c in cg], np.int32); qlen = np.array([len(q) for q in ql], np.int32)
+        p0 = np.ascontiguousarray(pos0, np.int64)
+        pf = np.ascontiguousarray(pal_flags if pal_flags is not None else np.zeros(n, np.uint8), np.uint8)
+        u64p_, i64p = C.POINTER(C.c_uint64), C.POINTER(C.c_int64)
+        lib.lcd_chunk_create.restype = C.c_void_p
+        lib.lcd_chunk_create.argtypes = [C.POINTER(LcdDigarOpt), C.c_int, i64p, C.POINTER(C.c_uint32), u64p_, i32p, u8p, u64p_, i32p, u8p, u8p, u64p_, C.c_int64, C.c_int64, C.c_int64]
+        self.h = lib.lcd_chunk_create(C.byref(opt), n, p0.ctypes.data_as(i64p), cpool.ctypes.data_as(C.POINTER(C.c_uint32)), coff.ctypes.data_as(u64p_), ncig.ctypes.data_as(i32p),
+                                      _p8(qpool), qoff.ctypes.data_as(u64p_), qlen.ctypes.data_as(i32p), _p8(pf), _p8(spool), soff.ctypes.data_as(u64p_),
+                                      int(reg_beg), int(reg_end), int(whole_ref_len))
+        if not self.h:
+            raise RuntimeError("lcd_chunk_create failed: " + lib.lcd_last_error().decode())
+        self.packed_bytes = int(soff[-1])
+
+    def read_info(self):
+        n = self.n
+        st = np.zeros(n, np.int32); beg = np.zeros(n, np.int64); end = np.zeros(n, np.int64); nc = np.zeros(n, np.int32); nd = np.zeros(n, np.int32)
+        i64p = C.POINTER(C.c_int64)
+        self.lib.lcd_chunk_read_info.argtypes = [C.c_void_p, i32p, i64p, i64p, i32p, i32p]
+        self.lib.lcd_chunk_read_info(self.h, st.ctypes.data_as(i32p), beg.ctypes.data_as(i64p), end.ctypes.data_as(i64p), nc.ctypes.data_as(i32p), nd.ctypes.data_as(i32p))
+        return dict(status=st, beg=beg, end=end, n_cand=nc, n_digars=nd)
+
+    def intervals(self):
+        """-> per read (noisy (m, 3) int64 [start, end, label], in_chunk mask)"""
+        u64p_ = C.POINTER(C.c_uint64)
+        ioff, iv, inc = u64p_(), C.POINTER(LcdNoisyIv)(), u8p()
+        self.lib.lcd_chunk_intervals.argtypes = [C.c_void_p, C.POINTER(u64p_), C.POINTER(C.POINTER(LcdNoisyIv)), C.POINTER(u8p)]
+        self.lib.lcd_chunk_intervals(self.h, C.byref(ioff), C.byref(iv), C.byref(inc))
+        out = []
+        for r in range(self.n):
+            a, b = int(ioff[r]), int(ioff[r + 1])
+            out.append((np.array([[iv[k].start, iv[k].end, iv[k].label] for k in range(a, b)], np.int64).reshape(-1, 3), np.array([inc[k] for k in range(a, b)], bool)))
+        return out
+
+    def region_slices(self, pair_read, pair_beg, pair_end, flank=10):
+        pr = np.ascontiguousarray(pair_read, np.int32); pb = np.ascontiguousarray(pair_beg, np.int64); pe = np.ascontiguousarray(pair_end, np.int64)
+        n = len(pr)
+        rb = np.zeros(n, np.int32); re_ = np.zeros(n, np.int32); cv = np.zeros(n, np.int32)
+        i64p = C.POINTER(C.c_int64)
+        self.lib.lcd_chunk_region_slices.argtypes = [C.c_void_p, C.c_int, i32p, i64p, i64p, C.c_int, i32p, i32p, i32p]
+        check(self.lib.lcd_chunk_region_slices(self.h, n, pr.ctypes.data_as(i32p), pb.ctypes.data_as(i64p), pe.ctypes.data_as(i64p), int(flank),
+                                               rb.ctypes.data_as(i32p), re_.ctypes.data_as(i32p), cv.ctypes.data_as(i32p)), self.lib)
+        return rb, re_, cv
+
+    def add_region(self, batch, reg_beg, reg_end, read_ids, read_beg, read_end, cover, haps, phase_sets, ref):
+        ids = np.ascontiguousarray(read_ids, np.int32); rb = np.ascontiguousarray(read_beg, np.int32); re_ = np.ascontiguousarray(read_end, np.int32)
+        cv = np.ascontiguousarray(cover, np.int32); hp = np.ascontiguousarray(haps, np.int32); ps = np.ascontiguousarray(phase_sets, np.int64)
+        rf = np.ascontiguousarray(ref, np.uint8)
+        i64p = C.POINTER(C.c_int64)
+        self.lib.lcd_batch_add_region_from_chunk_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, i32p, i32p, i32p, i32p, i32p, i64p, u8p, C.c_int]
+        ri = check(self.lib.lcd_batch_add_region_from_chunk_dev(batch.h, self.h, int(reg_beg), int(reg_end), len(ids), ids.ctypes.data_as(i32p), rb.ctypes.data_as(i32p),
+                                                                re_.ctypes.data_as(i32p), cv.ctypes.data_as(i32p), hp.ctypes.data_as(i32p), ps.ctypes.data_as(i64p), _p8(rf), len(rf)), self.lib)
+        batch.n_reads.append(len(ids))
+        return ri
+
+    def close(self):
+        if self.h:
+            self.lib.lcd_chunk_destroy.argtypes = [C.c_void_p]
+            self.lib.lcd_chunk_destroy(self.h)
+            self.h = None
+
+
 def digar_batch(pos0, cigars, quals, reg_beg, reg_end, whole_ref_len, is_ont=0, pal_flags=None, opt=None, cs=None, md=None, seqs=None, ref=None):
     """collect_digar_from_eqx_cigar (src/bam_utils.c:701) for a list of reads on the GPU: cigars[i] = uint32 BAM CIGAR words, quals[i] = phred bytes.
     The reference's three other sources (src/collect_var.c:1072-1079): cs=[bytes, ...] -> collect_digar_from_cs_tag (:844), md=[bytes, ...] ->

@@ -76,6 +76,7 @@ int cur_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGet
 std::atomic<long long> g_dev_bytes[LCD_MAX_DEV];
 std::atomic<long long> g_dev_budget[LCD_MAX_DEV];
 std::once_flag g_budget_once[LCD_MAX_DEV];
+std::atomic<unsigned long long> g_copy_bytes[4]; // [0] digars device -> host, [1] digars host -> device, [2] read bases host -> device (packed or unpacked), [3] read bases device -> host
 std::atomic<long long> g_alloc_events{0}; // hipMalloc calls of the grow-only buffers (bench.py reports how many fell into its timed region)
 long long dev_budget(int d) {
     std::call_once(g_budget_once[d], [d] {
@@ -220,6 +221,7 @@ struct lcd_batch_s {
     hipEvent_t ev[10];
     hipEvent_t sev[LCD_NSIDE + 1];
     std::vector<uint8_t> h_pool;
+    std::vector<UnpackJob> unpack_abs; DevBuf d_unpack_abs; uint64_t pool_read_bytes = 0; // slices whose packed bases are ALREADY in HBM (lcd_chunk_t): src = device address; read bases inside h_pool (the copy counter)
     std::vector<uint8_t> h_packed; std::vector<UnpackJob> unpack_jobs; // read slices handed over 4-bit packed: unpacked into d_in after the upload
     std::vector<RegionRec> regs;
     std::vector<ChainRec> chains;
@@ -413,6 +415,7 @@ int lcd_init(int device) { // the process default device (bench.py: LOCAL_RANK);
     return 0;
 }
 long long lcd_alloc_events(void) { return g_alloc_events.load(); }
+void lcd_copy_counters(unsigned long long out[4]) { for (int i = 0; i < 4; ++i) out[i] = g_copy_bytes[i].load(); }
 long long lcd_device_bytes(int device) { return device >= 0 && device < LCD_MAX_DEV ? g_dev_bytes[device].load() : 0; }
 int lcd_device_count(void) { return init_default_device() ? 0 : g_n_devices; }
 int lcd_set_thread_device(int device) {
@@ -458,7 +461,7 @@ void lcd_batch_destroy(lcd_batch_t *b) {
     delete b;
 }
 void lcd_batch_clear(lcd_batch_t *b) {
-    b->h_pool.clear(); b->h_packed.clear(); b->unpack_jobs.clear(); b->regs.clear(); b->chains.clear(); b->preads.clear(); b->anchors.clear(); b->ed_jobs.clear(); b->wfa_jobs.clear();
+    b->h_pool.clear(); b->h_packed.clear(); b->unpack_jobs.clear(); b->unpack_abs.clear(); b->pool_read_bytes = 0; b->regs.clear(); b->chains.clear(); b->preads.clear(); b->anchors.clear(); b->ed_jobs.clear(); b->wfa_jobs.clear();
     b->uploaded = b->ran = b->downloaded = false;
     memset(&b->st, 0, sizeof(b->st));
 }
@@ -486,6 +489,7 @@ int lcd_batch_add_region(lcd_batch_t *b, int64_t reg_len, int n_reads, const int
         RegRead &r = R.reads[i];
         r.id = read_ids[i]; r.len = lens[i]; r.cover = fully_covers[i]; r.hap = haps[i]; r.ps = phase_sets[i];
         r.off = lens[i] > 0 ? pool_push(b->h_pool, seqs[i], lens[i]) : b->h_pool.size();
+        if (lens[i] > 0 && seqs[i]) b->pool_read_bytes += (uint64_t)lens[i]; // (read bases that cross PCIe inside the pool: lcd_copy_counters)
         r.err = R.sampling ? calc_read_error_rate(lens[i], quals ? quals[i] : nullptr) : 0.0;
     }
     if (n_reads <= 0) { b->regs.push_back(R); return (int)b->regs.size() - 1; }
@@ -692,6 +696,13 @@ int lcd_batch_upload(lcd_batch_t *b) {
     const double t0 = now_ms();
     if (b->d_in.ensure(b->h_pool.size() + 64)) return -11;
     HIPCHK(hipMemcpyAsync(b->d_in.p, b->h_pool.data(), b->h_pool.size(), hipMemcpyHostToDevice, b->stream));
+    g_copy_bytes[2] += b->pool_read_bytes + b->h_packed.size();
+    if (!b->unpack_abs.empty()) { // slices of a device-resident chunk: the packed bases never left HBM
+        if (b->d_unpack_abs.ensure(b->unpack_abs.size() * sizeof(UnpackJob))) return -11;
+        HIPCHK(hipMemcpyAsync(b->d_unpack_abs.p, b->unpack_abs.data(), b->unpack_abs.size() * sizeof(UnpackJob), hipMemcpyHostToDevice, b->stream));
+        lcd_launch_unpack((const UnpackJob *)b->d_unpack_abs.p, (int)b->unpack_abs.size(), nullptr, (uint8_t *)b->d_in.p, b->stream);
+        HIPCHK(hipGetLastError());
+    }
     if (!b->unpack_jobs.empty()) { // slices that came 4-bit packed: unpacked here, into their holes in the pool
         if (b->d_packed.ensure(b->h_packed.size() + 64) || b->d_unpack.ensure(b->unpack_jobs.size() * sizeof(UnpackJob))) return -11;
         HIPCHK(hipMemcpyAsync(b->d_packed.p, b->h_packed.data(), b->h_packed.size(), hipMemcpyHostToDevice, b->stream));
@@ -2376,7 +2387,7 @@ int lcd_region_read_slices_batch(int n_pairs, const int *pair_read, const int64_
     StreamGuard st; if (st.create()) return -10;
     DevBuf d_dig, d_jobs, d_outs;
     if (d_dig.ensure((nd + 1) * sizeof(DigarRec)) || d_jobs.ensure(n_pairs * sizeof(SliceJob)) || d_outs.ensure(n_pairs * sizeof(SliceOut))) return -11;
-    if (nd) HIPCHK(hipMemcpyAsync(d_dig.p, digars, nd * sizeof(DigarRec), hipMemcpyHostToDevice, st));
+    if (nd) { HIPCHK(hipMemcpyAsync(d_dig.p, digars, nd * sizeof(DigarRec), hipMemcpyHostToDevice, st)); g_copy_bytes[1] += nd * sizeof(DigarRec); }
     HIPCHK(hipMemcpyAsync(d_jobs.p, jobs.data(), n_pairs * sizeof(SliceJob), hipMemcpyHostToDevice, st));
     lcd_launch_slices((const SliceJob *)d_jobs.p, (SliceOut *)d_outs.p, (const DigarRec *)d_dig.p, noisy_reg_flank_len, n_pairs, st);
     HIPCHK(hipGetLastError());
@@ -2519,10 +2530,13 @@ struct DigarWords {
     const DevBuf *d_words = nullptr; const RefCmpOut *counts = nullptr;
     int clip_rule = 0; const int64_t *rlen_true = nullptr; const int *pre_status = nullptr;
 };
+// keep: the digars stay in HBM (a device-resident chunk, lcd_chunk_t): `keep->d_dig` receives them, nothing of them is downloaded, *digars_out stays NULL and
+// keep->slot / keep->n_digar say where read r's digars are (record index into d_dig, count)
+struct DigarKeep { DevBuf *d_dig; std::vector<uint64_t> slot; std::vector<int> n_digar; };
 int digar_batch_core(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, const DigarWords &W,
                     const uint8_t *qual_pool, const uint64_t *qual_off, const int *qlen, const uint8_t *pal_flags, int64_t reg_beg, int64_t reg_end,
                     int64_t whole_ref_len, uint64_t **digar_off_out, lcd_digar_t **digars_out, uint64_t **iv_off_out, lcd_noisy_iv_t **ivs_out,
-                    uint8_t **iv_in_chunk_out, int *status, int64_t *beg, int64_t *end, int *n_cand_vars, hipStream_t st) {
+                    uint8_t **iv_in_chunk_out, int *status, int64_t *beg, int64_t *end, int *n_cand_vars, hipStream_t st, DigarKeep *keep = nullptr) {
     const uint32_t *cigar_pool = W.h_pool; const uint64_t *cigar_off = W.off; const int *n_cigar = W.n_cigar;
     static_assert(sizeof(lcd_digar_t) == sizeof(DigarRec) && sizeof(lcd_noisy_iv_t) == sizeof(IvRec), "ABI structs mirror the device records");
     // capacities from one pass over the CIGAR words (the host has them in hand anyway), or from the rewrite's count pass
@@ -2539,7 +2553,8 @@ int digar_batch_core(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, con
         j.cigar_off = cigar_off[r] * 4; j.qual_off = qual_off[r];
         j.digar_off = dtot * sizeof(DigarRec); dtot += nd; j.iv_off = itot * sizeof(IvRec); itot += j.iv_cap; j.ev_off = etot * 16; etot += j.ev_cap;
     }
-    DevBuf d_cig, d_qual, d_jobs, d_outs, d_dig, d_iv, d_ev;
+    DevBuf d_cig, d_qual, d_jobs, d_outs, d_dig_local, d_iv, d_ev;
+    DevBuf &d_dig = keep ? *keep->d_dig : d_dig_local;
     if ((!W.d_words && d_cig.ensure(cig_words * 4 + 64)) || d_qual.ensure(qual_bytes + 64) || d_jobs.ensure(n * sizeof(DigarJob)) || d_outs.ensure(n * sizeof(DigarOut)) ||
         d_dig.ensure(dtot * sizeof(DigarRec) + 64) || d_iv.ensure(itot * sizeof(IvRec) + 64) || d_ev.ensure(etot * 16 + 64)) return -11;
     const uint64_t cig_base = W.d_words ? W.d_words->addr() : d_cig.addr();
@@ -2552,21 +2567,24 @@ int digar_batch_core(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, con
     lcd_launch_digar((const DigarJob *)d_jobs.p, (DigarOut *)d_outs.p, dopt, n, st);
     HIPCHK(hipGetLastError());
     std::vector<DigarOut> outs(n);
-    std::vector<DigarRec> hd(dtot + 1); std::vector<IvRec> hiv(itot + 1);
+    std::vector<DigarRec> hd(keep ? 1 : dtot + 1); std::vector<IvRec> hiv(itot + 1);
     HIPCHK(hipMemcpyAsync(outs.data(), d_outs.p, n * sizeof(DigarOut), hipMemcpyDeviceToHost, st));
-    if (dtot) HIPCHK(hipMemcpyAsync(hd.data(), d_dig.p, dtot * sizeof(DigarRec), hipMemcpyDeviceToHost, st));
+    if (dtot && !keep) { HIPCHK(hipMemcpyAsync(hd.data(), d_dig.p, dtot * sizeof(DigarRec), hipMemcpyDeviceToHost, st)); g_copy_bytes[0] += dtot * sizeof(DigarRec); }
     if (itot) HIPCHK(hipMemcpyAsync(hiv.data(), d_iv.p, itot * sizeof(IvRec), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     uint64_t *doff = (uint64_t *)malloc((n + 1) * sizeof(uint64_t)), *ioff = (uint64_t *)malloc((n + 1) * sizeof(uint64_t));
     uint64_t niv = 0;
     for (int r = 0; r < n; ++r) { if (outs[r].status == -3) { free(doff); free(ioff); return set_err(-24, "digar batch: capacity estimate too small"); } niv += outs[r].n_iv; }
-    lcd_digar_t *dg = (lcd_digar_t *)malloc((dtot + 1) * sizeof(lcd_digar_t));
+    lcd_digar_t *dg = keep ? nullptr : (lcd_digar_t *)malloc((dtot + 1) * sizeof(lcd_digar_t));
+    if (keep) { keep->slot.resize(n); keep->n_digar.resize(n); }
     lcd_noisy_iv_t *iv = (lcd_noisy_iv_t *)malloc((niv + 1) * sizeof(lcd_noisy_iv_t)); uint8_t *inc = (uint8_t *)calloc(niv + 1, 1);
     uint64_t dw = 0, iw = 0;
     for (int r = 0; r < n; ++r) {
         const DigarJob &j = jobs[r]; const DigarOut &o = outs[r];
         doff[r] = dw; ioff[r] = iw;
-        memcpy(dg + dw, hd.data() + (j.digar_off - d_dig.addr()) / sizeof(DigarRec), (size_t)o.n_digar * sizeof(DigarRec)); dw += o.n_digar;
+        if (keep) { keep->slot[r] = (j.digar_off - d_dig.addr()) / sizeof(DigarRec); keep->n_digar[r] = o.n_digar; }
+        else memcpy(dg + dw, hd.data() + (j.digar_off - d_dig.addr()) / sizeof(DigarRec), (size_t)o.n_digar * sizeof(DigarRec));
+        dw += o.n_digar;
         const IvRec *src = hiv.data() + (j.iv_off - d_iv.addr()) / sizeof(IvRec);
         std::vector<IvRec> v(src, src + o.n_iv);
         // cr_index (src/cgranges.c): intervals stay as added when their starts are non-decreasing, otherwise they are sorted by start --
@@ -2663,6 +2681,105 @@ int lcd_digar_batch(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, cons
     DigarWords W; W.h_pool = cigar_pool; W.off = cigar_off; W.n_cigar = n_cigar;
     return digar_batch_core(opt, n, pos0, W, qual_pool, qual_off, qlen, pal_flags, reg_beg, reg_end, whole_ref_len, digar_off_out, digars_out, iv_off_out, ivs_out,
                             iv_in_chunk_out, status, beg, end, n_cand_vars, st);
+}
+
+// ---- a DEVICE-RESIDENT chunk (SURVEY 8f f2 -> region jobs without the host round trips): the reads' CIGARs, qualities and 4-bit bases go up ONCE, the digars are
+// made and KEPT in HBM, the (region, read) slices are cut there and a batch's read slices are unpacked from there -- the host sees what its glue needs (per-read
+// status / span / candidate count, the noisy intervals: tens per read; per slice two offsets and a cover flag) and never a digar or a base.
+// Reference: collect_digar_from_eqx_cigar src/bam_utils.c:701-842, collect_noisy_read_info src/align.c:1377-1461. ----
+struct lcd_chunk_s {
+    int device = 0, n_reads = 0; lcd_digar_opt_t opt;
+    DevBuf d_dig, d_seq;                                   // digars (DigarRec, per read at slot[r], n_digar[r] of them); the records' 4-bit packed bases
+    std::vector<uint64_t> slot, seq_off; std::vector<int> n_digar, qlen;
+    std::vector<uint8_t> h_qual; std::vector<uint64_t> qual_off;   // host copy: the sampling rule of >= 10 kb regions reads qualities on the host (src/seq.c:429)
+    std::vector<int> status, n_cand; std::vector<int64_t> beg, end;
+    uint64_t *iv_off = nullptr; lcd_noisy_iv_t *ivs = nullptr; uint8_t *iv_in_chunk = nullptr;
+    ~lcd_chunk_s() { free(iv_off); free(ivs); free(iv_in_chunk); }
+};
+lcd_chunk_t *lcd_chunk_create(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, const uint32_t *cigar_pool, const uint64_t *cigar_off, const int *n_cigar,
+                              const uint8_t *qual_pool, const uint64_t *qual_off, const int *qlen, const uint8_t *pal_flags, const uint8_t *seq_pool,
+                              const uint64_t *seq_off, int64_t reg_beg, int64_t reg_end, int64_t whole_ref_len) {
+    if (ensure_init() || n <= 0) return nullptr;
+    std::unique_ptr<lcd_chunk_s> c(new lcd_chunk_s());
+    c->device = cur_device(); c->n_reads = n; c->opt = *opt;
+    c->qlen.assign(qlen, qlen + n); c->seq_off.assign(seq_off, seq_off + n); c->qual_off.assign(qual_off, qual_off + n);
+    uint64_t seq_bytes = 0, qual_bytes = 0;
+    for (int r = 0; r < n; ++r) { seq_bytes = std::max<uint64_t>(seq_bytes, seq_off[r] + (uint64_t)(qlen[r] + 1) / 2); qual_bytes = std::max<uint64_t>(qual_bytes, qual_off[r] + (uint64_t)qlen[r]); }
+    c->h_qual.assign(qual_pool, qual_pool + qual_bytes);
+    StreamGuard st; if (st.create()) return nullptr;
+    if (c->d_seq.ensure(seq_bytes + 64)) return nullptr;
+    if (hipMemcpyAsync(c->d_seq.p, seq_pool, seq_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { set_err(-10, "lcd_chunk_create: upload failed"); return nullptr; }
+    g_copy_bytes[2] += seq_bytes; // the records' bases: once per chunk, 4-bit packed
+    c->status.resize(n); c->n_cand.resize(n); c->beg.resize(n); c->end.resize(n);
+    DigarWords W; W.h_pool = cigar_pool; W.off = cigar_off; W.n_cigar = n_cigar;
+    DigarKeep keep; keep.d_dig = &c->d_dig;
+    uint64_t *doff = nullptr; lcd_digar_t *dg = nullptr;
+    const int rc = digar_batch_core(opt, n, pos0, W, qual_pool, qual_off, qlen, pal_flags, reg_beg, reg_end, whole_ref_len, &doff, &dg, &c->iv_off, &c->ivs, &c->iv_in_chunk,
+                                    c->status.data(), c->beg.data(), c->end.data(), c->n_cand.data(), st, &keep);
+    free(doff);
+    if (rc) return nullptr;
+    if (hipStreamSynchronize(st) != hipSuccess) { set_err(-10, "lcd_chunk_create: synchronize failed"); return nullptr; }
+    c->slot.swap(keep.slot); c->n_digar.swap(keep.n_digar);
+    return c.release();
+}
+void lcd_chunk_destroy(lcd_chunk_t *c) { delete c; }
+int lcd_chunk_n_reads(const lcd_chunk_t *c) { return c ? c->n_reads : 0; }
+// what collect_digar_from_eqx_cigar leaves on the host side of the reference: per read 0 / -1 (skipped as too noisy) / -2 ('M' operation), digar->beg / end, the number
+// of candidate variants; the reads' noisy windows in cr_index order (CSR; pointers into the chunk, valid until it is destroyed) and which of them enter chunk_noisy_regs
+int lcd_chunk_read_info(const lcd_chunk_t *c, int *status, int64_t *beg, int64_t *end, int *n_cand_vars, int *n_digars) {
+    for (int r = 0; r < c->n_reads; ++r) { if (status) status[r] = c->status[r]; if (beg) beg[r] = c->beg[r]; if (end) end[r] = c->end[r]; if (n_cand_vars) n_cand_vars[r] = c->n_cand[r]; if (n_digars) n_digars[r] = c->n_digar[r]; }
+    return c->n_reads;
+}
+int lcd_chunk_intervals(const lcd_chunk_t *c, const uint64_t **iv_off, const lcd_noisy_iv_t **ivs, const uint8_t **iv_in_chunk) {
+    *iv_off = c->iv_off; *ivs = c->ivs; *iv_in_chunk = c->iv_in_chunk;
+    return c->n_reads;
+}
+// collect_noisy_read_info's digar walk (src/align.c:1392-1456) for many (region, read) pairs, on the digars in HBM: out per pair the read's query interval over the
+// region and the cover flag -- 12 bytes per pair come back
+int lcd_chunk_region_slices(const lcd_chunk_t *c, int n_pairs, const int *pair_read, const int64_t *pair_reg_beg, const int64_t *pair_reg_end, int noisy_reg_flank_len,
+                            int *read_beg, int *read_end, int *cover) {
+    if (n_pairs <= 0) return 0;
+    if (use_device(c->device)) return -1;
+    std::vector<SliceJob> jobs(n_pairs);
+    for (int i = 0; i < n_pairs; ++i) {
+        const int r = pair_read[i];
+        if (r < 0 || r >= c->n_reads) return set_err(-4, "lcd_chunk_region_slices: read index out of range");
+        SliceJob &j = jobs[i]; j.digar_off = c->slot[r]; j.n_digar = c->n_digar[r]; j.qlen = c->qlen[r]; j.reg_beg = pair_reg_beg[i]; j.reg_end = pair_reg_end[i];
+    }
+    StreamGuard st; if (st.create()) return -10;
+    DevBuf d_jobs, d_outs;
+    if (d_jobs.ensure(n_pairs * sizeof(SliceJob)) || d_outs.ensure(n_pairs * sizeof(SliceOut))) return -11;
+    HIPCHK(hipMemcpyAsync(d_jobs.p, jobs.data(), n_pairs * sizeof(SliceJob), hipMemcpyHostToDevice, st));
+    lcd_launch_slices((const SliceJob *)d_jobs.p, (SliceOut *)d_outs.p, (const DigarRec *)c->d_dig.p, noisy_reg_flank_len, n_pairs, st);
+    HIPCHK(hipGetLastError());
+    std::vector<SliceOut> outs(n_pairs);
+    HIPCHK(hipMemcpyAsync(outs.data(), d_outs.p, n_pairs * sizeof(SliceOut), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < n_pairs; ++i) { read_beg[i] = outs[i].read_beg; read_end[i] = outs[i].read_end; cover[i] = outs[i].cover; }
+    return 0;
+}
+// a region of the batch from the chunk in HBM: the slices (read_beg / read_end / cover, from lcd_chunk_region_slices) give the lengths and cover flags the host
+// plans the chains with; the bases are unpacked on the device from the chunk's packed records into the batch's input pool at lcd_batch_upload -- no base crosses
+// PCIe for a region.  Otherwise lcd_batch_add_region_from_chunk (same results).  The batch must live on the chunk's device.
+int lcd_batch_add_region_from_chunk_dev(lcd_batch_t *b, const lcd_chunk_t *c, int64_t reg_beg, int64_t reg_end, int n, const int *read_ids, const int *read_beg,
+                                        const int *read_end, const int *cover, const int *haps, const int64_t *phase_sets, const uint8_t *ref_seq, int ref_seq_len) {
+    if (b->device >= 0 && b->device != c->device) return set_err(-4, "lcd_batch_add_region_from_chunk_dev: batch and chunk on different devices");
+    std::vector<int> lens(n); std::vector<const uint8_t *> sp(n, nullptr), qp(n, nullptr);
+    for (int i = 0; i < n; ++i) {
+        const int r = read_ids[i];
+        if (r < 0 || r >= c->n_reads) return set_err(-4, "lcd_batch_add_region_from_chunk_dev: read index out of range");
+        lens[i] = read_end[i] - read_beg[i] + 1;
+        qp[i] = lens[i] > 0 ? c->h_qual.data() + c->qual_off[r] + read_beg[i] : nullptr;
+    }
+    const int ri = lcd_batch_add_region(b, reg_end - reg_beg + 1, n, read_ids, lens.data(), sp.data(), qp.data(), cover, haps, phase_sets, ref_seq, ref_seq_len);
+    if (ri >= 0)
+        for (RegRead &r : b->regs[ri].reads)
+            for (int i = 0; i < n; ++i) if (read_ids[i] == r.id) {
+                r.rb = read_beg[i]; r.re = read_end[i];
+                if (r.len > 0) { UnpackJob j; j.src = c->d_seq.addr() + c->seq_off[r.id] + (uint64_t)(read_beg[i] >> 1); j.dst = r.off; j.first = read_beg[i] & 1; j.len = r.len; b->unpack_abs.push_back(j); }
+                break;
+            }
+    return ri;
 }
 
 int lcd_digar_batch_tags(const lcd_digar_opt_t *opt, int mode, int n, const int64_t *pos0, const uint32_t *cigar_pool, const uint64_t *cigar_off, const int *n_cigar,

@@ -77,3 +77,67 @@ def test_bam_records_to_variants(lcd, oracle):
     assert n_res >= len(used) // 2 and n_vars > 20
     b.close()
     del keep
+
+
+def test_chunk_handle_keeps_digars_and_bases_on_the_device(lcd, oracle):
+    """the same chain through a DEVICE-RESIDENT chunk (lcd_chunk_t): records up once, digars made and kept in HBM, (region, read) slices cut there, the batch's read
+    bases unpacked there.  Per-read info, windows, slices and every region result equal the host path and the oracle -- and the copy counters show that no digar
+    byte and no read base crossed PCIe after the chunk was created (the host path moves both)."""
+    ch = tc.Chunk()
+    o = int(ch.z["ref_beg"]); ref = ch.z["ref"]
+    reg_beg, reg_end = o, o + len(ref) - 1
+    cigs = [_cigar_of(d) for d in ch.digars]; pos0 = [int(d[0][0]) - 1 for d in ch.digars]
+    quals = [np.full(int(q), 40, np.uint8) for q in ch.qlen]
+    dg = lcd.digar_batch(pos0, cigs, quals, reg_beg, reg_end, 135086622)                   # host path, for comparison
+    c0 = lcd.copy_counters()
+    assert c0[0] > 0                                                                       # (it downloaded the digars)
+    chunk = lcd.DeviceChunk(pos0, cigs, quals, ch.bseq, reg_beg, reg_end, 135086622)
+    c1 = lcd.copy_counters()
+    assert c1[0] == c0[0] and c1[1] == c0[1] and c1[2] - c0[2] == chunk.packed_bytes       # the records' packed bases went up once; no digar came down
+    info = chunk.read_info(); ivs = chunk.intervals()
+    for i in range(ch.n_reads):
+        assert (info["status"][i], info["beg"][i], info["end"][i], info["n_cand"][i], info["n_digars"][i]) == (dg[i]["rc"], dg[i]["beg"], dg[i]["end"], dg[i]["n_cand"], len(dg[i]["digars"]))
+        assert (ivs[i][0] == dg[i]["noisy"]).all() and (ivs[i][0][ivs[i][1]] == dg[i]["chunk_noisy"]).all()
+    kept = [i for i in range(ch.n_reads) if info["status"][i] == 0]
+    chunk_noisy = np.concatenate([ivs[i][0][ivs[i][1]] for i in kept])
+    regs = lcd.pre_process_noisy_regs(chunk_noisy, np.zeros((0, 2), np.int64), [info["beg"][i] for i in kept], [info["end"][i] for i in kept], [ivs[i][0] for i in kept])
+    from longcalld_amd import jobs
+    st = lcd.assign_hap_germline(ch.hap_problem(), jobs.GERMLINE_CLEAN)
+    used, pair_read, pair_beg, pair_end = [], [], [], []
+    for s_, e_, _ in regs:
+        beg, end = int(s_) + 1 - 10, int(e_) + 10
+        if end - beg + 1 > 3000 or beg <= o or end >= reg_end:
+            continue
+        ids = np.array([i for i in kept if info["beg"][i] <= end and info["end"][i] >= beg], np.int32)
+        if len(ids) < 5:
+            continue
+        used.append((beg, end, ids)); pair_read += list(ids); pair_beg += [beg] * len(ids); pair_end += [end] * len(ids)
+    assert len(used) >= 8
+    rb, re_, cv = chunk.region_slices(pair_read, pair_beg, pair_end, 10)
+    digars4 = [d["digars"][:, :4] for d in dg]
+    for k in range(0, len(pair_read), 5):                                                  # slices == the oracle's digar walk
+        assert (rb[k], re_[k], cv[k]) == oracle.read_region_slice(digars4[pair_read[k]], ch.qlen[pair_read[k]], pair_beg[k], pair_end[k], 10)
+    opt = lcd.default_opt()
+    b = lcd.RegionBatch(opt); bh = lcd.RegionBatch(opt)
+    views, keep = lcd.make_read_views(digars4, ch.bseq, ch.qual, ch.qlen, st["haps"], st["phase_sets"])
+    at = 0
+    for beg, end, ids in used:
+        n = len(ids)
+        chunk.add_region(b, beg, end, ids, rb[at:at + n], re_[at:at + n], cv[at:at + n], st["haps"][ids], st["phase_sets"][ids], ref[beg - o:end - o + 1])
+        bh.add_region_from_chunk(views, beg, end, ids, ref[beg - o:end - o + 1], packed=True)
+        at += n
+    c2 = lcd.copy_counters()
+    b.upload(); b.run(); b.download()
+    c3 = lcd.copy_counters()
+    assert c3[0] == c2[0] and c3[1] == c2[1] and c3[2] == c2[2] and c3[3] == c2[3]         # the device-resident path: nothing of the reads crossed PCIe
+    bh.upload(); bh.run(); bh.download()
+    assert lcd.copy_counters()[2] > c3[2]                                                  # (the host path uploads the slices' bases)
+    assert b.digest() == bh.digest()
+    n_res = 0
+    for k in range(len(used)):
+        g = b.result(k)
+        same_result(bh.result(k), g)
+        n_res += g["n_cons"] > 0
+    assert n_res >= len(used) // 2
+    b.close(); bh.close(); chunk.close()
+    del keep
