@@ -48,6 +48,11 @@ def test_no_cpu_fallback_without_gpu():
         align.region_read_slices_batch([0], [100], [200], [np.array([[90, 7, 200, 0]], np.int64)], [200])
     with pytest.raises(Exception):
         align.RegionBatch()
+    with pytest.raises(Exception):   # the device-resident chunk, HW-mode edlib and the one-block results: the device or nothing
+        align.DeviceChunk([0], [np.array([(100 << 4) | 7], np.uint32)], [np.full(100, 30, np.uint8)], [np.zeros(50, np.uint8)], 1, 1000, 100000)
+    with pytest.raises(Exception):
+        align.edlib_batch_hw([(np.zeros(30, np.uint8), np.zeros(10, np.uint8))])
+    assert align.edlib_infix_aln(np.zeros(30, np.uint8), np.zeros(10, np.uint8))[0] == -1
 
 
 def test_product_does_not_import_oracle():
