@@ -185,7 +185,7 @@ struct ChainRec {
     int read0;                    // first PoaRead
     int cert_fail_round = -1;     // K2: the last round in which the certified band did not fit its class's window (the chain then moves one class up)
     int solo = -1;                // -1: by the fixed threshold (LCD_SOLO_RL); 0 / 1: decided for the submission at hand (run_many_once: the longest chains of what is in flight)
-    int cert_level = -1;          // -1: not chosen yet; 1: certified band in the 64-thread class; 2: in the 256-thread class, rows on wavefront 0 (long chains); 0: full rows
+    int cert_level = -1;          // -1: not chosen yet; 1: certified band in the single-wavefront rows; 2: in the systolic rows of the class the reads' length asks for (noisy reads); 0: full rows
 };
 struct AnchorRec {
     int pread;                    // index into preads
@@ -738,7 +738,9 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     // the same rows (poa_kernel.hip align_windowed<.., SOLO>).  Measured slower at every threshold -- 20 batches: 36 - 42 k instead of 45 k regions/s, 2 x 32
     // batches: 52 k instead of 66 k -- so it is off by default.)
     const int solo_len = getenv("LCD_CERT_SOLO_LEN") ? atoi(getenv("LCD_CERT_SOLO_LEN")) : 0; // (read per call: a test switches it)
-    if (lvl < 0) lvl = (C.mode == 1 && maxl < 65536 && (cert_mode == 2 || (cert_mode == 1 && !opt.is_ont))) ? 1 : 0;
+    // Noisy reads (level 2): the band in the systolic rows of the class the reads' length asks for (poa_kernel.hip align_certified_sys); LCD_CERT_SYS=0: full rows
+    const int cert_sys = getenv("LCD_CERT_SYS") ? atoi(getenv("LCD_CERT_SYS")) : 0; // (read per call: the tests switch it)
+    if (lvl < 0) lvl = !(C.mode == 1 && maxl < 65535) ? 0 : (cert_mode == 2 || (cert_mode == 1 && !opt.is_ont)) ? 1 : (cert_mode == 1 && cert_sys && maxl >= 256) ? 2 : 0;
     pc.cert = C.mode == 1 ? lvl : 0; pc.ring_k = 0;
     // LONG chains -- the critical path of a submission, and of a single batch: 34 reads x 4 kb run 0.28 s on one wavefront, more than half of it the per-read phases around
     // the rows (row plan, graph update, re-sort, backtrack: latency chains through L2 with 64 loads in flight) -- get a 256-thread workgroup: wavefront 0 runs the same
@@ -746,7 +748,7 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     // chains by read length (test switch)
     {
         const long long solo_rl = getenv("LCD_SOLO_RL") ? atoll(getenv("LCD_SOLO_RL")) : 100000; // (read per call: tests switch it)
-        pc.solo = (C.solo >= 0 ? C.solo > 0 : (solo_rl > 0 && (long long)n * maxl >= solo_rl)) || (solo_len > 0 && pc.cert && maxl >= solo_len) ? 1 : 0;
+        pc.solo = (C.solo >= 0 ? C.solo > 0 : (solo_rl > 0 && (long long)n * maxl >= solo_rl)) || (solo_len > 0 && pc.cert == 1 && maxl >= solo_len) ? 1 : 0;
     }
     // graph capacity: the worst case is one node per base of every read (sum), the usual case a little more than the longest read.  Sized
     // from an estimate (a few per cent of new nodes per read on top of the backbone; g_node_hint learns noisier data); a chain that runs
@@ -775,6 +777,7 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     const long long rows_est = std::min<long long>(rows_worst, (long long)(rows_f[hint] * maxl) + 64);
     long long band;
     if (C.mode == 0) band = std::min<long long>(maxl + 1, 2ll * (10 + maxl / 100) + 1 + band_x[hint]);
+    else if (pc.cert == 2) band = std::min<long long>(maxl + 1, std::max<long long>(1040, (long long)(0.6 * maxl))); // (noisy reads: intervals of a third to a half of the read)
     else if (pc.cert) { // windowed rows of <= 260 columns at 1 B of code per cell -- and room for a few reads through the generic rows (12 B per cell of intervals wider
         // than the window, poa_kernel.hip align_certified): LCD_CERT_BAND columns per row
         static const long long cert_band = getenv("LCD_CERT_BAND") ? atoll(getenv("LCD_CERT_BAND")) : 1040;
@@ -805,7 +808,7 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
 // afterwards.  Chains are launched in groups of equal (threads, LDS bucket) so that short chains do not pay a long chain's LDS.
 static void chain_class(PoaChain &pc, bool noisy) {
     // DP row width: K2 rows span the whole read (+2 guard columns of the window); K1 rows are the adaptive band plus drift
-    const long long width = pc.cert ? 256 : pc.mode == 1 ? (long long)pc.max_len + 2 : 2ll * (10 + pc.max_len / 100) + 1 + 48;
+    const long long width = pc.cert == 1 ? 256 : pc.mode == 1 ? (long long)pc.max_len + 2 : 2ll * (10 + pc.max_len / 100) + 1 + 48;
     int threads, K, wmax; // wmax: window / ring-slot width in columns, a power of two <= 4 * threads (poa_kernel.hip align_windowed)
     if (width > 256) pc.solo = 0; // (the wide classes have their own rows)
     // one lane per four columns of the window: 64 / 128 / 256 / 512 / 1024 threads, so that no wavefront of a workgroup idles
@@ -815,7 +818,7 @@ static void chain_class(PoaChain &pc, bool noisy) {
         static const int margin = getenv("LCD_BAND_MARGIN") ? atoi(getenv("LCD_BAND_MARGIN")) : 12;
         const long long bw = 2ll * (10 + pc.max_len / 100) + 1 + margin; // adaptive band + a little drift; a band that outgrows it is re-run wider
         static const int cert_ring = getenv("LCD_CERT_RING") ? atoi(getenv("LCD_CERT_RING")) : 512; // (certified-band chains: ring slots wide enough for the reads that take the generic rows)
-        wmax = pc.cert ? std::max(256, cert_ring) : pc.mode == 1 ? 256 : bw <= 60 ? 64 : bw <= 124 ? 128 : 256;
+        wmax = pc.cert == 1 ? std::max(256, cert_ring) : pc.mode == 1 ? 256 : bw <= 60 ? 64 : bw <= 124 ? 128 : 256;
         if (pc.solo) threads = 256; // (same rows, same ring layout: only the per-read phases see the other three wavefronts)
     }
     else if (width <= 512) { threads = 128; K = 2; wmax = 512; }

@@ -137,7 +137,7 @@ static inline LCD_HD PoaLayout poa_layout(int node_cap, int edge_cap, int rid_wo
     LCD_TAKE(pl_rem, (uint64_t)node_cap * 4); LCD_TAKE(pl_base, (uint64_t)node_cap);
     LCD_TAKE(e_slot, (uint64_t)edge_cap * 4);
     LCD_TAKE(aa_node, (uint64_t)(max_len + 2) * 4); LCD_TAKE(aa_flag, (uint64_t)(max_len + 2) * 4); LCD_TAKE(aa_eid, (uint64_t)(max_len + 2) * 4);
-    LCD_TAKE(tb, max_len + 2 > 4096 && !cert ? (uint64_t)node_cap * 16 : 16); // (only reads longer than one 4 096-column tile use it)
+    LCD_TAKE(tb, max_len + 2 > 4096 && cert != 1 ? (uint64_t)node_cap * 16 : 16); // (only reads longer than one 4 096-column tile use it)
     LCD_TAKE(cert, cert ? (uint64_t)node_cap * 28 : 16);
 #undef LCD_TAKE
     L.total = lcd_align_up(o, 256);

@@ -1714,7 +1714,10 @@ __device__ __forceinline__ bool poll_ge(const int *p, const int v) { // p is in 
     return true;
 }
 
-template <int NT>
+// BAND: the rows are restricted to the certified intervals of the table (g.cert hull, align_certified_sys): a wavefront whose 256 columns miss a row's interval
+// only publishes fillers to its mailboxes (a few dozen instructions instead of a row), cells of an active wavefront outside the interval are stored as fillers,
+// and a row's codes / ordinals in HBM start at the interval's 4-cell group (rbeg / rend / roff say where, as for the windowed rows).
+template <int NT, bool BAND = false>
 __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const unsigned ring_, const unsigned pd_ /* 0xffffffff: none */, const LcdScoring sc_,
                                                         const int bi_, const int ei_, const uint8_t *seq_hbm_, const int qlen_, WinOut *wo_) {
     constexpr int NW = NT / 64, K = Cfg<NT>::K;
@@ -1735,9 +1738,12 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
     // through the LDS mailboxes.  Codes / ordinals are stored row-major over the WHOLE read, so the code-driven backtrack does not know about
     // tiles; spilled value rows are per tile and only the last tile's are read afterwards (the end node looks at column qlen).
     const int n_tiles = qlen + 2 > WIN ? (qlen >> (NT == 1024 ? 12 : 30)) + 1 : 1;
-    if (n_tiles > 1 && NT != 1024) return -1;
+    if (n_tiles > 1 && (NT != 1024 || BAND)) return -1;
+    if (BAND && qlen >= 65535) return -1;
+    const int *const hull = g.cert + 6 * (size_t)g.node_cap;
+    const int seg_lo = 256 * wave, seg_hi = seg_lo + 255; // this wavefront's columns (BAND: single tile)
     const int jl = 4 * tid;                  // first of this lane's four columns inside the tile
-    const int cw4 = ((qlen >> 2) + 1) << 2;  // cells of a row in HBM, padded to the lanes' 4-cell groups
+    const int cw4_full = ((qlen >> 2) + 1) << 2;  // cells of a full row in HBM, padded to the lanes' 4-cell groups
     const unsigned long long code_cap = g.cell_cap, ord_cap = g.spill_x > 2 ? g.cell_cap : g.cell_cap / 4;
     const long long spill_rows = g.cell_cap * g.spill_x > 64 ? (long long)((g.cell_cap * g.spill_x - 64) / ((unsigned long long)SLOTW * 4)) : 0;
     {
@@ -1768,35 +1774,46 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
     const unsigned lofs = 16u * (unsigned)tid;         // this lane's 4 cells inside a plane (bytes; tile-local)
     const unsigned PL = 4u * (unsigned)WIN;            // plane stride (bytes)
     int nsp = 0;
+    int src_be = qlen << 16; // (BAND: the source row's interval)
     // ---- source row (slot 0) ----
     {
         const bool spf = (g.imap[bi] & 2) != 0;
         if (spf && spill_rows < 1) { wo->status = LCD_ERR_CELLS; return 0; }
+        int end0 = qlen;
+        if (BAND) { const int hw = usgpr(glb_ld(hull + bi)); end0 = hw >> 16; if ((hw & 65535) != 0) return -1; src_be = end0 << 16; }
         int hh[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int j = jb + k;
             const int f1 = j ? -(o1 + e1 * j) : LCD_NEG, f2 = j ? -(o2 + e2 * j) : LCD_NEG;
             hh[k] = j <= qlen ? (j ? imax(f1, f2) : 0) : LCD_GUARD;
+            if (BAND && j > end0) hh[k] = LCD_GUARD;
         }
         const int4 H4 = make_int4(hh[0], hh[1], hh[2], hh[3]);
-        const int4 A4 = make_int4(hh[0] - o1, hh[1] - o1, hh[2] - o1, hh[3] - o1), B4 = make_int4(hh[0] - o2, hh[1] - o2, hh[2] - o2, hh[3] - o2);
+        int4 A4 = make_int4(hh[0] - o1, hh[1] - o1, hh[2] - o1, hh[3] - o1), B4 = make_int4(hh[0] - o2, hh[1] - o2, hh[2] - o2, hh[3] - o2);
+        if (BAND) { // (fillers stay fillers)
+            if (jb > end0) { A4.x = LCD_GUARD; B4.x = LCD_GUARD; } if (jb + 1 > end0) { A4.y = LCD_GUARD; B4.y = LCD_GUARD; }
+            if (jb + 2 > end0) { A4.z = LCD_GUARD; B4.z = LCD_GUARD; } if (jb + 3 > end0) { A4.w = LCD_GUARD; B4.w = LCD_GUARD; }
+        }
         {
             lds_st4(ring + lofs, H4); lds_st4(ring + PL + lofs, A4); lds_st4(ring + 2 * PL + lofs, B4);
             if (spf) { int *G = g.spill; glb_st4(G + jl, H4); glb_st4(G + WIN + jl, A4); glb_st4(G + 2 * WIN + jl, B4); }
         }
         if (SYS && lane == 63) { g_wide.bndH[bi & (SYS_D - 1)][wave] = H4.w; g_wide.prog[wave] = bi; }
         if (more && tid == NT - 1) glb_st(tb_h[par] + bi, H4.w); // the source row's H at the tile's last column
-        if (tid == 0) { g.rbeg[bi] = 0; g.rend[bi] = qlen; g.roff[bi] = 0; g.ml[bi] = 0; g.mr[bi] = 0; g.spoff[bi] = 0; sm.bc[7] = LCD_OK; }
+        if (tid == 0) { g.rbeg[bi] = 0; g.rend[bi] = end0; g.roff[bi] = 0; g.ml[bi] = 0; g.mr[bi] = 0; g.spoff[bi] = 0; sm.bc[7] = LCD_OK; }
         if (spf) nsp = 1;
     }
     unsigned long long cused = 0, oused = 0;
     const unsigned long long tcols = (unsigned long long)(imin(qlen, tbase + WIN - 1) - tbase + 1);
-    ncell += tcols;
+    ncell += BAND ? (unsigned long long)(src_be >> 16) + 1 : tcols;
     __syncthreads();
     int err = LCD_OK;
     if (wave < AW) {
         int wbase = -(1 << 20);
+        int w_x = 0;     // BAND: the rows' intervals (lo | hi << 16)
+        int m_be = 1;    // BAND: lane s = interval of the row in ring slot s (lo > hi: none)
+        if (BAND) m_be = lane == 0 ? src_be : 1;
         int w_pk = 0, w_pi0 = 0, w_pi1 = 0; // w_pk: #preds (16 bits) | base << 16 | spill << 19 | unreachable << 20 | bonus0 << 21 | bonus1 << 26
         const int ke1 = e1, ke2 = e2;
         for (int idx = bi + 1; idx < ei; ++idx) {
@@ -1811,9 +1828,10 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
                     int b0 = 0, b1 = 0;
                     if (cnt > 0) { w_pi0 = glb_ld(g.pl_pidx + s0); b0 = glb_ld(g.pl_bonus + s0); }
                     if (cnt > 1) { w_pi1 = glb_ld(g.pl_pidx + s0 + 1); b1 = glb_ld(g.pl_bonus + s0 + 1); }
+                    if (BAND) w_x = glb_ld(hull + ri);
                     w_pk = imin(cnt, 65535) | (glb_ld_u8(g.pl_base + ri) << 16) | ((glb_ld_u8(g.imap + ri) & 2) << 18) | (glb_ld(g.pl_rem + ri) == (1 << 30) ? 1 << 20 : 0) | (b0 << 21) | (b1 << 26);
                 }
-                LCD_PIN(w_pk); LCD_PIN(w_pi0); LCD_PIN(w_pi1);
+                LCD_PIN(w_pk); LCD_PIN(w_pi0); LCD_PIN(w_pi1); if (BAND) LCD_PIN(w_x);
                 t_plan += (unsigned long long)(clock64() - tp0);
             }
             const int wk = idx - wbase;
@@ -1822,12 +1840,39 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
             const bool spf = (pk >> 19) & 1;
             if ((pk >> 20) & 1) { // not reachable from the begin node (sub-graph alignments only)
                 if (tid == 0) { glb_st(g.rbeg + idx, 1); glb_st(g.rend + idx, 0); }
+                if (BAND) m_be = lean_wlane(1, (idx - bi) & (K - 1), m_be);
+                if (SYS && lane == 63) *(volatile lcd_lds_i32 *)(uintptr_t)lds_off(&g_wide.prog[wave]) = idx; // (a row nobody reads is done as soon as it is passed: a long run of them must not look like a stalled neighbour)
                 continue;
+            }
+            int beg = 0, end = qlen, begc = 0;
+            if (BAND) { const int xw = LCD_RL(w_x, wk); beg = xw & 65535; end = (int)((unsigned)xw >> 16); begc = beg & ~3; }
+            const int cw4 = BAND ? ((end - begc) + 4) & ~3 : cw4_full;
+            if (BAND && beg > end) { // empty row: no cell of it can lie on an optimal path
+                if (tid == 0) { glb_st(g.rbeg + idx, 1); glb_st(g.rend + idx, 0); }
+                m_be = lean_wlane(1, (idx - bi) & (K - 1), m_be);
+                if (SYS && lane == 63) *(volatile lcd_lds_i32 *)(uintptr_t)lds_off(&g_wide.prog[wave]) = idx;
+                continue; // (nobody reads this row's mailboxes: every reader looks at the row's interval first)
             }
             // every wavefront takes the same decisions from the same plan, so an error leaves the loop in all of them at the same row
             if (cused + cw4 > code_cap || (np > 1 && oused + cw4 > ord_cap) || (spf && nsp >= spill_rows)) { err = LCD_ERR_CELLS; break; }
             if (np > 256) { err = LCD_FALLBACK; break; } // ordinals are 8 bits (and the packed plan word holds 16): generic rows
             const int s = (idx - bi) & (K - 1);
+            if (BAND && (seg_lo > end || seg_hi < begc)) { // none of this wavefront's columns is in the row's interval: fillers to the mailboxes, the row's bookkeeping, on
+                if (SYS) {
+                    if (wave + 1 < AW && !poll_ge(&g_wide.prog[wave + 1], idx - (SYS_D - K - 1))) { err = LCD_ERR_SYNC; if (lane == 0) g_smem.bc[7] = LCD_ERR_SYNC; break; }
+                    if (lane == 63) { g_wide.bndH[idx & (SYS_D - 1)][wave] = LCD_GUARD; g_wide.carry1[idx & (SYS_D - 1)][wave] = LCD_GUARD; g_wide.carry2[idx & (SYS_D - 1)][wave] = LCD_GUARD; }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 63) *(volatile lcd_lds_i32 *)(uintptr_t)lds_off(&g_wide.prog[wave]) = idx;
+                }
+                if (tid == 0) {
+                    glb_st(g.rbeg + idx, beg); glb_st(g.rend + idx, end); glb_st(g.roff + idx, (int)cused); glb_st(g.ooff + idx, (int)oused);
+                    if (spf) { glb_st(g.ml + idx, 0); glb_st(g.mr + idx, 0); glb_st(g.spoff + idx, nsp); }
+                }
+                m_be = lean_wlane(beg | (end << 16), s, m_be);
+                cused += cw4; if (np > 1) oused += cw4; if (spf) ++nsp;
+                ncell += (unsigned long long)(end - beg + 1);
+                continue;
+            }
             const long long tq0 = clock64();
             if (SYS) {
                 bool ok = true;
@@ -1847,16 +1892,27 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
             // ---- phase A: best match / E1 / E2 input of the four cells ----
             int n0, n1, n2, n3, u0, u1, u2, u3, v0, v1, v2, v3;
             int om = 0, oa = 0, ob = 0; // ordinals of the first maximum, one byte per cell
+            auto fill_row = [&](int &hm, int4 &hv, int4 &av, int4 &bv) { hm = LCD_GUARD; hv = make_int4(LCD_GUARD, LCD_GUARD, LCD_GUARD, LCD_GUARD); av = hv; bv = hv; };
             auto near_row = [&](const int pi, int &hm, int4 &hv, int4 &av, int4 &bv) {
+                if (BAND) { // the slot holds this wavefront's columns of row pi only if they met that row's interval
+                    const int be = LCD_RL(m_be, (pi - bi) & (K - 1)), pb = be & 65535, pe = (int)((unsigned)be >> 16);
+                    if (pb > pe || seg_lo > pe || seg_hi < (pb & ~3)) { fill_row(hm, hv, av, bv); return; }
+                }
                 const unsigned S = ring + 4u * (unsigned)(((pi - bi) & (K - 1)) * SLOTW);
                 hm = lds_ld(S + lofs - 4); hv = lds_ld4(S + lofs); av = lds_ld4(S + PL + lofs); bv = lds_ld4(S + 2 * PL + lofs);
                 if (lane == 0) hm = wave == 0 ? (tile ? glb_ld(tb_h[par ^ 1] + pi) : LCD_GUARD) : (SYS ? g_wide.bndH[pi & (SYS_D - 1)][wave - 1] : hm);
             };
             auto far_row = [&](const int pi, int &hm, int4 &hv, int4 &av, int4 &bv) {
+                int pb = 0, pe = qlen;
+                if (BAND) {
+                    const int be = usgpr(glb_ld(hull + pi)); pb = be & 65535; pe = (int)((unsigned)be >> 16);
+                    if (pb > pe || seg_lo > pe || seg_hi < (pb & ~3)) { fill_row(hm, hv, av, bv); return; }
+                }
                 const int *G = g.spill + (size_t)(unsigned)glb_ld((const int *)g.spoff + pi) * SLOTW;
                 hm = tid ? glb_ld(G + jl - 1) : (tile ? glb_ld(tb_h[par ^ 1] + pi) : LCD_GUARD); hv = glb_ld4(G + jl); av = glb_ld4(G + WIN + jl); bv = glb_ld4(G + 2 * WIN + jl);
                 LCD_PIN(hm); LCD_PIN(hv.x); LCD_PIN(hv.y); LCD_PIN(hv.z); LCD_PIN(hv.w); LCD_PIN(av.x); LCD_PIN(av.y); LCD_PIN(av.z); LCD_PIN(av.w);
                 LCD_PIN(bv.x); LCD_PIN(bv.y); LCD_PIN(bv.z); LCD_PIN(bv.w);
+                if (BAND && (jb - 1 < pb || jb - 1 > pe)) hm = LCD_GUARD; // (lane 0: the left neighbour's column, written only if it met the row's interval)
             };
             if (np == 1 && d0 <= K) {
                 int hm; int4 hv, av, bv;
@@ -1893,8 +1949,9 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
             // which of match / E1 / E2 gives Hpre (the oracle's priority): used when H == Hpre
             const int sp0 = n0 == h0 ? 0 : u0 == h0 ? 1 : 2, sp1 = n1 == h1 ? 0 : u1 == h1 ? 1 : 2, sp2 = n2 == h2 ? 0 : u2 == h2 ? 1 : 2, sp3 = n3 == h3 ? 0 : u3 == h3 ? 1 : 2;
             // ---- F: A[k] = Hpre[k] + k*e; in-lane inclusive prefix, one scan pair over the lane totals, carry from the left wavefront ----
-            const int a10 = h0 + je1, a11 = h1 + je1 + ke1, a12 = h2 + je1 + 2 * ke1, a13 = h3 + je1 + 3 * ke1;
-            const int a20 = h0 + je2, a21 = h1 + je2 + ke2, a22 = h2 + je2 + 2 * ke2, a23 = h3 + je2 + 3 * ke2;
+            const bool i0 = !BAND || (jb >= beg && jb <= end), i1 = !BAND || (jb + 1 >= beg && jb + 1 <= end), i2 = !BAND || (jb + 2 >= beg && jb + 2 <= end), i3 = !BAND || (jb + 3 >= beg && jb + 3 <= end);
+            const int a10 = i0 ? h0 + je1 : LCD_GUARD, a11 = i1 ? h1 + je1 + ke1 : LCD_GUARD, a12 = i2 ? h2 + je1 + 2 * ke1 : LCD_GUARD, a13 = i3 ? h3 + je1 + 3 * ke1 : LCD_GUARD;
+            const int a20 = i0 ? h0 + je2 : LCD_GUARD, a21 = i1 ? h1 + je2 + ke2 : LCD_GUARD, a22 = i2 ? h2 + je2 + 2 * ke2 : LCD_GUARD, a23 = i3 ? h3 + je2 + 3 * ke2 : LCD_GUARD;
             const int p10 = a10, p11 = imax(p10, a11), p12 = imax(p11, a12);
             const int p20 = a20, p21 = imax(p20, a21), p22 = imax(p21, a22);
             int t1 = imax(p12, a13), t2 = imax(p22, a23);
@@ -1924,22 +1981,29 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
             LCD_CELL(2, h2, sp2, u2, v2, imax(x1, p11), imax(x2, p21), a12, a22, hh2, ea2, eb2)
             LCD_CELL(3, h3, sp3, u3, v3, imax(x1, p12), imax(x2, p22), a13, a23, hh3, ea3, eb3)
 #undef LCD_CELL
+            if (BAND) { // cells outside the interval are fillers; cells inside keep to the value range (>= LCD_NEG: a cell whose predecessors are all fillers)
+                hh0 = i0 ? imax(hh0, LCD_NEG) : LCD_GUARD; ea0 = i0 ? imax(ea0, LCD_NEG) : LCD_GUARD; eb0 = i0 ? imax(eb0, LCD_NEG) : LCD_GUARD;
+                hh1 = i1 ? imax(hh1, LCD_NEG) : LCD_GUARD; ea1 = i1 ? imax(ea1, LCD_NEG) : LCD_GUARD; eb1 = i1 ? imax(eb1, LCD_NEG) : LCD_GUARD;
+                hh2 = i2 ? imax(hh2, LCD_NEG) : LCD_GUARD; ea2 = i2 ? imax(ea2, LCD_NEG) : LCD_GUARD; eb2 = i2 ? imax(eb2, LCD_NEG) : LCD_GUARD;
+                hh3 = i3 ? imax(hh3, LCD_NEG) : LCD_GUARD; ea3 = i3 ? imax(ea3, LCD_NEG) : LCD_GUARD; eb3 = i3 ? imax(eb3, LCD_NEG) : LCD_GUARD;
+            }
             // ---- stores: ring slot (values), HBM (codes; values only for rows a far successor / the end node will read) ----
             const int4 H4 = make_int4(hh0, hh1, hh2, hh3), A4 = make_int4(ea0, ea1, ea2, ea3), B4 = make_int4(eb0, eb1, eb2, eb3);
             {
                 const unsigned S = ring + 4u * (unsigned)(s * SLOTW);
                 lds_st4(S + lofs, H4); lds_st4(S + PL + lofs, A4); lds_st4(S + 2 * PL + lofs, B4);
                 if (spf) { int *G = g.spill + (size_t)nsp * SLOTW; glb_st4(G + jl, H4); glb_st4(G + WIN + jl, A4); glb_st4(G + 2 * WIN + jl, B4); }
-                if (jb < cw4) {
-                    glb_st(g.code8 + cused + jb, (int)code);
-                    if (np > 1) glb_st4(g.ord + oused + jb, make_int4((om & 255) | ((oa & 255) << 8) | ((ob & 255) << 16),
+                if (BAND ? (jb >= begc && jb - begc < cw4) : jb < cw4) {
+                    const int jo = jb - begc; // (begc = 0 without a band)
+                    glb_st(g.code8 + cused + jo, (int)code);
+                    if (np > 1) glb_st4(g.ord + oused + jo, make_int4((om & 255) | ((oa & 255) << 8) | ((ob & 255) << 16),
                                                                          ((om >> 8) & 255) | (((oa >> 8) & 255) << 8) | (((ob >> 8) & 255) << 16),
                                                                          ((om >> 16) & 255) | (((oa >> 16) & 255) << 8) | (((ob >> 16) & 255) << 16),
                                                                          ((om >> 24) & 255) | (((oa >> 24) & 255) << 8) | (((ob >> 24) & 255) << 16)));
                 }
             }
             if (tid == 0) {
-                glb_st(g.rbeg + idx, 0); glb_st(g.rend + idx, qlen); glb_st(g.roff + idx, (int)cused); glb_st(g.ooff + idx, (int)oused);
+                glb_st(g.rbeg + idx, beg); glb_st(g.rend + idx, end); glb_st(g.roff + idx, (int)cused); glb_st(g.ooff + idx, (int)oused);
                 if (spf) { glb_st(g.ml + idx, 0); glb_st(g.mr + idx, 0); glb_st(g.spoff + idx, nsp); }
             }
             if (SYS) {
@@ -1952,8 +2016,9 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
                 if (spf) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 63) *(volatile lcd_lds_i32 *)(uintptr_t)lds_off(&g_wide.prog[wave]) = idx; // (LDS-typed: a generic volatile store is a flat store + vmcnt(0))
             }
+            if (BAND) m_be = lean_wlane(beg | (end << 16), s, m_be);
             cused += cw4; if (np > 1) oused += cw4; if (spf) ++nsp;
-            ncell += tcols;
+            ncell += BAND ? (unsigned long long)(end - beg + 1) : tcols;
         }
     }
     if (tid == 0 && err != LCD_OK) sm.bc[7] = err;
@@ -1969,6 +2034,7 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
     const int n_cig = sm.bc[0];
     wo->status = sm.bc[1];
     wo->cig_pos = sm.bc[4];
+    wo->score = sm.bc[5];
     wo->t_plan = sm.prof[0]; wo->t_poll = sm.prof[1];
     __syncthreads();
     wo->t_bt = (unsigned long long)(clock64() - t_bt0);
@@ -2330,6 +2396,54 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
             return leave(nc);
 }
 
+// The certified band of a NOISY read's K2 alignment is wider than any single wavefront's window (a third to a half of the read), so those chains stay in the class
+// their reads' length asks for and run the systolic rows over the intervals (align_unbanded<NT, true>): same bound, same guess-and-verify loop as align_certified,
+// no window to fit.  Returns the number of cigar entries, 0 with g.status set, or -3: not here (the caller's full rows take the read).
+template <int NT>
+__device__ __attribute__((noinline)) int align_certified_sys(Ctx *gp, const unsigned ro, const unsigned pdo, const LcdScoring sc, const int bi, const int ei,
+                                                             const uint8_t *seq_hbm, const int qlen, unsigned long long *cells_acc) {
+    Smem &sm = g_smem;
+    Ctx &g = *gp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (qlen >= 65535 || ei - bi < 2 || qlen + 2 > 4 * NT) return -3;
+    const long long tca0 = clock64();
+    if (wave == 0) cert_node_arrays(&g, bi, ei);
+    __syncthreads();
+    g.t_plan += (unsigned long long)(clock64() - tca0);
+    const unsigned long long cells_before = *cells_acc;
+    const int ubtop = cert_ubtop(g, ei, qlen, sc);
+    int delta = g.cert_hist < 0 ? 48 + qlen / 8 : g.cert_hist + g.cert_hist / 4 + 32; // (first read of a chain of noisy reads: every eighth base an error's worth of slack)
+    int sbest = LCD_NEG, nc = 0;
+    bool done = false;
+    WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0; wo.t_plan = wo.t_poll = 0; wo.score = LCD_NEG; wo.t_setup = 0;
+    for (int attempt = 0; attempt < 12 && !done; ++attempt, delta *= 2) {
+        const int sest = imax(sbest, ubtop - delta);
+        const long long th0 = clock64();
+        if (wave == 0) { const int m = cert_hull(&g, bi, ei, qlen, sest, sc); if (lane == 0) sm.bc[6] = m; }
+        __syncthreads();
+        const int mw = sm.bc[6];
+        __syncthreads();
+        g.t_poll += (unsigned long long)(clock64() - th0);
+        if (mw < 0) continue; // not even the source row qualifies: the guess is above the optimum
+        wo.status = g.status; wo.score = LCD_NEG; wo.t_dp = wo.t_bt = wo.cells = 0;
+        nc = align_unbanded<NT, true>(&g, ro, pdo, sc, bi, ei, seq_hbm, qlen, &wo);
+        if (nc < 0) return -3;
+        if (wo.status != LCD_OK) { g.status = wo.status; return 0; }
+        g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells;
+        const int S = wo.score;
+        if (S > LCD_NEG / 2) {
+            sbest = imax(sbest, S);
+            if (S >= sest) { done = true; g.cert_hist = imax(g.cert_hist, ubtop - S); }
+        }
+        __syncthreads();
+    }
+    if (!done) return -3;
+    g.alg_adjust += (long long)(ei - bi) * (qlen + 1) - (long long)(*cells_acc - cells_before); // what the full rows would have counted for this read
+    g.status = wo.status;
+    g.cig_node = g.cig_node0 + wo.cig_pos; g.cig_qpos = g.cig_qpos0 + wo.cig_pos;
+    return nc;
+}
+
 // the generic rows' end node + value backtrack (one thread, serial): a function of its own -- inlined, its loops were part of the chain kernel's body, which is what
 // spills (the same build with a call inside this block had 70 instead of 400 spilled VGPRs in the 64-thread kernel and ran 5 % faster).  Returns the
 // number of cigar entries; *best_out = the end cell's score.
@@ -2457,7 +2571,12 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
         const unsigned pdo = pd ? lds_off(pd) : 0xffffffffu, ro = lds_off(ring), so = lds_off(sseq);
         int nc = -1;
         bool to_generic_rows = false;
-        if constexpr (NT <= 256) if (wb < 0 && g.cert_on) {
+        if (wb < 0 && g.cert_on == 2) {
+            const int r = align_certified_sys<NT>(&g, ro, pdo, sc, bi, ei, seq_hbm, qlen, cells_acc);
+            if (r != -3) return r;
+            __syncthreads();
+        }
+        if constexpr (NT <= 256) if (wb < 0 && g.cert_on == 1) {
             const int r = align_certified<NT>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, cells_acc);
             if (r != -2) return r;
             to_generic_rows = true; // (g.cert_generic is set: the rows below take their intervals from the table)
@@ -2775,7 +2894,7 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
 // allocation; the host resets the pool between rounds).  false: no pool, pool exhausted, or the region already at its worst case.
 template <int NT>
 __device__ __attribute__((noinline)) bool grow_dp_region(Ctx &g, Smem &sm, const PoaChain &ch, PoaSpare *sp) {
-    if (!sp || ch.cert) return false;
+    if (!sp || ch.cert == 1) return false;
     const unsigned long long worst = (unsigned long long)g.node_cap * (unsigned long long)(ch.max_len + 1);
     if (g.cell_cap >= worst) return false;
     unsigned long long nc = g.cell_cap * 4ull; if (nc > worst) nc = worst;
@@ -3045,7 +3164,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.pl_rem = (int *)(ws + L.pl_rem); g.pl_base = ws + L.pl_base;
     g.e_slot = (int *)(ws + L.e_slot); g.plan_valid = 0; g.plan_bi = g.plan_ei = g.plan_rend = 0;
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
-    g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0; g.cert_generic = 0; g.cert_generic_seen = 0; g.cert_sest = 0; g.cert_ubtop = 0; g.cert_cells0 = 0;
+    g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = ch.cert == 2 ? 2 : NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0; g.cert_generic = 0; g.cert_generic_seen = 0; g.cert_sest = 0; g.cert_ubtop = 0; g.cert_cells0 = 0;
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
     g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - ring_k * 3 * ring_cols) * 4; g.ring_k = ring_k; g.plan_k = (NT == 64 || ch.solo) && ring_k > 2 && ch.wmax < 256 ? 2 : ring_k; // (slots beyond 2 of a chain laid out for a narrow window: not there when a read needs a wider one)
     g.solo = NT == 256 ? ch.solo : 0; g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0; g.t_bp = 0; g.t_setup = 0;

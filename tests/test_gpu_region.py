@@ -434,6 +434,23 @@ def test_certified_band_equals_full_rows_at_scale(lcd, monkeypatch):
     assert st1["poa_cells_computed"] * 2 < st0["poa_cells_computed"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,n", [("ont", 300), ("sv", 24)])
+def test_certified_band_in_the_systolic_rows_equals_full_rows(lcd, monkeypatch, shape, n):
+    """noisy reads: the K2 chains' certified band runs in the multi-wavefront (systolic) rows of the class the reads' length asks for (default; LCD_CERT_SYS=0:
+    full rows) -- the same digest over every consensus, cluster and alignment string, the same cells of the reference's algorithm accounted, fewer computed"""
+    from longcalld_amd import jobs
+    regs = jobs.make_regions(4242, n, jobs.ONT if shape == "ont" else jobs.SV)
+    o = lcd.default_opt(); o.is_ont = 1
+    monkeypatch.setenv("LCD_CERT_SYS", "1")
+    _, _, st1, d1 = _run_batch(lcd, regs, o)
+    monkeypatch.setenv("LCD_CERT_SYS", "0")
+    _, _, st0, d0 = _run_batch(lcd, regs, o)
+    assert d1 == d0
+    assert st1["poa_cells"] == st0["poa_cells"]
+    assert st1["poa_cells_computed"] < st0["poa_cells_computed"]
+
+
 @pytest.mark.parametrize("shape", ["hifi", "ont", "sv"])
 def test_dp_regions_grow_in_place(lcd, oracle, monkeypatch, shape):
     """DP regions sized far too small (test switch LCD_CELL_SHRINK): a chain whose read does not fit takes a larger region from the launch set's spare pool and
