@@ -463,6 +463,23 @@ int lcd_bam_load_region(const char *bam_path, const char *chrom, int64_t reg_beg
  * chunks are read and inflated -- what sam_itr_queryi does for the reference (src/bam_utils.c:1673) */
 int lcd_bam_load_region_indexed(const char *bam_path, const char *bai_path, const char *chrom, int64_t reg_beg, int64_t reg_end, int min_mapq, lcd_bam_reads_t *out);
 void lcd_bam_reads_free(lcd_bam_reads_t *r);
+/* BGZF blocks inflated ON THE DEVICE (inflate_kernel.hip) -- what bgzf_read_block + zlib's inflate do for the reference one block at a time on the calling thread
+ * (htslib behind sam_itr_next, src/bam_utils.c:1673-1675).  `file` is an image of a BGZF file or of a run of whole blocks (e.g. a .bai chunk): the block table
+ * comes from the BSIZE fields on the host (a hop per block), the compressed bytes are uploaded once, every block is one wavefront (dynamic / fixed / stored
+ * deflate blocks, decode tables and the 32 KB history in LDS), and the inflated stream -- the blocks' outputs back to back, exactly the bytes bgzf_read
+ * delivers -- stays in HBM: lcd_inflated_dev_ptr / lcd_inflated_size.  verify_crc != 0 checks every block's CRC-32 on the device (ISIZE is always checked).
+ * Returns NULL on a malformed container / deflate stream / CRC mismatch (lcd_io_last_error() names the block) and when there is no HIP device: this entry
+ * point has no host path (lcd_bam_load_region inflates on host threads).  lcd_inflated_to_host copies a range of the stream back (the record walk of a
+ * loader, tests); lcd_inflated_kernel_ms / lcd_inflated_upload_ms: HIP-event times of the decode kernel and of the upload, for the measurement. */
+typedef struct lcd_inflated_s lcd_inflated_t;
+lcd_inflated_t *lcd_bgzf_inflate_dev(const uint8_t *file, size_t n, int verify_crc);
+uint64_t lcd_inflated_dev_ptr(const lcd_inflated_t *h);
+size_t lcd_inflated_size(const lcd_inflated_t *h);
+size_t lcd_inflated_n_blocks(const lcd_inflated_t *h);
+double lcd_inflated_kernel_ms(const lcd_inflated_t *h);
+double lcd_inflated_upload_ms(const lcd_inflated_t *h);
+int lcd_inflated_to_host(const lcd_inflated_t *h, size_t off, size_t n, uint8_t *out);
+void lcd_inflated_free(lcd_inflated_t *h);
 /* faidx_fetch_seq of chrom:[beg, end] (1-based inclusive, clipped to the contig) through <fa_path>.fai, as byte codes A0 C1 G2 T3 N4 (get_bam_chunk_reg_ref_seq0,
  * src/bam_utils.c:1558); returns the length, *codes_out malloc()'d */
 int64_t lcd_fasta_fetch(const char *fa_path, const char *chrom, int64_t beg, int64_t end, uint8_t **codes_out);

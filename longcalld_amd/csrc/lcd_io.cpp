@@ -8,6 +8,7 @@
 //   * FASTA + .fai: faidx_fetch_seq of a region as byte codes (nst_nt4_table).
 //   * the VCF header lines of write_vcf_header (src/vcf_utils.c:17-96).  htslib's bcf_hdr_write decides their final order and adds
 //     ##fileformat itself; that library is absent, so the header text is this project's rendering (the BODY lines are lcd_format_vcf's, exact).
+#include <hip/hip_runtime.h>
 #include <zlib.h>
 #include <algorithm>
 #include <atomic>
@@ -32,9 +33,11 @@ int read_file(const char *path, std::vector<uint8_t> &buf) {
     fclose(f);
     return got == buf.size() ? 0 : io_err(-30, std::string("short read on ") + path);
 }
-struct Blk { size_t cdata, clen, uoff, ulen; };
-// BGZF: gzip members with an extra field 'B','C',2,BSIZE (total block size - 1); ISIZE (last 4 bytes) = uncompressed length
-int bgzf_blocks(const std::vector<uint8_t> &f, std::vector<Blk> &blks, size_t *total) {
+struct Blk { size_t cdata, clen, uoff, ulen; uint32_t crc; };
+// a view of the file image (the loaders hold it in a vector, lcd_bgzf_inflate_dev gets the caller's bytes)
+struct Bytes { const uint8_t *p; size_t n; size_t size() const { return n; } const uint8_t &operator[](size_t i) const { return p[i]; } };
+// BGZF: gzip members with an extra field 'B','C',2,BSIZE (total block size - 1); CRC32 and ISIZE (uncompressed length) are the last 8 bytes
+int bgzf_blocks(const Bytes f, std::vector<Blk> &blks, size_t *total) {
     size_t o = 0, u = 0;
     while (o + 18 <= f.size()) {
         if (f[o] != 31 || f[o + 1] != 139 || f[o + 2] != 8 || !(f[o + 3] & 4)) return io_err(-31, "not a BGZF block");
@@ -49,6 +52,8 @@ int bgzf_blocks(const std::vector<uint8_t> &f, std::vector<Blk> &blks, size_t *t
         const size_t end = o + bsize + 1;
         const unsigned isize = f[end - 4] | (f[end - 3] << 8) | (f[end - 2] << 16) | ((unsigned)f[end - 1] << 24);
         Blk b; b.cdata = o + 12 + xlen; b.clen = end - 8 - b.cdata; b.uoff = u; b.ulen = isize;
+        b.crc = f[end - 8] | (f[end - 7] << 8) | (f[end - 6] << 16) | ((uint32_t)f[end - 5] << 24);
+        if (end < 8 + b.cdata || isize > 65536) return io_err(-31, "malformed BGZF block");
         if (isize) blks.push_back(b);
         u += isize; o = end;
     }
@@ -57,7 +62,7 @@ int bgzf_blocks(const std::vector<uint8_t> &f, std::vector<Blk> &blks, size_t *t
 }
 int bgzf_inflate_all(const std::vector<uint8_t> &f, std::vector<uint8_t> &out, int n_threads) {
     std::vector<Blk> blks; size_t total = 0;
-    if (int rc = bgzf_blocks(f, blks, &total)) return rc;
+    if (int rc = bgzf_blocks(Bytes{f.data(), f.size()}, blks, &total)) return rc;
     out.resize(total);
     std::atomic<size_t> next{0}; std::atomic<int> bad{0};
     auto work = [&]() {
@@ -389,4 +394,83 @@ int lcd_vcf_header(const char *source_version, const char *cmdline, const char *
     *text_out = o;
     return (int)std::count(t.begin(), t.end(), '\n');
 }
+
+// ---- BGZF blocks inflated on the device (inflate_kernel.hip): one upload of the compressed bytes, one wavefront per block, the inflated stream stays in HBM ----
+struct InflateJobH { unsigned long long src, dst; unsigned clen, ulen, crc, pad_; };
+struct InflateOutH { int status; unsigned crc; unsigned ulen; unsigned pad_; };
+} // extern "C"
+void lcd_launch_inflate(const void *jobs, void *outs, int n_jobs, int verify, hipStream_t stream);
+void lcd_inflate_set_x2n(const unsigned *t32, hipStream_t st);
+namespace {
+unsigned gf2_mulmod_h(unsigned a, unsigned b) { unsigned m = 1u << 31, p = 0; for (;;) { if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; } m >>= 1; b = (b & 1) ? (b >> 1) ^ 0xedb88320u : b >> 1; } return p; }
 }
+struct lcd_inflated_s { void *d_in = nullptr, *d_out = nullptr, *d_jobs = nullptr, *d_outs = nullptr; size_t total = 0, n_blocks = 0, comp_bytes = 0; double ms_kernel = 0, ms_h2d = 0; };
+extern "C" {
+#define IOHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { io_err(-40, std::string("HIP: ") + hipGetErrorString(e_) + " in " #x); lcd_inflated_free(h); return nullptr; } } while (0)
+void lcd_inflated_free(lcd_inflated_t *h) {
+    if (!h) return;
+    if (h->d_in) (void)hipFree(h->d_in);
+    if (h->d_out) (void)hipFree(h->d_out);
+    if (h->d_jobs) (void)hipFree(h->d_jobs);
+    if (h->d_outs) (void)hipFree(h->d_outs);
+    delete h;
+}
+lcd_inflated_t *lcd_bgzf_inflate_dev(const uint8_t *file, size_t n, int verify_crc) {
+    lcd_inflated_t *h = new lcd_inflated_s();
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { io_err(-40, "lcd_bgzf_inflate_dev: no HIP device (this entry point has no host path: lcd_bam_load_region inflates on host threads)"); delete h; return nullptr; }
+    std::vector<Blk> blks; size_t total = 0;
+    if (bgzf_blocks(Bytes{file, n}, blks, &total)) { delete h; return nullptr; }
+    h->total = total; h->n_blocks = blks.size(); h->comp_bytes = n;
+    if (blks.empty()) return h;
+    IOHIP(hipMalloc(&h->d_in, n + 1024));            // (the decoder's 256-byte input windows read ahead of the stream)
+    IOHIP(hipMalloc(&h->d_out, total + 64));
+    IOHIP(hipMalloc(&h->d_jobs, blks.size() * sizeof(InflateJobH)));
+    IOHIP(hipMalloc(&h->d_outs, blks.size() * sizeof(InflateOutH)));
+    hipStream_t st = nullptr; hipEvent_t ev[3];
+    for (auto &e : ev) IOHIP(hipEventCreate(&e));
+    { // x^(2^k) mod P for the CRC combination: x^1 = 1 << 30 in the reflected representation, then squares
+        unsigned t[32]; unsigned p = 1u << 30; t[0] = p;
+        for (int k = 1; k < 32; ++k) t[k] = p = gf2_mulmod_h(p, p);
+        lcd_inflate_set_x2n(t, st);
+    }
+    std::vector<InflateJobH> jobs(blks.size());
+    for (size_t i = 0; i < blks.size(); ++i) {
+        jobs[i].src = (unsigned long long)(uintptr_t)h->d_in + blks[i].cdata; jobs[i].dst = (unsigned long long)(uintptr_t)h->d_out + blks[i].uoff;
+        jobs[i].clen = (unsigned)blks[i].clen; jobs[i].ulen = (unsigned)blks[i].ulen; jobs[i].crc = blks[i].crc; jobs[i].pad_ = 0;
+    }
+    IOHIP(hipEventRecord(ev[0], st));
+    IOHIP(hipMemsetAsync((uint8_t *)h->d_in + n, 0, 1024, st));
+    IOHIP(hipMemcpyAsync(h->d_in, file, n, hipMemcpyHostToDevice, st));
+    IOHIP(hipMemcpyAsync(h->d_jobs, jobs.data(), jobs.size() * sizeof(InflateJobH), hipMemcpyHostToDevice, st));
+    IOHIP(hipEventRecord(ev[1], st));
+    lcd_launch_inflate(h->d_jobs, h->d_outs, (int)blks.size(), verify_crc, st);
+    IOHIP(hipGetLastError());
+    IOHIP(hipEventRecord(ev[2], st));
+    std::vector<InflateOutH> outs(blks.size());
+    IOHIP(hipMemcpy(outs.data(), h->d_outs, outs.size() * sizeof(InflateOutH), hipMemcpyDeviceToHost));
+    float a = 0, b = 0; (void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]);
+    h->ms_h2d = a; h->ms_kernel = b;
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    for (size_t i = 0; i < outs.size(); ++i) if (outs[i].status != 0) {
+        static const char *why[] = {"ok", "?", "stored block: LEN / NLEN mismatch", "more output than ISIZE", "reserved block type", "too many codes", "bad code lengths", "no end-of-block code",
+                                    "over-subscribed code", "invalid code", "invalid symbol", "distance before the start of the block", "fewer bytes than ISIZE", "CRC-32 mismatch"};
+        io_err(-32, "device inflate failed on BGZF block " + std::to_string(i) + ": " + (outs[i].status < 14 ? why[outs[i].status] : "?"));
+        lcd_inflated_free(h); return nullptr;
+    }
+    return h;
+}
+#undef IOHIP
+uint64_t lcd_inflated_dev_ptr(const lcd_inflated_t *h) { return (uint64_t)(uintptr_t)h->d_out; }
+size_t lcd_inflated_size(const lcd_inflated_t *h) { return h->total; }
+size_t lcd_inflated_n_blocks(const lcd_inflated_t *h) { return h->n_blocks; }
+double lcd_inflated_kernel_ms(const lcd_inflated_t *h) { return h->ms_kernel; }
+double lcd_inflated_upload_ms(const lcd_inflated_t *h) { return h->ms_h2d; }
+int lcd_inflated_to_host(const lcd_inflated_t *h, size_t off, size_t n, uint8_t *out) {
+    if (off + n > h->total) return io_err(-41, "lcd_inflated_to_host: range past the end of the stream");
+    if (n == 0) return 0;
+    const hipError_t e = hipMemcpy(out, (const uint8_t *)h->d_out + off, n, hipMemcpyDeviceToHost);
+    return e == hipSuccess ? 0 : io_err(-40, std::string("HIP: ") + hipGetErrorString(e));
+}
+}
+
