@@ -397,9 +397,9 @@ int lcd_vcf_header(const char *source_version, const char *cmdline, const char *
 
 // ---- BGZF blocks inflated on the device (inflate_kernel.hip): one upload of the compressed bytes, one wavefront per block, the inflated stream stays in HBM ----
 struct InflateJobH { unsigned long long src, dst; unsigned clen, ulen, crc, pad_; };
-struct InflateOutH { int status; unsigned crc; unsigned ulen; unsigned pad_; };
+struct InflateOutH { int status; unsigned crc; unsigned ulen; unsigned n_sym; unsigned long long t_total, t_tables, t_flush, t_match; };
 } // extern "C"
-void lcd_launch_inflate(const void *jobs, void *outs, int n_jobs, int verify, hipStream_t stream);
+void lcd_launch_inflate(const void *jobs, void *outs, int n_jobs, int verify, int timers, hipStream_t stream);
 void lcd_inflate_set_x2n(const unsigned *t32, hipStream_t st);
 namespace {
 unsigned gf2_mulmod_h(unsigned a, unsigned b) { unsigned m = 1u << 31, p = 0; for (;;) { if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; } m >>= 1; b = (b & 1) ? (b >> 1) ^ 0xedb88320u : b >> 1; } return p; }
@@ -444,7 +444,8 @@ lcd_inflated_t *lcd_bgzf_inflate_dev(const uint8_t *file, size_t n, int verify_c
     IOHIP(hipMemcpyAsync(h->d_in, file, n, hipMemcpyHostToDevice, st));
     IOHIP(hipMemcpyAsync(h->d_jobs, jobs.data(), jobs.size() * sizeof(InflateJobH), hipMemcpyHostToDevice, st));
     IOHIP(hipEventRecord(ev[1], st));
-    lcd_launch_inflate(h->d_jobs, h->d_outs, (int)blks.size(), verify_crc, st);
+    const bool timers = getenv("LCD_INFLATE_PROFILE") != nullptr;
+    lcd_launch_inflate(h->d_jobs, h->d_outs, (int)blks.size(), verify_crc, timers ? 1 : 0, st);
     IOHIP(hipGetLastError());
     IOHIP(hipEventRecord(ev[2], st));
     std::vector<InflateOutH> outs(blks.size());
@@ -452,6 +453,12 @@ lcd_inflated_t *lcd_bgzf_inflate_dev(const uint8_t *file, size_t n, int verify_c
     float a = 0, b = 0; (void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]);
     h->ms_h2d = a; h->ms_kernel = b;
     for (auto &e : ev) (void)hipEventDestroy(e);
+    if (timers) {
+        unsigned long long tt = 0, tb = 0, tf = 0, tm = 0, ns = 0;
+        for (const InflateOutH &o : outs) { tt += o.t_total; tb += o.t_tables; tf += o.t_flush; tm += o.t_match; ns += o.n_sym; }
+        fprintf(stderr, "[inflate] %zu blocks: %.0f symbols per block, ticks per block %.0f (tables %.1f %%, matches %.1f %%, flushes %.1f %%), %.1f ticks per symbol\n", outs.size(), (double)ns / outs.size(),
+                (double)tt / outs.size(), 100.0 * tb / tt, 100.0 * tm / tt, 100.0 * tf / tt, (double)tt / (double)ns);
+    }
     for (size_t i = 0; i < outs.size(); ++i) if (outs[i].status != 0) {
         static const char *why[] = {"ok", "?", "stored block: LEN / NLEN mismatch", "more output than ISIZE", "reserved block type", "too many codes", "bad code lengths", "no end-of-block code",
                                     "over-subscribed code", "invalid code", "invalid symbol", "distance before the start of the block", "fewer bytes than ISIZE", "CRC-32 mismatch"};
