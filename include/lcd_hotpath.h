@@ -27,6 +27,7 @@
 #ifndef LCD_HOTPATH_H
 #define LCD_HOTPATH_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -340,9 +341,22 @@ int lcd_region_read_slices_batch(int n_pairs, const int *pair_read, const int64_
  * lcd_batch_upload).  No digar and no base crosses PCIe after lcd_chunk_create (lcd_copy_counters: [0] digar bytes D2H, [1] digar bytes H2D, [2] read-base bytes H2D,
  * [3] read-base bytes D2H since process start).  Results == the host path (lcd_digar_batch -> lcd_region_read_slices_batch -> lcd_batch_add_region_from_chunk). */
 typedef struct lcd_chunk_s lcd_chunk_t;
+struct lcd_bam_reads_t; /* (below: f3) */
 lcd_chunk_t *lcd_chunk_create(const lcd_digar_opt_t *opt, int n_reads, const int64_t *pos0, const uint32_t *cigar_pool, const uint64_t *cigar_off, const int *n_cigar,
                               const uint8_t *qual_pool, const uint64_t *qual_off, const int *qlen, const uint8_t *pal_flags, const uint8_t *seq_pool,
                               const uint64_t *seq_off, int64_t reg_beg, int64_t reg_end, int64_t whole_ref_len);
+/* f3 on the device, in front of the chunk: sam_itr_queryi + sam_itr_next (htslib: bgzf_read_block + inflate + bam_read1) and the record loop of
+ * collect_ref_seq_bam_main (src/bam_utils.c:1672-1706), then collect_digar_from_eqx_cigar (:701-842), for one region of an indexed BAM.  The region's BGZF blocks
+ * (the .bai's bins + linear index) are read from the file and uploaded COMPRESSED, inflated on the device (lcd_bgzf_inflate_dev's kernel), the records are found,
+ * measured and filtered in HBM (tid, overlap with (reg_beg - 1, reg_end], BAM_FUNMAP / FSECONDARY / FSUPPLEMENTARY, MAPQ >= min_mapq, CG-tag CIGARs of reads with more
+ * than 65 535 operations; file order; the loader's stop rule) and their digars made and kept there.  Bases and qualities are never moved: the region jobs unpack
+ * bases from the inflated stream, the sampling rule of long regions (calc_read_error_rate, src/seq.c:429) runs on the qualities in HBM.  The host receives 80 bytes
+ * per record and, with `meta`, the per-read scalars of lcd_bam_reads_t and the read names (cigar_pool / seq_pool / qual_pool stay NULL; seq_off / qual_off are
+ * offsets of the device stream; free with lcd_bam_reads_free).  whole_ref_len = the contig's length in the BAM header; pal_flags = 0 (is_ont_palindrome_clip needs
+ * the caller's clip test).  Result == lcd_bam_load_region_indexed + lcd_chunk_create on the same region.  A region without reads gives a chunk of 0 reads.
+ * NULL on failure (lcd_last_error()); no host path: without a HIP device the call fails. */
+lcd_chunk_t *lcd_chunk_create_from_bam(const lcd_digar_opt_t *opt, const char *bam_path, const char *bai_path, const char *chrom, int64_t reg_beg, int64_t reg_end,
+                                       int min_mapq, int verify_crc, struct lcd_bam_reads_t *meta);
 void lcd_chunk_destroy(lcd_chunk_t *c);
 int lcd_chunk_n_reads(const lcd_chunk_t *c);
 int lcd_chunk_read_info(const lcd_chunk_t *c, int *status, int64_t *beg, int64_t *end, int *n_cand_vars, int *n_digars);

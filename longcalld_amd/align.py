@@ -484,6 +484,31 @@ class DeviceChunk:
             raise RuntimeError("lcd_chunk_create failed: " + lib.lcd_last_error().decode())
         self.packed_bytes = int(soff[-1])
 
+    @classmethod
+    def from_bam(cls, bam_path, bai_path, chrom, reg_beg, reg_end, min_mapq=30, is_ont=0, verify_crc=1):
+        """lcd_chunk_create_from_bam: the region's BGZF blocks inflated on the device, records found / filtered / turned into digars there.
+        -> the chunk; .meta = per-read scalars and names (dict of numpy arrays / list)"""
+        from ._lib import LcdBamReads
+        self = cls.__new__(cls)
+        self.lib = lib = load_library()
+        opt = LcdDigarOpt(); lib.lcd_digar_opt_default(C.byref(opt), int(is_ont))
+        m = LcdBamReads()
+        lib.lcd_chunk_create_from_bam.restype = C.c_void_p
+        lib.lcd_chunk_create_from_bam.argtypes = [C.POINTER(LcdDigarOpt), C.c_char_p, C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(LcdBamReads)]
+        enc = lambda x: x if isinstance(x, bytes) else str(x).encode()
+        self.h = lib.lcd_chunk_create_from_bam(C.byref(opt), enc(bam_path), enc(bai_path), enc(chrom), int(reg_beg), int(reg_end), int(min_mapq), int(verify_crc), C.byref(m))
+        if not self.h:
+            raise RuntimeError("lcd_chunk_create_from_bam failed: " + lib.lcd_last_error().decode())
+        n = self.n = m.n_reads
+        arr = lambda p, dt: np.array([p[i] for i in range(n)], dt)
+        self.meta = dict(tid=m.tid, n_targets=m.n_targets, target_len=m.target_len, pos0=arr(m.pos0, np.int64), end_pos=arr(m.end_pos, np.int64), mapq=arr(m.mapq, np.int32),
+                         flag=arr(m.flag, np.int32), n_cigar=arr(m.n_cigar, np.int32), qlen=arr(m.qlen, np.int32),
+                         names=[C.string_at(C.addressof(m.name_pool.contents) + m.name_off[i]).decode() for i in range(n)])
+        lib.lcd_bam_reads_free.argtypes = [C.POINTER(LcdBamReads)]
+        lib.lcd_bam_reads_free(C.byref(m))
+        self.packed_bytes = 0
+        return self
+
     def read_info(self):
         n = self.n
         st = np.zeros(n, np.int32); beg = np.zeros(n, np.int64); end = np.zeros(n, np.int64); nc = np.zeros(n, np.int32); nd = np.zeros(n, np.int32)

@@ -26,6 +26,7 @@
 #include "../../include/lcd_hotpath.h"
 #include "lcd_kernels.h"
 #include "lcd_types.h"
+#include "lcd_io_internal.h"
 
 namespace {
 
@@ -475,9 +476,18 @@ static uint64_t pool_push(std::vector<uint8_t> &pool, const uint8_t *p, int n) {
     return off;
 }
 
+static int add_region_impl(lcd_batch_t *b, int64_t reg_len, int n_reads, const int *read_ids, const int *lens, const uint8_t *const *seqs,
+                           const uint8_t *const *quals, const int *fully_covers, const int *haps, const int64_t *phase_sets,
+                           const uint8_t *ref_seq, int ref_seq_len, const double *errs);
 int lcd_batch_add_region(lcd_batch_t *b, int64_t reg_len, int n_reads, const int *read_ids, const int *lens, const uint8_t *const *seqs,
                          const uint8_t *const *quals, const int *fully_covers, const int *haps, const int64_t *phase_sets,
                          const uint8_t *ref_seq, int ref_seq_len) {
+    return add_region_impl(b, reg_len, n_reads, read_ids, lens, seqs, quals, fully_covers, haps, phase_sets, ref_seq, ref_seq_len, nullptr);
+}
+// errs: the reads' error rates where the qualities live on the device (lcd_chunk_create_from_bam), else computed here from `quals`
+static int add_region_impl(lcd_batch_t *b, int64_t reg_len, int n_reads, const int *read_ids, const int *lens, const uint8_t *const *seqs,
+                           const uint8_t *const *quals, const int *fully_covers, const int *haps, const int64_t *phase_sets,
+                           const uint8_t *ref_seq, int ref_seq_len, const double *errs) {
     const lcd_opt_t &opt = b->opt;
     b->uploaded = b->ran = b->downloaded = false;
     RegionRec R;
@@ -490,7 +500,7 @@ int lcd_batch_add_region(lcd_batch_t *b, int64_t reg_len, int n_reads, const int
         r.id = read_ids[i]; r.len = lens[i]; r.cover = fully_covers[i]; r.hap = haps[i]; r.ps = phase_sets[i];
         r.off = lens[i] > 0 ? pool_push(b->h_pool, seqs[i], lens[i]) : b->h_pool.size();
         if (lens[i] > 0 && seqs[i]) b->pool_read_bytes += (uint64_t)lens[i]; // (read bases that cross PCIe inside the pool: lcd_copy_counters)
-        r.err = R.sampling ? calc_read_error_rate(lens[i], quals ? quals[i] : nullptr) : 0.0;
+        r.err = !R.sampling ? 0.0 : errs ? errs[i] : calc_read_error_rate(lens[i], quals ? quals[i] : nullptr);
     }
     if (n_reads <= 0) { b->regs.push_back(R); return (int)b->regs.size() - 1; }
     // sort_noisy_region_reads, src/align.c:963-985 (exchange sort, exact swap sequence)
@@ -2532,6 +2542,8 @@ struct DigarWords {
     const uint32_t *h_pool = nullptr; const uint64_t *off = nullptr; const int *n_cigar = nullptr;
     const DevBuf *d_words = nullptr; const RefCmpOut *counts = nullptr;
     int clip_rule = 0; const int64_t *rlen_true = nullptr; const int *pre_status = nullptr;
+    const int *n_indel = nullptr; // with counts: how many of the window events are insertions / deletions (tighter window capacity)
+    uint64_t d_qual_base = 0;   // != 0: the qualities are already in HBM (qual_off relative to this address; qual_pool unused)
 };
 // keep: the digars stay in HBM (a device-resident chunk, lcd_chunk_t): `keep->d_dig` receives them, nothing of them is downloaded, *digars_out stays NULL and
 // keep->slot / keep->n_digar say where read r's digars are (record index into d_dig, count)
@@ -2548,22 +2560,25 @@ int digar_batch_core(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, con
     for (int r = 0; r < n; ++r) { cig_words = std::max<uint64_t>(cig_words, cigar_off[r] + n_cigar[r]); qual_bytes = std::max<uint64_t>(qual_bytes, qual_off[r] + qlen[r]); }
     for (int r = 0; r < n; ++r) {
         DigarJob &j = jobs[r];
-        long long nd = 0, nev = 0;
-        if (W.counts) { nd = W.counts[r].nd; nev = W.counts[r].nev; }
-        else for (int i = 0; i < n_cigar[r]; ++i) { const uint32_t c = cigar_pool[cigar_off[r] + i]; const int op = c & 0xf, len = (int)(c >> 4); if (op == 8) { nd += len; nev += len; } else if (op != 3 && op != 9) { ++nd; if (op == 1 || op == 2) ++nev; } }
+        long long nd = 0, nev = 0, nid = -1; // digars; window events; of those insertions / deletions (-1: not counted)
+        if (W.counts) { nd = W.counts[r].nd; nev = W.counts[r].nev; if (W.n_indel) nid = W.n_indel[r]; }
+        else { nid = 0; for (int i = 0; i < n_cigar[r]; ++i) { const uint32_t c = cigar_pool[cigar_off[r] + i]; const int op = c & 0xf, len = (int)(c >> 4); if (op == 8) { nd += len; nev += len; } else if (op != 3 && op != 9) { ++nd; if (op == 1 || op == 2) { ++nev; ++nid; } } } }
         j.n_cigar = n_cigar[r]; j.qlen = qlen[r]; j.pos0 = pos0[r]; j.left_pal = pal_flags ? pal_flags[r] & 1 : 0; j.right_pal = pal_flags ? (pal_flags[r] >> 1) & 1 : 0;
-        j.digar_cap = (int)nd; j.ev_cap = (int)nev + 1; j.iv_cap = (int)(nev / (opt->noisy_reg_max_xgaps + 1)) + 4; j.clip_rule = W.clip_rule;
+        j.digar_cap = (int)nd; j.ev_cap = (int)nev + 1; j.clip_rule = W.clip_rule;
+        // windows are disjoint and each holds events of total weight > max_xgaps (a mismatch weighs 1, an insertion / deletion its length): at most one per
+        // indel event plus one per max_xgaps + 1 mismatches, plus the two clip flanks
+        j.iv_cap = (int)(nid >= 0 ? nid + (nev - nid) / (opt->noisy_reg_max_xgaps + 1) : nev) + 4;
         j.cigar_off = cigar_off[r] * 4; j.qual_off = qual_off[r];
         j.digar_off = dtot * sizeof(DigarRec); dtot += nd; j.iv_off = itot * sizeof(IvRec); itot += j.iv_cap; j.ev_off = etot * 16; etot += j.ev_cap;
     }
     DevBuf d_cig, d_qual, d_jobs, d_outs, d_dig_local, d_iv, d_ev;
     DevBuf &d_dig = keep ? *keep->d_dig : d_dig_local;
-    if ((!W.d_words && d_cig.ensure(cig_words * 4 + 64)) || d_qual.ensure(qual_bytes + 64) || d_jobs.ensure(n * sizeof(DigarJob)) || d_outs.ensure(n * sizeof(DigarOut)) ||
+    if ((!W.d_words && d_cig.ensure(cig_words * 4 + 64)) || (!W.d_qual_base && d_qual.ensure(qual_bytes + 64)) || d_jobs.ensure(n * sizeof(DigarJob)) || d_outs.ensure(n * sizeof(DigarOut)) ||
         d_dig.ensure(dtot * sizeof(DigarRec) + 64) || d_iv.ensure(itot * sizeof(IvRec) + 64) || d_ev.ensure(etot * 16 + 64)) return -11;
     const uint64_t cig_base = W.d_words ? W.d_words->addr() : d_cig.addr();
-    for (DigarJob &j : jobs) { j.cigar_off += cig_base; j.qual_off += d_qual.addr(); j.digar_off += d_dig.addr(); j.iv_off += d_iv.addr(); j.ev_off += d_ev.addr(); }
+    for (DigarJob &j : jobs) { j.cigar_off += cig_base; j.qual_off += W.d_qual_base ? W.d_qual_base : d_qual.addr(); j.digar_off += d_dig.addr(); j.iv_off += d_iv.addr(); j.ev_off += d_ev.addr(); }
     if (!W.d_words) HIPCHK(hipMemcpyAsync(d_cig.p, cigar_pool, cig_words * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_qual.p, qual_pool, qual_bytes, hipMemcpyHostToDevice, st));
+    if (!W.d_qual_base) HIPCHK(hipMemcpyAsync(d_qual.p, qual_pool, qual_bytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_jobs.p, jobs.data(), n * sizeof(DigarJob), hipMemcpyHostToDevice, st));
     DigarOpt dopt; dopt.min_bq = opt->min_bq; dopt.max_xgaps = opt->noisy_reg_max_xgaps; dopt.win = opt->noisy_reg_slide_win; dopt.end_clip_reg = opt->end_clip_reg;
     dopt.end_clip_flank = opt->end_clip_reg_flank_win; dopt.pad = 0; dopt.whole_ref_len = whole_ref_len;
@@ -2693,11 +2708,13 @@ int lcd_digar_batch(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, cons
 struct lcd_chunk_s {
     int device = 0, n_reads = 0; lcd_digar_opt_t opt;
     DevBuf d_dig, d_seq;                                   // digars (DigarRec, per read at slot[r], n_digar[r] of them); the records' 4-bit packed bases
+    lcd_inflated_t *stream = nullptr;                      // lcd_chunk_create_from_bam: the inflated BGZF blocks; bases and qualities are read where they lie in it
+    uint64_t seq_base = 0, qual_base = 0;                  // device address seq_off / qual_off are relative to (qual_base 0: the qualities are in h_qual)
     std::vector<uint64_t> slot, seq_off; std::vector<int> n_digar, qlen;
     std::vector<uint8_t> h_qual; std::vector<uint64_t> qual_off;   // host copy: the sampling rule of >= 10 kb regions reads qualities on the host (src/seq.c:429)
     std::vector<int> status, n_cand; std::vector<int64_t> beg, end;
     uint64_t *iv_off = nullptr; lcd_noisy_iv_t *ivs = nullptr; uint8_t *iv_in_chunk = nullptr;
-    ~lcd_chunk_s() { free(iv_off); free(ivs); free(iv_in_chunk); }
+    ~lcd_chunk_s() { free(iv_off); free(ivs); free(iv_in_chunk); if (stream) lcd_inflated_free(stream); }
 };
 lcd_chunk_t *lcd_chunk_create(const lcd_digar_opt_t *opt, int n, const int64_t *pos0, const uint32_t *cigar_pool, const uint64_t *cigar_off, const int *n_cigar,
                               const uint8_t *qual_pool, const uint64_t *qual_off, const int *qlen, const uint8_t *pal_flags, const uint8_t *seq_pool,
@@ -2722,6 +2739,146 @@ lcd_chunk_t *lcd_chunk_create(const lcd_digar_opt_t *opt, int n, const int64_t *
     free(doff);
     if (rc) return nullptr;
     if (hipStreamSynchronize(st) != hipSuccess) { set_err(-10, "lcd_chunk_create: synchronize failed"); return nullptr; }
+    c->slot.swap(keep.slot); c->n_digar.swap(keep.n_digar);
+    c->seq_base = c->d_seq.addr();
+    return c.release();
+}
+// f3 on the device, in front of the chunk: the region's BGZF blocks (through the .bai) are read from the file and uploaded compressed, inflated by
+// lcd_inflate_kernel, the records are found / measured / filtered in HBM (bam_kernel.hip) and their digars made there -- what sam_itr_queryi + sam_itr_next
+// (htslib: bgzf_read_block, inflate, bam_read1) and the record loop of collect_ref_seq_bam_main (src/bam_utils.c:1672-1706) followed by
+// collect_digar_from_eqx_cigar (:701-842) do for the reference on the calling thread.  The host sees 40 + 40 bytes per record (descriptor, CIGAR statistics),
+// never a base, a quality or a digar.  Records, filters, order and stop rule are lcd_bam_load_region_indexed's (Collector::take).
+lcd_chunk_t *lcd_chunk_create_from_bam(const lcd_digar_opt_t *opt, const char *bam_path, const char *bai_path, const char *chrom, int64_t reg_beg, int64_t reg_end,
+                                       int min_mapq, int verify_crc, lcd_bam_reads_t *meta) {
+    if (meta) memset(meta, 0, sizeof(*meta));
+    if (ensure_init()) return nullptr;
+    LcdRegionImage im;
+    if (lcd_io_region_image(bam_path, bai_path, chrom, reg_beg, reg_end, im)) { set_err(-30, std::string("lcd_chunk_create_from_bam: ") + lcd_io_last_error()); return nullptr; }
+    std::unique_ptr<lcd_chunk_s> c(new lcd_chunk_s());
+    c->device = cur_device(); c->n_reads = 0; c->opt = *opt;
+    if (meta) { meta->tid = im.tid; meta->n_targets = im.n_ref; meta->target_len = im.tlen; }
+    if (im.image.empty() || im.ranges.empty()) return c.release();
+    c->stream = lcd_bgzf_inflate_dev(im.image.data(), im.image.size(), verify_crc);
+    if (!c->stream) { set_err(-32, std::string("lcd_chunk_create_from_bam: ") + lcd_io_last_error()); return nullptr; }
+    const uint64_t base = lcd_inflated_dev_ptr(c->stream), usize = lcd_inflated_size(c->stream);
+    if (!usize) return c.release();
+    StreamGuard st; if (st.create()) return nullptr;
+    auto fail = [&](int code, const std::string &m) -> lcd_chunk_t * { set_err(code, "lcd_chunk_create_from_bam: " + m); return nullptr; };
+#define CHK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return fail(-10, "HIP call failed: " #x); } } while (0)
+    // 1. the records of every range: one serial hop per record on the device
+    const int nr = (int)im.ranges.size();
+    std::vector<BamWalkJob> wj(nr); std::vector<BamWalkOut> wo(nr);
+    std::vector<BamRecDesc> descs; std::vector<size_t> first(nr + 1, 0);
+    DevBuf d_desc, d_wj, d_wo;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        size_t tot = 0;
+        for (int k = 0; k < nr; ++k) {
+            const uint64_t len = im.ranges[k].second > im.ranges[k].first ? im.ranges[k].second - im.ranges[k].first : 0;
+            const size_t cap = attempt == 0 ? (size_t)(len / 256 + 1024) : (size_t)(len / 36 + 2); // (a record is at least 36 bytes; long reads are tens of kilobytes)
+            first[k] = tot; tot += cap; wj[k].cap = (int)cap;
+        }
+        first[nr] = tot;
+        if (d_desc.ensure(tot * sizeof(BamRecDesc)) || d_wj.ensure(nr * sizeof(BamWalkJob)) || d_wo.ensure(nr * sizeof(BamWalkOut))) return nullptr;
+        for (int k = 0; k < nr; ++k) {
+            wj[k].stream = base; wj[k].ubeg = im.ranges[k].first; wj[k].uend = std::min<uint64_t>(im.ranges[k].second, usize); wj[k].usize = usize;
+            wj[k].descs = d_desc.addr() + first[k] * sizeof(BamRecDesc); wj[k].reg_end = reg_end; wj[k].tid = im.tid;
+        }
+        CHK(hipMemcpyAsync(d_wj.p, wj.data(), nr * sizeof(BamWalkJob), hipMemcpyHostToDevice, st));
+        lcd_launch_bam_walk((const BamWalkJob *)d_wj.p, (BamWalkOut *)d_wo.p, nr, st);
+        CHK(hipGetLastError());
+        CHK(hipMemcpyAsync(wo.data(), d_wo.p, nr * sizeof(BamWalkOut), hipMemcpyDeviceToHost, st));
+        CHK(hipStreamSynchronize(st));
+        bool over = false; for (int k = 0; k < nr; ++k) if (wo[k].status == 3) over = true;
+        if (!over) break;
+        if (attempt == 1) return fail(-24, "record descriptor capacity");
+    }
+    size_t nrec = 0; std::vector<size_t> at(nr + 1, 0);
+    for (int k = 0; k < nr; ++k) { at[k] = nrec; nrec += (size_t)wo[k].n; } at[nr] = nrec;
+    descs.resize(nrec + 1);
+    for (int k = 0; k < nr; ++k) if (wo[k].n) CHK(hipMemcpyAsync(descs.data() + at[k], (const uint8_t *)d_desc.p + first[k] * sizeof(BamRecDesc), (size_t)wo[k].n * sizeof(BamRecDesc), hipMemcpyDeviceToHost, st));
+    CHK(hipStreamSynchronize(st));
+    // 2. CIGAR statistics of the wanted reference's records
+    std::vector<int> stat_of(nrec, -1); std::vector<BamStatJob> sj;
+    for (size_t i = 0; i < nrec; ++i) if (descs[i].refid == im.tid) {
+        BamStatJob j; j.rec = base + descs[i].off; j.bs = descs[i].bs; j.lname = descs[i].lname; j.nc = descs[i].nc; j.lseq = descs[i].lseq;
+        stat_of[i] = (int)sj.size(); sj.push_back(j);
+    }
+    std::vector<BamStatOut> so(sj.size() + 1);
+    DevBuf d_sj, d_so;
+    if (!sj.empty()) {
+        if (d_sj.ensure(sj.size() * sizeof(BamStatJob)) || d_so.ensure(sj.size() * sizeof(BamStatOut))) return nullptr;
+        CHK(hipMemcpyAsync(d_sj.p, sj.data(), sj.size() * sizeof(BamStatJob), hipMemcpyHostToDevice, st));
+        lcd_launch_bam_stat((const BamStatJob *)d_sj.p, (BamStatOut *)d_so.p, (int)sj.size(), st);
+        CHK(hipGetLastError());
+        CHK(hipMemcpyAsync(so.data(), d_so.p, sj.size() * sizeof(BamStatOut), hipMemcpyDeviceToHost, st));
+        CHK(hipStreamSynchronize(st));
+    }
+    // 3. the loader's rule, record by record in file order (Collector::take in lcd_io.cpp)
+    std::vector<int64_t> pos0, endp; std::vector<int> mapq, flag, ncig, qlen; std::vector<uint64_t> coff, soff, qoff, noff; std::vector<RefCmpOut> counts; std::vector<int> nindel; std::vector<GatherJob> gj, nj;
+    uint64_t cw = 0, nbytes = 0; bool done = false;
+    const char *malformed = "malformed BAM record (a field runs past the record, or a placeholder CIGAR without its CG tag)";
+    for (int k = 0; k < nr && !done; ++k) {
+        for (size_t i = at[k]; i < at[k + 1] && !done; ++i) {
+            const BamRecDesc &d = descs[i];
+            if (d.refid != im.tid) { if ((d.refid > im.tid || d.refid < 0) && !pos0.empty()) done = true; continue; }
+            const BamStatOut &x = so[stat_of[i]];
+            if (x.kind == -2) return fail(-33, malformed);
+            const int64_t e0 = (int64_t)d.pos + (x.rl > 0 ? x.rl : 1);
+            if (d.pos >= reg_end) { done = true; break; }
+            if (e0 <= reg_beg - 1) continue;
+            if ((d.flag & (0x4 | 0x100 | 0x800)) || (int)d.mapq < min_mapq) continue;
+            pos0.push_back(d.pos); endp.push_back(e0); mapq.push_back(d.mapq); flag.push_back(d.flag); ncig.push_back(x.nc); qlen.push_back(d.lseq);
+            const uint64_t sq = d.off + 32 + d.lname + 4ull * d.nc;
+            soff.push_back(sq); qoff.push_back(sq + ((uint64_t)d.lseq + 1) / 2);
+            coff.push_back(cw); { GatherJob g; g.src = x.cig_src; g.dst = cw * 4; g.bytes = (uint32_t)x.nc * 4u; g.pad_ = 0; gj.push_back(g); } cw += (uint64_t)x.nc;
+            RefCmpOut rc; rc.n_ops = x.nc; rc.nd = (int)x.nd; rc.nev = (int)x.nev; rc.pad = 0; counts.push_back(rc); nindel.push_back((int)x.nid);
+            noff.push_back(nbytes); { GatherJob g; g.src = base + d.off + 32; g.dst = nbytes; g.bytes = d.lname; g.pad_ = 0; nj.push_back(g); } nbytes += d.lname;
+        }
+        if (!done) {
+            if (wo[k].status == 1) return fail(-33, "truncated BAM record");
+            if (wo[k].status == 2) return fail(-33, malformed);
+        }
+    }
+    const int n = (int)pos0.size();
+    c->n_reads = n;
+    // read names: one gather + one copy (the only record bytes that come to the host)
+    std::vector<char> names(nbytes + 1, 0);
+    DevBuf d_cig, d_gj, d_names;
+    if (n > 0) {
+        if (d_cig.ensure(cw * 4 + 64) || d_gj.ensure((size_t)n * sizeof(GatherJob)) || d_names.ensure(nbytes + 64)) return nullptr;
+        for (GatherJob &g : gj) g.dst += d_cig.addr();
+        CHK(hipMemcpyAsync(d_gj.p, gj.data(), (size_t)n * sizeof(GatherJob), hipMemcpyHostToDevice, st));
+        lcd_launch_bam_cigar((const GatherJob *)d_gj.p, n, st);
+        CHK(hipGetLastError());
+        if (meta) {
+            CHK(hipStreamSynchronize(st)); // (d_gj is reused)
+            for (GatherJob &g : nj) g.dst += d_names.addr();
+            CHK(hipMemcpyAsync(d_gj.p, nj.data(), (size_t)n * sizeof(GatherJob), hipMemcpyHostToDevice, st));
+            lcd_launch_gather((const GatherJob *)d_gj.p, n, st);
+            CHK(hipGetLastError());
+            CHK(hipMemcpyAsync(names.data(), d_names.p, nbytes, hipMemcpyDeviceToHost, st));
+            CHK(hipStreamSynchronize(st));
+        }
+    }
+    auto dupv = [](const auto &v) { using T = typename std::decay<decltype(v[0])>::type; T *p = (T *)malloc((v.size() + 1) * sizeof(T)); if (!v.empty()) memcpy(p, v.data(), v.size() * sizeof(T)); return p; };
+    if (meta) {
+        meta->n_reads = n; meta->pos0 = dupv(pos0); meta->end_pos = dupv(endp); meta->mapq = dupv(mapq); meta->flag = dupv(flag); meta->n_cigar = dupv(ncig); meta->qlen = dupv(qlen);
+        meta->cigar_off = dupv(coff); meta->seq_off = dupv(soff); meta->qual_off = dupv(qoff); meta->name_off = dupv(noff); meta->name_pool = dupv(names);
+        // (cigar_pool / seq_pool / qual_pool stay NULL: those bytes are in HBM; seq_off / qual_off are offsets of the inflated stream)
+    }
+    if (n == 0) return c.release();
+    // 4. digars, kept in HBM; bases and qualities are read in place
+    c->qlen = qlen; c->seq_off = soff; c->qual_off = qoff; c->seq_base = base; c->qual_base = base;
+    c->status.resize(n); c->n_cand.resize(n); c->beg.resize(n); c->end.resize(n);
+    DigarWords W; W.off = coff.data(); W.n_cigar = ncig.data(); W.d_words = &d_cig; W.counts = counts.data(); W.n_indel = nindel.data(); W.d_qual_base = base;
+    DigarKeep keep; keep.d_dig = &c->d_dig;
+    uint64_t *doff = nullptr; lcd_digar_t *dg = nullptr;
+    const int rc = digar_batch_core(opt, n, pos0.data(), W, nullptr, qoff.data(), qlen.data(), nullptr, reg_beg, reg_end, im.tlen, &doff, &dg, &c->iv_off, &c->ivs, &c->iv_in_chunk,
+                                    c->status.data(), c->beg.data(), c->end.data(), c->n_cand.data(), st, &keep);
+    free(doff);
+    if (rc) return nullptr;
+    CHK(hipStreamSynchronize(st));
+#undef CHK
     c->slot.swap(keep.slot); c->n_digar.swap(keep.n_digar);
     return c.release();
 }
@@ -2772,14 +2929,32 @@ int lcd_batch_add_region_from_chunk_dev(lcd_batch_t *b, const lcd_chunk_t *c, in
         const int r = read_ids[i];
         if (r < 0 || r >= c->n_reads) return set_err(-4, "lcd_batch_add_region_from_chunk_dev: read index out of range");
         lens[i] = read_end[i] - read_beg[i] + 1;
-        qp[i] = lens[i] > 0 ? c->h_qual.data() + c->qual_off[r] + read_beg[i] : nullptr;
+        qp[i] = lens[i] > 0 && !c->qual_base ? c->h_qual.data() + c->qual_off[r] + read_beg[i] : nullptr;
     }
-    const int ri = lcd_batch_add_region(b, reg_end - reg_beg + 1, n, read_ids, lens.data(), sp.data(), qp.data(), cover, haps, phase_sets, ref_seq, ref_seq_len);
+    // the sampling rule of long regions (sort_noisy_region_reads by calc_read_error_rate, src/align.c:963-985, src/seq.c:429) on qualities that never left HBM
+    std::vector<double> errs;
+    if (c->qual_base && reg_end - reg_beg + 1 >= b->opt.min_noisy_reg_size_to_sample_reads && n > 0) {
+        if (use_device(c->device)) return -1;
+        errs.resize(n);
+        std::vector<ErrJob> ej(n);
+        for (int i = 0; i < n; ++i) { ej[i].qual = c->qual_base + c->qual_off[read_ids[i]] + (uint64_t)read_beg[i]; ej[i].len = lens[i]; ej[i].pad = 0; }
+        double tab[256]; for (int q = 0; q < 256; ++q) tab[q] = pow(10.0, -((double)q) / 10.0);
+        StreamGuard st; if (st.create()) return -10;
+        DevBuf dj, dt, dout;
+        if (dj.ensure(n * sizeof(ErrJob)) || dt.ensure(sizeof(tab)) || dout.ensure(n * sizeof(double))) return -11;
+        HIPCHK(hipMemcpyAsync(dj.p, ej.data(), n * sizeof(ErrJob), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dt.p, tab, sizeof(tab), hipMemcpyHostToDevice, st));
+        lcd_launch_errrate((const ErrJob *)dj.p, (const double *)dt.p, (double *)dout.p, n, st);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(errs.data(), dout.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    const int ri = add_region_impl(b, reg_end - reg_beg + 1, n, read_ids, lens.data(), sp.data(), qp.data(), cover, haps, phase_sets, ref_seq, ref_seq_len, errs.empty() ? nullptr : errs.data());
     if (ri >= 0)
         for (RegRead &r : b->regs[ri].reads)
             for (int i = 0; i < n; ++i) if (read_ids[i] == r.id) {
                 r.rb = read_beg[i]; r.re = read_end[i];
-                if (r.len > 0) { UnpackJob j; j.src = c->d_seq.addr() + c->seq_off[r.id] + (uint64_t)(read_beg[i] >> 1); j.dst = r.off; j.first = read_beg[i] & 1; j.len = r.len; b->unpack_abs.push_back(j); }
+                if (r.len > 0) { UnpackJob j; j.src = c->seq_base + c->seq_off[r.id] + (uint64_t)(read_beg[i] >> 1); j.dst = r.off; j.first = read_beg[i] & 1; j.len = r.len; b->unpack_abs.push_back(j); }
                 break;
             }
     return ri;

@@ -19,6 +19,7 @@
 #include <thread>
 #include <vector>
 #include "../../include/lcd_hotpath.h"
+#include "lcd_io_internal.h"
 
 namespace {
 thread_local std::string g_io_err;
@@ -217,7 +218,124 @@ void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t> &bins) {
     for (int64_t k = 4681 + (beg >> 14); k <= 4681 + (end >> 14); ++k) bins.push_back((uint32_t)k);
 }
 inline uint64_t le64(const uint8_t *p) { uint64_t v = 0; for (int i = 7; i >= 0; --i) v = (v << 8) | p[i]; return v; }
+// header (-> tid, target length) and .bai lookup of a region: the merged chunks (virtual offsets, file order) whose records may overlap it
+static int region_chunks(const char *bam_path, const char *bai_path, const char *chrom, int64_t reg_beg, int64_t reg_end, BgzfStream &bz, int &tid, int64_t &tlen, int &n_ref,
+                         std::vector<std::pair<uint64_t, uint64_t>> &merged) {
+    bz.f = fopen(bam_path, "rb");
+    if (!bz.f) return io_err(-30, std::string("cannot open ") + bam_path);
+    if (int rc = bz.seek(0)) return rc;
+    uint8_t w[8];
+    if (bz.read(w, 8) != 0 || memcmp(w, "BAM\1", 4) != 0) return io_err(-33, "not a BAM file");
+    { std::vector<uint8_t> text((size_t)std::max(le32(w + 4), 0)); if (!text.empty() && bz.read(text.data(), text.size()) != 0) return io_err(-33, "truncated BAM header"); }
+    if (bz.read(w, 4) != 0) return io_err(-33, "truncated BAM header");
+    n_ref = le32(w);
+    tid = -1; tlen = 0;
+    for (int i = 0; i < n_ref; ++i) {
+        if (bz.read(w, 4) != 0) return io_err(-33, "truncated BAM header");
+        const int ln = le32(w);
+        std::vector<uint8_t> nm((size_t)std::max(ln, 0) + 4);
+        if (bz.read(nm.data(), (size_t)ln + 4) != 0) return io_err(-33, "truncated BAM header");
+        if (std::string((const char *)nm.data(), (size_t)std::max(ln - 1, 0)) == chrom) { tid = i; tlen = le32(nm.data() + ln); }
+    }
+    if (tid < 0) return io_err(-34, std::string("contig not in the BAM header: ") + chrom);
+    std::vector<uint8_t> ix;
+    if (int rc = read_file(bai_path, ix)) return rc;
+    if (ix.size() < 8 || memcmp(ix.data(), "BAI\1", 4) != 0 || le32(ix.data() + 4) <= tid) return io_err(-35, "not a .bai of this BAM");
+    int64_t qb = reg_beg - 1, qe = reg_end; // 0-based half-open, as sam_itr_queryi(idx, tid, reg_beg - 1, reg_end)
+    if (qb < 0) qb = 0;
+    if (qe > (1ll << 29)) qe = 1ll << 29;
+    if (qe <= qb) return 0;
+    std::vector<uint32_t> want; reg2bins(qb, qe, want);
+    std::vector<std::pair<uint64_t, uint64_t>> chunks; uint64_t min_off = 0;
+    size_t o = 8;
+    for (int t = 0; t <= tid; ++t) { // walk to the reference's section
+        if (o + 4 > ix.size()) return io_err(-35, "truncated .bai");
+        const int n_bin = le32(ix.data() + o); o += 4;
+        for (int b = 0; b < n_bin; ++b) {
+            if (o + 8 > ix.size()) return io_err(-35, "truncated .bai");
+            const uint32_t bin = (uint32_t)le32(ix.data() + o); const int n_chunk = le32(ix.data() + o + 4); o += 8;
+            if (o + 16ull * (size_t)n_chunk > ix.size()) return io_err(-35, "truncated .bai");
+            if (t == tid && bin != 37450 && std::find(want.begin(), want.end(), bin) != want.end())
+                for (int c = 0; c < n_chunk; ++c) chunks.emplace_back(le64(ix.data() + o + 16 * (size_t)c), le64(ix.data() + o + 16 * (size_t)c + 8));
+            o += 16 * (size_t)n_chunk;
+        }
+        if (o + 4 > ix.size()) return io_err(-35, "truncated .bai");
+        const int n_intv = le32(ix.data() + o); o += 4;
+        if (o + 8ull * (size_t)n_intv > ix.size()) return io_err(-35, "truncated .bai");
+        if (t == tid && n_intv > 0) min_off = le64(ix.data() + o + 8 * (size_t)std::min<int64_t>(qb >> 14, n_intv - 1));
+        o += 8 * (size_t)n_intv;
+    }
+    std::vector<std::pair<uint64_t, uint64_t>> keep;
+    for (auto &c : chunks) if (c.second > min_off) keep.push_back(c);
+    std::sort(keep.begin(), keep.end());
+    for (auto &c : keep) { if (!merged.empty() && c.first <= merged.back().second) merged.back().second = std::max(merged.back().second, c.second); else merged.push_back(c); }
+    return 0;
+}
+// total length of the BGZF block at compressed offset c (0 at the end of the file, < 0 on a bad block)
+static long long bgzf_block_len(FILE *f, uint64_t c) {
+    uint8_t h[12];
+    if (fseek(f, (long)c, SEEK_SET) != 0 || fread(h, 1, 12, f) != 12) return 0;
+    if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return io_err(-31, "not a BGZF block");
+    const unsigned xlen = h[10] | (h[11] << 8);
+    std::vector<uint8_t> x(xlen);
+    if (xlen && fread(x.data(), 1, xlen, f) != xlen) return io_err(-31, "truncated BGZF header");
+    for (size_t q = 0; q + 4 <= xlen;) { const unsigned slen = x[q + 2] | (x[q + 3] << 8); if (x[q] == 'B' && x[q + 1] == 'C' && slen == 2 && q + 6 <= xlen) return (long long)(x[q + 4] | (x[q + 5] << 8)) + 1; q += 4 + slen; }
+    return io_err(-31, "BGZF block without BSIZE");
+}
 } // namespace
+
+int lcd_io_region_image(const char *bam_path, const char *bai_path, const char *chrom, int64_t reg_beg, int64_t reg_end, LcdRegionImage &out) {
+    BgzfStream bz; std::vector<std::pair<uint64_t, uint64_t>> merged;
+    if (int rc = region_chunks(bam_path, bai_path, chrom, reg_beg, reg_end, bz, out.tid, out.tlen, out.n_ref, merged)) return rc;
+    out.image.clear(); out.ranges.clear();
+    if (merged.empty()) return 0;
+    // whole blocks of the file: [first block of the chunk, the block its end lies in]
+    struct Iv { uint64_t c0, c1, at; };
+    std::vector<Iv> ivs;
+    fseek(bz.f, 0, SEEK_END); const uint64_t fsize = (uint64_t)std::max<long>(ftell(bz.f), 0);
+    for (auto &m : merged) {
+        const uint64_t cb = std::min<uint64_t>(m.first >> 16, fsize), ce = std::min<uint64_t>(m.second >> 16, fsize); // (an index chunk may end behind the file's last block)
+        uint64_t end = ce;
+        if ((m.second & 0xffff) && ce < fsize) { const long long bl = bgzf_block_len(bz.f, ce); if (bl < 0) return (int)bl; end = ce + (uint64_t)bl; }
+        if (!ivs.empty() && cb <= ivs.back().c1) ivs.back().c1 = std::max(ivs.back().c1, end);
+        else ivs.push_back(Iv{cb, end, 0});
+    }
+    size_t total = 0;
+    for (Iv &v : ivs) { v.at = total; total += (size_t)(v.c1 - v.c0); }
+    out.image.resize(total);
+    for (Iv &v : ivs) {
+        if (v.c1 == v.c0) continue;
+        if (fseek(bz.f, (long)v.c0, SEEK_SET) != 0 || fread(out.image.data() + v.at, 1, (size_t)(v.c1 - v.c0), bz.f) != (size_t)(v.c1 - v.c0)) return io_err(-31, "truncated BGZF block");
+    }
+    // block starts of the image -> offsets of its inflated stream
+    std::vector<std::pair<uint64_t, uint64_t>> starts; // (offset in the image, inflated offset)
+    {
+        std::vector<Blk> blks; size_t u = 0;
+        if (int rc = bgzf_blocks(Bytes{out.image.data(), out.image.size()}, blks, &u)) return rc;
+        size_t o = 0, uu = 0; const std::vector<uint8_t> &f = out.image;
+        while (o + 18 <= f.size()) { // (bgzf_blocks has checked every header)
+            const unsigned xlen = f[o + 10] | (f[o + 11] << 8); unsigned bsize = 0;
+            for (size_t x = o + 12; x + 4 <= o + 12 + xlen;) { const unsigned slen = f[x + 2] | (f[x + 3] << 8); if (f[x] == 'B' && f[x + 1] == 'C' && slen == 2) bsize = f[x + 4] | (f[x + 5] << 8); x += 4 + slen; }
+            const size_t end = o + bsize + 1;
+            starts.emplace_back(o, uu);
+            uu += f[end - 4] | (f[end - 3] << 8) | (f[end - 2] << 16) | ((size_t)f[end - 1] << 24);
+            o = end;
+        }
+        starts.emplace_back(f.size(), uu);
+    }
+    auto upos = [&](uint64_t v) -> uint64_t {
+        const uint64_t c = std::min<uint64_t>(v >> 16, fsize);
+        if ((v >> 16) >= fsize) v = c << 16;
+        size_t k = 0; while (k + 1 < ivs.size() && c > ivs[k].c1) ++k; // (sorted, disjoint and not adjacent: the interval the block starts in, or ends)
+        const uint64_t at = ivs[k].at + (c - ivs[k].c0);
+        auto it = std::lower_bound(starts.begin(), starts.end(), std::make_pair(at, (uint64_t)0));
+        const uint64_t u0 = it == starts.end() ? starts.back().second : it->second;
+        const uint64_t u1 = (it == starts.end() || it + 1 == starts.end()) ? starts.back().second : (it + 1)->second;
+        return std::min<uint64_t>(u0 + (v & 0xffff), std::max(u0, u1)); // (an offset at a block's end is the next block's start)
+    };
+    for (auto &m : merged) out.ranges.emplace_back(upos(m.first), upos(m.second));
+    return 0;
+}
 
 extern "C" {
 
@@ -260,56 +378,10 @@ void lcd_bam_reads_free(lcd_bam_reads_t *r) {
 // lcd_bam_load_region (what sam_itr_queryi + the loop of collect_ref_seq_bam_main, src/bam_utils.c:1672-1706, see).
 int lcd_bam_load_region_indexed(const char *bam_path, const char *bai_path, const char *chrom, int64_t reg_beg, int64_t reg_end, int min_mapq, lcd_bam_reads_t *out) {
     memset(out, 0, sizeof(*out));
-    BgzfStream bz; bz.f = fopen(bam_path, "rb");
-    if (!bz.f) return io_err(-30, std::string("cannot open ") + bam_path);
-    if (int rc = bz.seek(0)) return rc;
-    uint8_t w[8];
-    if (bz.read(w, 8) != 0 || memcmp(w, "BAM\1", 4) != 0) return io_err(-33, "not a BAM file");
-    { std::vector<uint8_t> text((size_t)std::max(le32(w + 4), 0)); if (!text.empty() && bz.read(text.data(), text.size()) != 0) return io_err(-33, "truncated BAM header"); }
-    if (bz.read(w, 4) != 0) return io_err(-33, "truncated BAM header");
-    const int n_ref = le32(w);
-    int tid = -1; int64_t tlen = 0;
-    for (int i = 0; i < n_ref; ++i) {
-        if (bz.read(w, 4) != 0) return io_err(-33, "truncated BAM header");
-        const int ln = le32(w);
-        std::vector<uint8_t> nm((size_t)std::max(ln, 0) + 4);
-        if (bz.read(nm.data(), (size_t)ln + 4) != 0) return io_err(-33, "truncated BAM header");
-        if (std::string((const char *)nm.data(), (size_t)std::max(ln - 1, 0)) == chrom) { tid = i; tlen = le32(nm.data() + ln); }
-    }
-    if (tid < 0) return io_err(-34, std::string("contig not in the BAM header: ") + chrom);
-    std::vector<uint8_t> ix;
-    if (int rc = read_file(bai_path, ix)) return rc;
-    if (ix.size() < 8 || memcmp(ix.data(), "BAI\1", 4) != 0 || le32(ix.data() + 4) <= tid) return io_err(-35, "not a .bai of this BAM");
-    int64_t qb = reg_beg - 1, qe = reg_end; // 0-based half-open, as sam_itr_queryi(idx, tid, reg_beg - 1, reg_end)
-    if (qb < 0) qb = 0;
-    if (qe > (1ll << 29)) qe = 1ll << 29;
-    Collector col(tid, reg_beg, reg_end, min_mapq);
-    if (qe <= qb) return col.finish(out, tid, tlen, n_ref);
-    std::vector<uint32_t> want; reg2bins(qb, qe, want);
-    std::vector<std::pair<uint64_t, uint64_t>> chunks; uint64_t min_off = 0;
-    size_t o = 8;
-    for (int t = 0; t <= tid; ++t) { // walk to the reference's section
-        if (o + 4 > ix.size()) return io_err(-35, "truncated .bai");
-        const int n_bin = le32(ix.data() + o); o += 4;
-        for (int b = 0; b < n_bin; ++b) {
-            if (o + 8 > ix.size()) return io_err(-35, "truncated .bai");
-            const uint32_t bin = (uint32_t)le32(ix.data() + o); const int n_chunk = le32(ix.data() + o + 4); o += 8;
-            if (o + 16ull * (size_t)n_chunk > ix.size()) return io_err(-35, "truncated .bai");
-            if (t == tid && bin != 37450 && std::find(want.begin(), want.end(), bin) != want.end())
-                for (int c = 0; c < n_chunk; ++c) chunks.emplace_back(le64(ix.data() + o + 16 * (size_t)c), le64(ix.data() + o + 16 * (size_t)c + 8));
-            o += 16 * (size_t)n_chunk;
-        }
-        if (o + 4 > ix.size()) return io_err(-35, "truncated .bai");
-        const int n_intv = le32(ix.data() + o); o += 4;
-        if (o + 8ull * (size_t)n_intv > ix.size()) return io_err(-35, "truncated .bai");
-        if (t == tid && n_intv > 0) min_off = le64(ix.data() + o + 8 * (size_t)std::min<int64_t>(qb >> 14, n_intv - 1));
-        o += 8 * (size_t)n_intv;
-    }
-    std::vector<std::pair<uint64_t, uint64_t>> keep;
-    for (auto &c : chunks) if (c.second > min_off) keep.push_back(c);
-    std::sort(keep.begin(), keep.end());
+    BgzfStream bz; int tid = -1, n_ref = 0; int64_t tlen = 0; uint8_t w[8];
     std::vector<std::pair<uint64_t, uint64_t>> merged;
-    for (auto &c : keep) { if (!merged.empty() && c.first <= merged.back().second) merged.back().second = std::max(merged.back().second, c.second); else merged.push_back(c); }
+    if (int rc = region_chunks(bam_path, bai_path, chrom, reg_beg, reg_end, bz, tid, tlen, n_ref, merged)) return rc;
+    Collector col(tid, reg_beg, reg_end, min_mapq);
     std::vector<uint8_t> rec;
     bool done = false;
     for (size_t m = 0; m < merged.size() && !done; ++m) {

@@ -202,6 +202,13 @@ static inline LCD_HD WfaLayout wfa_layout(int plen, int tlen, int s_cap, int blk
 
 // ---------------- edlib NW job (K4, src/align.c:222-232) ----------------
 struct GatherJob { uint64_t src, dst; uint32_t bytes, pad_; };   // strings_kernel.hip lcd_gather_kernel
+// ---------------- BAM records in the inflated stream (bam_kernel.hip; SURVEY 8f f3 on the device) ----------------
+struct BamWalkJob { uint64_t stream, ubeg, uend, usize, descs; long long reg_end; int tid, cap; };   // [ubeg, uend): a .bai chunk as offsets of the inflated stream; usize: its length
+struct BamRecDesc { uint64_t off; int bs, refid, pos, lseq; uint16_t flag, nc; uint8_t lname, mapq; uint16_t pad; uint32_t pad2; uint32_t pad3; }; // off: the record behind its block_size word
+struct BamWalkOut { int n, status; uint64_t next; };   // status 0 range done, 1 truncated record, 2 a field runs past the record, 3 descriptor capacity, 4 stopped at the first record at / behind reg_end
+struct BamStatJob { uint64_t rec; int bs, lname, nc, lseq; };
+struct BamStatOut { long long rl, nd, nev, nid; uint64_t cig_src; int nc, kind; };   // kind 0 the record's own CIGAR, 1 the CG tag's, -2 placeholder without its tag; cig_src: where the operations are
+struct ErrJob { uint64_t qual; int len, pad; };
 struct EdJob {
     uint64_t q_off, t_off;
     int qlen, tlen;

@@ -53,6 +53,8 @@ def test_no_cpu_fallback_without_gpu():
     with pytest.raises(Exception):
         align.edlib_batch_hw([(np.zeros(30, np.uint8), np.zeros(10, np.uint8))])
     assert align.edlib_infix_aln(np.zeros(30, np.uint8), np.zeros(10, np.uint8))[0] == -1
+    with pytest.raises(Exception):   # BGZF inflate + record decode of an indexed BAM on the device: no host path behind this entry
+        align.DeviceChunk.from_bam("/nonexistent.bam", "/nonexistent.bam.bai", "chr11", 1, 1000)
 
 
 def test_product_does_not_import_oracle():
