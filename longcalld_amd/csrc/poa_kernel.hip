@@ -3140,7 +3140,15 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
         }
         ws = (uint8_t *)(uintptr_t)ch.ws_off + (uint64_t)my_slot * ch.slot_bytes;
     }
-    Ctx g;
+    // The chain's context (sixty pointers into its arena, capacities, counters) is passed by reference to the non-inlined phase functions.  As a local it lives in
+    // the private segment: 700 bytes per LANE, every uniform field 64 times over, and each phase call re-reads the frame through the vector memory path -- with
+    // 4 096 resident chains those frames do not stay in the caches.  One copy per WAVEFRONT in LDS instead for the classes up to 256 threads (the wavefronts of
+    // a workgroup keep separate copies exactly as their lanes did: every update is made by all of them, unsynchronised); the two widest classes have no LDS to
+    // spare and keep theirs in the private segment.
+    constexpr bool CTX_LDS = NT <= 256;
+    __shared__ Ctx s_ctx[CTX_LDS ? NT / 64 : 1];
+    Ctx g_private;
+    Ctx &g = *(CTX_LDS ? &s_ctx[threadIdx.x >> 6] : &g_private);
     // DP region: 4 * cell_cap bytes.  Windowed / systolic rows: [direction codes: cell_cap B | predecessor ordinals: cell_cap B (one row
     // in four may have >= 2 predecessors) | spilled value rows: 2 * cell_cap B].  Generic rows: int32 H, E1, E2 planes of cell_cap / 3
     // cells.  Whatever does not fit ends the chain with LCD_ERR_CELLS and the host re-runs it with a larger arena.
