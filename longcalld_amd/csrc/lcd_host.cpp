@@ -759,6 +759,7 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     {
         const long long solo_rl = getenv("LCD_SOLO_RL") ? atoll(getenv("LCD_SOLO_RL")) : 100000; // (read per call: tests switch it)
         pc.solo = (C.solo >= 0 ? C.solo > 0 : (solo_rl > 0 && (long long)n * maxl >= solo_rl)) || (solo_len > 0 && pc.cert == 1 && maxl >= solo_len) ? 1 : 0;
+        if (pc.solo && pc.cert == 0 && getenv("LCD_SOLO_MW") && atoi(getenv("LCD_SOLO_MW")) > 0) pc.solo = 2; // (experiment: see poa_kernel.hip align_to_subgraph)
     }
     // graph capacity: the worst case is one node per base of every read (sum), the usual case a little more than the longest read.  Sized
     // from an estimate (a few per cent of new nodes per read on top of the backbone; g_node_hint learns noisier data); a chain that runs

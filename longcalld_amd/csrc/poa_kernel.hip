@@ -2591,7 +2591,10 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
                 if (g.wmax <= 64) nc = align_lean<1, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
                 if (nc < 0 && g.wmax <= 128) { __syncthreads(); nc = align_lean<1, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
                 if (nc < 0) { __syncthreads(); nc = align_lean<1, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+            } else if (NT == 256 && g.solo == 2 && g.wmax <= 256 && (nc = align_windowed<NT, 1, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo)) >= 0) {
+                // (LCD_SOLO_MW=1, experiment: the long chain's rows on all four wavefronts, one column per lane)
             } else if (NT == 256 && g.solo) { // a long K1 chain in a 256-thread workgroup: wavefront 0 runs the lean rows, the others wait for its result
+                __syncthreads();
                 if (wave == 0) {
                     if (g.wmax <= 64) nc = align_lean<1, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
                     if (nc < 0 && g.wmax <= 128) { win_sync<true>(); nc = align_lean<1, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
