@@ -1102,6 +1102,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     }
     HIPCHK(hipEventRecord(L->ev[1], st));
     const double tp0 = now_ms();
+    if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host] anchor stage: %.1f ms on the host clock\n", tp0 - t_begin);
     // ---------------- S2: POA chains ----------------
     std::vector<size_t> chain_base(nb + 1, 0), pread_base(nb + 1, 0);
     for (int k = 0; k < nb; ++k) { chain_base[k + 1] = chain_base[k] + bs[k]->chains.size(); pread_base[k + 1] = pread_base[k] + preads[k].size(); }
@@ -1159,6 +1160,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         for (int c = 0; c < nC; ++c) b->pchains[c].out_off = b->d_poa_out.addr() + out_rel[k][c];
     }
     auto PC = [&](size_t g) -> PoaChain & { const int k = chain_batch[g]; return bs[k]->pchains[g - chain_base[k]]; };
+    if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host]   POA prep: capacities after %.1f ms\n", now_ms() - tp0);
     if (nC_all) {
         if (L->d_preads.ensure(pread_base[nb] * sizeof(PoaRead)) || L->d_chains.ensure(nC_all * sizeof(PoaChain)) || L->d_poa_outs.ensure(nC_all * sizeof(PoaChainOut))) return -11;
         for (int k = 0; k < nb; ++k)
@@ -1197,11 +1199,15 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             }
         }
         // widest / largest-LDS group first, then biggest first so the long chains start early (LPT)
-        std::sort(which.begin(), which.end(), [&](size_t a, size_t c2) {
-            const long long ta = chain_group_key(PC(a)), tc = chain_group_key(PC(c2));
-            if (ta != tc) return ta > tc;
-            if (PC(a).cell_cap != PC(c2).cell_cap) return PC(a).cell_cap > PC(c2).cell_cap;
-            return a < c2; });
+        {   // (keys taken once: the comparator used to look both chains up through their batch for each of the ~600 000 comparisons of a 20-batch submission)
+            std::vector<std::pair<long long, uint64_t>> sk(nC_all);
+            for (size_t g = 0; g < nC_all; ++g) { const PoaChain &pc = PC(g); sk[g] = {chain_group_key(pc), pc.cell_cap}; }
+            std::sort(which.begin(), which.end(), [&](size_t a, size_t c2) {
+                if (sk[a].first != sk[c2].first) return sk[a].first > sk[c2].first;
+                if (sk[a].second != sk[c2].second) return sk[a].second > sk[c2].second;
+                return a < c2; });
+        }
+        if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host]   POA prep: classes + order after %.1f ms\n", now_ms() - tp0);
         int scale = 1;
         std::map<size_t, uint64_t> retry_out_off; // chains whose output block moved to a retry buffer
         for (int k = 0; k < nb; ++k) bs[k]->retry_out_used = 0;
@@ -1278,6 +1284,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                 }
                 i = j;
             }
+            if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host]   POA prep: arenas laid out after %.1f ms\n", now_ms() - tp0);
             if (getenv("LCD_MEM_DEBUG")) fprintf(stderr, "[mem] round %d arenas: %zu chains in %zu slot pools (%.2f GB), %zu with private arenas (%.2f GB)\n", round, n_pooled, n_pools, pool_bytes / 1e9, which.size() - n_pooled, private_bytes / 1e9);
             if (flag_ints) {
                 if (L->d_slot_flags.ensure(flag_ints * 4 + 64)) return -11;
