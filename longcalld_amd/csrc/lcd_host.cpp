@@ -759,7 +759,11 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     {
         const long long solo_rl = getenv("LCD_SOLO_RL") ? atoll(getenv("LCD_SOLO_RL")) : 100000; // (read per call: tests switch it)
         pc.solo = (C.solo >= 0 ? C.solo > 0 : (solo_rl > 0 && (long long)n * maxl >= solo_rl)) || (solo_len > 0 && pc.cert == 1 && maxl >= solo_len) ? 1 : 0;
-        if (pc.solo && pc.cert == 0 && getenv("LCD_SOLO_MW") && atoi(getenv("LCD_SOLO_MW")) > 0) pc.solo = 2; // (experiment: see poa_kernel.hip align_to_subgraph)
+        // LCD_SOLO_MW=1: long certified-band chains run their rows on all four wavefronts of the workgroup (poa_kernel.hip align_lean_mw) instead of wavefront 0 alone.
+        // Same alignments (digest 0004c9ba86f18807 at the driver's flags), but measured SLOWER: 3 530 instead of 2 950 ticks per row of the longest chain, 80.6 k instead
+        // of 88.4 k regions/s -- every wavefront pays the row's fixed cost (plan word, interval, predecessor loop, metadata: ~400 instructions in this version, which
+        // reads every predecessor from the LDS ring) plus two LDS round trips and two barriers, and the cells it saves are ~75 instructions.  Off by default.
+        if (pc.solo && pc.cert == 1 && getenv("LCD_SOLO_MW") && atoi(getenv("LCD_SOLO_MW")) > 0) pc.solo = 2;
     }
     // graph capacity: the worst case is one node per base of every read (sum), the usual case a little more than the longest read.  Sized
     // from an estimate (a few per cent of new nodes per read on top of the backbone; g_node_hint learns noisier data); a chain that runs

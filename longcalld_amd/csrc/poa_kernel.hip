@@ -1694,6 +1694,225 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     return n_cig;
 }
 
+// ================= long chains: certified-band rows on the FOUR wavefronts of a 256-thread workgroup (end of round 3) =================
+// The longest chain of a submission is its latency at every depth (32 reads x 4 kb = 200 ms on one wavefront, 78 % of it rows, against 147 ms of work for
+// the whole chip), and a row of ~230 cells is 520 instructions for ONE wavefront at four cells per lane.  Here thread t of the workgroup owns the columns
+// congruent to t modulo 256 -- one cell per lane, the same 256-column ring slots as align_lean<2, 4> -- and the four wavefronts run the row together:
+//   * predecessor values come from the LDS ring (or the HBM spill rows) for EVERY row, masked by the predecessor's interval: the match term's column j - 1 is just the
+//     slot entry to the left, whichever wavefront wrote it, so nothing special happens at a wavefront boundary;
+//   * the horizontal-gap prefix maximum is one DPP scan pair per wavefront plus the wavefronts' totals through LDS.  The row's columns wrap around the 256 threads
+//     at thread (beg mod 256): in that wavefront the lanes below the wrap point hold the row's LAST columns; their cells are kept out of the first columns' scan
+//     by an offset of 2^30 on the latter (a max scan: the offset values always win, and are recognised by their size afterwards);
+//   * two LDS barriers per row (totals; ring slot) -- the intervals of MODE 2 come from the table, so no row waits for another row's maximum.
+// Codes / ordinals / row metadata in HBM are those of the one-cell-per-lane lean rows (a row's cells start at its interval's first column), so the code-driven
+// backtrack is shared.  Returns the number of cigar entries, 0 with wo->status set, or -1 = not here (an interval wider than 254 columns, > 254 predecessors).
+__device__ __attribute__((noinline)) int align_lean_mw(const Ctx *gp_, const unsigned ring_, const unsigned sq1_, const unsigned pd_ /* 0xffffffff: none */, const LcdScoring sc_,
+                                                      const int bi_, const int ei_, const uint8_t *seq_hbm_, const int qlen_, WinOut *wo_) {
+    const long long t_in0 = clock64();
+    constexpr int NT = 256, WIN = 256, WM = WIN - 1, SLOTW = 3 * WIN, CP = 4, BIG = 1 << 30, BIGT = 1 << 28;
+    Smem &sm = g_smem;
+    Ctx g = *usgpr(gp_);
+    ctx_to_sgpr(g);
+    const int K = usgpr(g.ring_k), KM = K - 1;
+    const unsigned ring = usgpr(ring_), sq1 = usgpr(sq1_), pd = usgpr(pd_);
+    const int bi = usgpr(bi_), ei = usgpr(ei_), qlen = usgpr(qlen_);
+    const uint8_t *seq_hbm = usgpr(seq_hbm_); WinOut *wo = usgpr(wo_);
+    const int s_match = usgpr(sc_.match), s_mism = -usgpr(sc_.mismatch);
+    const int o1 = usgpr(sc_.o1), e1 = usgpr(sc_.e1), o2 = usgpr(sc_.o2), e2 = usgpr(sc_.e2), oe1 = o1 + e1, oe2 = o2 + e2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = usgpr(tid >> 6);
+    if (qlen >= 65535) return -1;
+    const int QB = (qlen + 12 + 15) & ~15;
+    if (sq1 < ring + (unsigned)(K * SLOTW * 4) || (K & KM) != 0) return -1; // (the pool is laid out for ring slots at least this wide: PoaChain.wmax >= 256)
+    for (int j = tid; j < QB; j += NT) lds_st_u8(sq1 + j, (j >= 1 && j <= qlen) ? glb_ld_u8(seq_hbm + (j - 1)) : 4); // shifted: sq1[j] = q[j-1]
+    const int qclamp = QB - CP;
+    const unsigned code_cap = (unsigned)(g.cell_cap > 0xfffffff0ull ? 0xfffffff0ull : g.cell_cap);
+    const unsigned ord_cap = g.spill_x > 2 ? code_cap : (unsigned)((g.cell_cap / 4) > 0xfffffff0ull ? 0xfffffff0ull : (g.cell_cap / 4));
+    const long long spill_rows_ll = g.cell_cap * g.spill_x > 64 ? (long long)((g.cell_cap * g.spill_x - 64) / ((unsigned long long)SLOTW * 4)) : 0;
+    const int spill_rows = (int)(spill_rows_ll > 0x7fffffffll ? 0x7fffffffll : spill_rows_ll);
+    const int *const hull = g.cert + 6 * (size_t)g.node_cap;
+    // ---- source row (slot 0): columns 0 .. end0 ----
+    int end0;
+    { const int hw = usgpr(glb_ld(hull + bi)); end0 = hw >> 16; if ((hw & 65535) != 0) return -1; }
+    if (end0 + 2 > WIN) return -1;
+    int nsp = 0;
+    {
+        const bool spf = (usgpr(glb_ld_u8(g.imap + bi)) & 2) != 0;
+        if (spf && spill_rows < 1) { wo->status = LCD_ERR_CELLS; return 0; }
+        const int j = tid;
+        const int f1 = j ? -(o1 + e1 * j) : LCD_NEG, f2 = j ? -(o2 + e2 * j) : LCD_NEG;
+        const int h = j ? imax(f1, f2) : 0;
+        const bool in = j <= end0;
+        const int vh = in ? h : LCD_GUARD, va = in ? h - oe1 : LCD_GUARD, vb2 = in ? h - oe2 : LCD_GUARD;
+        *(lcd_lds_i32 *)(uintptr_t)(ring + 4 * tid) = vh; *(lcd_lds_i32 *)(uintptr_t)(ring + 4 * (WIN + tid)) = va; *(lcd_lds_i32 *)(uintptr_t)(ring + 4 * (2 * WIN + tid)) = vb2;
+        if (spf) { int *G = g.spill; glb_st(G + tid, vh); glb_st(G + WIN + tid, va); glb_st(G + 2 * WIN + tid, vb2); nsp = 1; }
+        if (tid == 0) { glb_st(g.rbeg + bi, 0); glb_st(g.rend + bi, end0); glb_st(g.roff + bi, 0); glb_st(g.ml + bi, 0); glb_st(g.mr + bi, 0); glb_st(g.spoff + bi, 0); }
+    }
+    int m_be = 1;                       // ring slot meta, lane s of every wavefront: beg | end << 16 of slot s (an empty slot is beg 1, end 0)
+    if (lane == 0) m_be = end0 << 16;
+    unsigned cused = 0, oused = 0; unsigned long long ncell = (unsigned long long)end0 + 1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const long long t_dp0 = clock64();
+    wo->t_setup = (unsigned long long)(t_dp0 - t_in0);
+    int w_pk = 0, w_x = 0, w_pi0 = 0, w_pi1 = 0, w_p0 = 0; // plan window, lane = row - wbase (every wavefront keeps its own copy)
+    int r_be = 1, r_off = 0;
+    int wbase = bi + 1;
+    auto load_plan = [&](const int base) { // packed word as in align_lean: #preds | base << 8 | spill << 11 | unreachable << 12 | backbone << 13 | bonus0 << 14 | bonus1 << 19
+        const int ri = base + lane;
+        w_pk = 1 << 12;
+        if (ri < ei) {
+            const int s0 = glb_ld(g.pl_start + ri), s1 = glb_ld(g.pl_start + ri + 1);
+            const int cnt = s1 - s0;
+            int b0 = 0, b1 = 0;
+            w_p0 = s0;
+            if (cnt > 0) { w_pi0 = glb_ld(g.pl_pidx + s0); b0 = glb_ld(g.pl_bonus + s0); }
+            if (cnt > 1) { w_pi1 = glb_ld(g.pl_pidx + s0 + 1); b1 = glb_ld(g.pl_bonus + s0 + 1); }
+            const int rem = glb_ld(g.pl_rem + ri);
+            w_x = glb_ld(hull + ri);
+            w_pk = imin(cnt, 255) | (glb_ld_u8(g.pl_base + ri) << 8) | ((glb_ld_u8(g.imap + ri) & 2) << 10) | (rem == (1 << 30) ? 1 << 12 : 0) | (b0 << 14) | (b1 << 19);
+        }
+        LCD_PIN(w_pk); LCD_PIN(w_x); LCD_PIN(w_pi0); LCD_PIN(w_pi1); LCD_PIN(w_p0);
+    };
+    auto flush_meta = [&](const int base, const int n) { // rows base .. base + n - 1 (wavefront 0 stores; the windows are the same in all four)
+        if (wave == 0 && lane < n) { glb_st(g.rbeg + base + lane, r_be & 65535); glb_st(g.rend + base + lane, (int)((unsigned)r_be >> 16)); glb_st(g.roff + base + lane, r_off); }
+    };
+    load_plan(wbase);
+    for (int idx = bi + 1; idx < ei; ++idx) {
+        if (idx - wbase == 64) { flush_meta(wbase, 64); wbase = idx; load_plan(wbase); }
+        const int wk = idx - wbase;
+        const int pk = LCD_RL(w_pk, wk);
+        const int s = (idx - bi) & KM;
+        if (pk & (1 << 12)) { m_be = lean_wlane(1, s, m_be); r_be = lean_wlane(1, wk, r_be); continue; } // not reachable from the begin node
+        const int np = pk & 255, vb = (pk >> 8) & 7, bz0 = (pk >> 14) & 31;
+        const bool spf = (pk >> 11) & 1;
+        if (np == 255) return -1;
+        const int xw = LCD_RL(w_x, wk);
+        const int pi0 = LCD_RL(w_pi0, wk);
+        int pi1 = 0, bz1 = 0, p0 = 0;
+        if (np > 1) { pi1 = LCD_RL(w_pi1, wk); bz1 = (pk >> 19) & 31; p0 = LCD_RL(w_p0, wk); }
+        const int beg = xw & 65535, end = (int)((unsigned)xw >> 16); // the row's certified interval (beg > end: no cell of the row can lie on an optimal path)
+        if (beg > end) {
+            m_be = lean_wlane(1, s, m_be); r_be = lean_wlane(1, wk, r_be);
+            if (spf && tid == 0) { glb_st(g.rbeg + idx, 1); glb_st(g.rend + idx, 0); }
+            continue;
+        }
+        if (end - beg + 2 > WIN) return -1;
+        const int j = beg + ((tid - beg) & WM);       // this thread's column of the row
+        const bool inb = j <= end;
+        const int x = tid, xm = (tid - 1) & WM;       // ring slot entries of columns j and j - 1
+        int sk;
+        { const int q = lds_ld_u8(sq1 + (unsigned)imin(j, qclamp)); sk = (vb >= 4 || q >= 4) ? 0 : (vb == q ? s_match : s_mism); }
+        // ---- phase A: best match / E1 / E2 input over the predecessors (first maximum keeps its ordinal) ----
+        int nn = LCD_NEG, uu = LCD_NEG, vv = LCD_NEG, om = 0, oa = 0, ob = 0;
+        for (int t = 0; t < np; ++t) {
+            int pi = t == 0 ? pi0 : pi1, bz = t == 0 ? bz0 : bz1;
+            if (t > 1) { pi = usgpr(glb_ld(g.pl_pidx + p0 + t)); bz = usgpr(glb_ld(g.pl_bonus + p0 + t)); }
+            const bool near = idx - pi <= K;
+            int pb, pe, hm, av, bv;
+            if (near) {
+                const int sp = (pi - bi) & KM;
+                const int be = LCD_RL(m_be, sp); pb = be & 65535; pe = (int)((unsigned)be >> 16);
+                if (pb > pe) continue;
+                const unsigned S = ring + 4 * sp * SLOTW;
+                hm = lds_ld(S + 4 * xm); av = lds_ld(S + 4 * (WIN + x)); bv = lds_ld(S + 4 * (2 * WIN + x));
+            } else { // a far row: its metadata and values were stored to HBM when it was made (and waited for before that row's closing barrier)
+                pb = usgpr(glb_ld(g.rbeg + pi)); pe = usgpr(glb_ld(g.rend + pi));
+                if (pb > pe) continue;
+                const int *G = g.spill + (size_t)(unsigned)usgpr(glb_ld((const int *)g.spoff + pi)) * SLOTW;
+                hm = glb_ld(G + xm); av = glb_ld(G + WIN + x); bv = glb_ld(G + 2 * WIN + x);
+                LCD_PIN(hm); LCD_PIN(av); LCD_PIN(bv);
+            }
+            // a slot is addressed by (column mod 256): entries that belong to other columns of the predecessor's interval, or to none, are fillers here
+            if (j - 1 < pb || j - 1 > pe) hm = LCD_GUARD;
+            if (j < pb || j > pe) { av = LCD_GUARD; bv = LCD_GUARD; }
+            const int tt = t > 255 ? 255 : t;
+            const int c = hm + sk + bz, a = av + bz, b = bv + bz;
+            if (t == 0) { nn = imax(nn, c); uu = imax(uu, a); vv = imax(vv, b); }
+            else {
+                if (c > nn) { nn = c; om = tt; }
+                if (a > uu) { uu = a; oa = tt; }
+                if (b > vv) { vv = b; ob = tt; }
+            }
+        }
+        // ---- F: prefix maximum of A[j] = Hpre[j] + j e over the row's columns, which start at thread (beg mod 256) and wrap ----
+        const int hp = imax(nn, imax(uu, vv));
+        const int spk = nn == hp ? 0 : uu == hp ? 1 : 2;
+        const int je1 = j * e1, je2 = j * e2;
+        const int a1 = inb ? hp + je1 : LCD_GUARD, a2 = inb ? hp + je2 : LCD_GUARD;
+        const int t0 = beg & WM, wrapw = t0 >> 6, wrapl = t0 & 63;
+        const bool tail = wave == wrapw && lane < wrapl;   // the row's last columns, in the lanes below the wrap point of that wavefront
+        int v1 = (inb && !tail) ? a1 + BIG : a1, v2 = (inb && !tail) ? a2 + BIG : a2;
+        scan_max2(v1, v2);
+        const int buf = idx & 1;
+        if (lane == 63) { sm.tot1[buf][wave] = v1 >= BIGT ? v1 - BIG : LCD_GUARD; sm.tot2[buf][wave] = v2 >= BIGT ? v2 - BIG : LCD_GUARD; } // total of the wavefront's first-columns segment
+        int x1 = shr1(LCD_GUARD, v1), x2 = shr1(LCD_GUARD, v2);
+        x1 = x1 >= BIGT ? x1 - BIG : (tail ? x1 : LCD_GUARD); x2 = x2 >= BIGT ? x2 - BIG : (tail ? x2 : LCD_GUARD);
+        lds_barrier<NT>();
+        {
+            const int pw = (wave - wrapw) & 3; // this wavefront's place in the row's column order
+            int c1 = LCD_GUARD, c2 = LCD_GUARD;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t1k = sm.tot1[buf][k], t2k = sm.tot2[buf][k];
+                const bool before = tail || ((k - wrapw) & 3) < pw;
+                c1 = before ? imax(c1, t1k) : c1; c2 = before ? imax(c2, t2k) : c2;
+            }
+            x1 = imax(x1, c1); x2 = imax(x2, c2);
+        }
+        // ---- phase B: F, H, E-out, direction code ----
+        const int f1 = imax(LCD_NEG, x1 - je1 - o1), f2 = imax(LCD_NEG, x2 - je2 - o2);
+        const int h = imax(hp, imax(f1, f2));
+        const int q1 = h - oe1, w1 = uu - e1, q2 = h - oe2, w2 = vv - e2;
+        const int eo1 = imax(imax(q1, w1), LCD_NEG), eo2 = imax(imax(q2, w2), LCD_NEG);
+        const int fk = f1 == h ? (f2 == h ? 5 : 3) : 4;
+        const int hs = hp == h ? spk : fk;
+        unsigned fl = 0; // O2, O1, Y2, Y1 pushed in this order = bits 6, 5, 4, 3 of the code
+        LCD_PUSH_GE(fl, q2, w2); LCD_PUSH_GE(fl, q1, w1); LCD_PUSH_GT(fl, x2, a2); LCD_PUSH_GT(fl, x1, a1);
+        const unsigned cd = (unsigned)hs | (fl << 3) | (om ? CB_PM : 0);
+        const int oh = inb ? h : LCD_GUARD, oa1 = inb ? eo1 : LCD_GUARD, oa2 = inb ? eo2 : LCD_GUARD;
+        // ---- stores: ring slot (values), HBM (codes; values only for rows a far successor / the end node will read) ----
+        const int cw4 = ((end - beg) + CP) & ~(CP - 1);
+        if (cused + (unsigned)cw4 > code_cap || (np > 1 && oused + (unsigned)cw4 > ord_cap) || (spf && nsp >= spill_rows)) { wo->status = LCD_ERR_CELLS; return 0; }
+        {
+            const unsigned S = ring + 4 * s * SLOTW;
+            *(lcd_lds_i32 *)(uintptr_t)(S + 4 * x) = oh; *(lcd_lds_i32 *)(uintptr_t)(S + 4 * (WIN + x)) = oa1; *(lcd_lds_i32 *)(uintptr_t)(S + 4 * (2 * WIN + x)) = oa2;
+            if (spf) { int *G = g.spill + (size_t)nsp * SLOTW; glb_st(G + x, oh); glb_st(G + WIN + x, oa1); glb_st(G + 2 * WIN + x, oa2); }
+            const int cj = j - beg;
+            if (cj < cw4) {
+                *(__attribute__((address_space(1))) uint8_t *)(g.code8 + (size_t)(cused + (unsigned)cj)) = (uint8_t)cd;
+                if (np > 1) glb_st(g.ord + (size_t)(oused + (unsigned)cj), om | (oa << 8) | (ob << 16));
+            }
+        }
+        const int be = beg | (end << 16);
+        r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)cused, wk, r_off);
+        m_be = lean_wlane(be, s, m_be);
+        if ((np > 1 || spf) && tid == 0) {
+            if (np > 1) glb_st(g.ooff + idx, (int)oused);
+            if (spf) { glb_st(g.rbeg + idx, beg); glb_st(g.rend + idx, end); glb_st(g.ml + idx, 0); glb_st(g.mr + idx, 0); glb_st(g.spoff + idx, nsp); }
+        }
+        cused += (unsigned)cw4; if (np > 1) oused += (unsigned)cw4;
+        if (spf) { ++nsp; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } // (a row that others will read from HBM: there before anybody passes the barrier)
+        ncell += (unsigned long long)(end - beg + 1);
+        lds_barrier<NT>(); // the ring slot, to the other wavefronts
+    }
+    flush_meta(wbase, ei - wbase);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    wo->cells = ncell;
+    const long long t_bt0 = clock64();
+    wo->t_dp = (unsigned long long)(t_bt0 - t_dp0);
+    if (wave == 0) code_backtrack(g, sm, pd, bi, ei, qlen, SLOTW, WM, lane, ~0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int n_cig = sm.bc[0];
+    wo->status = sm.bc[1];
+    wo->cig_pos = sm.bc[4];
+    wo->score = sm.bc[5];
+    __syncthreads();
+    wo->t_bt = (unsigned long long)(clock64() - t_bt0);
+    return n_cig;
+}
+
 // ================= unbanded K2 rows: systolic across the wavefronts of the workgroup =================
 // wb < 0 makes every row [0, qlen] (oracle: w = qlen), so nothing about a row depends on the other rows' maxima and the only
 // data that crosses a wavefront boundary is (a) H of the last column of the left neighbour's 256-column segment, for the
@@ -2364,7 +2583,14 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                 wo.status = g.status; wo.score = LCD_NEG;
                 // one, two or four cells per lane by the widest interval (hull widths are computed for 4-cell groups: the narrower variants keep a margin)
                 nc = -1;
-                if (!SOLO || wave == 0) {
+                bool by_all = false;
+                if constexpr (NT == 256) if (SOLO && g.solo == 2 && mw <= 256) { // the rows on all four wavefronts (align_lean_mw); -1: not there, wavefront 0 takes the read as before
+                    nc = align_lean_mw(&g, ro, so, pdo, sc, bi, ei, seq_hbm, qlen, &wo);
+                    __syncthreads();
+                    by_all = nc >= 0; // (every wavefront has the result)
+                    if (!by_all) { wo.status = g.status; wo.score = LCD_NEG; }
+                }
+                if (!by_all && (!SOLO || wave == 0)) {
                     if (mw <= 60) nc = align_lean<2, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
                     if (nc < 0 && mw <= 124) { win_sync<SOLO>(); nc = align_lean<2, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
                     if (nc < 0 && mw <= 256) { win_sync<SOLO>(); nc = align_lean<2, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
@@ -2372,7 +2598,7 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                     if (SOLO && lane == 0) { g_wide.ppi[0] = nc; g_wide.ppi[1] = wo.status; g_wide.ppi[2] = wo.score; g_wide.ppi[3] = wo.cig_pos; g_wide.po[0] = (unsigned)wo.cells; g_wide.po[1] = (unsigned)(wo.cells >> 32);
                                              g_wide.po[2] = (unsigned)wo.t_dp; g_wide.po[3] = (unsigned)(wo.t_dp >> 32); g_wide.po[4] = (unsigned)wo.t_bt; g_wide.po[5] = (unsigned)(wo.t_bt >> 32); }
                 }
-                if (SOLO) { // the result of wavefront 0 to everybody
+                if (SOLO && !by_all) { // the result of wavefront 0 to everybody
                     __syncthreads();
                     nc = g_wide.ppi[0]; wo.status = g_wide.ppi[1]; wo.score = g_wide.ppi[2]; wo.cig_pos = g_wide.ppi[3]; wo.cells = g_wide.po[0] | ((unsigned long long)g_wide.po[1] << 32);
                     wo.t_dp = g_wide.po[2] | ((unsigned long long)g_wide.po[3] << 32); wo.t_bt = g_wide.po[4] | ((unsigned long long)g_wide.po[5] << 32); wo.t_setup = 0;
@@ -2591,10 +2817,7 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
                 if (g.wmax <= 64) nc = align_lean<1, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
                 if (nc < 0 && g.wmax <= 128) { __syncthreads(); nc = align_lean<1, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
                 if (nc < 0) { __syncthreads(); nc = align_lean<1, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
-            } else if (NT == 256 && g.solo == 2 && g.wmax <= 256 && (nc = align_windowed<NT, 1, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo)) >= 0) {
-                // (LCD_SOLO_MW=1, experiment: the long chain's rows on all four wavefronts, one column per lane)
             } else if (NT == 256 && g.solo) { // a long K1 chain in a 256-thread workgroup: wavefront 0 runs the lean rows, the others wait for its result
-                __syncthreads();
                 if (wave == 0) {
                     if (g.wmax <= 64) nc = align_lean<1, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
                     if (nc < 0 && g.wmax <= 128) { win_sync<true>(); nc = align_lean<1, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
