@@ -234,7 +234,8 @@ struct lcd_batch_s {
     // (d_poa_arena: the ONE transient workspace of a submission led by this batch -- chain arenas, WFA wavefronts and edlib blocks in turn)
     DevBuf d_in, d_chains, d_preads, d_poa_arena, d_poa_out, d_poa_outs, d_ed_jobs, d_ed_outs, d_wfa_jobs,
         d_wfa_out, d_wfa_outs, d_str_jobs, d_str_outs, d_final, d_gate, d_cmp_jobs, d_cmp_outs, d_cmp_seg, d_cmp_segres, d_seg_out, d_rr,
-        d_var_jobs, d_var_outs, d_var_work, d_vreg_jobs, d_vreg_outs, d_var_out, d_slot_flags, d_spare, d_packed, d_unpack;
+        d_var_jobs, d_var_outs, d_var_work, d_vreg_jobs, d_vreg_outs, d_var_out, d_slot_flags, d_spare, d_packed, d_unpack,
+        d_early_arena, d_chains_early, d_preads_early, d_poa_outs_early;   // the long K2 chains that start before the anchor stage (run_many_once)
     bool uploaded = false, ran = false, downloaded = false;
     // results (host)
     std::vector<PoaChainOut> couts;
@@ -896,7 +897,7 @@ static long long chain_group_key(const PoaChain &pc) { return (long long)pc.thre
 // uploads `sub` (already ordered so that equal classes are contiguous) and launches one kernel per class
 // (different classes go to side streams so a long wide chain does not hold back the narrow ones)
 static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, DevBuf &d_chains, const PoaRead *d_reads, DevBuf &d_outs, LcdScoring sc,
-                              hipStream_t *side = nullptr, hipEvent_t *sev = nullptr, DevBuf *d_gate = nullptr, PoaSpare *spare = nullptr) {
+                              hipStream_t *side = nullptr, hipEvent_t *sev = nullptr, DevBuf *d_gate = nullptr, PoaSpare *spare = nullptr, int busy_idx = -1, double busy_load = 0) {
     HIPCHK(hipMemcpyAsync(d_chains.p, sub.data(), sub.size() * sizeof(PoaChain), hipMemcpyHostToDevice, st));
     // The wide classes start first, widest first: a 1 024-thread chain needs ALL the vector registers of a CU and a 512-thread chain half of
     // them, so once narrower workgroups are spread over the chip they wait for a CU to drain completely -- and they are the longest
@@ -949,6 +950,7 @@ static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, 
     // many short chains come last and fill the machine while the long ones finish
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t c) { return rank(a) != rank(c) ? rank(a) < rank(c) : grps[a].tail > grps[c].tail; });
     std::vector<double> load(ns, 0.0);
+    if (busy_idx >= 0 && busy_idx < ns) load[busy_idx] = busy_load; // (a stream that already runs the long chains launched before the anchor stage: run_many_once)
     std::vector<bool> used(ns, false);
     for (size_t k : order) {
         int best = 0;
@@ -1038,16 +1040,111 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         S.n_chains = (int)bs[k]->chains.size(); S.n_anchor_jobs = (int)bs[k]->anchors.size();
     }
     HIPCHK(hipEventRecord(L->ev[0], st));
-    // ---------------- S1: anchors (K4 prefilter + K3b) ----------------
+    // the reads of every chain with their device addresses (the anchor stage below narrows the partial reads of K1 chains; lengths never change)
     std::vector<std::vector<PoaRead>> preads(nb);
+    for (int k = 0; k < nb; ++k) { preads[k] = bs[k]->preads; const uint64_t in_base = bs[k]->d_in.addr(); for (auto &r : preads[k]) r.seq_off += in_base; }
+    // ---- capacities, classes and output blocks of the chains: nothing here depends on the anchor stage, and the longest K2 chains start before it (below) ----
+    std::vector<size_t> chain_base(nb + 1, 0), pread_base(nb + 1, 0);
+    for (int k = 0; k < nb; ++k) { chain_base[k + 1] = chain_base[k] + bs[k]->chains.size(); pread_base[k + 1] = pread_base[k] + preads[k].size(); }
+    const size_t nC_all = chain_base[nb];
+    std::vector<int> chain_batch(nC_all);
+    for (int k = 0; k < nb; ++k) for (size_t g = chain_base[k]; g < chain_base[k + 1]; ++g) chain_batch[g] = k;
+    std::vector<std::vector<uint64_t>> out_rel(nb);
+    std::vector<uint64_t> out_tots(nb, 0);
+    // Which chains are LONG (256-thread workgroup: rows on wavefront 0, per-read phases on four) is decided for the submission at hand: at most LCD_SOLO_N
+    // (default: one per two CUs) of the longest chains in flight, and none below LCD_SOLO_MIN read-bases.  A lone batch leaves most of the chip idle and its
+    // longest chain IS its latency, so there the cut is low; twenty batches keep the wide workgroups for their top hundred.  LCD_SOLO_RL fixes the cut instead.
+    if (!getenv("LCD_SOLO_RL")) {
+        static const long long solo_min = getenv("LCD_SOLO_MIN") ? atoll(getenv("LCD_SOLO_MIN")) : 20000;
+        static const int solo_n_env = getenv("LCD_SOLO_N") ? atoi(getenv("LCD_SOLO_N")) : -1;
+        const size_t solo_n = (size_t)(solo_n_env >= 0 ? solo_n_env : std::max(1, g_n_cus / 2));
+        std::vector<long long> rls;
+        for (int k = 0; k < nb; ++k) for (ChainRec &C : bs[k]->chains) {
+            int maxl = 0; for (size_t q = 0; q < C.members.size(); ++q) maxl = std::max(maxl, preads[k][C.read0 + q].len);
+            rls.push_back((long long)C.members.size() * maxl);
+        }
+        long long cut = solo_min;
+        if (solo_n == 0) cut = 1ll << 62;
+        else if (rls.size() > solo_n) { std::vector<long long> t = rls; std::nth_element(t.begin(), t.begin() + (solo_n - 1), t.end(), std::greater<long long>()); cut = std::max(cut, t[solo_n - 1]); }
+        size_t q = 0;
+        // (with the long K2 chains launched ahead of the anchor stage -- below -- one of the four hardware queues is theirs for the length of the submission: K1 chains,
+        //  which wait for their anchors, then stay in the single-wavefront class instead of forming a fourth launch group that would queue behind another)
+        static const bool early_k2 = !(getenv("LCD_EARLY") && atoi(getenv("LCD_EARLY")) == 0);
+        for (int k = 0; k < nb; ++k) for (ChainRec &C : bs[k]->chains) C.solo = rls[q++] >= cut && (C.mode == 1 || !early_k2) ? 1 : 0;
+    } else for (int k = 0; k < nb; ++k) for (ChainRec &C : bs[k]->chains) C.solo = -1;
+    auto size_chains = [&](const int k) { // capacities, class and output offsets of a batch's chains (independent of the other batches: host threads)
+        lcd_batch_t *b = bs[k];
+        const int nC = (int)b->chains.size();
+        b->couts.assign(nC, PoaChainOut());
+        b->pchains.assign(nC, PoaChain());
+        out_rel[k].resize(nC);
+        uint64_t out_tot = 0;
+        for (int c = 0; c < nC; ++c) {
+            b->chains[c].cert_level = -1; b->chains[c].cert_fail_round = -1; // (nothing about the certified band is remembered from an earlier run of the same batch)
+            chain_caps(b->opt, b->chains[c], preads[k], 1, b->pchains[c]);
+            out_rel[k][c] = out_tot; out_tot += lcd_align_up(poa_out_bytes(b->pchains[c].node_cap, b->pchains[c].n_reads), 256);
+        }
+        out_tots[k] = out_tot;
+    };
+    {
+        const int nth = std::max(1, std::min(nb, 8));
+        if (nth == 1) size_chains(0);
+        else {
+            std::atomic<int> next{0};
+            std::vector<std::thread> ths;
+            for (int t = 0; t < nth; ++t) ths.emplace_back([&]() { for (int k; (k = next.fetch_add(1)) < nb;) size_chains(k); });
+            for (auto &t : ths) t.join();
+        }
+    }
+    for (int k = 0; k < nb; ++k) {
+        lcd_batch_t *b = bs[k];
+        const int nC = (int)b->chains.size();
+        if (nC && b->d_poa_out.ensure(out_tots[k])) return -11;
+        for (int c = 0; c < nC; ++c) b->pchains[c].out_off = b->d_poa_out.addr() + out_rel[k][c];
+    }
+    auto PC = [&](size_t g) -> PoaChain & { const int k = chain_batch[g]; return bs[k]->pchains[g - chain_base[k]]; };
+    if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host]   POA prep: capacities after %.1f ms\n", now_ms() - t_begin);
+    // ---- the long K2 chains start NOW: they are the latency of the submission (the longest chain lasts as long as the whole POA stage) and need nothing from
+    // the anchor stage -- their reads are aligned whole.  Own stream, own chain table / read table / arenas (the anchor stage's workspace is the leader's arena);
+    // their results join the others' after the first round's launches.  LCD_EARLY=0: off (they start with everybody else, as before).
+    std::vector<size_t> early; std::vector<PoaChainOut> tmp_early;
+    // (streams share the runtime's four hardware queues in creation order: the leader's stream and its first three side streams have one each -- a later side
+    //  stream would share the leader's queue and hold the anchor stage and the first launch group behind the long chains: measured, 272 instead of 220 ms of POA)
+    hipStream_t es = L->side[2];
+    double early_load = 0;
+    {
+        static const bool early_on = !(getenv("LCD_EARLY") && atoi(getenv("LCD_EARLY")) == 0);
+        if (early_on && es) for (size_t g = 0; g < nC_all; ++g) { const PoaChain &pc = PC(g); if (pc.solo && pc.mode == 1 && pc.threads == 256 && pc.n_reads > 0) early.push_back(g); }
+        if (early.size() == nC_all) early.clear(); // (the first round below is built around the launches of the others)
+        if (!early.empty()) {
+            std::vector<PoaChain> sub_e(early.size());
+            uint64_t tot_e = 0;
+            for (size_t i = 0; i < early.size(); ++i) {
+                PoaChain &pc = PC(early[i]);
+                early_load = std::max(early_load, (double)pc.n_reads * (pc.max_len + 64));
+                pc.ws_off = tot_e; pc.slot_flags = 0; pc.slot_bytes = 0; pc.n_slots = 0; pc.per_cu = 0; pc.cu_rank = 0;
+                tot_e += lcd_align_up(poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads, pc.spill_x, pc.cert).total, 256);
+            }
+            if (L->d_early_arena.ensure(tot_e, 3) || L->d_preads_early.ensure(pread_base[nb] * sizeof(PoaRead)) || L->d_chains_early.ensure(early.size() * sizeof(PoaChain)) ||
+                L->d_poa_outs_early.ensure(early.size() * sizeof(PoaChainOut))) { (void)hipGetLastError(); early.clear(); } // (no memory for it: they start with the others)
+            else {
+                for (size_t i = 0; i < early.size(); ++i) { PoaChain &pc = PC(early[i]); pc.ws_off += L->d_early_arena.addr(); sub_e[i] = pc; sub_e[i].read0 += (int)pread_base[chain_batch[early[i]]]; }
+                HIPCHK(hipStreamWaitEvent(es, L->ev[0], 0)); // (behind whatever the leader's stream held before this submission)
+                for (int k = 0; k < nb; ++k) if (!preads[k].empty())
+                    HIPCHK(hipMemcpyAsync((PoaRead *)L->d_preads_early.p + pread_base[k], preads[k].data(), preads[k].size() * sizeof(PoaRead), hipMemcpyHostToDevice, es));
+                { const int rc2 = launch_poa_grouped(es, sub_e, L->d_chains_early, (const PoaRead *)L->d_preads_early.p, L->d_poa_outs_early, sc); if (rc2) return rc2; }
+                tmp_early.resize(early.size()); // (fetched when the first round's own launches are done: a copy into pageable memory would hold this thread until the chains end)
+                if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host]   %zu long K2 chains launched %.1f ms after the start (%.2f GB of arenas)\n", early.size(), now_ms() - t_begin, tot_e / 1e9);
+            }
+        }
+    }
+    // ---------------- S1: anchors (K4 prefilter + K3b) ----------------
     {
         std::vector<EdJob> ej; std::vector<WfaJob> wj;
         std::vector<size_t> ej_base(nb + 1, 0), wj_base(nb + 1, 0);
         for (int k = 0; k < nb; ++k) {
             lcd_batch_t *b = bs[k];
             const uint64_t in_base = b->d_in.addr();
-            preads[k] = b->preads;
-            for (auto &r : preads[k]) r.seq_off += in_base;
             ej_base[k] = ej.size(); wj_base[k] = wj.size();
             if (b->anchors.empty()) continue;
             for (EdJob j : b->ed_jobs) { j.q_off += in_base; j.t_off += in_base; ej.push_back(j); }
@@ -1108,70 +1205,13 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     const double tp0 = now_ms();
     if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host] anchor stage: %.1f ms on the host clock\n", tp0 - t_begin);
     // ---------------- S2: POA chains ----------------
-    std::vector<size_t> chain_base(nb + 1, 0), pread_base(nb + 1, 0);
-    for (int k = 0; k < nb; ++k) { chain_base[k + 1] = chain_base[k] + bs[k]->chains.size(); pread_base[k + 1] = pread_base[k] + preads[k].size(); }
-    const size_t nC_all = chain_base[nb];
-    std::vector<int> chain_batch(nC_all);
-    for (int k = 0; k < nb; ++k) for (size_t g = chain_base[k]; g < chain_base[k + 1]; ++g) chain_batch[g] = k;
-    std::vector<std::vector<uint64_t>> out_rel(nb);
-    std::vector<uint64_t> out_tots(nb, 0);
-    // Which chains are LONG (256-thread workgroup: rows on wavefront 0, per-read phases on four) is decided for the submission at hand: at most LCD_SOLO_N
-    // (default: one per two CUs) of the longest chains in flight, and none below LCD_SOLO_MIN read-bases.  A lone batch leaves most of the chip idle and its
-    // longest chain IS its latency, so there the cut is low; twenty batches keep the wide workgroups for their top hundred.  LCD_SOLO_RL fixes the cut instead.
-    if (!getenv("LCD_SOLO_RL")) {
-        static const long long solo_min = getenv("LCD_SOLO_MIN") ? atoll(getenv("LCD_SOLO_MIN")) : 20000;
-        static const int solo_n_env = getenv("LCD_SOLO_N") ? atoi(getenv("LCD_SOLO_N")) : -1;
-        const size_t solo_n = (size_t)(solo_n_env >= 0 ? solo_n_env : std::max(1, g_n_cus / 2));
-        std::vector<long long> rls;
-        for (int k = 0; k < nb; ++k) for (ChainRec &C : bs[k]->chains) {
-            int maxl = 0; for (size_t q = 0; q < C.members.size(); ++q) maxl = std::max(maxl, preads[k][C.read0 + q].len);
-            rls.push_back((long long)C.members.size() * maxl);
-        }
-        long long cut = solo_min;
-        if (solo_n == 0) cut = 1ll << 62;
-        else if (rls.size() > solo_n) { std::vector<long long> t = rls; std::nth_element(t.begin(), t.begin() + (solo_n - 1), t.end(), std::greater<long long>()); cut = std::max(cut, t[solo_n - 1]); }
-        size_t q = 0;
-        for (int k = 0; k < nb; ++k) for (ChainRec &C : bs[k]->chains) C.solo = rls[q++] >= cut ? 1 : 0;
-    } else for (int k = 0; k < nb; ++k) for (ChainRec &C : bs[k]->chains) C.solo = -1;
-    auto size_chains = [&](const int k) { // capacities, class and output offsets of a batch's chains (independent of the other batches: host threads)
-        lcd_batch_t *b = bs[k];
-        const int nC = (int)b->chains.size();
-        b->couts.assign(nC, PoaChainOut());
-        b->pchains.assign(nC, PoaChain());
-        out_rel[k].resize(nC);
-        uint64_t out_tot = 0;
-        for (int c = 0; c < nC; ++c) {
-            b->chains[c].cert_level = -1; b->chains[c].cert_fail_round = -1; // (nothing about the certified band is remembered from an earlier run of the same batch)
-            chain_caps(b->opt, b->chains[c], preads[k], 1, b->pchains[c]);
-            out_rel[k][c] = out_tot; out_tot += lcd_align_up(poa_out_bytes(b->pchains[c].node_cap, b->pchains[c].n_reads), 256);
-        }
-        out_tots[k] = out_tot;
-    };
-    {
-        const int nth = std::max(1, std::min(nb, 8));
-        if (nth == 1) size_chains(0);
-        else {
-            std::atomic<int> next{0};
-            std::vector<std::thread> ths;
-            for (int t = 0; t < nth; ++t) ths.emplace_back([&]() { for (int k; (k = next.fetch_add(1)) < nb;) size_chains(k); });
-            for (auto &t : ths) t.join();
-        }
-    }
-    for (int k = 0; k < nb; ++k) {
-        lcd_batch_t *b = bs[k];
-        const int nC = (int)b->chains.size();
-        if (nC && b->d_poa_out.ensure(out_tots[k])) return -11;
-        for (int c = 0; c < nC; ++c) b->pchains[c].out_off = b->d_poa_out.addr() + out_rel[k][c];
-    }
-    auto PC = [&](size_t g) -> PoaChain & { const int k = chain_batch[g]; return bs[k]->pchains[g - chain_base[k]]; };
-    if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host]   POA prep: capacities after %.1f ms\n", now_ms() - tp0);
     if (nC_all) {
         if (L->d_preads.ensure(pread_base[nb] * sizeof(PoaRead)) || L->d_chains.ensure(nC_all * sizeof(PoaChain)) || L->d_poa_outs.ensure(nC_all * sizeof(PoaChainOut))) return -11;
         for (int k = 0; k < nb; ++k)
             if (!preads[k].empty())
                 HIPCHK(hipMemcpyAsync((PoaRead *)L->d_preads.p + pread_base[k], preads[k].data(), preads[k].size() * sizeof(PoaRead), hipMemcpyHostToDevice, st));
-        std::vector<size_t> which(nC_all);
-        for (size_t g = 0; g < nC_all; ++g) which[g] = g;
+        std::vector<size_t> which; which.reserve(nC_all);
+        { std::vector<char> is_early(nC_all, 0); for (size_t g : early) is_early[g] = 1; for (size_t g = 0; g < nC_all; ++g) if (!is_early[g]) which.push_back(g); }
         // No more launch groups than streams: a stream runs its kernels one after the other, so a fifth group starts only when some other group's LAST chain has
         // ended -- with the bulk of the work (40 000 short chains in the smallest LDS bucket) queued behind a group of a few hundred long chains the chip idled for a
         // third of the stage.  The single-wavefront group with the fewest chains moves up into the next larger LDS bucket in use (a bigger pool is always valid).
@@ -1343,13 +1383,18 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             }
             if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host] POA stage: %.1f ms of host work before the launches of round %d\n", now_ms() - tp0, round);
             HIPCHK(hipEventRecord(L->ev[6], st));
-            { int rc2 = launch_poa_grouped(st, sub, L->d_chains, (const PoaRead *)L->d_preads.p, L->d_poa_outs, sc, L->side, L->sev, &L->d_gate, d_spare); if (rc2) return rc2; }
+            { int rc2 = launch_poa_grouped(st, sub, L->d_chains, (const PoaRead *)L->d_preads.p, L->d_poa_outs, sc, L->side, L->sev, &L->d_gate, d_spare, round == 0 && !early.empty() ? 3 : -1, early_load); if (rc2) return rc2; }
             HIPCHK(hipEventRecord(L->ev[7], st));
             std::vector<PoaChainOut> tmp(sub.size());
             HIPCHK(hipMemcpyAsync(tmp.data(), L->d_poa_outs.p, sub.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, st));
             PoaSpare spare_seen; spare_seen.used = 0; spare_seen.n_grown = spare_seen.n_refused = 0;
             if (d_spare) HIPCHK(hipMemcpyAsync(&spare_seen, d_spare, sizeof(PoaSpare), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
+            if (round == 0 && !early.empty()) { // the long chains that started before the anchor stage: from here on they are chains of this round like the others
+                HIPCHK(hipMemcpyAsync(tmp_early.data(), L->d_poa_outs_early.p, early.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, es));
+                HIPCHK(hipStreamSynchronize(es));
+                which.insert(which.end(), early.begin(), early.end()); tmp.insert(tmp.end(), tmp_early.begin(), tmp_early.end());
+            }
             if (d_spare) {
                 bs[0]->st.poa_grown += (int)spare_seen.n_grown; // (a count of the launch set: kept on the leader, so that the batches' statistics add up)
                 if (getenv("LCD_MEM_DEBUG")) fprintf(stderr, "[mem] round %d: spare DP memory %.2f GB: %u regions grown in place (%.2f GB), %u refused\n", round, L->d_spare.cap / 1e9, spare_seen.n_grown, spare_seen.used / 1e9, spare_seen.n_refused);
