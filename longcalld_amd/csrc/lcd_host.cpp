@@ -1155,11 +1155,15 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             std::vector<EdOut> eo; std::vector<WfaOut> wo;
             // (ONE transient arena per leader for every stage's workspace -- edlib blocks, WFA wavefronts, the chains' DP regions: the stages of a
             // submission follow each other on the leader's stream and none of them reads another's workspace, so the arena is their maximum, not their sum)
+            const bool th = getenv("LCD_TIME_HOST") != nullptr;
+            if (th) fprintf(stderr, "[host]   anchors: job tables (%zu edlib, %zu WFA) after %.1f ms\n", ej.size(), wj.size(), now_ms() - t_begin);
             int rc = run_edlib_stage(st, ej, L->d_ed_jobs, L->d_poa_arena, L->d_ed_outs, eo);
             if (rc) return rc;
+            if (th) { hipStreamSynchronize(st); fprintf(stderr, "[host]   anchors: edlib stage done after %.1f ms\n", now_ms() - t_begin); }
             rc = run_wfa_stage(st, wj, L->d_wfa_jobs, L->d_poa_arena, L->d_wfa_out, L->d_wfa_outs, wo, sc, nullptr, true);
             if (rc) return rc;
             HIPCHK(hipStreamSynchronize(st));
+            if (th) fprintf(stderr, "[host]   anchors: WFA stage done after %.1f ms\n", now_ms() - t_begin);
             // cigars of the anchor jobs: ONE device->host copy of the output span of all of them (a copy per job costs more in
             // launch overhead than in bytes)
             uint64_t lo = ~0ull, hi = 0;
@@ -1170,6 +1174,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                 HIPCHK(hipMemcpyAsync(L->h_cig.data(), (void *)(uintptr_t)lo, hi - lo, hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
             }
+            if (th) fprintf(stderr, "[host]   anchors: CIGARs (%.1f MB) on the host after %.1f ms\n", hi > lo ? (hi - lo) / 1e6 : 0.0, now_ms() - t_begin);
             for (auto &e : eo) if (e.status != LCD_OK) return set_err(-20, "edlib kernel status " + std::to_string(e.status));
             for (int k = 0; k < nb; ++k) {
                 lcd_batch_t *b = bs[k]; lcd_batch_stats_t &S = b->st;
