@@ -1021,6 +1021,9 @@ int lcd_batch_run_many(lcd_batch_t **bs, int nb) {
     drop(bs[h]);
     return r2;
 }
+// submissions in flight per device (host lanes: several threads inside lcd_batch_run_many at once)
+static std::atomic<int> g_inflight[LCD_MAX_DEV];
+struct InflightGuard { int dev; int n; InflightGuard(int d) : dev(d) { n = g_inflight[d].fetch_add(1) + 1; } ~InflightGuard() { g_inflight[dev].fetch_sub(1); } };
 static int run_many_once(lcd_batch_t **bs, int nb) {
     if (nb <= 0) return 0;
     for (int k = 0; k < nb; ++k) {
@@ -1033,6 +1036,11 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     hipStream_t st = L->stream;
     const LcdScoring sc = scoring_of(L->opt);
     const double t_begin = now_ms();
+    // The long K2 chains ahead of the anchor stage (below) take a stream -- one of the runtime's four hardware queues -- for the length of the submission.  That pays
+    // when this submission has the device to itself; with other submissions in flight (host lanes) the queues are what is scarce and the lanes overlap each other's
+    // stages anyway: measured with two lanes of 32 batches 82.8 k instead of 100 k regions/s.  LCD_EARLY=0: never.
+    InflightGuard inflight(L->device >= 0 && L->device < LCD_MAX_DEV ? L->device : 0);
+    const bool early_k2 = inflight.n == 1 && !(getenv("LCD_EARLY") && atoi(getenv("LCD_EARLY")) == 0);
     for (int k = 0; k < nb; ++k) {
         lcd_batch_stats_t &S = bs[k]->st;
         const double keep_up = S.ms_upload;
@@ -1069,7 +1077,6 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         size_t q = 0;
         // (with the long K2 chains launched ahead of the anchor stage -- below -- one of the four hardware queues is theirs for the length of the submission: K1 chains,
         //  which wait for their anchors, then stay in the single-wavefront class instead of forming a fourth launch group that would queue behind another)
-        static const bool early_k2 = !(getenv("LCD_EARLY") && atoi(getenv("LCD_EARLY")) == 0);
         for (int k = 0; k < nb; ++k) for (ChainRec &C : bs[k]->chains) C.solo = rls[q++] >= cut && (C.mode == 1 || !early_k2) ? 1 : 0;
     } else for (int k = 0; k < nb; ++k) for (ChainRec &C : bs[k]->chains) C.solo = -1;
     auto size_chains = [&](const int k) { // capacities, class and output offsets of a batch's chains (independent of the other batches: host threads)
@@ -1113,8 +1120,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     hipStream_t es = L->side[2];
     double early_load = 0;
     {
-        static const bool early_on = !(getenv("LCD_EARLY") && atoi(getenv("LCD_EARLY")) == 0);
-        if (early_on && es) for (size_t g = 0; g < nC_all; ++g) { const PoaChain &pc = PC(g); if (pc.solo && pc.mode == 1 && pc.threads == 256 && pc.n_reads > 0) early.push_back(g); }
+        if (early_k2 && es) for (size_t g = 0; g < nC_all; ++g) { const PoaChain &pc = PC(g); if (pc.solo && pc.mode == 1 && pc.threads == 256 && pc.n_reads > 0) early.push_back(g); }
         if (early.size() == nC_all) early.clear(); // (the first round below is built around the launches of the others)
         if (!early.empty()) {
             std::vector<PoaChain> sub_e(early.size());
