@@ -897,7 +897,7 @@ static long long chain_group_key(const PoaChain &pc) { return (long long)pc.thre
 // uploads `sub` (already ordered so that equal classes are contiguous) and launches one kernel per class
 // (different classes go to side streams so a long wide chain does not hold back the narrow ones)
 static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, DevBuf &d_chains, const PoaRead *d_reads, DevBuf &d_outs, LcdScoring sc,
-                              hipStream_t *side = nullptr, hipEvent_t *sev = nullptr, DevBuf *d_gate = nullptr, PoaSpare *spare = nullptr, int busy_idx = -1, double busy_load = 0) {
+                              hipStream_t *side = nullptr, hipEvent_t *sev = nullptr, DevBuf *d_gate = nullptr, PoaSpare *spare = nullptr, int busy_idx = -1, double busy_load = 0, bool noisy = false) {
     HIPCHK(hipMemcpyAsync(d_chains.p, sub.data(), sub.size() * sizeof(PoaChain), hipMemcpyHostToDevice, st));
     // The wide classes start first, widest first: a 1 024-thread chain needs ALL the vector registers of a CU and a 512-thread chain half of
     // them, so once narrower workgroups are spread over the chip they wait for a CU to drain completely -- and they are the longest
@@ -931,6 +931,10 @@ static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, 
         // a group's demand in CU-time: a chain runs ~ reads x rows (a row costs about the same few thousand cycles in every class), and
         // `per_cu` chains of this (threads, LDS) shape share a CU (160 KB LDS, 16 wavefronts at 128 VGPRs)
         double tail = 0;
+        // (time per read-base by kind, measured with LCD_PROFILE_CHAINS on the SV shape: K1 chains of noisy reads 11 - 12 us -- general rows, a re-sort after every read --
+        //  K2 chains of noisy reads 6 - 7 us in every wide class; clean reads 1.6 us.  Tried: weighting the noisy K1 chains 1.8x here -- the eight launch groups of an
+        //  SV-shape submission are already packed onto the four queues within 5 % of each other (LCD_GROUP_DEBUG=1 prints the table), 1 676 regions/s either way;
+        //  eight hardware queues (GPU_MAX_HW_QUEUES=8 LCD_STREAMS=8) make it worse, 1 398: the queues time-slice)
         while (j < sub.size() && chain_group_key(sub[j]) == key) { const double t = (double)sub[j].n_reads * (sub[j].max_len + 64); cost += t; tail = std::max(tail, t); ++j; }
         {
             const int lds = sub[i].lds_words * 4, thr = sub[i].threads;
@@ -958,6 +962,8 @@ static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, 
         // a stream runs its kernels one after the other, and a kernel lasts at least as long as its longest chain whatever else shares the chip: what adds up on a
         // stream is tail + share of the chip's work, not the work alone (two groups of a few long chains each on one stream were the whole tail of an
         // SV-shape submission: 7.8 s before the last group could start, with 0.9 s of work for 256 CUs)
+        if (getenv("LCD_GROUP_DEBUG")) fprintf(stderr, "[groups] thr %4d lds %3dK: %6zu chains, tail %.3g, cost / CUs %.3g -> stream %d (load %.3g before)\n", chain_threads(sub[grps[k].i]), sub[grps[k].i].lds_words * 4 >> 10,
+                                               grps[k].j - grps[k].i, grps[k].tail, grps[k].cost / std::max(1, g_n_cus), best, load[best]);
         load[best] += grps[k].tail + grps[k].cost / std::max(1, g_n_cus);
         // stream 0 is the caller's; the others are side streams that first wait for the chain table to be uploaded
         hipStream_t s = best == 0 ? st : side[best - 1];
@@ -1394,7 +1400,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             }
             if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host] POA stage: %.1f ms of host work before the launches of round %d\n", now_ms() - tp0, round);
             HIPCHK(hipEventRecord(L->ev[6], st));
-            { int rc2 = launch_poa_grouped(st, sub, L->d_chains, (const PoaRead *)L->d_preads.p, L->d_poa_outs, sc, L->side, L->sev, &L->d_gate, d_spare, round == 0 && !early.empty() ? 3 : -1, early_load); if (rc2) return rc2; }
+            { int rc2 = launch_poa_grouped(st, sub, L->d_chains, (const PoaRead *)L->d_preads.p, L->d_poa_outs, sc, L->side, L->sev, &L->d_gate, d_spare, round == 0 && !early.empty() ? 3 : -1, early_load, L->opt.is_ont != 0); if (rc2) return rc2; }
             HIPCHK(hipEventRecord(L->ev[7], st));
             std::vector<PoaChainOut> tmp(sub.size());
             HIPCHK(hipMemcpyAsync(tmp.data(), L->d_poa_outs.p, sub.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, st));
