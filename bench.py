@@ -191,6 +191,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=200, help="cap on regions per CPU worker of the cpu_baseline leg, which is bounded to ~12 s (rank 0, N=1 only; 0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU worker processes of the cpu_baseline leg (0 = all host cores)")
     ap.add_argument("--seed", type=int, default=20250928)
+    ap.add_argument("--f3", type=int, default=-1, help="also measure the step in FRONT of the path on the device (SURVEY 8f f3; never part of `value`): BGZF inflate of 128 MB of BAM-like "
+                                                       "data against host zlib, and one 500 kb chunk of an indexed BAM -> device-resident chunk against the host loader; -1 = on for the "
+                                                       "single-GPU HiFi line, 0 = off")
     ap.add_argument("--lanes", type=int, default=0,
                     help="concurrent submission lanes per GPU (host threads, one leader lcd_batch_t + HIP stream each) -- the reference's own "
                          "execution model: kt_for runs n_threads chunk workers concurrently (src/call_var_main.c:773); the K steps are "
@@ -582,6 +585,21 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if (args.f3 > 0 or (args.f3 < 0 and world == 1 and not job_mode and args.shape == "hifi" and args.cpu_sample > 0)):
+            try:   # (tools/: importable measurements; a failure here never costs the line)
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_f3
+                import bench_inflate
+                inf = bench_inflate.measure(128, 2, host_threads=(16,))
+                ch = bench_f3.measure(600, 3)
+                out["f3_device"] = {"what": "in front of the path, never part of `value`: lcd_bgzf_inflate_dev (one wavefront per BGZF block, CRC-32 checked on the device) against zlib on host "
+                                            "threads, 128 MB of BAM-like records; lcd_chunk_create_from_bam (compressed blocks up, records + digars in HBM) against lcd_bam_load_region_indexed + "
+                                            "lcd_chunk_create for one 500 kb chunk (tools/bench_inflate.py, tools/bench_f3.py)",
+                                    "inflate_device_GBps_out": inf["device_crc1"]["kernel_GBps_out"], "inflate_device_call_ms": inf["device_crc1"]["call_ms"],
+                                    "inflate_host_zlib_1_thread_GBps_out": inf["host_zlib_1_thread_GBps_out"], "inflate_host_zlib_16_threads_GBps_out": inf.get("host_zlib_16_threads_GBps_out"),
+                                    "chunk_reads": ch["reads_in_region"], "chunk_device_ms": ch["device_path_ms"], "chunk_host_ms": round(ch["host_load_ms"] + ch["host_chunk_create_ms"], 2)}
+            except Exception as e:  # noqa
+                out["f3_device"] = {"error": repr(e)[:300]}
         if job_mode:
             out["queue_rebalance"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in (rb_stats or {}).items() if not k.startswith("loads")}
             out["config"]["sharding"] = (f"{int(round(args.job_mb / CHUNK_MB))} chunks of {CHUNK_MB} Mb in contiguous blocks per rank"

@@ -9,7 +9,9 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os  # noqa: E402
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, "tests"))
 from longcalld_amd import _lib, align as lcd  # noqa: E402
 from test_io import BamReads, _bgzf, _write_bai  # noqa: E402
 
@@ -51,13 +53,10 @@ def make_bam(path, n_reads, rng, span=500000, start=1000000):
     return len(d)
 
 
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+def measure(n=1000, reps=5, path="/tmp/f3_bench.bam"):
+    """-> dict: one 500 kb chunk of a 30x HiFi-like BAM of n reads -> lcd_chunk_t through the host loader and through the device path (medians of `reps`)"""
     rng = np.random.default_rng(3)
-    path = "/tmp/f3_bench.bam"
     ubytes = make_bam(path, n, rng)
-    import os
     L = C.CDLL(_lib.LIB_PATH)
     L.lcd_bam_load_region_indexed.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int, C.POINTER(BamReads)]
     beg, end = 1000000, 1500000
@@ -86,7 +85,8 @@ def main():
     host.sort(key=lambda x: x[0] + x[1]); dev.sort()
     res.update(reads_in_region=m, host_load_ms=round(host[len(host) // 2][0], 2), host_chunk_create_ms=round(host[len(host) // 2][1], 2),
                device_path_ms=round(dev[len(dev) // 2], 2), note="host_chunk_create includes the Python wrapper's array packing; host_load is one thread (the reference's per-chunk worker)")
-    print(json.dumps(res))
+    return res
 
 
-main()
+if __name__ == "__main__":
+    print(json.dumps(measure(int(sys.argv[1]) if len(sys.argv) > 1 else 1000, int(sys.argv[2]) if len(sys.argv) > 2 else 5)))

@@ -2,6 +2,7 @@
 usage: python tools/bench_inflate.py [MB of uncompressed stream, default 256] [repeats]"""
 import ctypes as C
 import json
+import os
 import struct
 import sys
 import time
@@ -10,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from longcalld_amd import _lib  # noqa: E402
 
 
@@ -33,9 +34,8 @@ def bam_like(rng, nbytes):
     return b"".join(out)[:nbytes]
 
 
-def main():
-    mb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+def measure(mb=256, reps=3, host_threads=(8, 32, 0)):
+    """-> dict: device inflate (kernel / upload / call ms, GB/s) and host zlib on 1 and on `host_threads` threads (0 = all cores) for `mb` MB of BAM-like data"""
     rng = np.random.default_rng(1)
     data = bam_like(rng, mb << 20)
     blocks = [data[o:o + 65280] for o in range(0, len(data), 65280)]
@@ -80,12 +80,18 @@ def main():
     t0 = time.perf_counter(); n1 = sum(inf(c) for c in raw[:400]); t1 = time.perf_counter() - t0
     res["host_zlib_1_thread_GBps_out"] = round(n1 / t1 / 1e9, 3)
     import os
-    for th in (8, 32, os.cpu_count() or 1):
+    for th in sorted({t if t > 0 else (os.cpu_count() or 1) for t in host_threads}):
         with ThreadPoolExecutor(th) as ex:
             t0 = time.perf_counter(); n = sum(ex.map(inf, raw, chunksize=8)); t = time.perf_counter() - t0
         res["host_zlib_%d_threads_GBps_out" % th] = round(n / t / 1e9, 3)
     res["host_cores"] = os.cpu_count()
-    print(json.dumps(res))
+    return res
+
+
+def main():
+    mb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    print(json.dumps(measure(mb, reps)))
 
 
 if __name__ == "__main__":
