@@ -2284,12 +2284,15 @@ __device__ __forceinline__ int wlane(const int val, const int l, int old) { // o
 __device__ __forceinline__ int cert_G(const int k, const int o1, const int e1, const int o2, const int e2) { return k <= 0 ? 0 : imin(o1 + e1 * k, o2 + e2 * k); }
 // forward / backward passes over the rows.  One wavefront; the rows are walked one by one with the values of the current and the previous 64-row block in
 // registers (lane = row - block base), so a predecessor / successor within 64..127 rows costs a v_readlane / v_writelane and only far ones go to HBM
+// SIDES: 1 = the source-side sweep, 2 = the sink-side sweep, 3 = both (the two are independent: a workgroup with a second wavefront runs them side by side)
+template <int SIDES>
 __device__ __attribute__((noinline)) void cert_node_arrays(const Ctx *gp_, const int bi_, const int ei_) {
     Ctx g = *usgpr(gp_); ctx_to_sgpr(g);
     const int bi = usgpr(bi_), ei = usgpr(ei_);
     const int lane = threadIdx.x & 63;
     const size_t cap = (size_t)g.node_cap;
     int *const dmin = g.cert, *const dmax = g.cert + cap, *const bp = g.cert + 2 * cap, *const rmin = g.cert + 3 * cap, *const rmax = g.cert + 4 * cap, *const bs = g.cert + 5 * cap;
+    if constexpr ((SIDES & 1) != 0) {
     // ---- source side ----
     int prev_mn = CERT_INF, prev_mx = -1, prev_b = LCD_NEG;
     for (int base = bi; base < ei; base += 64) {
@@ -2342,6 +2345,8 @@ __device__ __attribute__((noinline)) void cert_node_arrays(const Ctx *gp_, const
         prev_mn = cur_mn; prev_mx = cur_mx; prev_b = cur_b;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // a far successor reads these back
     }
+    }
+    if constexpr ((SIDES & 2) == 0) return;
     // ---- sink side: every row pushes (minR + 1, maxR + 1, Bs + bonus) to its predecessors, rows in descending order; the sink itself counts no node ----
     for (int i = bi + lane; i < ei; i += 64) { glb_st(rmin + i, CERT_INF); glb_st(rmax + i, -1); glb_st(bs + i, LCD_NEG); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2437,7 +2442,8 @@ __device__ int cert_ubtop(const Ctx &g, const int ei, const int qlen, const LcdS
 // it, so the hull's ends are found by one bisection each, on the first / last segment that has an end point at or above the bound.
 // Returns the widest window a row needs (columns from lo rounded down to the lane's 4-cell group to hi, + 2), or -1 when the source row has no interval
 // starting at column 0 (the guess was above the optimum).
-__device__ __attribute__((noinline)) int cert_hull(const Ctx *gp_, const int bi_, const int ei_, const int qlen_, const int sest_, const LcdScoring sc_) {
+// (wv of nw wavefronts: every nw-th block of 64 rows; the caller combines the wavefronts' results -- any -1, else the maximum)
+__device__ __attribute__((noinline)) int cert_hull(const Ctx *gp_, const int bi_, const int ei_, const int qlen_, const int sest_, const LcdScoring sc_, const int wv_ = 0, const int nw_ = 1) {
     Ctx g = *usgpr(gp_); ctx_to_sgpr(g);
     const int bi = usgpr(bi_), ei = usgpr(ei_), qlen = usgpr(qlen_), sest = usgpr(sest_);
     const int M = usgpr(sc_.match), o1 = usgpr(sc_.o1), e1 = usgpr(sc_.e1), o2 = usgpr(sc_.o2), e2 = usgpr(sc_.e2);
@@ -2447,7 +2453,8 @@ __device__ __attribute__((noinline)) int cert_hull(const Ctx *gp_, const int bi_
     int *hull = g.cert + 6 * cap;
     const int O = imax(o1, o2);
     int maxw = 0, src_ok = 1;
-    for (int base = bi; base < ei; base += 64) {
+    const int wv = usgpr(wv_), nw = usgpr(nw_);
+    for (int base = bi + 64 * wv; base < ei; base += 64 * nw) {
         const int ri = base + lane;
         int lo = 1, hi = 0;
         if (ri < ei) {
@@ -2533,7 +2540,8 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
             constexpr int WINC = 504; // the widest window the rows below hold (8 cells per lane, intervals start on a multiple of 8: hull widths are counted from a multiple of 4)
             if (qlen >= 65536 || ei - bi < 2) { g.status = LCD_ERR_CERT; return leave(0); }
             const long long tca0 = clock64();
-            if (wave == 0) cert_node_arrays(&g, bi, ei);   // (wavefront 0; the others only meet the barriers)
+            if constexpr (NT >= 128) { if (wave == 0) cert_node_arrays<1>(&g, bi, ei); else if (wave == 1) cert_node_arrays<2>(&g, bi, ei); } // (source side / sink side; the others only meet the barrier)
+            else cert_node_arrays<3>(&g, bi, ei);
             __syncthreads();
             g.t_plan += (unsigned long long)(clock64() - tca0); // (profiling: the bound's node arrays)
             const unsigned long long cells_before = *cells_acc;
@@ -2546,9 +2554,11 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
             bool done = false;
             auto hull_of = [&](const int sest) { // every row's interval for this score bound (table in g.cert); the widest window a row needs, or -1
                 const long long th0 = clock64();
-                if (wave == 0) { const int m = cert_hull(&g, bi, ei, qlen, sest, sc); if (lane == 0) sm.bc[6] = m; }
+                { const int mv = cert_hull(&g, bi, ei, qlen, sest, sc, wave, NT / 64); if (lane == 0) sm.scan[wave] = mv; } // (the rows are independent: every wavefront takes its share)
                 __syncthreads();
-                const int m = sm.bc[6];
+                int m = 0;
+#pragma unroll
+                for (int k = 0; k < NT / 64; ++k) { const int v = sm.scan[k]; m = (m < 0 || v < 0) ? -1 : imax(m, v); }
                 __syncthreads();
                 g.t_poll += (unsigned long long)(clock64() - th0); // (profiling: the rows' intervals)
                 return m;
@@ -2633,7 +2643,8 @@ __device__ __attribute__((noinline)) int align_certified_sys(Ctx *gp, const unsi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (qlen >= 65535 || ei - bi < 2 || qlen + 2 > 4 * NT) return -3;
     const long long tca0 = clock64();
-    if (wave == 0) cert_node_arrays(&g, bi, ei);
+    if constexpr (NT >= 128) { if (wave == 0) cert_node_arrays<1>(&g, bi, ei); else if (wave == 1) cert_node_arrays<2>(&g, bi, ei); }
+    else cert_node_arrays<3>(&g, bi, ei);
     __syncthreads();
     g.t_plan += (unsigned long long)(clock64() - tca0);
     const unsigned long long cells_before = *cells_acc;
