@@ -1083,7 +1083,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         size_t q = 0;
         // (with the long K2 chains launched ahead of the anchor stage -- below -- one of the four hardware queues is theirs for the length of the submission: K1 chains,
         //  which wait for their anchors, then stay in the single-wavefront class instead of forming a fourth launch group that would queue behind another)
-        for (int k = 0; k < nb; ++k) for (ChainRec &C : bs[k]->chains) C.solo = rls[q++] >= cut && (C.mode == 1 || !early_k2) ? 1 : 0;
+        for (int k = 0; k < nb; ++k) for (ChainRec &C : bs[k]->chains) C.solo = rls[q++] >= cut && (C.mode == 1 || !early_k2) ? 1 : 0; // (noisy reads have no certified-band K2 chains, but their long K1 chains are no faster in the wide workgroup: SV shape 1 608 with them there, 1 680 without)
     } else for (int k = 0; k < nb; ++k) for (ChainRec &C : bs[k]->chains) C.solo = -1;
     auto size_chains = [&](const int k) { // capacities, class and output offsets of a batch's chains (independent of the other batches: host threads)
         lcd_batch_t *b = bs[k];
@@ -1777,6 +1777,11 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                 tt += o.t_total; td += o.t_dp; tb += o.t_bt; tg += o.t_graph; to += o.t_out; ts += o.t_sub; tbp += o.t_bp; tad += o.t_add; tso += o.t_sort; tse += o.t_setup; tpl += o.t_plan; if (o.t_total >= mx) { mx = o.t_total; mxc = g; } }
             if (!cnt) continue;
             fprintf(stderr, "[lcd] class %4d: row plan %.3e  graph update %.3e  re-sort %.3e  row setup %.3e  bound arrays %.3e\n", cls, (double)tbp, (double)tad, (double)tso, (double)tse, (double)tpl);
+            if (getenv("LCD_DBG") && (atoi(getenv("LCD_DBG")) & 32)) { // reads of certified-band chains by their widest interval (the t_setup slot carries five 12-bit counters per chain)
+                unsigned long long h[5] = {0, 0, 0, 0, 0};
+                for (size_t g = 0; g < nC_all; ++g) { if (chain_threads(PC(g)) != cls || !PC(g).cert) continue; const unsigned long long v = bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]].t_setup; for (int q = 0; q < 5; ++q) h[q] += (v >> (12 * q)) & 4095; }
+                fprintf(stderr, "[lcd] class %4d: certified-band reads by widest interval <= 60 / 124 / 188 / 256 / wider: %llu / %llu / %llu / %llu / %llu\n", cls, h[0], h[1], h[2], h[3], h[4]);
+            }
             { double tk = 0; for (size_t g = 0; g < nC_all; ++g) if (chain_threads(PC(g)) == cls) tk += (double)bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]].t_poll;
               fprintf(stderr, "[lcd] class %4d: %5d chains  sum ticks total %.3e dp %.3e bt %.3e graph %.3e (of which serial Kahn walk %.3e) sub %.3e out %.3e\n", cls, cnt, (double)tt, (double)td, (double)tb, (double)tg, tk, (double)ts, (double)to); }
             const PoaChainOut &o = bs[chain_batch[mxc]]->couts[mxc - chain_base[chain_batch[mxc]]];

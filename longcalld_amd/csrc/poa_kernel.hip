@@ -2591,6 +2591,7 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                     continue;
                 }
                 wo.status = g.status; wo.score = LCD_NEG;
+                if (sc.dbg & 32) g.t_setup += 1ull << (12 * (mw <= 60 ? 0 : mw <= 124 ? 1 : mw <= 188 ? 2 : mw <= 256 ? 3 : 4)); // (LCD_DBG=32: reads per widest-interval class, 12 bits each, in the t_setup slot)
                 // one, two or four cells per lane by the widest interval (hull widths are computed for 4-cell groups: the narrower variants keep a margin)
                 nc = -1;
                 bool by_all = false;
@@ -2616,7 +2617,7 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                 }
                 if (nc < 0) return leave(to_generic((ubtop - sest) + (ubtop - sest) / 2 + 48)); // (the window's alias checks: rare)
                 if (wo.status != LCD_OK) { g.status = wo.status; return leave(0); }
-                g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells; g.t_setup += wo.t_setup; wo.t_setup = 0;
+                g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells; if (!(sc.dbg & 32)) g.t_setup += wo.t_setup; wo.t_setup = 0;
                 const int S = wo.score;
                 if (S > LCD_NEG / 2) {
                     sbest = imax(sbest, S);
