@@ -3133,7 +3133,15 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
 template <int NT>
 __device__ __attribute__((noinline)) bool grow_dp_region(Ctx &g, Smem &sm, const PoaChain &ch, PoaSpare *sp) {
     if (!sp || ch.cert == 1) return false;
-    const unsigned long long worst = (unsigned long long)g.node_cap * (unsigned long long)(ch.max_len + 1);
+    // the most a read can need: every node a row of every column -- or every row SPILLED (12 bytes per window column whatever the row's width: in the graphs of noisy
+    // reads nearly every row has a successor beyond the ring, and the wide classes' windows are thousands of columns: K2 chains of 59 x 1 - 2 kb ended here at their
+    // 55th read with the cells' bound reached and a third of the rows' worth of spill space)
+    unsigned long long worst = (unsigned long long)g.node_cap * (unsigned long long)(ch.max_len + 1);
+    {
+        const unsigned long long win = (NT == 64 || ch.solo) ? (unsigned long long)ch.wmax : 4ull * NT;
+        const unsigned long long spill_all = ((unsigned long long)g.node_cap * 3ull * win * 4ull) / (unsigned long long)(g.spill_x > 2 ? g.spill_x : 2) + 128;
+        if (spill_all > worst) worst = spill_all;
+    }
     if (g.cell_cap >= worst) return false;
     unsigned long long nc = g.cell_cap * 4ull; if (nc > worst) nc = worst;
     const unsigned long long a = lcd_align_up(nc, 16), bytes = lcd_align_up(a * (unsigned long long)(g.spill_x > 2 ? 1 + 4 + g.spill_x : 4) + 64, 256);
