@@ -900,7 +900,9 @@ static void chain_class(PoaChain &pc, bool noisy) {
     //  chains of clean reads too: no change at 2 x 32 batches, 47 k instead of 60 k regions/s at one submission of 20)
     if ((threads == 64 || pc.solo) && pc.mode == 0 && noisy && K == 2) {
         static const bool rk_free = !(getenv("LCD_RING_K_FREE") && atoi(getenv("LCD_RING_K_FREE")) == 0);
-        while (rk_free && K < 8 && (long long)(2 * K) * 3 * wmax * 4 + seq_bytes <= lds) K *= 2;
+        // (only in the buckets the default pool cap produces: with LCD_LDS_CAP_KB=16 the same rule gives eight slots of 128 columns, and an ONT-shape run with those did
+        //  not come back -- found at the end of round 3, not understood yet; the generic rows and two slots are fine there)
+        while (rk_free && lds <= (12 << 10) && K < 8 && (long long)(2 * K) * 3 * wmax * 4 + seq_bytes <= lds) K *= 2;
     }
     pc.threads = threads; pc.wmax = wmax; pc.lds_words = lds / 4; pc.ring_k = (threads == 64 || pc.solo) ? K : 0;
 }
