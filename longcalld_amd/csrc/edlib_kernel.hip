@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(64) lcd_edlib_kernel(const EdJob *jobs, const 
     const int qlen = jb.qlen, tlen = jb.tlen;
     if (qlen == 0 || tlen == 0) { // edlib.cpp:166-173: distance only, no alignment
         out.dist = qlen > tlen ? qlen : tlen;
-        if (lane == 0) outs[jid] = out;
+        if (lane == 0) outs[jb.pad_] = out;
         return;
     }
     // arena: P[52429] M[52429] (u64) S[52429] (i32) | colL[qlen] colR[qlen] | hcarry[2*tlen]
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(64) lcd_edlib_kernel(const EdJob *jobs, const 
         sg_pass<0>(top, tlen, false, lane, hcarry, &blocks, &best, &endf, &endl);
         Sub pre = {q, t, qlen, endf + 1};
         sg_pass<1>(pre, endf + 1, true, lane, hcarry, &blocks, &best2, &sf, &sl);
-        if (best2 != best || endf < 0 || sl < 0) { out.status = LCD_ERR_BACKTRACK; if (lane == 0) outs[jid] = out; return; }
+        if (best2 != best || endf < 0 || sl < 0) { out.status = LCD_ERR_BACKTRACK; if (lane == 0) outs[jb.pad_] = out; return; }
         dist = best; t0 = endf - sl; tl0 = sl + 1;
         out.start = t0; out.end = endf;
     } else
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(64) lcd_edlib_kernel(const EdJob *jobs, const 
     out.n_eq = T.n_eq;
     out.n_xid = T.n_mis + T.n_ins + T.n_del;
     out.blocks = blocks;
-    if (lane == 0) outs[jid] = out;
+    if (lane == 0) outs[jb.pad_] = out;
 }
 
 void lcd_launch_edlib(const EdJob *jobs, const uint8_t *pool, uint8_t *arena, EdOut *outs, int n_jobs, hipStream_t stream) {

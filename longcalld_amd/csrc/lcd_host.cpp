@@ -313,6 +313,10 @@ int run_edlib_stage(hipStream_t st, std::vector<EdJob> &jobs, DevBuf &d_jobs, De
     outs.resize(n);
     if (n == 0) return 0;
     uint64_t tot = 0;
+    // Longest pairs first: the kernel is one wavefront per pair and lasts as long as the pair that ends last -- in submission order a 4 kb x 4 kb pair near the end of
+    // 17 000 was the stage's tail.  pad_ carries the pair's index in the caller's order: that is where its result goes.
+    for (int i = 0; i < n; ++i) jobs[i].pad_ = i;
+    std::stable_sort(jobs.begin(), jobs.end(), [](const EdJob &a, const EdJob &b) { return (long long)a.qlen * a.tlen > (long long)b.qlen * b.tlen; });
     for (auto &j : jobs) { j.ws_bytes = lcd_align_up(ed_arena_bytes(j.qlen, j.tlen), 256); j.ws_off = tot; tot += j.ws_bytes; }
     if (d_arena.ensure(tot)) return -11;
     for (auto &j : jobs) j.ws_off += d_arena.addr();

@@ -213,7 +213,7 @@ struct EdJob {
     uint64_t q_off, t_off;
     int qlen, tlen;
     uint64_t ws_off, ws_bytes;
-    int mode, pad_;   // 0: NW (edlib_xgaps / edlib_end2end_aln / edlib_edit_distance), 1: HW = infix (edlib_infix_aln, src/align.c:256)
+    int mode, pad_;   // pad_: where the result goes (index in the caller's order; run_edlib_stage launches the longest pairs first).  mode 0: NW (edlib_xgaps / edlib_end2end_aln / edlib_edit_distance), 1: HW = infix (edlib_infix_aln, src/align.c:256)
 };
 struct EdOut {
     int status, dist, xgaps, n_eq, n_xid;
