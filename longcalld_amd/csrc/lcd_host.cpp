@@ -1168,6 +1168,54 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             }
         }
     }
+    // ---- classes and order of the chains that start after the anchor stage: host work that needs nothing from it -- made on a helper thread while the anchor kernels run
+    //      (4 ms of a 260 ms submission with the main launches waiting for it, before) ----
+    std::vector<size_t> which; which.reserve(nC_all);
+    auto order_chains = [&]() {
+        { std::vector<char> is_early(nC_all, 0); for (size_t g : early) is_early[g] = 1; for (size_t g = 0; g < nC_all; ++g) if (!is_early[g]) which.push_back(g); }
+        // No more launch groups than streams: a stream runs its kernels one after the other, so a fifth group starts only when some other group's LAST chain has
+        // ended -- with the bulk of the work (40 000 short chains in the smallest LDS bucket) queued behind a group of a few hundred long chains the chip idled for a
+        // third of the stage.  The single-wavefront group with the fewest chains moves up into the next larger LDS bucket in use (a bigger pool is always valid).
+        {
+            static const int n_streams = std::max(1, std::min(LCD_NSIDE + 1, getenv("LCD_STREAMS") ? atoi(getenv("LCD_STREAMS")) : 4));
+            for (;;) {
+                // (only SMALL groups move -- less than 8 % of the submission's CU-time: a bigger pool means fewer chains per CU, and the bulk of the work must keep the
+                //  occupancy of its own bucket; noisy-read submissions have five wide classes besides, there is no getting down to four groups)
+                std::map<long long, std::pair<size_t, double>> cnt;
+                double tot_w = 0;
+                for (size_t g = 0; g < nC_all; ++g) {
+                    const PoaChain &pc = PC(g);
+                    const int lds = pc.lds_words * 4, thr = pc.threads;
+                    const int per_cu = std::max(1, std::min((160 * 1024) / (lds + (thr == 64 ? 1 : 6) * 1024), 1024 / thr));
+                    const double w = (double)pc.n_reads * (pc.max_len + 64) / per_cu;
+                    auto &e = cnt[chain_group_key(pc)]; e.first++; e.second += w; tot_w += w;
+                }
+                if ((int)cnt.size() <= n_streams) break;
+                long long from = -1, to = -1; double least = 0.08 * tot_w;
+                for (auto it = cnt.begin(); it != cnt.end(); ++it) {
+                    if ((it->first >> 20) != 64) continue;
+                    auto nx = std::next(it);
+                    if (nx == cnt.end() || (nx->first >> 20) != 64) continue;
+                    if (it->second.second < least) { least = it->second.second; from = it->first; to = nx->first; }
+                }
+                if (from < 0) break;
+                const int lw = (int)(to & ((1 << 20) - 1));
+                for (size_t g = 0; g < nC_all; ++g) if (chain_group_key(PC(g)) == from) PC(g).lds_words = lw;
+            }
+        }
+        // widest / largest-LDS group first, then biggest first so the long chains start early (LPT)
+        {   // (keys taken once: the comparator used to look both chains up through their batch for each of the ~600 000 comparisons of a 20-batch submission)
+            std::vector<std::pair<long long, uint64_t>> sk(nC_all);
+            for (size_t g = 0; g < nC_all; ++g) { const PoaChain &pc = PC(g); sk[g] = {chain_group_key(pc), pc.cell_cap}; }
+            std::sort(which.begin(), which.end(), [&](size_t a, size_t c2) {
+                if (sk[a].first != sk[c2].first) return sk[a].first > sk[c2].first;
+                if (sk[a].second != sk[c2].second) return sk[a].second > sk[c2].second;
+                return a < c2; });
+        }
+    };
+    struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } order_thread; // (joins on every way out of this function)
+    const bool order_async = nC_all >= 2048 && !getenv("LCD_NO_PREP_THREAD");
+    if (order_async) order_thread.t = std::thread(order_chains);
     // ---------------- S1: anchors (K4 prefilter + K3b) ----------------
     {
         std::vector<EdJob> ej; std::vector<WfaJob> wj;
@@ -1245,47 +1293,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         for (int k = 0; k < nb; ++k)
             if (!preads[k].empty())
                 HIPCHK(hipMemcpyAsync((PoaRead *)L->d_preads.p + pread_base[k], preads[k].data(), preads[k].size() * sizeof(PoaRead), hipMemcpyHostToDevice, st));
-        std::vector<size_t> which; which.reserve(nC_all);
-        { std::vector<char> is_early(nC_all, 0); for (size_t g : early) is_early[g] = 1; for (size_t g = 0; g < nC_all; ++g) if (!is_early[g]) which.push_back(g); }
-        // No more launch groups than streams: a stream runs its kernels one after the other, so a fifth group starts only when some other group's LAST chain has
-        // ended -- with the bulk of the work (40 000 short chains in the smallest LDS bucket) queued behind a group of a few hundred long chains the chip idled for a
-        // third of the stage.  The single-wavefront group with the fewest chains moves up into the next larger LDS bucket in use (a bigger pool is always valid).
-        {
-            static const int n_streams = std::max(1, std::min(LCD_NSIDE + 1, getenv("LCD_STREAMS") ? atoi(getenv("LCD_STREAMS")) : 4));
-            for (;;) {
-                // (only SMALL groups move -- less than 8 % of the submission's CU-time: a bigger pool means fewer chains per CU, and the bulk of the work must keep the
-                //  occupancy of its own bucket; noisy-read submissions have five wide classes besides, there is no getting down to four groups)
-                std::map<long long, std::pair<size_t, double>> cnt;
-                double tot_w = 0;
-                for (size_t g = 0; g < nC_all; ++g) {
-                    const PoaChain &pc = PC(g);
-                    const int lds = pc.lds_words * 4, thr = pc.threads;
-                    const int per_cu = std::max(1, std::min((160 * 1024) / (lds + (thr == 64 ? 1 : 6) * 1024), 1024 / thr));
-                    const double w = (double)pc.n_reads * (pc.max_len + 64) / per_cu;
-                    auto &e = cnt[chain_group_key(pc)]; e.first++; e.second += w; tot_w += w;
-                }
-                if ((int)cnt.size() <= n_streams) break;
-                long long from = -1, to = -1; double least = 0.08 * tot_w;
-                for (auto it = cnt.begin(); it != cnt.end(); ++it) {
-                    if ((it->first >> 20) != 64) continue;
-                    auto nx = std::next(it);
-                    if (nx == cnt.end() || (nx->first >> 20) != 64) continue;
-                    if (it->second.second < least) { least = it->second.second; from = it->first; to = nx->first; }
-                }
-                if (from < 0) break;
-                const int lw = (int)(to & ((1 << 20) - 1));
-                for (size_t g = 0; g < nC_all; ++g) if (chain_group_key(PC(g)) == from) PC(g).lds_words = lw;
-            }
-        }
-        // widest / largest-LDS group first, then biggest first so the long chains start early (LPT)
-        {   // (keys taken once: the comparator used to look both chains up through their batch for each of the ~600 000 comparisons of a 20-batch submission)
-            std::vector<std::pair<long long, uint64_t>> sk(nC_all);
-            for (size_t g = 0; g < nC_all; ++g) { const PoaChain &pc = PC(g); sk[g] = {chain_group_key(pc), pc.cell_cap}; }
-            std::sort(which.begin(), which.end(), [&](size_t a, size_t c2) {
-                if (sk[a].first != sk[c2].first) return sk[a].first > sk[c2].first;
-                if (sk[a].second != sk[c2].second) return sk[a].second > sk[c2].second;
-                return a < c2; });
-        }
+        if (order_async) order_thread.t.join(); else order_chains();
         if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host]   POA prep: classes + order after %.1f ms\n", now_ms() - tp0);
         int scale = 1;
         std::map<size_t, uint64_t> retry_out_off; // chains whose output block moved to a retry buffer
