@@ -1213,9 +1213,68 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                 return a < c2; });
         }
     };
+    // the arena layout of a round (pure host work: slot pools and private arenas per launch group); round 0's is made on the helper thread as well
+    struct Item { uint64_t start, bytes, phys; };
+    struct ArenaPlan { uint64_t tot = 0, flag_ints = 0; size_t n_pooled = 0, n_pools = 0; uint64_t private_bytes = 0, pool_bytes = 0; std::vector<Item> items; std::vector<uint32_t> item_of; std::vector<uint64_t> need; bool valid = false; };
+    static const bool use_slots = !(getenv("LCD_ARENA_SLOTS") && atoi(getenv("LCD_ARENA_SLOTS")) == 0);
+    uint64_t cu_rank_addr = 0; int n_cu = g_n_cus;
+    if (use_slots) { const int rc3 = cu_rank_table(st, &cu_rank_addr, &n_cu); if (rc3) return rc3; }
+    if (getenv("LCD_ARENA_SLOT_CUS")) n_cu = std::max(1, atoi(getenv("LCD_ARENA_SLOT_CUS"))); // test switch: far fewer slots than resident workgroups (claims must wait)
+    auto segment_arenas = [&](ArenaPlan &P) { // needs: which (ordered), P.need[i] for which[i]
+        P.tot = 0; P.flag_ints = 0; P.n_pooled = P.n_pools = 0; P.private_bytes = P.pool_bytes = 0; P.items.clear(); P.item_of.assign(which.size(), 0);
+    for (size_t i = 0; i < which.size();) {
+        const long long key = chain_group_key(PC(which[i]));
+        size_t j = i;
+        while (j < which.size() && chain_group_key(PC(which[j])) == key) ++j;
+        const PoaChain &p0 = PC(which[i]);
+        const int lds = p0.lds_words * 4, thr = p0.threads;
+        const int per_cu = std::max(1, std::min((160 * 1024) / (lds + (thr == 64 ? 912 : 6096)), 1024 / thr));
+        const uint64_t R = (uint64_t)n_cu * per_cu;
+        // the group's chains by arena size, largest first, cut into segments at breakpoints where the size has dropped by >= 1.3x; a segment
+        // either keeps private arenas (cost: the sum of its sizes) or, if it has more than R chains, shares R slots of its largest size
+        // (cost R x size).  The cheapest segmentation is a shortest path over the <= ~40 breakpoints (sizes of a group span two orders of magnitude).
+        std::vector<size_t> ord(j - i);
+        for (size_t q = 0; q < ord.size(); ++q) ord[q] = i + q;
+        std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b2) { return P.need[a] > P.need[b2]; });
+        const size_t n = ord.size();
+        std::vector<size_t> bp(1, 0);
+        for (size_t q = 1; q < n; ++q) if ((double)P.need[ord[q]] * 1.3 <= (double)P.need[ord[bp.back()]]) bp.push_back(q);
+        bp.push_back(n);
+        std::vector<uint64_t> pre(n + 1, 0);
+        for (size_t q = 0; q < n; ++q) pre[q + 1] = pre[q] + P.need[ord[q]];
+        const size_t nbp = bp.size();
+        std::vector<uint64_t> cost(nbp, ~0ull); std::vector<size_t> nxt(nbp, nbp - 1);
+        cost[nbp - 1] = 0;
+        auto seg_pooled = [&](size_t a, size_t b2) { return use_slots && bp[b2] - bp[a] > R && R * lcd_align_up(P.need[ord[bp[a]]], 256) < pre[bp[b2]] - pre[bp[a]]; };
+        for (size_t a = nbp - 1; a-- > 0;)
+            for (size_t b2 = a + 1; b2 < nbp; ++b2) {
+                const uint64_t c = (seg_pooled(a, b2) ? R * lcd_align_up(P.need[ord[bp[a]]], 256) : pre[bp[b2]] - pre[bp[a]]) + cost[b2];
+                if (c < cost[a]) { cost[a] = c; nxt[a] = b2; }
+            }
+        for (size_t a = 0; a + 1 < nbp; a = nxt[a]) {
+            const size_t b2 = nxt[a];
+            if (seg_pooled(a, b2)) {
+                const uint64_t slot = lcd_align_up(P.need[ord[bp[a]]], 256);
+                for (size_t q = bp[a]; q < bp[b2]; ++q) { PoaChain &pc = PC(which[ord[q]]); pc.ws_off = P.tot; pc.slot_flags = 1 + P.flag_ints; pc.slot_bytes = slot; pc.n_slots = (int)R; pc.per_cu = per_cu; pc.cu_rank = cu_rank_addr; P.item_of[ord[q]] = (uint32_t)P.items.size(); }
+                P.items.push_back({P.tot, R * slot, 0});
+                P.tot += R * slot; P.flag_ints += R; P.n_pooled += bp[b2] - bp[a]; ++P.n_pools; P.pool_bytes += R * slot;
+            } else
+                for (size_t q = bp[a]; q < bp[b2]; ++q) { PoaChain &pc = PC(which[ord[q]]); pc.ws_off = P.tot; pc.slot_flags = 0; pc.slot_bytes = 0; pc.n_slots = 0; pc.per_cu = 0; pc.cu_rank = 0; P.item_of[ord[q]] = (uint32_t)P.items.size(); P.items.push_back({P.tot, P.need[ord[q]], 0}); P.tot += P.need[ord[q]]; P.private_bytes += P.need[ord[q]]; }
+        }
+        i = j;
+    }
+    };
+    ArenaPlan plan0;
+    auto prepare_round0 = [&]() {
+        order_chains();
+        plan0.need.resize(which.size());
+        for (size_t i = 0; i < which.size(); ++i) { const PoaChain &pc = PC(which[i]); plan0.need[i] = poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads, pc.spill_x, pc.cert).total; }
+        segment_arenas(plan0);
+        plan0.valid = true;
+    };
     struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } order_thread; // (joins on every way out of this function)
     const bool order_async = nC_all >= 2048 && !getenv("LCD_NO_PREP_THREAD");
-    if (order_async) order_thread.t = std::thread(order_chains);
+    if (order_async) order_thread.t = std::thread(prepare_round0);
     // ---------------- S1: anchors (K4 prefilter + K3b) ----------------
     {
         std::vector<EdJob> ej; std::vector<WfaJob> wj;
@@ -1293,20 +1352,19 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         for (int k = 0; k < nb; ++k)
             if (!preads[k].empty())
                 HIPCHK(hipMemcpyAsync((PoaRead *)L->d_preads.p + pread_base[k], preads[k].data(), preads[k].size() * sizeof(PoaRead), hipMemcpyHostToDevice, st));
-        if (order_async) order_thread.t.join(); else order_chains();
+        if (order_async) order_thread.t.join(); else prepare_round0();
         if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host]   POA prep: classes + order after %.1f ms\n", now_ms() - tp0);
         int scale = 1;
         std::map<size_t, uint64_t> retry_out_off; // chains whose output block moved to a retry buffer
         for (int k = 0; k < nb; ++k) bs[k]->retry_out_used = 0;
-        static const bool use_slots = !(getenv("LCD_ARENA_SLOTS") && atoi(getenv("LCD_ARENA_SLOTS")) == 0);
-        uint64_t cu_rank_addr = 0; int n_cu = g_n_cus;
-        if (use_slots) { const int rc3 = cu_rank_table(st, &cu_rank_addr, &n_cu); if (rc3) return rc3; }
-        if (getenv("LCD_ARENA_SLOT_CUS")) n_cu = std::max(1, atoi(getenv("LCD_ARENA_SLOT_CUS"))); // test switch: far fewer slots than resident workgroups (claims must wait)
         for (int round = 0; round < 12 && !which.empty(); ++round) {
-            uint64_t tot = 0;
+            ArenaPlan P;
+            if (round == 0 && plan0.valid) P = std::move(plan0);
+            else P.need.assign(which.size(), 0);
+            const bool planned = P.valid;
+            uint64_t &tot = P.tot; std::vector<uint64_t> &need = P.need;
             std::vector<PoaChain> sub(which.size());
-            std::vector<uint64_t> need(which.size());
-            for (size_t i = 0; i < which.size(); ++i) {
+            if (!planned) for (size_t i = 0; i < which.size(); ++i) {
                 const int k = chain_batch[which[i]]; const size_t c = which[i] - chain_base[k];
                 PoaChain &pc = bs[k]->pchains[c];
                 if (round) {
@@ -1327,50 +1385,9 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             // runs of chains of one launch group and one size class (half octaves of the arena size) that outnumber the chip's capacity share a pool of
             // n_cu x per_cu SLOTS claimed at workgroup start (poa_kernel.hip); the others keep private arenas.  Memory then scales with resident
             // workgroups, not with the number of chains in flight.
-            uint64_t flag_ints = 0; size_t n_pooled = 0, n_pools = 0; uint64_t private_bytes = 0, pool_bytes = 0;
-            struct Item { uint64_t start, bytes, phys; };
-            std::vector<Item> items; std::vector<uint32_t> item_of(which.size(), 0);
-            for (size_t i = 0; i < which.size();) {
-                const long long key = chain_group_key(PC(which[i]));
-                size_t j = i;
-                while (j < which.size() && chain_group_key(PC(which[j])) == key) ++j;
-                const PoaChain &p0 = PC(which[i]);
-                const int lds = p0.lds_words * 4, thr = p0.threads;
-                const int per_cu = std::max(1, std::min((160 * 1024) / (lds + (thr == 64 ? 912 : 6096)), 1024 / thr));
-                const uint64_t R = (uint64_t)n_cu * per_cu;
-                // the group's chains by arena size, largest first, cut into segments at breakpoints where the size has dropped by >= 1.3x; a segment
-                // either keeps private arenas (cost: the sum of its sizes) or, if it has more than R chains, shares R slots of its largest size
-                // (cost R x size).  The cheapest segmentation is a shortest path over the <= ~40 breakpoints (sizes of a group span two orders of magnitude).
-                std::vector<size_t> ord(j - i);
-                for (size_t q = 0; q < ord.size(); ++q) ord[q] = i + q;
-                std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b2) { return need[a] > need[b2]; });
-                const size_t n = ord.size();
-                std::vector<size_t> bp(1, 0);
-                for (size_t q = 1; q < n; ++q) if ((double)need[ord[q]] * 1.3 <= (double)need[ord[bp.back()]]) bp.push_back(q);
-                bp.push_back(n);
-                std::vector<uint64_t> pre(n + 1, 0);
-                for (size_t q = 0; q < n; ++q) pre[q + 1] = pre[q] + need[ord[q]];
-                const size_t nbp = bp.size();
-                std::vector<uint64_t> cost(nbp, ~0ull); std::vector<size_t> nxt(nbp, nbp - 1);
-                cost[nbp - 1] = 0;
-                auto seg_pooled = [&](size_t a, size_t b2) { return use_slots && bp[b2] - bp[a] > R && R * lcd_align_up(need[ord[bp[a]]], 256) < pre[bp[b2]] - pre[bp[a]]; };
-                for (size_t a = nbp - 1; a-- > 0;)
-                    for (size_t b2 = a + 1; b2 < nbp; ++b2) {
-                        const uint64_t c = (seg_pooled(a, b2) ? R * lcd_align_up(need[ord[bp[a]]], 256) : pre[bp[b2]] - pre[bp[a]]) + cost[b2];
-                        if (c < cost[a]) { cost[a] = c; nxt[a] = b2; }
-                    }
-                for (size_t a = 0; a + 1 < nbp; a = nxt[a]) {
-                    const size_t b2 = nxt[a];
-                    if (seg_pooled(a, b2)) {
-                        const uint64_t slot = lcd_align_up(need[ord[bp[a]]], 256);
-                        for (size_t q = bp[a]; q < bp[b2]; ++q) { PoaChain &pc = PC(which[ord[q]]); pc.ws_off = tot; pc.slot_flags = 1 + flag_ints; pc.slot_bytes = slot; pc.n_slots = (int)R; pc.per_cu = per_cu; pc.cu_rank = cu_rank_addr; item_of[ord[q]] = (uint32_t)items.size(); }
-                        items.push_back({tot, R * slot, 0});
-                        tot += R * slot; flag_ints += R; n_pooled += bp[b2] - bp[a]; ++n_pools; pool_bytes += R * slot;
-                    } else
-                        for (size_t q = bp[a]; q < bp[b2]; ++q) { PoaChain &pc = PC(which[ord[q]]); pc.ws_off = tot; pc.slot_flags = 0; pc.slot_bytes = 0; pc.n_slots = 0; pc.per_cu = 0; pc.cu_rank = 0; item_of[ord[q]] = (uint32_t)items.size(); items.push_back({tot, need[ord[q]], 0}); tot += need[ord[q]]; private_bytes += need[ord[q]]; }
-                }
-                i = j;
-            }
+            if (!planned) segment_arenas(P);
+            uint64_t &flag_ints = P.flag_ints; size_t &n_pooled = P.n_pooled, &n_pools = P.n_pools; uint64_t &private_bytes = P.private_bytes, &pool_bytes = P.pool_bytes;
+            std::vector<Item> &items = P.items; std::vector<uint32_t> &item_of = P.item_of;
             if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host]   POA prep: arenas laid out after %.1f ms\n", now_ms() - tp0);
             if (getenv("LCD_MEM_DEBUG")) fprintf(stderr, "[mem] round %d arenas: %zu chains in %zu slot pools (%.2f GB), %zu with private arenas (%.2f GB)\n", round, n_pooled, n_pools, pool_bytes / 1e9, which.size() - n_pooled, private_bytes / 1e9);
             if (flag_ints) {
