@@ -235,7 +235,8 @@ struct lcd_batch_s {
     DevBuf d_in, d_chains, d_preads, d_poa_arena, d_poa_out, d_poa_outs, d_ed_jobs, d_ed_outs, d_wfa_jobs,
         d_wfa_out, d_wfa_outs, d_str_jobs, d_str_outs, d_final, d_gate, d_cmp_jobs, d_cmp_outs, d_cmp_seg, d_cmp_segres, d_seg_out, d_rr,
         d_var_jobs, d_var_outs, d_var_work, d_vreg_jobs, d_vreg_outs, d_var_out, d_slot_flags, d_spare, d_packed, d_unpack,
-        d_early_arena, d_chains_early, d_preads_early, d_poa_outs_early;   // the long K2 chains that start before the anchor stage (run_many_once)
+        d_early_arena, d_chains_early, d_preads_early, d_poa_outs_early,   // the long K2 chains that start before the anchor stage (run_many_once)
+        d_ed_arena;                                                         // K4's stored columns when it runs beside K3 in the anchor stage
     bool uploaded = false, ran = false, downloaded = false;
     // results (host)
     std::vector<PoaChainOut> couts;
@@ -308,7 +309,8 @@ int wfa_class(const WfaJob &j, const LcdScoring &sc) { // 0: HBM ring, 1..3: LDS
 uint64_t ed_arena_bytes(int qlen, int tlen) { return (uint64_t)52432 * 20 + (uint64_t)qlen * 8 + (uint64_t)tlen * 2 + 512; }
 
 // ---- generic stage runners (absolute device addresses in job structs) ----
-int run_edlib_stage(hipStream_t st, std::vector<EdJob> &jobs, DevBuf &d_jobs, DevBuf &d_arena, DevBuf &d_outs, std::vector<EdOut> &outs) {
+// (defer_copy: the statuses stay on the device -- a copy into pageable host memory holds the calling thread until the kernel has ended; the caller fetches them later)
+int run_edlib_stage(hipStream_t st, std::vector<EdJob> &jobs, DevBuf &d_jobs, DevBuf &d_arena, DevBuf &d_outs, std::vector<EdOut> &outs, bool defer_copy = false) {
     const int n = (int)jobs.size();
     outs.resize(n);
     if (n == 0) return 0;
@@ -324,7 +326,7 @@ int run_edlib_stage(hipStream_t st, std::vector<EdJob> &jobs, DevBuf &d_jobs, De
     HIPCHK(hipMemcpyAsync(d_jobs.p, jobs.data(), n * sizeof(EdJob), hipMemcpyHostToDevice, st));
     lcd_launch_edlib((const EdJob *)d_jobs.p, nullptr, nullptr, (EdOut *)d_outs.p, n, st);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(outs.data(), d_outs.p, n * sizeof(EdOut), hipMemcpyDeviceToHost, st));
+    if (!defer_copy) HIPCHK(hipMemcpyAsync(outs.data(), d_outs.p, n * sizeof(EdOut), hipMemcpyDeviceToHost, st));
     return 0;
 }
 
@@ -1294,11 +1296,18 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             // submission follow each other on the leader's stream and none of them reads another's workspace, so the arena is their maximum, not their sum)
             const bool th = getenv("LCD_TIME_HOST") != nullptr;
             if (th) fprintf(stderr, "[host]   anchors: job tables (%zu edlib, %zu WFA) after %.1f ms\n", ej.size(), wj.size(), now_ms() - t_begin);
-            int rc = run_edlib_stage(st, ej, L->d_ed_jobs, L->d_poa_arena, L->d_ed_outs, eo);
+            // K4 and K3 of the anchor stage are independent and both latency-bound (one wavefront per pair, 60 % of its cycles waiting): side by side on two
+            // streams when K4's stored columns (1 MiB per pair, edlib's own rule) fit a workspace of their own of up to 20 GB -- 17 000 pairs; larger submissions and the noisy shapes keep the one shared arena and the old order
+            uint64_t ed_tot = 0; for (const EdJob &j : ej) ed_tot += lcd_align_up(ed_arena_bytes(j.qlen, j.tlen), 256);
+            const bool side_by_side = !ej.empty() && !wj.empty() && L->side[0] && ed_tot <= (20ull << 30) && !getenv("LCD_ANCHOR_SEQ");
+            hipStream_t ks = side_by_side ? L->side[0] : st;
+            if (side_by_side) HIPCHK(hipStreamWaitEvent(ks, L->ev[0], 0));
+            int rc = run_edlib_stage(ks, ej, L->d_ed_jobs, side_by_side ? L->d_ed_arena : L->d_poa_arena, L->d_ed_outs, eo, side_by_side);
             if (rc) return rc;
-            if (th) { hipStreamSynchronize(st); fprintf(stderr, "[host]   anchors: edlib stage done after %.1f ms\n", now_ms() - t_begin); }
+            if (th && !side_by_side) { hipStreamSynchronize(st); fprintf(stderr, "[host]   anchors: edlib stage done after %.1f ms\n", now_ms() - t_begin); }
             rc = run_wfa_stage(st, wj, L->d_wfa_jobs, L->d_poa_arena, L->d_wfa_out, L->d_wfa_outs, wo, sc, nullptr, true);
             if (rc) return rc;
+            if (side_by_side) { HIPCHK(hipMemcpyAsync(eo.data(), L->d_ed_outs.p, eo.size() * sizeof(EdOut), hipMemcpyDeviceToHost, ks)); HIPCHK(hipStreamSynchronize(ks)); }
             HIPCHK(hipStreamSynchronize(st));
             if (th) fprintf(stderr, "[host]   anchors: WFA stage done after %.1f ms\n", now_ms() - t_begin);
             // cigars of the anchor jobs: ONE device->host copy of the output span of all of them (a copy per job costs more in

@@ -536,7 +536,7 @@ def test_ont_batch_rows_degap_to_their_reads_at_full_size(lcd):
 
 def test_certified_band_and_long_chain_class_digest_at_job_scale(lcd, monkeypatch):
     """a configs[3]-sized sample (5 batches = 6 250 distinct regions in ONE submission): the digest over every consensus, cluster and alignment string is the same
-    with the certified band on / off, with the long chains in the 256-thread class or not (LCD_SOLO_RL) and with their rows on one or on four wavefronts (LCD_SOLO_MW) -- the joint submission, the launch-group merge
+    with the certified band on / off, with the long chains in the 256-thread class or not (LCD_SOLO_RL) with their rows on one or on four wavefronts (LCD_SOLO_MW), with the long K2 chains ahead of the anchor stage or not (LCD_EARLY) and with the host preparation on a helper thread or not -- the joint submission, the launch-group merge
     and the per-submission choice of long chains included"""
     from longcalld_amd import jobs
     batches = [jobs.make_regions(31000 + i, 1250, jobs.HIFI) for i in range(5)]
@@ -563,4 +563,9 @@ def test_certified_band_and_long_chain_class_digest_at_job_scale(lcd, monkeypatc
     monkeypatch.setenv("LCD_SOLO_RL", "30000")
     assert run() == ref
     monkeypatch.setenv("LCD_SOLO_MW", "1")       # the long certified-band chains' rows on all four wavefronts of their workgroup (align_lean_mw)
+    assert run() == ref
+    monkeypatch.delenv("LCD_SOLO_MW"); monkeypatch.delenv("LCD_SOLO_RL")
+    monkeypatch.setenv("LCD_EARLY", "0")         # the long K2 chains start with everybody else instead of ahead of the anchor stage
+    assert run() == ref
+    monkeypatch.delenv("LCD_EARLY"); monkeypatch.setenv("LCD_NO_PREP_THREAD", "1")   # classes, order and arena layout on the calling thread
     assert run() == ref
