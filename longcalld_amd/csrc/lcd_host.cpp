@@ -339,7 +339,8 @@ uint64_t wfa_out_bytes(const WfaJob &j) {
 // WFA stage with the overflow retry ladder (score bound x4 + 64).  jobs[i].s_cap holds the wanted score bound on entry (wfa_default_scap);
 // every round plans the pending jobs (class, block, snapshots), launches the LDS buckets and the HBM-ring class and waits for the statuses.
 int run_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, DevBuf &d_jobs, DevBuf &d_arena, DevBuf &d_out, DevBuf &d_outs,
-                  std::vector<WfaOut> &outs, LcdScoring sc, int *retries, bool learn = false) {
+                  std::vector<WfaOut> &outs, LcdScoring sc, int *retries, bool learn = false, hipStream_t *side = nullptr, hipEvent_t *sev = nullptr, int n_side = 0) {
+    // side / sev / n_side: the classes' launches are dealt to st and these streams (one kernel per class: six for a HiFi-shape stage, each as long as its longest job)
     const int n = (int)jobs.size();
     outs.assign(n, WfaOut());
     if (n == 0) return 0;
@@ -373,13 +374,21 @@ int run_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, DevBuf &d_jobs, Dev
         sub.resize(m); tmp.resize(m);
         for (size_t q = 0; q < m; ++q) { jobs[which[q]].ws_off += d_arena.addr(); sub[q] = jobs[which[q]]; }
         HIPCHK(hipMemcpyAsync(d_jobs.p, sub.data(), m * sizeof(WfaJob), hipMemcpyHostToDevice, st));
+        const int ns = (side && sev && n_side > 0) ? n_side + 1 : 1;
+        if (ns > 1) HIPCHK(hipEventRecord(sev[0], st)); // the job table is there
+        std::vector<char> used(ns, 0);
+        int turn = 0;
         for (size_t a = 0; a < m;) {
             size_t b = a; const int c = cls[which[a]];
             while (b < m && cls[which[b]] == c) ++b;
-            lcd_launch_wfa((const WfaJob *)d_jobs.p + a, nullptr, nullptr, nullptr, (WfaOut *)d_outs.p + a, sc, (int)(b - a), c ? kWfaLdsBuckets[c - 1] : 0, st);
+            const int t = turn++ % ns;
+            hipStream_t s2 = t == 0 ? st : side[t - 1];
+            if (t != 0 && !used[t]) { HIPCHK(hipStreamWaitEvent(s2, sev[0], 0)); used[t] = 1; }
+            lcd_launch_wfa((const WfaJob *)d_jobs.p + a, nullptr, nullptr, nullptr, (WfaOut *)d_outs.p + a, sc, (int)(b - a), c ? kWfaLdsBuckets[c - 1] : 0, s2);
             HIPCHK(hipGetLastError());
             a = b;
         }
+        for (int t = 1; t < ns; ++t) if (used[t]) { HIPCHK(hipEventRecord(sev[t], side[t - 1])); HIPCHK(hipStreamWaitEvent(st, sev[t], 0)); }
         HIPCHK(hipMemcpyAsync(tmp.data(), d_outs.p, m * sizeof(WfaOut), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st)); // (`sub` and `tmp` outlive the copies: they are only touched again after this)
         std::vector<int> again;
@@ -1610,7 +1619,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     {
         int wret = 0;
         std::vector<WfaOut> rc_outs;
-        int rc = run_wfa_stage(st, rc_all, L->d_wfa_jobs, L->d_poa_arena, L->d_wfa_out, L->d_wfa_outs, rc_outs, sc, &wret);
+        int rc = run_wfa_stage(st, rc_all, L->d_wfa_jobs, L->d_poa_arena, L->d_wfa_out, L->d_wfa_outs, rc_outs, sc, &wret, false, getenv("LCD_WFA_SEQ") ? nullptr : L->side, L->sev, 3); // (the POA streams are idle by now)
         if (rc) return rc;
         for (int k = 0; k < nb; ++k) {
             lcd_batch_t *b = bs[k];
