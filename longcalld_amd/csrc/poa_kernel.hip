@@ -3349,7 +3349,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     extern __shared__ int lds_pool[]; // [row ring | query cache], re-used by the re-sort; sized per launch (PoaChain.lds_words)
     int *ring = lds_pool;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const PoaChain ch = chains[cid];
+    const PoaChain &ch = chains[cid]; // (read where it lies: a copy is 200 B of every lane's private segment, and grow_dp_region / chain_output take it by reference anyway)
     // ring slots hold PoaChain.wmax columns: the class's widest window (4 * NT), or -- single-wavefront banded chains -- the narrower
     // window the host expects the band to fit (64 / 128 columns: LDS per chain is what limits how many of them share a CU)
     const int ring_cols = (NT == 64 || ch.solo) ? ch.wmax : 4 * NT;
