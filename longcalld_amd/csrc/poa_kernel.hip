@@ -2549,7 +2549,12 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
             // the guess: the bound at the end cell minus a slack -- the largest one an earlier read of this chain needed (+ 25 % + 32), or a small one for
             // the first alignment.  An attempt that comes back below its guess doubles the slack; the best score seen so far is a TRUE lower bound of the
             // optimum and takes over as soon as it is the tighter of the two (that attempt cannot fail)
-            int delta = g.cert_hist < 0 ? 48 + qlen / 32 : g.cert_hist + g.cert_hist / 4 + 32;
+            // the slack over the largest one the chain has needed so far: + 1/8 + 8.  It was + 1/4 + 32 until the end of round 3: every unit of slack widens every row's
+            // interval, and a wider widest interval means more cells per lane for the whole read; an attempt that falls short costs one more pass over the (narrower)
+            // intervals and leaves a true lower bound.  Measured at the driver's flags / 1 / 4 / 16 batches in flight: 100.5 k regions/s, 119 / 158 / 217 ms against
+            // 100.4 k, 119 / 175 / 223 ms; + 1/8 + 1 .. 4: 122 / 155 / 217; + 1/8 + 32: 120 / 174 / 223.  (LCD_DBG bits 8-11 / 12-19 override the eighths / the constant)
+            const int d_a = (sc.dbg >> 8) & 15, d_b = (sc.dbg >> 12) & 255;
+            int delta = g.cert_hist < 0 ? 48 + qlen / 32 : g.cert_hist + g.cert_hist * (d_a ? d_a : 1) / 8 + (d_b ? d_b : 8);
             int sbest = LCD_NEG;
             bool done = false;
             auto hull_of = [&](const int sest) { // every row's interval for this score bound (table in g.cert); the widest window a row needs, or -1
