@@ -780,6 +780,9 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
         // of 88.4 k regions/s -- every wavefront pays the row's fixed cost (plan word, interval, predecessor loop, metadata: ~400 instructions in this version, which
         // reads every predecessor from the LDS ring) plus two LDS round trips and two barriers, and the cells it saves are ~75 instructions.  Off by default.
         if (pc.solo && pc.cert == 1 && getenv("LCD_SOLO_MW") && atoi(getenv("LCD_SOLO_MW")) > 0) pc.solo = 2;
+        // Round 4: the rows of the long certified-band chains run as a PIPELINE over the four wavefronts (poa_kernel.hip align_cyc: mailboxes, no barrier, the row before in
+        // registers) -- LCD_SOLO_CYC=0 keeps them on wavefront 0
+        if (pc.solo == 1 && pc.cert == 1 && !(getenv("LCD_SOLO_CYC") && atoi(getenv("LCD_SOLO_CYC")) == 0)) pc.solo = 3;
     }
     // graph capacity: the worst case is one node per base of every read (sum), the usual case a little more than the longest read.  Sized
     // from an estimate (a few per cent of new nodes per read on top of the backbone; g_node_hint learns noisier data); a chain that runs
@@ -1856,6 +1859,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                     PC(mxc).n_reads, PC(mxc).max_len, o.n_node, (double)o.t_total, (double)o.t_dp, (double)o.t_bt, (double)o.t_graph, (double)o.t_sub, (double)o.t_out, o.cells);
             fprintf(stderr, "[lcd]     of its dp: plan-window refreshes %.3e  mailbox polls %.3e (one wavefront)\n", (double)o.t_plan, (double)o.t_poll);
             fprintf(stderr, "[lcd]     row plan %.3e  graph update %.3e  re-sort %.3e  row setup %.3e\n", (double)o.t_bp, (double)o.t_add, (double)o.t_sort, (double)o.t_setup);
+            if (getenv("LCD_DBG") && (atoi(getenv("LCD_DBG")) & 32)) fprintf(stderr, "[lcd]     reads by widest interval <=60 / <=124 / <=188 / <=380 / wider: %llu %llu %llu %llu %llu\n", (unsigned long long)(o.t_setup & 4095), (unsigned long long)((o.t_setup >> 12) & 4095), (unsigned long long)((o.t_setup >> 24) & 4095), (unsigned long long)((o.t_setup >> 36) & 4095), (unsigned long long)((o.t_setup >> 48) & 4095));
         }
     }
     return 0;

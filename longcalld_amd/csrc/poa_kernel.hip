@@ -286,32 +286,51 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
         return 2;
     }
     if (n_cig == 0) return 0;
+    // Every phase below is a chain of dependent loads per cigar entry (entry -> node -> its lists -> edge fields), and a workgroup -- one wavefront for most
+    // chains -- that walks the entries 64 at a time pays that chain's latency once per 64 entries.  U entries per thread are in flight instead: the loads of all U
+    // are issued before anything is stored (the stores are to int arrays the compiler must assume aliased), the prefix sums then run batch by batch in entry order.
+    constexpr int U = 4;
     // phase 1: the node each entry lands on: existing (>= 0), new and aligned to an anchor, or plain new
     int carry = 0;
-    for (int base = 0; base < n_cig; base += NT) {
-        const int i = base + tid;
-        int isnew = 0, flag = -2, T = 0;
-        if (i < n_cig) {
-            const uint8_t b = seq[g.cig_qpos[i]];
-            const int node = g.cig_node[i];
-            if (node >= 0) {
-                if (g.base[node] == b) T = node;
-                else {
-                    int a = -1;
-                    for (int x = g.aligned[node]; x != node; x = g.aligned[x]) if (g.base[x] == b) { a = x; break; }
-                    if (a >= 0) T = a; else { isnew = 1; flag = node; }
-                }
-            } else { isnew = 1; flag = -1; }
+    for (int base = 0; base < n_cig; base += U * NT) {
+        int isnew[U], flag[U], T[U];
+        int qp[U], nd[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = base + u * NT + tid; qp[u] = 0; nd[u] = -1; if (i < n_cig) { qp[u] = g.cig_qpos[i]; nd[u] = g.cig_node[i]; } }
+        int bq[U], bn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = base + u * NT + tid; bq[u] = 0; bn[u] = 0; if (i < n_cig) { bq[u] = seq[qp[u]]; if (nd[u] >= 0) bn[u] = g.base[nd[u]]; } }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * NT + tid;
+            isnew[u] = 0; flag[u] = -2; T[u] = 0;
+            if (i < n_cig) {
+                const int node = nd[u];
+                if (node >= 0) {
+                    if (bn[u] == bq[u]) T[u] = node;
+                    else {
+                        int a = -1;
+                        for (int x = g.aligned[node]; x != node; x = g.aligned[x]) if (g.base[x] == bq[u]) { a = x; break; }
+                        if (a >= 0) T[u] = a; else { isnew[u] = 1; flag[u] = node; }
+                    }
+                } else { isnew[u] = 1; flag[u] = -1; }
+            }
         }
-        int tot;
-        const int rank = block_excl_scan<NT>(isnew, sm, &tot);
-        if (i < n_cig) { g.aa_node[i] = isnew ? g.n_node + carry + rank : T; g.aa_flag[i] = flag; }
-        carry += tot;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (base + u * NT >= n_cig) break; // (uniform)
+            const int i = base + u * NT + tid;
+            int tot;
+            const int rank = block_excl_scan<NT>(isnew[u], sm, &tot);
+            if (i < n_cig) { g.aa_node[i] = isnew[u] ? g.n_node + carry + rank : T[u]; g.aa_flag[i] = flag[u]; }
+            carry += tot;
+        }
     }
     const int n_new = carry;
     if (g.n_node + n_new > g.node_cap) { g.status = LCD_ERR_NODES; return 0; }
     __syncthreads();
     // phase 2: new nodes
+    if (n_new > 0)
     for (int i = tid; i < n_cig; i += NT) {
         const int flag = g.aa_flag[i];
         if (flag == -2) continue;
@@ -322,39 +341,59 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
     // phase 3: edges j = 0..n_cig (from path[j-1] to path[j]); existing ones gain weight + read id, the others are numbered
     carry = 0;
     int heavy_moved = 0;
-    for (int base = 0; base <= n_cig; base += NT) {
-        const int j = base + tid;
-        int need = 0;
-        if (j <= n_cig) {
-            const int from = j == 0 ? beg_node : g.aa_node[j - 1], to = j == n_cig ? end_node : g.aa_node[j];
-            const bool from_new = j > 0 && g.aa_flag[j - 1] != -2, to_new = j < n_cig && g.aa_flag[j] != -2;
-            need = 1;
-            if (!from_new && !to_new) {
-                // the edge exists: one more read on it.  `remain` follows every node's HEAVIEST out-edge (first maximum in list order): it only has to be
-                // recomputed if this increment changes which edge that is -- reads on the majority path never do
-                int found = -1, pos_found = 0, amax = -1, pos_amax = 0, wmax = -1, pos = 0;
-                for (int e = g.out_head[from]; e >= 0; e = g.e_next_out[e], ++pos) {
-                    const int wt = g.e_w[e];
-                    if (wt > wmax) { wmax = wt; amax = e; pos_amax = pos; }
-                    if (found < 0 && g.e_to[e] == to) { found = e; pos_found = pos; }
-                }
-                if (found >= 0) {
-                    const int wn = g.e_w[found] + 1;
-                    g.e_w[found] = wn; g.rid[(size_t)found * g.rid_words + rw] |= rbit; need = 0;
-                    if (g.plan_valid && (wn & (wn - 1)) == 0) { const int sl = g.e_slot[found]; if (sl >= 0) g.pl_bonus[sl] = ilog2_32(wn); } // (the edge's bonus, ilog2 of its weight, went up)
-                    if (found != amax && (wn > wmax || (wn == wmax && pos_found < pos_amax))) heavy_moved = 1;
-                }
+    for (int base = 0; base <= n_cig; base += U * NT) {
+        int need[U], from[U], to[U], oh[U]; bool chk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = base + u * NT + tid;
+            need[u] = 0; from[u] = 0; to[u] = 0; chk[u] = false; oh[u] = -1;
+            if (j <= n_cig) {
+                from[u] = j == 0 ? beg_node : g.aa_node[j - 1]; to[u] = j == n_cig ? end_node : g.aa_node[j];
+                const bool from_new = j > 0 && g.aa_flag[j - 1] != -2, to_new = j < n_cig && g.aa_flag[j] != -2;
+                need[u] = 1; chk[u] = !from_new && !to_new;
             }
         }
-        int tot;
-        const int rank = block_excl_scan<NT>(need, sm, &tot);
-        if (j <= n_cig) g.aa_eid[j] = need ? g.n_edge + carry + rank : -1;
-        carry += tot;
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (chk[u]) oh[u] = g.out_head[from[u]];
+        // the first out-edge of every entry's node (the usual case: the one edge of a backbone node) in flight together
+        int e0w[U], e0t[U], e0n[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { e0w[u] = 0; e0t[u] = -1; e0n[u] = -1; if (oh[u] >= 0) { e0w[u] = g.e_w[oh[u]]; e0t[u] = g.e_to[oh[u]]; e0n[u] = g.e_next_out[oh[u]]; } }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!chk[u]) continue;
+            // the edge exists: one more read on it.  `remain` follows every node's HEAVIEST out-edge (first maximum in list order): it only has to be
+            // recomputed if this increment changes which edge that is -- reads on the majority path never do
+            int found = -1, pos_found = 0, amax = -1, pos_amax = 0, wmax = -1, pos = 0, wfound = 0;
+            for (int e = oh[u]; e >= 0; ++pos) {
+                int wt, et, en;
+                if (pos == 0) { wt = e0w[u]; et = e0t[u]; en = e0n[u]; } else { wt = g.e_w[e]; et = g.e_to[e]; en = g.e_next_out[e]; }
+                if (wt > wmax) { wmax = wt; amax = e; pos_amax = pos; }
+                if (found < 0 && et == to[u]) { found = e; pos_found = pos; wfound = wt; }
+                e = en;
+            }
+            if (found >= 0) {
+                const int wn = wfound + 1;
+                g.e_w[found] = wn; g.rid[(size_t)found * g.rid_words + rw] |= rbit; need[u] = 0;
+                if (g.plan_valid && (wn & (wn - 1)) == 0) { const int sl = g.e_slot[found]; if (sl >= 0) g.pl_bonus[sl] = ilog2_32(wn); } // (the edge's bonus, ilog2 of its weight, went up)
+                if (found != amax && (wn > wmax || (wn == wmax && pos_found < pos_amax))) heavy_moved = 1;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (base + u * NT > n_cig) break; // (uniform)
+            const int j = base + u * NT + tid;
+            int tot;
+            const int rank = block_excl_scan<NT>(need[u], sm, &tot);
+            if (j <= n_cig) g.aa_eid[j] = need[u] ? g.n_edge + carry + rank : -1;
+            carry += tot;
+        }
     }
     const int n_newe = carry;
     if (g.n_edge + n_newe > g.edge_cap) { g.status = LCD_ERR_EDGES; return 0; }
     __syncthreads(); // new-node fields (phase 2) and edge numbers are visible
     // phase 4: create + link the new edges
+    if (n_newe > 0)
     for (int j = tid; j <= n_cig; j += NT) {
         const int e = g.aa_eid[j];
         if (e < 0) continue;
@@ -1933,6 +1972,439 @@ __device__ __forceinline__ bool poll_ge(const int *p, const int v) { // p is in 
     return true;
 }
 
+// ================= long chains: certified-band rows SYSTOLIC over the four wavefronts of a 256-thread workgroup (round 4) =================
+// The longest chain of a submission is its latency at every depth: 32 reads x 4 kb of a K2 chain whose certified intervals are ~210 columns wide were 195 ms on ONE
+// wavefront (align_lean<2, 4>: ~480 instructions per row of four cells per lane) against 141 ms of work for the whole chip.  align_lean_mw put the row on four wavefronts
+// with two barriers per row and every predecessor through LDS and came out at 0.85x.  Here the four wavefronts form a PIPELINE, as in align_unbanded:
+//   * thread t owns the columns congruent to C t .. C t + C - 1 modulo WIN = 256 C for the whole read, so the previous row's values of a thread's cells are in that
+//     thread's REGISTERS whatever the interval does (no lane shifts, no LDS on a backbone row's critical path); the diagonal input of a lane's first cell is one
+//     DPP move from the lane to the left, and for lane 0 the boundary H the wavefront to the left has published in its mailbox;
+//   * a row's interval covers at most four consecutive 64 C-column blocks -- one per wavefront, no wavefront twice (rows wider than 192 C columns are not taken here) --
+//     and runs through them in column order starting at wavefront S = block of its first column: S starts row r as soon as it has finished row r - 1; the next one once
+//     its left neighbour has published the row's running gap prefixes (carry1 / carry2) and boundary H; wavefronts the interval does not reach only keep count.
+//     Steady state: one row per ~150 instructions of ONE wavefront, the four of them one row apart.  No workgroup barrier inside the read;
+//   * rows with several predecessors / predecessors further back read their OWN columns of those rows from the LDS ring (or the HBM spill rows) -- written by the
+//     same thread -- masked by the predecessor's interval, and the boundary column from the mailbox / the spill row: they stay inside the pipeline;
+//   * a wavefront is at most SYS_D - K - 1 rows ahead of its right neighbour (mailbox slots are re-used modulo SYS_D); every wait is a bounded poll (LCD_ERR_SYNC).
+// Codes / ordinals / row metadata in HBM are those of align_lean<2, C> (a row's cells start at its interval's first column rounded down to C), so the code-driven
+// backtrack is shared.  Returns the number of cigar entries, 0 with wo->status set, or -1 = not here (an interval wider than the blocks hold, > 254 predecessors).
+template <int C>
+__device__ __attribute__((noinline)) int align_cyc(const Ctx *gp_, const unsigned ring_, const unsigned sq1_, const unsigned pd_ /* 0xffffffff: none */, const LcdScoring sc_,
+                                                   const int bi_, const int ei_, const uint8_t *seq_hbm_, const int qlen_, WinOut *wo_) {
+    const long long t_in0 = clock64();
+    constexpr int NT = 256, BW = 64 * C, WIN = 256 * C, WM = WIN - 1, SLOTW = 3 * WIN, CP = 4, CM = ~(C - 1), BSH = C == 1 ? 6 : 7;
+    constexpr int AHEAD = SYS_D - 3; // a wavefront is at most this many rows ahead of its right neighbour (mailbox slots are re-used modulo SYS_D; readers look back K = 2 rows)
+    typedef typename LeanT<C>::word word;
+    Smem &sm = g_smem;
+    Ctx g = *usgpr(gp_);
+    ctx_to_sgpr(g);
+    const unsigned ring = usgpr(ring_), sq1 = usgpr(sq1_), pd = usgpr(pd_);
+    const int bi = usgpr(bi_), ei = usgpr(ei_), qlen = usgpr(qlen_);
+    const uint8_t *seq_hbm = usgpr(seq_hbm_); WinOut *wo = usgpr(wo_);
+    const int s_match = usgpr(sc_.match), s_mism = -usgpr(sc_.mismatch);
+    const int o1 = usgpr(sc_.o1), e1 = usgpr(sc_.e1), o2 = usgpr(sc_.o2), e2 = usgpr(sc_.e2), oe1 = o1 + e1, oe2 = o2 + e2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = usgpr(tid >> 6);
+    if (qlen >= 65535 || usgpr(g.ring_k) != 2) return -1; // (two ring slots: the slot metadata of a run of backbone rows is kept as "the last two rows")
+    const int QB = (qlen + 12 + 15) & ~15;
+    if (sq1 < ring + (unsigned)(2 * SLOTW * 4)) return -1; // (the pool is laid out for ring slots at least this wide: PoaChain.wmax >= WIN)
+    for (int j = tid; j < QB; j += NT) lds_st_u8(sq1 + j, (j >= 1 && j <= qlen) ? glb_ld_u8(seq_hbm + (j - 1)) : 4); // shifted: sq1[j] = q[j-1]
+    const int qclamp = QB - CP;
+    const unsigned code_cap = (unsigned)(g.cell_cap > 0xfffffff0ull ? 0xfffffff0ull : g.cell_cap);
+    const unsigned ord_cap = g.spill_x > 2 ? code_cap : (unsigned)((g.cell_cap / 4) > 0xfffffff0ull ? 0xfffffff0ull : (g.cell_cap / 4));
+    const long long spill_rows_ll = g.cell_cap * g.spill_x > 64 ? (long long)((g.cell_cap * g.spill_x - 64) / ((unsigned long long)SLOTW * 4)) : 0;
+    const int spill_rows = (int)(spill_rows_ll > 0x7fffffffll ? 0x7fffffffll : spill_rows_ll);
+    const int *const hull = g.cert + 6 * (size_t)g.node_cap;
+    const int cl = C * tid, cll = C * lane;         // this thread's cells inside a ring slot (modulo WIN) / inside its wavefront's block
+    const int left = (wave + 3) & 3, right = (wave + 1) & 3;
+    // mailboxes (LDS byte offsets): progress counter per wavefront; boundary H, running gap prefixes per (row mod SYS_D, wavefront)
+    // (made opaque scalars once: left to itself the compiler re-derives them -- a load from the module's LDS table and a null test -- inside the row loop)
+    const unsigned mb_prog = usgpr(lds_off(&g_wide.prog[0])), mb_c1 = usgpr(lds_off(&g_wide.carry1[0][0])), mb_c2 = usgpr(lds_off(&g_wide.carry2[0][0])), mb_h = usgpr(lds_off(&g_wide.bndH[0][0]));
+    const unsigned a_pl = usgpr(mb_prog + 4 * left), a_pr = usgpr(mb_prog + 4 * right), a_me = usgpr(mb_prog + 4 * wave);
+    const unsigned l_c1 = usgpr(mb_c1 + 4 * left), l_c2 = usgpr(mb_c2 + 4 * left), l_h = usgpr(mb_h + 4 * left);   // the left neighbour's mailbox column, row 0
+    const unsigned m_c1 = usgpr(mb_c1 + 4 * wave), m_c2 = usgpr(mb_c2 + 4 * wave), m_h = usgpr(mb_h + 4 * wave);   // this wavefront's
+    // ---- source row (slot 0): columns 0 .. end0, all of them in the blocks 0 .. 2 ----
+    int end0;
+    { const int hw = usgpr(glb_ld(hull + bi)); end0 = hw >> 16; if ((hw & 65535) != 0) return -1; }
+    if (end0 + 2 > WIN - BW) return -1;
+    int nsp = 0;
+    int pvh[C], pva[C], pvb[C]; // this thread's cells of the row before (fillers where that row's interval does not reach)
+    {
+        const bool spf = (usgpr(glb_ld_u8(g.imap + bi)) & 2) != 0;
+        if (spf && spill_rows < 1) { wo->status = LCD_ERR_CELLS; return 0; }
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int j = cl + k;
+            const int f1 = j ? -(o1 + e1 * j) : LCD_NEG, f2 = j ? -(o2 + e2 * j) : LCD_NEG;
+            const int h = j ? imax(f1, f2) : 0;
+            const bool in = j <= end0;
+            pvh[k] = in ? h : LCD_GUARD; pva[k] = in ? h - oe1 : LCD_GUARD; pvb[k] = in ? h - oe2 : LCD_GUARD;
+        }
+        lds_stc<C>(ring + 4 * cl, pvh); lds_stc<C>(ring + 4 * (WIN + cl), pva); lds_stc<C>(ring + 4 * (2 * WIN + cl), pvb);
+        if (spf) { int *G = g.spill; glb_stc<C>(G + cl, pvh); glb_stc<C>(G + WIN + cl, pva); glb_stc<C>(G + 2 * WIN + cl, pvb); nsp = 1; }
+        if (tid == 0) { glb_st(g.rbeg + bi, 0); glb_st(g.rend + bi, end0); glb_st(g.roff + bi, 0); glb_st(g.ml + bi, 0); glb_st(g.mr + bi, 0); glb_st(g.spoff + bi, 0); sm.bc[7] = LCD_OK; }
+        if (lane == 63) { // the source row's mailbox entries: boundary H of this wavefront's last column; progress = bi
+            *(lcd_lds_i32 *)(uintptr_t)(m_h + (unsigned)((bi & (SYS_D - 1)) * (MAXW * 4))) = pvh[C - 1];
+            *(lcd_lds_i32 *)(uintptr_t)a_me = bi;
+        }
+    }
+    // intervals (beg | end << 16; 1 = none) of the last two rows = of the two ring slots: l_be is row idx - 1 (whose values the pv registers hold), l_be2 row idx - 2
+    int l_be = end0 << 16, l_be2 = 1;
+    unsigned cused = 0, oused = 0; unsigned long long ncell = (unsigned long long)end0 + 1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const long long t_dp0 = clock64();
+    wo->t_setup = (unsigned long long)(t_dp0 - t_in0);
+    int w_pk = 0, w_x = 0, w_pi0 = 0, w_pi1 = 0, w_p0 = 0; // plan window, lane = row - wbase (every wavefront keeps its own copy)
+    int r_be = 1, r_off = 0;                              // row metadata window (wavefront 0 stores it)
+    int wbase = bi + 1;
+    auto load_plan = [&](const int base) { // packed word as in align_lean: #preds | base << 8 | spill << 11 | unreachable << 12 | backbone << 13 | bonus0 << 14 | bonus1 << 19
+        const int ri = base + lane;
+        w_pk = 1 << 12;
+        if (ri < ei) {
+            const int s0 = glb_ld(g.pl_start + ri), s1 = glb_ld(g.pl_start + ri + 1);
+            const int cnt = s1 - s0;
+            int b0 = 0, b1 = 0;
+            w_p0 = s0;
+            if (cnt > 0) { w_pi0 = glb_ld(g.pl_pidx + s0); b0 = glb_ld(g.pl_bonus + s0); }
+            if (cnt > 1) { w_pi1 = glb_ld(g.pl_pidx + s0 + 1); b1 = glb_ld(g.pl_bonus + s0 + 1); }
+            const int rem = glb_ld(g.pl_rem + ri);
+            w_x = glb_ld(hull + ri);
+            w_pk = imin(cnt, 255) | (glb_ld_u8(g.pl_base + ri) << 8) | ((glb_ld_u8(g.imap + ri) & 2) << 10) | (rem == (1 << 30) ? 1 << 12 : 0)
+                 | ((cnt == 1 && w_pi0 == ri - 1) ? 1 << 13 : 0) | (b0 << 14) | (b1 << 19);
+        }
+        LCD_PIN(w_pk); LCD_PIN(w_x); LCD_PIN(w_pi0); LCD_PIN(w_pi1); LCD_PIN(w_p0);
+    };
+    auto flush_meta = [&](const int base, const int n) { // rows base .. base + n - 1
+        if (wave == 0 && lane < n) { glb_st(g.rbeg + base + lane, r_be & 65535); glb_st(g.rend + base + lane, (int)((unsigned)r_be >> 16)); glb_st(g.roff + base + lane, r_off); }
+    };
+    // "the left neighbour has published row `need_l` and the right one row `need_r`" -- and, read behind the same counters (LDS operations of a wavefront are in
+    // order, the writer publishes its data before its counter), this row's running gap prefixes and the boundary H of row `rb`.  Bounded: false = timed out
+    auto sync_rows = [&](const int need_l_, const int need_r_, const int rc, const int rb, int &c1, int &c2, int &bh) {
+        const int need_l = usgpr(need_l_), need_r = usgpr(need_r_);
+        const unsigned ac = (unsigned)usgpr((rc & (SYS_D - 1)) * (MAXW * 4)), ab = (unsigned)usgpr((rb & (SYS_D - 1)) * (MAXW * 4));
+        for (int spins = 0;; ++spins) {
+            const int pl = *(const volatile lcd_lds_i32 *)(uintptr_t)a_pl, pr = *(const volatile lcd_lds_i32 *)(uintptr_t)a_pr;
+            const int v1 = *(const volatile lcd_lds_i32 *)(uintptr_t)(l_c1 + ac), v2 = *(const volatile lcd_lds_i32 *)(uintptr_t)(l_c2 + ac), vh = *(const volatile lcd_lds_i32 *)(uintptr_t)(l_h + ab);
+            if (usgpr(pl) >= need_l && usgpr(pr) >= need_r) { c1 = v1; c2 = v2; bh = vh; return true; }
+            if (usgpr(spins) > (1 << 24)) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    auto publish = [&](const int idx) { // "this wavefront is done with row idx": its LDS writes (ring slot, mailbox) first
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 63) *(volatile lcd_lds_i32 *)(uintptr_t)a_me = idx;
+    };
+    int fail = 0; // -1: not representable here; > 0: an error status.  Every wavefront takes the same decision at the same row (same plan, same counters)
+    unsigned long long t_poll = 0;
+    load_plan(wbase);
+    int idx = bi + 1;
+    while (idx < ei) {
+        if (idx - wbase == 64) { flush_meta(wbase, 64); wbase = idx; load_plan(wbase); }
+        int wk = idx - wbase;
+        // ===== a run of backbone rows: reachable, one usable predecessor = the row before (in the registers), not spilled.  Anything else leaves the loop with the
+        // row untouched and is the general row below. =====
+        {
+            // (the run's loop-carried scalars are locals, and made scalars again at the top of every row: as phis of the outer loop -- or behind the polling loop,
+            //  whose exit the compiler takes for divergent -- they end up in VGPRs, and with them every decision of the row)
+            int f_be = usgpr(l_be), f_be2 = usgpr(l_be2), f_idx = usgpr(idx), f_wk = usgpr(wk); unsigned run_cells = 0, f_cused = usgpr(cused);
+            while (true) {
+                f_be = usgpr(f_be); f_be2 = usgpr(f_be2); f_idx = usgpr(f_idx); f_wk = usgpr(f_wk); f_cused = usgpr(f_cused); run_cells = usgpr(run_cells);
+                const int idx = f_idx, wk = f_wk; const unsigned cused = f_cused;
+                if (wk >= 64) break;
+                const int pk = LCD_RL(w_pk, wk);
+                if ((pk & 0x38ff) != 0x2001) break;
+                const int xw = LCD_RL(w_x, wk);
+                const int beg = xw & 65535, end = (int)((unsigned)xw >> 16);
+                const int begc = beg & CM, blk0 = begc & ~(BW - 1);
+                const int cw4 = ((end - begc) + CP) & ~(CP - 1);
+                const int pb = f_be & 65535, pe = (int)((unsigned)f_be >> 16);
+                // (not here: an empty row / row before, an interval that would come round to its first wavefront, a full DP region, and columns a whole window away
+                //  from the row before -- a register would hold the value of another column)
+                if (beg > end || pb > pe || end - blk0 + 2 > WIN || cused + (unsigned)cw4 > code_cap || pe - begc + 2 >= WIN || end - pb + 1 >= WIN) break;
+                const int pw = (wave - (blk0 >> BSH)) & 3;                 // this wavefront's place in the row's column order (0: the row's first)
+                const int j0 = blk0 + BW * pw;                             // the column of its lane 0
+                const int j = j0 + cll;                                    // this lane's first column
+                const int vb = (pk >> 8) & 7, bz0 = (pk >> 14) & 31;
+                const int mt = vb >= 4 ? 0 : s_match, mm = vb >= 4 ? 0 : s_mism;
+                word qw;
+                {
+                    const unsigned a = sq1 + (unsigned)imin(j, qclamp);
+                    if constexpr (C == 1) qw = (word)*(const lcd_lds_u8 *)(uintptr_t)a;
+                    else qw = (word)*(const __attribute__((address_space(3))) unsigned short *)(uintptr_t)a;
+                }
+                // the first wavefront of a row does not wait for its left neighbour -- the LAST wavefront of the rows before -- unless the row before reaches into that
+                // block: then the neighbour was that row's first wavefront and is ahead anyway
+                const bool need_b = j0 - 1 >= pb && j0 - 1 <= pe;
+                int cin1, cin2, bnd;
+                if (!sync_rows(pw > 0 ? idx : (need_b ? idx - 1 : bi), idx - AHEAD, idx, idx - 1, cin1, cin2, bnd)) { fail = LCD_ERR_SYNC; break; }
+                if (pw == 0) { cin1 = LCD_GUARD; cin2 = LCD_GUARD; }
+                if (!need_b) bnd = LCD_GUARD;
+                const int hm = __builtin_amdgcn_update_dpp(bnd, pvh[C - 1], 0x138, 0xf, 0xf, false); // wave_shr:1, lane 0 keeps the boundary
+                const int je1 = __mul24(j, e1), je2 = __mul24(j, e2);
+                int hp[C], spk[C], a1[C], a2[C], p1[C], p2[C], uu[C], vv[C]; bool inb[C];
+#pragma unroll
+                for (int k = 0; k < C; ++k) {
+                    const int q = (int)(qw >> (8 * k)) & 255;
+                    const int sk = q >= 4 ? 0 : (q == vb ? mt : mm);
+                    const int nn = imax(LCD_NEG, (k ? pvh[k - 1] : hm) + sk + bz0);
+                    uu[k] = imax(LCD_NEG, pva[k] + bz0); vv[k] = imax(LCD_NEG, pvb[k] + bz0);
+                    inb[k] = (unsigned)(j + k - beg) <= (unsigned)(end - beg);
+                    hp[k] = imax(nn, imax(uu[k], vv[k]));
+                    spk[k] = nn == hp[k] ? 0 : uu[k] == hp[k] ? 1 : 2;
+                    a1[k] = inb[k] ? hp[k] + (je1 + k * e1) : LCD_GUARD; a2[k] = inb[k] ? hp[k] + (je2 + k * e2) : LCD_GUARD;
+                    p1[k] = k ? imax(p1[k - 1], a1[k]) : a1[k]; p2[k] = k ? imax(p2[k - 1], a2[k]) : a2[k];
+                }
+                int t1 = p1[C - 1], t2 = p2[C - 1];
+                scan_max2(t1, t2);
+                const int x1 = imax(shr1(LCD_GUARD, t1), cin1), x2 = imax(shr1(LCD_GUARD, t2), cin2);
+                word code = 0;
+#pragma unroll
+                for (int k = 0; k < C; ++k) {
+                    const int pf1 = k ? imax(x1, p1[k - 1]) : x1, pf2 = k ? imax(x2, p2[k - 1]) : x2;
+                    const int f1 = imax(LCD_NEG, pf1 - (o1 + je1 + k * e1)), f2 = imax(LCD_NEG, pf2 - (o2 + je2 + k * e2));
+                    const int h = imax(hp[k], imax(f1, f2));
+                    const int q1 = h - oe1, w1 = uu[k] - e1, q2 = h - oe2, w2 = vv[k] - e2;
+                    const int eo1 = imax(imax(q1, w1), LCD_NEG), eo2 = imax(imax(q2, w2), LCD_NEG);
+                    const int fk = f1 == h ? (f2 == h ? 5 : 3) : 4;
+                    const int hs = hp[k] == h ? spk[k] : fk;
+                    unsigned fl = 0; // O2, O1, Y2, Y1 pushed in this order = bits 6, 5, 4, 3 of the code
+                    { const int r2 = a2[k], r1 = a1[k]; LCD_PUSH_GE(fl, q2, w2); LCD_PUSH_GE(fl, q1, w1); LCD_PUSH_GT(fl, pf2, r2); LCD_PUSH_GT(fl, pf1, r1); }
+                    code |= (word)((unsigned)hs | (fl << 3)) << (8 * k);
+                    pvh[k] = inb[k] ? h : LCD_GUARD; pva[k] = inb[k] ? eo1 : LCD_GUARD; pvb[k] = inb[k] ? eo2 : LCD_GUARD;
+                }
+                {
+                    const unsigned SL = ring + 4 * ((idx - bi) & 1) * SLOTW;
+                    lds_stc<C>(SL + 4 * cl, pvh); lds_stc<C>(SL + 4 * (WIN + cl), pva); lds_stc<C>(SL + 4 * (2 * WIN + cl), pvb);
+                    const int cj = j - begc;
+                    if ((unsigned)cj < (unsigned)cw4) {
+                        uint8_t *cp = g.code8 + (size_t)(cused + (unsigned)cj);
+                        if constexpr (C == 2) *(__attribute__((address_space(1))) unsigned short *)cp = (unsigned short)code;
+                        else *(__attribute__((address_space(1))) uint8_t *)cp = (uint8_t)code;
+                    }
+                    if (lane == 63) {
+                        const unsigned mo = (unsigned)((idx & (SYS_D - 1)) * (MAXW * 4));
+                        *(lcd_lds_i32 *)(uintptr_t)(m_h + mo) = pvh[C - 1];
+                        *(lcd_lds_i32 *)(uintptr_t)(m_c1 + mo) = imax(cin1, t1); *(lcd_lds_i32 *)(uintptr_t)(m_c2 + mo) = imax(cin2, t2);
+                    }
+                }
+                const int be = beg | (end << 16);
+                if (wave == 0) { r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)cused, wk, r_off); }
+                f_be2 = f_be; f_be = be;
+                f_cused = cused + (unsigned)cw4; run_cells += (unsigned)(end - beg + 1);
+                publish(idx);
+                f_idx = idx + 1; f_wk = wk + 1;
+            }
+            l_be = usgpr(f_be); l_be2 = usgpr(f_be2); ncell += usgpr(run_cells); idx = usgpr(f_idx); wk = usgpr(f_wk); cused = usgpr(f_cused);
+            if (fail != 0) break;
+            if (wk == 64 || idx >= ei) continue;
+        }
+        // ===== general row: several predecessors, a predecessor further back, a spilled / empty / unreachable row =====
+        do {
+        const int pk = LCD_RL(w_pk, wk);
+        if (pk & (1 << 12)) { // not reachable from the begin node
+            if (wave == 0) r_be = lean_wlane(1, wk, r_be);
+#pragma unroll
+            for (int k = 0; k < C; ++k) { pvh[k] = LCD_GUARD; pva[k] = LCD_GUARD; pvb[k] = LCD_GUARD; }
+            l_be2 = l_be; l_be = 1; publish(idx);
+            break;
+        }
+        const int np = pk & 255, vb = (pk >> 8) & 7, bz0 = (pk >> 14) & 31;
+        const bool spf = (pk >> 11) & 1;
+        if (np == 255) { fail = -1; break; }
+        const int xw = LCD_RL(w_x, wk);
+        const int pi0 = LCD_RL(w_pi0, wk);
+        const int beg = xw & 65535, end = (int)((unsigned)xw >> 16); // the row's certified interval (beg > end: no cell of the row can lie on an optimal path)
+        if (beg > end) {
+            if (wave == 0) r_be = lean_wlane(1, wk, r_be);
+            if (spf && tid == 0) { glb_st(g.rbeg + idx, 1); glb_st(g.rend + idx, 0); }
+#pragma unroll
+            for (int k = 0; k < C; ++k) { pvh[k] = LCD_GUARD; pva[k] = LCD_GUARD; pvb[k] = LCD_GUARD; }
+            l_be2 = l_be; l_be = 1; publish(idx);
+            break;
+        }
+        const int begc = beg & CM, blk0 = begc & ~(BW - 1);
+        if (end - blk0 + 2 > WIN) { fail = -1; break; } // the interval would come round to its first wavefront again
+        const int cw4 = ((end - begc) + CP) & ~(CP - 1);
+        if (cused + (unsigned)cw4 > code_cap || (np > 1 && oused + (unsigned)cw4 > ord_cap) || (spf && nsp >= spill_rows)) { fail = LCD_ERR_CELLS; break; }
+        const int pw = (wave - (blk0 >> BSH)) & 3;
+        const int j0 = blk0 + BW * pw, j = j0 + cll;
+        int pi1 = 0, bz1 = 0, p0 = 0;
+        if (np > 1) { pi1 = LCD_RL(w_pi1, wk); bz1 = (pk >> 19) & 31; p0 = LCD_RL(w_p0, wk); }
+        // the rows this one reads of its left neighbour: every wavefront but the row's first needs the row itself (gap prefixes); a predecessor's boundary column needs
+        // that predecessor.  (Simply: the row itself, or the newest predecessor whose interval holds column j0 - 1.)
+        int need_l = bi;
+        if (pw > 0) need_l = idx;
+        else {
+            for (int t = 0; t < np; ++t) {
+                int pi = t == 0 ? pi0 : pi1;
+                if (t > 1) pi = usgpr(glb_ld(g.pl_pidx + p0 + t));
+                int pbe;
+                if (idx - pi <= 2) pbe = idx - pi == 1 ? l_be : l_be2;
+                else pbe = usgpr(glb_ld(hull + pi)); // (a far row: its interval is the table's)
+                const int pb = pbe & 65535, pe = (int)((unsigned)pbe >> 16);
+                if (pb <= pe && j0 - 1 >= pb && j0 - 1 <= pe) need_l = smax(need_l, pi);
+            }
+        }
+        int cin1, cin2, bnd_unused;
+        const long long tq0 = clock64();
+        if (!sync_rows(need_l, idx - AHEAD, idx, idx, cin1, cin2, bnd_unused)) { fail = LCD_ERR_SYNC; break; }
+        t_poll += (unsigned long long)(clock64() - tq0);
+        if (pw == 0) { cin1 = LCD_GUARD; cin2 = LCD_GUARD; }
+        word qw;
+        {
+            const unsigned a = sq1 + (unsigned)imin(j, qclamp);
+            if constexpr (C == 1) qw = (word)*(const lcd_lds_u8 *)(uintptr_t)a;
+            else qw = (word)*(const __attribute__((address_space(3))) unsigned short *)(uintptr_t)a;
+        }
+        bool inb[C]; int sk[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            inb[k] = j + k >= beg && j + k <= end;
+            const int q = (int)(qw >> (8 * k)) & 255;
+            sk[k] = (vb >= 4 || q >= 4) ? 0 : (vb == q ? s_match : s_mism);
+        }
+        // ---- phase A: best match / E1 / E2 input over the predecessors (first maximum keeps its ordinal); own columns from the ring slot / spill row this thread wrote ----
+        int nn[C], uu[C], vv[C];
+        word om = 0, oa = 0, ob = 0;
+#pragma unroll
+        for (int k = 0; k < C; ++k) { nn[k] = LCD_NEG; uu[k] = LCD_NEG; vv[k] = LCD_NEG; }
+        {
+            bool synced = false;
+            for (int t = 0; t < np; ++t) {
+                int pi = t == 0 ? pi0 : pi1, bz = t == 0 ? bz0 : bz1;
+                if (t > 1) { pi = usgpr(glb_ld(g.pl_pidx + p0 + t)); bz = usgpr(glb_ld(g.pl_bonus + p0 + t)); }
+                const bool near = idx - pi <= 2;
+                int pb, pe, hm, hv[C], av[C], bv[C];
+                if (near) {
+                    const int pbe = idx - pi == 1 ? l_be : l_be2; pb = pbe & 65535; pe = (int)((unsigned)pbe >> 16);
+                    if (pb > pe) continue;
+                    const unsigned SL = ring + 4 * ((pi - bi) & 1) * SLOTW;
+                    hm = lds_ld(SL + 4 * ((cl - 1) & WM)); lds_ldc<C>(SL + 4 * cl, hv); lds_ldc<C>(SL + 4 * (WIN + cl), av); lds_ldc<C>(SL + 4 * (2 * WIN + cl), bv);
+                    if (j0 - 1 >= pb && j0 - 1 <= pe) { // lane 0: the boundary column from the left neighbour's mailbox
+                        const int bh = *(const volatile lcd_lds_i32 *)(uintptr_t)(l_h + (unsigned)((pi & (SYS_D - 1)) * (MAXW * 4)));
+                        if (lane == 0) hm = bh;
+                    }
+                } else { // a far row: its metadata and values were stored to HBM when it was made (and waited for before that row was published)
+                    if (!synced) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); synced = true; }
+                    { const int pbe = usgpr(glb_ld(hull + pi)); pb = pbe & 65535; pe = (int)((unsigned)pbe >> 16); } // (the table's interval: the row's metadata in HBM is another wavefront's store)
+                    if (pb > pe) continue;
+                    const int *G = g.spill + (size_t)(unsigned)usgpr(glb_ld((const int *)g.spoff + pi)) * SLOTW; // (every wavefront stores the same spoff: this one reads its own store)
+                    hm = glb_ld(G + ((cl - 1) & WM)); glb_ldc<C>(G + cl, hv); glb_ldc<C>(G + WIN + cl, av); glb_ldc<C>(G + 2 * WIN + cl, bv);
+                    LCD_PIN(hm);
+#pragma unroll
+                    for (int k = 0; k < C; ++k) { LCD_PIN(hv[k]); LCD_PIN(av[k]); LCD_PIN(bv[k]); }
+                }
+                // a slot is addressed by (column mod WIN): entries that belong to other columns of the predecessor's interval, or to none, are fillers here
+                if (j - 1 < pb || j - 1 > pe) hm = LCD_GUARD;
+#pragma unroll
+                for (int k = 0; k < C; ++k) if (j + k < pb || j + k > pe) { hv[k] = LCD_GUARD; av[k] = LCD_GUARD; bv[k] = LCD_GUARD; }
+                const int tt = t > 255 ? 255 : t;
+#pragma unroll
+                for (int k = 0; k < C; ++k) {
+                    const int c = (k == 0 ? hm : hv[k - 1]) + sk[k] + bz, a = av[k] + bz, b = bv[k] + bz;
+                    if (t == 0) { nn[k] = imax(nn[k], c); uu[k] = imax(uu[k], a); vv[k] = imax(vv[k], b); }
+                    else {
+                        if (c > nn[k]) { nn[k] = c; om = (om & ~((word)255 << (8 * k))) | ((word)tt << (8 * k)); }
+                        if (a > uu[k]) { uu[k] = a; oa = (oa & ~((word)255 << (8 * k))) | ((word)tt << (8 * k)); }
+                        if (b > vv[k]) { vv[k] = b; ob = (ob & ~((word)255 << (8 * k))) | ((word)tt << (8 * k)); }
+                    }
+                }
+            }
+        }
+        // ---- F: A[k] = Hpre[k] + column * e; in-lane inclusive prefix, one scan pair over the lanes, carry from the wavefront to the left ----
+        int hp[C], spk[C], a1[C], a2[C], p1[C], p2[C];
+        const int je1 = __mul24(j, e1), je2 = __mul24(j, e2);
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            hp[k] = imax(nn[k], imax(uu[k], vv[k]));
+            spk[k] = nn[k] == hp[k] ? 0 : uu[k] == hp[k] ? 1 : 2;
+            a1[k] = inb[k] ? hp[k] + (je1 + k * e1) : LCD_GUARD; a2[k] = inb[k] ? hp[k] + (je2 + k * e2) : LCD_GUARD;
+            p1[k] = k ? imax(p1[k - 1], a1[k]) : a1[k]; p2[k] = k ? imax(p2[k - 1], a2[k]) : a2[k];
+        }
+        int t1 = p1[C - 1], t2 = p2[C - 1];
+        scan_max2(t1, t2);
+        const int x1 = imax(shr1(LCD_GUARD, t1), cin1), x2 = imax(shr1(LCD_GUARD, t2), cin2);
+        // ---- phase B: F, H, E-out, direction code ----
+        word code = 0;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int pf1 = k ? imax(x1, p1[k - 1]) : x1, pf2 = k ? imax(x2, p2[k - 1]) : x2;
+            const int f1 = imax(LCD_NEG, pf1 - (o1 + je1 + k * e1)), f2 = imax(LCD_NEG, pf2 - (o2 + je2 + k * e2));
+            const int h = imax(hp[k], imax(f1, f2));
+            const int q1 = h - oe1, w1 = uu[k] - e1, q2 = h - oe2, w2 = vv[k] - e2;
+            const int eo1 = imax(imax(q1, w1), LCD_NEG), eo2 = imax(imax(q2, w2), LCD_NEG);
+            const int fk = f1 == h ? (f2 == h ? 5 : 3) : 4;
+            const int hs = hp[k] == h ? spk[k] : fk;
+            unsigned fl = 0; // O2, O1, Y2, Y1 pushed in this order = bits 6, 5, 4, 3 of the code
+            { const int r2 = a2[k], r1 = a1[k]; LCD_PUSH_GE(fl, q2, w2); LCD_PUSH_GE(fl, q1, w1); LCD_PUSH_GT(fl, pf2, r2); LCD_PUSH_GT(fl, pf1, r1); }
+            const unsigned cd = (unsigned)hs | (fl << 3) | (((om >> (8 * k)) & 255) ? CB_PM : 0);
+            code |= (word)cd << (8 * k);
+            pvh[k] = inb[k] ? h : LCD_GUARD; pva[k] = inb[k] ? eo1 : LCD_GUARD; pvb[k] = inb[k] ? eo2 : LCD_GUARD;
+        }
+        // ---- stores: ring slot (values), HBM (codes; values only for rows a far successor / the end node will read), mailbox ----
+        {
+            const unsigned SL = ring + 4 * ((idx - bi) & 1) * SLOTW;
+            lds_stc<C>(SL + 4 * cl, pvh); lds_stc<C>(SL + 4 * (WIN + cl), pva); lds_stc<C>(SL + 4 * (2 * WIN + cl), pvb);
+            if (spf) { int *G = g.spill + (size_t)nsp * SLOTW; glb_stc<C>(G + cl, pvh); glb_stc<C>(G + WIN + cl, pva); glb_stc<C>(G + 2 * WIN + cl, pvb); }
+            const int cj = j - begc;
+            if ((unsigned)cj < (unsigned)cw4) {
+                uint8_t *cp = g.code8 + (size_t)(cused + (unsigned)cj);
+                if constexpr (C == 2) *(__attribute__((address_space(1))) unsigned short *)cp = (unsigned short)code;
+                else *(__attribute__((address_space(1))) uint8_t *)cp = (uint8_t)code;
+                if (np > 1) {
+                    int ow[C];
+#pragma unroll
+                    for (int k = 0; k < C; ++k) ow[k] = (int)((om >> (8 * k)) & 255) | ((int)((oa >> (8 * k)) & 255) << 8) | ((int)((ob >> (8 * k)) & 255) << 16);
+                    glb_stc<C>(g.ord + (size_t)(oused + (unsigned)cj), ow);
+                }
+            }
+            if (lane == 63) {
+                const unsigned mo = (unsigned)((idx & (SYS_D - 1)) * (MAXW * 4));
+                *(lcd_lds_i32 *)(uintptr_t)(m_h + mo) = pvh[C - 1];
+                *(lcd_lds_i32 *)(uintptr_t)(m_c1 + mo) = imax(cin1, t1); *(lcd_lds_i32 *)(uintptr_t)(m_c2 + mo) = imax(cin2, t2);
+            }
+        }
+        const int be = beg | (end << 16);
+        if (wave == 0) { r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)cused, wk, r_off); }
+        l_be2 = l_be; l_be = be;
+        if ((np > 1 || spf) && lane == 0) { // (all four wavefronts, the same values: each reads back only what it stored itself)
+            if (np > 1) glb_st(g.ooff + idx, (int)oused);
+            if (spf) { glb_st(g.rbeg + idx, beg); glb_st(g.rend + idx, end); glb_st(g.ml + idx, 0); glb_st(g.mr + idx, 0); glb_st(g.spoff + idx, nsp); }
+        }
+        cused += (unsigned)cw4; if (np > 1) oused += (unsigned)cw4;
+        if (spf) { ++nsp; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } // (a row that others will read from HBM: there before it is published)
+        ncell += (unsigned long long)(end - beg + 1);
+        publish(idx);
+        } while (0);
+        if (fail != 0) break;
+        ++idx;
+    }
+    if (fail != 0) { // nobody may wait for this wavefront any more; the others reach the same row and the same decision
+        if (lane == 63) *(volatile lcd_lds_i32 *)(uintptr_t)a_me = 0x7ffffff0;
+        if (fail == LCD_ERR_SYNC && lane == 0) sm.bc[7] = LCD_ERR_SYNC;
+    }
+    if (fail == 0) flush_meta(wbase, ei - wbase);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (sm.bc[7] != LCD_OK) fail = sm.bc[7]; // (a wavefront that timed out waiting for another: everybody leaves with the error)
+    __syncthreads();
+    if (fail < 0) return -1;
+    if (fail > 0) { wo->status = fail; return 0; }
+    wo->cells = ncell;
+    const long long t_bt0 = clock64();
+    wo->t_dp = (unsigned long long)(t_bt0 - t_dp0); wo->t_poll = t_poll;
+    if (wave == 0) code_backtrack(g, sm, pd, bi, ei, qlen, SLOTW, WM, lane, CM);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int n_cig = sm.bc[0];
+    wo->status = sm.bc[1];
+    wo->cig_pos = sm.bc[4];
+    wo->score = sm.bc[5];
+    __syncthreads();
+    wo->t_bt = (unsigned long long)(clock64() - t_bt0);
+    return n_cig;
+}
+
 // BAND: the rows are restricted to the certified intervals of the table (g.cert hull, align_certified_sys): a wavefront whose 256 columns miss a row's interval
 // only publishes fillers to its mailboxes (a few dozen instructions instead of a row), cells of an active wavefront outside the interval are stored as fillers,
 // and a row's codes / ordinals in HBM start at the interval's 4-cell group (rbeg / rend / roff say where, as for the windowed rows).
@@ -2596,7 +3068,7 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                     continue;
                 }
                 wo.status = g.status; wo.score = LCD_NEG;
-                if (sc.dbg & 32) g.t_setup += 1ull << (12 * (mw <= 60 ? 0 : mw <= 124 ? 1 : mw <= 188 ? 2 : mw <= 256 ? 3 : 4)); // (LCD_DBG=32: reads per widest-interval class, 12 bits each, in the t_setup slot)
+                if (sc.dbg & 32) g.t_setup += 1ull << (12 * (mw <= 60 ? 0 : mw <= 124 ? 1 : mw <= 188 ? 2 : mw <= 380 ? 3 : 4)); // (LCD_DBG=32: reads per widest-interval class, 12 bits each, in the t_setup slot)
                 // one, two or four cells per lane by the widest interval (hull widths are computed for 4-cell groups: the narrower variants keep a margin)
                 nc = -1;
                 bool by_all = false;
@@ -2604,6 +3076,14 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                     nc = align_lean_mw(&g, ro, so, pdo, sc, bi, ei, seq_hbm, qlen, &wo);
                     __syncthreads();
                     by_all = nc >= 0; // (every wavefront has the result)
+                    if (!by_all) { wo.status = g.status; wo.score = LCD_NEG; }
+                }
+                if constexpr (NT == 256) if (SOLO && g.solo == 3 && mw > 60 && mw <= 380) { // the rows as a pipeline over the four wavefronts (align_cyc): one or two cells per lane by the widest interval
+                    nc = mw <= 188 ? align_cyc<1>(&g, ro, so, pdo, sc, bi, ei, seq_hbm, qlen, &wo) : -1;
+                    if (nc < 0) { __syncthreads(); nc = align_cyc<2>(&g, ro, so, pdo, sc, bi, ei, seq_hbm, qlen, &wo); }
+                    __syncthreads();
+                    by_all = nc >= 0;
+                    if (by_all && !(sc.dbg & 32)) g.t_setup += wo.t_poll; // (profiling: wavefront 0's mailbox polls, in the "row setup" slot)
                     if (!by_all) { wo.status = g.status; wo.score = LCD_NEG; }
                 }
                 if (!by_all && (!SOLO || wave == 0)) {
@@ -3189,20 +3669,34 @@ __device__ __attribute__((noinline)) void chain_output(Ctx &g, Smem &sm, const P
     if (g.status == LCD_OK && g.n_node > 2) {
         const int n = g.n_node;
         int *rank = g.deg;
-        if (tid == 0) {
-            int nc = 0;
-            for (int i = 0; i < n; ++i) rank[i] = -1;
-            for (int idx = 1; idx < n - 1; ++idx) {
-                int v = g.idx2node[idx];
-                if (rank[v] >= 0) continue;
-                rank[v] = nc;
-                for (int a = g.aligned[v]; a != v; a = g.aligned[a]) rank[a] = nc;
-                ++nc;
+        // MSA column of every node = the number of aligned rings whose FIRST node (in topological order) comes before this ring's first node (the oracle hands the
+        // columns out in one serial pass over the order: oracle/poa.c poa_output).  In parallel: every row finds its ring's smallest index (rings are short), the
+        // rows that ARE that smallest index are numbered by a prefix sum, and every node takes its ring leader's number.  (The serial pass on one lane -- three
+        // dependent loads per node -- was 6 % of a HiFi-shape step.)
+        int *lead_idx = g.pl_start, *colnum = g.queue; // (free after the last read)
+        int ncol = 0;
+        {
+            if (tid == 0) { rank[0] = -1; rank[1] = -1; }
+            int carry = 0;
+            for (int base = 1; base < n - 1; base += NT) {
+                const int idx = base + tid;
+                int isl = 0;
+                if (idx < n - 1) {
+                    const int v = g.idx2node[idx];
+                    int m = idx;
+                    for (int a = g.aligned[v]; a != v; a = g.aligned[a]) m = imin(m, g.node2idx[a]);
+                    lead_idx[idx] = m; isl = m == idx;
+                }
+                int tot;
+                const int r = block_excl_scan<NT>(isl, sm, &tot);
+                if (idx < n - 1) colnum[idx] = carry + r;
+                carry += tot;
             }
-            sm.bc[0] = nc;
+            ncol = carry;
+            __syncthreads();
+            for (int idx = 1 + tid; idx < n - 1; idx += NT) rank[g.idx2node[idx]] = colnum[lead_idx[idx]];
         }
         __syncthreads();
-        const int ncol = sm.bc[0];
         for (size_t t = tid; t < (size_t)(n_seq + 2) * ncol; t += NT) msa[(t / ncol) * (size_t)nc_cap + (t % ncol)] = LCD_GAP;
         __syncthreads();
         for (int v = 2 + tid; v < n; v += NT) {
