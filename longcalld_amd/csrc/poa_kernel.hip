@@ -412,6 +412,20 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
     return (n_new || n_newe) ? 2 : moved ? 1 : 3;
 }
 
+// A parallel pass over [lo, hi) with U elements per thread IN FLIGHT: `ld` (straight-line loads, no side effects; called with an index clamped into the range)
+// runs for all U before `st` runs for any, so the U dependent-load chains overlap instead of following one another -- the per-read graph phases are latency
+// chains through L2 / HBM run by one wavefront, and a loop that stores into an int array between two loads is a chain per iteration for the compiler.
+template <int U, int NT, typename LoadF, typename StoreF>
+__device__ __forceinline__ void batched_for(const int lo, const int hi, LoadF ld, StoreF st) {
+    for (int b = lo + (int)threadIdx.x; b < hi; b += U * NT) {
+        decltype(ld(0)) r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = b + u * NT; r[u] = ld(i < hi ? i : hi - 1); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = b + u * NT; if (i < hi) st(i, r[u]); }
+    }
+}
+
 // Kahn BFS order + remain for the whole workgroup: the pointer-chasing part still runs on one lane (the FIFO order is
 // inherently serial) but on 16-bit copies of the graph staged in LDS, so each dependent step costs an LDS access (~60 clk)
 // instead of an HBM/L2 access (~500 clk); staging in and out is a coalesced parallel copy.  Falls back to HBM when the
@@ -436,12 +450,14 @@ __device__ __forceinline__ void remain_by_jumping(Ctx &g, const int n, U16P b0, 
     for (int r = 0; r < rounds; ++r) {
         U16P Ps = buf[src], Ds = Ps + n;
         U16P Pd = buf[src ^ 1], Dd = Pd + n;
-        for (int v = tid; v < n; v += NT) { const int p = Ps[v]; Pd[v] = Ps[p]; Dd[v] = (unsigned short)(Ds[v] + Ds[p]); }
+        struct PD { int pp, d; };
+        batched_for<4, NT>(0, n, [&](const int v) { const int p = Ps[v]; PD r; r.pp = Ps[p]; r.d = Ds[v] + Ds[p]; return r; },
+                           [&](const int v, const PD r) { Pd[v] = (unsigned short)r.pp; Dd[v] = (unsigned short)r.d; });
         __syncthreads();
         src ^= 1;
     }
     U16P D = buf[src] + n;
-    for (int v = tid; v < n; v += NT) g.remain[v] = (int)D[v] - 1;
+    batched_for<4, NT>(0, n, [&](const int v) { return (int)D[v]; }, [&](const int v, const int d) { g.remain[v] = d - 1; });
 }
 typedef __attribute__((address_space(3))) unsigned short *lcd_lds_u16p;
 __device__ __forceinline__ lcd_lds_u16p lds_u16(const void *p) { return (lcd_lds_u16p)(uintptr_t)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)p; }
@@ -450,39 +466,37 @@ template <int NT, bool INLDS>
 __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned short *deg, unsigned short *queue, unsigned *nw, unsigned *ew) {
     const int tid = threadIdx.x;
     const int n = g.n_node, E = g.n_edge;
-    for (int i = tid; i < n; i += NT) { deg[i] = (unsigned short)g.nin[i]; nw[i] = (unsigned)(g.out_head[i] + 1) | ((unsigned)g.aligned[i] << 16); }
-    for (int e = tid; e < E; e += NT) ew[e] = (unsigned)g.e_to[e] | ((unsigned)(g.e_next_out[e] + 1) << 16);
+    struct NW { int d; unsigned w; };
+    batched_for<4, NT>(0, n, [&](const int i) { NW r; r.d = g.nin[i]; r.w = (unsigned)(g.out_head[i] + 1) | ((unsigned)g.aligned[i] << 16); return r; },
+                       [&](const int i, const NW r) { deg[i] = (unsigned short)r.d; nw[i] = r.w; });
+    batched_for<4, NT>(0, E, [&](const int e) { return (unsigned)g.e_to[e] | ((unsigned)(g.e_next_out[e] + 1) << 16); }, [&](const int e, const unsigned w) { ew[e] = w; });
     // Chain links for the walk below: link(v) = w when v's only out-edge goes to w, w has no other in-edge and no aligned ring -- when v is
     // popped with nothing else queued, w is the next node whatever else happens.  POA graphs are mostly such chains (the backbone between
     // bubbles), so the walk takes them 64 nodes at a time: jump tables J1 = link, J4 = link^4, J16 = link^16 (self-loops at chain ends) let
     // lane t of wavefront 0 reach link^t(v) in <= 9 loads.  The tables live in the row-plan arrays (HBM, free between two reads).
     unsigned short *J1 = (unsigned short *)g.pl_start, *J4 = J1 + n, *J16 = (unsigned short *)g.pl_rem;
     __syncthreads();
-    for (int v = tid; v < n; v += NT) {
+    batched_for<4, NT>(0, n, [&](const int v) {
         const unsigned e = nw[v] & 0xffffu;
-        int l = v;
-        if (e != 0) {
-            const unsigned w = ew[e - 1];
-            const int to = (int)(w & 0xffffu);
-            if ((w >> 16) == 0 && deg[to] == 1 && (int)(nw[to] >> 16) == to) l = to;
-        }
-        J1[v] = (unsigned short)l;
-    }
+        const unsigned w = ew[e != 0 ? e - 1 : 0];      // (straight-line: the loads of a node without an out-edge are harmless)
+        const int to = (int)(w & 0xffffu);
+        const bool link = e != 0 && (w >> 16) == 0 && deg[to] == 1 && (int)(nw[to] >> 16) == to;
+        return link ? to : v;
+    }, [&](const int v, const int l) { J1[v] = (unsigned short)l; });
     __syncthreads();
     // RL[v] = length of the chain that starts at v, capped at 16: a jump costs up to 9 dependent loads, so chains shorter than 4 are walked
     // node by node (graphs of noisy reads are bubbles every few nodes: probing every node for a chain cost more than it saved)
     unsigned char *RL = (unsigned char *)(J16 + n), *R4 = RL + n; // (second half of pl_rem: 2n bytes)
-    for (int v = tid; v < n; v += NT) {
-        int x = v, r = 0;
-        for (int k = 0; k < 4; ++k) { const int y = J1[x]; r += y != x; x = y; }
-        J4[v] = (unsigned short)x; R4[v] = (unsigned char)r;
-    }
+    struct XR { int x, r; };
+    batched_for<4, NT>(0, n, [&](const int v) { XR o; o.x = v; o.r = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int y = J1[o.x]; o.r += y != o.x; o.x = y; }
+        return o; }, [&](const int v, const XR o) { J4[v] = (unsigned short)o.x; R4[v] = (unsigned char)o.r; });
     __syncthreads();
-    for (int v = tid; v < n; v += NT) {
-        int x = v, r = 0;
-        for (int k = 0; k < 4; ++k) { r += R4[x]; x = J4[x]; }
-        J16[v] = (unsigned short)x; RL[v] = (unsigned char)r;
-    }
+    batched_for<4, NT>(0, n, [&](const int v) { XR o; o.x = v; o.r = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o.r += R4[o.x]; o.x = J4[o.x]; }
+        return o; }, [&](const int v, const XR o) { J16[v] = (unsigned short)o.x; RL[v] = (unsigned char)o.r; });
     __syncthreads();
     const long long tk0 = clock64();
     if (tid < 64) { // wavefront 0, every lane with the same scalars (loads broadcast, identical stores coincide); lanes differ only in the chain step
@@ -542,12 +556,22 @@ __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned shor
         // (P, D) buffers of the pointer jumping: with the walk's arrays in LDS, buffer 0 takes the place of deg | queue (dead after this loop; thread v alone touches
         // slot v) and buffer 1 that of the node words -- every round is then an LDS pass instead of a round trip to HBM; otherwise the row-plan arrays in HBM
         unsigned short *P0 = INLDS ? deg : (unsigned short *)g.pl_start, *D0 = INLDS ? queue : P0 + n; // (the jump tables of the walk are dead now)
-        for (int v = tid; v < n; v += NT) {
-            int mw = -1, mid = 1;
-            for (unsigned e = nw[v] & 0xffffu; e != 0;) { const unsigned w = ew[e - 1]; const int wt = g.e_w[e - 1]; if (wt > mw) { mw = wt; mid = (int)(w & 0xffffu); } e = w >> 16; }
-            g.idx2node[v] = queue[v];
-            P0[v] = (unsigned short)mid; D0[v] = (unsigned short)(v == 1 ? 0 : 1);
-        }
+        struct HV { int mw, mid, q; unsigned more; };
+        batched_for<4, NT>(0, n, [&](const int v) { // (the first two out-edges straight-line: nearly every node has no more)
+            HV r; r.mw = -1; r.mid = 1; r.q = queue[v];
+            const unsigned e0 = nw[v] & 0xffffu;
+            const unsigned w0 = ew[e0 ? e0 - 1 : 0]; const int t0 = g.e_w[e0 ? e0 - 1 : 0];
+            const unsigned e1 = e0 ? w0 >> 16 : 0;
+            const unsigned w1 = ew[e1 ? e1 - 1 : 0]; const int t1 = g.e_w[e1 ? e1 - 1 : 0];
+            if (e0) { r.mw = t0; r.mid = (int)(w0 & 0xffffu); }
+            if (e1 && t1 > r.mw) { r.mw = t1; r.mid = (int)(w1 & 0xffffu); }
+            r.more = e1 ? w1 >> 16 : 0;
+            return r;
+        }, [&](const int v, HV r) {
+            for (unsigned e = r.more; e != 0;) { const unsigned w = ew[e - 1]; const int wt = g.e_w[e - 1]; if (wt > r.mw) { r.mw = wt; r.mid = (int)(w & 0xffffu); } e = w >> 16; }
+            g.idx2node[v] = r.q;
+            P0[v] = (unsigned short)r.mid; D0[v] = (unsigned short)(v == 1 ? 0 : 1);
+        });
         __syncthreads();
         if (INLDS) remain_by_jumping<NT, lcd_lds_u16p>(g, n, lds_u16(deg), lds_u16(nw));
         else remain_by_jumping<NT, unsigned short *>(g, n, (unsigned short *)g.pl_start, (unsigned short *)g.pl_rem);
@@ -597,20 +621,38 @@ __device__ __attribute__((noinline)) void topo_remain_block(Ctx &g, Smem &sm, in
     const bool inlds = (size_t)8 * n + 64 <= (size_t)g.pool_words * 4; // both (P, D) buffers in the workgroup's LDS pool (free between two reads)
     if (inlds) {
         const lcd_lds_u16p P0 = lds_u16(lds_pool), D0 = P0 + n;
-        for (int v = tid; v < n; v += NT) {
-            int mw = -1, mid = 1;
-            for (int e = g.out_head[v]; e >= 0; e = g.e_next_out[e]) { const int wt = g.e_w[e]; if (wt > mw) { mw = wt; mid = g.e_to[e]; } }
-            P0[v] = (unsigned short)mid; D0[v] = (unsigned short)(v == 1 ? 0 : 1);
-        }
+        struct HV { int mw, mid, more; };
+        batched_for<4, NT>(0, n, [&](const int v) { // (the first two out-edges straight-line: nearly every node has no more)
+            HV r; r.mw = -1; r.mid = 1;
+            const int e0 = g.out_head[v], c0 = e0 >= 0 ? e0 : 0;
+            const int t0 = g.e_w[c0], to0 = g.e_to[c0], e1 = e0 >= 0 ? g.e_next_out[c0] : -1, c1 = e1 >= 0 ? e1 : 0;
+            const int t1 = g.e_w[c1], to1 = g.e_to[c1];
+            if (e0 >= 0) { r.mw = t0; r.mid = to0; }
+            if (e1 >= 0 && t1 > r.mw) { r.mw = t1; r.mid = to1; }
+            r.more = e1 >= 0 ? g.e_next_out[c1] : -1;
+            return r;
+        }, [&](const int v, HV r) {
+            for (int e = r.more; e >= 0; e = g.e_next_out[e]) { const int wt = g.e_w[e]; if (wt > r.mw) { r.mw = wt; r.mid = g.e_to[e]; } }
+            P0[v] = (unsigned short)r.mid; D0[v] = (unsigned short)(v == 1 ? 0 : 1);
+        });
         __syncthreads();
         remain_by_jumping<NT, lcd_lds_u16p>(g, n, P0, P0 + 2 * n);
     } else {
         unsigned short *P0 = (unsigned short *)g.pl_start, *D0 = P0 + n;
-        for (int v = tid; v < n; v += NT) {
-            int mw = -1, mid = 1;
-            for (int e = g.out_head[v]; e >= 0; e = g.e_next_out[e]) { const int wt = g.e_w[e]; if (wt > mw) { mw = wt; mid = g.e_to[e]; } }
-            P0[v] = (unsigned short)mid; D0[v] = (unsigned short)(v == 1 ? 0 : 1);
-        }
+        struct HV { int mw, mid, more; };
+        batched_for<4, NT>(0, n, [&](const int v) { // (the first two out-edges straight-line: nearly every node has no more)
+            HV r; r.mw = -1; r.mid = 1;
+            const int e0 = g.out_head[v], c0 = e0 >= 0 ? e0 : 0;
+            const int t0 = g.e_w[c0], to0 = g.e_to[c0], e1 = e0 >= 0 ? g.e_next_out[c0] : -1, c1 = e1 >= 0 ? e1 : 0;
+            const int t1 = g.e_w[c1], to1 = g.e_to[c1];
+            if (e0 >= 0) { r.mw = t0; r.mid = to0; }
+            if (e1 >= 0 && t1 > r.mw) { r.mw = t1; r.mid = to1; }
+            r.more = e1 >= 0 ? g.e_next_out[c1] : -1;
+            return r;
+        }, [&](const int v, HV r) {
+            for (int e = r.more; e >= 0; e = g.e_next_out[e]) { const int wt = g.e_w[e]; if (wt > r.mw) { r.mw = wt; r.mid = g.e_to[e]; } }
+            P0[v] = (unsigned short)r.mid; D0[v] = (unsigned short)(v == 1 ? 0 : 1);
+        });
         __syncthreads();
         remain_by_jumping<NT, unsigned short *>(g, n, (unsigned short *)g.pl_start, (unsigned short *)g.pl_rem);
     }
@@ -742,45 +784,74 @@ __device__ void build_plan(Ctx &g, Smem &sm, const int bi, const int ei, const i
     }
     for (int e = tid; e < g.n_edge; e += NT) g.e_slot[e] = -1;
     __syncthreads();
+    // U rows per thread in flight (see batched_for): a row's chain is index -> node -> first in-edge -> its source -> that row's index -> its reachability, six
+    // dependent loads, and nearly every row has one or two in-edges -- those are taken straight-line for all U rows together and kept for the second pass
+    constexpr int U = 4;
     int carry = 0;
-    for (int base = bi; base <= ei; base += NT) {
-        const int idx = base + tid;
-        int cnt = 0, v = -1;
-        if (idx <= ei && g.imap[idx]) {
-            v = g.idx2node[idx];
-            for (int e = g.in_head[v]; e >= 0; e = g.e_next_in[e]) {
-                int pi = g.node2idx[g.e_from[e]];
-                cnt += (pi >= bi && pi < ei && g.imap[pi]);
+    for (int base = bi; base <= ei; base += U * NT) {
+        int v[U], cnt[U], rem[U], vbs[U], ih[U], n0[U], n1[U], p0[U], p1[U], w0[U], w1[U]; bool us0[U], us1[U];
+        {
+            int vv[U], im[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int idx = base + u * NT + tid, ci = idx <= ei ? idx : ei; im[u] = g.imap[ci]; vv[u] = g.idx2node[ci]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { ih[u] = g.in_head[vv[u]]; rem[u] = g.remain[vv[u]]; vbs[u] = g.base[vv[u]]; }
+            int f0[U], f1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int c = ih[u] >= 0 ? ih[u] : 0; f0[u] = g.e_from[c]; n0[u] = ih[u] >= 0 ? g.e_next_in[c] : -1; w0[u] = g.e_w[c]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int c = n0[u] >= 0 ? n0[u] : 0; p0[u] = g.node2idx[f0[u]]; f1[u] = g.e_from[c]; n1[u] = n0[u] >= 0 ? g.e_next_in[c] : -1; w1[u] = g.e_w[c]; }
+            int i0[U], i1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { p1[u] = g.node2idx[f1[u]]; i0[u] = g.imap[p0[u] >= 0 && p0[u] < n ? p0[u] : 0]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) i1[u] = g.imap[p1[u] >= 0 && p1[u] < n ? p1[u] : 0];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * NT + tid;
+                v[u] = (idx <= ei && im[u]) ? vv[u] : -1;
+                us0[u] = v[u] >= 0 && ih[u] >= 0 && p0[u] >= bi && p0[u] < ei && i0[u];
+                us1[u] = v[u] >= 0 && n0[u] >= 0 && p1[u] >= bi && p1[u] < ei && i1[u];
+                cnt[u] = (us0[u] ? 1 : 0) + (us1[u] ? 1 : 0);
+                if (v[u] >= 0) for (int e = n1[u]; e >= 0; e = g.e_next_in[e]) { const int pi = g.node2idx[g.e_from[e]]; cnt[u] += (pi >= bi && pi < ei && g.imap[pi]); }
             }
         }
-        const int incl = scan_add(cnt);
-        if (lane == 63) sm.scan[wave] = incl;
-        __syncthreads();
-        int woff = 0, tot = 0;
 #pragma unroll
-        for (int k = 0; k < NW; ++k) { const int t = sm.scan[k]; if (k < wave) woff += t; tot += t; }
-        const int start = carry + woff + incl - cnt;
-        if (idx <= ei) {
-            g.pl_start[idx] = start;
-            g.pl_rem[idx] = v >= 0 ? g.remain[v] - remain_end : (1 << 30); // 1<<30: row not reachable from beg
-            g.pl_base[idx] = v >= 0 ? g.base[v] : 4;
-            int first = 255;
-            if (v >= 0) {
-                int k = start;
-                for (int e = g.in_head[v]; e >= 0; e = g.e_next_in[e]) {
-                    int pi = g.node2idx[g.e_from[e]];
-                    if (pi >= bi && pi < ei && g.imap[pi]) {
-                        g.pl_pidx[k] = pi; g.pl_bonus[k] = ilog2_32(g.e_w[e]); g.e_slot[e] = k;
+        for (int u = 0; u < U; ++u) {
+            if (base + u * NT > ei) break; // (uniform)
+            const int idx = base + u * NT + tid;
+            const int incl = scan_add(cnt[u]);
+            if (lane == 63) sm.scan[wave] = incl;
+            __syncthreads();
+            int woff = 0, tot = 0;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) { const int t = sm.scan[k]; if (k < wave) woff += t; tot += t; }
+            const int start = carry + woff + incl - cnt[u];
+            if (idx <= ei) {
+                g.pl_start[idx] = start;
+                g.pl_rem[idx] = v[u] >= 0 ? rem[u] - remain_end : (1 << 30); // 1<<30: row not reachable from beg
+                g.pl_base[idx] = v[u] >= 0 ? vbs[u] : 4;
+                int first = 255;
+                if (v[u] >= 0) {
+                    int k = start;
+                    auto put = [&](const int e, const int pi, const int wt) {
+                        g.pl_pidx[k] = pi; g.pl_bonus[k] = ilog2_32(wt); g.e_slot[e] = k;
                         if (k == start && idx - pi < 255) first = idx - pi;
                         if (idx == ei || idx - pi > K) g.imap[pi] = 3; // same value from every writer
                         ++k;
+                    };
+                    if (us0[u]) put(ih[u], p0[u], w0[u]);
+                    if (us1[u]) put(n0[u], p1[u], w1[u]);
+                    for (int e = n1[u]; e >= 0; e = g.e_next_in[e]) {
+                        const int pi = g.node2idx[g.e_from[e]];
+                        if (pi >= bi && pi < ei && g.imap[pi]) put(e, pi, g.e_w[e]);
                     }
                 }
+                if (pd) pd[idx - bi] = (uint8_t)first;
             }
-            if (pd) pd[idx - bi] = (uint8_t)first;
+            carry += tot;
+            __syncthreads();
         }
-        carry += tot;
-        __syncthreads();
     }
     if (tid == 0) { g.pl_start[ei + 1] = carry; g.pl_start[ei + 2] = carry; g.pl_start[ei + 3] = carry; }
     __syncthreads();
