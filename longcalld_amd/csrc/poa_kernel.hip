@@ -79,6 +79,7 @@ struct Ctx {
     int cert_generic, cert_generic_seen, cert_sest, cert_ubtop; unsigned long long cert_cells0; // the read at hand goes through the generic rows over its intervals (align_certified)
     int *cert; int cert_on, cert_hist; // certified band of a K2 chain (align_certified): 7 x node_cap ints; largest bound-to-score slack of the chain's reads so far
     int wmax, seq_cap, pool_words, spill_x, ring_k, plan_k, solo;
+    int mm_valid;                      // g.deg / g.queue hold, by topological index, every row's smallest predecessor index / largest successor index (topo_sort_block; subgraph_nodes_wave0)
     int n_node, n_edge, node_cap, edge_cap, rid_words;
     unsigned long long cell_cap;
     int status;
@@ -580,13 +581,14 @@ __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned shor
 }
 
 template <int NT>
-__device__ __attribute__((noinline)) void topo_sort_block(Ctx &g, Smem &sm, int *lds_pool) {
+__device__ __attribute__((noinline)) void topo_sort_block(Ctx &g, Smem &sm, int *lds_pool, const int want_mm) {
     const int tid = threadIdx.x;
     const int n = g.n_node, E = g.n_edge;
     if (n >= 65535 || E >= 65535) { // ids do not fit 16 bits: plain serial walk on the graph arrays
         if (tid == 0) { topo_sort(g); sm.bc[6] = g.status; }
         __syncthreads();
         g.status = sm.bc[6];
+        g.mm_valid = 0;
         __syncthreads();
         return;
     }
@@ -598,6 +600,32 @@ __device__ __attribute__((noinline)) void topo_sort_block(Ctx &g, Smem &sm, int 
         topo_sort_arrays<NT, true>(g, sm, deg, queue, nw, ew);
     } else
         topo_sort_arrays<NT, false>(g, sm, (unsigned short *)g.deg, (unsigned short *)g.queue, (unsigned *)g.pl_bonus, (unsigned *)g.pl_pidx);
+    // every row's smallest predecessor index / largest successor index, for the sub-graph sweeps of the reads until the next re-sort (g.deg / g.queue are free now)
+    g.mm_valid = 0;
+    if (g.status == LCD_OK && want_mm) { // (K1 chains: only sub-graph alignments have sweeps)
+        struct MM { int mn, mx, ein, eout; };
+        batched_for<4, NT>(0, n, [&](const int idx) { // (the first two edges of either list straight-line: nearly every node has no more)
+            MM r; r.mn = 1 << 30; r.mx = -1;
+            const int v = g.idx2node[idx];
+            const int i0 = g.in_head[v], o0 = g.out_head[v], ci0 = i0 >= 0 ? i0 : 0, co0 = o0 >= 0 ? o0 : 0;
+            const int fi0 = g.e_from[ci0], i1 = i0 >= 0 ? g.e_next_in[ci0] : -1, to0 = g.e_to[co0], o1 = o0 >= 0 ? g.e_next_out[co0] : -1;
+            const int ci1 = i1 >= 0 ? i1 : 0, co1 = o1 >= 0 ? o1 : 0;
+            const int fi1 = g.e_from[ci1], to1 = g.e_to[co1];
+            const int a0 = g.node2idx[fi0], a1 = g.node2idx[fi1], b0 = g.node2idx[to0], b1 = g.node2idx[to1];
+            if (i0 >= 0) r.mn = a0;
+            if (i1 >= 0) r.mn = imin(r.mn, a1);
+            if (o0 >= 0) r.mx = b0;
+            if (o1 >= 0) r.mx = imax(r.mx, b1);
+            r.ein = i1 >= 0 ? g.e_next_in[ci1] : -1; r.eout = o1 >= 0 ? g.e_next_out[co1] : -1;
+            return r;
+        }, [&](const int idx, MM r) {
+            for (int e = r.ein; e >= 0; e = g.e_next_in[e]) r.mn = imin(r.mn, g.node2idx[g.e_from[e]]);
+            for (int e = r.eout; e >= 0; e = g.e_next_out[e]) r.mx = imax(r.mx, g.node2idx[g.e_to[e]]);
+            g.deg[idx] = r.mn; g.queue[idx] = r.mx;
+        });
+        g.mm_valid = 1;
+    }
+    __syncthreads();
 }
 
 // The read changed edge weights only (no new node, no new edge): the topological order stands; `remain` follows the heaviest out-edge
@@ -663,6 +691,41 @@ __device__ __attribute__((noinline)) void topo_remain_block(Ctx &g, Smem &sm, in
 __device__ void subgraph_nodes_wave0(Ctx &g, int lane, int inc_beg, int inc_end, int *exc_beg, int *exc_end) {
     const int bi = g.node2idx[inc_beg], ei = g.node2idx[inc_end];
     int b = bi, e = ei, up, down;
+    if (g.mm_valid) {
+        // the sweeps over the per-row extremes the last re-sort left behind (reads that only add weight change neither the order nor the edges): one coalesced load
+        // per row, four of them in flight, instead of a walk index -> node -> in-edges -> their sources -> those rows' indices per row and per read
+        const int *minp = g.deg, *maxs = g.queue;
+        auto sweep_min = [&](const int lo, const int hi, const int init) { // min over [lo, hi]
+            int m = init;
+            for (int i = lo + lane; i <= hi; i += 256) {
+                const int a0 = minp[i], a1 = minp[imin(i + 64, hi)], a2 = minp[imin(i + 128, hi)], a3 = minp[imin(i + 192, hi)];
+                m = imin(imin(m, a0), imin(imin(a1, a2), a3));
+            }
+            return wave_min(m);
+        };
+        auto sweep_max = [&](const int lo, const int hi, const int init) {
+            int m = init;
+            for (int i = lo + lane; i <= hi; i += 256) {
+                const int a0 = maxs[i], a1 = maxs[imin(i + 64, hi)], a2 = maxs[imin(i + 128, hi)], a3 = maxs[imin(i + 192, hi)];
+                m = imax(imax(m, a0), imax(imax(a1, a2), a3));
+            }
+            return wave_max(m);
+        };
+        for (;;) {
+            const int mn = sweep_min(b, e, b);
+            // (a row in (mn, b] with a predecessor before mn <=> the minimum over those rows is below mn)
+            if (mn + 1 > b || sweep_min(mn + 1, b, mn) >= mn) { up = mn; break; }
+            e = b; b = mn;
+        }
+        b = bi; e = ei;
+        for (;;) {
+            const int mx = sweep_max(b, e, e);
+            if (e > mx - 1 || sweep_max(e, mx - 1, mx) <= mx) { down = mx; break; }
+            b = e; e = mx;
+        }
+        *exc_beg = g.idx2node[up]; *exc_end = g.idx2node[down];
+        return;
+    }
     for (;;) {
         int mn = b;
         for (int i = b + lane; i <= e; i += 64)
@@ -933,6 +996,54 @@ __device__ __forceinline__ void code_backtrack(const Ctx &g, Smem &sm, const uns
                             alive = ok && d != 255;
                             if (!alive) break;
                             cur -= d;
+                        }
+                    }
+                    // A full 64-step stretch of backbone: look at the next three stretches of 64 in the same round trips (the loads of all four are issued together;
+                    // runs of matches of a clean read are hundreds of cells long, and every round of this loop is a chain metadata -> code -> node of dependent loads)
+                    if (nbb == 64 && sw == 64) {
+                        int ex = 0; // further steps along the backbone, a multiple of 64 lanes' worth or less
+                        int dd[3];
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) { const int ci = i - 64 * (u + 1) - lane; const bool okl = ci > bi && j - 64 * (u + 1) - lane > 0; dd[u] = okl ? lds_ld_u8(pd + (ci - bi)) : 255; }
+                        bool open = true;
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) {
+                            const unsigned long long one = __ballot(dd[u] == 1);
+                            const int c = one == ~0ull ? 64 : (int)__builtin_ctzll(~one);
+                            if (open) ex += c;
+                            open = open && c == 64;
+                        }
+                        // cells 0 .. 63 + ex: all of them step to the row before (the cell AFTER the last one is reached by row - 1 as well)
+                        int rbv[4], rev[4], rov[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int ci = imax(i - 64 * u - lane, bi); rbv[u] = glb_ld(g.rbeg + ci); rev[u] = glb_ld(g.rend + ci); rov[u] = glb_ld((const int *)g.roff + ci); }
+                        int cdv[4]; bool inr[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int jj = j - 64 * u - lane;
+                            inr[u] = 64 * u + lane < 64 + ex && jj >= rbv[u] && jj <= rev[u];
+                            cdv[u] = glb_ld_u8(g.code8 + ((size_t)(unsigned)rov[u] + (inr[u] ? jj - (rbv[u] & amask) : 0)));
+                        }
+                        int mtot = 0; open = true;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool good = inr[u] && (cdv[u] & (7 | CB_PM)) == 0;
+                            const unsigned long long bad = __ballot(!good);
+                            const int c = bad ? __ffsll((long long)bad) - 1 : 64;
+                            if (open) mtot += c;
+                            open = open && c == 64;
+                        }
+                        if (mtot > 0) {
+                            int nodev[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) nodev[u] = glb_ld(g.idx2node + imax(i - 64 * u - lane, bi));
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int st_ = 64 * u + lane;
+                                if (st_ < mtot) { g.cig_node0[pos - 1 - st_] = nodev[u]; g.cig_qpos0[pos - 1 - st_] = j - st_ - 1; }
+                            }
+                            i -= mtot; pos -= mtot; j -= mtot;
+                            continue;
                         }
                     }
                     bool good = false;
@@ -3991,7 +4102,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = ch.cert == 2 ? 2 : NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0; g.cert_generic = 0; g.cert_generic_seen = 0; g.cert_sest = 0; g.cert_ubtop = 0; g.cert_cells0 = 0;
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
     g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - ring_k * 3 * ring_cols) * 4; g.ring_k = ring_k; g.plan_k = (NT == 64 || ch.solo) && ring_k > 2 && ch.wmax < 256 ? 2 : ring_k; // (slots beyond 2 of a chain laid out for a narrow window: not there when a read needs a wider one)
-    g.solo = NT == 256 ? ch.solo : 0; g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0; g.t_bp = 0; g.t_setup = 0;
+    g.mm_valid = 0; g.solo = NT == 256 ? ch.solo : 0; g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0; g.t_bp = 0; g.t_setup = 0;
     const long long t_begin = clock64();
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
     unsigned long long t_graph = 0, t_sub = 0, t_add = 0;
@@ -4039,7 +4150,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
         if (len > 0 && g.status == LCD_OK) changed = add_alignment_block<NT>(g, sm, exc_beg, exc_end, seq, len, n_cig, i);
         t_add += (unsigned long long)(clock64() - tg0);
         if (changed == 1 || changed == 2) g.plan_valid = 0; // (3: weights only, every heaviest out-edge the same -- order, remain and the plan's structure stand; its bonuses were patched)
-        if (changed == 2 && g.status == LCD_OK) topo_sort_block<NT>(g, sm, lds_pool);
+        if (changed == 2 && g.status == LCD_OK) topo_sort_block<NT>(g, sm, lds_pool, ch.mode == 0);
         else if (changed == 1 && g.status == LCD_OK) topo_remain_block<NT>(g, sm, lds_pool);
         t_graph += (unsigned long long)(clock64() - tg0);
     }
