@@ -150,6 +150,33 @@ __device__ __forceinline__ void scan_max2(int &a, int &b) {
         "s_nop 1"
         : "+v"(a), "+v"(b));
 }
+// three inclusive prefix-max scans interleaved: each chain's next DPP read is two instructions behind its write, which is the wait a DPP operand needs -- no s_nop
+// inside.  (The third chain is the adaptive band's row maximum: H = max(Hpre, F) and F[j] <= Hpre[k] - (o + e) for some k < j, so the row's maximum and the columns
+// that reach it are those of Hpre -- known before the F scan, not after it.)
+__device__ __forceinline__ void scan_max3(int &a, int &b, int &c) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_max_i32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_max_i32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(a), "+v"(b), "+v"(c));
+}
 __device__ __forceinline__ int shr1(int identity, int v) { return dpp_take<0x138, 0xf>(identity, v); } // wave_shr:1
 __device__ __forceinline__ int lane63(int v) { return __builtin_amdgcn_readlane(v, 63); }
 
@@ -1513,6 +1540,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     const int o1 = usgpr(sc_.o1), e1 = usgpr(sc_.e1), o2 = usgpr(sc_.o2), e2 = usgpr(sc_.e2), oe1 = o1 + e1, oe2 = o2 + e2;
     const int lane = threadIdx.x & 63;
     if (qlen >= 65535) return -1; // (beg | end << 16 words)
+    if (BANDED && (oe1 <= 0 || oe2 <= 0 || e1 < 0 || e2 < 0)) return -1; // (the row maximum is taken from Hpre: a horizontal gap must cost something)
     const int QB = (qlen + 12 + 15) & ~15;
     {
         // the pool of a single-wavefront chain is laid out for the window the host expects (PoaChain.wmax columns per ring slot); a wider window moves the
@@ -1654,7 +1682,29 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                     p1[k] = k ? imax(p1[k - 1], a1[k]) : a1[k]; p2[k] = k ? imax(p2[k - 1], a2[k]) : a2[k];
                 }
                 int t1 = p1[C - 1], t2 = p2[C - 1];
-                scan_max2(t1, t2);
+                int ml = 0, mr = 0;
+                if (BANDED) { // the row maximum and its leftmost / rightmost column, from Hpre (see scan_max3), in the same scan as the gap prefixes
+                    int hm_[C];
+#pragma unroll
+                    for (int k = 0; k < C; ++k) hm_[k] = inb[k] ? hp[k] : LCD_GUARD;
+                    int hb = hm_[0];
+#pragma unroll
+                    for (int k = 1; k < C; ++k) hb = imax(hb, hm_[k]);
+                    int hbs = hb;
+                    scan_max3(t1, t2, hbs);
+                    const int wm = lane63(hbs);
+                    const unsigned long long mk = __ballot(hb == wm); // (the row is not empty: its in-band cells are >= LCD_NEG > the filler)
+                    const int fl = usgpr((int)__builtin_ctzll(mk)), ll = usgpr(63 - (int)__builtin_clzll(mk));
+                    if (C == 1) { ml = begc + fl; mr = begc + ll; }
+                    else {
+                        int bl = C - 1, brr = 0;
+#pragma unroll
+                        for (int k = C - 2; k >= 0; --k) bl = hm_[k] == hb ? k : bl;
+#pragma unroll
+                        for (int k = 1; k < C; ++k) brr = hm_[k] == hb ? k : brr;
+                        ml = begc + C * fl + LCD_RL(bl, fl); mr = begc + C * ll + LCD_RL(brr, ll);
+                    }
+                } else scan_max2(t1, t2);
                 const int x1 = shr1(LCD_GUARD, t1), x2 = shr1(LCD_GUARD, t2);
                 word code = 0;
 #pragma unroll
@@ -1670,24 +1720,6 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                     { const int r2 = a2[k], r1 = a1[k]; LCD_PUSH_GE(fl, q2, w2); LCD_PUSH_GE(fl, q1, w1); LCD_PUSH_GT(fl, pf2, r2); LCD_PUSH_GT(fl, pf1, r1); }
                     code |= (word)((unsigned)hs | (fl << 3)) << (8 * k);
                     pvh[k] = inb[k] ? h : LCD_GUARD; pva[k] = inb[k] ? eo1 : LCD_GUARD; pvb[k] = inb[k] ? eo2 : LCD_GUARD;
-                }
-                int ml = 0, mr = 0;
-                if (BANDED) {
-                    int hb = pvh[0];
-#pragma unroll
-                    for (int k = 1; k < C; ++k) hb = imax(hb, pvh[k]);
-                    const int wm = lane63(scan_max(hb));
-                    const unsigned long long mk = __ballot(hb == wm); // (the row is not empty: its in-band cells are >= LCD_NEG > the filler)
-                    const int fl = usgpr((int)__builtin_ctzll(mk)), ll = usgpr(63 - (int)__builtin_clzll(mk));
-                    if (C == 1) { ml = begc + fl; mr = begc + ll; }
-                    else {
-                        int bl = C - 1, brr = 0;
-#pragma unroll
-                        for (int k = C - 2; k >= 0; --k) bl = pvh[k] == hb ? k : bl;
-#pragma unroll
-                        for (int k = 1; k < C; ++k) brr = pvh[k] == hb ? k : brr;
-                        ml = begc + C * fl + LCD_RL(bl, fl); mr = begc + C * ll + LCD_RL(brr, ll);
-                    }
                 }
                 {
                     const int x = (begc + cl) & WM;
