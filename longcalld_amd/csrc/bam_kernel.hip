@@ -64,12 +64,15 @@ __global__ void __launch_bounds__(64) lcd_bam_stat_kernel(const BamStatJob *jobs
     const uint8_t *r = (const uint8_t *)(uintptr_t)j.rec;
     const uint8_t *cg = r + 32 + j.lname;
     int nc = j.nc, kind = 0;
-    if (nc == 2 && j.lseq > 0) {
-        const unsigned c0 = ld32u(cg), c1 = ld32u(cg + 4);
-        if ((c0 & 0xf) == 4 && (int)(c0 >> 4) == j.lseq && (c1 & 0xf) == 3) { // the placeholder: the real operations are in the CG:B,I tag (htslib's bam_read1 swaps them in)
+    // htslib's bam_tag2cigar (behind the reference's sam_itr_next): a record with a reference and a position whose FIRST operation is `<l_seq>S` may carry its real
+    // operations in a CG:B,I (or B,i) tag with at least n_cigar and fewer than 2^29 entries; anything else -- no tag, another type, a shorter array, a broken
+    // auxiliary field -- leaves the record's own CIGAR in place, silently
+    if (nc >= 1 && (int)ld32u(r) >= 0 && (int)ld32u(r + 4) >= 0) {
+        const unsigned c0 = ld32u(cg);
+        if ((c0 & 0xf) == 4 && (int)(c0 >> 4) == j.lseq) {
             unsigned long long found = 0; unsigned cnt_found = 0;
             if (lane == 0) { // the auxiliary fields, one after the other
-                const uint8_t *aux = cg + 8 + ((size_t)j.lseq + 1) / 2 + (size_t)j.lseq, *end = r + j.bs;
+                const uint8_t *aux = cg + 4 * (size_t)nc + ((size_t)j.lseq + 1) / 2 + (size_t)j.lseq, *end = r + j.bs;
                 while (aux + 3 <= end) {
                     const uint8_t t0 = aux[0], t1 = aux[1], ty = aux[2]; aux += 3;
                     size_t sz = 0; bool bad = false;
@@ -83,18 +86,18 @@ __global__ void __launch_bounds__(64) lcd_bam_stat_kernel(const BamStatJob *jobs
                             const uint8_t sub = aux[0]; const unsigned cnt = ld32u(aux + 1);
                             const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : 0;
                             if (!es || (size_t)(end - (aux + 5)) < (size_t)cnt * es) bad = true;
-                            else if (t0 == 'C' && t1 == 'G' && sub == 'I') { found = (unsigned long long)(uintptr_t)(aux + 5); cnt_found = cnt; break; }
+                            else if (t0 == 'C' && t1 == 'G') { if ((sub == 'I' || sub == 'i') && cnt >= (unsigned)nc && cnt < (1u << 29)) { found = (unsigned long long)(uintptr_t)(aux + 5); cnt_found = cnt; } break; } // (bam_aux_get: the first CG tag decides)
                             else sz = 5 + (size_t)cnt * es;
                         }
                     } else bad = true;
+                    if (t0 == 'C' && t1 == 'G') break; // a CG tag of another type: not a CIGAR
                     if (bad || (size_t)(end - aux) < sz) break;
                     aux += sz;
                 }
             }
             found = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(found >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)found);
             cnt_found = (unsigned)__builtin_amdgcn_readfirstlane((int)cnt_found);
-            if (!found || cnt_found == 0) kind = -2; // a placeholder without its tag
-            else { kind = 1; cg = (const uint8_t *)(uintptr_t)found; nc = (int)cnt_found; }
+            if (found) { kind = 1; cg = (const uint8_t *)(uintptr_t)found; nc = (int)cnt_found; }
         }
     }
     long long rl = 0, nd = 0, nev = 0, nid = 0;

@@ -77,11 +77,14 @@ struct BitIn {
     int widx;              // next dword of `cur` to take (0..64)
     unsigned long long bb; // bit buffer (uniform)
     int bc;                // valid bits in bb
+    const unsigned *lim;   // no window of the stream starts at or behind this address: the job's compressed bytes (+ the gzip trailer) end before it
+    int over;              // the stream asked for one: a truncated or crafted block (the decode stops with a status; nothing is read beyond lim + 512 bytes)
 };
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ unsigned bi_word(BitIn &s, const int lane) { // the stream's next aligned dword
     if (s.widx == 64) {
-        s.base = sgpr(s.base + 64); s.cur = s.nxt; s.nxt = __builtin_nontemporal_load(s.base + 64 + lane); s.widx = 0;
+        if (s.base + 64 >= s.lim) { s.over = 1; s.widx = 0; } // (the window is kept: whatever is decoded from here on is discarded with the error)
+        else { s.base = sgpr(s.base + 64); s.cur = s.nxt; s.nxt = __builtin_nontemporal_load(s.base + 64 + lane); s.widx = 0; }
     }
     const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)s.cur, sgpr(s.widx));
     s.widx = sgpr(s.widx + 1);
@@ -230,6 +233,8 @@ __global__ void __launch_bounds__(64) lcd_inflate_kernel(const InflateJob *jobs,
     const unsigned lane_l = lane < 29 ? (unsigned)c_lbase[lane] | ((unsigned)c_lext[lane] << 16) : 0u;
     const unsigned lane_d = lane < 30 ? (unsigned)c_dbase[lane] | ((unsigned)c_dext[lane] << 16) : 0u;
     BitIn s;
+    const unsigned clen = sgpr(job.clen);
+    s.lim = sgpr((const unsigned *)((((uintptr_t)src + clen + 8) + 255) & ~(uintptr_t)255)); s.over = 0;
     bi_start(s, src, lane);
     int pos = 0, flushed = 0, status = 0;
     bool last = false;
@@ -241,11 +246,13 @@ __global__ void __launch_bounds__(64) lcd_inflate_kernel(const InflateJob *jobs,
         const int type = (int)bi_take(s, 2);
         if (type == 0) { // stored
             const uint8_t *p = bi_byte_pos(s);
+            if (s.over || p + 4 > src + clen) { status = 14; break; }
             // LEN / NLEN straight from the stream (the bytes may straddle the windows: byte loads, uniform address)
             const unsigned len = sgpr((unsigned)(p[0] | (p[1] << 8))), nlen = sgpr((unsigned)(p[2] | (p[3] << 8))); // (loads are per-lane values to the compiler: everything the loop's control depends on is made uniform explicitly)
             if ((len ^ nlen) != 0xffffu) { status = 2; break; }
             if (pos + (int)len > ulen) { status = 3; break; }
             p += 4;
+            if (p + len > src + clen) { status = 14; break; } // the stored bytes would come from behind the block
             for (int done = 0; done < (int)len;) {
                 const int room = imin((int)len - done, HALF - (pos & (HALF - 1)));
                 for (int k = lane; k < room; k += 64) win[(pos + k) & WINM] = p[done + k];
@@ -313,6 +320,7 @@ __global__ void __launch_bounds__(64) lcd_inflate_kernel(const InflateJob *jobs,
         // ---- the block's symbols ----
         for (;;) {
             ++n_sym;
+            if (s.over) { status = 14; break; }
             bi_fill(s, lane);
             unsigned e = sgpr((unsigned)ltab[s.bb & ((1u << LBITS) - 1)]);
             int sym;
@@ -364,6 +372,7 @@ __global__ void __launch_bounds__(64) lcd_inflate_kernel(const InflateJob *jobs,
             }
         }
     }
+    if (status == 0 && (s.over || bi_byte_pos(s) > src + clen)) status = 14; // the stream ran over the end of the block's compressed bytes (input side of a truncated / crafted block)
     if (status == 0 && pos != ulen) status = 12;
     if (status == 0) { __builtin_amdgcn_s_waitcnt(0xc07f); flush_half(lds, out, flushed, pos - flushed, lane); }
     unsigned crc = 0;

@@ -433,6 +433,7 @@ int lcd_init(int device) { // the process default device (bench.py: LOCAL_RANK);
 }
 long long lcd_alloc_events(void) { return g_alloc_events.load(); }
 void lcd_copy_counters(unsigned long long out[4]) { for (int i = 0; i < 4; ++i) out[i] = g_copy_bytes[i].load(); }
+void lcd_account_device_bytes(int device, long long delta) { if (device >= 0 && device < LCD_MAX_DEV) g_dev_bytes[device] += delta; } // (buffers allocated outside DevBuf: lcd_io.cpp's inflated streams)
 long long lcd_device_bytes(int device) { return device >= 0 && device < LCD_MAX_DEV ? g_dev_bytes[device].load() : 0; }
 int lcd_device_count(void) { return init_default_device() ? 0 : g_n_devices; }
 int lcd_set_thread_device(int device) {
@@ -3026,8 +3027,8 @@ lcd_chunk_t *lcd_chunk_create_from_bam(const lcd_digar_opt_t *opt, const char *b
     const int rc = digar_batch_core(opt, n, pos0.data(), W, nullptr, qoff.data(), qlen.data(), nullptr, reg_beg, reg_end, im.tlen, &doff, &dg, &c->iv_off, &c->ivs, &c->iv_in_chunk,
                                     c->status.data(), c->beg.data(), c->end.data(), c->n_cand.data(), st, &keep);
     free(doff);
-    if (rc) return nullptr;
-    CHK(hipStreamSynchronize(st));
+    if (rc) { if (meta) { lcd_bam_reads_free(meta); memset(meta, 0, sizeof(*meta)); } return nullptr; } // (the caller's arrays were handed out above)
+    if (hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); if (meta) { lcd_bam_reads_free(meta); memset(meta, 0, sizeof(*meta)); } return fail(-10, "HIP call failed: hipStreamSynchronize"); }
 #undef CHK
     c->slot.swap(keep.slot); c->n_digar.swap(keep.n_digar);
     return c.release();

@@ -43,6 +43,7 @@ int bgzf_blocks(const Bytes f, std::vector<Blk> &blks, size_t *total) {
     while (o + 18 <= f.size()) {
         if (f[o] != 31 || f[o + 1] != 139 || f[o + 2] != 8 || !(f[o + 3] & 4)) return io_err(-31, "not a BGZF block");
         const unsigned xlen = f[o + 10] | (f[o + 11] << 8);
+        if (o + 12 + (size_t)xlen + 8 > f.size()) return io_err(-31, "BGZF block: extra field runs past the end of the file");
         size_t x = o + 12; unsigned bsize = 0; bool found = false;
         while (x + 4 <= o + 12 + xlen) {
             const unsigned slen = f[x + 2] | (f[x + 3] << 8);
@@ -51,6 +52,7 @@ int bgzf_blocks(const Bytes f, std::vector<Blk> &blks, size_t *total) {
         }
         if (!found || o + bsize + 1 > f.size()) return io_err(-31, "BGZF block without BSIZE / truncated file");
         const size_t end = o + bsize + 1;
+        if (end < o + 12 + (size_t)xlen + 8) return io_err(-31, "malformed BGZF block: BSIZE smaller than header + trailer"); // (before any f[end - k] is read: a hostile BSIZE must not index in front of the block)
         const unsigned isize = f[end - 4] | (f[end - 3] << 8) | (f[end - 2] << 16) | ((unsigned)f[end - 1] << 24);
         Blk b; b.cdata = o + 12 + xlen; b.clen = end - 8 - b.cdata; b.uoff = u; b.ulen = isize;
         b.crc = f[end - 8] | (f[end - 7] << 8) | (f[end - 6] << 16) | ((uint32_t)f[end - 5] << 24);
@@ -98,10 +100,11 @@ struct Collector {
     Collector(int t, int64_t b, int64_t e, int mq) : tid(t), reg_beg(b), reg_end(e), min_mapq(mq) {}
     // the real CIGAR of a read with more than 65 535 operations (ultra-long ONT reads): BAM keeps the placeholder `<l_seq>S<ref_len>N` in the 16-bit field and the
     // operations in the CG:B,I tag; htslib's bam_read1 (behind the reference's sam_itr_next) swaps them in.  Returns the tag's operations, or nullptr.
-    static const uint8_t *cg_tag(const uint8_t *aux, const uint8_t *end, uint32_t *n) {
+    static const uint8_t *cg_tag(const uint8_t *aux, const uint8_t *end, uint32_t *n, const uint32_t n_cigar) {
         while (aux + 3 <= end) {
             const uint8_t t0 = aux[0], t1 = aux[1], ty = aux[2]; aux += 3;
             size_t sz;
+            if (t0 == 'C' && t1 == 'G' && ty != 'B') return nullptr; // (bam_aux_get: the first CG tag decides; another type is not a CIGAR)
             switch (ty) {
                 case 'A': case 'c': case 'C': sz = 1; break;
                 case 's': case 'S': sz = 2; break;
@@ -112,7 +115,7 @@ struct Collector {
                     const uint8_t sub = aux[0]; const uint32_t cnt = (uint32_t)le32(aux + 1);
                     const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : 0;
                     if (!es || (size_t)(end - (aux + 5)) < (size_t)cnt * es) return nullptr;
-                    if (t0 == 'C' && t1 == 'G' && sub == 'I') { *n = cnt; return aux + 5; }
+                    if (t0 == 'C' && t1 == 'G') { if ((sub == 'I' || sub == 'i') && cnt >= n_cigar && cnt < (1u << 29)) { *n = cnt; return aux + 5; } return nullptr; }
                     sz = 5 + (size_t)cnt * es; break;
                 }
                 default: return nullptr;
@@ -131,13 +134,14 @@ struct Collector {
         if (refid != tid) return (refid > tid || refid < 0) && !pos0.empty() ? -1 : 0;
         const uint8_t *cg = r + 32 + lname;
         const uint8_t *const sq = cg + 4 * (size_t)nc, *const ql = sq + (lseq + 1) / 2;
-        if (nc == 2 && lseq > 0) { // `<l_seq>S<n>N`: the placeholder of a CIGAR that did not fit 16 bits
-            const uint32_t c0 = (uint32_t)le32(cg), c1 = (uint32_t)le32(cg + 4);
-            if ((c0 & 0xf) == 4 && (int)(c0 >> 4) == lseq && (c1 & 0xf) == 3) {
+        // htslib's bam_tag2cigar: a mapped record whose first operation is `<l_seq>S` takes its operations from a CG:B,I / B,i tag with >= n_cigar (and < 2^29)
+        // entries; without such a tag the record keeps its own CIGAR (no error: htslib returns 0 and goes on)
+        if (nc >= 1 && refid >= 0 && p >= 0) {
+            const uint32_t c0 = (uint32_t)le32(cg);
+            if ((c0 & 0xf) == 4 && (int)(c0 >> 4) == lseq) {
                 uint32_t n = 0;
-                const uint8_t *real = cg_tag(ql + lseq, r + bs, &n);
-                if (!real || n == 0) return -2;
-                cg = real; nc = (int)n;
+                const uint8_t *real = cg_tag(ql + lseq, r + bs, &n, (uint32_t)nc);
+                if (real) { cg = real; nc = (int)n; }
             }
         }
         int64_t rl = 0;
@@ -476,7 +480,9 @@ void lcd_inflate_set_x2n(const unsigned *t32, hipStream_t st);
 namespace {
 unsigned gf2_mulmod_h(unsigned a, unsigned b) { unsigned m = 1u << 31, p = 0; for (;;) { if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; } m >>= 1; b = (b & 1) ? (b >> 1) ^ 0xedb88320u : b >> 1; } return p; }
 }
-struct lcd_inflated_s { void *d_in = nullptr, *d_out = nullptr, *d_jobs = nullptr, *d_outs = nullptr; size_t total = 0, n_blocks = 0, comp_bytes = 0; double ms_kernel = 0, ms_h2d = 0; };
+struct lcd_inflated_s { void *d_in = nullptr, *d_out = nullptr, *d_jobs = nullptr, *d_outs = nullptr; size_t total = 0, n_blocks = 0, comp_bytes = 0; double ms_kernel = 0, ms_h2d = 0;
+                        long long accounted = 0; int device = 0; hipStream_t st = nullptr; hipEvent_t ev[3] = {nullptr, nullptr, nullptr}; };
+extern "C" void lcd_account_device_bytes(int device, long long delta); // lcd_host.cpp: the library's device-memory ledger (LCD_MEM_FRACTION planning sees an inflated stream too)
 extern "C" {
 #define IOHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { io_err(-40, std::string("HIP: ") + hipGetErrorString(e_) + " in " #x); lcd_inflated_free(h); return nullptr; } } while (0)
 void lcd_inflated_free(lcd_inflated_t *h) {
@@ -485,6 +491,9 @@ void lcd_inflated_free(lcd_inflated_t *h) {
     if (h->d_out) (void)hipFree(h->d_out);
     if (h->d_jobs) (void)hipFree(h->d_jobs);
     if (h->d_outs) (void)hipFree(h->d_outs);
+    for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->st) (void)hipStreamDestroy(h->st);
+    if (h->accounted) lcd_account_device_bytes(h->device, -h->accounted);
     delete h;
 }
 lcd_inflated_t *lcd_bgzf_inflate_dev(const uint8_t *file, size_t n, int verify_crc) {
@@ -495,11 +504,15 @@ lcd_inflated_t *lcd_bgzf_inflate_dev(const uint8_t *file, size_t n, int verify_c
     if (bgzf_blocks(Bytes{file, n}, blks, &total)) { delete h; return nullptr; }
     h->total = total; h->n_blocks = blks.size(); h->comp_bytes = n;
     if (blks.empty()) return h;
-    IOHIP(hipMalloc(&h->d_in, n + 1024));            // (the decoder's 256-byte input windows read ahead of the stream)
+    (void)hipGetDevice(&h->device);
+    IOHIP(hipMalloc(&h->d_in, n + 1024));            // (the decoder's 256-byte input windows read ahead of the stream: at most 512 bytes behind a block's end, inflate_kernel.hip BitIn::lim)
     IOHIP(hipMalloc(&h->d_out, total + 64));
     IOHIP(hipMalloc(&h->d_jobs, blks.size() * sizeof(InflateJobH)));
     IOHIP(hipMalloc(&h->d_outs, blks.size() * sizeof(InflateOutH)));
-    hipStream_t st = nullptr; hipEvent_t ev[3];
+    h->accounted = (long long)(n + 1024 + total + 64 + blks.size() * (sizeof(InflateJobH) + sizeof(InflateOutH)));
+    lcd_account_device_bytes(h->device, h->accounted);
+    IOHIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking)); // (not the NULL stream: that one serialises with every blocking stream of the device)
+    hipStream_t st = h->st; hipEvent_t (&ev)[3] = h->ev;
     for (auto &e : ev) IOHIP(hipEventCreate(&e));
     { // x^(2^k) mod P for the CRC combination: x^1 = 1 << 30 in the reflected representation, then squares
         unsigned t[32]; unsigned p = 1u << 30; t[0] = p;
@@ -521,10 +534,11 @@ lcd_inflated_t *lcd_bgzf_inflate_dev(const uint8_t *file, size_t n, int verify_c
     IOHIP(hipGetLastError());
     IOHIP(hipEventRecord(ev[2], st));
     std::vector<InflateOutH> outs(blks.size());
-    IOHIP(hipMemcpy(outs.data(), h->d_outs, outs.size() * sizeof(InflateOutH), hipMemcpyDeviceToHost));
+    IOHIP(hipMemcpyAsync(outs.data(), h->d_outs, outs.size() * sizeof(InflateOutH), hipMemcpyDeviceToHost, st));
+    IOHIP(hipStreamSynchronize(st));
     float a = 0, b = 0; (void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]);
     h->ms_h2d = a; h->ms_kernel = b;
-    for (auto &e : ev) (void)hipEventDestroy(e);
+    for (auto &e : ev) { (void)hipEventDestroy(e); e = nullptr; }
     if (timers) {
         unsigned long long tt = 0, tb = 0, tf = 0, tm = 0, ns = 0;
         for (const InflateOutH &o : outs) { tt += o.t_total; tb += o.t_tables; tf += o.t_flush; tm += o.t_match; ns += o.n_sym; }
@@ -533,8 +547,9 @@ lcd_inflated_t *lcd_bgzf_inflate_dev(const uint8_t *file, size_t n, int verify_c
     }
     for (size_t i = 0; i < outs.size(); ++i) if (outs[i].status != 0) {
         static const char *why[] = {"ok", "?", "stored block: LEN / NLEN mismatch", "more output than ISIZE", "reserved block type", "too many codes", "bad code lengths", "no end-of-block code",
-                                    "over-subscribed code", "invalid code", "invalid symbol", "distance before the start of the block", "fewer bytes than ISIZE", "CRC-32 mismatch"};
-        io_err(-32, "device inflate failed on BGZF block " + std::to_string(i) + ": " + (outs[i].status < 14 ? why[outs[i].status] : "?"));
+                                    "over-subscribed code", "invalid code", "invalid symbol", "distance before the start of the block", "fewer bytes than ISIZE", "CRC-32 mismatch",
+                                    "the deflate stream runs past the block's compressed bytes (truncated or crafted block)"};
+        io_err(-32, "device inflate failed on BGZF block " + std::to_string(i) + ": " + (outs[i].status < 15 ? why[outs[i].status] : "?"));
         lcd_inflated_free(h); return nullptr;
     }
     return h;

@@ -202,9 +202,15 @@ def test_cg_tag_cigars_and_malformed_records_on_the_device(lcd, io, tmp_path):
     ref = _same_chunk(lcd, dev, h, 1, 2000000, 2000000)
     assert dev.meta["n_cigar"][0] == n_ops and dev.meta["end_pos"][0] == 5000 + rl
     ref.close(); dev.close()
-    write([head + b"NMi" + struct.pack("<i", 3)])
-    with pytest.raises(RuntimeError, match="malformed"):
-        lcd.DeviceChunk.from_bam(path, path + ".bai", "chr11", 1, 2000000)
+    # htslib's bam_tag2cigar: B,i counts as well; no tag / another type / a shorter array leave the record's own (placeholder) CIGAR in place -- same as the host loader
+    for tail, want in ((b"CGBi" + struct.pack("<i", n_ops) + ops.tobytes(), n_ops), (b"NMi" + struct.pack("<i", 3), 2), (b"CGZnot-a-cigar\0", 2),
+                       (b"CGBI" + struct.pack("<i", 1) + ops[:1].tobytes(), 2)):
+        write([head + tail])
+        h = _host_reads(io, path, "chr11", 1, 2000000, 30)
+        assert h["n"] == 1 and len(h["cig"][0]) == want
+        dev = lcd.DeviceChunk.from_bam(path, path + ".bai", "chr11", 1, 2000000, min_mapq=30)
+        assert dev.meta["n_cigar"][0] == want and dev.meta["end_pos"][0] == 5000 + rl
+        dev.close()
     short = struct.pack("<iiBBHHHiiii", 0, 5000, len(name), 60, 4680, 1, 0, 100000, -1, -1, 0) + name + struct.pack("<I", (100000 << 4) | 7) + b"\x11" * 50
     write([short])
     with pytest.raises(RuntimeError, match="malformed"):

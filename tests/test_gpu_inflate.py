@@ -128,6 +128,35 @@ def test_container_checks(lib):
     assert _inflate(lib, good[:len(good) // 2]) is None
 
 
+def test_truncated_and_crafted_blocks_stop_at_the_blocks_own_bytes(lib):
+    """input side of the decoder: a block whose deflate stream is cut short -- with the header's BSIZE and the trailer's ISIZE still claiming the whole
+    block -- must end with an error, with and without the CRC check, instead of decoding on into the bytes behind it; a stored block whose LEN reaches behind the
+    block likewise.  (The decoder's input windows never start behind the block's last byte + 8: inflate_kernel.hip BitIn::lim.)"""
+    rng = np.random.default_rng(9)
+    data = bytes(rng.integers(0, 256, 40000).astype(np.uint8))             # incompressible: the stream is about as long as the data
+    whole = _member(data)
+    comp = whole[18:-8]
+    for cut in (1, 7, 300, len(comp) // 2):
+        short = comp[:-cut]
+        m = (struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(short) + 25) + short + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
+        # behind it: another member whose bytes would happily decode as more symbols
+        for verify in (0, 1):
+            assert _inflate(lib, m + _member(data[:5000]) + EOF_BLOCK, verify) is None, (cut, verify)
+    # a stored block whose LEN runs past the member: 1 (final, stored) + LEN 60000 / NLEN, with 100 bytes present
+    stored = b"\x01" + struct.pack("<HH", 60000, 60000 ^ 0xffff) + b"x" * 100
+    m = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(stored) + 25) + stored + struct.pack("<II", 0, 60000)
+    assert _inflate(lib, m + _member(data) + _member(data) + EOF_BLOCK, 0) is None and b"past the block" in lib.lcd_io_last_error()
+    # the 1-bit-code worst case of the review: a block of 65 280 equal bytes is ~80 bytes of stream; cut to 20 it still claims ISIZE 65 280
+    run = _member(b"\x07" * 65280)
+    short = run[18:-8][:20]
+    m = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(short) + 25) + short + struct.pack("<II", zlib.crc32(b"\x07" * 65280) & 0xffffffff, 65280)
+    for verify in (0, 1):
+        assert _inflate(lib, m + EOF_BLOCK, verify) is None
+    # hostile container: BSIZE smaller than header + trailer
+    bad = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, 5) + b"\0" * 40
+    assert _inflate(lib, bad) is None and b"BSIZE" in lib.lcd_io_last_error()
+
+
 def test_a_bam_file_image_round_trip(lib, tmp_path):
     """the BAM the host loader's tests write (tests/test_io.py): the device's inflated stream == gzip's, i.e. exactly the bytes the record walk reads"""
     import gzip

@@ -183,7 +183,7 @@ def _one_record_bam(path, body_of):
 def test_long_cigar_in_cg_tag_and_malformed_records(lib, tmp_path):
     """a read with more than 65 535 CIGAR operations keeps `<l_seq>S<ref_len>N` in the record and the operations in CG:B,I (SAM specification 4.2.2); htslib's
     bam_read1, behind the reference's sam_itr_next (src/bam_utils.c:1672), puts the real CIGAR back -- so does the loader.  A record whose fields run past its
-    block_size, or a placeholder without the tag, is an error and not an out-of-bounds read."""
+    block_size is an error and not an out-of-bounds read; a placeholder without a usable tag keeps its own two operations, as in htslib's bam_tag2cigar."""
     rng = np.random.default_rng(5)
     n_ops = 70001
     ops = np.empty(n_ops, "<u4")
@@ -205,13 +205,32 @@ def test_long_cigar_in_cg_tag_and_malformed_records(lib, tmp_path):
     got = np.ctypeslib.as_array(r.cigar_pool, shape=(n_ops,))
     assert (got == ops).all()
     lib.lcd_bam_reads_free(C.byref(r))
-    # the placeholder without its tag
-    _one_record_bam(path, [head + b"NMi" + struct.pack("<i", 3)])
-    assert lib.lcd_bam_load_region(path.encode(), b"chr11", 1, 2000000, 30, 1, C.byref(r)) < 0 and b"malformed" in lib.lcd_io_last_error()
+    # htslib's bam_tag2cigar: B,i is accepted like B,I
+    _one_record_bam(path, [head + b"CGBi" + struct.pack("<i", n_ops) + ops.tobytes()])
+    assert lib.lcd_bam_load_region(path.encode(), b"chr11", 1, 2000000, 30, 1, C.byref(r)) == 1 and r.n_cigar[0] == n_ops
+    lib.lcd_bam_reads_free(C.byref(r))
+    # the placeholder without its tag, with a CG tag of another type, or with a CG array shorter than n_cigar: htslib keeps the record's own CIGAR, silently
+    for tail in (b"NMi" + struct.pack("<i", 3), b"CGZnot-a-cigar\0", b"CGBI" + struct.pack("<i", 1) + ops[:1].tobytes()):
+        _one_record_bam(path, [head + tail])
+        assert lib.lcd_bam_load_region(path.encode(), b"chr11", 1, 2000000, 30, 1, C.byref(r)) == 1, lib.lcd_io_last_error()
+        assert r.n_cigar[0] == 2 and r.end_pos[0] == 5000 + rl
+        assert (np.ctypeslib.as_array(r.cigar_pool, shape=(2,)) == placeholder).all()
+        lib.lcd_bam_reads_free(C.byref(r))
     # l_seq larger than the record holds
     short = struct.pack("<iiBBHHHiiii", 0, 5000, len(name), 60, 4680, 1, 0, 100000, -1, -1, 0) + name + struct.pack("<I", (100000 << 4) | 7) + b"\x11" * 50
     _one_record_bam(path, [short])
     assert lib.lcd_bam_load_region(path.encode(), b"chr11", 1, 2000000, 30, 1, C.byref(r)) < 0 and b"malformed" in lib.lcd_io_last_error()
+
+
+def test_hostile_bgzf_header_is_an_error_not_an_out_of_bounds_read(lib, tmp_path):
+    """a BSIZE smaller than header + trailer (or an extra field that runs past the file) must be refused BEFORE the trailer bytes f[end - 8 ..] are read"""
+    r = BamReads()
+    for bsize, xlen, tail in ((3, 6, b"\0" * 4), (5, 6, b"\0" * 64), (40, 60000, b"\0" * 64)):
+        img = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, xlen, 66, 67, 2, bsize) + tail
+        path = str(tmp_path / f"hostile{bsize}.bam")
+        open(path, "wb").write(img)
+        assert lib.lcd_bam_load_region(path.encode(), b"chr11", 1, 10, 30, 1, C.byref(r)) < 0
+        assert b"BGZF" in lib.lcd_io_last_error()
 
 
 def test_fasta_fetch_matches_python(lib, tmp_path):
