@@ -264,7 +264,7 @@ struct lcd_batch_s {
 
 namespace {
 
-LcdScoring scoring_of(const lcd_opt_t &o) { LcdScoring s; s.match = o.match; s.mismatch = o.mismatch; s.o1 = o.gap_open1; s.e1 = o.gap_ext1; s.o2 = o.gap_open2; s.e2 = o.gap_ext2; s.dbg = getenv("LCD_DBG") ? atoi(getenv("LCD_DBG")) : 0; return s; }
+LcdScoring scoring_of(const lcd_opt_t &o) { LcdScoring s; s.match = o.match; s.mismatch = o.mismatch; s.o1 = o.gap_open1; s.e1 = o.gap_ext1; s.o2 = o.gap_open2; s.e2 = o.gap_ext2; s.dbg = getenv("LCD_DBG") ? atoi(getenv("LCD_DBG")) : 0; s.wd_s = getenv("LCD_WATCHDOG_S") ? atoi(getenv("LCD_WATCHDOG_S")) : 0; return s; }
 
 std::atomic<int> g_wfa_hint{0}; // 0..2: learned from the overflow retries of earlier ANCHOR stages (read vs read windows of noisy reads)
 // first score bound of a job (WfaJob.s_cap on entry of run_wfa_stage; overflow -> x4 + 64): the length difference as one long gap plus a little
@@ -792,7 +792,8 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     const long long node_worst = std::min<long long>(sum + 2, 2000000000ll), edge_worst = std::min<long long>(sum + n + 2, 2000000000ll);
     {
         static const double nf[3] = {1.25, 2.0, 4.0}, sf[3] = {0.03, 0.10, 0.30};
-        const int nh = g_node_hint.load();
+        static const int nh_env = getenv("LCD_NODE_HINT") ? atoi(getenv("LCD_NODE_HINT")) : -1; // (test switch: the learned level, fixed)
+        const int nh = nh_env >= 0 && nh_env <= 2 ? nh_env : g_node_hint.load();
         long long est = (long long)(nf[nh] * maxl + sf[nh] * (double)sum) + 64;
         for (int sc2 = 1; sc2 < scale; sc2 *= 2) est *= 4;
         pc.node_cap = (int)std::min(node_worst, est);
@@ -807,7 +808,8 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     // g_cell_hint[mode]: learned from the overflow retries of earlier submissions (noisy reads: every read adds ~error-rate new nodes,
     // and the row-max columns that steer the adaptive band drift further) -- a chain that overflows is re-run from scratch, so data that
     // keeps overflowing is given the larger estimate up front
-    const int hint = g_cell_hint[C.mode ? 1 : 0].load();
+    static const int ch_env = getenv("LCD_CELL_HINT") ? atoi(getenv("LCD_CELL_HINT")) : -1; // (test switch)
+    const int hint = ch_env >= 0 && ch_env <= 2 ? ch_env : g_cell_hint[C.mode ? 1 : 0].load();
     static const double rows_f[3] = {1.3, 2.2, 3.2}; static const int band_x[3] = {64, 128, 192};
     const long long rows_est = std::min<long long>(rows_worst, (long long)(rows_f[hint] * maxl) + 64);
     long long band;
@@ -921,7 +923,8 @@ static void chain_class(PoaChain &pc, bool noisy) {
         static const bool rk_free = !(getenv("LCD_RING_K_FREE") && atoi(getenv("LCD_RING_K_FREE")) == 0);
         // (only in the buckets the default pool cap produces: with LCD_LDS_CAP_KB=16 the same rule gives eight slots of 128 columns, and an ONT-shape run with those did
         //  not come back -- found at the end of round 3, not understood yet; the generic rows and two slots are fine there)
-        while (rk_free && lds <= (12 << 10) && K < 8 && (long long)(2 * K) * 3 * wmax * 4 + seq_bytes <= lds) K *= 2;
+        static const int rk_maxlds = getenv("LCD_RING_K_MAXLDS_KB") ? atoi(getenv("LCD_RING_K_MAXLDS_KB")) : 12; // (test switch: 16 re-creates the round-3 combination)
+        while (rk_free && lds <= (rk_maxlds << 10) && K < 8 && (long long)(2 * K) * 3 * wmax * 4 + seq_bytes <= lds) K *= 2;
     }
     pc.threads = threads; pc.wmax = wmax; pc.lds_words = lds / 4; pc.ring_k = (threads == 64 || pc.solo) ? K : 0;
 }
@@ -1496,7 +1499,28 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                     CR.cert_fail_round = round; CR.cert_level = cert_next_level(PC(which[i]));
                     again.push_back(which[i]); ++n_cert_fail;
                 }
-                else if (tmp[i].status != LCD_OK) return set_err(-20, "POA kernel status " + std::to_string(tmp[i].status) + " on chain " + std::to_string(which[i] - chain_base[k]));
+                else if (tmp[i].status != LCD_OK) { const PoaChain &pc = PC(which[i]);
+                    if (const char *dump = getenv("LCD_DUMP_CHAIN")) { // the failing chain's reads, for a replay in isolation (tools/replay_chain.py): header, then per read {len, skip, anchors, bases}
+                        if (FILE *f = fopen(dump, "wb")) {
+                            const int hdr[8] = {0x4c434443, pc.mode, pc.n_reads, tmp[i].status, pc.threads, pc.wmax, pc.ring_k, pc.lds_words * 4};
+                            fwrite(hdr, sizeof(int), 8, f);
+                            const std::vector<PoaRead> &pr = preads[k];
+                            for (int q = 0; q < pc.n_reads; ++q) {
+                                const PoaRead &r = pr[pc.read0 + q];
+                                const int rec[6] = {r.len, r.skip, r.ref_beg, r.ref_end, r.read_beg, r.read_end};
+                                fwrite(rec, sizeof(int), 6, f);
+                                std::vector<uint8_t> bases((size_t)std::max(r.len, 0));
+                                if (r.len > 0) (void)hipMemcpy(bases.data(), (const void *)(uintptr_t)r.seq_off, (size_t)r.len, hipMemcpyDeviceToHost);
+                                fwrite(bases.data(), 1, bases.size(), f);
+                            }
+                            fclose(f);
+                        }
+                    }
+                    return set_err(-20, "POA kernel status " + std::to_string(tmp[i].status) + " on chain " + std::to_string(which[i] - chain_base[k]) + " of batch " + std::to_string(k) + " (mode " + std::to_string(pc.mode) +
+                                   ", " + std::to_string(pc.n_reads) + " reads, longest " + std::to_string(pc.max_len) + ", threads " + std::to_string(pc.threads) + ", window " + std::to_string(pc.wmax) + ", ring slots " +
+                                   std::to_string(pc.ring_k) + ", LDS " + std::to_string(pc.lds_words * 4) + " B, nodes " + std::to_string(tmp[i].n_node) + "/" + std::to_string(pc.node_cap) + ", reads aligned " + std::to_string(tmp[i].n_aligned_reads) + ")" +
+                                   (tmp[i].status == LCD_ERR_WATCHDOG ? [&] { std::string t = "; last backtrack states (row, column, state):"; const unsigned long long w[4] = {tmp[i].t_plan, tmp[i].t_poll, tmp[i].t_bp, tmp[i].t_add};
+                                        for (int q = 0; q < 4; ++q) t += " (" + std::to_string((unsigned)(w[q] & 0xffffffffu)) + ", " + std::to_string((unsigned)((w[q] >> 32) & 0xffffff)) + ", " + std::to_string((unsigned)(w[q] >> 56)) + ")"; return t; }() : std::string())); }
             }
             if (getenv("LCD_MEM_DEBUG")) {
                 { size_t nc = 0; for (size_t g : which) nc += PC(g).cert != 0; fprintf(stderr, "[mem] round %d: %zu chains with a certified band, %zu sent back for full rows\n", round, nc, n_cert_fail); }
@@ -2355,7 +2379,7 @@ static int edlib_batch_mode(int mode, int n, const uint8_t *pool, uint64_t pool_
 // work-arena bytes of one alignment whose score bound is `score_bound` (what run_wfa_stage lays out for it): DESIGN / tests
 uint64_t lcd_wfa_arena_bytes(int plen, int tlen, int score_bound, int b, int q, int e, int q2, int e2) {
     WfaJob j; memset(&j, 0, sizeof(j)); j.plen = plen; j.tlen = tlen;
-    LcdScoring sc; sc.dbg = 0; sc.match = 0; sc.mismatch = b; sc.o1 = q; sc.e1 = e; sc.o2 = q2; sc.e2 = e2;
+    LcdScoring sc; sc.dbg = 0; sc.wd_s = 0; sc.match = 0; sc.mismatch = b; sc.o1 = q; sc.e1 = e; sc.o2 = q2; sc.e2 = e2;
     wfa_plan(j, sc, score_bound);
     return j.ws_bytes;
 }
@@ -2374,7 +2398,7 @@ int lcd_wfa_batch(int n, const uint8_t *pool, uint64_t pool_len, const uint64_t 
         j.p_off = d_pool.addr() + p_off[i]; j.t_off = d_pool.addr() + t_off[i]; j.plen = plen[i]; j.tlen = tlen[i]; j.gap_aln = gap_aln[i]; j.want = want;
         j.s_cap = wfa_default_scap(plen[i], tlen[i]); j.ws_off = j.ws_bytes = j.out_off = 0;
     }
-    LcdScoring sc; sc.dbg = 0; sc.match = 0; sc.mismatch = b; sc.o1 = q; sc.e1 = e; sc.o2 = q2; sc.e2 = e2;
+    LcdScoring sc; sc.dbg = 0; sc.wd_s = 0; sc.match = 0; sc.mismatch = b; sc.o1 = q; sc.e1 = e; sc.o2 = q2; sc.e2 = e2;
     std::vector<WfaOut> outs;
     int rc = run_wfa_stage(st, jobs, d_jobs, d_arena, d_out, d_outs, outs, sc, nullptr);
     if (rc) return rc;

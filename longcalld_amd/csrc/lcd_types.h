@@ -27,13 +27,15 @@
 // scoring, src/align.h:21-26 via call_var_opt_t
 struct LcdScoring {
     int match, mismatch, o1, e1, o2, e2;
+    int wd_s; // watchdog of the POA chain kernel: a chain that has not finished after this many seconds ends with LCD_ERR_WATCHDOG (0: 30 s; env LCD_WATCHDOG_S)
     int dbg; // test switches (env LCD_DBG; 0 in production): 8 = force the generic rows of the POA kernel, 16 = a certified-band read that outgrows the window ends its
              // chain (LCD_ERR_CERT, re-run with full rows) instead of taking the generic rows (tests/test_gpu_kernels.py)
 };
 
 // status codes written by kernels (0 = ok). Anything else makes the host fail loudly or retry with a bigger arena.
 enum { LCD_OK = 0, LCD_ERR_CELLS = 1, LCD_ERR_NODES = 2, LCD_ERR_EDGES = 3, LCD_ERR_BACKTRACK = 4, LCD_ERR_WF = 5, LCD_ERR_TOPO = 6, LCD_ERR_SYNC = 7, LCD_ERR_LDS = 8,
-       LCD_ERR_CERT = 9 /* a K2 chain's certified band did not fit the single-wavefront window: the host re-runs the chain with full rows */, LCD_FALLBACK = 100 /* internal: take the generic rows */ };
+       LCD_ERR_CERT = 9 /* a K2 chain's certified band did not fit the single-wavefront window: the host re-runs the chain with full rows */,
+       LCD_ERR_WATCHDOG = 10 /* a POA chain ran past its deadline (LcdScoring.wd_s): a loop that does not end is a bug, and this turns it into a loud error instead of a hung GPU */, LCD_FALLBACK = 100 /* internal: take the generic rows */ };
 
 // ---------------- POA chain (one graph build = one abpoa_t life, src/align.c:762 / :872) ----------------
 struct PoaRead {

@@ -79,6 +79,7 @@ struct Ctx {
     int cert_generic, cert_generic_seen, cert_sest, cert_ubtop; unsigned long long cert_cells0; // the read at hand goes through the generic rows over its intervals (align_certified)
     int *cert; int cert_on, cert_hist; // certified band of a K2 chain (align_certified): 7 x node_cap ints; largest bound-to-score slack of the chain's reads so far
     int wmax, seq_cap, pool_words, spill_x, ring_k, plan_k, solo;
+    unsigned long long wd_deadline;   // shader-clock tick after which the chain gives up (LCD_ERR_WATCHDOG): checked once per 64 DP rows, per read, per 256 backtrack steps
     int mm_valid;                      // g.deg / g.queue hold, by topological index, every row's smallest predecessor index / largest successor index (topo_sort_block; subgraph_nodes_wave0)
     int n_node, n_edge, node_cap, edge_cap, rid_words;
     unsigned long long cell_cap;
@@ -552,10 +553,10 @@ __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned shor
                 if (lane >= 1 && lane < L) queue[qh - 1 + lane] = (unsigned short)x;
                 index += L - 1; qh += L - 1; qt = qh;
                 cur = __shfl(x, L - 1);
-                if (L < 64) break;
+                if (L < 64 || index > n) break; // (index > n: the jump tables do not describe chains -- the count below turns it into LCD_ERR_TOPO)
             }
             g.node2idx[cur] = index; ++index; // (idx2node is the queue itself, copied out below)
-            if (cur == 1) break;
+            if (cur == 1 || index > n) break;
             for (unsigned e = nw[cur] & 0xffffu; e != 0;) {
                 const unsigned w = ew[e - 1];
                 const int out = (int)(w & 0xffffu);
@@ -972,7 +973,7 @@ __device__ void ctx_to_sgpr(Ctx &g) {
     g.cig_node0 = usgpr(g.cig_node0); g.cig_qpos0 = usgpr(g.cig_qpos0); g.imap = usgpr(g.imap);
     g.tb = usgpr(g.tb); g.cert = usgpr(g.cert); g.node_cap = usgpr(g.node_cap);
     g.pl_start = usgpr(g.pl_start); g.pl_pidx = usgpr(g.pl_pidx); g.pl_bonus = usgpr(g.pl_bonus); g.pl_rem = usgpr(g.pl_rem); g.pl_base = usgpr(g.pl_base);
-    g.wmax = usgpr(g.wmax); g.pool_words = usgpr(g.pool_words); g.seq_cap = usgpr(g.seq_cap); g.cell_cap = usgpr(g.cell_cap); g.status = usgpr(g.status); g.spill_x = usgpr(g.spill_x); g.ring_k = usgpr(g.ring_k); g.plan_k = usgpr(g.plan_k);
+    g.wd_deadline = usgpr(g.wd_deadline); g.wmax = usgpr(g.wmax); g.pool_words = usgpr(g.pool_words); g.seq_cap = usgpr(g.seq_cap); g.cell_cap = usgpr(g.cell_cap); g.status = usgpr(g.status); g.spill_x = usgpr(g.spill_x); g.ring_k = usgpr(g.ring_k); g.plan_k = usgpr(g.plan_k);
 }
 // End node (best predecessor at column qlen; its values are in the spill area) + the code-driven backtrack, on wavefront 0.
 // Results through sm.bc[0] = #cigar entries, [1] = status, [4] = first cigar slot.
@@ -996,7 +997,15 @@ __device__ __forceinline__ void code_backtrack(const Ctx &g, Smem &sm, const uns
             // of columns); halved down to 8 when they turn out short (noisy reads: a difference every ~20 columns) -- the chain is followed
             // lane-serially through LDS before the codes can be fetched, so a 64-step look-ahead for a 3-step run was most of the backtrack there
             int sw = 64;
+            unsigned wd_it = 0; int wd_left = -1; // (a backtrack that does not end: the last four states (row, column, state) go out with the error -- LCD_ERR_WATCHDOG, sm.prof -> PoaChainOut.t_plan ...)
             while (i != bi && j > 0 && status == LCD_OK) {
+                if (wd_left < 0 && (++wd_it & 255u) == 0 && (unsigned long long)clock64() > g.wd_deadline) wd_left = 3;
+                if (wd_left >= 0) {
+                    if (lane == 0) sm.prof[3 - wd_left] = (unsigned long long)(unsigned)i | ((unsigned long long)(unsigned)(j & 0xffffff) << 32) | ((unsigned long long)(unsigned)st << 56);
+                    if (wd_left-- == 0) {
+                        status = LCD_ERR_WATCHDOG; break;
+                    }
+                }
                 if (st == 0 && pd != 0xffffffffu) {
                     // speculate a run of matches along first predecessors: lane t looks at the cell t steps up the diagonal
                     int my_i = -1, my_nx = -1;
@@ -1121,7 +1130,8 @@ __device__ __forceinline__ void code_backtrack(const Ctx &g, Smem &sm, const uns
         if (lane == 0) { sm.bc[0] = qlen - pos; sm.bc[1] = status; sm.bc[4] = pos; sm.bc[5] = best; }
     }
 
-struct WinOut { int status; unsigned long long t_dp, t_bt, cells; int cig_pos; unsigned long long t_plan, t_poll; int score; unsigned long long t_setup; };
+struct WinOut { int status; unsigned long long t_dp, t_bt, cells; int cig_pos; unsigned long long t_plan, t_poll; int score; unsigned long long t_setup;
+                int clobber; /* the rows' ring outgrew the pool's layout and took the place of the query cache / first-predecessor distances: whatever runs next for this read must not trust `pd` */ };
 // (not inlined, context by value: the row loop then only carries the dozen pointers it uses instead of the chain's whole
 //  context -- inlined, hipcc spilled the scalar registers of ~45 pointers into VGPR lanes and re-read them every row)
 // C consecutive ints from / to LDS (byte offset) or HBM: one ds_read_b128 / b64 / b32 (global_load_dwordx4 / x2 / dword)
@@ -1191,7 +1201,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
                 K = g.plan_k; ring_bytes = (unsigned)(K * SLOTW * 4);                        // the slots the plan's spill flags were made for
             }
             if (ring_bytes + (unsigned)QB > (unsigned)g.pool_words * 4u) return -1;
-            if (sq1 < ring + ring_bytes) { sq1 = ring + ring_bytes; pd = 0xffffffffu; }
+            if (sq1 < ring + ring_bytes) { sq1 = ring + ring_bytes; pd = 0xffffffffu; wo->clobber = 1; }
         }
     }
     for (int j = tid; j < QB; j += NT) lds_st_u8(sq1 + j, (j >= 1 && j <= qlen) ? seq_hbm[j - 1] : 4); // shifted: sq1[j] = q[j-1]
@@ -1232,6 +1242,7 @@ __device__ __attribute__((noinline)) int align_windowed(const Ctx *gp_, const un
     int w_p0 = 0, w_np = 0, w_rem = 1 << 30, w_vb = 4, w_pi0 = 0, w_b0 = 0, w_pi1 = 0, w_b1 = 0, w_sp = 0, w_hull = 1;
     for (int idx = bi + 1; idx < ei; ++idx) {
         if (idx - wbase >= 64) { // plan window: each lane loads the plan of one upcoming row; rows then take it by v_readlane
+            if constexpr (NT == 64) if ((unsigned long long)clock64() > g.wd_deadline) { wo->status = LCD_ERR_WATCHDOG; return 0; }
             wbase = idx;
             const int ri = idx + lane;
             w_np = 0; w_rem = 1 << 30;
@@ -1549,7 +1560,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
         if (sq1 < ring + ring_bytes) {
             if (ring_bytes + (unsigned)QB > (unsigned)g.pool_words * 4u && K > g.plan_k) { K = usgpr(g.plan_k); ring_bytes = (unsigned)(K * SLOTW * 4); }
             if (ring_bytes + (unsigned)QB > (unsigned)g.pool_words * 4u) return -1;
-            if (sq1 < ring + ring_bytes) { sq1 = ring + ring_bytes; pd = 0xffffffffu; }
+            if (sq1 < ring + ring_bytes) { sq1 = ring + ring_bytes; pd = 0xffffffffu; wo->clobber = 1; }
         }
     }
     const int KM = K - 1;
@@ -1630,7 +1641,10 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     const int cle1 = cl * e1, cle2 = cl * e2, ncle1 = -cle1, ncle2 = -cle2; // (the cells' k * e and the window's begc * e are added on the scalar side)
     int idx = bi + 1;
     while (idx < ei) {
-        if (idx - wbase == 64) { flush_meta(wbase, 64); wbase = idx; load_plan(wbase); }
+        if (idx - wbase == 64) {
+            flush_meta(wbase, 64); wbase = idx; load_plan(wbase);
+            if ((unsigned long long)clock64() > g.wd_deadline) { wo->status = LCD_ERR_WATCHDOG; return 0; }
+        }
         int wk = idx - wbase;
         // ===== a run of PLAIN rows: reachable, one usable predecessor = the row before (whose values are in registers), not spilled, window on the same lanes
         // or one lane group further.  Anything else leaves the loop with the row untouched and is handled by the general row below. =====
@@ -2313,7 +2327,10 @@ __device__ __attribute__((noinline)) int align_cyc(const Ctx *gp_, const unsigne
     load_plan(wbase);
     int idx = bi + 1;
     while (idx < ei) {
-        if (idx - wbase == 64) { flush_meta(wbase, 64); wbase = idx; load_plan(wbase); }
+        if (idx - wbase == 64) {
+            flush_meta(wbase, 64); wbase = idx; load_plan(wbase);
+            if ((unsigned long long)clock64() > g.wd_deadline) { fail = LCD_ERR_WATCHDOG; break; } // (the others reach the same row; a wavefront that waits for this one runs into its poll bound)
+        }
         int wk = idx - wbase;
         // ===== a run of backbone rows: reachable, one usable predecessor = the row before (in the registers), not spilled.  Anything else leaves the loop with the
         // row untouched and is the general row below. =====
@@ -2723,6 +2740,7 @@ __device__ __attribute__((noinline)) int align_unbanded(const Ctx *gp_, const un
         const int ke1 = e1, ke2 = e2;
         for (int idx = bi + 1; idx < ei; ++idx) {
             if (idx - wbase >= 64) { // plan window: each lane loads the plan of one upcoming row; rows then take it by v_readlane
+                if ((unsigned long long)clock64() > g.wd_deadline) { err = LCD_ERR_WATCHDOG; break; } // (every wavefront on its own: the others run into it, or into their poll bound)
                 const long long tp0 = clock64();
                 wbase = idx;
                 const int ri = idx + lane;
@@ -3211,12 +3229,13 @@ __device__ __attribute__((noinline)) int cert_hull(const Ctx *gp_, const int bi_
 // kernel's body -- its loops and lambdas cost every chain of every class another 50 - 110 B of scratch (the kernel body is what spills).
 // Returns the number of cigar entries (status LCD_OK), or 0 with gp->status = LCD_ERR_CERT / an error.
 template <int NT>
-__device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned ro, const unsigned so, const unsigned pdo, const LcdScoring sc, const int w, const int bi, const int ei,
+__device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned ro, const unsigned so, const unsigned pdo_, const LcdScoring sc, const int w, const int bi, const int ei,
                                                          const int rem_beg, const uint8_t *seq_hbm, const int qlen, unsigned long long *cells_acc) {
     Smem &sm = g_smem;
     Ctx &g = *gp; // (the caller's context itself: the few fields this function changes are changed in place)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0; wo.t_plan = wo.t_poll = 0; wo.score = LCD_NEG; wo.t_setup = 0;
+    unsigned pdo = pdo_; // (a window wider than the pool was laid out for overwrites the first-predecessor distances: no attempt after it may use them -- WinOut.clobber)
+    WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0; wo.t_plan = wo.t_poll = 0; wo.score = LCD_NEG; wo.t_setup = 0; wo.clobber = 0;
     int nc = -1;
     auto leave = [&](const int r) { return r; };
             // 64-thread class: the workgroup IS that wavefront.  256-thread class (long chains: the critical path of a submission): wavefront 0 runs the same
@@ -3302,14 +3321,19 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
                 }
                 if (!by_all && (!SOLO || wave == 0)) {
                     if (mw <= 60) nc = align_lean<2, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+                    if (wo.clobber) pdo = 0xffffffffu;
                     if (nc < 0 && mw <= 124) { win_sync<SOLO>(); nc = align_lean<2, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                    if (wo.clobber) pdo = 0xffffffffu;
                     if (nc < 0 && mw <= 256) { win_sync<SOLO>(); nc = align_lean<2, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                    if (wo.clobber) pdo = 0xffffffffu;
                     if (nc < 0) { win_sync<SOLO>(); nc = align_lean<2, 8>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); } // (512 columns: a region whose reads differ by an SV-size indel)
+                    if (wo.clobber) pdo = 0xffffffffu; // (and the attempts after this one)
                     if (SOLO && lane == 0) { g_wide.ppi[0] = nc; g_wide.ppi[1] = wo.status; g_wide.ppi[2] = wo.score; g_wide.ppi[3] = wo.cig_pos; g_wide.po[0] = (unsigned)wo.cells; g_wide.po[1] = (unsigned)(wo.cells >> 32);
-                                             g_wide.po[2] = (unsigned)wo.t_dp; g_wide.po[3] = (unsigned)(wo.t_dp >> 32); g_wide.po[4] = (unsigned)wo.t_bt; g_wide.po[5] = (unsigned)(wo.t_bt >> 32); }
+                                             g_wide.po[2] = (unsigned)wo.t_dp; g_wide.po[3] = (unsigned)(wo.t_dp >> 32); g_wide.po[4] = (unsigned)wo.t_bt; g_wide.po[5] = (unsigned)(wo.t_bt >> 32); g_wide.ppi[4] = wo.clobber; }
                 }
                 if (SOLO && !by_all) { // the result of wavefront 0 to everybody
                     __syncthreads();
+                    if (g_wide.ppi[4]) { pdo = 0xffffffffu; wo.clobber = 1; }
                     nc = g_wide.ppi[0]; wo.status = g_wide.ppi[1]; wo.score = g_wide.ppi[2]; wo.cig_pos = g_wide.ppi[3]; wo.cells = g_wide.po[0] | ((unsigned long long)g_wide.po[1] << 32);
                     wo.t_dp = g_wide.po[2] | ((unsigned long long)g_wide.po[3] << 32); wo.t_bt = g_wide.po[4] | ((unsigned long long)g_wide.po[5] << 32); wo.t_setup = 0;
                     __syncthreads();
@@ -3352,7 +3376,7 @@ __device__ __attribute__((noinline)) int align_certified_sys(Ctx *gp, const unsi
     int delta = g.cert_hist < 0 ? 48 + qlen / 8 : g.cert_hist + g.cert_hist / 4 + 32; // (first read of a chain of noisy reads: every eighth base an error's worth of slack)
     int sbest = LCD_NEG, nc = 0;
     bool done = false;
-    WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0; wo.t_plan = wo.t_poll = 0; wo.score = LCD_NEG; wo.t_setup = 0;
+    WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0; wo.t_plan = wo.t_poll = 0; wo.score = LCD_NEG; wo.t_setup = 0; wo.clobber = 0;
     for (int attempt = 0; attempt < 12 && !done; ++attempt, delta *= 2) {
         const int sest = imax(sbest, ubtop - delta);
         const long long th0 = clock64();
@@ -3503,7 +3527,7 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
     }
     g.t_bp += (unsigned long long)(clock64() - tb0); } // (rows to spill: those with a successor further away than the windowed rows' ring -- the smallest ring a window of this chain may run with)
     if (!(sc.dbg & 8)) {
-        WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0; wo.t_plan = wo.t_poll = 0; wo.t_setup = 0;
+        WinOut wo; wo.status = g.status; wo.t_dp = wo.t_bt = wo.cells = 0; wo.cig_pos = 0; wo.t_plan = wo.t_poll = 0; wo.t_setup = 0; wo.clobber = 0;
         const int rem_beg = g.remain[beg_node] - remain_end;
         const unsigned pdo = pd ? lds_off(pd) : 0xffffffffu, ro = lds_off(ring), so = lds_off(sseq);
         int nc = -1;
@@ -3525,15 +3549,25 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
         } else {
             // the host's preferred window (PoaChain.wmax) first; a band that outgrows it is re-run in the next wider one
             if constexpr (NT == 64) { // single wavefront: the lean rows (align_lean); a band that outgrows 256 columns takes the generic rows below
-                if (g.wmax <= 64) nc = align_lean<1, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
-                if (nc < 0 && g.wmax <= 128) { __syncthreads(); nc = align_lean<1, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
-                if (nc < 0) { __syncthreads(); nc = align_lean<1, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                // (a window wider than the pool was laid out for puts its ring over the first-predecessor distances -- eight slots of 128 columns in a 16 KB pool did,
+                //  and the four-cells-per-lane rows that ran next, on two slots, followed the overwritten distances in their backtrack: the round-3 "hang", a backtrack
+                //  that walked out of a row's band and stepped from a row to itself for ever.  WinOut.clobber: nothing after such a window uses them)
+                unsigned pdl = pdo;
+                if (g.wmax <= 64) nc = align_lean<1, 1>(&g, ro, so, pdl, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+                if (wo.clobber) pdl = 0xffffffffu;
+                if (nc < 0 && g.wmax <= 128) { __syncthreads(); nc = align_lean<1, 2>(&g, ro, so, pdl, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                if (wo.clobber) pdl = 0xffffffffu;
+                if (nc < 0) { __syncthreads(); nc = align_lean<1, 4>(&g, ro, so, pdl, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
             } else if (NT == 256 && g.solo) { // a long K1 chain in a 256-thread workgroup: wavefront 0 runs the lean rows, the others wait for its result
                 if (wave == 0) {
-                    if (g.wmax <= 64) nc = align_lean<1, 1>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
-                    if (nc < 0 && g.wmax <= 128) { win_sync<true>(); nc = align_lean<1, 2>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
-                    if (nc < 0 && g.wmax <= 256) { win_sync<true>(); nc = align_lean<1, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
-                    if (nc < 0) { win_sync<true>(); nc = align_lean<1, 8>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                    unsigned pdl = pdo;
+                    if (g.wmax <= 64) nc = align_lean<1, 1>(&g, ro, so, pdl, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
+                    if (wo.clobber) pdl = 0xffffffffu;
+                    if (nc < 0 && g.wmax <= 128) { win_sync<true>(); nc = align_lean<1, 2>(&g, ro, so, pdl, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                    if (wo.clobber) pdl = 0xffffffffu;
+                    if (nc < 0 && g.wmax <= 256) { win_sync<true>(); nc = align_lean<1, 4>(&g, ro, so, pdl, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
+                    if (wo.clobber) pdl = 0xffffffffu;
+                    if (nc < 0) { win_sync<true>(); nc = align_lean<1, 8>(&g, ro, so, pdl, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo); }
                     if (lane == 0) { g_wide.ppi[0] = nc; g_wide.ppi[1] = wo.status; g_wide.ppi[2] = wo.score; g_wide.ppi[3] = wo.cig_pos; g_wide.po[0] = (unsigned)wo.cells; g_wide.po[1] = (unsigned)(wo.cells >> 32);
                                      g_wide.po[2] = (unsigned)wo.t_dp; g_wide.po[3] = (unsigned)(wo.t_dp >> 32); g_wide.po[4] = (unsigned)wo.t_bt; g_wide.po[5] = (unsigned)(wo.t_bt >> 32); }
                 }
@@ -3600,6 +3634,7 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
     // ---- rows ----
     for (int idx = bi + 1; idx < ei; ++idx) {
         if (idx - wbase >= 64) {
+            if constexpr (NT == 64) if ((unsigned long long)clock64() > g.wd_deadline) { g.status = LCD_ERR_WATCHDOG; return 0; }
             wbase = idx;
             const int ri = idx + lane;
             w_np = 0; w_rem = 1 << 30;
@@ -4134,6 +4169,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = ch.cert == 2 ? 2 : NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0; g.cert_generic = 0; g.cert_generic_seen = 0; g.cert_sest = 0; g.cert_ubtop = 0; g.cert_cells0 = 0;
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
     g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - ring_k * 3 * ring_cols) * 4; g.ring_k = ring_k; g.plan_k = (NT == 64 || ch.solo) && ring_k > 2 && ch.wmax < 256 ? 2 : ring_k; // (slots beyond 2 of a chain laid out for a narrow window: not there when a read needs a wider one)
+    g.wd_deadline = (unsigned long long)clock64() + (unsigned long long)(sc.wd_s > 0 ? sc.wd_s : 30) * 2400000000ull; // (~2.4 GHz shader clock: the bound is about seconds, not exact)
     g.mm_valid = 0; g.solo = NT == 256 ? ch.solo : 0; g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0; g.t_bp = 0; g.t_setup = 0;
     const long long t_begin = clock64();
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
@@ -4150,6 +4186,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     for (int i = 0; i < n_seq && g.status == LCD_OK; ++i) {
         const PoaRead r = rd[i];
         if (r.skip) continue;
+        if (__syncthreads_or((unsigned long long)clock64() > g.wd_deadline)) { g.status = LCD_ERR_WATCHDOG; break; } // (one decision for the workgroup: its wavefronts meet at barriers inside the phases)
         int exc_beg = 0, exc_end = 1, beg_cut = 0, end_cut = 0;
         if (ch.mode == 0 && i != 0) {
             const long long ts0 = clock64();
@@ -4199,6 +4236,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
         out.rt_begin = rt_begin; out.rt_end = __builtin_amdgcn_s_memrealtime();
         out.t_out = (unsigned long long)(t_end - t_out0);
         out.t_bp = g.t_bp; out.t_add = t_add; out.t_sort = t_graph - t_add; out.t_setup = g.t_setup;
+        if (g.status == LCD_ERR_WATCHDOG) { out.t_plan = sm.prof[0]; out.t_poll = sm.prof[1]; out.t_bp = sm.prof[2]; out.t_add = sm.prof[3]; } // (the backtrack's last states, if that is where it was)
         outs[cid] = out;
     }
     if (my_slot >= 0) { // every store of this workgroup into the slot has completed (barrier = vmcnt(0) per wavefront) before the next owner may start

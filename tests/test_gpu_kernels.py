@@ -446,3 +446,22 @@ def test_poa_k2_column_tiles_agree_with_generic_rows_and_oracle(lcd, oracle, mon
         assert (a[0]["cons"][c] == exp["cons"][c]).all()
     for r, q in zip(a[0]["msa"], exp["msa"]):
         assert (r == q).all()
+
+
+def test_wider_window_after_a_ring_that_outgrew_the_pool_layout(tmp_path):
+    """DESIGN 8.7 (the round-3 "hang"): a noisy K1 chain with eight ring slots in a 16 KB pool whose band outgrows 64 and then 128 columns.  The eight slots of 128 columns
+    lie over the first-predecessor distances, and the four-cells-per-lane rows that ran next used to follow the overwritten distances in their backtrack -- out of a
+    row's band, from a row to itself, for ever.  The chain (tests/golden/ring8_chain.bin: dumped by LCD_DUMP_CHAIN from the failing ONT-shape submission) must now
+    come back with the results of the default layout, well inside the watchdog.  (Separate processes: the layout switches are read once per process.)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fx = os.path.join(root, "tests", "golden", "ring8_chain.bin")
+    outs = []
+    for extra in ({}, {"LCD_RING_K_MAXLDS_KB": "16", "LCD_LDS_CAP_KB": "16"}):
+        env = dict(os.environ, LCD_WATCHDOG_S="5", **extra)
+        out = str(tmp_path / f"r{len(outs)}.json")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "replay_chain.py"), fx, "--ont", "--json", out], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-400:] + r.stderr[-400:]
+        outs.append(json.load(open(out)))
+    assert outs[0]["status"] == 0 and outs[0]["rows_degap_to_reads"]
+    assert outs[1] == outs[0]
