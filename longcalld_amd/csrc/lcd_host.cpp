@@ -921,9 +921,11 @@ static void chain_class(PoaChain &pc, bool noisy) {
     //  chains of clean reads too: no change at 2 x 32 batches, 47 k instead of 60 k regions/s at one submission of 20)
     if ((threads == 64 || pc.solo) && pc.mode == 0 && noisy && K == 2) {
         static const bool rk_free = !(getenv("LCD_RING_K_FREE") && atoi(getenv("LCD_RING_K_FREE")) == 0);
-        // (only in the buckets the default pool cap produces: with LCD_LDS_CAP_KB=16 the same rule gives eight slots of 128 columns, and an ONT-shape run with those did
-        //  not come back -- found at the end of round 3, not understood yet; the generic rows and two slots are fine there)
-        static const int rk_maxlds = getenv("LCD_RING_K_MAXLDS_KB") ? atoi(getenv("LCD_RING_K_MAXLDS_KB")) : 12; // (test switch: 16 re-creates the round-3 combination)
+        // (until round 4 only in the buckets the default pool cap produces: with LCD_LDS_CAP_KB=16 the rule gives eight slots of 64 columns whose next wider window --
+        //  eight slots of 128 -- lies over the first-predecessor distances, and the rows that ran after it followed the overwritten distances for ever.  Root cause fixed
+        //  in poa_kernel.hip (WinOut.clobber; tests/test_gpu_kernels.py::test_wider_window_after_a_ring_that_outgrew_the_pool_layout); the restriction is gone: same
+        //  digest and rate on the ONT shape with and without it.  LCD_RING_K_MAXLDS_KB restores it)
+        static const int rk_maxlds = getenv("LCD_RING_K_MAXLDS_KB") ? atoi(getenv("LCD_RING_K_MAXLDS_KB")) : 148;
         while (rk_free && lds <= (rk_maxlds << 10) && K < 8 && (long long)(2 * K) * 3 * wmax * 4 + seq_bytes <= lds) K *= 2;
     }
     pc.threads = threads; pc.wmax = wmax; pc.lds_words = lds / 4; pc.ring_k = (threads == 64 || pc.solo) ? K : 0;
