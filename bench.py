@@ -204,6 +204,8 @@ def main():
     ap.add_argument("--coalesce", type=int, default=0,
                     help="steps (batches) submitted together through lcd_batch_run_many: one set of launches per stage over the chains of "
                          "all of them, so that the GPU's workgroup dispatcher -- not HIP streams -- packs several chunks' chains onto the CUs")
+    ap.add_argument("--overlap", type=int, default=-1, help="PCIe-inclusive pipeline (never `value`): two submissions of the timed region's size alternate on the GPU while a pool of "
+                    "host threads downloads and materialises the previous one's results and uploads the next one's inputs; -1 = on for the single-GPU HiFi line, 0 = off")
     ap.add_argument("--e2e", type=int, default=0, help="also time the PCIe-inclusive path with E lanes (host threads) each doing upload -> run -> download -> "
                     "materialisation of every result for its own batches, so that one lane's copies overlap another's kernels; reported under pcie_inclusive")
     args = ap.parse_args()
@@ -458,6 +460,98 @@ def main():
         e2e = {"lanes": E, "batches_per_submission": per_lane, "rounds": rounds, "seconds": round(te, 4), "regions_per_sec": round(e_regions[0] / te, 1),
                "what": "upload + run + download + materialisation of every result (strings" + (" left in HBM, variants + alleles" if args.vars == 2 else "") + "), lanes overlapped"}
 
+    # PCIe-inclusive PIPELINE (never `value`): what a caller that consumes every result on the host gets when it keeps two submissions in flight --
+    # the reference's kt_for workers do exactly that with their chunks (src/collect_var.c:2952-2969: one pass's regions are independent).  Two lanes, each with its
+    # OWN batches of the timed region's size: a lane runs its submission (the GPU phases of the two lanes are serialised by a lock: two submissions side by side only
+    # time-slice the hardware queues), then a pool of host threads does lcd_batch_download + lcd_batch_region_results_arena of every batch (and uploads the inputs
+    # again, as a new pass would) WHILE the other lane's kernels run.
+    overlap = None
+    if (args.overlap > 0 or (args.overlap < 0 and args.shape == "hifi")) and world == 1 and not job_mode and args.steps > 0 and args.vars != 2 and st is not None:
+        from concurrent.futures import ThreadPoolExecutor
+        n_sub = min(n_co, len(groups[0]))
+        n_ol = max(2, int(os.environ.get("BENCH_OVL_LANES", "2")))
+        lanes2 = [groups[0][:n_sub]] + [[align.RegionBatch(bench_opt) for _ in range(n_sub)] for _ in range(n_ol - 1)]
+        for grp_ in lanes2[1:]:
+            for q, bt in enumerate(grp_):
+                load_slot(bt, timed_regs[(q + 3) % len(timed_regs)])
+        # (measured on the 16-CPU quota of the GPU box: 6 threads x 1 -> 103 k regions/s, 10 x 1 -> 97 k, 8 x 16 (a thread team inside every call) -> 66 k: the
+        #  submission's own host threads -- job tables, launches -- need cores too, and a cgroup that runs out of quota stalls all of them)
+        n_host = int(os.environ.get("BENCH_OVL_THREADS", "0")) or max(2, min(8, (_host_cores() * 3) // 8))
+        arena_env = os.environ.get("LCD_ARENA_THREADS")
+        os.environ["LCD_ARENA_THREADS"] = os.environ.get("BENCH_OVL_ARENA_THREADS", "1")   # host threads INSIDE one lcd_batch_region_results_arena call (n_host calls run side by side)
+        pool_ex = ThreadPoolExecutor(n_host)
+        gpu_lock = threading.Lock()
+        o_err, o_bytes = [], [0]
+
+        o_t = {"wait_results": 0.0, "upload": 0.0, "wait_gpu": 0.0, "run": 0.0, "download_thread_s": 0.0, "arena_thread_s": 0.0}
+
+        def post(bt):
+            t1 = time.perf_counter()
+            bt.download()
+            t2 = time.perf_counter()
+            nreg, nbytes = bt.results_arena(parse=False)
+            t3 = time.perf_counter()
+            with lock:
+                o_t["download_thread_s"] = o_t.get("download_thread_s", 0.0) + (t2 - t1); o_t["arena_thread_s"] = o_t.get("arena_thread_s", 0.0) + (t3 - t2)
+            return nbytes
+
+        def o_lane(grp, rounds_):
+            try:
+                pending = None
+                for _ in range(rounds_):
+                    ta = time.perf_counter()
+                    if pending is not None:
+                        nb_ = sum(f.result() for f in pending)
+                        tb = time.perf_counter()
+                        with lock:
+                            o_bytes[0] += nb_; o_t["wait_results"] += tb - ta
+                        list(pool_ex.map(lambda bt: bt.upload(), grp))   # the next pass's inputs (the same regions: a caller's next chunk has the same shape), once every
+                        ta = time.perf_counter()                           # result of the last one is on the host
+                        with lock:
+                            o_t["upload"] += ta - tb
+                    with gpu_lock:
+                        tb = time.perf_counter()
+                        align.RegionBatch.run_many(grp)
+                        tc = time.perf_counter()
+                    with lock:
+                        o_t["wait_gpu"] += tb - ta; o_t["run"] += tc - tb
+                    pending = [pool_ex.submit(post, bt) for bt in grp]
+                nb_ = sum(f.result() for f in pending)
+                with lock:
+                    o_bytes[0] += nb_
+            except Exception as e:  # noqa
+                o_err.append(e)
+        for grp in lanes2:      # untimed: the second lane's buffers grow to size, every batch's host blocks are allocated once
+            o_lane(grp, 1)
+        o_rounds = 3
+        o_bytes[0] = 0
+        for k_ in o_t:
+            o_t[k_] = 0.0
+        barrier()
+        to0 = time.perf_counter()
+        ths = [threading.Thread(target=o_lane, args=(g, o_rounds)) for g in lanes2]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        barrier()
+        to = time.perf_counter() - to0
+        pool_ex.shutdown()
+        if arena_env is None:
+            os.environ.pop("LCD_ARENA_THREADS", None)
+        else:
+            os.environ["LCD_ARENA_THREADS"] = arena_env
+        if o_err:
+            raise o_err[0]
+        overlap = {"lanes": n_ol, "batches_per_submission": n_sub, "rounds_per_lane": o_rounds, "host_threads": n_host, "seconds": round(to, 4),
+                   "regions_per_sec": round(n_ol * o_rounds * n_sub * n_regions / to, 1), "result_bytes_per_submission": int(o_bytes[0] / (n_ol * o_rounds)),
+                   "lane_seconds": {k_: round(v_ / n_ol, 4) for k_, v_ in o_t.items()},
+                   "what": "two submissions in flight: lcd_batch_run_many of one while a pool of host threads runs lcd_batch_download + lcd_batch_region_results_arena + "
+                           "(then) lcd_batch_upload for every batch of the other; every result byte lands in host memory (one block per batch)"}
+        for grp_ in lanes2[1:]:
+            for bt in grp_:
+                bt.close()
+
     # PCIe-inclusive figure for DESIGN.md (never `value`)
     digest, t_dl, t_ar, arena_bytes = 0, 0.0, 0.0, 0
     if st is not None:
@@ -576,7 +670,10 @@ def main():
             "depth": depth,
             "device_memory": {"library_buffers_gb": round(dev_gb, 2), "allocations_inside_timed_region": int(allocs_timed)},
             "pcie_inclusive": {"upload_s": round(t_up, 4), "download_and_materialize_s": round(t_dl, 4),
-                               "regions_per_sec": round(tot_regions / max(world, 1) / steps / (t_up + ms_step / 1e3 + t_dl), 2),
+                               # the pipelined rate when it was measured (two submissions in flight, see `pipeline`); else the serial sum of one batch's phases
+                               "regions_per_sec": overlap["regions_per_sec"] if overlap else round(tot_regions / max(world, 1) / steps / (t_up + ms_step / 1e3 + t_dl), 2),
+                               "regions_per_sec_one_batch_serial": round(tot_regions / max(world, 1) / steps / (t_up + ms_step / 1e3 + t_dl), 2),
+                               "pipeline": overlap,
                                "download_and_arena_s": round(t_ar, 4), "arena_bytes": int(arena_bytes),
                                "regions_per_sec_arena": round(tot_regions / max(world, 1) / steps / (t_up + ms_step / 1e3 + t_ar), 2) if t_ar > 0 else None,
                                "what": "one batch: upload + its share of the timed run + download + every result on the host -- one malloc() per row as the reference's contract "
