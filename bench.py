@@ -274,8 +274,21 @@ def main():
         queue = [(sum(rb.region_cost(r) for r in regs), rb.pack_regions(regs)) for regs in timed_regs]
         if world > 1 and args.rebalance:
             t_rb = time.perf_counter()
-            queue, rb_stats = rb.rebalance(queue, device=dev)
+            depth_before = len(queue)
+            if os.environ.get("LCD_REBALANCE_VIA", "torch") == "lib":   # the epoch inside liblcd_hotpath.so (lcd_rebalance_exchange over librccl); the id travels by torch
+                uid = [rb.Comm.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                comm = rb.Comm(world, rank, uid[0], local_rank)
+                queue, rb_stats = rb.rebalance_c(comm, queue)
+                comm.close()
+            else:                                                        # the same plan (lcd_rebalance_plan), torch.distributed's RCCL point-to-point as the transport
+                queue, rb_stats = rb.rebalance(queue, device=dev)
             rb_stats["seconds"] = round(time.perf_counter() - t_rb, 4)
+            # every rank's queue depth and load before / after the epoch, so that a scaling run shows what the epoch did
+            dl = torch.tensor([depth_before, len(queue), sum(c for c, _ in queue)], dtype=torch.float64, device=dev); al = [torch.zeros_like(dl) for _ in range(world)]
+            dist.all_gather(al, dl)
+            rb_stats["queue_depth_before_per_rank"] = [int(x[0].item()) for x in al]; rb_stats["queue_depth_after_per_rank"] = [int(x[1].item()) for x in al]
+            rb_stats["load_after_per_rank"] = [float(x[2].item()) for x in al]
         else:
             loads = [sum(c for c, _ in queue)]
             if world > 1:

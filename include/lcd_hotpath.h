@@ -214,6 +214,36 @@ int lcd_dispatch_busy(const lcd_dispatch_t *d, double *busy_ms, int *n_submissio
 double lcd_batch_cost(const lcd_batch_t *b);   /* the work estimate the queue is ordered by (DP cells of the batch's chains) */
 /* longest-processing-time assignment of n costs to n_bins bins (static sharding across processes / ranks: bench.py --job-mb) */
 void lcd_lpt_assign(int n, const double *cost, int n_bins, int *bin_of, double *bin_load);
+/* ---- one process per GPU: cross-rank rebalancing of region queues (the reference's analogue inside one process is kt_for's work stealing,
+ * src/kthread.c:24-64, called at src/call_var_main.c:773).  One epoch before the hot path: every rank packs its region jobs chunk by chunk
+ * (lcd_region_jobs_pack: the arguments of lcd_batch_add_region, byte for byte) and prices them (lcd_region_job_cost); lcd_rebalance_exchange all-gathers the queue
+ * depths and the (cost, bytes) tables over RCCL, computes the same plan on every rank (lcd_rebalance_plan) and moves WHOLE packed buffers with ncclSend / ncclRecv;
+ * the receiver adds them to its batches with lcd_batch_add_packed.  No data-path collective (chunks are independent until stitch_var_main, src/collect_var.c:2983).
+ * librccl is opened lazily by lcd_comm_create. */
+typedef struct lcd_region_job_t {      /* the arguments of lcd_batch_add_region */
+    int64_t reg_len; int n_reads;
+    const int *read_ids, *lens; const uint8_t *const *seqs; const uint8_t *const *quals /* NULL, or NULL entries: zeros travel */;
+    const int *fully_covers, *haps; const int64_t *phase_sets; const uint8_t *ref_seq; int ref_seq_len;
+} lcd_region_job_t;
+typedef struct lcd_move_t { int src, index /* in src's queue */, dst; } lcd_move_t;
+typedef struct lcd_rebalance_stats_t { int n_moves, world; uint64_t moved_bytes; double imbalance_before, imbalance_after /* max load / mean load over the ranks */;
+                                       double load_before_mine, load_after_mine; int jobs_before_mine, jobs_after_mine; } lcd_rebalance_stats_t;
+typedef struct lcd_comm_s lcd_comm_t;
+double lcd_region_job_cost(const lcd_region_job_t *job);                                  /* DP-cell estimate: banded K1 chains if any read is phased, else the unbanded K2 chain */
+uint64_t lcd_region_jobs_pack(int n, const lcd_region_job_t *jobs, uint8_t *buf);         /* buf == NULL: the size; else fills buf (that many bytes) */
+int lcd_batch_add_packed(lcd_batch_t *b, const uint8_t *buf, uint64_t nbytes);            /* -> regions added (lcd_batch_add_region each), < 0: malformed (lcd_rebalance_last_error) */
+/* costs: every rank's job costs, rank after rank (n_jobs[r] each); moves: room for sum(n_jobs) entries.  From the most loaded rank to the least loaded one, the job
+ * that brings the pair closest to equal, until the most loaded rank is within tol of the mean or max_moves (< 0: no limit) are made; a job moves at most once.
+ * Deterministic.  Returns the number of moves; load_before / load_after (world entries each, nullable). */
+int lcd_rebalance_plan(int world, const int *n_jobs, const double *costs, double tol, int max_moves, lcd_move_t *moves, double *load_before, double *load_after);
+int lcd_rccl_unique_id(uint8_t id[128]);                                                   /* ncclGetUniqueId on rank 0; the caller gives the bytes to the other ranks */
+lcd_comm_t *lcd_comm_create(int world, int rank, const uint8_t id[128], int device);       /* ncclCommInitRank; NULL on failure */
+void lcd_comm_destroy(lcd_comm_t *c);
+/* One epoch.  In: this rank's queue.  Out (arrays malloc()'d): its new queue -- kept jobs (bufs_out[i] is the caller's pointer, owned_out[i] = 0) and received ones
+ * (malloc()'d buffers, owned_out[i] = 1: the caller frees them). */
+int lcd_rebalance_exchange(lcd_comm_t *c, int n_jobs, const double *cost, const uint64_t *nbytes, const uint8_t *const *bufs, double tol,
+                           int *n_out, double **cost_out, uint64_t **nbytes_out, uint8_t ***bufs_out, uint8_t **owned_out, lcd_rebalance_stats_t *stats);
+const char *lcd_rebalance_last_error(void);
 /* region results; clu_read_ids[c] and aln_strs[c][j].target_aln are malloc()'d (aln_strs[c] must hold 1+2*n_reads zeroed entries) */
 int lcd_batch_region_result(lcd_batch_t *b, int region, int *clu_n_seqs, int **clu_read_ids, lcd_aln_str_t **aln_strs);
 /* ---- candidate variants of a region + the read x variant allele profile (opt.collect_noisy_vars) ----

@@ -7,6 +7,8 @@ identically on every rank, and point-to-point sends of WHOLE packed job buffers 
 RCCL over xGMI with backend "nccl" on the GPU node (device tensors) and gloo in the CPU tests (host tensors).  Job buffers are 15 KB - a few MB, so
 ring / per-link bandwidth is irrelevant; what matters is that a job moves at most once per epoch and that every rank agrees on the plan.
 """
+import ctypes as C
+
 import numpy as np
 
 MAGIC = 0x4C434452  # 'LCDR'
@@ -65,7 +67,85 @@ def unpack_regions(buf):
     return out
 
 
+class _RegionJob(C.Structure):
+    _fields_ = [("reg_len", C.c_int64), ("n_reads", C.c_int), ("read_ids", C.POINTER(C.c_int)), ("lens", C.POINTER(C.c_int)), ("seqs", C.POINTER(C.POINTER(C.c_uint8))),
+                ("quals", C.POINTER(C.POINTER(C.c_uint8))), ("fully_covers", C.POINTER(C.c_int)), ("haps", C.POINTER(C.c_int)), ("phase_sets", C.POINTER(C.c_int64)),
+                ("ref_seq", C.POINTER(C.c_uint8)), ("ref_seq_len", C.c_int)]
+
+
+class _Move(C.Structure):
+    _fields_ = [("src", C.c_int), ("index", C.c_int), ("dst", C.c_int)]
+
+
+def _clib():
+    from ._lib import load_library
+    lib = load_library()
+    if not getattr(lib, "_rb_ready", False):
+        lib.lcd_region_job_cost.restype = C.c_double
+        lib.lcd_region_job_cost.argtypes = [C.POINTER(_RegionJob)]
+        lib.lcd_region_jobs_pack.restype = C.c_uint64
+        lib.lcd_region_jobs_pack.argtypes = [C.c_int, C.POINTER(_RegionJob), C.c_void_p]
+        lib.lcd_batch_add_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        lib.lcd_rebalance_plan.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_double, C.c_int, C.POINTER(_Move), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        lib.lcd_rebalance_last_error.restype = C.c_char_p
+        lib._rb_ready = True
+    return lib
+
+
+def _c_jobs(regs):
+    """the regions as lcd_region_job_t records (+ the arrays they point into, which the caller keeps alive)"""
+    keep, jobs = [], (_RegionJob * max(len(regs), 1))()
+    u8pp = C.POINTER(C.c_uint8)
+    for k, r in enumerate(regs):
+        n = len(r["seqs"])
+        ids = np.ascontiguousarray(r["read_ids"], np.int32); cov = np.ascontiguousarray(r["covers"], np.int32); haps = np.ascontiguousarray(r["haps"], np.int32)
+        ps = np.ascontiguousarray(r["phase_sets"], np.int64); lens = np.array([len(x) for x in r["seqs"]], np.int32); ref = np.ascontiguousarray(r["ref"], np.uint8)
+        seqs = [np.ascontiguousarray(x, np.uint8) for x in r["seqs"]]
+        q = r.get("quals")
+        quals = [np.ascontiguousarray(x, np.uint8) for x in q] if q is not None else None
+        sp = (u8pp * max(n, 1))(*[x.ctypes.data_as(u8pp) for x in seqs])
+        qp = (u8pp * max(n, 1))(*[x.ctypes.data_as(u8pp) for x in quals]) if quals is not None else None
+        keep += [ids, cov, haps, ps, lens, ref, seqs, quals, sp, qp]
+        j = jobs[k]
+        j.reg_len, j.n_reads, j.ref_seq_len = int(r["reg_len"]), n, len(ref)
+        j.read_ids = ids.ctypes.data_as(C.POINTER(C.c_int)); j.lens = lens.ctypes.data_as(C.POINTER(C.c_int)); j.seqs = sp
+        j.quals = qp if qp is not None else C.POINTER(u8pp)()
+        j.fully_covers = cov.ctypes.data_as(C.POINTER(C.c_int)); j.haps = haps.ctypes.data_as(C.POINTER(C.c_int)); j.phase_sets = ps.ctypes.data_as(C.POINTER(C.c_int64))
+        j.ref_seq = ref.ctypes.data_as(u8pp)
+    return jobs, keep
+
+
+def region_cost_c(reg):
+    """lcd_region_job_cost (liblcd_hotpath.so): the library's own price of a region job"""
+    jobs, keep = _c_jobs([reg])
+    return float(_clib().lcd_region_job_cost(C.byref(jobs[0])))
+
+
+def pack_regions_c(regs):
+    """lcd_region_jobs_pack (liblcd_hotpath.so): the same bytes as pack_regions"""
+    lib = _clib()
+    jobs, keep = _c_jobs(regs)
+    n = int(lib.lcd_region_jobs_pack(len(regs), jobs, None))
+    buf = np.zeros(n, np.uint8)
+    assert int(lib.lcd_region_jobs_pack(len(regs), jobs, buf.ctypes.data_as(C.c_void_p))) == n
+    return buf
+
+
 def plan_moves(costs_per_rank, tol=0.02, max_moves=None):
+    """lcd_rebalance_plan (liblcd_hotpath.so): the plan every rank computes from the gathered queues.  -> list of (src_rank, index in src's queue, dst_rank),
+    loads before, loads after.  (plan_moves_py below is the same rule in Python: the tests hold the two together.)"""
+    lib = _clib()
+    world = len(costs_per_rank)
+    nj = np.array([len(c) for c in costs_per_rank], np.int32)
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(c, np.float64) for c in costs_per_rank]) if nj.sum() else np.zeros(1), np.float64)
+    moves = (_Move * (int(nj.sum()) + 1))()
+    lb, la = np.zeros(max(world, 1), np.float64), np.zeros(max(world, 1), np.float64)
+    n = lib.lcd_rebalance_plan(world, nj.ctypes.data_as(C.POINTER(C.c_int)), flat.ctypes.data_as(C.POINTER(C.c_double)), float(tol), -1 if max_moves is None else int(max_moves),
+                               moves, lb.ctypes.data_as(C.POINTER(C.c_double)), la.ctypes.data_as(C.POINTER(C.c_double)))
+    return [(int(moves[i].src), int(moves[i].index), int(moves[i].dst)) for i in range(n)], [float(x) for x in lb[:world]], [float(x) for x in la[:world]]
+
+
+def plan_moves_py(costs_per_rank, tol=0.02, max_moves=None):
     """deterministic greedy plan: repeatedly move, from the most loaded rank to the least loaded one, the job that brings the pair closest to equal
     (a job moves at most once).  -> list of (src_rank, index in src's queue, dst_rank), loads before, loads after"""
     load = [float(sum(c)) for c in costs_per_rank]
@@ -124,4 +204,69 @@ def rebalance(queue, group=None, device=None, tol=0.02):
     mean = sum(before) / world if world else 0.0
     stats = dict(n_moves=len(moves), moved_bytes=int(moved_bytes), imbalance_before=(max(before) / mean if mean > 0 else 1.0),
                  imbalance_after=(max(after) / mean if mean > 0 else 1.0), loads_before=before, loads_after=after)
+    return new_q, stats
+
+
+class _RbStats(C.Structure):
+    _fields_ = [("n_moves", C.c_int), ("world", C.c_int), ("moved_bytes", C.c_uint64), ("imbalance_before", C.c_double), ("imbalance_after", C.c_double),
+                ("load_before_mine", C.c_double), ("load_after_mine", C.c_double), ("jobs_before_mine", C.c_int), ("jobs_after_mine", C.c_int)]
+
+
+class Comm:
+    """lcd_comm_create: an RCCL communicator owned by the library (librccl opened lazily).  `uid` = the 128 bytes of lcd_rccl_unique_id made on rank 0 and handed
+    to the others by the caller (bench.py: torch.distributed's broadcast_object_list)."""
+
+    def __init__(self, world, rank, uid, device):
+        lib = _clib()
+        lib.lcd_comm_create.restype = C.c_void_p
+        lib.lcd_comm_create.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+        lib.lcd_comm_destroy.argtypes = [C.c_void_p]; lib.lcd_comm_destroy.restype = None
+        self.lib, self.world, self.rank = lib, world, rank
+        self.h = lib.lcd_comm_create(int(world), int(rank), bytes(uid), int(device))
+        if not self.h:
+            raise RuntimeError("lcd_comm_create: " + lib.lcd_rebalance_last_error().decode())
+
+    @staticmethod
+    def unique_id():
+        lib = _clib()
+        buf = C.create_string_buffer(128)
+        lib.lcd_rccl_unique_id.argtypes = [C.c_char_p]
+        if lib.lcd_rccl_unique_id(buf) != 0:
+            raise RuntimeError("lcd_rccl_unique_id: " + lib.lcd_rebalance_last_error().decode())
+        return buf.raw
+
+    def close(self):
+        if self.h:
+            self.lib.lcd_comm_destroy(self.h); self.h = None
+
+
+def rebalance_c(comm, queue, tol=0.02):
+    """One epoch through the LIBRARY (lcd_rebalance_exchange: ncclAllGather of the queue depths and (cost, bytes) tables, lcd_rebalance_plan, ncclSend / ncclRecv of
+    whole packed buffers).  queue: list of (cost, packed uint8 buffer) of this rank -> (new queue, stats)."""
+    lib = comm.lib
+    n = len(queue)
+    cost = np.array([c for c, _ in queue] or [0.0], np.float64)
+    bufs = [np.ascontiguousarray(b, np.uint8) for _, b in queue]
+    nb = np.array([len(b) for b in bufs] or [0], np.uint64)
+    u8p = C.POINTER(C.c_uint8)
+    bp = (u8p * max(n, 1))(*[b.ctypes.data_as(u8p) for b in bufs])
+    n_out = C.c_int(0); co = C.POINTER(C.c_double)(); no = C.POINTER(C.c_uint64)(); bo = C.POINTER(u8p)(); ow = u8p(); st = _RbStats()
+    lib.lcd_rebalance_exchange.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(u8p), C.c_double, C.POINTER(C.c_int),
+                                           C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(u8p)), C.POINTER(u8p), C.POINTER(_RbStats)]
+    rc = lib.lcd_rebalance_exchange(comm.h, n, cost.ctypes.data_as(C.POINTER(C.c_double)), nb.ctypes.data_as(C.POINTER(C.c_uint64)), bp, float(tol), C.byref(n_out),
+                                    C.byref(co), C.byref(no), C.byref(bo), C.byref(ow), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("lcd_rebalance_exchange: " + lib.lcd_rebalance_last_error().decode())
+    libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]
+    new_q = []
+    for i in range(n_out.value):
+        b = np.ctypeslib.as_array(bo[i], shape=(max(int(no[i]), 1),))[:int(no[i])].copy()
+        new_q.append((float(co[i]), b))
+        if ow[i]:
+            libc.free(C.cast(bo[i], C.c_void_p))
+    for p_ in (co, no, bo, ow):
+        libc.free(C.cast(p_, C.c_void_p))
+    stats = dict(n_moves=st.n_moves, moved_bytes=int(st.moved_bytes), imbalance_before=st.imbalance_before, imbalance_after=st.imbalance_after,
+                 load_before_mine=st.load_before_mine, load_after_mine=st.load_after_mine, jobs_before_mine=st.jobs_before_mine, jobs_after_mine=st.jobs_after_mine,
+                 transport="librccl via liblcd_hotpath.so (lcd_rebalance_exchange)")
     return new_q, stats

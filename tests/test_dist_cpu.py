@@ -22,7 +22,7 @@ rank, world = dist.get_rank(), dist.get_world_size()
 n_chunks = 12
 lo, hi = rank * n_chunks // world, (rank + 1) * n_chunks // world
 chunks = {i: jobs.make_regions(4000 + i, 6 if i < 6 else 3, jobs.SV if i in (0, 1, 2, 4) else jobs.HIFI, poisson_sv=False) for i in range(lo, hi)}
-queue = [(sum(rb.region_cost(r) for r in regs), rb.pack_regions(regs)) for _, regs in sorted(chunks.items())]
+queue = [(sum(rb.region_cost_c(r) for r in regs), rb.pack_regions_c(regs)) for _, regs in sorted(chunks.items())]   # price and wire format: the library's (lcd_region_job_cost, lcd_region_jobs_pack)
 dig = lambda b: hashlib.sha1(np.ascontiguousarray(b).tobytes()).hexdigest()
 before = [dig(b) for _, b in queue]
 new_q, st = rb.rebalance(queue, tol=0.05)
@@ -154,3 +154,30 @@ def test_job_mb_block_and_batch_arithmetic_of_bench():
             assert sorted(flat) == list(range(len(q))) and all(len(b_) <= 20 for b_ in bt)
             cs = [q[i][2] for i in flat]
             assert cs == sorted(cs, reverse=True)
+
+
+def test_c_plan_pack_and_cost_equal_the_python_definitions():
+    """the queue rebalance's plan, wire format and price live in the library (lcd_rebalance_plan, lcd_region_jobs_pack, lcd_region_job_cost:
+    longcalld_amd/csrc/lcd_rebalance.cpp); rebalance.py is a thin caller.  Held against the Python definitions they replace: same moves on random queues (ties,
+    empty queues, one rank, jobs bigger than the gap), byte-identical packed buffers, the same costs."""
+    from longcalld_amd import jobs, rebalance as rb
+    rng = np.random.default_rng(11)
+    for trial in range(300):
+        world = int(rng.integers(1, 9))
+        costs = []
+        for r in range(world):
+            n = int(rng.integers(0, 9))
+            c = rng.choice([0.0, 1.0, 2.0, 2.0, 5.0, 1e3, 7.5e6], n) if trial % 3 == 0 else rng.lognormal(10, 1.5, n)
+            costs.append([float(x) for x in c])
+        tol = float(rng.choice([0.0, 0.02, 0.05, 0.3]))
+        mm = None if trial % 4 else int(rng.integers(0, 4))
+        assert rb.plan_moves(costs, tol, mm) == rb.plan_moves_py(costs, tol, mm), (trial, costs)
+    regs = jobs.make_regions(77, 5, jobs.HIFI) + jobs.make_regions(78, 2, jobs.SV, poisson_sv=False)
+    for r in regs:
+        assert rb.region_cost_c(r) == rb.region_cost(r)
+    assert (rb.pack_regions_c(regs) == rb.pack_regions(regs)).all()
+    assert (rb.pack_regions_c([]) == rb.pack_regions([])).all()
+    noq = [dict(r, quals=None) for r in regs[:2]]
+    assert (rb.pack_regions_c(noq) == rb.pack_regions(noq)).all()
+    back = rb.unpack_regions(rb.pack_regions_c(regs))
+    assert len(back) == len(regs) and all((a == b).all() for x, y in zip(back, regs) for a, b in zip(x["seqs"], y["seqs"]))
