@@ -408,6 +408,10 @@ int lcd_pre_process_noisy_regs(const lcd_noisy_iv_t *chunk_noisy, int n_noisy, c
                                const int64_t *read_end, const uint64_t *read_iv_off, const lcd_noisy_iv_t *read_ivs, int min_alt_dp, float min_af,
                                lcd_noisy_iv_t **regs_out);
 
+/* cr_merge (src/cgranges.h:73, src/cgranges.c:289): the interval merge chunk_noisy_regs goes through (src/collect_var.c:552, :568 with a negative fixed window =
+ * "the smaller of the two labels"; :657 with 0).  Pinned to the reference's own cgranges by tests/golden/cgranges_golden.json.  *out malloc()'d. */
+int lcd_cr_merge(const lcd_noisy_iv_t *iv, int n, int fixed_merge_win, lcd_noisy_iv_t **out);
+
 /* post_process_noisy_regs (src/collect_var.c:640-660, collect_noisy_reg_start_end :481-536): every region is grown by noisy_reg_flank_len and
  * further while a candidate variant (categories outside LONGCALLD_NOT_CAND_VAR_CATE, src/collect_var.h:28) sits within the flank, then overlapping /
  * touching regions are merged (cr_merge(cr, 0, -1, -1)).  Host code, as in the reference (a two-pointer walk over tens of regions); it closes the

@@ -684,6 +684,22 @@ def post_process_noisy_regs(regs, var_pos, var_ref_len, var_cate, flank=10):
     return res
 
 
+def cr_merge(ivs, fixed_merge_win=-1):
+    """lcd_cr_merge: cr_merge (src/cgranges.c:289) of (n,3) (start, end, label) intervals -> merged (m,3)"""
+    lib = load_library()
+    r = np.asarray(ivs, np.int64).reshape(-1, 3)
+    arr = (LcdNoisyIv * max(len(r), 1))()
+    for i, row in enumerate(r):
+        arr[i].start, arr[i].end, arr[i].label = int(row[0]), int(row[1]), int(row[2])
+    out = C.POINTER(LcdNoisyIv)()
+    lib.lcd_cr_merge.argtypes = [C.POINTER(LcdNoisyIv), C.c_int, C.c_int, C.POINTER(C.POINTER(LcdNoisyIv))]
+    n = lib.lcd_cr_merge(arr, len(r), int(fixed_merge_win), C.byref(out))
+    res = np.array([[out[i].start, out[i].end, out[i].label] for i in range(n)], np.int64).reshape(-1, 3)
+    if out:
+        _libc.free(C.cast(out, C.c_void_p))
+    return res
+
+
 def sdust(seq, T=5, W=20):
     """low-complexity intervals (src/sdust.c) of a code / letter sequence on the GPU -> (n, 2) array of (start, finish)"""
     lib = load_library()

@@ -183,8 +183,9 @@ __global__ void __launch_bounds__(64) lcd_edlib_kernel(const EdJob *jobs, const 
     EdOut out; out.status = LCD_OK; out.dist = -1; out.xgaps = 0; out.n_eq = 0; out.n_xid = 0; out.blocks = 0; out.start = 0; out.end = jb.tlen - 1;
     const uint8_t *q = pool + jb.q_off, *t = pool + jb.t_off;
     const int qlen = jb.qlen, tlen = jb.tlen;
-    if (qlen == 0 || tlen == 0) { // edlib.cpp:166-173: distance only, no alignment
-        out.dist = qlen > tlen ? qlen : tlen;
+    if (qlen == 0 || tlen == 0) { // edlib.cpp:166-177: distance only, no alignment.  NW: the longer side; HW: the query's length (an empty query matches the empty infix), end -1
+        out.dist = jb.mode == 1 ? qlen : (qlen > tlen ? qlen : tlen);
+        if (jb.mode == 1) { out.start = -1; out.end = -1; }
         if (lane == 0) outs[jb.pad_] = out;
         return;
     }
@@ -203,6 +204,12 @@ __global__ void __launch_bounds__(64) lcd_edlib_kernel(const EdJob *jobs, const 
         // prefix that ends there (anchored, the LAST position with the best score = the longest stretch); the path is then the NW path on that stretch
         int best, endf, endl, best2, sf, sl;
         sg_pass<0>(top, tlen, false, lane, hcarry, &blocks, &best, &endf, &endl);
+        if (best >= qlen) { // no end position beats "the whole query in front of the target": edlib reports end -1 (the padded last block sees that position first,
+            out.dist = qlen; out.start = 0; out.end = -1;            // edlib.cpp:659-691), takes 0 as its start (:236) and aligns against an empty target: qlen insertions
+            out.xgaps = 1; out.n_eq = 0; out.n_xid = qlen; out.blocks = blocks;
+            if (lane == 0) outs[jb.pad_] = out;
+            return;
+        }
         Sub pre = {q, t, qlen, endf + 1};
         sg_pass<1>(pre, endf + 1, true, lane, hcarry, &blocks, &best2, &sf, &sl);
         if (best2 != best || endf < 0 || sl < 0) { out.status = LCD_ERR_BACKTRACK; if (lane == 0) outs[jb.pad_] = out; return; }

@@ -2567,7 +2567,7 @@ void niv_index(std::vector<NIv> &v) {
 void niv_add(std::vector<NIv> &v, long long st, long long en, int label) { if (st < 0) st = 0; if (st > en) return; v.push_back({(uint64_t)st, en, label}); } // cr_add :145-149
 // cr_merge(cr, -1, ...) (src/cgranges.c:225-300): passes of "merge every later interval that starts within min(label, label') of the running end"
 // until the number of intervals stops changing; each pass re-indexes
-void niv_merge(std::vector<NIv> &v) {
+void niv_merge(std::vector<NIv> &v, const int fixed_win = -1) { // fixed_win >= 0: cr_merge(cr, fixed_win, ..): that window instead of the smaller label
     size_t cur = v.size();
     for (;;) {
         std::vector<NIv> out; std::vector<char> merged(v.size(), 0);
@@ -2576,7 +2576,7 @@ void niv_merge(std::vector<NIv> &v) {
             uint64_t ms = v[j].x; long long me = v[j].en; int ml = v[j].label;
             for (size_t k = j + 1; k < v.size(); ++k) {
                 if (merged[k]) continue;
-                const int win = ml < v[k].label ? ml : v[k].label;
+                const int win = fixed_win >= 0 ? fixed_win : (ml < v[k].label ? ml : v[k].label);
                 if ((uint64_t)(me + win) >= v[k].x) { ml = std::max(ml, v[k].label); ms = std::min(ms, v[k].x); me = std::max(me, v[k].en); merged[k] = 1; }
             }
             niv_add(out, (long long)ms, me, ml);
@@ -2674,6 +2674,21 @@ int lcd_pre_process_noisy_regs(const lcd_noisy_iv_t *chunk_noisy, int n_noisy, c
     }
     *regs_out = out;
     return n_out;
+}
+
+// cr_merge (src/cgranges.c:289-300; cr_cluster0 :225-268) of n labelled intervals: cr_add (negative starts clamped to 0, st > en dropped), cr_index, then passes of
+// "from every interval not yet merged, swallow every later one that starts within the window of the running end" until the count stops changing.  Window:
+// fixed_merge_win if >= 0 (src/collect_var.c:657 uses 0), else the smaller of the two labels (the dynamic window and its label minimum are not used by the
+// reference's code: src/cgranges.c:248-254).  Host code, as in the reference.  *out malloc()'d, index order; returns the number of merged intervals.
+int lcd_cr_merge(const lcd_noisy_iv_t *iv, int n, int fixed_merge_win, lcd_noisy_iv_t **out) {
+    std::vector<NIv> v;
+    for (int i = 0; i < n; ++i) niv_add(v, iv[i].start, iv[i].end, iv[i].label);
+    niv_index(v);
+    niv_merge(v, fixed_merge_win);
+    lcd_noisy_iv_t *o = (lcd_noisy_iv_t *)calloc(v.size() + 1, sizeof(lcd_noisy_iv_t));
+    for (size_t i = 0; i < v.size(); ++i) { o[i].start = (int64_t)v[i].x; o[i].end = v[i].en; o[i].label = v[i].label; }
+    *out = o;
+    return (int)v.size();
 }
 
 // post_process_noisy_regs (src/collect_var.c:640-660) -- host glue, see include/lcd_hotpath.h

@@ -197,7 +197,8 @@ int lcdo_edlib_hw(const uint8_t *query, int qlen, const uint8_t *target, int tle
     if (aln) { *aln = NULL; *aln_len = 0; }
     if (start_out) *start_out = -1;
     if (end_out) *end_out = -1;
-    if (qlen == 0 || tlen == 0) return qlen > tlen ? qlen : tlen; /* edlib.cpp:166-173 (mode-independent): distance only */
+    if (qlen == 0 || tlen == 0) return qlen; /* edlib.cpp:166-177: in HW (and SHW) mode an empty side gives editDistance = queryLength -- an empty query matches the empty infix --
+                                               * and endLocations[0] = -1, no path (NW: max of the lengths).  Pinned by the round-4 HW vectors of tests/golden/edlib_golden.json */
     int *prev = (int *)malloc((size_t)(tlen + 1) * sizeof(int)), *cur = (int *)malloc((size_t)(tlen + 1) * sizeof(int));
     for (int j = 0; j <= tlen; ++j) prev[j] = 0;                       /* free start anywhere in the target */
     for (int i = 1; i <= qlen; ++i) {
@@ -208,8 +209,16 @@ int lcdo_edlib_hw(const uint8_t *query, int qlen, const uint8_t *target, int tle
         }
         int *t = prev; prev = cur; cur = t;
     }
-    int best = 1 << 30, end0 = -1;
-    for (int j = 1; j <= tlen; ++j) if (prev[j] < best) { best = prev[j]; end0 = j - 1; } /* the first end position with the best score */
+    /* the first end position with the best score.  Position -1 -- the query placed in front of the target, score qlen -- is a candidate too (edlib.cpp:659-691: the
+     * padded last block reports it through "c - W" / "targetLength - W + i"; :222-236 then takes 0 as its start), so a query that matches nothing ends at -1 */
+    int best = qlen, end0 = -1;
+    for (int j = 1; j <= tlen; ++j) if (prev[j] < best) { best = prev[j]; end0 = j - 1; }
+    if (end0 < 0) { /* all of the query inserted in front of the target: start 0 (edlib.cpp:236), the path of an empty target (obtainAlignment: queryLength insertions) */
+        free(prev); free(cur);
+        if (start_out) *start_out = 0;
+        if (aln) { *aln = (uint8_t *)malloc((size_t)qlen + 1); for (int i = 0; i < qlen; ++i) (*aln)[i] = LCDO_EDOP_INSERT; *aln_len = qlen; }
+        return best;
+    }
     /* start: reversed query vs the reversed prefix target[0 .. end0], anchored at its first character */
     const int plen = end0 + 1;
     for (int j = 0; j <= plen; ++j) prev[j] = j;

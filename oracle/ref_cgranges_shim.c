@@ -148,3 +148,17 @@ int ref_post_process_noisy_regs(int n_regs, const int *regs, int n_vars, const i
     cr_destroy(nw); free(maxl); free(minr); free(st); free(en);
     return m;
 }
+
+/* cr_merge(cr, fixed_merge_win, dynamic_merge_win, dynamic_merge_label_min) (src/cgranges.c:289) on n labelled intervals: the merged intervals (st, en, label) in
+ * index order; returns their number.  (collect_var.c calls it with (-1, noisy_reg_merge_dis, min_sv_len) and with (0, -1, -1).) */
+int ref_cr_merge(int n, const int *st, const int *en, const int *label, int fixed_win, int dyn_win, int dyn_label_min, int *out, int cap) {
+    cgranges_t *cr = cr_init();
+    for (int i = 0; i < n; ++i) cr_add(cr, "cr", st[i], en[i], label[i]);
+    cr_index(cr);
+    cr = cr_merge(cr, fixed_win, dyn_win, dyn_label_min);
+    int k = 0;
+    for (int64_t i = 0; i < cr->n_r && k < cap; ++i, ++k) { out[3 * k] = cr_start(cr, i); out[3 * k + 1] = cr_end(cr, i); out[3 * k + 2] = cr_label(cr, i); }
+    const int total = (int)cr->n_r;
+    cr_destroy(cr);
+    return total;
+}

@@ -58,6 +58,26 @@ def main():
         d, s0, e0, ops = pyoracle.ref_edlib_hw(q, t)
         hw_cases.append(dict(target="".join(map(str, t)), query="".join(map(str, q)), dist=int(d), start=int(s0), end=int(e0), xgaps=int(pyoracle.ops_to_xgaps(ops)),
                              n_eq=int((ops == 0).sum()), n_xid=int((ops != 0).sum()), path_sha1=hashlib.sha1(ops.tobytes()).hexdigest()))
+    # round 4: the corners of HW mode -- an empty query, a query longer than its target, a target of one base, and distances on either side of
+    # the band doublings of edlibAlign (k = 64, 128, 256: edlib/src/edlib.cpp:185-200 starts at 64 and doubles until the distance fits)
+    rng3 = np.random.default_rng(20250931)
+    extra = [(rng3.integers(0, 4, 40).astype(np.uint8), np.zeros(0, np.uint8)), (rng3.integers(0, 4, 30).astype(np.uint8), rng3.integers(0, 4, 100).astype(np.uint8)),
+             (rng3.integers(0, 4, 64).astype(np.uint8), rng3.integers(0, 4, 65).astype(np.uint8)), (np.array([2], np.uint8), np.array([2], np.uint8)), (np.array([2], np.uint8), np.array([1, 3, 0], np.uint8))]
+    for d_want in (62, 63, 64, 65, 66, 126, 127, 128, 129, 130, 255, 256, 257):
+        L = 5 * d_want + 40
+        t = rng3.integers(0, 4, 3 * L).astype(np.uint8)
+        a = int(rng3.integers(10, len(t) - L - 10))
+        q = t[a:a + L].copy()
+        for ppos in np.linspace(2, L - 3, d_want).astype(int):     # d_want substitutions, evenly spread: the infix distance is d_want (or just below it)
+            q[ppos] = (q[ppos] + 1 + int(rng3.integers(0, 3))) % 4
+        extra.append((t, q))
+    # 64 / 65 / 128 / 129-base queries (one / two / three Myers blocks exactly full) against unrelated targets: distances close to the query length
+    for L in (63, 64, 65, 127, 128, 129):
+        extra.append((rng3.integers(0, 4, 4 * L).astype(np.uint8), rng3.integers(0, 4, L).astype(np.uint8)))
+    for t, q in extra:
+        d, s0, e0, ops = pyoracle.ref_edlib_hw(q, t)
+        hw_cases.append(dict(target="".join(map(str, t)), query="".join(map(str, q)), dist=int(d), start=int(s0), end=int(e0), xgaps=int(pyoracle.ops_to_xgaps(ops)),
+                             n_eq=int((ops == 0).sum()), n_xid=int((ops != 0).sum()), path_sha1=hashlib.sha1(ops.tobytes()).hexdigest()))
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "edlib_golden.json")
     json.dump(dict(source="reference edlib (edlib/src/edlib.cpp) via oracle/_ref, NW + TASK_PATH, k=-1; hw_cases: HW + TASK_PATH", cases=cases, hw_cases=hw_cases), open(out, "w"))
     print(len(cases), "NW cases,", len(hw_cases), "HW cases ->", out, os.path.getsize(out), "bytes")

@@ -134,6 +134,19 @@ def test_pre_process_noisy_regs(lcd, oracle):
             assert exp.shape == res.shape and (exp == res).all(), (trial, min_dp)
 
 
+def test_pre_process_noisy_regs_committed_reference_vectors(lcd):
+    """the pre_process_noisy_regs cases of tests/golden/cgranges_golden.json (expected regions from the reference's own cgranges, generated by
+    tests/golden/make_cgranges_golden.py): no dependence on oracle/_ref being present on the box"""
+    import json, os
+    from conftest import ROOT
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "cgranges_golden.json")))["pre_process"]
+    assert len(cases) >= 20
+    for c in cases:
+        got = lcd.pre_process_noisy_regs(np.array(c["chunk_noisy"], np.int64).reshape(-1, 3), np.array(c["low_comp"], np.int64).reshape(-1, 2), c["read_beg"], c["read_end"],
+                                         [np.array(x, np.int64).reshape(-1, 3) for x in c["read_ivs"]], c["min_alt_dp"], c["min_af"])
+        assert got.tolist() == c["out"]
+
+
 def _lowcomp_seq(rng, n, n_frac):
     s = rng.integers(0, 4, n).astype(np.uint8)
     for _ in range(n // 400):

@@ -53,3 +53,40 @@ def test_post_process_noisy_regs_host_glue(ref):
             got = lcd.post_process_noisy_regs(regs, vp, vl, vc, flank)
             assert exp.shape == got.shape and (exp == got).all(), (trial, flank)
     assert len(lcd.post_process_noisy_regs(np.zeros((0, 3), np.int64), [], [], [])) == 0
+
+
+def _golden():
+    import json, os
+    from conftest import ROOT
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "cgranges_golden.json")))
+
+
+def test_committed_vectors_of_the_reference_cgranges(oracle):
+    """tests/golden/cgranges_golden.json (made by tests/golden/make_cgranges_golden.py from the reference's own src/cgranges.c): the pins above, independent of
+    oracle/_ref being built -- cr_index order against the oracle's restatement, cr_overlap's hit order against the rule the oracle's K5 assumes, cr_merge with both
+    parameter sets of src/collect_var.c and whole pre_ / post_process_noisy_regs cases against the library's host code (touching, nested and tied intervals, negative
+    starts, chains that need several passes, label-dependent distances)."""
+    from longcalld_amd import align as lcd
+    g = _golden()
+    for c in g["order"]:
+        st, en = np.array(c["st"], np.int32), np.array(c["en"], np.int32)
+        if (st < 0).any() or (st > en).any():
+            continue        # (cr_add clamps / drops those: the restatement is called on what cr_add keeps -- covered by the merge cases below)
+        assert oracle.cr_sorted_order(st, en).tolist() == c["order"]
+    for c in g["overlap"]:
+        st, en = np.array(c["st"], np.int32), np.array(c["en"], np.int32)
+        order = oracle.cr_sorted_order(st, en)
+        q0, q1 = c["q"]
+        assert [int(i) for i in order if st[i] < q1 and q0 < en[i]] == c["hits"]
+    n_dyn = 0
+    for c in g["merge"]:
+        fixed, dyn, lmin = c["args"]
+        ivs = np.stack([c["st"], c["en"], c["label"]], 1)
+        got = lcd.cr_merge(ivs, fixed)
+        assert got.tolist() == c["merged"], c["args"]
+        n_dyn += fixed < 0
+    assert n_dyn >= 30
+    for c in g["post_process"]:
+        got = lcd.post_process_noisy_regs(np.array(c["regs"], np.int64).reshape(-1, 3), c["var_pos"], c["var_ref_len"], c["var_cate"], c["flank"])
+        assert got.tolist() == c["out"]
+    assert len(g["pre_process"]) >= 20   # (lcd_pre_process_noisy_regs starts the device: those cases run in tests/test_gpu_digar.py)
