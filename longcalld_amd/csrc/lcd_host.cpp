@@ -233,7 +233,7 @@ struct lcd_batch_s {
     std::vector<WfaJob> wfa_jobs;
     // device
     // (d_poa_arena: the ONE transient workspace of a submission led by this batch -- chain arenas, WFA wavefronts and edlib blocks in turn)
-    DevBuf d_in, d_chains, d_preads, d_poa_arena, d_poa_out, d_poa_outs, d_ed_jobs, d_ed_outs, d_wfa_jobs,
+    DevBuf d_aends_jobs, d_aends_outs, d_in, d_chains, d_preads, d_poa_arena, d_poa_out, d_poa_outs, d_ed_jobs, d_ed_outs, d_wfa_jobs,
         d_wfa_out, d_wfa_outs, d_str_jobs, d_str_outs, d_final, d_gate, d_cmp_jobs, d_cmp_outs, d_cmp_seg, d_cmp_segres, d_seg_out, d_rr,
         d_var_jobs, d_var_outs, d_var_work, d_vreg_jobs, d_vreg_outs, d_var_out, d_slot_flags, d_spare, d_packed, d_unpack,
         d_early_arena, d_chains_early, d_preads_early, d_poa_outs_early,   // the long K2 chains that start before the anchor stage (run_many_once)
@@ -1335,15 +1335,19 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             if (th) fprintf(stderr, "[host]   anchors: WFA stage done after %.1f ms\n", now_ms() - t_begin);
             // cigars of the anchor jobs: ONE device->host copy of the output span of all of them (a copy per job costs more in
             // launch overhead than in bytes)
-            uint64_t lo = ~0ull, hi = 0;
-            for (size_t i = 0; i < wj.size(); ++i)
-                if (wo[i].n_cigar) { lo = std::min<uint64_t>(lo, wj[i].out_off); hi = std::max<uint64_t>(hi, wj[i].out_off + (uint64_t)wo[i].n_cigar * 4); }
-            if (hi > lo) {
-                L->h_cig.resize(hi - lo);
-                HIPCHK(hipMemcpyAsync(L->h_cig.data(), (void *)(uintptr_t)lo, hi - lo, hipMemcpyDeviceToHost, st));
+            // the alignments' ends (collect_aln_beg_end) are computed where the CIGARs are: 20 bytes per job come back (strings_kernel.hip lcd_anchor_ends_kernel)
+            std::vector<AnchorEndsOut> aends(wj.size());
+            if (!wj.empty()) {
+                std::vector<AnchorEndsJob> aj(wj.size());
+                for (size_t i = 0; i < wj.size(); ++i) { aj[i].cigar = wj[i].out_off; aj[i].n_cigar = wo[i].n_cigar; aj[i].pad_ = 0; }
+                if (L->d_aends_jobs.ensure(aj.size() * sizeof(AnchorEndsJob)) || L->d_aends_outs.ensure(aj.size() * sizeof(AnchorEndsOut))) return -11;
+                HIPCHK(hipMemcpyAsync(L->d_aends_jobs.p, aj.data(), aj.size() * sizeof(AnchorEndsJob), hipMemcpyHostToDevice, st));
+                lcd_launch_anchor_ends((const AnchorEndsJob *)L->d_aends_jobs.p, (AnchorEndsOut *)L->d_aends_outs.p, (int)aj.size(), st);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(aends.data(), L->d_aends_outs.p, aends.size() * sizeof(AnchorEndsOut), hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
             }
-            if (th) fprintf(stderr, "[host]   anchors: CIGARs (%.1f MB) on the host after %.1f ms\n", hi > lo ? (hi - lo) / 1e6 : 0.0, now_ms() - t_begin);
+            if (th) fprintf(stderr, "[host]   anchors: alignment ends (%.2f MB) on the host after %.1f ms\n", aends.size() * sizeof(AnchorEndsOut) / 1e6, now_ms() - t_begin);
             for (auto &e : eo) if (e.status != LCD_OK) return set_err(-20, "edlib kernel status " + std::to_string(e.status));
             for (int k = 0; k < nb; ++k) {
                 lcd_batch_t *b = bs[k]; lcd_batch_stats_t &S = b->st;
@@ -1358,17 +1362,13 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                     const size_t wi = wj_base[k] + A.wfa_job;
                     const int ncg = wo[wi].n_cigar;
                     if (ncg == 0) { pr.skip = 1; continue; }
-                    const uint32_t *c = (const uint32_t *)(L->h_cig.data() + (wj[wi].out_off - lo));
-                    // collect_aln_beg_end, src/align.c:630-663
+                    // collect_aln_beg_end, src/align.c:630-663: left to right the end of the last '=' run, right to left the start of the first one (counted back from
+                    // tlen + 1 / qlen + 1); an alignment without a '=' run keeps the whole sequences
+                    const AnchorEndsOut &ae = aends[wi];
                     int rb = 1, qb = 1, re = A.tlen_full, qe = A.qlen_full;
-                    if (A.ext == 1) {
-                        int tr = 0, tq = 0;
-                        for (int i = 0; i < ncg; ++i) { int op = c[i] & 0xf, len = c[i] >> 4;
-                            if (op == 7 || op == 0) { tr += len; tq += len; re = tr; qe = tq; } else if (op == 8) { tr += len; tq += len; } else if (op == 2) tr += len; else if (op == 1) tq += len; }
-                    } else {
-                        int tr = A.tlen_full + 1, tq = A.qlen_full + 1;
-                        for (int i = ncg - 1; i >= 0; --i) { int op = c[i] & 0xf, len = c[i] >> 4;
-                            if (op == 7 || op == 0) { tr -= len; tq -= len; rb = tr; qb = tq; } else if (op == 8) { tr -= len; tq -= len; } else if (op == 2) tr -= len; else if (op == 1) tq -= len; }
+                    if (ae.has_eq) {
+                        if (A.ext == 1) { re = ae.pre_r; qe = ae.pre_q; }
+                        else { rb = A.tlen_full + 1 - ae.suf_r; qb = A.qlen_full + 1 - ae.suf_q; }
                     }
                     pr.ref_beg = rb; pr.ref_end = re; pr.read_beg = qb; pr.read_end = qe;
                 }

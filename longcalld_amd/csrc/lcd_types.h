@@ -204,6 +204,10 @@ static inline LCD_HD WfaLayout wfa_layout(int plen, int tlen, int s_cap, int blk
 
 // ---------------- edlib NW job (K4, src/align.c:222-232) ----------------
 struct GatherJob { uint64_t src, dst; uint32_t bytes, pad_; };   // strings_kernel.hip lcd_gather_kernel
+// collect_aln_beg_end (src/align.c:630-663) on the device: reference / query bases consumed up to the END of the last '=' run (a left-to-right anchor) and from the
+// START of the first '=' run to the end (a right-to-left one) of a BAM-style CIGAR -- 20 bytes per anchor job come back instead of the CIGARs themselves
+struct AnchorEndsJob { uint64_t cigar; int n_cigar, pad_; };
+struct AnchorEndsOut { int has_eq, pre_r, pre_q, suf_r, suf_q; };
 // ---------------- BAM records in the inflated stream (bam_kernel.hip; SURVEY 8f f3 on the device) ----------------
 struct BamWalkJob { uint64_t stream, ubeg, uend, usize, descs; long long reg_end; int tid, cap; };   // [ubeg, uend): a .bai chunk as offsets of the inflated stream; usize: its length
 struct BamRecDesc { uint64_t off; int bs, refid, pos, lseq; uint16_t flag, nc; uint8_t lname, mapq; uint16_t pad; uint32_t pad2; uint32_t pad3; }; // off: the record behind its block_size word

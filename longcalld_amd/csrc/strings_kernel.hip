@@ -128,3 +128,28 @@ void lcd_launch_gather(const GatherJob *jobs, int n_jobs, hipStream_t stream) {
     if (n_jobs <= 0) return;
     hipLaunchKernelGGL(lcd_gather_kernel, dim3(n_jobs), dim3(64), 0, stream, jobs, n_jobs);
 }
+
+
+// collect_aln_beg_end (src/align.c:630-663) for the anchor jobs of a submission: one lane per K3b alignment walks its CIGAR once (tens of operations: the pair is two
+// read ends of ~1.1x the shorter one's length) and returns the prefix sums through the last '=' run and the suffix sums from the first one.  The host used to fetch every
+// CIGAR -- one copy of the whole output span, 48 MB for 17 000 jobs -- and scan them between the anchor kernels and the first chain launch.
+__global__ void __launch_bounds__(64) lcd_anchor_ends_kernel(const AnchorEndsJob *jobs, AnchorEndsOut *outs, const int n_jobs) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_jobs) return;
+    const AnchorEndsJob j = jobs[i];
+    const uint32_t *c = (const uint32_t *)(uintptr_t)j.cigar;
+    int tr = 0, tq = 0, pre_r = 0, pre_q = 0, first_r = -1, first_q = -1, has = 0;
+    for (int k = 0; k < j.n_cigar; ++k) {
+        const uint32_t w = c[k]; const int op = (int)(w & 0xf), len = (int)(w >> 4);
+        if (op == 7 || op == 0) { if (first_r < 0) { first_r = tr; first_q = tq; } tr += len; tq += len; pre_r = tr; pre_q = tq; has = 1; }
+        else if (op == 8) { tr += len; tq += len; }
+        else if (op == 2) tr += len;
+        else if (op == 1) tq += len;
+    }
+    AnchorEndsOut o; o.has_eq = has; o.pre_r = pre_r; o.pre_q = pre_q; o.suf_r = has ? tr - first_r : 0; o.suf_q = has ? tq - first_q : 0;
+    outs[i] = o;
+}
+void lcd_launch_anchor_ends(const AnchorEndsJob *jobs, AnchorEndsOut *outs, int n_jobs, hipStream_t stream) {
+    if (n_jobs <= 0) return;
+    hipLaunchKernelGGL(lcd_anchor_ends_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, stream, jobs, outs, n_jobs);
+}
