@@ -80,6 +80,7 @@ struct Ctx {
     int *cert; int cert_on, cert_hist; // certified band of a K2 chain (align_certified): 7 x node_cap ints; largest bound-to-score slack of the chain's reads so far
     int wmax, seq_cap, pool_words, spill_x, ring_k, plan_k, solo;
     unsigned long long wd_deadline;   // shader-clock tick after which the chain gives up (LCD_ERR_WATCHDOG): checked once per 64 DP rows, per read, per 256 backtrack steps
+    int topo_mode;                     // test switches of the re-sort (LCD_DBG bits 64 / 128 / 256): 1 = never the compact LDS copy, 2 = the compact copy even where the packed words fit, 4 = its FIFO holds three nodes
     int mm_valid;                      // g.deg / g.queue hold, by topological index, every row's smallest predecessor index / largest successor index (topo_sort_block; subgraph_nodes_wave0)
     int n_node, n_edge, node_cap, edge_cap, rid_words;
     unsigned long long cell_cap;
@@ -608,6 +609,170 @@ __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned shor
     __syncthreads();
 }
 
+
+// ---- the re-sort of graphs that do not fit the pool as packed words (above): a COMPACT copy -- 5 B per node + 2 B per edge + a 512 B FIFO ----
+// Graphs of noisy reads are twice the size of their reads and re-sorted after nearly every read; at 8 B per node + 4 B per edge an 800-node graph misses the 8 KB
+// pool of the single-wavefront class and walked its packed words in HBM: ~1 300 ticks per node, 36 % of that class's time on the ONT shape (round 4 chain profile).
+// Here: in-degrees as bytes (bit 7: "a chain of >= 4 links starts here", the jump test), out-edges as CSR (u16 offsets + u16 targets, in out-edge list order -- the
+// order of the FIFO), the aligned ring as u16, and the FIFO itself a 256-entry ring: the order goes straight to idx2node / node2idx in HBM (stores do not stall the
+// walk).  A FIFO that would hold more than 256 nodes, or an in-degree above 127, hands the graph to the HBM walk (returns false; nothing it wrote is kept).
+typedef __attribute__((address_space(3))) uint8_t *lcd_lds_u8p;
+template <int NT>
+__device__ __forceinline__ bool topo_sort_compact(Ctx &g, Smem &sm, int *lds_pool) {
+    const int tid = threadIdx.x;
+    const int n = g.n_node, E = g.n_edge;
+    constexpr int QR = 256;
+    const int qcap = (g.topo_mode & 4) ? 3 : QR; // (LCD_DBG bit 256: a FIFO of three nodes -- every bubble hands the graph to the HBM walk: the test of that hand-over)
+    const int n1 = (n + 2) & ~1;
+    lcd_lds_u16p ring = lds_u16(lds_pool), ostart = ring + QR, al = ostart + n1, eto = al + n;
+    lcd_lds_u8p deg = (lcd_lds_u8p)(eto + E);
+    // ---- staging: in-degree, aligned ring, out-degree (into ostart[v + 1]) ----
+    int bad = 0;
+    struct S1 { int d, a, cnt, more; };
+    batched_for<4, NT>(0, n, [&](const int v) {
+        S1 r; r.d = g.nin[v]; r.a = g.aligned[v];
+        const int e0 = g.out_head[v], c0 = e0 >= 0 ? e0 : 0;
+        const int e1 = e0 >= 0 ? g.e_next_out[c0] : -1, c1 = e1 >= 0 ? e1 : 0;
+        r.more = e1 >= 0 ? g.e_next_out[c1] : -1;
+        r.cnt = (e0 >= 0) + (e1 >= 0);
+        return r;
+    }, [&](const int v, S1 r) {
+        for (int e = r.more; e >= 0; e = g.e_next_out[e]) ++r.cnt;
+        if (r.d > 127) bad = 1;
+        deg[v] = (uint8_t)r.d; al[v] = (unsigned short)r.a; ostart[v + 1] = (unsigned short)r.cnt;
+    });
+    if (__syncthreads_or(bad)) return false;
+    { // exclusive prefix sums of the out-degrees: a contiguous chunk per thread, one block scan of the chunk sums
+        const int per = (n + NT - 1) / NT, lo = imin(n, tid * per), hi = imin(n, lo + per);
+        int sum = 0;
+        for (int v = lo; v < hi; ++v) sum += ostart[v + 1];
+        int tot;
+        int run = block_excl_scan<NT>(sum, sm, &tot);
+        // (in place: ostart[v + 1] <- offset of v + 1; a thread's chunk is its own, ostart[lo] belongs to the chunk before -- written by that thread as ITS last entry)
+        for (int v = lo; v < hi; ++v) { run += ostart[v + 1]; ostart[v + 1] = (unsigned short)run; }
+        if (tid == 0) ostart[0] = 0;
+        if (tot != E) bad = 1; // (every edge is on exactly one out-list)
+    }
+    if (__syncthreads_or(bad)) return false;
+    struct S2 { int t0, t1, more; };
+    batched_for<4, NT>(0, n, [&](const int v) {
+        S2 r;
+        const int e0 = g.out_head[v], c0 = e0 >= 0 ? e0 : 0;
+        r.t0 = e0 >= 0 ? g.e_to[c0] : -1;
+        const int e1 = e0 >= 0 ? g.e_next_out[c0] : -1, c1 = e1 >= 0 ? e1 : 0;
+        r.t1 = e1 >= 0 ? g.e_to[c1] : -1;
+        r.more = e1 >= 0 ? g.e_next_out[c1] : -1;
+        return r;
+    }, [&](const int v, const S2 r) {
+        int k = ostart[v];
+        if (r.t0 >= 0) eto[k++] = (unsigned short)r.t0;
+        if (r.t1 >= 0) eto[k++] = (unsigned short)r.t1;
+        for (int e = r.more; e >= 0; e = g.e_next_out[e]) eto[k++] = (unsigned short)g.e_to[e];
+    });
+    __syncthreads();
+    // ---- chain links and jump tables, as in topo_sort_arrays (tables in the row-plan arrays in HBM) ----
+    unsigned short *J1 = (unsigned short *)g.pl_start, *J4 = J1 + n, *J16 = (unsigned short *)g.pl_rem;
+    batched_for<4, NT>(0, n, [&](const int v) {
+        const int s0 = ostart[v], s1 = ostart[v + 1];
+        const int to = eto[s0 < E ? s0 : 0];
+        const bool link = s1 - s0 == 1 && deg[to] == 1 && (int)al[to] == to;
+        return link ? to : v;
+    }, [&](const int v, const int l) { J1[v] = (unsigned short)l; });
+    __syncthreads();
+    unsigned char *R4 = (unsigned char *)(J16 + n) + n;
+    struct XR { int x, r; };
+    batched_for<4, NT>(0, n, [&](const int v) { XR o; o.x = v; o.r = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int y = J1[o.x]; o.r += y != o.x; o.x = y; }
+        return o; }, [&](const int v, const XR o) { J4[v] = (unsigned short)o.x; R4[v] = (unsigned char)o.r; });
+    __syncthreads();
+    batched_for<4, NT>(0, n, [&](const int v) { XR o; o.x = v; o.r = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o.r += R4[o.x]; o.x = J4[o.x]; }
+        return o; }, [&](const int v, const XR o) { J16[v] = (unsigned short)o.x; if (o.r >= 4) deg[v] = (uint8_t)(deg[v] | 0x80); });
+    __syncthreads();
+    const long long tk0 = clock64();
+    if (tid < 64) { // wavefront 0, every lane with the same scalars
+        const int lane = tid;
+        int qh = 0, qt = 1, index = 0, ovf = 0;
+        int cur = 0; bool have = true;
+        while (qh < qt) {
+            if (!have) cur = ring[qh & (QR - 1)];
+            ++qh; have = false;
+            while (qh == qt) { // nothing else queued: follow the chain that starts at cur, 64 nodes per step
+                if (!(deg[cur] & 0x80)) break;
+                int x = cur;
+                const int c16 = lane >> 4, c4 = (lane >> 2) & 3, c1 = lane & 3;
+                for (int i = 0; i < 3; ++i) if (i < c16) x = J16[x];
+                for (int i = 0; i < 3; ++i) if (i < c4) x = J4[x];
+                for (int i = 0; i < 3; ++i) if (i < c1) x = J1[x];
+                const int prev = __shfl_up(x, 1);
+                const unsigned long long adv = __ballot(lane == 0 || x != prev);
+                const int L = __popcll(adv);
+                if (L <= 1) break;
+                if (lane < L - 1) { g.node2idx[x] = index + lane; g.idx2node[index + lane] = x; }
+                index += L - 1; qh += L - 1; qt = qh;
+                cur = __shfl(x, L - 1);
+                if (L < 64 || index > n) break;
+            }
+            g.node2idx[cur] = index; g.idx2node[index < n ? index : 0] = cur; ++index;
+            if (cur == 1 || index > n) break;
+            const int s0 = ostart[cur], s1 = ostart[cur + 1];
+            int out_n = eto[s0 < E ? s0 : 0];
+            for (int k = s0; k < s1;) {
+                const int out = out_n;
+                ++k;
+                out_n = eto[k < E ? k : 0]; // (the targets do not change during the walk: the next one is on its way while this one is handled)
+                const int dv = deg[out], d = (dv & 0x7f) - 1;
+                deg[out] = (uint8_t)((dv & 0x80) | d);
+                if (d == 0) {
+                    bool ok = true;
+                    const int a0 = al[out];
+                    int na = 0;
+                    for (int a = a0; a != out; a = al[a]) { if (deg[a] & 0x7f) { ok = false; break; } ++na; }
+                    if (!ok) continue;
+                    if (qt - qh + na + 1 > qcap) { ovf = 1; break; }
+                    if (qh == qt) { cur = out; have = true; }
+                    ring[qt++ & (QR - 1)] = (unsigned short)out;
+                    for (int a = a0; a != out; a = al[a]) ring[qt++ & (QR - 1)] = (unsigned short)a;
+                }
+            }
+            if (ovf) break;
+        }
+        if (!ovf && index != n) g.status = LCD_ERR_TOPO;
+        if (lane == 0) { sm.bc[6] = g.status; sm.bc[5] = ovf; }
+    }
+    __syncthreads();
+    g.t_kahn += (unsigned long long)(clock64() - tk0);
+    g.status = sm.bc[6];
+    const int ovf = sm.bc[5];
+    __syncthreads();
+    if (ovf) return false;
+    if (g.status == LCD_OK) {
+        // heaviest successor of every node from the graph's own arrays (parallel: their latency overlaps), remain by pointer jumping in LDS (the walk's arrays are dead)
+        lcd_lds_u16p P0 = lds_u16(lds_pool), D0 = P0 + n;
+        struct HV { int mw, mid, more; };
+        batched_for<4, NT>(0, n, [&](const int v) {
+            HV r; r.mw = -1; r.mid = 1;
+            const int e0 = g.out_head[v], c0 = e0 >= 0 ? e0 : 0;
+            const int t0 = g.e_w[c0], to0 = g.e_to[c0];
+            const int e1 = e0 >= 0 ? g.e_next_out[c0] : -1, c1 = e1 >= 0 ? e1 : 0;
+            const int t1 = g.e_w[c1], to1 = g.e_to[c1];
+            if (e0 >= 0) { r.mw = t0; r.mid = to0; }
+            if (e1 >= 0 && t1 > r.mw) { r.mw = t1; r.mid = to1; }
+            r.more = e1 >= 0 ? g.e_next_out[c1] : -1;
+            return r;
+        }, [&](const int v, HV r) {
+            for (int e = r.more; e >= 0; e = g.e_next_out[e]) { const int wt = g.e_w[e]; if (wt > r.mw) { r.mw = wt; r.mid = g.e_to[e]; } }
+            P0[v] = (unsigned short)r.mid; D0[v] = (unsigned short)(v == 1 ? 0 : 1);
+        });
+        __syncthreads();
+        remain_by_jumping<NT, lcd_lds_u16p>(g, n, P0, P0 + 2 * n);
+    }
+    __syncthreads();
+    return true;
+}
+
 template <int NT>
 __device__ __attribute__((noinline)) void topo_sort_block(Ctx &g, Smem &sm, int *lds_pool, const int want_mm) {
     const int tid = threadIdx.x;
@@ -622,7 +787,13 @@ __device__ __attribute__((noinline)) void topo_sort_block(Ctx &g, Smem &sm, int 
     }
     // node word = out_head + 1 (low 16 bits) | next node of the aligned ring (high 16); edge word = to (low) | next out-edge + 1 (high):
     // one read per node / edge instead of two on the serial walk's dependency chain
-    if ((size_t)8 * n + (size_t)4 * E + 64 <= (size_t)g.pool_words * 4) {
+    const bool fits_packed = (size_t)8 * n + (size_t)4 * E + 64 <= (size_t)g.pool_words * 4;
+    const size_t compact_bytes = (size_t)512 + 2 * (size_t)((n + 2) & ~1) + 2 * (size_t)n + 2 * (size_t)E + (size_t)n + 64;
+    const bool fits_compact = !(g.topo_mode & 1) && (compact_bytes > (size_t)8 * n + 64 ? compact_bytes : (size_t)8 * n + 64) <= (size_t)g.pool_words * 4;
+    bool done = false;
+    if (fits_compact && (!fits_packed || (g.topo_mode & 2))) done = topo_sort_compact<NT>(g, sm, lds_pool);
+    if (done) { /* order, node2idx, remain are there */ }
+    else if (fits_packed) {
         unsigned short *deg = (unsigned short *)lds_pool, *queue = deg + n;
         unsigned *nw = (unsigned *)(queue + n + (n & 1)), *ew = nw + n; // (4-byte aligned: the pool is, and 2n + (n & 1) halfwords are even)
         topo_sort_arrays<NT, true>(g, sm, deg, queue, nw, ew);
@@ -4170,7 +4341,10 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
     g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - ring_k * 3 * ring_cols) * 4; g.ring_k = ring_k; g.plan_k = (NT == 64 || ch.solo) && ring_k > 2 && ch.wmax < 256 ? 2 : ring_k; // (slots beyond 2 of a chain laid out for a narrow window: not there when a read needs a wider one)
     g.wd_deadline = (unsigned long long)clock64() + (unsigned long long)(sc.wd_s > 0 ? sc.wd_s : 30) * 2400000000ull; // (~2.4 GHz shader clock: the bound is about seconds, not exact)
-    g.mm_valid = 0; g.solo = NT == 256 ? ch.solo : 0; g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0; g.t_bp = 0; g.t_setup = 0;
+    g.mm_valid = 0; g.topo_mode = (sc.dbg >> 6) & 7; g.solo = NT == 256 ? ch.solo : 0; g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0; g.t_bp = 0; g.t_setup = 0;
+    // The long chains are the latency of a submission at every depth, and next to 8 - 12 other wavefronts of their CU each of theirs issues when the arbiter gets round
+    // to it: highest wavefront priority for them (the others fill the slots their dependency stalls leave).  LCD_DBG bit 512: off
+    if constexpr (NT == 256) { if (ch.solo && !(sc.dbg & 512)) __builtin_amdgcn_s_setprio(3); }
     const long long t_begin = clock64();
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
     unsigned long long t_graph = 0, t_sub = 0, t_add = 0;

@@ -451,6 +451,29 @@ def test_certified_band_in_the_systolic_rows_equals_full_rows(lcd, monkeypatch, 
     assert st1["poa_cells_computed"] < st0["poa_cells_computed"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,n", [("hifi", 400), ("ont", 300), ("sv", 16)])
+def test_resort_layouts_give_the_same_order(lcd, oracle, monkeypatch, shape, n):
+    """the re-sort's three homes of the graph -- packed words in LDS, the compact copy in LDS (bytes + CSR + a 256-entry FIFO; graphs of noisy reads that miss
+    the pool as packed words), packed words in HBM -- are one Kahn FIFO order: same digest with the compact copy never used (LCD_DBG=64) and used wherever it
+    fits (LCD_DBG=128), and the default equals the oracle region by region"""
+    from longcalld_amd import jobs
+    regs = jobs.make_regions(777, n, {"hifi": jobs.HIFI, "ont": jobs.ONT, "sv": jobs.SV}[shape])
+    o = lcd.default_opt(); o.is_ont = 0 if shape == "hifi" else 1
+    monkeypatch.delenv("LCD_DBG", raising=False)
+    res, _, _, d0 = _run_batch(lcd, regs, o)
+    monkeypatch.setenv("LCD_DBG", "64")
+    _, _, _, d1 = _run_batch(lcd, regs, o)
+    monkeypatch.setenv("LCD_DBG", "128")
+    _, _, _, d2 = _run_batch(lcd, regs, o)
+    monkeypatch.setenv("LCD_DBG", "384")   # ... with a FIFO of three nodes: graphs with bubbles are handed over to the walk in HBM half way
+    _, _, _, d3 = _run_batch(lcd, regs, o)
+    assert d0 == d1 == d2 == d3
+    monkeypatch.delenv("LCD_DBG")
+    for r, got in list(zip(regs, res))[:: max(1, n // 20)]:
+        same_result(oracle.collect_noisy_reg_aln_strs(r), got)
+
+
 @pytest.mark.parametrize("shape", ["hifi", "ont", "sv"])
 def test_dp_regions_grow_in_place(lcd, oracle, monkeypatch, shape):
     """DP regions sized far too small (test switch LCD_CELL_SHRINK): a chain whose read does not fit takes a larger region from the launch set's spare pool and
