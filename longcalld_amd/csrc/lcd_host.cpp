@@ -1110,6 +1110,16 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     // Which chains are LONG (256-thread workgroup: rows on wavefront 0, per-read phases on four) is decided for the submission at hand: at most LCD_SOLO_N
     // (default: one per two CUs) of the longest chains in flight, and none below LCD_SOLO_MIN read-bases.  A lone batch leaves most of the chip idle and its
     // longest chain IS its latency, so there the cut is low; twenty batches keep the wide workgroups for their top hundred.  LCD_SOLO_RL fixes the cut instead.
+    auto PC = [&](size_t g) -> PoaChain & { const int k = chain_batch[g]; return bs[k]->pchains[g - chain_base[k]]; };
+    std::vector<size_t> early; std::vector<PoaChainOut> tmp_early;
+    // (streams share the runtime's four hardware queues in creation order: the leader's stream and its first three side streams have one each -- a later side
+    //  stream would share the leader's queue and hold the anchor stage and the first launch group behind the long chains: measured, 272 instead of 220 ms of POA)
+    hipStream_t es = L->side[2];
+    double early_load = 0;
+    // Everything between here and the row-0 arena layout needs nothing from the anchor stage and the anchor stage nothing from it (the reads' narrowed ends are applied
+    // after the join): capacities (3 ms of a 20-batch submission), the early launch of the long K2 chains (2 ms) and classes / order / arenas (1 ms) run on a helper
+    // thread while this one builds the anchor job tables and runs the anchor kernels -- the anchor kernels start ~5 ms earlier.  LCD_NO_PREP_THREAD=1: in line, as before
+    auto prep_chains = [&]() -> int {
     if (!getenv("LCD_SOLO_RL")) {
         static const long long solo_min = getenv("LCD_SOLO_MIN") ? atoll(getenv("LCD_SOLO_MIN")) : 20000;
         static const int solo_n_env = getenv("LCD_SOLO_N") ? atoi(getenv("LCD_SOLO_N")) : -1;
@@ -1158,16 +1168,10 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         if (nC && b->d_poa_out.ensure(out_tots[k])) return -11;
         for (int c = 0; c < nC; ++c) b->pchains[c].out_off = b->d_poa_out.addr() + out_rel[k][c];
     }
-    auto PC = [&](size_t g) -> PoaChain & { const int k = chain_batch[g]; return bs[k]->pchains[g - chain_base[k]]; };
     if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host]   POA prep: capacities after %.1f ms\n", now_ms() - t_begin);
     // ---- the long K2 chains start NOW: they are the latency of the submission (the longest chain lasts as long as the whole POA stage) and need nothing from
     // the anchor stage -- their reads are aligned whole.  Own stream, own chain table / read table / arenas (the anchor stage's workspace is the leader's arena);
     // their results join the others' after the first round's launches.  LCD_EARLY=0: off (they start with everybody else, as before).
-    std::vector<size_t> early; std::vector<PoaChainOut> tmp_early;
-    // (streams share the runtime's four hardware queues in creation order: the leader's stream and its first three side streams have one each -- a later side
-    //  stream would share the leader's queue and hold the anchor stage and the first launch group behind the long chains: measured, 272 instead of 220 ms of POA)
-    hipStream_t es = L->side[2];
-    double early_load = 0;
     {
         if (early_k2 && es) for (size_t g = 0; g < nC_all; ++g) { const PoaChain &pc = PC(g); if (pc.solo && pc.mode == 1 && pc.threads == 256 && pc.n_reads > 0) early.push_back(g); }
         if (early.size() == nC_all) early.clear(); // (the first round below is built around the launches of the others)
@@ -1193,6 +1197,8 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             }
         }
     }
+    return 0;
+    };
     // ---- classes and order of the chains that start after the anchor stage: host work that needs nothing from it -- made on a helper thread while the anchor kernels run
     //      (4 ms of a 260 ms submission with the main launches waiting for it, before) ----
     std::vector<size_t> which; which.reserve(nC_all);
@@ -1298,8 +1304,14 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         plan0.valid = true;
     };
     struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } order_thread; // (joins on every way out of this function)
-    const bool order_async = nC_all >= 2048 && !getenv("LCD_NO_PREP_THREAD");
-    if (order_async) order_thread.t = std::thread(prepare_round0);
+    const bool prep_async = !getenv("LCD_NO_PREP_THREAD");
+    const bool order_async = nC_all >= 2048 && prep_async;
+    int prep_rc = 0;
+    if (prep_async) {
+        const int dev_here = cur_device();
+        order_thread.t = std::thread([&, dev_here]() { if (hipSetDevice(dev_here) != hipSuccess) { prep_rc = -1; return; } prep_rc = prep_chains(); if (!prep_rc && order_async) prepare_round0(); });
+    } else { const int rc0 = prep_chains(); if (rc0) return rc0; }
+    auto join_prep = [&]() -> int { if (order_thread.t.joinable()) order_thread.t.join(); return prep_rc; };
     // ---------------- S1: anchors (K4 prefilter + K3b) ----------------
     {
         std::vector<EdJob> ej; std::vector<WfaJob> wj;
@@ -1349,6 +1361,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             }
             if (th) fprintf(stderr, "[host]   anchors: alignment ends (%.2f MB) on the host after %.1f ms\n", aends.size() * sizeof(AnchorEndsOut) / 1e6, now_ms() - t_begin);
             for (auto &e : eo) if (e.status != LCD_OK) return set_err(-20, "edlib kernel status " + std::to_string(e.status));
+            { const int rcp = join_prep(); if (rcp) return rcp; } // (the read tables below are the helper thread's)
             for (int k = 0; k < nb; ++k) {
                 lcd_batch_t *b = bs[k]; lcd_batch_stats_t &S = b->st;
                 for (size_t i = ej_base[k]; i < ej_base[k + 1]; ++i) S.edlib_blocks += eo[i].blocks;
@@ -1375,6 +1388,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             }
         }
     }
+    { const int rcp = join_prep(); if (rcp) return rcp; }
     HIPCHK(hipEventRecord(L->ev[1], st));
     const double tp0 = now_ms();
     if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host] anchor stage: %.1f ms on the host clock\n", tp0 - t_begin);
@@ -1384,7 +1398,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         for (int k = 0; k < nb; ++k)
             if (!preads[k].empty())
                 HIPCHK(hipMemcpyAsync((PoaRead *)L->d_preads.p + pread_base[k], preads[k].data(), preads[k].size() * sizeof(PoaRead), hipMemcpyHostToDevice, st));
-        if (order_async) order_thread.t.join(); else prepare_round0();
+        if (!order_async) prepare_round0();
         if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host]   POA prep: classes + order after %.1f ms\n", now_ms() - tp0);
         int scale = 1;
         std::map<size_t, uint64_t> retry_out_off; // chains whose output block moved to a retry buffer

@@ -8,8 +8,8 @@ cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 CMD="python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0"
 # the counter passes take ONE timed repeat and no depth profile (the driver's line reports the median of five repeats of the same submission and adds lone submissions of
-# 1 / 4 / 16 batches): warm-up submission + timed submission, which is what tools/rocprof_summary.py's "second half of the dispatches" rule assumes
-PMC="$CMD --repeats 1 --depth-profile 0"
+# 1 / 4 / 16 batches, and the PCIe-inclusive pipeline of --overlap runs more submissions): warm-up submission + timed submission, which is what tools/rocprof_summary.py's "second half of the dispatches" rule assumes
+PMC="$CMD --repeats 1 --depth-profile 0 --overlap 0"
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o kt -- $PMC > gpurun_out/prof_$tag.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch_$tag -o f -- $PMC > gpurun_out/pmc_fetch_$tag.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write_$tag -o w -- $PMC > gpurun_out/pmc_write_$tag.log 2>&1
