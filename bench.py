@@ -161,6 +161,7 @@ def _inproc(args, align, lib, timed_regs, warm_regs, n_regions, shape, torch):
            "repeats": {"n": n_rep, "seconds": [round(r["elapsed"], 4) for r in reps], "reported": "median", "allocations_per_repeat": [r["allocs"] for r in reps]},
            "dispatcher": {"busy_ms_per_device": med["busy"], "submissions_per_device": med["nsub"],
                           "busy_over_wall": [round(x / (med["elapsed"] * 1e3), 3) for x in med["busy"]]},
+           "results_downloaded": False,   # (the dispatcher leaves results on the devices: the same clock as the per-process line, whose timed region ends before the download)
            "roofline": None, "cpu_baseline": None}
     print(json.dumps(out), flush=True)
     for _, bt in slots:
