@@ -150,6 +150,17 @@ struct PinBuf {
 };
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// a loop over [0, n) cut into chunks taken by up to `max_threads` host threads (the calling thread is one of them); f(lo, hi, thread index)
+template <class F> static void par_chunks(const size_t n, const int max_threads, const size_t chunk, F f) {
+    const int nth = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, max_threads), (n + chunk - 1) / std::max<size_t>(1, chunk)));
+    if (nth <= 1) { if (n) f((size_t)0, n, 0); return; }
+    std::atomic<size_t> next{0};
+    auto work = [&](const int t) { for (size_t lo; (lo = next.fetch_add(chunk)) < n;) f(lo, std::min(n, lo + chunk), t); };
+    std::vector<std::thread> ths;
+    for (int t = 1; t < nth; ++t) ths.emplace_back(work, t);
+    work(0);
+    for (auto &t : ths) t.join();
+}
 
 // ---------------- host glue (restating src/align.c; see cited lines) ----------------
 int full_cover_cmp(int c1, int c2) { // src/align.c:945-952
@@ -233,10 +244,10 @@ struct lcd_batch_s {
     std::vector<WfaJob> wfa_jobs;
     // device
     // (d_poa_arena: the ONE transient workspace of a submission led by this batch -- chain arenas, WFA wavefronts and edlib blocks in turn)
-    DevBuf d_aends_jobs, d_aends_outs, d_in, d_chains, d_preads, d_poa_arena, d_poa_out, d_poa_outs, d_ed_jobs, d_ed_outs, d_wfa_jobs,
+    DevBuf d_read_patches, d_aends_jobs, d_aends_outs, d_in, d_chains, d_preads, d_poa_arena, d_poa_out, d_poa_outs, d_ed_jobs, d_ed_outs, d_wfa_jobs,
         d_wfa_out, d_wfa_outs, d_str_jobs, d_str_outs, d_final, d_gate, d_cmp_jobs, d_cmp_outs, d_cmp_seg, d_cmp_segres, d_seg_out, d_rr,
         d_var_jobs, d_var_outs, d_var_work, d_vreg_jobs, d_vreg_outs, d_var_out, d_slot_flags, d_spare, d_packed, d_unpack,
-        d_early_arena, d_chains_early, d_preads_early, d_poa_outs_early,   // the long K2 chains that start before the anchor stage (run_many_once)
+        d_early_arena, d_chains_early, d_poa_outs_early,   // the long K2 chains that start before the anchor stage (run_many_once)
         d_ed_arena;                                                         // K4's stored columns when it runs beside K3 in the anchor stage
     bool uploaded = false, ran = false, downloaded = false;
     // results (host)
@@ -248,6 +259,7 @@ struct lcd_batch_s {
     std::vector<StrJob> str_jobs; std::vector<StrOut> str_outs;
     std::vector<int> str_region, str_clu, str_k;
     PinnedBuf h_final; std::vector<uint8_t> h_poa_out; std::vector<uint8_t> h_cig;
+    PinnedBuf h_sub_pin, h_tmp_pin; // leader: the chain table of a round and the chains' output records (page-locked and kept: 7 + 9 MB per 20-batch round were allocated, zeroed and faulted in every time)
     std::vector<std::pair<int, uint32_t>> clu_gather_index;
     bool gathered = false; uint64_t g_extra = 0, g_clu_base = 0; std::vector<uint64_t> g_rc_off; // the scattered result pieces are already in d_gather (stage_gather at the end of the run): the download is copies only
     DevBuf d_gather, d_gather_jobs; std::vector<std::pair<int, uint32_t>> clu_index;   // download: staging block of the scattered pieces; (chain, offset into h_poa_out) of the K2 cluster lists
@@ -283,12 +295,12 @@ int wfa_default_scap(int plen, int tlen, bool anchor = false) {
 }
 const int kWfaLdsBuckets[3] = {16 << 10, 32 << 10, 64 << 10};
 // class (value ring in LDS or HBM), decision-byte block and snapshots of one job for the score bound s_want
-void wfa_plan(WfaJob &j, const LcdScoring &sc, long long s_want) {
+static uint64_t wfa_block_target() { return (uint64_t)(getenv("LCD_WFA_BLOCK_KB") ? atoi(getenv("LCD_WFA_BLOCK_KB")) : 16 << 10) << 10; } // (test switch: tiny blocks; read once per stage, not per job)
+void wfa_plan(WfaJob &j, const LcdScoring &sc, long long s_want, const uint64_t blk_target = wfa_block_target()) {
     auto gap = [&](long long n) { return n <= 0 ? 0ll : std::min<long long>(sc.o1 + sc.e1 * n, sc.o2 + sc.e2 * n); };
     const long long ub = gap(j.plen) + gap(j.tlen); // delete the pattern, insert the text: no optimal score is above it
     s_want = std::max<long long>(8, std::min(s_want, ub));
     WfaLayout L = wfa_layout(j.plen, j.tlen, (int)s_want, (int)s_want + 1, 0, 1, sc.mismatch, sc.o1, sc.e1, sc.o2, sc.e2);
-    const uint64_t blk_target = (uint64_t)(getenv("LCD_WFA_BLOCK_KB") ? atoi(getenv("LCD_WFA_BLOCK_KB")) : 16 << 10) << 10; // (test switch: tiny blocks)
     if (L.ring_bytes <= (uint64_t)kWfaLdsBuckets[2] && L.blk_bytes <= blk_target) { j.lds = 1; j.s_cap = (int)s_want; j.blk_rows = j.s_cap + 1; j.n_ckpt = 0; }
     else {
         j.lds = 0;
@@ -362,11 +374,24 @@ int run_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, DevBuf &d_jobs, Dev
     std::vector<WfaJob> sub; std::vector<WfaOut> tmp;
     for (int round = 0; round < 10 && !which.empty(); ++round) {
         const size_t m = which.size();
-        for (int i : which) wfa_plan(jobs[i], sc, want[i]);
-        // equal classes contiguous (one launch each); inside a class the largest arenas first (they last longest)
+        const double tw0 = now_ms();
+        // (plans and classes of the jobs are independent: a few host threads -- 50 000 ref<->cons jobs of a 20-batch submission were 3.5 ms of one thread with the GPU idle)
         std::vector<int> cls(n, 0);
-        for (int i : which) cls[i] = wfa_class(jobs[i], sc);
-        std::stable_sort(which.begin(), which.end(), [&](int a, int b) { return cls[a] != cls[b] ? cls[a] < cls[b] : jobs[a].ws_bytes > jobs[b].ws_bytes; });
+        const uint64_t blk_target = wfa_block_target();
+        par_chunks(m, 8, 4096, [&](const size_t lo, const size_t hi, int) { for (size_t q = lo; q < hi; ++q) { const int i = which[q]; wfa_plan(jobs[i], sc, want[i], blk_target); cls[i] = wfa_class(jobs[i], sc); } });
+        const double tw1 = now_ms();
+        // equal classes contiguous (one launch each); inside a class the larger arenas first (they last longest): a stable counting sort on class | size class (the
+        // arena size's exponent and four mantissa bits, descending) -- the order inside a launch is about its tail, nothing else depends on it
+        {
+            auto key_of = [&](const int i) { const uint64_t w = std::max<uint64_t>(jobs[i].ws_bytes, 16); const int e = 63 - __builtin_clzll(w); return (unsigned)cls[i] * 1024u + (1023u - (unsigned)(e * 16 + (int)((w >> (e - 4)) & 15))); };
+            std::vector<uint32_t> cnt(4 * 1024 + 1, 0);
+            std::vector<unsigned> kq(m);
+            for (size_t q = 0; q < m; ++q) { kq[q] = key_of(which[q]); cnt[kq[q] + 1]++; }
+            for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
+            std::vector<int> w2(m);
+            for (size_t q = 0; q < m; ++q) w2[cnt[kq[q]]++] = which[q];
+            which.swap(w2);
+        }
         uint64_t tot = 0;
         for (int i : which) { jobs[i].ws_off = tot; tot += jobs[i].ws_bytes; }
         if (getenv("LCD_MEM_DEBUG")) {
@@ -377,6 +402,7 @@ int run_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, DevBuf &d_jobs, Dev
         sub.resize(m); tmp.resize(m);
         for (size_t q = 0; q < m; ++q) { jobs[which[q]].ws_off += d_arena.addr(); sub[q] = jobs[which[q]]; }
         HIPCHK(hipMemcpyAsync(d_jobs.p, sub.data(), m * sizeof(WfaJob), hipMemcpyHostToDevice, st));
+        if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host]   WFA stage round %d: %zu jobs planned (%.1f ms), ordered and laid out in %.1f ms\n", round, m, tw1 - tw0, now_ms() - tw0);
         const int ns = (side && sev && n_side > 0) ? n_side + 1 : 1;
         if (ns > 1) HIPCHK(hipEventRecord(sev[0], st)); // the job table is there
         std::vector<char> used(ns, 0);
@@ -747,6 +773,7 @@ int lcd_batch_upload(lcd_batch_t *b) {
 }
 
 static int stage_gather(lcd_batch_t *b, hipStream_t st);
+static int stage_gather_many(lcd_batch_t **bs, int nb, hipStream_t st);
 static std::atomic<int> g_cell_hint[2] = {{0}, {0}}; // per mode (K1, K2): 0..2, see chain_caps
 static std::atomic<int> g_node_hint{0};                // 0..2: graph capacity estimate, see chain_caps
 static void chain_class(PoaChain &pc, bool noisy);
@@ -754,7 +781,21 @@ static void chain_class(PoaChain &pc, bool noisy);
 // their rows meet at a workgroup barrier twice per row and measured SLOWER than the systolic full rows they would replace -- configs[1]: 46.9 k instead of
 // 52.5 k regions/s with three such chains per batch; ONT shape with every K2 chain there: 6.6 k instead of 13.1 k)
 static int cert_next_level(const PoaChain &) { return 0; }
-static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vector<PoaRead> &preads, int scale, PoaChain &pc) {
+// the test switches chain_caps looks at, read ONCE per caller (a submission sizes 46 000 chains: seven getenv() scans of the environment per chain were most of the
+// 3 ms x 8 threads this took)
+struct ChainEnv {
+    int cert_mode, solo_len, cert_sys, solo_mw, solo_cyc, cell_shrink; long long solo_rl;
+    ChainEnv() {
+        cert_mode = getenv("LCD_CERT") ? atoi(getenv("LCD_CERT")) : 1;
+        solo_len = getenv("LCD_CERT_SOLO_LEN") ? atoi(getenv("LCD_CERT_SOLO_LEN")) : 0;
+        cert_sys = getenv("LCD_CERT_SYS") ? atoi(getenv("LCD_CERT_SYS")) : 0;
+        solo_rl = getenv("LCD_SOLO_RL") ? atoll(getenv("LCD_SOLO_RL")) : 100000;
+        solo_mw = getenv("LCD_SOLO_MW") ? atoi(getenv("LCD_SOLO_MW")) : 0;
+        solo_cyc = getenv("LCD_SOLO_CYC") ? atoi(getenv("LCD_SOLO_CYC")) : 1;
+        cell_shrink = getenv("LCD_CELL_SHRINK") ? std::max(1, atoi(getenv("LCD_CELL_SHRINK"))) : 0;
+    }
+};
+static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vector<PoaRead> &preads, int scale, PoaChain &pc, const ChainEnv &env) {
     const int n = (int)C.members.size();
     long long sum = 0; int maxl = 0;
     for (int k = 0; k < n; ++k) { const PoaRead &r = preads[C.read0 + k]; sum += r.len; maxl = std::max(maxl, r.len); }
@@ -762,15 +803,15 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     // K2 chains of clean reads run in the single-wavefront class with rows restricted to the CERTIFIED band (poa_kernel.hip align_certified: same
     // alignments as the full rows, ~20x fewer cells on HiFi-shape regions); noisy reads' bounds are too loose for a 256-column window (LCD_CERT=2 forces
     // them through it, 0 switches the path off).  A chain whose band outgrows the window comes back with LCD_ERR_CERT and is re-run with full rows.
-    const int cert_mode = getenv("LCD_CERT") ? atoi(getenv("LCD_CERT")) : 1; // (read per call: the tests switch it)
+    const int cert_mode = env.cert_mode; // (LCD_CERT, read per submission: the tests switch it)
     int lvl = C.cert_level;
     // (Long chains are the critical path of a submission, and in a 64-thread workgroup a third to a half of such a chain is the per-read work around the rows --
     // graph update, re-sort, plan: parallel over the nodes.  LCD_CERT_SOLO_LEN=n gives chains of reads >= n bases a 256-thread workgroup whose wavefront 0 runs
     // the same rows (poa_kernel.hip align_windowed<.., SOLO>).  Measured slower at every threshold -- 20 batches: 36 - 42 k instead of 45 k regions/s, 2 x 32
     // batches: 52 k instead of 66 k -- so it is off by default.)
-    const int solo_len = getenv("LCD_CERT_SOLO_LEN") ? atoi(getenv("LCD_CERT_SOLO_LEN")) : 0; // (read per call: a test switches it)
+    const int solo_len = env.solo_len; // (LCD_CERT_SOLO_LEN, read per submission: a test switches it)
     // Noisy reads (level 2): the band in the systolic rows of the class the reads' length asks for (poa_kernel.hip align_certified_sys); LCD_CERT_SYS=0: full rows
-    const int cert_sys = getenv("LCD_CERT_SYS") ? atoi(getenv("LCD_CERT_SYS")) : 0; // (read per call: the tests switch it)
+    const int cert_sys = env.cert_sys; // (LCD_CERT_SYS, read per submission: the tests switch it)
     if (lvl < 0) lvl = !(C.mode == 1 && maxl < 65535) ? 0 : (cert_mode == 2 || (cert_mode == 1 && !opt.is_ont)) ? 1 : (cert_mode == 1 && cert_sys && maxl >= 256) ? 2 : 0;
     pc.cert = C.mode == 1 ? lvl : 0; pc.ring_k = 0;
     // LONG chains -- the critical path of a submission, and of a single batch: 34 reads x 4 kb run 0.28 s on one wavefront, more than half of it the per-read phases around
@@ -778,16 +819,16 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     // lean rows, all four the phases around them (4x the loads in flight).  LCD_SOLO_RL: reads x longest read from which on (0 = off); LCD_CERT_SOLO_LEN: certified-band
     // chains by read length (test switch)
     {
-        const long long solo_rl = getenv("LCD_SOLO_RL") ? atoll(getenv("LCD_SOLO_RL")) : 100000; // (read per call: tests switch it)
+        const long long solo_rl = env.solo_rl; // (LCD_SOLO_RL, read per submission: tests switch it)
         pc.solo = (C.solo >= 0 ? C.solo > 0 : (solo_rl > 0 && (long long)n * maxl >= solo_rl)) || (solo_len > 0 && pc.cert == 1 && maxl >= solo_len) ? 1 : 0;
         // LCD_SOLO_MW=1: long certified-band chains run their rows on all four wavefronts of the workgroup (poa_kernel.hip align_lean_mw) instead of wavefront 0 alone.
         // Same alignments (digest 0004c9ba86f18807 at the driver's flags), but measured SLOWER: 3 530 instead of 2 950 ticks per row of the longest chain, 80.6 k instead
         // of 88.4 k regions/s -- every wavefront pays the row's fixed cost (plan word, interval, predecessor loop, metadata: ~400 instructions in this version, which
         // reads every predecessor from the LDS ring) plus two LDS round trips and two barriers, and the cells it saves are ~75 instructions.  Off by default.
-        if (pc.solo && pc.cert == 1 && getenv("LCD_SOLO_MW") && atoi(getenv("LCD_SOLO_MW")) > 0) pc.solo = 2;
+        if (pc.solo && pc.cert == 1 && env.solo_mw > 0) pc.solo = 2;
         // Round 4: the rows of the long certified-band chains run as a PIPELINE over the four wavefronts (poa_kernel.hip align_cyc: mailboxes, no barrier, the row before in
         // registers) -- LCD_SOLO_CYC=0 keeps them on wavefront 0
-        if (pc.solo == 1 && pc.cert == 1 && !(getenv("LCD_SOLO_CYC") && atoi(getenv("LCD_SOLO_CYC")) == 0)) pc.solo = 3;
+        if (pc.solo == 1 && pc.cert == 1 && env.solo_cyc != 0) pc.solo = 3;
     }
     // graph capacity: the worst case is one node per base of every read (sum), the usual case a little more than the longest read.  Sized
     // from an estimate (a few per cent of new nodes per read on top of the backbone; g_node_hint learns noisier data); a chain that runs
@@ -826,7 +867,7 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     }
     else band = maxl + 1;
     long long cells = rows_est * band;
-    if (const char *shrink = getenv("LCD_CELL_SHRINK")) cells = std::max<long long>(cells / std::max(1, atoi(shrink)), 1); // test switch: estimates far too small, so that the chains have to grow their regions (tests/test_gpu_region.py)
+    if (env.cell_shrink > 0) cells = std::max<long long>(cells / env.cell_shrink, 1); // test switch: estimates far too small, so that the chains have to grow their regions (tests/test_gpu_region.py)
     // (tried: the single-wavefront class compiled for 64 VGPRs (__launch_bounds__(64, 8): 32 instead of 16 wavefronts per CU, 4 - 8 KB pools): 34 - 37 k instead of
     // 51 k regions/s -- the row loops spill (40 - 170 B of scratch per lane inside align_windowed) and the graph phases' scratch grows from 924 to 1 336 B)
     // (tried: 3x the estimate up front for the long K1 chains of noisy reads, which overflow most -- 5 instead of 60 re-runs per 4 SV-shape batches, but
@@ -938,9 +979,10 @@ static int chain_threads(const PoaChain &pc) { return pc.threads; }
 static long long chain_group_key(const PoaChain &pc) { return (long long)pc.threads * (1 << 20) + pc.lds_words; }
 // uploads `sub` (already ordered so that equal classes are contiguous) and launches one kernel per class
 // (different classes go to side streams so a long wide chain does not hold back the narrow ones)
-static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, DevBuf &d_chains, const PoaRead *d_reads, DevBuf &d_outs, LcdScoring sc,
+static int launch_poa_grouped(hipStream_t st, const PoaChain *sub_p, const size_t sub_n, DevBuf &d_chains, const PoaRead *d_reads, DevBuf &d_outs, LcdScoring sc,
                               hipStream_t *side = nullptr, hipEvent_t *sev = nullptr, DevBuf *d_gate = nullptr, PoaSpare *spare = nullptr, int busy_idx = -1, double busy_load = 0, bool noisy = false) {
-    HIPCHK(hipMemcpyAsync(d_chains.p, sub.data(), sub.size() * sizeof(PoaChain), hipMemcpyHostToDevice, st));
+    struct View { const PoaChain *p; size_t n; size_t size() const { return n; } const PoaChain &operator[](size_t i) const { return p[i]; } const PoaChain *begin() const { return p; } const PoaChain *end() const { return p + n; } } sub{sub_p, sub_n};
+    HIPCHK(hipMemcpyAsync(d_chains.p, sub_p, sub_n * sizeof(PoaChain), hipMemcpyHostToDevice, st));
     // The wide classes start first, widest first: a 1 024-thread chain needs ALL the vector registers of a CU and a 512-thread chain half of
     // them, so once narrower workgroups are spread over the chip they wait for a CU to drain completely -- and they are the longest
     // chains.  gate[0] / gate[1] count the 1 024- / 512-thread workgroups that have started; the 512-thread launch is held
@@ -1021,6 +1063,10 @@ static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, 
     if (gate && getenv("LCD_GATE_DEBUG")) { int h[8]; hipStreamSynchronize(st); hipMemcpy(h, gate, 32, hipMemcpyDeviceToHost); fprintf(stderr, "[gate] started: %d x 1024-thread, %d x 512-thread workgroups; longest gate wait %d polls (targets %d, %d)\n", h[0], h[1], h[4], target0, target1); }
     return 0;
 }
+static int launch_poa_grouped(hipStream_t st, const std::vector<PoaChain> &sub, DevBuf &d_chains, const PoaRead *d_reads, DevBuf &d_outs, LcdScoring sc,
+                              hipStream_t *side = nullptr, hipEvent_t *sev = nullptr, DevBuf *d_gate = nullptr, PoaSpare *spare = nullptr, int busy_idx = -1, double busy_load = 0, bool noisy = false) {
+    return launch_poa_grouped(st, sub.data(), sub.size(), d_chains, d_reads, d_outs, sc, side, sev, d_gate, spare, busy_idx, busy_load, noisy);
+}
 
 // Runs the hot path of n batches JOINTLY: every stage is one set of launches over the jobs / chains of all batches, so the GPU's
 // own workgroup dispatcher packs the chains of several batches onto the CUs (a chain is a sequential object that can use at most
@@ -1098,6 +1144,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     HIPCHK(hipEventRecord(L->ev[0], st));
     // the reads of every chain with their device addresses (the anchor stage below narrows the partial reads of K1 chains; lengths never change)
     std::vector<std::vector<PoaRead>> preads(nb);
+    const ChainEnv cenv;
     // (filled per batch by the host threads of size_chains below: 24 MB for a 20-batch submission, 3 ms when one thread copied them)
     // ---- capacities, classes and output blocks of the chains: nothing here depends on the anchor stage, and the longest K2 chains start before it (below) ----
     std::vector<size_t> chain_base(nb + 1, 0), pread_base(nb + 1, 0);
@@ -1111,11 +1158,11 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     // (default: one per two CUs) of the longest chains in flight, and none below LCD_SOLO_MIN read-bases.  A lone batch leaves most of the chip idle and its
     // longest chain IS its latency, so there the cut is low; twenty batches keep the wide workgroups for their top hundred.  LCD_SOLO_RL fixes the cut instead.
     auto PC = [&](size_t g) -> PoaChain & { const int k = chain_batch[g]; return bs[k]->pchains[g - chain_base[k]]; };
-    std::vector<size_t> early; std::vector<PoaChainOut> tmp_early;
+    std::vector<size_t> early;
     // (streams share the runtime's four hardware queues in creation order: the leader's stream and its first three side streams have one each -- a later side
     //  stream would share the leader's queue and hold the anchor stage and the first launch group behind the long chains: measured, 272 instead of 220 ms of POA)
     hipStream_t es = L->side[2];
-    double early_load = 0;
+    double early_load = 0; bool reads_up = false; // (reads_up: the read table is in d_preads already, as of before the anchor stage)
     // Everything between here and the row-0 arena layout needs nothing from the anchor stage and the anchor stage nothing from it (the reads' narrowed ends are applied
     // after the join): capacities (3 ms of a 20-batch submission), the early launch of the long K2 chains (2 ms) and classes / order / arenas (1 ms) run on a helper
     // thread while this one builds the anchor job tables and runs the anchor kernels -- the anchor kernels start ~5 ms earlier.  LCD_NO_PREP_THREAD=1: in line, as before
@@ -1147,7 +1194,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         uint64_t out_tot = 0;
         for (int c = 0; c < nC; ++c) {
             b->chains[c].cert_level = -1; b->chains[c].cert_fail_round = -1; // (nothing about the certified band is remembered from an earlier run of the same batch)
-            chain_caps(b->opt, b->chains[c], preads[k], 1, b->pchains[c]);
+            chain_caps(b->opt, b->chains[c], preads[k], 1, b->pchains[c], cenv);
             out_rel[k][c] = out_tot; out_tot += lcd_align_up(poa_out_bytes(b->pchains[c].node_cap, b->pchains[c].n_reads), 256);
         }
         out_tots[k] = out_tot;
@@ -1173,6 +1220,15 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     // the anchor stage -- their reads are aligned whole.  Own stream, own chain table / read table / arenas (the anchor stage's workspace is the leader's arena);
     // their results join the others' after the first round's launches.  LCD_EARLY=0: off (they start with everybody else, as before).
     {
+        // the read table goes up ONCE, here, on the long chains' stream (24 MB for 20 batches: 1.5 - 1.8 ms of this helper thread instead of the calling thread's, which
+        // used to send it a second time between the anchor stage and the main launches); the reads the anchor stage narrows are patched afterwards (lcd_patch_reads_kernel)
+        if (early_k2 && es && nC_all && !L->d_preads.ensure(pread_base[nb] * sizeof(PoaRead))) {
+            HIPCHK(hipStreamWaitEvent(es, L->ev[0], 0)); // (behind whatever the leader's stream held before this submission)
+            for (int k = 0; k < nb; ++k) if (!preads[k].empty())
+                HIPCHK(hipMemcpyAsync((PoaRead *)L->d_preads.p + pread_base[k], preads[k].data(), preads[k].size() * sizeof(PoaRead), hipMemcpyHostToDevice, es));
+            HIPCHK(hipEventRecord(L->ev[8], es));
+            reads_up = true;
+        } else (void)hipGetLastError();
         if (early_k2 && es) for (size_t g = 0; g < nC_all; ++g) { const PoaChain &pc = PC(g); if (pc.solo && pc.mode == 1 && pc.threads == 256 && pc.n_reads > 0) early.push_back(g); }
         if (early.size() == nC_all) early.clear(); // (the first round below is built around the launches of the others)
         if (!early.empty()) {
@@ -1184,15 +1240,11 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                 pc.ws_off = tot_e; pc.slot_flags = 0; pc.slot_bytes = 0; pc.n_slots = 0; pc.per_cu = 0; pc.cu_rank = 0;
                 tot_e += lcd_align_up(poa_layout(pc.node_cap, pc.edge_cap, pc.rid_words, pc.max_len, pc.cell_cap, pc.n_reads, pc.spill_x, pc.cert).total, 256);
             }
-            if (L->d_early_arena.ensure(tot_e, 3) || L->d_preads_early.ensure(pread_base[nb] * sizeof(PoaRead)) || L->d_chains_early.ensure(early.size() * sizeof(PoaChain)) ||
+            if (!reads_up || L->d_early_arena.ensure(tot_e, 3) || L->d_chains_early.ensure(early.size() * sizeof(PoaChain)) ||
                 L->d_poa_outs_early.ensure(early.size() * sizeof(PoaChainOut))) { (void)hipGetLastError(); early.clear(); } // (no memory for it: they start with the others)
             else {
                 for (size_t i = 0; i < early.size(); ++i) { PoaChain &pc = PC(early[i]); pc.ws_off += L->d_early_arena.addr(); sub_e[i] = pc; sub_e[i].read0 += (int)pread_base[chain_batch[early[i]]]; }
-                HIPCHK(hipStreamWaitEvent(es, L->ev[0], 0)); // (behind whatever the leader's stream held before this submission)
-                for (int k = 0; k < nb; ++k) if (!preads[k].empty())
-                    HIPCHK(hipMemcpyAsync((PoaRead *)L->d_preads_early.p + pread_base[k], preads[k].data(), preads[k].size() * sizeof(PoaRead), hipMemcpyHostToDevice, es));
-                { const int rc2 = launch_poa_grouped(es, sub_e, L->d_chains_early, (const PoaRead *)L->d_preads_early.p, L->d_poa_outs_early, sc); if (rc2) return rc2; }
-                tmp_early.resize(early.size()); // (fetched when the first round's own launches are done: a copy into pageable memory would hold this thread until the chains end)
+                { const int rc2 = launch_poa_grouped(es, sub_e, L->d_chains_early, (const PoaRead *)L->d_preads.p, L->d_poa_outs_early, sc); if (rc2) return rc2; }
                 if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host]   %zu long K2 chains launched %.1f ms after the start (%.2f GB of arenas)\n", early.size(), now_ms() - t_begin, tot_e / 1e9);
             }
         }
@@ -1395,6 +1447,18 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     // ---------------- S2: POA chains ----------------
     if (nC_all) {
         if (L->d_preads.ensure(pread_base[nb] * sizeof(PoaRead)) || L->d_chains.ensure(nC_all * sizeof(PoaChain)) || L->d_poa_outs.ensure(nC_all * sizeof(PoaChainOut))) return -11;
+        if (reads_up) { // only what the anchor stage changed
+            std::vector<ReadPatch> pt;
+            for (int k = 0; k < nb; ++k) for (const AnchorRec &A : bs[k]->anchors) { ReadPatch p; p.idx = (uint32_t)(pread_base[k] + A.pread); p.pad_ = 0; p.r = preads[k][A.pread]; pt.push_back(p); }
+            HIPCHK(hipStreamWaitEvent(st, L->ev[8], 0));
+            if (!pt.empty()) {
+                if (L->d_read_patches.ensure(pt.size() * sizeof(ReadPatch))) return -11;
+                HIPCHK(hipMemcpyAsync(L->d_read_patches.p, pt.data(), pt.size() * sizeof(ReadPatch), hipMemcpyHostToDevice, st));
+                lcd_launch_patch_reads((PoaRead *)L->d_preads.p, (const ReadPatch *)L->d_read_patches.p, (int)pt.size(), st);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(st)); // (pt is a local)
+            }
+        } else
         for (int k = 0; k < nb; ++k)
             if (!preads[k].empty())
                 HIPCHK(hipMemcpyAsync((PoaRead *)L->d_preads.p + pread_base[k], preads[k].data(), preads[k].size() * sizeof(PoaRead), hipMemcpyHostToDevice, st));
@@ -1409,14 +1473,15 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             else P.need.assign(which.size(), 0);
             const bool planned = P.valid;
             uint64_t &tot = P.tot; std::vector<uint64_t> &need = P.need;
-            std::vector<PoaChain> sub(which.size());
+            L->h_sub_pin.resize(which.size() * sizeof(PoaChain));
+            PoaChain *const sub = (PoaChain *)L->h_sub_pin.data(); const size_t sub_n = which.size();
             if (!planned) for (size_t i = 0; i < which.size(); ++i) {
                 const int k = chain_batch[which[i]]; const size_t c = which[i] - chain_base[k];
                 PoaChain &pc = bs[k]->pchains[c];
                 if (round) {
                     const int old_cap = pc.node_cap;
                     const ChainRec &CR = bs[k]->chains[c];   // (a chain sent back by the certified band starts its capacity ladder in the round after)
-                    chain_caps(bs[k]->opt, CR, preads[k], CR.cert_fail_round < 0 ? scale : std::max(1, scale >> (CR.cert_fail_round + 1)), pc);
+                    chain_caps(bs[k]->opt, CR, preads[k], CR.cert_fail_round < 0 ? scale : std::max(1, scale >> (CR.cert_fail_round + 1)), pc, cenv);
                     if (pc.node_cap > old_cap) { // the chain's output block (cons + MSA rows of node_cap columns) grows with it: a fresh block
                         lcd_batch_t *b = bs[k];
                         if (b->retry_out_used == b->retry_out.size()) b->retry_out.emplace_back(new DevBuf());
@@ -1461,13 +1526,13 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                     it.phys = ch[k]->addr() + off; off += it.bytes; left -= it.bytes;
                 }
             }
-            for (size_t i = 0; i < which.size(); ++i) {
+            par_chunks(which.size(), 8, 4096, [&](const size_t lo, const size_t hi, int) { for (size_t i = lo; i < hi; ++i) {
                 const int k = chain_batch[which[i]];
                 PoaChain &pc = PC(which[i]);
                 pc.ws_off = items[item_of[i]].phys + (pc.ws_off - items[item_of[i]].start);
                 if (pc.slot_flags) pc.slot_flags = L->d_slot_flags.addr() + (pc.slot_flags - 1) * 4;
                 sub[i] = pc; sub[i].read0 += (int)pread_base[k]; // the device read table is the concatenation of the batches' tables
-            }
+            } });
             // Spare DP memory (PoaSpare, poa_kernel.hip grow_dp_region): what a chain whose estimate was too small for one of its reads continues in.  Taken
             // after the arenas have their memory, from what the budget leaves (LCD_SPARE_GB caps it, 0 switches it off); without it -- or once it is used
             // up -- such a chain comes back with LCD_ERR_CELLS and is re-run from its first read in the next round, as before.
@@ -1491,17 +1556,19 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             }
             if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host] POA stage: %.1f ms of host work before the launches of round %d\n", now_ms() - tp0, round);
             HIPCHK(hipEventRecord(L->ev[6], st));
-            { int rc2 = launch_poa_grouped(st, sub, L->d_chains, (const PoaRead *)L->d_preads.p, L->d_poa_outs, sc, L->side, L->sev, &L->d_gate, d_spare, round == 0 && !early.empty() ? 3 : -1, early_load, L->opt.is_ont != 0); if (rc2) return rc2; }
+            { int rc2 = launch_poa_grouped(st, sub, sub_n, L->d_chains, (const PoaRead *)L->d_preads.p, L->d_poa_outs, sc, L->side, L->sev, &L->d_gate, d_spare, round == 0 && !early.empty() ? 3 : -1, early_load, L->opt.is_ont != 0); if (rc2) return rc2; }
             HIPCHK(hipEventRecord(L->ev[7], st));
-            std::vector<PoaChainOut> tmp(sub.size());
-            HIPCHK(hipMemcpyAsync(tmp.data(), L->d_poa_outs.p, sub.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, st));
+            L->h_tmp_pin.resize((sub_n + (round == 0 ? early.size() : 0)) * sizeof(PoaChainOut)); // (with room for the early chains' records: appending them to a vector re-allocated 9 MB with the GPU idle)
+            PoaChainOut *const tmp = (PoaChainOut *)L->h_tmp_pin.data();
+            HIPCHK(hipMemcpyAsync(tmp, L->d_poa_outs.p, sub_n * sizeof(PoaChainOut), hipMemcpyDeviceToHost, st));
             PoaSpare spare_seen; spare_seen.used = 0; spare_seen.n_grown = spare_seen.n_refused = 0;
             if (d_spare) HIPCHK(hipMemcpyAsync(&spare_seen, d_spare, sizeof(PoaSpare), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
+            if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host]   round %d: kernels and statuses back %.1f ms after the stage's start\n", round, now_ms() - tp0);
             if (round == 0 && !early.empty()) { // the long chains that started before the anchor stage: from here on they are chains of this round like the others
-                HIPCHK(hipMemcpyAsync(tmp_early.data(), L->d_poa_outs_early.p, early.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, es));
+                HIPCHK(hipMemcpyAsync(tmp + sub_n, L->d_poa_outs_early.p, early.size() * sizeof(PoaChainOut), hipMemcpyDeviceToHost, es));
                 HIPCHK(hipStreamSynchronize(es));
-                which.insert(which.end(), early.begin(), early.end()); tmp.insert(tmp.end(), tmp_early.begin(), tmp_early.end());
+                which.insert(which.end(), early.begin(), early.end());
             }
             if (d_spare) {
                 bs[0]->st.poa_grown += (int)spare_seen.n_grown; // (a count of the launch set: kept on the leader, so that the batches' statistics add up)
@@ -1510,9 +1577,25 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             { float kms = 0; hipEventElapsedTime(&kms, L->ev[6], L->ev[7]); for (int k = 0; k < nb; ++k) { bs[k]->st.ms_poa_kernel += kms; bs[k]->st.n_poa_launches++; }
               if (getenv("LCD_MEM_DEBUG")) fprintf(stderr, "[mem] round %d: %zu chains, POA kernels %.1f ms\n", round, which.size(), kms); }
             std::vector<size_t> again; size_t n_node_ovf = 0, n_cert_fail = 0;
-            for (size_t i = 0; i < which.size(); ++i) {
+            // (the chains' output records -- 200 B each, 46 000 of them in a 20-batch submission -- go to their batches on a few threads: serial this was 3.4 ms
+            //  with the GPU idle; the chains that did not end with LCD_OK are few and are looked at one by one below)
+            std::vector<size_t> flagged;
+            {
+                constexpr int NTH = 8;
+                std::vector<size_t> fl[NTH];
+                par_chunks(which.size(), NTH, 2048, [&](const size_t lo, const size_t hi, const int t) {
+                    for (size_t i = lo; i < hi; ++i) {
+                        const int k = chain_batch[which[i]];
+                        bs[k]->couts[which[i] - chain_base[k]] = tmp[i];
+                        if (tmp[i].status != LCD_OK) fl[t].push_back(i);
+                    }
+                });
+                for (int t = 0; t < NTH; ++t) flagged.insert(flagged.end(), fl[t].begin(), fl[t].end());
+                std::sort(flagged.begin(), flagged.end());
+            }
+            if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host]   round %d: records in their batches %.1f ms after the stage's start (%zu not LCD_OK)\n", round, now_ms() - tp0, flagged.size());
+            for (const size_t i : flagged) {
                 const int k = chain_batch[which[i]];
-                bs[k]->couts[which[i] - chain_base[k]] = tmp[i];
                 if (tmp[i].status == LCD_ERR_CELLS || tmp[i].status == LCD_ERR_NODES || tmp[i].status == LCD_ERR_EDGES) { again.push_back(which[i]); n_node_ovf += tmp[i].status != LCD_ERR_CELLS; }
                 else if (tmp[i].status == LCD_ERR_CERT && PC(which[i]).cert > 0) { // one class up (512, 1 024 columns), then full rows
                     ChainRec &CR = bs[k]->chains[which[i] - chain_base[k]];
@@ -1855,8 +1938,8 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             S.poa_alg_bytes += 2 * o.aligned_bases + o.cells_alg + 6ull * (uint64_t)o.n_node * (uint64_t)o.n_aligned_reads;
         }
         b->ran = true; b->downloaded = false; b->gathered = false;
-        if (int rc = stage_gather(b, st)) return rc;
     }
+    if (int rc = stage_gather_many(bs, nb, st)) return rc;
     if (getenv("LCD_MEM_DEBUG")) fprintf(stderr, "[mem] device buffers of this process after the submission: %.2f GB (budget %.2f GB)\n", g_dev_bytes[L->device].load() / 1e9, dev_budget(L->device) / 1e9);
     if (getenv("LCD_PLACEMENT")) { // experiment: which CU did every wide chain run on, and when
         for (size_t g = 0; g < nC_all; ++g) { if (chain_threads(PC(g)) < 512) continue; const PoaChainOut &o = bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]];
@@ -2015,7 +2098,7 @@ int lcd_dispatch_run(lcd_dispatch_t *d, lcd_batch_t **bs, int n, int *device_of)
 // piece per chain in the chain-output buffer) -- gathered into ONE staging block on the device.  Since round 4 this runs at the END OF THE RUN, on the submission's
 // stream: a download is then DMA copies only.  (As a kernel inside lcd_batch_download it had to find a hardware queue next to another submission's chain kernels --
 // four queues, all busy for the length of that submission -- so a download never overlapped the next submission: the pipeline of bench.py's pcie_inclusive.)
-static int stage_gather(lcd_batch_t *b, hipStream_t st) {
+static int gather_plan(lcd_batch_t *b, std::vector<GatherJob> &gj_all) { // the batch's pieces appended to gj_all with absolute destinations in its own staging block
     const bool vars_only = b->opt.collect_noisy_vars == 2;
     const uint64_t final_bytes = vars_only ? 0 : b->final_bytes;
     uint64_t extra = 0;
@@ -2042,16 +2125,29 @@ static int stage_gather(lcd_batch_t *b, hipStream_t st) {
     }
     b->g_extra = extra;
     if (!gj.empty()) {
-        if (b->d_gather.ensure(extra + 64) || b->d_gather_jobs.ensure(gj.size() * sizeof(GatherJob))) return -11;
+        if (b->d_gather.ensure(extra + 64)) return -11;
         for (auto &g : gj) g.dst += b->d_gather.addr();
-        HIPCHK(hipMemcpyAsync(b->d_gather_jobs.p, gj.data(), gj.size() * sizeof(GatherJob), hipMemcpyHostToDevice, st));
-        lcd_launch_gather((const GatherJob *)b->d_gather_jobs.p, (int)gj.size(), st);
+        gj_all.insert(gj_all.end(), gj.begin(), gj.end());
+    }
+    return 0;
+}
+// one job table, one launch for all the batches of a submission (leader = bs[0] lends the table's buffer): per batch this was 20 x (upload, kernel, synchronize) =
+// 3.4 ms at the end of a 20-batch run
+static int stage_gather_many(lcd_batch_t **bs, int nb, hipStream_t st) {
+    std::vector<GatherJob> gj;
+    for (int k = 0; k < nb; ++k) if (int rc = gather_plan(bs[k], gj)) return rc;
+    if (!gj.empty()) {
+        lcd_batch_t *L = bs[0];
+        if (L->d_gather_jobs.ensure(gj.size() * sizeof(GatherJob))) return -11;
+        HIPCHK(hipMemcpyAsync(L->d_gather_jobs.p, gj.data(), gj.size() * sizeof(GatherJob), hipMemcpyHostToDevice, st));
+        lcd_launch_gather((const GatherJob *)L->d_gather_jobs.p, (int)gj.size(), st);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st)); // (gj is a local: the job table must have left the host before it goes out of scope)
     }
-    b->gathered = true;
+    for (int k = 0; k < nb; ++k) bs[k]->gathered = true;
     return 0;
 }
+static int stage_gather(lcd_batch_t *b, hipStream_t st) { return stage_gather_many(&b, 1, st); }
 
 int lcd_batch_download(lcd_batch_t *b) {
     if (!b->ran) return set_err(-3, "lcd_batch_download before lcd_batch_run");
@@ -3276,11 +3372,12 @@ int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int
         PoaRead &r = preads[i]; r.seq_off = d_pool.addr() + seq_off[i]; r.len = len[i]; r.skip = skip ? skip[i] : 0;
         r.ref_beg = anchors[4 * i]; r.ref_end = anchors[4 * i + 1]; r.read_beg = anchors[4 * i + 2]; r.read_end = anchors[4 * i + 3];
     }
+    const ChainEnv cenv;
     std::vector<ChainRec> crec(n_chains); std::vector<PoaChain> pch(n_chains); std::vector<uint64_t> out_rel(n_chains);
     uint64_t out_tot = 0;
     for (int c = 0; c < n_chains; ++c) {
         crec[c].mode = mode[c]; crec[c].read0 = chain_read0[c]; crec[c].members.resize(chain_n_reads[c]);
-        chain_caps(*opt, crec[c], preads, 1, pch[c]);
+        chain_caps(*opt, crec[c], preads, 1, pch[c], cenv);
         out_rel[c] = out_tot; out_tot += lcd_align_up(poa_out_bytes(pch[c].node_cap, pch[c].n_reads), 256);
     }
     if (d_out.ensure(out_tot) || d_reads.ensure(preads.size() * sizeof(PoaRead) + 16) || d_chains.ensure(n_chains * sizeof(PoaChain)) || d_outs.ensure(n_chains * sizeof(PoaChainOut))) return -11;
@@ -3298,7 +3395,7 @@ int lcd_poa_batch(const lcd_opt_t *opt, int n_chains, const int *mode, const int
             if (!round) pc.out_off = d_out.addr() + out_rel[which[i]];
             else {
                 const int old_cap = pc.node_cap; const uint64_t keep = pc.out_off;
-                chain_caps(*opt, crec[which[i]], preads, crec[which[i]].cert_fail_round < 0 ? scale : std::max(1, scale >> (crec[which[i]].cert_fail_round + 1)), pc);
+                chain_caps(*opt, crec[which[i]], preads, crec[which[i]].cert_fail_round < 0 ? scale : std::max(1, scale >> (crec[which[i]].cert_fail_round + 1)), pc, cenv);
                 pc.out_off = keep;
                 if (pc.node_cap > old_cap) { // larger graph capacity -> larger output block
                     retry_out.emplace_back(new DevBuf());

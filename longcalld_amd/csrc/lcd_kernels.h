@@ -13,6 +13,7 @@ void lcd_launch_wfa(const WfaJob *jobs, const uint8_t *pool, uint8_t *arena, uin
 void lcd_launch_edlib(const EdJob *jobs, const uint8_t *pool, uint8_t *arena, EdOut *outs, int n_jobs, hipStream_t stream);
 void lcd_launch_strings(const StrJob *jobs, uint8_t *pool, StrOut *outs, int n_jobs, hipStream_t stream);
 void lcd_launch_gather(const GatherJob *jobs, int n_jobs, hipStream_t stream);
+void lcd_launch_patch_reads(PoaRead *tab, const ReadPatch *patches, int n, hipStream_t stream);
 void lcd_launch_anchor_ends(const AnchorEndsJob *jobs, AnchorEndsOut *outs, int n_jobs, hipStream_t stream);
 void lcd_launch_bam_walk(const BamWalkJob *jobs, BamWalkOut *outs, int n_jobs, hipStream_t st);
 void lcd_launch_bam_stat(const BamStatJob *jobs, BamStatOut *outs, int n_jobs, hipStream_t st);

@@ -46,6 +46,9 @@ struct PoaRead {
     int read_beg, read_end; // 1-based anchors on this read
 };
 
+// a read-table entry the anchor stage narrowed (run_many_once: the table goes up once, before the anchor stage; the anchored reads are patched after it)
+struct ReadPatch { uint32_t idx, pad_; PoaRead r; };
+
 struct PoaChain {
     int n_reads;
     int read0;        // first PoaRead of this chain

@@ -153,3 +153,15 @@ void lcd_launch_anchor_ends(const AnchorEndsJob *jobs, AnchorEndsOut *outs, int 
     if (n_jobs <= 0) return;
     hipLaunchKernelGGL(lcd_anchor_ends_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, stream, jobs, outs, n_jobs);
 }
+
+// the anchored reads' entries of the submission's read table, replaced after the anchor stage (40 bytes per anchored read instead of the whole table a second time)
+__global__ void __launch_bounds__(64) lcd_patch_reads_kernel(PoaRead *tab, const ReadPatch *patches, const int n) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const ReadPatch p = patches[i];
+    tab[p.idx] = p.r;
+}
+void lcd_launch_patch_reads(PoaRead *tab, const ReadPatch *patches, int n, hipStream_t stream) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(lcd_patch_reads_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, tab, patches, n);
+}
