@@ -293,7 +293,17 @@ int wfa_default_scap(int plen, int tlen, bool anchor = false) {
     long long s = 24 + d + 40 + (long long)(m * div[anchor ? g_wfa_hint.load() : 0]) * 6; // (ref<->cons and segment jobs are clean: no hint)
     return (int)std::min<long long>(s, 2000000);
 }
-const int kWfaLdsBuckets[3] = {16 << 10, 32 << 10, 64 << 10};
+// LDS classes of the value ring.  A class is one launch whose jobs-per-CU is 160 KB / bucket: until round 4 the buckets were 16 / 32 / 64 KB, and the 64 KB class (two
+// jobs per CU) was the tail of both WFA stages -- 8 800 ref<->cons jobs of a 20-batch submission: 7.8 ms; in the HBM-ring class (256 threads, the ring in L2) the same
+// jobs take 2 ms.  LCD_WFA_BUCKETS_KB="a,b,c" overrides (ascending; the last one is the largest ring that stays in LDS unless LCD_WFA_LDS_MAX_KB says otherwise).
+static std::vector<int> wfa_buckets_init() {
+    std::vector<int> v;
+    if (const char *e = getenv("LCD_WFA_BUCKETS_KB")) { for (const char *p = e; *p;) { const int kb = atoi(p); if (kb > 0) v.push_back(kb << 10); while (*p && *p != ',') ++p; if (*p == ',') ++p; } }
+    if (v.empty()) v = {16 << 10, 32 << 10};
+    std::sort(v.begin(), v.end());
+    return v;
+}
+static const std::vector<int> kWfaLdsBuckets = wfa_buckets_init();
 // class (value ring in LDS or HBM), decision-byte block and snapshots of one job for the score bound s_want
 static uint64_t wfa_block_target() { return (uint64_t)(getenv("LCD_WFA_BLOCK_KB") ? atoi(getenv("LCD_WFA_BLOCK_KB")) : 16 << 10) << 10; } // (test switch: tiny blocks; read once per stage, not per job)
 void wfa_plan(WfaJob &j, const LcdScoring &sc, long long s_want, const uint64_t blk_target = wfa_block_target()) {
@@ -301,7 +311,8 @@ void wfa_plan(WfaJob &j, const LcdScoring &sc, long long s_want, const uint64_t 
     const long long ub = gap(j.plen) + gap(j.tlen); // delete the pattern, insert the text: no optimal score is above it
     s_want = std::max<long long>(8, std::min(s_want, ub));
     WfaLayout L = wfa_layout(j.plen, j.tlen, (int)s_want, (int)s_want + 1, 0, 1, sc.mismatch, sc.o1, sc.e1, sc.o2, sc.e2);
-    if (L.ring_bytes <= (uint64_t)kWfaLdsBuckets[2] && L.blk_bytes <= blk_target) { j.lds = 1; j.s_cap = (int)s_want; j.blk_rows = j.s_cap + 1; j.n_ckpt = 0; }
+    static const uint64_t lds_max = getenv("LCD_WFA_LDS_MAX_KB") ? (uint64_t)atoi(getenv("LCD_WFA_LDS_MAX_KB")) << 10 : (uint64_t)kWfaLdsBuckets.back();
+    if (L.ring_bytes <= lds_max && L.blk_bytes <= blk_target) { j.lds = 1; j.s_cap = (int)s_want; j.blk_rows = j.s_cap + 1; j.n_ckpt = 0; }
     else {
         j.lds = 0;
         if (L.blk_bytes <= blk_target) { j.s_cap = (int)s_want; j.blk_rows = j.s_cap + 1; j.n_ckpt = 0; }
@@ -315,11 +326,11 @@ void wfa_plan(WfaJob &j, const LcdScoring &sc, long long s_want, const uint64_t 
     }
     j.ws_bytes = lcd_align_up(L.total, 256);
 }
-int wfa_class(const WfaJob &j, const LcdScoring &sc) { // 0: HBM ring, 1..3: LDS bucket
+int wfa_class(const WfaJob &j, const LcdScoring &sc) { // 0: HBM ring, 1..: LDS bucket
     if (!j.lds) return 0;
     const WfaLayout L = wfa_layout(j.plen, j.tlen, j.s_cap, j.blk_rows, 0, 1, sc.mismatch, sc.o1, sc.e1, sc.o2, sc.e2);
-    for (int b = 0; b < 3; ++b) if (L.ring_bytes <= (uint64_t)kWfaLdsBuckets[b]) return b + 1;
-    return 3;
+    for (size_t b = 0; b < kWfaLdsBuckets.size(); ++b) if (L.ring_bytes <= (uint64_t)kWfaLdsBuckets[b]) return (int)b + 1;
+    return (int)kWfaLdsBuckets.size();
 }
 uint64_t ed_arena_bytes(int qlen, int tlen) { return (uint64_t)52432 * 20 + (uint64_t)qlen * 8 + (uint64_t)tlen * 2 + 512; }
 
@@ -384,7 +395,7 @@ int run_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, DevBuf &d_jobs, Dev
         // arena size's exponent and four mantissa bits, descending) -- the order inside a launch is about its tail, nothing else depends on it
         {
             auto key_of = [&](const int i) { const uint64_t w = std::max<uint64_t>(jobs[i].ws_bytes, 16); const int e = 63 - __builtin_clzll(w); return (unsigned)cls[i] * 1024u + (1023u - (unsigned)(e * 16 + (int)((w >> (e - 4)) & 15))); };
-            std::vector<uint32_t> cnt(4 * 1024 + 1, 0);
+            std::vector<uint32_t> cnt((kWfaLdsBuckets.size() + 1) * 1024 + 1, 0);
             std::vector<unsigned> kq(m);
             for (size_t q = 0; q < m; ++q) { kq[q] = key_of(which[q]); cnt[kq[q] + 1]++; }
             for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
