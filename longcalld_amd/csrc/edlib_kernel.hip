@@ -52,6 +52,7 @@ __device__ __forceinline__ int myers_pass(const Sub &sp, int ncols, bool rev, in
                                           unsigned long long *blocks_acc) {
     const int qlen = sp.qlen, nb = (qlen + 63) >> 6;
     int result = 0;
+    __shared__ uint8_t tbuf[128];
     for (int tile0 = 0; tile0 < nb; tile0 += 64) {
         const int b = tile0 + lane;
         const bool act = b < nb;
@@ -71,11 +72,19 @@ __device__ __forceinline__ int myers_pass(const Sub &sp, int ncols, bool rev, in
         const bool more = tile0 + 64 < nb;
         const int nsteps = ncols + 63;
         for (int step = 0; step < nsteps; ++step) {
+            // the target's characters come through a 128-byte ring in LDS, 64 columns ahead: read from HBM inside the step they were one dependent ~1 us load per
+            // column -- 0.5 ms per pass of a 400-column pair, which is what the anchor stage's K4 kernel lasted (three passes per pair, 17 000 pairs in two rounds)
+            if ((step & 63) == 0) {
+                const int cc = step + lane;
+                __syncthreads();
+                tbuf[cc & 127] = cc < ncols ? (rev ? sp.t[sp.tlen - 1 - cc] : sp.t[cc]) : (uint8_t)4;
+                __syncthreads();
+            }
             const int hleft = __shfl_up(hout, 1);
             const int c = step - lane;
             if (act && c >= 0 && c < ncols) {
                 const int hin = lane == 0 ? (tile0 == 0 ? 1 : (int)hcarry[c]) : hleft;
-                const uint8_t tc = rev ? sp.t[sp.tlen - 1 - c] : sp.t[c];
+                const uint8_t tc = tbuf[c & 127];
                 const Word Eq = tc == 0 ? peq[0] : tc == 1 ? peq[1] : tc == 2 ? peq[2] : tc == 3 ? peq[3] : peq[4];
                 hout = calc_block(Pv, Mv, Eq, hin, Pv, Mv);
                 score += hout;
@@ -118,6 +127,7 @@ template <int HIN0>
 __device__ __forceinline__ void sg_pass(const Sub &sp, int ncols, bool rev, int lane, signed char *hcarry, unsigned long long *blocks_acc, int *best_out, int *first_out, int *last_out) {
     const int qlen = sp.qlen, nb = (qlen + 63) >> 6;
     int best = 1 << 30, first_c = -1, last_c = -1;
+    __shared__ uint8_t tbuf2[128];
     for (int tile0 = 0; tile0 < nb; tile0 += 64) {
         const int b = tile0 + lane;
         const bool act = b < nb;
@@ -139,11 +149,17 @@ __device__ __forceinline__ void sg_pass(const Sub &sp, int ncols, bool rev, int 
         const int pos = (qlen - 1) & 63;
         const int nsteps = ncols + 63;
         for (int step = 0; step < nsteps; ++step) {
+            if ((step & 63) == 0) { // (the target through a 128-byte LDS ring, 64 columns ahead: myers_pass)
+                const int cc = step + lane;
+                __syncthreads();
+                tbuf2[cc & 127] = cc < ncols ? (rev ? sp.t[sp.tlen - 1 - cc] : sp.t[cc]) : (uint8_t)4;
+                __syncthreads();
+            }
             const int hleft = __shfl_up(hout, 1);
             const int c = step - lane;
             if (act && c >= 0 && c < ncols) {
                 const int hin = lane == 0 ? (tile0 == 0 ? HIN0 : (int)hcarry[c]) : hleft;
-                const uint8_t tc = rev ? sp.t[sp.tlen - 1 - c] : sp.t[c];
+                const uint8_t tc = tbuf2[c & 127];
                 const Word Eq = tc == 0 ? peq[0] : tc == 1 ? peq[1] : tc == 2 ? peq[2] : tc == 3 ? peq[3] : peq[4];
                 hout = calc_block(Pv, Mv, Eq, hin, Pv, Mv);
                 score += hout;
@@ -244,32 +260,57 @@ __global__ void __launch_bounds__(64) lcd_edlib_kernel(const EdJob *jobs, const 
         if (data_size < 1024 * 1024) {
             myers_pass<true, false>(s, tl, false, lane, P, M, S, nullptr, hcarry, &blocks);
             __syncthreads();
-            // traceback on lane 0; tallies broadcast afterwards
+            // Traceback, wave-uniform (every lane walks the same path on the same scalars).  The stored columns are in HBM, and a step needs up to three cells of
+            // two adjacent columns: walked by one lane with dependent loads this was ~2 us per step, 1 - 3 ms per pair -- the anchor stage's K4 kernel (9.4 ms for 17 000
+            // pairs) was its slowest pair's walk.  Now the 64 columns ending at the current one are CACHED IN REGISTERS, lane l holding column c0 - l for the two row
+            // blocks the walk can be in (the current one and the one above: 64 diagonal steps move 64 rows); a cell is three v_readlane's away.  A step that leaves
+            // the cached columns or blocks refreshes the cache (one round trip per ~64 steps); a cell outside it (a long vertical run) is read from HBM as before.
             int r_mis = 0, r_eq = 0, r_ins = 0, r_del = 0, r_runs = 0, leaf_first = -1, leaf_last = -1;
-            if (lane == 0) {
+            {
                 const int NB = (int)nb;
-#define VAL(r, c) ((r) < 0 ? (c) + 1 : (c) < 0 ? (r) + 1 : \
-                   S[(size_t)(c) * NB + ((r) >> 6)] + ((((r) & 63) < 63) ? (-__popcll(P[(size_t)(c) * NB + ((r) >> 6)] >> (((r) & 63) + 1)) + __popcll(M[(size_t)(c) * NB + ((r) >> 6)] >> (((r) & 63) + 1))) : 0))
-                int r = ql - 1, c = tl - 1, cur = VAL(r, c), prev = -1;
+                int c0 = -1, bA = -1;                       // cache: columns c0 - 63 .. c0, blocks bA and bA - 1
+                Word cPa = 0, cMa = 0, cPb = 0, cMb = 0; int cSa = 0, cSb = 0;
+                auto refresh = [&](const int r, const int c) {
+                    c0 = c; bA = r >> 6;
+                    const int cl = c - lane;
+                    if (cl >= 0) {
+                        const size_t oa = (size_t)cl * NB + bA;
+                        cPa = P[oa]; cMa = M[oa]; cSa = S[oa];
+                        if (bA > 0) { cPb = P[oa - 1]; cMb = M[oa - 1]; cSb = S[oa - 1]; }
+                    }
+                };
+                auto rl64 = [&](const Word v, const int l) { return (Word)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l) | ((Word)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l) << 32); };
+                auto val = [&](const int r, const int c) -> int {
+                    if (r < 0) return c + 1;
+                    if (c < 0) return r + 1;
+                    const int b = r >> 6, l = __builtin_amdgcn_readfirstlane(c0 - c), pos = r & 63;
+                    Word pv, mv; int sv;
+                    if (l >= 0 && l < 64 && b == bA) { pv = rl64(cPa, l); mv = rl64(cMa, l); sv = __builtin_amdgcn_readlane(cSa, l); }
+                    else if (l >= 0 && l < 64 && b == bA - 1) { pv = rl64(cPb, l); mv = rl64(cMb, l); sv = __builtin_amdgcn_readlane(cSb, l); }
+                    else { const size_t o = (size_t)c * NB + b; pv = P[o]; mv = M[o]; sv = S[o]; }
+                    return sv + (pos < 63 ? (-__popcll(pv >> (pos + 1)) + __popcll(mv >> (pos + 1))) : 0);
+                };
+                int r = __builtin_amdgcn_readfirstlane(ql - 1), c = __builtin_amdgcn_readfirstlane(tl - 1), prev = -1;
+                refresh(r, c);
+                int cur = val(r, c);
                 while (r >= 0 && c >= 0) {
+                    if (c - 1 < c0 - 63 || (r > 0 && ((r - 1) >> 6) < bA - 1)) refresh(r, c);
                     int op;
-                    const int up = VAL(r - 1, c);
+                    const int up = val(r - 1, c);
                     if (up + 1 == cur) { op = 1; --r; cur = up; }
                     else {
-                        const int left = VAL(r, c - 1);
+                        const int left = val(r, c - 1);
                         if (left + 1 == cur) { op = 2; --c; cur = left; }
-                        else { const int d = VAL(r - 1, c - 1); op = d == cur ? 0 : 3; --r; --c; cur = d; }
+                        else { const int d = val(r - 1, c - 1); op = d == cur ? 0 : 3; --r; --c; cur = d; }
                     }
+                    r = __builtin_amdgcn_readfirstlane(r); c = __builtin_amdgcn_readfirstlane(c); cur = __builtin_amdgcn_readfirstlane(cur);
                     if (op == 0) r_eq++; else if (op == 3) r_mis++; else { if (op == 1) r_ins++; else r_del++; if (op != prev) r_runs++; }
                     if (leaf_last < 0) leaf_last = op;
                     leaf_first = op; prev = op;
                 }
-#undef VAL
                 if (c >= 0) { const int n = c + 1; r_del += n; if (prev != 2) r_runs++; if (leaf_last < 0) leaf_last = 2; leaf_first = 2; }
                 if (r >= 0) { const int n = r + 1; r_ins += n; if (prev != 1) r_runs++; if (leaf_last < 0) leaf_last = 1; leaf_first = 1; }
             }
-            r_mis = __shfl(r_mis, 0); r_eq = __shfl(r_eq, 0); r_ins = __shfl(r_ins, 0); r_del = __shfl(r_del, 0);
-            r_runs = __shfl(r_runs, 0); leaf_first = __shfl(leaf_first, 0); leaf_last = __shfl(leaf_last, 0);
             T.n_mis += r_mis; T.n_eq += r_eq; T.n_ins += r_ins; T.n_del += r_del; T.runs += r_runs;
             if (leaf_first >= 0) {
                 if ((leaf_first == 1 || leaf_first == 2) && T.last_op == leaf_first) T.runs--; // run continues across leaves

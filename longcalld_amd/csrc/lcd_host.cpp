@@ -290,7 +290,7 @@ int wfa_default_scap(int plen, int tlen, bool anchor = false) {
     int d = plen > tlen ? plen - tlen : tlen - plen;
     int m = plen < tlen ? plen : tlen;
     static const double div[3] = {0.005, 0.06, 0.20};
-    long long s = 24 + d + 40 + (long long)(m * div[anchor ? g_wfa_hint.load() : 0]) * 6; // (ref<->cons and segment jobs are clean: no hint)
+    long long s = 24 + d + 40 + (long long)(m * div[anchor ? g_wfa_hint.load() : 0]) * 6; // (ref<->cons and segment jobs are clean: no hint.  Tried in round 4: twice / four times the slope -- 2 002 / 756 instead of 3 441 second-round jobs of 50 000, the stage within noise)
     return (int)std::min<long long>(s, 2000000);
 }
 // LDS classes of the value ring.  A class is one launch whose jobs-per-CU is 160 KB / bucket: until round 4 the buckets were 16 / 32 / 64 KB, and the 64 KB class (two
@@ -1403,7 +1403,10 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             int rc = run_edlib_stage(ks, ej, L->d_ed_jobs, side_by_side ? L->d_ed_arena : L->d_poa_arena, L->d_ed_outs, eo, side_by_side);
             if (rc) return rc;
             if (th && !side_by_side) { hipStreamSynchronize(st); fprintf(stderr, "[host]   anchors: edlib stage done after %.1f ms\n", now_ms() - t_begin); }
-            rc = run_wfa_stage(st, wj, L->d_wfa_jobs, L->d_poa_arena, L->d_wfa_out, L->d_wfa_outs, wo, sc, nullptr, true);
+            // (K3's class launches -- each as long as its longest job -- on the leader's stream and the second side stream: the first has K4, the third the long chains;
+            //  LCD_ANCHOR_WFA_SEQ=1: one after the other on the leader's stream, as before)
+            static const bool k3_two = !(getenv("LCD_ANCHOR_WFA_SEQ") && atoi(getenv("LCD_ANCHOR_WFA_SEQ")) != 0);
+            rc = run_wfa_stage(st, wj, L->d_wfa_jobs, L->d_poa_arena, L->d_wfa_out, L->d_wfa_outs, wo, sc, nullptr, true, k3_two && side_by_side && L->side[1] ? L->side + 1 : nullptr, L->sev, k3_two && side_by_side && L->side[1] ? 1 : 0);
             if (rc) return rc;
             if (side_by_side) { HIPCHK(hipMemcpyAsync(eo.data(), L->d_ed_outs.p, eo.size() * sizeof(EdOut), hipMemcpyDeviceToHost, ks)); HIPCHK(hipStreamSynchronize(ks)); }
             HIPCHK(hipStreamSynchronize(st));
