@@ -205,8 +205,8 @@ __global__ void __launch_bounds__(64) lcd_edlib_kernel(const EdJob *jobs, const 
         if (lane == 0) outs[jb.pad_] = out;
         return;
     }
-    // arena: P[52429] M[52429] (u64) S[52429] (i32) | colL[qlen] colR[qlen] | hcarry[2*tlen]
-    const size_t TB_CAP = 52432;
+    // arena: P[TB_CAP] M[TB_CAP] (u64) S[TB_CAP] (i32) | colL[qlen] colR[qlen] | hcarry[2*tlen]
+    const size_t TB_CAP = (size_t)ed_tb_cap(qlen, tlen); // (the pair's own blocks x columns, at most edlib's 1 MiB rule: lcd_types.h)
     uint8_t *ws = arena + jb.ws_off;
     Word *P = (Word *)ws, *M = P + TB_CAP;
     int *S = (int *)(M + TB_CAP);

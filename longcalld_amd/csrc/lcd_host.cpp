@@ -332,7 +332,7 @@ int wfa_class(const WfaJob &j, const LcdScoring &sc) { // 0: HBM ring, 1..: LDS 
     for (size_t b = 0; b < kWfaLdsBuckets.size(); ++b) if (L.ring_bytes <= (uint64_t)kWfaLdsBuckets[b]) return (int)b + 1;
     return (int)kWfaLdsBuckets.size();
 }
-uint64_t ed_arena_bytes(int qlen, int tlen) { return (uint64_t)52432 * 20 + (uint64_t)qlen * 8 + (uint64_t)tlen * 2 + 512; }
+uint64_t ed_arena_bytes(int qlen, int tlen) { return ed_tb_cap(qlen, tlen) * 20 + (uint64_t)qlen * 8 + (uint64_t)tlen * 2 + 512; }
 
 // ---- generic stage runners (absolute device addresses in job structs) ----
 // (defer_copy: the statuses stay on the device -- a copy into pageable host memory holds the calling thread until the kernel has ended; the caller fetches them later)

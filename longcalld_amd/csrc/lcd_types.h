@@ -206,6 +206,13 @@ static inline LCD_HD WfaLayout wfa_layout(int plen, int tlen, int s_cap, int blk
 }
 
 // ---------------- edlib NW job (K4, src/align.c:222-232) ----------------
+// K4's stored columns (P, M: u64, score: i32 per (column, 64-row block)): edlib keeps them when 20 * blocks * columns + 8 * columns < 1 MiB (edlib.cpp:1188) and splits the
+// problem otherwise (Hirschberg); a sub-problem is never larger than the pair, so the pair's own blocks x columns -- capped by that rule -- is all the room a job needs
+// (until round 4 every pair took the cap: 1 MiB x 17 000 pairs = 18 GB of workspace for a 20-batch submission, 56 KB per pair were used)
+static inline LCD_HD uint64_t ed_tb_cap(int qlen, int tlen) {
+    const uint64_t need = (uint64_t)((qlen + 63) >> 6) * (uint64_t)(tlen > 0 ? tlen : 0) + 16;
+    return (need < 52432 ? need : 52432) + 3 & ~(uint64_t)3;
+}
 struct GatherJob { uint64_t src, dst; uint32_t bytes, pad_; };   // strings_kernel.hip lcd_gather_kernel
 // collect_aln_beg_end (src/align.c:630-663) on the device: reference / query bases consumed up to the END of the last '=' run (a left-to-right anchor) and from the
 // START of the first '=' run to the end (a right-to-left one) of a BAM-style CIGAR -- 20 bytes per anchor job come back instead of the CIGARs themselves
