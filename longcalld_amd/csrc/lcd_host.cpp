@@ -1960,6 +1960,15 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             fprintf(stderr, "[place] thr %d xcc %u se %u sh %u cu %u simd %u  t %.1f..%.1f ms ticks %.3e\n", chain_threads(PC(g)), o.xcc_id & 15, (o.hw_id >> 13) & 7, (o.hw_id >> 12) & 1, (o.hw_id >> 8) & 15, (o.hw_id >> 4) & 3,
                     o.rt_begin / 1e5, o.rt_end / 1e5, (double)o.t_total); }
     }
+    if (const char *ct = getenv("LCD_CHAIN_TIMES")) { // every chain's class, pool, start and end (100 MHz device clock, relative to the first start): tools/occupancy.py
+        if (FILE *f = fopen(ct, "w")) {
+            unsigned long long t0 = ~0ull;
+            for (size_t g = 0; g < nC_all; ++g) t0 = std::min(t0, bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]].rt_begin);
+            for (size_t g = 0; g < nC_all; ++g) { const PoaChainOut &o = bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]]; const PoaChain &pc = PC(g);
+                fprintf(f, "%d %d %d %llu %llu %u %u %d %d %d %llu\n", pc.threads, pc.lds_words * 4, pc.mode, o.rt_begin - t0, o.rt_end - t0, o.xcc_id & 15, (o.hw_id >> 8) & 15, pc.max_len, pc.n_reads, pc.cert, (unsigned long long)o.t_setup); }
+            fclose(f);
+        }
+    }
     if (getenv("LCD_PROFILE_CHAINS")) {
         { // the chains that end last: the tail of the submission (times on the device's 100 MHz clock, relative to the first chain's start)
             std::vector<size_t> ord(nC_all); unsigned long long t0 = ~0ull;
