@@ -493,6 +493,8 @@ def main():
         n_host = int(os.environ.get("BENCH_OVL_THREADS", "0")) or max(2, min(8, (_host_cores() * 3) // 8))
         arena_env = os.environ.get("LCD_ARENA_THREADS")
         os.environ["LCD_ARENA_THREADS"] = os.environ.get("BENCH_OVL_ARENA_THREADS", "1")   # host threads INSIDE one lcd_batch_region_results_arena call (n_host calls run side by side)
+        team_env = os.environ.get("LCD_HOST_TEAM")
+        os.environ["LCD_HOST_TEAM"] = os.environ.get("BENCH_OVL_TEAM", "4")   # the submission's own short thread teams, beside n_host busy pool threads on a 16-CPU quota
         pool_ex = ThreadPoolExecutor(n_host)
         gpu_lock = threading.Lock()
         o_err, o_bytes = [], [0]
@@ -537,7 +539,7 @@ def main():
                 o_err.append(e)
         for grp in lanes2:      # untimed: the second lane's buffers grow to size, every batch's host blocks are allocated once
             o_lane(grp, 1)
-        o_rounds = 3
+        o_rounds = int(os.environ.get("BENCH_OVL_ROUNDS", "5"))   # (per lane: the first upload and the last download are not overlapped -- 2 of 6 submissions at 3 rounds, 2 of 10 at 5)
         o_bytes[0] = 0
         for k_ in o_t:
             o_t[k_] = 0.0
@@ -555,6 +557,10 @@ def main():
             os.environ.pop("LCD_ARENA_THREADS", None)
         else:
             os.environ["LCD_ARENA_THREADS"] = arena_env
+        if team_env is None:
+            os.environ.pop("LCD_HOST_TEAM", None)
+        else:
+            os.environ["LCD_HOST_TEAM"] = team_env
         if o_err:
             raise o_err[0]
         overlap = {"lanes": n_ol, "batches_per_submission": n_sub, "rounds_per_lane": o_rounds, "host_threads": n_host, "seconds": round(to, 4),

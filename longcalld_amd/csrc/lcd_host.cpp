@@ -150,6 +150,10 @@ struct PinBuf {
 };
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// host threads per team of the submission's short parallel loops (capacities, job tables, records, plans).  LCD_HOST_TEAM, read per call: a caller whose own
+// threads are busy beside the submission -- bench.py's PCIe-inclusive pipeline on a box whose cgroup allows 16 CPUs -- asks for fewer; a team that overruns the
+// quota freezes every thread of the process, the submitter included, until the next period
+static int host_team() { const char *e = getenv("LCD_HOST_TEAM"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : v > 32 ? 32 : v; }
 // a loop over [0, n) cut into chunks taken by up to `max_threads` host threads (the calling thread is one of them); f(lo, hi, thread index)
 template <class F> static void par_chunks(const size_t n, const int max_threads, const size_t chunk, F f) {
     const int nth = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, max_threads), (n + chunk - 1) / std::max<size_t>(1, chunk)));
@@ -389,7 +393,7 @@ int run_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, DevBuf &d_jobs, Dev
         // (plans and classes of the jobs are independent: a few host threads -- 50 000 ref<->cons jobs of a 20-batch submission were 3.5 ms of one thread with the GPU idle)
         std::vector<int> cls(n, 0);
         const uint64_t blk_target = wfa_block_target();
-        par_chunks(m, 8, 4096, [&](const size_t lo, const size_t hi, int) { for (size_t q = lo; q < hi; ++q) { const int i = which[q]; wfa_plan(jobs[i], sc, want[i], blk_target); cls[i] = wfa_class(jobs[i], sc); } });
+        par_chunks(m, host_team(), 4096, [&](const size_t lo, const size_t hi, int) { for (size_t q = lo; q < hi; ++q) { const int i = which[q]; wfa_plan(jobs[i], sc, want[i], blk_target); cls[i] = wfa_class(jobs[i], sc); } });
         const double tw1 = now_ms();
         // equal classes contiguous (one launch each); inside a class the larger arenas first (they last longest): a stable counting sort on class | size class (the
         // arena size's exponent and four mantissa bits, descending) -- the order inside a launch is about its tail, nothing else depends on it
@@ -1211,7 +1215,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         out_tots[k] = out_tot;
     };
     {
-        const int nth = std::max(1, std::min(nb, 8));
+        const int nth = std::max(1, std::min(nb, host_team()));
         if (nth == 1) size_chains(0);
         else {
             std::atomic<int> next{0};
@@ -1540,7 +1544,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                     it.phys = ch[k]->addr() + off; off += it.bytes; left -= it.bytes;
                 }
             }
-            par_chunks(which.size(), 8, 4096, [&](const size_t lo, const size_t hi, int) { for (size_t i = lo; i < hi; ++i) {
+            par_chunks(which.size(), host_team(), 4096, [&](const size_t lo, const size_t hi, int) { for (size_t i = lo; i < hi; ++i) {
                 const int k = chain_batch[which[i]];
                 PoaChain &pc = PC(which[i]);
                 pc.ws_off = items[item_of[i]].phys + (pc.ws_off - items[item_of[i]].start);
@@ -1595,9 +1599,9 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             //  with the GPU idle; the chains that did not end with LCD_OK are few and are looked at one by one below)
             std::vector<size_t> flagged;
             {
-                constexpr int NTH = 8;
+                constexpr int NTH = 32; const int nth_r = host_team();
                 std::vector<size_t> fl[NTH];
-                par_chunks(which.size(), NTH, 2048, [&](const size_t lo, const size_t hi, const int t) {
+                par_chunks(which.size(), nth_r, 2048, [&](const size_t lo, const size_t hi, const int t) {
                     for (size_t i = lo; i < hi; ++i) {
                         const int k = chain_batch[which[i]];
                         bs[k]->couts[which[i] - chain_base[k]] = tmp[i];
@@ -1721,7 +1725,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         str_tots[k] = str_tot;
     };
     {
-        const int nth = std::max(1, std::min(nb, 16));
+        const int nth = std::max(1, std::min(nb, 2 * host_team()));
         if (nth == 1) build_jobs(0);
         else {
             std::atomic<int> next{0};
@@ -1750,7 +1754,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             if (!b->rc_jobs.empty()) memcpy(rc_all.data() + rc_base[k], b->rc_jobs.data(), b->rc_jobs.size() * sizeof(WfaJob));
             if (!b->str_jobs.empty()) memcpy(str_all.data() + str_base[k], b->str_jobs.data(), b->str_jobs.size() * sizeof(StrJob));
         };
-        const int nth = std::max(1, std::min(nb, 16));
+        const int nth = std::max(1, std::min(nb, 2 * host_team()));
         if (nth == 1) fill(0);
         else {
             std::atomic<int> next{0};
