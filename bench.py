@@ -205,7 +205,7 @@ def main():
     ap.add_argument("--coalesce", type=int, default=0,
                     help="steps (batches) submitted together through lcd_batch_run_many: one set of launches per stage over the chains of "
                          "all of them, so that the GPU's workgroup dispatcher -- not HIP streams -- packs several chunks' chains onto the CUs")
-    ap.add_argument("--overlap", type=int, default=-1, help="PCIe-inclusive pipeline (never `value`): two submissions of the timed region's size alternate on the GPU while a pool of "
+    ap.add_argument("--overlap", type=int, default=-1, help="PCIe-inclusive pipeline (never `value`): BENCH_OVL_LANES (3) submissions of the timed region's size take turns on the GPU while a pool of "
                     "host threads downloads and materialises the previous one's results and uploads the next one's inputs; -1 = on for the single-GPU HiFi line, 0 = off")
     ap.add_argument("--e2e", type=int, default=0, help="also time the PCIe-inclusive path with E lanes (host threads) each doing upload -> run -> download -> "
                     "materialisation of every result for its own batches, so that one lane's copies overlap another's kernels; reported under pcie_inclusive")
@@ -483,7 +483,7 @@ def main():
     if (args.overlap > 0 or (args.overlap < 0 and args.shape == "hifi")) and world == 1 and not job_mode and args.steps > 0 and args.vars != 2 and st is not None:
         from concurrent.futures import ThreadPoolExecutor
         n_sub = min(n_co, len(groups[0]))
-        n_ol = max(2, int(os.environ.get("BENCH_OVL_LANES", "2")))
+        n_ol = max(2, int(os.environ.get("BENCH_OVL_LANES", "3")))   # (three: a lane's cycle is run + results + upload = ~300 ms of which 200 on the GPU -- with two lanes the GPU waits for results a fifth of the time)
         lanes2 = [groups[0][:n_sub]] + [[align.RegionBatch(bench_opt) for _ in range(n_sub)] for _ in range(n_ol - 1)]
         for grp_ in lanes2[1:]:
             for q, bt in enumerate(grp_):
@@ -539,7 +539,7 @@ def main():
                 o_err.append(e)
         for grp in lanes2:      # untimed: the second lane's buffers grow to size, every batch's host blocks are allocated once
             o_lane(grp, 1)
-        o_rounds = int(os.environ.get("BENCH_OVL_ROUNDS", "5"))   # (per lane: the first upload and the last download are not overlapped -- 2 of 6 submissions at 3 rounds, 2 of 10 at 5)
+        o_rounds = int(os.environ.get("BENCH_OVL_ROUNDS", "4"))   # (per lane: the first upload and the last download are not overlapped -- 2 of 6 submissions at 3 rounds, 2 of 10 at 5)
         o_bytes[0] = 0
         for k_ in o_t:
             o_t[k_] = 0.0
@@ -566,7 +566,7 @@ def main():
         overlap = {"lanes": n_ol, "batches_per_submission": n_sub, "rounds_per_lane": o_rounds, "host_threads": n_host, "seconds": round(to, 4),
                    "regions_per_sec": round(n_ol * o_rounds * n_sub * n_regions / to, 1), "result_bytes_per_submission": int(o_bytes[0] / (n_ol * o_rounds)),
                    "lane_seconds": {k_: round(v_ / n_ol, 4) for k_, v_ in o_t.items()},
-                   "what": "two submissions in flight: lcd_batch_run_many of one while a pool of host threads runs lcd_batch_download + lcd_batch_region_results_arena + "
+                   "what": "several submissions in flight (`lanes`): lcd_batch_run_many of one while a pool of host threads runs lcd_batch_download + lcd_batch_region_results_arena + "
                            "(then) lcd_batch_upload for every batch of the other; every result byte lands in host memory (one block per batch)"}
         for grp_ in lanes2[1:]:
             for bt in grp_:
