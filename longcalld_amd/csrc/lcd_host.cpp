@@ -800,7 +800,9 @@ static int cert_next_level(const PoaChain &) { return 0; }
 // 3 ms x 8 threads this took)
 struct ChainEnv {
     int cert_mode, solo_len, cert_sys, solo_mw, solo_cyc, cell_shrink; long long solo_rl;
+    long long n_chains = 1ll << 40, solo_cyc_min; // (chains in the submission at hand: run_many_once sets it)
     ChainEnv() {
+        solo_cyc_min = getenv("LCD_SOLO_CYC_MIN") ? atoll(getenv("LCD_SOLO_CYC_MIN")) : 16000;
         cert_mode = getenv("LCD_CERT") ? atoi(getenv("LCD_CERT")) : 1;
         solo_len = getenv("LCD_CERT_SOLO_LEN") ? atoi(getenv("LCD_CERT_SOLO_LEN")) : 0;
         cert_sys = getenv("LCD_CERT_SYS") ? atoi(getenv("LCD_CERT_SYS")) : 0;
@@ -843,7 +845,10 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
         if (pc.solo && pc.cert == 1 && env.solo_mw > 0) pc.solo = 2;
         // Round 4: the rows of the long certified-band chains run as a PIPELINE over the four wavefronts (poa_kernel.hip align_cyc: mailboxes, no barrier, the row before in
         // registers) -- LCD_SOLO_CYC=0 keeps them on wavefront 0
-        if (pc.solo == 1 && pc.cert == 1 && env.solo_cyc != 0) pc.solo = 3;
+        // (the four-wavefront pipeline pays on a CROWDED chip, where a lone wavefront of the long chain gets a quarter of its SIMD: 16 / 20 batches 173 / 200 ms with it,
+        //  197 / 206 without.  A chain that has its CU to itself is faster on one wavefront -- a lone batch 117 ms instead of 128, four batches 152 instead of 154:
+        //  the pipeline from LCD_SOLO_CYC_MIN chains per submission on)
+        if (pc.solo == 1 && pc.cert == 1 && env.solo_cyc != 0 && env.n_chains >= env.solo_cyc_min) pc.solo = 3;
     }
     // graph capacity: the worst case is one node per base of every read (sum), the usual case a little more than the longest read.  Sized
     // from an estimate (a few per cent of new nodes per read on top of the backbone; g_node_hint learns noisier data); a chain that runs
@@ -1159,12 +1164,13 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     HIPCHK(hipEventRecord(L->ev[0], st));
     // the reads of every chain with their device addresses (the anchor stage below narrows the partial reads of K1 chains; lengths never change)
     std::vector<std::vector<PoaRead>> preads(nb);
-    const ChainEnv cenv;
+    ChainEnv cenv;
     // (filled per batch by the host threads of size_chains below: 24 MB for a 20-batch submission, 3 ms when one thread copied them)
     // ---- capacities, classes and output blocks of the chains: nothing here depends on the anchor stage, and the longest K2 chains start before it (below) ----
     std::vector<size_t> chain_base(nb + 1, 0), pread_base(nb + 1, 0);
     for (int k = 0; k < nb; ++k) { chain_base[k + 1] = chain_base[k] + bs[k]->chains.size(); pread_base[k + 1] = pread_base[k] + bs[k]->preads.size(); }
     const size_t nC_all = chain_base[nb];
+    cenv.n_chains = (long long)nC_all;
     std::vector<int> chain_batch(nC_all);
     for (int k = 0; k < nb; ++k) for (size_t g = chain_base[k]; g < chain_base[k + 1]; ++g) chain_batch[g] = k;
     std::vector<std::vector<uint64_t>> out_rel(nb);
