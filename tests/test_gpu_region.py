@@ -592,3 +592,11 @@ def test_certified_band_and_long_chain_class_digest_at_job_scale(lcd, monkeypatc
     assert run() == ref
     monkeypatch.delenv("LCD_EARLY"); monkeypatch.setenv("LCD_NO_PREP_THREAD", "1")   # classes, order and arena layout on the calling thread
     assert run() == ref
+    monkeypatch.delenv("LCD_NO_PREP_THREAD")
+    # the long chains' certified-band rows as a pipeline over four wavefronts (align_cyc): the default only from 16 000 chains per submission on -- here always / never
+    monkeypatch.setenv("LCD_SOLO_CYC_MIN", "0")
+    assert run() == ref
+    monkeypatch.setenv("LCD_SOLO_RL", "30000")   # ... and with many more chains in that class
+    assert run() == ref
+    monkeypatch.delenv("LCD_SOLO_RL"); monkeypatch.delenv("LCD_SOLO_CYC_MIN"); monkeypatch.setenv("LCD_SOLO_CYC", "0")
+    assert run() == ref
