@@ -1039,7 +1039,12 @@ static int launch_poa_grouped(hipStream_t st, const PoaChain *sub_p, const size_
         //  K2 chains of noisy reads 6 - 7 us in every wide class; clean reads 1.6 us.  Tried: weighting the noisy K1 chains 1.8x here -- the eight launch groups of an
         //  SV-shape submission are already packed onto the four queues within 5 % of each other (LCD_GROUP_DEBUG=1 prints the table), 1 676 regions/s either way;
         //  eight hardware queues (GPU_MAX_HW_QUEUES=8 LCD_STREAMS=8) make it worse, 1 398: the queues time-slice)
-        while (j < sub.size() && chain_group_key(sub[j]) == key) { const double t = (double)sub[j].n_reads * (sub[j].max_len + 64); cost += t; tail = std::max(tail, t); ++j; }
+        // (noisy reads: a K1 chain's read-base costs 11 - 12 us -- general rows, a re-sort after every read -- against 6 - 7 us in the K2 classes (LCD_PROFILE_CHAINS, SV
+        //  shape); unweighted, the two groups whose single longest K1 chain runs 4 s looked like the lightest streams and the last small groups queued behind them:
+        //  342 + 170 ms at the end of a 6.2 s submission while another stream had been idle for 2.5 s -- tools/timeline.py)
+        static const double k1w = getenv("LCD_NOISY_K1_WEIGHT") ? atof(getenv("LCD_NOISY_K1_WEIGHT")) : 3.0;
+        static const double k1w_from = getenv("LCD_NOISY_K1_FROM") ? atof(getenv("LCD_NOISY_K1_FROM")) : 150000.0; // read-bases (reads x longest read)
+        while (j < sub.size() && chain_group_key(sub[j]) == key) { const double t = (double)sub[j].n_reads * (sub[j].max_len + 64); cost += t; tail = std::max(tail, t * (noisy && sub[j].mode == 0 && t >= k1w_from ? k1w : 1.0)); ++j; } // (the weight on a group's LONGEST chain only, and only on chains of SV-shape size: weighting the ONT shape's K1 groups -- many short chains -- as well moved that shape from 18.5 to 16.9 - 17.5 k regions/s)
         {
             const int lds = sub[i].lds_words * 4, thr = sub[i].threads;
             const int per_cu = std::max(1, std::min((160 * 1024) / (lds + (thr == 64 ? 1 : 6) * 1024), 1024 / thr));
