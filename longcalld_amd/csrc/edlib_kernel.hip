@@ -215,6 +215,7 @@ __global__ void __launch_bounds__(64) lcd_edlib_kernel(const EdJob *jobs, const 
     unsigned long long blocks = 0;
     Sub top = {q, t, qlen, tlen};
     int dist, t0 = 0, tl0 = tlen;
+    const bool top_leaf = jb.mode != 1 && 20ll * ((qlen + 63) >> 6) * tlen + 8ll * tlen < 1024 * 1024;
     if (jb.mode == 1) {
         // HW (infix, edlib.cpp:146-280): best score over all end positions with a free start; the FIRST end position; its start from the reversed problem on the
         // prefix that ends there (anchored, the LAST position with the best score = the longest stretch); the path is then the NW path on that stretch
@@ -231,7 +232,9 @@ __global__ void __launch_bounds__(64) lcd_edlib_kernel(const EdJob *jobs, const 
         if (best2 != best || endf < 0 || sl < 0) { out.status = LCD_ERR_BACKTRACK; if (lane == 0) outs[jb.pad_] = out; return; }
         dist = best; t0 = endf - sl; tl0 = sl + 1;
         out.start = t0; out.end = endf;
-    } else
+    } else if (top_leaf)
+        dist = -1; // (the pair is one leaf of the path search: its stored-column pass below gives the distance as well -- a distance-only pass in front of it was half the kernel)
+    else
         dist = myers_pass<false, false>(top, tlen, false, lane, nullptr, nullptr, nullptr, nullptr, hcarry, &blocks);
     out.dist = dist;
     __shared__ int stk[64][5]; // qoff, qlen, toff, tlen, best
@@ -258,7 +261,8 @@ __global__ void __launch_bounds__(64) lcd_edlib_kernel(const EdJob *jobs, const 
         const long long nb = (ql + 63) >> 6;
         const long long data_size = 20ll * nb * tl + 8ll * tl;
         if (data_size < 1024 * 1024) {
-            myers_pass<true, false>(s, tl, false, lane, P, M, S, nullptr, hcarry, &blocks);
+            const int leaf_score = myers_pass<true, false>(s, tl, false, lane, P, M, S, nullptr, hcarry, &blocks);
+            if (top_leaf) out.dist = leaf_score;
             __syncthreads();
             // Traceback, wave-uniform (every lane walks the same path on the same scalars).  The stored columns are in HBM, and a step needs up to three cells of
             // two adjacent columns: walked by one lane with dependent loads this was ~2 us per step, 1 - 3 ms per pair -- the anchor stage's K4 kernel (9.4 ms for 17 000
