@@ -1776,6 +1776,33 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     }
     if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host] job tables of the WFA / string stages: %.1f ms (%zu + %zu jobs)\n", now_ms() - th0, rc_all.size(), str_all.size());
     HIPCHK(hipEventRecord(L->ev[3], st));
+    // S4 (MSA rows -> strings) needs the chains' outputs only, not the ref<->cons alignments: it runs BESIDE S3 -- its 37 MB job table (670 000 jobs of a 20-batch
+    // submission) goes up from a helper thread on a side stream while this thread plans and launches the WFA classes (one after the other they were 8 + 4 ms, the
+    // table's pageable upload alone 2 ms of this thread).  LCD_STRINGS_SEQ=1: after S3 on the leader's stream, as before
+    std::vector<StrOut> &str_outs = L->h_str_outs;
+    if (str_outs.capacity() < str_all.size()) str_outs.reserve(str_all.size() + str_all.size() / 4 + 64);
+    str_outs.resize(str_all.size());
+    if (!str_all.empty() && (L->d_str_jobs.ensure(str_all.size() * sizeof(StrJob)) || L->d_str_outs.ensure(str_all.size() * sizeof(StrOut)))) return -11;
+    auto strings_stage = [&](hipStream_t s2) -> int {
+        if (str_all.empty()) return 0;
+        HIPCHK(hipMemcpyAsync(L->d_str_jobs.p, str_all.data(), str_all.size() * sizeof(StrJob), hipMemcpyHostToDevice, s2));
+        lcd_launch_strings((const StrJob *)L->d_str_jobs.p, nullptr, (StrOut *)L->d_str_outs.p, (int)str_all.size(), s2);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(str_outs.data(), L->d_str_outs.p, str_all.size() * sizeof(StrOut), hipMemcpyDeviceToHost, s2));
+        return 0;
+    };
+    const bool strings_beside = L->side[3] && !getenv("LCD_STRINGS_SEQ") && !str_all.empty();
+    int strings_rc = 0;
+    Joiner strings_thread;
+    if (strings_beside) {
+        HIPCHK(hipStreamWaitEvent(L->side[3], L->ev[3], 0));
+        const int dev_here = cur_device();
+        strings_thread.t = std::thread([&, dev_here]() {
+            if (hipSetDevice(dev_here) != hipSuccess) { strings_rc = -1; return; }
+            strings_rc = strings_stage(L->side[3]);
+            if (!strings_rc && hipStreamSynchronize(L->side[3]) != hipSuccess) strings_rc = -1;
+        });
+    }
     {
         int wret = 0;
         std::vector<WfaOut> rc_outs;
@@ -1790,16 +1817,8 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         }
     }
     HIPCHK(hipEventRecord(L->ev[4], st));
-    std::vector<StrOut> &str_outs = L->h_str_outs;
-    if (str_outs.capacity() < str_all.size()) str_outs.reserve(str_all.size() + str_all.size() / 4 + 64);
-    str_outs.resize(str_all.size());
-    if (!str_all.empty()) {
-        if (L->d_str_jobs.ensure(str_all.size() * sizeof(StrJob)) || L->d_str_outs.ensure(str_all.size() * sizeof(StrOut))) return -11;
-        HIPCHK(hipMemcpyAsync(L->d_str_jobs.p, str_all.data(), str_all.size() * sizeof(StrJob), hipMemcpyHostToDevice, st));
-        lcd_launch_strings((const StrJob *)L->d_str_jobs.p, nullptr, (StrOut *)L->d_str_outs.p, (int)str_all.size(), st);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(str_outs.data(), L->d_str_outs.p, str_all.size() * sizeof(StrOut), hipMemcpyDeviceToHost, st));
-    }
+    if (strings_beside) { if (strings_thread.t.joinable()) strings_thread.t.join(); if (strings_rc) return set_err(-20, "strings stage failed on its side stream"); }
+    else { const int rcs = strings_stage(st); if (rcs) return rcs; }
     HIPCHK(hipEventRecord(L->ev[5], st));
     HIPCHK(hipStreamSynchronize(st));
     // ---------------- S5 (only with opt.collect_ref_read_aln_str): ref<->read strings, src/align.c:1056-1146 ----------------
