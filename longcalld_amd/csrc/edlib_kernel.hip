@@ -297,15 +297,26 @@ __global__ void __launch_bounds__(64) lcd_edlib_kernel(const EdJob *jobs, const 
                 int r = __builtin_amdgcn_readfirstlane(ql - 1), c = __builtin_amdgcn_readfirstlane(tl - 1), prev = -1;
                 refresh(r, c);
                 int cur = val(r, c);
+                // the vertical step D[r][c] - D[r-1][c] of a stored column IS its P / M bit at row r (row -1 is the boundary c + 1): the Up test and the diagonal
+                // cell (= the left cell minus ITS vertical step) need one 32-bit half of a word instead of a full cell value (score + two popcounts)
+                auto vbit = [&](const Word wa, const Word wb, const Word *G, const int r, const int c) -> int { // bit (r & 63) of the word at (column c, block r >> 6)
+                    const int b = r >> 6, l = __builtin_amdgcn_readfirstlane(c0 - c), pos = r & 63;
+                    unsigned h;
+                    if (l >= 0 && l < 64 && (b == bA || b == bA - 1)) { const Word w = b == bA ? wa : wb; h = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(pos < 32 ? w : w >> 32), l); }
+                    else { const Word w = G[(size_t)c * NB + b]; h = (unsigned)(pos < 32 ? w : w >> 32); }
+                    return (int)((h >> (pos & 31)) & 1u);
+                };
                 while (r >= 0 && c >= 0) {
                     if (c - 1 < c0 - 63 || (r > 0 && ((r - 1) >> 6) < bA - 1)) refresh(r, c);
                     int op;
-                    const int up = val(r - 1, c);
-                    if (up + 1 == cur) { op = 1; --r; cur = up; }
+                    if (vbit(cPa, cPb, P, r, c)) { op = 1; --r; cur -= 1; }   // Up: D[r-1][c] + 1 == D[r][c]
                     else {
                         const int left = val(r, c - 1);
                         if (left + 1 == cur) { op = 2; --c; cur = left; }
-                        else { const int d = val(r - 1, c - 1); op = d == cur ? 0 : 3; --r; --c; cur = d; }
+                        else {
+                            const int d = c == 0 ? val(r - 1, c - 1) : left - vbit(cPa, cPb, P, r, c - 1) + vbit(cMa, cMb, M, r, c - 1);
+                            op = d == cur ? 0 : 3; --r; --c; cur = d;
+                        }
                     }
                     r = __builtin_amdgcn_readfirstlane(r); c = __builtin_amdgcn_readfirstlane(c); cur = __builtin_amdgcn_readfirstlane(cur);
                     if (op == 0) r_eq++; else if (op == 3) r_mis++; else { if (op == 1) r_ins++; else r_del++; if (op != prev) r_runs++; }
