@@ -1690,32 +1690,41 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     // the job tables of the batches are independent: built on a few host threads (37 000 string jobs per configs[1] batch; serial, this was 30 ms of a 20-batch
     // submission), concatenated and given their device blocks afterwards
     std::vector<uint64_t> str_tots(nb, 0);
-    auto build_jobs = [&](const int k) {
+    // (two passes over a batch's regions: `what` 1 = consensus counts, statistics and the ref<->cons jobs -- what the WFA stage waits for; 2 = the string jobs, twelve
+    //  times as many, built on the strings stage's own thread while the WFA kernels run)
+    auto build_jobs = [&](const int k, const int what) {
         lcd_batch_t *b = bs[k]; lcd_batch_stats_t &S = b->st;
         const uint64_t in_base = b->d_in.addr();
-        b->rc_jobs.clear(); b->rc_region.clear(); b->rc_clu.clear();
-        b->str_jobs.clear(); b->str_region.clear(); b->str_clu.clear(); b->str_k.clear();
+        if (what == 1) { b->rc_jobs.clear(); b->rc_region.clear(); b->rc_clu.clear(); b->reg_rc0.assign(b->regs.size() + 1, 0); }
+        else { b->str_jobs.clear(); b->str_region.clear(); b->str_clu.clear(); b->str_k.clear(); b->reg_str0.assign(b->regs.size() + 1, 0); }
         uint64_t str_tot = 0;
-        b->reg_rc0.assign(b->regs.size() + 1, 0); b->reg_str0.assign(b->regs.size() + 1, 0);
         for (size_t ri = 0; ri < b->regs.size(); ++ri) {
             RegionRec &R = b->regs[ri];
-            b->reg_rc0[ri] = (uint32_t)b->rc_jobs.size(); b->reg_str0[ri] = (uint32_t)b->str_jobs.size();
-            R.n_cons = 0;
-            if (R.branch == 0) continue;
-            S.n_regions++;
-            if (R.branch == 1) {
-                const PoaChainOut &o0 = b->couts[R.chain[0]], &o1 = b->couts[R.chain[1]];
-                if (o0.n_cons + o1.n_cons != 2) continue; // src/align.c:1339
-                R.n_cons = 2;
-            } else R.n_cons = b->couts[R.chain[0]].n_cons;
-            if (R.n_cons > 0) S.n_regions_resolved++;
+            if (what == 1) {
+                b->reg_rc0[ri] = (uint32_t)b->rc_jobs.size();
+                R.n_cons = 0;
+                if (R.branch == 0) continue;
+                S.n_regions++;
+                if (R.branch == 1) {
+                    const PoaChainOut &o0 = b->couts[R.chain[0]], &o1 = b->couts[R.chain[1]];
+                    if (o0.n_cons + o1.n_cons != 2) continue; // src/align.c:1339
+                    R.n_cons = 2;
+                } else R.n_cons = b->couts[R.chain[0]].n_cons;
+                if (R.n_cons > 0) S.n_regions_resolved++;
+            } else {
+                b->reg_str0[ri] = (uint32_t)b->str_jobs.size();
+                if (R.branch == 0) continue;
+            }
             for (int c = 0; c < R.n_cons; ++c) {
                 const int ch = R.branch == 1 ? R.chain[c] : R.chain[0];
                 const int cc = R.branch == 1 ? 0 : c; // consensus index inside the chain
                 const PoaChain &pc = b->pchains[ch]; const PoaChainOut &co = b->couts[ch];
-                WfaJob wj; wj.p_off = in_base + R.ref_off; wj.plen = R.ref_len; wj.t_off = pc.out_off + (uint64_t)cc * pc.node_cap; wj.tlen = co.cons_len[cc];
-                wj.gap_aln = b->opt.gap_aln; wj.want = 2; wj.s_cap = wfa_default_scap(wj.plen, wj.tlen); wj.ws_off = wj.ws_bytes = wj.out_off = 0;
-                b->rc_jobs.push_back(wj); b->rc_region.push_back((int)ri); b->rc_clu.push_back(c);
+                if (what == 1) {
+                    WfaJob wj; wj.p_off = in_base + R.ref_off; wj.plen = R.ref_len; wj.t_off = pc.out_off + (uint64_t)cc * pc.node_cap; wj.tlen = co.cons_len[cc];
+                    wj.gap_aln = b->opt.gap_aln; wj.want = 2; wj.s_cap = wfa_default_scap(wj.plen, wj.tlen); wj.ws_off = wj.ws_bytes = wj.out_off = 0;
+                    b->rc_jobs.push_back(wj); b->rc_region.push_back((int)ri); b->rc_clu.push_back(c);
+                    continue;
+                }
                 const uint64_t msa0 = pc.out_off + 2ull * pc.node_cap;
                 const uint64_t cons_row = msa0 + (uint64_t)(pc.n_reads + cc) * pc.node_cap;
                 const int nk = R.branch == 1 ? pc.n_reads : co.clu_n[cc];
@@ -1732,66 +1741,61 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                 }
             }
         }
-        b->reg_rc0[b->regs.size()] = (uint32_t)b->rc_jobs.size(); b->reg_str0[b->regs.size()] = (uint32_t)b->str_jobs.size();
-        str_tots[k] = str_tot;
+        if (what == 1) b->reg_rc0[b->regs.size()] = (uint32_t)b->rc_jobs.size();
+        else { b->reg_str0[b->regs.size()] = (uint32_t)b->str_jobs.size(); str_tots[k] = str_tot; }
     };
-    {
+    auto over_batches = [&](auto f) { // f(k) for every batch, on a team of host threads
         const int nth = std::max(1, std::min(nb, 2 * host_team()));
-        if (nth == 1) build_jobs(0);
-        else {
-            std::atomic<int> next{0};
-            std::vector<std::thread> ths;
-            for (int t = 0; t < nth; ++t) ths.emplace_back([&]() { for (int k; (k = next.fetch_add(1)) < nb;) build_jobs(k); });
-            for (auto &t : ths) t.join();
-        }
-    }
-    if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host]   per-batch tables built: %.1f ms\n", now_ms() - th0);
-    for (int k = 0; k < nb; ++k) {
-        lcd_batch_t *b = bs[k]; const uint64_t str_tot = str_tots[k];
-        if (!b->str_jobs.empty() && b->d_final.ensure(str_tot)) return -11;
-        b->final_bytes = str_tot;
-        rc_base[k + 1] = rc_base[k] + b->rc_jobs.size(); str_base[k + 1] = str_base[k] + b->str_jobs.size();
-    }
-    // (the joint tables: sized once, filled by the same host threads -- 670 000 string jobs per 20 batches; appended serially into fresh vectors this was 15 - 25 ms
-    //  of a 300 ms submission with the GPU idle)
+        if (nth == 1) { for (int k = 0; k < nb; ++k) f(k); return; }
+        std::atomic<int> next{0};
+        std::vector<std::thread> ths;
+        for (int t = 0; t < nth; ++t) ths.emplace_back([&]() { for (int k; (k = next.fetch_add(1)) < nb;) f(k); });
+        for (auto &t : ths) t.join();
+    };
+    over_batches([&](const int k) { build_jobs(k, 1); });
+    for (int k = 0; k < nb; ++k) rc_base[k + 1] = rc_base[k] + bs[k]->rc_jobs.size();
     if (rc_all.capacity() < rc_base[nb]) rc_all.reserve(rc_base[nb] + rc_base[nb] / 4 + 64); // (headroom: the next submission's tables are a few per cent larger or smaller)
-    if (str_all.capacity() < str_base[nb]) str_all.reserve(str_base[nb] + str_base[nb] / 4 + 64);
-    rc_all.resize(rc_base[nb]); str_all.resize(str_base[nb]);
-    {
-        auto fill = [&](const int k) {
+    rc_all.resize(rc_base[nb]);
+    for (int k = 0; k < nb; ++k) if (!bs[k]->rc_jobs.empty()) memcpy(rc_all.data() + rc_base[k], bs[k]->rc_jobs.data(), bs[k]->rc_jobs.size() * sizeof(WfaJob));
+    if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host] job table of the WFA stage: %.1f ms (%zu jobs)\n", now_ms() - th0, rc_all.size());
+    // the string jobs (670 000 per 20 batches; appended serially into fresh vectors their tables were 15 - 25 ms of a 300 ms submission with the GPU idle): per batch on
+    // host threads, the joint table sized once and filled by the same threads, the batches' output blocks given their device memory in between
+    auto build_string_tables = [&]() -> int {
+        over_batches([&](const int k) { build_jobs(k, 2); });
+        for (int k = 0; k < nb; ++k) {
+            lcd_batch_t *b = bs[k]; const uint64_t str_tot = str_tots[k];
+            if (!b->str_jobs.empty() && b->d_final.ensure(str_tot)) return -11;
+            b->final_bytes = str_tot;
+            str_base[k + 1] = str_base[k] + b->str_jobs.size();
+        }
+        if (str_all.capacity() < str_base[nb]) str_all.reserve(str_base[nb] + str_base[nb] / 4 + 64);
+        str_all.resize(str_base[nb]);
+        over_batches([&](const int k) {
             lcd_batch_t *b = bs[k];
             const uint64_t fin = b->d_final.addr();
             for (auto &j : b->str_jobs) j.out_off += fin;
-            if (!b->rc_jobs.empty()) memcpy(rc_all.data() + rc_base[k], b->rc_jobs.data(), b->rc_jobs.size() * sizeof(WfaJob));
             if (!b->str_jobs.empty()) memcpy(str_all.data() + str_base[k], b->str_jobs.data(), b->str_jobs.size() * sizeof(StrJob));
-        };
-        const int nth = std::max(1, std::min(nb, 2 * host_team()));
-        if (nth == 1) fill(0);
-        else {
-            std::atomic<int> next{0};
-            std::vector<std::thread> ths;
-            for (int t = 0; t < nth; ++t) ths.emplace_back([&]() { for (int k; (k = next.fetch_add(1)) < nb;) fill(k); });
-            for (auto &t : ths) t.join();
-        }
-    }
-    if (getenv("LCD_TIME_HOST")) fprintf(stderr, "[host] job tables of the WFA / string stages: %.1f ms (%zu + %zu jobs)\n", now_ms() - th0, rc_all.size(), str_all.size());
+        });
+        return 0;
+    };
     HIPCHK(hipEventRecord(L->ev[3], st));
     // S4 (MSA rows -> strings) needs the chains' outputs only, not the ref<->cons alignments: it runs BESIDE S3 -- its 37 MB job table (670 000 jobs of a 20-batch
     // submission) goes up from a helper thread on a side stream while this thread plans and launches the WFA classes (one after the other they were 8 + 4 ms, the
     // table's pageable upload alone 2 ms of this thread).  LCD_STRINGS_SEQ=1: after S3 on the leader's stream, as before
     std::vector<StrOut> &str_outs = L->h_str_outs;
-    if (str_outs.capacity() < str_all.size()) str_outs.reserve(str_all.size() + str_all.size() / 4 + 64);
-    str_outs.resize(str_all.size());
-    if (!str_all.empty() && (L->d_str_jobs.ensure(str_all.size() * sizeof(StrJob)) || L->d_str_outs.ensure(str_all.size() * sizeof(StrOut)))) return -11;
     auto strings_stage = [&](hipStream_t s2) -> int {
+        if (const int rcb = build_string_tables()) return rcb;
+        if (str_outs.capacity() < str_all.size()) str_outs.reserve(str_all.size() + str_all.size() / 4 + 64);
+        str_outs.resize(str_all.size());
         if (str_all.empty()) return 0;
+        if (L->d_str_jobs.ensure(str_all.size() * sizeof(StrJob)) || L->d_str_outs.ensure(str_all.size() * sizeof(StrOut))) return -11;
         HIPCHK(hipMemcpyAsync(L->d_str_jobs.p, str_all.data(), str_all.size() * sizeof(StrJob), hipMemcpyHostToDevice, s2));
         lcd_launch_strings((const StrJob *)L->d_str_jobs.p, nullptr, (StrOut *)L->d_str_outs.p, (int)str_all.size(), s2);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(str_outs.data(), L->d_str_outs.p, str_all.size() * sizeof(StrOut), hipMemcpyDeviceToHost, s2));
         return 0;
     };
-    const bool strings_beside = L->side[3] && !getenv("LCD_STRINGS_SEQ") && !str_all.empty();
+    const bool strings_beside = L->side[3] && !getenv("LCD_STRINGS_SEQ");
     int strings_rc = 0;
     Joiner strings_thread;
     if (strings_beside) {
@@ -1817,7 +1821,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         }
     }
     HIPCHK(hipEventRecord(L->ev[4], st));
-    if (strings_beside) { if (strings_thread.t.joinable()) strings_thread.t.join(); if (strings_rc) return set_err(-20, "strings stage failed on its side stream"); }
+    if (strings_beside) { if (strings_thread.t.joinable()) strings_thread.t.join(); if (strings_rc) return strings_rc == -11 ? -11 : set_err(-20, "strings stage failed on its side stream"); }
     else { const int rcs = strings_stage(st); if (rcs) return rcs; }
     HIPCHK(hipEventRecord(L->ev[5], st));
     HIPCHK(hipStreamSynchronize(st));
