@@ -948,7 +948,11 @@ static void chain_class(PoaChain &pc, bool noisy) {
         static const int rk_env = getenv("LCD_RING_K") ? atoi(getenv("LCD_RING_K")) : 8, rk_len = getenv("LCD_RING_K_LEN") ? atoi(getenv("LCD_RING_K_LEN")) : 1500;
         if (pc.max_len >= rk_len && rk_env >= 2 && (rk_env & (rk_env - 1)) == 0 && rk_env <= 32) K = rk_env;
     }
-    const long long dp_bytes = (long long)K * 3 * wmax * 4 + seq_bytes; // the ring holds `wmax` columns per slot (4 * threads, or the narrower preferred window of a single-wavefront banded chain)
+    // certified-band K2 chains of the single-wavefront class keep 16-bit ring values (H, E1, E2 of reads below 15 000 bases fit int16): their 512-column ring was 12 of
+    // their 16 KB, and LDS x time is what a submission runs out of first ("Where the chain kernels' time goes now").  LCD_RING16=0: 32-bit, as before
+    static const bool ring16_on = !(getenv("LCD_RING16") && atoi(getenv("LCD_RING16")) == 0);
+    pc.ring16 = ring16_on && threads == 64 && !pc.solo && pc.cert == 1 && pc.max_len < 15000 ? 1 : 0; pc.pad3_ = 0;
+    const long long dp_bytes = (long long)K * 3 * wmax * (pc.ring16 ? 2 : 4) + seq_bytes; // the ring holds `wmax` columns per slot (4 * threads, or the narrower preferred window of a single-wavefront banded chain)
     // the re-sort's LDS copy of the graph: 8 B per node + 4 B per edge (topo_sort_block); edges ~ nodes + a few per bubble
     long long need = std::max(dp_bytes, est_nodes * 8 + (est_nodes + est_nodes / 8) * 4 + 64);
     { // the single-wavefront class is kept to a small pool: 16 such chains per CU (8 KB each, the wavefront limit at 128 VGPRs) instead of 2-9

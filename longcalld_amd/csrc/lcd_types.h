@@ -71,6 +71,7 @@ struct PoaChain {
     uint64_t cu_rank;     // device address of int[4096]: raw (XCC, SE, SH, CU) id -> compact CU index, -1 unknown; 0: none
     int n_slots, per_cu;
     int solo;             // 1: a long single-wavefront chain in a 256-thread workgroup -- wavefront 0 runs the rows (align_lean), all four the per-read graph phases
+    int ring16, pad3_;    // ring16: the LDS ring of this chain holds 16-bit values (certified-band K2 chains of the single-wavefront class: half the pool, lcd_host.cpp chain_class)
     int cert, ring_k;     // ring_k: ring slots of the single-wavefront class's windowed rows (a power of two >= 2, 0 = 2; the other classes: 2), lcd_host.cpp chain_class;  cert 1: K2 chain in the single-wavefront class, rows restricted to the certified band (poa_kernel.hip align_certified)
 };
 

@@ -80,6 +80,7 @@ struct Ctx {
     int *cert; int cert_on, cert_hist; // certified band of a K2 chain (align_certified): 7 x node_cap ints; largest bound-to-score slack of the chain's reads so far
     int wmax, seq_cap, pool_words, spill_x, ring_k, plan_k, solo;
     unsigned long long wd_deadline;   // shader-clock tick after which the chain gives up (LCD_ERR_WATCHDOG): checked once per 64 DP rows, per read, per 256 backtrack steps
+    int ring16;                        // the chain's LDS ring holds 16-bit values (align_lean<2, C> only; the generic rows then see half as many int32 columns)
     int topo_mode;                     // test switches of the re-sort (LCD_DBG bits 64 / 128 / 256): 1 = never the compact LDS copy, 2 = the compact copy even where the packed words fit, 4 = its FIFO holds three nodes
     int mm_valid;                      // g.deg / g.queue hold, by topological index, every row's smallest predecessor index / largest successor index (topo_sort_block; subgraph_nodes_wave0)
     int n_node, n_edge, node_cap, edge_cap, rid_words;
@@ -1319,6 +1320,30 @@ template <int C> __device__ __forceinline__ void lds_stc(const unsigned o, const
     else if constexpr (C == 2) { lcd_v2i t; t.x = v[0]; t.y = v[1]; *(__attribute__((address_space(3))) lcd_v2i *)(uintptr_t)o = t; }
     else *(lcd_lds_i32 *)(uintptr_t)o = v[0];
 }
+// 16-bit ring values (certified-band K2 chains of the single-wavefront class: H, E1, E2 of reads below 15 000 bases fit int16; the ring is three quarters of such a
+// chain's LDS pool, and LDS x time is what a submission runs out of first).  Stores saturate (v_cvt_pk_i16_i32); everything at the floor -- the fillers outside a
+// row's interval, unreachable cells -- comes back as LCD_GUARD: below every real value, which is all the rows ask of them
+typedef short lcd_v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk16(const int a, const int b) { const lcd_v2s t = __builtin_amdgcn_cvt_pk_i16(a, b); return __builtin_bit_cast(unsigned, t); }
+__device__ __forceinline__ int un16(const int v) { return v == -32768 ? LCD_GUARD : v; }
+__device__ __forceinline__ int lds_ld16(const unsigned o) { return un16((int)*(const __attribute__((address_space(3))) short *)(uintptr_t)o); }
+template <int C> __device__ __forceinline__ void lds_ldc16(const unsigned o, int (&v)[C]) {
+    if constexpr (C == 1) v[0] = lds_ld16(o);
+    else {
+        unsigned w[C / 2];
+        if constexpr (C == 2) w[0] = (unsigned)*(const lcd_lds_i32 *)(uintptr_t)o;
+        else if constexpr (C == 4) { const lcd_v2i t = *(const __attribute__((address_space(3))) lcd_v2i *)(uintptr_t)o; w[0] = (unsigned)t.x; w[1] = (unsigned)t.y; }
+        else { const lcd_v4i t = *(const lcd_lds_v4i *)(uintptr_t)o; w[0] = (unsigned)t.x; w[1] = (unsigned)t.y; w[2] = (unsigned)t.z; w[3] = (unsigned)t.w; }
+#pragma unroll
+        for (int k = 0; k < C / 2; ++k) { v[2 * k] = un16((int)(short)(w[k] & 0xffffu)); v[2 * k + 1] = un16((int)w[k] >> 16); }
+    }
+}
+template <int C> __device__ __forceinline__ void lds_stc16(const unsigned o, const int (&v)[C]) {
+    if constexpr (C == 1) *(__attribute__((address_space(3))) short *)(uintptr_t)o = (short)(pk16(v[0], v[0]) & 0xffffu);
+    else if constexpr (C == 2) *(lcd_lds_i32 *)(uintptr_t)o = (int)pk16(v[0], v[1]);
+    else if constexpr (C == 4) { lcd_v2i t; t.x = (int)pk16(v[0], v[1]); t.y = (int)pk16(v[2], v[3]); *(__attribute__((address_space(3))) lcd_v2i *)(uintptr_t)o = t; }
+    else { lcd_v4i t; t.x = (int)pk16(v[0], v[1]); t.y = (int)pk16(v[2], v[3]); t.z = (int)pk16(v[4], v[5]); t.w = (int)pk16(v[6], v[7]); *(lcd_lds_v4i *)(uintptr_t)o = t; }
+}
 template <int C> __device__ __forceinline__ void glb_ldc(const int *p, int (&v)[C]) {
     if constexpr (C == 8) { const lcd_v4i t = *(const lcd_glb_v4i *)p, u = *(const lcd_glb_v4i *)(p + 4); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; v[4] = u.x; v[5] = u.y; v[6] = u.z; v[7] = u.w; }
     else if constexpr (C == 4) { const lcd_v4i t = *(const lcd_glb_v4i *)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
@@ -1724,12 +1749,18 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     if (qlen >= 65535) return -1; // (beg | end << 16 words)
     if (BANDED && (oe1 <= 0 || oe2 <= 0 || e1 < 0 || e2 < 0)) return -1; // (the row maximum is taken from Hpre: a horizontal gap must cost something)
     const int QB = (qlen + 12 + 15) & ~15;
+    const bool r16 = FIXED && usgpr(g.ring16) != 0; // (16-bit ring values: lds_stc16 / lds_ldc16)
+    const unsigned RB = r16 ? 2u : 4u;
+    auto ring_st3 = [&](const unsigned slot, const int x, const int (&va)[C], const int (&vb)[C], const int (&vc)[C]) { // slot: byte address of a ring slot; x: its first column here
+        if (FIXED && r16) { lds_stc16<C>(slot + 2 * x, va); lds_stc16<C>(slot + 2 * (WIN + x), vb); lds_stc16<C>(slot + 2 * (2 * WIN + x), vc); }
+        else { lds_stc<C>(slot + 4 * x, va); lds_stc<C>(slot + 4 * (WIN + x), vb); lds_stc<C>(slot + 4 * (2 * WIN + x), vc); }
+    };
     {
         // the pool of a single-wavefront chain is laid out for the window the host expects (PoaChain.wmax columns per ring slot); a wider window moves the
         // query cache up and gives up the first-predecessor distances -- or, if the pool is too small for that, leaves the read to the next wider window
-        unsigned ring_bytes = (unsigned)(K * SLOTW * 4);
+        unsigned ring_bytes = (unsigned)(K * SLOTW) * RB;
         if (sq1 < ring + ring_bytes) {
-            if (ring_bytes + (unsigned)QB > (unsigned)g.pool_words * 4u && K > g.plan_k) { K = usgpr(g.plan_k); ring_bytes = (unsigned)(K * SLOTW * 4); }
+            if (ring_bytes + (unsigned)QB > (unsigned)g.pool_words * 4u && K > g.plan_k) { K = usgpr(g.plan_k); ring_bytes = (unsigned)(K * SLOTW) * RB; }
             if (ring_bytes + (unsigned)QB > (unsigned)g.pool_words * 4u) return -1;
             if (sq1 < ring + ring_bytes) { sq1 = ring + ring_bytes; pd = 0xffffffffu; wo->clobber = 1; }
         }
@@ -1760,7 +1791,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
             const bool in = j <= end0;
             pvh[k] = in ? h : LCD_GUARD; pva[k] = in ? h - oe1 : LCD_GUARD; pvb[k] = in ? h - oe2 : LCD_GUARD;
         }
-        lds_stc<C>(ring + 4 * cl, pvh); lds_stc<C>(ring + 4 * (WIN + cl), pva); lds_stc<C>(ring + 4 * (2 * WIN + cl), pvb);
+        ring_st3(ring, cl, pvh, pva, pvb);
         if (spf) { int *G = g.spill; glb_stc<C>(G + cl, pvh); glb_stc<C>(G + WIN + cl, pva); glb_stc<C>(G + 2 * WIN + cl, pvb); nsp = 1; }
         if (lane == 0) { glb_st(g.rbeg + bi, 0); glb_st(g.rend + bi, end0); glb_st(g.roff + bi, 0); glb_st(g.ml + bi, 0); glb_st(g.mr + bi, 0); glb_st(g.spoff + bi, 0); }
     }
@@ -1908,8 +1939,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                 }
                 {
                     const int x = (begc + cl) & WM;
-                    const unsigned S = ring + 4 * s * SLOTW;
-                    lds_stc<C>(S + 4 * x, pvh); lds_stc<C>(S + 4 * (WIN + x), pva); lds_stc<C>(S + 4 * (2 * WIN + x), pvb);
+                    ring_st3(ring + RB * (unsigned)(s * SLOTW), x, pvh, pva, pvb);
                     if (cl < cw4) {
                         uint8_t *cp = g.code8 + (size_t)(cused + (unsigned)cl);
                         if constexpr (C == 8) *(__attribute__((address_space(1))) unsigned long long *)cp = code;
@@ -2007,8 +2037,9 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                 const bool risk = pe - beg + 2 >= WIN || end - pb + 1 >= WIN;
                 int hm, hv[C], av[C], bv[C];
                 if (near) {
-                    const unsigned S = ring + 4 * sp * SLOTW;
-                    hm = lds_ld(S + 4 * xm); lds_ldc<C>(S + 4 * x, hv); lds_ldc<C>(S + 4 * (WIN + x), av); lds_ldc<C>(S + 4 * (2 * WIN + x), bv);
+                    const unsigned S = ring + RB * (unsigned)(sp * SLOTW);
+                    if (FIXED && r16) { hm = lds_ld16(S + 2 * xm); lds_ldc16<C>(S + 2 * x, hv); lds_ldc16<C>(S + 2 * (WIN + x), av); lds_ldc16<C>(S + 2 * (2 * WIN + x), bv); }
+                    else { hm = lds_ld(S + 4 * xm); lds_ldc<C>(S + 4 * x, hv); lds_ldc<C>(S + 4 * (WIN + x), av); lds_ldc<C>(S + 4 * (2 * WIN + x), bv); }
                 } else {
                     const int *G = g.spill + (size_t)(unsigned)usgpr(glb_ld((const int *)g.spoff + pi)) * SLOTW;
                     hm = glb_ld(G + xm); glb_ldc<C>(G + x, hv); glb_ldc<C>(G + WIN + x, av); glb_ldc<C>(G + 2 * WIN + x, bv);
@@ -2086,8 +2117,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
         if (cused + (unsigned)cw4 > code_cap || (np > 1 && oused + (unsigned)cw4 > ord_cap) || (spf && nsp >= spill_rows)) { wo->status = LCD_ERR_CELLS; return 0; }
         {
             const int x = jb & WM;
-            const unsigned S = ring + 4 * s * SLOTW;
-            lds_stc<C>(S + 4 * x, pvh); lds_stc<C>(S + 4 * (WIN + x), pva); lds_stc<C>(S + 4 * (2 * WIN + x), pvb);
+            ring_st3(ring + RB * (unsigned)(s * SLOTW), x, pvh, pva, pvb);
             if (spf) { int *G = g.spill + (size_t)nsp * SLOTW; glb_stc<C>(G + x, pvh); glb_stc<C>(G + WIN + x, pva); glb_stc<C>(G + 2 * WIN + x, pvb); }
             if (cl < cw4) {
                 uint8_t *cp = g.code8 + (size_t)(cused + (unsigned)cl);
@@ -3762,7 +3792,7 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
     // ring slots of the generic rows: RW columns each -- the class's widest window, or what the host laid the pool out for in the single-wavefront class
     // (64 / 128 columns for banded chains, 384 for certified-band chains: their few reads that come here have intervals of 260 - 380 columns, and a row that
     // fits its slot needs neither the HBM round trip nor the store drain of a row that does not)
-    const int RW = (NT == 64 || g.solo) ? g.wmax : WMAX;
+    const int RW = (NT == 64 || g.solo) ? (g.ring16 ? g.wmax / 2 : g.wmax) : WMAX; // (a 16-bit ring of wmax columns is half as many int32 columns here)
     const bool ring_ok = RW >= 64;
     for (int i = tid; i < qlen; i += NT) sseq[i] = seq_hbm[i];
     __syncthreads();
@@ -4273,7 +4303,9 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     // window the host expects the band to fit (64 / 128 columns: LDS per chain is what limits how many of them share a CU)
     const int ring_cols = (NT == 64 || ch.solo) ? ch.wmax : 4 * NT;
     const int ring_k = (NT == 64 || ch.solo) && ch.ring_k > 2 ? ch.ring_k : Cfg<NT>::K;
-    uint8_t *sseq = (uint8_t *)(lds_pool + ring_k * 3 * ring_cols);
+    const int ring16 = (NT == 64 && !ch.solo && ch.cert == 1 && ch.ring16) ? 1 : 0;
+    const int ring_words = ring_k * 3 * ring_cols / (ring16 ? 2 : 1);
+    uint8_t *sseq = (uint8_t *)(lds_pool + ring_words);
     const PoaLayout L = poa_layout(ch.node_cap, ch.edge_cap, ch.rid_words, ch.max_len, ch.cell_cap, ch.n_reads, ch.spill_x, ch.cert);
     uint8_t *ws = arena + ch.ws_off;
     int my_slot = -1;
@@ -4339,7 +4371,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
     g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = ch.cert == 2 ? 2 : NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0; g.cert_generic = 0; g.cert_generic_seen = 0; g.cert_sest = 0; g.cert_ubtop = 0; g.cert_cells0 = 0;
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
-    g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - ring_k * 3 * ring_cols) * 4; g.ring_k = ring_k; g.plan_k = (NT == 64 || ch.solo) && ring_k > 2 && ch.wmax < 256 ? 2 : ring_k; // (slots beyond 2 of a chain laid out for a narrow window: not there when a read needs a wider one)
+    g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - ring_words) * 4; g.ring16 = ring16; g.ring_k = ring_k; g.plan_k = (NT == 64 || ch.solo) && ring_k > 2 && ch.wmax < 256 ? 2 : ring_k; // (slots beyond 2 of a chain laid out for a narrow window: not there when a read needs a wider one)
     g.wd_deadline = (unsigned long long)clock64() + (unsigned long long)(sc.wd_s > 0 ? sc.wd_s : 30) * 2400000000ull; // (~2.4 GHz shader clock: the bound is about seconds, not exact)
     g.mm_valid = 0; g.topo_mode = (sc.dbg >> 6) & 7; g.solo = NT == 256 ? ch.solo : 0; g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0; g.t_bp = 0; g.t_setup = 0;
     // The long chains are the latency of a submission at every depth, and next to 8 - 12 other wavefronts of their CU each of theirs issues when the arbiter gets round
