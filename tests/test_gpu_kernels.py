@@ -328,7 +328,8 @@ def test_poa_k2_bubbles_all_workgroup_classes(lcd, oracle, L, monkeypatch):
     _check_k2(got, oracle.poa_aln_msa_cons(reads, 2))
 
 
-@pytest.mark.parametrize("L,rate,sv", [(300, 0.002, 12), (900, 0.001, 40), (900, 0.02, 25), (2600, 0.002, 60), (2600, 0.003, 400), (1500, 0.06, 30)])
+@pytest.mark.parametrize("L,rate,sv", [(300, 0.002, 12), (900, 0.001, 40), (900, 0.02, 25), (2600, 0.002, 60), (2600, 0.003, 400), (1500, 0.06, 30),
+                                       (14000, 0.001, 40)])   # (14 kb: scores of 28 000, the top of what the 16-bit LDS ring of these chains holds)
 def test_poa_k2_certified_band(lcd, oracle, L, rate, sv, monkeypatch):
     """K2 with rows restricted to the certified band (single-wavefront class, poa_kernel.hip align_certified) == full rows == oracle: clean and noisy reads,
     small and large het insertions (a 400-base one needs more than the 256-column window: the chain comes back with LCD_ERR_CERT and is re-run with

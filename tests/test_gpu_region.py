@@ -600,3 +600,6 @@ def test_certified_band_and_long_chain_class_digest_at_job_scale(lcd, monkeypatc
     assert run() == ref
     monkeypatch.delenv("LCD_SOLO_RL"); monkeypatch.delenv("LCD_SOLO_CYC_MIN"); monkeypatch.setenv("LCD_SOLO_CYC", "0")
     assert run() == ref
+    monkeypatch.delenv("LCD_SOLO_CYC")
+    monkeypatch.setenv("LCD_RING16", "0")        # the certified-band chains' LDS ring as 32-bit values (default: 16-bit, saturating)
+    assert run() == ref
