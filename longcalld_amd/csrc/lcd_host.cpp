@@ -970,6 +970,10 @@ static void chain_class(PoaChain &pc, bool noisy) {
         //  re-sort's LDS path, not their place in the queue)
         const int cap_here = cap_kb;
         if (cap_here > 0 && threads == 64) need = std::max(dp_bytes, std::min<long long>(need, (long long)cap_here << 10));
+        // (the long chains: what the re-sort would like beyond their bucket does not move them into the 148 KB bucket -- one workgroup per CU -- any more; LCD_SOLO_CAP=0: as before)
+        static const bool solo_cap = !(getenv("LCD_SOLO_CAP") && atoi(getenv("LCD_SOLO_CAP")) == 0);
+        static const int solo_kb0 = getenv("LCD_SOLO_KB") ? atoi(getenv("LCD_SOLO_KB")) : 64;
+        if (solo_cap && pc.solo) need = std::max(dp_bytes, std::min<long long>(need, (long long)solo_kb0 << 10));
     }
     // LDS per workgroup decides how many single-wavefront chains share a CU (160 KB, 16 wavefronts at 128 VGPRs), and those chains are
     // most of the work: fine-grained buckets; every (threads, bucket) group is one launch, a few streams run the groups (launch_poa_grouped)
