@@ -922,6 +922,12 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
 // Workgroup size class + LDS budget of a chain (poa_kernel.hip): threads follow the DP row width; the dynamic LDS pool holds
 // K ring slots of `wmax` columns + the query cache during the DP and the 16-bit graph copy of the re-sort (about 22 B per node)
 // afterwards.  Chains are launched in groups of equal (threads, LDS bucket) so that short chains do not pay a long chain's LDS.
+// LCD_SOLO_KB, rounded up to an LDS bucket (a value between two buckets -- 56 -- made the long chains' kernel end 3 s late: not understood, so not offered)
+static int solo_kb_env() {
+    const int v = getenv("LCD_SOLO_KB") ? atoi(getenv("LCD_SOLO_KB")) : 64;
+    for (int b : {8, 12, 16, 24, 32, 48, 64, 96, 148}) if (v <= b) return b;
+    return 148;
+}
 static void chain_class(PoaChain &pc, bool noisy) {
     // DP row width: K2 rows span the whole read (+2 guard columns of the window); K1 rows are the adaptive band plus drift
     const long long width = pc.cert == 1 ? 256 : pc.mode == 1 ? (long long)pc.max_len + 2 : 2ll * (10 + pc.max_len / 100) + 1 + 48;
@@ -972,7 +978,7 @@ static void chain_class(PoaChain &pc, bool noisy) {
         if (cap_here > 0 && threads == 64) need = std::max(dp_bytes, std::min<long long>(need, (long long)cap_here << 10));
         // (the long chains: what the re-sort would like beyond their bucket does not move them into the 148 KB bucket -- one workgroup per CU -- any more; LCD_SOLO_CAP=0: as before)
         static const bool solo_cap = !(getenv("LCD_SOLO_CAP") && atoi(getenv("LCD_SOLO_CAP")) == 0);
-        static const int solo_kb0 = getenv("LCD_SOLO_KB") ? atoi(getenv("LCD_SOLO_KB")) : 64;
+        static const int solo_kb0 = solo_kb_env();
         if (solo_cap && pc.solo) need = std::max(dp_bytes, std::min<long long>(need, (long long)solo_kb0 << 10));
     }
     // LDS per workgroup decides how many single-wavefront chains share a CU (160 KB, 16 wavefronts at 128 VGPRs), and those chains are
@@ -982,7 +988,7 @@ static void chain_class(PoaChain &pc, bool noisy) {
     for (int b : buckets) if (need <= b) { lds = b; break; }
     // the long chains of a submission are ONE launch group (one LDS size): kernels of a stream run one after the other, and every group of a few long chains lasts as
     // long as its longest chain -- four such groups on the four streams held everything else back for 0.2 s
-    if (pc.solo) { static const int solo_kb = getenv("LCD_SOLO_KB") ? atoi(getenv("LCD_SOLO_KB")) : 64; lds = std::max(std::min(lds, 148 << 10), solo_kb << 10); if (lds > (solo_kb << 10)) lds = 148 << 10; }
+    if (pc.solo) { static const int solo_kb = solo_kb_env(); lds = std::max(std::min(lds, 148 << 10), solo_kb << 10); if (lds > (solo_kb << 10)) lds = 148 << 10; }
     // The longest single-wavefront chains are the critical path of a submission (34 reads x 4 kb: 0.28 s against 0.20 s of work for the whole chip), and next to 15
     // other chains of its CU such a wavefront issues one instruction per ~7 cycles.  Chains above LCD_ISO_RL read-bases ask for LCD_ISO_KB of LDS: three of them fill
     // a CU's LDS, so each has a SIMD (nearly) to itself -- and a pool its re-sort runs in.
