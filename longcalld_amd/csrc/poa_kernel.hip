@@ -1751,6 +1751,11 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     const int QB = (qlen + 12 + 15) & ~15;
     const bool r16 = FIXED && usgpr(g.ring16) != 0; // (16-bit ring values: lds_stc16 / lds_ldc16)
     const unsigned RB = r16 ? 2u : 4u;
+    if (FIXED && r16) { // every value of this read inside the int16 range, by the scores' own bounds: best case all matches, worst case one gap over all rows or all columns
+        const long long span = (long long)(ei - bi) > qlen ? (long long)(ei - bi) : qlen;
+        const long long worst = 2 * ((o1 > o2 ? o1 : o2) + (long long)(e1 < e2 ? e1 : e2) * span) + (o1 + o2) + 2LL * (e1 + e2) + 64; // (no cell is worse than a gap over its rows plus a gap over its columns -- the cheaper extension wins on a long gap; E-out is one open + extend below H)
+        if ((long long)qlen * s_match + 64 > 32000 || worst > 32000) return -1; // (not representable here: the generic rows keep 32-bit values)
+    }
     auto ring_st3 = [&](const unsigned slot, const int x, const int (&va)[C], const int (&vb)[C], const int (&vc)[C]) { // slot: byte address of a ring slot; x: its first column here
         if (FIXED && r16) { lds_stc16<C>(slot + 2 * x, va); lds_stc16<C>(slot + 2 * (WIN + x), vb); lds_stc16<C>(slot + 2 * (2 * WIN + x), vc); }
         else { lds_stc<C>(slot + 4 * x, va); lds_stc<C>(slot + 4 * (WIN + x), vb); lds_stc<C>(slot + 4 * (2 * WIN + x), vc); }
