@@ -169,9 +169,27 @@ def _inproc(args, align, lib, timed_regs, warm_regs, n_regions, shape, torch):
     disp.close()
 
 
+def launcher_command(n_gpus, argv, port=None, python=None):
+    """The command `python bench.py --gpus N ...` turns itself into when it is started WITHOUT a launcher (no RANK in the environment): one rank per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1 (the container's hostname may not resolve), exactly what the driver would have typed.  `argv` = the arguments
+    after the script name, passed through unchanged."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:   # a free port: two benches on one host must not meet on 29500
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}", "--master-addr", "127.0.0.1",
+            "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def needs_self_launch(args, environ):
+    """N > 1 ranks wanted (one process per GPU, not the --inproc dispatcher) and nobody has launched them: RANK / WORLD_SIZE are not set"""
+    return args.gpus > 1 and not args.inproc and "RANK" not in environ and "WORLD_SIZE" not in environ
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--print-launch", type=int, default=0, help="1: print the launcher command `--gpus N` (N > 1, no RANK in the environment) would exec, and exit")
     ap.add_argument("--steps", type=int, default=192)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ref-mb", type=float, default=10.0, help="synthetic reference size per step (10 Mb = configs[1]: 1 250 regions)")
@@ -210,10 +228,35 @@ def main():
     ap.add_argument("--e2e", type=int, default=0, help="also time the PCIe-inclusive path with E lanes (host threads) each doing upload -> run -> download -> "
                     "materialisation of every result for its own batches, so that one lane's copies overlap another's kernels; reported under pcie_inclusive")
     args = ap.parse_args()
+    if needs_self_launch(args, os.environ):
+        # `python bench.py --gpus N` by itself: become N ranks (the first multi-GPU run must not die at init_process_group for want of a launcher)
+        cmd = launcher_command(args.gpus, [a for a in sys.argv[1:]])
+        if args.print_launch:
+            print(json.dumps({"launch": cmd}), flush=True)
+            return
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (dmabuf IPC: what the host driver supports; RCCL's peer mappings fail without it)
+        env.setdefault("OMP_NUM_THREADS", "1")
+        sys.stdout.flush(); sys.stderr.flush()
+        os.execve(cmd[0], cmd, env)
+    if args.print_launch:
+        print(json.dumps({"launch": None, "why": "no launcher needed: --gpus 1, --inproc, or RANK / WORLD_SIZE already set"}), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("BENCH_LAUNCH_PROBE") == "1":
+        # (tests/test_dist_cpu.py: the launcher path end to end without a GPU -- the ranks the self-launch made meet over gloo, rank 0 says who came, nobody touches HIP)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "local_rank": local_rank, "pid": os.getpid()})
+        if rank == 0:
+            print(json.dumps({"probe": True, "world": world, "gpus_arg": args.gpus, "ranks": seen}), flush=True)
+        dist.destroy_process_group()
+        return
     from longcalld_amd import jobs
     shape = jobs.SHAPES[args.shape]
     n_regions = jobs.regions_for_ref_mb(args.ref_mb)
@@ -270,20 +313,40 @@ def main():
     # have two submissions (one lane's anchor / WFA / string stages and the tail of its chain launches overlap the other lane's chains),
     # else one lane of up to 32; the noisy-read shapes (4x graph estimates, ~8 GB per batch in flight) run one lane of 24 (sv: 8)
     rb_stats = None
+    rccl_info = None
+    lib_comm = None
+    if world > 1:
+        # The library's own RCCL communicator (lcd_comm_create over the dlopen'ed librccl): torch.distributed only carries its 128-byte id.  What RCCL reports for
+        # it on every rank (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) goes into the line: evidence that N ranks really met over RCCL
+        from longcalld_amd import rebalance as rb
+        try:
+            uid = [rb.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            lib_comm = rb.Comm(world, rank, uid[0], local_rank)
+            mine = dict(lib_comm.info(), rank=rank, local_rank=local_rank, hip_device=int(torch.cuda.current_device()))
+        except Exception as e:  # noqa  (the run itself does not depend on it: the epoch falls back to torch.distributed's RCCL)
+            lib_comm = None
+            mine = {"rank": rank, "error": repr(e)[:200]}
+        allinfo = [None] * world
+        dist.all_gather_object(allinfo, mine)
+        rccl_info = {"library_communicator": "lcd_comm_create (librccl via dlopen), id broadcast by torch.distributed", "per_rank": allinfo,
+                     "world_seen_by_rccl": sorted({i.get("nccl_world", -1) for i in allinfo}), "torch_backend": dist.get_backend()}
     if job_mode:
         from longcalld_amd import rebalance as rb
         queue = [(sum(rb.region_cost(r) for r in regs), rb.pack_regions(regs)) for regs in timed_regs]
         if world > 1 and args.rebalance:
             t_rb = time.perf_counter()
             depth_before = len(queue)
-            if os.environ.get("LCD_REBALANCE_VIA", "torch") == "lib":   # the epoch inside liblcd_hotpath.so (lcd_rebalance_exchange over librccl); the id travels by torch
-                uid = [rb.Comm.unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)
-                comm = rb.Comm(world, rank, uid[0], local_rank)
-                queue, rb_stats = rb.rebalance_c(comm, queue)
-                comm.close()
-            else:                                                        # the same plan (lcd_rebalance_plan), torch.distributed's RCCL point-to-point as the transport
+            # default: the epoch inside liblcd_hotpath.so (lcd_rebalance_exchange over librccl).  LCD_REBALANCE_VIA=torch (or no library communicator on some
+            # rank -- decided together, a rank must not wait in a collective the others never enter): the same plan (lcd_rebalance_plan) with torch.distributed's
+            # RCCL point-to-point as the transport
+            ok_t = torch.tensor([1 if lib_comm is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+            if os.environ.get("LCD_REBALANCE_VIA", "lib") == "lib" and int(ok_t.item()) == 1:
+                queue, rb_stats = rb.rebalance_c(lib_comm, queue)
+            else:
                 queue, rb_stats = rb.rebalance(queue, device=dev)
+                rb_stats["transport"] = "torch.distributed (RCCL) point-to-point"
             rb_stats["seconds"] = round(time.perf_counter() - t_rb, 4)
             # every rank's queue depth and load before / after the epoch, so that a scaling run shows what the epoch did
             dl = torch.tensor([depth_before, len(queue), sum(c for c, _ in queue)], dtype=torch.float64, device=dev); al = [torch.zeros_like(dl) for _ in range(world)]
@@ -721,9 +784,13 @@ def main():
             out["queue_rebalance"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in (rb_stats or {}).items() if not k.startswith("loads")}
             out["config"]["sharding"] = (f"{int(round(args.job_mb / CHUNK_MB))} chunks of {CHUNK_MB} Mb in contiguous blocks per rank"
                                          + (", one RCCL rebalance epoch (whole packed chunks moved)" if world > 1 and args.rebalance else "") + ", no data-path collective")
+        if rccl_info is not None:
+            out["rccl"] = rccl_info
         print(json.dumps(out), flush=True)
     for bt in batches:
         bt.close()
+    if lib_comm is not None:
+        lib_comm.close()
     if world > 1:
         dist.destroy_process_group()
 

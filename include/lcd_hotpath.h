@@ -239,6 +239,7 @@ int lcd_rebalance_plan(int world, const int *n_jobs, const double *costs, double
 int lcd_rccl_unique_id(uint8_t id[128]);                                                   /* ncclGetUniqueId on rank 0; the caller gives the bytes to the other ranks */
 lcd_comm_t *lcd_comm_create(int world, int rank, const uint8_t id[128], int device);       /* ncclCommInitRank; NULL on failure */
 void lcd_comm_destroy(lcd_comm_t *c);
+int lcd_comm_info(lcd_comm_t *c, int *nccl_world, int *nccl_rank, int *nccl_device);      /* ncclCommCount / ncclCommUserRank / ncclCommCuDevice of the communicator: what RCCL itself sees */
 /* One epoch.  In: this rank's queue.  Out (arrays malloc()'d): its new queue -- kept jobs (bufs_out[i] is the caller's pointer, owned_out[i] = 0) and received ones
  * (malloc()'d buffers, owned_out[i] = 1: the caller frees them). */
 int lcd_rebalance_exchange(lcd_comm_t *c, int n_jobs, const double *cost, const uint64_t *nbytes, const uint8_t *const *bufs, double tol,

@@ -92,7 +92,7 @@ EXPORTS = [
     "lcd_batch_clear", "lcd_batch_region_vars", "lcd_digar_opt_default", "lcd_digar_batch", "lcd_digar_batch_tags", "lcd_digar_batch_ref", "lcd_region_read_slices_batch", "lcd_te_opt_default", "lcd_te_lib_create", "lcd_te_lib_destroy", "lcd_te_lib_n_seqs", "lcd_check_te_seq", "lcd_collect_te_info", "lcd_collect_te_info_from_cons", "lcd_annotate_te", "lcd_format_vcf_te", "lcd_pre_process_noisy_regs", "lcd_post_process_noisy_regs", "lcd_cr_merge", "lcd_sdust", "lcd_sdust_batch", "lcd_batch_add_region", "lcd_batch_add_region_from_chunk", "lcd_batch_add_region_from_chunk_packed", "lcd_batch_upload", "lcd_batch_run", "lcd_batch_run_many",
     "lcd_batch_download", "lcd_dispatch_create", "lcd_dispatch_destroy", "lcd_dispatch_n_devices", "lcd_dispatch_run", "lcd_dispatch_set_flags", "lcd_dispatch_busy", "lcd_batch_cost", "lcd_lpt_assign", "lcd_batch_region_result", "lcd_batch_region_sorted_ids", "lcd_batch_region_read_slices", "lcd_batch_get_stats", "lcd_batch_k4_jobs", "lcd_chunk_create", "lcd_chunk_create_from_bam", "lcd_chunk_destroy", "lcd_chunk_n_reads", "lcd_chunk_read_info", "lcd_chunk_intervals", "lcd_chunk_region_slices", "lcd_batch_add_region_from_chunk_dev", "lcd_copy_counters", "lcd_batch_digest", "lcd_batch_materialize", "lcd_batch_region_results_arena",
     "lcd_edlib_batch", "lcd_edlib_batch_hw", "lcd_wfa_batch", "lcd_wfa_arena_bytes", "lcd_poa_batch", "lcd_assign_hap_germline", "lcd_assign_hap_batch", "lcd_flip_variant_hap", "lcd_stitch_chunks", "lcd_call_opt_default", "lcd_make_variants", "lcd_free_variants", "lcd_format_vcf", "lcd_read_tags", "lcd_update_digars_from_msa1", "lcd_bam_load_region", "lcd_bam_load_region_indexed", "lcd_bam_reads_free", "lcd_fasta_fetch", "lcd_vcf_header", "lcd_io_last_error",
-    "lcd_region_job_cost", "lcd_region_jobs_pack", "lcd_batch_add_packed", "lcd_rebalance_plan", "lcd_rccl_unique_id", "lcd_comm_create", "lcd_comm_destroy", "lcd_rebalance_exchange", "lcd_rebalance_last_error",
+    "lcd_region_job_cost", "lcd_region_jobs_pack", "lcd_batch_add_packed", "lcd_rebalance_plan", "lcd_rccl_unique_id", "lcd_comm_create", "lcd_comm_destroy", "lcd_comm_info", "lcd_rebalance_exchange", "lcd_rebalance_last_error",
     "lcd_bgzf_inflate_dev", "lcd_inflated_dev_ptr", "lcd_inflated_size", "lcd_inflated_n_blocks", "lcd_inflated_kernel_ms", "lcd_inflated_upload_ms", "lcd_inflated_to_host", "lcd_inflated_free",
 ]
 

@@ -802,7 +802,7 @@ struct ChainEnv {
     int cert_mode, solo_len, cert_sys, solo_mw, solo_cyc, cell_shrink, ring16; long long solo_rl;
     long long n_chains = 1ll << 40, solo_cyc_min; // (chains in the submission at hand: run_many_once sets it)
     ChainEnv() {
-        ring16 = !(getenv("LCD_RING16") && atoi(getenv("LCD_RING16")) == 0);
+        ring16 = getenv("LCD_RING16") ? atoi(getenv("LCD_RING16")) : 1; // (0: 32-bit rings; 2: test switch -- 16-bit pools whatever the bounds below say, so that the kernel's own range guard is what sends a read to the generic rows)
         solo_cyc_min = getenv("LCD_SOLO_CYC_MIN") ? atoll(getenv("LCD_SOLO_CYC_MIN")) : 16000;
         cert_mode = getenv("LCD_CERT") ? atoi(getenv("LCD_CERT")) : 1;
         solo_len = getenv("LCD_CERT_SOLO_LEN") ? atoi(getenv("LCD_CERT_SOLO_LEN")) : 0;
@@ -906,7 +906,18 @@ static void chain_caps(const lcd_opt_t &opt, const ChainRec &C, const std::vecto
     for (int s = 1; s < scale && cells < worst; s *= 2) cells *= 8;
     cells = std::min(cells, worst);
     pc.cell_cap = (uint64_t)std::max<long long>(cells, maxl + 64);
-    pc.ring16 = env.ring16; // (wanted; chain_class keeps it for certified-band chains of the single-wavefront class)
+    // 16-bit ring values: wanted (LCD_RING16) and representable -- the same bounds the kernel checks per read (poa_kernel.hip align_lean, "int16 range"), here on the
+    // chain's longest read with the scoring at hand: best case every base a match plus the heaviest bonus path (every traversed edge adds ilog2(weight) <= ilog2(reads),
+    // a path has ~1.1 nodes per base), worst case a gap over all rows plus a gap over all columns.  A chain that fails this is laid out for a 32-bit ring from the
+    // start (its pool and bucket are those of the 32-bit ring) instead of meeting the kernel's guard on every read and taking the generic rows
+    {
+        int lg = 0; while ((2 << lg) <= std::max(n, 1)) ++lg; // ilog2(n): the largest edge weight is the number of reads
+        const long long rows = (long long)(1.1 * maxl) + 64;
+        const long long o_max = std::max(opt.gap_open1, opt.gap_open2), e_min = std::min(opt.gap_ext1, opt.gap_ext2);
+        const long long best = (long long)maxl * opt.match + rows * lg + 64;
+        const long long worstv = 2 * (o_max + e_min * rows) + (opt.gap_open1 + opt.gap_open2) + 2ll * (opt.gap_ext1 + opt.gap_ext2) + 64;
+        pc.ring16 = env.ring16 == 2 ? 2 : env.ring16 && best <= 32000 && worstv <= 32000 ? 1 : 0; // (chain_class keeps it for certified-band chains of the single-wavefront class)
+    }
     chain_class(pc, opt.is_ont != 0);
     // SMALL graphs of noisy reads: nearly every row has a successor further away than the ring and is spilled -- 12 bytes per WINDOW column (768 B for the narrowest
     // window) whatever the chain's width -- while their DP region, at the worst case of nodes x (length + 1) cells, is a few tens of KB: 45 of the 58 chains an
@@ -958,7 +969,7 @@ static void chain_class(PoaChain &pc, bool noisy) {
     }
     // certified-band K2 chains of the single-wavefront class keep 16-bit ring values (H, E1, E2 of reads below 15 000 bases fit int16): their 512-column ring was 12 of
     // their 16 KB, and LDS x time is what a submission runs out of first ("Where the chain kernels' time goes now").  LCD_RING16=0 (read per submission): 32-bit, as before
-    pc.ring16 = pc.ring16 /* wanted: chain_caps, LCD_RING16 */ && threads == 64 && !pc.solo && pc.cert == 1 && pc.max_len < 15000 ? 1 : 0; pc.pad3_ = 0;
+    pc.ring16 = pc.ring16 /* wanted and representable: chain_caps, LCD_RING16 */ && threads == 64 && !pc.solo && pc.cert == 1 && (pc.ring16 == 2 || pc.max_len < 15000) ? 1 : 0; pc.pad3_ = 0;
     const long long dp_bytes = (long long)K * 3 * wmax * (pc.ring16 ? 2 : 4) + seq_bytes; // the ring holds `wmax` columns per slot (4 * threads, or the narrower preferred window of a single-wavefront banded chain)
     // the re-sort's LDS copy of the graph: 8 B per node + 4 B per edge (topo_sort_block); edges ~ nodes + a few per bubble
     long long need = std::max(dp_bytes, est_nodes * 8 + (est_nodes + est_nodes / 8) * 4 + 64);

@@ -43,6 +43,11 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    // optional (absent from a very old librccl: the epoch works without them)
+    int (*CommAbort)(nccl_comm_t) = nullptr;
+    int (*CommCount)(nccl_comm_t, int *) = nullptr;
+    int (*CommUserRank)(nccl_comm_t, int *) = nullptr;
+    int (*CommCuDevice)(nccl_comm_t, int *) = nullptr;
 };
 Rccl g_rccl; std::once_flag g_rccl_once; std::string g_rccl_why;
 bool rccl_open() {
@@ -53,12 +58,14 @@ bool rccl_open() {
         LCD_SYM(GetUniqueId, "ncclGetUniqueId"); LCD_SYM(CommInitRank, "ncclCommInitRank"); LCD_SYM(CommDestroy, "ncclCommDestroy"); LCD_SYM(AllGather, "ncclAllGather");
         LCD_SYM(Send, "ncclSend"); LCD_SYM(Recv, "ncclRecv"); LCD_SYM(GroupStart, "ncclGroupStart"); LCD_SYM(GroupEnd, "ncclGroupEnd"); LCD_SYM(GetErrorString, "ncclGetErrorString");
 #undef LCD_SYM
+        *(void **)(&g_rccl.CommAbort) = dlsym(g_rccl.h, "ncclCommAbort"); *(void **)(&g_rccl.CommCount) = dlsym(g_rccl.h, "ncclCommCount");
+        *(void **)(&g_rccl.CommUserRank) = dlsym(g_rccl.h, "ncclCommUserRank"); *(void **)(&g_rccl.CommCuDevice) = dlsym(g_rccl.h, "ncclCommCuDevice");
     });
     return g_rccl.h != nullptr;
 }
 } // namespace
 
-struct lcd_comm_s { nccl_comm_t comm = nullptr; int world = 1, rank = 0, device = 0; hipStream_t st = nullptr; };
+struct lcd_comm_s { nccl_comm_t comm = nullptr; int world = 1, rank = 0, device = 0; hipStream_t st = nullptr; bool dead = false; /* aborted by a failed epoch: only lcd_comm_destroy is left */ };
 
 extern "C" {
 const char *lcd_rebalance_last_error(void) { return g_rb_err.c_str(); }
@@ -103,20 +110,21 @@ uint64_t lcd_region_jobs_pack(int n, const lcd_region_job_t *jobs, uint8_t *buf)
 int lcd_batch_add_packed(lcd_batch_t *b, const uint8_t *buf, uint64_t nbytes) {
     if (nbytes < 16) return rb_err(-50, "packed region buffer: shorter than its header");
     int64_t h[2]; memcpy(h, buf, 16);
-    if (h[0] != LCD_PACK_MAGIC || h[1] < 0 || 16 + 24ull * (uint64_t)h[1] > nbytes) return rb_err(-50, "packed region buffer: bad magic / region count");
+    if (h[0] != LCD_PACK_MAGIC || h[1] < 0 || h[1] > INT32_MAX || 16 + 24ull * (uint64_t)h[1] > nbytes) return rb_err(-50, "packed region buffer: bad magic / region count");
     const int n = (int)h[1];
     uint64_t o = 16 + 24ull * (uint64_t)n;
     std::vector<int> ids, cov, haps, lens; std::vector<int64_t> ps; std::vector<const uint8_t *> sp, qp;
     for (int r = 0; r < n; ++r) {
         int64_t s[3]; memcpy(s, buf + 16 + 24ull * r, 24);
-        if (s[1] < 0 || s[2] < 0 || s[1] > (1 << 24)) return rb_err(-50, "packed region buffer: bad region header");
+        // (bytes from another rank: nothing is cast before it is bounded -- a region is at most LONGCALLD max_noisy_reg_len = 50 kb + flanks, a read slice far below 2^30)
+        if (s[0] < 0 || s[0] > INT32_MAX || s[1] < 0 || s[2] < 0 || s[1] > (1 << 24) || s[2] > INT32_MAX) return rb_err(-50, "packed region buffer: bad region header");
         const size_t m = (size_t)s[1];
         if (o + 24 * m + (uint64_t)s[2] > nbytes) return rb_err(-50, "packed region buffer: truncated");
         ids.resize(m); cov.resize(m); haps.resize(m); lens.resize(m); ps.resize(m); sp.resize(m); qp.resize(m);
         memcpy(ids.data(), buf + o, 4 * m); o += 4 * m; memcpy(cov.data(), buf + o, 4 * m); o += 4 * m; memcpy(haps.data(), buf + o, 4 * m); o += 4 * m;
         memcpy(ps.data(), buf + o, 8 * m); o += 8 * m; memcpy(lens.data(), buf + o, 4 * m); o += 4 * m;
         const uint8_t *ref = buf + o; o += (uint64_t)s[2];
-        uint64_t tot = 0; for (size_t i = 0; i < m; ++i) { if (lens[i] < 0) return rb_err(-50, "packed region buffer: negative read length"); tot += (uint64_t)lens[i]; }
+        uint64_t tot = 0; for (size_t i = 0; i < m; ++i) { if (lens[i] < 0 || lens[i] > (1 << 30)) return rb_err(-50, "packed region buffer: bad read length"); tot += (uint64_t)lens[i]; }
         if (o + 2 * tot > nbytes) return rb_err(-50, "packed region buffer: truncated");
         for (size_t i = 0; i < m; ++i) { sp[i] = buf + o; o += (uint64_t)lens[i]; }
         for (size_t i = 0; i < m; ++i) { qp[i] = buf + o; o += (uint64_t)lens[i]; }
@@ -180,38 +188,63 @@ lcd_comm_t *lcd_comm_create(int world, int rank, const uint8_t id[128], int devi
 void lcd_comm_destroy(lcd_comm_t *c) {
     if (!c) return;
     if (c->st) (void)hipStreamDestroy(c->st);
-    if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+    if (c->comm) (void)g_rccl.CommDestroy(c->comm); // (NULL after an abort)
     delete c;
 }
 
 // One epoch.  In: this rank's queue (cost, bytes, buffer per job).  Out: its new queue -- the jobs it keeps (pointers into the caller's buffers, owned = 0) and the
 // jobs it received (malloc()'d, owned = 1: the caller frees those buffers), out arrays malloc()'d -- and the epoch's statistics.
+// Failure: every device buffer and every host block this call made is released on every path (Scratch below); a group that was started is ended; and because the
+// peers of a rank that stops in the middle of the epoch would wait in their collectives for ever, a failure after the first collective ABORTS the communicator
+// (ncclCommAbort: the peers' calls return with an error) and marks it dead -- the only thing left to do with `c` is lcd_comm_destroy.
+namespace {
+struct Scratch { // what one epoch allocates; anything not handed to the caller dies with it
+    std::vector<void *> dev; std::vector<void *> host; bool group_open = false;
+    void *dmalloc(size_t n) { void *p = nullptr; if (hipMalloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; } dev.push_back(p); return p; }
+    void *hmalloc(size_t n) { void *p = malloc(n ? n : 1); if (p) host.push_back(p); return p; }
+    void keep_host() { host.clear(); } // (the out arrays and received buffers now belong to the caller)
+    ~Scratch() {
+        if (group_open) (void)g_rccl.GroupEnd();
+        for (void *p : dev) (void)hipFree(p);
+        for (void *p : host) free(p);
+    }
+};
+}
 int lcd_rebalance_exchange(lcd_comm_t *c, int n_jobs, const double *cost, const uint64_t *nbytes, const uint8_t *const *bufs, double tol,
                            int *n_out, double **cost_out, uint64_t **nbytes_out, uint8_t ***bufs_out, uint8_t **owned_out, lcd_rebalance_stats_t *st) {
-#define RB_HIP(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return rb_err(-10, "HIP call failed: " #x); } } while (0)
-#define RB_NCCL(x) do { const int rc_ = (x); if (rc_ != 0) return rb_err(-53, std::string(#x ": ") + g_rccl.GetErrorString(rc_)); } while (0)
     if (!c) return rb_err(-4, "lcd_rebalance_exchange: no communicator");
+    if (c->dead) return rb_err(-53, "lcd_rebalance_exchange: the communicator was aborted by an earlier failure");
+    if (n_jobs < 0) return rb_err(-4, "lcd_rebalance_exchange: negative queue depth");
+    Scratch sc;
+    bool in_epoch = false; // (a collective has been issued: the peers are waiting for this rank)
+    auto fail = [&](int code, const std::string &m) {
+        if (sc.group_open) { (void)g_rccl.GroupEnd(); sc.group_open = false; }
+        if (in_epoch && c->comm) { if (g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm); else (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; c->dead = true; }
+        return rb_err(code, m);
+    };
+#define RB_HIP(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return fail(-10, "HIP call failed: " #x); } } while (0)
+#define RB_NCCL(x) do { const int rc_ = (x); if (rc_ != 0) return fail(-53, std::string(#x ": ") + g_rccl.GetErrorString(rc_)); } while (0)
+#define RB_MEM(p) do { if (!(p)) return fail(-3, "lcd_rebalance_exchange: out of memory (" #p ")"); } while (0)
     RB_HIP(hipSetDevice(c->device));
     const int W = c->world, me = c->rank;
     // 1. queue depths
-    int *d_cnt = nullptr; RB_HIP(hipMalloc(&d_cnt, sizeof(int) * (size_t)(W + 1)));
+    int *d_cnt = (int *)sc.dmalloc(sizeof(int) * (size_t)(W + 1)); RB_MEM(d_cnt);
     RB_HIP(hipMemcpyAsync(d_cnt + W, &n_jobs, sizeof(int), hipMemcpyHostToDevice, c->st));
+    in_epoch = true;
     RB_NCCL(g_rccl.AllGather(d_cnt + W, d_cnt, 1, NCCL_INT32, c->comm, c->st));
     std::vector<int> cnt((size_t)W);
     RB_HIP(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * (size_t)W, hipMemcpyDeviceToHost, c->st));
     RB_HIP(hipStreamSynchronize(c->st));
-    (void)hipFree(d_cnt);
-    int maxn = 0; for (int x : cnt) maxn = std::max(maxn, x);
+    int maxn = 0; for (int x : cnt) { if (x < 0) return fail(-50, "lcd_rebalance_exchange: a rank reported a negative queue depth"); maxn = std::max(maxn, x); }
     // 2. the (cost, bytes) tables, padded to the deepest queue
     std::vector<double> tab((size_t)2 * maxn, 0.0), all((size_t)2 * maxn * W, 0.0);
     for (int i = 0; i < n_jobs; ++i) { tab[2 * (size_t)i] = cost[i]; tab[2 * (size_t)i + 1] = (double)nbytes[i]; } // (a job buffer is far below 2^53 bytes)
     if (maxn > 0) {
-        double *d_tab = nullptr; RB_HIP(hipMalloc(&d_tab, sizeof(double) * (size_t)2 * maxn * (W + 1)));
+        double *d_tab = (double *)sc.dmalloc(sizeof(double) * (size_t)2 * maxn * (W + 1)); RB_MEM(d_tab);
         RB_HIP(hipMemcpyAsync(d_tab + (size_t)2 * maxn * W, tab.data(), sizeof(double) * (size_t)2 * maxn, hipMemcpyHostToDevice, c->st));
         RB_NCCL(g_rccl.AllGather(d_tab + (size_t)2 * maxn * W, d_tab, (size_t)2 * maxn, NCCL_FLOAT64, c->comm, c->st));
         RB_HIP(hipMemcpyAsync(all.data(), d_tab, sizeof(double) * (size_t)2 * maxn * W, hipMemcpyDeviceToHost, c->st));
         RB_HIP(hipStreamSynchronize(c->st));
-        (void)hipFree(d_tab);
     }
     std::vector<double> costs; std::vector<uint64_t> sizes; std::vector<size_t> first((size_t)W + 1, 0);
     for (int r = 0; r < W; ++r) { first[r + 1] = first[r] + (size_t)cnt[r]; for (int i = 0; i < cnt[r]; ++i) { costs.push_back(all[((size_t)r * maxn + i) * 2]); sizes.push_back((uint64_t)all[((size_t)r * maxn + i) * 2 + 1]); } }
@@ -219,43 +252,46 @@ int lcd_rebalance_exchange(lcd_comm_t *c, int n_jobs, const double *cost, const 
     std::vector<lcd_move_t> mv(costs.size() + 1); std::vector<double> lb((size_t)W), la((size_t)W);
     const int nm = lcd_rebalance_plan(W, cnt.data(), costs.data(), tol, -1, mv.data(), lb.data(), la.data());
     // 4. whole buffers, point to point, one group
-    std::vector<char> sent((size_t)std::max(n_jobs, 0), 0);
+    std::vector<char> sent((size_t)n_jobs, 0);
     struct Rx { double cost; uint64_t n; uint8_t *d; };
     std::vector<Rx> rx; std::vector<uint8_t *> d_tx; uint64_t moved_bytes = 0;
     for (int k = 0; k < nm; ++k) {
         const uint64_t nb = sizes[first[mv[k].src] + (size_t)mv[k].index]; moved_bytes += nb;
         if (mv[k].src == me) {
-            uint8_t *d = nullptr; RB_HIP(hipMalloc(&d, nb ? nb : 1));
+            uint8_t *d = (uint8_t *)sc.dmalloc(nb); RB_MEM(d);
             RB_HIP(hipMemcpyAsync(d, bufs[mv[k].index], nb, hipMemcpyHostToDevice, c->st));
             d_tx.push_back(d); sent[(size_t)mv[k].index] = 1;
         } else if (mv[k].dst == me) {
-            uint8_t *d = nullptr; RB_HIP(hipMalloc(&d, nb ? nb : 1));
+            uint8_t *d = (uint8_t *)sc.dmalloc(nb); RB_MEM(d);
             rx.push_back({costs[first[mv[k].src] + (size_t)mv[k].index], nb, d});
         }
     }
     if (nm > 0) {
         RB_NCCL(g_rccl.GroupStart());
+        sc.group_open = true;
         size_t it = 0, ir = 0;
         for (int k = 0; k < nm; ++k) { // (the same order on every rank: the k-th transfer between a pair is the k-th on both sides)
             const uint64_t nb = sizes[first[mv[k].src] + (size_t)mv[k].index];
             if (mv[k].src == me) { RB_NCCL(g_rccl.Send(d_tx[it++], nb, NCCL_UINT8, mv[k].dst, c->comm, c->st)); }
             else if (mv[k].dst == me) { RB_NCCL(g_rccl.Recv(rx[ir++].d, nb, NCCL_UINT8, mv[k].src, c->comm, c->st)); }
         }
+        sc.group_open = false;
         RB_NCCL(g_rccl.GroupEnd());
     }
     const int n_keep = (int)std::count(sent.begin(), sent.end(), 0), n_new = n_keep + (int)rx.size();
-    double *co = (double *)malloc(sizeof(double) * (size_t)(n_new + 1)); uint64_t *no = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n_new + 1));
-    uint8_t **bo = (uint8_t **)malloc(sizeof(uint8_t *) * (size_t)(n_new + 1)); uint8_t *ow = (uint8_t *)malloc((size_t)(n_new + 1));
+    double *co = (double *)sc.hmalloc(sizeof(double) * (size_t)(n_new + 1)); RB_MEM(co);
+    uint64_t *no = (uint64_t *)sc.hmalloc(sizeof(uint64_t) * (size_t)(n_new + 1)); RB_MEM(no);
+    uint8_t **bo = (uint8_t **)sc.hmalloc(sizeof(uint8_t *) * (size_t)(n_new + 1)); RB_MEM(bo);
+    uint8_t *ow = (uint8_t *)sc.hmalloc((size_t)(n_new + 1)); RB_MEM(ow);
     int w = 0;
     for (int i = 0; i < n_jobs; ++i) if (!sent[(size_t)i]) { co[w] = cost[i]; no[w] = nbytes[i]; bo[w] = (uint8_t *)bufs[i]; ow[w] = 0; ++w; }
     for (const Rx &r : rx) {
-        uint8_t *hbuf = (uint8_t *)malloc(r.n ? r.n : 1);
+        uint8_t *hbuf = (uint8_t *)sc.hmalloc(r.n); RB_MEM(hbuf);
         RB_HIP(hipMemcpyAsync(hbuf, r.d, r.n, hipMemcpyDeviceToHost, c->st));
         co[w] = r.cost; no[w] = r.n; bo[w] = hbuf; ow[w] = 1; ++w;
     }
     RB_HIP(hipStreamSynchronize(c->st));
-    for (uint8_t *d : d_tx) (void)hipFree(d);
-    for (const Rx &r : rx) (void)hipFree(r.d);
+    sc.keep_host(); // (from here on nothing fails: the host blocks are the caller's; the device buffers go with `sc`)
     *n_out = n_new; *cost_out = co; *nbytes_out = no; *bufs_out = bo; *owned_out = ow;
     if (st) {
         double mean = 0; for (double l : lb) mean += l; mean = W > 0 ? mean / W : 0.0;
@@ -267,5 +303,19 @@ int lcd_rebalance_exchange(lcd_comm_t *c, int n_jobs, const double *cost, const 
     return 0;
 #undef RB_HIP
 #undef RB_NCCL
+#undef RB_MEM
+}
+
+// What RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): the evidence a scaling run prints per rank.  0, or < 0 if the
+// communicator is dead / librccl lacks the calls
+int lcd_comm_info(lcd_comm_t *c, int *nccl_world, int *nccl_rank, int *nccl_device) {
+    if (!c || !c->comm || c->dead) return rb_err(-4, "lcd_comm_info: no live communicator");
+    if (!g_rccl.CommCount || !g_rccl.CommUserRank) return rb_err(-52, "librccl lacks ncclCommCount / ncclCommUserRank");
+    int n = -1, r = -1, d = -1;
+    int rc = g_rccl.CommCount(c->comm, &n); if (rc != 0) return rb_err(-53, std::string("ncclCommCount: ") + g_rccl.GetErrorString(rc));
+    rc = g_rccl.CommUserRank(c->comm, &r); if (rc != 0) return rb_err(-53, std::string("ncclCommUserRank: ") + g_rccl.GetErrorString(rc));
+    if (g_rccl.CommCuDevice && g_rccl.CommCuDevice(c->comm, &d) != 0) d = -1;
+    if (nccl_world) *nccl_world = n; if (nccl_rank) *nccl_rank = r; if (nccl_device) *nccl_device = d;
+    return 0;
 }
 }

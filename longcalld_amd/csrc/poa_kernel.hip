@@ -76,7 +76,7 @@ struct Ctx {
     int *aa_node, *aa_flag, *aa_eid;
     int *tb;                          // column-tile boundaries of the unbanded rows: 4 x node_cap ints (H of the last column, by tile parity; F carries)
     long long alg_adjust;             // cells of the reference's algorithm minus cells computed (certified band: full rows minus the intervals, attempts included)
-    int cert_generic, cert_generic_seen, cert_sest, cert_ubtop; unsigned long long cert_cells0; // the read at hand goes through the generic rows over its intervals (align_certified)
+    int cert_generic, cert_generic_seen, cert_sest, cert_ubtop, cert_bztop; unsigned long long cert_cells0; // the read at hand goes through the generic rows over its intervals (align_certified)
     int *cert; int cert_on, cert_hist; // certified band of a K2 chain (align_certified): 7 x node_cap ints; largest bound-to-score slack of the chain's reads so far
     int wmax, seq_cap, pool_words, spill_x, ring_k, plan_k, solo;
     unsigned long long wd_deadline;   // shader-clock tick after which the chain gives up (LCD_ERR_WATCHDOG): checked once per 64 DP rows, per read, per 256 backtrack steps
@@ -1754,7 +1754,9 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     if (FIXED && r16) { // every value of this read inside the int16 range, by the scores' own bounds: best case all matches, worst case one gap over all rows or all columns
         const long long span = (long long)(ei - bi) > qlen ? (long long)(ei - bi) : qlen;
         const long long worst = 2 * ((o1 > o2 ? o1 : o2) + (long long)(e1 < e2 ? e1 : e2) * span) + (o1 + o2) + 2LL * (e1 + e2) + 64; // (no cell is worse than a gap over its rows plus a gap over its columns -- the cheaper extension wins on a long gap; E-out is one open + extend below H)
-        if ((long long)qlen * s_match + 64 > 32000 || worst > 32000) return -1; // (not representable here: the generic rows keep 32-bit values)
+        // (best case: every base a match AND the heaviest bonus path -- every traversed edge adds ilog2(weight), which on a deep chain is worth more than the matches:
+        //  cert_bztop = the largest bonus sum of a source..sink path, from the bound's node arrays)
+        if ((long long)qlen * s_match + (long long)usgpr(g.cert_bztop) + 64 > 32000 || worst > 32000) return -1; // (not representable here: the generic rows keep 32-bit values)
     }
     auto ring_st3 = [&](const unsigned slot, const int x, const int (&va)[C], const int (&vb)[C], const int (&vc)[C]) { // slot: byte address of a ring slot; x: its first column here
         if (FIXED && r16) { lds_stc16<C>(slot + 2 * x, va); lds_stc16<C>(slot + 2 * (WIN + x), vb); lds_stc16<C>(slot + 2 * (2 * WIN + x), vc); }
@@ -3335,16 +3337,18 @@ __device__ __attribute__((noinline)) void cert_node_arrays(const Ctx *gp_, const
     }
 }
 // the bound at the end cell: the best any alignment of the whole read can score (the guess S_est is taken below it)
-__device__ int cert_ubtop(const Ctx &g, const int ei, const int qlen, const LcdScoring &sc) {
+__device__ int cert_ubtop(const Ctx &g, const int ei, const int qlen, const LcdScoring &sc, int *bztop = nullptr) {
     const size_t cap = (size_t)g.node_cap;
     const int *dmin = g.cert, *dmax = g.cert + cap, *bp = g.cert + 2 * cap;
     const int p0 = g.pl_start[ei], np = g.pl_start[ei + 1] - p0;
-    int ub = LCD_NEG;
+    int ub = LCD_NEG, bz = 0;
     for (int t = 0; t < np; ++t) {
         const int pi = g.pl_pidx[p0 + t], mx = dmax[pi], mn = dmin[pi];
         if (mx < 0) continue;
+        bz = imax(bz, bp[pi] + g.pl_bonus[p0 + t]);
         ub = imax(ub, bp[pi] + g.pl_bonus[p0 + t] + sc.match * imin(qlen, mx) - cert_G(qlen - mx, sc.o1, sc.e1, sc.o2, sc.e2) - cert_G(mn - qlen, sc.o1, sc.e1, sc.o2, sc.e2));
     }
+    if (bztop) *bztop = bz; // the largest sum of edge bonuses over a source..sink path: no cell's value is above qlen * match + this
     return ub;
 }
 // rows' intervals for the score bound `sest`, lane = row.  On every segment between two consecutive breakpoints {minD, maxD, qlen - maxR, qlen - minR} the
@@ -3456,7 +3460,9 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
             __syncthreads();
             g.t_plan += (unsigned long long)(clock64() - tca0); // (profiling: the bound's node arrays)
             const unsigned long long cells_before = *cells_acc;
-            const int ubtop = cert_ubtop(g, ei, qlen, sc);
+            int bztop = 0;
+            const int ubtop = cert_ubtop(g, ei, qlen, sc, &bztop);
+            g.cert_bztop = bztop;
             // the guess: the bound at the end cell minus a slack -- the largest one an earlier read of this chain needed (+ 25 % + 32), or a small one for
             // the first alignment.  An attempt that comes back below its guess doubles the slack; the best score seen so far is a TRUE lower bound of the
             // optimum and takes over as soon as it is the tighter of the two (that attempt cannot fail)
@@ -4374,7 +4380,7 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.pl_rem = (int *)(ws + L.pl_rem); g.pl_base = ws + L.pl_base;
     g.e_slot = (int *)(ws + L.e_slot); g.plan_valid = 0; g.plan_bi = g.plan_ei = g.plan_rend = 0;
     g.aa_node = (int *)(ws + L.aa_node); g.aa_flag = (int *)(ws + L.aa_flag); g.aa_eid = (int *)(ws + L.aa_eid);
-    g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = ch.cert == 2 ? 2 : NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0; g.cert_generic = 0; g.cert_generic_seen = 0; g.cert_sest = 0; g.cert_ubtop = 0; g.cert_cells0 = 0;
+    g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = ch.cert == 2 ? 2 : NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0; g.cert_generic = 0; g.cert_generic_seen = 0; g.cert_sest = 0; g.cert_ubtop = 0; g.cert_bztop = 0; g.cert_cells0 = 0;
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
     g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - ring_words) * 4; g.ring16 = ring16; g.ring_k = ring_k; g.plan_k = (NT == 64 || ch.solo) && ring_k > 2 && ch.wmax < 256 ? 2 : ring_k; // (slots beyond 2 of a chain laid out for a narrow window: not there when a read needs a wider one)
     g.wd_deadline = (unsigned long long)clock64() + (unsigned long long)(sc.wd_s > 0 ? sc.wd_s : 30) * 2400000000ull; // (~2.4 GHz shader clock: the bound is about seconds, not exact)

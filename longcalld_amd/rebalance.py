@@ -235,6 +235,14 @@ class Comm:
             raise RuntimeError("lcd_rccl_unique_id: " + lib.lcd_rebalance_last_error().decode())
         return buf.raw
 
+    def info(self):
+        """what RCCL itself reports for this communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice)"""
+        w, r, d = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        self.lib.lcd_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        if self.lib.lcd_comm_info(self.h, C.byref(w), C.byref(r), C.byref(d)) != 0:
+            raise RuntimeError("lcd_comm_info: " + self.lib.lcd_rebalance_last_error().decode())
+        return dict(nccl_world=w.value, nccl_rank=r.value, nccl_device=d.value)
+
     def close(self):
         if self.h:
             self.lib.lcd_comm_destroy(self.h); self.h = None

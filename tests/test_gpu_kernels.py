@@ -366,6 +366,84 @@ def test_poa_k2_certified_band(lcd, oracle, L, rate, sv, monkeypatch):
             _check_k2(x, oracle.poa_aln_msa_cons(j["reads"], 2))
 
 
+def _same_chains(xs, ys):
+    for x, y in zip(xs, ys):
+        assert x["status"] == 0 and y["status"] == 0 and x["n_cons"] == y["n_cons"] and x["msa_len"] == y["msa_len"]
+        for r, q in zip(x["msa"], y["msa"]):
+            assert (r == q).all()
+        for c in range(x["n_cons"]):
+            assert (x["cons"][c] == y["cons"][c]).all() and (x["clu"][c] == y["clu"][c]).all()
+
+
+def _het_chain(rng, L, n, rate=0.001, sv=40):
+    h1 = rng.integers(0, 4, L).astype(np.uint8)
+    h2 = np.concatenate([h1[:L // 3], rng.integers(0, 4, sv).astype(np.uint8), h1[L // 3:]])
+    for p in range(L // 2, L - 20, max(200, L // 12)):     # SNP bubbles all the way to the end: rows with two predecessors read the ring where the scores are largest
+        h2[p + sv] = (h2[p + sv] + 1) % 4
+    return [mutate(rng, h1 if i % 2 == 0 else h2, rate) for i in range(n)]
+
+
+def test_poa_k2_int16_ring_bonus_overflow(lcd, oracle, monkeypatch):
+    """The 16-bit LDS ring's range guard (poa_kernel.hip align_lean "int16 range", lcd_host.cpp chain_caps): every traversed edge adds ilog2(weight), so on a DEEP
+    chain the best score is far above qlen * match -- 34 reads x 4.8 kb reach 4 800 x (2 + 5) = 33 600 > int16 although 2 x 4 800 is nowhere near it (round 4's
+    guard looked at the matches only and let such a chain's ring saturate).  Default (the host lays the chain out for a 32-bit ring) == LCD_RING16=2 (16-bit pools
+    forced: the KERNEL's guard sends the late reads through the generic rows) == LCD_RING16=0 == full rows == oracle"""
+    rng = np.random.default_rng(5100)
+    jobs = [dict(mode=1, reads=_het_chain(rng, 4800, 34))]
+    monkeypatch.setenv("LCD_CERT", "1")
+    a = lcd.poa_batch(jobs)
+    monkeypatch.setenv("LCD_RING16", "2")
+    b = lcd.poa_batch(jobs)
+    monkeypatch.setenv("LCD_RING16", "0")
+    c = lcd.poa_batch(jobs)
+    monkeypatch.delenv("LCD_RING16")
+    monkeypatch.setenv("LCD_CERT", "0")
+    d = lcd.poa_batch(jobs)
+    _same_chains(a, b); _same_chains(a, c); _same_chains(a, d)
+    _check_k2(a[0], oracle.poa_aln_msa_cons(jobs[0]["reads"], 2))
+
+
+@pytest.mark.parametrize("L,n", [(15900, 6), (16100, 6), (30000, 5)])
+def test_poa_k2_int16_ring_guard_long_reads(lcd, L, n, monkeypatch):
+    """reads around and beyond the int16 limit of the matches alone (2 x 16 000 = 32 000; regions go to 50 kb, src/call_var_main.h:36): 16-bit pools forced
+    (LCD_RING16=2, the kernel's guard decides per read) == default == 32-bit rings == full rows.  (Too large for the scalar oracle in test time: the full rows
+    are the reference here, and every row must de-gap to its read.)"""
+    rng = np.random.default_rng(5200 + L)
+    jobs = [dict(mode=1, reads=_het_chain(rng, L, n))]
+    monkeypatch.setenv("LCD_CERT", "1")
+    a = lcd.poa_batch(jobs)
+    monkeypatch.setenv("LCD_RING16", "2")
+    b = lcd.poa_batch(jobs)
+    monkeypatch.setenv("LCD_RING16", "0")
+    c = lcd.poa_batch(jobs)
+    monkeypatch.delenv("LCD_RING16")
+    monkeypatch.setenv("LCD_CERT", "0")
+    d = lcd.poa_batch(jobs)
+    _same_chains(a, b); _same_chains(a, c); _same_chains(a, d)
+    for r, row in zip(jobs[0]["reads"], a[0]["msa"]):
+        assert (row[row != 5] == r).all()
+
+
+def test_poa_k2_int16_ring_guard_large_penalties(lcd, oracle, monkeypatch):
+    """gap_open2 = 4 000: the WORST-case bound (a gap over all rows plus a gap over all columns: 2 x (4 000 + ...) + ...) leaves the int16 range for a 900-base read, and
+    real cells do go below -8 000 at the corners of the intervals.  Forced 16-bit pools == default == 32-bit == full rows == oracle with the same penalties"""
+    from longcalld_amd import align
+    from oracle import pyoracle
+    rng = np.random.default_rng(5300)
+    jobs = [dict(mode=1, reads=_het_chain(rng, 900, 12, rate=0.004, sv=25))]
+    opt, oopt = align.default_opt(), pyoracle.default_opt()
+    opt.gap_open2 = oopt.gap_open2 = 4000
+    outs = []
+    for cert, r16 in (("1", None), ("1", "2"), ("1", "0"), ("0", None)):
+        monkeypatch.setenv("LCD_CERT", cert)
+        if r16 is None: monkeypatch.delenv("LCD_RING16", raising=False)
+        else: monkeypatch.setenv("LCD_RING16", r16)
+        outs.append(lcd.poa_batch(jobs, opt))
+    for o in outs[1:]:
+        _same_chains(outs[0], o)
+    _check_k2(outs[0][0], oracle.poa_aln_msa_cons(jobs[0]["reads"], 2, oopt))
+
+
 def test_poa_reads_with_n(lcd, oracle):
     """N bases (code 4, score 0 against everything, src/align.c:316) in reads: K2 leaves the systolic rows for the windowed ones"""
     rng = np.random.default_rng(500)
