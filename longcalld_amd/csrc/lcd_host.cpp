@@ -2029,7 +2029,8 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
             unsigned long long t0 = ~0ull;
             for (size_t g = 0; g < nC_all; ++g) t0 = std::min(t0, bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]].rt_begin);
             for (size_t g = 0; g < nC_all; ++g) { const PoaChainOut &o = bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]]; const PoaChain &pc = PC(g);
-                fprintf(f, "%d %d %d %llu %llu %u %u %d %d %d %llu\n", pc.threads, pc.lds_words * 4, pc.mode, o.rt_begin - t0, o.rt_end - t0, o.xcc_id & 15, (o.hw_id >> 8) & 15, pc.max_len, pc.n_reads, pc.cert, (unsigned long long)o.t_setup); }
+                fprintf(f, "%d %d %d %llu %llu %u %u %d %d %d %llu %llu %llu %llu %llu\n", pc.threads, pc.lds_words * 4, pc.mode, o.rt_begin - t0, o.rt_end - t0, o.xcc_id & 15, (o.hw_id >> 8) & 15, pc.max_len, pc.n_reads, pc.cert, (unsigned long long)o.t_setup,
+                        (unsigned long long)o.t_total, (unsigned long long)o.t_dp, (unsigned long long)o.cells, (unsigned long long)o.t_bt); }
             fclose(f);
         }
     }
@@ -2055,6 +2056,19 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
                 fprintf(stderr, "[lcd] group thr %4d lds %3dK: %6d chains, %7.2f wg-s, %2d per CU -> %7.2f CU-s\n", thr, lds >> 10, kv.second.second, kv.second.first / 2.4e9, per_cu, cus);
             }
             fprintf(stderr, "[lcd] total %.2f CU-s = %.1f ms of %d CUs\n", tot, tot / g_n_cus * 1e3, g_n_cus);
+        }
+        // per (class, kind of chain): ticks per phase and cells -- kind 0: K1 (adaptive band), 1: K2 full rows, 2: K2 certified band, +4: long-chain (solo) workgroup
+        {
+            struct Acc { double n = 0, tt = 0, td = 0, tb = 0, tbp = 0, tad = 0, tso = 0, tse = 0, tsub = 0, to = 0, cells = 0, reads = 0, rows = 0; };
+            std::map<int, Acc> by;
+            for (size_t g = 0; g < nC_all; ++g) { const PoaChain &pc = PC(g); const PoaChainOut &o = bs[chain_batch[g]]->couts[g - chain_base[chain_batch[g]]];
+                Acc &a = by[chain_threads(pc) * 8 + (pc.mode ? (pc.cert ? 2 : 1) : 0) + (pc.solo ? 4 : 0)];
+                a.n += 1; a.tt += (double)o.t_total; a.td += (double)o.t_dp; a.tb += (double)o.t_bt; a.tbp += (double)o.t_bp; a.tad += (double)o.t_add; a.tso += (double)o.t_sort; a.tse += (double)o.t_setup;
+                a.tsub += (double)o.t_sub; a.to += (double)o.t_out; a.cells += (double)o.cells; a.reads += o.n_aligned_reads; a.rows += (double)o.n_aligned_reads * o.n_node; }
+            for (auto &kv : by) { const Acc &a = kv.second;
+                fprintf(stderr, "[kind] thr %4d kind %d: %6.0f chains %8.0f reads  ticks total %.3e | dp %.1f%% bt %.1f%% plan %.1f%% update %.1f%% re-sort %.1f%% setup %.1f%% sub %.1f%% out %.1f%% | cells %.3e  ticks/cell(dp) %.2f  ~rows %.3e\n",
+                        kv.first >> 3, kv.first & 7, a.n, a.reads, a.tt, 100 * a.td / a.tt, 100 * a.tb / a.tt, 100 * a.tbp / a.tt, 100 * a.tad / a.tt, 100 * a.tso / a.tt, 100 * a.tse / a.tt, 100 * a.tsub / a.tt, 100 * a.to / a.tt,
+                        a.cells, a.td / std::max(1.0, a.cells), a.rows); }
         }
         // per-phase shader-clock ticks, summed per workgroup class and for the slowest chain
         for (int cls : {64, 128, 256, 512, 1024}) {

@@ -1748,6 +1748,15 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     const int lane = threadIdx.x & 63;
     if (qlen >= 65535) return -1; // (beg | end << 16 words)
     if (BANDED && (oe1 <= 0 || oe2 <= 0 || e1 < 0 || e2 < 0)) return -1; // (the row maximum is taken from Hpre: a horizontal gap must cost something)
+    if (s_match < -32 || s_match > 31 || s_mism < -32 || s_mism > 31) return -1; // (the substitution score of a cell is a 6-bit field of a per-row scalar word, see `lut`)
+    // Substitution scores: the query cache holds 6 * min(base, 4), and a row's five scores (its node's base against A C G T N, + 32) are 6-bit fields of ONE scalar
+    // word picked per row: the cell's score is a single v_bfe_u32 (was two compares and two selects per cell, plus two moves of the row's match / mismatch into VGPRs)
+    unsigned lut4 = 0;
+    for (int q = 0; q < 5; ++q) lut4 |= 32u << (6 * q);
+    unsigned lutb[4];
+    for (int v = 0; v < 4; ++v) { unsigned w_ = 32u << 24; for (int q = 0; q < 4; ++q) w_ |= (unsigned)(32 + (q == v ? s_match : s_mism)) << (6 * q); lutb[v] = usgpr(w_); }
+    lut4 = usgpr(lut4);
+    auto lut_of = [&](const int vb) -> unsigned { return vb == 0 ? lutb[0] : vb == 1 ? lutb[1] : vb == 2 ? lutb[2] : vb == 3 ? lutb[3] : lut4; };
     const int QB = (qlen + 12 + 15) & ~15;
     const bool r16 = FIXED && usgpr(g.ring16) != 0; // (16-bit ring values: lds_stc16 / lds_ldc16)
     const unsigned RB = r16 ? 2u : 4u;
@@ -1773,8 +1782,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
         }
     }
     const int KM = K - 1;
-    for (int j = lane; j < QB; j += 64) lds_st_u8(sq1 + j, (j >= 1 && j <= qlen) ? glb_ld_u8(seq_hbm + (j - 1)) : 4); // shifted: sq1[j] = q[j-1]
-    const int qclamp = QB - CP;
+    for (int j = lane; j < QB; j += 64) { const int qb_ = (j >= 1 && j <= qlen) ? glb_ld_u8(seq_hbm + (j - 1)) : 4; lds_st_u8(sq1 + j, 6 * (qb_ > 4 ? 4 : qb_)); } // shifted: sq1[j] = 6 * q[j-1] (the field offset into `lut`)
     const unsigned code_cap = (unsigned)(g.cell_cap > 0xfffffff0ull ? 0xfffffff0ull : g.cell_cap);
     const unsigned ord_cap = g.spill_x > 2 ? code_cap : (unsigned)((g.cell_cap / 4) > 0xfffffff0ull ? 0xfffffff0ull : (g.cell_cap / 4));
     const long long spill_rows_ll = g.cell_cap * g.spill_x > 64 ? (long long)((g.cell_cap * g.spill_x - 64) / ((unsigned long long)SLOTW * 4)) : 0;
@@ -1787,25 +1795,30 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     int nsp = 0;
     int pvh[C], pva[C], pvb[C]; // the previous row's values, lane = (column - pv_begc) / C
     const int cl = C * lane;
+    // one cell per lane: the plain rows' lanes follow the diagonal, and the adaptive band stays at column 0 for its first w rows -- the source row's window starts
+    // w + LCD_DIAG_SLACK columns LEFT of column 0 (lanes of negative columns are outside every band), as far as its own last column allows
+    constexpr int LCD_DIAG_SLACK = 0; // (columns a window is started left of its band: nothing gained once the plain rows could also keep their window, see there)
+    const int wb0 = C == 1 && LCD_DIAG_SLACK > 0 ? -smax(0, smin(LCD_DIAG_SLACK + (BANDED ? w : 0), WIN - 2 - end0)) : 0;
     {
         const bool spf = (usgpr(glb_ld_u8(g.imap + bi)) & 2) != 0;
         if (spf && spill_rows < 1) { wo->status = LCD_ERR_CELLS; return 0; }
 #pragma unroll
         for (int k = 0; k < C; ++k) {
-            const int j = cl + k;
+            const int j = cl + k + wb0;
             const int f1 = j ? -(o1 + e1 * j) : LCD_NEG, f2 = j ? -(o2 + e2 * j) : LCD_NEG;
             const int h = j ? imax(f1, f2) : 0;
-            const bool in = j <= end0;
+            const bool in = j >= 0 && j <= end0;
             pvh[k] = in ? h : LCD_GUARD; pva[k] = in ? h - oe1 : LCD_GUARD; pvb[k] = in ? h - oe2 : LCD_GUARD;
         }
-        ring_st3(ring, cl, pvh, pva, pvb);
-        if (spf) { int *G = g.spill; glb_stc<C>(G + cl, pvh); glb_stc<C>(G + WIN + cl, pva); glb_stc<C>(G + 2 * WIN + cl, pvb); nsp = 1; }
+        const int x0 = (wb0 + cl) & WM;
+        ring_st3(ring, x0, pvh, pva, pvb);
+        if (spf) { int *G = g.spill; glb_stc<C>(G + x0, pvh); glb_stc<C>(G + WIN + x0, pva); glb_stc<C>(G + 2 * WIN + x0, pvb); nsp = 1; }
         if (lane == 0) { glb_st(g.rbeg + bi, 0); glb_st(g.rend + bi, end0); glb_st(g.roff + bi, 0); glb_st(g.ml + bi, 0); glb_st(g.mr + bi, 0); glb_st(g.spoff + bi, 0); }
     }
     // ring slot meta: lane s holds (beg | end << 16, ml | mr << 16) of slot s; an empty slot is beg 1, end 0
     int m_be = 1, m_mm = 0;
     if (lane == 0) m_be = end0 << 16;
-    int pv_begc = 0, pv_beg = 0, pv_end = end0, pv_ml = 0, pv_mr = 0; bool pv_ok = true;
+    int pv_begc = wb0, pv_beg = 0, pv_end = end0, pv_ml = 0, pv_mr = 0; bool pv_ok = true;
     unsigned cused = 0, oused = 0; unsigned long long ncell = (unsigned long long)end0 + 1;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const long long t_dp0 = clock64();
@@ -1814,6 +1827,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     int w_pk = 0, w_x = 0, w_pi0 = 0, w_pi1 = 0, w_p0 = 0; // w_x: remain (MODE 1) / interval (MODE 2)
     int r_be = 1, r_off = 0;
     int wbase = bi + 1;
+    unsigned long long keep_mask = ~0ull, np_mask = ~0ull; // rows of the plan window that are NOT plain by their plan word (several / far / no predecessors, spilled, unreachable, past the end)
     // packed plan word: #preds (8 bits, 255 = more) | base << 8 | spill << 11 | unreachable << 12 | backbone << 13 | bonus0 << 14 | bonus1 << 19
     auto load_plan = [&](const int base) {
         const int ri = base + lane;
@@ -1831,6 +1845,14 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                  | ((cnt == 1 && w_pi0 == ri - 1) ? 1 << 13 : 0) | (b0 << 14) | (b1 << 19);
         }
         LCD_PIN(w_pk); LCD_PIN(w_x); LCD_PIN(w_pi0); LCD_PIN(w_pi1); LCD_PIN(w_p0);
+        np_mask = __ballot((w_pk & 0x38ff) != 0x2001);
+        // rows whose ring slot a general row may read: one of the next K rows is not plain by its plan word (the last K rows of a window: always)
+        unsigned long long km = 0;
+        for (int d = 1; d <= K; ++d) km |= (np_mask >> d) | (1ull << (64 - d));
+        keep_mask = km;
+#ifdef LCD_X_KEEPALL
+        keep_mask = ~0ull;
+#endif
     };
     auto flush_meta = [&](const int base, const int n) { // rows base .. base + n - 1
         if (lane < n) { glb_st(g.rbeg + base + lane, r_be & 65535); glb_st(g.rend + base + lane, (int)((unsigned)r_be >> 16)); glb_st(g.roff + base + lane, r_off); }
@@ -1839,7 +1861,13 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     // query bases of the lanes' cells for the window that starts at column b: sq1[b + cl + k], k < C, in the low bytes of one word
     // (one LDS load of exactly C bytes -- jq is a multiple of C -- so that a prefetched word needs no arithmetic before the row that uses it)
     auto q_of = [&](const int b) {
-        const unsigned a = sq1 + (unsigned)imin(b + cl, qclamp);
+        // (no clamp: columns past the cache belong to lanes past the read's end -- never inside a band, their cells are masked -- and an LDS read past the
+        //  workgroup's allocation returns 0)
+#ifdef LCD_X_QCLAMP
+        const unsigned a = sq1 + (unsigned)imin(b + cl, QB - CP);
+#else
+        const unsigned a = (unsigned)cl + (sq1 + (unsigned)b);
+#endif
         if constexpr (C == 1) return (word)*(const lcd_lds_u8 *)(uintptr_t)a;
         else if constexpr (C == 2) return (word)*(const __attribute__((address_space(3))) unsigned short *)(uintptr_t)a;
         else if constexpr (C == 4) return (word)(unsigned)lds_ld(a);
@@ -1847,122 +1875,343 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     };
     word q_cur = 0, q_nxt = 0; int q_ok = 0; // windows at pv_begc and pv_begc + C, valid while q_ok (the run loop keeps them; a general row drops them)
     // per-lane constants: (cl + k) * e and -(o + (cl + k) * e)
-    const int cle1 = cl * e1, cle2 = cl * e2, ncle1 = -cle1, ncle2 = -cle2; // (the cells' k * e and the window's begc * e are added on the scalar side)
+    int bcle1 = cl * e1 + (1 << 29), bcle2 = cl * e2 + (1 << 29), nbcle1 = -bcle1 - (C == 1 ? o1 : 0), nbcle2 = -bcle2 - (C == 1 ? o2 : 0); // (the plain rows' biased gap prefixes)
+    if constexpr (C <= 2) { LCD_PIN(bcle1); LCD_PIN(bcle2); LCD_PIN(nbcle1); LCD_PIN(nbcle2); } // (opaque: the compiler would re-derive them from cl * e and add the bias in an instruction of its own; the wider variants have no registers to spare for that)
     int idx = bi + 1;
+#ifdef LCD_X_ROWSTAT
+    unsigned n_pl_ = 0, n_gn_ = 0;
+#endif
     while (idx < ei) {
         if (idx - wbase == 64) {
             flush_meta(wbase, 64); wbase = idx; load_plan(wbase);
             if ((unsigned long long)clock64() > g.wd_deadline) { wo->status = LCD_ERR_WATCHDOG; return 0; }
         }
         int wk = idx - wbase;
-        // ===== a run of PLAIN rows: reachable, one usable predecessor = the row before (whose values are in registers), not spilled, window on the same lanes
-        // or one lane group further.  Anything else leaves the loop with the row untouched and is handled by the general row below. =====
+        // ===== a run of PLAIN rows: reachable, one usable predecessor = the row before (whose values are in registers), not spilled, window reachable from the
+        // previous row's lanes.  Anything else leaves the loop with the row untouched and is handled by the general row below. =====
+        // No clamp to LCD_NEG on the way: every value a cell of a plain row can win with is a real one (the row before has a reachable cell on the cell's diagonal or
+        // above it, or the cell is reached from its left), fillers stay a factor of two below LCD_NEG whatever a row adds to them, and the E values that go on to the
+        // next row keep their floor (max3).  What differs from the clamped rows is the code of cells NO alignment reaches -- never read.
+        // The ring slot (and its lane of slot metadata) is written only for rows a general row will look at: one of the next K rows is not plain by its plan word
+        // (keep_mask; a row that stops being plain at run time has one predecessor, the row before: flushed from the registers when the run ends).
         if (pv_ok) {
-            if (!q_ok) { q_cur = q_of(pv_begc); q_nxt = q_of(pv_begc + C); q_ok = 1; }
+#ifdef LCD_X_ROWSTAT
+            const int idx0_ = idx;
+#endif
             unsigned run_cells = 0;
             // (the run's loop-carried scalars are locals initialised through readfirstlane: as phis of the outer loop the compiler keeps them in VGPRs)
             int l_begc = usgpr(pv_begc), l_beg = usgpr(pv_beg), l_end = usgpr(pv_end), l_ml = usgpr(pv_ml), l_mr = usgpr(pv_mr);
-            while (wk < 64) {
-                const int pk = LCD_RL(w_pk, wk);
-                if ((pk & 0x38ff) != 0x2001) break; // #preds == 1, not spilled, reachable, backbone
-                const int xw = LCD_RL(w_x, wk);
-                int beg, end;
-                if (BANDED) {
-                    const int diag = qlen - xw;
-                    beg = smax(smax(smin(l_ml + 1, diag) - w, 0), l_beg);
-                    end = smin(smin(smax(l_mr + 1, diag) + w, qlen), l_end + 1);
-                } else { beg = xw & 65535; end = (int)((unsigned)xw >> 16); }
-                const int begc = beg & CM;
-                const int sh = begc - l_begc;
-                const int cw4 = ((end - begc) + CP) & ~(CP - 1);
-                if (beg > end || end - begc + 2 > WIN || (unsigned)sh > (unsigned)C || cused + (unsigned)cw4 > code_cap) break;
-                const int vb = (pk >> 8) & 7, bz0 = (pk >> 14) & 31;
-                const int s = (idx - bi) & KM;
-                const int mt = vb >= 4 ? 0 : s_match, mm = vb >= 4 ? 0 : s_mism;
-                // previous row: same lanes (sh == 0) or one lane to the left (sh == C)
-                int hm, av[C], bv[C], hd[C]; // hd[k]: H of the previous row at this cell's column - 1
-                if (sh == 0) {
-                    hm = shr1(LCD_GUARD, pvh[C - 1]);
-#pragma unroll
-                    for (int k = 0; k < C; ++k) { hd[k] = k ? pvh[k - 1] : hm; av[k] = pva[k]; bv[k] = pvb[k]; }
-                } else {
-                    q_cur = q_nxt; q_nxt = q_of(begc + C);
-#pragma unroll
-                    for (int k = 0; k < C; ++k) { hd[k] = k ? dpp_shl1(LCD_GUARD, pvh[k - 1]) : pvh[C - 1]; av[k] = dpp_shl1(LCD_GUARD, pva[k]); bv[k] = dpp_shl1(LCD_GUARD, pvb[k]); }
-                }
-                const int be1 = begc * e1, be2 = begc * e2, lo = beg - begc, span = end - beg;
-                int hp[C], spk[C], a1[C], a2[C], p1[C], p2[C], uu[C], vv[C]; bool inb[C];
-#pragma unroll
-                for (int k = 0; k < C; ++k) {
-                    const int q = (int)(q_cur >> (8 * k)) & 255;
-                    const int sk = q >= 4 ? 0 : (q == vb ? mt : mm);
-                    const int nn = imax(LCD_NEG, hd[k] + sk + bz0);
-                    uu[k] = imax(LCD_NEG, av[k] + bz0); vv[k] = imax(LCD_NEG, bv[k] + bz0);
-                    inb[k] = (unsigned)(cl + k - lo) <= (unsigned)span;
-                    hp[k] = imax(nn, imax(uu[k], vv[k]));
-                    spk[k] = nn == hp[k] ? 0 : uu[k] == hp[k] ? 1 : 2;
-                    a1[k] = inb[k] ? hp[k] + cle1 + (be1 + k * e1) : LCD_GUARD; a2[k] = inb[k] ? hp[k] + cle2 + (be2 + k * e2) : LCD_GUARD;
-                    p1[k] = k ? imax(p1[k - 1], a1[k]) : a1[k]; p2[k] = k ? imax(p2[k - 1], a2[k]) : a2[k];
-                }
-                int t1 = p1[C - 1], t2 = p2[C - 1];
-                int ml = 0, mr = 0;
-                if (BANDED) { // the row maximum and its leftmost / rightmost column, from Hpre (see scan_max3), in the same scan as the gap prefixes
-                    int hm_[C];
-#pragma unroll
-                    for (int k = 0; k < C; ++k) hm_[k] = inb[k] ? hp[k] : LCD_GUARD;
-                    int hb = hm_[0];
-#pragma unroll
-                    for (int k = 1; k < C; ++k) hb = imax(hb, hm_[k]);
-                    int hbs = hb;
-                    scan_max3(t1, t2, hbs);
-                    const int wm = lane63(hbs);
-                    const unsigned long long mk = __ballot(hb == wm); // (the row is not empty: its in-band cells are >= LCD_NEG > the filler)
-                    const int fl = usgpr((int)__builtin_ctzll(mk)), ll = usgpr(63 - (int)__builtin_clzll(mk));
-                    if (C == 1) { ml = begc + fl; mr = begc + ll; }
-                    else {
-                        int bl = C - 1, brr = 0;
-#pragma unroll
-                        for (int k = C - 2; k >= 0; --k) bl = hm_[k] == hb ? k : bl;
-#pragma unroll
-                        for (int k = 1; k < C; ++k) brr = hm_[k] == hb ? k : brr;
-                        ml = begc + C * fl + LCD_RL(bl, fl); mr = begc + C * ll + LCD_RL(brr, ll);
-                    }
-                } else scan_max2(t1, t2);
-                const int x1 = shr1(LCD_GUARD, t1), x2 = shr1(LCD_GUARD, t2);
-                word code = 0;
-#pragma unroll
-                for (int k = 0; k < C; ++k) {
-                    const int pf1 = k ? imax(x1, p1[k - 1]) : x1, pf2 = k ? imax(x2, p2[k - 1]) : x2;
-                    const int f1 = imax(LCD_NEG, pf1 + ncle1 - (o1 + be1 + k * e1)), f2 = imax(LCD_NEG, pf2 + ncle2 - (o2 + be2 + k * e2));
-                    const int h = imax(hp[k], imax(f1, f2));
-                    const int q1 = h - oe1, w1 = uu[k] - e1, q2 = h - oe2, w2 = vv[k] - e2;
+            int pend = 0; // the last row of the run has not been stored to its ring slot
+            if constexpr (C == 1) {
+                int q_c1 = lds_ld_u8((unsigned)lane + (sq1 + (unsigned)l_begc)), q_n1 = lds_ld_u8((unsigned)lane + (sq1 + (unsigned)(l_begc + 1))); // query bytes (x 6) of the lanes' columns in the window at hand / one column on
+                // ---- one cell per lane: lanes follow the DIAGONAL.  The window moves one column per row whatever the band does, so the cell's diagonal neighbour
+                // is the lane's own previous value, the cell above it one lane to the right (two in-place DPP moves, unconditionally: no branch on how the window
+                // moved, no register copies where two branches join), and the band [beg, end] drifts inside the 64 lanes (the general rows leave LCD_DIAG_SLACK
+                // columns to its left; a band that reaches a window edge ends the run).  Codes in HBM still start at the row's first column. ----
+                while (wk < 64) {
+                    const int pk = LCD_RL(w_pk, wk);
+                    if ((pk & 0x38ff) != 0x2001) break; // #preds == 1, not spilled, reachable, backbone
+                    const int xw = LCD_RL(w_x, wk);
+                    int beg, end;
+                    if (BANDED) {
+                        const int diag = qlen - xw;
+                        beg = smax(smax(smin(l_ml + 1, diag) - w, 0), l_beg);
+                        end = smin(smin(smax(l_mr + 1, diag) + w, qlen), l_end + 1);
+                    } else { beg = xw & 65535; end = (int)((unsigned)xw >> 16); }
+                    const int adv = smin(beg - l_begc, 1); // (0 or 1: beg >= l_beg >= l_begc) the window follows the band's first column by one column per row (a band that jumps further leaves lanes idle on its left)
+                    const int wb = l_begc + adv;        // this row's window: lane = column - wb
+                    const int lo = beg - wb, span = end - beg;
+                    const int cw4 = (span + CP) & ~(CP - 1);
+                    if (beg > end || beg < l_begc || end - wb + 2 > WIN || cused + (unsigned)cw4 > code_cap) break; // (beg < l_begc: an interval of MODE 2 that starts left of the window)
+                    const int vb = (pk >> 8) & 7, bz0 = (pk >> 14) & 31;
+                    const int s = (idx - bi) & KM;
+                    const unsigned lut = lut_of(vb);
+                    const int bzb = bz0 - 32; // (the score fields of `lut` are biased by 32)
+                    // Hand-over from the row before WITHOUT a branch (two branches that join cost a register copy per value) and without touching the execution mask:
+                    // v_cndmask with a DPP source, the condition a scalar mask that is all ones or all zeros.  Window moved (adv): the cell above is one lane to the
+                    // right -- E values shift left in place (lane 63 keeps its own old values: its column is never inside a band, end - wb <= WIN - 2, and is
+                    // masked) -- the diagonal neighbour is the lane's own H, and the query byte is the one prefetched for the next column.  Window stayed: E values
+                    // and query byte stay, H shifts right in place and lane 0 (the column left of the window) gets the filler.
+                    asm volatile("s_cmp_lg_u32 %5, 0\n\t"
+                                 "s_cselect_b64 vcc, 0, -1\n\ts_nop 1\n\t"                                               // vcc = stayed ? all lanes : none;  D = vcc ? src1 : src0
+                                 "v_cndmask_b32_dpp %0, %0, %0, vcc wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_cndmask_b32_dpp %1, %1, %1, vcc wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_cndmask_b32_e32 %3, %4, %3, vcc\n\t"
+                                 "s_cselect_b64 vcc, -1, 0\n\ts_nop 1\n\t"                                               // vcc = moved ? all lanes : none
+                                 "v_cndmask_b32_dpp %2, %2, %2, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                                 "s_cselect_b64 vcc, 0, 1\n\ts_nop 1\n\t"                                                // vcc = stayed ? lane 0 : none
+                                 "v_cndmask_b32_e64 %2, %2, -2.0, vcc"                                                       // (-2.0f is LCD_GUARD's bit pattern)
+                                 : "+v"(pva[0]), "+v"(pvb[0]), "+v"(pvh[0]), "+v"(q_c1) : "v"(q_n1), "s"(usgpr(adv)) : "vcc", "scc");
+                    static_assert(LCD_GUARD == (int)0xc0000000, "the filler above is written as the inline constant -2.0f");
+                    const unsigned q6 = (unsigned)q_c1;
+                    q_n1 = lds_ld_u8((unsigned)lane + (sq1 + (unsigned)(wb + 1))); // the next row's byte if its window moves again (the usual case): a row of latency to arrive in
+                    const int sk = (int)__builtin_amdgcn_ubfe(lut, q6, 6u);
+                    const int nn = pvh[0] + sk + bzb;
+                    const int uu = pva[0] + bz0, vv = pvb[0] + bz0;
+                    const bool inb = (unsigned)(lane - lo) <= (unsigned)span;
+                    const int m_ = imax(uu, vv);
+                    int spk = nn >= m_ ? 0 : uu >= vv ? 1 : 2;
+                    LCD_PIN(spk); // (made here: left to the code store at the end it keeps the old E values alive past their successors)
+                    const int hp = inb ? imax(nn, m_) : LCD_GUARD; // masked once: the gap prefixes, the row maximum and H all take it from here
+                    const int a1 = hp + bcle1, a2 = hp + bcle2; // (relative to the window's first column: the row's own offset cancels in every comparison; + 2^29, see x1)
+                    int t1 = a1, t2 = a2;
+                    int ml = 0, mr = 0;
+                    if (BANDED) { // the row maximum and its leftmost / rightmost column, from Hpre (see scan_max3), in the same scan as the gap prefixes
+                        int hbs = hp;
+                        scan_max3(t1, t2, hbs);
+                        const int wm = lane63(hbs);
+                        const unsigned long long mk = __ballot(hp == wm); // (the row is not empty: its in-band cells are real values > the filler)
+                        ml = wb + usgpr((int)__builtin_ctzll(mk)); mr = wb + usgpr(63 - (int)__builtin_clzll(mk));
+                    } else scan_max2(t1, t2);
+                    // exclusive prefix over the lanes.  The prefixes carry a bias of 2^29 (every real one is positive, a masked one negative), so the 0 that lane 0
+                    // gets from the shift's bound control stands for "nothing to the left" without a register set up for it
+                    const int pf1 = __builtin_amdgcn_update_dpp(0, t1, 0x138, 0xf, 0xf, true), pf2 = __builtin_amdgcn_update_dpp(0, t2, 0x138, 0xf, 0xf, true);
+                    const int f1 = pf1 + nbcle1, f2 = pf2 + nbcle2; // (the opening penalty is in the lane's constant)
+                    const int fm = imax(f1, f2);
+                    const int h = imax(hp, fm);
+                    const int q1 = h - oe1, w1 = uu - e1, q2 = h - oe2, w2 = vv - e2;
                     const int eo1 = imax(imax(q1, w1), LCD_NEG), eo2 = imax(imax(q2, w2), LCD_NEG);
                     const int fk = f1 == h ? (f2 == h ? 5 : 3) : 4;
-                    const int hs = hp[k] == h ? spk[k] : fk;
-                    unsigned fl = 0; // O2, O1, Y2, Y1 pushed in this order = bits 6, 5, 4, 3 of the code
-                    { const int r2 = a2[k], r1 = a1[k]; LCD_PUSH_GE(fl, q2, w2); LCD_PUSH_GE(fl, q1, w1); LCD_PUSH_GT(fl, pf2, r2); LCD_PUSH_GT(fl, pf1, r1); }
-                    code |= (word)((unsigned)hs | (fl << 3)) << (8 * k);
-                    pvh[k] = inb[k] ? h : LCD_GUARD; pva[k] = inb[k] ? eo1 : LCD_GUARD; pvb[k] = inb[k] ? eo2 : LCD_GUARD;
+                    const int hs = hp >= fm ? spk : fk;
+                    unsigned fl = q2 >= w2 ? 1u : 0u; // O2, O1, Y2, Y1 pushed in this order = bits 6, 5, 4, 3 of the code
+                    LCD_PUSH_GE(fl, q1, w1); LCD_PUSH_GT(fl, pf2, a2); LCD_PUSH_GT(fl, pf1, a1);
+                    const unsigned code = (unsigned)hs | (fl << 3);
+                    pvh[0] = inb ? h : LCD_GUARD; pva[0] = inb ? eo1 : LCD_GUARD; pvb[0] = inb ? eo2 : LCD_GUARD;
+                    const int be = beg | (end << 16);
+                    if (((keep_mask >> wk) & 1ull) != 0ull) {
+                        ring_st3(ring + RB * (unsigned)(s * SLOTW), (wb + lane) & WM, pvh, pva, pvb);
+                        m_be = lean_wlane(be, s, m_be); m_mm = lean_wlane(ml | (mr << 16), s, m_mm);
+                        pend = 0;
+                    } else pend = 1;
+                    if (inb) *(__attribute__((address_space(1))) uint8_t *)(g.code8 + (size_t)(cused + (unsigned)(lane - lo))) = (uint8_t)code;
+                    r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)cused, wk, r_off);
+                    l_begc = wb; l_beg = beg; l_end = end; l_ml = ml; l_mr = mr;
+                    cused += (unsigned)cw4; run_cells += (unsigned)(span + 1);
+                    ++idx; ++wk;
                 }
-                {
-                    const int x = (begc + cl) & WM;
-                    ring_st3(ring + RB * (unsigned)(s * SLOTW), x, pvh, pva, pvb);
+            } else if constexpr (C >= 8) {
+                // ---- eight cells per lane (intervals of 257 - 508 columns: a handful of reads per submission, but the longest ones): the rows as they were before
+                // round 5 -- clamped, every row to its ring slot.  The leaner formulation below needs more registers at this width than the class has (30 scratch
+                // accesses per row against 2) ----
+                if (!q_ok) { q_cur = q_of(pv_begc); q_nxt = q_of(pv_begc + C); q_ok = 1; }
+                const int cle1 = cl * e1, cle2 = cl * e2, ncle1 = -cle1, ncle2 = -cle2; // (the cells' k * e and the window's begc * e are added on the scalar side)
+                while (wk < 64) {
+                    const int pk = LCD_RL(w_pk, wk);
+                    if ((pk & 0x38ff) != 0x2001) break; // #preds == 1, not spilled, reachable, backbone
+                    const int xw = LCD_RL(w_x, wk);
+                    int beg, end;
+                    if (BANDED) {
+                        const int diag = qlen - xw;
+                        beg = smax(smax(smin(l_ml + 1, diag) - w, 0), l_beg);
+                        end = smin(smin(smax(l_mr + 1, diag) + w, qlen), l_end + 1);
+                    } else { beg = xw & 65535; end = (int)((unsigned)xw >> 16); }
+                    const int begc = beg & CM;
+                    const int sh = begc - l_begc;
+                    const int cw4 = ((end - begc) + CP) & ~(CP - 1);
+                    if (beg > end || end - begc + 2 > WIN || (unsigned)sh > (unsigned)C || cused + (unsigned)cw4 > code_cap) break;
+                    const int vb = (pk >> 8) & 7, bz0 = (pk >> 14) & 31;
+                    const int s = (idx - bi) & KM;
+                    const int mt = vb >= 4 ? 0 : s_match, mm = vb >= 4 ? 0 : s_mism;
+                    // previous row: same lanes (sh == 0) or one lane to the left (sh == C)
+                    int hm, av[C], bv[C], hd[C]; // hd[k]: H of the previous row at this cell's column - 1
+                    if (sh == 0) {
+                        hm = shr1(LCD_GUARD, pvh[C - 1]);
+    #pragma unroll
+                        for (int k = 0; k < C; ++k) { hd[k] = k ? pvh[k - 1] : hm; av[k] = pva[k]; bv[k] = pvb[k]; }
+                    } else {
+                        q_cur = q_nxt; q_nxt = q_of(begc + C);
+    #pragma unroll
+                        for (int k = 0; k < C; ++k) { hd[k] = k ? dpp_shl1(LCD_GUARD, pvh[k - 1]) : pvh[C - 1]; av[k] = dpp_shl1(LCD_GUARD, pva[k]); bv[k] = dpp_shl1(LCD_GUARD, pvb[k]); }
+                    }
+                    const int be1 = begc * e1, be2 = begc * e2, lo = beg - begc, span = end - beg;
+                    int hp[C], spk[C], a1[C], a2[C], p1[C], p2[C], uu[C], vv[C]; bool inb[C];
+    #pragma unroll
+                    for (int k = 0; k < C; ++k) {
+                        const int q = (int)(q_cur >> (8 * k)) & 255; // (6 * base)
+                        const int sk = q >= 24 ? 0 : (q == 6 * vb ? mt : mm);
+                        const int nn = imax(LCD_NEG, hd[k] + sk + bz0);
+                        uu[k] = imax(LCD_NEG, av[k] + bz0); vv[k] = imax(LCD_NEG, bv[k] + bz0);
+                        inb[k] = (unsigned)(cl + k - lo) <= (unsigned)span;
+                        hp[k] = imax(nn, imax(uu[k], vv[k]));
+                        spk[k] = nn == hp[k] ? 0 : uu[k] == hp[k] ? 1 : 2;
+                        a1[k] = inb[k] ? hp[k] + cle1 + (be1 + k * e1) : LCD_GUARD; a2[k] = inb[k] ? hp[k] + cle2 + (be2 + k * e2) : LCD_GUARD;
+                        p1[k] = k ? imax(p1[k - 1], a1[k]) : a1[k]; p2[k] = k ? imax(p2[k - 1], a2[k]) : a2[k];
+                    }
+                    int t1 = p1[C - 1], t2 = p2[C - 1];
+                    int ml = 0, mr = 0;
+                    if (BANDED) { // the row maximum and its leftmost / rightmost column, from Hpre (see scan_max3), in the same scan as the gap prefixes
+                        int hm_[C];
+    #pragma unroll
+                        for (int k = 0; k < C; ++k) hm_[k] = inb[k] ? hp[k] : LCD_GUARD;
+                        int hb = hm_[0];
+    #pragma unroll
+                        for (int k = 1; k < C; ++k) hb = imax(hb, hm_[k]);
+                        int hbs = hb;
+                        scan_max3(t1, t2, hbs);
+                        const int wm = lane63(hbs);
+                        const unsigned long long mk = __ballot(hb == wm); // (the row is not empty: its in-band cells are >= LCD_NEG > the filler)
+                        const int fl = usgpr((int)__builtin_ctzll(mk)), ll = usgpr(63 - (int)__builtin_clzll(mk));
+                        if (C == 1) { ml = begc + fl; mr = begc + ll; }
+                        else {
+                            int bl = C - 1, brr = 0;
+    #pragma unroll
+                            for (int k = C - 2; k >= 0; --k) bl = hm_[k] == hb ? k : bl;
+    #pragma unroll
+                            for (int k = 1; k < C; ++k) brr = hm_[k] == hb ? k : brr;
+                            ml = begc + C * fl + LCD_RL(bl, fl); mr = begc + C * ll + LCD_RL(brr, ll);
+                        }
+                    } else scan_max2(t1, t2);
+                    const int x1 = shr1(LCD_GUARD, t1), x2 = shr1(LCD_GUARD, t2);
+                    word code = 0;
+    #pragma unroll
+                    for (int k = 0; k < C; ++k) {
+                        const int pf1 = k ? imax(x1, p1[k - 1]) : x1, pf2 = k ? imax(x2, p2[k - 1]) : x2;
+                        const int f1 = imax(LCD_NEG, pf1 + ncle1 - (o1 + be1 + k * e1)), f2 = imax(LCD_NEG, pf2 + ncle2 - (o2 + be2 + k * e2));
+                        const int h = imax(hp[k], imax(f1, f2));
+                        const int q1 = h - oe1, w1 = uu[k] - e1, q2 = h - oe2, w2 = vv[k] - e2;
+                        const int eo1 = imax(imax(q1, w1), LCD_NEG), eo2 = imax(imax(q2, w2), LCD_NEG);
+                        const int fk = f1 == h ? (f2 == h ? 5 : 3) : 4;
+                        const int hs = hp[k] == h ? spk[k] : fk;
+                        unsigned fl = 0; // O2, O1, Y2, Y1 pushed in this order = bits 6, 5, 4, 3 of the code
+                        { const int r2 = a2[k], r1 = a1[k]; LCD_PUSH_GE(fl, q2, w2); LCD_PUSH_GE(fl, q1, w1); LCD_PUSH_GT(fl, pf2, r2); LCD_PUSH_GT(fl, pf1, r1); }
+                        code |= (word)((unsigned)hs | (fl << 3)) << (8 * k);
+                        pvh[k] = inb[k] ? h : LCD_GUARD; pva[k] = inb[k] ? eo1 : LCD_GUARD; pvb[k] = inb[k] ? eo2 : LCD_GUARD;
+                    }
+                    {
+                        const int x = (begc + cl) & WM;
+                        ring_st3(ring + RB * (unsigned)(s * SLOTW), x, pvh, pva, pvb);
+                        if (cl < cw4) {
+                            uint8_t *cp = g.code8 + (size_t)(cused + (unsigned)cl);
+                            if constexpr (C == 8) *(__attribute__((address_space(1))) unsigned long long *)cp = code;
+                            else if constexpr (C == 4) glb_st(cp, (int)code);
+                            else if constexpr (C == 2) *(__attribute__((address_space(1))) unsigned short *)cp = (unsigned short)code;
+                            else *(__attribute__((address_space(1))) uint8_t *)cp = (uint8_t)code;
+                        }
+                    }
+                    const int be = beg | (end << 16);
+                    r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)cused, wk, r_off);
+                    m_be = lean_wlane(be, s, m_be); m_mm = lean_wlane(ml | (mr << 16), s, m_mm);
+                    l_begc = begc; l_beg = beg; l_end = end; l_ml = ml; l_mr = mr;
+                    cused += (unsigned)cw4; run_cells += (unsigned)(span + 1);
+                    ++idx; ++wk;
+                }
+            } else {
+                if (!q_ok) { q_cur = q_of(pv_begc); q_nxt = q_of(pv_begc + C); q_ok = 1; }
+                while (wk < 64) {
+                    const int pk = LCD_RL(w_pk, wk);
+                    if ((pk & 0x38ff) != 0x2001) break; // #preds == 1, not spilled, reachable, backbone
+                    const int xw = LCD_RL(w_x, wk);
+                    int beg, end;
+                    if (BANDED) {
+                        const int diag = qlen - xw;
+                        beg = smax(smax(smin(l_ml + 1, diag) - w, 0), l_beg);
+                        end = smin(smin(smax(l_mr + 1, diag) + w, qlen), l_end + 1);
+                    } else { beg = xw & 65535; end = (int)((unsigned)xw >> 16); }
+                    const int begc = beg & CM;
+                    const int sh = begc - l_begc;
+                    const int cw4 = ((end - begc) + CP) & ~(CP - 1);
+                    if (beg > end || end - begc + 2 > WIN || (unsigned)sh > (unsigned)C || cused + (unsigned)cw4 > code_cap) break;
+                    const int vb = (pk >> 8) & 7, bz0 = (pk >> 14) & 31;
+                    const int s = (idx - bi) & KM;
+                    const unsigned lut = lut_of(vb);
+                    const int bzb = bz0 - 32; // (the score fields of `lut` are biased by 32)
+                    // previous row: same lanes (sh == 0) or one lane to the left (sh == C); hd[k]: H of the previous row at this cell's column - 1
+                    int hd[C];
+                    if (sh == 0) {
+                        hd[0] = shr1(LCD_GUARD, pvh[C - 1]);
+#pragma unroll
+                        for (int k = 1; k < C; ++k) hd[k] = pvh[k - 1];
+                    } else {
+                        q_cur = q_nxt; q_nxt = q_of(begc + C);
+                        hd[0] = pvh[C - 1];
+#pragma unroll
+                        for (int k = 1; k < C; ++k) hd[k] = dpp_shl1(LCD_GUARD, pvh[k - 1]);
+#pragma unroll
+                        for (int k = 0; k < C; ++k) { pva[k] = dpp_shl1(LCD_GUARD, pva[k]); pvb[k] = dpp_shl1(LCD_GUARD, pvb[k]); }
+                    }
+                    const int lo = beg - begc, span = end - beg;
+                    int hp[C], spk[C], a1[C], a2[C], p1[C], p2[C], uu[C], vv[C]; bool inb[C];
+#pragma unroll
+                    for (int k = 0; k < C; ++k) {
+                        const unsigned q6 = (unsigned)(q_cur >> (8 * k)) & 255u;
+                        const int sk = (int)__builtin_amdgcn_ubfe(lut, q6, 6u);
+                        const int nn = hd[k] + sk + bzb;
+                        uu[k] = pva[k] + bz0; vv[k] = pvb[k] + bz0;
+                        inb[k] = (unsigned)(cl + k - lo) <= (unsigned)span;
+                        const int m_ = imax(uu[k], vv[k]);
+                        spk[k] = nn >= m_ ? 0 : uu[k] >= vv[k] ? 1 : 2;
+                        hp[k] = inb[k] ? imax(nn, m_) : LCD_GUARD; // masked once: the gap prefixes, the row maximum and H all take it from here
+                        a1[k] = hp[k] + bcle1 + k * e1; a2[k] = hp[k] + bcle2 + k * e2; // (relative to the window's first column; + 2^29, see x1)
+                        p1[k] = k ? imax(p1[k - 1], a1[k]) : a1[k]; p2[k] = k ? imax(p2[k - 1], a2[k]) : a2[k];
+                    }
+                    int t1 = p1[C - 1], t2 = p2[C - 1];
+                    int ml = 0, mr = 0;
+                    if (BANDED) { // the row maximum and its leftmost / rightmost column, from Hpre (see scan_max3), in the same scan as the gap prefixes
+                        int hb = hp[0];
+#pragma unroll
+                        for (int k = 1; k < C; ++k) hb = imax(hb, hp[k]);
+                        int hbs = hb;
+                        scan_max3(t1, t2, hbs);
+                        const int wm = lane63(hbs);
+                        const unsigned long long mk = __ballot(hb == wm); // (the row is not empty: its in-band cells are real values > the filler)
+                        const int fl = usgpr((int)__builtin_ctzll(mk)), ll = usgpr(63 - (int)__builtin_clzll(mk));
+                        int bl = C - 1, brr = 0;
+#pragma unroll
+                        for (int k = C - 2; k >= 0; --k) bl = hp[k] == hb ? k : bl;
+#pragma unroll
+                        for (int k = 1; k < C; ++k) brr = hp[k] == hb ? k : brr;
+                        ml = begc + C * fl + LCD_RL(bl, fl); mr = begc + C * ll + LCD_RL(brr, ll);
+                    } else scan_max2(t1, t2);
+                    // exclusive prefix over the lanes.  The prefixes carry a bias of 2^29 (every real one is positive, a masked one negative), so the 0 that lane 0
+                    // gets from the shift's bound control stands for "nothing to the left" without a register set up for it
+                    const int x1 = __builtin_amdgcn_update_dpp(0, t1, 0x138, 0xf, 0xf, true), x2 = __builtin_amdgcn_update_dpp(0, t2, 0x138, 0xf, 0xf, true);
+                    word code = 0;
+#pragma unroll
+                    for (int k = 0; k < C; ++k) {
+                        const int pf1 = k ? imax(x1, p1[k - 1]) : x1, pf2 = k ? imax(x2, p2[k - 1]) : x2;
+                        const int sn1 = -(o1 + k * e1), sn2 = -(o2 + k * e2);
+                        const int f1 = pf1 + nbcle1 + sn1, f2 = pf2 + nbcle2 + sn2;
+                        const int fm = imax(f1, f2);
+                        const int h = imax(hp[k], fm);
+                        const int q1 = h - oe1, w1 = uu[k] - e1, q2 = h - oe2, w2 = vv[k] - e2;
+                        const int eo1 = imax(imax(q1, w1), LCD_NEG), eo2 = imax(imax(q2, w2), LCD_NEG);
+                        const int fk = f1 == h ? (f2 == h ? 5 : 3) : 4;
+                        const int hs = hp[k] >= fm ? spk[k] : fk;
+                        unsigned fl = q2 >= w2 ? 1u : 0u; // O2, O1, Y2, Y1 pushed in this order = bits 6, 5, 4, 3 of the code
+                        { // (eight cells per lane: the cells' own prefix terms are made again here instead of being kept over the scan -- sixteen registers the class does not have)
+                          int r2 = a2[k], r1 = a1[k];
+                          if constexpr (C >= 8) { int hq = hp[k]; LCD_PIN(hq); r2 = hq + bcle2 + k * e2; r1 = hq + bcle1 + k * e1; }
+                          LCD_PUSH_GE(fl, q1, w1); LCD_PUSH_GT(fl, pf2, r2); LCD_PUSH_GT(fl, pf1, r1); }
+                        code |= (word)((unsigned)hs | (fl << 3)) << (8 * k);
+                        pvh[k] = inb[k] ? h : LCD_GUARD; pva[k] = inb[k] ? eo1 : LCD_GUARD; pvb[k] = inb[k] ? eo2 : LCD_GUARD;
+                    }
+                    const int be = beg | (end << 16);
+                    if (((keep_mask >> wk) & 1ull) != 0ull) {
+                        ring_st3(ring + RB * (unsigned)(s * SLOTW), (begc + cl) & WM, pvh, pva, pvb);
+                        m_be = lean_wlane(be, s, m_be); m_mm = lean_wlane(ml | (mr << 16), s, m_mm);
+                        pend = 0;
+                    } else pend = 1;
                     if (cl < cw4) {
                         uint8_t *cp = g.code8 + (size_t)(cused + (unsigned)cl);
                         if constexpr (C == 8) *(__attribute__((address_space(1))) unsigned long long *)cp = code;
                         else if constexpr (C == 4) glb_st(cp, (int)code);
-                        else if constexpr (C == 2) *(__attribute__((address_space(1))) unsigned short *)cp = (unsigned short)code;
-                        else *(__attribute__((address_space(1))) uint8_t *)cp = (uint8_t)code;
+                        else *(__attribute__((address_space(1))) unsigned short *)cp = (unsigned short)code;
                     }
+                    r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)cused, wk, r_off);
+                    l_begc = begc; l_beg = beg; l_end = end; l_ml = ml; l_mr = mr;
+                    cused += (unsigned)cw4; run_cells += (unsigned)(span + 1);
+                    ++idx; ++wk;
                 }
-                const int be = beg | (end << 16);
-                r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)cused, wk, r_off);
-                m_be = lean_wlane(be, s, m_be); m_mm = lean_wlane(ml | (mr << 16), s, m_mm);
-                l_begc = begc; l_beg = beg; l_end = end; l_ml = ml; l_mr = mr;
-                cused += (unsigned)cw4; run_cells += (unsigned)(span + 1);
-                ++idx; ++wk;
+            }
+            if (pend) { // a general row comes next (or the window ends): it reads its predecessor from the ring
+                const int sl = (idx - 1 - bi) & KM;
+                ring_st3(ring + RB * (unsigned)(sl * SLOTW), (l_begc + cl) & WM, pvh, pva, pvb);
+                m_be = lean_wlane(l_beg | (l_end << 16), sl, m_be); m_mm = lean_wlane(l_ml | (l_mr << 16), sl, m_mm);
             }
             pv_begc = l_begc; pv_beg = l_beg; pv_end = l_end; pv_ml = l_ml; pv_mr = l_mr;
+#ifdef LCD_X_ROWSTAT
+            n_pl_ += (unsigned)(idx - idx0_);
+#endif
             ncell += run_cells;
             if (wk == 64 || idx >= ei) continue;
         }
@@ -2009,16 +2258,20 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
             pv_ok = false;
             break;
         }
-        const int begc = beg & CM;
+        if (C == 1 && end - beg + 2 > WIN) return -1;
+        // (one cell per lane: the window starts LCD_DIAG_SLACK columns left of the band, as far as the band's width allows -- the plain rows that follow move their
+        //  window one column per row, and a band that lags behind the diagonal needs room on its left; cells in HBM start at the band's first column all the same)
+        const int begc = C == 1 ? smax(beg - LCD_DIAG_SLACK, end + 2 - WIN) : (beg & CM);
         if (end - begc + 2 > WIN) return -1;
+        const int lo_g = C == 1 ? beg - begc : 0; // the band's first lane
         const int jb = begc + cl;
         const word qw = q_of(begc);
+        const unsigned lutg = lut_of(vb);
         bool inb[C]; int sk[C];
 #pragma unroll
         for (int k = 0; k < C; ++k) {
             inb[k] = jb + k >= beg && jb + k <= end;
-            const int q = (int)(qw >> (8 * k)) & 255;
-            sk[k] = (vb >= 4 || q >= 4) ? 0 : (vb == q ? s_match : s_mism);
+            sk[k] = (int)__builtin_amdgcn_ubfe(lutg, (unsigned)(qw >> (8 * k)) & 255u, 6u) - 32;
         }
         // ---- phase A: best match / E1 / E2 input of the cells over the predecessors (first maximum keeps its ordinal) ----
         int nn[C], uu[C], vv[C];
@@ -2079,7 +2332,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
         for (int k = 0; k < C; ++k) {
             hp[k] = imax(nn[k], imax(uu[k], vv[k]));                     // Hpre
             spk[k] = nn[k] == hp[k] ? 0 : uu[k] == hp[k] ? 1 : 2;        // which of match / E1 / E2 gives it (the oracle's priority)
-            a1[k] = inb[k] ? hp[k] + cle1 + (je1 + k * e1) : LCD_GUARD; a2[k] = inb[k] ? hp[k] + cle2 + (je2 + k * e2) : LCD_GUARD;
+            a1[k] = inb[k] ? hp[k] + bcle1 + k * e1 : LCD_GUARD; a2[k] = inb[k] ? hp[k] + bcle2 + k * e2 : LCD_GUARD; // (window-relative and biased, like the plain rows': one set of lane constants)
             p1[k] = k ? imax(p1[k - 1], a1[k]) : a1[k]; p2[k] = k ? imax(p2[k - 1], a2[k]) : a2[k];
         }
         int t1 = p1[C - 1], t2 = p2[C - 1];
@@ -2090,7 +2343,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
 #pragma unroll
         for (int k = 0; k < C; ++k) {
             const int pf1 = k ? imax(x1, p1[k - 1]) : x1, pf2 = k ? imax(x2, p2[k - 1]) : x2;
-            const int f1 = imax(LCD_NEG, pf1 + ncle1 - (o1 + je1 + k * e1)), f2 = imax(LCD_NEG, pf2 + ncle2 - (o2 + je2 + k * e2));
+            const int f1 = imax(LCD_NEG, pf1 + nbcle1 - ((C == 1 ? 0 : o1) + k * e1)), f2 = imax(LCD_NEG, pf2 + nbcle2 - ((C == 1 ? 0 : o2) + k * e2));
             const int h = imax(hp[k], imax(f1, f2));
             const int eo1 = imax(imax(h - oe1, uu[k] - e1), LCD_NEG), eo2 = imax(imax(h - oe2, vv[k] - e2), LCD_NEG);
             const int fk = f1 == h ? (f2 == h ? 5 : 3) : 4;
@@ -2120,14 +2373,14 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
             else { ml = begc + C * fl + LCD_RL(bl, fl); mr = begc + C * ll + LCD_RL(brr, ll); }
         }
         // ---- stores: ring slot (values), HBM (codes; values only for rows a far successor / the end node will read) ----
-        const int cw4 = ((end - begc) + CP) & ~(CP - 1); // cells of this row in HBM, padded to a multiple of 4 (rows stay dword-aligned for every C)
+        const int cw4 = ((end - begc - lo_g) + CP) & ~(CP - 1); // cells of this row in HBM, padded to a multiple of 4 (rows stay dword-aligned for every C)
         if (cused + (unsigned)cw4 > code_cap || (np > 1 && oused + (unsigned)cw4 > ord_cap) || (spf && nsp >= spill_rows)) { wo->status = LCD_ERR_CELLS; return 0; }
         {
             const int x = jb & WM;
             ring_st3(ring + RB * (unsigned)(s * SLOTW), x, pvh, pva, pvb);
             if (spf) { int *G = g.spill + (size_t)nsp * SLOTW; glb_stc<C>(G + x, pvh); glb_stc<C>(G + WIN + x, pva); glb_stc<C>(G + 2 * WIN + x, pvb); }
-            if (cl < cw4) {
-                uint8_t *cp = g.code8 + (size_t)(cused + (unsigned)cl);
+            if (C == 1 ? inb[0] : cl < cw4) {
+                uint8_t *cp = g.code8 + (size_t)(cused + (unsigned)(cl - lo_g));
                 if constexpr (C == 8) *(__attribute__((address_space(1))) unsigned long long *)cp = code;
                 else if constexpr (C == 4) glb_st(cp, (int)code);
                 else if constexpr (C == 2) *(__attribute__((address_space(1))) unsigned short *)cp = (unsigned short)code;
@@ -2136,7 +2389,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                     int ow[C];
 #pragma unroll
                     for (int k = 0; k < C; ++k) ow[k] = (int)((om >> (8 * k)) & 255) | ((int)((oa >> (8 * k)) & 255) << 8) | ((int)((ob >> (8 * k)) & 255) << 16);
-                    glb_stc<C>(g.ord + (size_t)(oused + (unsigned)cl), ow);
+                    glb_stc<C>(g.ord + (size_t)(oused + (unsigned)(cl - lo_g)), ow);
                 }
             }
         }
@@ -2151,11 +2404,17 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
         cused += (unsigned)cw4; if (np > 1) oused += (unsigned)cw4; if (spf) ++nsp;
         ncell += (unsigned long long)(end - beg + 1);
         } while (0);
+#ifdef LCD_X_ROWSTAT
+        ++n_gn_;
+#endif
         ++idx;
     }
     flush_meta(wbase, ei - wbase);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     wo->cells = ncell;
+#ifdef LCD_X_ROWSTAT
+    wo->t_setup = (unsigned long long)n_pl_ | ((unsigned long long)n_gn_ << 24) | ((unsigned long long)(C >= 4 ? n_gn_ + n_pl_ : 0u) << 44);
+#endif
     const long long t_bt0 = clock64();
     wo->t_dp = (unsigned long long)(t_bt0 - t_dp0);
     code_backtrack(g, sm, pd, bi, ei, qlen, SLOTW, WM, lane, CM);
@@ -4298,8 +4557,17 @@ __device__ __attribute__((noinline)) void chain_output(Ctx &g, Smem &sm, const P
 
 } // namespace
 
+// Register budget per class (second launch-bound argument = wavefronts per SIMD the kernel must allow: 4 -> 128 VGPRs, 3 -> 168, 2 -> 256).  LCD_MINW64 / LCD_MINW256
+// are build-time switches (Makefile); the per-read phase functions are instantiated per NT and inherit their kernel's budget.
+#ifndef LCD_MINW64
+#define LCD_MINW64 4
+#endif
+#ifndef LCD_MINW256
+#define LCD_MINW256 4
+#endif
+#define LCD_MINW(NT) ((NT) == 64 ? LCD_MINW64 : (NT) == 256 ? LCD_MINW256 : 4)
 template <int NT>
-__global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool,
+__global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const PoaChain *chains, const PoaRead *reads, const uint8_t *pool,
                                                            uint8_t *arena, uint8_t *outpool, PoaChainOut *outs, LcdScoring sc,
                                                            int n_chains, int *gate, PoaSpare *spare) {
     const int cid = blockIdx.x;
@@ -4383,7 +4651,12 @@ __global__ void __launch_bounds__(NT, 4) lcd_poa_chain_kernel(const PoaChain *ch
     g.tb = (int *)(ws + L.tb); g.cert = (int *)(ws + L.cert); g.cert_on = ch.cert == 2 ? 2 : NT <= 256 ? ch.cert : 0; g.cert_hist = -1; g.alg_adjust = 0; g.cert_generic = 0; g.cert_generic_seen = 0; g.cert_sest = 0; g.cert_ubtop = 0; g.cert_bztop = 0; g.cert_cells0 = 0;
     g.node_cap = ch.node_cap; g.edge_cap = ch.edge_cap; g.rid_words = ch.rid_words; g.cell_cap = ch.cell_cap;
     g.spill_x = ch.spill_x < 2 ? 2 : ch.spill_x; g.wmax = ch.wmax; g.pool_words = ch.lds_words; g.seq_cap = (ch.lds_words - ring_words) * 4; g.ring16 = ring16; g.ring_k = ring_k; g.plan_k = (NT == 64 || ch.solo) && ring_k > 2 && ch.wmax < 256 ? 2 : ring_k; // (slots beyond 2 of a chain laid out for a narrow window: not there when a read needs a wider one)
-    g.wd_deadline = (unsigned long long)clock64() + (unsigned long long)(sc.wd_s > 0 ? sc.wd_s : 30) * 2400000000ull; // (~2.4 GHz shader clock: the bound is about seconds, not exact)
+    {   // deadline = a floor (LcdScoring.wd_s, 30 s) + the chain's own work at a rate far below the slowest class on a crowded chip (5e7 cells/s; the generic rows
+        // alone on a CU run 2.4e8): a legitimately long chain -- ultra-long noisy reads, 60x depth, unbanded K2 rows over a graph twice the read -- is not a hang
+        const unsigned long long width = ch.mode ? 2ull * (unsigned long long)(ch.max_len > 0 ? ch.max_len : 1) : 1024ull;
+        const unsigned long long work_s = (unsigned long long)(ch.n_reads > 0 ? ch.n_reads : 1) * (unsigned long long)(ch.max_len > 0 ? ch.max_len : 1) * width / 50000000ull;
+        g.wd_deadline = (unsigned long long)clock64() + ((unsigned long long)(sc.wd_s > 0 ? sc.wd_s : 30) + work_s) * 2400000000ull; // (~2.4 GHz shader clock: the bound is about seconds, not exact)
+    }
     g.mm_valid = 0; g.topo_mode = (sc.dbg >> 6) & 7; g.solo = NT == 256 ? ch.solo : 0; g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0; g.t_bp = 0; g.t_setup = 0;
     // The long chains are the latency of a submission at every depth, and next to 8 - 12 other wavefronts of their CU each of theirs issues when the arbiter gets round
     // to it: highest wavefront priority for them (the others fill the slots their dependency stalls leave).  LCD_DBG bit 512: off
