@@ -28,6 +28,37 @@ def lcd():
     return align
 
 
+def _oracle_chunk(a):
+    """one worker of oracle_many: a slice of a seeded workload through the oracle (spawned process: no HIP state is inherited)"""
+    seed, n, shape_name, lo, hi = a
+    from longcalld_amd import jobs
+    from oracle import pyoracle
+    regs = jobs.make_regions(seed, n, jobs.SHAPES[shape_name])
+    return [pyoracle.collect_noisy_reg_aln_strs(regs[i]) for i in range(lo, hi)]
+
+
+def oracle_many(seed, n, shape_name, workers=0):
+    """the oracle's result for every region of jobs.make_regions(seed, n, shape) on all host cores: full-size batches of the noisy-read shapes take minutes on one
+    core (a 10 kb SV region alone ~10 s).  Regions are dealt out in strides of 8 so that the expensive ones spread over the workers"""
+    import multiprocessing as mp
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:  # noqa
+        cores = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cores = max(1, min(cores, -(-int(q) // int(per))))
+    except Exception:  # noqa
+        pass
+    w = workers or max(1, min(cores, 16))
+    step = 8
+    tasks = [(seed, n, shape_name, lo, min(n, lo + step)) for lo in range(0, n, step)]
+    with mp.get_context("spawn").Pool(w) as pool:
+        parts = pool.map(_oracle_chunk, tasks, chunksize=1)
+    return [e for part in parts for e in part]
+
+
 def mutate(rng, s, rate, sv=0.0):
     out, i = [], 0
     while i < len(s):

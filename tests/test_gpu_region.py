@@ -331,6 +331,46 @@ def test_ont_batch_at_scale_equals_oracle(lcd, oracle):
         assert st["n_regions_resolved"] == sum(e["n_cons"] > 0 for e in exp)
 
 
+def test_full_ont_batch_equals_oracle(lcd):
+    """ONE FULL configs[2] batch -- the 1 250 regions of a 10 Mb step of 5 %-error reads, exactly what bench.py --shape ont submits per
+    step -- region by region == oracle (sorted read order, clusters, every alignment string and coordinate).  This is where the retry / spill / overflow
+    paths live (capacities start from the clean-read estimates; the first run meets the overflow rounds), so the batch is run twice.  The oracle runs on all
+    host cores (conftest.oracle_many: ~5 CPU-minutes)."""
+    from conftest import oracle_many
+    from longcalld_amd import jobs
+    n = jobs.regions_for_ref_mb(10.0)
+    assert n == 1250
+    regs = jobs.make_regions(3100, n, jobs.ONT)
+    exp = oracle_many(3100, n, "ont")
+    o = lcd.default_opt(); o.is_ont = 1
+    for attempt in range(2):
+        got, ids, st, _ = _run_batch(lcd, regs, o)
+        for k, (e, g, sid) in enumerate(zip(exp, got, ids)):
+            assert (sid == e["sorted_ids"]).all(), k
+            same_result(e, g)
+        assert st["n_regions"] == n and st["n_regions_resolved"] == sum(e["n_cons"] > 0 for e in exp)
+
+
+def test_ont_certified_band_ring16_on_off_equals_oracle(lcd, oracle, monkeypatch):
+    """noisy K2 chains through the certified band (LCD_CERT=2: off by default for noisy reads) with the 16-bit LDS ring on (forced), at its
+    default and off -- 120 ONT-shape regions, all three == oracle"""
+    from longcalld_amd import jobs
+    regs = jobs.make_regions(3200, 120, jobs.ONT)
+    exp = [oracle.collect_noisy_reg_aln_strs(r) for r in regs]
+    o = lcd.default_opt(); o.is_ont = 1
+    monkeypatch.setenv("LCD_CERT", "2")
+    dgs = []
+    for r16 in ("2", None, "0"):
+        if r16 is None: monkeypatch.delenv("LCD_RING16", raising=False)
+        else: monkeypatch.setenv("LCD_RING16", r16)
+        got, ids, st, dg = _run_batch(lcd, regs, o)
+        for e, g, sid in zip(exp, got, ids):
+            assert (sid == e["sorted_ids"]).all()
+            same_result(e, g)
+        dgs.append(dg)
+    assert dgs[0] == dgs[1] == dgs[2]
+
+
 def test_concurrent_callers(lcd):
     """SURVEY 8b threading: kt_for workers call into the library concurrently, each on its own chunk; four host threads with their own batches
     (ctypes releases the GIL during the calls) get the digests of the same batches run one after the other"""

@@ -58,6 +58,24 @@ def test_sv_sampling_region_matches_oracle(lcd, oracle):
     assert check_invariants(reg, got[0]) > 0
 
 
+def test_sv_batch_equals_oracle(lcd, monkeypatch):
+    """the configs[4]-shaped batch below (125 regions of a 1 Mb slice: 10 SV regions of 1 - 10 kb among 60x noisy-read regions), EVERY region ==
+    oracle -- read order, clusters, every alignment string -- and the digest the same with the 16-bit LDS ring forced / off (item 2c: the SV shape is where int16
+    values of a sub-graph alignment leave their range).  The oracle runs on all host cores (conftest.oracle_many)."""
+    from conftest import oracle_many
+    from longcalld_amd import jobs
+    regs = jobs.make_regions(777, 125, jobs.SV)
+    exp = oracle_many(777, 125, "sv")
+    got, ids, st, dg = _run(lcd, regs, _opt(lcd))
+    for k, (e, g, sid) in enumerate(zip(exp, got, ids)):
+        assert (sid == e["sorted_ids"]).all(), k
+        same_result(e, g)
+    assert st["n_regions_resolved"] == sum(e["n_cons"] > 0 for e in exp) and sum("sv" in r for r in regs) == 10
+    for r16 in ("2", "0"):
+        monkeypatch.setenv("LCD_RING16", r16)
+        assert _run(lcd, regs, _opt(lcd))[3] == dg
+
+
 def test_sv_batch_properties_and_digest(lcd):
     """a configs[4]-shaped batch (125 regions of a 1 Mb slice: 10 SV regions up to 10 kb among 60x noisy-read regions): invariants on every region
     (clusters partition the reads, every row de-gaps to its read / consensus / reference), the SV consensus carries the SV, and the digest does not

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 CMD1="python bench.py --steps 1 --warmup 0 --lanes 1 --coalesce 1 --cpu-sample 0 $*"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM -d gpurun_out/pmc_stall_$tag -o s -- $CMD1 > gpurun_out/pmc_stall_$tag.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM -d gpurun_out/pmc_stall_$tag -o s -- $CMD1 > gpurun_out/pmc_stall_$tag.log 2>&1
 tail -2 gpurun_out/pmc_stall_$tag.log
 python - <<PY
 import sqlite3, glob, collections
