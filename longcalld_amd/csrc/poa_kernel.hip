@@ -4670,6 +4670,9 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
         }
     __syncthreads();
     unsigned long long cells = 0, aligned_bases = 0;
+#ifdef LCD_X_ROWSTAT
+    unsigned long long chg_stat_ = 0;
+#endif
     int n_aligned_reads = 0;
     const int n_seq = ch.n_reads;
     const PoaRead *rd = reads + ch.read0;
@@ -4708,6 +4711,9 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
         int changed = 0;
         if (len > 0 && g.status == LCD_OK) changed = add_alignment_block<NT>(g, sm, exc_beg, exc_end, seq, len, n_cig, i);
         t_add += (unsigned long long)(clock64() - tg0);
+#ifdef LCD_X_ROWSTAT
+        if (len > 0) { chg_stat_ += changed == 2 ? 1ull : changed == 1 ? (1ull << 16) : changed == 3 ? (1ull << 32) : 0ull; chg_stat_ += 1ull << 48; }
+#endif
         if (changed == 1 || changed == 2) g.plan_valid = 0; // (3: weights only, every heaviest out-edge the same -- order, remain and the plan's structure stand; its bonuses were patched)
         if (changed == 2 && g.status == LCD_OK) topo_sort_block<NT>(g, sm, lds_pool, ch.mode == 0);
         else if (changed == 1 && g.status == LCD_OK) topo_remain_block<NT>(g, sm, lds_pool);
@@ -4726,6 +4732,9 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
         out.rt_begin = rt_begin; out.rt_end = __builtin_amdgcn_s_memrealtime();
         out.t_out = (unsigned long long)(t_end - t_out0);
         out.t_bp = g.t_bp; out.t_add = t_add; out.t_sort = t_graph - t_add; out.t_setup = g.t_setup;
+#ifdef LCD_X_ROWSTAT
+        out.t_bt = chg_stat_;
+#endif
         if (g.status == LCD_ERR_WATCHDOG) { out.t_plan = sm.prof[0]; out.t_poll = sm.prof[1]; out.t_bp = sm.prof[2]; out.t_add = sm.prof[3]; } // (the backtrack's last states, if that is where it was)
         outs[cid] = out;
     }
