@@ -115,15 +115,16 @@ struct DevBuf {
         dev = cur_device();
         const long long budget = dev_budget(dev);
         size_t want = n + (n >> headroom_shift) + 256; // (headroom: the buffers only grow, a slightly larger next batch does not reallocate)
-        if (g_dev_bytes[dev].load() + (long long)want > budget) want = n + 256;
-        if (g_dev_bytes[dev].load() + (long long)want > budget)
-            return set_err(-11, "device memory budget: " + std::to_string(want) + " more bytes on top of " + std::to_string(g_dev_bytes[dev].load()));
+        // the budget is RESERVED before the allocation (compare-exchange): the submission's helper threads grow buffers beside the calling thread
+        auto reserve = [&](const size_t bytes) { long long cur = g_dev_bytes[dev].load(); while (cur + (long long)bytes <= budget) if (g_dev_bytes[dev].compare_exchange_weak(cur, cur + (long long)bytes)) return true; return false; };
+        if (!reserve(want)) { want = n + 256; if (!reserve(want)) return set_err(-11, "device memory budget: " + std::to_string(want) + " more bytes on top of " + std::to_string(g_dev_bytes[dev].load())); }
         if (hipMalloc(&p, want) != hipSuccess) {
             (void)hipGetLastError(); // out-of-memory is not sticky, but the "last error" slot is read after every launch
+            g_dev_bytes[dev] -= (long long)want;
             p = nullptr; cap = 0; return set_err(-11, "hipMalloc failed for " + std::to_string(want) + " bytes");
         }
-        if (getenv("LCD_ALLOC_DEBUG")) fprintf(stderr, "[alloc] %zu bytes asked, %zu allocated (device %d now %.2f GB)\n", n, want, dev, (g_dev_bytes[dev].load() + (long long)want) / 1e9);
-        cap = want; g_dev_bytes[dev] += (long long)cap; ++g_alloc_events; return 0;
+        if (getenv("LCD_ALLOC_DEBUG")) fprintf(stderr, "[alloc] %zu bytes asked, %zu allocated (device %d now %.2f GB)\n", n, want, dev, g_dev_bytes[dev].load() / 1e9);
+        cap = want; ++g_alloc_events; return 0;
     }
     void release() { if (p) { hipFree(p); g_dev_bytes[dev] -= (long long)cap; p = nullptr; cap = 0; } }
     uint64_t addr() const { return (uint64_t)(uintptr_t)p; }
@@ -1411,11 +1412,12 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     const bool prep_async = !getenv("LCD_NO_PREP_THREAD");
     const bool order_async = nC_all >= 2048 && prep_async;
     int prep_rc = 0;
+    std::string prep_err; // (g_err is per thread: a helper's message is carried over to the calling thread at the join)
     if (prep_async) {
         const int dev_here = cur_device();
-        order_thread.t = std::thread([&, dev_here]() { if (hipSetDevice(dev_here) != hipSuccess) { prep_rc = -1; return; } prep_rc = prep_chains(); if (!prep_rc && order_async) prepare_round0(); });
+        order_thread.t = std::thread([&, dev_here]() { if (hipSetDevice(dev_here) != hipSuccess) { prep_rc = -1; prep_err = "hipSetDevice failed on the preparation thread"; return; } prep_rc = prep_chains(); if (!prep_rc && order_async) prepare_round0(); if (prep_rc) prep_err = g_err; });
     } else { const int rc0 = prep_chains(); if (rc0) return rc0; }
-    auto join_prep = [&]() -> int { if (order_thread.t.joinable()) order_thread.t.join(); return prep_rc; };
+    auto join_prep = [&]() -> int { if (order_thread.t.joinable()) order_thread.t.join(); if (prep_rc && !prep_err.empty()) g_err = prep_err; return prep_rc; };
     // ---------------- S1: anchors (K4 prefilter + K3b) ----------------
     {
         std::vector<EdJob> ej; std::vector<WfaJob> wj;
@@ -1823,6 +1825,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
     };
     const bool strings_beside = L->side[3] && !getenv("LCD_STRINGS_SEQ");
     int strings_rc = 0;
+    std::string strings_err;
     Joiner strings_thread;
     if (strings_beside) {
         HIPCHK(hipStreamWaitEvent(L->side[3], L->ev[3], 0));
@@ -1830,6 +1833,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         strings_thread.t = std::thread([&, dev_here]() {
             if (hipSetDevice(dev_here) != hipSuccess) { strings_rc = -1; return; }
             strings_rc = strings_stage(L->side[3]);
+            if (strings_rc) strings_err = g_err;
             if (!strings_rc && hipStreamSynchronize(L->side[3]) != hipSuccess) strings_rc = -1;
         });
     }
@@ -1847,7 +1851,7 @@ static int run_many_once(lcd_batch_t **bs, int nb) {
         }
     }
     HIPCHK(hipEventRecord(L->ev[4], st));
-    if (strings_beside) { if (strings_thread.t.joinable()) strings_thread.t.join(); if (strings_rc) return strings_rc == -11 ? -11 : set_err(-20, "strings stage failed on its side stream"); }
+    if (strings_beside) { if (strings_thread.t.joinable()) strings_thread.t.join(); if (strings_rc) return strings_rc == -11 ? set_err(-11, strings_err.empty() ? "device memory budget (strings stage)" : strings_err) : set_err(-20, "strings stage failed on its side stream" + (strings_err.empty() ? std::string() : ": " + strings_err)); }
     else { const int rcs = strings_stage(st); if (rcs) return rcs; }
     HIPCHK(hipEventRecord(L->ev[5], st));
     HIPCHK(hipStreamSynchronize(st));
