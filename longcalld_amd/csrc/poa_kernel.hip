@@ -1756,7 +1756,10 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     unsigned lutb[4];
     for (int v = 0; v < 4; ++v) { unsigned w_ = 32u << 24; for (int q = 0; q < 4; ++q) w_ |= (unsigned)(32 + (q == v ? s_match : s_mism)) << (6 * q); lutb[v] = usgpr(w_); }
     lut4 = usgpr(lut4);
-    auto lut_of = [&](const int vb) -> unsigned { return vb == 0 ? lutb[0] : vb == 1 ? lutb[1] : vb == 2 ? lutb[2] : vb == 3 ? lutb[3] : lut4; };
+    // (the five words sit in lanes 0 - 4 of one register and a row takes its own by v_readlane: as a select chain on the scalar side the choice was three branches per row)
+    int lutv = (int)lut4;
+    for (int v = 0; v < 4; ++v) lutv = lean_wlane((int)lutb[v], v, lutv);
+    auto lut_of = [&](const int vb) -> unsigned { return (unsigned)LCD_RL(lutv, smin(vb, 4)); };
     const int QB = (qlen + 12 + 15) & ~15;
     const bool r16 = FIXED && usgpr(g.ring16) != 0; // (16-bit ring values: lds_stc16 / lds_ldc16)
     const unsigned RB = r16 ? 2u : 4u;
@@ -1902,6 +1905,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
             // (the run's loop-carried scalars are locals initialised through readfirstlane: as phis of the outer loop the compiler keeps them in VGPRs)
             int l_begc = usgpr(pv_begc), l_beg = usgpr(pv_beg), l_end = usgpr(pv_end), l_ml = usgpr(pv_ml), l_mr = usgpr(pv_mr);
             int pend = 0; // the last row of the run has not been stored to its ring slot
+            unsigned l_cused = usgpr(cused); // (as a phi of the outer loop the code offset sat in a vector register, and the capacity test was a 64-bit vector compare)
             if constexpr (C == 1) {
                 int q_c1 = lds_ld_u8((unsigned)lane + (sq1 + (unsigned)l_begc)), q_n1 = lds_ld_u8((unsigned)lane + (sq1 + (unsigned)(l_begc + 1))); // query bytes (x 6) of the lanes' columns in the window at hand / one column on
                 // ---- one cell per lane: lanes follow the DIAGONAL.  The window moves one column per row whatever the band does, so the cell's diagonal neighbour
@@ -1922,7 +1926,9 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                     const int wb = l_begc + adv;        // this row's window: lane = column - wb
                     const int lo = beg - wb, span = end - beg;
                     const int cw4 = (span + CP) & ~(CP - 1);
-                    if (beg > end || beg < l_begc || end - wb + 2 > WIN || cused + (unsigned)cw4 > code_cap) break; // (beg < l_begc: an interval of MODE 2 that starts left of the window)
+                    // (one test: each of the four quantities is negative exactly when its condition fails -- empty band; an interval of MODE 2 that starts left of the
+                    //  window; band past the window's last lane; code capacity, which is below 2^32 - 16 so the difference fits a signed compare after the shift)
+                    if (((end - beg) | (beg - l_begc) | (WIN - 2 - (end - wb)) | (l_cused + (unsigned)cw4 > code_cap ? -1 : 0)) < 0) break;
                     const int vb = (pk >> 8) & 7, bz0 = (pk >> 14) & 31;
                     const int s = (idx - bi) & KM;
                     const unsigned lut = lut_of(vb);
@@ -1983,10 +1989,10 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                         m_be = lean_wlane(be, s, m_be); m_mm = lean_wlane(ml | (mr << 16), s, m_mm);
                         pend = 0;
                     } else pend = 1;
-                    if (inb) *(__attribute__((address_space(1))) uint8_t *)(g.code8 + (size_t)(cused + (unsigned)(lane - lo))) = (uint8_t)code;
-                    r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)cused, wk, r_off);
+                    if (inb) *(__attribute__((address_space(1))) uint8_t *)(g.code8 + (size_t)(l_cused + (unsigned)(lane - lo))) = (uint8_t)code;
+                    r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)l_cused, wk, r_off);
                     l_begc = wb; l_beg = beg; l_end = end; l_ml = ml; l_mr = mr;
-                    cused += (unsigned)cw4; run_cells += (unsigned)(span + 1);
+                    l_cused += (unsigned)cw4; run_cells += (unsigned)(span + 1);
                     ++idx; ++wk;
                 }
             } else if constexpr (C >= 8) {
@@ -2008,7 +2014,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                     const int begc = beg & CM;
                     const int sh = begc - l_begc;
                     const int cw4 = ((end - begc) + CP) & ~(CP - 1);
-                    if (beg > end || end - begc + 2 > WIN || (unsigned)sh > (unsigned)C || cused + (unsigned)cw4 > code_cap) break;
+                    if (((end - beg) | (WIN - 2 - (end - begc)) | ((unsigned)sh > (unsigned)C ? -1 : 0) | (l_cused + (unsigned)cw4 > code_cap ? -1 : 0)) < 0) break; // (one test, as above)
                     const int vb = (pk >> 8) & 7, bz0 = (pk >> 14) & 31;
                     const int s = (idx - bi) & KM;
                     const int mt = vb >= 4 ? 0 : s_match, mm = vb >= 4 ? 0 : s_mism;
@@ -2081,7 +2087,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                         const int x = (begc + cl) & WM;
                         ring_st3(ring + RB * (unsigned)(s * SLOTW), x, pvh, pva, pvb);
                         if (cl < cw4) {
-                            uint8_t *cp = g.code8 + (size_t)(cused + (unsigned)cl);
+                            uint8_t *cp = g.code8 + (size_t)(l_cused + (unsigned)cl);
                             if constexpr (C == 8) *(__attribute__((address_space(1))) unsigned long long *)cp = code;
                             else if constexpr (C == 4) glb_st(cp, (int)code);
                             else if constexpr (C == 2) *(__attribute__((address_space(1))) unsigned short *)cp = (unsigned short)code;
@@ -2089,10 +2095,10 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                         }
                     }
                     const int be = beg | (end << 16);
-                    r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)cused, wk, r_off);
+                    r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)l_cused, wk, r_off);
                     m_be = lean_wlane(be, s, m_be); m_mm = lean_wlane(ml | (mr << 16), s, m_mm);
                     l_begc = begc; l_beg = beg; l_end = end; l_ml = ml; l_mr = mr;
-                    cused += (unsigned)cw4; run_cells += (unsigned)(span + 1);
+                    l_cused += (unsigned)cw4; run_cells += (unsigned)(span + 1);
                     ++idx; ++wk;
                 }
             } else {
@@ -2110,7 +2116,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                     const int begc = beg & CM;
                     const int sh = begc - l_begc;
                     const int cw4 = ((end - begc) + CP) & ~(CP - 1);
-                    if (beg > end || end - begc + 2 > WIN || (unsigned)sh > (unsigned)C || cused + (unsigned)cw4 > code_cap) break;
+                    if (((end - beg) | (WIN - 2 - (end - begc)) | ((unsigned)sh > (unsigned)C ? -1 : 0) | (l_cused + (unsigned)cw4 > code_cap ? -1 : 0)) < 0) break; // (one test, as above)
                     const int vb = (pk >> 8) & 7, bz0 = (pk >> 14) & 31;
                     const int s = (idx - bi) & KM;
                     const unsigned lut = lut_of(vb);
@@ -2192,14 +2198,14 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                         pend = 0;
                     } else pend = 1;
                     if (cl < cw4) {
-                        uint8_t *cp = g.code8 + (size_t)(cused + (unsigned)cl);
+                        uint8_t *cp = g.code8 + (size_t)(l_cused + (unsigned)cl);
                         if constexpr (C == 8) *(__attribute__((address_space(1))) unsigned long long *)cp = code;
                         else if constexpr (C == 4) glb_st(cp, (int)code);
                         else *(__attribute__((address_space(1))) unsigned short *)cp = (unsigned short)code;
                     }
-                    r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)cused, wk, r_off);
+                    r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)l_cused, wk, r_off);
                     l_begc = begc; l_beg = beg; l_end = end; l_ml = ml; l_mr = mr;
-                    cused += (unsigned)cw4; run_cells += (unsigned)(span + 1);
+                    l_cused += (unsigned)cw4; run_cells += (unsigned)(span + 1);
                     ++idx; ++wk;
                 }
             }
@@ -2208,7 +2214,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                 ring_st3(ring + RB * (unsigned)(sl * SLOTW), (l_begc + cl) & WM, pvh, pva, pvb);
                 m_be = lean_wlane(l_beg | (l_end << 16), sl, m_be); m_mm = lean_wlane(l_ml | (l_mr << 16), sl, m_mm);
             }
-            pv_begc = l_begc; pv_beg = l_beg; pv_end = l_end; pv_ml = l_ml; pv_mr = l_mr;
+            pv_begc = l_begc; pv_beg = l_beg; pv_end = l_end; pv_ml = l_ml; pv_mr = l_mr; cused = l_cused;
 #ifdef LCD_X_ROWSTAT
             n_pl_ += (unsigned)(idx - idx0_);
 #endif
