@@ -280,6 +280,60 @@ def test_poa_k2_matches_oracle(lcd, oracle, L, rate):
             assert (a == b).all()
 
 
+@pytest.mark.parametrize("match,mismatch", [(2, 6), (31, 32), (40, 50), (1, 33)])
+def test_poa_scores_outside_the_lean_rows_score_fields(lcd, oracle, match, mismatch):
+    """round 5: the lean rows take a cell's substitution score from a 6-bit field of a per-row scalar word (match and -mismatch in [-32, 31]); scoring outside that
+    range makes them decline the read (poa_kernel.hip align_lean "6-bit field") and the windowed / generic rows take it.  K1 and K2 (certified band and full rows) ==
+    oracle with the same scoring, at the range's edge and beyond it"""
+    from longcalld_amd import align
+    from oracle import pyoracle
+    opt, oopt = align.default_opt(), pyoracle.default_opt()
+    opt.match = oopt.match = match; opt.mismatch = oopt.mismatch = mismatch
+    rng = np.random.default_rng(9100 + match)
+    k1 = _poa_chains(rng, 3, 300, 0.01, 9, False)
+    got = lcd.poa_batch([dict(mode=0, reads=r) for r in k1], opt)
+    for reads, g in zip(k1, got):
+        exp = oracle.poa_partial_aln_msa_cons(reads, [12] * len(reads), oopt)
+        assert g["status"] == 0 and g["n_cons"] == exp["n_cons"] == 1 and g["msa_len"] == exp["msa_len"]
+        for a, b in zip(g["msa"], exp["msa"]):
+            assert (a == b).all()
+    k2 = _poa_chains(rng, 3, 300, 0.004, 12, True)
+    got = lcd.poa_batch([dict(mode=1, reads=r) for r in k2], opt)
+    for reads, g in zip(k2, got):
+        _check_k2(g, oracle.poa_aln_msa_cons(reads, 2, oopt))
+
+
+def test_poa_lean_rows_window_that_stays_jumps_and_restarts(lcd, oracle):
+    """round 5, one cell per lane: the lanes follow the diagonal and the window either moves one column per row or stays (poa_kernel.hip align_lean, "lanes follow the
+    DIAGONAL").  Reads with deletions of 1 - 30 bases against the backbone (the band's first column stalls: the window stays), insertions (it jumps: lanes idle on the
+    left until a general row re-anchors), both at the very start and end of the read, homopolymer runs, and reads with N bases (score 0 against everything: the
+    fifth score field) -- K1 with the adaptive band and K2 with certified intervals and with full rows, all == oracle"""
+    rng = np.random.default_rng(9200)
+    truth = rng.integers(0, 4, 420).astype(np.uint8)
+    truth[200:230] = truth[200]                                    # a homopolymer run: ties between gap placements
+    def edit(r, dels=(), ins=()):
+        out, i = [], 0
+        dels = dict(dels); ins = dict(ins)
+        while i < len(r):
+            if i in ins: out.extend(rng.integers(0, 4, ins[i]))
+            if i in dels: i += dels[i]; continue
+            out.append(r[i]); i += 1
+        return np.array(out, np.uint8)
+    reads = [truth.copy(), edit(truth, dels={0: 7}), edit(truth, dels={50: 1, 120: 30, 300: 12}), edit(truth, ins={0: 9, 210: 25}), edit(truth, ins={60: 14}, dels={400: 15}),
+             edit(truth, dels={205: 9}), edit(truth, ins={419: 11}), mutate(rng, truth, 0.02), mutate(rng, truth, 0.02), edit(truth, dels={10: 3, 20: 3, 30: 3, 40: 3, 50: 3, 60: 3})]
+    withn = [r.copy() for r in reads]
+    for r in withn[1::2]:
+        r[rng.integers(0, len(r), 6)] = 4
+    for rs in (reads, withn):
+        g = lcd.poa_batch([dict(mode=0, reads=rs)])[0]
+        exp = oracle.poa_partial_aln_msa_cons(rs, [12] * len(rs))
+        assert g["status"] == 0 and g["msa_len"] == exp["msa_len"]
+        for a, b in zip(g["msa"], exp["msa"]):
+            assert (a == b).all()
+    g2 = lcd.poa_batch([dict(mode=1, reads=reads)])[0]
+    _check_k2(g2, oracle.poa_aln_msa_cons(reads, 2))
+
+
 def test_poa_invariants_large(lcd):
     """size-independent properties on a region longer than the oracle is comfortable with: every MSA row de-gaps to its read,
     the consensus row de-gaps to the consensus, clusters partition the reads"""
