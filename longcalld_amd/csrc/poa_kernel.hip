@@ -1881,12 +1881,21 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     int bcle1 = cl * e1 + (1 << 29), bcle2 = cl * e2 + (1 << 29), nbcle1 = -bcle1 - (C == 1 ? o1 : 0), nbcle2 = -bcle2 - (C == 1 ? o2 : 0); // (the plain rows' biased gap prefixes)
     if constexpr (C <= 2) { LCD_PIN(bcle1); LCD_PIN(bcle2); LCD_PIN(nbcle1); LCD_PIN(nbcle2); } // (opaque: the compiler would re-derive them from cl * e and add the bias in an instruction of its own; the wider variants have no registers to spare for that)
     int idx = bi + 1;
+#ifdef LCD_X_PLANSTAT
+    unsigned long long t_plan_ = 0;
+#endif
 #ifdef LCD_X_ROWSTAT
     unsigned n_pl_ = 0, n_gn_ = 0;
 #endif
     while (idx < ei) {
         if (idx - wbase == 64) {
+#ifdef LCD_X_PLANSTAT
+            const long long tp0_ = clock64();
+#endif
             flush_meta(wbase, 64); wbase = idx; load_plan(wbase);
+#ifdef LCD_X_PLANSTAT
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_plan_ += (unsigned long long)(clock64() - tp0_);
+#endif
             if ((unsigned long long)clock64() > g.wd_deadline) { wo->status = LCD_ERR_WATCHDOG; return 0; }
         }
         int wk = idx - wbase;
@@ -2418,6 +2427,9 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     flush_meta(wbase, ei - wbase);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     wo->cells = ncell;
+#ifdef LCD_X_PLANSTAT
+    wo->t_plan = t_plan_;
+#endif
 #ifdef LCD_X_ROWSTAT
     wo->t_setup = (unsigned long long)n_pl_ | ((unsigned long long)n_gn_ << 24) | ((unsigned long long)(C >= 4 ? n_gn_ + n_pl_ : 0u) << 44);
 #endif
