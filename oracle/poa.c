@@ -705,6 +705,32 @@ int lcdo_poa_partial_aln_msa_cons(const lcdo_opt_t *opt, int sampling_reads, int
     return n_cons;
 }
 
+/* K1 with the anchors GIVEN (test infrastructure: a chain dumped by the library, LCD_DUMP_CHAIN, carries the anchors its anchor stage computed -- the loop is the one
+   above with collect_partial_aln_beg_end's results read from `anchors[4 * i]` = {ref_beg, ref_end, read_beg, read_end} and reads with skip[i] != 0 left out) */
+int lcdo_poa_partial_aln_msa_cons_anchored(const lcdo_opt_t *opt, int n_reads, uint8_t **read_seqs, const int *read_lens, const int *anchors, const int *skip,
+                                           lcdo_poa_result_t *res) {
+    lcdo_poa_t *g = poa_init(n_reads);
+    for (int i = 0; i < n_reads; ++i) {
+        int exc_beg = 0, exc_end = 1, beg_cut = 0, end_cut = 0;
+        if (skip && skip[i]) continue;
+        if (i != 0) {
+            const int ref_beg = anchors[4 * i], ref_end = anchors[4 * i + 1], read_beg = anchors[4 * i + 2], read_end = anchors[4 * i + 3];
+            beg_cut = read_beg - 1; end_cut = read_lens[i] - read_end;
+            subgraph_nodes(g, ref_beg + 1, ref_end + 1, &exc_beg, &exc_end);
+        }
+        const uint8_t *seq = read_seqs[i] + beg_cut; int len = read_lens[i] - beg_cut - end_cut;
+        gcig_t *cig = NULL; int n_cig = 0, sc = NEG;
+        if (g->n_node > 2) n_cig = align_to_subgraph(g, opt, 10, 0.01, exc_beg, exc_end, seq, len, &cig, &sc);
+        if (len > 0) add_alignment(g, exc_beg, exc_end, seq, len, cig, n_cig, i);
+        free(cig);
+    }
+    if (g->idx2node == NULL) topo_sort(g);
+    poa_output(g, opt, 1, res);
+    int n_cons = res->n_cons;
+    poa_free(g);
+    return n_cons;
+}
+
 /* K2: src/align.c:872-943 (abpoa_msa on all reads, unbanded, <= max_n_cons consensus) */
 int lcdo_poa_aln_msa_cons(const lcdo_opt_t *opt, int n_reads, uint8_t **read_seqs, const int *read_lens, int max_n_cons,
                           lcdo_poa_result_t *res) {

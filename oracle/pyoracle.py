@@ -290,6 +290,22 @@ def poa_partial_aln_msa_cons(reads, covers, opt=None, sampling=0):
     return _poa_unpack(res, n, nc)
 
 
+def poa_partial_aln_msa_cons_anchored(reads, anchors, skip=None, opt=None):
+    """K1 with given anchors [(ref_beg, ref_end, read_beg, read_end)] (a chain dumped by LCD_DUMP_CHAIN: tools/replay_chain.py --oracle)"""
+    opt = opt or default_opt()
+    reads = [_c8(r) for r in reads]
+    n = len(reads)
+    arr = (u8p * n)(*[_p(r) for r in reads])
+    lens = (C.c_int * n)(*[len(r) for r in reads])
+    an = (C.c_int * (4 * n))(*[int(x) for a in anchors for x in a])
+    sk = (C.c_int * n)(*[int(x) for x in (skip or [0] * n)])
+    res = PoaRes()
+    L = lib()
+    L.lcdo_poa_partial_aln_msa_cons_anchored.restype = C.c_int
+    nc = L.lcdo_poa_partial_aln_msa_cons_anchored(C.byref(opt), n, arr, lens, an, sk, C.byref(res))
+    return _poa_unpack(res, n, nc)
+
+
 def poa_cert_stats():
     """counters of oracle/poa.c's certified-band checker (run poa_aln_msa_cons with LCDO_CERT_STATS=1 in the environment first)"""
     L = lib()

@@ -593,8 +593,9 @@ def test_wider_window_after_a_ring_that_outgrew_the_pool_layout(tmp_path):
     for extra in ({}, {"LCD_RING_K_MAXLDS_KB": "16", "LCD_LDS_CAP_KB": "16"}):
         env = dict(os.environ, LCD_WATCHDOG_S="5", **extra)
         out = str(tmp_path / f"r{len(outs)}.json")
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "replay_chain.py"), fx, "--ont", "--json", out], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "replay_chain.py"), fx, "--ont", "--json", out, "--oracle"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout[-400:] + r.stderr[-400:]
         outs.append(json.load(open(out)))
     assert outs[0]["status"] == 0 and outs[0]["rows_degap_to_reads"]
+    assert outs[0]["equals_oracle"] and outs[1]["equals_oracle"]   # (against the oracle run with the dump's own anchors, not only layout against layout)
     assert outs[1] == outs[0]
