@@ -1853,9 +1853,6 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
         unsigned long long km = 0;
         for (int d = 1; d <= K; ++d) km |= (np_mask >> d) | (1ull << (64 - d));
         keep_mask = km;
-#ifdef LCD_X_KEEPALL
-        keep_mask = ~0ull;
-#endif
     };
     auto flush_meta = [&](const int base, const int n) { // rows base .. base + n - 1
         if (lane < n) { glb_st(g.rbeg + base + lane, r_be & 65535); glb_st(g.rend + base + lane, (int)((unsigned)r_be >> 16)); glb_st(g.roff + base + lane, r_off); }
@@ -1866,11 +1863,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     auto q_of = [&](const int b) {
         // (no clamp: columns past the cache belong to lanes past the read's end -- never inside a band, their cells are masked -- and an LDS read past the
         //  workgroup's allocation returns 0)
-#ifdef LCD_X_QCLAMP
-        const unsigned a = sq1 + (unsigned)imin(b + cl, QB - CP);
-#else
         const unsigned a = (unsigned)cl + (sq1 + (unsigned)b);
-#endif
         if constexpr (C == 1) return (word)*(const lcd_lds_u8 *)(uintptr_t)a;
         else if constexpr (C == 2) return (word)*(const __attribute__((address_space(3))) unsigned short *)(uintptr_t)a;
         else if constexpr (C == 4) return (word)(unsigned)lds_ld(a);
@@ -1881,6 +1874,8 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     int bcle1 = cl * e1 + (1 << 29), bcle2 = cl * e2 + (1 << 29), nbcle1 = -bcle1 - (C == 1 ? o1 : 0), nbcle2 = -bcle2 - (C == 1 ? o2 : 0); // (the plain rows' biased gap prefixes)
     if constexpr (C <= 2) { LCD_PIN(bcle1); LCD_PIN(bcle2); LCD_PIN(nbcle1); LCD_PIN(nbcle2); } // (opaque: the compiler would re-derive them from cl * e and add the bias in an instruction of its own; the wider variants have no registers to spare for that)
     int idx = bi + 1;
+    // (statistics builds, tools/ab_build.sh <name> -DLCD_X_ROWSTAT / -DLCD_X_PLANSTAT: plain / general row counts and the kinds of graph change per read through the
+    //  LCD_CHAIN_TIMES dump's t_setup / t_bt columns; ticks of the plan-window refreshes through t_plan.  Never defined in the product build.)
 #ifdef LCD_X_PLANSTAT
     unsigned long long t_plan_ = 0;
 #endif
