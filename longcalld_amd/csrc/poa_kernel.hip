@@ -1828,9 +1828,10 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
     wo->t_setup = (unsigned long long)(t_dp0 - t_in0);
     // plan window (lane = row - wbase) and the rows' metadata window
     int w_pk = 0, w_x = 0, w_pi0 = 0, w_pi1 = 0, w_p0 = 0; // w_x: remain (MODE 1) / interval (MODE 2)
-    int r_be = 1, r_off = 0;
+    int r_be = 1;
+    unsigned cused_w0 = 0; // code offset of the metadata window's first row: the rows' offsets are made from it and the rows' intervals when the window is flushed
     int wbase = bi + 1;
-    unsigned long long keep_mask = ~0ull, np_mask = ~0ull; // rows of the plan window that are NOT plain by their plan word (several / far / no predecessors, spilled, unreachable, past the end)
+    unsigned long long np_mask = ~0ull; // rows of the plan window that are NOT plain by their plan word (several / far / no predecessors, spilled, unreachable, past the end)
     // packed plan word: #preds (8 bits, 255 = more) | base << 8 | spill << 11 | unreachable << 12 | backbone << 13 | bonus0 << 14 | bonus1 << 19
     auto load_plan = [&](const int base) {
         const int ri = base + lane;
@@ -1852,10 +1853,15 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
         // rows whose ring slot a general row may read: one of the next K rows is not plain by its plan word (the last K rows of a window: always)
         unsigned long long km = 0;
         for (int d = 1; d <= K; ++d) km |= (np_mask >> d) | (1ull << (64 - d));
-        keep_mask = km;
+        w_pk |= (int)((km >> lane) & 1ull) << 24; // (bit 24 of the plan word: keep this row's ring slot)
     };
     auto flush_meta = [&](const int base, const int n) { // rows base .. base + n - 1
-        if (lane < n) { glb_st(g.rbeg + base + lane, r_be & 65535); glb_st(g.rend + base + lane, (int)((unsigned)r_be >> 16)); glb_st(g.roff + base + lane, r_off); }
+        // (a row's cells follow the previous row's in HBM, padded to a multiple of four: its offset is a prefix sum over the window's intervals -- one scan per 64 rows
+        //  instead of a lane write per row)
+        const int rb_ = r_be & 65535, re_ = (int)((unsigned)r_be >> 16);
+        const int cw_ = (lane < n && rb_ <= re_) ? (((re_ - (C == 1 ? rb_ : (rb_ & CM))) + CP) & ~(CP - 1)) : 0;
+        const int off_ = (int)cused_w0 + scan_add(cw_) - cw_;
+        if (lane < n) { glb_st(g.rbeg + base + lane, rb_); glb_st(g.rend + base + lane, re_); glb_st(g.roff + base + lane, off_); }
     };
     load_plan(wbase);
     // query bases of the lanes' cells for the window that starts at column b: sq1[b + cl + k], k < C, in the low bytes of one word
@@ -1887,7 +1893,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
 #ifdef LCD_X_PLANSTAT
             const long long tp0_ = clock64();
 #endif
-            flush_meta(wbase, 64); wbase = idx; load_plan(wbase);
+            flush_meta(wbase, 64); wbase = idx; cused_w0 = cused; load_plan(wbase);
 #ifdef LCD_X_PLANSTAT
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_plan_ += (unsigned long long)(clock64() - tp0_);
 #endif
@@ -1900,7 +1906,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
         // above it, or the cell is reached from its left), fillers stay a factor of two below LCD_NEG whatever a row adds to them, and the E values that go on to the
         // next row keep their floor (max3).  What differs from the clamped rows is the code of cells NO alignment reaches -- never read.
         // The ring slot (and its lane of slot metadata) is written only for rows a general row will look at: one of the next K rows is not plain by its plan word
-        // (keep_mask; a row that stops being plain at run time has one predecessor, the row before: flushed from the registers when the run ends).
+        // (bit 24 of the plan word; a row that stops being plain at run time has one predecessor, the row before: flushed from the registers when the run ends).
         if (pv_ok) {
 #ifdef LCD_X_ROWSTAT
             const int idx0_ = idx;
@@ -1932,7 +1938,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                     const int cw4 = (span + CP) & ~(CP - 1);
                     // (one test: each of the four quantities is negative exactly when its condition fails -- empty band; an interval of MODE 2 that starts left of the
                     //  window; band past the window's last lane; code capacity, which is below 2^32 - 16 so the difference fits a signed compare after the shift)
-                    if (((end - beg) | (beg - l_begc) | (WIN - 2 - (end - wb)) | (l_cused + (unsigned)cw4 > code_cap ? -1 : 0)) < 0) break;
+                    if (((end - beg) | (FIXED ? beg - l_begc : 0) | (WIN - 2 - (end - wb)) | (l_cused + (unsigned)cw4 > code_cap ? -1 : 0)) < 0) break; // (the adaptive band never starts left of the row before)
                     const int vb = (pk >> 8) & 7, bz0 = (pk >> 14) & 31;
                     const int s = (idx - bi) & KM;
                     const unsigned lut = lut_of(vb);
@@ -1988,13 +1994,13 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                     const unsigned code = (unsigned)hs | (fl << 3);
                     pvh[0] = inb ? h : LCD_GUARD; pva[0] = inb ? eo1 : LCD_GUARD; pvb[0] = inb ? eo2 : LCD_GUARD;
                     const int be = beg | (end << 16);
-                    if (((keep_mask >> wk) & 1ull) != 0ull) {
+                    if (pk & (1 << 24)) {
                         ring_st3(ring + RB * (unsigned)(s * SLOTW), (wb + lane) & WM, pvh, pva, pvb);
                         m_be = lean_wlane(be, s, m_be); m_mm = lean_wlane(ml | (mr << 16), s, m_mm);
                         pend = 0;
                     } else pend = 1;
                     if (inb) *(__attribute__((address_space(1))) uint8_t *)(g.code8 + (size_t)(l_cused + (unsigned)(lane - lo))) = (uint8_t)code;
-                    r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)l_cused, wk, r_off);
+                    r_be = lean_wlane(be, wk, r_be);
                     l_begc = wb; l_beg = beg; l_end = end; l_ml = ml; l_mr = mr;
                     l_cused += (unsigned)cw4; run_cells += (unsigned)(span + 1);
                     ++idx; ++wk;
@@ -2099,7 +2105,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                         }
                     }
                     const int be = beg | (end << 16);
-                    r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)l_cused, wk, r_off);
+                    r_be = lean_wlane(be, wk, r_be);
                     m_be = lean_wlane(be, s, m_be); m_mm = lean_wlane(ml | (mr << 16), s, m_mm);
                     l_begc = begc; l_beg = beg; l_end = end; l_ml = ml; l_mr = mr;
                     l_cused += (unsigned)cw4; run_cells += (unsigned)(span + 1);
@@ -2196,7 +2202,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                         pvh[k] = inb[k] ? h : LCD_GUARD; pva[k] = inb[k] ? eo1 : LCD_GUARD; pvb[k] = inb[k] ? eo2 : LCD_GUARD;
                     }
                     const int be = beg | (end << 16);
-                    if (((keep_mask >> wk) & 1ull) != 0ull) {
+                    if (pk & (1 << 24)) {
                         ring_st3(ring + RB * (unsigned)(s * SLOTW), (begc + cl) & WM, pvh, pva, pvb);
                         m_be = lean_wlane(be, s, m_be); m_mm = lean_wlane(ml | (mr << 16), s, m_mm);
                         pend = 0;
@@ -2207,7 +2213,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
                         else if constexpr (C == 4) glb_st(cp, (int)code);
                         else *(__attribute__((address_space(1))) unsigned short *)cp = (unsigned short)code;
                     }
-                    r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)l_cused, wk, r_off);
+                    r_be = lean_wlane(be, wk, r_be);
                     l_begc = begc; l_beg = beg; l_end = end; l_ml = ml; l_mr = mr;
                     l_cused += (unsigned)cw4; run_cells += (unsigned)(span + 1);
                     ++idx; ++wk;
@@ -2404,7 +2410,7 @@ __device__ __attribute__((noinline)) int align_lean(const Ctx *gp_, const unsign
             }
         }
         const int be = beg | (end << 16);
-        r_be = lean_wlane(be, wk, r_be); r_off = lean_wlane((int)cused, wk, r_off);
+        r_be = lean_wlane(be, wk, r_be);
         m_be = lean_wlane(be, s, m_be); m_mm = lean_wlane(ml | (mr << 16), s, m_mm);
         if ((np > 1 || spf) && lane == 0) {
             if (np > 1) glb_st(g.ooff + idx, (int)oused);
