@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/lines
-tag=r05_v2
+tag=${1:-r05_v3}
 CMD="python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0"
 PMC="$CMD --repeats 1 --depth-profile 0 --overlap 0"
 timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o kt -- $PMC > gpurun_out/prof_$tag.log 2>&1
