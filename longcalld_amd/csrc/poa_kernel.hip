@@ -446,6 +446,9 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
 // A parallel pass over [lo, hi) with U elements per thread IN FLIGHT: `ld` (straight-line loads, no side effects; called with an index clamped into the range)
 // runs for all U before `st` runs for any, so the U dependent-load chains overlap instead of following one another -- the per-read graph phases are latency
 // chains through L2 / HBM run by one wavefront, and a loop that stores into an int array between two loads is a chain per iteration for the compiler.
+#ifndef LCD_BF_U
+#define LCD_BF_U 4 // elements per thread in flight in the per-read O(nodes) passes (build switch; 8 measured in round 5: see profiles/NOTES_r05.md)
+#endif
 template <int U, int NT, typename LoadF, typename StoreF>
 __device__ __forceinline__ void batched_for(const int lo, const int hi, LoadF ld, StoreF st) {
     for (int b = lo + (int)threadIdx.x; b < hi; b += U * NT) {
@@ -482,13 +485,13 @@ __device__ __forceinline__ void remain_by_jumping(Ctx &g, const int n, U16P b0, 
         U16P Ps = buf[src], Ds = Ps + n;
         U16P Pd = buf[src ^ 1], Dd = Pd + n;
         struct PD { int pp, d; };
-        batched_for<4, NT>(0, n, [&](const int v) { const int p = Ps[v]; PD r; r.pp = Ps[p]; r.d = Ds[v] + Ds[p]; return r; },
+        batched_for<LCD_BF_U, NT>(0, n, [&](const int v) { const int p = Ps[v]; PD r; r.pp = Ps[p]; r.d = Ds[v] + Ds[p]; return r; },
                            [&](const int v, const PD r) { Pd[v] = (unsigned short)r.pp; Dd[v] = (unsigned short)r.d; });
         __syncthreads();
         src ^= 1;
     }
     U16P D = buf[src] + n;
-    batched_for<4, NT>(0, n, [&](const int v) { return (int)D[v]; }, [&](const int v, const int d) { g.remain[v] = d - 1; });
+    batched_for<LCD_BF_U, NT>(0, n, [&](const int v) { return (int)D[v]; }, [&](const int v, const int d) { g.remain[v] = d - 1; });
 }
 typedef __attribute__((address_space(3))) unsigned short *lcd_lds_u16p;
 __device__ __forceinline__ lcd_lds_u16p lds_u16(const void *p) { return (lcd_lds_u16p)(uintptr_t)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)p; }
@@ -498,16 +501,16 @@ __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned shor
     const int tid = threadIdx.x;
     const int n = g.n_node, E = g.n_edge;
     struct NW { int d; unsigned w; };
-    batched_for<4, NT>(0, n, [&](const int i) { NW r; r.d = g.nin[i]; r.w = (unsigned)(g.out_head[i] + 1) | ((unsigned)g.aligned[i] << 16); return r; },
+    batched_for<LCD_BF_U, NT>(0, n, [&](const int i) { NW r; r.d = g.nin[i]; r.w = (unsigned)(g.out_head[i] + 1) | ((unsigned)g.aligned[i] << 16); return r; },
                        [&](const int i, const NW r) { deg[i] = (unsigned short)r.d; nw[i] = r.w; });
-    batched_for<4, NT>(0, E, [&](const int e) { return (unsigned)g.e_to[e] | ((unsigned)(g.e_next_out[e] + 1) << 16); }, [&](const int e, const unsigned w) { ew[e] = w; });
+    batched_for<LCD_BF_U, NT>(0, E, [&](const int e) { return (unsigned)g.e_to[e] | ((unsigned)(g.e_next_out[e] + 1) << 16); }, [&](const int e, const unsigned w) { ew[e] = w; });
     // Chain links for the walk below: link(v) = w when v's only out-edge goes to w, w has no other in-edge and no aligned ring -- when v is
     // popped with nothing else queued, w is the next node whatever else happens.  POA graphs are mostly such chains (the backbone between
     // bubbles), so the walk takes them 64 nodes at a time: jump tables J1 = link, J4 = link^4, J16 = link^16 (self-loops at chain ends) let
     // lane t of wavefront 0 reach link^t(v) in <= 9 loads.  The tables live in the row-plan arrays (HBM, free between two reads).
     unsigned short *J1 = (unsigned short *)g.pl_start, *J4 = J1 + n, *J16 = (unsigned short *)g.pl_rem;
     __syncthreads();
-    batched_for<4, NT>(0, n, [&](const int v) {
+    batched_for<LCD_BF_U, NT>(0, n, [&](const int v) {
         const unsigned e = nw[v] & 0xffffu;
         const unsigned w = ew[e != 0 ? e - 1 : 0];      // (straight-line: the loads of a node without an out-edge are harmless)
         const int to = (int)(w & 0xffffu);
@@ -519,12 +522,12 @@ __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned shor
     // node by node (graphs of noisy reads are bubbles every few nodes: probing every node for a chain cost more than it saved)
     unsigned char *RL = (unsigned char *)(J16 + n), *R4 = RL + n; // (second half of pl_rem: 2n bytes)
     struct XR { int x, r; };
-    batched_for<4, NT>(0, n, [&](const int v) { XR o; o.x = v; o.r = 0;
+    batched_for<LCD_BF_U, NT>(0, n, [&](const int v) { XR o; o.x = v; o.r = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const int y = J1[o.x]; o.r += y != o.x; o.x = y; }
         return o; }, [&](const int v, const XR o) { J4[v] = (unsigned short)o.x; R4[v] = (unsigned char)o.r; });
     __syncthreads();
-    batched_for<4, NT>(0, n, [&](const int v) { XR o; o.x = v; o.r = 0;
+    batched_for<LCD_BF_U, NT>(0, n, [&](const int v) { XR o; o.x = v; o.r = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { o.r += R4[o.x]; o.x = J4[o.x]; }
         return o; }, [&](const int v, const XR o) { J16[v] = (unsigned short)o.x; RL[v] = (unsigned char)o.r; });
@@ -588,7 +591,7 @@ __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned shor
         // slot v) and buffer 1 that of the node words -- every round is then an LDS pass instead of a round trip to HBM; otherwise the row-plan arrays in HBM
         unsigned short *P0 = INLDS ? deg : (unsigned short *)g.pl_start, *D0 = INLDS ? queue : P0 + n; // (the jump tables of the walk are dead now)
         struct HV { int mw, mid, q; unsigned more; };
-        batched_for<4, NT>(0, n, [&](const int v) { // (the first two out-edges straight-line: nearly every node has no more)
+        batched_for<LCD_BF_U, NT>(0, n, [&](const int v) { // (the first two out-edges straight-line: nearly every node has no more)
             HV r; r.mw = -1; r.mid = 1; r.q = queue[v];
             const unsigned e0 = nw[v] & 0xffffu;
             const unsigned w0 = ew[e0 ? e0 - 1 : 0]; const int t0 = g.e_w[e0 ? e0 - 1 : 0];
@@ -630,7 +633,7 @@ __device__ __forceinline__ bool topo_sort_compact(Ctx &g, Smem &sm, int *lds_poo
     // ---- staging: in-degree, aligned ring, out-degree (into ostart[v + 1]) ----
     int bad = 0;
     struct S1 { int d, a, cnt, more; };
-    batched_for<4, NT>(0, n, [&](const int v) {
+    batched_for<LCD_BF_U, NT>(0, n, [&](const int v) {
         S1 r; r.d = g.nin[v]; r.a = g.aligned[v];
         const int e0 = g.out_head[v], c0 = e0 >= 0 ? e0 : 0;
         const int e1 = e0 >= 0 ? g.e_next_out[c0] : -1, c1 = e1 >= 0 ? e1 : 0;
@@ -656,7 +659,7 @@ __device__ __forceinline__ bool topo_sort_compact(Ctx &g, Smem &sm, int *lds_poo
     }
     if (__syncthreads_or(bad)) return false;
     struct S2 { int t0, t1, more; };
-    batched_for<4, NT>(0, n, [&](const int v) {
+    batched_for<LCD_BF_U, NT>(0, n, [&](const int v) {
         S2 r;
         const int e0 = g.out_head[v], c0 = e0 >= 0 ? e0 : 0;
         r.t0 = e0 >= 0 ? g.e_to[c0] : -1;
@@ -673,7 +676,7 @@ __device__ __forceinline__ bool topo_sort_compact(Ctx &g, Smem &sm, int *lds_poo
     __syncthreads();
     // ---- chain links and jump tables, as in topo_sort_arrays (tables in the row-plan arrays in HBM) ----
     unsigned short *J1 = (unsigned short *)g.pl_start, *J4 = J1 + n, *J16 = (unsigned short *)g.pl_rem;
-    batched_for<4, NT>(0, n, [&](const int v) {
+    batched_for<LCD_BF_U, NT>(0, n, [&](const int v) {
         const int s0 = ostart[v], s1 = ostart[v + 1];
         const int to = eto[s0 < E ? s0 : 0];
         const bool link = s1 - s0 == 1 && deg[to] == 1 && (int)al[to] == to;
@@ -682,12 +685,12 @@ __device__ __forceinline__ bool topo_sort_compact(Ctx &g, Smem &sm, int *lds_poo
     __syncthreads();
     unsigned char *R4 = (unsigned char *)(J16 + n) + n;
     struct XR { int x, r; };
-    batched_for<4, NT>(0, n, [&](const int v) { XR o; o.x = v; o.r = 0;
+    batched_for<LCD_BF_U, NT>(0, n, [&](const int v) { XR o; o.x = v; o.r = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const int y = J1[o.x]; o.r += y != o.x; o.x = y; }
         return o; }, [&](const int v, const XR o) { J4[v] = (unsigned short)o.x; R4[v] = (unsigned char)o.r; });
     __syncthreads();
-    batched_for<4, NT>(0, n, [&](const int v) { XR o; o.x = v; o.r = 0;
+    batched_for<LCD_BF_U, NT>(0, n, [&](const int v) { XR o; o.x = v; o.r = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { o.r += R4[o.x]; o.x = J4[o.x]; }
         return o; }, [&](const int v, const XR o) { J16[v] = (unsigned short)o.x; if (o.r >= 4) deg[v] = (uint8_t)(deg[v] | 0x80); });
@@ -753,7 +756,7 @@ __device__ __forceinline__ bool topo_sort_compact(Ctx &g, Smem &sm, int *lds_poo
         // heaviest successor of every node from the graph's own arrays (parallel: their latency overlaps), remain by pointer jumping in LDS (the walk's arrays are dead)
         lcd_lds_u16p P0 = lds_u16(lds_pool), D0 = P0 + n;
         struct HV { int mw, mid, more; };
-        batched_for<4, NT>(0, n, [&](const int v) {
+        batched_for<LCD_BF_U, NT>(0, n, [&](const int v) {
             HV r; r.mw = -1; r.mid = 1;
             const int e0 = g.out_head[v], c0 = e0 >= 0 ? e0 : 0;
             const int t0 = g.e_w[c0], to0 = g.e_to[c0];
@@ -804,7 +807,7 @@ __device__ __attribute__((noinline)) void topo_sort_block(Ctx &g, Smem &sm, int 
     g.mm_valid = 0;
     if (g.status == LCD_OK && want_mm) { // (K1 chains: only sub-graph alignments have sweeps)
         struct MM { int mn, mx, ein, eout; };
-        batched_for<4, NT>(0, n, [&](const int idx) { // (the first two edges of either list straight-line: nearly every node has no more)
+        batched_for<LCD_BF_U, NT>(0, n, [&](const int idx) { // (the first two edges of either list straight-line: nearly every node has no more)
             MM r; r.mn = 1 << 30; r.mx = -1;
             const int v = g.idx2node[idx];
             const int i0 = g.in_head[v], o0 = g.out_head[v], ci0 = i0 >= 0 ? i0 : 0, co0 = o0 >= 0 ? o0 : 0;
@@ -850,7 +853,7 @@ __device__ __attribute__((noinline)) void topo_remain_block(Ctx &g, Smem &sm, in
     if (inlds) {
         const lcd_lds_u16p P0 = lds_u16(lds_pool), D0 = P0 + n;
         struct HV { int mw, mid, more; };
-        batched_for<4, NT>(0, n, [&](const int v) { // (the first two out-edges straight-line: nearly every node has no more)
+        batched_for<LCD_BF_U, NT>(0, n, [&](const int v) { // (the first two out-edges straight-line: nearly every node has no more)
             HV r; r.mw = -1; r.mid = 1;
             const int e0 = g.out_head[v], c0 = e0 >= 0 ? e0 : 0;
             const int t0 = g.e_w[c0], to0 = g.e_to[c0], e1 = e0 >= 0 ? g.e_next_out[c0] : -1, c1 = e1 >= 0 ? e1 : 0;
@@ -868,7 +871,7 @@ __device__ __attribute__((noinline)) void topo_remain_block(Ctx &g, Smem &sm, in
     } else {
         unsigned short *P0 = (unsigned short *)g.pl_start, *D0 = P0 + n;
         struct HV { int mw, mid, more; };
-        batched_for<4, NT>(0, n, [&](const int v) { // (the first two out-edges straight-line: nearly every node has no more)
+        batched_for<LCD_BF_U, NT>(0, n, [&](const int v) { // (the first two out-edges straight-line: nearly every node has no more)
             HV r; r.mw = -1; r.mid = 1;
             const int e0 = g.out_head[v], c0 = e0 >= 0 ? e0 : 0;
             const int t0 = g.e_w[c0], to0 = g.e_to[c0], e1 = e0 >= 0 ? g.e_next_out[c0] : -1, c1 = e1 >= 0 ? e1 : 0;
