@@ -83,6 +83,12 @@ struct Ctx {
     int ring16;                        // the chain's LDS ring holds 16-bit values (align_lean<2, C> only; the generic rows then see half as many int32 columns)
     int topo_mode;                     // test switches of the re-sort (LCD_DBG bits 64 / 128 / 256): 1 = never the compact LDS copy, 2 = the compact copy even where the packed words fit, 4 = its FIFO holds three nodes
     int mm_valid;                      // g.deg / g.queue hold, by topological index, every row's smallest predecessor index / largest successor index (topo_sort_block; subgraph_nodes_wave0)
+    uint8_t *cut; int cut_valid;       // cut[i] != 0: the Kahn walk's FIFO was empty right after it popped the node of topological index i (where topo_sort_incremental may restart the walk); same bytes as `prof` (chain_output only)
+    int upd_new, upd_newe, upd_moved;  // add_alignment_block's last call: nodes / edges it created, and whether some node's heaviest out-edge is another one now
+    int inc_off;                       // LCD_DBG bit 1024: every topology change takes the full re-sort (test switch)
+#ifdef LCD_X_INCSTAT
+    unsigned inc_stat[13];             // (experiment) topo_sort_incremental: refusals by reason 0..9, successes, nodes walked, pieces
+#endif
     int n_node, n_edge, node_cap, edge_cap, rid_words;
     unsigned long long cell_cap;
     int status;
@@ -183,6 +189,17 @@ __device__ __forceinline__ void scan_max3(int &a, int &b, int &c) {
 __device__ __forceinline__ int shr1(int identity, int v) { return dpp_take<0x138, 0xf>(identity, v); } // wave_shr:1
 __device__ __forceinline__ int lane63(int v) { return __builtin_amdgcn_readlane(v, 63); }
 
+
+// LDS-only workgroup barrier: orders LDS traffic without draining the HBM store queue (vmcnt), which a
+// __syncthreads() would do.  Single-wavefront workgroups need no s_barrier at all (LDS ops of one wave are in order).
+template <int NT>
+__device__ __forceinline__ void lds_barrier() {
+    if (NT > 64) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ int glb_ld(const int *p);
+__device__ __forceinline__ int glb_ld_u8(const uint8_t *p);
+__device__ __forceinline__ int usgpr(const int v);
 
 // ---------------- graph mutation (thread 0 only) ----------------
 __device__ int add_node(Ctx &g, uint8_t b) {
@@ -285,12 +302,13 @@ __device__ int block_excl_scan(int v, Smem &sm, int *total) { // exclusive prefi
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NW = NT / 64;
     const int incl = scan_add(v);
+    if constexpr (NW == 1) { *total = lane63(incl); return incl - v; } // (one wavefront: no exchange, and no barrier -- a barrier drains the stores the caller has in flight, ~2 us each time)
     if (lane == 63) sm.scan[wave] = incl;
-    __syncthreads();
+    lds_barrier<NT>(); // (the partial sums go through LDS only: no need to wait for the caller's HBM stores)
     int woff = 0, tot = 0;
 #pragma unroll
     for (int k = 0; k < NW; ++k) { const int t = sm.scan[k]; if (k < wave) woff += t; tot += t; }
-    __syncthreads();
+    lds_barrier<NT>();
     *total = tot;
     return woff + incl - v;
 }
@@ -313,6 +331,7 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
         }
         if (tid == 0) { g.out_head[0] = g.out_tail[0] = 0; g.in_head[1] = g.in_tail[1] = len; g.nin[1] = 1; }
         g.n_node = len + 2; g.n_edge = len + 1;
+        g.upd_new = len; g.upd_newe = len + 1; g.upd_moved = 0;
         __syncthreads();
         return 2;
     }
@@ -440,6 +459,7 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
     }
     g.n_node += n_new; g.n_edge += n_newe;
     const int moved = __syncthreads_or(heavy_moved);
+    g.upd_new = n_new; g.upd_newe = n_newe; g.upd_moved = moved;
     return (n_new || n_newe) ? 2 : moved ? 1 : 3;
 }
 
@@ -554,13 +574,13 @@ __device__ __forceinline__ void topo_sort_arrays(Ctx &g, Smem &sm, unsigned shor
                 const int L = __popcll(adv);
                 if (L <= 1) break;
                 // x_0 .. x_{L-2} are complete (their one out-edge leads to the next node, which nothing else waits for); x_{L-1} goes on
-                if (lane < L - 1) g.node2idx[x] = index + lane;
+                if (lane < L - 1) { g.node2idx[x] = index + lane; g.cut[index + lane] = 1; }
                 if (lane >= 1 && lane < L) queue[qh - 1 + lane] = (unsigned short)x;
                 index += L - 1; qh += L - 1; qt = qh;
                 cur = __shfl(x, L - 1);
                 if (L < 64 || index > n) break; // (index > n: the jump tables do not describe chains -- the count below turns it into LCD_ERR_TOPO)
             }
-            g.node2idx[cur] = index; ++index; // (idx2node is the queue itself, copied out below)
+            g.node2idx[cur] = index; g.cut[index] = (uint8_t)(qh == qt); ++index; // (idx2node is the queue itself, copied out below)
             if (cur == 1 || index > n) break;
             for (unsigned e = nw[cur] & 0xffffu; e != 0;) {
                 const unsigned w = ew[e - 1];
@@ -714,12 +734,12 @@ __device__ __forceinline__ bool topo_sort_compact(Ctx &g, Smem &sm, int *lds_poo
                 const unsigned long long adv = __ballot(lane == 0 || x != prev);
                 const int L = __popcll(adv);
                 if (L <= 1) break;
-                if (lane < L - 1) { g.node2idx[x] = index + lane; g.idx2node[index + lane] = x; }
+                if (lane < L - 1) { g.node2idx[x] = index + lane; g.idx2node[index + lane] = x; g.cut[index + lane] = 1; }
                 index += L - 1; qh += L - 1; qt = qh;
                 cur = __shfl(x, L - 1);
                 if (L < 64 || index > n) break;
             }
-            g.node2idx[cur] = index; g.idx2node[index < n ? index : 0] = cur; ++index;
+            g.node2idx[cur] = index; g.idx2node[index < n ? index : 0] = cur; g.cut[index < n ? index : 0] = (uint8_t)(qh == qt); ++index;
             if (cur == 1 || index > n) break;
             const int s0 = ostart[cur], s1 = ostart[cur + 1];
             int out_n = eto[s0 < E ? s0 : 0];
@@ -785,7 +805,7 @@ __device__ __attribute__((noinline)) void topo_sort_block(Ctx &g, Smem &sm, int 
         if (tid == 0) { topo_sort(g); sm.bc[6] = g.status; }
         __syncthreads();
         g.status = sm.bc[6];
-        g.mm_valid = 0;
+        g.mm_valid = 0; g.cut_valid = 0;
         __syncthreads();
         return;
     }
@@ -803,32 +823,208 @@ __device__ __attribute__((noinline)) void topo_sort_block(Ctx &g, Smem &sm, int 
         topo_sort_arrays<NT, true>(g, sm, deg, queue, nw, ew);
     } else
         topo_sort_arrays<NT, false>(g, sm, (unsigned short *)g.deg, (unsigned short *)g.queue, (unsigned *)g.pl_bonus, (unsigned *)g.pl_pidx);
-    // every row's smallest predecessor index / largest successor index, for the sub-graph sweeps of the reads until the next re-sort (g.deg / g.queue are free now)
-    g.mm_valid = 0;
-    if (g.status == LCD_OK && want_mm) { // (K1 chains: only sub-graph alignments have sweeps)
-        struct MM { int mn, mx, ein, eout; };
-        batched_for<LCD_BF_U, NT>(0, n, [&](const int idx) { // (the first two edges of either list straight-line: nearly every node has no more)
-            MM r; r.mn = 1 << 30; r.mx = -1;
-            const int v = g.idx2node[idx];
-            const int i0 = g.in_head[v], o0 = g.out_head[v], ci0 = i0 >= 0 ? i0 : 0, co0 = o0 >= 0 ? o0 : 0;
-            const int fi0 = g.e_from[ci0], i1 = i0 >= 0 ? g.e_next_in[ci0] : -1, to0 = g.e_to[co0], o1 = o0 >= 0 ? g.e_next_out[co0] : -1;
-            const int ci1 = i1 >= 0 ? i1 : 0, co1 = o1 >= 0 ? o1 : 0;
-            const int fi1 = g.e_from[ci1], to1 = g.e_to[co1];
-            const int a0 = g.node2idx[fi0], a1 = g.node2idx[fi1], b0 = g.node2idx[to0], b1 = g.node2idx[to1];
-            if (i0 >= 0) r.mn = a0;
-            if (i1 >= 0) r.mn = imin(r.mn, a1);
-            if (o0 >= 0) r.mx = b0;
-            if (o1 >= 0) r.mx = imax(r.mx, b1);
-            r.ein = i1 >= 0 ? g.e_next_in[ci1] : -1; r.eout = o1 >= 0 ? g.e_next_out[co1] : -1;
-            return r;
-        }, [&](const int idx, MM r) {
-            for (int e = r.ein; e >= 0; e = g.e_next_in[e]) r.mn = imin(r.mn, g.node2idx[g.e_from[e]]);
-            for (int e = r.eout; e >= 0; e = g.e_next_out[e]) r.mx = imax(r.mx, g.node2idx[g.e_to[e]]);
-            g.deg[idx] = r.mn; g.queue[idx] = r.mx;
-        });
-        g.mm_valid = 1;
+    // (every row's smallest predecessor index / largest successor index, for the sub-graph sweeps of partial-cover reads: compute_mm, made when such a read comes)
+    g.mm_valid = 0; g.cut_valid = g.status == LCD_OK;
+    __syncthreads();
+}
+
+// every row's smallest predecessor index / largest successor index (g.deg / g.queue, free between two re-sorts), for the sub-graph sweeps of the partial-cover reads
+// until the order changes again (subgraph_nodes_wave0)
+template <int NT>
+__device__ __attribute__((noinline)) void compute_mm(Ctx &g) {
+    const int n = g.n_node;
+    struct MM { int mn, mx, ein, eout; };
+    batched_for<LCD_BF_U, NT>(0, n, [&](const int idx) { // (the first two edges of either list straight-line: nearly every node has no more)
+        MM r; r.mn = 1 << 30; r.mx = -1;
+        const int v = g.idx2node[idx];
+        const int i0 = g.in_head[v], o0 = g.out_head[v], ci0 = i0 >= 0 ? i0 : 0, co0 = o0 >= 0 ? o0 : 0;
+        const int fi0 = g.e_from[ci0], i1 = i0 >= 0 ? g.e_next_in[ci0] : -1, to0 = g.e_to[co0], o1 = o0 >= 0 ? g.e_next_out[co0] : -1;
+        const int ci1 = i1 >= 0 ? i1 : 0, co1 = o1 >= 0 ? o1 : 0;
+        const int fi1 = g.e_from[ci1], to1 = g.e_to[co1];
+        const int a0 = g.node2idx[fi0], a1 = g.node2idx[fi1], b0 = g.node2idx[to0], b1 = g.node2idx[to1];
+        if (i0 >= 0) r.mn = a0;
+        if (i1 >= 0) r.mn = imin(r.mn, a1);
+        if (o0 >= 0) r.mx = b0;
+        if (o1 >= 0) r.mx = imax(r.mx, b1);
+        r.ein = i1 >= 0 ? g.e_next_in[ci1] : -1; r.eout = o1 >= 0 ? g.e_next_out[co1] : -1;
+        return r;
+    }, [&](const int idx, MM r) {
+        for (int e = r.ein; e >= 0; e = g.e_next_in[e]) r.mn = imin(r.mn, g.node2idx[g.e_from[e]]);
+        for (int e = r.eout; e >= 0; e = g.e_next_out[e]) r.mx = imax(r.mx, g.node2idx[g.e_to[e]]);
+        g.deg[idx] = r.mn; g.queue[idx] = r.mx;
+    });
+    g.mm_valid = 1;
+    __syncthreads();
+}
+
+// ---- the re-sort of a graph that changed in a few places: the Kahn walk repeated only where it can differ (round 6) ----
+// 45 % of the clean reads add one or two bubbles (a substituted base, a homopolymer one longer or shorter) to a graph of several hundred nodes, and the full re-sort
+// above -- staging, jump tables, the serial walk over all nodes, heaviest successors, log2(n) pointer-jumping rounds -- cost as much as half the read's DP.  The
+// oracle's order (oracle/poa.c topo_sort: Kahn with a FIFO, aligned groups released together) is reproduced EXACTLY from the old one:
+//   * `cut[i]` (recorded by every walk): the FIFO was empty right after the node of index i was popped.  At such a point the walk's state is (popped = the first i + 1
+//     nodes, nothing queued), so it can be restarted there with "a node is ready when all its in-edges come from popped nodes" in place of in-degree counters.
+//   * the read's path is monotone in the old order, and what it added starts at old nodes (the source of a new edge; the row before an aligned group that gained a
+//     member): before the first of them nothing moves.  The walk restarts at the largest cut at or before it and goes on until it pops a node c with nothing queued,
+//     c a cut of the OLD order as well, and the old nodes emitted so far exactly the old range [q, idx(c)]: from there on both walks are in the same state (a popped
+//     source of an in-edge delays nobody), so the old order stands, shifted by the number of new nodes emitted -- up to the largest cut before the next thing added.
+//   * anything unexpected (no cut in reach, too many nodes walked, a new node never emitted, a queue that runs dry) returns false: the caller takes the full re-sort.
+// `remain` of a new node is that of its only successor plus one; an old node's heaviest out-edge cannot become a new edge (weight 1, last in its list), and
+// add_alignment_block says when a weight increment moved one (upd_moved: the caller then re-makes `remain` as after a weights-only read).
+constexpr int INC_ML = 64, INC_EL = 256, INC_SEG = 16, INC_Q = 32, INC_NEW = 64, INC_MAXN = 16384;
+template <int NT>
+__device__ __attribute__((noinline)) bool topo_sort_incremental(Ctx &g, Smem &sm, int *lds_pool, const int beg_node, const int end_node, const int n_cig) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = g.n_node, n_new = g.upd_new, n_old = n - n_new;
+    const int bm_words = (n + 31) >> 5;
+    if (!g.cut_valid || g.inc_off || n >= INC_MAXN || n_new > INC_NEW || n_old < 3 || bm_words + INC_ML + INC_NEW + INC_EL + 6 * INC_SEG + INC_Q + 16 > g.pool_words) {
+#ifdef LCD_X_INCSTAT
+        g.inc_stat[0] += 1;
+#endif
+        return false;
+    }
+    unsigned *bm = (unsigned *)lds_pool;            // nodes the walks below have popped
+    int *ml = lds_pool + bm_words;                  // where the walk has to be repeated: old indices, in path order (ascending)
+    int *newj = ml + INC_ML;                        // path positions of the new nodes
+    int *el = newj + INC_NEW;                       // the nodes the walks emitted: id | (FIFO empty after the pop) << 16
+    int *seg = el + INC_EL;                         // per repeated stretch: q, ic, first entry of el, entries, new nodes emitted before / after
+    int *qring = seg + 6 * INC_SEG;
+    int *seen = qring + INC_Q;                      // targets of the out-edges of the node at hand that have been taken (8)
+    for (int i = tid; i < bm_words; i += NT) bm[i] = 0;
+    __syncthreads();
+    if (wave == 0) {
+        int fail = 0;
+        int n_ml = 0, n_nj = 0;
+        // ---- what the read added, in path order: edge j runs from path[j - 1] (beg_node) to path[j] (end_node) ----
+        for (int base = 0; base <= n_cig && !fail; base += 64) {
+            const int j = base + lane;
+            int has0 = 0, v0 = 0, has1 = 0, v1 = 0, isn = 0;
+            if (j <= n_cig) {
+                const int eid = g.aa_eid[j];
+                const int fl = j < n_cig ? g.aa_flag[j] : -2, flp = j > 0 ? g.aa_flag[j - 1] : -2;
+                isn = fl != -2;
+                if (eid >= 0 && flp == -2) { const int from = j == 0 ? beg_node : g.aa_node[j - 1]; v0 = g.node2idx[from]; has0 = 1; }
+                if (fl >= 0) { v1 = g.node2idx[fl] - 1; has1 = 1; }
+            }
+            const int cnt = has0 + has1, incl = scan_add(cnt), tot = lane63(incl);
+            if (n_ml + tot > INC_ML) { fail = 1; break; }
+            const int off = n_ml + incl - cnt;
+            if (has0) ml[off] = v0;
+            if (has1) ml[off + has0] = v1;
+            n_ml += tot;
+            const unsigned long long mn = __ballot(isn != 0);
+            if (n_nj + __popcll(mn) > INC_NEW) { fail = 2; break; }
+            if (isn) newj[n_nj + __popcll(mn & ((1ull << lane) - 1))] = j;
+            n_nj += __popcll(mn);
+        }
+        if (!fail && n_nj != n_new) fail = 3;
+        auto LD = [&](const int *p) { return usgpr(glb_ld(p)); };
+        auto largest_cut = [&](const int p) { // largest i <= p with cut[i] (-1: none within 256 indices)
+            for (int base = p, it = 0; it < 4 && base >= 0; ++it, base -= 64) {
+                const int i = base - lane;
+                const int c = i >= 0 ? glb_ld_u8(g.cut + i) : 0;
+                const unsigned long long m = __ballot(c != 0);
+                if (m) return base - (int)__builtin_ctzll(m);
+            }
+            return -1;
+        };
+        int k = 0, D = 0, n_el = 0, n_seg = 0, ic_prev = -1;
+        while (k < n_ml && !fail) {
+            const int q = largest_cut(ml[k]);
+            if (q <= ic_prev || n_seg >= INC_SEG || n_el >= INC_EL) { fail = q <= ic_prev ? 4 : 5; break; }
+            int cur = LD(g.idx2node + q);
+            bm[cur >> 5] |= 1u << (cur & 31);
+            const int off = n_el, d0 = D;
+            el[n_el++] = cur | (1 << 16);
+            int m_old = 1, maxe = q, qh = 0, qt = 0, ic = -1;
+            auto is_done = [&](const int f) { return ((bm[f >> 5] >> (f & 31)) & 1u) != 0 || (f < n_old && LD(g.node2idx + f) <= q); };
+            // the oracle's counters: a node's in-degree reaches 0 when its LAST in-edge is taken, and the out-edges of the node at hand are taken one by one -- an in-edge
+            // from a popped node has been taken, one from the node at hand only if it comes earlier in that node's out-list (`seen`)
+            int n_seen = 0;
+            auto ready = [&](const int w) {
+                for (int e = LD(g.in_head + w); e >= 0;) {
+                    const int f = LD(g.e_from + e), en = LD(g.e_next_in + e);
+                    if (f == cur) { bool hit = false; for (int t = 0; t < n_seen; ++t) hit = hit || usgpr(seen[t]) == w; if (!hit) return false; }
+                    else if (!is_done(f)) return false;
+                    e = en;
+                }
+                return true;
+            };
+            for (;;) {
+                n_seen = 0;
+                for (int e = LD(g.out_head + cur); e >= 0 && !fail;) {
+                    const int w = LD(g.e_to + e);
+                    e = LD(g.e_next_out + e);
+                    if (n_seen >= 8) { fail = 6; break; }
+                    seen[n_seen++] = w;
+                    if (!ready(w)) continue;
+                    bool ok = true; int na = 0;
+                    for (int a = LD(g.aligned + w); a != w; a = LD(g.aligned + a)) { if (++na > 8 || !ready(a)) { ok = false; break; } }
+                    if (!ok) continue;
+                    if (qt - qh + na + 1 > INC_Q) { fail = 6; break; }
+                    qring[qt++ & (INC_Q - 1)] = w;
+                    for (int a = LD(g.aligned + w); a != w; a = LD(g.aligned + a)) qring[qt++ & (INC_Q - 1)] = a;
+                }
+                if (fail || qh == qt || n_el >= INC_EL) { if (!fail) fail = qh == qt ? 7 : 8; break; } // (a FIFO that runs dry before the walk is back on the old order: not a state the argument above covers)
+                cur = usgpr(qring[qh++ & (INC_Q - 1)]);
+                bm[cur >> 5] |= 1u << (cur & 31);
+                const bool empty = qh == qt;
+                el[n_el++] = cur | ((int)empty << 16);
+                int oi = -1;
+                if (cur < n_old) { oi = LD(g.node2idx + cur); ++m_old; maxe = imax(maxe, oi); } else ++D;
+                if (empty && oi >= 0 && oi == maxe && maxe == q + m_old - 1 && usgpr(glb_ld_u8(g.cut + oi)) != 0) {
+                    while (k < n_ml && usgpr(ml[k]) < oi) ++k;
+                    if (k < n_ml && largest_cut(usgpr(ml[k])) == oi) continue; // the next thing added starts right here: the walk goes on
+                    ic = oi;
+                    break;
+                }
+            }
+            if (fail) break;
+            seg[6 * n_seg + 0] = q; seg[6 * n_seg + 1] = ic; seg[6 * n_seg + 2] = off; seg[6 * n_seg + 3] = n_el - off; seg[6 * n_seg + 4] = d0; seg[6 * n_seg + 5] = D;
+            ++n_seg; ic_prev = ic;
+        }
+        if (!fail && D != n_new) fail = 9;
+        if (lane == 0) { sm.bc[5] = fail; sm.bc[4] = n_seg; sm.bc[3] = n_nj; sm.bc[2] = n_el; }
     }
     __syncthreads();
+    const int fail = sm.bc[5];
+    const int n_seg = sm.bc[4], n_nj = sm.bc[3];
+#ifdef LCD_X_INCSTAT
+    if (fail) g.inc_stat[fail < 10 ? fail : 0] += 1; else { g.inc_stat[10] += 1; g.inc_stat[11] += (unsigned)sm.bc[2]; g.inc_stat[12] += (unsigned)n_seg; }
+#endif
+    __syncthreads();
+    if (fail) return false;
+    // ---- apply, back to front: the stretch behind a repeated piece moves up by the new nodes emitted so far, then the piece itself is written ----
+    constexpr int U = 4;
+    for (int s = n_seg - 1; s >= 0; --s) {
+        const int q = seg[6 * s], ic = seg[6 * s + 1], off = seg[6 * s + 2], cnt = seg[6 * s + 3], d0 = seg[6 * s + 4], d1 = seg[6 * s + 5];
+        const int lo = ic + 1, hi = s == n_seg - 1 ? n_old : seg[6 * (s + 1)];
+        if (d1 > 0)
+            for (int top = hi; top > lo; top -= U * NT) { // (top-down: a chunk's stores land at or above its own loads, never on a lower chunk's)
+                int v[U], c[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { const int i = top - 1 - (u * NT + tid); v[u] = 0; c[u] = 0; if (i >= lo) { v[u] = g.idx2node[i]; c[u] = g.cut[i]; } }
+                __syncthreads(); // (every wavefront's loads have returned -- the barrier waits for vmcnt(0) -- before any store of the chunk)
+#pragma unroll
+                for (int u = 0; u < U; ++u) { const int i = top - 1 - (u * NT + tid); if (i >= lo) { g.idx2node[i + d1] = v[u]; g.cut[i + d1] = (uint8_t)c[u]; g.node2idx[v[u]] = i + d1; } }
+            }
+        __syncthreads();
+        for (int t = tid; t < cnt; t += NT) { const int w = el[off + t], v = w & 0xffff, pos = q + d0 + t; g.idx2node[pos] = v; g.node2idx[v] = pos; g.cut[pos] = (uint8_t)(w >> 16); }
+        __syncthreads();
+    }
+    // ---- remain of the new nodes, last one first (each has one out-edge: to the next node of the read's path) ----
+    if (wave == 0) {
+        int last_x = -1, last_r = 0;
+        for (int t = n_nj - 1; t >= 0; --t) {
+            const int j = usgpr(newj[t]);
+            const int x = usgpr(glb_ld(g.aa_node + j)), nxt = j + 1 < n_cig ? usgpr(glb_ld(g.aa_node + j + 1)) : end_node;
+            const int r = (nxt == last_x ? last_r : usgpr(glb_ld(g.remain + nxt))) + 1;
+            if (lane == 0) g.remain[x] = r;
+            last_x = x; last_r = r;
+        }
+    }
+    g.mm_valid = 0;
+    __syncthreads();
+    return true;
 }
 
 // The read changed edge weights only (no new node, no new edge): the topological order stands; `remain` follows the heaviest out-edge
@@ -955,13 +1151,6 @@ __device__ void subgraph_nodes_wave0(Ctx &g, int lane, int inc_beg, int inc_end,
     *exc_beg = g.idx2node[up]; *exc_end = g.idx2node[down];
 }
 
-// LDS-only workgroup barrier: orders LDS traffic without draining the HBM store queue (vmcnt), which a
-// __syncthreads() would do.  Single-wavefront workgroups need no s_barrier at all (LDS ops of one wave are in order).
-template <int NT>
-__device__ __forceinline__ void lds_barrier() {
-    if (NT > 64) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("" ::: "memory");
-}
 
 #define LCD_RL(v, t) __builtin_amdgcn_readlane((v), (t))
 
@@ -1087,11 +1276,14 @@ __device__ void build_plan(Ctx &g, Smem &sm, const int bi, const int ei, const i
             if (base + u * NT > ei) break; // (uniform)
             const int idx = base + u * NT + tid;
             const int incl = scan_add(cnt[u]);
-            if (lane == 63) sm.scan[wave] = incl;
-            __syncthreads();
             int woff = 0, tot = 0;
+            if constexpr (NW == 1) tot = lane63(incl); // (one wavefront: no exchange and no barrier -- a barrier drains the plan stores in flight, ~2 us each time)
+            else {
+                if (lane == 63) sm.scan[wave] = incl;
+                lds_barrier<NT>();
 #pragma unroll
-            for (int k = 0; k < NW; ++k) { const int t = sm.scan[k]; if (k < wave) woff += t; tot += t; }
+                for (int k = 0; k < NW; ++k) { const int t = sm.scan[k]; if (k < wave) woff += t; tot += t; }
+            }
             const int start = carry + woff + incl - cnt[u];
             if (idx <= ei) {
                 g.pl_start[idx] = start;
@@ -1116,7 +1308,7 @@ __device__ void build_plan(Ctx &g, Smem &sm, const int bi, const int ei, const i
                 if (pd) pd[idx - bi] = (uint8_t)first;
             }
             carry += tot;
-            __syncthreads();
+            if constexpr (NW > 1) lds_barrier<NT>();
         }
     }
     if (tid == 0) { g.pl_start[ei + 1] = carry; g.pl_start[ei + 2] = carry; g.pl_start[ei + 3] = carry; }
@@ -4679,6 +4871,10 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
         const unsigned long long work_s = (unsigned long long)(ch.n_reads > 0 ? ch.n_reads : 1) * (unsigned long long)(ch.max_len > 0 ? ch.max_len : 1) * width / 50000000ull;
         g.wd_deadline = (unsigned long long)clock64() + ((unsigned long long)(sc.wd_s > 0 ? sc.wd_s : 30) + work_s) * 2400000000ull; // (~2.4 GHz shader clock: the bound is about seconds, not exact)
     }
+#ifdef LCD_X_INCSTAT
+    for (int k_ = 0; k_ < 13; ++k_) g.inc_stat[k_] = 0;
+#endif
+    g.cut = g.prof; g.cut_valid = 0; g.upd_new = g.upd_newe = g.upd_moved = 0; g.inc_off = (sc.dbg >> 10) & 1;
     g.mm_valid = 0; g.topo_mode = (sc.dbg >> 6) & 7; g.solo = NT == 256 ? ch.solo : 0; g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0; g.t_bp = 0; g.t_setup = 0;
     // The long chains are the latency of a submission at every depth, and next to 8 - 12 other wavefronts of their CU each of theirs issues when the arbiter gets round
     // to it: highest wavefront priority for them (the others fill the slots their dependency stalls leave).  LCD_DBG bit 512: off
@@ -4695,7 +4891,7 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
 #ifdef LCD_X_ROWSTAT
     unsigned long long chg_stat_ = 0;
 #endif
-    int n_aligned_reads = 0;
+    int n_aligned_reads = 0, backbone_len = 0;
     const int n_seq = ch.n_reads;
     const PoaRead *rd = reads + ch.read0;
     for (int i = 0; i < n_seq && g.status == LCD_OK; ++i) {
@@ -4706,14 +4902,19 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
         if (ch.mode == 0 && i != 0) {
             const long long ts0 = clock64();
             beg_cut = r.read_beg - 1; end_cut = r.len - r.read_end;
-            if (wave == 0) {
-                int eb, ee;
-                subgraph_nodes_wave0(g, lane, r.ref_beg + 1, r.ref_end + 1, &eb, &ee);
-                if (lane == 0) { sm.bc[2] = eb; sm.bc[3] = ee; }
+            // A read anchored at the backbone's first and last base: node 2 hangs on the source (index 0) and the last backbone node leads to the sink (the last
+            // index), so the sweeps of oracle/poa.c subgraph_nodes end at once with (source, sink) whatever else the graph holds -- no sweep, no per-row extremes
+            if (!(backbone_len > 0 && r.ref_beg == 1 && r.ref_end == backbone_len)) {
+                if (!g.mm_valid && g.cut_valid) compute_mm<NT>(g);
+                if (wave == 0) {
+                    int eb, ee;
+                    subgraph_nodes_wave0(g, lane, r.ref_beg + 1, r.ref_end + 1, &eb, &ee);
+                    if (lane == 0) { sm.bc[2] = eb; sm.bc[3] = ee; }
+                }
+                __syncthreads();
+                exc_beg = sm.bc[2]; exc_end = sm.bc[3];
+                __syncthreads();
             }
-            __syncthreads();
-            exc_beg = sm.bc[2]; exc_end = sm.bc[3];
-            __syncthreads();
             t_sub += (unsigned long long)(clock64() - ts0);
         }
         const uint8_t *seq = pool + r.seq_off + beg_cut;
@@ -4731,14 +4932,40 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
         // graph update + re-sort: serial pointer work on thread 0; results published through LDS
         const long long tg0 = clock64();
         int changed = 0;
+        if (len > 0 && g.status == LCD_OK && g.n_node == 2) backbone_len = len; // (this read becomes the backbone: node id of its base k is k + 1)
         if (len > 0 && g.status == LCD_OK) changed = add_alignment_block<NT>(g, sm, exc_beg, exc_end, seq, len, n_cig, i);
         t_add += (unsigned long long)(clock64() - tg0);
 #ifdef LCD_X_ROWSTAT
         if (len > 0) { chg_stat_ += changed == 2 ? 1ull : changed == 1 ? (1ull << 16) : changed == 3 ? (1ull << 32) : 0ull; chg_stat_ += 1ull << 48; }
 #endif
         if (changed == 1 || changed == 2) g.plan_valid = 0; // (3: weights only, every heaviest out-edge the same -- order, remain and the plan's structure stand; its bonuses were patched)
-        if (changed == 2 && g.status == LCD_OK) topo_sort_block<NT>(g, sm, lds_pool, ch.mode == 0);
-        else if (changed == 1 && g.status == LCD_OK) topo_remain_block<NT>(g, sm, lds_pool);
+        if (changed == 2 && g.status == LCD_OK) {
+            if (!topo_sort_incremental<NT>(g, sm, lds_pool, exc_beg, exc_end, n_cig)) topo_sort_block<NT>(g, sm, lds_pool, ch.mode == 0);
+            else {
+                if (g.upd_moved) topo_remain_block<NT>(g, sm, lds_pool);
+#ifdef LCD_X_VERIFY_INC
+                {   // (experiment) the full re-sort must give the same order, the same `remain`, and a cut wherever the incremental one says so (the DP region is free here)
+                    const int n_ = g.n_node;
+                    int *sv_i2n = g.H, *sv_n2i = g.H + n_, *sv_rem = g.H + 2 * n_; uint8_t *sv_cut = (uint8_t *)(g.H + 3 * n_);
+                    if ((unsigned long long)n_ * 13 + 64 < g.cell_cap * 4) {
+                        for (int t = tid; t < n_; t += NT) { sv_i2n[t] = g.idx2node[t]; sv_n2i[t] = g.node2idx[t]; sv_rem[t] = g.remain[t]; sv_cut[t] = g.cut[t]; }
+                        __syncthreads();
+                        topo_sort_block<NT>(g, sm, lds_pool, 0);
+                        int bad = 0;
+                        for (int t = tid; t < n_; t += NT) {
+                            if (sv_i2n[t] != g.idx2node[t]) bad |= 1;
+                            if (sv_n2i[t] != g.node2idx[t]) bad |= 2;
+                            if (sv_rem[t] != g.remain[t]) bad |= 4;
+                            if (sv_cut[t] && !g.cut[t]) bad |= 8;
+                        }
+                        bad = __syncthreads_or(bad);
+                        if (bad) { if (tid == 0) printf("[verify-inc] chain %d read %d n %d new %d newe %d: mismatch %d\n", cid, i, n_, g.upd_new, g.upd_newe, bad); g.status = LCD_ERR_TOPO; }
+                        g.mm_valid = 0;
+                    }
+                }
+#endif
+            }
+        } else if (changed == 1 && g.status == LCD_OK) topo_remain_block<NT>(g, sm, lds_pool);
         t_graph += (unsigned long long)(clock64() - tg0);
     }
     const long long t_out0 = clock64();
@@ -4756,6 +4983,10 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
         out.t_bp = g.t_bp; out.t_add = t_add; out.t_sort = t_graph - t_add; out.t_setup = g.t_setup;
 #ifdef LCD_X_ROWSTAT
         out.t_bt = chg_stat_;
+#endif
+#ifdef LCD_X_INCSTAT
+        if ((cid & 511) == 0) printf("[inc] chain %d mode %d reads %d nodes %d: refused pre %u ml %u new %u cnt %u cut %u cap %u q %u dry %u el %u left %u | ok %u walked %u pieces %u\n", cid, ch.mode, n_seq, g.n_node,
+            g.inc_stat[0], g.inc_stat[1], g.inc_stat[2], g.inc_stat[3], g.inc_stat[4], g.inc_stat[5], g.inc_stat[6], g.inc_stat[7], g.inc_stat[8], g.inc_stat[9], g.inc_stat[10], g.inc_stat[11], g.inc_stat[12]);
 #endif
         if (g.status == LCD_ERR_WATCHDOG) { out.t_plan = sm.prof[0]; out.t_poll = sm.prof[1]; out.t_bp = sm.prof[2]; out.t_add = sm.prof[3]; } // (the backtrack's last states, if that is where it was)
         outs[cid] = out;
