@@ -86,6 +86,9 @@ struct Ctx {
     uint8_t *cut; int cut_valid;       // cut[i] != 0: the Kahn walk's FIFO was empty right after it popped the node of topological index i (where topo_sort_incremental may restart the walk); same bytes as `prof` (chain_output only)
     int upd_new, upd_newe, upd_moved;  // add_alignment_block's last call: nodes / edges it created, and whether some node's heaviest out-edge is another one now
     int inc_off;                       // LCD_DBG bit 1024: every topology change takes the full re-sort (test switch)
+#ifdef LCD_X_PHASESTAT
+    unsigned long long pstat[24];      // (experiment) ticks inside the per-read phases, see LCD_PT
+#endif
 #ifdef LCD_X_INCSTAT
     unsigned inc_stat[13];             // (experiment) topo_sort_incremental: refusals by reason 0..9, successes, nodes walked, pieces
 #endif
@@ -200,6 +203,15 @@ __device__ __forceinline__ void lds_barrier() {
 __device__ __forceinline__ int glb_ld(const int *p);
 __device__ __forceinline__ int glb_ld_u8(const uint8_t *p);
 __device__ __forceinline__ int usgpr(const int v);
+
+// (experiment, -DLCD_X_PHASESTAT) ticks between two marks of a per-read phase, outstanding memory operations drained at each mark
+#ifdef LCD_X_PHASESTAT
+#define LCD_PT0() long long pt_ = clock64()
+#define LCD_PT(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = clock64(); g.pstat[k] += (unsigned long long)(t_ - pt_); pt_ = t_; } while (0)
+#else
+#define LCD_PT0() do { } while (0)
+#define LCD_PT(k) do { } while (0)
+#endif
 
 // ---------------- graph mutation (thread 0 only) ----------------
 __device__ int add_node(Ctx &g, uint8_t b) {
@@ -342,6 +354,7 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
     constexpr int U = 4;
     // phase 1: the node each entry lands on: existing (>= 0), new and aligned to an anchor, or plain new
     int carry = 0;
+    LCD_PT0();
     for (int base = 0; base < n_cig; base += U * NT) {
         int isnew[U], flag[U], T[U];
         int qp[U], nd[U];
@@ -366,6 +379,7 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
                 } else { isnew[u] = 1; flag[u] = -1; }
             }
         }
+        LCD_PT(0);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (base + u * NT >= n_cig) break; // (uniform)
@@ -375,10 +389,12 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
             if (i < n_cig) { g.aa_node[i] = isnew[u] ? g.n_node + carry + rank : T[u]; g.aa_flag[i] = flag[u]; }
             carry += tot;
         }
+        LCD_PT(1);
     }
     const int n_new = carry;
     if (g.n_node + n_new > g.node_cap) { g.status = LCD_ERR_NODES; return 0; }
     __syncthreads();
+    LCD_PT(2);
     // phase 2: new nodes
     if (n_new > 0)
     for (int i = tid; i < n_cig; i += NT) {
@@ -388,6 +404,7 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
         g.base[id] = seq[g.cig_qpos[i]]; g.out_head[id] = g.out_tail[id] = g.in_head[id] = g.in_tail[id] = -1; g.nin[id] = 0;
         if (flag >= 0) { g.aligned[id] = g.aligned[flag]; g.aligned[flag] = id; } else g.aligned[id] = id;
     }
+    LCD_PT(3);
     // phase 3: edges j = 0..n_cig (from path[j-1] to path[j]); existing ones gain weight + read id, the others are numbered
     carry = 0;
     int heavy_moved = 0;
@@ -409,6 +426,7 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
         int e0w[U], e0t[U], e0n[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) { e0w[u] = 0; e0t[u] = -1; e0n[u] = -1; if (oh[u] >= 0) { e0w[u] = g.e_w[oh[u]]; e0t[u] = g.e_to[oh[u]]; e0n[u] = g.e_next_out[oh[u]]; } }
+        LCD_PT(4);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!chk[u]) continue;
@@ -429,6 +447,7 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
                 if (found != amax && (wn > wmax || (wn == wmax && pos_found < pos_amax))) heavy_moved = 1;
             }
         }
+        LCD_PT(5);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (base + u * NT > n_cig) break; // (uniform)
@@ -438,6 +457,7 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
             if (j <= n_cig) g.aa_eid[j] = need[u] ? g.n_edge + carry + rank : -1;
             carry += tot;
         }
+        LCD_PT(6);
     }
     const int n_newe = carry;
     if (g.n_edge + n_newe > g.edge_cap) { g.status = LCD_ERR_EDGES; return 0; }
@@ -459,6 +479,7 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
     }
     g.n_node += n_new; g.n_edge += n_newe;
     const int moved = __syncthreads_or(heavy_moved);
+    LCD_PT(7);
     g.upd_new = n_new; g.upd_newe = n_newe; g.upd_moved = moved;
     return (n_new || n_newe) ? 2 : moved ? 1 : 3;
 }
@@ -889,34 +910,46 @@ __device__ __attribute__((noinline)) bool topo_sort_incremental(Ctx &g, Smem &sm
     int *seg = el + INC_EL;                         // per repeated stretch: q, ic, first entry of el, entries, new nodes emitted before / after
     int *qring = seg + 6 * INC_SEG;
     int *seen = qring + INC_Q;                      // targets of the out-edges of the node at hand that have been taken (8)
+    LCD_PT0();
     for (int i = tid; i < bm_words; i += NT) bm[i] = 0;
     __syncthreads();
     if (wave == 0) {
         int fail = 0;
         int n_ml = 0, n_nj = 0;
         // ---- what the read added, in path order: edge j runs from path[j - 1] (beg_node) to path[j] (end_node) ----
-        for (int base = 0; base <= n_cig && !fail; base += 64) {
-            const int j = base + lane;
-            int has0 = 0, v0 = 0, has1 = 0, v1 = 0, isn = 0;
-            if (j <= n_cig) {
-                const int eid = g.aa_eid[j];
-                const int fl = j < n_cig ? g.aa_flag[j] : -2, flp = j > 0 ? g.aa_flag[j - 1] : -2;
-                isn = fl != -2;
+        for (int base4 = 0; base4 <= n_cig && !fail; base4 += 256) {
+            int eid4[4], fl4[4], flp4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { // (the loads of four 64-entry pieces in flight; an entry of the path array costs one trip)
+                const int j = base4 + u * 64 + lane;
+                eid4[u] = -1; fl4[u] = -2; flp4[u] = -2;
+                if (j <= n_cig) { eid4[u] = g.aa_eid[j]; if (j < n_cig) fl4[u] = g.aa_flag[j]; if (j > 0) flp4[u] = g.aa_flag[j - 1]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int base = base4 + u * 64;
+                if (base > n_cig || fail) break; // (uniform)
+                const int j = base + lane;
+                const int eid = eid4[u], fl = fl4[u], flp = flp4[u];
+                if (!__any(eid >= 0 || fl != -2)) continue; // nothing added on these 64 entries (uniform)
+                int has0 = 0, v0 = 0, has1 = 0, v1 = 0;
+                const int isn = fl != -2;
                 if (eid >= 0 && flp == -2) { const int from = j == 0 ? beg_node : g.aa_node[j - 1]; v0 = g.node2idx[from]; has0 = 1; }
                 if (fl >= 0) { v1 = g.node2idx[fl] - 1; has1 = 1; }
+                const int cnt = has0 + has1, incl = scan_add(cnt), tot = lane63(incl);
+                if (n_ml + tot > INC_ML) { fail = 1; break; }
+                const int off = n_ml + incl - cnt;
+                if (has0) ml[off] = v0;
+                if (has1) ml[off + has0] = v1;
+                n_ml += tot;
+                const unsigned long long mn = __ballot(isn != 0);
+                if (n_nj + __popcll(mn) > INC_NEW) { fail = 2; break; }
+                if (isn) newj[n_nj + __popcll(mn & ((1ull << lane) - 1))] = j;
+                n_nj += __popcll(mn);
             }
-            const int cnt = has0 + has1, incl = scan_add(cnt), tot = lane63(incl);
-            if (n_ml + tot > INC_ML) { fail = 1; break; }
-            const int off = n_ml + incl - cnt;
-            if (has0) ml[off] = v0;
-            if (has1) ml[off + has0] = v1;
-            n_ml += tot;
-            const unsigned long long mn = __ballot(isn != 0);
-            if (n_nj + __popcll(mn) > INC_NEW) { fail = 2; break; }
-            if (isn) newj[n_nj + __popcll(mn & ((1ull << lane) - 1))] = j;
-            n_nj += __popcll(mn);
         }
         if (!fail && n_nj != n_new) fail = 3;
+        LCD_PT(15);
         auto LD = [&](const int *p) { return usgpr(glb_ld(p)); };
         auto largest_cut = [&](const int p) { // largest i <= p with cut[i] (-1: none within 256 indices)
             for (int base = p, it = 0; it < 4 && base >= 0; ++it, base -= 64) {
@@ -983,6 +1016,7 @@ __device__ __attribute__((noinline)) bool topo_sort_incremental(Ctx &g, Smem &sm
             ++n_seg; ic_prev = ic;
         }
         if (!fail && D != n_new) fail = 9;
+        LCD_PT(16);
         if (lane == 0) { sm.bc[5] = fail; sm.bc[4] = n_seg; sm.bc[3] = n_nj; sm.bc[2] = n_el; }
     }
     __syncthreads();
@@ -1011,6 +1045,7 @@ __device__ __attribute__((noinline)) bool topo_sort_incremental(Ctx &g, Smem &sm
         for (int t = tid; t < cnt; t += NT) { const int w = el[off + t], v = w & 0xffff, pos = q + d0 + t; g.idx2node[pos] = v; g.node2idx[v] = pos; g.cut[pos] = (uint8_t)(w >> 16); }
         __syncthreads();
     }
+    LCD_PT(17);
     // ---- remain of the new nodes, last one first (each has one out-edge: to the next node of the read's path) ----
     if (wave == 0) {
         int last_x = -1, last_r = 0;
@@ -1024,6 +1059,7 @@ __device__ __attribute__((noinline)) bool topo_sort_incremental(Ctx &g, Smem &sm
     }
     g.mm_valid = 0;
     __syncthreads();
+    LCD_PT(18);
     return true;
 }
 
@@ -1216,14 +1252,77 @@ constexpr int LCD_GUARD = LCD_NEG * 2; // out-of-band filler: (guard + anything 
 // predecessors + edge bonus).  Also marks (imap bit 1) every row whose VALUES must outlive the LDS ring: a predecessor more
 // than K rows back, or a predecessor of the end node; and fills pd[] (LDS, optional) with the distance to each row's first
 // predecessor for the speculative backtrack.
+// Reachability map of a sub-graph [bi, ei] (oracle/poa.c align_to_subgraph: a row counts if a path from the first row reaches it inside the range; the last row always
+// counts): reach[x] = OR over x's predecessors p >= bi of reach[p].  It was one lane pushing flags row by row -- four dependent trips to HBM per row, ~8 M ticks for a
+// 650-row graph, and with 3 % of the reads partial-cover ones that was 11 % of the K1 chains' time (round 6, -DLCD_X_PHASESTAT).  Here wavefront 0 takes 64 rows at a
+// time (lane = row): every lane fetches its row's first two predecessors' indices in parallel, flags of earlier blocks come from a bitmap in LDS, and inside the block
+// rows that hang on the row before them (the backbone) are filled a run at a time with shifts of a 64-bit mask; only the other rows are taken one by one.
+// `rb`: 8 bytes per 64 rows in LDS (the ring's place: nothing lives there before the rows start).  Called by wavefront 0 only; writes g.imap[bi..ei].
+__device__ __attribute__((noinline)) void reach_map_wave0(const Ctx &g, const int bi, const int ei, unsigned long long *rb) {
+    const int lane = threadIdx.x & 63;
+    for (int base = bi, blk = 0; base <= ei; base += 64, ++blk) {
+        const int row = base + lane;
+        const bool valid = row <= ei;
+        int p0 = -1, p1 = -1, n1 = -1;
+        if (valid) {
+            const int v = g.idx2node[row];
+            const int ih = g.in_head[v];
+            if (ih >= 0) {
+                const int f0 = g.e_from[ih], n0 = g.e_next_in[ih];
+                p0 = g.node2idx[f0];
+                if (n0 >= 0) { const int f1 = g.e_from[n0]; n1 = g.e_next_in[n0]; p1 = g.node2idx[f1]; }
+            }
+        }
+        if (p0 < bi) p0 = -1; // (a predecessor before the range's first row does not count)
+        if (p1 < bi) p1 = -1;
+        auto outside = [&](const int p) { return p >= 0 && p < base && ((rb[(p - bi) >> 6] >> ((p - bi) & 63)) & 1ull) != 0; };
+        const bool ext = valid && (row == bi || row == ei || outside(p0) || outside(p1));
+        const bool chain = valid && lane > 0 && p0 == row - 1 && p1 < 0 && n1 < 0;
+        const bool odd = valid && !chain && (p0 >= base || p1 >= base || n1 >= 0);
+        const unsigned long long C = __ballot(chain);
+        unsigned long long O = __ballot(odd), R = __ballot(ext);
+        auto flood = [&](unsigned long long r) { // set bits run up through consecutive rows of C
+            unsigned long long m = C;
+            r |= (r << 1) & m; m &= m << 1;
+            r |= (r << 2) & m; m &= m << 2;
+            r |= (r << 4) & m; m &= m << 4;
+            r |= (r << 8) & m; m &= m << 8;
+            r |= (r << 16) & m; m &= m << 16;
+            r |= (r << 32) & m;
+            return r;
+        };
+        while (O) {
+            const int k = (int)__builtin_ctzll(O);
+            O &= O - 1;
+            if ((R >> k) & 1ull) continue;
+            R = flood(R);
+            const int q0 = __builtin_amdgcn_readlane(p0, k), q1 = __builtin_amdgcn_readlane(p1, k);
+            bool hit = (q0 >= base && ((R >> (q0 - base)) & 1ull)) || (q1 >= base && ((R >> (q1 - base)) & 1ull));
+            for (int e = __builtin_amdgcn_readlane(n1, k); e >= 0 && !hit; e = usgpr(glb_ld(g.e_next_in + e))) { // (a third, fourth ... in-edge: rare)
+                const int p = usgpr(glb_ld(g.node2idx + usgpr(glb_ld(g.e_from + e))));
+                if (p < bi) continue;
+                hit = p >= base ? ((R >> (p - base)) & 1ull) != 0 : ((rb[(p - bi) >> 6] >> ((p - bi) & 63)) & 1ull) != 0;
+            }
+            if (hit) R |= 1ull << k;
+        }
+        R = flood(R);
+        if (lane == 0) rb[blk] = R;
+        if (valid) g.imap[row] = (uint8_t)((R >> lane) & 1ull);
+    }
+}
+
 template <int NT>
-__device__ void build_plan(Ctx &g, Smem &sm, const int bi, const int ei, const int remain_end, uint8_t *pd, const int K) {
+__device__ void build_plan(Ctx &g, Smem &sm, const int bi, const int ei, const int remain_end, uint8_t *pd, const int K, int *ring, const int ring_bytes) {
     constexpr int NW = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = g.n_node;
+    LCD_PT0();
     if (bi == 0 && ei == n - 1) {
         for (int i = tid; i < n; i += NT) g.imap[i] = 1;
     } else {
+        if (!(g.topo_mode & 1) && (size_t)((ei - bi) / 64 + 1) * 8 <= (size_t)ring_bytes) { // (LCD_DBG bit 64, as for the re-sort: the serial form)
+            if (tid < 64) reach_map_wave0(g, bi, ei, (unsigned long long *)ring);
+        } else {
         for (int i = bi + tid; i <= ei; i += NT) g.imap[i] = 0;
         __syncthreads();
         if (tid == 0) {
@@ -1236,9 +1335,11 @@ __device__ void build_plan(Ctx &g, Smem &sm, const int bi, const int ei, const i
                 }
             }
         }
+        }
     }
     for (int e = tid; e < g.n_edge; e += NT) g.e_slot[e] = -1;
     __syncthreads();
+    LCD_PT(8);
     // U rows per thread in flight (see batched_for): a row's chain is index -> node -> first in-edge -> its source -> that row's index -> its reachability, six
     // dependent loads, and nearly every row has one or two in-edges -- those are taken straight-line for all U rows together and kept for the second pass
     constexpr int U = 4;
@@ -1249,13 +1350,17 @@ __device__ void build_plan(Ctx &g, Smem &sm, const int bi, const int ei, const i
             int vv[U], im[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) { const int idx = base + u * NT + tid, ci = idx <= ei ? idx : ei; im[u] = g.imap[ci]; vv[u] = g.idx2node[ci]; }
+            LCD_PT(9);
 #pragma unroll
             for (int u = 0; u < U; ++u) { ih[u] = g.in_head[vv[u]]; rem[u] = g.remain[vv[u]]; vbs[u] = g.base[vv[u]]; }
+            LCD_PT(10);
             int f0[U], f1[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) { const int c = ih[u] >= 0 ? ih[u] : 0; f0[u] = g.e_from[c]; n0[u] = ih[u] >= 0 ? g.e_next_in[c] : -1; w0[u] = g.e_w[c]; }
+            LCD_PT(11);
 #pragma unroll
             for (int u = 0; u < U; ++u) { const int c = n0[u] >= 0 ? n0[u] : 0; p0[u] = g.node2idx[f0[u]]; f1[u] = g.e_from[c]; n1[u] = n0[u] >= 0 ? g.e_next_in[c] : -1; w1[u] = g.e_w[c]; }
+            LCD_PT(12);
             int i0[U], i1[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) { p1[u] = g.node2idx[f1[u]]; i0[u] = g.imap[p0[u] >= 0 && p0[u] < n ? p0[u] : 0]; }
@@ -1271,6 +1376,7 @@ __device__ void build_plan(Ctx &g, Smem &sm, const int bi, const int ei, const i
                 if (v[u] >= 0) for (int e = n1[u]; e >= 0; e = g.e_next_in[e]) { const int pi = g.node2idx[g.e_from[e]]; cnt[u] += (pi >= bi && pi < ei && g.imap[pi]); }
             }
         }
+        LCD_PT(13);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (base + u * NT > ei) break; // (uniform)
@@ -1310,6 +1416,7 @@ __device__ void build_plan(Ctx &g, Smem &sm, const int bi, const int ei, const i
             carry += tot;
             if constexpr (NW > 1) lds_barrier<NT>();
         }
+        LCD_PT(14);
     }
     if (tid == 0) { g.pl_start[ei + 1] = carry; g.pl_start[ei + 2] = carry; g.pl_start[ei + 3] = carry; }
     __syncthreads();
@@ -4204,10 +4311,22 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
     if (g.plan_valid && g.plan_bi == bi && g.plan_ei == ei && g.plan_rend == remain_end) {
         // the graph has the nodes, edges, order and `remain` it had when this plan was built (the reads since only added weight, and add_alignment_block patched the
         // bonuses): only the first-predecessor distances are made again -- they live in the LDS pool behind the query cache, whose place depends on the read
-        if (pd) for (int idx = bi + tid; idx <= ei; idx += NT) { const int p0 = g.pl_start[idx], np = g.pl_start[idx + 1] - p0; const int d = np > 0 ? idx - g.pl_pidx[p0] : 255; pd[idx - bi] = (uint8_t)(d < 255 ? d : 255); }
+        LCD_PT0();
+        if (pd) { // (two dependent trips per row: four rows per thread in flight)
+            for (int b = bi + tid; b <= ei; b += 4 * NT) {
+                int p0[4], np[4], pi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int idx = imin(b + u * NT, ei); p0[u] = g.pl_start[idx]; np[u] = g.pl_start[idx + 1] - p0[u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pi[u] = g.pl_pidx[np[u] > 0 ? p0[u] : 0];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int idx = b + u * NT; if (idx <= ei) { const int d = np[u] > 0 ? idx - pi[u] : 255; pd[idx - bi] = (uint8_t)(d < 255 ? d : 255); } }
+            }
+        }
         __syncthreads();
+        LCD_PT(19);
     } else {
-        build_plan<NT>(g, sm, bi, ei, remain_end, pd, (NT == 64 || g.solo) ? g.plan_k : K);
+        build_plan<NT>(g, sm, bi, ei, remain_end, pd, (NT == 64 || g.solo) ? g.plan_k : K, ring, (int)((uint8_t *)sseq - (uint8_t *)ring));
         g.plan_valid = 1; g.plan_bi = bi; g.plan_ei = ei; g.plan_rend = remain_end;
     }
     g.t_bp += (unsigned long long)(clock64() - tb0); } // (rows to spill: those with a successor further away than the windowed rows' ring -- the smallest ring a window of this chain may run with)
@@ -4874,6 +4993,9 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
 #ifdef LCD_X_INCSTAT
     for (int k_ = 0; k_ < 13; ++k_) g.inc_stat[k_] = 0;
 #endif
+#ifdef LCD_X_PHASESTAT
+    for (int k_ = 0; k_ < 24; ++k_) g.pstat[k_] = 0;
+#endif
     g.cut = g.prof; g.cut_valid = 0; g.upd_new = g.upd_newe = g.upd_moved = 0; g.inc_off = (sc.dbg >> 10) & 1;
     g.mm_valid = 0; g.topo_mode = (sc.dbg >> 6) & 7; g.solo = NT == 256 ? ch.solo : 0; g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0; g.t_bp = 0; g.t_setup = 0;
     // The long chains are the latency of a submission at every depth, and next to 8 - 12 other wavefronts of their CU each of theirs issues when the arbiter gets round
@@ -4983,6 +5105,11 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
         out.t_bp = g.t_bp; out.t_add = t_add; out.t_sort = t_graph - t_add; out.t_setup = g.t_setup;
 #ifdef LCD_X_ROWSTAT
         out.t_bt = chg_stat_;
+#endif
+#ifdef LCD_X_PHASESTAT
+        if ((cid & 127) == 0 && NT == 64) printf("[pt] chain %d mode %d reads %d nodes %d total %llu : %llu %llu %llu %llu %llu %llu %llu %llu | %llu %llu %llu %llu %llu %llu %llu | %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", cid, ch.mode, n_seq, g.n_node, (unsigned long long)(clock64() - t_begin),
+            g.pstat[0], g.pstat[1], g.pstat[2], g.pstat[3], g.pstat[4], g.pstat[5], g.pstat[6], g.pstat[7], g.pstat[8], g.pstat[9], g.pstat[10], g.pstat[11], g.pstat[12], g.pstat[13], g.pstat[14],
+            g.pstat[15], g.pstat[16], g.pstat[17], g.pstat[18], g.pstat[19], g.pstat[20], g.pstat[21], g.pstat[22], g.pstat[23]);
 #endif
 #ifdef LCD_X_INCSTAT
         if ((cid & 511) == 0) printf("[inc] chain %d mode %d reads %d nodes %d: refused pre %u ml %u new %u cnt %u cut %u cap %u q %u dry %u el %u left %u | ok %u walked %u pieces %u\n", cid, ch.mode, n_seq, g.n_node,
