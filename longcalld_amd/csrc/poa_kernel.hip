@@ -200,6 +200,7 @@ __device__ __forceinline__ void lds_barrier() {
     if (NT > 64) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("" ::: "memory");
 }
+#define LCD_RL(v, t) __builtin_amdgcn_readlane((v), (t))
 __device__ __forceinline__ int glb_ld(const int *p);
 __device__ __forceinline__ int glb_ld_u8(const uint8_t *p);
 __device__ __forceinline__ int usgpr(const int v);
@@ -891,28 +892,33 @@ __device__ __attribute__((noinline)) void compute_mm(Ctx &g) {
 //   * anything unexpected (no cut in reach, too many nodes walked, a new node never emitted, a queue that runs dry) returns false: the caller takes the full re-sort.
 // `remain` of a new node is that of its only successor plus one; an old node's heaviest out-edge cannot become a new edge (weight 1, last in its list), and
 // add_alignment_block says when a weight increment moved one (upd_moved: the caller then re-makes `remain` as after a weights-only read).
-constexpr int INC_ML = 64, INC_EL = 256, INC_SEG = 16, INC_Q = 32, INC_NEW = 64, INC_MAXN = 16384;
+// The walk itself runs on REGISTERS: the rows of a 64-row window of the old order (lane = row: node, cut flag, up to three out-edge targets, up to three in-edge
+// sources, next node of the aligned ring) and the new nodes (lane = new node: its one source, its one target, its ring) are fetched by all lanes at once -- six
+// dependent trips for the whole window instead of five per node walked -- with every reference already turned into "old index" or "new node t"; the serial part then
+// reads them by v_readlane and keeps the popped sets as two 64-bit masks.  A node with a fourth edge, or a piece that outgrows its window twice, hands the graph to the
+// full re-sort; the far end of a long deletion edge (an old node beyond the window whose readiness is asked) is looked up in HBM.
+constexpr int INC_Q = 32, INC_NEW = 128, INC_NEWREF = 1 << 20;
+typedef __attribute__((address_space(3))) int inc_lds_i32; // (the lists live in the workgroup's LDS pool, addressed by byte offset: ds_read / ds_write, not flat operations)
+__device__ __forceinline__ int inc_ld(const unsigned o) { return *(const inc_lds_i32 *)(uintptr_t)o; }
+__device__ __forceinline__ void inc_st(const unsigned o, const int v) { *(inc_lds_i32 *)(uintptr_t)o = v; }
 template <int NT>
-__device__ __attribute__((noinline)) bool topo_sort_incremental(Ctx &g, Smem &sm, int *lds_pool, const int beg_node, const int end_node, const int n_cig) {
+__device__ __attribute__((noinline)) bool topo_sort_incremental(Ctx &g, Smem &sm, const unsigned pool_off, const int beg_node, const int end_node, const int n_cig) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = g.n_node, n_new = g.upd_new, n_old = n - n_new;
-    const int bm_words = (n + 31) >> 5;
-    if (!g.cut_valid || g.inc_off || n >= INC_MAXN || n_new > INC_NEW || n_old < 3 || bm_words + INC_ML + INC_NEW + INC_EL + 6 * INC_SEG + INC_Q + 16 > g.pool_words) {
+    // the pool's words (free between two reads) go to the lists below: 1/8 to the places to revisit, 3/8 to the pieces' table (6 words each), 1/2 to the nodes emitted
+    const int inc_free = g.pool_words - INC_Q - 8;
+    const int INC_ML = imin(1024, inc_free / 8), INC_SEG = imin(512, inc_free * 3 / 8 / 6), INC_EL = imin(4096, inc_free - INC_ML - 6 * INC_SEG);
+    if (!g.cut_valid || g.inc_off || n >= 65535 || n_new > INC_NEW || n_old < 3 || INC_ML < 32 || INC_SEG < 16 || INC_EL < 128) {
 #ifdef LCD_X_INCSTAT
         g.inc_stat[0] += 1;
 #endif
         return false;
     }
-    unsigned *bm = (unsigned *)lds_pool;            // nodes the walks below have popped
-    int *ml = lds_pool + bm_words;                  // where the walk has to be repeated: old indices, in path order (ascending)
-    int *newj = ml + INC_ML;                        // path positions of the new nodes
-    int *el = newj + INC_NEW;                       // the nodes the walks emitted: id | (FIFO empty after the pop) << 16
-    int *seg = el + INC_EL;                         // per repeated stretch: q, ic, first entry of el, entries, new nodes emitted before / after
-    int *qring = seg + 6 * INC_SEG;
-    int *seen = qring + INC_Q;                      // targets of the out-edges of the node at hand that have been taken (8)
+    const unsigned ml_o = pool_off;                      // where the walk has to be repeated: old indices, in path order (ascending)
+    const unsigned el_o = ml_o + 4u * (unsigned)INC_ML;  // the nodes the walks emitted: id | (FIFO empty after the pop) << 16
+    const unsigned seg_o = el_o + 4u * (unsigned)INC_EL; // per repeated piece: q, ic, first entry of el, entries, new nodes emitted before / after
+    const unsigned q_o = seg_o + 24u * (unsigned)INC_SEG;
     LCD_PT0();
-    for (int i = tid; i < bm_words; i += NT) bm[i] = 0;
-    __syncthreads();
     if (wave == 0) {
         int fail = 0;
         int n_ml = 0, n_nj = 0;
@@ -925,32 +931,34 @@ __device__ __attribute__((noinline)) bool topo_sort_incremental(Ctx &g, Smem &sm
                 eid4[u] = -1; fl4[u] = -2; flp4[u] = -2;
                 if (j <= n_cig) { eid4[u] = g.aa_eid[j]; if (j < n_cig) fl4[u] = g.aa_flag[j]; if (j > 0) flp4[u] = g.aa_flag[j - 1]; }
             }
+            int v04[4], v14[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { // (and the old indices the entries refer to, for all four pieces before the first list is written)
+                const int j = base4 + u * 64 + lane;
+                v04[u] = -1; v14[u] = -1;
+                if (eid4[u] >= 0 && flp4[u] == -2) { const int from = j == 0 ? beg_node : g.aa_node[j - 1]; v04[u] = g.node2idx[from]; }
+                if (fl4[u] >= 0) v14[u] = g.node2idx[fl4[u]] - 1;
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int base = base4 + u * 64;
                 if (base > n_cig || fail) break; // (uniform)
-                const int j = base + lane;
                 const int eid = eid4[u], fl = fl4[u], flp = flp4[u];
                 if (!__any(eid >= 0 || fl != -2)) continue; // nothing added on these 64 entries (uniform)
-                int has0 = 0, v0 = 0, has1 = 0, v1 = 0;
-                const int isn = fl != -2;
-                if (eid >= 0 && flp == -2) { const int from = j == 0 ? beg_node : g.aa_node[j - 1]; v0 = g.node2idx[from]; has0 = 1; }
-                if (fl >= 0) { v1 = g.node2idx[fl] - 1; has1 = 1; }
+                const int has0 = (eid >= 0 && flp == -2) ? 1 : 0, has1 = fl >= 0 ? 1 : 0;
                 const int cnt = has0 + has1, incl = scan_add(cnt), tot = lane63(incl);
                 if (n_ml + tot > INC_ML) { fail = 1; break; }
                 const int off = n_ml + incl - cnt;
-                if (has0) ml[off] = v0;
-                if (has1) ml[off + has0] = v1;
+                if (has0) inc_st(ml_o + 4u * (unsigned)off, v04[u]);
+                if (has1) inc_st(ml_o + 4u * (unsigned)(off + has0), v14[u]);
                 n_ml += tot;
-                const unsigned long long mn = __ballot(isn != 0);
-                if (n_nj + __popcll(mn) > INC_NEW) { fail = 2; break; }
-                if (isn) newj[n_nj + __popcll(mn & ((1ull << lane) - 1))] = j;
-                n_nj += __popcll(mn);
+                n_nj += (int)__popcll(__ballot(fl != -2));
             }
         }
         if (!fail && n_nj != n_new) fail = 3;
         LCD_PT(15);
         auto LD = [&](const int *p) { return usgpr(glb_ld(p)); };
+        auto ref_of = [&](const int x) { return x < n_old ? g.node2idx[x] : INC_NEWREF + (x - n_old); }; // (per lane: a gather)
         auto largest_cut = [&](const int p) { // largest i <= p with cut[i] (-1: none within 256 indices)
             for (int base = p, it = 0; it < 4 && base >= 0; ++it, base -= 64) {
                 const int i = base - lane;
@@ -960,106 +968,269 @@ __device__ __attribute__((noinline)) bool topo_sort_incremental(Ctx &g, Smem &sm
             }
             return -1;
         };
-        int k = 0, D = 0, n_el = 0, n_seg = 0, ic_prev = -1;
-        while (k < n_ml && !fail) {
-            const int q = largest_cut(ml[k]);
-            if (q <= ic_prev || n_seg >= INC_SEG || n_el >= INC_EL) { fail = q <= ic_prev ? 4 : 5; break; }
-            int cur = LD(g.idx2node + q);
-            bm[cur >> 5] |= 1u << (cur & 31);
-            const int off = n_el, d0 = D;
-            el[n_el++] = cur | (1 << 16);
-            int m_old = 1, maxe = q, qh = 0, qt = 0, ic = -1;
-            auto is_done = [&](const int f) { return ((bm[f >> 5] >> (f & 31)) & 1u) != 0 || (f < n_old && LD(g.node2idx + f) <= q); };
-            // the oracle's counters: a node's in-degree reaches 0 when its LAST in-edge is taken, and the out-edges of the node at hand are taken one by one -- an in-edge
-            // from a popped node has been taken, one from the node at hand only if it comes earlier in that node's out-list (`seen`)
-            int n_seen = 0;
-            auto ready = [&](const int w) {
-                for (int e = LD(g.in_head + w); e >= 0;) {
-                    const int f = LD(g.e_from + e), en = LD(g.e_next_in + e);
-                    if (f == cur) { bool hit = false; for (int t = 0; t < n_seen; ++t) hit = hit || usgpr(seen[t]) == w; if (!hit) return false; }
-                    else if (!is_done(f)) return false;
-                    e = en;
-                }
-                return true;
-            };
-            for (;;) {
-                n_seen = 0;
-                for (int e = LD(g.out_head + cur); e >= 0 && !fail;) {
-                    const int w = LD(g.e_to + e);
-                    e = LD(g.e_next_out + e);
-                    if (n_seen >= 8) { fail = 6; break; }
-                    seen[n_seen++] = w;
-                    if (!ready(w)) continue;
-                    bool ok = true; int na = 0;
-                    for (int a = LD(g.aligned + w); a != w; a = LD(g.aligned + a)) { if (++na > 8 || !ready(a)) { ok = false; break; } }
-                    if (!ok) continue;
-                    if (qt - qh + na + 1 > INC_Q) { fail = 6; break; }
-                    qring[qt++ & (INC_Q - 1)] = w;
-                    for (int a = LD(g.aligned + w); a != w; a = LD(g.aligned + a)) qring[qt++ & (INC_Q - 1)] = a;
-                }
-                if (fail || qh == qt || n_el >= INC_EL) { if (!fail) fail = qh == qt ? 7 : 8; break; } // (a FIFO that runs dry before the walk is back on the old order: not a state the argument above covers)
-                cur = usgpr(qring[qh++ & (INC_Q - 1)]);
-                bm[cur >> 5] |= 1u << (cur & 31);
-                const bool empty = qh == qt;
-                el[n_el++] = cur | ((int)empty << 16);
-                int oi = -1;
-                if (cur < n_old) { oi = LD(g.node2idx + cur); ++m_old; maxe = imax(maxe, oi); } else ++D;
-                if (empty && oi >= 0 && oi == maxe && maxe == q + m_old - 1 && usgpr(glb_ld_u8(g.cut + oi)) != 0) {
-                    while (k < n_ml && usgpr(ml[k]) < oi) ++k;
-                    if (k < n_ml && largest_cut(usgpr(ml[k])) == oi) continue; // the next thing added starts right here: the walk goes on
-                    ic = oi;
-                    break;
+        // ---- the new nodes' records: lane t (and t + 64) = node n_old + t: one in-edge, one out-edge (the read's path enters and leaves it once), and `remain` of the
+        //      old node its out-edge leads to ----
+        int Nf[2], Nt[2], Nal[2], Nrm[2];
+        {
+            int nbad = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                Nf[h] = -1; Nt[h] = -1; Nal[h] = -1; Nrm[h] = LCD_NEG; // (LCD_NEG: the out-edge leads to the next new node; remain of the sink is -1)
+                const int t = h * 64 + lane;
+                if (t < n_new) {
+                    const int x = n_old + t;
+                    const int ih = g.in_head[x], oh = g.out_head[x], al = g.aligned[x];
+                    if (ih < 0 || oh < 0) nbad = 1;
+                    else {
+                        const int f = g.e_from[ih], to = g.e_to[oh];
+                        if (g.e_next_in[ih] >= 0 || g.e_next_out[oh] >= 0) nbad = 1;
+                        Nf[h] = ref_of(f); Nt[h] = ref_of(to);
+                        if (to < n_old) Nrm[h] = g.remain[to]; else if (to != x + 1) nbad = 1; // (the next new node of the path has the next id)
+                    }
+                    if (al != x) Nal[h] = ref_of(al);
                 }
             }
+            if (__any(nbad) && !fail) fail = 3;
+        }
+        // ---- the window: lane l = old row B + l ----
+        int B = 0, Wv = -1, Wcf = 0, Wno = 0, Wt0 = -1, Wt1 = -1, Wt2 = -1, Wox = -1, Wni = 0, Wf0 = -1, Wf1 = -1, Wf2 = -1, Wix = -1, Wal = -1;
+        auto gather = [&](const int base) {
+#ifdef LCD_X_PHASESTAT
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long tg0_ = clock64();
+#endif
+            B = base;
+            const int r = base + lane; const bool val = r < n_old;
+            int v = -1, cf = 0, oh = -1, ih = -1, al = -1;
+            if (val) { v = g.idx2node[r]; cf = glb_ld_u8(g.cut + r); }
+            if (val) { oh = g.out_head[v]; ih = g.in_head[v]; al = g.aligned[v]; }
+            int t0 = -1, t1 = -1, t2 = -1, o1 = -1, o2 = -1, o3 = -1, f0 = -1, f1 = -1, f2 = -1, i1 = -1, i2 = -1, i3 = -1;
+            if (oh >= 0) { t0 = g.e_to[oh]; o1 = g.e_next_out[oh]; }
+            if (ih >= 0) { f0 = g.e_from[ih]; i1 = g.e_next_in[ih]; }
+            if (o1 >= 0) { t1 = g.e_to[o1]; o2 = g.e_next_out[o1]; }
+            if (i1 >= 0) { f1 = g.e_from[i1]; i2 = g.e_next_in[i1]; }
+            if (o2 >= 0) { t2 = g.e_to[o2]; o3 = g.e_next_out[o2]; }
+            if (i2 >= 0) { f2 = g.e_from[i2]; i3 = g.e_next_in[i2]; }
+            Wv = v; Wcf = cf;
+            Wno = (oh >= 0) + (o1 >= 0) + (o2 >= 0) + (o3 >= 0); // (4: more than the record holds -- the fourth edge's id goes along, the list is followed in HBM from there)
+            Wni = (ih >= 0) + (i1 >= 0) + (i2 >= 0) + (i3 >= 0);
+            Wox = o3; Wix = i3;
+            Wt0 = t0 >= 0 ? ref_of(t0) : -1; Wt1 = t1 >= 0 ? ref_of(t1) : -1; Wt2 = t2 >= 0 ? ref_of(t2) : -1;
+            Wf0 = f0 >= 0 ? ref_of(f0) : -1; Wf1 = f1 >= 0 ? ref_of(f1) : -1; Wf2 = f2 >= 0 ? ref_of(f2) : -1;
+            Wal = (val && al != v) ? ref_of(al) : -1;
+#ifdef LCD_X_PHASESTAT
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g.pstat[23] += (unsigned long long)(clock64() - tg0_);
+#endif
+        };
+        struct Rec { int no, t0, t1, t2, ox, ni, f0, f1, f2, ix, al; };
+        auto rec = [&](const int ref, Rec &R) { // false: an old row outside the window
+            if (ref >= INC_NEWREF) {
+                const int t = ref - INC_NEWREF, l = t & 63;
+                R.no = 1; R.t1 = R.t2 = R.ox = -1; R.ni = 1; R.f1 = R.f2 = R.ix = -1;
+                if (t < 64) { R.t0 = LCD_RL(Nt[0], l); R.f0 = LCD_RL(Nf[0], l); R.al = LCD_RL(Nal[0], l); }
+                else { R.t0 = LCD_RL(Nt[1], l); R.f0 = LCD_RL(Nf[1], l); R.al = LCD_RL(Nal[1], l); }
+                return true;
+            }
+            if (ref < B || ref >= B + 64 || ref >= n_old) return false;
+            const int l = ref - B;
+            R.no = LCD_RL(Wno, l); R.t0 = LCD_RL(Wt0, l); R.t1 = LCD_RL(Wt1, l); R.t2 = LCD_RL(Wt2, l); R.ox = R.no > 3 ? LCD_RL(Wox, l) : -1;
+            R.ni = LCD_RL(Wni, l); R.f0 = LCD_RL(Wf0, l); R.f1 = LCD_RL(Wf1, l); R.f2 = LCD_RL(Wf2, l); R.ix = R.ni > 3 ? LCD_RL(Wix, l) : -1; R.al = LCD_RL(Wal, l);
+            return true;
+        };
+        unsigned long long Rdone = 0, Nd0 = 0, Nd1 = 0; // popped: rows of the window (every row before it is), new nodes 0..63 / 64..127
+        auto done = [&](const int ref) {
+            if (ref >= INC_NEWREF) { const int t = ref - INC_NEWREF; return (((t < 64 ? Nd0 : Nd1) >> (t & 63)) & 1ull) != 0; }
+            if (ref < B) return true;
+            if (ref >= B + 64) return false;
+            return ((Rdone >> (ref - B)) & 1ull) != 0;
+        };
+        auto upto = [&](const int l) { return l >= 63 ? ~0ull : ((2ull << l) - 1ull); }; // lanes 0..l
+        int k = 0, D = 0, n_el = 0, n_seg = 0, ic_prev = -1;
+        bool have_window = false;
+        while (k < n_ml && !fail) {
+            const int p = usgpr(inc_ld(ml_o + 4u * (unsigned)k));
+            int q;
+            if (have_window && p >= B && p < B + 64) { // (the cut flags of the window's rows are in the lanes)
+                const unsigned long long cm = __ballot(Wcf != 0) & upto(p - B);
+                q = cm ? B + 63 - (int)__builtin_clzll(cm) : largest_cut(p);
+            } else q = largest_cut(p);
+            if (q <= ic_prev || n_seg >= INC_SEG || n_el >= INC_EL) { fail = q <= ic_prev ? 4 : 5; break; }
+            if (!have_window || q < B || q + 12 > B + 64) { gather(q); have_window = true; Rdone = 0; }
+            Rdone |= upto(q - B); // (every row up to q has been popped)
+            const int k0 = k, D0 = D, el0 = n_el; const unsigned long long Ns0 = Nd0, Ns1 = Nd1;
+            int ic = -1;
+            for (int attempt = 0; attempt < 2 && !fail; ++attempt) {
+                bool exceed = false;
+                int cur = q, m_old = 1, maxe = q, qh = 0, qt = 0;
+                inc_st(el_o + 4u * (unsigned)n_el, LCD_RL(Wv, q - B) | (1 << 16)); ++n_el;
+                for (;;) {
+                    Rec C;
+                    if (!rec(cur, C)) { exceed = true; break; }
+                    // the oracle's counters: a node's in-degree reaches 0 when its LAST in-edge is taken, and the out-edges of the node at hand are taken one by one --
+                    // an in-edge from a popped node has been taken, one from the node at hand only if its target is among those already visited (`seen`: window rows and
+                    // new nodes as masks, the rare target beyond the window by value)
+                    unsigned long long seenR = 0, seenN0 = 0, seenN1 = 0; int so0 = -2, so1 = -2;
+                    auto ref1 = [&](const int x) { return x < n_old ? LD(g.node2idx + x) : INC_NEWREF + (x - n_old); }; // (uniform)
+                    auto is_seen = [&](const int w) {
+                        if (w >= INC_NEWREF) { const int t = w - INC_NEWREF; return (((t < 64 ? seenN0 : seenN1) >> (t & 63)) & 1ull) != 0; }
+                        if (w >= B && w < B + 64) return ((seenR >> (w - B)) & 1ull) != 0;
+                        return w == so0 || w == so1;
+                    };
+                    auto ready = [&](const int w) {
+                        Rec R;
+                        int e = -1;
+                        if (!rec(w, R)) { // an old node beyond the window (the far end of a long deletion edge): its in-edges from HBM
+                            if (w < B || w >= n_old) { fail = 7; return false; }
+                            e = LD(g.in_head + LD(g.idx2node + w));
+                        } else {
+                            for (int t = 0; t < R.ni && t < 3; ++t) {
+                                const int fr = t == 0 ? R.f0 : t == 1 ? R.f1 : R.f2;
+                                if (fr == cur) { if (!is_seen(w)) return false; }
+                                else if (!done(fr)) return false;
+                            }
+                            e = R.ix; // (a fourth, fifth ... in-edge: followed in HBM)
+                        }
+                        for (; e >= 0;) {
+                            const int f = LD(g.e_from + e), en = LD(g.e_next_in + e);
+                            const int fr = ref1(f);
+                            if (fr == cur) { if (!is_seen(w)) return false; }
+                            else if (!done(fr)) return false;
+                            e = en;
+                        }
+                        return true;
+                    };
+                    int emore = C.ox;
+                    for (int kk = 0; !fail && !exceed; ++kk) {
+                        int w;
+                        if (kk < 3) { if (kk >= C.no) break; w = kk == 0 ? C.t0 : kk == 1 ? C.t1 : C.t2; }
+                        else { if (emore < 0) break; w = ref1(LD(g.e_to + emore)); emore = LD(g.e_next_out + emore); }
+                        if (w >= INC_NEWREF) { const int t = w - INC_NEWREF; if (t < 64) seenN0 |= 1ull << t; else seenN1 |= 1ull << (t - 64); }
+                        else if (w >= B && w < B + 64) seenR |= 1ull << (w - B);
+                        else if (so0 == -2) so0 = w; else if (so1 == -2) so1 = w; else { fail = 6; break; }
+                        if (!ready(w)) continue;
+                        // the aligned group goes out together, the node whose in-degree just ran out first, the others in ring order -- if every member is ready
+                        bool ok = true; int na = 0;
+                        Rec Rw;
+                        if (rec(w, Rw)) {
+                            for (int a = Rw.al; a >= 0 && a != w;) {
+                                if (++na > 8) { fail = 6; ok = false; break; }
+                                if (!ready(a)) { ok = false; break; }
+                                Rec Ra;
+                                if (!rec(a, Ra)) { exceed = true; ok = false; break; }
+                                a = Ra.al;
+                            }
+                        } else { // (beyond the window: alone in its ring, or the piece needs a window further on)
+                            const int wn = LD(g.idx2node + w);
+                            if (LD(g.aligned + wn) != wn) { exceed = true; ok = false; }
+                        }
+                        if (!ok || fail) continue;
+                        if (qt - qh + na + 1 > INC_Q) { fail = 6; break; }
+                        inc_st(q_o + 4u * (unsigned)(qt++ & (INC_Q - 1)), w);
+                        if (na > 0) for (int a = Rw.al; a >= 0 && a != w;) { inc_st(q_o + 4u * (unsigned)(qt++ & (INC_Q - 1)), a); Rec Ra; rec(a, Ra); a = Ra.al; }
+                    }
+                    if (fail || exceed) break;
+                    if (qh == qt || n_el >= INC_EL) { fail = qh == qt ? 7 : 8; break; } // (a FIFO that runs dry before the walk is back on the old order: not a state the argument above covers)
+                    cur = usgpr(inc_ld(q_o + 4u * (unsigned)(qh++ & (INC_Q - 1))));
+                    const bool empty = qh == qt;
+                    int oi = -1;
+                    if (cur >= INC_NEWREF) {
+                        const int t = cur - INC_NEWREF;
+                        if (t < 64) Nd0 |= 1ull << t; else Nd1 |= 1ull << (t - 64);
+                        ++D; inc_st(el_o + 4u * (unsigned)n_el, (n_old + t) | ((int)empty << 16)); ++n_el;
+                    } else {
+                        if (cur < B || cur >= B + 64) { exceed = true; break; }
+                        Rdone |= 1ull << (cur - B);
+                        oi = cur; ++m_old; maxe = imax(maxe, oi);
+                        inc_st(el_o + 4u * (unsigned)n_el, LCD_RL(Wv, cur - B) | ((int)empty << 16)); ++n_el;
+                    }
+                    if (empty && oi >= 0 && oi == maxe && maxe == q + m_old - 1 && LCD_RL(Wcf, oi - B) != 0) {
+                        while (k < n_ml && usgpr(inc_ld(ml_o + 4u * (unsigned)k)) < oi) ++k;
+                        if (k < n_ml) { // the next thing added: does it start right here?
+                            const int p2 = usgpr(inc_ld(ml_o + 4u * (unsigned)k));
+                            int q2;
+                            if (p2 < B + 64) { const unsigned long long cm = __ballot(Wcf != 0) & upto(p2 - B); q2 = cm ? B + 63 - (int)__builtin_clzll(cm) : -1; }
+                            else q2 = largest_cut(p2);
+                            if (q2 == oi) continue; // the walk goes on
+                        }
+                        ic = oi;
+                        break;
+                    }
+                }
+                if (!exceed || fail) break;
+                // the piece left the window: once more with the window at its own start (if it is not there already)
+                if (q == B || attempt == 1) { fail = 8; break; }
+                gather(q); Rdone = 1ull;
+                k = k0; D = D0; n_el = el0; Nd0 = Ns0; Nd1 = Ns1;
+            }
             if (fail) break;
-            seg[6 * n_seg + 0] = q; seg[6 * n_seg + 1] = ic; seg[6 * n_seg + 2] = off; seg[6 * n_seg + 3] = n_el - off; seg[6 * n_seg + 4] = d0; seg[6 * n_seg + 5] = D;
+            if (ic < 0) { fail = 8; break; }
+            const unsigned so = seg_o + 24u * (unsigned)n_seg;
+            inc_st(so, q); inc_st(so + 4, ic); inc_st(so + 8, el0); inc_st(so + 12, n_el - el0); inc_st(so + 16, D0); inc_st(so + 20, D);
             ++n_seg; ic_prev = ic;
         }
         if (!fail && D != n_new) fail = 9;
         LCD_PT(16);
-        if (lane == 0) { sm.bc[5] = fail; sm.bc[4] = n_seg; sm.bc[3] = n_nj; sm.bc[2] = n_el; }
+        if (!fail) {
+            // ---- apply.  One wavefront, no barrier.  First every old row behind a piece moves up by the new nodes emitted before it (top-down, 256 rows at a time: a
+            //      chunk's stores land at or above its own rows, which have all been loaded, never on the rows of a later chunk), then the pieces' rows are written ----
+            auto piece_of = [&](const int key, const unsigned field) { // last piece whose `field` (0: q, 8: first entry of el) is <= key; -1: none  (per lane)
+                int lo = 0, hi = n_seg; // invariant: pieces [0, lo) qualify, [hi, n_seg) do not
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (inc_ld(seg_o + 24u * (unsigned)mid + field) <= key) lo = mid + 1; else hi = mid; }
+                return lo - 1;
+            };
+            if (n_new > 0) {
+                int s0 = 0;
+                while (s0 < n_seg && usgpr(inc_ld(seg_o + 24u * (unsigned)s0 + 20)) == 0) ++s0; // the first piece with a new node: nothing before its end moves
+                const int row_lo = s0 < n_seg ? usgpr(inc_ld(seg_o + 24u * (unsigned)s0 + 4)) + 1 : n_old;
+                for (int top = n_old; top > row_lo; top -= 256) {
+                    int v[4], c[4], d[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = top - 1 - (u * 64 + lane);
+                        v[u] = 0; c[u] = 0; d[u] = 0;
+                        if (i >= row_lo) {
+                            const int sp = piece_of(i, 0);
+                            if (sp >= 0 && i > inc_ld(seg_o + 24u * (unsigned)sp + 4)) d[u] = inc_ld(seg_o + 24u * (unsigned)sp + 20); // (behind piece sp; rows inside a piece are written below)
+                            if (d[u] > 0) { v[u] = g.idx2node[i]; c[u] = g.cut[i]; }
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int i = top - 1 - (u * 64 + lane); if (d[u] > 0) { g.idx2node[i + d[u]] = v[u]; g.cut[i + d[u]] = (uint8_t)c[u]; g.node2idx[v[u]] = i + d[u]; } }
+                }
+            }
+            for (int e = lane; e < n_el; e += 64) {
+                const int sp = piece_of(e, 8);
+                const unsigned so = seg_o + 24u * (unsigned)(sp < 0 ? 0 : sp);
+                const int w = inc_ld(el_o + 4u * (unsigned)e), v = w & 0xffff, pos = inc_ld(so) + inc_ld(so + 16) + (e - inc_ld(so + 8));
+                g.idx2node[pos] = v; g.node2idx[v] = pos; g.cut[pos] = (uint8_t)(w >> 16);
+            }
+            LCD_PT(17);
+            // ---- remain of the new nodes: that of the node its one out-edge leads to, plus one; runs of new nodes (an inserted stretch) from their last node backwards ----
+            if (n_new > 0) {
+                int r0 = Nrm[0] > LCD_NEG ? Nrm[0] + 1 : LCD_NEG, r1 = Nrm[1] > LCD_NEG ? Nrm[1] + 1 : LCD_NEG; // (LCD_NEG: the out-edge leads to the next new node)
+                if (lane >= n_new) r0 = 0;
+                if (64 + lane >= n_new) r1 = 0;
+                for (int it = 0; it < INC_NEW && __any(r0 == LCD_NEG || r1 == LCD_NEG); ++it) {
+                    const int n0 = __shfl_down(r0, 1), n1 = __shfl_down(r1, 1), b0 = __builtin_amdgcn_readfirstlane(r1);
+                    const int nx0 = lane == 63 ? b0 : n0;
+                    if (r0 == LCD_NEG && nx0 != LCD_NEG) r0 = nx0 + 1;
+                    if (r1 == LCD_NEG && lane < 63 && n1 != LCD_NEG) r1 = n1 + 1;
+                }
+                if (lane < n_new) g.remain[n_old + lane] = r0;
+                if (64 + lane < n_new) g.remain[n_old + 64 + lane] = r1;
+            }
+            LCD_PT(18);
+        }
+        if (lane == 0) { sm.bc[5] = fail; sm.bc[4] = n_seg; sm.bc[2] = n_el; }
     }
     __syncthreads();
     const int fail = sm.bc[5];
-    const int n_seg = sm.bc[4], n_nj = sm.bc[3];
 #ifdef LCD_X_INCSTAT
-    if (fail) g.inc_stat[fail < 10 ? fail : 0] += 1; else { g.inc_stat[10] += 1; g.inc_stat[11] += (unsigned)sm.bc[2]; g.inc_stat[12] += (unsigned)n_seg; }
+    if (fail) g.inc_stat[fail < 10 ? fail : 0] += 1; else { g.inc_stat[10] += 1; g.inc_stat[11] += (unsigned)sm.bc[2]; g.inc_stat[12] += (unsigned)sm.bc[4]; }
 #endif
     __syncthreads();
     if (fail) return false;
-    // ---- apply, back to front: the stretch behind a repeated piece moves up by the new nodes emitted so far, then the piece itself is written ----
-    constexpr int U = 4;
-    for (int s = n_seg - 1; s >= 0; --s) {
-        const int q = seg[6 * s], ic = seg[6 * s + 1], off = seg[6 * s + 2], cnt = seg[6 * s + 3], d0 = seg[6 * s + 4], d1 = seg[6 * s + 5];
-        const int lo = ic + 1, hi = s == n_seg - 1 ? n_old : seg[6 * (s + 1)];
-        if (d1 > 0)
-            for (int top = hi; top > lo; top -= U * NT) { // (top-down: a chunk's stores land at or above its own loads, never on a lower chunk's)
-                int v[U], c[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) { const int i = top - 1 - (u * NT + tid); v[u] = 0; c[u] = 0; if (i >= lo) { v[u] = g.idx2node[i]; c[u] = g.cut[i]; } }
-                __syncthreads(); // (every wavefront's loads have returned -- the barrier waits for vmcnt(0) -- before any store of the chunk)
-#pragma unroll
-                for (int u = 0; u < U; ++u) { const int i = top - 1 - (u * NT + tid); if (i >= lo) { g.idx2node[i + d1] = v[u]; g.cut[i + d1] = (uint8_t)c[u]; g.node2idx[v[u]] = i + d1; } }
-            }
-        __syncthreads();
-        for (int t = tid; t < cnt; t += NT) { const int w = el[off + t], v = w & 0xffff, pos = q + d0 + t; g.idx2node[pos] = v; g.node2idx[v] = pos; g.cut[pos] = (uint8_t)(w >> 16); }
-        __syncthreads();
-    }
-    LCD_PT(17);
-    // ---- remain of the new nodes, last one first (each has one out-edge: to the next node of the read's path) ----
-    if (wave == 0) {
-        int last_x = -1, last_r = 0;
-        for (int t = n_nj - 1; t >= 0; --t) {
-            const int j = usgpr(newj[t]);
-            const int x = usgpr(glb_ld(g.aa_node + j)), nxt = j + 1 < n_cig ? usgpr(glb_ld(g.aa_node + j + 1)) : end_node;
-            const int r = (nxt == last_x ? last_r : usgpr(glb_ld(g.remain + nxt))) + 1;
-            if (lane == 0) g.remain[x] = r;
-            last_x = x; last_r = r;
-        }
-    }
     g.mm_valid = 0;
-    __syncthreads();
-    LCD_PT(18);
     return true;
 }
 
@@ -1188,7 +1359,6 @@ __device__ void subgraph_nodes_wave0(Ctx &g, int lane, int inc_beg, int inc_end,
 }
 
 
-#define LCD_RL(v, t) __builtin_amdgcn_readlane((v), (t))
 
 // six per-symbol counters packed 3 x 21 bits into two 64-bit words (register-resident, no dynamic array indexing)
 struct Cnt6 {
@@ -5062,9 +5232,11 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
 #endif
         if (changed == 1 || changed == 2) g.plan_valid = 0; // (3: weights only, every heaviest out-edge the same -- order, remain and the plan's structure stand; its bonuses were patched)
         if (changed == 2 && g.status == LCD_OK) {
-            if (!topo_sort_incremental<NT>(g, sm, lds_pool, exc_beg, exc_end, n_cig)) topo_sort_block<NT>(g, sm, lds_pool, ch.mode == 0);
+            LCD_PT0();
+            if (!topo_sort_incremental<NT>(g, sm, lds_off(lds_pool), exc_beg, exc_end, n_cig)) { LCD_PT(22); topo_sort_block<NT>(g, sm, lds_pool, ch.mode == 0); LCD_PT(21); }
             else {
-                if (g.upd_moved) topo_remain_block<NT>(g, sm, lds_pool);
+                LCD_PT(22);
+                if (g.upd_moved) { topo_remain_block<NT>(g, sm, lds_pool); LCD_PT(20); }
 #ifdef LCD_X_VERIFY_INC
                 {   // (experiment) the full re-sort must give the same order, the same `remain`, and a cut wherever the incremental one says so (the DP region is free here)
                     const int n_ = g.n_node;
@@ -5075,12 +5247,12 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
                         topo_sort_block<NT>(g, sm, lds_pool, 0);
                         int bad = 0;
                         for (int t = tid; t < n_; t += NT) {
-                            if (sv_i2n[t] != g.idx2node[t]) bad |= 1;
+                            if (sv_i2n[t] != g.idx2node[t]) { if (!(bad & 1)) printf("[vi] chain %d read %d n %d new %d: idx %d inc %d (its n2i %d) full %d (its n2i %d)\n", cid, i, n_, g.upd_new, t, sv_i2n[t], sv_n2i[sv_i2n[t]], g.idx2node[t], g.node2idx[g.idx2node[t]]); bad |= 1; }
                             if (sv_n2i[t] != g.node2idx[t]) bad |= 2;
-                            if (sv_rem[t] != g.remain[t]) bad |= 4;
-                            if (sv_cut[t] && !g.cut[t]) bad |= 8;
+                            if (sv_rem[t] != g.remain[t]) { if (!(bad & 4)) printf("[vr] chain %d read %d n %d new %d: node %d remain inc %d full %d\n", cid, i, n_, g.upd_new, t, sv_rem[t], g.remain[t]); bad |= 4; }
+                            if (sv_cut[t] && !g.cut[t]) { if (!(bad & 8)) printf("[vc] chain %d read %d n %d new %d: idx %d cut inc %d full %d\n", cid, i, n_, g.upd_new, t, (int)sv_cut[t], (int)g.cut[t]); bad |= 8; }
                         }
-                        bad = __syncthreads_or(bad);
+                        bad = (__syncthreads_or(bad & 1) ? 1 : 0) | (__syncthreads_or(bad & 2) ? 2 : 0) | (__syncthreads_or(bad & 4) ? 4 : 0) | (__syncthreads_or(bad & 8) ? 8 : 0);
                         if (bad) { if (tid == 0) printf("[verify-inc] chain %d read %d n %d new %d newe %d: mismatch %d\n", cid, i, n_, g.upd_new, g.upd_newe, bad); g.status = LCD_ERR_TOPO; }
                         g.mm_valid = 0;
                     }
