@@ -319,12 +319,21 @@ def main():
         # The library's own RCCL communicator (lcd_comm_create over the dlopen'ed librccl): torch.distributed only carries its 128-byte id.  What RCCL reports for
         # it on every rank (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) goes into the line: evidence that N ranks really met over RCCL
         from longcalld_amd import rebalance as rb
+        # (every collective sits OUTSIDE the try blocks: a rank whose librccl call fails still takes part in the broadcast / gather the others are waiting in)
+        uid = [None]
+        if rank == 0:
+            try:
+                uid = [rb.Comm.unique_id()]
+            except Exception as e:  # noqa
+                uid = [None]
+                print(f"bench.py: ncclGetUniqueId failed on rank 0: {e!r}", file=sys.stderr, flush=True)
+        dist.broadcast_object_list(uid, src=0)
         try:
-            uid = [rb.Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
+            if uid[0] is None:
+                raise RuntimeError("no RCCL unique id from rank 0")
             lib_comm = rb.Comm(world, rank, uid[0], local_rank)
             mine = dict(lib_comm.info(), rank=rank, local_rank=local_rank, hip_device=int(torch.cuda.current_device()))
-        except Exception as e:  # noqa  (the run itself does not depend on it: the epoch falls back to torch.distributed's RCCL)
+        except Exception as e:  # noqa  (the run itself does not depend on it: the epoch falls back to torch.distributed's RCCL -- decided together, below)
             lib_comm = None
             mine = {"rank": rank, "error": repr(e)[:200]}
         allinfo = [None] * world
@@ -467,9 +476,16 @@ def main():
         # repeat, allocating or not, is listed in `repeats`); if three extra repeats do not settle it the line is not printed and the exit code says so.
         if _rep == n_rep and not any(r_["allocs"] == 0 for r_ in reps) and n_rep < (args.repeats if args.repeats > 0 else 1) + 3 and args.steps > 0 and world == 1:
             n_rep += 1   # (one rank only: with several ranks every rank must run the same number of barriers)
-    clean = [i for i in range(n_rep) if reps[i]["allocs"] == 0] if args.steps > 0 else list(range(n_rep))
-    if world > 1:   # (every rank must take the same repeat: a rank-local choice would mix regions of different repeats)
+    if world > 1 and args.steps > 0:   # (every rank must take the same repeat: the allocation counts are agreed first -- MAX over the ranks, per repeat)
+        a_t = torch.tensor([r_["allocs"] for r_ in reps], dtype=torch.int64, device=dev)
+        dist.all_reduce(a_t, op=dist.ReduceOp.MAX)
+        for r_, a_ in zip(reps, a_t.tolist()):
+            r_["allocs_any_rank"] = int(a_)
+    clean = [i for i in range(n_rep) if reps[i].get("allocs_any_rank", reps[i]["allocs"]) == 0] if args.steps > 0 else list(range(n_rep))
+    reported = "median of the repeats without an allocation"
+    if world > 1 and not clean:   # (no extra repeats with several ranks: the line says what it is)
         clean = list(range(n_rep))
+        reported = "median of all repeats (every repeat allocated device memory on some rank; extra repeats are only run with one rank)"
     if not clean:
         print(f"bench.py: every one of the {n_rep} repeats of the timed region allocated device memory (allocations per repeat: {[r_['allocs'] for r_ in reps]})", file=sys.stderr, flush=True)
         sys.exit(3)
@@ -478,6 +494,13 @@ def main():
     elapsed, rank_elapsed, allocs_timed = med["elapsed"], med["rank_elapsed"], med["allocs"]
     acc.update(med["acc"])
     dev_gb = lib.lcd_device_bytes(local_rank) / 1e9
+    # host threads of this rank beside the submitting thread: the library divides the CPUs the process may use (affinity mask, cgroup quota) by the
+    # ranks on the host, so N ranks do not each start the teams a lone process starts
+    import ctypes as _C
+    _ht = [_C.c_int(0) for _ in range(4)]
+    lib.lcd_host_threads(*[_C.byref(v) for v in _ht])
+    host_info = {"host_threads_per_rank": {"team": _ht[0].value, "arena": _ht[1].value}, "cpus_this_process_may_use": _ht[2].value, "ranks_on_this_host": _ht[3].value,
+                 "generator_processes": n_gen_procs}
     poa_kernel_ms, poa_launches, st = acc["ms"], acc["launches"], acc["st"]
     tot_regions, tot_bases = acc["regions"], acc["bases"]
     if world > 1:
@@ -762,7 +785,8 @@ def main():
             "stage_ms": {k: round(st[k], 3) for k in ("ms_anchor", "ms_poa", "ms_wfa", "ms_strings", "ms_vars", "ms_total", "ms_host", "ms_poa_kernel")} if st else None,
             "noisy_vars_stage": args.vars,
             "rank_seconds": rank_times,
-            "repeats": {"n": n_rep, "seconds": [round(r_["elapsed"], 4) for r_ in reps], "reported": "median of the repeats without an allocation", "allocations_per_repeat": [r_["allocs"] for r_ in reps]},
+            "host": host_info,
+            "repeats": {"n": n_rep, "seconds": [round(r_["elapsed"], 4) for r_ in reps], "reported": reported, "allocations_per_repeat": [r_.get("allocs_any_rank", r_["allocs"]) for r_ in reps]},
             "depth": depth,
             "device_memory": {"library_buffers_gb": round(dev_gb, 2), "allocations_inside_timed_region": int(allocs_timed)},
             "pcie_inclusive": {"upload_s": round(t_up, 4), "download_and_materialize_s": round(t_dl, 4),

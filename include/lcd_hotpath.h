@@ -84,6 +84,11 @@ long long lcd_alloc_events(void);           /* device allocations made so far by
 long long lcd_device_bytes(int device);     /* bytes those buffers hold on a device right now */
 int lcd_set_thread_device(int device);
 const char *lcd_last_error(void);
+/* Host threads this process uses beside the calling thread: `team` = threads of a submission's short parallel loops (LCD_HOST_TEAM), `arena_threads` = threads that lay
+ * results out on the host (LCD_ARENA_THREADS).  Their defaults are the CPUs this process may use (`cpus`: affinity mask cut by the cgroup's CPU quota) divided by the
+ * processes of the job on this host (`local_world`: LOCAL_WORLD_SIZE, else WORLD_SIZE, else 1), at most 8 / 16 -- so N ranks on one host (one per GPU) share the host
+ * instead of each taking what a lone process takes.  Additive (the reference sizes its one thread pool by -t, src/call_var_main.c:773).  Any pointer may be NULL; returns 0. */
+int lcd_host_threads(int *team, int *arena_threads, int *cpus, int *local_world);
 const char *lcd_version(void);
 
 /* ---- drop-in mirrors of src/align.h:50-65 ---- */
@@ -233,7 +238,8 @@ double lcd_region_job_cost(const lcd_region_job_t *job);                        
 uint64_t lcd_region_jobs_pack(int n, const lcd_region_job_t *jobs, uint8_t *buf);         /* buf == NULL: the size; else fills buf (that many bytes) */
 int lcd_batch_add_packed(lcd_batch_t *b, const uint8_t *buf, uint64_t nbytes);            /* -> regions added (lcd_batch_add_region each), < 0: malformed (lcd_rebalance_last_error) */
 /* costs: every rank's job costs, rank after rank (n_jobs[r] each); moves: room for sum(n_jobs) entries.  From the most loaded rank to the least loaded one, the job
- * that brings the pair closest to equal, until the most loaded rank is within tol of the mean or max_moves (< 0: no limit) are made; a job moves at most once.
+ * that brings the pair closest to equal -- or, when every job of the most loaded rank is at least as large as the gap (SV-heavy chunks), the swap of one job of
+ * each whose difference does (two moves) -- until the most loaded rank is within tol of the mean or max_moves (< 0: no limit) are made; a job moves at most once.
  * Deterministic.  Returns the number of moves; load_before / load_after (world entries each, nullable). */
 int lcd_rebalance_plan(int world, const int *n_jobs, const double *costs, double tol, int max_moves, lcd_move_t *moves, double *load_before, double *load_after);
 int lcd_rccl_unique_id(uint8_t id[128]);                                                   /* ncclGetUniqueId on rank 0; the caller gives the bytes to the other ranks */

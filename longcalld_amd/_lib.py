@@ -87,7 +87,7 @@ _lib = None
 
 # every symbol include/lcd_hotpath.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "lcd_opt_default", "lcd_init", "lcd_device_count", "lcd_alloc_events", "lcd_device_bytes", "lcd_set_thread_device", "lcd_batch_create_on", "lcd_last_error", "lcd_version", "lcd_wfa_end2end_aln", "lcd_edlib_end2end_aln",
+    "lcd_opt_default", "lcd_init", "lcd_device_count", "lcd_alloc_events", "lcd_device_bytes", "lcd_set_thread_device", "lcd_batch_create_on", "lcd_last_error", "lcd_host_threads", "lcd_version", "lcd_wfa_end2end_aln", "lcd_edlib_end2end_aln",
     "lcd_edlib_xgaps", "lcd_edlib_edit_distance", "lcd_end2end_aln", "lcd_wfa_collect_diff_ins_seq", "lcd_edlib_infix_aln", "lcd_wfa_heuristic_aln", "lcd_collect_noisy_reg_aln_strs", "lcd_batch_create", "lcd_batch_destroy",
     "lcd_batch_clear", "lcd_batch_region_vars", "lcd_digar_opt_default", "lcd_digar_batch", "lcd_digar_batch_tags", "lcd_digar_batch_ref", "lcd_region_read_slices_batch", "lcd_te_opt_default", "lcd_te_lib_create", "lcd_te_lib_destroy", "lcd_te_lib_n_seqs", "lcd_check_te_seq", "lcd_collect_te_info", "lcd_collect_te_info_from_cons", "lcd_annotate_te", "lcd_format_vcf_te", "lcd_pre_process_noisy_regs", "lcd_post_process_noisy_regs", "lcd_cr_merge", "lcd_sdust", "lcd_sdust_batch", "lcd_batch_add_region", "lcd_batch_add_region_from_chunk", "lcd_batch_add_region_from_chunk_packed", "lcd_batch_upload", "lcd_batch_run", "lcd_batch_run_many",
     "lcd_batch_download", "lcd_dispatch_create", "lcd_dispatch_destroy", "lcd_dispatch_n_devices", "lcd_dispatch_run", "lcd_dispatch_set_flags", "lcd_dispatch_busy", "lcd_batch_cost", "lcd_lpt_assign", "lcd_batch_region_result", "lcd_batch_region_sorted_ids", "lcd_batch_region_read_slices", "lcd_batch_get_stats", "lcd_batch_k4_jobs", "lcd_chunk_create", "lcd_chunk_create_from_bam", "lcd_chunk_destroy", "lcd_chunk_n_reads", "lcd_chunk_read_info", "lcd_chunk_intervals", "lcd_chunk_region_slices", "lcd_batch_add_region_from_chunk_dev", "lcd_copy_counters", "lcd_batch_digest", "lcd_batch_materialize", "lcd_batch_region_results_arena",
@@ -109,6 +109,7 @@ def load_library():
     u8p, i32p, u64p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
     lib.lcd_last_error.restype = C.c_char_p
     lib.lcd_version.restype = C.c_char_p
+    lib.lcd_host_threads.argtypes = [i32p, i32p, i32p, i32p]
     lib.lcd_opt_default.argtypes = [C.POINTER(LcdOpt)]
     lib.lcd_init.argtypes = [C.c_int]
     lib.lcd_batch_create.restype = C.c_void_p

@@ -9,6 +9,7 @@
 // All *_off fields handed to kernels are absolute device addresses (kernels get nullptr bases), so every
 // stage can live in its own grow-only hipMalloc buffer.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <algorithm>
 #include <atomic>
@@ -154,7 +155,44 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 // host threads per team of the submission's short parallel loops (capacities, job tables, records, plans).  LCD_HOST_TEAM, read per call: a caller whose own
 // threads are busy beside the submission -- bench.py's PCIe-inclusive pipeline on a box whose cgroup allows 16 CPUs -- asks for fewer; a team that overruns the
 // quota freezes every thread of the process, the submitter included, until the next period
-static int host_team() { const char *e = getenv("LCD_HOST_TEAM"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : v > 32 ? 32 : v; }
+// CPUs this process may use: its affinity mask, cut by the cgroup's CPU quota (v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us) -- a container with 128 visible
+// cores and a 16-CPU quota is a 16-CPU box for thread teams
+static int host_cpus() {
+    static const int n = [] {
+        int k = 0;
+        cpu_set_t set; CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) k = CPU_COUNT(&set);
+        if (k <= 0) k = (int)std::max(1u, std::thread::hardware_concurrency());
+        double quota = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { char a[64] = {0}; long long per = 0; if (fscanf(f, "%63s %lld", a, &per) == 2 && strcmp(a, "max") != 0 && per > 0) quota = atof(a) / (double)per; fclose(f); }
+        else {
+            long long q = -1, per = 0;
+            if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lld", &q) != 1) q = -1; fclose(fq); }
+            if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &per) != 1) per = 0; fclose(fp); }
+            if (q > 0 && per > 0) quota = (double)q / (double)per;
+        }
+        if (quota > 0) k = std::max(1, std::min(k, (int)(quota + 0.5)));
+        return k;
+    }();
+    return n;
+}
+// processes of this job on this host: one per GPU under torch.distributed.run (LOCAL_WORLD_SIZE; WORLD_SIZE on a single node)
+static int host_local_world() {
+    const char *e = getenv("LOCAL_WORLD_SIZE"); if (!e || atoi(e) < 1) e = getenv("WORLD_SIZE");
+    const int w = e ? atoi(e) : 1;
+    return w < 1 ? 1 : w;
+}
+// With N ranks on one host every rank runs these teams at the same moments (the ranks step together): the default is the host's CPUs divided by the ranks, at most 8.
+static int host_team() {
+    const char *e = getenv("LCD_HOST_TEAM");
+    const int v = e ? atoi(e) : std::min(8, std::max(1, host_cpus() / host_local_world()));
+    return v < 1 ? 1 : v > 32 ? 32 : v;
+}
+// (threads that lay results out on the host, lcd_batch_results_arena: LCD_ARENA_THREADS, default 16 -- or the rank's share of the host's CPUs)
+static int host_arena_threads() {
+    const char *e = getenv("LCD_ARENA_THREADS");
+    return e ? std::max(1, atoi(e)) : std::min(16, std::max(1, host_cpus() / host_local_world()));
+}
 // a loop over [0, n) cut into chunks taken by up to `max_threads` host threads (the calling thread is one of them); f(lo, hi, thread index)
 template <class F> static void par_chunks(const size_t n, const int max_threads, const size_t chunk, F f) {
     const int nth = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, max_threads), (n + chunk - 1) / std::max<size_t>(1, chunk)));
@@ -489,6 +527,13 @@ int lcd_set_thread_device(int device) {
 }
 const char *lcd_last_error(void) { return g_err.c_str(); }
 const char *lcd_version(void) { return "longcalld_amd hot path 0.1 (gfx950)"; }
+int lcd_host_threads(int *team, int *arena_threads, int *cpus, int *local_world) {
+    if (team) *team = host_team();
+    if (arena_threads) *arena_threads = host_arena_threads();
+    if (cpus) *cpus = host_cpus();
+    if (local_world) *local_world = host_local_world();
+    return 0;
+}
 
 // ---------------------------------------------------------------------------------------------------
 lcd_batch_t *lcd_batch_create(const lcd_opt_t *opt) { return lcd_batch_create_on(opt, -1); }
@@ -2413,7 +2458,7 @@ int lcd_batch_region_results_arena(lcd_batch_t *b, lcd_region_result_t **results
     // pass 1: bytes per region (a dry run of the same code with a counting allocator that returns a scratch block)
     std::vector<uint64_t> need(nr, 0);
     auto run = [&](const bool dry, uint8_t *base, lcd_region_result_t *tab) {
-        const char *nth_env = getenv("LCD_ARENA_THREADS"); const int nth_max = nth_env ? std::max(1, atoi(nth_env)) : 16; // (read per call; a caller that materialises several batches at once on its own threads wants fewer per batch)
+        const int nth_max = host_arena_threads(); // (read per call; a caller that materialises several batches at once on its own threads wants fewer per batch)
         const int nth = dry ? 1 : (int)std::max<size_t>(1, std::min<size_t>((size_t)nth_max, nr / 64 + 1)); // (the sizing pass is a few additions per row)
         std::atomic<size_t> next{0};
         auto work = [&]() {

@@ -158,7 +158,27 @@ int lcd_rebalance_plan(int world, const int *n_jobs, const double *costs, double
             if (moved[i] || c <= 0 || c >= gap) continue;
             if (best < 0 || std::fabs(c - gap / 2) < std::fabs(best_c - gap / 2)) { best = (long)i; best_c = c; }
         }
-        if (best < 0) break;
+        if (best < 0) {
+            // nothing of src's is smaller than the gap (SV-heavy chunks: a few jobs as large as the whole imbalance).  A SWAP still levels the pair: src's job a for
+            // dst's job b with 0 < a - b < gap, the difference closest to half the gap -- two moves, each job still moves once.  (the first pair in (a, b) order wins ties)
+            long ba = -1, bb = -1; double bd = 0.0;
+            if (max_moves < 0 || nm + 2 <= max_moves)
+                for (size_t i = first[src]; i < first[src + 1]; ++i) {
+                    if (moved[i] || costs[i] <= 0) continue;
+                    for (size_t j = first[dst]; j < first[dst + 1]; ++j) {
+                        if (moved[j] || costs[j] <= 0) continue;
+                        const double d = costs[i] - costs[j];
+                        if (d <= 0 || d >= gap) continue;
+                        if (ba < 0 || std::fabs(d - gap / 2) < std::fabs(bd - gap / 2)) { ba = (long)i; bb = (long)j; bd = d; }
+                    }
+                }
+            if (ba < 0) break;
+            moved[(size_t)ba] = 1; moved[(size_t)bb] = 1;
+            moves[nm].src = src; moves[nm].index = (int)((size_t)ba - first[src]); moves[nm].dst = dst; ++nm;
+            moves[nm].src = dst; moves[nm].index = (int)((size_t)bb - first[dst]); moves[nm].dst = src; ++nm;
+            load[src] -= bd; load[dst] += bd;
+            continue;
+        }
         moved[(size_t)best] = 1;
         moves[nm].src = src; moves[nm].index = (int)((size_t)best - first[src]); moves[nm].dst = dst; ++nm;
         load[src] -= best_c; load[dst] += best_c;

@@ -146,8 +146,8 @@ def plan_moves(costs_per_rank, tol=0.02, max_moves=None):
 
 
 def plan_moves_py(costs_per_rank, tol=0.02, max_moves=None):
-    """deterministic greedy plan: repeatedly move, from the most loaded rank to the least loaded one, the job that brings the pair closest to equal
-    (a job moves at most once).  -> list of (src_rank, index in src's queue, dst_rank), loads before, loads after"""
+    """deterministic greedy plan: repeatedly move, from the most loaded rank to the least loaded one, the job that brings the pair closest to equal -- or, when
+    every job of the most loaded rank is at least as large as the gap, swap the pair of jobs whose difference does (a job moves at most once).  -> list of (src_rank, index in src's queue, dst_rank), loads before, loads after"""
     load = [float(sum(c)) for c in costs_per_rank]
     before = list(load)
     moved = [set() for _ in costs_per_rank]
@@ -164,7 +164,25 @@ def plan_moves_py(costs_per_rank, tol=0.02, max_moves=None):
             if best < 0 or abs(c - gap / 2) < abs(best_c - gap / 2):
                 best, best_c = i, c
         if best < 0:
-            break
+            # nothing of src's is smaller than the gap: a swap -- src's job a for dst's job b with 0 < a - b < gap, the difference closest to half the gap
+            ba, bb, bd = -1, -1, 0.0
+            if max_moves is None or len(moves) + 2 <= max_moves:
+                for i, a in enumerate(costs_per_rank[src]):
+                    if i in moved[src] or a <= 0:
+                        continue
+                    for j, b in enumerate(costs_per_rank[dst]):
+                        if j in moved[dst] or b <= 0:
+                            continue
+                        d = a - b
+                        if d <= 0 or d >= gap:
+                            continue
+                        if ba < 0 or abs(d - gap / 2) < abs(bd - gap / 2):
+                            ba, bb, bd = i, j, d
+            if ba < 0:
+                break
+            moved[src].add(ba); moved[dst].add(bb)
+            moves.append((src, ba, dst)); moves.append((dst, bb, src)); load[src] -= bd; load[dst] += bd
+            continue
         moved[src].add(best); moves.append((src, best, dst)); load[src] -= best_c; load[dst] += best_c
     return moves, before, load
 

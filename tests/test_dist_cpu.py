@@ -102,6 +102,81 @@ def test_rebalance_inside_a_sub_group_gloo(tmp_path):
     assert len(r[2]["after"]) != len(r[2]["before"]) and len(r[1]["after"]) + len(r[2]["after"]) == 8 and r[1]["imb"][1] < r[1]["imb"][0]
 
 
+WORKER8 = r"""
+import hashlib, json, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch, torch.distributed as dist
+from longcalld_amd import jobs, rebalance as rb
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+# a configs[4]-shaped job cut into 128 chunks in genome order, contiguous blocks of 16 per rank; the SV regions cluster in the first quarter of the genome (ranks 0, 1)
+n_chunks = 128
+lo, hi = rank * n_chunks // world, (rank + 1) * n_chunks // world
+def chunk(i):
+    n_sv = (3 if i % 3 == 0 else 1) if i < n_chunks // 4 else (1 if i % 11 == 0 else 0)
+    regs = jobs.make_regions(7000 + i, 10 + i % 3, jobs.HIFI, poisson_sv=False)   # (a 500 kb chunk holds ~60 ordinary regions: enough that no single one is a rank's whole share)
+    rng = np.random.default_rng(9000 + i)
+    regs += [jobs.make_sv_region(rng, sv_len=1000 + 97 * (i % 13), ctx=200, n_reads=12) for _ in range(n_sv)]
+    return regs
+queue = [(sum(rb.region_cost_c(r) for r in regs), rb.pack_regions_c(regs)) for regs in (chunk(i) for i in range(lo, hi))]
+dig = lambda b: hashlib.sha1(np.ascontiguousarray(b).tobytes()).hexdigest()
+before = [dig(b) for _, b in queue]
+new_q, st = rb.rebalance(queue, tol=0.02)
+gathered = [None] * world
+dist.all_gather_object(gathered, dict(before=before, after=[dig(b) for _, b in new_q], load=sum(c for c, _ in new_q), st={k: v for k, v in st.items()}))
+if rank == 0:
+    print(json.dumps(gathered))
+dist.destroy_process_group()
+"""
+
+
+def test_eight_rank_sv_heavy_queue_is_level_after_one_epoch_gloo(tmp_path):
+    """eight ranks, an SV-heavy job in contiguous blocks (the SV chunks sit on two ranks): one epoch of the product's plan + exchange leaves
+    max / mean <= 1.05, every rank computed the same plan, and the chunks are a byte-identical partition before and after"""
+    w = tmp_path / "worker8.py"
+    w.write_text(WORKER8)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29523", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                          "--master-port", "29523", str(w), ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("[")][-1])
+    assert len(r) == 8 and all(k["st"] == r[0]["st"] for k in r)                 # one plan, computed identically on every rank
+    before = sorted(d for k in r for d in k["before"])
+    after = sorted(d for k in r for d in k["after"])
+    assert before == after and len(set(after)) == 128
+    st = r[0]["st"]
+    loads = [k["load"] for k in r]
+    mean = sum(loads) / 8
+    assert st["imbalance_before"] > 1.15                                         # the contiguous blocks were not level
+    assert max(loads) / mean <= 1.05, (max(loads) / mean, st)
+    assert all(abs(l - la) < 1e-6 * max(loads) for l, la in zip(loads, st["loads_after"]))
+
+
+def test_host_threads_are_divided_by_the_ranks_on_the_host(monkeypatch):
+    """the library's own thread teams default to (CPUs this process may use) / (ranks on this host), not to a lone process's eight"""
+    import ctypes as C
+    from longcalld_amd import _lib
+    lib = _lib.load_library()
+
+    def ask():
+        v = [C.c_int(0) for _ in range(4)]
+        assert lib.lcd_host_threads(*[C.byref(x) for x in v]) == 0
+        return [x.value for x in v]
+    for k in ("LCD_HOST_TEAM", "LCD_ARENA_THREADS", "WORLD_SIZE", "LOCAL_WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    team1, arena1, cpus, lw = ask()
+    assert lw == 1 and cpus >= 1 and team1 == min(8, cpus) and arena1 == min(16, cpus)
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    team8, arena8, cpus8, lw8 = ask()
+    assert lw8 == 8 and cpus8 == cpus and team8 == max(1, min(8, cpus // 8)) and arena8 == max(1, min(16, cpus // 8))
+    assert 8 * team8 <= max(cpus, 8)                                              # eight ranks together stay within the host
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")                                   # two ranks on this host of an 8-rank job
+    assert ask()[3] == 2
+    monkeypatch.setenv("LCD_HOST_TEAM", "3")                                      # an explicit setting wins
+    assert ask()[0] == 3
+
+
 def test_plan_is_deterministic_and_never_moves_a_job_twice():
     from longcalld_amd import rebalance as rb
     rng = np.random.default_rng(5)
