@@ -20,6 +20,9 @@ namespace {
 typedef unsigned long long Word;
 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+// lane l <- lane l - 1 (lane 0: 0) as a DPP wave shift: the horizontal delta of the block above is on every step's dependency chain, and __shfl_up is a trip
+// through the LDS crossbar (ds_bpermute, ~120 clk) where the DPP form is one VALU instruction.  All 64 lanes must be active.
+__device__ __forceinline__ int wave_shr1(const int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
 
 __device__ __forceinline__ int calc_block(Word Pv, Word Mv, Word Eq, int hin, Word &PvOut, Word &MvOut) {
     const Word hinIsNeg = (Word)(hin < 0);
@@ -80,7 +83,7 @@ __device__ __forceinline__ int myers_pass(const Sub &sp, int ncols, bool rev, in
                 tbuf[cc & 127] = cc < ncols ? (rev ? sp.t[sp.tlen - 1 - cc] : sp.t[cc]) : (uint8_t)4;
                 __syncthreads();
             }
-            const int hleft = __shfl_up(hout, 1);
+            const int hleft = wave_shr1(hout);
             const int c = step - lane;
             if (act && c >= 0 && c < ncols) {
                 const int hin = lane == 0 ? (tile0 == 0 ? 1 : (int)hcarry[c]) : hleft;
@@ -155,7 +158,7 @@ __device__ __forceinline__ void sg_pass(const Sub &sp, int ncols, bool rev, int 
                 tbuf2[cc & 127] = cc < ncols ? (rev ? sp.t[sp.tlen - 1 - cc] : sp.t[cc]) : (uint8_t)4;
                 __syncthreads();
             }
-            const int hleft = __shfl_up(hout, 1);
+            const int hleft = wave_shr1(hout);
             const int c = step - lane;
             if (act && c >= 0 && c < ncols) {
                 const int hin = lane == 0 ? (tile0 == 0 ? HIN0 : (int)hcarry[c]) : hleft;

@@ -238,8 +238,11 @@ int lcd_rebalance_exchange(lcd_comm_t *c, int n_jobs, const double *cost, const 
     Scratch sc;
     bool in_epoch = false; // (a collective has been issued: the peers are waiting for this rank)
     auto fail = [&](int code, const std::string &m) {
+        //  abort FIRST: ending a partly filled group would launch a subset of the planned send / recv pairs and can block in connection setup against
+        // peers that posted the full set; ncclCommAbort is legal with a group pending.  The group is ended afterwards (its error is of no interest).  Without
+        // ncclCommAbort in the library the communicator is leaked rather than destroyed: ncclCommDestroy on a communicator with operations outstanding can hang.
+        if (in_epoch && c->comm) { if (g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm); c->comm = nullptr; c->dead = true; }
         if (sc.group_open) { (void)g_rccl.GroupEnd(); sc.group_open = false; }
-        if (in_epoch && c->comm) { if (g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm); else (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; c->dead = true; }
         return rb_err(code, m);
     };
 #define RB_HIP(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return fail(-10, "HIP call failed: " #x); } } while (0)

@@ -48,6 +48,10 @@ struct SmemWide { // multi-wavefront classes only (never referenced by the 64-th
     int carry1[16][MAXW], carry2[16][MAXW], bndH[16][MAXW];
 };
 
+#ifdef LCD_X_BYTESTAT
+__device__ unsigned long long g_bs_tot[15][19]; // (experiment) bytes by (class, array group), + chains, reads, cells
+__device__ unsigned g_bs_done[256]; // finished chains per launch (keyed by the launch's chain table)
+#endif
 __shared__ SmemWide g_wide;
 __shared__ Smem g_smem; // file scope: non-inlined device functions reach it as LDS (a Smem& parameter would be a generic pointer -> flat ops)
 
@@ -88,6 +92,9 @@ struct Ctx {
     int inc_off;                       // LCD_DBG bit 1024: every topology change takes the full re-sort (test switch)
 #ifdef LCD_X_PHASESTAT
     unsigned long long pstat[24];      // (experiment) ticks inside the per-read phases, see LCD_PT
+#endif
+#ifdef LCD_X_BYTESTAT
+    unsigned long long bstat[16];      // (experiment) bytes the chain's memory instructions ask for, by array group, see LCD_BS
 #endif
 #ifdef LCD_X_INCSTAT
     unsigned inc_stat[13];             // (experiment) topo_sort_incremental: refusals by reason 0..9, successes, nodes walked, pieces
@@ -205,6 +212,17 @@ __device__ __forceinline__ int glb_ld(const int *p);
 __device__ __forceinline__ int glb_ld_u8(const uint8_t *p);
 __device__ __forceinline__ int usgpr(const int v);
 
+// (experiment, -DLCD_X_BYTESTAT) the HBM account of a chain: bytes its memory instructions ask for (elements x element size, per lane -- not sectors or cache lines),
+// by array group, from the trip counts the phases actually ran with.  tools/hbm_account.py sums the chains' lines and sets them against the PMC counters.
+//  0 direction codes written   1 row metadata written (rbeg, rend, roff)   2 plan arrays read by the rows   3 read bases staged
+//  4 backtrack reads (codes, row metadata, order)   5 path (cigar) written + read   6 graph update (node / edge / read-set arrays, path scratch)
+//  7 plan build: graph arrays read   8 plan build: plan arrays written   9 full re-sort   10 incremental re-sort   11 remain by pointer jumping
+//  12 chain output (MSA rows, consensus)   13 certified-band node arrays + intervals   14 generic rows (int32 planes)   15 per-row extremes (compute_mm)
+#ifdef LCD_X_BYTESTAT
+#define LCD_BS(k, v) do { g.bstat[k] += (unsigned long long)(v); } while (0)
+#else
+#define LCD_BS(k, v) do { } while (0)
+#endif
 // (experiment, -DLCD_X_PHASESTAT) ticks between two marks of a per-read phase, outstanding memory operations drained at each mark
 #ifdef LCD_X_PHASESTAT
 #define LCD_PT0() long long pt_ = clock64()
@@ -428,8 +446,10 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
 #pragma unroll
         for (int u = 0; u < U; ++u) { e0w[u] = 0; e0t[u] = -1; e0n[u] = -1; if (oh[u] >= 0) { e0w[u] = g.e_w[oh[u]]; e0t[u] = g.e_to[oh[u]]; e0n[u] = g.e_next_out[oh[u]]; } }
         LCD_PT(4);
+        int fnd[U], wnew[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            fnd[u] = -1; wnew[u] = 0;
             if (!chk[u]) continue;
             // the edge exists: one more read on it.  `remain` follows every node's HEAVIEST out-edge (first maximum in list order): it only has to be
             // recomputed if this increment changes which edge that is -- reads on the majority path never do
@@ -443,11 +463,28 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
             }
             if (found >= 0) {
                 const int wn = wfound + 1;
-                g.e_w[found] = wn; g.rid[(size_t)found * g.rid_words + rw] |= rbit; need[u] = 0;
-                if (g.plan_valid && (wn & (wn - 1)) == 0) { const int sl = g.e_slot[found]; if (sl >= 0) g.pl_bonus[sl] = ilog2_32(wn); } // (the edge's bonus, ilog2 of its weight, went up)
+                fnd[u] = found; wnew[u] = wn; need[u] = 0;
                 if (found != amax && (wn > wmax || (wn == wmax && pos_found < pos_amax))) heavy_moved = 1;
             }
         }
+        // the read sets and (where a weight reached a power of two: the edge's bonus, ilog2 of its weight, goes up) the edges' plan entries of all U edges are fetched
+        // together, then everything is stored: a path visits an edge once, so no two of these touch the same words -- and a load behind each store would be U round
+        // trips one after the other
+        unsigned long long rv[U]; int sl[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            rv[u] = 0; sl[u] = -1;
+            if (fnd[u] >= 0) {
+                rv[u] = g.rid[(size_t)fnd[u] * g.rid_words + rw];
+                if (g.plan_valid && (wnew[u] & (wnew[u] - 1)) == 0) sl[u] = g.e_slot[fnd[u]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (fnd[u] >= 0) {
+                g.e_w[fnd[u]] = wnew[u]; g.rid[(size_t)fnd[u] * g.rid_words + rw] = rv[u] | rbit;
+                if (sl[u] >= 0) g.pl_bonus[sl[u]] = ilog2_32(wnew[u]);
+            }
         LCD_PT(5);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -4209,6 +4246,7 @@ __device__ __attribute__((noinline)) int align_certified(Ctx *gp, const unsigned
             else cert_node_arrays<3>(&g, bi, ei);
             __syncthreads();
             g.t_plan += (unsigned long long)(clock64() - tca0); // (profiling: the bound's node arrays)
+            LCD_BS(13, 90ull * (unsigned long long)(ei - bi + 1)); // (six node arrays written 24 B and the plan read for them 20 B per row, twice (both sweeps); the intervals 4 B written, 4 read by the rows)
             const unsigned long long cells_before = *cells_acc;
             int bztop = 0;
             const int ubtop = cert_ubtop(g, ei, qlen, sc, &bztop);
@@ -4482,6 +4520,7 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
         // the graph has the nodes, edges, order and `remain` it had when this plan was built (the reads since only added weight, and add_alignment_block patched the
         // bonuses): only the first-predecessor distances are made again -- they live in the LDS pool behind the query cache, whose place depends on the read
         LCD_PT0();
+        if (pd) LCD_BS(2, 12ull * (unsigned long long)(ei - bi + 1)); // (pl_start twice, pl_pidx once per row)
         if (pd) { // (two dependent trips per row: four rows per thread in flight)
             for (int b = bi + tid; b <= ei; b += 4 * NT) {
                 int p0[4], np[4], pi[4];
@@ -4497,6 +4536,10 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
         LCD_PT(19);
     } else {
         build_plan<NT>(g, sm, bi, ei, remain_end, pd, (NT == 64 || g.solo) ? g.plan_k : K, ring, (int)((uint8_t *)sseq - (uint8_t *)ring));
+        // plan build, per row: read imap 1, idx2node 4, in_head 4, remain 4, base 1, and for each of the two in-edge slots taken straight-line e_from 4, e_next_in 4,
+        // e_w 4, node2idx 4, imap 1 (= 48 B); written pl_start 4, pl_rem 4, pl_base 1, and per plan entry pl_pidx 4, pl_bonus 4, e_slot 4 (~1.05 entries per row);
+        // before it imap (1 B per node) and e_slot (4 B per edge) are reset
+        LCD_BS(7, 48ull * (unsigned long long)(ei - bi + 1)); LCD_BS(8, 9ull * (unsigned long long)(ei - bi + 1) + 12ull * (unsigned long long)g.pl_start[ei + 1] + (unsigned long long)g.n_node + 4ull * (unsigned long long)g.n_edge);
         g.plan_valid = 1; g.plan_bi = bi; g.plan_ei = ei; g.plan_rend = remain_end;
     }
     g.t_bp += (unsigned long long)(clock64() - tb0); } // (rows to spill: those with a successor further away than the windowed rows' ring -- the smallest ring a window of this chain may run with)
@@ -4552,6 +4595,10 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
             } else nc = align_windowed<NT, 1, 4>(&g, ro, so, pdo, sc, w, bi, ei, rem_beg, seq_hbm, qlen, &wo);
         }
         if (nc >= 0) {
+            // rows: 1 B of direction code per cell; 12 B of row metadata per row (rbeg, rend, roff); 18 B of plan per row (pl_start, pl_pidx, pl_bonus, pl_rem 4 B each,
+            // pl_base, imap 1 B each); the read once.  Backtrack: per path entry 8 B of row metadata + 1 B of code + 4 B of order (idx2node); path out 8 B, read back 8 B
+            LCD_BS(0, wo.cells); LCD_BS(1, 12ull * (unsigned long long)(ei - bi + 1)); LCD_BS(2, 18ull * (unsigned long long)(ei - bi + 1)); LCD_BS(3, qlen);
+            LCD_BS(4, 13ull * (unsigned long long)nc); LCD_BS(5, 16ull * (unsigned long long)nc);
             g.status = wo.status; g.t_dp += wo.t_dp; g.t_bt += wo.t_bt; *cells_acc += wo.cells; g.t_plan += wo.t_plan; g.t_poll += wo.t_poll; g.t_setup += wo.t_setup;
             g.cig_node = g.cig_node0 + wo.cig_pos; g.cig_qpos = g.cig_qpos0 + wo.cig_pos;
             return nc;
@@ -4812,6 +4859,7 @@ __device__ __attribute__((noinline)) int align_to_subgraph(Ctx &g, Smem &sm, int
     }
     __syncthreads();
     *cells_acc += used;
+    LCD_BS(14, 24ull * used); // (generic rows: H, E1, E2 written and read back, 4 B each per cell)
     const long long t_bt0 = clock64();
     g.t_dp += (unsigned long long)(t_bt0 - t_dp0);
     // ---- end node: best predecessor at column qlen, then backtrack (thread 0) ----
@@ -5157,7 +5205,8 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
     {   // deadline = a floor (LcdScoring.wd_s, 30 s) + the chain's own work at a rate far below the slowest class on a crowded chip (5e7 cells/s; the generic rows
         // alone on a CU run 2.4e8): a legitimately long chain -- ultra-long noisy reads, 60x depth, unbanded K2 rows over a graph twice the read -- is not a hang
         const unsigned long long width = ch.mode ? 2ull * (unsigned long long)(ch.max_len > 0 ? ch.max_len : 1) : 1024ull;
-        const unsigned long long work_s = (unsigned long long)(ch.n_reads > 0 ? ch.n_reads : 1) * (unsigned long long)(ch.max_len > 0 ? ch.max_len : 1) * width / 50000000ull;
+        unsigned long long work_s = (unsigned long long)(ch.n_reads > 0 ? ch.n_reads : 1) * (unsigned long long)(ch.max_len > 0 ? ch.max_len : 1) * width / 50000000ull;
+        { const unsigned long long cap_s = 10ull * (unsigned long long)(sc.wd_s > 0 ? sc.wd_s : 30); if (work_s > cap_s) work_s = cap_s; } // (the unbanded worst case of 60 reads of 50 kb is 6 000 s -- a hung long chain must still be caught: at most ten floors on top of the floor)
         g.wd_deadline = (unsigned long long)clock64() + ((unsigned long long)(sc.wd_s > 0 ? sc.wd_s : 30) + work_s) * 2400000000ull; // (~2.4 GHz shader clock: the bound is about seconds, not exact)
     }
 #ifdef LCD_X_INCSTAT
@@ -5165,6 +5214,9 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
 #endif
 #ifdef LCD_X_PHASESTAT
     for (int k_ = 0; k_ < 24; ++k_) g.pstat[k_] = 0;
+#endif
+#ifdef LCD_X_BYTESTAT
+    for (int k_ = 0; k_ < 16; ++k_) g.bstat[k_] = 0;
 #endif
     g.cut = g.prof; g.cut_valid = 0; g.upd_new = g.upd_newe = g.upd_moved = 0; g.inc_off = (sc.dbg >> 10) & 1;
     g.mm_valid = 0; g.topo_mode = (sc.dbg >> 6) & 7; g.solo = NT == 256 ? ch.solo : 0; g.n_node = 2; g.n_edge = 0; g.status = LCD_OK; g.t_dp = g.t_bt = 0; g.t_plan = g.t_poll = 0; g.t_kahn = 0; g.t_bp = 0; g.t_setup = 0;
@@ -5197,7 +5249,7 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
             // A read anchored at the backbone's first and last base: node 2 hangs on the source (index 0) and the last backbone node leads to the sink (the last
             // index), so the sweeps of oracle/poa.c subgraph_nodes end at once with (source, sink) whatever else the graph holds -- no sweep, no per-row extremes
             if (!(backbone_len > 0 && r.ref_beg == 1 && r.ref_end == backbone_len)) {
-                if (!g.mm_valid && g.cut_valid) compute_mm<NT>(g);
+                if (!g.mm_valid && g.cut_valid) { compute_mm<NT>(g); LCD_BS(15, 60ull * (unsigned long long)g.n_node); }
                 if (wave == 0) {
                     int eb, ee;
                     subgraph_nodes_wave0(g, lane, r.ref_beg + 1, r.ref_end + 1, &eb, &ee);
@@ -5226,6 +5278,10 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
         int changed = 0;
         if (len > 0 && g.status == LCD_OK && g.n_node == 2) backbone_len = len; // (this read becomes the backbone: node id of its base k is k + 1)
         if (len > 0 && g.status == LCD_OK) changed = add_alignment_block<NT>(g, sm, exc_beg, exc_end, seq, len, n_cig, i);
+        // graph update, per path entry: path 8 (read), read base 1, node base 1, path scratch written 8 (aa_node, aa_flag) and read back 16, out_head 4, the first
+        // out-edge's e_w, e_to, e_next_out 12, e_w written 4, read set read + written 16, aa_eid 4 (= 74 B); a new node 28 B of node arrays, a new edge 20 B + its read set
+        if (len > 0) LCD_BS(6, n_cig > 0 ? 74ull * (unsigned long long)n_cig + 28ull * (unsigned long long)g.upd_new + (20ull + 8ull * (unsigned long long)g.rid_words) * (unsigned long long)g.upd_newe
+                                         : (unsigned long long)len * (30ull + 20ull + 8ull * (unsigned long long)g.rid_words));
         t_add += (unsigned long long)(clock64() - tg0);
 #ifdef LCD_X_ROWSTAT
         if (len > 0) { chg_stat_ += changed == 2 ? 1ull : changed == 1 ? (1ull << 16) : changed == 3 ? (1ull << 32) : 0ull; chg_stat_ += 1ull << 48; }
@@ -5233,9 +5289,14 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
         if (changed == 1 || changed == 2) g.plan_valid = 0; // (3: weights only, every heaviest out-edge the same -- order, remain and the plan's structure stand; its bonuses were patched)
         if (changed == 2 && g.status == LCD_OK) {
             LCD_PT0();
-            if (!topo_sort_incremental<NT>(g, sm, lds_off(lds_pool), exc_beg, exc_end, n_cig)) { LCD_PT(22); topo_sort_block<NT>(g, sm, lds_pool, ch.mode == 0); LCD_PT(21); }
+            // full re-sort, per node: staged nin, out_head, aligned 12; jump tables written and read ~16; node2idx, idx2node, cut, remain written 13; heaviest successor
+            // e_w 8 -- ~50 B -- and per edge e_to, e_next_out 8 (twice when the walk runs on the words in HBM: not counted).  Incremental: the path scratch once (12 B per
+            // entry), ~60 B per row of each 64-row window fetched (counted as two windows + one per 3 new nodes), 13 B per row of the order behind the first new node (half the order on average)
+            if (!topo_sort_incremental<NT>(g, sm, lds_off(lds_pool), exc_beg, exc_end, n_cig)) { LCD_PT(22); topo_sort_block<NT>(g, sm, lds_pool, ch.mode == 0); LCD_PT(21); LCD_BS(9, 50ull * (unsigned long long)g.n_node + 8ull * (unsigned long long)g.n_edge); }
             else {
                 LCD_PT(22);
+                LCD_BS(10, 12ull * (unsigned long long)n_cig + 3840ull * (2ull + (unsigned long long)g.upd_new / 3ull) + (g.upd_new > 0 ? 13ull * (unsigned long long)g.n_node / 2ull : 0ull));
+                if (g.upd_moved) LCD_BS(11, 34ull * (unsigned long long)g.n_node);
                 if (g.upd_moved) { topo_remain_block<NT>(g, sm, lds_pool); LCD_PT(20); }
 #ifdef LCD_X_VERIFY_INC
                 {   // (experiment) the full re-sort must give the same order, the same `remain`, and a cut wherever the incremental one says so (the DP region is free here)
@@ -5259,7 +5320,7 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
                 }
 #endif
             }
-        } else if (changed == 1 && g.status == LCD_OK) topo_remain_block<NT>(g, sm, lds_pool);
+        } else if (changed == 1 && g.status == LCD_OK) { topo_remain_block<NT>(g, sm, lds_pool); LCD_BS(11, 34ull * (unsigned long long)g.n_node); } // (out_head, e_w x 2, e_to x 2, e_next_out x 2, remain: ~34 B per node)
         t_graph += (unsigned long long)(clock64() - tg0);
     }
     const long long t_out0 = clock64();
@@ -5268,6 +5329,8 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
     out.status = g.status; out.n_cons = 0; out.cons_len[0] = out.cons_len[1] = 0; out.msa_len = 0; out.clu_n[0] = out.clu_n[1] = 0;
     out.n_node = g.n_node; out.n_edge = g.n_edge; out.n_aligned_reads = n_aligned_reads; out.cells = cells; out.cells_alg = (unsigned long long)((long long)cells + g.alg_adjust); out.aligned_bases = aligned_bases;
     chain_output<NT>(g, sm, ch, outpool, out);
+    // output: the MSA rows ((reads + 2) x columns bytes written, read again for the column profile and the consensus), rank / column arrays ~24 B per node
+    LCD_BS(12, 2ull * (unsigned long long)(n_seq + 2) * (unsigned long long)g.n_node + 24ull * (unsigned long long)g.n_node);
     if (tid == 0) {
         const long long t_end = clock64();
         out.t_total = (unsigned long long)(t_end - t_begin); out.t_dp = g.t_dp; out.t_bt = g.t_bt; out.t_graph = t_graph; out.t_sub = t_sub; out.t_plan = g.t_plan; out.t_poll = NT == 64 && ch.cert ? g.t_poll : g.t_kahn; /* (profiling: t_poll slot reports the serial Kahn walk; certified-band chains: t_plan / t_poll = node arrays / intervals) */
@@ -5277,6 +5340,23 @@ __global__ void __launch_bounds__(NT, LCD_MINW(NT)) lcd_poa_chain_kernel(const P
         out.t_bp = g.t_bp; out.t_add = t_add; out.t_sort = t_graph - t_add; out.t_setup = g.t_setup;
 #ifdef LCD_X_ROWSTAT
         out.t_bt = chg_stat_;
+#endif
+#ifdef LCD_X_BYTESTAT
+        {   // totals of the process by (threads, kind), printed whenever a launch has finished: the last line of a run holds every chain (tools/hbm_account.py)
+            const int cls = (NT == 64 ? 0 : NT == 128 ? 1 : NT == 256 ? 2 : NT == 512 ? 3 : 4) * 3 + (ch.mode == 0 ? 0 : ch.cert ? 1 : 2);
+            for (int k_ = 0; k_ < 16; ++k_) atomicAdd(&g_bs_tot[cls][k_], g.bstat[k_]);
+            atomicAdd(&g_bs_tot[cls][16], 1ull); atomicAdd(&g_bs_tot[cls][17], (unsigned long long)n_aligned_reads); atomicAdd(&g_bs_tot[cls][18], cells);
+            __threadfence();
+            const unsigned key_ = (unsigned)(((unsigned long long)(uintptr_t)chains >> 8) * 2654435761ull >> 16) & 255u;
+            if (atomicAdd(&g_bs_done[key_], 1u) + 1u == (unsigned)n_chains) {
+                g_bs_done[key_] = 0;
+                for (int c_ = 0; c_ < 15; ++c_) if (g_bs_tot[c_][16])
+                    printf("[bs] %d %d %d %llu %llu %llu : %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", c_ / 3 == 0 ? 64 : c_ / 3 == 1 ? 128 : c_ / 3 == 2 ? 256 : c_ / 3 == 3 ? 512 : 1024, c_ % 3 == 0 ? 0 : 1, c_ % 3 == 1 ? 1 : 0,
+                           g_bs_tot[c_][16], g_bs_tot[c_][17], g_bs_tot[c_][18], g_bs_tot[c_][0], g_bs_tot[c_][1], g_bs_tot[c_][2], g_bs_tot[c_][3], g_bs_tot[c_][4], g_bs_tot[c_][5], g_bs_tot[c_][6], g_bs_tot[c_][7],
+                           g_bs_tot[c_][8], g_bs_tot[c_][9], g_bs_tot[c_][10], g_bs_tot[c_][11], g_bs_tot[c_][12], g_bs_tot[c_][13], g_bs_tot[c_][14], g_bs_tot[c_][15]);
+                printf("[bs-end]\n");
+            }
+        }
 #endif
 #ifdef LCD_X_PHASESTAT
         if ((cid & 127) == 0 && NT == 64) printf("[pt] chain %d mode %d reads %d nodes %d total %llu : %llu %llu %llu %llu %llu %llu %llu %llu | %llu %llu %llu %llu %llu %llu %llu | %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", cid, ch.mode, n_seq, g.n_node, (unsigned long long)(clock64() - t_begin),

@@ -59,6 +59,29 @@ def oracle_many(seed, n, shape_name, workers=0):
     return [e for part in parts for e in part]
 
 
+def _oracle_poa_task(t):
+    """worker of oracle_poa_many (spawned: imports the oracle itself)"""
+    kind, reads, extra = t
+    sys.path.insert(0, ROOT)
+    from oracle import pyoracle
+    if kind == "k2":
+        return pyoracle.poa_aln_msa_cons(reads, extra)
+    return pyoracle.poa_partial_aln_msa_cons(reads, extra)
+
+
+def oracle_poa_many(tasks, workers=0):
+    """the oracle's K1 / K2 chains for [(kind, reads, max_n_cons | covers)], each in its own spawned process (a 16 - 45 kb K2 chain is minutes of scalar DP and
+    3 - 25 GB of matrices: side by side instead of one after the other, and the memory goes back when the worker ends)"""
+    import multiprocessing as mp
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:  # noqa
+        cores = os.cpu_count() or 1
+    w = workers or max(1, min(cores, len(tasks)))
+    with mp.get_context("spawn").Pool(w, maxtasksperchild=1) as pool:
+        return pool.map(_oracle_poa_task, tasks, chunksize=1)
+
+
 def mutate(rng, s, rate, sv=0.0):
     out, i = [], 0
     while i < len(s):

@@ -457,13 +457,25 @@ def test_poa_k2_int16_ring_bonus_overflow(lcd, oracle, monkeypatch):
     _check_k2(a[0], oracle.poa_aln_msa_cons(jobs[0]["reads"], 2))
 
 
-@pytest.mark.parametrize("L,n", [(15900, 6), (16100, 6), (30000, 5)])
+_LONG_K2 = [(15900, 6), (16100, 6), (30000, 5)]
+_long_k2_oracle = {}
+
+
+def _long_k2_reads(L, n):
+    return _het_chain(np.random.default_rng(5200 + L), L, n)
+
+
+@pytest.mark.parametrize("L,n", _LONG_K2)
 def test_poa_k2_int16_ring_guard_long_reads(lcd, L, n, monkeypatch):
     """reads around and beyond the int16 limit of the matches alone (2 x 16 000 = 32 000; regions go to 50 kb, src/call_var_main.h:36): 16-bit pools forced
-    (LCD_RING16=2, the kernel's guard decides per read) == default == 32-bit rings == full rows.  (Too large for the scalar oracle in test time: the full rows
-    are the reference here, and every row must de-gap to its read.)"""
-    rng = np.random.default_rng(5200 + L)
-    jobs = [dict(mode=1, reads=_het_chain(rng, L, n))]
+    (LCD_RING16=2, the kernel's guard decides per read) == default == 32-bit rings == full rows == ORACLE (the three chains' scalar oracle runs --
+    1 - 3 minutes and 3 - 11 GB each -- side by side in spawned workers, once for the three cases)"""
+    from conftest import oracle_poa_many
+    if not _long_k2_oracle:
+        res = oracle_poa_many([("k2", _long_k2_reads(l_, n_), 2) for l_, n_ in _LONG_K2])
+        for (l_, n_), r in zip(_LONG_K2, res):
+            _long_k2_oracle[(l_, n_)] = r
+    jobs = [dict(mode=1, reads=_long_k2_reads(L, n))]
     monkeypatch.setenv("LCD_CERT", "1")
     a = lcd.poa_batch(jobs)
     monkeypatch.setenv("LCD_RING16", "2")
@@ -476,6 +488,29 @@ def test_poa_k2_int16_ring_guard_long_reads(lcd, L, n, monkeypatch):
     _same_chains(a, b); _same_chains(a, c); _same_chains(a, d)
     for r, row in zip(jobs[0]["reads"], a[0]["msa"]):
         assert (row[row != 5] == r).all()
+    _check_k2(a[0], _long_k2_oracle[(L, n)])
+
+
+def test_poa_regions_near_the_50kb_cap_and_a_1000_read_region(lcd):
+    """the longest region longcallD hands over is 50 kb (LONGCALLD_NOISY_REG_MAX_LEN, src/call_var_main.h:36) and the deepest 1 000 reads (:42).
+    A K1 chain of 48 kb reads (banded: the adaptive band is 10 + 480 columns either side), a K2 chain of 45 kb reads (unbanded in the oracle: 2 x 2 G cells) and a
+    1 000-read K1 chain of short reads (every read-set word of an edge in use) == oracle, the oracle's runs side by side in spawned workers"""
+    from conftest import oracle_poa_many
+    rng = np.random.default_rng(5600)
+    h = rng.integers(0, 4, 48000).astype(np.uint8)
+    k1_long = [mutate(rng, h, 0.001) for _ in range(5)]
+    k2_long = _het_chain(rng, 45000, 3)
+    s = rng.integers(0, 4, 150).astype(np.uint8)
+    s2 = s.copy(); s2[70] = (s2[70] + 1) % 4
+    k1_deep = [mutate(rng, s if i % 3 else s2, 0.002) for i in range(1000)]
+    exp = oracle_poa_many([("k2", k2_long, 2), ("k1", k1_long, [12] * len(k1_long)), ("k1", k1_deep, [12] * len(k1_deep))])
+    got = lcd.poa_batch([dict(mode=1, reads=k2_long), dict(mode=0, reads=k1_long), dict(mode=0, reads=k1_deep)])
+    _check_k2(got[0], exp[0])
+    for g, e in zip(got[1:], exp[1:]):
+        assert g["status"] == 0 and g["n_cons"] == e["n_cons"] == 1 and g["msa_len"] == e["msa_len"]
+        assert len(g["cons"][0]) == len(e["cons"][0]) and (g["cons"][0] == e["cons"][0]).all()
+        for a, b in zip(g["msa"], e["msa"]):
+            assert (a == b).all()
 
 
 def test_poa_k2_int16_ring_guard_large_penalties(lcd, oracle, monkeypatch):
