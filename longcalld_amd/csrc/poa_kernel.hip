@@ -28,6 +28,13 @@
 
 namespace {
 
+#ifndef LCD_UPD_U
+#define LCD_UPD_U 6 // path entries per thread in flight in the graph update (build switch; 4 / 6 / 8 measured in round 6: 6 and 8 are ~1 % ahead -- a 650-entry path is two chunks of 384 instead of three of 256)
+#endif
+#ifndef LCD_PLAN_U
+#define LCD_PLAN_U 6 // rows per thread in flight in the plan build (build switch; see LCD_UPD_U)
+#endif
+
 constexpr int MAXP = 64;   // predecessors staged in LDS per row (more are read from the plan in HBM)
 constexpr int MAXW = 16;   // wavefronts per workgroup
 
@@ -370,7 +377,7 @@ __device__ __attribute__((noinline)) int add_alignment_block(Ctx &g, Smem &sm, i
     // Every phase below is a chain of dependent loads per cigar entry (entry -> node -> its lists -> edge fields), and a workgroup -- one wavefront for most
     // chains -- that walks the entries 64 at a time pays that chain's latency once per 64 entries.  U entries per thread are in flight instead: the loads of all U
     // are issued before anything is stored (the stores are to int arrays the compiler must assume aliased), the prefix sums then run batch by batch in entry order.
-    constexpr int U = 4;
+    constexpr int U = LCD_UPD_U;
     // phase 1: the node each entry lands on: existing (>= 0), new and aligned to an anchor, or plain new
     int carry = 0;
     LCD_PT0();
@@ -1549,7 +1556,7 @@ __device__ void build_plan(Ctx &g, Smem &sm, const int bi, const int ei, const i
     LCD_PT(8);
     // U rows per thread in flight (see batched_for): a row's chain is index -> node -> first in-edge -> its source -> that row's index -> its reachability, six
     // dependent loads, and nearly every row has one or two in-edges -- those are taken straight-line for all U rows together and kept for the second pass
-    constexpr int U = 4;
+    constexpr int U = LCD_PLAN_U;
     int carry = 0;
     for (int base = bi; base <= ei; base += U * NT) {
         int v[U], cnt[U], rem[U], vbs[U], ih[U], n0[U], n1[U], p0[U], p1[U], w0[U], w1[U]; bool us0[U], us1[U];
