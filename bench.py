@@ -697,8 +697,11 @@ def main():
         traffic, traffic_src = None, None
         import glob
         import re
-        if args.ref_mb == 10 and shape["name"] == "hifi" and world == 1 and not job_mode:
-            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])   # r01_v9 < r01_v10 < r02_v1
+        if args.ref_mb == 10 and shape["name"] in ("hifi", "ont", "sv") and world == 1 and not job_mode:
+            # (the driver's workload: profiles/rNN_vM_traffic.json; the two noisy shapes' builder commands: profiles/rNN_vM_<shape>_traffic.json, tools/profile_shapes.sh)
+            pat = r"^r\d+_v\d+_traffic\.json$" if shape["name"] == "hifi" else r"^r\d+_v\d+_" + shape["name"] + r"_traffic\.json$"
+            cand = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")) if re.match(pat, os.path.basename(f))),
+                          key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])   # r01_v9 < r01_v10 < r02_v1
             if cand:
                 tj = json.load(open(cand[-1]))
                 traffic, traffic_src = float(tj["hbm_bytes_per_step"]) * n_co, tj["source"] + f" x {n_co} coalesced steps"
@@ -707,7 +710,7 @@ def main():
         valu = None
         if traffic is not None:
             cand2 = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq.json")), key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
-            if cand2 and mean_launch_s > 0:
+            if cand2 and mean_launch_s > 0 and shape["name"] == "hifi":
                 sj = json.load(open(cand2[-1]))
                 ops = float(sj["valu_wave_insts_per_step"]) * 64 * n_co
                 valu = {"achieved": round(ops / mean_launch_s / 1e12, 3), "peak": 78.6, "unit": "Tops/s (int32 lane-ops)", "frac": round(ops / mean_launch_s / 78.6e12, 4),

@@ -74,19 +74,28 @@ __device__ __forceinline__ int myers_pass(const Sub &sp, int ncols, bool rev, in
         int score = (b + 1) << 6, hout = 0;
         const bool more = tile0 + 64 < nb;
         const int nsteps = ncols + 63;
+        // the target's characters come through a 128-byte ring in LDS, 64 columns ahead: read from HBM inside the step they were one dependent ~1 us load per
+        // column -- 0.5 ms per pass of a 400-column pair, which is what the anchor stage's K4 kernel lasted (three passes per pair, 17 000 pairs in two rounds).
+        // Round 6: the 64 characters (and, for the second and later 64-block tiles of a long query, the 64 horizontal deltas the tile above left in HBM -- they were
+        // one dependent load per STEP on lane 0) of the NEXT block of columns are fetched a block ahead into a register: the refill is an LDS write, not a round trip
+        auto tchar = [&](const int cc) -> uint8_t { return cc < ncols ? (rev ? sp.t[sp.tlen - 1 - cc] : sp.t[cc]) : (uint8_t)4; };
+        uint8_t tnext = tchar(lane);
+        int hcnext = (tile0 != 0 && lane < ncols) ? (int)hcarry[lane] : 0, hcreg = 0;
         for (int step = 0; step < nsteps; ++step) {
-            // the target's characters come through a 128-byte ring in LDS, 64 columns ahead: read from HBM inside the step they were one dependent ~1 us load per
-            // column -- 0.5 ms per pass of a 400-column pair, which is what the anchor stage's K4 kernel lasted (three passes per pair, 17 000 pairs in two rounds)
             if ((step & 63) == 0) {
                 const int cc = step + lane;
                 __syncthreads();
-                tbuf[cc & 127] = cc < ncols ? (rev ? sp.t[sp.tlen - 1 - cc] : sp.t[cc]) : (uint8_t)4;
+                tbuf[cc & 127] = tnext;
+                hcreg = hcnext;
                 __syncthreads();
+                tnext = tchar(cc + 64);
+                if (tile0 != 0) hcnext = cc + 64 < ncols ? (int)hcarry[cc + 64] : 0;
             }
             const int hleft = wave_shr1(hout);
             const int c = step - lane;
+            const int hc0 = __builtin_amdgcn_readlane(hcreg, step & 63); // (lane 0's column is `step`: the delta it needs sits in lane step & 63 of this block's register)
             if (act && c >= 0 && c < ncols) {
-                const int hin = lane == 0 ? (tile0 == 0 ? 1 : (int)hcarry[c]) : hleft;
+                const int hin = lane == 0 ? (tile0 == 0 ? 1 : hc0) : hleft;
                 const uint8_t tc = tbuf[c & 127];
                 const Word Eq = tc == 0 ? peq[0] : tc == 1 ? peq[1] : tc == 2 ? peq[2] : tc == 3 ? peq[3] : peq[4];
                 hout = calc_block(Pv, Mv, Eq, hin, Pv, Mv);
@@ -151,17 +160,24 @@ __device__ __forceinline__ void sg_pass(const Sub &sp, int ncols, bool rev, int 
         const bool is_last = b == nb - 1;
         const int pos = (qlen - 1) & 63;
         const int nsteps = ncols + 63;
+        auto tchar = [&](const int cc) -> uint8_t { return cc < ncols ? (rev ? sp.t[sp.tlen - 1 - cc] : sp.t[cc]) : (uint8_t)4; }; // (a block ahead, as in myers_pass)
+        uint8_t tnext = tchar(lane);
+        int hcnext = (tile0 != 0 && lane < ncols) ? (int)hcarry[lane] : 0, hcreg = 0;
         for (int step = 0; step < nsteps; ++step) {
             if ((step & 63) == 0) { // (the target through a 128-byte LDS ring, 64 columns ahead: myers_pass)
                 const int cc = step + lane;
                 __syncthreads();
-                tbuf2[cc & 127] = cc < ncols ? (rev ? sp.t[sp.tlen - 1 - cc] : sp.t[cc]) : (uint8_t)4;
+                tbuf2[cc & 127] = tnext;
+                hcreg = hcnext;
                 __syncthreads();
+                tnext = tchar(cc + 64);
+                if (tile0 != 0) hcnext = cc + 64 < ncols ? (int)hcarry[cc + 64] : 0;
             }
             const int hleft = wave_shr1(hout);
             const int c = step - lane;
+            const int hc0 = __builtin_amdgcn_readlane(hcreg, step & 63);
             if (act && c >= 0 && c < ncols) {
-                const int hin = lane == 0 ? (tile0 == 0 ? HIN0 : (int)hcarry[c]) : hleft;
+                const int hin = lane == 0 ? (tile0 == 0 ? HIN0 : hc0) : hleft;
                 const uint8_t tc = tbuf2[c & 127];
                 const Word Eq = tc == 0 ? peq[0] : tc == 1 ? peq[1] : tc == 2 ? peq[2] : tc == 3 ? peq[3] : peq[4];
                 hout = calc_block(Pv, Mv, Eq, hin, Pv, Mv);

@@ -1065,20 +1065,13 @@ __device__ __attribute__((noinline)) bool topo_sort_incremental(Ctx &g, Smem &sm
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g.pstat[23] += (unsigned long long)(clock64() - tg0_);
 #endif
         };
-        struct Rec { int no, t0, t1, t2, ox, ni, f0, f1, f2, ix, al; };
-        auto rec = [&](const int ref, Rec &R) { // false: an old row outside the window
-            if (ref >= INC_NEWREF) {
-                const int t = ref - INC_NEWREF, l = t & 63;
-                R.no = 1; R.t1 = R.t2 = R.ox = -1; R.ni = 1; R.f1 = R.f2 = R.ix = -1;
-                if (t < 64) { R.t0 = LCD_RL(Nt[0], l); R.f0 = LCD_RL(Nf[0], l); R.al = LCD_RL(Nal[0], l); }
-                else { R.t0 = LCD_RL(Nt[1], l); R.f0 = LCD_RL(Nf[1], l); R.al = LCD_RL(Nal[1], l); }
-                return true;
-            }
-            if (ref < B || ref >= B + 64 || ref >= n_old) return false;
-            const int l = ref - B;
-            R.no = LCD_RL(Wno, l); R.t0 = LCD_RL(Wt0, l); R.t1 = LCD_RL(Wt1, l); R.t2 = LCD_RL(Wt2, l); R.ox = R.no > 3 ? LCD_RL(Wox, l) : -1;
-            R.ni = LCD_RL(Wni, l); R.f0 = LCD_RL(Wf0, l); R.f1 = LCD_RL(Wf1, l); R.f2 = LCD_RL(Wf2, l); R.ix = R.ni > 3 ? LCD_RL(Wix, l) : -1; R.al = LCD_RL(Wal, l);
-            return true;
+        // a record is read field by field, as the walk needs it (a typical node: one out-edge, one or two in-edges, no ring -- five v_readlane's, not thirty)
+        auto in_window = [&](const int ref) { return ref >= B && ref < B + 64 && ref < n_old; };
+        auto ring_next = [&](const int ref, bool &ok) { // next node of ref's aligned ring (-1: alone); ok = false: an old row outside the window
+            ok = true;
+            if (ref >= INC_NEWREF) { const int t = ref - INC_NEWREF; return t < 64 ? LCD_RL(Nal[0], t) : LCD_RL(Nal[1], t - 64); }
+            if (!in_window(ref)) { ok = false; return -1; }
+            return LCD_RL(Wal, ref - B);
         };
         unsigned long long Rdone = 0, Nd0 = 0, Nd1 = 0; // popped: rows of the window (every row before it is), new nodes 0..63 / 64..127
         auto done = [&](const int ref) {
@@ -1107,8 +1100,18 @@ __device__ __attribute__((noinline)) bool topo_sort_incremental(Ctx &g, Smem &sm
                 int cur = q, m_old = 1, maxe = q, qh = 0, qt = 0;
                 inc_st(el_o + 4u * (unsigned)n_el, LCD_RL(Wv, q - B) | (1 << 16)); ++n_el;
                 for (;;) {
-                    Rec C;
-                    if (!rec(cur, C)) { exceed = true; break; }
+                    // the out-edges of the node at hand: a new node has one; a window row up to three in its record, the rest followed in HBM from the fourth edge's id
+                    int c_no, c_t0 = -1, c_t1 = -1, c_t2 = -1, emore = -1;
+                    if (cur >= INC_NEWREF) { const int t = cur - INC_NEWREF; c_no = 1; c_t0 = t < 64 ? LCD_RL(Nt[0], t) : LCD_RL(Nt[1], t - 64); }
+                    else {
+                        if (!in_window(cur)) { exceed = true; break; }
+                        const int l = cur - B;
+                        c_no = LCD_RL(Wno, l);
+                        if (c_no > 0) c_t0 = LCD_RL(Wt0, l);
+                        if (c_no > 1) c_t1 = LCD_RL(Wt1, l);
+                        if (c_no > 2) c_t2 = LCD_RL(Wt2, l);
+                        if (c_no > 3) emore = LCD_RL(Wox, l);
+                    }
                     // the oracle's counters: a node's in-degree reaches 0 when its LAST in-edge is taken, and the out-edges of the node at hand are taken one by one --
                     // an in-edge from a popped node has been taken, one from the node at hand only if its target is among those already visited (`seen`: window rows and
                     // new nodes as masks, the rare target beyond the window by value)
@@ -1119,48 +1122,46 @@ __device__ __attribute__((noinline)) bool topo_sort_incremental(Ctx &g, Smem &sm
                         if (w >= B && w < B + 64) return ((seenR >> (w - B)) & 1ull) != 0;
                         return w == so0 || w == so1;
                     };
+                    auto taken = [&](const int fr, const int w) { return fr == cur ? is_seen(w) : done(fr); }; // has the in-edge fr -> w been taken?
                     auto ready = [&](const int w) {
-                        Rec R;
                         int e = -1;
-                        if (!rec(w, R)) { // an old node beyond the window (the far end of a long deletion edge): its in-edges from HBM
+                        if (w >= INC_NEWREF) { const int t = w - INC_NEWREF; return taken(t < 64 ? LCD_RL(Nf[0], t) : LCD_RL(Nf[1], t - 64), w); }
+                        if (in_window(w)) {
+                            const int l = w - B, ni = LCD_RL(Wni, l);
+                            if (ni > 0 && !taken(LCD_RL(Wf0, l), w)) return false;
+                            if (ni > 1 && !taken(LCD_RL(Wf1, l), w)) return false;
+                            if (ni > 2 && !taken(LCD_RL(Wf2, l), w)) return false;
+                            if (ni <= 3) return true;
+                            e = LCD_RL(Wix, l); // (a fourth, fifth ... in-edge: followed in HBM)
+                        } else { // an old node beyond the window (the far end of a long deletion edge): its in-edges from HBM
                             if (w < B || w >= n_old) { fail = 7; return false; }
                             e = LD(g.in_head + LD(g.idx2node + w));
-                        } else {
-                            for (int t = 0; t < R.ni && t < 3; ++t) {
-                                const int fr = t == 0 ? R.f0 : t == 1 ? R.f1 : R.f2;
-                                if (fr == cur) { if (!is_seen(w)) return false; }
-                                else if (!done(fr)) return false;
-                            }
-                            e = R.ix; // (a fourth, fifth ... in-edge: followed in HBM)
                         }
                         for (; e >= 0;) {
                             const int f = LD(g.e_from + e), en = LD(g.e_next_in + e);
-                            const int fr = ref1(f);
-                            if (fr == cur) { if (!is_seen(w)) return false; }
-                            else if (!done(fr)) return false;
+                            if (!taken(ref1(f), w)) return false;
                             e = en;
                         }
                         return true;
                     };
-                    int emore = C.ox;
                     for (int kk = 0; !fail && !exceed; ++kk) {
                         int w;
-                        if (kk < 3) { if (kk >= C.no) break; w = kk == 0 ? C.t0 : kk == 1 ? C.t1 : C.t2; }
+                        if (kk < 3) { if (kk >= c_no) break; w = kk == 0 ? c_t0 : kk == 1 ? c_t1 : c_t2; }
                         else { if (emore < 0) break; w = ref1(LD(g.e_to + emore)); emore = LD(g.e_next_out + emore); }
                         if (w >= INC_NEWREF) { const int t = w - INC_NEWREF; if (t < 64) seenN0 |= 1ull << t; else seenN1 |= 1ull << (t - 64); }
                         else if (w >= B && w < B + 64) seenR |= 1ull << (w - B);
                         else if (so0 == -2) so0 = w; else if (so1 == -2) so1 = w; else { fail = 6; break; }
                         if (!ready(w)) continue;
                         // the aligned group goes out together, the node whose in-degree just ran out first, the others in ring order -- if every member is ready
-                        bool ok = true; int na = 0;
-                        Rec Rw;
-                        if (rec(w, Rw)) {
-                            for (int a = Rw.al; a >= 0 && a != w;) {
+                        bool ok = true, inw; int na = 0;
+                        const int al0 = ring_next(w, inw);
+                        if (inw) {
+                            for (int a = al0; a >= 0 && a != w;) {
                                 if (++na > 8) { fail = 6; ok = false; break; }
                                 if (!ready(a)) { ok = false; break; }
-                                Rec Ra;
-                                if (!rec(a, Ra)) { exceed = true; ok = false; break; }
-                                a = Ra.al;
+                                bool ina; const int an = ring_next(a, ina);
+                                if (!ina) { exceed = true; ok = false; break; }
+                                a = an;
                             }
                         } else { // (beyond the window: alone in its ring, or the piece needs a window further on)
                             const int wn = LD(g.idx2node + w);
@@ -1169,7 +1170,7 @@ __device__ __attribute__((noinline)) bool topo_sort_incremental(Ctx &g, Smem &sm
                         if (!ok || fail) continue;
                         if (qt - qh + na + 1 > INC_Q) { fail = 6; break; }
                         inc_st(q_o + 4u * (unsigned)(qt++ & (INC_Q - 1)), w);
-                        if (na > 0) for (int a = Rw.al; a >= 0 && a != w;) { inc_st(q_o + 4u * (unsigned)(qt++ & (INC_Q - 1)), a); Rec Ra; rec(a, Ra); a = Ra.al; }
+                        if (na > 0) for (int a = al0; a >= 0 && a != w;) { inc_st(q_o + 4u * (unsigned)(qt++ & (INC_Q - 1)), a); bool ina; a = ring_next(a, ina); }
                     }
                     if (fail || exceed) break;
                     if (qh == qt || n_el >= INC_EL) { fail = qh == qt ? 7 : 8; break; } // (a FIFO that runs dry before the walk is back on the old order: not a state the argument above covers)
