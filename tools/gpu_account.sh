@@ -9,5 +9,5 @@ timeout 900 python bench.py --gpus 1 --steps 20 --warmup 0 --cpu-sample 0 --repe
 cp /tmp/lib_orig.so longcalld_amd/liblcd_hotpath.so
 grep -c "^\[bs\]" gpurun_out/${tag}_bs.out
 # keep only what the summaries need (the merge back is capped at 64 MiB)
-grep "^\[bs\]\|^{" gpurun_out/${tag}_bs.out > gpurun_out/${tag}_bs.tmp; mv gpurun_out/${tag}_bs.tmp gpurun_out/${tag}_bs.out
+grep "^\[bs\]\|^\[bs-end\]\|^{" gpurun_out/${tag}_bs.out > gpurun_out/${tag}_bs.tmp; mv gpurun_out/${tag}_bs.tmp gpurun_out/${tag}_bs.out
 du -sh gpurun_out/* | sort -h | tail -8

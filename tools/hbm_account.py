@@ -27,9 +27,16 @@ def main():
     blocks, cur = [], []
     for line in open(src, errors="replace"):
         if line.startswith("[bs-end]"):
-            blocks.append(cur); cur = []
+            if cur:
+                blocks.append(cur)
+            cur = []
         elif line.startswith("[bs] "):
-            cur.append(line.split())
+            f = line.split()
+            if any(g[1:4] == f[1:4] for g in cur):   # (a file without the end marks: a class that comes again opens the next block)
+                blocks.append(cur); cur = []
+            cur.append(f)
+    if cur:
+        blocks.append(cur)
     best = max(blocks, key=lambda b: sum(int(f[4]) for f in b)) if blocks else []
     for f in best:
         nt, mode, cert, chains, reads, cells = int(f[1]), int(f[2]), int(f[3]), int(f[4]), int(f[5]), int(f[6])
