@@ -461,13 +461,17 @@ int run_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, DevBuf &d_jobs, Dev
         if (ns > 1) HIPCHK(hipEventRecord(sev[0], st)); // the job table is there
         std::vector<char> used(ns, 0);
         int turn = 0;
+        // (the HBM-ring class's jobs with workspaces of a megabyte and more -- fronts of thousands of diagonals: SV-size gaps -- are a launch of their own, on the
+        //  instantiation that keeps several diagonals per thread in flight; the class is sorted by workspace size, largest first, so they are its head)
+        static const uint64_t wide_from = getenv("LCD_WFA_WIDE_KB") ? (uint64_t)atoll(getenv("LCD_WFA_WIDE_KB")) << 10 : (uint64_t)1 << 20;
+        auto is_wide = [&](const size_t q) { return cls[which[q]] == 0 && wide_from > 0 && jobs[which[q]].ws_bytes >= wide_from; };
         for (size_t a = 0; a < m;) {
-            size_t b = a; const int c = cls[which[a]];
-            while (b < m && cls[which[b]] == c) ++b;
+            size_t b = a; const int c = cls[which[a]]; const bool wide = is_wide(a);
+            while (b < m && cls[which[b]] == c && is_wide(b) == wide) ++b;
             const int t = turn++ % ns;
             hipStream_t s2 = t == 0 ? st : side[t - 1];
             if (t != 0 && !used[t]) { HIPCHK(hipStreamWaitEvent(s2, sev[0], 0)); used[t] = 1; }
-            lcd_launch_wfa((const WfaJob *)d_jobs.p + a, nullptr, nullptr, nullptr, (WfaOut *)d_outs.p + a, sc, (int)(b - a), c ? kWfaLdsBuckets[c - 1] : 0, s2);
+            lcd_launch_wfa((const WfaJob *)d_jobs.p + a, nullptr, nullptr, nullptr, (WfaOut *)d_outs.p + a, sc, (int)(b - a), c ? kWfaLdsBuckets[c - 1] : 0, s2, wide ? 1 : 0);
             HIPCHK(hipGetLastError());
             a = b;
         }

@@ -9,7 +9,7 @@ void lcd_launch_cu_probe(int *seen /* int[4096], zeroed */, hipStream_t stream);
 void lcd_launch_gate(int *ctr, int target0, int target1, hipStream_t stream);
 // lds_bytes > 0: the jobs keep their value ring in that much dynamic LDS (one wavefront per job); 0: ring in HBM, 256 threads per job
 void lcd_launch_wfa(const WfaJob *jobs, const uint8_t *pool, uint8_t *arena, uint8_t *outpool, WfaOut *outs, LcdScoring sc,
-                    int n_jobs, int lds_bytes, hipStream_t stream);
+                    int n_jobs, int lds_bytes, hipStream_t stream, int wide = 0); // wide: the HBM-ring class's SV-size jobs (diagonals in flight, wfa_kernel.hip)
 void lcd_launch_edlib(const EdJob *jobs, const uint8_t *pool, uint8_t *arena, EdOut *outs, int n_jobs, hipStream_t stream);
 void lcd_launch_strings(const StrJob *jobs, uint8_t *pool, StrOut *outs, int n_jobs, hipStream_t stream);
 void lcd_launch_gather(const GatherJob *jobs, int n_jobs, hipStream_t stream);

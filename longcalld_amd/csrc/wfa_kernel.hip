@@ -76,7 +76,7 @@ __device__ __forceinline__ int coop_ext(const Seq &q, int v, int h, int lane) {
 
 } // namespace
 
-template <int NT, bool LDSR>
+template <int NT, bool LDSR, bool WIDE = false>
 __global__ void __launch_bounds__(NT) lcd_wfa_kernel(const WfaJob *jobs, const uint8_t *pool, uint8_t *arena, uint8_t *outpool, WfaOut *outs,
                                                      LcdScoring sc, int n_jobs) {
     extern __shared__ int lds_ring[];
@@ -119,6 +119,60 @@ __global__ void __launch_bounds__(NT) lcd_wfa_kernel(const WfaJob *jobs, const u
         }
         const int *Mx = slot(0, rm, s - x), *Mo1 = slot(0, rm, s - o1 - e1), *Mo2 = slot(0, rm, s - o2 - e2);
         const int *I1e = slot(rm, r1, s - e1), *D1e = slot(rm + r1, r1, s - e1), *I2e = slot(rm + 2 * r1, r2, s - e2), *D2e = slot(rm + 2 * r1 + r2, r2, s - e2);
+        // WIDE (the launch of an SV-size job class, lcd_host.cpp run_wfa_stage): U diagonals per thread IN FLIGHT on rows of thousands of diagonals (round 6).  The nine ring
+        // values of all U are fetched before anything is stored -- the row being written and the rows being read are different slots of the same ring, which the compiler
+        // cannot know, so the plain loop below is one memory round trip per diagonal: a 20 000-diagonal front of a 10 kb gap was 78 such trips per row and thread.  The
+        // first base of every extension is probed the same way (most diagonals off the alignment's path stop there).  A separate instantiation: inside the common
+        // kernel the batched form cost the clean-read shapes 1 - 2 % (registers shared with the narrow rows), profiles/NOTES_r06.md 9.
+        constexpr int U = 4;
+        if (WIDE && khi - klo + 1 >= 2 * U * NT) {
+        for (int k0 = klo + tid; k0 <= khi; k0 += U * NT) {
+            int vmx[U], vi1o[U], vi1x[U], vi2o[U], vi2x[U], vd1o[U], vd1x[U], vd2o[U], vd2x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = imin(k0 + u * NT, khi), c = k + cbase; // (past the row's end: the last diagonal once more, not stored)
+                vmx[u] = Mx[c] + 1;
+                vi1o[u] = Mo1[c - 1] + 1; vi1x[u] = I1e[c - 1] + 1; vi2o[u] = Mo2[c - 1] + 1; vi2x[u] = I2e[c - 1] + 1;
+                vd1o[u] = Mo1[c + 1]; vd1x[u] = D1e[c + 1]; vd2o[u] = Mo2[c + 1]; vd2x[u] = D2e[c + 1];
+            }
+            int vmv[U], vi1[U], vi2[U], vd1[U], vd2[U], vcode[U]; bool live[U];
+            uint8_t pf[U], tf[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = imin(k0 + u * NT, khi);
+                const int mx = vmx[u], i1o = vi1o[u], i1x = vi1x[u], i2o = vi2o[u], i2x = vi2x[u], d1o = vd1o[u], d1x = vd1x[u], d2o = vd2o[u], d2x = vd2x[u];
+                int i1 = imax(i1o, i1x), i2 = imax(i2o, i2x), d1 = imax(d1o, d1x), d2 = imax(d2o, d2x);
+                int mv = imax(imax(mx, imax(i1, i2)), imax(d1, d2));
+                int code = mx == mv ? 9 : d2x == mv ? 8 : d2o == mv ? 7 : d1x == mv ? 6 : d1o == mv ? 5 : i2x == mv ? 4 : i2o == mv ? 3 : i1x == mv ? 2 : 1; // (as in the plain loop below)
+                code |= (i1x >= i1o ? 16 : 0) | (i2x >= i2o ? 32 : 0) | (d1x >= d1o ? 64 : 0) | (d2x >= d2o ? 128 : 0);
+                if (i1 < 0) i1 = WF_NULL;
+                if (i2 < 0) i2 = WF_NULL;
+                if (d1 < 0) d1 = WF_NULL;
+                if (d2 < 0) d2 = WF_NULL;
+                live[u] = !(mv < 0 || mv > tlen || mv - k > plen || mv - k < 0);
+                if (!live[u]) mv = WF_NULL;
+                vmv[u] = mv; vi1[u] = i1; vi2[u] = i2; vd1[u] = d1; vd2[u] = d2; vcode[u] = code;
+                pf[u] = 0; tf[u] = 1;
+                if (live[u]) { // the first base of the extension from (mv - k, mv)
+                    const int v = mv - k, h = mv;
+                    if (v < plen && h < tlen) { pf[u] = q.rev ? q.pat[plen - 1 - v] : q.pat[v]; tf[u] = q.rev ? q.txt[tlen - 1 - h] : q.txt[h]; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + u * NT;
+                if (k > khi) continue;
+                const int c = k + cbase;
+                int mv = vmv[u];
+                if (live[u]) {
+                    if (pf[u] == tf[u]) mv += ext_run(q, mv - k, mv);
+                    if (k == k_end && mv >= tlen) done = 1;
+                }
+                Mw[c] = mv; I1w[c] = vi1[u]; I2w[c] = vi2[u]; D1w[c] = vd1[u]; D2w[c] = vd2[u];
+                chrow[k - klo] = (uint8_t)vcode[u];
+            }
+        }
+        } else
         for (int k = klo + tid; k <= khi; k += NT) {
             const int c = k + cbase;
             const int mx = Mx[c] + 1;
@@ -285,13 +339,15 @@ __global__ void __launch_bounds__(NT) lcd_wfa_kernel(const WfaJob *jobs, const u
 }
 
 void lcd_launch_wfa(const WfaJob *jobs, const uint8_t *pool, uint8_t *arena, uint8_t *outpool, WfaOut *outs, LcdScoring sc, int n_jobs, int lds_bytes,
-                    hipStream_t stream) {
+                    hipStream_t stream, int wide) {
     if (n_jobs <= 0) return;
     if (lds_bytes > 0) {
         static std::once_flag attr_once[16]; // (function attributes are per device)
         int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
         std::call_once(attr_once[dev], [] { hipFuncSetAttribute((const void *)lcd_wfa_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
         hipLaunchKernelGGL((lcd_wfa_kernel<64, true>), dim3(n_jobs), dim3(64), lds_bytes, stream, jobs, pool, arena, outpool, outs, sc, n_jobs);
-    } else
+    } else if (wide)
+        hipLaunchKernelGGL((lcd_wfa_kernel<256, false, true>), dim3(n_jobs), dim3(256), 0, stream, jobs, pool, arena, outpool, outs, sc, n_jobs);
+    else
         hipLaunchKernelGGL((lcd_wfa_kernel<256, false>), dim3(n_jobs), dim3(256), 0, stream, jobs, pool, arena, outpool, outs, sc, n_jobs);
 }
