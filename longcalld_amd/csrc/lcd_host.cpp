@@ -464,7 +464,13 @@ int run_wfa_stage(hipStream_t st, std::vector<WfaJob> &jobs, DevBuf &d_jobs, Dev
         // (the HBM-ring class's jobs with workspaces of a megabyte and more -- fronts of thousands of diagonals: SV-size gaps -- are a launch of their own, on the
         //  instantiation that keeps several diagonals per thread in flight; the class is sorted by workspace size, largest first, so they are its head)
         static const uint64_t wide_from = getenv("LCD_WFA_WIDE_KB") ? (uint64_t)atoll(getenv("LCD_WFA_WIDE_KB")) << 10 : (uint64_t)1 << 20;
-        auto is_wide = [&](const size_t q) { return cls[which[q]] == 0 && wide_from > 0 && jobs[which[q]].ws_bytes >= wide_from; };
+        // (only when there are enough of them to be a workload of their own -- 64, LCD_WFA_WIDE_MIN: a handful of such jobs in a clean-read submission as one more launch
+        //  took a stream's turn from the LDS classes, which then queued behind the longest jobs: 156 k against 172 k regions/s at the default flags, two lanes of 32 batches)
+        static const size_t wide_min = getenv("LCD_WFA_WIDE_MIN") ? (size_t)atoll(getenv("LCD_WFA_WIDE_MIN")) : 64;
+        size_t n_wide = 0;
+        if (wide_from > 0) for (size_t q = 0; q < m; ++q) n_wide += cls[which[q]] == 0 && jobs[which[q]].ws_bytes >= wide_from;
+        const bool wide_on = wide_from > 0 && n_wide >= wide_min;
+        auto is_wide = [&](const size_t q) { return wide_on && cls[which[q]] == 0 && jobs[which[q]].ws_bytes >= wide_from; };
         for (size_t a = 0; a < m;) {
             size_t b = a; const int c = cls[which[a]]; const bool wide = is_wide(a);
             while (b < m && cls[which[b]] == c && is_wide(b) == wide) ++b;
